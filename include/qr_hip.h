@@ -1,0 +1,207 @@
+/*
+ * qr_hip.h -- C-ABI of the MI355X (gfx950) LambdaMART/GBRT training + scoring
+ * device layer.  Plain pointers and sizes only; no C++/torch types cross it.
+ *
+ * QuickRank has no FFI layer: the seam is the set of protected virtual hooks
+ * that Mart::learn calls in order.  Each entry point
+ * below names the reference call site it stands behind (file:line relative to
+ * the upstream hpclab/quickrank tree) so a maintainer can bind it from
+ * Mart/LambdaMart/RegressionTree/ObliviousRT/Ensemble.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a QR_ERR_* code otherwise;
+ *     qr_last_error(ctx) gives the message (the host CLI keeps the reference
+ *     behaviour: message on stderr + exit(EXIT_FAILURE), e.g. dataset.cc:37-43)
+ *   - the context owns all device memory; host buffers belong to the caller
+ *   - one host thread drives a context; calls are synchronous at return unless
+ *     the name ends in _async; a context is not thread-safe (the reference is
+ *     single-caller too: one thread drives OpenMP regions, rt.cc:247)
+ *   - types follow include/types.h:28-35 of the reference: Feature/Label f32,
+ *     Score/MetricScore f64; counts are 64-bit at the boundary
+ *   - there is NO CPU fallback: without a visible gfx950 device
+ *     qr_ctx_create fails with QR_ERR_NO_DEVICE
+ */
+#ifndef QR_HIP_H_
+#define QR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QR_OK 0
+#define QR_ERR_NO_DEVICE 1
+#define QR_ERR_HIP 2
+#define QR_ERR_ARG 3
+#define QR_ERR_STATE 4
+#define QR_ERR_UNSUPPORTED 5
+
+#define QR_MAX_BINS 256 /* threshold slots per feature: 255 + FLT_MAX sentinel */
+
+#define QR_ALGO_MART 0          /* mart.cc                                    */
+#define QR_ALGO_LAMBDAMART 1    /* lambdamart.cc                              */
+#define QR_ALGO_OBVMART 2       /* obliviousmart.cc                           */
+#define QR_ALGO_OBVLAMBDAMART 3 /* obliviouslambdamart.cc                     */
+
+#define QR_METRIC_DCG 0  /* dcg.cc   */
+#define QR_METRIC_NDCG 1 /* ndcg.cc  */
+
+typedef struct qr_ctx qr_ctx;
+
+/* One tree node as the host RTNode mirror needs it (rtnode.h:37-52).          */
+typedef struct {
+  int32_t feature;  /* featureidx, -1 for a leaf (uint_max in the reference)   */
+  int32_t thr_id;   /* threshold slot                                          */
+  float threshold;  /* RTNode::threshold                                       */
+  int32_t left, right; /* node indices, -1 for a leaf                          */
+  double value;     /* RTNode::avglabel (leaf output after update_output)      */
+  double deviance;  /* RTNode::deviance                                        */
+  uint64_t nsamples;
+} qr_node_t;
+
+/* A best-split record (rt.cc:257-312), also the unit exchanged between GPUs. */
+typedef struct {
+  double score;     /* -1 when the node has no valid split (rt.cc:213,312)     */
+  uint32_t feature; /* global feature index, UINT32_MAX when none              */
+  uint32_t thr_id;
+  uint64_t lcount;
+  uint64_t rcount;
+} qr_split_t;
+
+/* ---- context ---------------------------------------------------------------- */
+int qr_ctx_create(int device, qr_ctx **out);
+void qr_ctx_destroy(qr_ctx *ctx);
+const char *qr_last_error(const qr_ctx *ctx);
+/* run every launch on the caller's HIP stream (e.g. torch's current stream)    */
+int qr_ctx_set_stream(qr_ctx *ctx, void *hip_stream);
+/* feature-block sharding for the multi-GPU path: this   */
+/* rank owns 64-feature blocks  rank, rank+world, ...  of the bin matrix.       */
+/* Must be called before qr_bins_build.  Default rank 0 / world 1.              */
+int qr_ctx_set_shard(qr_ctx *ctx, int rank, int world);
+int qr_synchronize(qr_ctx *ctx);
+
+/* ---- data: replaces Dataset -> VerticalDataset (vertical_dataset.cc:29-66)    */
+/*      and Mart::init (mart.cc:117-176) + RTRootHistogram (rtnode_histogram.cc */
+/*      :227-253)                                                                */
+/* rowmajor: host f32 [N][F] (Dataset::at, dataset.h:65-67); qoff: [Q+1]         */
+int qr_dataset_upload(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
+                      const float *labels, const uint64_t *qoff, size_t Q);
+/* optional validation set (mart.cc:231-233, 354-360)                            */
+int qr_valid_upload(qr_ctx *ctx, const float *rowmajor, size_t N,
+                    const float *labels, const uint64_t *qoff, size_t Q);
+/* thresholds + uint8 bin map.  nthresholds in [1,255], or 0 (= every unique     */
+/* value) if no feature has more than 255 uniques (else QR_ERR_UNSUPPORTED).     */
+/* thr_out: host [F][QR_MAX_BINS] (padded with FLT_MAX), thr_size_out: [F].      */
+int qr_bins_build(qr_ctx *ctx, size_t nthresholds, float *thr_out,
+                  uint32_t *thr_size_out);
+/* debug/parity: bin ids as u8 [N][F] row-major (global features; features this  */
+/* rank does not own read back as 0xFF)                                          */
+int qr_bins_read(qr_ctx *ctx, uint8_t *out);
+
+/* ---- model state: scores_on_training_ (mart.cc:121), pseudoresponses_,        */
+/*      instance_weights_ (lambdamart.cc:34-39)                                  */
+int qr_scores_reset(qr_ctx *ctx);                       /* zero train+valid      */
+int qr_scores_set(qr_ctx *ctx, const double *scores);   /* host [N] -> device    */
+int qr_scores_get(qr_ctx *ctx, double *scores);         /* device -> host [N]    */
+int qr_valid_scores_get(qr_ctx *ctx, double *scores);
+int qr_pseudo_get(qr_ctx *ctx, double *lambda, double *weight); /* NULL = skip   */
+int qr_pseudo_set(qr_ctx *ctx, const double *lambda, const double *weight);
+
+/* ---- pseudo-responses --------------------------------------------------------*/
+/* LambdaMart::compute_pseudoresponses (lambdamart.cc:62-152) for metric@cutoff. */
+/* cutoff 0 = no cutoff (metric.h:65-67).  Also leaves the training metric of    */
+/* the CURRENT scores in the context (same ranking), see qr_metric_last.         */
+int qr_lambda_compute(qr_ctx *ctx, int metric, size_t cutoff);
+/* Mart::compute_pseudoresponses (mart.cc:418-431)                               */
+int qr_residual_compute(qr_ctx *ctx);
+
+/* ---- metric: Metric::evaluate_dataset (metric.h:77-106) over the device       */
+/*      scores.  which: 0 = training set, 1 = validation set.                    */
+int qr_metric_eval(qr_ctx *ctx, int which, int metric, size_t cutoff,
+                   double *out);
+/* training metric of the scores the last qr_lambda_compute ranked (the lambda   */
+/* kernel evaluates it on the way: same ranking, no second sort)                 */
+int qr_metric_last(qr_ctx *ctx, double *out);
+
+/* ---- regression tree: RegressionTree::fit (rt.cc:49-90) + split (:209-362) +  */
+/*      RTNodeHistogram (rtnode_histogram.cc:41-87,172-217) + update_output      */
+/*      (rt.cc:165-207) on the current pseudo-responses.                         */
+/* newton != 0: LambdaMART leaf = sum(lambda)/sum(weight) (rt.cc:186-207),       */
+/* else MART mean (rt.cc:165-184).  nodes_out: capacity 2*nleaves+1, creation    */
+/* order (root 0; each split appends left,right).  leaf ids are DFS left-first   */
+/* (rtnode.cc:34-46).                                                            */
+int qr_tree_fit(qr_ctx *ctx, size_t nleaves, uint64_t minls, int newton,
+                qr_node_t *nodes_out, size_t *nnodes_out);
+/* ObliviousRT::fit (ot.cc:32-201): nodes_out in heap order (2i+1, 2i+2),        */
+/* capacity 2^(depth+1)-1; absent nodes have feature == -2.                      */
+int qr_oblivious_fit(qr_ctx *ctx, size_t depth, uint64_t minls, int newton,
+                     qr_node_t *nodes_out, size_t *nnodes_out);
+/* Mart::update_modelscores (mart.cc:447-468) with the tree just fitted:         */
+/* training scores through the leaf membership, validation scores by walking     */
+/* the tree on raw f32 features.  shrinkage is f64 (mart.h).                     */
+int qr_scores_update(qr_ctx *ctx, double shrinkage);
+
+/* ---- multi-GPU split protocol -------------------------*/
+/* The feature-sharded path runs qr_tree_fit as explicit phases so the caller    */
+/* can put its collectives (RCCL via torch.distributed) in between, all on the   */
+/* context's stream, no host sync:                                               */
+/*   qr_tree_begin -> [all_gather recs] -> loop { qr_tree_decide ->              */
+/*   [all_reduce mask] -> qr_tree_apply -> [all_gather recs] } -> qr_tree_end    */
+/* recs: device buffer of 2 qr_split_t per rank (left, right child of the last   */
+/* split; root in slot 0 after begin).  mask: device u32 words, bit d = doc at   */
+/* position d of the split node's segment goes left (zeros on non-owners).       */
+int qr_tree_begin(qr_ctx *ctx, size_t nleaves, uint64_t minls);
+int qr_tree_decide(qr_ctx *ctx);
+int qr_tree_apply(qr_ctx *ctx);
+int qr_tree_end(qr_ctx *ctx, int newton, qr_node_t *nodes_out,
+                size_t *nnodes_out);
+/* device pointers for the exchange buffers (valid after qr_bins_build)           */
+int qr_exchange_buffers(qr_ctx *ctx, void **recs_local, void **recs_all,
+                        size_t *rec_bytes_per_rank, void **mask,
+                        size_t *mask_bytes);
+
+/* ---- parity/debug read-backs --------------------------------------------------*/
+/* cumulative histogram of a node slot of the LAST fitted tree, as the           */
+/* reference keeps it (sumlbl f64 / count u64, [F][QR_MAX_BINS], owned features  */
+/* only, others zero).  The device accumulates order-independent fixed-point     */
+/* sums; sum_out = fixed * 2^-scale_exp.                                         */
+int qr_node_hist_read(qr_ctx *ctx, int node, double *sum_out,
+                      uint64_t *count_out);
+/* sample ids (ascending doc ids) of a node of the last fitted tree              */
+int qr_node_samples_read(qr_ctx *ctx, int node, uint32_t *ids_out,
+                         size_t *n_out);
+/* accepted splits of the last fitted tree in order                              */
+int qr_tree_split_log(qr_ctx *ctx, qr_split_t *out, size_t *n_out);
+/* per-query metric of the last qr_lambda_compute / qr_metric_eval(which=0)      */
+int qr_metric_per_query(qr_ctx *ctx, double *out);
+/* rank permutation (pos_of_rank, rankedresults.cc:27-41) of the last            */
+/* qr_lambda_compute: host u32 [N], query-local doc index per rank               */
+int qr_ranks_read(qr_ctx *ctx, uint32_t *out);
+
+/* ---- inference: Ensemble::score_instance (ensemble.cc:111-118) over           */
+/*      LTR_Algorithm::score_dataset (ltr_algorithm.cc:44-52)                    */
+/* nodes: [ntrees][max_nodes] in the qr_node_t layout; weights f64 [ntrees].     */
+int qr_ensemble_upload(qr_ctx *ctx, const qr_node_t *nodes, size_t ntrees,
+                       size_t max_nodes, const double *weights);
+/* rowmajor: HOST f32 [N][F]; scores_out: host f64 [N].  Timing of the kernel    */
+/* alone (features resident) is returned in *kernel_ms when non-NULL.            */
+int qr_ensemble_score(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
+                      double *scores_out, float *kernel_ms);
+/* same, features already resident on the device (device pointer)               */
+int qr_ensemble_score_device(qr_ctx *ctx, const void *d_rowmajor, size_t N,
+                             size_t F, void *d_scores_out);
+
+/* ---- instrumentation ---------------------------------------------------------*/
+/* HIP-event timing of the dominant kernel (root histogram build) accumulated    */
+/* since the last reset: launches, total ms, algorithmic bytes per launch.       */
+int qr_prof_reset(qr_ctx *ctx);
+int qr_prof_get(qr_ctx *ctx, uint64_t *launches, double *total_ms,
+                double *alg_bytes_per_launch);
+int qr_prof_enable(qr_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QR_HIP_H_ */

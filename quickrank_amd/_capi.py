@@ -1,0 +1,322 @@
+"""ctypes binding of include/qr_hip.h (the C-ABI of libqr_hip.so).
+
+Fails loudly when the HIP library is missing or no GPU is visible: there is no
+CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+NODE_DTYPE = np.dtype([("feature", np.int32), ("thr_id", np.int32),
+                       ("threshold", np.float32), ("left", np.int32),
+                       ("right", np.int32), ("value", np.float64),
+                       ("deviance", np.float64), ("nsamples", np.uint64)],
+                      align=True)
+SPLIT_DTYPE = np.dtype([("score", np.float64), ("feature", np.uint32),
+                        ("thr_id", np.uint32), ("lcount", np.uint64),
+                        ("rcount", np.uint64)], align=True)
+assert NODE_DTYPE.itemsize == 48 and SPLIT_DTYPE.itemsize == 32
+
+QR_MAX_BINS = 256
+METRICS = {"DCG": 0, "NDCG": 1}
+
+# every symbol include/qr_hip.h declares
+SYMBOLS = [
+    "qr_ctx_create", "qr_ctx_destroy", "qr_last_error", "qr_ctx_set_stream",
+    "qr_ctx_set_shard", "qr_synchronize", "qr_dataset_upload", "qr_valid_upload",
+    "qr_bins_build", "qr_bins_read", "qr_scores_reset", "qr_scores_set",
+    "qr_scores_get", "qr_valid_scores_get", "qr_pseudo_get", "qr_pseudo_set",
+    "qr_lambda_compute", "qr_residual_compute", "qr_metric_eval", "qr_metric_last",
+    "qr_tree_fit", "qr_oblivious_fit", "qr_scores_update", "qr_tree_begin",
+    "qr_tree_decide", "qr_tree_apply", "qr_tree_end", "qr_exchange_buffers",
+    "qr_node_hist_read", "qr_node_samples_read", "qr_tree_split_log",
+    "qr_metric_per_query", "qr_ranks_read", "qr_ensemble_upload",
+    "qr_ensemble_score", "qr_ensemble_score_device", "qr_prof_reset",
+    "qr_prof_get", "qr_prof_enable",
+]
+
+_LIB = None
+
+
+class QrError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libqr_hip.so (never builds implicitly on import; see build.build())."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if not os.path.exists(path):
+        raise QrError(
+            f"{path} is missing: build the HIP extension first "
+            "(python -m quickrank_amd.build, or __graft_entry__.build()). "
+            "quickrank_amd has no CPU fallback.")
+    L = C.CDLL(path)
+    vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+    L.qr_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.qr_ctx_destroy.argtypes = [vp]
+    L.qr_ctx_destroy.restype = None
+    L.qr_last_error.argtypes = [vp]
+    L.qr_last_error.restype = C.c_char_p
+    L.qr_ctx_set_stream.argtypes = [vp, vp]
+    L.qr_ctx_set_shard.argtypes = [vp, C.c_int, C.c_int]
+    L.qr_synchronize.argtypes = [vp]
+    L.qr_dataset_upload.argtypes = [vp, vp, sz, sz, vp, vp, sz]
+    L.qr_valid_upload.argtypes = [vp, vp, sz, vp, vp, sz]
+    L.qr_bins_build.argtypes = [vp, sz, vp, vp]
+    L.qr_bins_read.argtypes = [vp, vp]
+    L.qr_scores_reset.argtypes = [vp]
+    L.qr_scores_set.argtypes = [vp, vp]
+    L.qr_scores_get.argtypes = [vp, vp]
+    L.qr_valid_scores_get.argtypes = [vp, vp]
+    L.qr_pseudo_get.argtypes = [vp, vp, vp]
+    L.qr_pseudo_set.argtypes = [vp, vp, vp]
+    L.qr_lambda_compute.argtypes = [vp, C.c_int, sz]
+    L.qr_residual_compute.argtypes = [vp]
+    L.qr_metric_eval.argtypes = [vp, C.c_int, C.c_int, sz, C.POINTER(C.c_double)]
+    L.qr_metric_last.argtypes = [vp, C.POINTER(C.c_double)]
+    L.qr_tree_fit.argtypes = [vp, sz, u64, C.c_int, vp, C.POINTER(sz)]
+    L.qr_oblivious_fit.argtypes = [vp, sz, u64, C.c_int, vp, C.POINTER(sz)]
+    L.qr_scores_update.argtypes = [vp, C.c_double]
+    L.qr_tree_begin.argtypes = [vp, sz, u64]
+    L.qr_tree_decide.argtypes = [vp]
+    L.qr_tree_apply.argtypes = [vp]
+    L.qr_tree_end.argtypes = [vp, C.c_int, vp, C.POINTER(sz)]
+    L.qr_exchange_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz),
+                                      C.POINTER(vp), C.POINTER(sz)]
+    L.qr_node_hist_read.argtypes = [vp, C.c_int, vp, vp]
+    L.qr_node_samples_read.argtypes = [vp, C.c_int, vp, C.POINTER(sz)]
+    L.qr_tree_split_log.argtypes = [vp, vp, C.POINTER(sz)]
+    L.qr_metric_per_query.argtypes = [vp, vp]
+    L.qr_ranks_read.argtypes = [vp, vp]
+    L.qr_ensemble_upload.argtypes = [vp, vp, sz, sz, vp]
+    L.qr_ensemble_score.argtypes = [vp, vp, sz, sz, vp, C.POINTER(C.c_float)]
+    L.qr_ensemble_score_device.argtypes = [vp, vp, sz, sz, vp]
+    L.qr_prof_reset.argtypes = [vp]
+    L.qr_prof_get.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.qr_prof_enable.argtypes = [vp, C.c_int]
+    for s in SYMBOLS:
+        fn = getattr(L, s)
+        if s not in ("qr_ctx_destroy", "qr_last_error"):
+            fn.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Context:
+    """One device context (= one GPU, one stream).  Thin, 1:1 over the C-ABI."""
+
+    def __init__(self, device=0, rank=0, world=1, stream=None):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.qr_ctx_create(device, C.byref(h))
+        if rc:
+            raise QrError(f"qr_ctx_create: {self.L.qr_last_error(None).decode()} (code {rc})")
+        self.h = h
+        self.N = self.F = self.Q = 0
+        self.vN = 0
+        if stream is not None:
+            self._ck(self.L.qr_ctx_set_stream(self.h, C.c_void_p(stream)))
+        if world > 1:
+            self._ck(self.L.qr_ctx_set_shard(self.h, rank, world))
+        self.rank, self.world = rank, world
+
+    def _ck(self, rc):
+        if rc:
+            raise QrError(f"{self.L.qr_last_error(self.h).decode()} (code {rc})")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.qr_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data ---------------------------------------------------------------
+    def upload(self, x, labels, qoff):
+        x = np.ascontiguousarray(x, np.float32)
+        labels = np.ascontiguousarray(labels, np.float32)
+        qoff = np.ascontiguousarray(qoff, np.uint64)
+        self.N, self.F = x.shape
+        self.Q = len(qoff) - 1
+        self._ck(self.L.qr_dataset_upload(self.h, _ptr(x), self.N, self.F, _ptr(labels),
+                                          _ptr(qoff), self.Q))
+
+    def upload_valid(self, x, labels, qoff):
+        x = np.ascontiguousarray(x, np.float32)
+        labels = np.ascontiguousarray(labels, np.float32)
+        qoff = np.ascontiguousarray(qoff, np.uint64)
+        self.vN = x.shape[0]
+        self._ck(self.L.qr_valid_upload(self.h, _ptr(x), self.vN, _ptr(labels), _ptr(qoff),
+                                        len(qoff) - 1))
+
+    def build_bins(self, nthresholds):
+        thr = np.empty((self.F, QR_MAX_BINS), np.float32)
+        ts = np.empty(self.F, np.uint32)
+        self._ck(self.L.qr_bins_build(self.h, nthresholds, _ptr(thr), _ptr(ts)))
+        return thr, ts
+
+    def read_bins(self):
+        out = np.empty((self.N, self.F), np.uint8)
+        self._ck(self.L.qr_bins_read(self.h, _ptr(out)))
+        return out
+
+    # -- state --------------------------------------------------------------
+    def reset_scores(self):
+        self._ck(self.L.qr_scores_reset(self.h))
+
+    def set_scores(self, s):
+        s = np.ascontiguousarray(s, np.float64)
+        self._ck(self.L.qr_scores_set(self.h, _ptr(s)))
+
+    def get_scores(self):
+        s = np.empty(self.N, np.float64)
+        self._ck(self.L.qr_scores_get(self.h, _ptr(s)))
+        return s
+
+    def get_valid_scores(self):
+        s = np.empty(self.vN, np.float64)
+        self._ck(self.L.qr_valid_scores_get(self.h, _ptr(s)))
+        return s
+
+    def get_pseudo(self):
+        l = np.empty(self.N, np.float64)
+        w = np.empty(self.N, np.float64)
+        self._ck(self.L.qr_pseudo_get(self.h, _ptr(l), _ptr(w)))
+        return l, w
+
+    def set_pseudo(self, lam, w=None):
+        lam = np.ascontiguousarray(lam, np.float64)
+        w = None if w is None else np.ascontiguousarray(w, np.float64)
+        self._ck(self.L.qr_pseudo_set(self.h, _ptr(lam), _ptr(w)))
+
+    # -- hot path -----------------------------------------------------------
+    def compute_lambdas(self, metric="NDCG", cutoff=10):
+        self._ck(self.L.qr_lambda_compute(self.h, METRICS[metric], cutoff))
+
+    def compute_residuals(self):
+        self._ck(self.L.qr_residual_compute(self.h))
+
+    def metric_eval(self, which=0, metric="NDCG", cutoff=10):
+        out = C.c_double()
+        self._ck(self.L.qr_metric_eval(self.h, which, METRICS[metric], cutoff, C.byref(out)))
+        return out.value
+
+    def metric_last(self):
+        out = C.c_double()
+        self._ck(self.L.qr_metric_last(self.h, C.byref(out)))
+        return out.value
+
+    def fit_tree(self, nleaves=10, minls=1, newton=True):
+        nodes = np.zeros(2 * nleaves + 1, NODE_DTYPE)
+        n = C.c_size_t()
+        self._ck(self.L.qr_tree_fit(self.h, nleaves, minls, int(newton), _ptr(nodes), C.byref(n)))
+        return nodes[:n.value].copy()
+
+    def fit_oblivious(self, depth=3, minls=1, newton=True):
+        nodes = np.zeros((1 << (depth + 1)) - 1, NODE_DTYPE)
+        n = C.c_size_t()
+        self._ck(self.L.qr_oblivious_fit(self.h, depth, minls, int(newton), _ptr(nodes),
+                                         C.byref(n)))
+        return nodes[:n.value].copy()
+
+    def update_scores(self, shrinkage):
+        self._ck(self.L.qr_scores_update(self.h, float(shrinkage)))
+
+    # -- multi-GPU phases -----------------------------------------------------
+    def tree_begin(self, nleaves, minls=1):
+        self._ck(self.L.qr_tree_begin(self.h, nleaves, minls))
+
+    def tree_decide(self):
+        self._ck(self.L.qr_tree_decide(self.h))
+
+    def tree_apply(self):
+        self._ck(self.L.qr_tree_apply(self.h))
+
+    def tree_end(self, nleaves, newton=True):
+        nodes = np.zeros(2 * nleaves + 1, NODE_DTYPE)
+        n = C.c_size_t()
+        self._ck(self.L.qr_tree_end(self.h, int(newton), _ptr(nodes), C.byref(n)))
+        return nodes[:n.value].copy()
+
+    def exchange_buffers(self):
+        a, b, m = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rb, mb = C.c_size_t(), C.c_size_t()
+        self._ck(self.L.qr_exchange_buffers(self.h, C.byref(a), C.byref(b), C.byref(rb),
+                                            C.byref(m), C.byref(mb)))
+        return dict(recs_local=a.value, recs_all=b.value, rec_bytes=rb.value,
+                    mask=m.value, mask_bytes=mb.value)
+
+    def synchronize(self):
+        self._ck(self.L.qr_synchronize(self.h))
+
+    # -- read-backs ---------------------------------------------------------
+    def node_hist(self, node):
+        s = np.zeros((self.F, QR_MAX_BINS), np.float64)
+        c = np.zeros((self.F, QR_MAX_BINS), np.uint64)
+        self._ck(self.L.qr_node_hist_read(self.h, node, _ptr(s), _ptr(c)))
+        return s, c
+
+    def node_samples(self, node):
+        n = C.c_size_t()
+        self._ck(self.L.qr_node_samples_read(self.h, node, None, C.byref(n)))
+        ids = np.zeros(n.value, np.uint32)
+        self._ck(self.L.qr_node_samples_read(self.h, node, _ptr(ids), C.byref(n)))
+        return ids
+
+    def split_log(self):
+        out = np.zeros(1024, SPLIT_DTYPE)
+        n = C.c_size_t()
+        self._ck(self.L.qr_tree_split_log(self.h, _ptr(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def metric_per_query(self):
+        out = np.empty(self.Q, np.float64)
+        self._ck(self.L.qr_metric_per_query(self.h, _ptr(out)))
+        return out
+
+    def ranks(self):
+        out = np.empty(self.N, np.uint32)
+        self._ck(self.L.qr_ranks_read(self.h, _ptr(out)))
+        return out
+
+    # -- inference ------------------------------------------------------------
+    def upload_ensemble(self, nodes, weights):
+        nodes = np.ascontiguousarray(nodes)
+        assert nodes.dtype == NODE_DTYPE and nodes.ndim == 2
+        weights = np.ascontiguousarray(weights, np.float64)
+        self._ck(self.L.qr_ensemble_upload(self.h, _ptr(nodes), nodes.shape[0], nodes.shape[1],
+                                           _ptr(weights)))
+
+    def score(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty(x.shape[0], np.float64)
+        ms = C.c_float()
+        self._ck(self.L.qr_ensemble_score(self.h, _ptr(x), x.shape[0], x.shape[1], _ptr(out),
+                                          C.byref(ms)))
+        return out, ms.value
+
+    # -- instrumentation ------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._ck(self.L.qr_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        self._ck(self.L.qr_prof_reset(self.h))
+
+    def prof_get(self):
+        n, ms, b = C.c_uint64(), C.c_double(), C.c_double()
+        self._ck(self.L.qr_prof_get(self.h, C.byref(n), C.byref(ms), C.byref(b)))
+        return dict(launches=n.value, total_ms=ms.value, alg_bytes=b.value)

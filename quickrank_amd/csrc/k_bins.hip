@@ -1,0 +1,176 @@
+// k_bins.hip -- one-time data preparation kernels (gfx950).
+//
+// Stands behind Mart::init (mart.cc:117-176) and the RTRootHistogram ctor
+// (rtnode_histogram.cc:227-253): threshold candidates per feature and the bin
+// map.  The reference argsorts every column (radix.cc:35-73) only to obtain
+// (a) the distinct values in ascending order, capped at nthresholds+1, and
+// (b) min/max.  Here each column is streamed once by one workgroup that keeps
+// an LDS hash set of distinct bit patterns (early-out once it overflows) plus
+// min/max of the radix key; the host finishes the (tiny) threshold arithmetic
+// with the exact f32 operations of mart.cc:147-169.  The bin map is stored as
+// uint8 in 64-feature blocks, row-major inside a block ([block][doc][fw]), the
+// layout the histogram kernels stream and gather (DESIGN.md "HBM layout").
+#include "qr_internal.h"
+
+// ---------------------------------------------------------------------------
+// [N][F] row-major -> [F][N] column-major (vertical_dataset.cc:45-51)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose(const float *__restrict__ in,
+                                                   float *__restrict__ out,
+                                                   uint32_t N, uint32_t F) {
+  __shared__ float tile[32][33];
+  const uint32_t bx = blockIdx.x * 32;  // feature tile
+  const uint32_t by = blockIdx.y * 32;  // doc tile
+  const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (uint32_t j = ty; j < 32; j += 8) {
+    const uint32_t d = by + j, f = bx + tx;
+    if (d < N && f < F) tile[j][tx] = in[(size_t)d * F + f];
+  }
+  __syncthreads();
+  for (uint32_t j = ty; j < 32; j += 8) {
+    const uint32_t f = bx + j, d = by + tx;
+    if (d < N && f < F) out[(size_t)f * N + d] = tile[tx][j];
+  }
+}
+
+int qr_k_transpose(qr_ctx *c, const float *raw, float *col, size_t N, size_t F) {
+  dim3 grid((unsigned)((F + 31) / 32), (unsigned)((N + 31) / 32));
+  hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, c->stream, raw, col,
+                     (uint32_t)N, (uint32_t)F);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Distinct values (as bit patterns) of one column, capped at `limit`, and the
+// min/max of the radix key (radix.cc:28-30: sign-flip so unsigned order ==
+// float order with -0.0 < +0.0).
+// ---------------------------------------------------------------------------
+#define QR_HASH_SLOTS 2048u
+#define QR_HASH_EMPTY 0xFFFFFFFFu
+
+__device__ __forceinline__ uint32_t flip_key(uint32_t x) {
+  return x ^ ((uint32_t)(-(int32_t)(x >> 31)) | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void k_colstats(const float *__restrict__ col,
+                                                  uint32_t N, uint32_t limit,
+                                                  uint32_t *__restrict__ vals,
+                                                  uint32_t *__restrict__ cnt,
+                                                  uint32_t *__restrict__ minmax) {
+  __shared__ uint32_t table[QR_HASH_SLOTS];
+  __shared__ uint32_t s_count, s_min, s_max;
+  const uint32_t f = blockIdx.x;
+  const uint32_t *x = reinterpret_cast<const uint32_t *>(col) + (size_t)f * N;
+  for (uint32_t i = threadIdx.x; i < QR_HASH_SLOTS; i += blockDim.x)
+    table[i] = QR_HASH_EMPTY;
+  if (threadIdx.x == 0) {
+    s_count = 0;
+    s_min = 0xFFFFFFFFu;
+    s_max = 0;
+  }
+  __syncthreads();
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) {
+    const uint32_t v = x[i];
+    const uint32_t k = flip_key(v);
+    kmin = k < kmin ? k : kmin;
+    kmax = k > kmax ? k : kmax;
+    // the set saturates at limit+1 entries: beyond that only min/max matter
+    if (*(volatile uint32_t *)&s_count <= limit) {
+      uint32_t h = (v * 2654435761u) >> 21;  // 11 bits
+      for (uint32_t probe = 0; probe < QR_HASH_SLOTS; ++probe) {
+        const uint32_t cur = table[h];
+        if (cur == v) break;
+        if (cur == QR_HASH_EMPTY) {
+          const uint32_t old = atomicCAS(&table[h], QR_HASH_EMPTY, v);
+          if (old == QR_HASH_EMPTY) {
+            atomicAdd(&s_count, 1u);
+            break;
+          }
+          if (old == v) break;
+        }
+        h = (h + 1) & (QR_HASH_SLOTS - 1);
+        if (*(volatile uint32_t *)&s_count > limit) break;
+      }
+    }
+  }
+  atomicMin(&s_min, kmin);
+  atomicMax(&s_max, kmax);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cnt[f] = s_count;
+    minmax[2 * f] = s_min;
+    minmax[2 * f + 1] = s_max;
+  }
+  // compact the (<= limit+1 + racing inserts) distinct patterns
+  __shared__ uint32_t s_out;
+  if (threadIdx.x == 0) s_out = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < QR_HASH_SLOTS; i += blockDim.x) {
+    const uint32_t v = table[i];
+    if (v != QR_HASH_EMPTY) {
+      const uint32_t o = atomicAdd(&s_out, 1u);
+      if (o < limit + 1) vals[(size_t)f * (limit + 1) + o] = v;
+    }
+  }
+}
+
+int qr_k_colstats(qr_ctx *c, const float *col, size_t N, size_t F,
+                  uint32_t limit, uint32_t *d_vals, uint32_t *d_cnt,
+                  uint32_t *d_minmax) {
+  hipLaunchKernelGGL(k_colstats, dim3((unsigned)F), dim3(256), 0, c->stream, col,
+                     (uint32_t)N, limit, d_vals, d_cnt, d_minmax);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Bin map: bin = first slot t with x <= thr[f][t] (rtnode_histogram.cc:241-251)
+// = lower_bound over the non-decreasing threshold row.  One thread per
+// (doc, local column); columns fastest so both the f32 row read and the u8
+// block-row write are coalesced.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_binning(const float *__restrict__ raw,
+                                                 uint32_t N, uint32_t F,
+                                                 const float *__restrict__ thr,
+                                                 const uint32_t *__restrict__ thr_size,
+                                                 QrBlock blk,
+                                                 uint8_t *__restrict__ bins) {
+  const uint32_t fw = (uint32_t)blk.fw;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * fw;
+  if (idx >= total) return;
+  const uint32_t d = (uint32_t)(idx / fw);
+  const uint32_t cidx = (uint32_t)(idx % fw);
+  uint8_t out = 0;  // padded columns: constant bin 0 (never a split candidate)
+  if (cidx < (uint32_t)blk.nreal) {
+    const uint32_t f = blk.f0 + cidx;
+    const float x = raw[(size_t)d * F + f];
+    const float *t = thr + (size_t)f * QR_MAX_BINS;
+    uint32_t lo = 0, hi = thr_size[f];  // first lo with x <= t[lo]
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (x <= t[mid])
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    const uint32_t last = thr_size[f] - 1;
+    out = (uint8_t)(lo > last ? last : lo);  // NaN/+inf -> sentinel slot
+  }
+  bins[blk.off + (size_t)d * fw + cidx] = out;
+}
+
+int qr_k_binning(qr_ctx *c) {
+  for (int b = 0; b < c->nblocks; ++b) {
+    const QrBlock &blk = c->blocks[b];
+    const size_t total = c->N * (size_t)blk.fw;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(k_binning, dim3(grid), dim3(256), 0, c->stream, c->d_raw,
+                       (uint32_t)c->N, (uint32_t)c->F, c->d_thr, c->d_thr_size,
+                       blk, c->d_bins);
+    QR_CHECK(c, hipGetLastError());
+  }
+  return QR_OK;
+}

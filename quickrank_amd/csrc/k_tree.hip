@@ -1,0 +1,1006 @@
+// k_tree.hip -- regression-tree construction on the device (gfx950).
+//
+// Stands behind RTNodeHistogram::update / child ctor / sibling subtraction
+// (rtnode_histogram.cc:41-87, 172-217), RegressionTree::fit + split
+// (rt.cc:49-90, 209-362), MaxHeap (maxheap.h:58-88), RTNode stats
+// (rtnode.h:97-107), RTNode::save_leaves (rtnode.cc:34-46),
+// RegressionTree::update_output (rt.cc:165-207) and Mart::update_modelscores
+// (mart.cc:447-468).
+//
+// Kernels (one stream, no host round trip inside a tree):
+//   k_hist     histogram build of one node over the rank's 64-feature blocks:
+//              LDS-resident [bin][feature] cells, one ds_add_u64 per
+//              (doc, feature) carrying gradient AND count (fixed point, see
+//              qr_internal.h), bank-conflict-free by construction
+//   k_scan     per feature: reduce the workgroup partials, prefix-sum over the
+//              256 slots, derive the sibling (parent - child), evaluate the
+//              split gain of every slot and keep the first best one
+//   k_merge    best (feature, slot) over the local features (lowest f wins ties)
+//   k_decide   single-lane control: node statistics, max-deviance heap growth,
+//              next split descriptor
+//   k_mask / k_part_count / k_part_scatter   stable partition of the node's
+//              doc list (ascending doc ids are preserved)
+//   k_finish / k_leaf_sums / k_leaf_final / k_score_update / k_valid_update
+#include "qr_internal.h"
+
+typedef unsigned long long u64;
+
+// ===========================================================================
+// k_hist
+// ===========================================================================
+// Bank-conflict-free LDS accumulation.
+//   lane = (doc slot dsub = lane / CH, 16-feature chunk c = lane % CH)
+//   each lane loads the 16 bin ids (16 B) of its chunk of its doc, then issues
+//   16 ds_add_u64.  At step k lane L touches column 16c + ((k + L) & 15):
+//   the 16 lanes of a hardware LDS lane group (L & ~15 .. +15) therefore hit 16
+//   distinct (column mod 16) values; with the [bin][fw] cell layout (fw a
+//   multiple of 16, 8-byte cells) that is 16 distinct bank pairs whatever the
+//   bins are.  Same-cell collisions between groups / waves are what the
+//   atomic is for.
+__device__ __forceinline__ long long quantize(double x) {
+  // round-to-nearest-even of |x| < 2^51 via the 1.5*2^52 trick
+  const double magic = 6755399441055744.0;
+  return __double_as_longlong(x + magic) - __double_as_longlong(magic);
+}
+
+template <int CH>
+__device__ __forceinline__ void hist_accumulate(
+    u64 *__restrict__ hist, const uint8_t *__restrict__ bins_b,
+    const uint32_t *__restrict__ order, const bool identity,
+    const uint32_t seg_begin, const uint32_t r0, const uint32_t r1,
+    const double *__restrict__ lambda, const double scale) {
+  constexpr int FW = 16 * CH;
+  constexpr int DW = 64 / CH;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nw = blockDim.x >> 6;
+  const int dsub = lane / CH;
+  const int c = lane - dsub * CH;
+  const bool lane_ok = dsub < DW;
+  const int r = lane & 15;
+  uint32_t colk[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) colk[k] = 16 * c + ((k + r) & 15);
+  const int dr = r >> 2;       // dword rotation
+  const uint32_t br = r & 3;   // byte rotation inside a dword
+  for (uint32_t base = r0 + wave * DW; base < r1; base += nw * DW) {
+    const uint32_t pos = base + dsub;
+    if (lane_ok && pos < r1) {
+      const uint32_t id = identity ? seg_begin + pos : order[seg_begin + pos];
+      const uint4 row =
+          *reinterpret_cast<const uint4 *>(bins_b + (size_t)id * FW + 16 * c);
+      const double lam = lambda[id];
+      const u64 addend = (1ull << QR_SB) + (u64)quantize(lam * scale);
+      // rotate the 16 bytes right by r so that byte k of R is byte (k+r)&15
+      uint32_t t0 = (dr & 1) ? row.y : row.x;
+      uint32_t t1 = (dr & 1) ? row.z : row.y;
+      uint32_t t2 = (dr & 1) ? row.w : row.z;
+      uint32_t t3 = (dr & 1) ? row.x : row.w;
+      const uint32_t u0 = (dr & 2) ? t2 : t0;
+      const uint32_t u1 = (dr & 2) ? t3 : t1;
+      const uint32_t u2 = (dr & 2) ? t0 : t2;
+      const uint32_t u3 = (dr & 2) ? t1 : t3;
+      uint32_t R[4];
+      R[0] = __builtin_amdgcn_alignbyte(u1, u0, br);
+      R[1] = __builtin_amdgcn_alignbyte(u2, u1, br);
+      R[2] = __builtin_amdgcn_alignbyte(u3, u2, br);
+      R[3] = __builtin_amdgcn_alignbyte(u0, u3, br);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const uint32_t bin = (R[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        atomicAdd(&hist[bin * FW + colk[k]], addend);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_hist(
+    const QrTreeState *__restrict__ ts, const int root_mode, const uint32_t N,
+    const QrBlock *__restrict__ blocks, const int nblocks,
+    const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
+    const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
+    const QrScalars *__restrict__ scal, u64 *__restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) u64 hist[];
+  uint32_t seg_begin, n;
+  int buf;
+  if (root_mode) {
+    seg_begin = 0;
+    n = N;
+    buf = 2;
+  } else {
+    if (!ts->desc.active) return;
+    seg_begin = ts->desc.small_begin;
+    n = ts->desc.small_n;
+    buf = ts->desc.dst_buf;
+  }
+  __shared__ QrPlan plan;
+  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, (int)gridDim.x, &plan);
+  __syncthreads();
+  int b = -1;
+  for (int i = 0; i < nblocks; ++i)
+    if ((int)blockIdx.x >= plan.wg_start[i] && (int)blockIdx.x < plan.wg_start[i + 1])
+      b = i;
+  if (b < 0) return;
+  const uint32_t j = blockIdx.x - plan.wg_start[b];
+  const uint32_t per = plan.per[b];
+  const uint32_t r0 = j * per;
+  const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
+  const int fw = blocks[b].fw;
+  const uint8_t *bins_b = bins + blocks[b].off;
+  const uint32_t *order = buf == 0 ? order0 : order1;
+  const bool identity = buf == 2;
+  const double scale = scal->scale;
+  const uint32_t cells = 256u * fw;
+  uint32_t k = 0;
+  for (uint32_t s0 = r0; s0 < r1; s0 += QR_DPW, ++k) {
+    const uint32_t s1 = (s0 + QR_DPW < r1) ? s0 + QR_DPW : r1;
+    for (uint32_t i = threadIdx.x * 2; i < cells; i += blockDim.x * 2) {
+      hist[i] = 0;
+      hist[i + 1] = 0;
+    }
+    __syncthreads();
+    switch (fw) {
+      case 16: hist_accumulate<1>(hist, bins_b, order, identity, seg_begin, s0, s1, lambda, scale); break;
+      case 32: hist_accumulate<2>(hist, bins_b, order, identity, seg_begin, s0, s1, lambda, scale); break;
+      case 48: hist_accumulate<3>(hist, bins_b, order, identity, seg_begin, s0, s1, lambda, scale); break;
+      default: hist_accumulate<4>(hist, bins_b, order, identity, seg_begin, s0, s1, lambda, scale); break;
+    }
+    __syncthreads();
+    u64 *dst = partials + ((size_t)blockIdx.x * plan.kmax + k) * (256u * 64u);
+    for (uint32_t i = threadIdx.x * 2; i < cells; i += blockDim.x * 2) {
+      ulonglong2 v;
+      v.x = hist[i];
+      v.y = hist[i + 1];
+      *reinterpret_cast<ulonglong2 *>(dst + i) = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ===========================================================================
+// k_scan
+// ===========================================================================
+struct Best {
+  double score;
+  uint32_t t;
+};
+
+__device__ __forceinline__ Best best_pick(Best a, Best b) {
+  // first max: higher score wins, equal scores -> lower slot (rt.cc:285)
+  if (b.score > a.score || (b.score == a.score && b.t < a.t)) return b;
+  return a;
+}
+
+__device__ __forceinline__ Best block_best(Best v, Best *sh) {
+  for (int off = 32; off > 0; off >>= 1) {
+    Best o;
+    o.score = __shfl_xor(v.score, off, 64);
+    o.t = __shfl_xor(v.t, off, 64);
+    v = best_pick(v, o);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  Best r = sh[0];
+  for (int i = 1; i < 4; ++i) r = best_pick(r, sh[i]);
+  return r;
+}
+
+// gain of slot t of a node: rt.cc:268-291
+__device__ __forceinline__ Best slot_gain(long long cs, uint32_t cc, long long S,
+                                          uint32_t C, uint32_t t, uint32_t tsize,
+                                          u64 minls, double inv_scale) {
+  Best b;
+  b.score = -1.0;
+  b.t = 0xFFFFFFFFu;
+  const u64 lc = cc, rc = (u64)C - cc;
+  if (t < tsize && lc >= minls && rc >= minls) {
+    const double s = (double)S * inv_scale;
+    const double lsum = (double)cs * inv_scale;
+    const double rsum = s - lsum;
+    const double score = lsum * lsum / (double)lc + rsum * rsum / (double)rc;
+    if (score > -1.0) {
+      b.score = score;
+      b.t = t;
+    }
+  }
+  return b;
+}
+
+__global__ __launch_bounds__(256) void k_scan(
+    const QrTreeState *__restrict__ ts, const int root_mode, const uint32_t N,
+    const QrBlock *__restrict__ blocks, const int nblocks, const int G,
+    const u64 *__restrict__ partials, long long *__restrict__ hsum,
+    uint32_t *__restrict__ hcnt, const int flocal,
+    const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
+    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec) {
+  __shared__ long long sh_s[4];
+  __shared__ uint32_t sh_c[4];
+  __shared__ long long tot_s[2];
+  __shared__ uint32_t tot_c[2];
+  __shared__ Best sh_b[4];
+  uint32_t n;
+  int small_slot, big_slot = -1, parent_slot = -1, small_is_left = 1;
+  u64 minls = ts->minls;
+  if (root_mode) {
+    n = N;
+    small_slot = 0;
+  } else {
+    if (!ts->desc.active) return;
+    n = ts->desc.small_n;
+    small_slot = ts->desc.small_slot;
+    big_slot = ts->desc.big_slot;
+    parent_slot = ts->desc.parent_slot;
+    small_is_left = ts->desc.small_is_left;
+  }
+  const int lf = blockIdx.x;
+  int b = 0;
+  for (int i = 0; i < nblocks; ++i)
+    if (lf >= blocks[i].lf0 && lf < blocks[i].lf0 + blocks[i].nreal) b = i;
+  const int col = lf - blocks[b].lf0;
+  const int fw = blocks[b].fw;
+  __shared__ QrPlan plan;
+  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, G, &plan);
+  __syncthreads();
+  const uint32_t t = threadIdx.x;
+  long long s = 0;
+  uint32_t cn = 0;
+  const uint32_t per = plan.per[b];
+  const int W = plan.wg_start[b + 1] - plan.wg_start[b];
+  for (int j = 0; j < W; ++j) {
+    const uint32_t r0 = j * per;
+    const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
+    const int nk = (int)((r1 - r0 + QR_DPW - 1) / QR_DPW);
+    for (int k = 0; k < nk; ++k) {
+      const size_t slot = (size_t)(plan.wg_start[b] + j) * plan.kmax + k;
+      const u64 cell = partials[slot * (256u * 64u) + (size_t)t * fw + col];
+      const u64 cnt = (cell + (1ull << (QR_SB - 1))) >> QR_SB;
+      s += (long long)(cell - (cnt << QR_SB));
+      cn += (uint32_t)cnt;
+    }
+  }
+  // inclusive scan over the 256 slots (exact integers: any association)
+  const int lane = t & 63, wave = t >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const long long os = __shfl_up(s, off, 64);
+    const uint32_t oc = __shfl_up(cn, off, 64);
+    if (lane >= off) {
+      s += os;
+      cn += oc;
+    }
+  }
+  if (lane == 63) {
+    sh_s[wave] = s;
+    sh_c[wave] = cn;
+  }
+  __syncthreads();
+  for (int w = 0; w < wave; ++w) {
+    s += sh_s[w];
+    cn += sh_c[w];
+  }
+  const size_t hidx = ((size_t)small_slot * flocal + lf) * 256 + t;
+  hsum[hidx] = s;
+  hcnt[hidx] = cn;
+  long long bs = 0;
+  uint32_t bc = 0;
+  if (!root_mode) {
+    const size_t pidx = ((size_t)parent_slot * flocal + lf) * 256 + t;
+    bs = hsum[pidx] - s;
+    bc = hcnt[pidx] - cn;
+    const size_t bidx = ((size_t)big_slot * flocal + lf) * 256 + t;
+    hsum[bidx] = bs;
+    hcnt[bidx] = bc;
+  }
+  if (t == 255) {
+    tot_s[0] = s;
+    tot_c[0] = cn;
+    tot_s[1] = bs;
+    tot_c[1] = bc;
+  }
+  __syncthreads();
+  const int gf = lf2gf[lf];
+  const uint32_t tsize = thr_size[gf];
+  const double inv_scale = scal->inv_scale;
+  {
+    Best v = slot_gain(s, cn, tot_s[0], tot_c[0], t, tsize, minls, inv_scale);
+    v = block_best(v, sh_b);
+    if (t == 0) {
+      const int which = root_mode ? 0 : (small_is_left ? 0 : 1);
+      qr_split_t *o = &featrec[(size_t)which * flocal + lf];
+      o->score = v.score;
+      o->feature = v.t == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)gf;
+      o->thr_id = v.t;
+      o->lcount = 0;
+      o->rcount = 0;
+    }
+  }
+  if (!root_mode) {
+    Best v = slot_gain(bs, bc, tot_s[1], tot_c[1], t, tsize, minls, inv_scale);
+    v = block_best(v, sh_b);
+    if (t == 0) {
+      const int which = small_is_left ? 1 : 0;
+      qr_split_t *o = &featrec[(size_t)which * flocal + lf];
+      o->score = v.score;
+      o->feature = v.t == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)gf;
+      o->thr_id = v.t;
+      o->lcount = 0;
+      o->rcount = 0;
+    }
+  }
+}
+
+// ===========================================================================
+// k_merge: best over the local features; local features are in ascending
+// global order and the comparison is strict, so the lowest feature wins ties
+// (rt.cc:297-306).  Also attaches lcount/rcount from the node histogram.
+// ===========================================================================
+__global__ __launch_bounds__(64) void k_merge(
+    const QrTreeState *__restrict__ ts, const int root_mode,
+    const qr_split_t *__restrict__ featrec, const int flocal,
+    const long long *__restrict__ hsum, const uint32_t *__restrict__ hcnt,
+    const int32_t *__restrict__ gf2lf, qr_split_t *__restrict__ recs_local) {
+  if (!root_mode && !ts->desc.active) return;
+  const int which = threadIdx.x;
+  if (which >= 2) return;
+  if (root_mode && which == 1) {
+    recs_local[1].score = -1.0;
+    recs_local[1].feature = 0xFFFFFFFFu;
+    recs_local[1].thr_id = 0xFFFFFFFFu;
+    recs_local[1].lcount = recs_local[1].rcount = 0;
+    return;
+  }
+  qr_split_t best;
+  best.score = -1.0;
+  best.feature = 0xFFFFFFFFu;
+  best.thr_id = 0xFFFFFFFFu;
+  best.lcount = best.rcount = 0;
+  for (int lf = 0; lf < flocal; ++lf) {
+    const qr_split_t r = featrec[(size_t)which * flocal + lf];
+    if (r.score > best.score) best = r;
+  }
+  if (best.feature != 0xFFFFFFFFu) {
+    int slot;
+    if (root_mode)
+      slot = 0;
+    else
+      slot = which == 0 ? (ts->desc.small_is_left ? ts->desc.small_slot : ts->desc.big_slot)
+                        : (ts->desc.small_is_left ? ts->desc.big_slot : ts->desc.small_slot);
+    const int lf = gf2lf[best.feature];
+    const size_t base = ((size_t)slot * flocal + lf) * 256;
+    best.lcount = hcnt[base + best.thr_id];
+    best.rcount = (u64)hcnt[base + 255] - best.lcount;
+  }
+  recs_local[which] = best;
+}
+
+// ===========================================================================
+// k_decide: the host logic of RegressionTree::fit, on one lane.
+// ===========================================================================
+__device__ void heap_push(QrTreeState *ts, double key, int32_t val) {
+  // maxheap.h:58-68 (arr[0] is a DBL_MAX sentinel)
+  size_t p = (size_t)(++ts->heap_size);
+  while (key > ts->heap[p >> 1].key) {
+    ts->heap[p] = ts->heap[p >> 1];
+    p >>= 1;
+  }
+  ts->heap[p].key = key;
+  ts->heap[p].val = val;
+}
+
+__device__ void heap_pop(QrTreeState *ts) {
+  // maxheap.h:71-84
+  const QrHeapItem last = ts->heap[ts->heap_size--];
+  size_t child, p = 1;
+  const size_t size = (size_t)ts->heap_size;
+  while ((p << 1) <= size) {
+    child = p << 1;
+    if (child < size && ts->heap[child + 1].key > ts->heap[child].key) ++child;
+    if (last.key < ts->heap[child].key)
+      ts->heap[p] = ts->heap[child];
+    else
+      break;
+    p = child;
+  }
+  ts->heap[p] = last;
+}
+
+// RTNode(sampleids, hist): rtnode.h:97-107
+__device__ void node_stats(QrNode *nd, long long total_q, double inv_scale,
+                           double ss, u64 count) {
+  nd->count = count;
+  nd->sum = (double)total_q * inv_scale;
+  nd->ss = ss;
+  nd->value = count ? nd->sum / (double)count : 0.0;
+  nd->deviance = ss - nd->sum * nd->sum / (double)count;
+}
+
+__device__ void node_set_best(QrNode *nd, const qr_split_t *recs, int world,
+                              int which) {
+  // deterministic merge over ranks: max score, ties -> lowest feature
+  nd->best_score = -1.0;
+  nd->best_f = 0xFFFFFFFFu;
+  nd->best_t = 0xFFFFFFFFu;
+  nd->best_lc = nd->best_rc = 0;
+  for (int r = 0; r < world; ++r) {
+    const qr_split_t x = recs[(size_t)r * 2 + which];
+    if (x.feature == 0xFFFFFFFFu) continue;
+    if (x.score > nd->best_score ||
+        (x.score == nd->best_score && x.feature < nd->best_f)) {
+      nd->best_score = x.score;
+      nd->best_f = x.feature;
+      nd->best_t = x.thr_id;
+      nd->best_lc = x.lcount;
+      nd->best_rc = x.rcount;
+    }
+  }
+}
+
+__device__ bool node_splittable(const QrNode *nd) {
+  // rt.cc:212 (deviance > 0.0f) and :312 (best_score == initvar => unsplittable)
+  return nd->deviance > 0.0 && nd->best_f != 0xFFFFFFFFu;
+}
+
+__device__ void make_desc(QrTreeState *ts, int node, const float *thr,
+                          const int32_t *gf2lf) {
+  QrNode *nd = &ts->nodes[node];
+  QrSplitDesc *d = &ts->desc;
+  const int li = ts->nnodes, ri = ts->nnodes + 1;
+  ts->nnodes += 2;
+  d->active = 1;
+  d->node = node;
+  d->left = li;
+  d->right = ri;
+  d->begin = nd->begin;
+  d->end = nd->end;
+  d->src_buf = nd->buf;
+  d->dst_buf = nd->buf == 0 ? 1 : 0;
+  d->lcount = (uint32_t)nd->best_lc;
+  d->rcount = (uint32_t)nd->best_rc;
+  d->feature = nd->best_f;
+  d->thr_id = nd->best_t;
+  d->owner_local = gf2lf[nd->best_f];
+  d->small_is_left = d->lcount <= d->rcount;
+  d->small_node = d->small_is_left ? li : ri;
+  d->big_node = d->small_is_left ? ri : li;
+  d->parent_slot = nd->hslot;
+  d->small_slot = d->small_node;
+  d->big_slot = d->big_node;
+  d->small_begin = d->small_is_left ? nd->begin : nd->begin + d->lcount;
+  d->small_n = d->small_is_left ? d->lcount : d->rcount;
+  nd->feature = (int32_t)nd->best_f;
+  nd->thr_id = (int32_t)nd->best_t;
+  nd->threshold = thr[(size_t)nd->best_f * QR_MAX_BINS + nd->best_t];
+  nd->left = li;
+  nd->right = ri;
+  QrNode *L = &ts->nodes[li], *R = &ts->nodes[ri];
+  L->begin = nd->begin;
+  L->end = nd->begin + d->lcount;
+  R->begin = L->end;
+  R->end = nd->end;
+  L->buf = R->buf = d->dst_buf;
+  L->hslot = li;
+  R->hslot = ri;
+  L->feature = R->feature = -1;
+  L->thr_id = R->thr_id = -1;
+  L->threshold = R->threshold = 0.f;
+  L->left = L->right = R->left = R->right = -1;
+  L->parent = R->parent = node;
+  L->leaf_id = R->leaf_id = -1;
+  qr_split_t *lg = &ts->split_log[ts->nsplits++];
+  lg->score = nd->best_score;
+  lg->feature = nd->best_f;
+  lg->thr_id = nd->best_t;
+  lg->lcount = nd->best_lc;
+  lg->rcount = nd->best_rc;
+}
+
+__global__ __launch_bounds__(64) void k_decide(
+    QrTreeState *__restrict__ ts, const uint32_t N, const int flocal,
+    const long long *__restrict__ hsum, const qr_split_t *__restrict__ recs,
+    const int world, const QrScalars *__restrict__ scal,
+    const double *__restrict__ part_ss, const float *__restrict__ thr,
+    const int32_t *__restrict__ gf2lf) {
+  if (threadIdx.x != 0) return;
+  const double inv_scale = scal->inv_scale;
+  if (ts->step == 0) {
+    QrNode *root = &ts->nodes[0];
+    root->begin = 0;
+    root->end = N;
+    root->buf = 2;
+    root->hslot = 0;
+    root->feature = -1;
+    root->thr_id = -1;
+    root->threshold = 0.f;
+    root->left = root->right = root->parent = -1;
+    root->leaf_id = -1;
+    node_stats(root, hsum[255], inv_scale, scal->root_ss, N);
+    node_set_best(root, recs, world, 0);
+    ts->nnodes = 1;
+    ts->heap_size = 0;
+    ts->heap[0].key = 1.7976931348623157e308;  // DBL_MAX sentinel
+    ts->heap[0].val = -1;
+    ts->taken = 0;
+    ts->done = 0;
+    ts->nsplits = 0;
+    ts->desc.active = 0;
+    if (node_splittable(root))
+      make_desc(ts, 0, thr, gf2lf);
+    else
+      ts->done = 1;
+    ts->step = 1;
+    return;
+  }
+  if (ts->desc.active) {
+    // children of the split just applied
+    const QrSplitDesc d = ts->desc;
+    QrNode *P = &ts->nodes[d.node];
+    QrNode *S = &ts->nodes[d.small_node], *B = &ts->nodes[d.big_node];
+    const uint32_t nwg = (d.end - d.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
+    double ss_small = 0.0;
+    for (uint32_t i = 0; i < nwg; ++i) ss_small += part_ss[i];
+    const long long sq = hsum[((size_t)d.small_slot * flocal) * 256 + 255];
+    const long long bq = hsum[((size_t)d.big_slot * flocal) * 256 + 255];
+    node_stats(S, sq, inv_scale, ss_small, d.small_n);
+    node_stats(B, bq, inv_scale, P->ss - ss_small,
+               (u64)(d.end - d.begin) - d.small_n);
+    node_set_best(&ts->nodes[d.left], recs, world, 0);
+    node_set_best(&ts->nodes[d.right], recs, world, 1);
+    heap_push(ts, ts->nodes[d.left].deviance, d.left);    // rt.cc:76-77
+    heap_push(ts, ts->nodes[d.right].deviance, d.right);
+    ts->desc.active = 0;
+  }
+  ts->step++;
+  if (ts->done) return;
+  bool found = false;
+  while (ts->heap_size > 0 &&
+         (ts->nleaves_req == 0 || ts->taken + ts->heap_size < ts->nleaves_req)) {
+    const int node = ts->heap[1].val;
+    heap_pop(ts);
+    if (node_splittable(&ts->nodes[node])) {
+      make_desc(ts, node, thr, gf2lf);
+      found = true;
+      break;
+    }
+    ++ts->taken;
+  }
+  if (!found) ts->done = 1;
+}
+
+// ===========================================================================
+// Partition (rt.cc:325-334): stable, x <= threshold  <=>  bin <= thr_id.
+// ===========================================================================
+__device__ __forceinline__ bool go_left(const QrSplitDesc &d, uint32_t p, uint32_t id,
+                                        const QrBlock *blocks, int nblocks,
+                                        const uint8_t *bins, const uint32_t *mask,
+                                        int use_mask) {
+  if (use_mask) return (mask[p >> 5] >> (p & 31)) & 1u;
+  const int lf = d.owner_local;
+  int b = 0;
+  for (int i = 0; i < nblocks; ++i)
+    if (lf >= blocks[i].lf0 && lf < blocks[i].lf0 + blocks[i].nreal) b = i;
+  const uint8_t v = bins[blocks[b].off + (size_t)id * blocks[b].fw + (lf - blocks[b].lf0)];
+  return v <= d.thr_id;
+}
+
+// multi-GPU: the owner of the winning feature publishes the go-left bits of the
+// node's positions; everybody else contributes zeros to the bitwise-or/sum.
+__global__ __launch_bounds__(256) void k_mask(
+    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks,
+    const int nblocks, const uint8_t *__restrict__ bins,
+    const uint32_t *__restrict__ order0, const uint32_t *__restrict__ order1,
+    uint32_t *__restrict__ mask, const uint32_t mask_words) {
+  const QrSplitDesc d = ts->desc;
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= mask_words) return;
+  uint32_t bits = 0;
+  if (d.active && d.owner_local >= 0) {
+    const uint32_t n = d.end - d.begin;
+    const uint32_t *order = d.src_buf == 0 ? order0 : order1;
+    for (uint32_t k = 0; k < 32; ++k) {
+      const uint32_t p = w * 32 + k;
+      if (p < n) {
+        const uint32_t id = d.src_buf == 2 ? d.begin + p : order[d.begin + p];
+        if (go_left(d, p, id, blocks, nblocks, bins, nullptr, 0)) bits |= 1u << k;
+      }
+    }
+  }
+  mask[w] = bits;
+}
+
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *sh) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+#define PART_PER_THREAD (QR_PART_SLICE / 256)
+
+__global__ __launch_bounds__(256) void k_part_count(
+    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks,
+    const int nblocks, const uint8_t *__restrict__ bins,
+    const uint32_t *__restrict__ order0, const uint32_t *__restrict__ order1,
+    const uint32_t *__restrict__ mask, const int use_mask,
+    uint32_t *__restrict__ blkcnt) {
+  __shared__ uint32_t sh[4];
+  const QrSplitDesc d = ts->desc;
+  if (!d.active) return;
+  const uint32_t n = d.end - d.begin;
+  const uint32_t base = blockIdx.x * QR_PART_SLICE;
+  if (base >= n) return;
+  const uint32_t *order = d.src_buf == 0 ? order0 : order1;
+  uint32_t cnt = 0;
+  for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
+    const uint32_t p = base + threadIdx.x * PART_PER_THREAD + k;
+    if (p < n) {
+      const uint32_t id = d.src_buf == 2 ? d.begin + p : order[d.begin + p];
+      cnt += go_left(d, p, id, blocks, nblocks, bins, mask, use_mask) ? 1u : 0u;
+    }
+  }
+  const uint32_t tot = block_sum_u32(cnt, sh);
+  if (threadIdx.x == 0) blkcnt[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_part_scatter(
+    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks,
+    const int nblocks, const uint8_t *__restrict__ bins,
+    uint32_t *__restrict__ order0, uint32_t *__restrict__ order1,
+    const uint32_t *__restrict__ mask, const int use_mask,
+    const uint32_t *__restrict__ blkcnt, const double *__restrict__ lambda,
+    double *__restrict__ part_ss) {
+  __shared__ uint32_t sh[4];
+  __shared__ uint32_t wave_off[4];
+  __shared__ double shd[4];
+  const QrSplitDesc d = ts->desc;
+  if (!d.active) return;
+  const uint32_t n = d.end - d.begin;
+  const uint32_t base = blockIdx.x * QR_PART_SLICE;
+  if (base >= n) return;
+  // lefts in the slices before mine
+  uint32_t pre = 0;
+  for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) pre += blkcnt[i];
+  const uint32_t left_before = block_sum_u32(pre, sh);
+  const uint32_t *src = d.src_buf == 0 ? order0 : order1;
+  uint32_t *dst = d.dst_buf == 0 ? order0 : order1;
+  uint32_t ids[PART_PER_THREAD];
+  bool fl[PART_PER_THREAD];
+  uint32_t cnt = 0;
+  for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
+    const uint32_t p = base + threadIdx.x * PART_PER_THREAD + k;
+    fl[k] = false;
+    ids[k] = 0;
+    if (p < n) {
+      ids[k] = d.src_buf == 2 ? d.begin + p : src[d.begin + p];
+      fl[k] = go_left(d, p, ids[k], blocks, nblocks, bins, mask, use_mask);
+      cnt += fl[k] ? 1u : 0u;
+    }
+  }
+  // exclusive scan of cnt over the 256 threads
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = cnt;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  __syncthreads();
+  if (lane == 63) wave_off[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wave_off[w];
+  uint32_t lpos = left_before + woff + inc - cnt;  // lefts before my first doc
+  const uint32_t first_p = base + threadIdx.x * PART_PER_THREAD;
+  double sq = 0.0;
+  for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
+    const uint32_t p = first_p + k;
+    if (p < n) {
+      uint32_t o;
+      if (fl[k]) {
+        o = d.begin + lpos;
+        ++lpos;
+      } else {
+        o = d.begin + d.lcount + (p - lpos);
+      }
+      dst[o] = ids[k];
+      if (fl[k] == (d.small_is_left != 0)) {
+        const double l = lambda[ids[k]];
+        sq += l * l;
+      }
+    }
+  }
+  // squares_sum_ of the directly built child (rtnode_histogram.cc:65-69),
+  // fixed reduction tree
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+  __syncthreads();
+  if (lane == 0) shd[wave] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) part_ss[blockIdx.x] = (shd[0] + shd[1]) + (shd[2] + shd[3]);
+}
+
+// ===========================================================================
+// Tree end: leaves, leaf outputs, score update
+// ===========================================================================
+__global__ __launch_bounds__(64) void k_finish(QrTreeState *__restrict__ ts) {
+  if (threadIdx.x != 0) return;
+  // RTNode::save_leaves (rtnode.cc:34-46): DFS, left first
+  int stack[QR_MAXNODES];
+  int sp = 0, nl = 0;
+  stack[sp++] = 0;
+  while (sp > 0) {
+    const int n = stack[--sp];
+    QrNode *nd = &ts->nodes[n];
+    if (nd->feature < 0) {
+      nd->leaf_id = nl;
+      ts->leaf_nodes[nl] = n;
+      ts->leaf_begin[nl] = nd->begin;  // DFS order == ascending positions
+      ++nl;
+    } else {
+      stack[sp++] = nd->right;
+      stack[sp++] = nd->left;
+    }
+  }
+  ts->nleaves = nl;
+  ts->leaf_begin[nl] = ts->nodes[0].end;
+}
+
+__device__ __forceinline__ int leaf_of_pos(const uint32_t *lb, int nl, uint32_t p) {
+  int lo = 0, hi = nl;  // last l with lb[l] <= p
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (lb[mid] <= p)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// partial sums of (lambda, weight) per (slice, leaf) pair, entry = slice + leaf
+__global__ __launch_bounds__(256) void k_leaf_sums(
+    const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ order0,
+    const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
+    const double *__restrict__ weight, double *__restrict__ leafpart) {
+  __shared__ double sh1[4], sh2[4];
+  __shared__ uint32_t lb[QR_MAXNODES + 1];
+  const int nl = ts->nleaves;
+  for (int i = threadIdx.x; i <= nl; i += 256) lb[i] = ts->leaf_begin[i];
+  __syncthreads();
+  const uint32_t N = lb[nl];
+  const uint32_t base = blockIdx.x * QR_SLICE;
+  if (base >= N) return;
+  const uint32_t end = base + QR_SLICE < N ? base + QR_SLICE : N;
+  double v1[QR_SLICE / 256], v2[QR_SLICE / 256];
+  int lf[QR_SLICE / 256];
+  for (uint32_t k = 0; k < QR_SLICE / 256; ++k) {
+    const uint32_t p = base + k * 256 + threadIdx.x;
+    v1[k] = v2[k] = 0.0;
+    lf[k] = -1;
+    if (p < end) {
+      const int l = leaf_of_pos(lb, nl, p);
+      const int buf = ts->nodes[ts->leaf_nodes[l]].buf;
+      const uint32_t id = buf == 2 ? p : (buf == 0 ? order0[p] : order1[p]);
+      v1[k] = lambda[id];
+      v2[k] = weight ? weight[id] : 0.0;
+      lf[k] = l;
+    }
+  }
+  const int l0 = leaf_of_pos(lb, nl, base);
+  for (int l = l0; l < nl && lb[l] < end; ++l) {
+    double a = 0.0, b = 0.0;
+    for (uint32_t k = 0; k < QR_SLICE / 256; ++k)
+      if (lf[k] == l) {
+        a += v1[k];
+        b += v2[k];
+      }
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_xor(a, off, 64);
+      b += __shfl_xor(b, off, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+      sh1[threadIdx.x >> 6] = a;
+      sh2[threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const size_t e = (size_t)blockIdx.x + l;
+      leafpart[2 * e] = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]);
+      leafpart[2 * e + 1] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+    }
+  }
+}
+
+// rt.cc:165-207
+__global__ __launch_bounds__(256) void k_leaf_final(QrTreeState *__restrict__ ts,
+                                                    const double *__restrict__ leafpart,
+                                                    const int newton) {
+  const int nl = ts->nleaves;
+  for (int l = threadIdx.x; l < nl; l += blockDim.x) {
+    const uint32_t b = ts->leaf_begin[l], e = ts->leaf_begin[l + 1];
+    double s1 = 0.0, s2 = 0.0;
+    if (e > b) {
+      const uint32_t sl0 = b / QR_SLICE, sl1 = (e - 1) / QR_SLICE;
+      for (uint32_t s = sl0; s <= sl1; ++s) {
+        s1 += leafpart[2 * ((size_t)s + l)];
+        s2 += leafpart[2 * ((size_t)s + l) + 1];
+      }
+    }
+    double v;
+    if (newton)
+      v = s2 >= 2.2204460492503131e-16 ? s1 / s2 : 0.0;  // DBL_EPSILON
+    else
+      v = s1 / (double)(e - b);
+    ts->leaf_value[l] = v;
+    ts->nodes[ts->leaf_nodes[l]].value = v;
+  }
+}
+
+// mart.cc:459-468 through the leaf membership instead of a tree walk:
+// scores[i] += shrinkage * leaf(i)   (f64 multiply, then add; no contraction)
+__global__ __launch_bounds__(256) void k_score_update(
+    const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ order0,
+    const uint32_t *__restrict__ order1, const double shrinkage,
+    double *__restrict__ scores) {
+  __shared__ uint32_t lb[QR_MAXNODES + 1];
+  __shared__ double lv[QR_MAXNODES];
+  __shared__ int lbuf[QR_MAXNODES];
+  const int nl = ts->nleaves;
+  for (int i = threadIdx.x; i <= nl; i += 256) lb[i] = ts->leaf_begin[i];
+  for (int i = threadIdx.x; i < nl; i += 256) {
+    lv[i] = ts->leaf_value[i];
+    lbuf[i] = ts->nodes[ts->leaf_nodes[i]].buf;
+  }
+  __syncthreads();
+  const uint32_t N = lb[nl];
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= N) return;
+  const int l = leaf_of_pos(lb, nl, p);
+  const int buf = lbuf[l];
+  const uint32_t id = buf == 2 ? p : (buf == 0 ? order0[p] : order1[p]);
+  const double add = shrinkage * lv[l];
+  scores[id] = scores[id] + add;
+}
+
+// mart.cc:447-457: validation scores by walking the tree on raw f32 rows
+__global__ __launch_bounds__(256) void k_valid_update(
+    const QrTreeState *__restrict__ ts, const float *__restrict__ raw,
+    const uint32_t vN, const uint32_t F, const double shrinkage,
+    double *__restrict__ vscores) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= vN) return;
+  const float *x = raw + (size_t)i * F;
+  int n = 0;
+  while (ts->nodes[n].feature >= 0)
+    n = x[ts->nodes[n].feature] <= ts->nodes[n].threshold ? ts->nodes[n].left
+                                                           : ts->nodes[n].right;
+  const double add = shrinkage * ts->nodes[n].value;
+  vscores[i] = vscores[i] + add;
+}
+
+// ===========================================================================
+// host launchers
+// ===========================================================================
+static size_t hist_lds(const qr_ctx *c) {
+  int fwmax = 16;
+  for (const auto &b : c->blocks) fwmax = b.fw > fwmax ? b.fw : fwmax;
+  return (size_t)256 * fwmax * 8;
+}
+
+static int launch_hist_scan(qr_ctx *c, int root_mode) {
+  const size_t lds = hist_lds(c);
+  static bool attr_done = false;
+  if (!attr_done) {
+    QR_CHECK(c, hipFuncSetAttribute((const void *)k_hist,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 256));
+    attr_done = true;
+  }
+  const int G = c->ncu;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool prof = c->prof_on && root_mode;
+  if (prof) {
+    QR_CHECK(c, hipEventCreate(&e0));
+    QR_CHECK(c, hipEventCreate(&e1));
+    QR_CHECK(c, hipEventRecord(e0, c->stream));
+  }
+  hipLaunchKernelGGL(k_hist, dim3(G), dim3(1024), lds, c->stream, c->d_tree,
+                     root_mode, (uint32_t)c->N, c->d_blocks, c->nblocks, c->d_bins,
+                     c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars,
+                     (u64 *)c->d_partials);
+  QR_CHECK(c, hipGetLastError());
+  if (prof) {
+    QR_CHECK(c, hipEventRecord(e1, c->stream));
+    c->prof_events.push_back({e0, e1});
+  }
+  hipLaunchKernelGGL(k_scan, dim3(c->flocal), dim3(256), 0, c->stream, c->d_tree,
+                     root_mode, (uint32_t)c->N, c->d_blocks, c->nblocks, G,
+                     (const u64 *)c->d_partials, c->d_hsum, c->d_hcnt, c->flocal,
+                     c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_merge, dim3(1), dim3(64), 0, c->stream, c->d_tree, root_mode,
+                     c->d_featrec, c->flocal, c->d_hsum, c->d_hcnt, c->d_gf2lf,
+                     c->d_recs_local);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+__global__ void k_tree_reset(QrTreeState *ts, int nleaves, u64 minls) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ts->nleaves_req = nleaves;
+  ts->nnodes = 0;
+  ts->taken = 0;
+  ts->done = 0;
+  ts->step = 0;
+  ts->nsplits = 0;
+  ts->minls = minls;
+  ts->heap_size = 0;
+  ts->desc.active = 0;
+  ts->nleaves = 0;
+}
+
+int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
+  hipLaunchKernelGGL(k_tree_reset, dim3(1), dim3(64), 0, c->stream, c->d_tree,
+                     (int)nleaves, (u64)minls);
+  QR_CHECK(c, hipGetLastError());
+  return launch_hist_scan(c, 1);
+}
+
+int qr_k_tree_decide(qr_ctx *c) {
+  const qr_split_t *recs = c->world > 1 ? c->d_recs_all : c->d_recs_local;
+  hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_tree,
+                     (uint32_t)c->N, c->flocal, c->d_hsum, recs, c->world,
+                     c->d_scalars, c->d_part_ss, c->d_thr, c->d_gf2lf);
+  QR_CHECK(c, hipGetLastError());
+  if (c->world > 1) {
+    const unsigned grid = (unsigned)((c->mask_words + 255) / 256);
+    hipLaunchKernelGGL(k_mask, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
+                       c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
+                       c->d_order[1], c->d_mask, (uint32_t)c->mask_words);
+    QR_CHECK(c, hipGetLastError());
+  }
+  return QR_OK;
+}
+
+int qr_k_tree_apply(qr_ctx *c) {
+  const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
+  const int use_mask = c->world > 1;
+  hipLaunchKernelGGL(k_part_count, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
+                     c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
+                     c->d_order[1], c->d_mask, use_mask, c->d_blkcnt);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_part_scatter, dim3(pgrid), dim3(256), 0, c->stream,
+                     c->d_tree, c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
+                     c->d_order[1], c->d_mask, use_mask, c->d_blkcnt, c->d_lambda,
+                     c->d_part_ss);
+  QR_CHECK(c, hipGetLastError());
+  return launch_hist_scan(c, 0);
+}
+
+int qr_k_tree_finish(qr_ctx *c, int newton) {
+  const unsigned sgrid = (unsigned)((c->N + QR_SLICE - 1) / QR_SLICE);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, c->stream, c->d_tree);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_leaf_sums, dim3(sgrid), dim3(256), 0, c->stream, c->d_tree,
+                     c->d_order[0], c->d_order[1], c->d_lambda,
+                     newton ? c->d_weight : (const double *)nullptr, c->d_leafpart);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_leaf_final, dim3(1), dim3(256), 0, c->stream, c->d_tree,
+                     c->d_leafpart, newton);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+int qr_k_scores_update(qr_ctx *c, double shrinkage) {
+  const unsigned grid = (unsigned)((c->N + 255) / 256);
+  hipLaunchKernelGGL(k_score_update, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
+                     c->d_order[0], c->d_order[1], shrinkage, c->d_scores);
+  QR_CHECK(c, hipGetLastError());
+  if (c->vN) {
+    const unsigned vgrid = (unsigned)((c->vN + 255) / 256);
+    hipLaunchKernelGGL(k_valid_update, dim3(vgrid), dim3(256), 0, c->stream,
+                       c->d_tree, c->d_vraw, (uint32_t)c->vN, (uint32_t)c->F,
+                       shrinkage, c->d_vscores);
+    QR_CHECK(c, hipGetLastError());
+  }
+  return QR_OK;
+}

@@ -1,0 +1,798 @@
+// qr_api.hip -- implementation of the C-ABI declared in include/qr_hip.h:
+// device memory management, the (tiny) host-side arithmetic of Mart::init
+// (mart.cc:147-169) and Ndcg::compute_idcg (ndcg.cc:35-47), and the launch
+// sequences.  No CPU fallback: every compute entry point needs the gfx950
+// device the context was created on.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+#include "qr_internal.h"
+
+static thread_local std::string g_create_err;
+
+template <class T>
+static hipError_t dalloc(T **p, size_t n) {
+  return hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
+}
+template <class T>
+static void dfree(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+extern "C" {
+
+int qr_ctx_create(int device, qr_ctx **out) {
+  if (out) *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    g_create_err = "no HIP device visible (this library has no CPU fallback)";
+    return QR_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) {
+    g_create_err = "device index out of range";
+    return QR_ERR_ARG;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_create_err = "hipSetDevice failed";
+    return QR_ERR_HIP;
+  }
+  qr_ctx *c = new qr_ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (hipStreamCreate(&c->stream) != hipSuccess) {
+    delete c;
+    g_create_err = "hipStreamCreate failed";
+    return QR_ERR_HIP;
+  }
+  c->own_stream = true;
+  if (dalloc(&c->d_scalars, 1) != hipSuccess) {
+    delete c;
+    g_create_err = "hipMalloc failed";
+    return QR_ERR_HIP;
+  }
+  (void)hipMemset(c->d_scalars, 0, sizeof(QrScalars));
+  *out = c;
+  return QR_OK;
+}
+
+static void free_train(qr_ctx *c) {
+  dfree(c->d_raw); dfree(c->d_labels); dfree(c->d_qoff);
+  dfree(c->d_scores); dfree(c->d_lambda); dfree(c->d_weight);
+  dfree(c->d_idcg); dfree(c->d_qmetric); dfree(c->d_ranks); dfree(c->d_ssq);
+  dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins);
+  dfree(c->d_thr); dfree(c->d_thr_size);
+  dfree(c->d_order[0]); dfree(c->d_order[1]); dfree(c->d_partials);
+  dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec);
+  dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
+  dfree(c->d_blkcnt); dfree(c->d_part_ss); dfree(c->d_tree); dfree(c->d_leafpart);
+  c->binned = false;
+  c->tree_valid = false;
+  c->hist_slots = 0;
+}
+static void free_valid(qr_ctx *c) {
+  dfree(c->d_vraw); dfree(c->d_vlabels); dfree(c->d_vqoff); dfree(c->d_vscores);
+  dfree(c->d_vidcg); dfree(c->d_vqmetric);
+  c->vN = c->vQ = 0;
+}
+
+void qr_ctx_destroy(qr_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_train(c);
+  free_valid(c);
+  dfree(c->d_lg2); dfree(c->d_scalars); dfree(c->d_ens); dfree(c->d_ens_w);
+  for (auto &p : c->prof_events) {
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *qr_last_error(const qr_ctx *c) {
+  return c ? c->err.c_str() : g_create_err.c_str();
+}
+
+int qr_ctx_set_stream(qr_ctx *c, void *s) {
+  if (!c) return QR_ERR_ARG;
+  (void)hipStreamSynchronize(c->stream);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  c->stream = (hipStream_t)s;
+  c->own_stream = false;
+  return QR_OK;
+}
+
+int qr_ctx_set_shard(qr_ctx *c, int rank, int world) {
+  if (!c) return QR_ERR_ARG;
+  if (world < 1 || rank < 0 || rank >= world) QR_FAIL(c, QR_ERR_ARG, "bad rank/world");
+  if (c->binned) QR_FAIL(c, QR_ERR_STATE, "qr_ctx_set_shard must precede qr_bins_build");
+  c->rank = rank;
+  c->world = world;
+  return QR_OK;
+}
+
+int qr_synchronize(qr_ctx *c) {
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  return QR_OK;
+}
+
+// ---------------------------------------------------------------------------
+static int upload_queries(qr_ctx *c, const uint64_t *qoff, size_t Q, size_t N,
+                          uint32_t **d_qoff, size_t *maxq) {
+  std::vector<uint32_t> q32(Q + 1);
+  size_t mq = 0;
+  for (size_t i = 0; i <= Q; ++i) {
+    if (qoff[i] > N || (i && qoff[i] < qoff[i - 1]))
+      QR_FAIL(c, QR_ERR_ARG, "query offsets must be non-decreasing and <= N");
+    q32[i] = (uint32_t)qoff[i];
+    if (i) mq = std::max(mq, (size_t)(qoff[i] - qoff[i - 1]));
+  }
+  if (Q && (qoff[0] != 0 || qoff[Q] != N))
+    QR_FAIL(c, QR_ERR_ARG, "query offsets must span [0, N]");
+  QR_CHECK(c, dalloc(d_qoff, Q + 1));
+  QR_CHECK(c, hipMemcpy(*d_qoff, q32.data(), (Q + 1) * 4, hipMemcpyHostToDevice));
+  *maxq = mq;
+  return QR_OK;
+}
+
+static int ensure_lg2(qr_ctx *c) {
+  const size_t need = std::max(c->maxq, c->vmaxq) + 2;
+  if (need <= c->lg2_len) return QR_OK;
+  std::vector<double> t(need);
+  // dcg.cc:37 forms (i + 2.0f) in f32 then promotes; ndcg.cc:79 uses
+  // (double)(j + 2): identical values while r + 2 < 2^24.
+  for (size_t r = 0; r < need; ++r) t[r] = log2((double)((float)r + 2.0f));
+  dfree(c->d_lg2);
+  QR_CHECK(c, dalloc(&c->d_lg2, need));
+  QR_CHECK(c, hipMemcpy(c->d_lg2, t.data(), need * 8, hipMemcpyHostToDevice));
+  c->lg2_len = need;
+  return QR_OK;
+}
+
+int qr_dataset_upload(qr_ctx *c, const float *x, size_t N, size_t F,
+                      const float *labels, const uint64_t *qoff, size_t Q) {
+  if (!c) return QR_ERR_ARG;
+  if (!x || !labels || !qoff || N == 0 || F == 0)
+    QR_FAIL(c, QR_ERR_ARG, "empty dataset");
+  if (N >= (1ull << 31)) QR_FAIL(c, QR_ERR_UNSUPPORTED, "N must be < 2^31");
+  if ((F + 63) / 64 > QR_MAXBLK * (size_t)c->world)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "too many features");
+  QR_CHECK(c, hipSetDevice(c->device));
+  free_train(c);
+  c->N = N; c->F = F; c->Q = Q;
+  QR_CHECK(c, dalloc(&c->d_raw, N * F));
+  QR_CHECK(c, hipMemcpy(c->d_raw, x, N * F * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, dalloc(&c->d_labels, N));
+  QR_CHECK(c, hipMemcpy(c->d_labels, labels, N * 4, hipMemcpyHostToDevice));
+  c->h_labels.assign(labels, labels + N);
+  c->h_qoff.assign(qoff, qoff + Q + 1);
+  int rc = upload_queries(c, qoff, Q, N, &c->d_qoff, &c->maxq);
+  if (rc) return rc;
+  QR_CHECK(c, dalloc(&c->d_scores, N));
+  QR_CHECK(c, dalloc(&c->d_lambda, N));
+  QR_CHECK(c, dalloc(&c->d_weight, N));
+  QR_CHECK(c, hipMemset(c->d_scores, 0, N * 8));
+  QR_CHECK(c, hipMemset(c->d_lambda, 0, N * 8));
+  QR_CHECK(c, hipMemset(c->d_weight, 0, N * 8));
+  QR_CHECK(c, dalloc(&c->d_idcg, Q));
+  QR_CHECK(c, dalloc(&c->d_qmetric, Q));
+  QR_CHECK(c, dalloc(&c->d_ranks, N));
+  QR_CHECK(c, dalloc(&c->d_ssq, std::max(Q, N / QR_SLICE + 2)));
+  c->idcg_metric = -1;
+  return ensure_lg2(c);
+}
+
+int qr_valid_upload(qr_ctx *c, const float *x, size_t N, const float *labels,
+                    const uint64_t *qoff, size_t Q) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->F) QR_FAIL(c, QR_ERR_STATE, "upload the training set first");
+  if (!x || !labels || !qoff || N == 0) QR_FAIL(c, QR_ERR_ARG, "empty validation set");
+  free_valid(c);
+  c->vN = N; c->vQ = Q;
+  QR_CHECK(c, dalloc(&c->d_vraw, N * c->F));
+  QR_CHECK(c, hipMemcpy(c->d_vraw, x, N * c->F * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, dalloc(&c->d_vlabels, N));
+  QR_CHECK(c, hipMemcpy(c->d_vlabels, labels, N * 4, hipMemcpyHostToDevice));
+  c->h_vlabels.assign(labels, labels + N);
+  c->h_vqoff.assign(qoff, qoff + Q + 1);
+  int rc = upload_queries(c, qoff, Q, N, &c->d_vqoff, &c->vmaxq);
+  if (rc) return rc;
+  QR_CHECK(c, dalloc(&c->d_vscores, N));
+  QR_CHECK(c, hipMemset(c->d_vscores, 0, N * 8));
+  QR_CHECK(c, dalloc(&c->d_vidcg, Q));
+  QR_CHECK(c, dalloc(&c->d_vqmetric, Q));
+  c->vidcg_metric = -1;
+  return ensure_lg2(c);
+}
+
+// ---------------------------------------------------------------------------
+static inline uint32_t h_flip(uint32_t x) {
+  return x ^ ((uint32_t)(-(int32_t)(x >> 31)) | 0x80000000u);
+}
+static inline uint32_t h_unflip(uint32_t x) {
+  return x ^ (((x >> 31) - 1) | 0x80000000u);
+}
+static inline float bits2f(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
+                  uint32_t *thr_size_out) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->d_raw) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
+  if (nthresholds > 255)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "the device path stores uint8 bins: nthresholds <= 255");
+  QR_CHECK(c, hipSetDevice(c->device));
+  const size_t N = c->N, F = c->F;
+  // ---- feature blocks owned by this rank
+  const size_t nglob = (F + 63) / 64;
+  c->blocks.clear();
+  c->h_gf2lf.assign(F, -1);
+  c->h_lf2gf.clear();
+  size_t off = 0;
+  int lf = 0;
+  for (size_t g = 0; g < nglob; ++g) {
+    if ((int)(g % (size_t)c->world) != c->rank) continue;
+    QrBlock b;
+    b.f0 = (int)(g * 64);
+    b.nreal = (int)std::min<size_t>(64, F - g * 64);
+    b.fw = (b.nreal + 15) / 16 * 16;
+    b.lf0 = lf;
+    b.off = off;
+    off += N * (size_t)b.fw;
+    off = (off + 255) & ~(size_t)255;
+    for (int i = 0; i < b.nreal; ++i) {
+      c->h_gf2lf[b.f0 + i] = lf + i;
+      c->h_lf2gf.push_back(b.f0 + i);
+    }
+    lf += b.nreal;
+    c->blocks.push_back(b);
+  }
+  c->nblocks = (int)c->blocks.size();
+  c->flocal = lf;
+  if (c->nblocks == 0) QR_FAIL(c, QR_ERR_ARG, "this rank owns no feature block (world > #blocks)");
+  if (c->nblocks > QR_MAXBLK) QR_FAIL(c, QR_ERR_UNSUPPORTED, "too many feature blocks");
+  c->bins_bytes = off;
+  // ---- distinct values / min / max per column
+  const uint32_t limit = (uint32_t)(nthresholds ? nthresholds + 1 : 256);
+  float *d_col = nullptr;
+  uint32_t *d_vals = nullptr, *d_cnt = nullptr, *d_mm = nullptr;
+  QR_CHECK(c, dalloc(&d_col, N * F));
+  QR_CHECK(c, dalloc(&d_vals, F * (size_t)(limit + 1)));
+  QR_CHECK(c, dalloc(&d_cnt, F));
+  QR_CHECK(c, dalloc(&d_mm, 2 * F));
+  int rc = qr_k_transpose(c, c->d_raw, d_col, N, F);
+  if (rc) return rc;
+  rc = qr_k_colstats(c, d_col, N, F, limit, d_vals, d_cnt, d_mm);
+  if (rc) return rc;
+  std::vector<uint32_t> vals(F * (size_t)(limit + 1)), cnt(F), mm(2 * F);
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(vals.data(), d_vals, vals.size() * 4, hipMemcpyDeviceToHost));
+  QR_CHECK(c, hipMemcpy(cnt.data(), d_cnt, F * 4, hipMemcpyDeviceToHost));
+  QR_CHECK(c, hipMemcpy(mm.data(), d_mm, 2 * F * 4, hipMemcpyDeviceToHost));
+  dfree(d_col); dfree(d_vals); dfree(d_cnt); dfree(d_mm);
+  // ---- thresholds: mart.cc:147-169 with the same f32 operations
+  c->h_thr.assign(F * QR_MAX_BINS, FLT_MAX);
+  c->h_thr_size.assign(F, 0);
+  for (size_t f = 0; f < F; ++f) {
+    float *out = &c->h_thr[f * QR_MAX_BINS];
+    bool equal_width = cnt[f] > limit;
+    std::vector<float> uniqs;
+    if (!equal_width) {
+      std::vector<uint32_t> keys(cnt[f]);
+      for (uint32_t i = 0; i < cnt[f]; ++i) keys[i] = h_flip(vals[f * (size_t)(limit + 1) + i]);
+      std::sort(keys.begin(), keys.end());  // radix order (radix.cc:28-30)
+      for (uint32_t k : keys) {
+        const float v = bits2f(h_unflip(k));
+        if (uniqs.empty() || uniqs.back() < v) uniqs.push_back(v);  // mart.cc:149-151
+      }
+      if (!(uniqs.size() <= nthresholds || nthresholds == 0)) equal_width = true;
+    }
+    if (!equal_width) {
+      if (uniqs.size() + 1 > QR_MAX_BINS)
+        QR_FAIL(c, QR_ERR_UNSUPPORTED,
+                "nthresholds == 0 with a feature of more than 255 distinct values");
+      for (size_t i = 0; i < uniqs.size(); ++i) out[i] = uniqs[i];
+      out[uniqs.size()] = FLT_MAX;
+      c->h_thr_size[f] = (uint32_t)uniqs.size() + 1;
+    } else {
+      if (nthresholds == 0)
+        QR_FAIL(c, QR_ERR_UNSUPPORTED,
+                "nthresholds == 0 with a feature of more than 255 distinct values");
+      const float fmin = bits2f(h_unflip(mm[2 * f]));
+      const float fmax = bits2f(h_unflip(mm[2 * f + 1]));
+      float t = fmin;
+      const float step = (float)fabs(fmax - t) / nthresholds;  // mart.cc:164-165
+      for (size_t j = 0; j != nthresholds; t += step) out[j++] = t;
+      out[nthresholds] = FLT_MAX;
+      c->h_thr_size[f] = (uint32_t)nthresholds + 1;
+    }
+  }
+  QR_CHECK(c, dalloc(&c->d_thr, F * QR_MAX_BINS));
+  QR_CHECK(c, dalloc(&c->d_thr_size, F));
+  QR_CHECK(c, hipMemcpy(c->d_thr, c->h_thr.data(), F * QR_MAX_BINS * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_thr_size, c->h_thr_size.data(), F * 4, hipMemcpyHostToDevice));
+  if (thr_out) memcpy(thr_out, c->h_thr.data(), F * QR_MAX_BINS * 4);
+  if (thr_size_out) memcpy(thr_size_out, c->h_thr_size.data(), F * 4);
+  // ---- bin map
+  QR_CHECK(c, dalloc(&c->d_bins, c->bins_bytes));
+  QR_CHECK(c, dalloc(&c->d_blocks, (size_t)c->nblocks));
+  QR_CHECK(c, hipMemcpy(c->d_blocks, c->blocks.data(), c->nblocks * sizeof(QrBlock), hipMemcpyHostToDevice));
+  QR_CHECK(c, dalloc(&c->d_lf2gf, (size_t)c->flocal));
+  QR_CHECK(c, dalloc(&c->d_gf2lf, F));
+  QR_CHECK(c, hipMemcpy(c->d_lf2gf, c->h_lf2gf.data(), c->flocal * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_gf2lf, c->h_gf2lf.data(), F * 4, hipMemcpyHostToDevice));
+  rc = qr_k_binning(c);
+  if (rc) return rc;
+  // ---- tree working set
+  QR_CHECK(c, dalloc(&c->d_order[0], N));
+  QR_CHECK(c, dalloc(&c->d_order[1], N));
+  QrPlan plan;
+  qr_make_plan((uint32_t)N, c->nblocks, c->blocks.data(), c->ncu, &plan);
+  c->partial_slots = (size_t)c->ncu * plan.kmax;
+  QR_CHECK(c, dalloc(&c->d_partials, c->partial_slots * 256 * 64));
+  QR_CHECK(c, dalloc(&c->d_featrec, 2 * (size_t)c->flocal));
+  QR_CHECK(c, dalloc(&c->d_recs_local, (size_t)2));
+  QR_CHECK(c, dalloc(&c->d_recs_all, 2 * (size_t)c->world));
+  c->mask_words = (N + 31) / 32;
+  QR_CHECK(c, dalloc(&c->d_mask, c->mask_words));
+  QR_CHECK(c, dalloc(&c->d_blkcnt, N / QR_PART_SLICE + 2));
+  QR_CHECK(c, dalloc(&c->d_part_ss, N / QR_PART_SLICE + 2));
+  QR_CHECK(c, dalloc(&c->d_tree, (size_t)1));
+  QR_CHECK(c, hipMemset(c->d_tree, 0, sizeof(QrTreeState)));
+  QR_CHECK(c, dalloc(&c->d_leafpart, 2 * (N / QR_SLICE + QR_MAXNODES + 4)));
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  c->binned = true;
+  return QR_OK;
+}
+
+int qr_bins_read(qr_ctx *c, uint8_t *out) {
+  if (!c || !out) return QR_ERR_ARG;
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  std::vector<uint8_t> h(c->bins_bytes);
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(h.data(), c->d_bins, c->bins_bytes, hipMemcpyDeviceToHost));
+  memset(out, 0xFF, c->N * c->F);
+  for (const QrBlock &b : c->blocks)
+    for (size_t d = 0; d < c->N; ++d)
+      for (int i = 0; i < b.nreal; ++i)
+        out[d * c->F + b.f0 + i] = h[b.off + d * (size_t)b.fw + i];
+  return QR_OK;
+}
+
+// ---------------------------------------------------------------------------
+int qr_scores_reset(qr_ctx *c) {
+  if (!c || !c->d_scores) return QR_ERR_STATE;
+  QR_CHECK(c, hipMemsetAsync(c->d_scores, 0, c->N * 8, c->stream));
+  if (c->d_vscores) QR_CHECK(c, hipMemsetAsync(c->d_vscores, 0, c->vN * 8, c->stream));
+  return QR_OK;
+}
+int qr_scores_set(qr_ctx *c, const double *s) {
+  if (!c || !c->d_scores || !s) return QR_ERR_ARG;
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(c->d_scores, s, c->N * 8, hipMemcpyHostToDevice));
+  return QR_OK;
+}
+int qr_scores_get(qr_ctx *c, double *s) {
+  if (!c || !c->d_scores || !s) return QR_ERR_ARG;
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(s, c->d_scores, c->N * 8, hipMemcpyDeviceToHost));
+  return QR_OK;
+}
+int qr_valid_scores_get(qr_ctx *c, double *s) {
+  if (!c || !c->d_vscores || !s) return QR_ERR_ARG;
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(s, c->d_vscores, c->vN * 8, hipMemcpyDeviceToHost));
+  return QR_OK;
+}
+int qr_pseudo_get(qr_ctx *c, double *l, double *w) {
+  if (!c || !c->d_lambda) return QR_ERR_ARG;
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  if (l) QR_CHECK(c, hipMemcpy(l, c->d_lambda, c->N * 8, hipMemcpyDeviceToHost));
+  if (w) QR_CHECK(c, hipMemcpy(w, c->d_weight, c->N * 8, hipMemcpyDeviceToHost));
+  return QR_OK;
+}
+
+// host side of the scale derivation for caller-supplied pseudo-responses
+int qr_pseudo_set(qr_ctx *c, const double *l, const double *w) {
+  if (!c || !c->d_lambda || !l) return QR_ERR_ARG;
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(c->d_lambda, l, c->N * 8, hipMemcpyHostToDevice));
+  if (w) QR_CHECK(c, hipMemcpy(c->d_weight, w, c->N * 8, hipMemcpyHostToDevice));
+  // maxabs + per-slice sum of squares with the same kernels' conventions:
+  // reuse k_residual's reduction by computing on the host what it would write
+  double mx = 0.0;
+  const size_t ns = (c->N + QR_SLICE - 1) / QR_SLICE;
+  std::vector<double> ssq(ns, 0.0);
+  for (size_t i = 0; i < c->N; ++i) {
+    mx = std::max(mx, std::fabs(l[i]));
+    ssq[i / QR_SLICE] += l[i] * l[i];
+  }
+  QrScalars s;
+  QR_CHECK(c, hipMemcpy(&s, c->d_scalars, sizeof(s), hipMemcpyDeviceToHost));
+  memcpy(&s.maxabs_bits, &mx, 8);
+  QR_CHECK(c, hipMemcpy(c->d_scalars, &s, sizeof(s), hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_ssq, ssq.data(), ns * 8, hipMemcpyHostToDevice));
+  return qr_k_prep(c, ns);
+}
+
+// ---------------------------------------------------------------------------
+// Ndcg::compute_idcg (ndcg.cc:35-47) per query: labels sorted with
+// std::greater<int> (the same libstdc++ std::sort the reference calls), then
+// Dcg::compute_dcg (dcg.cc:33-39).  Labels never change, so this runs once per
+// (metric, cutoff) on the host and is uploaded.
+static void host_idcg(const std::vector<float> &labels, const std::vector<uint64_t> &qoff,
+                      size_t cutoff, std::vector<double> &out) {
+  const size_t Q = qoff.size() - 1;
+  out.assign(Q, 0.0);
+  const size_t k = cutoff == 0 ? SIZE_MAX : cutoff;
+  std::vector<float> copy;
+  for (size_t q = 0; q < Q; ++q) {
+    const size_t n = qoff[q + 1] - qoff[q];
+    copy.assign(labels.begin() + qoff[q], labels.begin() + qoff[q + 1]);
+    std::sort(copy.begin(), copy.end(), std::greater<int>());
+    const size_t size = std::min(k, n);
+    double dcg = 0.0;
+    for (size_t i = 0; i < size; ++i)
+      dcg += (pow(2.0, (double)copy[i]) - 1.0f) / log2((double)((float)i + 2.0f));
+    out[q] = dcg;
+  }
+}
+
+static int ensure_idcg(qr_ctx *c, int which, int metric, size_t cutoff) {
+  if (metric != QR_METRIC_NDCG) return QR_OK;
+  int &m = which ? c->vidcg_metric : c->idcg_metric;
+  size_t &k = which ? c->vidcg_cutoff : c->idcg_cutoff;
+  if (m == metric && k == cutoff) return QR_OK;
+  std::vector<double> v;
+  host_idcg(which ? c->h_vlabels : c->h_labels, which ? c->h_vqoff : c->h_qoff, cutoff, v);
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(which ? c->d_vidcg : c->d_idcg, v.data(), v.size() * 8, hipMemcpyHostToDevice));
+  m = metric;
+  k = cutoff;
+  return QR_OK;
+}
+
+int qr_lambda_compute(qr_ctx *c, int metric, size_t cutoff) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->d_scores) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
+  if (metric != QR_METRIC_NDCG && metric != QR_METRIC_DCG)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "metric must be DCG or NDCG");
+  int rc = ensure_idcg(c, 0, metric, cutoff);
+  if (rc) return rc;
+  QR_CHECK(c, hipMemsetAsync(&c->d_scalars->maxabs_bits, 0, 8, c->stream));
+  rc = qr_k_lambda(c, 0, metric, cutoff, 0);
+  if (rc) return rc;
+  return qr_k_prep(c, c->Q);
+}
+
+int qr_residual_compute(qr_ctx *c) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->d_scores) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
+  QR_CHECK(c, hipMemsetAsync(&c->d_scalars->maxabs_bits, 0, 8, c->stream));
+  int rc = qr_k_residual(c);
+  if (rc) return rc;
+  return qr_k_prep(c, (c->N + QR_SLICE - 1) / QR_SLICE);
+}
+
+static int metric_finish(qr_ctx *c, int which, double *out) {
+  int rc = qr_k_metric_reduce(c, which);
+  if (rc) return rc;
+  QrScalars s;
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(&s, c->d_scalars, sizeof(s), hipMemcpyDeviceToHost));
+  const size_t Q = which ? c->vQ : c->Q;
+  // metric.h:93-105: avg_score /= num_queries (0 queries -> 0.0)
+  *out = Q ? s.metric_sum / (double)Q : 0.0;
+  return QR_OK;
+}
+
+int qr_metric_eval(qr_ctx *c, int which, int metric, size_t cutoff, double *out) {
+  if (!c || !out) return QR_ERR_ARG;
+  if (which ? !c->d_vscores : !c->d_scores) QR_FAIL(c, QR_ERR_STATE, "dataset not uploaded");
+  int rc = ensure_idcg(c, which, metric, cutoff);
+  if (rc) return rc;
+  rc = qr_k_lambda(c, which, metric, cutoff, 1);
+  if (rc) return rc;
+  return metric_finish(c, which, out);
+}
+
+int qr_metric_last(qr_ctx *c, double *out) {
+  if (!c || !out) return QR_ERR_ARG;
+  return metric_finish(c, 0, out);
+}
+
+// ---------------------------------------------------------------------------
+static int ensure_hist_slots(qr_ctx *c, size_t slots) {
+  if (slots <= c->hist_slots) return QR_OK;
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  dfree(c->d_hsum);
+  dfree(c->d_hcnt);
+  QR_CHECK(c, dalloc(&c->d_hsum, slots * c->flocal * 256));
+  QR_CHECK(c, dalloc(&c->d_hcnt, slots * c->flocal * 256));
+  c->hist_slots = slots;
+  return QR_OK;
+}
+
+static void copy_nodes(const QrTreeState &ts, qr_node_t *out, size_t *n_out) {
+  for (int i = 0; i < ts.nnodes; ++i) {
+    const QrNode &s = ts.nodes[i];
+    qr_node_t &d = out[i];
+    d.feature = s.feature;
+    d.thr_id = s.thr_id;
+    d.threshold = s.threshold;
+    d.left = s.left;
+    d.right = s.right;
+    d.value = s.value;
+    d.deviance = s.deviance;
+    d.nsamples = s.count;
+  }
+  if (n_out) *n_out = (size_t)ts.nnodes;
+}
+
+int qr_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  if (nleaves < 1 || 2 * nleaves + 1 > QR_MAXNODES)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "nleaves must be in [1, 511]");
+  int rc = ensure_hist_slots(c, 2 * nleaves + 1);
+  if (rc) return rc;
+  c->cur_nleaves = nleaves;
+  c->tree_open = true;
+  c->tree_valid = false;
+  return qr_k_tree_begin(c, nleaves, minls);
+}
+
+int qr_tree_decide(qr_ctx *c) {
+  if (!c || !c->tree_open) return QR_ERR_STATE;
+  return qr_k_tree_decide(c);
+}
+
+int qr_tree_apply(qr_ctx *c) {
+  if (!c || !c->tree_open) return QR_ERR_STATE;
+  return qr_k_tree_apply(c);
+}
+
+int qr_tree_end(qr_ctx *c, int newton, qr_node_t *nodes_out, size_t *nnodes_out) {
+  if (!c || !c->tree_open) return QR_ERR_STATE;
+  int rc = qr_k_tree_finish(c, newton);
+  if (rc) return rc;
+  c->tree_open = false;
+  c->tree_valid = true;
+  if (nodes_out) {
+    std::vector<char> buf(sizeof(QrTreeState));
+    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    QR_CHECK(c, hipMemcpy(buf.data(), c->d_tree, offsetof(QrTreeState, split_log), hipMemcpyDeviceToHost));
+    copy_nodes(*reinterpret_cast<QrTreeState *>(buf.data()), nodes_out, nnodes_out);
+  }
+  return QR_OK;
+}
+
+int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
+                qr_node_t *nodes_out, size_t *nnodes_out) {
+  if (!c) return QR_ERR_ARG;
+  if (c->world > 1)
+    QR_FAIL(c, QR_ERR_STATE,
+            "feature-sharded contexts must drive qr_tree_begin/decide/apply/end "
+            "with the collectives in between");
+  int rc = qr_tree_begin(c, nleaves, minls);
+  if (rc) return rc;
+  for (size_t s = 0; s + 1 < nleaves; ++s) {
+    if ((rc = qr_k_tree_decide(c))) return rc;
+    if ((rc = qr_k_tree_apply(c))) return rc;
+  }
+  if ((rc = qr_k_tree_decide(c))) return rc;
+  return qr_tree_end(c, newton, nodes_out, nnodes_out);
+}
+
+int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
+                     qr_node_t *nodes_out, size_t *nnodes_out) {
+  if (!c) return QR_ERR_ARG;
+  (void)depth; (void)minls; (void)newton; (void)nodes_out; (void)nnodes_out;
+  QR_FAIL(c, QR_ERR_UNSUPPORTED, "oblivious trees: not implemented in this round");
+}
+
+int qr_scores_update(qr_ctx *c, double shrinkage) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->tree_valid) QR_FAIL(c, QR_ERR_STATE, "no fitted tree");
+  return qr_k_scores_update(c, shrinkage);
+}
+
+int qr_exchange_buffers(qr_ctx *c, void **recs_local, void **recs_all,
+                        size_t *rec_bytes_per_rank, void **mask, size_t *mask_bytes) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  if (recs_local) *recs_local = c->d_recs_local;
+  if (recs_all) *recs_all = c->d_recs_all;
+  if (rec_bytes_per_rank) *rec_bytes_per_rank = 2 * sizeof(qr_split_t);
+  if (mask) *mask = c->d_mask;
+  if (mask_bytes) *mask_bytes = c->mask_words * 4;
+  return QR_OK;
+}
+
+// ---------------------------------------------------------------------------
+static int read_tree(qr_ctx *c, std::vector<char> &buf) {
+  if (!c->tree_valid) QR_FAIL(c, QR_ERR_STATE, "no fitted tree");
+  buf.resize(sizeof(QrTreeState));
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(buf.data(), c->d_tree, sizeof(QrTreeState), hipMemcpyDeviceToHost));
+  return QR_OK;
+}
+
+int qr_node_hist_read(qr_ctx *c, int node, double *sum_out, uint64_t *count_out) {
+  if (!c) return QR_ERR_ARG;
+  std::vector<char> buf;
+  int rc = read_tree(c, buf);
+  if (rc) return rc;
+  const QrTreeState &ts = *reinterpret_cast<QrTreeState *>(buf.data());
+  if (node < 0 || node >= ts.nnodes) QR_FAIL(c, QR_ERR_ARG, "node out of range");
+  QrScalars s;
+  QR_CHECK(c, hipMemcpy(&s, c->d_scalars, sizeof(s), hipMemcpyDeviceToHost));
+  const size_t n = (size_t)c->flocal * 256;
+  std::vector<long long> hs(n);
+  std::vector<uint32_t> hc(n);
+  const size_t slot = (size_t)ts.nodes[node].hslot;
+  QR_CHECK(c, hipMemcpy(hs.data(), c->d_hsum + slot * n, n * 8, hipMemcpyDeviceToHost));
+  QR_CHECK(c, hipMemcpy(hc.data(), c->d_hcnt + slot * n, n * 4, hipMemcpyDeviceToHost));
+  if (sum_out) memset(sum_out, 0, c->F * 256 * 8);
+  if (count_out) memset(count_out, 0, c->F * 256 * 8);
+  for (int lf = 0; lf < c->flocal; ++lf) {
+    const size_t gf = (size_t)c->h_lf2gf[lf];
+    for (int t = 0; t < 256; ++t) {
+      if (sum_out) sum_out[gf * 256 + t] = (double)hs[(size_t)lf * 256 + t] * s.inv_scale;
+      if (count_out) count_out[gf * 256 + t] = hc[(size_t)lf * 256 + t];
+    }
+  }
+  return QR_OK;
+}
+
+int qr_node_samples_read(qr_ctx *c, int node, uint32_t *ids_out, size_t *n_out) {
+  if (!c) return QR_ERR_ARG;
+  std::vector<char> buf;
+  int rc = read_tree(c, buf);
+  if (rc) return rc;
+  const QrTreeState &ts = *reinterpret_cast<QrTreeState *>(buf.data());
+  if (node < 0 || node >= ts.nnodes) QR_FAIL(c, QR_ERR_ARG, "node out of range");
+  const QrNode &nd = ts.nodes[node];
+  const size_t n = nd.end - nd.begin;
+  if (n_out) *n_out = n;
+  if (!ids_out) return QR_OK;
+  if (nd.buf == 2) {
+    for (size_t i = 0; i < n; ++i) ids_out[i] = (uint32_t)(nd.begin + i);
+  } else {
+    QR_CHECK(c, hipMemcpy(ids_out, c->d_order[nd.buf] + nd.begin, n * 4, hipMemcpyDeviceToHost));
+  }
+  return QR_OK;
+}
+
+int qr_tree_split_log(qr_ctx *c, qr_split_t *out, size_t *n_out) {
+  if (!c) return QR_ERR_ARG;
+  std::vector<char> buf;
+  int rc = read_tree(c, buf);
+  if (rc) return rc;
+  const QrTreeState &ts = *reinterpret_cast<QrTreeState *>(buf.data());
+  if (n_out) *n_out = (size_t)ts.nsplits;
+  if (out) memcpy(out, ts.split_log, ts.nsplits * sizeof(qr_split_t));
+  return QR_OK;
+}
+
+int qr_metric_per_query(qr_ctx *c, double *out) {
+  if (!c || !out || !c->d_qmetric) return QR_ERR_ARG;
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(out, c->d_qmetric, c->Q * 8, hipMemcpyDeviceToHost));
+  return QR_OK;
+}
+
+int qr_ranks_read(qr_ctx *c, uint32_t *out) {
+  if (!c || !out || !c->d_ranks) return QR_ERR_ARG;
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(out, c->d_ranks, c->N * 4, hipMemcpyDeviceToHost));
+  return QR_OK;
+}
+
+// ---------------------------------------------------------------------------
+int qr_ensemble_upload(qr_ctx *c, const qr_node_t *nodes, size_t ntrees,
+                       size_t max_nodes, const double *weights) {
+  if (!c || !nodes || !weights || !ntrees || !max_nodes) return QR_ERR_ARG;
+  QR_CHECK(c, hipSetDevice(c->device));
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  dfree(c->d_ens);
+  dfree(c->d_ens_w);
+  QR_CHECK(c, dalloc(&c->d_ens, ntrees * max_nodes));
+  QR_CHECK(c, dalloc(&c->d_ens_w, ntrees));
+  QR_CHECK(c, hipMemcpy(c->d_ens, nodes, ntrees * max_nodes * sizeof(qr_node_t), hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_ens_w, weights, ntrees * 8, hipMemcpyHostToDevice));
+  c->ens_trees = ntrees;
+  c->ens_maxnodes = max_nodes;
+  return QR_OK;
+}
+
+int qr_ensemble_score_device(qr_ctx *c, const void *d_x, size_t N, size_t F, void *d_out) {
+  if (!c || !d_x || !d_out) return QR_ERR_ARG;
+  return qr_k_ensemble_score(c, (const float *)d_x, N, F, (double *)d_out);
+}
+
+int qr_ensemble_score(qr_ctx *c, const float *x, size_t N, size_t F, double *out,
+                      float *kernel_ms) {
+  if (!c || !x || !out || !N || !F) return QR_ERR_ARG;
+  float *d_x = nullptr;
+  double *d_o = nullptr;
+  QR_CHECK(c, dalloc(&d_x, N * F));
+  QR_CHECK(c, dalloc(&d_o, N));
+  QR_CHECK(c, hipMemcpy(d_x, x, N * F * 4, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  QR_CHECK(c, hipEventCreate(&e0));
+  QR_CHECK(c, hipEventCreate(&e1));
+  QR_CHECK(c, hipEventRecord(e0, c->stream));
+  int rc = qr_k_ensemble_score(c, d_x, N, F, d_o);
+  QR_CHECK(c, hipEventRecord(e1, c->stream));
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  if (!rc) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (kernel_ms) *kernel_ms = ms;
+    QR_CHECK(c, hipMemcpy(out, d_o, N * 8, hipMemcpyDeviceToHost));
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  dfree(d_x);
+  dfree(d_o);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+int qr_prof_enable(qr_ctx *c, int on) {
+  if (!c) return QR_ERR_ARG;
+  c->prof_on = on != 0;
+  return QR_OK;
+}
+
+static int prof_drain(qr_ctx *c) {
+  if (c->prof_events.empty()) return QR_OK;
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  for (auto &p : c->prof_events) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+      c->prof_ms += ms;
+      c->prof_launches++;
+    }
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  c->prof_events.clear();
+  return QR_OK;
+}
+
+int qr_prof_reset(qr_ctx *c) {
+  if (!c) return QR_ERR_ARG;
+  int rc = prof_drain(c);
+  c->prof_ms = 0;
+  c->prof_launches = 0;
+  return rc;
+}
+
+int qr_prof_get(qr_ctx *c, uint64_t *launches, double *total_ms, double *alg_bytes) {
+  if (!c) return QR_ERR_ARG;
+  int rc = prof_drain(c);
+  if (rc) return rc;
+  if (launches) *launches = c->prof_launches;
+  if (total_ms) *total_ms = c->prof_ms;
+  // n*F_loc (uint8 bins) + n*8 (f64 gradient, once) +
+  // F_loc*256*16 (result); no sample ids at the root.
+  if (alg_bytes)
+    *alg_bytes = (double)c->N * c->flocal + (double)c->N * 8 + (double)c->flocal * 256 * 16;
+  return QR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// qr_internal.h -- shared declarations of the gfx950 device layer (not part of
+// the C-ABI; see include/qr_hip.h for the boundary).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/qr_hip.h"
+
+// ---------------------------------------------------------------------------
+// Fixed-point histogram accumulators.
+// A (feature, bin) cell of a workgroup's LDS histogram is ONE u64:
+//     cell = count * 2^QR_SB + sum_q        (sum_q signed, two's complement)
+// where sum_q = sum of q_d = rint(lambda_d * 2^scale_exp), |q_d| < 2^33.
+// A workgroup flushes after at most QR_DPW docs, so count < 2^15 and
+// |sum_q| < 2^47: one ds_add_u64 per (doc, feature) carries gradient and count.
+// Integer sums are associative => any accumulation order gives identical bits
+// (deterministic, and structural ties between split candidates are preserved
+// exactly -- SURVEY.md section 7 hard part 1).
+// ---------------------------------------------------------------------------
+#define QR_SB 49
+#define QR_DPW 16384u     /* docs per workgroup between flushes              */
+#define QR_QBITS 33       /* |q| < 2^33                                      */
+#define QR_SLICE 1024u    /* doc-range alignment of hist workgroups          */
+#define QR_MAXBLK 64      /* max 64-feature blocks per rank (F <= 4096)      */
+#define QR_PART_SLICE 2048u /* positions per partition workgroup             */
+
+struct QrBlock {
+  int f0;        // first global feature
+  int fw;        // padded width: 16,32,48,64
+  int nreal;     // real features in the block
+  int lf0;       // first local feature index
+  size_t off;    // byte offset of the block's [N][fw] u8 matrix in d_bins
+};
+
+// Work plan of one histogram launch: which workgroups serve which block.
+struct alignas(16) QrPlan {
+  int wg_start[QR_MAXBLK + 1];
+  uint32_t per[QR_MAXBLK];  // docs per workgroup (multiple of QR_SLICE)
+  int kmax;                 // flushes per workgroup
+  int pad[2];               // sizeof == 528: keeps the dynamic-LDS base 16-B aligned
+};
+
+__host__ __device__ inline void qr_make_plan(uint32_t n, int nblocks,
+                                             const QrBlock *blk, int G,
+                                             QrPlan *p) {
+  int wsum = 0;
+  for (int b = 0; b < nblocks; ++b) wsum += blk[b].fw / 16;
+  p->wg_start[0] = 0;
+  p->kmax = 1;
+  for (int b = 0; b < nblocks; ++b) {
+    int W = G * (blk[b].fw / 16) / wsum;
+    if (W < 1) W = 1;
+    uint32_t per = (n + W - 1) / W;
+    per = (per + QR_SLICE - 1) / QR_SLICE * QR_SLICE;
+    if (per == 0) per = QR_SLICE;
+    int weff = (int)((n + per - 1) / per);
+    p->per[b] = per;
+    p->wg_start[b + 1] = p->wg_start[b] + weff;
+    int k = (int)((per + QR_DPW - 1) / QR_DPW);
+    if (k > p->kmax) p->kmax = k;
+  }
+}
+
+// Node bookkeeping of the tree under construction (device resident).
+struct QrNode {
+  uint32_t begin, end;   // segment of positions in the order buffers
+  int32_t buf;           // 0 = order A, 1 = order B, 2 = identity (root)
+  int32_t hslot;         // histogram slot
+  int32_t feature, thr_id;
+  float threshold;
+  int32_t left, right, parent;
+  double sum, ss, deviance, value;
+  uint64_t count;
+  // best split of this node (merged over all features / ranks)
+  double best_score;
+  uint32_t best_f, best_t;
+  uint64_t best_lc, best_rc;
+  int32_t leaf_id;       // DFS leaf index, -1 for internal
+  int32_t pad;
+};
+
+struct QrHeapItem {
+  double key;
+  int32_t val;
+  int32_t pad;
+};
+
+#define QR_MAXNODES 1024
+
+// Descriptor of the split being applied; written by the control kernel and
+// consumed by the partition / histogram / scan kernels of the same step.
+struct QrSplitDesc {
+  int32_t active;          // 0 = nothing to do this step (tree finished)
+  int32_t node, left, right;
+  uint32_t begin, end;     // parent segment
+  int32_t src_buf;         // buffer holding the parent segment
+  int32_t dst_buf;
+  uint32_t lcount, rcount;
+  uint32_t feature, thr_id;  // global feature
+  int32_t owner_local;     // local feature index on this rank, -1 if not owned
+  int32_t small_is_left;
+  // histogram work: direct build of `small`, sibling = parent - small
+  int32_t small_node, big_node;
+  int32_t parent_slot, small_slot, big_slot;
+  uint32_t small_begin, small_n;
+  int32_t pad;
+};
+
+struct QrTreeState {
+  int32_t nleaves_req;
+  int32_t nnodes;
+  int32_t taken;
+  int32_t done;
+  int32_t step;
+  int32_t nsplits;
+  uint64_t minls;
+  int32_t heap_size;
+  int32_t pad;
+  QrHeapItem heap[QR_MAXNODES + 2];
+  QrNode nodes[QR_MAXNODES];
+  qr_split_t split_log[QR_MAXNODES];
+  QrSplitDesc desc;
+  // leaves in DFS order
+  int32_t nleaves;
+  int32_t leaf_nodes[QR_MAXNODES];
+  uint32_t leaf_begin[QR_MAXNODES + 1];  // sorted by position
+  int32_t leaf_at[QR_MAXNODES];          // node index per position-sorted leaf
+  double leaf_value[QR_MAXNODES];        // per position-sorted leaf
+};
+
+// Per-iteration scalars produced on the device.
+struct QrScalars {
+  unsigned long long maxabs_bits;  // max |pseudo-response| (bits of a double)
+  int32_t scale_exp;               // q = rint(lambda * 2^scale_exp)
+  int32_t pad;
+  double scale, inv_scale;
+  double root_ss;                  // sum of squares of the pseudo-responses
+  double metric_sum;               // sum of per-query metric
+};
+
+struct qr_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  int rank = 0, world = 1;
+  int ncu = 256;
+  // training data
+  size_t N = 0, F = 0, Q = 0, maxq = 0;
+  float *d_raw = nullptr;        // [N][F] row-major f32
+  float *d_labels = nullptr;
+  uint32_t *d_qoff = nullptr;    // [Q+1]
+  std::vector<float> h_labels;
+  std::vector<uint64_t> h_qoff;
+  // validation data
+  size_t vN = 0, vQ = 0, vmaxq = 0;
+  float *d_vraw = nullptr, *d_vlabels = nullptr;
+  uint32_t *d_vqoff = nullptr;
+  double *d_vscores = nullptr;
+  std::vector<float> h_vlabels;
+  std::vector<uint64_t> h_vqoff;
+  // bins
+  bool binned = false;
+  int nblocks = 0;               // local blocks
+  int flocal = 0;                // local real features
+  std::vector<QrBlock> blocks;
+  QrBlock *d_blocks = nullptr;
+  int32_t *d_lf2gf = nullptr;    // local feature -> global feature
+  int32_t *d_gf2lf = nullptr;    // global feature -> local feature or -1
+  std::vector<int32_t> h_gf2lf, h_lf2gf;
+  uint8_t *d_bins = nullptr;
+  size_t bins_bytes = 0;
+  float *d_thr = nullptr;        // [F][256]
+  uint32_t *d_thr_size = nullptr;
+  std::vector<float> h_thr;
+  std::vector<uint32_t> h_thr_size;
+  // model state
+  double *d_scores = nullptr, *d_lambda = nullptr, *d_weight = nullptr;
+  // lambda / metric
+  double *d_lg2 = nullptr;       // log2(r + 2), r < maxq(+valid)
+  size_t lg2_len = 0;
+  double *d_idcg = nullptr, *d_vidcg = nullptr;
+  int idcg_metric = -1, vidcg_metric = -1;
+  size_t idcg_cutoff = (size_t)-1, vidcg_cutoff = (size_t)-1;
+  double *d_qmetric = nullptr, *d_vqmetric = nullptr;
+  uint32_t *d_ranks = nullptr;
+  double *d_ssq = nullptr;       // per-slice sum of squares partials
+  QrScalars *d_scalars = nullptr;
+  // tree
+  uint32_t *d_order[2] = {nullptr, nullptr};
+  uint64_t *d_partials = nullptr;
+  size_t partial_slots = 0;
+  long long *d_hsum = nullptr;   // [QR_MAXNODES..][flocal][256] cumulative fixed-point
+  uint32_t *d_hcnt = nullptr;
+  size_t hist_slots = 0;
+  qr_split_t *d_featrec = nullptr;  // [2][flocal] per-feature best of the 2 nodes just scanned
+  qr_split_t *d_recs_local = nullptr;  // [2]
+  qr_split_t *d_recs_all = nullptr;    // [world][2]
+  uint32_t *d_mask = nullptr;
+  size_t mask_words = 0;
+  uint32_t *d_blkcnt = nullptr;
+  double *d_part_ss = nullptr;
+  QrTreeState *d_tree = nullptr;
+  double *d_leafpart = nullptr;  // [slices][2] partial sums
+  bool tree_valid = false;
+  bool tree_open = false;
+  size_t cur_nleaves = 0;
+  // ensemble
+  qr_node_t *d_ens = nullptr;
+  double *d_ens_w = nullptr;
+  size_t ens_trees = 0, ens_maxnodes = 0;
+  // profiling
+  bool prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  uint64_t prof_launches = 0;
+  double prof_ms = 0.0;
+  double prof_bytes = 0.0;
+};
+
+#define QR_CHECK(ctx, expr)                                                  \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);        \
+      return QR_ERR_HIP;                                                     \
+    }                                                                        \
+  } while (0)
+
+#define QR_FAIL(ctx, code, msg) \
+  do {                          \
+    (ctx)->err = (msg);         \
+    return (code);              \
+  } while (0)
+
+// kernel launchers implemented in the .hip files -----------------------------
+int qr_k_transpose(qr_ctx *c, const float *raw, float *col, size_t N, size_t F);
+int qr_k_colstats(qr_ctx *c, const float *col, size_t N, size_t F, uint32_t limit,
+                  uint32_t *d_vals, uint32_t *d_cnt, uint32_t *d_minmax);
+int qr_k_binning(qr_ctx *c);
+int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode);
+int qr_k_residual(qr_ctx *c);
+int qr_k_prep(qr_ctx *c, size_t nslices);
+int qr_k_metric_reduce(qr_ctx *c, int which);
+int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls);
+int qr_k_tree_decide(qr_ctx *c);
+int qr_k_tree_apply(qr_ctx *c);
+int qr_k_tree_finish(qr_ctx *c, int newton);
+int qr_k_scores_update(qr_ctx *c, double shrinkage);
+int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
+                        double *d_out);

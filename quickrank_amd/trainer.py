@@ -1,0 +1,115 @@
+"""Host mirror of Mart / LambdaMart (mart.cc:208-416, lambdamart.cc:47-60).
+
+The boosting loop keeps the reference's phase order -- compute_pseudoresponses
+-> root histogram + fit_regressor_on_gradient -> ensemble push ->
+update_modelscores -> evaluate_dataset (+ validation, best model, early stop,
+rollback) -- with every phase running on the device through the C-ABI
+(include/qr_hip.h).  Only tree nodes and metric scalars return to the host.
+"""
+import time
+
+import numpy as np
+
+from ._capi import Context, NODE_DTYPE
+
+ALGOS = ("MART", "LAMBDAMART")
+
+
+class Ensemble:
+    """ensemble.h:82-98: (root, weight) pairs; nodes kept as flat records."""
+
+    def __init__(self, max_nodes):
+        self.max_nodes = max_nodes
+        self.trees = []
+        self.weights = []
+
+    def push(self, nodes, weight):
+        t = np.zeros(self.max_nodes, NODE_DTYPE)
+        t["feature"] = -1
+        t[:len(nodes)] = nodes
+        self.trees.append(t)
+        self.weights.append(weight)
+
+    def pop(self):
+        self.trees.pop()
+        self.weights.pop()
+
+    def __len__(self):
+        return len(self.trees)
+
+    def arrays(self):
+        return np.stack(self.trees), np.asarray(self.weights, np.float64)
+
+
+class Mart:
+    """GBRT on the device; `algo` selects MART or LAMBDAMART pseudo-responses."""
+
+    def __init__(self, algo="LAMBDAMART", ntrees=1000, shrinkage=0.1, nthresholds=0,
+                 nleaves=10, minls=1, esr=100, metric="NDCG", cutoff=10, device=0,
+                 ctx=None, dist=None):
+        if algo not in ALGOS:
+            raise ValueError(f"unsupported algorithm {algo}")
+        self.algo, self.ntrees, self.shrinkage = algo, ntrees, shrinkage
+        self.nthresholds, self.nleaves, self.minls, self.esr = nthresholds, nleaves, minls, esr
+        self.metric, self.cutoff = metric, cutoff
+        self.ctx = ctx if ctx is not None else Context(device)
+        self.dist = dist
+        self.ensemble = Ensemble(2 * nleaves + 1)
+        self.thr = self.thr_size = None
+        self.train_metric, self.valid_metric, self.iter_seconds = [], [], []
+        self.best_model = 0
+
+    # Mart::init (mart.cc:117-176)
+    def init(self, x, labels, qoff, valid=None):
+        self.ctx.upload(x, labels, qoff)
+        if valid is not None:
+            self.ctx.upload_valid(*valid)
+        self.thr, self.thr_size = self.ctx.build_bins(self.nthresholds)
+        self.ctx.reset_scores()
+
+    def _fit_tree(self, newton):
+        if self.dist is not None:
+            return self.dist.fit_tree(self.ctx, self.nleaves, self.minls, newton)
+        return self.ctx.fit_tree(self.nleaves, self.minls, newton)
+
+    # Mart::learn main loop (mart.cc:307-383) + rollback (:390-395)
+    def learn(self, x, labels, qoff, valid=None, verbose=False, eval_every=1):
+        self.init(x, labels, qoff, valid)
+        lam = self.algo == "LAMBDAMART"
+        best_valid = best_train = -np.inf
+        self.best_model = 0
+        for m in range(self.ntrees):
+            if valid is not None and self.esr and m > self.best_model + self.esr:
+                break
+            t0 = time.perf_counter()
+            if lam:
+                self.ctx.compute_lambdas(self.metric, self.cutoff)
+            else:
+                self.ctx.compute_residuals()
+            nodes = self._fit_tree(newton=lam)
+            self.ensemble.push(nodes, self.shrinkage)
+            self.ctx.update_scores(self.shrinkage)
+            mt = self.ctx.metric_eval(0, self.metric, self.cutoff) if eval_every else 0.0
+            self.train_metric.append(mt)
+            if valid is not None:
+                mv = self.ctx.metric_eval(1, self.metric, self.cutoff)
+                self.valid_metric.append(mv)
+                if mv > best_valid:
+                    best_train, best_valid = mt, mv
+                    self.best_model = len(self.ensemble) - 1
+            elif mt > best_train:
+                best_train = mt
+                self.best_model = len(self.ensemble) - 1
+            self.iter_seconds.append(time.perf_counter() - t0)
+            if verbose:
+                print(f"{m + 1:7d} {mt:9.4f}" + (f" {self.valid_metric[-1]:9.4f}" if valid else ""))
+        if valid is not None:
+            while len(self.ensemble) > self.best_model + 1:
+                self.ensemble.pop()
+        return self
+
+    # LTR_Algorithm::score_dataset (ltr_algorithm.cc:44-52)
+    def score_dataset(self, x):
+        nodes, w = self.ensemble.arrays()
+        self.ctx.upload_ensemble(nodes, w)
+        return self.ctx.score(x)[0]

@@ -1,0 +1,226 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): split (feature, threshold-slot) sequences and
+all integer/index work bit-exact; leaf outputs / NDCG within 1e-5 relative (the
+tests ask for far tighter where the arithmetic allows it).
+"""
+import numpy as np
+import pytest
+
+from datagen import make_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qr():
+    import quickrank_amd
+    from quickrank_amd import build
+    build.build()
+    return quickrank_amd
+
+
+@pytest.fixture(scope="module")
+def ora(oracle_lib):
+    return oracle_lib
+
+
+def _ctx(qr, x, labels, qoff, nthr):
+    c = qr.Context(0)
+    c.upload(x, labels, qoff)
+    thr, ts = c.build_bins(nthr)
+    return c, thr, ts
+
+
+CASES = [
+    dict(nq=40, docs_per_query=30, F=16, seed=0),
+    dict(nq=25, docs_per_query=60, F=136, seed=1, ragged=True),
+    dict(nq=30, docs_per_query=40, F=70, seed=2, adversarial=True),
+    dict(nq=12, docs_per_query=300, F=33, seed=3, ragged=True, adversarial=True),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("nthr", [255, 16, 0])
+def test_thresholds_and_bins(qr, ora, case, nthr):
+    x, labels, qoff = make_dataset(**case)
+    if nthr == 0:
+        x = np.floor(x * 200) / 200  # <= 255 distinct values per column
+    col = np.ascontiguousarray(x.T)
+    othr, ots = ora.thresholds(col, nthr)
+    if nthr == 0:
+        assert ots.max() <= 256
+    c, thr, ts = _ctx(qr, x, labels, qoff, nthr)
+    assert np.array_equal(ts.astype(np.uint64), ots)
+    for f in range(x.shape[1]):
+        n = int(ots[f])
+        assert np.array_equal(thr[f, :n].view(np.uint32), othr[f, :n].view(np.uint32)), f
+    stmap, _ = ora.binmap(col, othr, ots)
+    bins = c.read_bins()
+    assert np.array_equal(bins.T.astype(np.uint32), stmap)
+    c.close()
+
+
+def test_nthr0_too_many_uniques_is_an_error(qr):
+    x, labels, qoff = make_dataset(nq=20, docs_per_query=30, F=8, seed=0)
+    c = qr.Context(0)
+    c.upload(x, labels, qoff)
+    with pytest.raises(qr.QrError):
+        c.build_bins(0)
+    c.close()
+
+
+def _scores_for(kind, n, rng):
+    if kind == "zero":
+        return np.zeros(n)
+    if kind == "few":
+        return rng.integers(0, 5, n) * 0.1
+    if kind == "mixed":
+        s = rng.standard_normal(n)
+        s[rng.integers(0, n, n // 4)] = 0.25
+        return s
+    return rng.standard_normal(n)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("kind", ["zero", "few", "mixed", "random"])
+@pytest.mark.parametrize("metric,cutoff", [("NDCG", 10), ("NDCG", 3), ("NDCG", 0), ("DCG", 10)])
+def test_ranks_metric_lambdas(qr, ora, case, kind, metric, cutoff):
+    x, labels, qoff = make_dataset(**case)
+    rng = np.random.default_rng(5)
+    scores = _scores_for(kind, len(labels), rng)
+    c = qr.Context(0)
+    c.upload(x, labels, qoff)
+    c.set_scores(scores)
+    c.compute_lambdas(metric, cutoff)
+    m = 1 if metric == "NDCG" else 0
+    # rank permutation: bit-exact incl. the std::sort tie order
+    ranks = c.ranks()
+    for q in range(len(qoff) - 1):
+        a, b = int(qoff[q]), int(qoff[q + 1])
+        assert np.array_equal(ranks[a:b].astype(np.uint64), ora.rank_by_score(scores[a:b])), q
+    # per-query metric: bit-exact (same ranking, host-built log2 table)
+    pq = c.metric_per_query()
+    L = ora.lib()
+    for q in range(len(qoff) - 1):
+        a, b = int(qoff[q]), int(qoff[q + 1])
+        fn = L.qro_ndcg_query if m else L.qro_dcg_query
+        want = fn(np.ascontiguousarray(labels[a:b]), np.ascontiguousarray(scores[a:b]), b - a, cutoff)
+        assert pq[q] == want, q
+    assert c.metric_last() == pytest.approx(ora.eval_dataset(labels, scores, qoff, cutoff, m), rel=1e-13)
+    assert c.metric_eval(0, metric, cutoff) == pytest.approx(
+        ora.eval_dataset(labels, scores, qoff, cutoff, m), rel=1e-13)
+    lam, w = c.get_pseudo()
+    olam, ow = ora.lambdas(labels, scores, qoff, cutoff, m)
+    scale = max(1.0, np.abs(olam).max())
+    assert np.allclose(lam, olam, rtol=1e-11, atol=1e-13 * scale)
+    assert np.allclose(w, ow, rtol=1e-11, atol=1e-13 * scale)
+    c.close()
+
+
+def _oracle_tree(ora, x, nthr, lam, w, nleaves, minls):
+    tr = ora.Trainer(x, nthr)
+    t = tr.fit_tree(lam, nleaves=nleaves, minls=minls)
+    tr.update_output(t, lam, w)
+    return tr, t
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("nthr,nleaves,minls", [(255, 10, 1), (32, 16, 5), (255, 4, 1), (8, 31, 2)])
+def test_root_histogram_and_tree(qr, ora, case, nthr, nleaves, minls):
+    x, labels, qoff = make_dataset(**case)
+    rng = np.random.default_rng(11)
+    scores = rng.standard_normal(len(labels)) * 0.3
+    olam, ow = ora.lambdas(labels, scores, qoff, 10, 1)
+    c, thr, ts = _ctx(qr, x, labels, qoff, nthr)
+    c.set_pseudo(olam, ow)
+    nodes = c.fit_tree(nleaves, minls, True)
+    tr, ot = _oracle_tree(ora, x, nthr, olam, ow, nleaves, minls)
+    # root histogram: counts exact, sums to fixed-point resolution
+    hs, hc = c.node_hist(0)
+    os_, oc, _ = ora.hist_build(tr.stmap, tr.thr_size, tr.cap, olam)
+    for f in range(x.shape[1]):
+        n = int(tr.thr_size[f])
+        assert np.array_equal(hc[f, :n], oc[f, :n]), f
+        tol = 2.0 ** -30 * max(1.0, np.abs(olam).max()) * np.sqrt(len(olam))
+        assert np.allclose(hs[f, :n], os_[f, :n], rtol=0, atol=tol), f
+    # split sequence and structure: bit-exact
+    log = c.split_log()
+    olog = ot["splits"]
+    assert len(log) == len(olog)
+    assert np.array_equal(log["feature"].astype(np.uint64), olog["feature"])
+    assert np.array_equal(log["thr_id"].astype(np.uint64), olog["thr_id"])
+    assert np.array_equal(log["lcount"], olog["lcount"])
+    assert np.array_equal(log["rcount"], olog["rcount"])
+    on = ot["nodes"]
+    assert len(nodes) == len(on)
+    for k in ("feature", "thr_id", "left", "right", "nsamples"):
+        assert np.array_equal(nodes[k], on[k]), k
+    assert np.array_equal(nodes["threshold"].view(np.uint32), on["threshold"].view(np.uint32))
+    leaf = nodes["feature"] < 0
+    assert np.allclose(nodes["value"][leaf], on["value"][leaf], rtol=1e-9, atol=1e-12)
+    assert np.allclose(nodes["deviance"], on["deviance"], rtol=1e-6, atol=1e-9)
+    # leaf membership (stable partition => ascending doc ids)
+    for li, n in enumerate(np.nonzero(leaf)[0]):
+        ids = c.node_samples(int(n))
+        assert np.all(np.diff(ids.astype(np.int64)) > 0)
+        want = np.nonzero(ot["leaf_of_doc"] == list(ot["leaf_nodes"]).index(n))[0]
+        assert np.array_equal(ids, want.astype(np.uint32))
+    # score update through the leaf membership
+    c.set_scores(scores)
+    c.update_scores(0.1)
+    s2 = scores.copy()
+    tr.update_scores(ot, 0.1, s2)
+    assert np.allclose(c.get_scores(), s2, rtol=1e-12, atol=1e-13)
+    c.close()
+
+
+@pytest.mark.parametrize("algo", ["LAMBDAMART", "MART"])
+@pytest.mark.parametrize("case,nthr,nleaves", [(CASES[0], 255, 10), (CASES[1], 255, 10),
+                                               (CASES[2], 64, 8), (CASES[3], 255, 16)])
+def test_training_loop(qr, ora, algo, case, nthr, nleaves):
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(**case)
+    ntrees = 12
+    om = ora.train(x, labels, qoff, algo=algo, ntrees=ntrees, shrinkage=0.1, nthresholds=nthr,
+                   nleaves=nleaves, minls=1, esr=0)
+    gm = Mart(algo=algo, ntrees=ntrees, shrinkage=0.1, nthresholds=nthr, nleaves=nleaves, minls=1,
+              esr=0).learn(x, labels, qoff)
+    assert len(gm.ensemble) == om["ntrees_built"]
+    for t in range(ntrees):
+        n = int(om["nnodes"][t])
+        g, o = gm.ensemble.trees[t][:n], om["nodes"][t][:n]
+        for k in ("feature", "thr_id", "left", "right", "nsamples"):
+            assert np.array_equal(g[k], o[k]), (t, k)
+        leaf = o["feature"] < 0
+        assert np.allclose(g["value"][leaf], o["value"][leaf], rtol=1e-7, atol=1e-10), t
+    assert np.allclose(gm.train_metric, om["train_metric"], rtol=1e-9)
+    assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-8, atol=1e-10)
+    # inference: bit-exact given the same model
+    nodes, w = gm.ensemble.arrays()
+    gm.ctx.upload_ensemble(nodes, w)
+    got, _ = gm.ctx.score(x)
+    model = dict(nodes=nodes, nnodes=np.full(len(nodes), nodes.shape[1], np.uint64),
+                 ntrees=len(nodes), max_nodes=nodes.shape[1], shrinkage=0.1)
+    want = ora.ensemble_score(model, x)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    gm.ctx.close()
+
+
+def test_validation_early_stop_and_rollback(qr, ora):
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(nq=40, docs_per_query=30, F=20, seed=7)
+    vx, vl, vq = make_dataset(nq=15, docs_per_query=25, F=20, seed=8)
+    kw = dict(ntrees=30, shrinkage=0.3, nthresholds=64, nleaves=8, minls=1, esr=3)
+    om = ora.train(x, labels, qoff, algo="LAMBDAMART", valid=(vx, vl, vq), **kw)
+    gm = Mart(algo="LAMBDAMART", **kw).learn(x, labels, qoff, valid=(vx, vl, vq))
+    assert len(gm.train_metric) == om["ntrees_built"]
+    assert gm.best_model == om["best_model"]
+    assert len(gm.ensemble) == om["ntrees"]
+    assert np.allclose(gm.valid_metric, om["valid_metric"], rtol=1e-9)
+    gm.ctx.close()
+
+
+def test_no_device_index_is_an_error(qr):
+    with pytest.raises(qr.QrError):
+        qr.Context(63)

@@ -73,10 +73,26 @@ def build(ref=True):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
 
 
+def available_cores():
+    """Cores this process may really use (affinity mask and cgroup quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return n
+
+
 def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # libgomp sizes its pool from the visible cores; on a many-core host with a
+    # small cgroup quota that oversubscribes badly.  Cap before the first region.
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(8, available_cores())))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     path = os.path.join(_HERE, "liboracle.so")
     if not os.path.exists(path):
         build(ref=False)

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64) void k_lambda(
   if (n == 0) {
     if (lane == 0) {
       qmetric[q] = 0.0;
-      if (mode == 0 && ssq) ssq[q] = 0.0;
+      if (mode == 0 && ssq) ssq[2 * q] = ssq[2 * q + 1] = 0.0;
     }
     return;
   }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) void k_lambda(
       lambda[off + i] = 0.0;
       weight[off + i] = 0.0;
     }
-    if (lane == 0 && ssq) ssq[q] = 0.0;
+    if (lane == 0 && ssq) ssq[2 * q] = ssq[2 * q + 1] = 0.0;
     return;
   }
   for (uint32_t i = lane; i < size; i += 64) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64) void k_lambda(
   }
   __syncthreads();
   // fold the top-`size` accumulators in (same lane wrote the own part: r % 64)
-  double mx = 0.0, sq = 0.0;
+  double mx = 0.0, sq = 0.0, sm = 0.0;
   for (uint32_t r = lane; r < n; r += 64) {
     const uint32_t d = off + unmap[r];
     double l = lambda[d];
@@ -362,12 +362,17 @@ __global__ __launch_bounds__(64) void k_lambda(
     const double a = fabs(l);
     mx = a > mx ? a : mx;
     sq += l * l;
+    sm += l;
   }
   mx = wave_max(mx);
   sq = wave_sum(sq);
+  sm = wave_sum(sm);
   if (lane == 0) {
     atomicMax(&scal->maxabs_bits, (unsigned long long)__double_as_longlong(mx));
-    if (ssq) ssq[q] = sq;
+    if (ssq) {
+      ssq[2 * q] = sq;
+      ssq[2 * q + 1] = sm;
+    }
   }
 }
 
@@ -377,28 +382,32 @@ __global__ __launch_bounds__(256) void k_residual(const float *__restrict__ labe
                                                   double *__restrict__ out, uint32_t N,
                                                   double *__restrict__ ssq,
                                                   QrScalars *__restrict__ scal) {
-  __shared__ double red[4], redm[4];
+  __shared__ double red[4], redm[4], reds[4];
   const uint32_t base = blockIdx.x * QR_SLICE;
-  double sq = 0.0, mx = 0.0;
+  double sq = 0.0, mx = 0.0, sm = 0.0;
   for (uint32_t k = 0; k < QR_SLICE / 256; ++k) {
     const uint32_t i = base + k * 256 + threadIdx.x;
     if (i < N) {
       const double r = (double)labels[i] - scores[i];
       out[i] = r;
       sq += r * r;
+      sm += r;
       const double a = fabs(r);
       mx = a > mx ? a : mx;
     }
   }
   sq = wave_sum(sq);
+  sm = wave_sum(sm);
   mx = wave_max(mx);
   if ((threadIdx.x & 63) == 0) {
     red[threadIdx.x >> 6] = sq;
+    reds[threadIdx.x >> 6] = sm;
     redm[threadIdx.x >> 6] = mx;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    ssq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    ssq[2 * blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    ssq[2 * blockIdx.x + 1] = (reds[0] + reds[1]) + (reds[2] + reds[3]);
     double m = redm[0];
     for (int i = 1; i < 4; ++i) m = redm[i] > m ? redm[i] : m;
     atomicMax(&scal->maxabs_bits, (unsigned long long)__double_as_longlong(m));
@@ -413,23 +422,35 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
                                                uint32_t nq,
                                                QrScalars *__restrict__ scal) {
   __shared__ double red[16];
-  double a = 0.0, b = 0.0;
-  for (uint32_t i = threadIdx.x; i < nss; i += 1024) a += ssq[i];
+  double a = 0.0, b = 0.0, a2 = 0.0;
+  for (uint32_t i = threadIdx.x; i < nss; i += 1024) {
+    a += ssq[2 * i];
+    a2 += ssq[2 * i + 1];
+  }
   for (uint32_t i = threadIdx.x; i < nq; i += 1024) b += qmetric[i];
   a = wave_sum(a);
+  a2 = wave_sum(a2);
   b = wave_sum(b);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
-  double ta = 0.0;
+  double ta = 0.0, ta2 = 0.0;
   if (threadIdx.x == 0)
     for (int i = 0; i < 16; ++i) ta += red[i];
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a2;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 16; ++i) ta2 += red[i];
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = b;
   __syncthreads();
   if (threadIdx.x == 0) {
     double tb = 0.0;
     for (int i = 0; i < 16; ++i) tb += red[i];
-    if (ssq) scal->root_ss = ta;
+    if (ssq) {
+      scal->root_ss = ta;
+      scal->root_sum = ta2;
+    }
     if (qmetric) scal->metric_sum = tb;
     if (ssq) {
       const double mx = __longlong_as_double((long long)scal->maxabs_bits);

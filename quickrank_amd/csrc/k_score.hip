@@ -85,7 +85,7 @@ int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
   const size_t lds = rows_bytes + tbatch * c->ens_maxnodes * 24;
   QR_CHECK(c, hipFuncSetAttribute((const void *)k_ensemble_score,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(160 * 1024 - 256)));
+                                  (int)lds));
   const unsigned grid = (unsigned)((N + SC_DOCS - 1) / SC_DOCS);
   hipLaunchKernelGGL(k_ensemble_score, dim3(grid), dim3(SC_DOCS), lds, c->stream,
                      d_x, (uint32_t)N, (uint32_t)F, c->d_ens, c->d_ens_w,

@@ -405,10 +405,12 @@ __device__ void heap_pop(QrTreeState *ts) {
 }
 
 // RTNode(sampleids, hist): rtnode.h:97-107
-__device__ void node_stats(QrNode *nd, long long total_q, double inv_scale,
-                           double ss, u64 count) {
+__device__ void node_stats(QrNode *nd, double sum, double ss, u64 count) {
+  // `sum` is the f64 sum of the node's pseudo-responses (not the fixed-point
+  // histogram total): a one-document node must come out with deviance == 0
+  // exactly, as in the reference, because `deviance > 0` gates the split.
   nd->count = count;
-  nd->sum = (double)total_q * inv_scale;
+  nd->sum = sum;
   nd->ss = ss;
   nd->value = count ? nd->sum / (double)count : 0.0;
   nd->deviance = ss - nd->sum * nd->sum / (double)count;
@@ -501,7 +503,6 @@ __global__ __launch_bounds__(64) void k_decide(
     const double *__restrict__ part_ss, const float *__restrict__ thr,
     const int32_t *__restrict__ gf2lf) {
   if (threadIdx.x != 0) return;
-  const double inv_scale = scal->inv_scale;
   if (ts->step == 0) {
     QrNode *root = &ts->nodes[0];
     root->begin = 0;
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(64) void k_decide(
     root->threshold = 0.f;
     root->left = root->right = root->parent = -1;
     root->leaf_id = -1;
-    node_stats(root, hsum[255], inv_scale, scal->root_ss, N);
+    node_stats(root, scal->root_sum, scal->root_ss, N);
     node_set_best(root, recs, world, 0);
     ts->nnodes = 1;
     ts->heap_size = 0;
@@ -536,12 +537,15 @@ __global__ __launch_bounds__(64) void k_decide(
     QrNode *P = &ts->nodes[d.node];
     QrNode *S = &ts->nodes[d.small_node], *B = &ts->nodes[d.big_node];
     const uint32_t nwg = (d.end - d.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
-    double ss_small = 0.0;
-    for (uint32_t i = 0; i < nwg; ++i) ss_small += part_ss[i];
-    const long long sq = hsum[((size_t)d.small_slot * flocal) * 256 + 255];
-    const long long bq = hsum[((size_t)d.big_slot * flocal) * 256 + 255];
-    node_stats(S, sq, inv_scale, ss_small, d.small_n);
-    node_stats(B, bq, inv_scale, P->ss - ss_small,
+    double ss_small = 0.0, sum_small = 0.0;
+    for (uint32_t i = 0; i < nwg; ++i) {
+      ss_small += part_ss[2 * i];
+      sum_small += part_ss[2 * i + 1];
+    }
+    // directly accumulated child, sibling by subtraction
+    // (rtnode_histogram.cc:65-69, 79-86)
+    node_stats(S, sum_small, ss_small, d.small_n);
+    node_stats(B, P->sum - sum_small, P->ss - ss_small,
                (u64)(d.end - d.begin) - d.small_n);
     node_set_best(&ts->nodes[d.left], recs, world, 0);
     node_set_best(&ts->nodes[d.right], recs, world, 1);
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(
     double *__restrict__ part_ss) {
   __shared__ uint32_t sh[4];
   __shared__ uint32_t wave_off[4];
-  __shared__ double shd[4];
+  __shared__ double shd[4], shs[4];
   const QrSplitDesc d = ts->desc;
   if (!d.active) return;
   const uint32_t n = d.end - d.begin;
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(
   for (int w = 0; w < wave; ++w) woff += wave_off[w];
   uint32_t lpos = left_before + woff + inc - cnt;  // lefts before my first doc
   const uint32_t first_p = base + threadIdx.x * PART_PER_THREAD;
-  double sq = 0.0;
+  double sq = 0.0, sm = 0.0;
   for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
     const uint32_t p = first_p + k;
     if (p < n) {
@@ -705,16 +709,26 @@ __global__ __launch_bounds__(256) void k_part_scatter(
       if (fl[k] == (d.small_is_left != 0)) {
         const double l = lambda[ids[k]];
         sq += l * l;
+        sm += l;
       }
     }
   }
   // squares_sum_ of the directly built child (rtnode_histogram.cc:65-69),
   // fixed reduction tree
-  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+  for (int off = 32; off > 0; off >>= 1) {
+    sq += __shfl_xor(sq, off, 64);
+    sm += __shfl_xor(sm, off, 64);
+  }
   __syncthreads();
-  if (lane == 0) shd[wave] = sq;
+  if (lane == 0) {
+    shd[wave] = sq;
+    shs[wave] = sm;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) part_ss[blockIdx.x] = (shd[0] + shd[1]) + (shd[2] + shd[3]);
+  if (threadIdx.x == 0) {
+    part_ss[2 * blockIdx.x] = (shd[0] + shd[1]) + (shd[2] + shd[3]);
+    part_ss[2 * blockIdx.x + 1] = (shs[0] + shs[1]) + (shs[2] + shs[3]);
+  }
 }
 
 // ===========================================================================
@@ -888,12 +902,12 @@ static size_t hist_lds(const qr_ctx *c) {
 
 static int launch_hist_scan(qr_ctx *c, int root_mode) {
   const size_t lds = hist_lds(c);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
     QR_CHECK(c, hipFuncSetAttribute((const void *)k_hist,
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 256));
-    attr_done = true;
+                                    (int)lds));
+    attr_lds = lds;
   }
   const int G = c->ncu;
   hipEvent_t e0 = nullptr, e1 = nullptr;

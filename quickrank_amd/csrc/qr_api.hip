@@ -186,7 +186,7 @@ int qr_dataset_upload(qr_ctx *c, const float *x, size_t N, size_t F,
   QR_CHECK(c, dalloc(&c->d_idcg, Q));
   QR_CHECK(c, dalloc(&c->d_qmetric, Q));
   QR_CHECK(c, dalloc(&c->d_ranks, N));
-  QR_CHECK(c, dalloc(&c->d_ssq, std::max(Q, N / QR_SLICE + 2)));
+  QR_CHECK(c, dalloc(&c->d_ssq, 2 * std::max(Q, N / QR_SLICE + 2)));
   c->idcg_metric = -1;
   return ensure_lg2(c);
 }
@@ -348,7 +348,7 @@ int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
   c->mask_words = (N + 31) / 32;
   QR_CHECK(c, dalloc(&c->d_mask, c->mask_words));
   QR_CHECK(c, dalloc(&c->d_blkcnt, N / QR_PART_SLICE + 2));
-  QR_CHECK(c, dalloc(&c->d_part_ss, N / QR_PART_SLICE + 2));
+  QR_CHECK(c, dalloc(&c->d_part_ss, 2 * (N / QR_PART_SLICE + 2)));
   QR_CHECK(c, dalloc(&c->d_tree, (size_t)1));
   QR_CHECK(c, hipMemset(c->d_tree, 0, sizeof(QrTreeState)));
   QR_CHECK(c, dalloc(&c->d_leafpart, 2 * (N / QR_SLICE + QR_MAXNODES + 4)));
@@ -414,16 +414,17 @@ int qr_pseudo_set(qr_ctx *c, const double *l, const double *w) {
   // reuse k_residual's reduction by computing on the host what it would write
   double mx = 0.0;
   const size_t ns = (c->N + QR_SLICE - 1) / QR_SLICE;
-  std::vector<double> ssq(ns, 0.0);
+  std::vector<double> ssq(2 * ns, 0.0);
   for (size_t i = 0; i < c->N; ++i) {
     mx = std::max(mx, std::fabs(l[i]));
-    ssq[i / QR_SLICE] += l[i] * l[i];
+    ssq[2 * (i / QR_SLICE)] += l[i] * l[i];
+    ssq[2 * (i / QR_SLICE) + 1] += l[i];
   }
   QrScalars s;
   QR_CHECK(c, hipMemcpy(&s, c->d_scalars, sizeof(s), hipMemcpyDeviceToHost));
   memcpy(&s.maxabs_bits, &mx, 8);
   QR_CHECK(c, hipMemcpy(c->d_scalars, &s, sizeof(s), hipMemcpyHostToDevice));
-  QR_CHECK(c, hipMemcpy(c->d_ssq, ssq.data(), ns * 8, hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_ssq, ssq.data(), 2 * ns * 8, hipMemcpyHostToDevice));
   return qr_k_prep(c, ns);
 }
 

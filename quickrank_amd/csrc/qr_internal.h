@@ -138,6 +138,7 @@ struct QrScalars {
   int32_t pad;
   double scale, inv_scale;
   double root_ss;                  // sum of squares of the pseudo-responses
+  double root_sum;                 // their plain f64 sum
   double metric_sum;               // sum of per-query metric
 };
 

@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- docs/sec per LambdaMART boosting iteration on synthetic MSLR-shaped data.
+
+Workload (BASELINE.json configs[1]): 1,000,000 docs x 136 features x 10,000
+queries (100 docs each), LambdaMART, 255 thresholds (256 slots), 10 leaves,
+shrinkage 0.1, min-leaf-support 1, NDCG@10, no validation set.
+
+A step = one boosting iteration (mart.cc:307-383): per-query lambdas/weights,
+root histogram, tree fit (split scans, partitions, child histograms), leaf
+outputs, training-score update and training NDCG@10 -- all on the device,
+inputs resident in HBM before the timed region starts.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: feature-block-sharded histograms (quickrank_amd/dist.py); total work is
+fixed, so scaling is "strong".  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def synth(nq, dpq, F, seed=42):
+    """MSLR-shaped synthetic data: U[0,1) f32 features, labels 0..4 driven by
+    the first four features."""
+    rng = np.random.default_rng(seed)
+    N = nq * dpq
+    x = rng.random((N, F), dtype=np.float32)
+    labels = np.minimum(4, np.floor(1.25 * x[:, :4].sum(axis=1, dtype=np.float64))).astype(np.float32)
+    qoff = (np.arange(nq + 1, dtype=np.uint64) * dpq)
+    return x, labels, qoff
+
+
+def cpu_baseline(x, labels, qoff, args):
+    """The oracle (C + OpenMP restatement of the reference's loop, bit-exact to
+    it on the fixtures) timed on this host's cores on a bounded sample."""
+    import oracle
+    cores = oracle.available_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    nq = min(len(qoff) - 1, args.cpu_queries)
+    n = int(qoff[nq])
+    iters = args.cpu_iters
+    m = oracle.train(x[:n], labels[:n], qoff[:nq + 1], algo="LAMBDAMART", ntrees=iters,
+                     shrinkage=0.1, nthresholds=args.nthresholds, nleaves=args.nleaves, minls=1,
+                     esr=0, threads=cores)
+    sec = float(np.mean(m["iter_seconds"][1:])) if iters > 1 else float(m["iter_seconds"][0])
+    return {"value": n / sec, "unit": "docs/s per boosting iteration", "cores": cores,
+            "kind": "port",
+            "sample": f"first {nq} queries ({n} docs x {x.shape[1]} features) of the same synthetic "
+                      f"set, {iters} iterations, first discarded, {sec * 1e3:.1f} ms/iteration, "
+                      f"OpenMP x{cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--queries", type=int, default=10000)
+    ap.add_argument("--docs-per-query", type=int, default=100)
+    ap.add_argument("--features", type=int, default=136)
+    ap.add_argument("--nleaves", type=int, default=10)
+    ap.add_argument("--nthresholds", type=int, default=255)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-queries", type=int, default=2500)
+    ap.add_argument("--cpu-iters", type=int, default=6)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node == --gpus")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: quickrank_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from quickrank_amd import build as qbuild
+    if rank == 0:
+        qbuild.build()
+    if dist is not None:
+        dist.barrier()
+    from quickrank_amd._capi import Context
+
+    x, labels, qoff = synth(args.queries, args.docs_per_query, args.features)
+    N, F = x.shape
+    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
+    ctx = Context(local_rank, rank=rank, world=world, stream=stream)
+    ctx.upload(x, labels, qoff)
+    ctx.build_bins(args.nthresholds)
+    ctx.reset_scores()
+    fitter = None
+    if world > 1:
+        from quickrank_amd.dist import ShardedTreeFitter
+        fitter = ShardedTreeFitter(ctx)
+
+    ndcg = []
+
+    def step():
+        ctx.compute_lambdas("NDCG", 10)
+        if fitter is not None:
+            fitter.fit_tree(ctx, args.nleaves, 1, True)
+        else:
+            ctx.fit_tree(args.nleaves, 1, True)
+        ctx.update_scores(0.1)
+        ndcg.append(ctx.metric_eval(0, "NDCG", 10))
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = ctx.prof_get()
+    ctx.prof_enable(False)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = N * args.steps / elapsed
+        roof = None
+        if prof["launches"]:
+            sec = prof["total_ms"] / prof["launches"] * 1e-3
+            ach = prof["alg_bytes"] / sec / 1e9
+            roof = {"bound": "hbm", "kernel": "k_hist (root histogram build)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "alg_bytes_per_launch": prof["alg_bytes"],
+                    "avg_launch_us": round(sec * 1e6, 2), "launches": prof["launches"]}
+        out = {
+            "metric": "docs/sec per LambdaMART boosting iter (1Mx136)",
+            "value": value, "unit": "docs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {N} docs x {F} features x {args.queries} queries, "
+                                   f"LambdaMART {args.nleaves} leaves, {args.nthresholds} thresholds, "
+                                   "NDCG@10, shrinkage 0.1, min-leaf-support 1",
+                       "parallelism": "1 GPU" if world == 1 else f"feature-block sharding x{world}",
+                       "ndcg10_last": ndcg[-1] if ndcg else None},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(x, labels, qoff, args)
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,7 +77,7 @@ const char *qr_last_error(const qr_ctx *ctx);
 /* run every launch on the caller's HIP stream (e.g. torch's current stream)    */
 int qr_ctx_set_stream(qr_ctx *ctx, void *hip_stream);
 /* feature-block sharding for the multi-GPU path: this   */
-/* rank owns 64-feature blocks  rank, rank+world, ...  of the bin matrix.       */
+/* rank owns features [rank*ceil(F/world), (rank+1)*ceil(F/world)) of the bins.  */
 /* Must be called before qr_bins_build.  Default rank 0 / world 1.              */
 int qr_ctx_set_shard(qr_ctx *ctx, int rank, int world);
 int qr_synchronize(qr_ctx *ctx);

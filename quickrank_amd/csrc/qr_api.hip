@@ -235,18 +235,21 @@ int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "the device path stores uint8 bins: nthresholds <= 255");
   QR_CHECK(c, hipSetDevice(c->device));
   const size_t N = c->N, F = c->F;
-  // ---- feature blocks owned by this rank
-  const size_t nglob = (F + 63) / 64;
+  // ---- feature blocks owned by this rank: rank r owns the contiguous range
+  // [r*ceil(F/world), (r+1)*ceil(F/world)), cut into
+  // blocks of at most 64 features
+  const size_t per_rank = (F + (size_t)c->world - 1) / (size_t)c->world;
+  const size_t f_lo = std::min(F, per_rank * (size_t)c->rank);
+  const size_t f_hi = std::min(F, f_lo + per_rank);
   c->blocks.clear();
   c->h_gf2lf.assign(F, -1);
   c->h_lf2gf.clear();
   size_t off = 0;
   int lf = 0;
-  for (size_t g = 0; g < nglob; ++g) {
-    if ((int)(g % (size_t)c->world) != c->rank) continue;
+  for (size_t g0 = f_lo; g0 < f_hi; g0 += 64) {
     QrBlock b;
-    b.f0 = (int)(g * 64);
-    b.nreal = (int)std::min<size_t>(64, F - g * 64);
+    b.f0 = (int)g0;
+    b.nreal = (int)std::min<size_t>(64, f_hi - g0);
     b.fw = (b.nreal + 15) / 16 * 16;
     b.lf0 = lf;
     b.off = off;
@@ -261,7 +264,7 @@ int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
   }
   c->nblocks = (int)c->blocks.size();
   c->flocal = lf;
-  if (c->nblocks == 0) QR_FAIL(c, QR_ERR_ARG, "this rank owns no feature block (world > #blocks)");
+  if (c->nblocks == 0) QR_FAIL(c, QR_ERR_ARG, "this rank owns no feature (world > F)");
   if (c->nblocks > QR_MAXBLK) QR_FAIL(c, QR_ERR_UNSUPPORTED, "too many feature blocks");
   c->bins_bytes = off;
   // ---- distinct values / min / max per column

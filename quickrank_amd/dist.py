@@ -1,0 +1,76 @@
+"""Feature-block sharding across the GPUs of one node.
+
+Rank r owns the contiguous feature range [r*ceil(F/P), (r+1)*ceil(F/P)) of the
+bin matrix for ALL documents (17 features per GPU for F = 136, P = 8); labels, scores, pseudo-responses and document lists are replicated,
+so every rank makes the same control decisions.  Per split there are exactly two
+exchanges, both enqueued on the context's stream with no host synchronisation:
+
+  1. all_gather of the per-rank best-split records (2 x 32 B per rank: left and
+     right child of the split just applied) -> every rank merges them with the
+     same deterministic rule (max gain, ties -> lowest feature) in k_decide;
+  2. all_reduce(sum) of the go-left bit mask of the node being split: only the
+     owner of the winning feature contributes non-zero words, so the sum is the
+     owner's mask (a broadcast whose root need not be known on the host).
+
+Each feature's histogram is accumulated on exactly one GPU, so the sums -- and
+therefore the trees -- are bit-identical to the 1-GPU run.
+
+The transport is torch.distributed (backend "nccl" == RCCL over xGMI on GPUs;
+"gloo" in the CPU protocol tests, which drive the same class with a host-side
+stand-in context).
+"""
+import numpy as np
+
+
+class _DevArray:
+    """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, nbytes, typestr="|u1", itemsize=1):
+        self.__cuda_array_interface__ = {
+            "shape": (nbytes // itemsize,), "typestr": typestr,
+            "data": (int(ptr), False), "version": 2}
+
+
+class ShardedTreeFitter:
+    """Drives qr_tree_begin/decide/apply/end with the collectives in between."""
+
+    def __init__(self, ctx, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        b = ctx.exchange_buffers()
+        self.rec_bytes = b["rec_bytes"]
+        if hasattr(ctx, "host_buffers"):        # CPU protocol stand-in (tests)
+            hb = ctx.host_buffers()
+            self.recs_local = torch.from_numpy(hb["recs_local"])
+            self.recs_all = torch.from_numpy(hb["recs_all"])
+            self.mask = torch.from_numpy(hb["mask"])
+        else:
+            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+            self.recs_local = torch.as_tensor(_DevArray(b["recs_local"], self.rec_bytes), device=dev)
+            self.recs_all = torch.as_tensor(_DevArray(b["recs_all"], self.rec_bytes * self.world),
+                                            device=dev)
+            self.mask = torch.as_tensor(_DevArray(b["mask"], b["mask_bytes"], "<i4", 4), device=dev)
+
+    def _gather_records(self):
+        self.dist.all_gather_into_tensor(self.recs_all, self.recs_local, group=self.group)
+
+    def fit_tree(self, ctx, nleaves, minls, newton):
+        ctx.tree_begin(nleaves, minls)
+        self._gather_records()
+        for _ in range(nleaves - 1):
+            ctx.tree_decide()
+            self.dist.all_reduce(self.mask, op=self.dist.ReduceOp.SUM, group=self.group)
+            ctx.tree_apply()
+            self._gather_records()
+        ctx.tree_decide()
+        return ctx.tree_end(nleaves, newton)
+
+
+def owned_features(F, rank, world):
+    """Global feature indices rank owns (same rule as qr_ctx_set_shard)."""
+    per = (F + world - 1) // world
+    lo = min(F, per * rank)
+    return np.arange(lo, min(F, lo + per), dtype=np.int64)

@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: world_size 2, gloo.  Two processes run the real
+quickrank_amd.dist.ShardedTreeFitter (all_gather of best-split records,
+sum all-reduce of the go-left mask) over host stand-in contexts whose per-rank
+histogram work is done by the oracle on the rank's feature range.  The sharded
+tree must equal the unsharded oracle tree split for split."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, q, nleaves, F):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from datagen import make_dataset
+    from quickrank_amd.dist import ShardedTreeFitter
+    from shard_standin import StandinContext
+    x, labels, qoff = make_dataset(nq=20, docs_per_query=50, F=F, seed=13, adversarial=True)
+    rng = np.random.default_rng(3)
+    lam, w = oracle.lambdas(labels, rng.standard_normal(len(labels)) * 0.2, qoff)
+    ctx = StandinContext(x, 255, rank, world)
+    ctx.set_pseudo(lam, w)
+    fitter = ShardedTreeFitter(ctx)
+    nodes = fitter.fit_tree(ctx, nleaves, 5, True)
+    if rank == 0:
+        tr = oracle.Trainer(x, 255)
+        t = tr.fit_tree(lam, nleaves=nleaves, minls=5)
+        tr.update_output(t, lam, w)
+        o = t["nodes"]
+        ok = (len(o) == len(nodes)
+              and all(np.array_equal(nodes[k], o[k]) for k in ("feature", "thr_id", "left", "right", "nsamples"))
+              and np.allclose(nodes["value"][o["feature"] < 0], o["value"][o["feature"] < 0], rtol=1e-12))
+        q.put(bool(ok))
+    # every rank must have produced the same tree
+    t = torch.from_numpy(np.ascontiguousarray(nodes["feature"]).astype(np.int64))
+    ref = t.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(t, ref)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F", [(2, 136), (2, 9), (3, 70)])
+def test_sharded_fit_equals_unsharded(world, F):
+    import oracle
+    oracle.build(ref=False)
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29500 + (os.getpid() + world * 7 + F) % 2000
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, 12, F)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_owned_features_cover_and_match_capi_rule():
+    from quickrank_amd.dist import owned_features
+    for F in (1, 9, 64, 65, 136, 700):
+        for world in (1, 2, 3, 8):
+            got = [owned_features(F, r, world) for r in range(world)]
+            cat = np.concatenate(got)
+            assert np.array_equal(cat, np.arange(F))
+            per = (F + world - 1) // world
+            assert all(len(g) <= per for g in got)

@@ -113,13 +113,16 @@ def main():
     ndcg = []
 
     def step():
+        # ranking + NDCG@10 of the current scores (= the training metric the
+        # reference evaluates at the end of the previous iteration, mart.cc:347)
+        # + lambdas/weights, one pass over the queries
         ctx.compute_lambdas("NDCG", 10)
+        ndcg.append(ctx.metric_last())
         if fitter is not None:
             fitter.fit_tree(ctx, args.nleaves, 1, True)
         else:
             ctx.fit_tree(args.nleaves, 1, True)
         ctx.update_scores(0.1)
-        ndcg.append(ctx.metric_eval(0, "NDCG", 10))
 
     def sync():
         if dist is not None:

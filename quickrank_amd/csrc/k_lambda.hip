@@ -14,19 +14,22 @@
 //      is whatever GNU libstdc++ std::sort (introsort: median-of-3 to first,
 //      unguarded Hoare partition, threshold 16, depth limit 2*lg n with a
 //      heapsort fallback, final insertion sort) leaves -- SURVEY.md Appendix A.
-//      Lane 0 then re-ranks the query with a sequential emulation of exactly
-//      that algorithm (ties dominate the first boosting iterations, where all
-//      scores are 0 and the tie order decides the discounts).
+//      The wave then re-ranks the query with a wave-parallel emulation of
+//      exactly that algorithm (wave_gnu_sort below; ties dominate the first
+//      boosting iterations, where all scores are 0 and the tie order decides the
+//      discounts, and never fully disappear).
 //   3. metric of the current ranking (lane 0, same summation order as
 //      dcg.cc:36-38) -- the training NDCG comes for free with the lambdas.
 //   4. pair loop: lane <-> rank r2, loop r1 over the top-`cutoff` ranks;
 //      the swap-delta is the closed form of ndcg.cc:76-88 (no n^2 jacobian),
 //      rho/lambda/delta as lambdamart.cc:129-141; contributions to r1 are
 //      reduced across the wave with a fixed shuffle tree (deterministic).
-// exp() is OCML's f64 exp: lambdas agree with glibc to ~1e-16 relative, not
-// bitwise (SURVEY.md section 7 hard part 3); log2 discounts come from a
+// exp() is a table + degree-5 polynomial f64 exp (qr_exp, ~1 ulp): lambdas agree
+// with glibc to ~1e-15 relative, not bitwise (SURVEY.md section 7 hard part 3); log2 discounts come from a
 // host-built table (glibc values) so the metric itself is bit-exact given the
 // ranking.
+#include <algorithm>
+
 #include "qr_internal.h"
 
 #define NO_CUTOFF 0xFFFFFFFFu
@@ -39,6 +42,12 @@ struct DescCmp {
   const double *s;
   __device__ __forceinline__ bool operator()(uint32_t a, uint32_t b) const {
     return s[a] > s[b];
+  }
+};
+
+struct PackedCmp {  // comp on packed (key << 16 | doc): key = #strictly greater scores
+  __device__ __forceinline__ bool operator()(uint32_t a, uint32_t b) const {
+    return (a >> 16) < (b >> 16);
   }
 };
 
@@ -188,17 +197,81 @@ __device__ void g_gnu_sort(uint32_t *a, int n, C c) {
 }
 
 // ---------------------------------------------------------------------------
+// Wave reductions on DPP (no LDS round trip): quad butterflies, row_half_mirror,
+// row_mirror give every lane its 16-lane row total; the four row totals are
+// combined in a fixed order through readlane.  Deterministic association.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-  // fixed butterfly: identical association on every launch
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v) {
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
-  }
-  return v;
+  double o = dpp_f64<0xB1>(v);
+  v = o > v ? o : v;
+  o = dpp_f64<0x4E>(v);
+  v = o > v ? o : v;
+  o = dpp_f64<0x141>(v);
+  v = o > v ? o : v;
+  o = dpp_f64<0x140>(v);
+  v = o > v ? o : v;
+  const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32),
+               d = readlane_f64(v, 48);
+  const double ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+
+// ---------------------------------------------------------------------------
+// exp(x) in f64: x = k*ln2/64 + r, |r| <= ln2/128;  exp(x) = 2^(k>>6) * T[k&63] *
+// (1 + r + r^2/2 + ... + r^5/120), T[j] = 2^(j/64) correctly rounded.  About a
+// dozen f64 operations and ~1 ulp (the reference tolerance is 1e-5; OCML's exp
+// costs ~10x more instructions and was half of the kernel's time).
+// ---------------------------------------------------------------------------
+__device__ const double QR_EXP_T[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+};
+
+__device__ __forceinline__ double qr_exp(double x, const double *T) {
+  x = x > 709.7 ? 709.7 : x;
+  x = x < -745.1 ? -745.1 : x;
+  const double kd = rint(x * 92.33248261689366);                   // 64 / ln2
+  const int k = (int)kd;
+  double r = fma(-kd, 0x1.62e42fef00000p-7, x);                    // ln2/64, high part
+  r = fma(-kd, 1.162596423439437e-12, r);                          //         low part
+  double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  const double e = fma(p, r * r, r);                               // exp(r) - 1
+  const double t = T[k & 63];
+  return ldexp(fma(t, e, t), k >> 6);
 }
 
 // pow(2.0, label) of dcg.cc:37 / ndcg.cc:80: exact for the integral relevance
@@ -209,26 +282,189 @@ __device__ __forceinline__ double pow2_label(float l) {
   return pow(2.0, (double)l);
 }
 
+// ---------------------------------------------------------------------------
+// Wave-parallel emulation of GNU std::sort on a packed (key << 16 | doc) array
+// in LDS, key = number of strictly greater scores, so that
+//     comp(a, b) = score[a] > score[b]  <=>  key(a) < key(b).
+// The permutation a sort leaves depends only on its comparison outcomes, so the
+// emulation may run the same algorithm with a different schedule:
+//  * introsort loop: ranges are processed from an explicit stack (disjoint
+//    ranges commute); median-of-3 and the swap to `first` are uniform scalar
+//    work; the unguarded Hoare partition is done by the whole wave -- the
+//    sequential scan pairs the k-th position from the left with key >= pivot
+//    ("LB") with the k-th position from the right with key <= pivot ("RB") and
+//    swaps them while LB[k] < RB[k]; both lists and the number of swaps K come
+//    from ballots/prefix counts, and the returned cut is
+//    K ? min(LB[K], RB[K-1]) : LB[0]   (the left scan stops at the next
+//    untouched >= pivot position or at the last swapped-in element).
+//  * depth limit 2*lg(n): the heapsort fallback runs sequentially on lane 0
+//    (only adversarial inputs reach it).
+//  * final insertion sort: linear insertion with a strict comparison never
+//    moves an element past an equal one, so it equals a STABLE sort by key of
+//    the arrangement the partition phase left -- done by counting.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pk(uint32_t v) { return v >> 16; }
+
+__device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *RB,
+                              int *stk, uint32_t *out) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  if (n > 16) {
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) ++lg;
+    int sp = 0;
+    if (lane == 0) {
+      stk[0] = 0;
+      stk[1] = n;
+      stk[2] = 2 * lg;
+    }
+    sp = 1;
+    __syncthreads();
+    while (sp > 0) {
+      --sp;
+      int first = stk[3 * sp], last = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+      __syncthreads();
+      while (last - first > 16) {
+        if (depth == 0) {
+          if (lane == 0) g_heapsort(a + first, last - first, PackedCmp());
+          __syncthreads();
+          break;
+        }
+        --depth;
+        // __move_median_to_first(first, first+1, mid, last-1): uniform
+        {
+          const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+          const uint32_t ka = pk(a[ia]), kb = pk(a[ib]), kc = pk(a[ic]);
+          int pick;
+          if (ka < kb) {
+            if (kb < kc) pick = ib;
+            else if (ka < kc) pick = ic;
+            else pick = ia;
+          } else if (ka < kc) pick = ia;
+          else if (kb < kc) pick = ic;
+          else pick = ib;
+          __syncthreads();
+          if (lane == 0) {
+            const uint32_t t = a[first];
+            a[first] = a[pick];
+            a[pick] = t;
+          }
+          __syncthreads();
+        }
+        const uint32_t p = pk(a[first]);
+        const int lo0 = first + 1;
+        // LB: ascending positions with key >= p
+        int nl = 0;
+        for (int base = lo0; base < last; base += 64) {
+          const int x = base + lane;
+          const bool in = x < last;
+          const bool lb = in && !(pk(a[in ? x : first]) < p);
+          const unsigned long long m = __ballot(lb);
+          if (lb) LB[nl + __popcll(m & lt)] = (uint32_t)x;
+          nl += __popcll(m);
+        }
+        // RB: descending positions with key <= p
+        int nr = 0;
+        for (int top = last; top > lo0; top -= 64) {
+          const int x = top - 1 - lane;
+          const bool in = x >= lo0;
+          const bool rb = in && !(p < pk(a[in ? x : first]));
+          const unsigned long long m = __ballot(rb);
+          if (rb) RB[nr + __popcll(m & lt)] = (uint32_t)x;
+          nr += __popcll(m);
+        }
+        __syncthreads();
+        const int np = nl < nr ? nl : nr;
+        int K = 0;
+        for (int base = 0; base < np; base += 64) {
+          const int k = base + lane;
+          const bool v = k < np && LB[k] < RB[k];
+          const unsigned long long m = __ballot(v);
+          K += __popcll(m);
+          if (m != ~0ull) break;
+        }
+        uint32_t cut;
+        if (K > 0) {
+          const uint32_t c1 = K < nl ? LB[K] : 0xFFFFFFFFu;
+          const uint32_t c2 = RB[K - 1];
+          cut = c1 < c2 ? c1 : c2;
+        } else
+          cut = nl > 0 ? LB[0] : (uint32_t)last;
+        __syncthreads();
+        for (int k = lane; k < K; k += 64) {
+          const uint32_t x = LB[k], y = RB[k];
+          const uint32_t t = a[x];
+          a[x] = a[y];
+          a[y] = t;
+        }
+        __syncthreads();
+        // recurse on [cut, last) (pushed), loop on [first, cut)
+        if (lane == 0) {
+          stk[3 * sp] = (int)cut;
+          stk[3 * sp + 1] = last;
+          stk[3 * sp + 2] = depth;
+        }
+        ++sp;
+        last = (int)cut;
+        __syncthreads();
+      }
+    }
+  }
+  // final insertion sort == stable sort by key of the current arrangement
+  // (a[n .. n4) is padded with key 0xFFFF by the caller: never counted)
+  const int n4 = (n + 3) & ~3;
+  for (int x = lane; x < n; x += 64) {
+    const uint32_t kx = pk(a[x]);
+    uint32_t r = 0;
+#pragma unroll 4
+    for (int y = 0; y < n4; ++y) {
+      const uint32_t ky = pk(a[y]);
+      r += (ky < kx) || (ky == kx && y < x);
+    }
+    out[r] = a[x] & 0xFFFFu;
+  }
+  __syncthreads();
+}
+
 // mode 0: lambdas + metric, mode 1: metric only.
+// lg2[r] = log2(r + 2) and ilg2[r] = 1.0 / lg2[r] are host-built tables (glibc
+// log2, IEEE division): the same values the reference computes inline.
 __global__ __launch_bounds__(64) void k_lambda(
     const double *__restrict__ scores, const float *__restrict__ labels,
     const uint32_t *__restrict__ qoff, int metric, uint32_t cutoff,
     const double *__restrict__ idcg, const double *__restrict__ lg2,
-    double *__restrict__ lambda, double *__restrict__ weight,
-    double *__restrict__ qmetric, uint32_t *__restrict__ ranks_out,
-    double *__restrict__ ssq, QrScalars *__restrict__ scal, uint32_t nmax,
-    uint32_t kacc, int mode) {
+    const double *__restrict__ ilg2, double *__restrict__ lambda,
+    double *__restrict__ weight, double *__restrict__ qmetric,
+    uint32_t *__restrict__ ranks_out, double *__restrict__ ssq,
+    QrScalars *__restrict__ scal, uint32_t nmax, uint32_t kacc, int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t q = blockIdx.x;
   const uint32_t lane = threadIdx.x;
+#ifdef QR_LAMBDA_TIMING
+  long long tq[8];
+  tq[0] = clock64();
+#define QR_T(i) tq[i] = clock64()
+#else
+#define QR_T(i)
+#endif
   const uint32_t off = qoff[q];
   const uint32_t n = qoff[q + 1] - off;
   double *s = reinterpret_cast<double *>(smem);          // [nmax] scores by doc
-  double *accl = s + nmax;                               // [kacc]
+  double *sr = s + nmax;                                 // [nmax] scores by rank
+  double *accl = sr + nmax;                              // [kacc] contributions to top ranks
   double *accw = accl + kacc;                            // [kacc]
-  float *lab0 = reinterpret_cast<float *>(accw + kacc);  // [nmax] labels by doc
+  double *ownl = accw + kacc;                            // [nmax] own accumulators by rank
+  double *ownw = ownl + nmax;                            // [nmax]
+  float *lab0 = reinterpret_cast<float *>(ownw + nmax);  // [nmax] labels by doc
   float *sl = lab0 + nmax;                               // [nmax] labels by rank
   uint32_t *unmap = reinterpret_cast<uint32_t *>(sl + nmax);  // [nmax] pos_of_rank
+  // sort scratch aliases the own accumulators (16 * nmax bytes, used before them)
+  uint32_t *pa = reinterpret_cast<uint32_t *>(ownl);     // packed (key << 16 | doc)
+  uint32_t *LB = pa + nmax;
+  uint32_t *RB = LB + nmax;
+  int *stk = reinterpret_cast<int *>(unmap + nmax);      // [3 * 64]
+  double *ilt = reinterpret_cast<double *>(stk + 3 * 64);  // [kacc] 1/log2(r+2), top ranks
+  double *expt = ilt + kacc;                               // [64] 2^(j/64)
   if (n == 0) {
     if (lane == 0) {
       qmetric[q] = 0.0;
@@ -240,34 +476,50 @@ __global__ __launch_bounds__(64) void k_lambda(
     s[i] = scores[off + i];
     lab0[i] = labels[off + i];
   }
+  // NaN padding to a multiple of 4: compares false, so it never counts
+  const uint32_t n4 = (n + 3) & ~3u;
+  if (lane < n4 - n) s[n + lane] = __longlong_as_double(0x7ff8000000000000LL);
   __syncthreads();
-  // ---- 1. rank by counting + tie detection
+  QR_T(1);
+  // ---- 1. rank by counting: g = #docs with a strictly greater score.  Two docs
+  //         per lane per sweep share the broadcast read of s[j]; one f64 compare
+  //         and one add per (j, doc).  Without ties g is a permutation of 0..n-1;
+  //         a tie makes two docs collide on the same slot, which the check below
+  //         detects (the loser does not find itself in unmap[g]).
+  for (uint32_t r = lane; r < n; r += 64) unmap[r] = 0xFFFFFFFFu;
+  __syncthreads();
   bool tie = false;
-  for (uint32_t i = lane; i < n; i += 64) {
-    const double si = s[i];
-    uint32_t r = 0;
-    for (uint32_t j = 0; j < n; ++j) {
+  for (uint32_t ib = lane; ib < n; ib += 128) {
+    const uint32_t i0 = ib, i1 = ib + 64;
+    const bool has1 = i1 < n;
+    const double a0 = s[i0], a1 = has1 ? s[i1] : 0.0;
+    uint32_t g0 = 0, g1 = 0;
+#pragma unroll 4
+    for (uint32_t j = 0; j < n4; ++j) {
       const double sj = s[j];
-      const bool eq = (sj == si);
-      r += (sj > si) || (eq && j < i);
-      tie |= eq && (j != i);
+      g0 += sj > a0;
+      g1 += sj > a1;
     }
-    unmap[r] = i;
+    unmap[g0] = i0;            // exact whenever no two scores tie
+    pa[i0] = (g0 << 16) | i0;  // identity arrangement, as queryresults.cc:50-51
+    if (has1) {
+      unmap[g1] = i1;
+      pa[i1] = (g1 << 16) | i1;
+    }
   }
+  __syncthreads();
+  for (uint32_t i = lane; i < n; i += 64) tie |= unmap[pa[i] >> 16] != i;
+  if (lane < n4 - n) pa[n + lane] = 0xFFFFFFFFu;
   const bool anytie = __any(tie);
   __syncthreads();
-  // ---- 2. exact std::sort tie order
-  if (anytie) {
-    if (lane == 0) {
-      for (uint32_t i = 0; i < n; ++i) unmap[i] = i;
-      DescCmp c{s};
-      g_gnu_sort(unmap, (int)n, c);
-    }
-    __syncthreads();
-  }
+  QR_T(2);
+  // ---- 2. with ties the permutation is what GNU std::sort leaves
+  if (anytie) wave_gnu_sort(pa, (int)n, LB, RB, stk, unmap);
+  QR_T(3);
   for (uint32_t r = lane; r < n; r += 64) {
     const uint32_t d = unmap[r];
     sl[r] = lab0[d];
+    sr[r] = s[d];
     if (ranks_out) ranks_out[off + r] = d;
   }
   __syncthreads();
@@ -282,6 +534,7 @@ __global__ __launch_bounds__(64) void k_lambda(
     if (metric == QR_METRIC_NDCG) m = my_idcg > 0 ? dcg / my_idcg : 0.0;
     qmetric[q] = m;
   }
+  QR_T(4);
   if (mode == 1) return;
   // ---- 4. lambdas
   if (metric == QR_METRIC_NDCG && !(my_idcg > 0.0)) {
@@ -293,72 +546,73 @@ __global__ __launch_bounds__(64) void k_lambda(
     if (lane == 0 && ssq) ssq[2 * q] = ssq[2 * q + 1] = 0.0;
     return;
   }
-  for (uint32_t i = lane; i < size; i += 64) {
-    accl[i] = 0.0;
-    accw[i] = 0.0;
+  for (uint32_t i = lane; i < n; i += 64) {
+    ownl[i] = 0.0;
+    ownw[i] = 0.0;
+    s[i] = pow2_label(sl[i]);  // 2^label by rank (scores by doc are no longer needed)
   }
+  for (uint32_t i = lane; i < size; i += 64) ilt[i] = ilg2[i];
+  expt[lane] = QR_EXP_T[lane];
   __syncthreads();
+  const double *pw = s;
   const uint32_t nbatch = (n + 63) / 64;
-  for (uint32_t bt = 0; bt < nbatch; ++bt) {
-    const uint32_t r2 = bt * 64 + lane;
-    const bool live = r2 < n;
-    const float l2 = live ? sl[r2] : 0.f;
-    const double p2 = live ? pow2_label(l2) : 0.0;
-    const double s2 = live ? s[unmap[r2]] : 0.0;
-    const double inv2 = live ? 1.0 / lg2[r2] : 0.0;
-    double al = 0.0, aw = 0.0;
-    // r1 only needs to reach the ranks below the highest r2 of this batch
-    const uint32_t r1_end = size < bt * 64 + 64 ? size : bt * 64 + 64;
-    for (uint32_t r1 = 0; r1 < r1_end; ++r1) {
-      const float l1 = sl[r1];
-      double c1 = 0.0, cw = 0.0;
-      if (live && r1 < r2 && l1 != l2) {
-        const double p1 = pow2_label(l1);
-        const double inv1 = 1.0 / lg2[r1];
-        double j;
-        if (r2 < size)
-          j = (inv2 - inv1) * (p1 - p2);
-        else
-          j = (-inv1) * (p1 - p2);
-        if (metric == QR_METRIC_NDCG) j = j / my_idcg;
-        const double d = fabs(j);
-        const double s1 = s[unmap[r1]];
-        const bool hi1 = l1 > l2;  // the higher label plays "j" in lambdamart.cc:127
-        const double diff = hi1 ? s1 - s2 : s2 - s1;
-        const double rho = 1.0 / (1.0 + exp(diff));
-        const double lam = rho * d;
-        const double del = rho * (1.0 - rho) * d;
-        c1 = hi1 ? lam : -lam;
-        cw = del;
-        al += hi1 ? -lam : lam;
-        aw += del;
-      }
-      if (__any(c1 != 0.0 || cw != 0.0)) {
-        const double t1 = wave_sum(c1);
-        const double tw = wave_sum(cw);
-        if (lane == 0) {
-          accl[r1] += t1;
-          accw[r1] += tw;
+  for (uint32_t r1 = 0; r1 < size; ++r1) {
+    // uniform over the wave
+    const float l1 = sl[r1];
+    const double p1 = pw[r1];
+    const double inv1 = ilt[r1];
+    const double s1 = sr[r1];
+    double c1 = 0.0, cw = 0.0;
+    for (uint32_t bt = r1 / 64; bt < nbatch; ++bt) {
+      const uint32_t r2 = bt * 64 + lane;
+      if (r2 < n && r2 > r1) {
+        const float l2 = sl[r2];
+        if (l1 != l2) {
+          const double p2 = pw[r2];
+          double j;
+          if (r2 < size)
+            j = (ilt[r2] - inv1) * (p1 - p2);
+          else
+            j = (-inv1) * (p1 - p2);
+          if (metric == QR_METRIC_NDCG) j = j / my_idcg;
+          const double d = fabs(j);
+          const bool hi1 = l1 > l2;  // the higher label plays "j" in lambdamart.cc:127
+          const double s2 = sr[r2];
+          const double diff = hi1 ? s1 - s2 : s2 - s1;
+          const double rho = 1.0 / (1.0 + qr_exp(diff, expt));
+          const double lam = rho * d;
+          const double del = rho * (1.0 - rho) * d;
+          c1 += hi1 ? lam : -lam;
+          cw += del;
+          ownl[r2] += hi1 ? -lam : lam;  // only this lane touches rank r2
+          ownw[r2] += del;
         }
       }
     }
-    if (live) {
-      const uint32_t d = off + unmap[r2];
-      lambda[d] = al;
-      weight[d] = aw;
+    if (__any(c1 != 0.0 || cw != 0.0)) {
+      const double t1 = wave_sum(c1);
+      const double tw = wave_sum(cw);
+      if (lane == 0) {
+        accl[r1] = t1;
+        accw[r1] = tw;
+      }
+    } else if (lane == 0) {
+      accl[r1] = 0.0;
+      accw[r1] = 0.0;
     }
   }
   __syncthreads();
-  // fold the top-`size` accumulators in (same lane wrote the own part: r % 64)
+  QR_T(5);
   double mx = 0.0, sq = 0.0, sm = 0.0;
   for (uint32_t r = lane; r < n; r += 64) {
     const uint32_t d = off + unmap[r];
-    double l = lambda[d];
+    double l = ownl[r], w = ownw[r];
     if (r < size) {
       l += accl[r];
-      lambda[d] = l;
-      weight[d] += accw[r];
+      w += accw[r];
     }
+    lambda[d] = l;
+    weight[d] = w;
     const double a = fabs(l);
     mx = a > mx ? a : mx;
     sq += l * l;
@@ -374,6 +628,13 @@ __global__ __launch_bounds__(64) void k_lambda(
       ssq[2 * q + 1] = sm;
     }
   }
+#ifdef QR_LAMBDA_TIMING
+  QR_T(6);
+  if (lane == 0 && (q == 0 || q == 5000))
+    printf("k_lambda q=%u n=%u tie=%d: load %lld count %lld sort %lld rank/metric %lld pairs %lld out %lld total %lld\n",
+           q, n, (int)anytie, tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4],
+           tq[6] - tq[5], tq[6] - tq[0]);
+#endif
 }
 
 // Mart::compute_pseudoresponses (mart.cc:418-431): label - score
@@ -466,7 +727,9 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
 
 // ---------------------------------------------------------------------------
 static size_t lambda_lds(size_t nmax, size_t kacc) {
-  return nmax * 8 + kacc * 16 + nmax * 12;
+  // s/sr[nmax] f64, accl/accw[kacc] f64, ownl/ownw[nmax] f64 (aliased by the sort
+  // scratch), lab0/sl f32, unmap u32, stk, ilt[kacc] f64
+  return nmax * 16 + kacc * 16 + nmax * 16 + nmax * 12 + 3 * 64 * 4 + kacc * 8 + 64 * 8;
 }
 
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
@@ -476,27 +739,28 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   const uint32_t cut = cutoff == 0 ? NO_CUTOFF : (uint32_t)cutoff;
   size_t kacc = cutoff == 0 || cutoff > maxq ? maxq : cutoff;
   if (kacc == 0) kacc = 1;
-  const size_t nmax = (maxq + 1) & ~(size_t)1;
+  const size_t nmax = (maxq + 3) & ~(size_t)3;
   kacc = (kacc + 1) & ~(size_t)1;
   const size_t lds = lambda_lds(nmax, kacc);
-  if (lds > 160 * 1024 - 512)
+  if (lds > 160 * 1024 - 512 || maxq > 65535)
     QR_FAIL(c, QR_ERR_UNSUPPORTED,
-            "query too long for the LDS-resident lambda kernel (max ~7000 docs "
-            "with a cutoff, ~4400 without)");
-  if (lds > 64 * 1024)
+            "query too long for the LDS-resident lambda kernel (max ~3600 docs)");
+  static size_t attr_lds = 64 * 1024;
+  if (lds > attr_lds) {
     QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
   if (which == 0) {
     hipLaunchKernelGGL(k_lambda, dim3((unsigned)Q), dim3(64), lds, c->stream,
                        c->d_scores, c->d_labels, c->d_qoff, metric, cut, c->d_idcg,
-                       c->d_lg2, c->d_lambda, c->d_weight, c->d_qmetric, c->d_ranks,
+                       c->d_lg2, c->d_ilg2, c->d_lambda, c->d_weight, c->d_qmetric, c->d_ranks,
                        mode == 0 ? c->d_ssq : nullptr, c->d_scalars, (uint32_t)nmax,
                        (uint32_t)kacc, mode);
   } else {
     hipLaunchKernelGGL(k_lambda, dim3((unsigned)Q), dim3(64), lds, c->stream,
                        c->d_vscores, c->d_vlabels, c->d_vqoff, metric, cut,
-                       c->d_vidcg, c->d_lg2, (double *)nullptr, (double *)nullptr,
+                       c->d_vidcg, c->d_lg2, c->d_ilg2, (double *)nullptr, (double *)nullptr,
                        c->d_vqmetric, (uint32_t *)nullptr, (double *)nullptr,
                        c->d_scalars, (uint32_t)nmax, (uint32_t)kacc, 1);
   }

@@ -43,12 +43,11 @@ __device__ __forceinline__ long long quantize(double x) {
   return __double_as_longlong(x + magic) - __double_as_longlong(magic);
 }
 
-template <int CH>
+template <int CH, bool IDENTITY>
 __device__ __forceinline__ void hist_accumulate(
     u64 *__restrict__ hist, const uint8_t *__restrict__ bins_b,
-    const uint32_t *__restrict__ order, const bool identity,
-    const uint32_t seg_begin, const uint32_t r0, const uint32_t r1,
-    const double *__restrict__ lambda, const double scale) {
+    const uint32_t *__restrict__ order, const uint32_t seg_begin, const uint32_t r0,
+    const uint32_t r1, const double *__restrict__ lambda, const double scale) {
   constexpr int FW = 16 * CH;
   constexpr int DW = 64 / CH;
   const int lane = threadIdx.x & 63;
@@ -63,34 +62,75 @@ __device__ __forceinline__ void hist_accumulate(
   for (int k = 0; k < 16; ++k) colk[k] = 16 * c + ((k + r) & 15);
   const int dr = r >> 2;       // dword rotation
   const uint32_t br = r & 3;   // byte rotation inside a dword
-  for (uint32_t base = r0 + wave * DW; base < r1; base += nw * DW) {
-    const uint32_t pos = base + dsub;
-    if (lane_ok && pos < r1) {
-      const uint32_t id = identity ? seg_begin + pos : order[seg_begin + pos];
-      const uint4 row =
-          *reinterpret_cast<const uint4 *>(bins_b + (size_t)id * FW + 16 * c);
-      const double lam = lambda[id];
-      const u64 addend = (1ull << QR_SB) + (u64)quantize(lam * scale);
-      // rotate the 16 bytes right by r so that byte k of R is byte (k+r)&15
-      uint32_t t0 = (dr & 1) ? row.y : row.x;
-      uint32_t t1 = (dr & 1) ? row.z : row.y;
-      uint32_t t2 = (dr & 1) ? row.w : row.z;
-      uint32_t t3 = (dr & 1) ? row.x : row.w;
-      const uint32_t u0 = (dr & 2) ? t2 : t0;
-      const uint32_t u1 = (dr & 2) ? t3 : t1;
-      const uint32_t u2 = (dr & 2) ? t0 : t2;
-      const uint32_t u3 = (dr & 2) ? t1 : t3;
-      uint32_t R[4];
-      R[0] = __builtin_amdgcn_alignbyte(u1, u0, br);
-      R[1] = __builtin_amdgcn_alignbyte(u2, u1, br);
-      R[2] = __builtin_amdgcn_alignbyte(u3, u2, br);
-      R[3] = __builtin_amdgcn_alignbyte(u0, u3, br);
+  auto process = [&](const uint4 &row, const double lam) {
+    const u64 addend = (1ull << QR_SB) + (u64)quantize(lam * scale);
+    // rotate the 16 bytes right by r so that byte k of R is byte (k+r)&15
+    const uint32_t t0 = (dr & 1) ? row.y : row.x;
+    const uint32_t t1 = (dr & 1) ? row.z : row.y;
+    const uint32_t t2 = (dr & 1) ? row.w : row.z;
+    const uint32_t t3 = (dr & 1) ? row.x : row.w;
+    const uint32_t u0 = (dr & 2) ? t2 : t0;
+    const uint32_t u1 = (dr & 2) ? t3 : t1;
+    const uint32_t u2 = (dr & 2) ? t0 : t2;
+    const uint32_t u3 = (dr & 2) ? t1 : t3;
+    uint32_t R[4];
+    R[0] = __builtin_amdgcn_alignbyte(u1, u0, br);
+    R[1] = __builtin_amdgcn_alignbyte(u2, u1, br);
+    R[2] = __builtin_amdgcn_alignbyte(u3, u2, br);
+    R[3] = __builtin_amdgcn_alignbyte(u0, u3, br);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const uint32_t bin = (R[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        atomicAdd(&hist[bin * FW + colk[k]], addend);
-      }
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t bin = (R[k >> 2] >> (8 * (k & 3))) & 0xffu;
+      atomicAdd(&hist[bin * FW + colk[k]], addend);
     }
+  };
+  // Software pipeline: three register sets rotate (A, B, C), so two tiles of
+  // loads stay in flight behind the tile whose 16 LDS atomics are issuing; in the
+  // gather case each set also keeps the document id of its NEXT tile in flight.
+  // No register copies between stages (a copy would wait for the load it forwards).
+  const uint32_t step = nw * DW;
+  const uint32_t p0 = r0 + wave * DW + dsub;
+  auto valid = [&](uint32_t p) { return lane_ok && p < r1; };
+  auto get_id = [&](uint32_t p) -> uint32_t {
+    return IDENTITY ? seg_begin + p : order[seg_begin + p];
+  };
+  auto load_row = [&](uint32_t id) -> uint4 {
+    return *reinterpret_cast<const uint4 *>(bins_b + (size_t)id * FW + 16 * c);
+  };
+  // Loads are unconditional (positions clamped into the range) so that no
+  // exec-masked branch surrounds a VMEM instruction: the compiler then emits
+  // counted s_waitcnt vmcnt(N) instead of draining the queue at every stage.
+  const uint32_t plast = r1 - 1;
+  auto clampp = [&](uint32_t p) { return p < plast ? p : plast; };
+  uint4 rowA, rowB, rowC;
+  double lamA, lamB, lamC;
+  uint32_t idA, idB, idC;
+  bool vA = valid(p0), vB = valid(p0 + step), vC = valid(p0 + 2 * step);
+  idA = get_id(clampp(p0));
+  idB = get_id(clampp(p0 + step));
+  idC = get_id(clampp(p0 + 2 * step));
+  rowA = load_row(idA); lamA = lambda[idA];
+  rowB = load_row(idB); lamB = lambda[idB];
+  rowC = load_row(idC); lamC = lambda[idC];
+  idA = get_id(clampp(p0 + 3 * step));
+  idB = get_id(clampp(p0 + 4 * step));
+  idC = get_id(clampp(p0 + 5 * step));
+  uint32_t pos = p0;
+  for (uint32_t tile = r0 + wave * DW; tile < r1; tile += 3 * step, pos += 3 * step) {
+    if (vA) process(rowA, lamA);
+    vA = valid(pos + 3 * step);
+    rowA = load_row(idA); lamA = lambda[idA];
+    idA = get_id(clampp(pos + 6 * step));
+
+    if (vB) process(rowB, lamB);
+    vB = valid(pos + 4 * step);
+    rowB = load_row(idB); lamB = lambda[idB];
+    idB = get_id(clampp(pos + 7 * step));
+
+    if (vC) process(rowC, lamC);
+    vC = valid(pos + 5 * step);
+    rowC = load_row(idC); lamC = lambda[idC];
+    idC = get_id(clampp(pos + 8 * step));
   }
 }
 
@@ -139,11 +179,20 @@ __global__ __launch_bounds__(1024) void k_hist(
       hist[i + 1] = 0;
     }
     __syncthreads();
-    switch (fw) {
-      case 16: hist_accumulate<1>(hist, bins_b, order, identity, seg_begin, s0, s1, lambda, scale); break;
-      case 32: hist_accumulate<2>(hist, bins_b, order, identity, seg_begin, s0, s1, lambda, scale); break;
-      case 48: hist_accumulate<3>(hist, bins_b, order, identity, seg_begin, s0, s1, lambda, scale); break;
-      default: hist_accumulate<4>(hist, bins_b, order, identity, seg_begin, s0, s1, lambda, scale); break;
+    if (identity) {
+      switch (fw) {
+        case 16: hist_accumulate<1, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
+        case 32: hist_accumulate<2, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
+        case 48: hist_accumulate<3, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
+        default: hist_accumulate<4, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
+      }
+    } else {
+      switch (fw) {
+        case 16: hist_accumulate<1, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
+        case 32: hist_accumulate<2, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
+        case 48: hist_accumulate<3, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
+        default: hist_accumulate<4, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
+      }
     }
     __syncthreads();
     u64 *dst = partials + ((size_t)blockIdx.x * plan.kmax + k) * (256u * 64u);
@@ -154,6 +203,81 @@ __global__ __launch_bounds__(1024) void k_hist(
       *reinterpret_cast<ulonglong2 *>(dst + i) = v;
     }
     __syncthreads();
+  }
+}
+
+// ===========================================================================
+// k_reduce: sum the workgroup partials of one histogram launch, in the native
+// [bin][fw] cell order (fully coalesced 8-byte reads), unpacking count and sum.
+// One workgroup = 64 consecutive cells x 4 slot groups; exact integers, so the
+// reduction order is free.
+// ===========================================================================
+__global__ __launch_bounds__(512) void k_reduce(
+    const QrTreeState *__restrict__ ts, const int root_mode, const uint32_t N,
+    const QrBlock *__restrict__ blocks, const int nblocks, const int G,
+    const u64 *__restrict__ partials, long long *__restrict__ red_sum,
+    uint32_t *__restrict__ red_cnt) {
+  __shared__ long long sh_s[512];
+  __shared__ uint32_t sh_c[512];
+  __shared__ QrPlan plan;
+  uint32_t n;
+  if (root_mode) {
+    n = N;
+  } else {
+    if (!ts->desc.active) return;
+    n = ts->desc.small_n;
+  }
+  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, G, &plan);
+  __syncthreads();
+  // which block does this workgroup's cell range belong to?
+  uint32_t cell0 = blockIdx.x * 64u;  // over the concatenation of 256*fw cells per block
+  int b = -1;
+  uint32_t base = 0;
+  for (int i = 0; i < nblocks; ++i) {
+    const uint32_t cells = 256u * blocks[i].fw;
+    if (b < 0 && cell0 < base + cells) {
+      b = i;
+      cell0 -= base;
+    }
+    if (b < 0) base += cells;
+  }
+  if (b < 0) return;
+  const uint32_t c = threadIdx.x & 63, g = threadIdx.x >> 6;  // 8 slot groups
+  const uint32_t per = plan.per[b];
+  const int W = plan.wg_start[b + 1] - plan.wg_start[b];
+  const int kmax = plan.kmax;
+  const int total = W * kmax;
+  const u64 *src = partials + (size_t)plan.wg_start[b] * kmax * (256u * 64u) + cell0 + c;
+  long long s = 0;
+  uint32_t cn = 0;
+#pragma unroll 4
+  for (int idx = (int)g; idx < total; idx += 8) {
+    bool valid = true;
+    if (kmax > 1) {  // workgroup j flushed only ceil(docs_j / QR_DPW) slots
+      const int j = idx / kmax, k = idx - j * kmax;
+      const uint32_t r0 = j * per;
+      const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
+      valid = k < (int)((r1 - r0 + QR_DPW - 1) / QR_DPW);
+    }
+    if (valid) {
+      const u64 cell = src[(size_t)idx * (256u * 64u)];
+      const u64 cnt = (cell + (1ull << (QR_SB - 1))) >> QR_SB;
+      s += (long long)(cell - (cnt << QR_SB));
+      cn += (uint32_t)cnt;
+    }
+  }
+  sh_s[threadIdx.x] = s;
+  sh_c[threadIdx.x] = cn;
+  __syncthreads();
+  if (g == 0) {
+    s = 0;
+    cn = 0;
+    for (int i = 0; i < 8; ++i) {
+      s += sh_s[i * 64 + c];
+      cn += sh_c[i * 64 + c];
+    }
+    red_sum[base + cell0 + c] = s;
+    red_cnt[base + cell0 + c] = cn;
   }
 }
 
@@ -209,9 +333,9 @@ __device__ __forceinline__ Best slot_gain(long long cs, uint32_t cc, long long S
 
 __global__ __launch_bounds__(256) void k_scan(
     const QrTreeState *__restrict__ ts, const int root_mode, const uint32_t N,
-    const QrBlock *__restrict__ blocks, const int nblocks, const int G,
-    const u64 *__restrict__ partials, long long *__restrict__ hsum,
-    uint32_t *__restrict__ hcnt, const int flocal,
+    const QrBlock *__restrict__ blocks, const int nblocks,
+    const long long *__restrict__ red_sum, const uint32_t *__restrict__ red_cnt,
+    long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
     const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
     const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec) {
   __shared__ long long sh_s[4];
@@ -219,15 +343,12 @@ __global__ __launch_bounds__(256) void k_scan(
   __shared__ long long tot_s[2];
   __shared__ uint32_t tot_c[2];
   __shared__ Best sh_b[4];
-  uint32_t n;
   int small_slot, big_slot = -1, parent_slot = -1, small_is_left = 1;
   u64 minls = ts->minls;
   if (root_mode) {
-    n = N;
     small_slot = 0;
   } else {
     if (!ts->desc.active) return;
-    n = ts->desc.small_n;
     small_slot = ts->desc.small_slot;
     big_slot = ts->desc.big_slot;
     parent_slot = ts->desc.parent_slot;
@@ -235,30 +356,19 @@ __global__ __launch_bounds__(256) void k_scan(
   }
   const int lf = blockIdx.x;
   int b = 0;
-  for (int i = 0; i < nblocks; ++i)
-    if (lf >= blocks[i].lf0 && lf < blocks[i].lf0 + blocks[i].nreal) b = i;
+  uint32_t base = 0, mybase = 0;
+  for (int i = 0; i < nblocks; ++i) {
+    if (lf >= blocks[i].lf0 && lf < blocks[i].lf0 + blocks[i].nreal) {
+      b = i;
+      mybase = base;
+    }
+    base += 256u * blocks[i].fw;
+  }
   const int col = lf - blocks[b].lf0;
   const int fw = blocks[b].fw;
-  __shared__ QrPlan plan;
-  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, G, &plan);
-  __syncthreads();
   const uint32_t t = threadIdx.x;
-  long long s = 0;
-  uint32_t cn = 0;
-  const uint32_t per = plan.per[b];
-  const int W = plan.wg_start[b + 1] - plan.wg_start[b];
-  for (int j = 0; j < W; ++j) {
-    const uint32_t r0 = j * per;
-    const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
-    const int nk = (int)((r1 - r0 + QR_DPW - 1) / QR_DPW);
-    for (int k = 0; k < nk; ++k) {
-      const size_t slot = (size_t)(plan.wg_start[b] + j) * plan.kmax + k;
-      const u64 cell = partials[slot * (256u * 64u) + (size_t)t * fw + col];
-      const u64 cnt = (cell + (1ull << (QR_SB - 1))) >> QR_SB;
-      s += (long long)(cell - (cnt << QR_SB));
-      cn += (uint32_t)cnt;
-    }
-  }
+  long long s = red_sum[mybase + t * fw + col];
+  uint32_t cn = red_cnt[mybase + t * fw + col];
   // inclusive scan over the 256 slots (exact integers: any association)
   const int lane = t & 63, wave = t >> 6;
   for (int off = 1; off < 64; off <<= 1) {
@@ -334,30 +444,37 @@ __global__ __launch_bounds__(256) void k_scan(
 // global order and the comparison is strict, so the lowest feature wins ties
 // (rt.cc:297-306).  Also attaches lcount/rcount from the node histogram.
 // ===========================================================================
-__global__ __launch_bounds__(64) void k_merge(
+__global__ __launch_bounds__(128) void k_merge(
     const QrTreeState *__restrict__ ts, const int root_mode,
     const qr_split_t *__restrict__ featrec, const int flocal,
     const long long *__restrict__ hsum, const uint32_t *__restrict__ hcnt,
     const int32_t *__restrict__ gf2lf, qr_split_t *__restrict__ recs_local) {
   if (!root_mode && !ts->desc.active) return;
-  const int which = threadIdx.x;
-  if (which >= 2) return;
-  if (root_mode && which == 1) {
-    recs_local[1].score = -1.0;
-    recs_local[1].feature = 0xFFFFFFFFu;
-    recs_local[1].thr_id = 0xFFFFFFFFu;
-    recs_local[1].lcount = recs_local[1].rcount = 0;
-    return;
-  }
+  const int which = threadIdx.x >> 6;  // wave 0: left child (or root), wave 1: right
+  const int lane = threadIdx.x & 63;
   qr_split_t best;
   best.score = -1.0;
   best.feature = 0xFFFFFFFFu;
   best.thr_id = 0xFFFFFFFFu;
   best.lcount = best.rcount = 0;
-  for (int lf = 0; lf < flocal; ++lf) {
-    const qr_split_t r = featrec[(size_t)which * flocal + lf];
-    if (r.score > best.score) best = r;
+  if (!(root_mode && which == 1)) {
+    for (int lf = lane; lf < flocal; lf += 64) {
+      const qr_split_t r = featrec[(size_t)which * flocal + lf];
+      if (r.score > best.score) best = r;  // ascending lf within the lane
+    }
+    // butterfly: higher score wins, equal scores -> lower feature index
+    for (int off = 32; off > 0; off >>= 1) {
+      const double os = __shfl_xor(best.score, off, 64);
+      const uint32_t of = __shfl_xor(best.feature, off, 64);
+      const uint32_t ot = __shfl_xor(best.thr_id, off, 64);
+      if (os > best.score || (os == best.score && of < best.feature)) {
+        best.score = os;
+        best.feature = of;
+        best.thr_id = ot;
+      }
+    }
   }
+  if (lane != 0) return;
   if (best.feature != 0xFFFFFFFFu) {
     int slot;
     if (root_mode)
@@ -502,6 +619,20 @@ __global__ __launch_bounds__(64) void k_decide(
     const int world, const QrScalars *__restrict__ scal,
     const double *__restrict__ part_ss, const float *__restrict__ thr,
     const int32_t *__restrict__ gf2lf) {
+  // squares_sum_ / sum of the directly built child: fixed-order reduction of the
+  // partition workgroups' partials by the whole wave
+  double ss_small = 0.0, sum_small = 0.0;
+  if (ts->step != 0 && ts->desc.active) {
+    const uint32_t nwg = (ts->desc.end - ts->desc.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
+    for (uint32_t i = threadIdx.x; i < nwg; i += 64) {
+      ss_small += part_ss[2 * i];
+      sum_small += part_ss[2 * i + 1];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      ss_small += __shfl_xor(ss_small, off, 64);
+      sum_small += __shfl_xor(sum_small, off, 64);
+    }
+  }
   if (threadIdx.x != 0) return;
   if (ts->step == 0) {
     QrNode *root = &ts->nodes[0];
@@ -536,12 +667,6 @@ __global__ __launch_bounds__(64) void k_decide(
     const QrSplitDesc d = ts->desc;
     QrNode *P = &ts->nodes[d.node];
     QrNode *S = &ts->nodes[d.small_node], *B = &ts->nodes[d.big_node];
-    const uint32_t nwg = (d.end - d.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
-    double ss_small = 0.0, sum_small = 0.0;
-    for (uint32_t i = 0; i < nwg; ++i) {
-      ss_small += part_ss[2 * i];
-      sum_small += part_ss[2 * i + 1];
-    }
     // directly accumulated child, sibling by subtraction
     // (rtnode_histogram.cc:65-69, 79-86)
     node_stats(S, sum_small, ss_small, d.small_n);
@@ -825,27 +950,34 @@ __global__ __launch_bounds__(256) void k_leaf_sums(
 }
 
 // rt.cc:165-207
-__global__ __launch_bounds__(256) void k_leaf_final(QrTreeState *__restrict__ ts,
-                                                    const double *__restrict__ leafpart,
-                                                    const int newton) {
+__global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ ts,
+                                                     const double *__restrict__ leafpart,
+                                                     const int newton) {
   const int nl = ts->nleaves;
-  for (int l = threadIdx.x; l < nl; l += blockDim.x) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int l = wave; l < nl; l += 16) {  // one wave per leaf, fixed reduction tree
     const uint32_t b = ts->leaf_begin[l], e = ts->leaf_begin[l + 1];
     double s1 = 0.0, s2 = 0.0;
     if (e > b) {
       const uint32_t sl0 = b / QR_SLICE, sl1 = (e - 1) / QR_SLICE;
-      for (uint32_t s = sl0; s <= sl1; ++s) {
+      for (uint32_t s = sl0 + lane; s <= sl1; s += 64) {
         s1 += leafpart[2 * ((size_t)s + l)];
         s2 += leafpart[2 * ((size_t)s + l) + 1];
       }
     }
-    double v;
-    if (newton)
-      v = s2 >= 2.2204460492503131e-16 ? s1 / s2 : 0.0;  // DBL_EPSILON
-    else
-      v = s1 / (double)(e - b);
-    ts->leaf_value[l] = v;
-    ts->nodes[ts->leaf_nodes[l]].value = v;
+    for (int off = 32; off > 0; off >>= 1) {
+      s1 += __shfl_xor(s1, off, 64);
+      s2 += __shfl_xor(s2, off, 64);
+    }
+    if (lane == 0) {
+      double v;
+      if (newton)
+        v = s2 >= 2.2204460492503131e-16 ? s1 / s2 : 0.0;  // DBL_EPSILON
+      else
+        v = s1 / (double)(e - b);
+      ts->leaf_value[l] = v;
+      ts->nodes[ts->leaf_nodes[l]].value = v;
+    }
   }
 }
 
@@ -926,12 +1058,18 @@ static int launch_hist_scan(qr_ctx *c, int root_mode) {
     QR_CHECK(c, hipEventRecord(e1, c->stream));
     c->prof_events.push_back({e0, e1});
   }
-  hipLaunchKernelGGL(k_scan, dim3(c->flocal), dim3(256), 0, c->stream, c->d_tree,
-                     root_mode, (uint32_t)c->N, c->d_blocks, c->nblocks, G,
-                     (const u64 *)c->d_partials, c->d_hsum, c->d_hcnt, c->flocal,
-                     c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec);
+  size_t cells = 0;
+  for (const auto &b : c->blocks) cells += (size_t)256 * b.fw;
+  hipLaunchKernelGGL(k_reduce, dim3((unsigned)(cells / 64)), dim3(512), 0, c->stream,
+                     c->d_tree, root_mode, (uint32_t)c->N, c->d_blocks, c->nblocks, G,
+                     (const u64 *)c->d_partials, c->d_red_sum, c->d_red_cnt);
   QR_CHECK(c, hipGetLastError());
-  hipLaunchKernelGGL(k_merge, dim3(1), dim3(64), 0, c->stream, c->d_tree, root_mode,
+  hipLaunchKernelGGL(k_scan, dim3(c->flocal), dim3(256), 0, c->stream, c->d_tree,
+                     root_mode, (uint32_t)c->N, c->d_blocks, c->nblocks, c->d_red_sum,
+                     c->d_red_cnt, c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size,
+                     c->d_lf2gf, c->d_scalars, c->d_featrec);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_merge, dim3(1), dim3(128), 0, c->stream, c->d_tree, root_mode,
                      c->d_featrec, c->flocal, c->d_hsum, c->d_hcnt, c->d_gf2lf,
                      c->d_recs_local);
   QR_CHECK(c, hipGetLastError());
@@ -998,7 +1136,7 @@ int qr_k_tree_finish(qr_ctx *c, int newton) {
                      c->d_order[0], c->d_order[1], c->d_lambda,
                      newton ? c->d_weight : (const double *)nullptr, c->d_leafpart);
   QR_CHECK(c, hipGetLastError());
-  hipLaunchKernelGGL(k_leaf_final, dim3(1), dim3(256), 0, c->stream, c->d_tree,
+  hipLaunchKernelGGL(k_leaf_final, dim3(1), dim3(1024), 0, c->stream, c->d_tree,
                      c->d_leafpart, newton);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;

@@ -70,6 +70,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins);
   dfree(c->d_thr); dfree(c->d_thr_size);
   dfree(c->d_order[0]); dfree(c->d_order[1]); dfree(c->d_partials);
+  dfree(c->d_red_sum); dfree(c->d_red_cnt);
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
   dfree(c->d_blkcnt); dfree(c->d_part_ss); dfree(c->d_tree); dfree(c->d_leafpart);
@@ -79,7 +80,7 @@ static void free_train(qr_ctx *c) {
 }
 static void free_valid(qr_ctx *c) {
   dfree(c->d_vraw); dfree(c->d_vlabels); dfree(c->d_vqoff); dfree(c->d_vscores);
-  dfree(c->d_vidcg); dfree(c->d_vqmetric);
+  dfree(c->d_vidcg); dfree(c->d_vqmetric); dfree(c->d_vranks);
   c->vN = c->vQ = 0;
 }
 
@@ -89,7 +90,8 @@ void qr_ctx_destroy(qr_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_train(c);
   free_valid(c);
-  dfree(c->d_lg2); dfree(c->d_scalars); dfree(c->d_ens); dfree(c->d_ens_w);
+  dfree(c->d_lg2); dfree(c->d_ilg2); dfree(c->d_scalars); dfree(c->d_ens); dfree(c->d_ens_w);
+  dfree(c->d_keys); dfree(c->d_tied);
   for (auto &p : c->prof_events) {
     (void)hipEventDestroy(p.first);
     (void)hipEventDestroy(p.second);
@@ -144,7 +146,24 @@ static int upload_queries(qr_ctx *c, const uint64_t *qoff, size_t Q, size_t N,
   return QR_OK;
 }
 
+static int ensure_rank_scratch(qr_ctx *c) {
+  const size_t nk = std::max(c->N, c->vN), nq = std::max(c->Q, c->vQ);
+  if (nk > c->keys_cap) {
+    dfree(c->d_keys);
+    QR_CHECK(c, dalloc(&c->d_keys, nk));
+    c->keys_cap = nk;
+  }
+  if (nq > c->tied_cap || !c->d_tied) {
+    dfree(c->d_tied);
+    QR_CHECK(c, dalloc(&c->d_tied, nq + 1));
+    c->tied_cap = nq;
+  }
+  return QR_OK;
+}
+
 static int ensure_lg2(qr_ctx *c) {
+  int rc0 = ensure_rank_scratch(c);
+  if (rc0) return rc0;
   const size_t need = std::max(c->maxq, c->vmaxq) + 2;
   if (need <= c->lg2_len) return QR_OK;
   std::vector<double> t(need);
@@ -152,8 +171,13 @@ static int ensure_lg2(qr_ctx *c) {
   // (double)(j + 2): identical values while r + 2 < 2^24.
   for (size_t r = 0; r < need; ++r) t[r] = log2((double)((float)r + 2.0f));
   dfree(c->d_lg2);
+  dfree(c->d_ilg2);
   QR_CHECK(c, dalloc(&c->d_lg2, need));
   QR_CHECK(c, hipMemcpy(c->d_lg2, t.data(), need * 8, hipMemcpyHostToDevice));
+  // ndcg.cc:78-79: 1.0f / log2((double)(j + 2)) -- one IEEE division, tabulated
+  for (size_t r = 0; r < need; ++r) t[r] = 1.0 / t[r];
+  QR_CHECK(c, dalloc(&c->d_ilg2, need));
+  QR_CHECK(c, hipMemcpy(c->d_ilg2, t.data(), need * 8, hipMemcpyHostToDevice));
   c->lg2_len = need;
   return QR_OK;
 }
@@ -210,6 +234,7 @@ int qr_valid_upload(qr_ctx *c, const float *x, size_t N, const float *labels,
   QR_CHECK(c, hipMemset(c->d_vscores, 0, N * 8));
   QR_CHECK(c, dalloc(&c->d_vidcg, Q));
   QR_CHECK(c, dalloc(&c->d_vqmetric, Q));
+  QR_CHECK(c, dalloc(&c->d_vranks, N));
   c->vidcg_metric = -1;
   return ensure_lg2(c);
 }
@@ -345,6 +370,12 @@ int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
   qr_make_plan((uint32_t)N, c->nblocks, c->blocks.data(), c->ncu, &plan);
   c->partial_slots = (size_t)c->ncu * plan.kmax;
   QR_CHECK(c, dalloc(&c->d_partials, c->partial_slots * 256 * 64));
+  {
+    size_t cells = 0;
+    for (const auto &b : c->blocks) cells += (size_t)256 * b.fw;
+    QR_CHECK(c, dalloc(&c->d_red_sum, cells));
+    QR_CHECK(c, dalloc(&c->d_red_cnt, cells));
+  }
   QR_CHECK(c, dalloc(&c->d_featrec, 2 * (size_t)c->flocal));
   QR_CHECK(c, dalloc(&c->d_recs_local, (size_t)2));
   QR_CHECK(c, dalloc(&c->d_recs_all, 2 * (size_t)c->world));

@@ -182,17 +182,23 @@ struct qr_ctx {
   double *d_scores = nullptr, *d_lambda = nullptr, *d_weight = nullptr;
   // lambda / metric
   double *d_lg2 = nullptr;       // log2(r + 2), r < maxq(+valid)
+  double *d_ilg2 = nullptr;      // 1.0 / log2(r + 2)
   size_t lg2_len = 0;
   double *d_idcg = nullptr, *d_vidcg = nullptr;
   int idcg_metric = -1, vidcg_metric = -1;
   size_t idcg_cutoff = (size_t)-1, vidcg_cutoff = (size_t)-1;
   double *d_qmetric = nullptr, *d_vqmetric = nullptr;
-  uint32_t *d_ranks = nullptr;
+  uint32_t *d_ranks = nullptr, *d_vranks = nullptr;
+  uint32_t *d_keys = nullptr;    // #strictly-greater scores per doc (k_rank)
+  uint32_t *d_tied = nullptr;    // queue of queries with tied scores; [tied_cap] = count
+  size_t tied_cap = 0, keys_cap = 0;
   double *d_ssq = nullptr;       // per-slice sum of squares partials
   QrScalars *d_scalars = nullptr;
   // tree
   uint32_t *d_order[2] = {nullptr, nullptr};
   uint64_t *d_partials = nullptr;
+  long long *d_red_sum = nullptr;  // partials reduced over workgroups, [block][bin][fw]
+  uint32_t *d_red_cnt = nullptr;
   size_t partial_slots = 0;
   long long *d_hsum = nullptr;   // [QR_MAXNODES..][flocal][256] cumulative fixed-point
   uint32_t *d_hcnt = nullptr;

@@ -78,17 +78,31 @@ class Mart:
         lam = self.algo == "LAMBDAMART"
         best_valid = best_train = -np.inf
         self.best_model = 0
+        # The lambda kernel ranks every query anyway, so the training metric of the
+        # scores it ranks (= the previous iteration's, mart.cc:347) falls out of it:
+        # without a validation set the bookkeeping of mart.cc:369-375 simply runs
+        # one iteration late (same values, same best model at the end).
+        fused = lam and valid is None
         for m in range(self.ntrees):
             if valid is not None and self.esr and m > self.best_model + self.esr:
                 break
             t0 = time.perf_counter()
             if lam:
                 self.ctx.compute_lambdas(self.metric, self.cutoff)
+                if fused and m > 0:
+                    mt = self.ctx.metric_last()
+                    self.train_metric.append(mt)
+                    if mt > best_train:
+                        best_train = mt
+                        self.best_model = m - 1
             else:
                 self.ctx.compute_residuals()
             nodes = self._fit_tree(newton=lam)
             self.ensemble.push(nodes, self.shrinkage)
             self.ctx.update_scores(self.shrinkage)
+            if fused:
+                self.iter_seconds.append(time.perf_counter() - t0)
+                continue
             mt = self.ctx.metric_eval(0, self.metric, self.cutoff) if eval_every else 0.0
             self.train_metric.append(mt)
             if valid is not None:
@@ -103,6 +117,12 @@ class Mart:
             self.iter_seconds.append(time.perf_counter() - t0)
             if verbose:
                 print(f"{m + 1:7d} {mt:9.4f}" + (f" {self.valid_metric[-1]:9.4f}" if valid else ""))
+        if fused and len(self.ensemble):
+            mt = self.ctx.metric_eval(0, self.metric, self.cutoff)
+            self.train_metric.append(mt)
+            if mt > best_train:
+                best_train = mt
+                self.best_model = len(self.ensemble) - 1
         if valid is not None:
             while len(self.ensemble) > self.best_model + 1:
                 self.ensemble.pop()

@@ -1,0 +1,132 @@
+"""Feature-sharded device protocol on ONE GPU: P contexts (rank r of P) on the
+same device, the two collectives of quickrank_amd/dist.py replaced by explicit
+copies between the contexts' exchange buffers.  The sharded trees must be
+bit-identical to the single-context tree (every feature's histogram lives on
+exactly one rank, integer accumulation)."""
+import numpy as np
+import pytest
+
+from datagen import make_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _views(torch, ctx, world):
+    from quickrank_amd.dist import _DevArray
+    b = ctx.exchange_buffers()
+    dev = torch.device("cuda", 0)
+    return dict(
+        loc=torch.as_tensor(_DevArray(b["recs_local"], b["rec_bytes"]), device=dev),
+        all=torch.as_tensor(_DevArray(b["recs_all"], b["rec_bytes"] * world), device=dev),
+        mask=torch.as_tensor(_DevArray(b["mask"], b["mask_bytes"], "<i4", 4), device=dev))
+
+
+def _sharded_fit(torch, ctxs, nleaves, minls):
+    world = len(ctxs)
+    v = [_views(torch, c, world) for c in ctxs]
+
+    def sync():
+        for c in ctxs:
+            c.synchronize()
+        torch.cuda.synchronize()
+
+    def gather():
+        sync()
+        cat = torch.cat([x["loc"] for x in v])
+        for x in v:
+            x["all"].copy_(cat)
+        sync()
+
+    def reduce_mask():
+        sync()
+        tot = v[0]["mask"].clone()
+        for x in v[1:]:
+            tot += x["mask"]
+        for x in v:
+            x["mask"].copy_(tot)
+        sync()
+
+    for c in ctxs:
+        c.tree_begin(nleaves, minls)
+    gather()
+    for _ in range(nleaves - 1):
+        for c in ctxs:
+            c.tree_decide()
+        reduce_mask()
+        for c in ctxs:
+            c.tree_apply()
+        gather()
+    for c in ctxs:
+        c.tree_decide()
+    return [c.tree_end(nleaves, True) for c in ctxs]
+
+
+@pytest.mark.parametrize("world,F", [(2, 136), (3, 70), (8, 136), (2, 9)])
+def test_sharded_contexts_equal_single(world, F, oracle_lib):
+    import torch
+    import quickrank_amd as qr
+    from quickrank_amd import build
+    build.build()
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=50, F=F, seed=17, adversarial=True)
+    rng = np.random.default_rng(2)
+    lam, w = oracle_lib.lambdas(labels, rng.standard_normal(len(labels)) * 0.3, qoff)
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(255)
+    single.set_pseudo(lam, w)
+    want = single.fit_tree(12, 3, True)
+    single.set_scores(np.zeros(len(labels)))
+    single.update_scores(0.1)
+    want_scores = single.get_scores()
+    ctxs = []
+    for r in range(world):
+        c = qr.Context(0, rank=r, world=world)
+        c.upload(x, labels, qoff)
+        c.build_bins(255)
+        c.set_pseudo(lam, w)
+        ctxs.append(c)
+    got = _sharded_fit(torch, ctxs, 12, 3)
+    for g in got:
+        assert len(g) == len(want)
+        for k in want.dtype.names:
+            assert np.array_equal(g[k], want[k], equal_nan=True) if g[k].dtype.kind == "f" else \
+                np.array_equal(g[k], want[k]), k
+    for c in ctxs:
+        c.set_scores(np.zeros(len(labels)))
+        c.update_scores(0.1)
+        assert np.array_equal(c.get_scores(), want_scores)
+        c.close()
+    single.close()
+
+
+def test_torch_distributed_fitter_world1(oracle_lib):
+    """The real ShardedTreeFitter over torch.distributed/nccl (RCCL) with one
+    rank: zero-copy tensor views of the exchange buffers, collectives enqueued on
+    the context's stream (= torch's current stream), no host sync inside a tree."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import quickrank_amd as qr
+    from quickrank_amd.dist import ShardedTreeFitter
+    x, labels, qoff = make_dataset(nq=50, docs_per_query=40, F=40, seed=5)
+    lam, w = oracle_lib.lambdas(labels, np.zeros(len(labels)), qoff)
+    ref = qr.Context(0)
+    ref.upload(x, labels, qoff)
+    ref.build_bins(64)
+    ref.set_pseudo(lam, w)
+    want = ref.fit_tree(8, 1, True)
+    ref.close()
+    torch.cuda.set_device(0)
+    port = 29600 + os.getpid() % 1000
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        c = qr.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        c.upload(x, labels, qoff)
+        c.build_bins(64)
+        c.set_pseudo(lam, w)
+        got = ShardedTreeFitter(c).fit_tree(c, 8, 1, True)
+        for k in want.dtype.names:
+            assert np.array_equal(got[k], want[k]), k
+        c.close()
+    finally:
+        dist.destroy_process_group()

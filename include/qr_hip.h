@@ -193,6 +193,17 @@ int qr_ensemble_score(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
 int qr_ensemble_score_device(qr_ctx *ctx, const void *d_rowmajor, size_t N,
                              size_t F, void *d_scores_out);
 
+/* ---- oblivious ensembles: the bit-interleaved scorer `quicklearn --generator    */
+/*      oblivious` emits (generate_oblivious.cc:237-324).  feat/thr: [ntrees][depth]*/
+/*      root level first; leaves: [ntrees][2^depth] DFS left-first; weights f32     */
+/*      (generate_oblivious.cc:166 parses them with as_float); depths: per-tree     */
+/*      number of levels actually used (NULL = all `depth`).                        */
+int qr_oblivious_upload(qr_ctx *ctx, const uint32_t *feat, const float *thr,
+                        const double *leaves, const float *weights,
+                        const uint32_t *depths, size_t ntrees, size_t depth);
+int qr_oblivious_score(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
+                       double *scores_out, float *kernel_ms);
+
 /* ---- instrumentation ---------------------------------------------------------*/
 /* HIP-event timing of the dominant kernel (root histogram build) accumulated    */
 /* since the last reset: launches, total ms, algorithmic bytes per launch.       */

@@ -35,7 +35,7 @@ SYMBOLS = [
     "qr_node_hist_read", "qr_node_samples_read", "qr_tree_split_log",
     "qr_metric_per_query", "qr_ranks_read", "qr_ensemble_upload",
     "qr_ensemble_score", "qr_ensemble_score_device", "qr_prof_reset",
-    "qr_prof_get", "qr_prof_enable",
+    "qr_prof_get", "qr_prof_enable", "qr_oblivious_upload", "qr_oblivious_score",
 ]
 
 _LIB = None
@@ -97,6 +97,8 @@ def lib():
     L.qr_ensemble_upload.argtypes = [vp, vp, sz, sz, vp]
     L.qr_ensemble_score.argtypes = [vp, vp, sz, sz, vp, C.POINTER(C.c_float)]
     L.qr_ensemble_score_device.argtypes = [vp, vp, sz, sz, vp]
+    L.qr_oblivious_upload.argtypes = [vp, vp, vp, vp, vp, vp, sz, sz]
+    L.qr_oblivious_score.argtypes = [vp, vp, sz, sz, vp, C.POINTER(C.c_float)]
     L.qr_prof_reset.argtypes = [vp]
     L.qr_prof_get.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.qr_prof_enable.argtypes = [vp, C.c_int]
@@ -307,6 +309,25 @@ class Context:
         ms = C.c_float()
         self._ck(self.L.qr_ensemble_score(self.h, _ptr(x), x.shape[0], x.shape[1], _ptr(out),
                                           C.byref(ms)))
+        return out, ms.value
+
+    def upload_oblivious(self, feat, thr, leaves, weights, depths=None):
+        feat = np.ascontiguousarray(feat, np.uint32)
+        thr = np.ascontiguousarray(thr, np.float32)
+        leaves = np.ascontiguousarray(leaves, np.float64)
+        weights = np.ascontiguousarray(weights, np.float32)
+        depths = None if depths is None else np.ascontiguousarray(depths, np.uint32)
+        T, D = feat.shape
+        assert leaves.shape == (T, 1 << D)
+        self._ck(self.L.qr_oblivious_upload(self.h, _ptr(feat), _ptr(thr), _ptr(leaves),
+                                            _ptr(weights), _ptr(depths), T, D))
+
+    def score_oblivious(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty(x.shape[0], np.float64)
+        ms = C.c_float()
+        self._ck(self.L.qr_oblivious_score(self.h, _ptr(x), x.shape[0], x.shape[1], _ptr(out),
+                                           C.byref(ms)))
         return out, ms.value
 
     # -- instrumentation ------------------------------------------------------

@@ -1023,6 +1023,212 @@ __global__ __launch_bounds__(256) void k_valid_update(
   vscores[i] = vscores[i] + add;
 }
 
+
+// ===========================================================================
+// Oblivious (level-wise, symmetric) trees: ObliviousRT::fit, ot.cc:32-201
+// ===========================================================================
+// fill() + argmax of one level for one feature (ot.cc:177-201, 67-92): the gain
+// of slot t is summed over the nodes of the level in node order; a slot where any
+// node violates minls is invalid for the whole level; only sums > 0 compete and
+// the first maximum wins.
+__global__ __launch_bounds__(256) void k_obl_fill(
+    const QrTreeState *__restrict__ ts, const int level,
+    const long long *__restrict__ hsum, const uint32_t *__restrict__ hcnt,
+    const int flocal, const uint32_t *__restrict__ thr_size,
+    const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
+    qr_split_t *__restrict__ featrec) {
+  __shared__ Best sh_b[4];
+  if (ts->obl_done) return;
+  const int lf = blockIdx.x;
+  const uint32_t t = threadIdx.x;
+  const int gf = lf2gf[lf];
+  const uint32_t tsize = thr_size[gf];
+  const u64 minls = ts->minls;
+  const double inv_scale = scal->inv_scale;
+  const int lbegin = (1 << level) - 1, lend = (1 << (level + 1)) - 1;
+  double sum = 0.0;
+  bool invalid = t >= tsize;
+  for (int i = lbegin; i < lend; ++i) {
+    const size_t base = ((size_t)ts->nodes[i].hslot * flocal + lf) * 256;
+    const long long cs = hsum[base + t], S = hsum[base + 255];
+    const u64 lc = hcnt[base + t], C = hcnt[base + 255];
+    const u64 rc = C - lc;
+    if (lc >= minls && rc >= minls) {
+      const double s = (double)S * inv_scale;
+      const double lsum = (double)cs * inv_scale;
+      const double rsum = s - lsum;
+      sum += lsum * lsum / (double)lc + rsum * rsum / (double)rc;
+    } else
+      invalid = true;
+  }
+  Best v;
+  v.score = -1.0;
+  v.t = 0xFFFFFFFFu;
+  if (!invalid && sum > 0.0) {  // NaN fails the comparison, as in ot.cc:77-78
+    v.score = sum;
+    v.t = t;
+  }
+  v = block_best(v, sh_b);
+  if (t == 0) {
+    qr_split_t *o = &featrec[lf];
+    o->score = v.score;
+    o->feature = v.t == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)gf;
+    o->thr_id = v.t;
+    o->lcount = o->rcount = 0;
+  }
+}
+
+// choose the level's (feature, slot): first maximum over features (ot.cc:84-95)
+__global__ __launch_bounds__(64) void k_obl_level(QrTreeState *__restrict__ ts,
+                                                  const int level, const uint32_t N,
+                                                  const qr_split_t *__restrict__ featrec,
+                                                  const int flocal,
+                                                  const QrScalars *__restrict__ scal) {
+  const int lane = threadIdx.x;
+  if (level == 0 && lane == 0) {
+    QrNode *root = &ts->nodes[0];
+    root->begin = 0;
+    root->end = N;
+    root->buf = 2;
+    root->hslot = 0;
+    root->feature = -1;
+    root->thr_id = -1;
+    root->threshold = 0.f;
+    root->left = root->right = root->parent = -1;
+    root->leaf_id = -1;
+    node_stats(root, scal->root_sum, scal->root_ss, N);
+    ts->nnodes = 1;
+    ts->obl_done = 0;
+    ts->nsplits = 0;
+    ts->desc.active = 0;
+  }
+  if (ts->obl_done) return;
+  qr_split_t best;
+  best.score = -1.0;
+  best.feature = 0xFFFFFFFFu;
+  best.thr_id = 0xFFFFFFFFu;
+  for (int lf = lane; lf < flocal; lf += 64) {
+    const qr_split_t r = featrec[lf];
+    if (r.score > best.score) best = r;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double os = __shfl_xor(best.score, off, 64);
+    const uint32_t of = __shfl_xor(best.feature, off, 64);
+    const uint32_t ot = __shfl_xor(best.thr_id, off, 64);
+    if (os > best.score || (os == best.score && of < best.feature)) {
+      best.score = os;
+      best.feature = of;
+      best.thr_id = ot;
+    }
+  }
+  if (lane != 0) return;
+  ts->obl_level = level;
+  if (best.feature == 0xFFFFFFFFu) {  // ot.cc:96: node is unsplittable
+    ts->obl_done = 1;
+    return;
+  }
+  ts->obl_f = best.feature;
+  ts->obl_t = best.thr_id;
+  ts->obl_score = best.score;
+  qr_split_t *lg = &ts->split_log[ts->nsplits++];
+  lg->score = best.score;
+  lg->feature = best.feature;
+  lg->thr_id = best.thr_id;
+  lg->lcount = lg->rcount = 0;
+}
+
+// descriptor for splitting node `lbegin + i` of the level with the level's split
+__global__ __launch_bounds__(64) void k_obl_desc(
+    QrTreeState *__restrict__ ts, const int level, const int i, const int last_level,
+    const int flocal, const uint32_t *__restrict__ hcnt, const float *__restrict__ thr,
+    const int32_t *__restrict__ gf2lf) {
+  if (threadIdx.x != 0) return;
+  QrSplitDesc *d = &ts->desc;
+  d->active = 0;
+  if (ts->obl_done) return;
+  const int node = (1 << level) - 1 + i;
+  QrNode *nd = &ts->nodes[node];
+  const uint32_t f = ts->obl_f, t = ts->obl_t;
+  const int lf = gf2lf[f];
+  const size_t base = ((size_t)nd->hslot * flocal + lf) * 256;
+  const uint32_t lcount = hcnt[base + t];
+  const uint32_t rcount = hcnt[base + 255] - lcount;
+  const int li = 2 * node + 1, ri = 2 * node + 2;
+  if (ts->nnodes < ri + 1) ts->nnodes = ri + 1;
+  d->active = 1;
+  d->node = node;
+  d->left = li;
+  d->right = ri;
+  d->begin = nd->begin;
+  d->end = nd->end;
+  d->src_buf = nd->buf;
+  d->dst_buf = nd->buf == 0 ? 1 : 0;
+  d->lcount = lcount;
+  d->rcount = rcount;
+  d->feature = f;
+  d->thr_id = t;
+  d->owner_local = lf;
+  d->small_is_left = lcount <= rcount;
+  d->small_node = d->small_is_left ? li : ri;
+  d->big_node = d->small_is_left ? ri : li;
+  d->parent_slot = nd->hslot;
+  d->small_slot = d->small_node;
+  d->big_slot = d->big_node;
+  d->small_begin = d->small_is_left ? nd->begin : nd->begin + lcount;
+  d->small_n = d->small_is_left ? lcount : rcount;
+  nd->feature = (int32_t)f;
+  nd->thr_id = (int32_t)t;
+  nd->threshold = thr[(size_t)f * QR_MAX_BINS + t];
+  nd->left = li;
+  nd->right = ri;
+  QrNode *L = &ts->nodes[li], *R = &ts->nodes[ri];
+  L->begin = nd->begin;
+  L->end = nd->begin + lcount;
+  R->begin = L->end;
+  R->end = nd->end;
+  L->buf = R->buf = d->dst_buf;
+  L->hslot = li;
+  R->hslot = ri;
+  L->feature = R->feature = -1;
+  L->thr_id = R->thr_id = -1;
+  L->threshold = R->threshold = 0.f;
+  L->left = L->right = R->left = R->right = -1;
+  L->parent = R->parent = node;
+  L->leaf_id = R->leaf_id = -1;
+  L->count = lcount;
+  R->count = rcount;
+  L->sum = R->sum = L->ss = R->ss = L->deviance = R->deviance = 0.0;
+  L->value = R->value = 0.0;  // overwritten by update_output (ot.cc:141-149)
+  (void)last_level;
+}
+
+__global__ void k_obl_reset(QrTreeState *ts, int maxnodes, u64 minls) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < maxnodes) {
+    ts->nodes[i].feature = -2;  // absent
+    ts->nodes[i].left = ts->nodes[i].right = -1;
+    ts->nodes[i].count = 0;
+    ts->nodes[i].value = 0.0;
+    ts->nodes[i].deviance = 0.0;
+    ts->nodes[i].threshold = 0.f;
+    ts->nodes[i].thr_id = -1;
+  }
+  if (i == 0) {
+    ts->nleaves_req = 0;
+    ts->nnodes = 0;
+    ts->taken = 0;
+    ts->done = 0;
+    ts->step = 0;
+    ts->nsplits = 0;
+    ts->minls = minls;
+    ts->heap_size = 0;
+    ts->desc.active = 0;
+    ts->nleaves = 0;
+    ts->obl_done = 0;
+    ts->obl_level = 0;
+  }
+}
+
 // ===========================================================================
 // host launchers
 // ===========================================================================
@@ -1126,6 +1332,49 @@ int qr_k_tree_apply(qr_ctx *c) {
                      c->d_part_ss);
   QR_CHECK(c, hipGetLastError());
   return launch_hist_scan(c, 0);
+}
+
+
+static int launch_partition(qr_ctx *c) {
+  const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
+  const int use_mask = c->world > 1;
+  hipLaunchKernelGGL(k_part_count, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
+                     c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
+                     c->d_order[1], c->d_mask, use_mask, c->d_blkcnt);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_part_scatter, dim3(pgrid), dim3(256), 0, c->stream,
+                     c->d_tree, c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
+                     c->d_order[1], c->d_mask, use_mask, c->d_blkcnt, c->d_lambda,
+                     c->d_part_ss);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
+  const int maxnodes = (1 << (depth + 1)) - 1;
+  hipLaunchKernelGGL(k_obl_reset, dim3((maxnodes + 255) / 256), dim3(256), 0, c->stream,
+                     c->d_tree, maxnodes, (u64)minls);
+  QR_CHECK(c, hipGetLastError());
+  int rc = launch_hist_scan(c, 1);  // root histogram -> slot 0
+  if (rc) return rc;
+  for (int level = 0; level < (int)depth; ++level) {
+    hipLaunchKernelGGL(k_obl_fill, dim3(c->flocal), dim3(256), 0, c->stream, c->d_tree, level,
+                       c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf,
+                       c->d_scalars, c->d_featrec);
+    QR_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_obl_level, dim3(1), dim3(64), 0, c->stream, c->d_tree, level,
+                       (uint32_t)c->N, c->d_featrec, c->flocal, c->d_scalars);
+    QR_CHECK(c, hipGetLastError());
+    const int last = level == (int)depth - 1;
+    for (int i = 0; i < (1 << level); ++i) {
+      hipLaunchKernelGGL(k_obl_desc, dim3(1), dim3(64), 0, c->stream, c->d_tree, level, i, last,
+                         c->flocal, c->d_hcnt, c->d_thr, c->d_gf2lf);
+      QR_CHECK(c, hipGetLastError());
+      if ((rc = launch_partition(c))) return rc;
+      if (!last && (rc = launch_hist_scan(c, 0))) return rc;  // ot.cc:127: no histograms for leaves
+    }
+  }
+  return QR_OK;
 }
 
 int qr_k_tree_finish(qr_ctx *c, int newton) {

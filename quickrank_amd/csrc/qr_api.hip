@@ -92,6 +92,8 @@ void qr_ctx_destroy(qr_ctx *c) {
   free_valid(c);
   dfree(c->d_lg2); dfree(c->d_ilg2); dfree(c->d_scalars); dfree(c->d_ens); dfree(c->d_ens_w);
   dfree(c->d_keys); dfree(c->d_tied);
+  dfree(c->d_obl_feat); dfree(c->d_obl_thr); dfree(c->d_obl_leaves); dfree(c->d_obl_w);
+  dfree(c->d_obl_depths);
   for (auto &p : c->prof_events) {
     (void)hipEventDestroy(p.first);
     (void)hipEventDestroy(p.second);
@@ -634,8 +636,17 @@ int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
 int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
                      qr_node_t *nodes_out, size_t *nnodes_out) {
   if (!c) return QR_ERR_ARG;
-  (void)depth; (void)minls; (void)newton; (void)nodes_out; (void)nnodes_out;
-  QR_FAIL(c, QR_ERR_UNSUPPORTED, "oblivious trees: not implemented in this round");
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  if (c->world > 1)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "oblivious trees are single-GPU in this round");
+  if (depth < 1 || ((size_t)1 << (depth + 1)) - 1 > QR_MAXNODES)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
+  int rc = ensure_hist_slots(c, ((size_t)1 << (depth + 1)) - 1);
+  if (rc) return rc;
+  c->tree_valid = false;
+  c->tree_open = true;
+  if ((rc = qr_k_oblivious_fit(c, depth, minls))) return rc;
+  return qr_tree_end(c, newton, nodes_out, nnodes_out);
 }
 
 int qr_scores_update(qr_ctx *c, double shrinkage) {
@@ -771,6 +782,61 @@ int qr_ensemble_score(qr_ctx *c, const float *x, size_t N, size_t F, double *out
   QR_CHECK(c, hipEventCreate(&e1));
   QR_CHECK(c, hipEventRecord(e0, c->stream));
   int rc = qr_k_ensemble_score(c, d_x, N, F, d_o);
+  QR_CHECK(c, hipEventRecord(e1, c->stream));
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  if (!rc) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (kernel_ms) *kernel_ms = ms;
+    QR_CHECK(c, hipMemcpy(out, d_o, N * 8, hipMemcpyDeviceToHost));
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  dfree(d_x);
+  dfree(d_o);
+  return rc;
+}
+
+int qr_oblivious_upload(qr_ctx *c, const uint32_t *feat, const float *thr,
+                        const double *leaves, const float *weights,
+                        const uint32_t *depths, size_t ntrees, size_t depth) {
+  if (!c || !feat || !thr || !leaves || !weights || !ntrees || !depth || depth > 12)
+    return QR_ERR_ARG;
+  QR_CHECK(c, hipSetDevice(c->device));
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  dfree(c->d_obl_feat); dfree(c->d_obl_thr); dfree(c->d_obl_leaves); dfree(c->d_obl_w);
+  dfree(c->d_obl_depths);
+  const size_t nl = (size_t)1 << depth;
+  QR_CHECK(c, dalloc(&c->d_obl_feat, ntrees * depth));
+  QR_CHECK(c, dalloc(&c->d_obl_thr, ntrees * depth));
+  QR_CHECK(c, dalloc(&c->d_obl_leaves, ntrees * nl));
+  QR_CHECK(c, dalloc(&c->d_obl_w, ntrees));
+  QR_CHECK(c, hipMemcpy(c->d_obl_feat, feat, ntrees * depth * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_obl_thr, thr, ntrees * depth * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_obl_leaves, leaves, ntrees * nl * 8, hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_obl_w, weights, ntrees * 4, hipMemcpyHostToDevice));
+  if (depths) {
+    QR_CHECK(c, dalloc(&c->d_obl_depths, ntrees));
+    QR_CHECK(c, hipMemcpy(c->d_obl_depths, depths, ntrees * 4, hipMemcpyHostToDevice));
+  }
+  c->obl_trees = ntrees;
+  c->obl_depth = depth;
+  return QR_OK;
+}
+
+int qr_oblivious_score(qr_ctx *c, const float *x, size_t N, size_t F, double *out,
+                       float *kernel_ms) {
+  if (!c || !x || !out || !N || !F) return QR_ERR_ARG;
+  float *d_x = nullptr;
+  double *d_o = nullptr;
+  QR_CHECK(c, dalloc(&d_x, N * F));
+  QR_CHECK(c, dalloc(&d_o, N));
+  QR_CHECK(c, hipMemcpy(d_x, x, N * F * 4, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  QR_CHECK(c, hipEventCreate(&e0));
+  QR_CHECK(c, hipEventCreate(&e1));
+  QR_CHECK(c, hipEventRecord(e0, c->stream));
+  int rc = qr_k_obl_score(c, d_x, N, F, d_o);
   QR_CHECK(c, hipEventRecord(e1, c->stream));
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   if (!rc) {

@@ -123,6 +123,10 @@ struct QrTreeState {
   QrNode nodes[QR_MAXNODES];
   qr_split_t split_log[QR_MAXNODES];
   QrSplitDesc desc;
+  // oblivious (level-wise) growth: the split chosen for the current level
+  int32_t obl_done, obl_level;
+  uint32_t obl_f, obl_t;
+  double obl_score;
   // leaves in DFS order
   int32_t nleaves;
   int32_t leaf_nodes[QR_MAXNODES];
@@ -219,6 +223,11 @@ struct qr_ctx {
   qr_node_t *d_ens = nullptr;
   double *d_ens_w = nullptr;
   size_t ens_trees = 0, ens_maxnodes = 0;
+  // oblivious ensemble (generate_oblivious.cc layout)
+  uint32_t *d_obl_feat = nullptr, *d_obl_depths = nullptr;
+  float *d_obl_thr = nullptr, *d_obl_w = nullptr;
+  double *d_obl_leaves = nullptr;
+  size_t obl_trees = 0, obl_depth = 0;
   // profiling
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -256,5 +265,7 @@ int qr_k_tree_decide(qr_ctx *c);
 int qr_k_tree_apply(qr_ctx *c);
 int qr_k_tree_finish(qr_ctx *c, int newton);
 int qr_k_scores_update(qr_ctx *c, double shrinkage);
+int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls);
 int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
                         double *d_out);
+int qr_k_obl_score(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);

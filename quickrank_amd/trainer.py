@@ -12,7 +12,7 @@ import numpy as np
 
 from ._capi import Context, NODE_DTYPE
 
-ALGOS = ("MART", "LAMBDAMART")
+ALGOS = ("MART", "LAMBDAMART", "OBVMART", "OBVLAMBDAMART")
 
 
 class Ensemble:
@@ -46,7 +46,7 @@ class Mart:
 
     def __init__(self, algo="LAMBDAMART", ntrees=1000, shrinkage=0.1, nthresholds=0,
                  nleaves=10, minls=1, esr=100, metric="NDCG", cutoff=10, device=0,
-                 ctx=None, dist=None):
+                 ctx=None, dist=None, depth=3):
         if algo not in ALGOS:
             raise ValueError(f"unsupported algorithm {algo}")
         self.algo, self.ntrees, self.shrinkage = algo, ntrees, shrinkage
@@ -54,7 +54,9 @@ class Mart:
         self.metric, self.cutoff = metric, cutoff
         self.ctx = ctx if ctx is not None else Context(device)
         self.dist = dist
-        self.ensemble = Ensemble(2 * nleaves + 1)
+        self.depth = depth
+        self.oblivious = algo.startswith("OBV")  # obliviousmart.cc / obliviouslambdamart.cc
+        self.ensemble = Ensemble((1 << (depth + 1)) - 1 if self.oblivious else 2 * nleaves + 1)
         self.thr = self.thr_size = None
         self.train_metric, self.valid_metric, self.iter_seconds = [], [], []
         self.best_model = 0
@@ -68,6 +70,8 @@ class Mart:
         self.ctx.reset_scores()
 
     def _fit_tree(self, newton):
+        if self.oblivious:
+            return self.ctx.fit_oblivious(self.depth, self.minls, newton)
         if self.dist is not None:
             return self.dist.fit_tree(self.ctx, self.nleaves, self.minls, newton)
         return self.ctx.fit_tree(self.nleaves, self.minls, newton)
@@ -75,7 +79,7 @@ class Mart:
     # Mart::learn main loop (mart.cc:307-383) + rollback (:390-395)
     def learn(self, x, labels, qoff, valid=None, verbose=False, eval_every=1):
         self.init(x, labels, qoff, valid)
-        lam = self.algo == "LAMBDAMART"
+        lam = self.algo.endswith("LAMBDAMART")
         best_valid = best_train = -np.inf
         self.best_model = 0
         # The lambda kernel ranks every query anyway, so the training metric of the

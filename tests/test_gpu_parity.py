@@ -269,6 +269,72 @@ def test_training_loop_medium_exact(qr, ora, algo):
     gm.ctx.close()
 
 
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("nthr,depth,minls", [(255, 3, 1), (32, 4, 5), (255, 6, 1), (16, 2, 2)])
+def test_oblivious_tree(qr, ora, case, nthr, depth, minls):
+    """ObliviousRT::fit (ot.cc:32-201): one (feature, slot) per level."""
+    x, labels, qoff = make_dataset(**case)
+    rng = np.random.default_rng(13)
+    scores = rng.standard_normal(len(labels)) * 0.3
+    olam, ow = ora.lambdas(labels, scores, qoff, 10, 1)
+    c, thr, ts = _ctx(qr, x, labels, qoff, nthr)
+    c.set_pseudo(olam, ow)
+    nodes = c.fit_oblivious(depth, minls, True)
+    tr = ora.Trainer(x, nthr)
+    ot = tr.fit_tree(olam, minls=minls, oblivious_depth=depth)
+    tr.update_output(ot, olam, ow)
+    on = ot["nodes"]
+    assert len(nodes) == len(on)
+    assert np.array_equal(nodes["feature"] == -2, on["feature"] == -2)
+    ties = assert_tree_parity(tr.stmap, on, nodes, value_rtol=1e-9)
+    log, olog = c.split_log(), ot["splits"]
+    assert len(log) == len(olog)
+    if ties == 0:
+        assert np.array_equal(log["feature"].astype(np.uint64), olog["feature"])
+        assert np.array_equal(log["thr_id"].astype(np.uint64), olog["thr_id"])
+        assert np.allclose(log["score"], olog["score"], rtol=1e-9)
+    c.set_scores(scores)
+    c.update_scores(0.1)
+    s2 = scores.copy()
+    tr.update_scores(ot, 0.1, s2)
+    assert np.allclose(c.get_scores(), s2, rtol=1e-12, atol=1e-13)
+    c.close()
+
+
+@pytest.mark.parametrize("algo", ["OBVLAMBDAMART", "OBVMART"])
+def test_oblivious_training_loop(qr, ora, algo):
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(nq=120, docs_per_query=60, F=40, seed=23)
+    kw = dict(ntrees=8, shrinkage=0.1, nthresholds=64, minls=10, esr=0)
+    om = ora.train(x, labels, qoff, algo=algo, depth=4, **kw)
+    gm = Mart(algo=algo, depth=4, **kw).learn(x, labels, qoff)
+    tr = ora.Trainer(x, 64)
+    for t in range(kw["ntrees"]):
+        n = int(om["nnodes"][t])
+        assert_tree_parity(tr.stmap, om["nodes"][t][:n], gm.ensemble.trees[t][:n])
+    assert np.allclose(gm.train_metric, om["train_metric"], rtol=1e-9)
+    assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-8, atol=1e-10)
+    gm.ctx.close()
+
+
+def test_oblivious_bit_interleaved_scoring(qr, ora):
+    """generate_oblivious.cc:237-324 semantics (f32 tree weights, `>` = right)."""
+    rng = np.random.default_rng(3)
+    T, D, F, N = 37, 6, 50, 1000
+    feat = rng.integers(0, F, (T, D)).astype(np.uint32)
+    thr = rng.random((T, D)).astype(np.float32)
+    leaves = rng.standard_normal((T, 1 << D))
+    w = np.full(T, 0.1, np.float32)
+    x = rng.random((N, F), dtype=np.float32)
+    want = np.zeros(N)
+    ora.lib().qro_oblivious_score(feat, thr, leaves, w, T, D, x, N, F, want)
+    c = qr.Context(0)
+    c.upload_oblivious(feat, thr, leaves, w)
+    got, _ = c.score_oblivious(x)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    c.close()
+
+
 def test_validation_early_stop_and_rollback(qr, ora):
     from quickrank_amd.trainer import Mart
     x, labels, qoff = make_dataset(nq=40, docs_per_query=30, F=20, seed=7)

@@ -153,9 +153,17 @@ def main():
         if prof["launches"]:
             sec = prof["total_ms"] / prof["launches"] * 1e-3
             ach = prof["alg_bytes"] / sec / 1e9
+            # HBM bytes per launch from the PMC passes committed under profiles/
+            # (collected separately: counters cannot be read inside this process);
+            # only quoted when it was measured on this very workload
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hist.json")
+            if (os.path.exists(pmc) and world == 1 and N == 1000000 and F == 136
+                    and args.nthresholds == 255):
+                traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
             roof = {"bound": "hbm", "kernel": "k_hist (root histogram build)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": prof["alg_bytes"],
                     "avg_launch_us": round(sec * 1e6, 2), "launches": prof["launches"]}
         out = {

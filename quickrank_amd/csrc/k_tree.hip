@@ -444,37 +444,32 @@ __global__ __launch_bounds__(256) void k_scan(
 // global order and the comparison is strict, so the lowest feature wins ties
 // (rt.cc:297-306).  Also attaches lcount/rcount from the node histogram.
 // ===========================================================================
-__global__ __launch_bounds__(128) void k_merge(
-    const QrTreeState *__restrict__ ts, const int root_mode,
-    const qr_split_t *__restrict__ featrec, const int flocal,
-    const long long *__restrict__ hsum, const uint32_t *__restrict__ hcnt,
-    const int32_t *__restrict__ gf2lf, qr_split_t *__restrict__ recs_local) {
-  if (!root_mode && !ts->desc.active) return;
-  const int which = threadIdx.x >> 6;  // wave 0: left child (or root), wave 1: right
+// merge by one wave; every lane returns the same record
+__device__ qr_split_t wave_merge(const QrTreeState *ts, const int root_mode, const int which,
+                                 const qr_split_t *featrec, const int flocal,
+                                 const uint32_t *hcnt, const int32_t *gf2lf) {
   const int lane = threadIdx.x & 63;
   qr_split_t best;
   best.score = -1.0;
   best.feature = 0xFFFFFFFFu;
   best.thr_id = 0xFFFFFFFFu;
   best.lcount = best.rcount = 0;
-  if (!(root_mode && which == 1)) {
-    for (int lf = lane; lf < flocal; lf += 64) {
-      const qr_split_t r = featrec[(size_t)which * flocal + lf];
-      if (r.score > best.score) best = r;  // ascending lf within the lane
-    }
-    // butterfly: higher score wins, equal scores -> lower feature index
-    for (int off = 32; off > 0; off >>= 1) {
-      const double os = __shfl_xor(best.score, off, 64);
-      const uint32_t of = __shfl_xor(best.feature, off, 64);
-      const uint32_t ot = __shfl_xor(best.thr_id, off, 64);
-      if (os > best.score || (os == best.score && of < best.feature)) {
-        best.score = os;
-        best.feature = of;
-        best.thr_id = ot;
-      }
+  if (root_mode && which == 1) return best;
+  for (int lf = lane; lf < flocal; lf += 64) {
+    const qr_split_t r = featrec[(size_t)which * flocal + lf];
+    if (r.score > best.score) best = r;  // ascending lf within the lane
+  }
+  // butterfly: higher score wins, equal scores -> lower feature index
+  for (int off = 32; off > 0; off >>= 1) {
+    const double os = __shfl_xor(best.score, off, 64);
+    const uint32_t of = __shfl_xor(best.feature, off, 64);
+    const uint32_t ot = __shfl_xor(best.thr_id, off, 64);
+    if (os > best.score || (os == best.score && of < best.feature)) {
+      best.score = os;
+      best.feature = of;
+      best.thr_id = ot;
     }
   }
-  if (lane != 0) return;
   if (best.feature != 0xFFFFFFFFu) {
     int slot;
     if (root_mode)
@@ -487,7 +482,19 @@ __global__ __launch_bounds__(128) void k_merge(
     best.lcount = hcnt[base + best.thr_id];
     best.rcount = (u64)hcnt[base + 255] - best.lcount;
   }
-  recs_local[which] = best;
+  return best;
+}
+
+// multi-GPU only: publish this rank's best records for the all_gather
+__global__ __launch_bounds__(128) void k_merge(
+    const QrTreeState *__restrict__ ts, const int root_mode,
+    const qr_split_t *__restrict__ featrec, const int flocal,
+    const long long *__restrict__ hsum, const uint32_t *__restrict__ hcnt,
+    const int32_t *__restrict__ gf2lf, qr_split_t *__restrict__ recs_local) {
+  if (!root_mode && !ts->desc.active) return;
+  const int which = threadIdx.x >> 6;  // wave 0: left child (or root), wave 1: right
+  const qr_split_t best = wave_merge(ts, root_mode, which, featrec, flocal, hcnt, gf2lf);
+  if ((threadIdx.x & 63) == 0) recs_local[which] = best;
 }
 
 // ===========================================================================
@@ -566,6 +573,7 @@ __device__ void make_desc(QrTreeState *ts, int node, const float *thr,
   const int li = ts->nnodes, ri = ts->nnodes + 1;
   ts->nnodes += 2;
   d->active = 1;
+  ts->part_epoch++;
   d->node = node;
   d->left = li;
   d->right = ri;
@@ -615,10 +623,27 @@ __device__ void make_desc(QrTreeState *ts, int node, const float *thr,
 
 __global__ __launch_bounds__(64) void k_decide(
     QrTreeState *__restrict__ ts, const uint32_t N, const int flocal,
-    const long long *__restrict__ hsum, const qr_split_t *__restrict__ recs,
+    const long long *__restrict__ hsum, const qr_split_t *recs,
     const int world, const QrScalars *__restrict__ scal,
     const double *__restrict__ part_ss, const float *__restrict__ thr,
-    const int32_t *__restrict__ gf2lf) {
+    const int32_t *__restrict__ gf2lf, const qr_split_t *__restrict__ featrec,
+    const uint32_t *__restrict__ hcnt) {
+  // single GPU: the merge over features happens here (no k_merge launch, no
+  // exchange); with several ranks `recs` is the all-gathered buffer
+  __shared__ qr_split_t own[2];
+  if (world == 1) {
+    const int root_mode = ts->step == 0;
+    if (root_mode || ts->desc.active) {
+      const qr_split_t a = wave_merge(ts, root_mode, 0, featrec, flocal, hcnt, gf2lf);
+      const qr_split_t b = wave_merge(ts, root_mode, 1, featrec, flocal, hcnt, gf2lf);
+      if (threadIdx.x == 0) {
+        own[0] = a;
+        own[1] = b;
+      }
+    }
+    __syncthreads();
+    recs = own;
+  }
   // squares_sum_ / sum of the directly built child: fixed-order reduction of the
   // partition workgroups' partials by the whole wave
   double ss_small = 0.0, sum_small = 0.0;
@@ -840,6 +865,108 @@ __global__ __launch_bounds__(256) void k_part_scatter(
   }
   // squares_sum_ of the directly built child (rtnode_histogram.cc:65-69),
   // fixed reduction tree
+  for (int off = 32; off > 0; off >>= 1) {
+    sq += __shfl_xor(sq, off, 64);
+    sm += __shfl_xor(sm, off, 64);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    shd[wave] = sq;
+    shs[wave] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part_ss[2 * blockIdx.x] = (shd[0] + shd[1]) + (shd[2] + shd[3]);
+    part_ss[2 * blockIdx.x + 1] = (shs[0] + shs[1]) + (shs[2] + shs[3]);
+  }
+}
+
+// Single-pass stable partition with a look-back chain over the slice workgroups.
+// Workgroup w publishes ONE 8-byte granule {tag = epoch, value = #lefts in its
+// slice} with a relaxed agent-scope store (the data is the flag: no fence needed,
+// cdna_hip_programming.md guideline 16, form R2) and sums the granules of all
+// predecessors, polling each until its tag matches.  Predecessors are always
+// dispatched first and never wait on successors, so the chain cannot deadlock.
+// The epoch increases with every split of the context's lifetime, so the granule
+// array never needs clearing.
+__global__ __launch_bounds__(256) void k_partition(
+    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks,
+    const int nblocks, const uint8_t *__restrict__ bins,
+    uint32_t *__restrict__ order0, uint32_t *__restrict__ order1,
+    const uint32_t *__restrict__ mask, const int use_mask,
+    u64 *__restrict__ state, const double *__restrict__ lambda,
+    double *__restrict__ part_ss) {
+  __shared__ uint32_t sh[4];
+  __shared__ uint32_t wave_off[4];
+  __shared__ double shd[4], shs[4];
+  const QrSplitDesc d = ts->desc;
+  if (!d.active) return;
+  const uint32_t n = d.end - d.begin;
+  const uint32_t base = blockIdx.x * QR_PART_SLICE;
+  if (base >= n) return;
+  const u64 epoch = ts->part_epoch;
+  const uint32_t *src = d.src_buf == 0 ? order0 : order1;
+  uint32_t *dst = d.dst_buf == 0 ? order0 : order1;
+  uint32_t ids[PART_PER_THREAD];
+  bool fl[PART_PER_THREAD];
+  uint32_t cnt = 0;
+  for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
+    const uint32_t p = base + threadIdx.x * PART_PER_THREAD + k;
+    fl[k] = false;
+    ids[k] = 0;
+    if (p < n) {
+      ids[k] = d.src_buf == 2 ? d.begin + p : src[d.begin + p];
+      fl[k] = go_left(d, p, ids[k], blocks, nblocks, bins, mask, use_mask);
+      cnt += fl[k] ? 1u : 0u;
+    }
+  }
+  // intra-workgroup inclusive scan of cnt
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = cnt;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) wave_off[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wave_off[w];
+  const uint32_t total = wave_off[0] + wave_off[1] + wave_off[2] + wave_off[3];
+  // publish my count, then look back
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&state[blockIdx.x], (epoch << 32) | (u64)total, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t pre = 0;
+  for (uint32_t v = threadIdx.x; v < blockIdx.x; v += 256) {
+    u64 g;
+    do {
+      g = __hip_atomic_load(&state[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((g >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
+    } while ((g >> 32) != epoch);
+    pre += (uint32_t)g;
+  }
+  const uint32_t left_before = block_sum_u32(pre, sh);
+  uint32_t lpos = left_before + woff + inc - cnt;  // lefts before my first doc
+  const uint32_t first_p = base + threadIdx.x * PART_PER_THREAD;
+  double sq = 0.0, sm = 0.0;
+  for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
+    const uint32_t p = first_p + k;
+    if (p < n) {
+      uint32_t o;
+      if (fl[k]) {
+        o = d.begin + lpos;
+        ++lpos;
+      } else {
+        o = d.begin + d.lcount + (p - lpos);
+      }
+      dst[o] = ids[k];
+      if (fl[k] == (d.small_is_left != 0)) {
+        const double l = lambda[ids[k]];
+        sq += l * l;
+        sm += l;
+      }
+    }
+  }
   for (int off = 32; off > 0; off >>= 1) {
     sq += __shfl_xor(sq, off, 64);
     sm += __shfl_xor(sm, off, 64);
@@ -1156,6 +1283,7 @@ __global__ __launch_bounds__(64) void k_obl_desc(
   const int li = 2 * node + 1, ri = 2 * node + 2;
   if (ts->nnodes < ri + 1) ts->nnodes = ri + 1;
   d->active = 1;
+  ts->part_epoch++;
   d->node = node;
   d->left = li;
   d->right = ri;
@@ -1275,10 +1403,12 @@ static int launch_hist_scan(qr_ctx *c, int root_mode) {
                      c->d_red_cnt, c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size,
                      c->d_lf2gf, c->d_scalars, c->d_featrec);
   QR_CHECK(c, hipGetLastError());
-  hipLaunchKernelGGL(k_merge, dim3(1), dim3(128), 0, c->stream, c->d_tree, root_mode,
-                     c->d_featrec, c->flocal, c->d_hsum, c->d_hcnt, c->d_gf2lf,
-                     c->d_recs_local);
-  QR_CHECK(c, hipGetLastError());
+  if (c->world > 1) {
+    hipLaunchKernelGGL(k_merge, dim3(1), dim3(128), 0, c->stream, c->d_tree, root_mode,
+                       c->d_featrec, c->flocal, c->d_hsum, c->d_hcnt, c->d_gf2lf,
+                       c->d_recs_local);
+    QR_CHECK(c, hipGetLastError());
+  }
   return QR_OK;
 }
 
@@ -1307,7 +1437,8 @@ int qr_k_tree_decide(qr_ctx *c) {
   const qr_split_t *recs = c->world > 1 ? c->d_recs_all : c->d_recs_local;
   hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_tree,
                      (uint32_t)c->N, c->flocal, c->d_hsum, recs, c->world,
-                     c->d_scalars, c->d_part_ss, c->d_thr, c->d_gf2lf);
+                     c->d_scalars, c->d_part_ss, c->d_thr, c->d_gf2lf, c->d_featrec,
+                     c->d_hcnt);
   QR_CHECK(c, hipGetLastError());
   if (c->world > 1) {
     const unsigned grid = (unsigned)((c->mask_words + 255) / 256);
@@ -1322,14 +1453,9 @@ int qr_k_tree_decide(qr_ctx *c) {
 int qr_k_tree_apply(qr_ctx *c) {
   const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
   const int use_mask = c->world > 1;
-  hipLaunchKernelGGL(k_part_count, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
-                     c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
-                     c->d_order[1], c->d_mask, use_mask, c->d_blkcnt);
-  QR_CHECK(c, hipGetLastError());
-  hipLaunchKernelGGL(k_part_scatter, dim3(pgrid), dim3(256), 0, c->stream,
-                     c->d_tree, c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
-                     c->d_order[1], c->d_mask, use_mask, c->d_blkcnt, c->d_lambda,
-                     c->d_part_ss);
+  hipLaunchKernelGGL(k_partition, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
+                     c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_order[1],
+                     c->d_mask, use_mask, (u64 *)c->d_part_state, c->d_lambda, c->d_part_ss);
   QR_CHECK(c, hipGetLastError());
   return launch_hist_scan(c, 0);
 }
@@ -1338,14 +1464,9 @@ int qr_k_tree_apply(qr_ctx *c) {
 static int launch_partition(qr_ctx *c) {
   const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
   const int use_mask = c->world > 1;
-  hipLaunchKernelGGL(k_part_count, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
-                     c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
-                     c->d_order[1], c->d_mask, use_mask, c->d_blkcnt);
-  QR_CHECK(c, hipGetLastError());
-  hipLaunchKernelGGL(k_part_scatter, dim3(pgrid), dim3(256), 0, c->stream,
-                     c->d_tree, c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
-                     c->d_order[1], c->d_mask, use_mask, c->d_blkcnt, c->d_lambda,
-                     c->d_part_ss);
+  hipLaunchKernelGGL(k_partition, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
+                     c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_order[1],
+                     c->d_mask, use_mask, (u64 *)c->d_part_state, c->d_lambda, c->d_part_ss);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

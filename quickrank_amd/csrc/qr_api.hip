@@ -73,7 +73,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_red_sum); dfree(c->d_red_cnt);
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
-  dfree(c->d_blkcnt); dfree(c->d_part_ss); dfree(c->d_tree); dfree(c->d_leafpart);
+  dfree(c->d_blkcnt); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_tree); dfree(c->d_leafpart);
   c->binned = false;
   c->tree_valid = false;
   c->hist_slots = 0;
@@ -384,6 +384,8 @@ int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
   c->mask_words = (N + 31) / 32;
   QR_CHECK(c, dalloc(&c->d_mask, c->mask_words));
   QR_CHECK(c, dalloc(&c->d_blkcnt, N / QR_PART_SLICE + 2));
+  QR_CHECK(c, dalloc(&c->d_part_state, N / QR_PART_SLICE + 2));
+  QR_CHECK(c, hipMemset(c->d_part_state, 0, (N / QR_PART_SLICE + 2) * 8));
   QR_CHECK(c, dalloc(&c->d_part_ss, 2 * (N / QR_PART_SLICE + 2)));
   QR_CHECK(c, dalloc(&c->d_tree, (size_t)1));
   QR_CHECK(c, hipMemset(c->d_tree, 0, sizeof(QrTreeState)));

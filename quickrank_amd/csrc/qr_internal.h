@@ -124,6 +124,7 @@ struct QrTreeState {
   qr_split_t split_log[QR_MAXNODES];
   QrSplitDesc desc;
   // oblivious (level-wise) growth: the split chosen for the current level
+  uint32_t part_epoch;  // tag of the current partition's look-back granules
   int32_t obl_done, obl_level;
   uint32_t obl_f, obl_t;
   double obl_score;
@@ -213,6 +214,7 @@ struct qr_ctx {
   uint32_t *d_mask = nullptr;
   size_t mask_words = 0;
   uint32_t *d_blkcnt = nullptr;
+  unsigned long long *d_part_state = nullptr;  // look-back granules {epoch, count}
   double *d_part_ss = nullptr;
   QrTreeState *d_tree = nullptr;
   double *d_leafpart = nullptr;  // [slices][2] partial sums

@@ -167,6 +167,9 @@ def ref():
                                  C.POINTER(C.c_double), f64p, u64p,
                                  C.POINTER(C.c_double), f64p, u64p,
                                  C.POINTER(C.c_double)]
+    R.ref_svml_read.argtypes = [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.c_void_p,
+                                C.c_void_p, C.c_void_p]
+    R.ref_svml_write.argtypes = [C.c_char_p, f32p, f32p, u64p, sz, sz]
     _REF = R
     return R
 

@@ -5,7 +5,7 @@
 // It links the reference's unmodified sources
 //   src/data/{dataset,vertical_dataset,queryresults,rankedresults}.cc
 //   src/metric/ir/{dcg,ndcg}.cc   src/learning/tree/rtnode_histogram.cc
-//   src/utils/radix.cc
+//   src/utils/radix.cc   src/io/svml.cc   src/utils/strutils.cc
 // (the subset of the hot path that compiles from its own files; everything that
 // includes learning/tree/rtnode.h needs the un-vendored pugixml submodule and is
 // treated as unbuildable -- no stand-in headers are written).
@@ -24,6 +24,7 @@
 #include "learning/tree/rtnode_histogram.h"
 #include "metric/ir/dcg.h"
 #include "metric/ir/ndcg.h"
+#include "io/svml.h"
 #include "utils/radix.h"
 
 using namespace quickrank;
@@ -180,6 +181,30 @@ void ref_histograms(const float *rowmajor, size_t N, size_t F, const float *thr,
   delete left;
   delete root;
   for (size_t f = 0; f < F; ++f) delete[] sorted[f];
+}
+
+// Svml::read_horizontal (svml.cc:38-161).  Call with NULL buffers to size them.
+int ref_svml_read(const char *path, size_t *N, size_t *F, size_t *Q, float *x, float *labels,
+                  uint64_t *qoff) {
+  io::Svml reader;
+  auto ds = reader.read_horizontal(path);
+  *N = ds->num_instances();
+  *F = ds->num_features();
+  *Q = ds->num_queries();
+  if (x) memcpy(x, ds->at(0, 0), *N * *F * sizeof(float));
+  if (labels)
+    for (size_t i = 0; i < *N; ++i) labels[i] = ds->getLabel(i);
+  if (qoff)
+    for (size_t q = 0; q <= *Q; ++q) qoff[q] = ds->offset(q);
+  return 0;
+}
+
+// Svml::write (svml.cc:163-188)
+int ref_svml_write(const char *path, const float *x, const float *labels, const uint64_t *qoff,
+                   size_t Q, size_t F) {
+  auto ds = make_dataset(x, labels, qoff, Q, F);
+  io::Svml().write(ds, path);
+  return 0;
 }
 
 }  // extern "C"

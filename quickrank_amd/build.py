@@ -36,5 +36,34 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+BINDIR = os.path.join(HERE, "bin")
+HOST_SRCS = ["svml.cc", "xml.cc", "mart.cc"]
+HOST_LIB = os.path.join(LIBDIR, "libqr_host.so")
+
+
+def build_host(force=False, verbose=False):
+    """C++ host mirror (Mart/LambdaMart, SVMLight, XML) + the quicklearn/quickscore CLIs."""
+    outs = [HOST_LIB, os.path.join(BINDIR, "quicklearn"), os.path.join(BINDIR, "quickscore")]
+    srcs = [os.path.join(HOST, f) for f in os.listdir(HOST)]
+    if not force and all(os.path.exists(o) for o in outs) and \
+            min(os.path.getmtime(o) for o in outs) > max(os.path.getmtime(s) for s in srcs + [LIB]):
+        return outs
+    os.makedirs(BINDIR, exist_ok=True)
+    cxx = os.environ.get("CXX", "g++")
+    common = [cxx, "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wno-unused-result"]
+    core = [os.path.join(HOST, f) for f in HOST_SRCS]
+    link = ["-L" + LIBDIR, "-lqr_hip", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,$ORIGIN"]
+    cmds = [common + ["-shared", "-o", HOST_LIB] + core + [os.path.join(HOST, "host_capi.cc")] + link,
+            common + ["-o", outs[1]] + core + [os.path.join(HOST, "quicklearn.cc")] + link,
+            common + ["-o", outs[2]] + core + [os.path.join(HOST, "quickscore.cc")] + link]
+    for c in cmds:
+        if verbose:
+            print(" ".join(c), file=sys.stderr)
+        subprocess.check_call(c)
+    return outs
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,99 @@
+// host_capi.cc -- C shims over the host classes for the (CPU-side) tests of the
+// SVMLight reader and the XML model round trip; no device calls here.
+#include <cstring>
+
+#include "mart.h"
+#include "svml.h"
+
+using namespace quickrank;
+
+extern "C" {
+
+// reads `path`; returns N, F, Q through pointers, copies into caller buffers when
+// they are non-NULL (call once with NULLs to size them)
+int qrh_svml_read(const char *path, size_t *N, size_t *F, size_t *Q, float *x, float *labels,
+                  uint64_t *qoff) {
+  io::Svml reader;
+  auto ds = reader.read_horizontal(path);
+  *N = ds->num_instances();
+  *F = ds->num_features();
+  *Q = ds->num_queries();
+  if (x) memcpy(x, ds->at(0, 0), *N * *F * sizeof(float));
+  if (labels) memcpy(labels, ds->labels(), *N * sizeof(float));
+  if (qoff) memcpy(qoff, ds->offsets().data(), (*Q + 1) * sizeof(uint64_t));
+  return 0;
+}
+
+int qrh_svml_write(const char *path, const float *x, const float *labels, const uint64_t *qoff,
+                   size_t Q, size_t F) {
+  const size_t N = qoff[Q];
+  data::Dataset ds(N, F);
+  for (size_t q = 0; q < Q; ++q)
+    for (size_t i = qoff[q]; i < qoff[q + 1]; ++i)
+      ds.addInstance((QueryID)(q + 1), labels[i], std::vector<Feature>(x + i * F, x + (i + 1) * F));
+  io::Svml().write(ds, path);
+  return 0;
+}
+
+// load a model file and write it back (XML round trip)
+int qrh_model_roundtrip(const char *in_path, const char *out_path) {
+  auto m = learning::forests::Mart::load_model_from_file(in_path);
+  if (!m) return 1;
+  m->save(out_path);
+  return 0;
+}
+
+// write a model from flat node records (qr_node_t layout), as Mart::save would
+int qrh_model_write(const char *path, int algo, size_t ntrees_cfg, double shrinkage, size_t nthresholds,
+                    size_t nleaves, size_t minls, size_t esr, size_t depth, const qr_node_t *nodes,
+                    size_t ntrees, size_t max_nodes) {
+  using learning::forests::Mart;
+  using learning::forests::RTNode;
+  // build an XML document directly from the records through the same writer
+  struct B {
+    static std::unique_ptr<RTNode> rec(const qr_node_t *n, int i) {
+      std::unique_ptr<RTNode> r(new RTNode());
+      r->avglabel = n[i].value;
+      if (n[i].feature >= 0) {
+        r->featureidx = n[i].feature;
+        r->featureid = (unsigned)n[i].feature + 1;
+        r->threshold = n[i].threshold;
+        r->left = rec(n, n[i].left);
+        r->right = rec(n, n[i].right);
+      }
+      return r;
+    }
+  };
+  Mart proto((Mart::Algo)algo, ntrees_cfg, shrinkage, nthresholds, nleaves, minls, esr, depth);
+  auto doc = proto.get_xml_model();
+  xml::Node *ens = nullptr;
+  for (auto &c : doc->children)
+    if (c->name == "ensemble") ens = c.get();
+  for (size_t t = 0; t < ntrees; ++t) {
+    xml::Node *tree = ens->append_child("tree");
+    tree->append_attribute("id", std::to_string(t + 1));
+    tree->append_attribute("weight", xml::fmt_double(shrinkage));
+    B::rec(nodes + t * max_nodes, 0)->append_xml_model(tree);
+  }
+  return xml::save_file(*doc, path) ? 0 : 1;
+}
+
+// flatten a model file into qr_node_t records (for scoring through the C-ABI)
+int qrh_model_read(const char *path, qr_node_t *nodes, double *weights, size_t *ntrees,
+                   size_t *max_nodes, size_t cap_nodes, size_t cap_trees) {
+  auto m = learning::forests::Mart::load_model_from_file(path);
+  if (!m) return 1;
+  std::vector<qr_node_t> n;
+  std::vector<double> w;
+  const size_t mn = m->ensemble().flatten(&n, &w);
+  *ntrees = w.size();
+  *max_nodes = mn;
+  if (nodes && weights) {
+    if (n.size() > cap_nodes || w.size() > cap_trees) return 2;
+    memcpy(nodes, n.data(), n.size() * sizeof(qr_node_t));
+    memcpy(weights, w.data(), w.size() * sizeof(double));
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// quicklearn -- command-line front end with QuickRank's flag surface for the
+// algorithms this build accelerates (src/quicklearn.cc:89-507 and
+// src/driver/driver.cc:45-226 of the reference): same option names, defaults
+// and phase order (load -> train -> save -> test -> scores file).  Options of
+// out-of-scope subsystems (DART, CLEAVER, linear rankers, code generators) are
+// recognised and rejected with a message.
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <set>
+
+#include "mart.h"
+#include "svml.h"
+
+using namespace quickrank;
+using learning::forests::Mart;
+
+namespace {
+struct Opt {
+  std::string help, dflt;
+  bool has_arg;
+};
+const std::vector<std::pair<std::string, Opt>> kOptions = {
+    {"algo", {"LtR algorithm: [MART|LAMBDAMART|OBVMART|OBVLAMBDAMART].", "LAMBDAMART", true}},
+    {"train-metric", {"set train metric: [DCG|NDCG].", "NDCG", true}},
+    {"train-cutoff", {"set train metric cutoff.", "10", true}},
+    {"partial", {"set partial file save frequency.", "100", true}},
+    {"train", {"set training file.", "", true}},
+    {"valid", {"set validation file.", "", true}},
+    {"features", {"set features file.", "", true}},
+    {"model-in", {"set input model file (for testing, re-training or optimization)", "", true}},
+    {"model-out", {"set output model file", "", true}},
+    {"skip-train", {"skip training phase.", "", false}},
+    {"restart-train", {"restart training phase from a previous trained model.", "", false}},
+    {"num-trees", {"set number of trees.", "1000", true}},
+    {"shrinkage", {"set shrinkage.", "0.1", true}},
+    {"num-thresholds", {"set number of thresholds.", "0", true}},
+    {"min-leaf-support", {"set minimum number of leaf support.", "1", true}},
+    {"end-after-rounds",
+     {"set num. rounds with no gain in validation before ending (if 0 disabled).", "100", true}},
+    {"num-leaves", {"set number of leaves [applies only to MART/LambdaMART].", "10", true}},
+    {"tree-depth", {"set tree depth [applies only to ObliviousMART/ObliviousLambdaMART].", "3", true}},
+    {"test-metric", {"set test metric: [DCG|NDCG].", "NDCG", true}},
+    {"test-cutoff", {"set test metric cutoff.", "10", true}},
+    {"test", {"set testing file.", "", true}},
+    {"scores", {"set output scores file.", "", true}},
+};
+const std::set<std::string> kOutOfScope = {
+    "meta-algo", "final-num-trees", "opt-last-only", "meta-end-after-rounds", "meta-verbose",
+    "sample-type", "normalize-type", "adaptive-type", "rate-drop", "skip-drop", "keep-drop",
+    "best-on-train", "random-keep", "drop-on-best", "num-samples", "window-size", "reduction-factor",
+    "max-iterations", "max-failed-valid", "adaptive", "train-partial", "valid-partial", "opt-algo",
+    "opt-method", "opt-model", "opt-algo-model", "pruning-rate", "with-line-search",
+    "line-search-model", "detailed", "model-file", "code-file", "generator", "subsample",
+    "max-features", "collapse-leaves-factor"};
+
+void help() {
+  std::cout << "quicklearn (MI355X build): LambdaMART / MART / oblivious variants on the GPU\n\n";
+  for (auto &o : kOptions) {
+    std::string left = "  --" + o.first + (o.second.has_arg ? " <arg>" : "");
+    if (!o.second.dflt.empty()) left += " (" + o.second.dflt + ")";
+    std::cout << std::left << std::setw(40) << left << o.second.help << "\n";
+  }
+  std::cout << "  -h,--help                             print help message.\n";
+}
+
+std::shared_ptr<data::Dataset> load_dataset(const std::string &file, const std::string &label) {
+  io::Svml reader;
+  std::cout << "# Reading " + label + " dataset: " << file << std::endl;
+  std::shared_ptr<data::Dataset> ds = reader.read_horizontal(file);  // driver.cc:387-407
+  std::cout << std::setprecision(2) << "#\t Reading time: " << reader.reading_time() << " s. @ "
+            << reader.file_size() / 1024 / 1024 / std::max(reader.reading_time(), 1e-9) << " MB/s "
+            << " (post-proc.: " << reader.processing_time() << " s.)" << std::endl;
+  std::cout << "#\t Dataset size: " << ds->num_instances() << " x " << ds->num_features()
+            << " (instances x features)" << std::endl
+            << "#\t Num queries: " << ds->num_queries() << " | Avg. len: " << std::setprecision(3)
+            << ds->num_instances() / (float)ds->num_queries() << std::endl;
+  return ds;
+}
+}  // namespace
+
+int main(int argc, char *argv[]) {
+  std::cout << std::fixed;
+  std::map<std::string, std::string> v;
+  std::set<std::string> isset;
+  for (auto &o : kOptions) v[o.first] = o.second.dflt;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a == "-h" || a == "--help") {
+      help();
+      return EXIT_SUCCESS;
+    }
+    if (a.rfind("--", 0) != 0) {
+      std::cerr << "!!! unexpected argument " << a << std::endl;
+      return EXIT_FAILURE;
+    }
+    a = a.substr(2);
+    if (kOutOfScope.count(a)) {
+      std::cerr << "!!! option --" << a << " belongs to a subsystem outside this build's scope "
+                << "(see DESIGN.md section 8)." << std::endl;
+      return EXIT_FAILURE;
+    }
+    bool found = false;
+    for (auto &o : kOptions)
+      if (o.first == a) {
+        found = true;
+        isset.insert(a);
+        if (o.second.has_arg) {
+          if (i + 1 >= argc) {
+            std::cerr << "!!! option --" << a << " needs an argument" << std::endl;
+            return EXIT_FAILURE;
+          }
+          v[a] = argv[++i];
+        }
+      }
+    if (!found) {
+      std::cerr << "!!! unknown option --" << a << std::endl;
+      return EXIT_FAILURE;
+    }
+  }
+  if (!isset.count("train") && !isset.count("test")) {  // driver.cc:47-51
+    help();
+    return EXIT_FAILURE;
+  }
+  // ltr_algorithm_factory.cc:41-261 for the in-scope names
+  std::shared_ptr<Mart> algo;
+  if (isset.count("model-in") && !isset.count("restart-train") &&
+      (isset.count("skip-train") || !isset.count("train"))) {
+    std::cout << "# Loading model from file " << v["model-in"] << std::endl;
+    algo = Mart::load_model_from_file(v["model-in"]);
+  } else {
+    Mart::Algo a;
+    if (!Mart::algo_from_name(v["algo"], &a)) {
+      std::cerr << " !! LTR Algorithm was not set properly" << std::endl;  // driver.cc:58-61
+      return EXIT_FAILURE;
+    }
+    algo = std::make_shared<Mart>(a, std::stoul(v["num-trees"]), std::stod(v["shrinkage"]),
+                                  std::stoul(v["num-thresholds"]), std::stoul(v["num-leaves"]),
+                                  std::stoul(v["min-leaf-support"]), std::stoul(v["end-after-rounds"]),
+                                  std::stoul(v["tree-depth"]));
+    if (isset.count("model-in") && isset.count("restart-train")) {
+      auto loaded = Mart::load_model_from_file(v["model-in"]);
+      if (!loaded || !algo->import_model_state(*loaded)) {  // ltr_algorithm_factory.cc:249-258
+        std::cerr << " !! Mismatch between the loaded model and the parameters of the model to train"
+                  << std::endl;
+        return EXIT_FAILURE;
+      }
+    }
+  }
+  if (!algo) {
+    std::cerr << " !! LTR Algorithm was not set properly" << std::endl;
+    return EXIT_FAILURE;
+  }
+  std::cout << std::endl;
+  algo->print(std::cout);
+  std::cout << std::endl;
+
+  if (isset.count("train") && !isset.count("skip-train")) {
+    auto training = load_dataset(v["train"], "training");
+    std::shared_ptr<data::Dataset> validation;
+    if (!v["valid"].empty()) validation = load_dataset(v["valid"], "validation");
+    algo->learn(training, validation, v["train-metric"], std::stoul(v["train-cutoff"]),
+                std::stoul(v["partial"]), v["model-out"]);  // driver.cc:228-246
+    if (!v["model-out"].empty()) {
+      std::cout << std::endl << "# Writing model to file: " << v["model-out"] << std::endl << std::endl;
+      algo->save(v["model-out"]);
+    }
+  }
+  if (isset.count("test")) {  // driver.cc:326-385
+    auto test = load_dataset(v["test"], "test");
+    std::vector<Score> scores(test->num_instances(), 0.0);
+    algo->score_dataset(*test, scores.data());
+    const size_t k = std::stoul(v["test-cutoff"]);
+    MetricScore s = algo->evaluate(*test, scores.data(), v["test-metric"], k);
+    std::cout << std::endl << v["test-metric"] << "@" << k << " on test data = " << std::setprecision(4)
+              << s << std::endl << std::endl;
+    if (!v["scores"].empty()) {
+      std::ofstream os;
+      os << std::setprecision(std::numeric_limits<Score>::max_digits10);
+      os.open(v["scores"], std::fstream::out);
+      for (size_t i = 0; i < test->num_instances(); ++i) os << scores[i] << std::endl;
+      os.close();
+      std::cout << "# Scores written to file: " << v["scores"] << std::endl;
+    }
+  }
+  return EXIT_SUCCESS;
+}

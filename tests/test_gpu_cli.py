@@ -1,0 +1,133 @@
+"""quicklearn / quickscore end to end on the GPU: SVMLight in, XML model out,
+scores file, reload -- the reference's own forest-test pattern
+(catch-unit-tests/learning/forests/test-lambdamart.cc:36-138: train, save, reload,
+re-score, same metric) plus parity of the saved trees with the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from datagen import make_dataset
+from parity_util import assert_tree_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tools():
+    from quickrank_amd import build
+    build.build()
+    outs = build.build_host()
+    return dict(lib=outs[0], quicklearn=outs[1], quickscore=outs[2])
+
+
+def _write_svml(path, x, labels, qoff):
+    with open(path, "w") as f:
+        for q in range(len(qoff) - 1):
+            for i in range(int(qoff[q]), int(qoff[q + 1])):
+                feats = " ".join(f"{j + 1}:{float(v):.9g}" for j, v in enumerate(x[i]))
+                f.write(f"{int(labels[i])} qid:{q + 1} {feats}\n")
+
+
+def _load_model(tools, path):
+    from quickrank_amd import _capi
+    L = C.CDLL(tools["lib"])
+    sz = C.c_size_t
+    L.qrh_model_read.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(sz), C.POINTER(sz), sz, sz]
+    nt, mn = sz(), sz()
+    assert L.qrh_model_read(path.encode(), None, None, C.byref(nt), C.byref(mn), 0, 0) == 0
+    nodes = np.zeros((nt.value, mn.value), _capi.NODE_DTYPE)
+    w = np.zeros(nt.value)
+    assert L.qrh_model_read(path.encode(), nodes.ctypes.data, w.ctypes.data, C.byref(nt), C.byref(mn),
+                            nodes.size, nt.value) == 0
+    return nodes, w
+
+
+@pytest.mark.parametrize("algo,extra", [("LAMBDAMART", ["--num-leaves", "8"]),
+                                        ("MART", ["--num-leaves", "6"]),
+                                        ("OBVLAMBDAMART", ["--tree-depth", "3"])])
+def test_quicklearn_end_to_end(tools, oracle_lib, tmp_path, algo, extra):
+    x, labels, qoff = make_dataset(nq=150, docs_per_query=40, F=25, seed=41)
+    x = x.astype(np.float32)
+    vx, vl, vq = make_dataset(nq=40, docs_per_query=30, F=25, seed=42)
+    tr, va, te = (str(tmp_path / n) for n in ("train.svml", "valid.svml", "test.svml"))
+    _write_svml(tr, x, labels, qoff)
+    _write_svml(va, vx, vl, vq)
+    _write_svml(te, vx, vl, vq)
+    # the text round trip is part of the pipeline: train the oracle on what the file holds
+    x = np.array([[np.float32(f"{float(v):.9g}") for v in row] for row in x], np.float32)
+    model, scores = str(tmp_path / "model.xml"), str(tmp_path / "scores.txt")
+    cmd = [tools["quicklearn"], "--algo", algo, "--train", tr, "--valid", va, "--test", te,
+           "--num-trees", "6", "--shrinkage", "0.1", "--num-thresholds", "64", "--min-leaf-support", "10",
+           "--end-after-rounds", "0", "--model-out", model, "--scores", scores, "--partial", "3"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "# iter. training validation" in out.stdout and "on test data" in out.stdout
+    assert os.path.exists(model + ".T3.xml") and os.path.exists(model + ".T6.xml")   # --partial 3
+    nodes, w = _load_model(tools, model)
+    assert len(nodes) == 6 and np.allclose(w, 0.1)
+    kw = dict(ntrees=6, shrinkage=0.1, nthresholds=64, minls=10, esr=0)
+    if algo.startswith("OBV"):
+        om = oracle_lib.train(x, labels, qoff, algo=algo, depth=3, valid=(vx, vl, vq), **kw)
+    else:
+        om = oracle_lib.train(x, labels, qoff, algo=algo, nleaves=int(extra[1]), valid=(vx, vl, vq), **kw)
+    t = oracle_lib.Trainer(x, 64)
+    for i in range(6):
+        n = int(om["nnodes"][i])
+        o = om["nodes"][i][:n]
+        # the XML keeps (feature, threshold), not the slot: recover the slot from the thresholds
+        g = nodes[i].copy()
+        for k in range(len(g)):
+            if g[k]["feature"] >= 0:
+                f = g[k]["feature"]
+                ts = int(t.thr_size[f])
+                hit = np.nonzero(t.thr[f, :ts].view(np.uint32) == g[k]["threshold"].view(np.uint32))[0]
+                assert len(hit) >= 1
+                g[k]["thr_id"] = hit[0]
+        # node numbering differs (XML is pre-order); parity_util walks by child links
+        g["nsamples"] = 0
+        _walk_equal(t.stmap, o, g)
+    # scores file == scoring the reloaded model (driver.cc:371-379 precision)
+    s = np.loadtxt(scores)
+    out2 = subprocess.run([tools["quicklearn"], "--model-in", model, "--test", te, "--scores",
+                           str(tmp_path / "s2.txt")], capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stdout + out2.stderr
+    assert np.array_equal(np.loadtxt(str(tmp_path / "s2.txt")), s)
+    want = oracle_lib.ensemble_score(dict(nodes=nodes, nnodes=np.full(6, nodes.shape[1], np.uint64), ntrees=6,
+                                          max_nodes=nodes.shape[1], shrinkage=0.1), vx)
+    assert np.array_equal(s, want)
+    out3 = subprocess.run([tools["quickscore"], "-d", te, "-m", model, "-r", "2", "-s",
+                           str(tmp_path / "s3.txt")], capture_output=True, text=True, timeout=300)
+    assert out3.returncode == 0 and "Avg.    Doc. scoring time" in out3.stdout
+    assert np.array_equal(np.loadtxt(str(tmp_path / "s3.txt")), s)
+
+
+def _walk_equal(stmap, onodes, gnodes):
+    """Same split (feature, slot) and leaf values along matching child links."""
+    stack = [(0, 0)]
+    while stack:
+        oi, gi = stack.pop()
+        o, g = onodes[oi], gnodes[gi]
+        assert (o["feature"] < 0) == (g["feature"] < 0)
+        if o["feature"] < 0:
+            assert np.isclose(g["value"], o["value"], rtol=1e-7, atol=1e-10)
+            continue
+        assert (o["feature"], o["thr_id"]) == (g["feature"], g["thr_id"]), (oi, gi)
+        stack.append((int(o["left"]), int(g["left"])))
+        stack.append((int(o["right"]), int(g["right"])))
+
+
+def test_quicklearn_rejects_out_of_scope_and_bad_input(tools, tmp_path):
+    r = subprocess.run([tools["quicklearn"], "--algo", "DART", "--train", "x"], capture_output=True, text=True)
+    assert r.returncode != 0 and "not set properly" in r.stderr
+    r = subprocess.run([tools["quicklearn"], "--opt-algo", "CLEAVER"], capture_output=True, text=True)
+    assert r.returncode != 0 and "outside this build's scope" in r.stderr
+    bad = str(tmp_path / "bad.svml")
+    open(bad, "w").write("1 quid:3 1:2\n")
+    r = subprocess.run([tools["quicklearn"], "--train", bad], capture_output=True, text=True)
+    assert r.returncode == 1            # strutils.cc:68: missing "qid:" -> exit(1)
+    open(bad, "w").write("1 qid:3 1:2 x:y\n")
+    r = subprocess.run([tools["quicklearn"], "--train", bad], capture_output=True, text=True)
+    assert r.returncode == 4            # svml.cc:112: malformed feature -> exit(4)

@@ -1,0 +1,150 @@
+"""Host C++ layer (quickrank_amd/host): SVMLight reader/writer against the
+reference's own Svml (oracle/_ref, bit for bit) and the XML model format."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from datagen import make_dataset
+
+
+@pytest.fixture(scope="module")
+def host():
+    from quickrank_amd import build
+    build.build()
+    build.build_host()
+    L = C.CDLL(build.HOST_LIB)
+    sz = C.c_size_t
+    L.qrh_svml_read.argtypes = [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.c_void_p,
+                                C.c_void_p, C.c_void_p]
+    L.qrh_svml_write.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, sz, sz]
+    L.qrh_model_roundtrip.argtypes = [C.c_char_p, C.c_char_p]
+    L.qrh_model_write.argtypes = [C.c_char_p, C.c_int, sz, C.c_double, sz, sz, sz, sz, sz, C.c_void_p,
+                                  sz, sz]
+    L.qrh_model_read.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(sz), C.POINTER(sz), sz, sz]
+    return L
+
+
+def _read(fn, path):
+    sz = C.c_size_t
+    N, F, Q = sz(), sz(), sz()
+    fn(path.encode(), C.byref(N), C.byref(F), C.byref(Q), None, None, None)
+    x = np.zeros((N.value, F.value), np.float32)
+    lab = np.zeros(N.value, np.float32)
+    qoff = np.zeros(Q.value + 1, np.uint64)
+    fn(path.encode(), C.byref(N), C.byref(F), C.byref(Q), x.ctypes.data, lab.ctypes.data, qoff.ctypes.data)
+    return x, lab, qoff
+
+
+SVML_TEXT = """# a comment line
+2 qid:1 1:0.5 3:1.25 # doc one
+0 qid:1 2:-3e-2\t4:7
+   1   qid:1    1:1 2:2 3:3 4:4 5:5
+# another comment
+3 qid:2 5:0.125
+0 qid:2
+1 qid:7 1:1e10 2:-0
+2 qid:2 3:9.5 #trailing description 6:1
+"""
+
+
+@pytest.mark.ref
+def test_svml_reader_matches_reference(host, oracle_lib, tmp_path):
+    R = oracle_lib.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not present")
+    p = str(tmp_path / "a.svml")
+    open(p, "w").write(SVML_TEXT)
+    a, b = _read(host.qrh_svml_read, p), _read(R.ref_svml_read, p)
+    for u, v in zip(a, b):
+        assert u.shape == v.shape and np.array_equal(u.view(np.uint32) if u.dtype == np.float32 else u,
+                                                     v.view(np.uint32) if v.dtype == np.float32 else v)
+    assert a[0].shape == (7, 5) and a[2].tolist() == [0, 3, 5, 6, 7]   # qid change = new query
+    # a generated file, written by the reference's writer and by ours: identical bytes
+    x, labels, qoff = make_dataset(nq=9, docs_per_query=7, F=11, seed=4, ragged=True, adversarial=True)
+    p1, p2 = str(tmp_path / "ref.svml"), str(tmp_path / "ours.svml")
+    R.ref_svml_write(p1.encode(), x, labels, qoff, len(qoff) - 1, x.shape[1])
+    host.qrh_svml_write(p2.encode(), x.ctypes.data, labels.ctypes.data, qoff.ctypes.data, len(qoff) - 1,
+                        x.shape[1])
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+    rx, rl, rq = _read(host.qrh_svml_read, p2)
+    # svml.cc:176-180 writes std::fixed with 9 decimals: exact only to 1e-9 absolute
+    assert np.allclose(rx, x, rtol=0, atol=1e-9) and np.array_equal(rl, labels) and np.array_equal(rq, qoff)
+
+
+def test_svml_reader_standalone(host, tmp_path):
+    p = str(tmp_path / "a.svml")
+    open(p, "w").write(SVML_TEXT)
+    x, lab, qoff = _read(host.qrh_svml_read, p)
+    assert x.shape == (7, 5) and lab.tolist() == [2, 0, 1, 3, 0, 1, 2]
+    assert x[0].tolist() == [0.5, 0, 1.25, 0, 0] and x[6].tolist() == [0, 0, 9.5, 0, 0]
+
+
+def _toy_nodes(capi):
+    n = np.zeros((2, 5), capi.NODE_DTYPE)
+    n["feature"] = -1
+    n["left"] = n["right"] = -1
+    n[0, 0] = (2, 7, np.float32(0.1), 1, 2, 0.0, 0.0, 10)
+    n[0, 1]["value"] = -1.5
+    n[0, 2] = (0, 3, np.float32(3.4028235e38), 3, 4, 0.0, 0.0, 5)
+    n[0, 3]["value"] = 0.1
+    n[0, 4]["value"] = 1.0 / 3.0
+    n[1, 0]["value"] = 2.0
+    return n
+
+
+def test_xml_model_format_and_roundtrip(host, tmp_path):
+    from quickrank_amd import _capi
+    nodes = _toy_nodes(_capi)
+    p = str(tmp_path / "m.xml")
+    assert host.qrh_model_write(p.encode(), 1, 100, 0.1, 255, 10, 1, 100, 3, nodes.ctypes.data, 2, 5) == 0
+    text = open(p).read()
+    want = (
+        "<ranker>\n\t<info>\n\t\t<type>LAMBDAMART</type>\n\t\t<trees>100</trees>\n\t\t<leaves>10</leaves>\n"
+        "\t\t<shrinkage>0.10000000000000001</shrinkage>\n\t\t<leafsupport>1</leafsupport>\n"
+        "\t\t<discretization>255</discretization>\n\t\t<estop>100</estop>\n\t\t<subsample>1</subsample>\n"
+        "\t\t<max_features>1</max_features>\n\t\t<collapse_leaves_factor>0</collapse_leaves_factor>\n"
+        "\t</info>\n\t<ensemble>\n\t\t<tree id=\"1\" weight=\"0.10000000000000001\">\n\t\t\t<split>\n"
+        "\t\t\t\t<feature>3</feature>\n\t\t\t\t<threshold>0.100000001</threshold>\n"
+        "\t\t\t\t<split pos=\"left\">\n\t\t\t\t\t<output>-1.5</output>\n\t\t\t\t</split>\n"
+        "\t\t\t\t<split pos=\"right\">\n\t\t\t\t\t<feature>1</feature>\n"
+        "\t\t\t\t\t<threshold>3.40282347e+38</threshold>\n\t\t\t\t\t<split pos=\"left\">\n"
+        "\t\t\t\t\t\t<output>0.10000000000000001</output>\n\t\t\t\t\t</split>\n"
+        "\t\t\t\t\t<split pos=\"right\">\n\t\t\t\t\t\t<output>0.33333333333333331</output>\n"
+        "\t\t\t\t\t</split>\n\t\t\t\t</split>\n\t\t\t</split>\n\t\t</tree>\n"
+        "\t\t<tree id=\"2\" weight=\"0.10000000000000001\">\n\t\t\t<split>\n\t\t\t\t<output>2</output>\n"
+        "\t\t\t</split>\n\t\t</tree>\n\t</ensemble>\n</ranker>\n")
+    assert text == want
+    # load -> save is the identity on the text
+    p2 = str(tmp_path / "m2.xml")
+    assert host.qrh_model_roundtrip(p.encode(), p2.encode()) == 0
+    assert open(p2).read() == text
+    # and on the numbers (thresholds to 9, outputs to 17 significant digits: rtnode.cc:58-70)
+    sz = C.c_size_t
+    nt, mn = sz(), sz()
+    host.qrh_model_read(p.encode(), None, None, C.byref(nt), C.byref(mn), 0, 0)
+    assert (nt.value, mn.value) == (2, 5)
+    back = np.zeros((2, 5), _capi.NODE_DTYPE)
+    w = np.zeros(2)
+    assert host.qrh_model_read(p.encode(), back.ctypes.data, w.ctypes.data, C.byref(nt), C.byref(mn), 10, 2) == 0
+    for k in ("feature", "left", "right"):
+        assert np.array_equal(back[k], nodes[k]), k
+    assert np.array_equal(back["threshold"].view(np.uint32), nodes["threshold"].view(np.uint32))
+    assert np.array_equal(back["value"].view(np.uint64), nodes["value"].view(np.uint64))
+    assert w.tolist() == [0.1, 0.1]
+    # a model with an XML declaration, comments and pretty spaces (other writers) still parses
+    p3 = str(tmp_path / "m3.xml")
+    open(p3, "w").write('<?xml version="1.0"?>\n<!-- c -->\n' + text.replace("\t", "  "))
+    assert host.qrh_model_roundtrip(p3.encode(), p2.encode()) == 0 and open(p2).read() == text
+
+
+def test_oblivious_xml_info_block(host, tmp_path):
+    from quickrank_amd import _capi
+    nodes = _toy_nodes(_capi)
+    p = str(tmp_path / "o.xml")
+    host.qrh_model_write(p.encode(), 3, 50, 0.05, 16, 8, 2, 7, 3, nodes.ctypes.data, 1, 5)
+    t = open(p).read()
+    # obliviouslambdamart.cc:72-83: <depth> after <leaves>, estop carries nthresholds, no subsample block
+    assert "<type>OBVLAMBDAMART</type>" in t and "<leaves>8</leaves>\n\t\t<depth>3</depth>" in t
+    assert "<estop>16</estop>" in t and "subsample" not in t

@@ -61,6 +61,25 @@ def cpu_baseline(x, labels, qoff, args):
                       f"OpenMP x{cores}"}
 
 
+def scoring_metric(ctx, args):
+    """Second metric of BASELINE.json ("ensemble-score docs/sec"): config 5's shape
+    (64-leaf trees, 200 features) at a size that keeps the default run short;
+    features resident on the device, kernel time from HIP events."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from score_bench import make_model
+    rng = np.random.default_rng(43)
+    nodes, w = make_model(args.score_trees, 6, 200, rng)
+    xs = rng.random((args.score_docs, 200), dtype=np.float32)
+    ctx.upload_ensemble(nodes, w)
+    ctx.score(xs)
+    _, ms = ctx.score(xs)
+    return {"metric": "ensemble-score docs/sec", "value": args.score_docs / ms * 1e3, "unit": "docs/s",
+            "node_visits_per_s": args.score_docs * args.score_trees * 6 / ms * 1e3,
+            "workload": f"{args.score_trees} trees x 64 leaves (depth 6) over {args.score_docs} docs x 200 "
+                        "features, synthetic; config 5 is 10x the trees and 10x the docs",
+            "kernel_ms": ms}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +91,9 @@ def main():
     ap.add_argument("--nleaves", type=int, default=10)
     ap.add_argument("--nthresholds", type=int, default=255)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scoring", action="store_true")
+    ap.add_argument("--score-trees", type=int, default=1000)
+    ap.add_argument("--score-docs", type=int, default=1000000)
     ap.add_argument("--cpu-queries", type=int, default=2500)
     ap.add_argument("--cpu-iters", type=int, default=6)
     args = ap.parse_args()
@@ -181,6 +203,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x, labels, qoff, args)
+        if world == 1 and not args.no_scoring:
+            out["ensemble_scoring"] = scoring_metric(ctx, args)
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

@@ -169,3 +169,250 @@ int qr_k_obl_score(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_ou
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
+
+
+// ===========================================================================
+// Binned doc-parallel scoring (the fast path of qr_ensemble_score)
+// ===========================================================================
+// The walk only ever evaluates `x[f] <= thr`; with the model's thresholds of
+// feature f sorted (t_0 < t_1 < ...), b(x) = #{t_i < x} gives
+//     x <= t_k  <=>  b(x) <= k                      (NaN -> b = count: always right)
+// so a document is reduced ONCE to one small integer per feature (u8 when every
+// feature has <= 255 distinct thresholds in the model -- any model trained with
+// --num-thresholds <= 255 -- else u16) and the trees compare integers.  This
+// quarters (halves) the LDS footprint of a document block, which is what limits
+// occupancy here, and keeps the result bit-identical to the f32 walk.
+//
+// k_doc_bins : f32 rows -> [64-doc block][feature][lane] bins (coalesced both ways)
+// k_score_bin: one wave = 64 documents whose bins sit in LDS as [feature][lane];
+//              the model streams through LDS in batches of trees shared by the
+//              workgroup's waves; each lane walks 4 trees at a time (independent
+//              chains hide the LDS latency) and adds leaf * weight strictly in
+//              tree order (ensemble.cc:111-118), separate multiply and add.
+struct CNode {  // 8 B: internal node of a compact tree
+  uint16_t feat, kbin, left, right;  // child: internal index, or 0x8000 | leaf index
+};
+
+// One workgroup = one group of DB_FG features x DB_BLOCKS 64-document blocks.  The
+// group's threshold rows are staged in LDS once (a binary search out of L2 costs a
+// 64-byte sector per step and made the first version L2-bandwidth-bound).
+#define DB_FG 32
+#define DB_BLOCKS 16
+template <typename BT>
+__global__ __launch_bounds__(256) void k_doc_bins(const float *__restrict__ x, const uint32_t N,
+                                                  const uint32_t F, const uint32_t xstride,
+                                                  const float *__restrict__ thr,
+                                                  const uint32_t *__restrict__ thr_cnt,
+                                                  const uint32_t tmax, const uint32_t lds_thr,
+                                                  BT *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *lt = reinterpret_cast<float *>(smem);                       // [DB_FG][tmax] when lds_thr
+  BT *tile = reinterpret_cast<BT *>(smem + (lds_thr ? (size_t)DB_FG * tmax * 4 : 0));  // [DB_FG][64]
+  __shared__ uint32_t cnt[DB_FG];
+  const uint32_t f0 = blockIdx.y * DB_FG;
+  const uint32_t nf = f0 + DB_FG <= F ? DB_FG : F - f0;
+  if (threadIdx.x < DB_FG) cnt[threadIdx.x] = threadIdx.x < nf ? thr_cnt[f0 + threadIdx.x] : 0;
+  if (lds_thr)
+    for (uint32_t i = threadIdx.x; i < nf * tmax; i += 256) lt[i] = thr[(size_t)f0 * tmax + i];
+  __syncthreads();
+  const uint32_t nblk = (N + 63) / 64;
+  for (uint32_t bb = 0; bb < DB_BLOCKS; ++bb) {
+    const uint32_t blk = blockIdx.x * DB_BLOCKS + bb;
+    if (blk >= nblk) break;
+    const uint32_t d0 = blk * 64;
+    for (uint32_t i = threadIdx.x; i < 64 * DB_FG; i += 256) {
+      const uint32_t r = i / DB_FG, f = i % DB_FG;
+      BT b = 0;
+      if (d0 + r < N && f < nf) {
+        const float v = x[(size_t)(d0 + r) * xstride + f0 + f];
+        const float *t = lds_thr ? lt + (size_t)f * tmax : thr + (size_t)(f0 + f) * tmax;
+        uint32_t lo = 0, hi = cnt[f];  // first index with t[idx] >= v
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (t[mid] < v)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        if (v != v) lo = cnt[f];  // NaN: x <= thr is false for every threshold
+        b = (BT)lo;
+      }
+      tile[f * 64 + r] = b;
+    }
+    __syncthreads();
+    BT *dst = out + ((size_t)blk * F + f0) * 64;
+    for (uint32_t i = threadIdx.x; i < 64 * nf; i += 256) dst[i] = tile[i];
+    __syncthreads();
+  }
+}
+
+template <typename BT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_score_bin(
+    const BT *__restrict__ bins, const uint32_t N, const uint32_t F,
+    const CNode *__restrict__ cnodes, const double *__restrict__ cleaves,
+    const uint16_t *__restrict__ root_code, const double *__restrict__ weights,
+    const uint32_t ntrees, const uint32_t NI, const uint32_t NL, const uint32_t tbatch,
+    double *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t doc_bytes = ((size_t)F * 64 * sizeof(BT) + 15) & ~(size_t)15;
+  BT *mybins = reinterpret_cast<BT *>(smem + wave * doc_bytes);
+  char *tb = smem + NW * doc_bytes;
+  double *lv = reinterpret_cast<double *>(tb);                          // [tbatch][NL]
+  CNode *ln = reinterpret_cast<CNode *>(lv + (size_t)tbatch * NL);      // [tbatch][NI]
+  double *lw = reinterpret_cast<double *>(ln + (size_t)tbatch * NI);    // [tbatch]
+  uint16_t *lr = reinterpret_cast<uint16_t *>(lw + tbatch);             // [tbatch]
+  const uint32_t nblocks = (N + 63) / 64;
+  const uint32_t blk = blockIdx.x * NW + wave;
+  const bool have = blk < nblocks;
+  if (have) {
+    const BT *src = bins + (size_t)blk * 64 * F;
+    // 16-byte copies of this wave's [F][64] block
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d4 = reinterpret_cast<uint4 *>(mybins);
+    const uint32_t n16 = (uint32_t)(F * 64 * sizeof(BT) / 16);
+    for (uint32_t i = lane; i < n16; i += 64) d4[i] = s4[i];
+  }
+  const uint32_t doc = blk * 64 + lane;
+  double sum = 0.0;
+  for (uint32_t t0 = 0; t0 < ntrees; t0 += tbatch) {
+    const uint32_t nb = t0 + tbatch <= ntrees ? tbatch : ntrees - t0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb * NL; i += NW * 64) lv[i] = cleaves[(size_t)t0 * NL + i];
+    {
+      const unsigned long long *sn = reinterpret_cast<const unsigned long long *>(cnodes + (size_t)t0 * NI);
+      unsigned long long *dn = reinterpret_cast<unsigned long long *>(ln);
+      for (uint32_t i = threadIdx.x; i < nb * NI; i += NW * 64) dn[i] = sn[i];
+    }
+    for (uint32_t i = threadIdx.x; i < nb; i += NW * 64) {
+      lw[i] = weights[t0 + i];
+      lr[i] = root_code[t0 + i];
+    }
+    __syncthreads();
+    if (!have) continue;
+    // branch-free step: a finished chain re-reads node 0 and keeps its leaf code
+    const unsigned long long *ln64 = reinterpret_cast<const unsigned long long *>(ln);
+    auto step = [&](const uint32_t c, const unsigned long long *nodes) -> uint32_t {
+      const bool leaf = (c & 0x8000u) != 0;
+      const unsigned long long nd = nodes[leaf ? 0u : c];
+      const uint32_t feat = (uint32_t)nd & 0xffffu, kbin = ((uint32_t)nd >> 16);
+      const uint32_t l = (uint32_t)(nd >> 32) & 0xffffu, r = (uint32_t)(nd >> 48);
+      const uint32_t bv = mybins[feat * 64 + lane];
+      const uint32_t nxt = bv <= kbin ? l : r;
+      return leaf ? c : nxt;
+    };
+    uint32_t t = 0;
+    for (; t + 8 <= nb; t += 8) {
+      uint32_t c[8];
+      const unsigned long long *nn[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        c[j] = lr[t + j];
+        nn[j] = ln64 + (size_t)(t + j) * NI;
+      }
+      for (;;) {
+        uint32_t all = c[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) all &= c[j];
+        if (!__any((all & 0x8000u) == 0)) break;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = step(c[j], nn[j]);
+      }
+      const double *l0 = lv + (size_t)t * NL;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double v = l0[j * NL + (c[j] & 0x7fffu)] * lw[t + j];
+        sum = sum + v;
+      }
+    }
+    for (; t + 4 <= nb; t += 4) {
+      uint32_t c0 = lr[t], c1 = lr[t + 1], c2 = lr[t + 2], c3 = lr[t + 3];
+      const unsigned long long *n0 = ln64 + (size_t)t * NI, *n1 = n0 + NI, *n2 = n1 + NI, *n3 = n2 + NI;
+      while (__any(((c0 & c1 & c2 & c3) & 0x8000u) == 0)) {
+        c0 = step(c0, n0);
+        c1 = step(c1, n1);
+        c2 = step(c2, n2);
+        c3 = step(c3, n3);
+      }
+      const double *l0 = lv + (size_t)t * NL;
+      const double v0 = l0[c0 & 0x7fffu] * lw[t];
+      const double v1 = l0[NL + (c1 & 0x7fffu)] * lw[t + 1];
+      const double v2 = l0[2 * NL + (c2 & 0x7fffu)] * lw[t + 2];
+      const double v3 = l0[3 * NL + (c3 & 0x7fffu)] * lw[t + 3];
+      sum = sum + v0;
+      sum = sum + v1;
+      sum = sum + v2;
+      sum = sum + v3;
+    }
+    for (; t < nb; ++t) {
+      uint32_t c0 = lr[t];
+      const unsigned long long *n0 = ln64 + (size_t)t * NI;
+      while (__any((c0 & 0x8000u) == 0)) c0 = step(c0, n0);
+      const double v0 = lv[(size_t)t * NL + (c0 & 0x7fffu)] * lw[t];
+      sum = sum + v0;
+    }
+  }
+  if (have && doc < N) out[doc] = sum;
+}
+
+template <typename BT, int NW>
+static int launch_binned_nw(qr_ctx *c, const float *d_x, size_t N, size_t xstride, double *d_out,
+                            size_t tbatch) {
+  const size_t F = c->sb_F;
+  const size_t doc_bytes = (F * 64 * sizeof(BT) + 15) & ~(size_t)15;
+  const size_t per_tree = c->sb_NL * 8 + c->sb_NI * 8 + 8 + 2;
+  const size_t lds = NW * doc_bytes + tbatch * per_tree + 64;
+  const size_t nblk = (N + 63) / 64;
+  QR_CHECK(c, hipFuncSetAttribute((const void *)k_score_bin<BT, NW>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_score_bin<BT, NW>), dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds,
+                     c->stream, (const BT *)c->d_sb_bins, (uint32_t)N, (uint32_t)F,
+                     (const CNode *)c->d_sb_nodes, c->d_sb_leaves, c->d_sb_root, c->d_ens_w,
+                     (uint32_t)c->ens_trees, (uint32_t)c->sb_NI, (uint32_t)c->sb_NL, (uint32_t)tbatch, d_out);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+template <typename BT>
+static int launch_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, double *d_out) {
+  const size_t F = c->sb_F;  // features the model tests; the rows may be wider
+  const size_t doc_bytes = (F * 64 * sizeof(BT) + 15) & ~(size_t)15;
+  const size_t per_tree = c->sb_NL * 8 + c->sb_NI * 8 + 8 + 2;
+  const size_t budget = 160 * 1024 - 1024;
+  // tree batch: 16..32 trees; the rest of the LDS goes to document blocks (occupancy)
+  size_t tbatch = 32;
+  while (tbatch > 8 && 4 * doc_bytes + tbatch * per_tree + 64 > budget) tbatch -= 8;
+  if (4 * doc_bytes + tbatch * per_tree + 64 > budget) return -1;  // caller falls back
+  size_t nw = (budget - tbatch * per_tree - 64) / doc_bytes;
+  nw = nw >= 16 ? 16 : nw >= 12 ? 12 : nw >= 8 ? 8 : 4;
+  const size_t nblk = (N + 63) / 64;
+  const size_t need = nblk * 64 * F * sizeof(BT);
+  if (need > c->sb_bins_bytes) {
+    if (c->d_sb_bins) (void)hipFree(c->d_sb_bins);
+    c->d_sb_bins = nullptr;
+    QR_CHECK(c, hipMalloc(&c->d_sb_bins, need));
+    c->sb_bins_bytes = need;
+  }
+  const uint32_t lds_thr = (size_t)DB_FG * c->sb_tmax * 4 <= 96 * 1024 ? 1 : 0;
+  const size_t lds_a = (lds_thr ? (size_t)DB_FG * c->sb_tmax * 4 : 0) + DB_FG * 64 * sizeof(BT);
+  if (lds_a > 64 * 1024)
+    QR_CHECK(c, hipFuncSetAttribute((const void *)k_doc_bins<BT>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+  hipLaunchKernelGGL(k_doc_bins<BT>,
+                     dim3((unsigned)((nblk + DB_BLOCKS - 1) / DB_BLOCKS), (unsigned)((F + DB_FG - 1) / DB_FG)),
+                     dim3(256), lds_a, c->stream, d_x, (uint32_t)N, (uint32_t)F, (uint32_t)xstride,
+                     c->d_sb_thr, c->d_sb_thr_cnt, (uint32_t)c->sb_tmax, lds_thr, (BT *)c->d_sb_bins);
+  QR_CHECK(c, hipGetLastError());
+  switch (nw) {
+    case 16: return launch_binned_nw<BT, 16>(c, d_x, N, xstride, d_out, tbatch);
+    case 12: return launch_binned_nw<BT, 12>(c, d_x, N, xstride, d_out, tbatch);
+    case 8: return launch_binned_nw<BT, 8>(c, d_x, N, xstride, d_out, tbatch);
+    default: return launch_binned_nw<BT, 4>(c, d_x, N, xstride, d_out, tbatch);
+  }
+}
+
+int qr_k_ensemble_score_fast(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out) {
+  if (!c->sb_ready || F < c->sb_F) return -1;
+  return c->sb_u8 ? launch_binned<uint8_t>(c, d_x, N, F, d_out)
+                  : launch_binned<uint16_t>(c, d_x, N, F, d_out);
+}

@@ -94,6 +94,9 @@ void qr_ctx_destroy(qr_ctx *c) {
   dfree(c->d_keys); dfree(c->d_tied);
   dfree(c->d_obl_feat); dfree(c->d_obl_thr); dfree(c->d_obl_leaves); dfree(c->d_obl_w);
   dfree(c->d_obl_depths);
+  if (c->d_sb_nodes) (void)hipFree(c->d_sb_nodes);
+  if (c->d_sb_bins) (void)hipFree(c->d_sb_bins);
+  dfree(c->d_sb_leaves); dfree(c->d_sb_root); dfree(c->d_sb_thr); dfree(c->d_sb_thr_cnt);
   for (auto &p : c->prof_events) {
     (void)hipEventDestroy(p.first);
     (void)hipEventDestroy(p.second);
@@ -750,6 +753,94 @@ int qr_ranks_read(qr_ctx *c, uint32_t *out) {
 }
 
 // ---------------------------------------------------------------------------
+// Compact binned form of the model for k_score_bin: per-feature sorted distinct
+// thresholds, internal nodes as {feature, threshold index, children}, leaves apart.
+static int build_binned_model(qr_ctx *c, const qr_node_t *nodes, size_t ntrees, size_t max_nodes) {
+  c->sb_ready = false;
+  int maxf = -1;
+  for (size_t i = 0; i < ntrees * max_nodes; ++i) maxf = std::max(maxf, nodes[i].feature);
+  if (maxf < 0) return QR_OK;  // only leaves: the generic kernel handles it
+  const size_t F = (size_t)maxf + 1;
+  std::vector<std::vector<float>> thr(F);
+  // reachable nodes only
+  std::vector<std::vector<int>> order(ntrees);
+  size_t NI = 1, NL = 1;
+  for (size_t t = 0; t < ntrees; ++t) {
+    const qr_node_t *n = nodes + t * max_nodes;
+    std::vector<int> stack = {0};
+    size_t ni = 0, nl = 0;
+    while (!stack.empty()) {
+      const int i = stack.back();
+      stack.pop_back();
+      if (i < 0 || (size_t)i >= max_nodes) return QR_OK;  // malformed: keep the generic kernel
+      order[t].push_back(i);
+      if (n[i].feature >= 0) {
+        ++ni;
+        thr[n[i].feature].push_back(n[i].threshold);
+        stack.push_back(n[i].right);
+        stack.push_back(n[i].left);
+      } else
+        ++nl;
+    }
+    NI = std::max(NI, ni);
+    NL = std::max(NL, nl);
+  }
+  if (NI > 0x7fff || NL > 0x7fff) return QR_OK;
+  size_t tmax = 1;
+  for (auto &v : thr) {
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());  // -0.0 == 0.0: same comparisons
+    tmax = std::max(tmax, v.size());
+  }
+  if (tmax > 65535) return QR_OK;
+  std::vector<uint16_t> cn(ntrees * NI * 4, 0), root(ntrees, 0);
+  std::vector<double> leaves(ntrees * NL, 0.0);
+  for (size_t t = 0; t < ntrees; ++t) {
+    const qr_node_t *n = nodes + t * max_nodes;
+    std::vector<int> idx(max_nodes, -1);
+    size_t ni = 0, nl = 0;
+    for (int i : order[t]) idx[i] = n[i].feature >= 0 ? (int)ni++ : (int)(0x8000 | nl++);
+    for (int i : order[t]) {
+      if (n[i].feature >= 0) {
+        uint16_t *o = &cn[(t * NI + idx[i]) * 4];
+        const auto &v = thr[n[i].feature];
+        o[0] = (uint16_t)n[i].feature;
+        o[1] = (uint16_t)(std::lower_bound(v.begin(), v.end(), n[i].threshold) - v.begin());
+        o[2] = (uint16_t)idx[n[i].left];
+        o[3] = (uint16_t)idx[n[i].right];
+      } else
+        leaves[t * NL + (idx[i] & 0x7fff)] = n[i].value;
+    }
+    root[t] = (uint16_t)idx[0];
+  }
+  std::vector<float> tt(F * tmax, 0.0f);
+  std::vector<uint32_t> tc(F, 0);
+  for (size_t f = 0; f < F; ++f) {
+    tc[f] = (uint32_t)thr[f].size();
+    std::copy(thr[f].begin(), thr[f].end(), tt.begin() + f * tmax);
+  }
+  if (c->d_sb_nodes) (void)hipFree(c->d_sb_nodes);
+  c->d_sb_nodes = nullptr;
+  dfree(c->d_sb_leaves); dfree(c->d_sb_root); dfree(c->d_sb_thr); dfree(c->d_sb_thr_cnt);
+  QR_CHECK(c, hipMalloc(&c->d_sb_nodes, cn.size() * 2));
+  QR_CHECK(c, dalloc(&c->d_sb_leaves, leaves.size()));
+  QR_CHECK(c, dalloc(&c->d_sb_root, root.size()));
+  QR_CHECK(c, dalloc(&c->d_sb_thr, tt.size()));
+  QR_CHECK(c, dalloc(&c->d_sb_thr_cnt, tc.size()));
+  QR_CHECK(c, hipMemcpy(c->d_sb_nodes, cn.data(), cn.size() * 2, hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_sb_leaves, leaves.data(), leaves.size() * 8, hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_sb_root, root.data(), root.size() * 2, hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_sb_thr, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_sb_thr_cnt, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
+  c->sb_F = F;
+  c->sb_NI = NI;
+  c->sb_NL = NL;
+  c->sb_tmax = tmax;
+  c->sb_u8 = tmax <= 255;
+  c->sb_ready = true;
+  return QR_OK;
+}
+
 int qr_ensemble_upload(qr_ctx *c, const qr_node_t *nodes, size_t ntrees,
                        size_t max_nodes, const double *weights) {
   if (!c || !nodes || !weights || !ntrees || !max_nodes) return QR_ERR_ARG;
@@ -763,12 +854,22 @@ int qr_ensemble_upload(qr_ctx *c, const qr_node_t *nodes, size_t ntrees,
   QR_CHECK(c, hipMemcpy(c->d_ens_w, weights, ntrees * 8, hipMemcpyHostToDevice));
   c->ens_trees = ntrees;
   c->ens_maxnodes = max_nodes;
-  return QR_OK;
+  return build_binned_model(c, nodes, ntrees, max_nodes);
+}
+
+// features with index >= sb_F are never tested by the model, so a wider matrix
+// is fine for the fast path as long as the row stride is passed along
+static int score_any(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out) {
+  if (c->sb_ready && F >= c->sb_F) {
+    const int rc = qr_k_ensemble_score_fast(c, d_x, N, F, d_out);
+    if (rc >= 0) return rc;
+  }
+  return qr_k_ensemble_score(c, d_x, N, F, d_out);
 }
 
 int qr_ensemble_score_device(qr_ctx *c, const void *d_x, size_t N, size_t F, void *d_out) {
   if (!c || !d_x || !d_out) return QR_ERR_ARG;
-  return qr_k_ensemble_score(c, (const float *)d_x, N, F, (double *)d_out);
+  return score_any(c, (const float *)d_x, N, F, (double *)d_out);
 }
 
 int qr_ensemble_score(qr_ctx *c, const float *x, size_t N, size_t F, double *out,
@@ -783,7 +884,7 @@ int qr_ensemble_score(qr_ctx *c, const float *x, size_t N, size_t F, double *out
   QR_CHECK(c, hipEventCreate(&e0));
   QR_CHECK(c, hipEventCreate(&e1));
   QR_CHECK(c, hipEventRecord(e0, c->stream));
-  int rc = qr_k_ensemble_score(c, d_x, N, F, d_o);
+  int rc = score_any(c, d_x, N, F, d_o);
   QR_CHECK(c, hipEventRecord(e1, c->stream));
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   if (!rc) {

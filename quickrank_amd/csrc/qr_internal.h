@@ -225,6 +225,14 @@ struct qr_ctx {
   qr_node_t *d_ens = nullptr;
   double *d_ens_w = nullptr;
   size_t ens_trees = 0, ens_maxnodes = 0;
+  // compact binned form of the ensemble (k_score_bin)
+  bool sb_ready = false, sb_u8 = false;
+  size_t sb_F = 0, sb_NI = 0, sb_NL = 0, sb_tmax = 0, sb_bins_bytes = 0;
+  void *d_sb_nodes = nullptr, *d_sb_bins = nullptr;
+  double *d_sb_leaves = nullptr;
+  uint16_t *d_sb_root = nullptr;
+  float *d_sb_thr = nullptr;
+  uint32_t *d_sb_thr_cnt = nullptr;
   // oblivious ensemble (generate_oblivious.cc layout)
   uint32_t *d_obl_feat = nullptr, *d_obl_depths = nullptr;
   float *d_obl_thr = nullptr, *d_obl_w = nullptr;
@@ -271,3 +279,4 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls);
 int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
                         double *d_out);
 int qr_k_obl_score(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);
+int qr_k_ensemble_score_fast(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);

@@ -1,0 +1,51 @@
+"""Ensemble-scoring micro-benchmark (BASELINE.json config 5 shape, scaled):
+T trees x 64 leaves (depth 6, thresholds drawn from a 255-value pool per feature,
+like a model trained with --num-thresholds 255) over N docs x 200 features."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from quickrank_amd._capi import Context, NODE_DTYPE
+
+
+def make_model(T, depth, F, rng, pool=255):
+    thr_pool = np.sort(rng.random((F, pool), dtype=np.float32), axis=1)
+    nn = (1 << (depth + 1)) - 1
+    nodes = np.zeros((T, nn), NODE_DTYPE)
+    nodes["feature"] = -1
+    nodes["left"] = nodes["right"] = -1
+    ni = (1 << depth) - 1
+    for i in range(ni):
+        f = rng.integers(0, F, T)
+        nodes["feature"][:, i] = f
+        nodes["threshold"][:, i] = thr_pool[f, rng.integers(0, pool, T)]
+        nodes["left"][:, i] = 2 * i + 1
+        nodes["right"][:, i] = 2 * i + 2
+    nodes["value"][:, ni:] = rng.standard_normal((T, nn - ni))
+    return nodes, np.full(T, 0.1)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trees", type=int, default=1000)
+    ap.add_argument("--docs", type=int, default=1000000)
+    ap.add_argument("--features", type=int, default=200)
+    ap.add_argument("--depth", type=int, default=6)
+    ap.add_argument("--check", type=int, default=2000)
+    a = ap.parse_args()
+    rng = np.random.default_rng(43)
+    nodes, w = make_model(a.trees, a.depth, a.features, rng)
+    x = rng.random((a.docs, a.features), dtype=np.float32)
+    c = Context(0)
+    c.upload_ensemble(nodes, w)
+    s, ms = c.score(x)
+    s, ms = c.score(x)
+    visits = a.docs * a.trees * a.depth
+    print(f"trees {a.trees} docs {a.docs} F {a.features}: kernel {ms:.2f} ms -> {a.docs / ms * 1e3:.3e} docs/s, "
+          f"{visits / ms * 1e3:.3e} node visits/s")
+    if a.check:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+        import oracle
+        model = dict(nodes=nodes, nnodes=np.full(a.trees, nodes.shape[1], np.uint64), ntrees=a.trees,
+                     max_nodes=nodes.shape[1], shrinkage=0.1)
+        want = oracle.ensemble_score(model, x[:a.check])
+        print("bit-exact vs oracle on", a.check, "docs:", bool(np.array_equal(s[:a.check], want)))

@@ -18,3 +18,18 @@ def oracle_lib():
     import oracle
     oracle.build(ref=True)
     return oracle
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_runtime_first():
+    """torch bundles its own HIP runtime.  When libqr_hip.so (linked against
+    /opt/rocm's) initialises first, a later torch.cuda initialisation in the same
+    process can report "No HIP GPUs are available"; initialising torch first is
+    harmless on a CPU-only box."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield

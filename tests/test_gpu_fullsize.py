@@ -1,0 +1,180 @@
+"""Parity at BASELINE.json's full size (1M docs x 136 features x 10k queries),
+where the oracle is too slow to be the checker: size-independent properties of
+the path -- conservation laws of the histograms, permutation / sortedness of the
+ranking and of the document lists, antisymmetry of the lambdas, agreement between
+the leaf-membership score update and an independent tree walk on the raw
+features, run-to-run determinism, and sharded == unsharded."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NQ, DPQ, F = 10000, 100, 136
+
+
+@pytest.fixture(scope="module")
+def big():
+    # torch bundles its own HIP runtime: it has to initialise before libqr_hip.so
+    # pulls in /opt/rocm's, or torch later reports "No HIP GPUs are available"
+    import torch
+    torch.cuda.init()
+    import quickrank_amd as qr
+    from quickrank_amd import build
+    build.build()
+    rng = np.random.default_rng(42)
+    x = rng.random((NQ * DPQ, F), dtype=np.float32)
+    labels = np.minimum(4, np.floor(1.25 * x[:, :4].sum(axis=1, dtype=np.float64))).astype(np.float32)
+    qoff = np.arange(NQ + 1, dtype=np.uint64) * DPQ
+    c = qr.Context(0)
+    c.upload(x, labels, qoff)
+    thr, ts = c.build_bins(255)
+    return dict(qr=qr, c=c, x=x, labels=labels, qoff=qoff, thr=thr, ts=ts)
+
+
+def test_bins_are_lower_bounds(big):
+    bins = big["c"].read_bins()
+    x, thr, ts = big["x"], big["thr"], big["ts"]
+    rng = np.random.default_rng(0)
+    for f in rng.choice(F, 12, replace=False):
+        b = bins[:, f].astype(np.int64)
+        t = thr[f]
+        assert b.max() < ts[f]
+        assert np.all(x[:, f] <= t[b])                       # x <= thr[bin]
+        assert np.all((b == 0) | (x[:, f] > t[np.maximum(b - 1, 0)]))  # and not <= the slot before
+    # thresholds: FLT_MAX sentinel, non-decreasing
+    for f in range(F):
+        n = int(ts[f])
+        assert thr[f, n - 1] == np.finfo(np.float32).max and np.all(np.diff(thr[f, :n]) >= 0)
+
+
+def test_ranking_metric_and_lambdas(big):
+    c, labels, qoff = big["c"], big["labels"], big["qoff"]
+    rng = np.random.default_rng(1)
+    scores = np.round(rng.standard_normal(NQ * DPQ), 2)      # plenty of ties
+    c.set_scores(scores)
+    c.compute_lambdas("NDCG", 10)
+    ranks = c.ranks().reshape(NQ, DPQ)
+    assert np.array_equal(np.sort(ranks, axis=1), np.broadcast_to(np.arange(DPQ), (NQ, DPQ)))  # permutations
+    s = scores.reshape(NQ, DPQ)
+    sorted_s = np.take_along_axis(s, ranks.astype(np.int64), axis=1)
+    assert np.all(np.diff(sorted_s, axis=1) <= 0)            # non-increasing along the ranks
+    lam, w = c.get_pseudo()
+    lam, w = lam.reshape(NQ, DPQ), w.reshape(NQ, DPQ)
+    assert np.all(w >= 0)
+    # every pair adds +l to one doc and -l to the other (lambdamart.cc:137-138)
+    assert np.all(np.abs(lam.sum(axis=1)) <= 1e-12 * np.abs(lam).sum(axis=1) + 1e-300)
+    lab = labels.reshape(NQ, DPQ)
+    flat = lab.max(axis=1) == lab.min(axis=1)                # all labels equal: no pair contributes
+    assert not lam[flat].any() and not w[flat].any()
+    pq = c.metric_per_query()
+    assert np.all((pq >= 0) & (pq <= 1 + 1e-12))
+    assert c.metric_last() == pytest.approx(pq.mean(), rel=1e-12)
+    # idempotence: same scores -> same bits
+    c.compute_lambdas("NDCG", 10)
+    lam2, w2 = c.get_pseudo()
+    assert np.array_equal(lam2, lam.ravel()) and np.array_equal(w2, w.ravel())
+
+
+def test_tree_conservation_membership_and_determinism(big):
+    qr, c, x = big["qr"], big["c"], big["x"]
+    c.reset_scores()
+    c.compute_lambdas("NDCG", 10)
+    lam, _ = c.get_pseudo()
+    nodes = c.fit_tree(10, 1, True)
+    N = NQ * DPQ
+    assert nodes[0]["nsamples"] == N
+    hs0, hc0 = c.node_hist(0)
+    # the root histogram: every feature sees every document once, and the same total
+    assert np.all(hc0[:, 255] == N) and np.all(np.diff(hc0.astype(np.int64), axis=1) >= 0)
+    assert np.all(hs0[:, 255] == hs0[0, 255])
+    assert hs0[0, 255] == pytest.approx(lam.sum(), abs=2.0 ** -30 * np.sqrt(N) * np.abs(lam).max())
+    for i, n in enumerate(nodes):
+        if n["feature"] >= 0:
+            l, r = nodes[n["left"]], nodes[n["right"]]
+            assert l["nsamples"] + r["nsamples"] == n["nsamples"]
+            hp, cp = c.node_hist(i)
+            hl, cl = c.node_hist(int(n["left"]))
+            hr, cr = c.node_hist(int(n["right"]))
+            assert np.array_equal(cl + cr, cp)               # sibling = parent - child, exactly
+            assert np.allclose(hl + hr, hp, rtol=0, atol=1e-9 * max(1.0, np.abs(hp).max()))
+            assert cl[n["feature"], n["thr_id"]] == l["nsamples"]   # the split slot's cumulative count
+    # leaves partition the documents; lists ascending (stable partition)
+    seen = np.zeros(N, np.int32)
+    leaf_of = np.full(N, -1, np.int64)
+    for i, n in enumerate(nodes):
+        if n["feature"] < 0:
+            ids = c.node_samples(i)
+            assert len(ids) == n["nsamples"] and np.all(np.diff(ids.astype(np.int64)) > 0)
+            seen[ids] += 1
+            leaf_of[ids] = i
+    assert np.all(seen == 1)
+    # independent check of the membership: walk the tree on the RAW f32 features
+    walk = np.zeros(N, np.int64)
+    active = np.ones(N, bool)
+    while active.any():
+        nd = nodes[walk]
+        internal = nd["feature"] >= 0
+        active = internal
+        idx = np.nonzero(internal)[0]
+        go_left = x[idx, nd["feature"][idx]] <= nd["threshold"][idx]
+        walk[idx] = np.where(go_left, nd["left"][idx], nd["right"][idx])
+    assert np.array_equal(walk, leaf_of)
+    # score update through the membership == shrinkage * leaf(tree walk)  (mart.cc:459-468)
+    c.update_scores(0.1)
+    assert np.array_equal(c.get_scores(), 0.1 * nodes["value"][walk])
+    # ... and == the ensemble-scoring kernel on the same tree (bit for bit)
+    pad = np.zeros((1, 21), qr.NODE_DTYPE)
+    pad["feature"] = -1
+    pad[0, :len(nodes)] = nodes
+    c.upload_ensemble(pad, np.array([0.1]))
+    assert np.array_equal(c.score(x)[0], c.get_scores())
+    # determinism: the same iteration again gives the same bits
+    c.reset_scores()
+    c.compute_lambdas("NDCG", 10)
+    again = c.fit_tree(10, 1, True)
+    for k in nodes.dtype.names:
+        assert np.array_equal(again[k], nodes[k]), k
+
+
+def test_sharded_equals_single_at_full_size(big):
+    import torch
+    from test_gpu_sharded import _sharded_fit
+    qr, c = big["qr"], big["c"]
+    c.reset_scores()
+    c.compute_lambdas("NDCG", 10)
+    lam, w = c.get_pseudo()
+    want = c.fit_tree(10, 1, True)
+    ctxs = []
+    for r in range(2):
+        s = qr.Context(0, rank=r, world=2)
+        s.upload(big["x"], big["labels"], big["qoff"])
+        s.build_bins(255)
+        s.set_pseudo(lam, w)
+        ctxs.append(s)
+    got = _sharded_fit(torch, ctxs, 10, 1)
+    for g in got:
+        for k in ("feature", "thr_id", "left", "right", "nsamples", "threshold"):
+            assert np.array_equal(g[k], want[k]), k
+        # set_pseudo derives the f64 node sums on the host: leaf values agree to rounding
+        assert np.allclose(g["value"], want["value"], rtol=1e-12, atol=1e-15)
+    for s in ctxs:
+        s.close()
+
+
+def test_scoring_linearity_and_tree_order(big):
+    qr, c, x = big["qr"], big["c"], big["x"]
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+    from score_bench import make_model
+    rng = np.random.default_rng(7)
+    nodes, w = make_model(64, 6, F, rng)
+    c.upload_ensemble(nodes, w)
+    s1, _ = c.score(x)
+    c.upload_ensemble(nodes, 2 * w)
+    s2, _ = c.score(x)
+    assert np.array_equal(s2, 2 * s1)                        # scaling by 2 is exact in f64
+    c.upload_ensemble(nodes[:32], w[:32])
+    a, _ = c.score(x)
+    c.upload_ensemble(nodes[32:], w[32:])
+    b, _ = c.score(x)
+    assert np.allclose(a + b, s1, rtol=1e-13, atol=1e-13)    # prefix + suffix, up to one rounding each

@@ -13,8 +13,15 @@ inputs resident in HBM before the timed region starts.
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: feature-block-sharded histograms (quickrank_amd/dist.py); total work is
-fixed, so scaling is "strong".  Prints ONE JSON line on rank 0.
+N > 1 (quickrank_amd/dist.py), two layouts:
+  --shard docs      (default) every rank holds its OWN 1M-document shard (whole
+                    queries, all features; seed 42 + rank): the job is N x 1M documents,
+                    one int64 all-reduce per node histogram, per-GPU work fixed
+                    -> "scaling": "weak"; value = all ranks' documents / time.
+  --shard features  the 1M-document set replicated, feature blocks of the bin
+                    matrix sharded -> "scaling": "strong" (DESIGN.md section 6 on why
+                    this cannot beat one GPU at 1M documents).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -96,6 +103,9 @@ def main():
     ap.add_argument("--score-docs", type=int, default=1000000)
     ap.add_argument("--cpu-queries", type=int, default=2500)
     ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--shard", choices=["docs", "features"], default="docs")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 code path (process group, sharded driver) with one rank")
     args = ap.parse_args()
 
     import torch
@@ -108,10 +118,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: quickrank_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     from quickrank_amd import build as qbuild
     if rank == 0:
@@ -120,17 +133,29 @@ def main():
         dist.barrier()
     from quickrank_amd._capi import Context
 
-    x, labels, qoff = synth(args.queries, args.docs_per_query, args.features)
+    docs_mode = multi and args.shard == "docs"
+    x, labels, qoff = synth(args.queries, args.docs_per_query, args.features,
+                            seed=42 + rank if docs_mode else 42)
     N, F = x.shape
-    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
-    ctx = Context(local_rank, rank=rank, world=world, stream=stream)
-    ctx.upload(x, labels, qoff)
-    ctx.build_bins(args.nthresholds)
-    ctx.reset_scores()
-    fitter = None
-    if world > 1:
-        from quickrank_amd.dist import ShardedTreeFitter
-        fitter = ShardedTreeFitter(ctx)
+    n_job = N * world if docs_mode else N        # documents one step processes
+    stream = torch.cuda.current_stream().cuda_stream if multi else None
+    fitter = trainer = None
+    if docs_mode:
+        from quickrank_amd.dist import DocShardedTrainer, gather_thresholds
+        ctx = Context(local_rank, rank=rank, world=world, stream=stream,
+                      doc_shard=(n_job, args.queries * world))
+        ctx.upload(x, labels, qoff)
+        ctx.build_bins_with(*gather_thresholds(ctx, args.nthresholds))
+        ctx.reset_scores()
+        trainer = DocShardedTrainer(ctx)
+    else:
+        ctx = Context(local_rank, rank=rank, world=world, stream=stream)
+        ctx.upload(x, labels, qoff)
+        ctx.build_bins(args.nthresholds)
+        ctx.reset_scores()
+        if multi:
+            from quickrank_amd.dist import ShardedTreeFitter
+            fitter = ShardedTreeFitter(ctx)
 
     ndcg = []
 
@@ -138,6 +163,12 @@ def main():
         # ranking + NDCG@10 of the current scores (= the training metric the
         # reference evaluates at the end of the previous iteration, mart.cc:347)
         # + lambdas/weights, one pass over the queries
+        if trainer is not None:
+            trainer.compute_lambdas("NDCG", 10)
+            ndcg.append(ctx.metric_last())
+            trainer.fit_tree(args.nleaves, 1, True, read=False)
+            ctx.update_scores(0.1)
+            return
         ctx.compute_lambdas("NDCG", 10)
         ndcg.append(ctx.metric_last())
         if fitter is not None:
@@ -170,7 +201,7 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = N * args.steps / elapsed
+        value = n_job * args.steps / elapsed
         roof = None
         if prof["launches"]:
             sec = prof["total_ms"] / prof["launches"] * 1e-3
@@ -192,12 +223,16 @@ def main():
             "metric": "docs/sec per LambdaMART boosting iter (1Mx136)",
             "value": value, "unit": "docs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"synthetic {N} docs x {F} features x {args.queries} queries, "
+            "scaling": "weak" if docs_mode or world == 1 else "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic {n_job} docs x {F} features x "
+                                   f"{args.queries * (world if docs_mode else 1)} queries"
+                                   + (f" ({N} docs per GPU)" if docs_mode else "") + ", "
                                    f"LambdaMART {args.nleaves} leaves, {args.nthresholds} thresholds, "
                                    "NDCG@10, shrinkage 0.1, min-leaf-support 1",
-                       "parallelism": "1 GPU" if world == 1 else f"feature-block sharding x{world}",
+                       "parallelism": "1 GPU" if world == 1 else
+                                      (f"document sharding x{world}: one int64 all-reduce per node histogram"
+                                       if docs_mode else f"feature-block sharding x{world}"),
                        "ndcg10_last": ndcg[-1] if ndcg else None},
             "roofline": roof,
         }

@@ -80,6 +80,12 @@ int qr_ctx_set_stream(qr_ctx *ctx, void *hip_stream);
 /* rank owns features [rank*ceil(F/world), (rank+1)*ceil(F/world)) of the bins.  */
 /* Must be called before qr_bins_build.  Default rank 0 / world 1.              */
 int qr_ctx_set_shard(qr_ctx *ctx, int rank, int world);
+/* document sharding (the second multi-GPU layout, section "document-sharded      */
+/* protocol" below): this rank holds whole queries of its own -- n_global /       */
+/* q_global documents / queries over all ranks -- and every feature of them.      */
+/* Must precede the bin build.                                                    */
+int qr_ctx_set_doc_shard(qr_ctx *ctx, int rank, int world, uint64_t n_global,
+                         uint64_t q_global);
 int qr_synchronize(qr_ctx *ctx);
 
 /* ---- data: replaces Dataset -> VerticalDataset (vertical_dataset.cc:29-66)    */
@@ -96,6 +102,23 @@ int qr_valid_upload(qr_ctx *ctx, const float *rowmajor, size_t N,
 /* thr_out: host [F][QR_MAX_BINS] (padded with FLT_MAX), thr_size_out: [F].      */
 int qr_bins_build(qr_ctx *ctx, size_t nthresholds, float *thr_out,
                   uint32_t *thr_size_out);
+/* The same in three steps, for document-sharded contexts whose thresholds must   */
+/* come from the WHOLE training set (mart.cc:147-169 runs over every document):  */
+/*   qr_bins_stats on every rank -> all_gather the three arrays ->                */
+/*   qr_thresholds_from_stats (pure host, same result on every rank) ->          */
+/*   qr_bins_build_with.                                                         */
+/* limit = nthresholds ? nthresholds + 1 : 256.  vals_out: [F][limit+1] f32 bit   */
+/* patterns of the first distinct values met, cnt_out: [F] number of distinct    */
+/* values (saturating at limit+1), minmax_out: [F][2] radix-ordered keys.        */
+int qr_bins_stats(qr_ctx *ctx, size_t nthresholds, uint32_t *vals_out,
+                  uint32_t *cnt_out, uint32_t *minmax_out);
+/* the arrays of `nranks` ranks concatenated rank-major                          */
+int qr_thresholds_from_stats(size_t F, size_t nthresholds, size_t nranks,
+                             const uint32_t *vals, const uint32_t *cnt,
+                             const uint32_t *minmax, float *thr_out,
+                             uint32_t *thr_size_out);
+/* bin map for caller-supplied thresholds ([F][QR_MAX_BINS], rows end in FLT_MAX) */
+int qr_bins_build_with(qr_ctx *ctx, const float *thr, const uint32_t *thr_size);
 /* debug/parity: bin ids as u8 [N][F] row-major (global features; features this  */
 /* rank does not own read back as 0xFF)                                          */
 int qr_bins_read(qr_ctx *ctx, uint8_t *out);
@@ -161,6 +184,29 @@ int qr_tree_end(qr_ctx *ctx, int newton, qr_node_t *nodes_out,
 int qr_exchange_buffers(qr_ctx *ctx, void **recs_local, void **recs_all,
                         size_t *rec_bytes_per_rank, void **mask,
                         size_t *mask_bytes);
+
+/* ---- document-sharded protocol ------------------------------------------------*/
+/* Each rank holds its own queries and all features; what is exchanged is the    */
+/* node histogram itself -- exact fixed-point integers, so ONE int64 sum          */
+/* all-reduce per histogram gives every rank the same bits as a single GPU would */
+/* compute, and every rank then scans / decides redundantly with no further      */
+/* exchange.  f64 quantities (sum / sum of squares of the pseudo-responses, leaf */
+/* sums, the metric) travel as bit patterns in per-rank slots of the same int64  */
+/* buffers (zeros elsewhere: sum == gather) and are added in rank order.         */
+/*   per iteration:                                                              */
+/*     qr_lambda_compute -> [all_reduce scal] -> qr_lambda_finish                */
+/*     qr_tree_begin     -> [all_reduce hist]                                    */
+/*     (nleaves-1) x { qr_tree_decide -> qr_tree_apply -> [all_reduce hist] }    */
+/*     qr_tree_decide -> qr_tree_end(nodes_out = NULL) -> [all_reduce leaf]      */
+/*     qr_tree_leaves_finish -> qr_scores_update                                 */
+/* all on the context's stream (int64 sum all-reduces, element counts below).    */
+int qr_lambda_finish(qr_ctx *ctx);
+int qr_tree_leaves_finish(qr_ctx *ctx, int newton, qr_node_t *nodes_out,
+                          size_t *nnodes_out);
+/* device pointers + int64 element counts; hist/scal valid after the bin build,  */
+/* leaf after qr_tree_begin                                                      */
+int qr_doc_exchange_buffers(qr_ctx *ctx, void **hist, size_t *hist_i64, void **scal,
+                            size_t *scal_i64, void **leaf, size_t *leaf_i64);
 
 /* ---- parity/debug read-backs --------------------------------------------------*/
 /* cumulative histogram of a node slot of the LAST fitted tree, as the           */

@@ -36,6 +36,9 @@ SYMBOLS = [
     "qr_metric_per_query", "qr_ranks_read", "qr_ensemble_upload",
     "qr_ensemble_score", "qr_ensemble_score_device", "qr_prof_reset",
     "qr_prof_get", "qr_prof_enable", "qr_oblivious_upload", "qr_oblivious_score",
+    "qr_ctx_set_doc_shard", "qr_bins_stats", "qr_thresholds_from_stats",
+    "qr_bins_build_with", "qr_lambda_finish", "qr_tree_leaves_finish",
+    "qr_doc_exchange_buffers",
 ]
 
 _LIB = None
@@ -102,6 +105,14 @@ def lib():
     L.qr_prof_reset.argtypes = [vp]
     L.qr_prof_get.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.qr_prof_enable.argtypes = [vp, C.c_int]
+    L.qr_ctx_set_doc_shard.argtypes = [vp, C.c_int, C.c_int, u64, u64]
+    L.qr_bins_stats.argtypes = [vp, sz, vp, vp, vp]
+    L.qr_thresholds_from_stats.argtypes = [sz, sz, sz, vp, vp, vp, vp, vp]
+    L.qr_bins_build_with.argtypes = [vp, vp, vp]
+    L.qr_lambda_finish.argtypes = [vp]
+    L.qr_tree_leaves_finish.argtypes = [vp, C.c_int, vp, C.POINTER(sz)]
+    L.qr_doc_exchange_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp),
+                                          C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
     for s in SYMBOLS:
         fn = getattr(L, s)
         if s not in ("qr_ctx_destroy", "qr_last_error"):
@@ -114,10 +125,29 @@ def _ptr(a):
     return a.ctypes.data if a is not None else None
 
 
+def thresholds_from_stats(F, nthresholds, vals, cnt, mm):
+    """Thresholds of the union of `nranks` document shards (mart.cc:147-169).
+    vals/cnt/mm: the per-rank arrays of Context.bins_stats stacked on axis 0."""
+    vals = np.ascontiguousarray(vals, np.uint32)
+    cnt = np.ascontiguousarray(cnt, np.uint32)
+    mm = np.ascontiguousarray(mm, np.uint32)
+    nranks = cnt.shape[0]
+    thr = np.empty((F, QR_MAX_BINS), np.float32)
+    ts = np.empty(F, np.uint32)
+    rc = lib().qr_thresholds_from_stats(F, nthresholds, nranks, _ptr(vals), _ptr(cnt), _ptr(mm),
+                                        _ptr(thr), _ptr(ts))
+    if rc:
+        raise QrError(f"qr_thresholds_from_stats failed (code {rc}): nthresholds == 0 needs "
+                      "<= 255 distinct values per feature")
+    return thr, ts
+
+
 class Context:
     """One device context (= one GPU, one stream).  Thin, 1:1 over the C-ABI."""
 
-    def __init__(self, device=0, rank=0, world=1, stream=None):
+    def __init__(self, device=0, rank=0, world=1, stream=None, doc_shard=None):
+        """doc_shard=(n_global, q_global): document-sharded context (this rank holds
+        its own queries and all features); otherwise world > 1 = feature-sharded."""
         self.L = lib()
         h = C.c_void_p()
         rc = self.L.qr_ctx_create(device, C.byref(h))
@@ -128,9 +158,13 @@ class Context:
         self.vN = 0
         if stream is not None:
             self._ck(self.L.qr_ctx_set_stream(self.h, C.c_void_p(stream)))
-        if world > 1:
+        if doc_shard is not None:
+            self._ck(self.L.qr_ctx_set_doc_shard(self.h, rank, world, int(doc_shard[0]),
+                                                 int(doc_shard[1])))
+        elif world > 1:
             self._ck(self.L.qr_ctx_set_shard(self.h, rank, world))
         self.rank, self.world = rank, world
+        self.doc_shard = doc_shard is not None
 
     def _ck(self, rc):
         if rc:
@@ -170,6 +204,21 @@ class Context:
         ts = np.empty(self.F, np.uint32)
         self._ck(self.L.qr_bins_build(self.h, nthresholds, _ptr(thr), _ptr(ts)))
         return thr, ts
+
+    def bins_stats(self, nthresholds):
+        """Column statistics of this rank's documents (see qr_bins_stats)."""
+        limit = nthresholds + 1 if nthresholds else 256
+        vals = np.zeros((self.F, limit + 1), np.uint32)
+        cnt = np.zeros(self.F, np.uint32)
+        mm = np.zeros((self.F, 2), np.uint32)
+        self._ck(self.L.qr_bins_stats(self.h, nthresholds, _ptr(vals), _ptr(cnt), _ptr(mm)))
+        return vals, cnt, mm
+
+    def build_bins_with(self, thr, ts):
+        thr = np.ascontiguousarray(thr, np.float32)
+        ts = np.ascontiguousarray(ts, np.uint32)
+        assert thr.shape == (self.F, QR_MAX_BINS) and ts.shape == (self.F,)
+        self._ck(self.L.qr_bins_build_with(self.h, _ptr(thr), _ptr(ts)))
 
     def read_bins(self):
         out = np.empty((self.N, self.F), np.uint8)
@@ -253,6 +302,30 @@ class Context:
         n = C.c_size_t()
         self._ck(self.L.qr_tree_end(self.h, int(newton), _ptr(nodes), C.byref(n)))
         return nodes[:n.value].copy()
+
+    def lambda_finish(self):
+        self._ck(self.L.qr_lambda_finish(self.h))
+
+    def tree_end_local(self, newton=True):
+        """document-sharded: local leaf sums only; all-reduce, then tree_leaves_finish"""
+        self._ck(self.L.qr_tree_end(self.h, int(newton), None, None))
+
+    def tree_leaves_finish(self, nleaves, newton=True, read=True):
+        if not read:
+            self._ck(self.L.qr_tree_leaves_finish(self.h, int(newton), None, None))
+            return None
+        nodes = np.zeros(2 * nleaves + 1, NODE_DTYPE)
+        n = C.c_size_t()
+        self._ck(self.L.qr_tree_leaves_finish(self.h, int(newton), _ptr(nodes), C.byref(n)))
+        return nodes[:n.value].copy()
+
+    def doc_exchange_buffers(self):
+        h, s, l = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        hn, sn, ln = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._ck(self.L.qr_doc_exchange_buffers(self.h, C.byref(h), C.byref(hn), C.byref(s),
+                                                C.byref(sn), C.byref(l), C.byref(ln)))
+        return dict(hist=h.value, hist_n=hn.value, scal=s.value, scal_n=sn.value,
+                    leaf=l.value, leaf_n=ln.value)
 
     def exchange_buffers(self):
         a, b, m = C.c_void_p(), C.c_void_p(), C.c_void_p()

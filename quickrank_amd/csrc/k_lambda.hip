@@ -787,6 +787,64 @@ int qr_k_prep(qr_ctx *c, size_t nss) {
   return QR_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Document-sharded contexts: the four per-iteration scalars of every rank are
+// exchanged through a [world][4] int64 buffer (own row filled, zeros elsewhere:
+// a sum all-reduce is then an all-gather of the bit patterns) and combined in
+// rank order, so that every rank derives the same quantisation scale, root
+// statistics and metric.
+// ---------------------------------------------------------------------------
+__global__ void k_scal_pack(const QrScalars *__restrict__ scal, long long *__restrict__ x,
+                            const int rank, const int world) {
+  const int i = threadIdx.x;
+  if (i >= 4 * world) return;
+  long long v = 0;
+  if (i == 4 * rank) v = (long long)scal->maxabs_bits;
+  if (i == 4 * rank + 1) v = __double_as_longlong(scal->root_ss);
+  if (i == 4 * rank + 2) v = __double_as_longlong(scal->root_sum);
+  if (i == 4 * rank + 3) v = __double_as_longlong(scal->metric_sum);
+  x[i] = v;
+}
+
+__global__ void k_scal_global(QrScalars *__restrict__ scal, const long long *__restrict__ x,
+                              const int world) {
+  if (threadIdx.x != 0) return;
+  double mx = 0.0, ss = 0.0, sm = 0.0, ms = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double m = __longlong_as_double(x[4 * r]);
+    mx = m > mx ? m : mx;
+    ss += __longlong_as_double(x[4 * r + 1]);
+    sm += __longlong_as_double(x[4 * r + 2]);
+    ms += __longlong_as_double(x[4 * r + 3]);
+  }
+  scal->root_ss = ss;
+  scal->root_sum = sm;
+  scal->metric_gsum = ms;
+  scal->maxabs_bits = (unsigned long long)__double_as_longlong(mx);
+  int e = 0;
+  if (mx > 0.0) frexp(mx, &e);
+  e = QR_QBITS - e;
+  scal->scale_exp = e;
+  scal->scale = ldexp(1.0, e);
+  scal->inv_scale = ldexp(1.0, -e);
+}
+
+// local reductions (sum of squares / sum / metric) + pack for the exchange
+int qr_k_prep_pack(qr_ctx *c) {
+  if (4 * c->world > 1024) QR_FAIL(c, QR_ERR_UNSUPPORTED, "world too large");
+  hipLaunchKernelGGL(k_scal_pack, dim3(1), dim3(4 * c->world), 0, c->stream, c->d_scalars,
+                     c->d_xscal, c->rank, c->world);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+int qr_k_prep_global(qr_ctx *c) {
+  hipLaunchKernelGGL(k_scal_global, dim3(1), dim3(64), 0, c->stream, c->d_scalars,
+                     c->d_xscal, c->world);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
 int qr_k_metric_reduce(qr_ctx *c, int which) {
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, c->stream,
                      (const double *)nullptr, 0u,

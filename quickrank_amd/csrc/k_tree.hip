@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void k_hist(
     const QrBlock *__restrict__ blocks, const int nblocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const QrScalars *__restrict__ scal, u64 *__restrict__ partials) {
+    const QrScalars *__restrict__ scal, u64 *__restrict__ partials, const int docmode) {
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
   uint32_t seg_begin, n;
   int buf;
@@ -149,8 +149,9 @@ __global__ __launch_bounds__(1024) void k_hist(
     buf = 2;
   } else {
     if (!ts->desc.active) return;
-    seg_begin = ts->desc.small_begin;
-    n = ts->desc.small_n;
+    // document-sharded: the rank's own part of the directly built child
+    seg_begin = docmode ? ts->loc.small_begin : ts->desc.small_begin;
+    n = docmode ? ts->loc.small_n : ts->desc.small_n;
     buf = ts->desc.dst_buf;
   }
   __shared__ QrPlan plan;
@@ -216,7 +217,8 @@ __global__ __launch_bounds__(512) void k_reduce(
     const QrTreeState *__restrict__ ts, const int root_mode, const uint32_t N,
     const QrBlock *__restrict__ blocks, const int nblocks, const int G,
     const u64 *__restrict__ partials, long long *__restrict__ red_sum,
-    uint32_t *__restrict__ red_cnt) {
+    uint32_t *__restrict__ red_cnt, const int docmode, const double *__restrict__ part_ss,
+    long long *__restrict__ tail, const int rank, const int world) {
   __shared__ long long sh_s[512];
   __shared__ uint32_t sh_c[512];
   __shared__ QrPlan plan;
@@ -225,7 +227,32 @@ __global__ __launch_bounds__(512) void k_reduce(
     n = N;
   } else {
     if (!ts->desc.active) return;
-    n = ts->desc.small_n;
+    n = docmode ? ts->loc.small_n : ts->desc.small_n;
+  }
+  // document-sharded: counts are int64 cells of the exchange buffer (low word
+  // written here, high word stays 0), and the rank's (sum of squares, sum) of the
+  // directly built child rides in its own slot of the tail -- zeros elsewhere, so
+  // the sum all-reduce doubles as an all-gather of the bit patterns.
+  const uint32_t cs = docmode ? 2u : 1u;
+  if (docmode && blockIdx.x == 0 && threadIdx.x < 64) {
+    double a = 0.0, b = 0.0;
+    if (!root_mode) {
+      const uint32_t nwg = (ts->desc.end - ts->desc.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
+      for (uint32_t i = threadIdx.x; i < nwg; i += 64) {
+        a += part_ss[2 * i];
+        b += part_ss[2 * i + 1];
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+      }
+    }
+    for (int i = threadIdx.x; i < 2 * world; i += 64) {
+      long long v = 0;
+      if (i == 2 * rank) v = __double_as_longlong(a);
+      if (i == 2 * rank + 1) v = __double_as_longlong(b);
+      tail[i] = v;
+    }
   }
   if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, G, &plan);
   __syncthreads();
@@ -277,7 +304,7 @@ __global__ __launch_bounds__(512) void k_reduce(
       cn += sh_c[i * 64 + c];
     }
     red_sum[base + cell0 + c] = s;
-    red_cnt[base + cell0 + c] = cn;
+    red_cnt[(size_t)(base + cell0 + c) * cs] = cn;
   }
 }
 
@@ -337,7 +364,7 @@ __global__ __launch_bounds__(256) void k_scan(
     const long long *__restrict__ red_sum, const uint32_t *__restrict__ red_cnt,
     long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
     const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
-    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec) {
+    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec, const uint32_t cs) {
   __shared__ long long sh_s[4];
   __shared__ uint32_t sh_c[4];
   __shared__ long long tot_s[2];
@@ -368,7 +395,7 @@ __global__ __launch_bounds__(256) void k_scan(
   const int fw = blocks[b].fw;
   const uint32_t t = threadIdx.x;
   long long s = red_sum[mybase + t * fw + col];
-  uint32_t cn = red_cnt[mybase + t * fw + col];
+  uint32_t cn = red_cnt[(size_t)(mybase + t * fw + col) * cs];
   // inclusive scan over the 256 slots (exact integers: any association)
   const int lane = t & 63, wave = t >> 6;
   for (int off = 1; off < 64; off <<= 1) {
@@ -627,9 +654,11 @@ __global__ __launch_bounds__(64) void k_decide(
     const int world, const QrScalars *__restrict__ scal,
     const double *__restrict__ part_ss, const float *__restrict__ thr,
     const int32_t *__restrict__ gf2lf, const qr_split_t *__restrict__ featrec,
-    const uint32_t *__restrict__ hcnt) {
-  // single GPU: the merge over features happens here (no k_merge launch, no
-  // exchange); with several ranks `recs` is the all-gathered buffer
+    const uint32_t *__restrict__ hcnt, const int docmode, const u64 Nglobal,
+    const long long *__restrict__ tail, const int dworld) {
+  // single GPU (and document-sharded, where every rank scans every feature of
+  // the all-reduced histogram): the merge over features happens here (no k_merge
+  // launch, no exchange); feature-sharded: `recs` is the all-gathered buffer
   __shared__ qr_split_t own[2];
   if (world == 1) {
     const int root_mode = ts->step == 0;
@@ -647,7 +676,15 @@ __global__ __launch_bounds__(64) void k_decide(
   // squares_sum_ / sum of the directly built child: fixed-order reduction of the
   // partition workgroups' partials by the whole wave
   double ss_small = 0.0, sum_small = 0.0;
-  if (ts->step != 0 && ts->desc.active) {
+  if (docmode) {
+    // per-rank partials gathered by the histogram all-reduce, summed in rank
+    // order: every rank computes the same bits
+    if (ts->step != 0 && ts->desc.active)
+      for (int r = 0; r < dworld; ++r) {
+        ss_small += __longlong_as_double(tail[2 * r]);
+        sum_small += __longlong_as_double(tail[2 * r + 1]);
+      }
+  } else if (ts->step != 0 && ts->desc.active) {
     const uint32_t nwg = (ts->desc.end - ts->desc.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
     for (uint32_t i = threadIdx.x; i < nwg; i += 64) {
       ss_small += part_ss[2 * i];
@@ -670,7 +707,7 @@ __global__ __launch_bounds__(64) void k_decide(
     root->threshold = 0.f;
     root->left = root->right = root->parent = -1;
     root->leaf_id = -1;
-    node_stats(root, scal->root_sum, scal->root_ss, N);
+    node_stats(root, scal->root_sum, scal->root_ss, docmode ? Nglobal : (u64)N);
     node_set_best(root, recs, world, 0);
     ts->nnodes = 1;
     ts->heap_size = 0;
@@ -695,8 +732,12 @@ __global__ __launch_bounds__(64) void k_decide(
     // directly accumulated child, sibling by subtraction
     // (rtnode_histogram.cc:65-69, 79-86)
     node_stats(S, sum_small, ss_small, d.small_n);
-    node_stats(B, P->sum - sum_small, P->ss - ss_small,
-               (u64)(d.end - d.begin) - d.small_n);
+    node_stats(B, P->sum - sum_small, P->ss - ss_small, P->count - d.small_n);
+    if (docmode) {
+      // the children's local segments: known only after the local partition
+      QrNode *L = &ts->nodes[d.left], *R = &ts->nodes[d.right];
+      L->end = R->begin = P->begin + ts->loc.lcount;
+    }
     node_set_best(&ts->nodes[d.left], recs, world, 0);
     node_set_best(&ts->nodes[d.right], recs, world, 1);
     heap_push(ts, ts->nodes[d.left].deviance, d.left);    // rt.cc:76-77
@@ -802,7 +843,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(
     uint32_t *__restrict__ order0, uint32_t *__restrict__ order1,
     const uint32_t *__restrict__ mask, const int use_mask,
     const uint32_t *__restrict__ blkcnt, const double *__restrict__ lambda,
-    double *__restrict__ part_ss) {
+    double *__restrict__ part_ss, QrLocalSplit *__restrict__ loc) {
   __shared__ uint32_t sh[4];
   __shared__ uint32_t wave_off[4];
   __shared__ double shd[4], shs[4];
@@ -810,11 +851,24 @@ __global__ __launch_bounds__(256) void k_part_scatter(
   if (!d.active) return;
   const uint32_t n = d.end - d.begin;
   const uint32_t base = blockIdx.x * QR_PART_SLICE;
-  if (base >= n) return;
-  // lefts in the slices before mine
-  uint32_t pre = 0;
-  for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) pre += blkcnt[i];
+  if (base >= n && blockIdx.x != 0) return;
+  // lefts in the slices before mine, and in the whole (local) segment: the
+  // document-sharded path cannot take the latter from the (global) histogram
+  const uint32_t nwg = (n + QR_PART_SLICE - 1) / QR_PART_SLICE;
+  uint32_t pre = 0, all = 0;
+  for (uint32_t i = threadIdx.x; i < nwg; i += 256) {
+    const uint32_t v = blkcnt[i];
+    all += v;
+    if (i < blockIdx.x) pre += v;
+  }
   const uint32_t left_before = block_sum_u32(pre, sh);
+  const uint32_t left_total = block_sum_u32(all, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    loc->lcount = left_total;
+    loc->small_begin = d.small_is_left ? d.begin : d.begin + left_total;
+    loc->small_n = d.small_is_left ? left_total : n - left_total;
+  }
+  if (base >= n) return;
   const uint32_t *src = d.src_buf == 0 ? order0 : order1;
   uint32_t *dst = d.dst_buf == 0 ? order0 : order1;
   uint32_t ids[PART_PER_THREAD];
@@ -853,7 +907,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(
         o = d.begin + lpos;
         ++lpos;
       } else {
-        o = d.begin + d.lcount + (p - lpos);
+        o = d.begin + left_total + (p - lpos);
       }
       dst[o] = ids[k];
       if (fl[k] == (d.small_is_left != 0)) {
@@ -1079,9 +1133,16 @@ __global__ __launch_bounds__(256) void k_leaf_sums(
 // rt.cc:165-207
 __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ ts,
                                                      const double *__restrict__ leafpart,
-                                                     const int newton) {
+                                                     const int newton, const int docmode,
+                                                     long long *__restrict__ xleaf,
+                                                     const int rank, const int world,
+                                                     const int stride) {
   const int nl = ts->nleaves;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (docmode) {  // own slot <- local sums, zeros elsewhere (all-reduce == all-gather)
+    for (int i = threadIdx.x; i < world * stride; i += 1024) xleaf[i] = 0;
+    __syncthreads();
+  }
   for (int l = wave; l < nl; l += 16) {  // one wave per leaf, fixed reduction tree
     const uint32_t b = ts->leaf_begin[l], e = ts->leaf_begin[l + 1];
     double s1 = 0.0, s2 = 0.0;
@@ -1097,6 +1158,11 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
       s2 += __shfl_xor(s2, off, 64);
     }
     if (lane == 0) {
+      if (docmode) {
+        xleaf[(size_t)rank * stride + 2 * l] = __double_as_longlong(s1);
+        xleaf[(size_t)rank * stride + 2 * l + 1] = __double_as_longlong(s2);
+        continue;
+      }
       double v;
       if (newton)
         v = s2 >= 2.2204460492503131e-16 ? s1 / s2 : 0.0;  // DBL_EPSILON
@@ -1105,6 +1171,30 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
       ts->leaf_value[l] = v;
       ts->nodes[ts->leaf_nodes[l]].value = v;
     }
+  }
+}
+
+// document-sharded: leaf outputs from the gathered per-rank sums, added in rank
+// order (every rank ends with the same bits); rt.cc:165-207
+__global__ __launch_bounds__(1024) void k_leaf_global(QrTreeState *__restrict__ ts,
+                                                      const long long *__restrict__ xleaf,
+                                                      const int newton, const int world,
+                                                      const int stride) {
+  const int nl = ts->nleaves;
+  for (int l = threadIdx.x; l < nl; l += 1024) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < world; ++r) {
+      s1 += __longlong_as_double(xleaf[(size_t)r * stride + 2 * l]);
+      s2 += __longlong_as_double(xleaf[(size_t)r * stride + 2 * l + 1]);
+    }
+    const QrNode *nd = &ts->nodes[ts->leaf_nodes[l]];
+    double v;
+    if (newton)
+      v = s2 >= 2.2204460492503131e-16 ? s1 / s2 : 0.0;  // DBL_EPSILON
+    else
+      v = s1 / (double)nd->count;
+    ts->leaf_value[l] = v;
+    ts->nodes[ts->leaf_nodes[l]].value = v;
   }
 }
 
@@ -1366,6 +1456,8 @@ static size_t hist_lds(const qr_ctx *c) {
   return (size_t)256 * fwmax * 8;
 }
 
+static int launch_scan(qr_ctx *c, int root_mode);
+
 static int launch_hist_scan(qr_ctx *c, int root_mode) {
   const size_t lds = hist_lds(c);
   static size_t attr_lds = 0;
@@ -1386,7 +1478,7 @@ static int launch_hist_scan(qr_ctx *c, int root_mode) {
   hipLaunchKernelGGL(k_hist, dim3(G), dim3(1024), lds, c->stream, c->d_tree,
                      root_mode, (uint32_t)c->N, c->d_blocks, c->nblocks, c->d_bins,
                      c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars,
-                     (u64 *)c->d_partials);
+                     (u64 *)c->d_partials, c->dmode);
   QR_CHECK(c, hipGetLastError());
   if (prof) {
     QR_CHECK(c, hipEventRecord(e1, c->stream));
@@ -1396,14 +1488,21 @@ static int launch_hist_scan(qr_ctx *c, int root_mode) {
   for (const auto &b : c->blocks) cells += (size_t)256 * b.fw;
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)(cells / 64)), dim3(512), 0, c->stream,
                      c->d_tree, root_mode, (uint32_t)c->N, c->d_blocks, c->nblocks, G,
-                     (const u64 *)c->d_partials, c->d_red_sum, c->d_red_cnt);
+                     (const u64 *)c->d_partials, c->d_red_sum, c->d_red_cnt, c->dmode,
+                     c->d_part_ss, c->dmode ? c->d_xh + 2 * c->xh_cells : (long long *)nullptr,
+                     c->rank, c->world);
   QR_CHECK(c, hipGetLastError());
+  if (c->dmode) return QR_OK;  // the scan follows the all-reduce (launch_scan)
+  return launch_scan(c, root_mode);
+}
+
+static int launch_scan(qr_ctx *c, int root_mode) {
   hipLaunchKernelGGL(k_scan, dim3(c->flocal), dim3(256), 0, c->stream, c->d_tree,
                      root_mode, (uint32_t)c->N, c->d_blocks, c->nblocks, c->d_red_sum,
                      c->d_red_cnt, c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size,
-                     c->d_lf2gf, c->d_scalars, c->d_featrec);
+                     c->d_lf2gf, c->d_scalars, c->d_featrec, c->dmode ? 2u : 1u);
   QR_CHECK(c, hipGetLastError());
-  if (c->world > 1) {
+  if (c->world > 1 && !c->dmode) {
     hipLaunchKernelGGL(k_merge, dim3(1), dim3(128), 0, c->stream, c->d_tree, root_mode,
                        c->d_featrec, c->flocal, c->d_hsum, c->d_hcnt, c->d_gf2lf,
                        c->d_recs_local);
@@ -1427,6 +1526,7 @@ __global__ void k_tree_reset(QrTreeState *ts, int nleaves, u64 minls) {
 }
 
 int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
+  c->tree_step = 0;
   hipLaunchKernelGGL(k_tree_reset, dim3(1), dim3(64), 0, c->stream, c->d_tree,
                      (int)nleaves, (u64)minls);
   QR_CHECK(c, hipGetLastError());
@@ -1434,13 +1534,23 @@ int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
 }
 
 int qr_k_tree_decide(qr_ctx *c) {
-  const qr_split_t *recs = c->world > 1 ? c->d_recs_all : c->d_recs_local;
+  const bool fshard = c->world > 1 && !c->dmode;
+  const qr_split_t *recs = fshard ? c->d_recs_all : c->d_recs_local;
+  if (c->dmode) {
+    // the histogram of this step has just been all-reduced; the first decide of a
+    // tree follows the root histogram
+    int rc = launch_scan(c, c->tree_step == 0);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_tree,
-                     (uint32_t)c->N, c->flocal, c->d_hsum, recs, c->world,
+                     (uint32_t)c->N, c->flocal, c->d_hsum, recs, fshard ? c->world : 1,
                      c->d_scalars, c->d_part_ss, c->d_thr, c->d_gf2lf, c->d_featrec,
-                     c->d_hcnt);
+                     c->d_hcnt, c->dmode, (u64)c->Nglobal,
+                     c->dmode ? c->d_xh + 2 * c->xh_cells : (const long long *)nullptr,
+                     c->world);
   QR_CHECK(c, hipGetLastError());
-  if (c->world > 1) {
+  ++c->tree_step;
+  if (fshard) {
     const unsigned grid = (unsigned)((c->mask_words + 255) / 256);
     hipLaunchKernelGGL(k_mask, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
                        c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
@@ -1452,7 +1562,20 @@ int qr_k_tree_decide(qr_ctx *c) {
 
 int qr_k_tree_apply(qr_ctx *c) {
   const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
-  const int use_mask = c->world > 1;
+  const int use_mask = c->world > 1 && !c->dmode;
+  if (c->dmode) {
+    // the local left count is not in the (global) histogram: count, then scatter
+    hipLaunchKernelGGL(k_part_count, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
+                       c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_order[1],
+                       c->d_mask, 0, c->d_blkcnt);
+    QR_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_part_scatter, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
+                       c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_order[1],
+                       c->d_mask, 0, c->d_blkcnt, c->d_lambda, c->d_part_ss,
+                       &c->d_tree->loc);
+    QR_CHECK(c, hipGetLastError());
+    return launch_hist_scan(c, 0);
+  }
   hipLaunchKernelGGL(k_partition, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
                      c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_order[1],
                      c->d_mask, use_mask, (u64 *)c->d_part_state, c->d_lambda, c->d_part_ss);
@@ -1507,7 +1630,15 @@ int qr_k_tree_finish(qr_ctx *c, int newton) {
                      newton ? c->d_weight : (const double *)nullptr, c->d_leafpart);
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_leaf_final, dim3(1), dim3(1024), 0, c->stream, c->d_tree,
-                     c->d_leafpart, newton);
+                     c->d_leafpart, newton, c->dmode, c->d_xleaf, c->rank, c->world,
+                     (int)(2 * c->cur_nleaves));
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+int qr_k_tree_leaves_global(qr_ctx *c, int newton) {
+  hipLaunchKernelGGL(k_leaf_global, dim3(1), dim3(1024), 0, c->stream, c->d_tree,
+                     c->d_xleaf, newton, c->world, (int)(2 * c->cur_nleaves));
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

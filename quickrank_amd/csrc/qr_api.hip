@@ -70,6 +70,12 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins);
   dfree(c->d_thr); dfree(c->d_thr_size);
   dfree(c->d_order[0]); dfree(c->d_order[1]); dfree(c->d_partials);
+  if (c->d_xh) {  // document-sharded: the reduced histogram lives in the exchange buffer
+    c->d_red_sum = nullptr;
+    c->d_red_cnt = nullptr;
+  }
+  dfree(c->d_xh); dfree(c->d_xscal); dfree(c->d_xleaf);
+  c->xleaf_cap = 0;
   dfree(c->d_red_sum); dfree(c->d_red_cnt);
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
@@ -124,6 +130,21 @@ int qr_ctx_set_shard(qr_ctx *c, int rank, int world) {
   if (c->binned) QR_FAIL(c, QR_ERR_STATE, "qr_ctx_set_shard must precede qr_bins_build");
   c->rank = rank;
   c->world = world;
+  c->dmode = 0;
+  return QR_OK;
+}
+
+int qr_ctx_set_doc_shard(qr_ctx *c, int rank, int world, uint64_t n_global,
+                         uint64_t q_global) {
+  if (!c) return QR_ERR_ARG;
+  if (world < 1 || rank < 0 || rank >= world) QR_FAIL(c, QR_ERR_ARG, "bad rank/world");
+  if (c->binned) QR_FAIL(c, QR_ERR_STATE, "qr_ctx_set_doc_shard must precede the bin build");
+  if (n_global >= (1ull << 32)) QR_FAIL(c, QR_ERR_UNSUPPORTED, "global N must be < 2^32");
+  c->rank = rank;
+  c->world = world;
+  c->dmode = 1;
+  c->Nglobal = n_global;
+  c->Qglobal = q_global;
   return QR_OK;
 }
 
@@ -257,19 +278,98 @@ static inline float bits2f(uint32_t u) {
   return f;
 }
 
-int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
-                  uint32_t *thr_size_out) {
-  if (!c) return QR_ERR_ARG;
-  if (!c->d_raw) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
-  if (nthresholds > 255)
-    QR_FAIL(c, QR_ERR_UNSUPPORTED, "the device path stores uint8 bins: nthresholds <= 255");
-  QR_CHECK(c, hipSetDevice(c->device));
+// distinct values (at most limit + 1 kept) / min / max per column of the rank's
+// documents; values are f32 bit patterns, min/max in radix-flipped form
+static int bins_stats(qr_ctx *c, uint32_t limit, std::vector<uint32_t> &vals,
+                      std::vector<uint32_t> &cnt, std::vector<uint32_t> &mm) {
   const size_t N = c->N, F = c->F;
-  // ---- feature blocks owned by this rank: rank r owns the contiguous range
-  // [r*ceil(F/world), (r+1)*ceil(F/world)), cut into
-  // blocks of at most 64 features
-  const size_t per_rank = (F + (size_t)c->world - 1) / (size_t)c->world;
-  const size_t f_lo = std::min(F, per_rank * (size_t)c->rank);
+  float *d_col = nullptr;
+  uint32_t *d_vals = nullptr, *d_cnt = nullptr, *d_mm = nullptr;
+  QR_CHECK(c, dalloc(&d_col, N * F));
+  QR_CHECK(c, dalloc(&d_vals, F * (size_t)(limit + 1)));
+  QR_CHECK(c, dalloc(&d_cnt, F));
+  QR_CHECK(c, dalloc(&d_mm, 2 * F));
+  int rc = qr_k_transpose(c, c->d_raw, d_col, N, F);
+  if (rc) return rc;
+  rc = qr_k_colstats(c, d_col, N, F, limit, d_vals, d_cnt, d_mm);
+  if (rc) return rc;
+  vals.resize(F * (size_t)(limit + 1));
+  cnt.resize(F);
+  mm.resize(2 * F);
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(vals.data(), d_vals, vals.size() * 4, hipMemcpyDeviceToHost));
+  QR_CHECK(c, hipMemcpy(cnt.data(), d_cnt, F * 4, hipMemcpyDeviceToHost));
+  QR_CHECK(c, hipMemcpy(mm.data(), d_mm, 2 * F * 4, hipMemcpyDeviceToHost));
+  dfree(d_col); dfree(d_vals); dfree(d_cnt); dfree(d_mm);
+  return QR_OK;
+}
+
+// thresholds: mart.cc:147-169 with the same f32 operations, from the column
+// statistics of `nranks` document shards (their union is the training set)
+static const char *thresholds_from_stats(size_t F, size_t nthresholds, size_t nranks,
+                                         const uint32_t *vals, const uint32_t *cnt,
+                                         const uint32_t *mm, float *thr, uint32_t *thr_size) {
+  const uint32_t limit = (uint32_t)(nthresholds ? nthresholds + 1 : 256);
+  const size_t vstride = F * (size_t)(limit + 1);
+  for (size_t f = 0; f < F; ++f) {
+    float *out = &thr[f * QR_MAX_BINS];
+    for (size_t i = 0; i < QR_MAX_BINS; ++i) out[i] = FLT_MAX;
+    bool equal_width = false;
+    std::vector<uint32_t> keys;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+    for (size_t r = 0; r < nranks; ++r) {
+      const uint32_t n = cnt[r * F + f];
+      if (n > limit) equal_width = true;
+      if (n) {  // a rank without documents contributes nothing
+        kmin = std::min(kmin, mm[r * 2 * F + 2 * f]);
+        kmax = std::max(kmax, mm[r * 2 * F + 2 * f + 1]);
+      }
+      if (!equal_width)
+        for (uint32_t i = 0; i < n; ++i)
+          keys.push_back(h_flip(vals[r * vstride + f * (size_t)(limit + 1) + i]));
+    }
+    std::vector<float> uniqs;
+    if (!equal_width) {
+      std::sort(keys.begin(), keys.end());  // radix order (radix.cc:28-30)
+      for (uint32_t k : keys) {
+        const float v = bits2f(h_unflip(k));
+        if (uniqs.empty() || uniqs.back() < v) uniqs.push_back(v);  // mart.cc:149-151
+      }
+      if (!(uniqs.size() <= nthresholds || nthresholds == 0)) equal_width = true;
+    }
+    if (!equal_width) {
+      if (uniqs.size() + 1 > QR_MAX_BINS)
+        return "nthresholds == 0 with a feature of more than 255 distinct values";
+      for (size_t i = 0; i < uniqs.size(); ++i) out[i] = uniqs[i];
+      out[uniqs.size()] = FLT_MAX;
+      thr_size[f] = (uint32_t)uniqs.size() + 1;
+    } else {
+      if (nthresholds == 0)
+        return "nthresholds == 0 with a feature of more than 255 distinct values";
+      const float fmin = bits2f(h_unflip(kmin));
+      const float fmax = bits2f(h_unflip(kmax));
+      float t = fmin;
+      const float step = (float)fabs(fmax - t) / nthresholds;  // mart.cc:164-165
+      for (size_t j = 0; j != nthresholds; t += step) out[j++] = t;
+      out[nthresholds] = FLT_MAX;
+      thr_size[f] = (uint32_t)nthresholds + 1;
+    }
+  }
+  return nullptr;
+}
+
+// feature blocks, bin map and the tree working set for the thresholds in
+// c->h_thr / c->h_thr_size
+static int bins_finish(qr_ctx *c) {
+  const size_t N = c->N, F = c->F;
+  // ---- feature blocks owned by this rank.  Feature-sharded: rank r owns the
+  // contiguous range [r*ceil(F/world), (r+1)*ceil(F/world)) (SURVEY.md section
+  // 8e); document-sharded and single-GPU contexts own every feature.  Blocks
+  // hold at most 64 features.
+  const size_t fworld = c->dmode ? 1 : (size_t)c->world;
+  const size_t frank = c->dmode ? 0 : (size_t)c->rank;
+  const size_t per_rank = (F + fworld - 1) / fworld;
+  const size_t f_lo = std::min(F, per_rank * frank);
   const size_t f_hi = std::min(F, f_lo + per_rank);
   c->blocks.clear();
   c->h_gf2lf.assign(F, -1);
@@ -297,67 +397,10 @@ int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
   if (c->nblocks == 0) QR_FAIL(c, QR_ERR_ARG, "this rank owns no feature (world > F)");
   if (c->nblocks > QR_MAXBLK) QR_FAIL(c, QR_ERR_UNSUPPORTED, "too many feature blocks");
   c->bins_bytes = off;
-  // ---- distinct values / min / max per column
-  const uint32_t limit = (uint32_t)(nthresholds ? nthresholds + 1 : 256);
-  float *d_col = nullptr;
-  uint32_t *d_vals = nullptr, *d_cnt = nullptr, *d_mm = nullptr;
-  QR_CHECK(c, dalloc(&d_col, N * F));
-  QR_CHECK(c, dalloc(&d_vals, F * (size_t)(limit + 1)));
-  QR_CHECK(c, dalloc(&d_cnt, F));
-  QR_CHECK(c, dalloc(&d_mm, 2 * F));
-  int rc = qr_k_transpose(c, c->d_raw, d_col, N, F);
-  if (rc) return rc;
-  rc = qr_k_colstats(c, d_col, N, F, limit, d_vals, d_cnt, d_mm);
-  if (rc) return rc;
-  std::vector<uint32_t> vals(F * (size_t)(limit + 1)), cnt(F), mm(2 * F);
-  QR_CHECK(c, hipStreamSynchronize(c->stream));
-  QR_CHECK(c, hipMemcpy(vals.data(), d_vals, vals.size() * 4, hipMemcpyDeviceToHost));
-  QR_CHECK(c, hipMemcpy(cnt.data(), d_cnt, F * 4, hipMemcpyDeviceToHost));
-  QR_CHECK(c, hipMemcpy(mm.data(), d_mm, 2 * F * 4, hipMemcpyDeviceToHost));
-  dfree(d_col); dfree(d_vals); dfree(d_cnt); dfree(d_mm);
-  // ---- thresholds: mart.cc:147-169 with the same f32 operations
-  c->h_thr.assign(F * QR_MAX_BINS, FLT_MAX);
-  c->h_thr_size.assign(F, 0);
-  for (size_t f = 0; f < F; ++f) {
-    float *out = &c->h_thr[f * QR_MAX_BINS];
-    bool equal_width = cnt[f] > limit;
-    std::vector<float> uniqs;
-    if (!equal_width) {
-      std::vector<uint32_t> keys(cnt[f]);
-      for (uint32_t i = 0; i < cnt[f]; ++i) keys[i] = h_flip(vals[f * (size_t)(limit + 1) + i]);
-      std::sort(keys.begin(), keys.end());  // radix order (radix.cc:28-30)
-      for (uint32_t k : keys) {
-        const float v = bits2f(h_unflip(k));
-        if (uniqs.empty() || uniqs.back() < v) uniqs.push_back(v);  // mart.cc:149-151
-      }
-      if (!(uniqs.size() <= nthresholds || nthresholds == 0)) equal_width = true;
-    }
-    if (!equal_width) {
-      if (uniqs.size() + 1 > QR_MAX_BINS)
-        QR_FAIL(c, QR_ERR_UNSUPPORTED,
-                "nthresholds == 0 with a feature of more than 255 distinct values");
-      for (size_t i = 0; i < uniqs.size(); ++i) out[i] = uniqs[i];
-      out[uniqs.size()] = FLT_MAX;
-      c->h_thr_size[f] = (uint32_t)uniqs.size() + 1;
-    } else {
-      if (nthresholds == 0)
-        QR_FAIL(c, QR_ERR_UNSUPPORTED,
-                "nthresholds == 0 with a feature of more than 255 distinct values");
-      const float fmin = bits2f(h_unflip(mm[2 * f]));
-      const float fmax = bits2f(h_unflip(mm[2 * f + 1]));
-      float t = fmin;
-      const float step = (float)fabs(fmax - t) / nthresholds;  // mart.cc:164-165
-      for (size_t j = 0; j != nthresholds; t += step) out[j++] = t;
-      out[nthresholds] = FLT_MAX;
-      c->h_thr_size[f] = (uint32_t)nthresholds + 1;
-    }
-  }
   QR_CHECK(c, dalloc(&c->d_thr, F * QR_MAX_BINS));
   QR_CHECK(c, dalloc(&c->d_thr_size, F));
   QR_CHECK(c, hipMemcpy(c->d_thr, c->h_thr.data(), F * QR_MAX_BINS * 4, hipMemcpyHostToDevice));
   QR_CHECK(c, hipMemcpy(c->d_thr_size, c->h_thr_size.data(), F * 4, hipMemcpyHostToDevice));
-  if (thr_out) memcpy(thr_out, c->h_thr.data(), F * QR_MAX_BINS * 4);
-  if (thr_size_out) memcpy(thr_size_out, c->h_thr_size.data(), F * 4);
   // ---- bin map
   QR_CHECK(c, dalloc(&c->d_bins, c->bins_bytes));
   QR_CHECK(c, dalloc(&c->d_blocks, (size_t)c->nblocks));
@@ -366,7 +409,7 @@ int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
   QR_CHECK(c, dalloc(&c->d_gf2lf, F));
   QR_CHECK(c, hipMemcpy(c->d_lf2gf, c->h_lf2gf.data(), c->flocal * 4, hipMemcpyHostToDevice));
   QR_CHECK(c, hipMemcpy(c->d_gf2lf, c->h_gf2lf.data(), F * 4, hipMemcpyHostToDevice));
-  rc = qr_k_binning(c);
+  int rc = qr_k_binning(c);
   if (rc) return rc;
   // ---- tree working set
   QR_CHECK(c, dalloc(&c->d_order[0], N));
@@ -378,8 +421,22 @@ int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
   {
     size_t cells = 0;
     for (const auto &b : c->blocks) cells += (size_t)256 * b.fw;
-    QR_CHECK(c, dalloc(&c->d_red_sum, cells));
-    QR_CHECK(c, dalloc(&c->d_red_cnt, cells));
+    if (c->dmode) {
+      // one int64 buffer carries the reduced sums, the counts (as int64, read
+      // back through their low words) and 2 doubles per rank: ONE sum all-reduce
+      // per histogram
+      c->xh_cells = cells;
+      c->xh_len = 2 * cells + 2 * (size_t)c->world;
+      QR_CHECK(c, dalloc(&c->d_xh, c->xh_len));
+      QR_CHECK(c, hipMemset(c->d_xh, 0, c->xh_len * 8));
+      c->d_red_sum = c->d_xh;
+      c->d_red_cnt = reinterpret_cast<uint32_t *>(c->d_xh + cells);
+      QR_CHECK(c, dalloc(&c->d_xscal, 4 * (size_t)c->world));
+      QR_CHECK(c, hipMemset(c->d_xscal, 0, 4 * (size_t)c->world * 8));
+    } else {
+      QR_CHECK(c, dalloc(&c->d_red_sum, cells));
+      QR_CHECK(c, dalloc(&c->d_red_cnt, cells));
+    }
   }
   QR_CHECK(c, dalloc(&c->d_featrec, 2 * (size_t)c->flocal));
   QR_CHECK(c, dalloc(&c->d_recs_local, (size_t)2));
@@ -396,6 +453,75 @@ int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   c->binned = true;
   return QR_OK;
+}
+
+static int bins_precheck(qr_ctx *c, size_t nthresholds) {
+  if (!c->d_raw) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
+  if (c->binned) QR_FAIL(c, QR_ERR_STATE, "bins already built: upload the dataset again first");
+  if (nthresholds > 255)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "the device path stores uint8 bins: nthresholds <= 255");
+  QR_CHECK(c, hipSetDevice(c->device));
+  return QR_OK;
+}
+
+int qr_bins_build(qr_ctx *c, size_t nthresholds, float *thr_out,
+                  uint32_t *thr_size_out) {
+  if (!c) return QR_ERR_ARG;
+  if (c->dmode && c->world > 1)
+    QR_FAIL(c, QR_ERR_STATE,
+            "document-sharded contexts need the thresholds of the whole training set: "
+            "qr_bins_stats -> all_gather -> qr_thresholds_from_stats -> qr_bins_build_with");
+  int rc = bins_precheck(c, nthresholds);
+  if (rc) return rc;
+  const uint32_t limit = (uint32_t)(nthresholds ? nthresholds + 1 : 256);
+  std::vector<uint32_t> vals, cnt, mm;
+  if ((rc = bins_stats(c, limit, vals, cnt, mm))) return rc;
+  c->h_thr.assign(c->F * QR_MAX_BINS, FLT_MAX);
+  c->h_thr_size.assign(c->F, 0);
+  const char *e = thresholds_from_stats(c->F, nthresholds, 1, vals.data(), cnt.data(), mm.data(),
+                                        c->h_thr.data(), c->h_thr_size.data());
+  if (e) QR_FAIL(c, QR_ERR_UNSUPPORTED, e);
+  if (thr_out) memcpy(thr_out, c->h_thr.data(), c->F * QR_MAX_BINS * 4);
+  if (thr_size_out) memcpy(thr_size_out, c->h_thr_size.data(), c->F * 4);
+  return bins_finish(c);
+}
+
+int qr_bins_stats(qr_ctx *c, size_t nthresholds, uint32_t *vals_out, uint32_t *cnt_out,
+                  uint32_t *minmax_out) {
+  if (!c || !vals_out || !cnt_out || !minmax_out) return QR_ERR_ARG;
+  int rc = bins_precheck(c, nthresholds);
+  if (rc) return rc;
+  const uint32_t limit = (uint32_t)(nthresholds ? nthresholds + 1 : 256);
+  std::vector<uint32_t> vals, cnt, mm;
+  if ((rc = bins_stats(c, limit, vals, cnt, mm))) return rc;
+  memcpy(vals_out, vals.data(), vals.size() * 4);
+  memcpy(cnt_out, cnt.data(), cnt.size() * 4);
+  memcpy(minmax_out, mm.data(), mm.size() * 4);
+  return QR_OK;
+}
+
+int qr_thresholds_from_stats(size_t F, size_t nthresholds, size_t nranks, const uint32_t *vals,
+                             const uint32_t *cnt, const uint32_t *minmax, float *thr_out,
+                             uint32_t *thr_size_out) {
+  if (!vals || !cnt || !minmax || !thr_out || !thr_size_out || nthresholds > 255 || !nranks)
+    return QR_ERR_ARG;
+  return thresholds_from_stats(F, nthresholds, nranks, vals, cnt, minmax, thr_out, thr_size_out)
+             ? QR_ERR_UNSUPPORTED
+             : QR_OK;
+}
+
+int qr_bins_build_with(qr_ctx *c, const float *thr, const uint32_t *thr_size) {
+  if (!c || !thr || !thr_size) return QR_ERR_ARG;
+  int rc = bins_precheck(c, 255);
+  if (rc) return rc;
+  for (size_t f = 0; f < c->F; ++f) {
+    const uint32_t n = thr_size[f];
+    if (n < 1 || n > QR_MAX_BINS || thr[f * QR_MAX_BINS + n - 1] != FLT_MAX)
+      QR_FAIL(c, QR_ERR_ARG, "every threshold row needs 1..256 slots ending in FLT_MAX");
+  }
+  c->h_thr.assign(thr, thr + c->F * QR_MAX_BINS);
+  c->h_thr_size.assign(thr_size, thr_size + c->F);
+  return bins_finish(c);
 }
 
 int qr_bins_read(qr_ctx *c, uint8_t *out) {
@@ -466,7 +592,9 @@ int qr_pseudo_set(qr_ctx *c, const double *l, const double *w) {
   memcpy(&s.maxabs_bits, &mx, 8);
   QR_CHECK(c, hipMemcpy(c->d_scalars, &s, sizeof(s), hipMemcpyHostToDevice));
   QR_CHECK(c, hipMemcpy(c->d_ssq, ssq.data(), 2 * ns * 8, hipMemcpyHostToDevice));
-  return qr_k_prep(c, ns);
+  int rc = qr_k_prep(c, ns);
+  if (rc || !c->dmode) return rc;
+  return qr_k_prep_pack(c);  // then: all-reduce the scalar buffer, qr_lambda_finish
 }
 
 // ---------------------------------------------------------------------------
@@ -516,7 +644,16 @@ int qr_lambda_compute(qr_ctx *c, int metric, size_t cutoff) {
   QR_CHECK(c, hipMemsetAsync(&c->d_scalars->maxabs_bits, 0, 8, c->stream));
   rc = qr_k_lambda(c, 0, metric, cutoff, 0);
   if (rc) return rc;
-  return qr_k_prep(c, c->Q);
+  if ((rc = qr_k_prep(c, c->Q)) || !c->dmode) return rc;
+  if ((rc = qr_k_metric_reduce(c, 0))) return rc;
+  return qr_k_prep_pack(c);  // then: all-reduce the scalar buffer, qr_lambda_finish
+}
+
+int qr_lambda_finish(qr_ctx *c) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->dmode) QR_FAIL(c, QR_ERR_STATE, "qr_lambda_finish is for document-sharded contexts");
+  if (!c->d_xscal) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  return qr_k_prep_global(c);
 }
 
 int qr_residual_compute(qr_ctx *c) {
@@ -525,7 +662,8 @@ int qr_residual_compute(qr_ctx *c) {
   QR_CHECK(c, hipMemsetAsync(&c->d_scalars->maxabs_bits, 0, 8, c->stream));
   int rc = qr_k_residual(c);
   if (rc) return rc;
-  return qr_k_prep(c, (c->N + QR_SLICE - 1) / QR_SLICE);
+  if ((rc = qr_k_prep(c, (c->N + QR_SLICE - 1) / QR_SLICE)) || !c->dmode) return rc;
+  return qr_k_prep_pack(c);
 }
 
 static int metric_finish(qr_ctx *c, int which, double *out) {
@@ -552,6 +690,13 @@ int qr_metric_eval(qr_ctx *c, int which, int metric, size_t cutoff, double *out)
 
 int qr_metric_last(qr_ctx *c, double *out) {
   if (!c || !out) return QR_ERR_ARG;
+  if (c->dmode) {  // the sum over all ranks came with the scalar exchange
+    QrScalars s;
+    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    QR_CHECK(c, hipMemcpy(&s, c->d_scalars, sizeof(s), hipMemcpyDeviceToHost));
+    *out = c->Qglobal ? s.metric_gsum / (double)c->Qglobal : 0.0;
+    return QR_OK;
+  }
   return metric_finish(c, 0, out);
 }
 
@@ -590,6 +735,13 @@ int qr_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "nleaves must be in [1, 511]");
   int rc = ensure_hist_slots(c, 2 * nleaves + 1);
   if (rc) return rc;
+  if (c->dmode && 2 * nleaves * (size_t)c->world > c->xleaf_cap) {
+    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    dfree(c->d_xleaf);
+    c->xleaf_cap = 2 * nleaves * (size_t)c->world;
+    QR_CHECK(c, dalloc(&c->d_xleaf, c->xleaf_cap));
+    QR_CHECK(c, hipMemset(c->d_xleaf, 0, c->xleaf_cap * 8));
+  }
   c->cur_nleaves = nleaves;
   c->tree_open = true;
   c->tree_valid = false;
@@ -611,6 +763,23 @@ int qr_tree_end(qr_ctx *c, int newton, qr_node_t *nodes_out, size_t *nnodes_out)
   int rc = qr_k_tree_finish(c, newton);
   if (rc) return rc;
   c->tree_open = false;
+  if (c->dmode) return QR_OK;  // all-reduce the leaf buffer, then qr_tree_leaves_finish
+  c->tree_valid = true;
+  if (nodes_out) {
+    std::vector<char> buf(sizeof(QrTreeState));
+    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    QR_CHECK(c, hipMemcpy(buf.data(), c->d_tree, offsetof(QrTreeState, split_log), hipMemcpyDeviceToHost));
+    copy_nodes(*reinterpret_cast<QrTreeState *>(buf.data()), nodes_out, nnodes_out);
+  }
+  return QR_OK;
+}
+
+int qr_tree_leaves_finish(qr_ctx *c, int newton, qr_node_t *nodes_out, size_t *nnodes_out) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->dmode || !c->d_xleaf || c->tree_open)
+    QR_FAIL(c, QR_ERR_STATE, "qr_tree_leaves_finish follows qr_tree_end on a document-sharded context");
+  int rc = qr_k_tree_leaves_global(c, newton);
+  if (rc) return rc;
   c->tree_valid = true;
   if (nodes_out) {
     std::vector<char> buf(sizeof(QrTreeState));
@@ -624,9 +793,9 @@ int qr_tree_end(qr_ctx *c, int newton, qr_node_t *nodes_out, size_t *nnodes_out)
 int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
                 qr_node_t *nodes_out, size_t *nnodes_out) {
   if (!c) return QR_ERR_ARG;
-  if (c->world > 1)
+  if (c->world > 1 || c->dmode)
     QR_FAIL(c, QR_ERR_STATE,
-            "feature-sharded contexts must drive qr_tree_begin/decide/apply/end "
+            "sharded contexts must drive qr_tree_begin/decide/apply/end "
             "with the collectives in between");
   int rc = qr_tree_begin(c, nleaves, minls);
   if (rc) return rc;
@@ -642,7 +811,7 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
                      qr_node_t *nodes_out, size_t *nnodes_out) {
   if (!c) return QR_ERR_ARG;
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
-  if (c->world > 1)
+  if (c->world > 1 || c->dmode)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "oblivious trees are single-GPU in this round");
   if (depth < 1 || ((size_t)1 << (depth + 1)) - 1 > QR_MAXNODES)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
@@ -669,6 +838,19 @@ int qr_exchange_buffers(qr_ctx *c, void **recs_local, void **recs_all,
   if (rec_bytes_per_rank) *rec_bytes_per_rank = 2 * sizeof(qr_split_t);
   if (mask) *mask = c->d_mask;
   if (mask_bytes) *mask_bytes = c->mask_words * 4;
+  return QR_OK;
+}
+
+int qr_doc_exchange_buffers(qr_ctx *c, void **hist, size_t *hist_i64, void **scal,
+                            size_t *scal_i64, void **leaf, size_t *leaf_i64) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->binned || !c->dmode) QR_FAIL(c, QR_ERR_STATE, "not a binned document-sharded context");
+  if (hist) *hist = c->d_xh;
+  if (hist_i64) *hist_i64 = c->xh_len;
+  if (scal) *scal = c->d_xscal;
+  if (scal_i64) *scal_i64 = 4 * (size_t)c->world;
+  if (leaf) *leaf = c->d_xleaf;  // valid after qr_tree_begin
+  if (leaf_i64) *leaf_i64 = 2 * c->cur_nleaves * (size_t)c->world;
   return QR_OK;
 }
 

@@ -109,6 +109,14 @@ struct QrSplitDesc {
   int32_t pad;
 };
 
+// Document-sharded contexts: the part of the current split that lives on this
+// rank (positions are local; QrSplitDesc::lcount / rcount / small_n are global).
+struct QrLocalSplit {
+  uint32_t lcount;               // local documents going left
+  uint32_t small_begin, small_n; // local segment of the directly built child
+  uint32_t pad;
+};
+
 struct QrTreeState {
   int32_t nleaves_req;
   int32_t nnodes;
@@ -123,6 +131,7 @@ struct QrTreeState {
   QrNode nodes[QR_MAXNODES];
   qr_split_t split_log[QR_MAXNODES];
   QrSplitDesc desc;
+  QrLocalSplit loc;
   // oblivious (level-wise) growth: the split chosen for the current level
   uint32_t part_epoch;  // tag of the current partition's look-back granules
   int32_t obl_done, obl_level;
@@ -145,6 +154,7 @@ struct QrScalars {
   double root_ss;                  // sum of squares of the pseudo-responses
   double root_sum;                 // their plain f64 sum
   double metric_sum;               // sum of per-query metric
+  double metric_gsum;              // document-sharded: the same over all ranks
 };
 
 struct qr_ctx {
@@ -153,6 +163,13 @@ struct qr_ctx {
   bool own_stream = false;
   std::string err;
   int rank = 0, world = 1;
+  int dmode = 0;                 // 0 = single GPU / feature-sharded, 1 = document-sharded
+  uint64_t Nglobal = 0, Qglobal = 0;
+  long long *d_xh = nullptr;     // doc-sharded histogram exchange: [cells] sums, [cells] counts, [2*world] f64 bits
+  size_t xh_len = 0, xh_cells = 0;
+  long long *d_xscal = nullptr;  // [world][4] f64 bits: maxabs, root_ss, root_sum, metric_sum
+  long long *d_xleaf = nullptr;  // [world][2*nleaves] f64 bits: per-leaf (sum lambda, sum weight)
+  size_t xleaf_cap = 0;
   int ncu = 256;
   // training data
   size_t N = 0, F = 0, Q = 0, maxq = 0;
@@ -220,6 +237,7 @@ struct qr_ctx {
   double *d_leafpart = nullptr;  // [slices][2] partial sums
   bool tree_valid = false;
   bool tree_open = false;
+  int tree_step = 0;             // decides issued for the open tree
   size_t cur_nleaves = 0;
   // ensemble
   qr_node_t *d_ens = nullptr;
@@ -269,6 +287,9 @@ int qr_k_binning(qr_ctx *c);
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode);
 int qr_k_residual(qr_ctx *c);
 int qr_k_prep(qr_ctx *c, size_t nslices);
+int qr_k_prep_pack(qr_ctx *c);
+int qr_k_prep_global(qr_ctx *c);
+int qr_k_tree_leaves_global(qr_ctx *c, int newton);
 int qr_k_metric_reduce(qr_ctx *c, int which);
 int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls);
 int qr_k_tree_decide(qr_ctx *c);

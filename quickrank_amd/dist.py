@@ -69,6 +69,90 @@ class ShardedTreeFitter:
         return ctx.tree_end(nleaves, newton)
 
 
+class DocShardedTrainer:
+    """Document sharding: rank r holds its own queries (all features of them).
+
+    The exchange is the histogram itself.  Its cells are exact fixed-point
+    integers, so ONE int64 sum all-reduce per node histogram leaves every rank
+    with the bits a single GPU would have computed over all documents; scan, gain
+    and the heap-driven growth then run redundantly on every rank and agree without
+    any further exchange.  The partition is local (every rank has every feature of
+    its documents): no mask.  f64 quantities (sum and sum of squares of the
+    pseudo-responses, leaf sums, the metric) ride as bit patterns in per-rank
+    slots of int64 buffers -- sum == gather -- and are added in rank order.
+    Collectives per boosting iteration: 1 (scalars) + nleaves (histograms) + 1
+    (leaves), none of which needs a host synchronisation.
+
+    This is the layout that scales with the number of documents (weak scaling):
+    the per-rank work is the single-GPU work on its own shard.  The feature-
+    sharded ShardedTreeFitter keeps every per-document step replicated.
+    """
+
+    def __init__(self, ctx, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group, self.ctx = torch, dist, group, ctx
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = device
+        b = ctx.doc_exchange_buffers()
+        self.hist = self._view(b["hist"], b["hist_n"], "hist")
+        self.scal = self._view(b["scal"], b["scal_n"], "scal")
+        self.leaf = None
+        self.leaf_n = 0
+
+    def _view(self, ptr, n, name):
+        torch = self.torch
+        if hasattr(self.ctx, "host_buffers"):        # CPU protocol stand-in (tests)
+            return torch.from_numpy(self.ctx.host_buffers()[name])
+        dev = self.device if self.device is not None else \
+            torch.device("cuda", torch.cuda.current_device())
+        return torch.as_tensor(_DevArray(ptr, n * 8, "<i8", 8), device=dev)
+
+    def _sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def compute_lambdas(self, metric="NDCG", cutoff=10):
+        self.ctx.compute_lambdas(metric, cutoff)
+        self._sum(self.scal)
+        self.ctx.lambda_finish()
+
+    def compute_residuals(self):
+        self.ctx.compute_residuals()
+        self._sum(self.scal)
+        self.ctx.lambda_finish()
+
+    def fit_tree(self, nleaves, minls, newton, read=True):
+        ctx = self.ctx
+        ctx.tree_begin(nleaves, minls)
+        self._sum(self.hist)
+        for _ in range(nleaves - 1):
+            ctx.tree_decide()
+            ctx.tree_apply()
+            self._sum(self.hist)
+        ctx.tree_decide()
+        ctx.tree_end_local(newton)
+        b = ctx.doc_exchange_buffers()
+        if self.leaf is None or self.leaf_n != b["leaf_n"]:
+            self.leaf = self._view(b["leaf"], b["leaf_n"], "leaf")
+            self.leaf_n = b["leaf_n"]
+        self._sum(self.leaf)
+        return ctx.tree_leaves_finish(nleaves, newton, read=read)
+
+
+def gather_thresholds(ctx, nthresholds, group=None):
+    """Thresholds of the whole (document-sharded) training set: every rank's column
+    statistics are all-gathered and merged with the reference's rule."""
+    import torch.distributed as dist
+    from ._capi import thresholds_from_stats
+    vals, cnt, mm = ctx.bins_stats(nthresholds)
+    world = dist.get_world_size(group)
+    parts = [None] * world
+    dist.all_gather_object(parts, (vals, cnt, mm), group=group)
+    return thresholds_from_stats(ctx.F, nthresholds, np.stack([p[0] for p in parts]),
+                                 np.stack([p[1] for p in parts]), np.stack([p[2] for p in parts]))
+
+
 def owned_features(F, rank, world):
     """Global feature indices rank owns (same rule as qr_ctx_set_shard)."""
     per = (F + world - 1) // world

@@ -1,0 +1,216 @@
+"""Host-side stand-in for a DOCUMENT-sharded device context (TEST INFRASTRUCTURE).
+
+Implements the document-sharded phase protocol of include/qr_hip.h (lambda
+compute / finish, tree begin / decide / apply / end / leaves_finish and the three
+int64 exchange buffers) on the CPU: lambdas and split search by the oracle, the
+histogram in the device's exact fixed-point integers, so that the collective
+sequence of quickrank_amd.dist.DocShardedTrainer runs under gloo with
+world_size > 1 and must reproduce the unsharded oracle tree.
+"""
+import numpy as np
+
+import oracle
+from quickrank_amd._capi import NODE_DTYPE
+from shard_standin import _Heap
+
+QBITS = 33
+NONE = 2 ** 64 - 1
+
+
+def _bits(x):
+    return np.float64(x).view(np.int64)
+
+
+def _dbl(i):
+    return np.int64(i).view(np.float64)
+
+
+class DocStandinContext:
+    def __init__(self, x, labels, qoff, thr, thr_size, rank, world, n_global, q_global):
+        self.x = np.ascontiguousarray(x, np.float32)
+        self.labels = np.ascontiguousarray(labels, np.float32)
+        self.qoff = np.ascontiguousarray(qoff, np.uint64)
+        self.N, self.F = self.x.shape
+        self.rank, self.world = rank, world
+        self.Ng, self.Qg = n_global, q_global
+        self.thr, self.thr_size = thr, np.ascontiguousarray(thr_size, np.uint64)
+        self.cap = thr.shape[1]
+        col = np.ascontiguousarray(self.x.T)
+        self.stmap, _ = oracle.binmap(col, self.thr, self.thr_size)   # [F][N] slot ids
+        self.cells = self.F * self.cap
+        self.hist = np.zeros(2 * self.cells + 2 * world, np.int64)
+        self.scal = np.zeros(4 * world, np.int64)
+        self.leaf = np.zeros(0, np.int64)
+        self.scores = np.zeros(self.N)
+
+    # -- exchange buffers ------------------------------------------------------
+    def doc_exchange_buffers(self):
+        return dict(hist=0, hist_n=len(self.hist), scal=0, scal_n=len(self.scal),
+                    leaf=0, leaf_n=len(self.leaf))
+
+    def host_buffers(self):
+        return dict(hist=self.hist, scal=self.scal, leaf=self.leaf)
+
+    # -- pseudo-responses --------------------------------------------------------
+    def compute_lambdas(self, metric="NDCG", cutoff=10):
+        self.lam, self.w = oracle.lambdas(self.labels, self.scores, self.qoff, cutoff)
+        msum = 0.0
+        for q in range(len(self.qoff) - 1):
+            a, b = int(self.qoff[q]), int(self.qoff[q + 1])
+            msum += oracle.eval_dataset(self.labels[a:b], self.scores[a:b],
+                                        np.array([0, b - a], np.uint64), cutoff)
+        self.scal[:] = 0
+        r = self.rank
+        self.scal[4 * r] = _bits(np.abs(self.lam).max() if self.N else 0.0)
+        self.scal[4 * r + 1] = _bits(float(np.sum(self.lam * self.lam)))
+        self.scal[4 * r + 2] = _bits(float(np.sum(self.lam)))
+        self.scal[4 * r + 3] = _bits(msum)
+
+    def lambda_finish(self):
+        v = self.scal.view(np.float64).reshape(self.world, 4)
+        mx = v[:, 0].max()
+        self.root_ss = sum(float(a) for a in v[:, 1])      # rank order
+        self.root_sum = sum(float(a) for a in v[:, 2])
+        self.metric = sum(float(a) for a in v[:, 3]) / self.Qg
+        e = QBITS - (int(np.frexp(mx)[1]) if mx > 0 else 0)
+        self.scale, self.inv_scale = np.ldexp(1.0, e), np.ldexp(1.0, -e)
+        self.q = np.rint(self.lam * self.scale).astype(np.int64)
+
+    # -- histogram in exact integers ----------------------------------------------
+    def _local_hist(self, ids, tail):
+        s = np.zeros((self.F, self.cap), np.int64)
+        c = np.zeros((self.F, self.cap), np.int64)
+        if len(ids):
+            for f in range(self.F):
+                b = self.stmap[f, ids]
+                np.add.at(s[f], b, self.q[ids])
+                np.add.at(c[f], b, 1)
+        self.hist[:self.cells] = np.cumsum(s, axis=1).ravel()
+        self.hist[self.cells:2 * self.cells] = np.cumsum(c, axis=1).ravel()
+        self.hist[2 * self.cells:] = 0
+        self.hist[2 * self.cells + 2 * self.rank] = _bits(tail[0])
+        self.hist[2 * self.cells + 2 * self.rank + 1] = _bits(tail[1])
+
+    def _global_hist(self):
+        s = self.hist[:self.cells].reshape(self.F, self.cap).copy()
+        c = self.hist[self.cells:2 * self.cells].reshape(self.F, self.cap).astype(np.uint64)
+        t = self.hist[2 * self.cells:].view(np.float64).reshape(self.world, 2)
+        return s, c, sum(float(a) for a in t[:, 0]), sum(float(a) for a in t[:, 1])
+
+    def _best(self, s, c):
+        sp = oracle.split_find(s.astype(np.float64) * self.inv_scale, c, self.thr_size, self.minls)
+        return None if sp.feature == NONE else (sp.score, int(sp.feature), int(sp.thr_id),
+                                                int(sp.lcount), int(sp.rcount))
+
+    # -- protocol ----------------------------------------------------------------
+    def tree_begin(self, nleaves, minls):
+        self.nleaves, self.minls = nleaves, minls
+        if len(self.leaf) != 2 * nleaves * self.world:
+            self.leaf = np.zeros(2 * nleaves * self.world, np.int64)
+        self.nodes, self.heap = [], _Heap()
+        self.taken, self.done, self.step, self.desc = 0, False, 0, None
+        self._local_hist(np.arange(self.N), (0.0, 0.0))
+
+    @staticmethod
+    def _node(ids, n, sm, ss, hist):
+        return dict(ids=ids, n=n, sum=sm, ss=ss, dev=ss - sm * sm / n if n else float("nan"),
+                    hist=hist, feature=-1, thr_id=-1, left=-1, right=-1, best=None)
+
+    def _splittable(self, nd):
+        return nd["dev"] > 0 and nd["best"] is not None
+
+    def _make_desc(self, i):
+        nd = self.nodes[i]
+        _, f, t, lc, rc = nd["best"]
+        nd["feature"], nd["thr_id"] = f, t
+        self.desc = dict(node=i, f=f, t=t, small_is_left=lc <= rc, small_n=min(lc, rc))
+
+    def tree_decide(self):
+        s, c, ss_small, sum_small = self._global_hist()
+        if self.step == 0:
+            root = self._node(np.arange(self.N), self.Ng, self.root_sum, self.root_ss, (s, c))
+            root["best"] = self._best(s, c)
+            self.nodes = [root]
+            if self._splittable(root):
+                self._make_desc(0)
+            else:
+                self.done = True
+            self.step = 1
+            return
+        if self.desc is not None:
+            d = self.desc
+            P = self.nodes[d["node"]]
+            ps, pc = P["hist"]
+            bs, bc = ps - s, pc - c                         # sibling by exact subtraction
+            small = self._node(d["small_ids"], d["small_n"], sum_small, ss_small, (s, c))
+            big = self._node(d["big_ids"], P["n"] - d["small_n"], P["sum"] - sum_small,
+                             P["ss"] - ss_small, (bs, bc))
+            small["best"], big["best"] = self._best(s, c), self._best(bs, bc)
+            L, R = (small, big) if d["small_is_left"] else (big, small)
+            P["left"], P["right"] = len(self.nodes), len(self.nodes) + 1
+            self.nodes += [L, R]
+            self.heap.push(L["dev"], P["left"])
+            self.heap.push(R["dev"], P["right"])
+            self.desc = None
+        self.step += 1
+        if self.done:
+            return
+        while len(self.heap) > 0 and self.taken + len(self.heap) < self.nleaves:
+            i = self.heap.pop()
+            if self._splittable(self.nodes[i]):
+                self._make_desc(i)
+                return
+            self.taken += 1
+        self.done = True
+
+    def tree_apply(self):
+        if self.desc is None:
+            return                                           # stale buffer is summed and ignored
+        d = self.desc
+        ids = self.nodes[d["node"]]["ids"]
+        go = self.stmap[d["f"], ids] <= d["t"]
+        lids, rids = ids[go], ids[~go]
+        d["small_ids"], d["big_ids"] = (lids, rids) if d["small_is_left"] else (rids, lids)
+        l = self.lam[d["small_ids"]]
+        self._local_hist(d["small_ids"], (float(np.sum(l * l)), float(np.sum(l))))
+
+    def tree_end_local(self, newton=True):
+        self.leaves = []
+        stack = [0]
+        while stack:                                         # DFS, left first (rtnode.cc:34-46)
+            i = stack.pop()
+            nd = self.nodes[i]
+            if nd["feature"] < 0:
+                self.leaves.append(i)
+            else:
+                stack += [nd["right"], nd["left"]]
+        self.leaf[:] = 0
+        base = self.rank * 2 * self.nleaves
+        for l, i in enumerate(self.leaves):
+            ids = self.nodes[i]["ids"]
+            self.leaf[base + 2 * l] = _bits(float(np.sum(self.lam[ids])))
+            self.leaf[base + 2 * l + 1] = _bits(float(np.sum(self.w[ids])) if newton else 0.0)
+
+    def tree_leaves_finish(self, nleaves, newton=True, read=True):
+        v = self.leaf.view(np.float64).reshape(self.world, nleaves, 2)
+        out = np.zeros(len(self.nodes), NODE_DTYPE)
+        for i, nd in enumerate(self.nodes):
+            out[i]["feature"], out[i]["thr_id"] = nd["feature"], nd["thr_id"]
+            out[i]["left"], out[i]["right"] = nd["left"], nd["right"]
+            out[i]["nsamples"] = nd["n"]
+            out[i]["deviance"] = nd["dev"]
+            if nd["feature"] >= 0:
+                out[i]["threshold"] = self.thr[nd["feature"], nd["thr_id"]]
+        self.leaf_value = {}
+        for l, i in enumerate(self.leaves):
+            s1 = sum(float(a) for a in v[:, l, 0])
+            s2 = sum(float(a) for a in v[:, l, 1])
+            val = (s1 / s2 if s2 >= np.finfo(float).eps else 0.0) if newton else s1 / self.nodes[i]["n"]
+            out[i]["value"] = val
+            self.leaf_value[i] = val
+        return out
+
+    def update_scores(self, shrinkage):
+        for i, val in self.leaf_value.items():
+            ids = self.nodes[i]["ids"]
+            self.scores[ids] = self.scores[ids] + shrinkage * val

@@ -1,0 +1,126 @@
+"""Document-sharded N > 1 path on CPU: world_size 2 and 3 over gloo.  Each process
+runs the real quickrank_amd.dist.DocShardedTrainer (int64 sum all-reduces of the
+scalar / histogram / leaf buffers) over a host stand-in context that holds only
+its own queries; the trees must reproduce the unsharded oracle training."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, q, cuts, ntrees):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from datagen import make_dataset
+    from parity_util import assert_tree_parity
+    from quickrank_amd.dist import DocShardedTrainer
+    from docshard_standin import DocStandinContext
+    x, labels, qoff = make_dataset(nq=24, docs_per_query=40, F=20, seed=31, adversarial=True)
+    whole = oracle.Trainer(x, 64)                      # thresholds of the WHOLE set
+    edges = [0] + list(cuts) + [len(qoff) - 1]
+    q0, q1 = edges[rank], edges[rank + 1]
+    d0, d1 = int(qoff[q0]), int(qoff[q1])
+    ctx = DocStandinContext(x[d0:d1], labels[d0:d1], qoff[q0:q1 + 1] - qoff[q0], whole.thr,
+                            whole.thr_size, rank, world, len(labels), len(qoff) - 1)
+    tr = DocShardedTrainer(ctx)
+    scores = np.zeros(len(labels))
+    ok = True
+    for it in range(ntrees):
+        tr.compute_lambdas("NDCG", 10)
+        nodes = tr.fit_tree(8, 2, True)
+        ctx.update_scores(0.1)
+        # unsharded oracle iteration on the same scores
+        lam, w = oracle.lambdas(labels, scores, qoff)
+        t = whole.fit_tree(lam, nleaves=8, minls=2)
+        whole.update_output(t, lam, w)
+        o = t["nodes"]
+        assert_tree_parity(whole.stmap, o, nodes, value_rtol=1e-9)
+        # the metric of the scores the lambdas ranked (summed over the ranks' queries)
+        assert ctx.metric == pytest.approx(oracle.eval_dataset(labels, scores, qoff), rel=1e-12)
+        scores = scores + 0.1 * o["value"][_leaf_of(whole, o)]
+        assert np.allclose(ctx.scores, scores[d0:d1], rtol=1e-9, atol=1e-12)
+        # every rank must hold the same tree, bit for bit
+        mine = torch.from_numpy(np.frombuffer(nodes.tobytes(), np.uint8).copy())
+        ref = mine.clone()
+        dist.broadcast(ref, 0)
+        ok = ok and torch.equal(mine, ref)
+    if rank == 0:
+        q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+def _leaf_of(tr, nodes):
+    """leaf node index of every document: walk on the bin ids"""
+    at = np.zeros(tr.N, np.int64)
+    while True:
+        nd = nodes[at]
+        internal = nd["feature"] >= 0
+        if not internal.any():
+            return at
+        idx = np.nonzero(internal)[0]
+        go = tr.stmap[nd["feature"][idx], idx] <= nd["thr_id"][idx]
+        at[idx] = np.where(go, nd["left"][idx], nd["right"][idx])
+
+
+@pytest.mark.parametrize("world,cuts", [(2, [9]), (3, [3, 15])])
+def test_doc_sharded_training_equals_unsharded(world, cuts):
+    import oracle
+    oracle.build(ref=False)
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 31500 + (os.getpid() + world * 11) % 2000
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, cuts, 3)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_thresholds_from_stats_symbol_is_pure_host():
+    """qr_thresholds_from_stats needs no GPU: merging the column statistics of two
+    document shards gives the thresholds of their union (mart.cc:147-169)."""
+    import oracle
+    from quickrank_amd import build
+    from quickrank_amd._capi import thresholds_from_stats
+    if not os.path.exists(build.LIB):
+        pytest.skip("HIP library not built")
+    rng = np.random.default_rng(0)
+    F, nthr = 6, 16
+    x = rng.random((400, F), dtype=np.float32)
+    x[:, 1] = np.floor(x[:, 1] * 5)            # few uniques -> the uniques branch
+    x[:, 2] = 0.25                             # constant
+    x[:200, 3] = np.floor(x[:200, 3] * 10)     # few uniques on one shard only
+    limit = nthr + 1
+
+    def flip(u):                               # radix key (radix.cc:28-30)
+        return np.where(u >> 31, ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+
+    vals = np.zeros((2, F, limit + 1), np.uint32)
+    cnt = np.zeros((2, F), np.uint32)
+    mm = np.zeros((2, F, 2), np.uint32)
+    for r, part in enumerate((x[:200], x[200:])):
+        for f in range(F):
+            u = np.unique(part[:, f])
+            k = min(len(u), limit + 1)
+            vals[r, f, :k] = u[:k].view(np.uint32)
+            cnt[r, f] = k
+            mm[r, f] = flip(np.array([part[:, f].min(), part[:, f].max()], np.float32).view(np.uint32))
+    thr, ts = thresholds_from_stats(F, nthr, vals, cnt, mm)
+    othr, ots = oracle.thresholds(np.ascontiguousarray(x.T), nthr)
+    assert np.array_equal(ts, ots.astype(np.uint32))
+    for f in range(F):
+        assert np.array_equal(thr[f, :ts[f]], othr[f, :ts[f]]), f

@@ -1,0 +1,219 @@
+"""Document-sharded device protocol on ONE GPU: P contexts, each holding its own
+queries (all features), the int64 sum all-reduces of quickrank_amd/dist.py
+replaced by explicit sums over the contexts' exchange buffers.  Histograms are
+exact integers, so the tree STRUCTURE must equal the single-context tree on the
+whole dataset bit for bit; f64 node sums are added in rank order instead of
+document order, so leaf values / scores agree to rounding (1e-12 relative, far
+inside the 1e-5 bar)."""
+import numpy as np
+import pytest
+
+from datagen import make_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _split_queries(qoff, cuts):
+    """cuts: query indices where a new rank starts -> list of (q0, q1)"""
+    edges = [0] + list(cuts) + [len(qoff) - 1]
+    return [(edges[i], edges[i + 1]) for i in range(len(edges) - 1)]
+
+
+class _Emu:
+    """all_reduce(sum) over the contexts' int64 exchange buffers, on one device"""
+
+    def __init__(self, torch, ctxs):
+        from quickrank_amd.dist import _DevArray
+        self.torch, self.ctxs, self.DevArray = torch, ctxs, _DevArray
+        self.dev = torch.device("cuda", 0)
+
+    def view(self, c, key):
+        b = c.doc_exchange_buffers()
+        return self.torch.as_tensor(self.DevArray(b[key], b[key + "_n"] * 8, "<i8", 8),
+                                    device=self.dev)
+
+    def sync(self):
+        for c in self.ctxs:
+            c.synchronize()
+        self.torch.cuda.synchronize()
+
+    def allreduce(self, key):
+        self.sync()
+        views = [self.view(c, key) for c in self.ctxs]
+        tot = views[0].clone()
+        for v in views[1:]:
+            tot += v
+        for v in views:
+            v.copy_(tot)
+        self.sync()
+
+
+def _make_ctxs(qr, x, labels, qoff, parts, nthr):
+    from quickrank_amd._capi import thresholds_from_stats
+    world = len(parts)
+    N, Q = len(labels), len(qoff) - 1
+    ctxs, stats = [], []
+    for r, (q0, q1) in enumerate(parts):
+        d0, d1 = int(qoff[q0]), int(qoff[q1])
+        c = qr.Context(0, rank=r, world=world, doc_shard=(N, Q))
+        c.upload(x[d0:d1], labels[d0:d1], qoff[q0:q1 + 1] - qoff[q0])
+        stats.append(c.bins_stats(nthr))
+        ctxs.append(c)
+    thr, ts = thresholds_from_stats(x.shape[1], nthr, np.stack([s[0] for s in stats]),
+                                    np.stack([s[1] for s in stats]), np.stack([s[2] for s in stats]))
+    for c in ctxs:
+        c.build_bins_with(thr, ts)
+    return ctxs, thr, ts
+
+
+def _doc_fit(emu, ctxs, nleaves, minls, newton):
+    for c in ctxs:
+        c.tree_begin(nleaves, minls)
+    emu.allreduce("hist")
+    for _ in range(nleaves - 1):
+        for c in ctxs:
+            c.tree_decide()
+            c.tree_apply()
+        emu.allreduce("hist")
+    for c in ctxs:
+        c.tree_decide()
+        c.tree_end_local(newton)
+    emu.allreduce("leaf")
+    return [c.tree_leaves_finish(nleaves, newton) for c in ctxs]
+
+
+@pytest.mark.parametrize("world,cuts,nthr,F", [
+    (2, [30], 255, 136),
+    (3, [5, 41], 255, 70),       # a small first shard
+    (4, [15, 30, 45], 16, 20),   # equal-width thresholds from the GLOBAL min/max
+    (8, [7, 14, 22, 30, 38, 45, 52], 255, 136),
+])
+def test_doc_sharded_training_equals_single(world, cuts, nthr, F):
+    import torch
+    import quickrank_amd as qr
+    from quickrank_amd import build
+    build.build()
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=50, F=F, seed=23, adversarial=True)
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    thr1, ts1 = single.build_bins(nthr)
+    single.reset_scores()
+    parts = _split_queries(qoff, cuts)
+    ctxs, thr, ts = _make_ctxs(qr, x, labels, qoff, parts, nthr)
+    assert np.array_equal(ts, ts1) and np.array_equal(thr, thr1)   # same thresholds, bit for bit
+    off = 0
+    for c, (q0, q1) in zip(ctxs, parts):
+        d0, d1 = int(qoff[q0]), int(qoff[q1])
+        assert np.array_equal(c.read_bins(), single.read_bins()[d0:d1])
+    emu = _Emu(torch, ctxs)
+    for c in ctxs:
+        c.reset_scores()
+    for it in range(6):
+        single.compute_lambdas("NDCG", 10)
+        want = single.fit_tree(10, 2, True)
+        single.update_scores(0.1)
+        for c in ctxs:
+            c.compute_lambdas("NDCG", 10)
+        emu.allreduce("scal")
+        for c in ctxs:
+            c.lambda_finish()
+        got = _doc_fit(emu, ctxs, 10, 2, True)
+        for c in ctxs:
+            c.update_scores(0.1)
+        for g in got:
+            assert len(g) == len(want), it
+            for k in ("feature", "thr_id", "left", "right", "nsamples", "threshold"):
+                assert np.array_equal(g[k], want[k]), (it, k)
+            assert np.allclose(g["value"], want["value"], rtol=1e-11, atol=1e-14), it
+            assert np.allclose(g["deviance"], want["deviance"], rtol=1e-9, atol=1e-12), it
+        for g in got[1:]:                      # every rank: the same bits
+            for k in want.dtype.names:
+                assert np.array_equal(g[k], got[0][k]), (it, k)
+        # the training metric of the scores the lambdas ranked
+        m1 = single.metric_last()
+        for c in ctxs:
+            assert c.metric_last() == pytest.approx(m1, rel=1e-12)
+    s1 = single.get_scores()
+    for c, (q0, q1) in zip(ctxs, parts):
+        d0, d1 = int(qoff[q0]), int(qoff[q1])
+        assert np.allclose(c.get_scores(), s1[d0:d1], rtol=1e-10, atol=1e-13)
+        c.close()
+    single.close()
+
+
+def test_doc_sharded_mart_residuals():
+    """MART (mean leaves, residual pseudo-responses) through the same protocol."""
+    import torch
+    import quickrank_amd as qr
+    x, labels, qoff = make_dataset(nq=40, docs_per_query=30, F=24, seed=4)
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(64)
+    single.reset_scores()
+    parts = _split_queries(qoff, [13, 29])
+    ctxs, _, _ = _make_ctxs(qr, x, labels, qoff, parts, 64)
+    emu = _Emu(torch, ctxs)
+    for c in ctxs:
+        c.reset_scores()
+    for it in range(4):
+        single.compute_residuals()
+        want = single.fit_tree(8, 1, False)
+        single.update_scores(0.1)
+        for c in ctxs:
+            c.compute_residuals()
+        emu.allreduce("scal")
+        for c in ctxs:
+            c.lambda_finish()
+        got = _doc_fit(emu, ctxs, 8, 1, False)
+        for c in ctxs:
+            c.update_scores(0.1)
+        for g in got:
+            for k in ("feature", "thr_id", "left", "right", "nsamples"):
+                assert np.array_equal(g[k], want[k]), (it, k)
+            assert np.allclose(g["value"], want["value"], rtol=1e-11, atol=1e-14)
+    for c in ctxs:
+        c.close()
+    single.close()
+
+
+def test_doc_sharded_trainer_over_rccl_world1():
+    """The real DocShardedTrainer over torch.distributed/nccl (RCCL) with one rank:
+    int64 all-reduces on zero-copy views of the exchange buffers, enqueued on the
+    context's stream.  With one rank every sum has one term: bit-identical."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import quickrank_amd as qr
+    from quickrank_amd.dist import DocShardedTrainer, gather_thresholds
+    x, labels, qoff = make_dataset(nq=50, docs_per_query=40, F=40, seed=5, adversarial=True)
+    ref = qr.Context(0)
+    ref.upload(x, labels, qoff)
+    thr1, ts1 = ref.build_bins(64)
+    ref.reset_scores()
+    torch.cuda.set_device(0)
+    port = 29600 + (os.getpid() + 7) % 1000
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        c = qr.Context(0, stream=torch.cuda.current_stream().cuda_stream,
+                       doc_shard=(len(labels), len(qoff) - 1))
+        c.upload(x, labels, qoff)
+        thr, ts = gather_thresholds(c, 64)
+        assert np.array_equal(thr, thr1) and np.array_equal(ts, ts1)
+        c.build_bins_with(thr, ts)
+        c.reset_scores()
+        tr = DocShardedTrainer(c)
+        for it in range(3):
+            ref.compute_lambdas("NDCG", 10)
+            want = ref.fit_tree(8, 1, True)
+            ref.update_scores(0.1)
+            tr.compute_lambdas("NDCG", 10)
+            got = tr.fit_tree(8, 1, True)
+            c.update_scores(0.1)
+            for k in want.dtype.names:
+                assert np.array_equal(got[k], want[k]), (it, k)
+            assert c.metric_last() == ref.metric_last()
+        assert np.array_equal(c.get_scores(), ref.get_scores())
+        c.close()
+    finally:
+        dist.destroy_process_group()
+    ref.close()

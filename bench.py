@@ -157,25 +157,27 @@ def main():
             from quickrank_amd.dist import ShardedTreeFitter
             fitter = ShardedTreeFitter(ctx)
 
-    ndcg = []
+    ndcg, trees = [], []
 
     def step():
         # ranking + NDCG@10 of the current scores (= the training metric the
         # reference evaluates at the end of the previous iteration, mart.cc:347)
-        # + lambdas/weights, one pass over the queries
+        # + lambdas/weights in one pass over the queries; tree; leaf outputs; score
+        # update.  Everything is enqueued first; the metric and the tree records are
+        # read last (pinned snapshots + events), so the host never drains the stream
+        # in the middle of an iteration.
         if trainer is not None:
             trainer.compute_lambdas("NDCG", 10)
-            ndcg.append(ctx.metric_last())
             trainer.fit_tree(args.nleaves, 1, True, read=False)
-            ctx.update_scores(0.1)
-            return
-        ctx.compute_lambdas("NDCG", 10)
-        ndcg.append(ctx.metric_last())
-        if fitter is not None:
-            fitter.fit_tree(ctx, args.nleaves, 1, True)
         else:
-            ctx.fit_tree(args.nleaves, 1, True)
+            ctx.compute_lambdas("NDCG", 10)
+            if fitter is not None:
+                fitter.fit_tree(ctx, args.nleaves, 1, True, read=False)
+            else:
+                ctx.fit_tree(args.nleaves, 1, True, read=False)
         ctx.update_scores(0.1)
+        ndcg.append(ctx.metric_last())
+        trees.append(ctx.tree_nodes())
 
     def sync():
         if dist is not None:

@@ -145,7 +145,8 @@ int qr_residual_compute(qr_ctx *ctx);
 int qr_metric_eval(qr_ctx *ctx, int which, int metric, size_t cutoff,
                    double *out);
 /* training metric of the scores the last qr_lambda_compute ranked (the lambda   */
-/* kernel evaluates it on the way: same ranking, no second sort)                 */
+/* kernel evaluates it on the way: same ranking, no second sort).  Waits for the */
+/* lambda pass only (pinned snapshot + event), not for work enqueued after it.   */
 int qr_metric_last(qr_ctx *ctx, double *out);
 
 /* ---- regression tree: RegressionTree::fit (rt.cc:49-90) + split (:209-362) +  */
@@ -155,8 +156,14 @@ int qr_metric_last(qr_ctx *ctx, double *out);
 /* else MART mean (rt.cc:165-184).  nodes_out: capacity 2*nleaves+1, creation    */
 /* order (root 0; each split appends left,right).  leaf ids are DFS left-first   */
 /* (rtnode.cc:34-46).                                                            */
+/* nodes_out == NULL and nnodes_out == NULL: enqueue only (no wait); fetch the    */
+/* records later with qr_tree_nodes.                                             */
 int qr_tree_fit(qr_ctx *ctx, size_t nleaves, uint64_t minls, int newton,
                 qr_node_t *nodes_out, size_t *nnodes_out);
+/* records of the last fitted tree.  They reach pinned host memory by an async   */
+/* copy enqueued right behind the tree's kernels, so this waits for the tree      */
+/* only -- not for work enqueued after it (score update, the next lambdas).       */
+int qr_tree_nodes(qr_ctx *ctx, qr_node_t *nodes_out, size_t *nnodes_out);
 /* ObliviousRT::fit (ot.cc:32-201): nodes_out in heap order (2i+1, 2i+2),        */
 /* capacity 2^(depth+1)-1; absent nodes have feature == -2.                      */
 int qr_oblivious_fit(qr_ctx *ctx, size_t depth, uint64_t minls, int newton,

@@ -38,7 +38,7 @@ SYMBOLS = [
     "qr_prof_get", "qr_prof_enable", "qr_oblivious_upload", "qr_oblivious_score",
     "qr_ctx_set_doc_shard", "qr_bins_stats", "qr_thresholds_from_stats",
     "qr_bins_build_with", "qr_lambda_finish", "qr_tree_leaves_finish",
-    "qr_doc_exchange_buffers",
+    "qr_doc_exchange_buffers", "qr_tree_nodes",
 ]
 
 _LIB = None
@@ -109,6 +109,7 @@ def lib():
     L.qr_bins_stats.argtypes = [vp, sz, vp, vp, vp]
     L.qr_thresholds_from_stats.argtypes = [sz, sz, sz, vp, vp, vp, vp, vp]
     L.qr_bins_build_with.argtypes = [vp, vp, vp]
+    L.qr_tree_nodes.argtypes = [vp, vp, C.POINTER(sz)]
     L.qr_lambda_finish.argtypes = [vp]
     L.qr_tree_leaves_finish.argtypes = [vp, C.c_int, vp, C.POINTER(sz)]
     L.qr_doc_exchange_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp),
@@ -271,10 +272,21 @@ class Context:
         self._ck(self.L.qr_metric_last(self.h, C.byref(out)))
         return out.value
 
-    def fit_tree(self, nleaves=10, minls=1, newton=True):
+    def fit_tree(self, nleaves=10, minls=1, newton=True, read=True):
+        """read=False: enqueue only; fetch the records later with tree_nodes()."""
+        if not read:
+            self._ck(self.L.qr_tree_fit(self.h, nleaves, minls, int(newton), None, None))
+            return None
         nodes = np.zeros(2 * nleaves + 1, NODE_DTYPE)
         n = C.c_size_t()
         self._ck(self.L.qr_tree_fit(self.h, nleaves, minls, int(newton), _ptr(nodes), C.byref(n)))
+        return nodes[:n.value].copy()
+
+    def tree_nodes(self):
+        """Records of the last fitted tree (waits for that tree only)."""
+        nodes = np.zeros(1024, NODE_DTYPE)
+        n = C.c_size_t()
+        self._ck(self.L.qr_tree_nodes(self.h, _ptr(nodes), C.byref(n)))
         return nodes[:n.value].copy()
 
     def fit_oblivious(self, depth=3, minls=1, newton=True):

@@ -131,6 +131,8 @@ int qr_k_colstats(qr_ctx *c, const float *col, size_t N, size_t F,
 // (doc, local column); columns fastest so both the f32 row read and the u8
 // block-row write are coalesced.
 // ---------------------------------------------------------------------------
+static int qr_k_binning_blocks(qr_ctx *c);
+
 __global__ __launch_bounds__(256) void k_binning(const float *__restrict__ raw,
                                                  uint32_t N, uint32_t F,
                                                  const float *__restrict__ thr,
@@ -162,7 +164,37 @@ __global__ __launch_bounds__(256) void k_binning(const float *__restrict__ raw,
   bins[blk.off + (size_t)d * fw + cidx] = out;
 }
 
+// feature-major copy of one block, [lf][doc]: 64 docs x fw columns per workgroup
+// through LDS so both sides are coalesced
+__global__ __launch_bounds__(256) void k_bins_fm(const uint8_t *__restrict__ bins, uint32_t N,
+                                                 QrBlock blk, uint8_t *__restrict__ fm) {
+  __shared__ uint8_t tile[64][65];
+  const uint32_t fw = (uint32_t)blk.fw;
+  const uint32_t d0 = blockIdx.x * 64;
+  for (uint32_t i = threadIdx.x; i < 64 * fw; i += 256) {
+    const uint32_t dd = i / fw, cc = i % fw;
+    tile[dd][cc] = d0 + dd < N ? bins[blk.off + (size_t)(d0 + dd) * fw + cc] : 0;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 64 * (uint32_t)blk.nreal; i += 256) {
+    const uint32_t cc = i / 64, dd = i % 64;
+    if (d0 + dd < N) fm[(size_t)(blk.lf0 + cc) * N + d0 + dd] = tile[dd][cc];
+  }
+}
+
 int qr_k_binning(qr_ctx *c) {
+  const int rc = qr_k_binning_blocks(c);
+  if (rc) return rc;
+  for (int b = 0; b < c->nblocks; ++b) {
+    const QrBlock &blk = c->blocks[b];
+    hipLaunchKernelGGL(k_bins_fm, dim3((unsigned)((c->N + 63) / 64)), dim3(256), 0, c->stream,
+                       c->d_bins, (uint32_t)c->N, blk, c->d_bins_fm);
+    QR_CHECK(c, hipGetLastError());
+  }
+  return QR_OK;
+}
+
+static int qr_k_binning_blocks(qr_ctx *c) {
   for (int b = 0; b < c->nblocks; ++b) {
     const QrBlock &blk = c->blocks[b];
     const size_t total = c->N * (size_t)blk.fw;

@@ -31,6 +31,7 @@
 #include <algorithm>
 
 #include "qr_internal.h"
+#include "qr_wave.h"
 
 #define NO_CUTOFF 0xFFFFFFFFu
 
@@ -194,44 +195,6 @@ __device__ void g_gnu_sort(uint32_t *a, int n, C c) {
     for (int i = 16; i < n; ++i) g_linear_insert(a, i, c);
   } else
     g_insertion_sort(a, 0, n, c);
-}
-
-// ---------------------------------------------------------------------------
-// Wave reductions on DPP (no LDS round trip): quad butterflies, row_half_mirror,
-// row_mirror give every lane its 16-lane row total; the four row totals are
-// combined in a fixed order through readlane.  Deterministic association.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_f64<0x141>(v);  // row_half_mirror
-  v += dpp_f64<0x140>(v);  // row_mirror
-  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
-}
-__device__ __forceinline__ double wave_max(double v) {
-  double o = dpp_f64<0xB1>(v);
-  v = o > v ? o : v;
-  o = dpp_f64<0x4E>(v);
-  v = o > v ? o : v;
-  o = dpp_f64<0x141>(v);
-  v = o > v ? o : v;
-  o = dpp_f64<0x140>(v);
-  v = o > v ? o : v;
-  const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32),
-               d = readlane_f64(v, 48);
-  const double ab = a > b ? a : b, cd = c > d ? c : d;
-  return ab > cd ? ab : cd;
 }
 
 // ---------------------------------------------------------------------------
@@ -681,7 +644,8 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
                                                uint32_t nss,
                                                const double *__restrict__ qmetric,
                                                uint32_t nq,
-                                               QrScalars *__restrict__ scal) {
+                                               QrScalars *__restrict__ scal,
+                                               const int reset_max) {
   __shared__ double red[16];
   double a = 0.0, b = 0.0, a2 = 0.0;
   for (uint32_t i = threadIdx.x; i < nss; i += 1024) {
@@ -721,6 +685,9 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
       scal->scale_exp = e;
       scal->scale = ldexp(1.0, e);
       scal->inv_scale = ldexp(1.0, -e);
+      // ready for the next iteration's atomicMax (document-sharded contexts still
+      // have to pack it for the exchange: k_scal_global clears it there)
+      if (reset_max) scal->maxabs_bits = 0;
     }
   }
 }
@@ -779,10 +746,11 @@ int qr_k_residual(qr_ctx *c) {
 
 // nss > 0: reduce ssq[nss] into root_ss and derive the scale; the per-query
 // metric of set `which` (encoded in the sign: nss == 0 means metric only).
-int qr_k_prep(qr_ctx *c, size_t nss) {
+int qr_k_prep(qr_ctx *c, size_t nss, int with_metric) {
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, c->stream,
                      nss ? c->d_ssq : (const double *)nullptr, (uint32_t)nss,
-                     (const double *)nullptr, 0u, c->d_scalars);
+                     with_metric ? c->d_qmetric : (const double *)nullptr,
+                     with_metric ? (uint32_t)c->Q : 0u, c->d_scalars, c->dmode ? 0 : 1);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -820,7 +788,7 @@ __global__ void k_scal_global(QrScalars *__restrict__ scal, const long long *__r
   scal->root_ss = ss;
   scal->root_sum = sm;
   scal->metric_gsum = ms;
-  scal->maxabs_bits = (unsigned long long)__double_as_longlong(mx);
+  scal->maxabs_bits = 0;  // ready for the next iteration's atomicMax
   int e = 0;
   if (mx > 0.0) frexp(mx, &e);
   e = QR_QBITS - e;
@@ -849,7 +817,7 @@ int qr_k_metric_reduce(qr_ctx *c, int which) {
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, c->stream,
                      (const double *)nullptr, 0u,
                      which ? c->d_vqmetric : c->d_qmetric,
-                     (uint32_t)(which ? c->vQ : c->Q), c->d_scalars);
+                     (uint32_t)(which ? c->vQ : c->Q), c->d_scalars, 0);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

@@ -22,6 +22,7 @@
 //              doc list (ascending doc ids are preserved)
 //   k_finish / k_leaf_sums / k_leaf_final / k_score_update / k_valid_update
 #include "qr_internal.h"
+#include "qr_wave.h"
 
 typedef unsigned long long u64;
 
@@ -242,10 +243,8 @@ __global__ __launch_bounds__(512) void k_reduce(
         a += part_ss[2 * i];
         b += part_ss[2 * i + 1];
       }
-      for (int off = 32; off > 0; off >>= 1) {
-        a += __shfl_xor(a, off, 64);
-        b += __shfl_xor(b, off, 64);
-      }
+      a = wave_sum(a);
+      b = wave_sum(b);
     }
     for (int i = threadIdx.x; i < 2 * world; i += 64) {
       long long v = 0;
@@ -323,14 +322,15 @@ __device__ __forceinline__ Best best_pick(Best a, Best b) {
 }
 
 __device__ __forceinline__ Best block_best(Best v, Best *sh) {
-  for (int off = 32; off > 0; off >>= 1) {
-    Best o;
-    o.score = __shfl_xor(v.score, off, 64);
-    o.t = __shfl_xor(v.t, off, 64);
-    v = best_pick(v, o);
-  }
+  // lanes are in slot order, so the first lane holding the wave maximum is the
+  // first maximum (rt.cc:285); scores are >= 0 or the -1 of "no valid slot"
+  const double m = wave_max(v.score);
+  const unsigned long long hit = __ballot(v.score == m && v.t != 0xFFFFFFFFu);
+  Best w;
+  w.score = hit ? m : -1.0;
+  w.t = hit ? (threadIdx.x & ~63u) + (uint32_t)__ffsll((long long)hit) - 1u : 0xFFFFFFFFu;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
   __syncthreads();
   Best r = sh[0];
   for (int i = 1; i < 4; ++i) r = best_pick(r, sh[i]);
@@ -398,14 +398,8 @@ __global__ __launch_bounds__(256) void k_scan(
   uint32_t cn = red_cnt[(size_t)(mybase + t * fw + col) * cs];
   // inclusive scan over the 256 slots (exact integers: any association)
   const int lane = t & 63, wave = t >> 6;
-  for (int off = 1; off < 64; off <<= 1) {
-    const long long os = __shfl_up(s, off, 64);
-    const uint32_t oc = __shfl_up(cn, off, 64);
-    if (lane >= off) {
-      s += os;
-      cn += oc;
-    }
-  }
+  s = wave_scan_i64(s);
+  cn = wave_scan_u32(cn);
   if (lane == 63) {
     sh_s[wave] = s;
     sh_c[wave] = cn;
@@ -486,15 +480,22 @@ __device__ qr_split_t wave_merge(const QrTreeState *ts, const int root_mode, con
     const qr_split_t r = featrec[(size_t)which * flocal + lf];
     if (r.score > best.score) best = r;  // ascending lf within the lane
   }
-  // butterfly: higher score wins, equal scores -> lower feature index
-  for (int off = 32; off > 0; off >>= 1) {
-    const double os = __shfl_xor(best.score, off, 64);
-    const uint32_t of = __shfl_xor(best.feature, off, 64);
-    const uint32_t ot = __shfl_xor(best.thr_id, off, 64);
-    if (os > best.score || (os == best.score && of < best.feature)) {
-      best.score = os;
-      best.feature = of;
-      best.thr_id = ot;
+  // max score over the wave, equal scores -> lowest feature index; the lane that
+  // holds the winner hands out its slot
+  {
+    const double m = wave_max(best.score);
+    const bool cand = best.score == m && best.feature != 0xFFFFFFFFu;
+    const uint32_t fmin = wave_min_u32(cand ? best.feature : 0xFFFFFFFFu);
+    const unsigned long long hit = __ballot(cand && best.feature == fmin);
+    if (hit) {
+      const int src = __ffsll((long long)hit) - 1;
+      best.score = m;
+      best.feature = fmin;
+      best.thr_id = (uint32_t)__builtin_amdgcn_readlane((int)best.thr_id, src);
+    } else {
+      best.score = -1.0;
+      best.feature = 0xFFFFFFFFu;
+      best.thr_id = 0xFFFFFFFFu;
     }
   }
   if (best.feature != 0xFFFFFFFFu) {
@@ -527,32 +528,45 @@ __global__ __launch_bounds__(128) void k_merge(
 // ===========================================================================
 // k_decide: the host logic of RegressionTree::fit, on one lane.
 // ===========================================================================
-__device__ void heap_push(QrTreeState *ts, double key, int32_t val) {
+// The control state the lane works on: header fields in registers, heap / nodes /
+// descriptor through pointers that lead either to LDS copies (small trees: every
+// access is an LDS access instead of a dependent L2 round trip) or straight to the
+// device-resident QrTreeState.
+struct DecideState {
+  int32_t nleaves_req, nnodes, taken, done, step, nsplits, heap_size;
+  uint32_t part_epoch;
+  QrHeapItem *heap;
+  QrNode *nodes;
+  QrSplitDesc *desc;
+  qr_split_t *split_log;
+};
+
+__device__ void heap_push(DecideState &st, double key, int32_t val) {
   // maxheap.h:58-68 (arr[0] is a DBL_MAX sentinel)
-  size_t p = (size_t)(++ts->heap_size);
-  while (key > ts->heap[p >> 1].key) {
-    ts->heap[p] = ts->heap[p >> 1];
+  size_t p = (size_t)(++st.heap_size);
+  while (key > st.heap[p >> 1].key) {
+    st.heap[p] = st.heap[p >> 1];
     p >>= 1;
   }
-  ts->heap[p].key = key;
-  ts->heap[p].val = val;
+  st.heap[p].key = key;
+  st.heap[p].val = val;
 }
 
-__device__ void heap_pop(QrTreeState *ts) {
+__device__ void heap_pop(DecideState &st) {
   // maxheap.h:71-84
-  const QrHeapItem last = ts->heap[ts->heap_size--];
+  const QrHeapItem last = st.heap[st.heap_size--];
   size_t child, p = 1;
-  const size_t size = (size_t)ts->heap_size;
+  const size_t size = (size_t)st.heap_size;
   while ((p << 1) <= size) {
     child = p << 1;
-    if (child < size && ts->heap[child + 1].key > ts->heap[child].key) ++child;
-    if (last.key < ts->heap[child].key)
-      ts->heap[p] = ts->heap[child];
+    if (child < size && st.heap[child + 1].key > st.heap[child].key) ++child;
+    if (last.key < st.heap[child].key)
+      st.heap[p] = st.heap[child];
     else
       break;
     p = child;
   }
-  ts->heap[p] = last;
+  st.heap[p] = last;
 }
 
 // RTNode(sampleids, hist): rtnode.h:97-107
@@ -593,14 +607,14 @@ __device__ bool node_splittable(const QrNode *nd) {
   return nd->deviance > 0.0 && nd->best_f != 0xFFFFFFFFu;
 }
 
-__device__ void make_desc(QrTreeState *ts, int node, const float *thr,
+__device__ void make_desc(DecideState &st, int node, const float *thr,
                           const int32_t *gf2lf) {
-  QrNode *nd = &ts->nodes[node];
-  QrSplitDesc *d = &ts->desc;
-  const int li = ts->nnodes, ri = ts->nnodes + 1;
-  ts->nnodes += 2;
+  QrNode *nd = &st.nodes[node];
+  QrSplitDesc *d = st.desc;
+  const int li = st.nnodes, ri = st.nnodes + 1;
+  st.nnodes += 2;
   d->active = 1;
-  ts->part_epoch++;
+  st.part_epoch++;
   d->node = node;
   d->left = li;
   d->right = ri;
@@ -626,7 +640,7 @@ __device__ void make_desc(QrTreeState *ts, int node, const float *thr,
   nd->threshold = thr[(size_t)nd->best_f * QR_MAX_BINS + nd->best_t];
   nd->left = li;
   nd->right = ri;
-  QrNode *L = &ts->nodes[li], *R = &ts->nodes[ri];
+  QrNode *L = &st.nodes[li], *R = &st.nodes[ri];
   L->begin = nd->begin;
   L->end = nd->begin + d->lcount;
   R->begin = L->end;
@@ -640,7 +654,7 @@ __device__ void make_desc(QrTreeState *ts, int node, const float *thr,
   L->left = L->right = R->left = R->right = -1;
   L->parent = R->parent = node;
   L->leaf_id = R->leaf_id = -1;
-  qr_split_t *lg = &ts->split_log[ts->nsplits++];
+  qr_split_t *lg = &st.split_log[st.nsplits++];
   lg->score = nd->best_score;
   lg->feature = nd->best_f;
   lg->thr_id = nd->best_t;
@@ -648,21 +662,62 @@ __device__ void make_desc(QrTreeState *ts, int node, const float *thr,
   lg->rcount = nd->best_rc;
 }
 
-__global__ __launch_bounds__(64) void k_decide(
-    QrTreeState *__restrict__ ts, const uint32_t N, const int flocal,
-    const long long *__restrict__ hsum, const qr_split_t *recs,
-    const int world, const QrScalars *__restrict__ scal,
-    const double *__restrict__ part_ss, const float *__restrict__ thr,
-    const int32_t *__restrict__ gf2lf, const qr_split_t *__restrict__ featrec,
-    const uint32_t *__restrict__ hcnt, const int docmode, const u64 Nglobal,
-    const long long *__restrict__ tail, const int dworld) {
+#define QR_DECIDE_LDS_NODES 96  /* trees of up to 47 leaves are staged in LDS */
+
+__device__ __forceinline__ void wave_copy8(void *dst, const void *src, size_t bytes) {
+  u64 *d = reinterpret_cast<u64 *>(dst);
+  const u64 *s_ = reinterpret_cast<const u64 *>(src);
+  for (size_t i = threadIdx.x; i < bytes / 8; i += 64) d[i] = s_[i];
+}
+
+// Runs on wave 0 of the calling workgroup; every thread must call it (barriers).
+__device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
+                            const qr_split_t *recs, const int world, const QrScalars *scal,
+                            const double *part_ss, const float *thr, const int32_t *gf2lf,
+                            const qr_split_t *featrec, const uint32_t *hcnt, const int docmode,
+                            const u64 Nglobal, const long long *tail, const int dworld) {
+  const bool w0 = threadIdx.x < 64;
   // single GPU (and document-sharded, where every rank scans every feature of
   // the all-reduced histogram): the merge over features happens here (no k_merge
   // launch, no exchange); feature-sharded: `recs` is the all-gathered buffer
   __shared__ qr_split_t own[2];
+  __shared__ QrNode sh_nodes[QR_DECIDE_LDS_NODES];
+  __shared__ QrHeapItem sh_heap[QR_DECIDE_LDS_NODES + 2];
+  __shared__ QrSplitDesc sh_desc;
+  static_assert(sizeof(QrNode) % 8 == 0 && sizeof(QrHeapItem) % 8 == 0 &&
+                    sizeof(QrSplitDesc) % 8 == 0,
+                "wave_copy8 moves 8-byte words");
+  DecideState st;
+  st.nleaves_req = ts->nleaves_req;
+  st.nnodes = ts->nnodes;
+  st.taken = ts->taken;
+  st.done = ts->done;
+  st.step = ts->step;
+  st.nsplits = ts->nsplits;
+  st.heap_size = ts->heap_size;
+  st.part_epoch = ts->part_epoch;
+  st.split_log = ts->split_log;
+  const int32_t active = ts->desc.active;
+  const int root_mode = st.step == 0;
+  // everything this step can touch: the live nodes + 2 new ones, the heap + 2
+  const bool staged = !root_mode && st.nnodes + 2 <= QR_DECIDE_LDS_NODES &&
+                      st.heap_size + 3 <= QR_DECIDE_LDS_NODES + 2;
+  if (staged && w0) {
+    wave_copy8(sh_nodes, ts->nodes, (size_t)st.nnodes * sizeof(QrNode));
+    wave_copy8(sh_heap, ts->heap, (size_t)(st.heap_size + 1) * sizeof(QrHeapItem));
+    wave_copy8(&sh_desc, &ts->desc, sizeof(QrSplitDesc));
+  }
+  if (staged) {
+    st.nodes = sh_nodes;
+    st.heap = sh_heap;
+    st.desc = &sh_desc;
+  } else {
+    st.nodes = ts->nodes;
+    st.heap = ts->heap;
+    st.desc = &ts->desc;
+  }
   if (world == 1) {
-    const int root_mode = ts->step == 0;
-    if (root_mode || ts->desc.active) {
+    if (w0 && (root_mode || active)) {
       const qr_split_t a = wave_merge(ts, root_mode, 0, featrec, flocal, hcnt, gf2lf);
       const qr_split_t b = wave_merge(ts, root_mode, 1, featrec, flocal, hcnt, gf2lf);
       if (threadIdx.x == 0) {
@@ -670,7 +725,6 @@ __global__ __launch_bounds__(64) void k_decide(
         own[1] = b;
       }
     }
-    __syncthreads();
     recs = own;
   }
   // squares_sum_ / sum of the directly built child: fixed-order reduction of the
@@ -679,109 +733,136 @@ __global__ __launch_bounds__(64) void k_decide(
   if (docmode) {
     // per-rank partials gathered by the histogram all-reduce, summed in rank
     // order: every rank computes the same bits
-    if (ts->step != 0 && ts->desc.active)
+    if (!root_mode && active)
       for (int r = 0; r < dworld; ++r) {
         ss_small += __longlong_as_double(tail[2 * r]);
         sum_small += __longlong_as_double(tail[2 * r + 1]);
       }
-  } else if (ts->step != 0 && ts->desc.active) {
+  } else if (w0 && !root_mode && active) {
     const uint32_t nwg = (ts->desc.end - ts->desc.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
     for (uint32_t i = threadIdx.x; i < nwg; i += 64) {
       ss_small += part_ss[2 * i];
       sum_small += part_ss[2 * i + 1];
     }
-    for (int off = 32; off > 0; off >>= 1) {
-      ss_small += __shfl_xor(ss_small, off, 64);
-      sum_small += __shfl_xor(sum_small, off, 64);
+    ss_small = wave_sum(ss_small);
+    sum_small = wave_sum(sum_small);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (root_mode) {
+      QrNode *root = &st.nodes[0];
+      root->begin = 0;
+      root->end = N;
+      root->buf = 2;
+      root->hslot = 0;
+      root->feature = -1;
+      root->thr_id = -1;
+      root->threshold = 0.f;
+      root->left = root->right = root->parent = -1;
+      root->leaf_id = -1;
+      node_stats(root, scal->root_sum, scal->root_ss, docmode ? Nglobal : (u64)N);
+      node_set_best(root, recs, world, 0);
+      st.nnodes = 1;
+      st.heap_size = 0;
+      st.heap[0].key = 1.7976931348623157e308;  // DBL_MAX sentinel
+      st.heap[0].val = -1;
+      st.taken = 0;
+      st.done = 0;
+      st.nsplits = 0;
+      st.desc->active = 0;
+      if (node_splittable(root))
+        make_desc(st, 0, thr, gf2lf);
+      else
+        st.done = 1;
+      st.step = 1;
+    } else {
+      if (active) {
+        // children of the split just applied
+        const QrSplitDesc d = *st.desc;
+        QrNode *P = &st.nodes[d.node];
+        QrNode *S = &st.nodes[d.small_node], *B = &st.nodes[d.big_node];
+        // directly accumulated child, sibling by subtraction
+        // (rtnode_histogram.cc:65-69, 79-86)
+        node_stats(S, sum_small, ss_small, d.small_n);
+        node_stats(B, P->sum - sum_small, P->ss - ss_small, P->count - d.small_n);
+        if (docmode) {
+          // the children's local segments: known only after the local partition
+          QrNode *L = &st.nodes[d.left], *R = &st.nodes[d.right];
+          L->end = R->begin = P->begin + ts->loc.lcount;
+        }
+        node_set_best(&st.nodes[d.left], recs, world, 0);
+        node_set_best(&st.nodes[d.right], recs, world, 1);
+        heap_push(st, st.nodes[d.left].deviance, d.left);    // rt.cc:76-77
+        heap_push(st, st.nodes[d.right].deviance, d.right);
+        st.desc->active = 0;
+      }
+      st.step++;
+      if (!st.done) {
+        bool found = false;
+        while (st.heap_size > 0 &&
+               (st.nleaves_req == 0 || st.taken + st.heap_size < st.nleaves_req)) {
+          const int node = st.heap[1].val;
+          heap_pop(st);
+          if (node_splittable(&st.nodes[node])) {
+            make_desc(st, node, thr, gf2lf);
+            found = true;
+            break;
+          }
+          ++st.taken;
+        }
+        if (!found) st.done = 1;
+      }
+    }
+    ts->nnodes = st.nnodes;
+    ts->taken = st.taken;
+    ts->done = st.done;
+    ts->step = st.step;
+    ts->nsplits = st.nsplits;
+    ts->heap_size = st.heap_size;
+    ts->part_epoch = st.part_epoch;
+    own[0].feature = (uint32_t)st.nnodes;    // broadcast the new extents for the copy-back
+    own[0].thr_id = (uint32_t)st.heap_size;
+  }
+  if (staged) {
+    __syncthreads();
+    if (w0) {
+      const size_t nn = own[0].feature, hs = own[0].thr_id;
+      wave_copy8(ts->nodes, sh_nodes, nn * sizeof(QrNode));
+      wave_copy8(ts->heap, sh_heap, (hs + 1) * sizeof(QrHeapItem));
+      wave_copy8(&ts->desc, &sh_desc, sizeof(QrSplitDesc));
     }
   }
-  if (threadIdx.x != 0) return;
-  if (ts->step == 0) {
-    QrNode *root = &ts->nodes[0];
-    root->begin = 0;
-    root->end = N;
-    root->buf = 2;
-    root->hslot = 0;
-    root->feature = -1;
-    root->thr_id = -1;
-    root->threshold = 0.f;
-    root->left = root->right = root->parent = -1;
-    root->leaf_id = -1;
-    node_stats(root, scal->root_sum, scal->root_ss, docmode ? Nglobal : (u64)N);
-    node_set_best(root, recs, world, 0);
-    ts->nnodes = 1;
-    ts->heap_size = 0;
-    ts->heap[0].key = 1.7976931348623157e308;  // DBL_MAX sentinel
-    ts->heap[0].val = -1;
-    ts->taken = 0;
-    ts->done = 0;
-    ts->nsplits = 0;
-    ts->desc.active = 0;
-    if (node_splittable(root))
-      make_desc(ts, 0, thr, gf2lf);
-    else
-      ts->done = 1;
-    ts->step = 1;
-    return;
-  }
-  if (ts->desc.active) {
-    // children of the split just applied
-    const QrSplitDesc d = ts->desc;
-    QrNode *P = &ts->nodes[d.node];
-    QrNode *S = &ts->nodes[d.small_node], *B = &ts->nodes[d.big_node];
-    // directly accumulated child, sibling by subtraction
-    // (rtnode_histogram.cc:65-69, 79-86)
-    node_stats(S, sum_small, ss_small, d.small_n);
-    node_stats(B, P->sum - sum_small, P->ss - ss_small, P->count - d.small_n);
-    if (docmode) {
-      // the children's local segments: known only after the local partition
-      QrNode *L = &ts->nodes[d.left], *R = &ts->nodes[d.right];
-      L->end = R->begin = P->begin + ts->loc.lcount;
-    }
-    node_set_best(&ts->nodes[d.left], recs, world, 0);
-    node_set_best(&ts->nodes[d.right], recs, world, 1);
-    heap_push(ts, ts->nodes[d.left].deviance, d.left);    // rt.cc:76-77
-    heap_push(ts, ts->nodes[d.right].deviance, d.right);
-    ts->desc.active = 0;
-  }
-  ts->step++;
-  if (ts->done) return;
-  bool found = false;
-  while (ts->heap_size > 0 &&
-         (ts->nleaves_req == 0 || ts->taken + ts->heap_size < ts->nleaves_req)) {
-    const int node = ts->heap[1].val;
-    heap_pop(ts);
-    if (node_splittable(&ts->nodes[node])) {
-      make_desc(ts, node, thr, gf2lf);
-      found = true;
-      break;
-    }
-    ++ts->taken;
-  }
-  if (!found) ts->done = 1;
+}
+
+__global__ __launch_bounds__(64) void k_decide(
+    QrTreeState *ts, const uint32_t N, const int flocal, const qr_split_t *recs,
+    const int world, const QrScalars *__restrict__ scal,
+    const double *__restrict__ part_ss, const float *__restrict__ thr,
+    const int32_t *__restrict__ gf2lf, const qr_split_t *__restrict__ featrec,
+    const uint32_t *__restrict__ hcnt, const int docmode, const u64 Nglobal,
+    const long long *__restrict__ tail, const int dworld) {
+  decide_body(ts, N, flocal, recs, world, scal, part_ss, thr, gf2lf, featrec, hcnt, docmode,
+              Nglobal, tail, dworld);
 }
 
 // ===========================================================================
 // Partition (rt.cc:325-334): stable, x <= threshold  <=>  bin <= thr_id.
 // ===========================================================================
 __device__ __forceinline__ bool go_left(const QrSplitDesc &d, uint32_t p, uint32_t id,
-                                        const QrBlock *blocks, int nblocks,
-                                        const uint8_t *bins, const uint32_t *mask,
-                                        int use_mask) {
+                                        const uint8_t *fm, uint32_t N,
+                                        const uint32_t *mask, int use_mask) {
   if (use_mask) return (mask[p >> 5] >> (p & 31)) & 1u;
-  const int lf = d.owner_local;
-  int b = 0;
-  for (int i = 0; i < nblocks; ++i)
-    if (lf >= blocks[i].lf0 && lf < blocks[i].lf0 + blocks[i].nreal) b = i;
-  const uint8_t v = bins[blocks[b].off + (size_t)id * blocks[b].fw + (lf - blocks[b].lf0)];
-  return v <= d.thr_id;
+  // feature-major copy of the bins: one byte per document, 32 neighbouring
+  // documents per 32-byte sector (the block-row layout costs a 64-byte sector per
+  // document here)
+  return fm[(size_t)d.owner_local * N + id] <= d.thr_id;
 }
 
 // multi-GPU: the owner of the winning feature publishes the go-left bits of the
 // node's positions; everybody else contributes zeros to the bitwise-or/sum.
 __global__ __launch_bounds__(256) void k_mask(
-    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks,
-    const int nblocks, const uint8_t *__restrict__ bins,
+    const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm,
+    const uint32_t Nfm,
     const uint32_t *__restrict__ order0, const uint32_t *__restrict__ order1,
     uint32_t *__restrict__ mask, const uint32_t mask_words) {
   const QrSplitDesc d = ts->desc;
@@ -795,7 +876,7 @@ __global__ __launch_bounds__(256) void k_mask(
       const uint32_t p = w * 32 + k;
       if (p < n) {
         const uint32_t id = d.src_buf == 2 ? d.begin + p : order[d.begin + p];
-        if (go_left(d, p, id, blocks, nblocks, bins, nullptr, 0)) bits |= 1u << k;
+        if (go_left(d, p, id, fm, Nfm, nullptr, 0)) bits |= 1u << k;
       }
     }
   }
@@ -803,7 +884,8 @@ __global__ __launch_bounds__(256) void k_mask(
 }
 
 __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *sh) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v = wave_scan_u32(v);
+  v = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -813,8 +895,8 @@ __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *sh) {
 #define PART_PER_THREAD (QR_PART_SLICE / 256)
 
 __global__ __launch_bounds__(256) void k_part_count(
-    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks,
-    const int nblocks, const uint8_t *__restrict__ bins,
+    const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm,
+    const uint32_t Nfm,
     const uint32_t *__restrict__ order0, const uint32_t *__restrict__ order1,
     const uint32_t *__restrict__ mask, const int use_mask,
     uint32_t *__restrict__ blkcnt) {
@@ -830,7 +912,7 @@ __global__ __launch_bounds__(256) void k_part_count(
     const uint32_t p = base + threadIdx.x * PART_PER_THREAD + k;
     if (p < n) {
       const uint32_t id = d.src_buf == 2 ? d.begin + p : order[d.begin + p];
-      cnt += go_left(d, p, id, blocks, nblocks, bins, mask, use_mask) ? 1u : 0u;
+      cnt += go_left(d, p, id, fm, Nfm, mask, use_mask) ? 1u : 0u;
     }
   }
   const uint32_t tot = block_sum_u32(cnt, sh);
@@ -838,8 +920,8 @@ __global__ __launch_bounds__(256) void k_part_count(
 }
 
 __global__ __launch_bounds__(256) void k_part_scatter(
-    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks,
-    const int nblocks, const uint8_t *__restrict__ bins,
+    const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm,
+    const uint32_t Nfm,
     uint32_t *__restrict__ order0, uint32_t *__restrict__ order1,
     const uint32_t *__restrict__ mask, const int use_mask,
     const uint32_t *__restrict__ blkcnt, const double *__restrict__ lambda,
@@ -880,17 +962,13 @@ __global__ __launch_bounds__(256) void k_part_scatter(
     ids[k] = 0;
     if (p < n) {
       ids[k] = d.src_buf == 2 ? d.begin + p : src[d.begin + p];
-      fl[k] = go_left(d, p, ids[k], blocks, nblocks, bins, mask, use_mask);
+      fl[k] = go_left(d, p, ids[k], fm, Nfm, mask, use_mask);
       cnt += fl[k] ? 1u : 0u;
     }
   }
   // exclusive scan of cnt over the 256 threads
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = cnt;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t o = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += o;
-  }
+  const uint32_t inc = wave_scan_u32(cnt);
   __syncthreads();
   if (lane == 63) wave_off[wave] = inc;
   __syncthreads();
@@ -919,10 +997,8 @@ __global__ __launch_bounds__(256) void k_part_scatter(
   }
   // squares_sum_ of the directly built child (rtnode_histogram.cc:65-69),
   // fixed reduction tree
-  for (int off = 32; off > 0; off >>= 1) {
-    sq += __shfl_xor(sq, off, 64);
-    sm += __shfl_xor(sm, off, 64);
-  }
+  sq = wave_sum(sq);
+  sm = wave_sum(sm);
   __syncthreads();
   if (lane == 0) {
     shd[wave] = sq;
@@ -944,8 +1020,8 @@ __global__ __launch_bounds__(256) void k_part_scatter(
 // The epoch increases with every split of the context's lifetime, so the granule
 // array never needs clearing.
 __global__ __launch_bounds__(256) void k_partition(
-    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks,
-    const int nblocks, const uint8_t *__restrict__ bins,
+    const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm,
+    const uint32_t Nfm,
     uint32_t *__restrict__ order0, uint32_t *__restrict__ order1,
     const uint32_t *__restrict__ mask, const int use_mask,
     u64 *__restrict__ state, const double *__restrict__ lambda,
@@ -970,17 +1046,13 @@ __global__ __launch_bounds__(256) void k_partition(
     ids[k] = 0;
     if (p < n) {
       ids[k] = d.src_buf == 2 ? d.begin + p : src[d.begin + p];
-      fl[k] = go_left(d, p, ids[k], blocks, nblocks, bins, mask, use_mask);
+      fl[k] = go_left(d, p, ids[k], fm, Nfm, mask, use_mask);
       cnt += fl[k] ? 1u : 0u;
     }
   }
   // intra-workgroup inclusive scan of cnt
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = cnt;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t o = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += o;
-  }
+  const uint32_t inc = wave_scan_u32(cnt);
   if (lane == 63) wave_off[wave] = inc;
   __syncthreads();
   uint32_t woff = 0;
@@ -1021,10 +1093,8 @@ __global__ __launch_bounds__(256) void k_partition(
       }
     }
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    sq += __shfl_xor(sq, off, 64);
-    sm += __shfl_xor(sm, off, 64);
-  }
+  sq = wave_sum(sq);
+  sm = wave_sum(sm);
   __syncthreads();
   if (lane == 0) {
     shd[wave] = sq;
@@ -1112,10 +1182,8 @@ __global__ __launch_bounds__(256) void k_leaf_sums(
         a += v1[k];
         b += v2[k];
       }
-    for (int off = 32; off > 0; off >>= 1) {
-      a += __shfl_xor(a, off, 64);
-      b += __shfl_xor(b, off, 64);
-    }
+    a = wave_sum(a);
+    b = wave_sum(b);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
       sh1[threadIdx.x >> 6] = a;
@@ -1130,13 +1198,34 @@ __global__ __launch_bounds__(256) void k_leaf_sums(
   }
 }
 
+// compact records of the finished tree (what crosses the C-ABI), written by the
+// whole workgroup once the leaf values are in place
+__device__ __forceinline__ void nodes_out_write(const QrTreeState *ts, QrNodesOut *out) {
+  const int nn = ts->nnodes;
+  for (int i = threadIdx.x; i < nn; i += blockDim.x) {
+    const QrNode &s = ts->nodes[i];
+    qr_node_t d;
+    d.feature = s.feature;
+    d.thr_id = s.thr_id;
+    d.threshold = s.threshold;
+    d.left = s.left;
+    d.right = s.right;
+    d.value = s.value;
+    d.deviance = s.deviance;
+    d.nsamples = s.count;
+    out->nodes[i] = d;
+  }
+  if (threadIdx.x == 0) out->nnodes = nn;
+}
+
 // rt.cc:165-207
 __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ ts,
                                                      const double *__restrict__ leafpart,
                                                      const int newton, const int docmode,
                                                      long long *__restrict__ xleaf,
                                                      const int rank, const int world,
-                                                     const int stride) {
+                                                     const int stride,
+                                                     QrNodesOut *__restrict__ nodes_out) {
   const int nl = ts->nleaves;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (docmode) {  // own slot <- local sums, zeros elsewhere (all-reduce == all-gather)
@@ -1153,10 +1242,8 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
         s2 += leafpart[2 * ((size_t)s + l) + 1];
       }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-      s1 += __shfl_xor(s1, off, 64);
-      s2 += __shfl_xor(s2, off, 64);
-    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
     if (lane == 0) {
       if (docmode) {
         xleaf[(size_t)rank * stride + 2 * l] = __double_as_longlong(s1);
@@ -1172,6 +1259,9 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
       ts->nodes[ts->leaf_nodes[l]].value = v;
     }
   }
+  if (docmode) return;  // k_leaf_global writes the records after the exchange
+  __syncthreads();
+  nodes_out_write(ts, nodes_out);
 }
 
 // document-sharded: leaf outputs from the gathered per-rank sums, added in rank
@@ -1179,7 +1269,8 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
 __global__ __launch_bounds__(1024) void k_leaf_global(QrTreeState *__restrict__ ts,
                                                       const long long *__restrict__ xleaf,
                                                       const int newton, const int world,
-                                                      const int stride) {
+                                                      const int stride,
+                                                      QrNodesOut *__restrict__ nodes_out) {
   const int nl = ts->nleaves;
   for (int l = threadIdx.x; l < nl; l += 1024) {
     double s1 = 0.0, s2 = 0.0;
@@ -1196,6 +1287,8 @@ __global__ __launch_bounds__(1024) void k_leaf_global(QrTreeState *__restrict__ 
     ts->leaf_value[l] = v;
     ts->nodes[ts->leaf_nodes[l]].value = v;
   }
+  __syncthreads();
+  nodes_out_write(ts, nodes_out);
 }
 
 // mart.cc:459-468 through the leaf membership instead of a tree walk:
@@ -1542,8 +1635,11 @@ int qr_k_tree_decide(qr_ctx *c) {
     int rc = launch_scan(c, c->tree_step == 0);
     if (rc) return rc;
   }
+  // (Letting k_scan's last workgroup take the decision saves this launch but was
+  // measured slower: the agent-scope release/acquire it needs writes back and
+  // invalidates the XCD L2s, 22.8 us for the fused kernel against 6 + 9 us.)
   hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_tree,
-                     (uint32_t)c->N, c->flocal, c->d_hsum, recs, fshard ? c->world : 1,
+                     (uint32_t)c->N, c->flocal, recs, fshard ? c->world : 1,
                      c->d_scalars, c->d_part_ss, c->d_thr, c->d_gf2lf, c->d_featrec,
                      c->d_hcnt, c->dmode, (u64)c->Nglobal,
                      c->dmode ? c->d_xh + 2 * c->xh_cells : (const long long *)nullptr,
@@ -1553,7 +1649,7 @@ int qr_k_tree_decide(qr_ctx *c) {
   if (fshard) {
     const unsigned grid = (unsigned)((c->mask_words + 255) / 256);
     hipLaunchKernelGGL(k_mask, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
+                       c->d_bins_fm, (uint32_t)c->N, c->d_order[0],
                        c->d_order[1], c->d_mask, (uint32_t)c->mask_words);
     QR_CHECK(c, hipGetLastError());
   }
@@ -1566,18 +1662,18 @@ int qr_k_tree_apply(qr_ctx *c) {
   if (c->dmode) {
     // the local left count is not in the (global) histogram: count, then scatter
     hipLaunchKernelGGL(k_part_count, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_order[1],
+                       c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
                        c->d_mask, 0, c->d_blkcnt);
     QR_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(k_part_scatter, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_order[1],
+                       c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
                        c->d_mask, 0, c->d_blkcnt, c->d_lambda, c->d_part_ss,
                        &c->d_tree->loc);
     QR_CHECK(c, hipGetLastError());
     return launch_hist_scan(c, 0);
   }
   hipLaunchKernelGGL(k_partition, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
-                     c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_order[1],
+                     c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
                      c->d_mask, use_mask, (u64 *)c->d_part_state, c->d_lambda, c->d_part_ss);
   QR_CHECK(c, hipGetLastError());
   return launch_hist_scan(c, 0);
@@ -1588,7 +1684,7 @@ static int launch_partition(qr_ctx *c) {
   const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
   const int use_mask = c->world > 1;
   hipLaunchKernelGGL(k_partition, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
-                     c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_order[1],
+                     c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
                      c->d_mask, use_mask, (u64 *)c->d_part_state, c->d_lambda, c->d_part_ss);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
@@ -1631,14 +1727,14 @@ int qr_k_tree_finish(qr_ctx *c, int newton) {
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_leaf_final, dim3(1), dim3(1024), 0, c->stream, c->d_tree,
                      c->d_leafpart, newton, c->dmode, c->d_xleaf, c->rank, c->world,
-                     (int)(2 * c->cur_nleaves));
+                     (int)(2 * c->cur_nleaves), c->d_nodes_out);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
 
 int qr_k_tree_leaves_global(qr_ctx *c, int newton) {
   hipLaunchKernelGGL(k_leaf_global, dim3(1), dim3(1024), 0, c->stream, c->d_tree,
-                     c->d_xleaf, newton, c->world, (int)(2 * c->cur_nleaves));
+                     c->d_xleaf, newton, c->world, (int)(2 * c->cur_nleaves), c->d_nodes_out);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

@@ -25,6 +25,8 @@ static void dfree(T *&p) {
 
 extern "C" {
 
+void qr_ctx_destroy(qr_ctx *c);
+
 int qr_ctx_create(int device, qr_ctx **out) {
   if (out) *out = nullptr;
   int ndev = 0;
@@ -59,6 +61,15 @@ int qr_ctx_create(int device, qr_ctx **out) {
     return QR_ERR_HIP;
   }
   (void)hipMemset(c->d_scalars, 0, sizeof(QrScalars));
+  if (hipHostMalloc((void **)&c->h_pin, sizeof(QrPinned), hipHostMallocDefault) != hipSuccess ||
+      dalloc(&c->d_nodes_out, 1) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_scal, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_nodes, hipEventDisableTiming) != hipSuccess) {
+    qr_ctx_destroy(c);
+    g_create_err = "allocating the read-back buffers failed";
+    return QR_ERR_HIP;
+  }
+  memset(c->h_pin, 0, sizeof(QrPinned));
   *out = c;
   return QR_OK;
 }
@@ -67,7 +78,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_raw); dfree(c->d_labels); dfree(c->d_qoff);
   dfree(c->d_scores); dfree(c->d_lambda); dfree(c->d_weight);
   dfree(c->d_idcg); dfree(c->d_qmetric); dfree(c->d_ranks); dfree(c->d_ssq);
-  dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins);
+  dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins); dfree(c->d_bins_fm);
   dfree(c->d_thr); dfree(c->d_thr_size);
   dfree(c->d_order[0]); dfree(c->d_order[1]); dfree(c->d_partials);
   if (c->d_xh) {  // document-sharded: the reduced histogram lives in the exchange buffer
@@ -97,6 +108,10 @@ void qr_ctx_destroy(qr_ctx *c) {
   free_train(c);
   free_valid(c);
   dfree(c->d_lg2); dfree(c->d_ilg2); dfree(c->d_scalars); dfree(c->d_ens); dfree(c->d_ens_w);
+  dfree(c->d_nodes_out);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->ev_scal) (void)hipEventDestroy(c->ev_scal);
+  if (c->ev_nodes) (void)hipEventDestroy(c->ev_nodes);
   dfree(c->d_keys); dfree(c->d_tied);
   dfree(c->d_obl_feat); dfree(c->d_obl_thr); dfree(c->d_obl_leaves); dfree(c->d_obl_w);
   dfree(c->d_obl_depths);
@@ -403,6 +418,7 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, hipMemcpy(c->d_thr_size, c->h_thr_size.data(), F * 4, hipMemcpyHostToDevice));
   // ---- bin map
   QR_CHECK(c, dalloc(&c->d_bins, c->bins_bytes));
+  QR_CHECK(c, dalloc(&c->d_bins_fm, (size_t)c->flocal * N));
   QR_CHECK(c, dalloc(&c->d_blocks, (size_t)c->nblocks));
   QR_CHECK(c, hipMemcpy(c->d_blocks, c->blocks.data(), c->nblocks * sizeof(QrBlock), hipMemcpyHostToDevice));
   QR_CHECK(c, dalloc(&c->d_lf2gf, (size_t)c->flocal));
@@ -592,7 +608,7 @@ int qr_pseudo_set(qr_ctx *c, const double *l, const double *w) {
   memcpy(&s.maxabs_bits, &mx, 8);
   QR_CHECK(c, hipMemcpy(c->d_scalars, &s, sizeof(s), hipMemcpyHostToDevice));
   QR_CHECK(c, hipMemcpy(c->d_ssq, ssq.data(), 2 * ns * 8, hipMemcpyHostToDevice));
-  int rc = qr_k_prep(c, ns);
+  int rc = qr_k_prep(c, ns, 0);
   if (rc || !c->dmode) return rc;
   return qr_k_prep_pack(c);  // then: all-reduce the scalar buffer, qr_lambda_finish
 }
@@ -634,6 +650,16 @@ static int ensure_idcg(qr_ctx *c, int which, int metric, size_t cutoff) {
   return QR_OK;
 }
 
+// snapshot of the per-iteration scalars into pinned host memory, stream-ordered:
+// qr_metric_last waits for this event only, not for the work enqueued after it
+static int snapshot_scalars(qr_ctx *c) {
+  QR_CHECK(c, hipMemcpyAsync(&c->h_pin->scal, c->d_scalars, sizeof(QrScalars),
+                             hipMemcpyDeviceToHost, c->stream));
+  QR_CHECK(c, hipEventRecord(c->ev_scal, c->stream));
+  c->scal_pending = true;
+  return QR_OK;
+}
+
 int qr_lambda_compute(qr_ctx *c, int metric, size_t cutoff) {
   if (!c) return QR_ERR_ARG;
   if (!c->d_scores) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
@@ -641,11 +667,11 @@ int qr_lambda_compute(qr_ctx *c, int metric, size_t cutoff) {
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "metric must be DCG or NDCG");
   int rc = ensure_idcg(c, 0, metric, cutoff);
   if (rc) return rc;
-  QR_CHECK(c, hipMemsetAsync(&c->d_scalars->maxabs_bits, 0, 8, c->stream));
   rc = qr_k_lambda(c, 0, metric, cutoff, 0);
   if (rc) return rc;
-  if ((rc = qr_k_prep(c, c->Q)) || !c->dmode) return rc;
-  if ((rc = qr_k_metric_reduce(c, 0))) return rc;
+  // sum of squares / sum / quantisation scale and the metric of the ranking, one launch
+  if ((rc = qr_k_prep(c, c->Q, 1))) return rc;
+  if (!c->dmode) return snapshot_scalars(c);
   return qr_k_prep_pack(c);  // then: all-reduce the scalar buffer, qr_lambda_finish
 }
 
@@ -653,16 +679,17 @@ int qr_lambda_finish(qr_ctx *c) {
   if (!c) return QR_ERR_ARG;
   if (!c->dmode) QR_FAIL(c, QR_ERR_STATE, "qr_lambda_finish is for document-sharded contexts");
   if (!c->d_xscal) QR_FAIL(c, QR_ERR_STATE, "bins not built");
-  return qr_k_prep_global(c);
+  int rc = qr_k_prep_global(c);
+  if (rc) return rc;
+  return snapshot_scalars(c);
 }
 
 int qr_residual_compute(qr_ctx *c) {
   if (!c) return QR_ERR_ARG;
   if (!c->d_scores) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
-  QR_CHECK(c, hipMemsetAsync(&c->d_scalars->maxabs_bits, 0, 8, c->stream));
   int rc = qr_k_residual(c);
   if (rc) return rc;
-  if ((rc = qr_k_prep(c, (c->N + QR_SLICE - 1) / QR_SLICE)) || !c->dmode) return rc;
+  if ((rc = qr_k_prep(c, (c->N + QR_SLICE - 1) / QR_SLICE, 0)) || !c->dmode) return rc;
   return qr_k_prep_pack(c);
 }
 
@@ -690,14 +717,17 @@ int qr_metric_eval(qr_ctx *c, int which, int metric, size_t cutoff, double *out)
 
 int qr_metric_last(qr_ctx *c, double *out) {
   if (!c || !out) return QR_ERR_ARG;
-  if (c->dmode) {  // the sum over all ranks came with the scalar exchange
-    QrScalars s;
-    QR_CHECK(c, hipStreamSynchronize(c->stream));
-    QR_CHECK(c, hipMemcpy(&s, c->d_scalars, sizeof(s), hipMemcpyDeviceToHost));
+  if (!c->scal_pending)
+    QR_FAIL(c, QR_ERR_STATE, "qr_metric_last follows qr_lambda_compute (+ qr_lambda_finish)");
+  // waits for the lambda pass only; whatever was enqueued after it keeps running
+  QR_CHECK(c, hipEventSynchronize(c->ev_scal));
+  const QrScalars &s = c->h_pin->scal;
+  // metric.h:93-105: avg_score /= num_queries (0 queries -> 0.0)
+  if (c->dmode)  // the sum over all ranks came with the scalar exchange
     *out = c->Qglobal ? s.metric_gsum / (double)c->Qglobal : 0.0;
-    return QR_OK;
-  }
-  return metric_finish(c, 0, out);
+  else
+    *out = c->Q ? s.metric_sum / (double)c->Q : 0.0;
+  return QR_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -710,22 +740,6 @@ static int ensure_hist_slots(qr_ctx *c, size_t slots) {
   QR_CHECK(c, dalloc(&c->d_hcnt, slots * c->flocal * 256));
   c->hist_slots = slots;
   return QR_OK;
-}
-
-static void copy_nodes(const QrTreeState &ts, qr_node_t *out, size_t *n_out) {
-  for (int i = 0; i < ts.nnodes; ++i) {
-    const QrNode &s = ts.nodes[i];
-    qr_node_t &d = out[i];
-    d.feature = s.feature;
-    d.thr_id = s.thr_id;
-    d.threshold = s.threshold;
-    d.left = s.left;
-    d.right = s.right;
-    d.value = s.value;
-    d.deviance = s.deviance;
-    d.nsamples = s.count;
-  }
-  if (n_out) *n_out = (size_t)ts.nnodes;
 }
 
 int qr_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
@@ -743,6 +757,7 @@ int qr_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
     QR_CHECK(c, hipMemset(c->d_xleaf, 0, c->xleaf_cap * 8));
   }
   c->cur_nleaves = nleaves;
+  c->cur_maxnodes = 2 * nleaves + 1;
   c->tree_open = true;
   c->tree_valid = false;
   return qr_k_tree_begin(c, nleaves, minls);
@@ -758,6 +773,27 @@ int qr_tree_apply(qr_ctx *c) {
   return qr_k_tree_apply(c);
 }
 
+// the finished tree's compact records travel to pinned host memory behind the
+// kernels that produced them; qr_tree_nodes waits for that copy only
+static int snapshot_nodes(qr_ctx *c) {
+  const size_t bytes = offsetof(QrNodesOut, nodes) + c->cur_maxnodes * sizeof(qr_node_t);
+  QR_CHECK(c, hipMemcpyAsync(&c->h_pin->tree, c->d_nodes_out, bytes, hipMemcpyDeviceToHost,
+                             c->stream));
+  QR_CHECK(c, hipEventRecord(c->ev_nodes, c->stream));
+  c->nodes_pending = true;
+  return QR_OK;
+}
+
+int qr_tree_nodes(qr_ctx *c, qr_node_t *nodes_out, size_t *nnodes_out) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->nodes_pending) QR_FAIL(c, QR_ERR_STATE, "no fitted tree");
+  QR_CHECK(c, hipEventSynchronize(c->ev_nodes));
+  const size_t n = (size_t)c->h_pin->tree.nnodes;
+  if (nodes_out) memcpy(nodes_out, c->h_pin->tree.nodes, n * sizeof(qr_node_t));
+  if (nnodes_out) *nnodes_out = n;
+  return QR_OK;
+}
+
 int qr_tree_end(qr_ctx *c, int newton, qr_node_t *nodes_out, size_t *nnodes_out) {
   if (!c || !c->tree_open) return QR_ERR_STATE;
   int rc = qr_k_tree_finish(c, newton);
@@ -765,12 +801,8 @@ int qr_tree_end(qr_ctx *c, int newton, qr_node_t *nodes_out, size_t *nnodes_out)
   c->tree_open = false;
   if (c->dmode) return QR_OK;  // all-reduce the leaf buffer, then qr_tree_leaves_finish
   c->tree_valid = true;
-  if (nodes_out) {
-    std::vector<char> buf(sizeof(QrTreeState));
-    QR_CHECK(c, hipStreamSynchronize(c->stream));
-    QR_CHECK(c, hipMemcpy(buf.data(), c->d_tree, offsetof(QrTreeState, split_log), hipMemcpyDeviceToHost));
-    copy_nodes(*reinterpret_cast<QrTreeState *>(buf.data()), nodes_out, nnodes_out);
-  }
+  if ((rc = snapshot_nodes(c))) return rc;
+  if (nodes_out || nnodes_out) return qr_tree_nodes(c, nodes_out, nnodes_out);
   return QR_OK;
 }
 
@@ -781,12 +813,8 @@ int qr_tree_leaves_finish(qr_ctx *c, int newton, qr_node_t *nodes_out, size_t *n
   int rc = qr_k_tree_leaves_global(c, newton);
   if (rc) return rc;
   c->tree_valid = true;
-  if (nodes_out) {
-    std::vector<char> buf(sizeof(QrTreeState));
-    QR_CHECK(c, hipStreamSynchronize(c->stream));
-    QR_CHECK(c, hipMemcpy(buf.data(), c->d_tree, offsetof(QrTreeState, split_log), hipMemcpyDeviceToHost));
-    copy_nodes(*reinterpret_cast<QrTreeState *>(buf.data()), nodes_out, nnodes_out);
-  }
+  if ((rc = snapshot_nodes(c))) return rc;
+  if (nodes_out || nnodes_out) return qr_tree_nodes(c, nodes_out, nnodes_out);
   return QR_OK;
 }
 
@@ -819,6 +847,7 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
   if (rc) return rc;
   c->tree_valid = false;
   c->tree_open = true;
+  c->cur_maxnodes = ((size_t)1 << (depth + 1)) - 1;
   if ((rc = qr_k_oblivious_fit(c, depth, minls))) return rc;
   return qr_tree_end(c, newton, nodes_out, nnodes_out);
 }

@@ -157,6 +157,18 @@ struct QrScalars {
   double metric_gsum;              // document-sharded: the same over all ranks
 };
 
+// Host-pinned landing zone of the per-iteration read-backs (async copies + events:
+// the host never has to drain the stream to learn a metric or a tree).
+struct QrNodesOut {
+  int64_t nnodes;
+  int64_t pad[7];
+  qr_node_t nodes[QR_MAXNODES];
+};
+struct QrPinned {
+  QrScalars scal;
+  QrNodesOut tree;
+};
+
 struct qr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -196,6 +208,7 @@ struct qr_ctx {
   std::vector<int32_t> h_gf2lf, h_lf2gf;
   uint8_t *d_bins = nullptr;
   size_t bins_bytes = 0;
+  uint8_t *d_bins_fm = nullptr;  // feature-major copy [flocal][N] for the partition
   float *d_thr = nullptr;        // [F][256]
   uint32_t *d_thr_size = nullptr;
   std::vector<float> h_thr;
@@ -216,6 +229,11 @@ struct qr_ctx {
   size_t tied_cap = 0, keys_cap = 0;
   double *d_ssq = nullptr;       // per-slice sum of squares partials
   QrScalars *d_scalars = nullptr;
+  QrPinned *h_pin = nullptr;
+  QrNodesOut *d_nodes_out = nullptr;  // compact records of the tree just finished
+  hipEvent_t ev_scal = nullptr, ev_nodes = nullptr;
+  bool scal_pending = false, nodes_pending = false;
+  size_t cur_maxnodes = 0;
   // tree
   uint32_t *d_order[2] = {nullptr, nullptr};
   uint64_t *d_partials = nullptr;
@@ -286,7 +304,7 @@ int qr_k_colstats(qr_ctx *c, const float *col, size_t N, size_t F, uint32_t limi
 int qr_k_binning(qr_ctx *c);
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode);
 int qr_k_residual(qr_ctx *c);
-int qr_k_prep(qr_ctx *c, size_t nslices);
+int qr_k_prep(qr_ctx *c, size_t nslices, int with_metric);
 int qr_k_prep_pack(qr_ctx *c);
 int qr_k_prep_global(qr_ctx *c);
 int qr_k_tree_leaves_global(qr_ctx *c, int newton);

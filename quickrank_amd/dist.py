@@ -57,7 +57,7 @@ class ShardedTreeFitter:
     def _gather_records(self):
         self.dist.all_gather_into_tensor(self.recs_all, self.recs_local, group=self.group)
 
-    def fit_tree(self, ctx, nleaves, minls, newton):
+    def fit_tree(self, ctx, nleaves, minls, newton, read=True):
         ctx.tree_begin(nleaves, minls)
         self._gather_records()
         for _ in range(nleaves - 1):
@@ -66,6 +66,9 @@ class ShardedTreeFitter:
             ctx.tree_apply()
             self._gather_records()
         ctx.tree_decide()
+        if not read:
+            ctx.tree_end_local(newton)        # records later: ctx.tree_nodes()
+            return None
         return ctx.tree_end(nleaves, newton)
 
 

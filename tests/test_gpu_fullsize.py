@@ -178,3 +178,26 @@ def test_scoring_linearity_and_tree_order(big):
     c.upload_ensemble(nodes[32:], w[32:])
     b, _ = c.score(x)
     assert np.allclose(a + b, s1, rtol=1e-13, atol=1e-13)    # prefix + suffix, up to one rounding each
+
+
+def test_config5_model_shape_vs_oracle(big, oracle_lib):
+    """BASELINE.json config 5's model (10,000 trees x 64 leaves, 200 features) on a
+    document sample the oracle can walk: bit-exact, and independent of how many
+    documents share the launch (the same rows scored inside a 300k-row batch)."""
+    qr = big["qr"]
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+    from score_bench import make_model
+    rng = np.random.default_rng(43)
+    nodes, w = make_model(10000, 6, 200, rng)
+    x = rng.random((300000, 200), dtype=np.float32)
+    c = qr.Context(0)
+    c.upload_ensemble(nodes, w)
+    model = dict(nodes=nodes, nnodes=np.full(len(nodes), nodes.shape[1], np.uint64), ntrees=len(nodes),
+                 max_nodes=nodes.shape[1], shrinkage=0.1)
+    want = oracle_lib.ensemble_score(model, x[:4096])
+    small, _ = c.score(x[:4096])
+    assert np.array_equal(small, want)
+    full, _ = c.score(x)
+    assert np.array_equal(full[:4096], want)
+    c.close()

@@ -21,6 +21,8 @@
 //   k_mask / k_part_count / k_part_scatter   stable partition of the node's
 //              doc list (ascending doc ids are preserved)
 //   k_finish / k_leaf_sums / k_leaf_final / k_score_update / k_valid_update
+#include <algorithm>
+
 #include "qr_internal.h"
 #include "qr_wave.h"
 
@@ -43,6 +45,10 @@ __device__ __forceinline__ long long quantize(double x) {
   const double magic = 6755399441055744.0;
   return __double_as_longlong(x + magic) - __double_as_longlong(magic);
 }
+
+#ifndef QR_HIST_SETS
+#define QR_HIST_SETS 3
+#endif
 
 template <int CH, bool IDENTITY>
 __device__ __forceinline__ void hist_accumulate(
@@ -85,10 +91,12 @@ __device__ __forceinline__ void hist_accumulate(
       atomicAdd(&hist[bin * FW + colk[k]], addend);
     }
   };
-  // Software pipeline: three register sets rotate (A, B, C), so two tiles of
-  // loads stay in flight behind the tile whose 16 LDS atomics are issuing; in the
-  // gather case each set also keeps the document id of its NEXT tile in flight.
-  // No register copies between stages (a copy would wait for the load it forwards).
+  // Software pipeline: NS register sets rotate, so NS-1 tiles of loads stay in
+  // flight behind the tile whose 16 LDS atomics are issuing; in the gather case
+  // each set also keeps the document id of its NEXT tile in flight.  No register
+  // copies between stages (a copy would wait for the load it forwards); the set
+  // index is a compile-time constant everywhere, so the sets live in registers.
+  constexpr int NS = QR_HIST_SETS;
   const uint32_t step = nw * DW;
   const uint32_t p0 = r0 + wave * DW + dsub;
   auto valid = [&](uint32_t p) { return lane_ok && p < r1; };
@@ -103,67 +111,51 @@ __device__ __forceinline__ void hist_accumulate(
   // counted s_waitcnt vmcnt(N) instead of draining the queue at every stage.
   const uint32_t plast = r1 - 1;
   auto clampp = [&](uint32_t p) { return p < plast ? p : plast; };
-  uint4 rowA, rowB, rowC;
-  double lamA, lamB, lamC;
-  uint32_t idA, idB, idC;
-  bool vA = valid(p0), vB = valid(p0 + step), vC = valid(p0 + 2 * step);
-  idA = get_id(clampp(p0));
-  idB = get_id(clampp(p0 + step));
-  idC = get_id(clampp(p0 + 2 * step));
-  rowA = load_row(idA); lamA = lambda[idA];
-  rowB = load_row(idB); lamB = lambda[idB];
-  rowC = load_row(idC); lamC = lambda[idC];
-  idA = get_id(clampp(p0 + 3 * step));
-  idB = get_id(clampp(p0 + 4 * step));
-  idC = get_id(clampp(p0 + 5 * step));
+  uint4 row[NS];
+  double lam[NS];
+  uint32_t id[NS];
+  bool v[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    v[i] = valid(p0 + i * step);
+    id[i] = get_id(clampp(p0 + i * step));
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    row[i] = load_row(id[i]);
+    lam[i] = lambda[id[i]];
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) id[i] = get_id(clampp(p0 + (NS + i) * step));
   uint32_t pos = p0;
-  for (uint32_t tile = r0 + wave * DW; tile < r1; tile += 3 * step, pos += 3 * step) {
-    if (vA) process(rowA, lamA);
-    vA = valid(pos + 3 * step);
-    rowA = load_row(idA); lamA = lambda[idA];
-    idA = get_id(clampp(pos + 6 * step));
-
-    if (vB) process(rowB, lamB);
-    vB = valid(pos + 4 * step);
-    rowB = load_row(idB); lamB = lambda[idB];
-    idB = get_id(clampp(pos + 7 * step));
-
-    if (vC) process(rowC, lamC);
-    vC = valid(pos + 5 * step);
-    rowC = load_row(idC); lamC = lambda[idC];
-    idC = get_id(clampp(pos + 8 * step));
+  for (uint32_t tile = r0 + wave * DW; tile < r1; tile += NS * step, pos += NS * step) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      if (v[i]) process(row[i], lam[i]);
+      v[i] = valid(pos + (NS + i) * step);
+      row[i] = load_row(id[i]);
+      lam[i] = lambda[id[i]];
+      id[i] = get_id(clampp(pos + (2 * NS + i) * step));
+    }
   }
 }
 
-__global__ __launch_bounds__(1024) void k_hist(
-    const QrTreeState *__restrict__ ts, const int root_mode, const uint32_t N,
-    const QrBlock *__restrict__ blocks, const int nblocks,
+// One workgroup's share of a node histogram: workgroup `wg` of the `G` that the
+// plan hands to a node of n documents; partial slots start at `slot_base`.
+__device__ __forceinline__ void hist_body(
+    u64 *hist, const uint32_t seg_begin, const uint32_t n, const int buf, const int G,
+    const int wg, const size_t slot_base, const QrBlock *__restrict__ blocks, const int nblocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const QrScalars *__restrict__ scal, u64 *__restrict__ partials, const int docmode) {
-  extern __shared__ __attribute__((aligned(16))) u64 hist[];
-  uint32_t seg_begin, n;
-  int buf;
-  if (root_mode) {
-    seg_begin = 0;
-    n = N;
-    buf = 2;
-  } else {
-    if (!ts->desc.active) return;
-    // document-sharded: the rank's own part of the directly built child
-    seg_begin = docmode ? ts->loc.small_begin : ts->desc.small_begin;
-    n = docmode ? ts->loc.small_n : ts->desc.small_n;
-    buf = ts->desc.dst_buf;
-  }
+    const double scale, u64 *__restrict__ partials) {
   __shared__ QrPlan plan;
-  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, (int)gridDim.x, &plan);
+  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, G, &plan);
   __syncthreads();
   int b = -1;
   for (int i = 0; i < nblocks; ++i)
-    if ((int)blockIdx.x >= plan.wg_start[i] && (int)blockIdx.x < plan.wg_start[i + 1])
-      b = i;
+    if (wg >= plan.wg_start[i] && wg < plan.wg_start[i + 1]) b = i;
   if (b < 0) return;
-  const uint32_t j = blockIdx.x - plan.wg_start[b];
+  const uint32_t j = wg - plan.wg_start[b];
   const uint32_t per = plan.per[b];
   const uint32_t r0 = j * per;
   const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
@@ -171,7 +163,6 @@ __global__ __launch_bounds__(1024) void k_hist(
   const uint8_t *bins_b = bins + blocks[b].off;
   const uint32_t *order = buf == 0 ? order0 : order1;
   const bool identity = buf == 2;
-  const double scale = scal->scale;
   const uint32_t cells = 256u * fw;
   uint32_t k = 0;
   for (uint32_t s0 = r0; s0 < r1; s0 += QR_DPW, ++k) {
@@ -197,7 +188,7 @@ __global__ __launch_bounds__(1024) void k_hist(
       }
     }
     __syncthreads();
-    u64 *dst = partials + ((size_t)blockIdx.x * plan.kmax + k) * (256u * 64u);
+    u64 *dst = partials + (slot_base + (size_t)wg * plan.kmax + k) * (256u * 64u);
     for (uint32_t i = threadIdx.x * 2; i < cells; i += blockDim.x * 2) {
       ulonglong2 v;
       v.x = hist[i];
@@ -208,21 +199,122 @@ __global__ __launch_bounds__(1024) void k_hist(
   }
 }
 
+__global__ __launch_bounds__(1024) void k_hist(
+    const QrTreeState *__restrict__ ts, const int root_mode, const uint32_t N,
+    const QrBlock *__restrict__ blocks, const int nblocks,
+    const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
+    const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
+    const QrScalars *__restrict__ scal, u64 *__restrict__ partials, const int docmode) {
+  extern __shared__ __attribute__((aligned(16))) u64 hist[];
+  uint32_t seg_begin, n;
+  int buf;
+  if (root_mode) {
+    seg_begin = 0;
+    n = N;
+    buf = 2;
+  } else {
+    if (!ts->desc.active) return;
+    // document-sharded: the rank's own part of the directly built child
+    seg_begin = docmode ? ts->loc.small_begin : ts->desc.small_begin;
+    n = docmode ? ts->loc.small_n : ts->desc.small_n;
+    buf = ts->desc.dst_buf;
+  }
+  hist_body(hist, seg_begin, n, buf, (int)gridDim.x, (int)blockIdx.x, 0, blocks, nblocks, bins,
+            order0, order1, lambda, scal->scale, partials);
+}
+
+// level-wise (oblivious) growth: the directly built children of ALL nodes of the
+// level in one launch; workgroup w serves node map[w] >> 16 as its workgroup
+// map[w] & 0xffff
+__global__ __launch_bounds__(1024) void k_hist_level(
+    const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ map,
+    const QrBlock *__restrict__ blocks, const int nblocks,
+    const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
+    const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
+    const QrScalars *__restrict__ scal, u64 *__restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) u64 hist[];
+  if (ts->obl_done || blockIdx.x >= ts->l_hist_wgs) return;
+  const uint32_t m = map[blockIdx.x];
+  const QrLevelNode &ln = ts->lnode[m >> 16];
+  hist_body(hist, ln.small_begin, ln.small_n, ln.dst_buf, ln.G, (int)(m & 0xffffu), ln.slot_base,
+            blocks, nblocks, bins, order0, order1, lambda, scal->scale, partials);
+}
+
 // ===========================================================================
 // k_reduce: sum the workgroup partials of one histogram launch, in the native
 // [bin][fw] cell order (fully coalesced 8-byte reads), unpacking count and sum.
 // One workgroup = 64 consecutive cells x 4 slot groups; exact integers, so the
 // reduction order is free.
 // ===========================================================================
+// sum of the partial slots [slot_base, ...) of a node of n documents planned with
+// G workgroups, for 64 consecutive cells starting at cellblock * 64
+__device__ __forceinline__ void reduce_body(
+    const uint32_t n, const int G, const size_t slot_base, const uint32_t cellblock,
+    const QrBlock *__restrict__ blocks, const int nblocks, const u64 *__restrict__ partials,
+    long long *__restrict__ red_sum, uint32_t *__restrict__ red_cnt, const uint32_t cs) {
+  __shared__ long long sh_s[512];
+  __shared__ uint32_t sh_c[512];
+  __shared__ QrPlan plan;
+  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, G, &plan);
+  __syncthreads();
+  // which block does this workgroup's cell range belong to?
+  uint32_t cell0 = cellblock * 64u;  // over the concatenation of 256*fw cells per block
+  int b = -1;
+  uint32_t base = 0;
+  for (int i = 0; i < nblocks; ++i) {
+    const uint32_t cells = 256u * blocks[i].fw;
+    if (b < 0 && cell0 < base + cells) {
+      b = i;
+      cell0 -= base;
+    }
+    if (b < 0) base += cells;
+  }
+  if (b < 0) return;
+  const uint32_t c = threadIdx.x & 63, g = threadIdx.x >> 6;  // 8 slot groups
+  const uint32_t per = plan.per[b];
+  const int W = plan.wg_start[b + 1] - plan.wg_start[b];
+  const int kmax = plan.kmax;
+  const int total = W * kmax;
+  const u64 *src = partials + (slot_base + (size_t)plan.wg_start[b] * kmax) * (256u * 64u) + cell0 + c;
+  long long s = 0;
+  uint32_t cn = 0;
+#pragma unroll 4
+  for (int idx = (int)g; idx < total; idx += 8) {
+    bool valid = true;
+    if (kmax > 1) {  // workgroup j flushed only ceil(docs_j / QR_DPW) slots
+      const int j = idx / kmax, k = idx - j * kmax;
+      const uint32_t r0 = j * per;
+      const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
+      valid = r0 < n && k < (int)((r1 - r0 + QR_DPW - 1) / QR_DPW);
+    }
+    if (valid) {
+      const u64 cell = src[(size_t)idx * (256u * 64u)];
+      const u64 cnt = (cell + (1ull << (QR_SB - 1))) >> QR_SB;
+      s += (long long)(cell - (cnt << QR_SB));
+      cn += (uint32_t)cnt;
+    }
+  }
+  sh_s[threadIdx.x] = s;
+  sh_c[threadIdx.x] = cn;
+  __syncthreads();
+  if (g == 0) {
+    s = 0;
+    cn = 0;
+    for (int i = 0; i < 8; ++i) {
+      s += sh_s[i * 64 + c];
+      cn += sh_c[i * 64 + c];
+    }
+    red_sum[base + cell0 + c] = s;
+    red_cnt[(size_t)(base + cell0 + c) * cs] = cn;
+  }
+}
+
 __global__ __launch_bounds__(512) void k_reduce(
     const QrTreeState *__restrict__ ts, const int root_mode, const uint32_t N,
     const QrBlock *__restrict__ blocks, const int nblocks, const int G,
     const u64 *__restrict__ partials, long long *__restrict__ red_sum,
     uint32_t *__restrict__ red_cnt, const int docmode, const double *__restrict__ part_ss,
     long long *__restrict__ tail, const int rank, const int world) {
-  __shared__ long long sh_s[512];
-  __shared__ uint32_t sh_c[512];
-  __shared__ QrPlan plan;
   uint32_t n;
   if (root_mode) {
     n = N;
@@ -253,58 +345,20 @@ __global__ __launch_bounds__(512) void k_reduce(
       tail[i] = v;
     }
   }
-  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, G, &plan);
-  __syncthreads();
-  // which block does this workgroup's cell range belong to?
-  uint32_t cell0 = blockIdx.x * 64u;  // over the concatenation of 256*fw cells per block
-  int b = -1;
-  uint32_t base = 0;
-  for (int i = 0; i < nblocks; ++i) {
-    const uint32_t cells = 256u * blocks[i].fw;
-    if (b < 0 && cell0 < base + cells) {
-      b = i;
-      cell0 -= base;
-    }
-    if (b < 0) base += cells;
-  }
-  if (b < 0) return;
-  const uint32_t c = threadIdx.x & 63, g = threadIdx.x >> 6;  // 8 slot groups
-  const uint32_t per = plan.per[b];
-  const int W = plan.wg_start[b + 1] - plan.wg_start[b];
-  const int kmax = plan.kmax;
-  const int total = W * kmax;
-  const u64 *src = partials + (size_t)plan.wg_start[b] * kmax * (256u * 64u) + cell0 + c;
-  long long s = 0;
-  uint32_t cn = 0;
-#pragma unroll 4
-  for (int idx = (int)g; idx < total; idx += 8) {
-    bool valid = true;
-    if (kmax > 1) {  // workgroup j flushed only ceil(docs_j / QR_DPW) slots
-      const int j = idx / kmax, k = idx - j * kmax;
-      const uint32_t r0 = j * per;
-      const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
-      valid = k < (int)((r1 - r0 + QR_DPW - 1) / QR_DPW);
-    }
-    if (valid) {
-      const u64 cell = src[(size_t)idx * (256u * 64u)];
-      const u64 cnt = (cell + (1ull << (QR_SB - 1))) >> QR_SB;
-      s += (long long)(cell - (cnt << QR_SB));
-      cn += (uint32_t)cnt;
-    }
-  }
-  sh_s[threadIdx.x] = s;
-  sh_c[threadIdx.x] = cn;
-  __syncthreads();
-  if (g == 0) {
-    s = 0;
-    cn = 0;
-    for (int i = 0; i < 8; ++i) {
-      s += sh_s[i * 64 + c];
-      cn += sh_c[i * 64 + c];
-    }
-    red_sum[base + cell0 + c] = s;
-    red_cnt[(size_t)(base + cell0 + c) * cs] = cn;
-  }
+  reduce_body(n, G, 0, blockIdx.x, blocks, nblocks, partials, red_sum, red_cnt, cs);
+}
+
+// level-wise growth: grid (cell blocks, nodes of the level); per-node reduced
+// arrays of `cells_total` entries each
+__global__ __launch_bounds__(512) void k_reduce_level(
+    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks, const int nblocks,
+    const u64 *__restrict__ partials, long long *__restrict__ red_sum,
+    uint32_t *__restrict__ red_cnt, const uint32_t cells_total) {
+  if (ts->obl_done || (int)blockIdx.y >= ts->l_nodes) return;
+  const QrLevelNode &ln = ts->lnode[blockIdx.y];
+  reduce_body(ln.small_n, ln.G, ln.slot_base, blockIdx.x, blocks, nblocks, partials,
+              red_sum + (size_t)blockIdx.y * cells_total, red_cnt + (size_t)blockIdx.y * cells_total,
+              1u);
 }
 
 // ===========================================================================
@@ -458,6 +512,54 @@ __global__ __launch_bounds__(256) void k_scan(
       o->rcount = 0;
     }
   }
+}
+
+// level-wise growth: prefix of the directly built child + sibling by subtraction
+// for every node of the level (grid = features x nodes); the gains are summed over
+// the level by k_obl_fill, not here
+__global__ __launch_bounds__(256) void k_scan_level(
+    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks, const int nblocks,
+    const long long *__restrict__ red_sum, const uint32_t *__restrict__ red_cnt,
+    const uint32_t cells_total, long long *__restrict__ hsum, uint32_t *__restrict__ hcnt,
+    const int flocal) {
+  __shared__ long long sh_s[4];
+  __shared__ uint32_t sh_c[4];
+  if (ts->obl_done || (int)blockIdx.y >= ts->l_nodes) return;
+  const QrLevelNode &ln = ts->lnode[blockIdx.y];
+  if (!ln.active) return;
+  const int lf = blockIdx.x;
+  int b = 0;
+  uint32_t base = 0, mybase = 0;
+  for (int i = 0; i < nblocks; ++i) {
+    if (lf >= blocks[i].lf0 && lf < blocks[i].lf0 + blocks[i].nreal) {
+      b = i;
+      mybase = base;
+    }
+    base += 256u * blocks[i].fw;
+  }
+  const int col = lf - blocks[b].lf0;
+  const int fw = blocks[b].fw;
+  const uint32_t t = threadIdx.x;
+  const size_t roff = (size_t)blockIdx.y * cells_total + mybase + t * fw + col;
+  long long s = wave_scan_i64(red_sum[roff]);
+  uint32_t cn = wave_scan_u32(red_cnt[roff]);
+  const int lane = t & 63, wave = t >> 6;
+  if (lane == 63) {
+    sh_s[wave] = s;
+    sh_c[wave] = cn;
+  }
+  __syncthreads();
+  for (int w = 0; w < wave; ++w) {
+    s += sh_s[w];
+    cn += sh_c[w];
+  }
+  const size_t hidx = ((size_t)ln.small_slot * flocal + lf) * 256 + t;
+  const size_t pidx = ((size_t)ln.parent_slot * flocal + lf) * 256 + t;
+  const size_t bidx = ((size_t)ln.big_slot * flocal + lf) * 256 + t;
+  hsum[hidx] = s;
+  hcnt[hidx] = cn;
+  hsum[bidx] = hsum[pidx] - s;
+  hcnt[bidx] = hcnt[pidx] - cn;
 }
 
 // ===========================================================================
@@ -1019,22 +1121,25 @@ __global__ __launch_bounds__(256) void k_part_scatter(
 // dispatched first and never wait on successors, so the chain cannot deadlock.
 // The epoch increases with every split of the context's lifetime, so the granule
 // array never needs clearing.
-__global__ __launch_bounds__(256) void k_partition(
-    const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm,
-    const uint32_t Nfm,
+struct PartNode {  // what the partition needs to know about the node being split
+  uint32_t begin, n, lcount;
+  int32_t src_buf, dst_buf, small_is_left;
+};
+
+// `w` = this workgroup's slice of the node, `first` = global index of the node's
+// first workgroup (granules are indexed globally: `first + w`)
+__device__ __forceinline__ void partition_body(
+    const PartNode d, const QrSplitDesc &gl, const uint32_t w, const uint32_t first,
+    const u64 epoch, const uint8_t *__restrict__ fm, const uint32_t Nfm,
     uint32_t *__restrict__ order0, uint32_t *__restrict__ order1,
-    const uint32_t *__restrict__ mask, const int use_mask,
-    u64 *__restrict__ state, const double *__restrict__ lambda,
-    double *__restrict__ part_ss) {
+    const uint32_t *__restrict__ mask, const int use_mask, u64 *__restrict__ state,
+    const double *__restrict__ lambda, double *__restrict__ part_ss) {
   __shared__ uint32_t sh[4];
   __shared__ uint32_t wave_off[4];
   __shared__ double shd[4], shs[4];
-  const QrSplitDesc d = ts->desc;
-  if (!d.active) return;
-  const uint32_t n = d.end - d.begin;
-  const uint32_t base = blockIdx.x * QR_PART_SLICE;
+  const uint32_t n = d.n;
+  const uint32_t base = w * QR_PART_SLICE;
   if (base >= n) return;
-  const u64 epoch = ts->part_epoch;
   const uint32_t *src = d.src_buf == 0 ? order0 : order1;
   uint32_t *dst = d.dst_buf == 0 ? order0 : order1;
   uint32_t ids[PART_PER_THREAD];
@@ -1046,7 +1151,7 @@ __global__ __launch_bounds__(256) void k_partition(
     ids[k] = 0;
     if (p < n) {
       ids[k] = d.src_buf == 2 ? d.begin + p : src[d.begin + p];
-      fl[k] = go_left(d, p, ids[k], fm, Nfm, mask, use_mask);
+      fl[k] = go_left(gl, p, ids[k], fm, Nfm, mask, use_mask);
       cnt += fl[k] ? 1u : 0u;
     }
   }
@@ -1056,17 +1161,17 @@ __global__ __launch_bounds__(256) void k_partition(
   if (lane == 63) wave_off[wave] = inc;
   __syncthreads();
   uint32_t woff = 0;
-  for (int w = 0; w < wave; ++w) woff += wave_off[w];
+  for (int x = 0; x < wave; ++x) woff += wave_off[x];
   const uint32_t total = wave_off[0] + wave_off[1] + wave_off[2] + wave_off[3];
-  // publish my count, then look back
+  // publish my count, then look back over the node's earlier slices
   if (threadIdx.x == 0)
-    __hip_atomic_store(&state[blockIdx.x], (epoch << 32) | (u64)total, __ATOMIC_RELAXED,
+    __hip_atomic_store(&state[first + w], (epoch << 32) | (u64)total, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   uint32_t pre = 0;
-  for (uint32_t v = threadIdx.x; v < blockIdx.x; v += 256) {
+  for (uint32_t v = threadIdx.x; v < w; v += 256) {
     u64 g;
     do {
-      g = __hip_atomic_load(&state[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g = __hip_atomic_load(&state[first + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((g >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
     } while ((g >> 32) != epoch);
     pre += (uint32_t)g;
@@ -1086,13 +1191,14 @@ __global__ __launch_bounds__(256) void k_partition(
         o = d.begin + d.lcount + (p - lpos);
       }
       dst[o] = ids[k];
-      if (fl[k] == (d.small_is_left != 0)) {
+      if (part_ss && fl[k] == (d.small_is_left != 0)) {
         const double l = lambda[ids[k]];
         sq += l * l;
         sm += l;
       }
     }
   }
+  if (!part_ss) return;  // level-wise growth keeps no per-node sums (ot.cc:141-149)
   sq = wave_sum(sq);
   sm = wave_sum(sm);
   __syncthreads();
@@ -1102,9 +1208,52 @@ __global__ __launch_bounds__(256) void k_partition(
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    part_ss[2 * blockIdx.x] = (shd[0] + shd[1]) + (shd[2] + shd[3]);
-    part_ss[2 * blockIdx.x + 1] = (shs[0] + shs[1]) + (shs[2] + shs[3]);
+    part_ss[2 * (size_t)(first + w)] = (shd[0] + shd[1]) + (shd[2] + shd[3]);
+    part_ss[2 * (size_t)(first + w) + 1] = (shs[0] + shs[1]) + (shs[2] + shs[3]);
   }
+}
+
+__global__ __launch_bounds__(256) void k_partition(
+    const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm,
+    const uint32_t Nfm,
+    uint32_t *__restrict__ order0, uint32_t *__restrict__ order1,
+    const uint32_t *__restrict__ mask, const int use_mask,
+    u64 *__restrict__ state, const double *__restrict__ lambda,
+    double *__restrict__ part_ss) {
+  const QrSplitDesc d = ts->desc;
+  if (!d.active) return;
+  PartNode pn;
+  pn.begin = d.begin;
+  pn.n = d.end - d.begin;
+  pn.lcount = d.lcount;
+  pn.src_buf = d.src_buf;
+  pn.dst_buf = d.dst_buf;
+  pn.small_is_left = d.small_is_left;
+  partition_body(pn, d, blockIdx.x, 0, ts->part_epoch, fm, Nfm, order0, order1, mask, use_mask,
+                 state, lambda, part_ss);
+}
+
+// level-wise growth: every node of the level in one launch; the look-back chain
+// of a node runs over its own workgroups only
+__global__ __launch_bounds__(256) void k_partition_level(
+    const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ map,
+    const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
+    uint32_t *__restrict__ order1, u64 *__restrict__ state) {
+  if (ts->obl_done || blockIdx.x >= ts->l_part_wgs) return;
+  const QrLevelNode &ln = ts->lnode[map[blockIdx.x]];
+  if (!ln.active) return;
+  PartNode pn;
+  pn.begin = ln.begin;
+  pn.n = ln.end - ln.begin;
+  pn.lcount = ln.lcount;
+  pn.src_buf = ln.src_buf;
+  pn.dst_buf = ln.dst_buf;
+  pn.small_is_left = ln.small_is_left;
+  QrSplitDesc gl;
+  gl.owner_local = ts->l_owner_local;
+  gl.thr_id = ts->obl_t;
+  partition_body(pn, gl, blockIdx.x - ln.part_first, ln.part_first, ts->part_epoch, fm, Nfm,
+                 order0, order1, nullptr, 0, state, nullptr, nullptr);
 }
 
 // ===========================================================================
@@ -1447,70 +1596,125 @@ __global__ __launch_bounds__(64) void k_obl_level(QrTreeState *__restrict__ ts,
   lg->lcount = lg->rcount = 0;
 }
 
-// descriptor for splitting node `lbegin + i` of the level with the level's split
-__global__ __launch_bounds__(64) void k_obl_desc(
-    QrTreeState *__restrict__ ts, const int level, const int i, const int last_level,
+// Descriptors of ALL nodes of the level for the level's split (one thread per
+// node), the children's records, and the work plan of the level's launches: how
+// many histogram workgroups / partial slots / partition workgroups each node gets
+// and the workgroup -> node maps.
+__global__ __launch_bounds__(256) void k_obl_plan(
+    QrTreeState *__restrict__ ts, const int level, const int last_level, const int G,
     const int flocal, const uint32_t *__restrict__ hcnt, const float *__restrict__ thr,
-    const int32_t *__restrict__ gf2lf) {
-  if (threadIdx.x != 0) return;
-  QrSplitDesc *d = &ts->desc;
-  d->active = 0;
+    const int32_t *__restrict__ gf2lf, const QrBlock *__restrict__ blocks, const int nblocks,
+    uint32_t *__restrict__ hist_map, uint32_t *__restrict__ part_map) {
+  __shared__ uint32_t sh_a[QR_MAXLEVEL], sh_b[QR_MAXLEVEL], sh_c[QR_MAXLEVEL];
+  __shared__ uint32_t tot_small;
   if (ts->obl_done) return;
-  const int node = (1 << level) - 1 + i;
-  QrNode *nd = &ts->nodes[node];
+  const int nodes = 1 << level;
+  const int j = threadIdx.x;
   const uint32_t f = ts->obl_f, t = ts->obl_t;
   const int lf = gf2lf[f];
-  const size_t base = ((size_t)nd->hslot * flocal + lf) * 256;
-  const uint32_t lcount = hcnt[base + t];
-  const uint32_t rcount = hcnt[base + 255] - lcount;
-  const int li = 2 * node + 1, ri = 2 * node + 2;
-  if (ts->nnodes < ri + 1) ts->nnodes = ri + 1;
-  d->active = 1;
-  ts->part_epoch++;
-  d->node = node;
-  d->left = li;
-  d->right = ri;
-  d->begin = nd->begin;
-  d->end = nd->end;
-  d->src_buf = nd->buf;
-  d->dst_buf = nd->buf == 0 ? 1 : 0;
-  d->lcount = lcount;
-  d->rcount = rcount;
-  d->feature = f;
-  d->thr_id = t;
-  d->owner_local = lf;
-  d->small_is_left = lcount <= rcount;
-  d->small_node = d->small_is_left ? li : ri;
-  d->big_node = d->small_is_left ? ri : li;
-  d->parent_slot = nd->hslot;
-  d->small_slot = d->small_node;
-  d->big_slot = d->big_node;
-  d->small_begin = d->small_is_left ? nd->begin : nd->begin + lcount;
-  d->small_n = d->small_is_left ? lcount : rcount;
-  nd->feature = (int32_t)f;
-  nd->thr_id = (int32_t)t;
-  nd->threshold = thr[(size_t)f * QR_MAX_BINS + t];
-  nd->left = li;
-  nd->right = ri;
-  QrNode *L = &ts->nodes[li], *R = &ts->nodes[ri];
-  L->begin = nd->begin;
-  L->end = nd->begin + lcount;
-  R->begin = L->end;
-  R->end = nd->end;
-  L->buf = R->buf = d->dst_buf;
-  L->hslot = li;
-  R->hslot = ri;
-  L->feature = R->feature = -1;
-  L->thr_id = R->thr_id = -1;
-  L->threshold = R->threshold = 0.f;
-  L->left = L->right = R->left = R->right = -1;
-  L->parent = R->parent = node;
-  L->leaf_id = R->leaf_id = -1;
-  L->count = lcount;
-  R->count = rcount;
-  L->sum = R->sum = L->ss = R->ss = L->deviance = R->deviance = 0.0;
-  L->value = R->value = 0.0;  // overwritten by update_output (ot.cc:141-149)
-  (void)last_level;
+  QrLevelNode ln;
+  ln.active = 0;
+  ln.small_n = 0;
+  uint32_t nseg = 0;
+  if (j < nodes) {
+    const int node = nodes - 1 + j;
+    QrNode *nd = &ts->nodes[node];
+    const size_t base = ((size_t)nd->hslot * flocal + lf) * 256;
+    const uint32_t lcount = hcnt[base + t];
+    const uint32_t rcount = hcnt[base + 255] - lcount;
+    const int li = 2 * node + 1, ri = 2 * node + 2;
+    ln.active = 1;
+    ln.begin = nd->begin;
+    ln.end = nd->end;
+    ln.src_buf = nd->buf;
+    ln.dst_buf = nd->buf == 0 ? 1 : 0;
+    ln.lcount = lcount;
+    ln.small_is_left = lcount <= rcount;
+    ln.parent_slot = nd->hslot;
+    ln.small_slot = ln.small_is_left ? li : ri;
+    ln.big_slot = ln.small_is_left ? ri : li;
+    ln.small_begin = ln.small_is_left ? nd->begin : nd->begin + lcount;
+    ln.small_n = ln.small_is_left ? lcount : rcount;
+    nseg = nd->end - nd->begin;
+    nd->feature = (int32_t)f;
+    nd->thr_id = (int32_t)t;
+    nd->threshold = thr[(size_t)f * QR_MAX_BINS + t];
+    nd->left = li;
+    nd->right = ri;
+    QrNode *L = &ts->nodes[li], *R = &ts->nodes[ri];
+    L->begin = nd->begin;
+    L->end = nd->begin + lcount;
+    R->begin = L->end;
+    R->end = nd->end;
+    L->buf = R->buf = ln.dst_buf;
+    L->hslot = li;
+    R->hslot = ri;
+    L->feature = R->feature = -1;
+    L->thr_id = R->thr_id = -1;
+    L->threshold = R->threshold = 0.f;
+    L->left = L->right = R->left = R->right = -1;
+    L->parent = R->parent = node;
+    L->leaf_id = R->leaf_id = -1;
+    L->count = lcount;
+    R->count = rcount;
+    L->sum = R->sum = L->ss = R->ss = L->deviance = R->deviance = 0.0;
+    L->value = R->value = 0.0;  // overwritten by update_output (ot.cc:141-149)
+  }
+  sh_a[j] = ln.small_n;
+  __syncthreads();
+  if (j == 0) {
+    uint32_t s = 0;
+    for (int i = 0; i < nodes; ++i) s += sh_a[i];
+    tot_small = s ? s : 1u;
+  }
+  __syncthreads();
+  // histogram workgroups in proportion to the node's share of the level's direct
+  // builds (ot.cc:127: no histograms for the leaves of the last level)
+  uint32_t hw = 0, slots = 0, pw = 0;
+  if (j < nodes) {
+    pw = (nseg + QR_PART_SLICE - 1) / QR_PART_SLICE;
+    if (!last_level) {
+      long long g = ((long long)G * ln.small_n + tot_small - 1) / tot_small;
+      ln.G = (int)(g < 1 ? 1 : (g > G ? G : g));
+      QrPlan pl;
+      qr_make_plan(ln.small_n, nblocks, blocks, ln.G, &pl);
+      hw = (uint32_t)pl.wg_start[nblocks];
+      slots = hw * (uint32_t)pl.kmax;
+    } else {
+      ln.G = 0;
+    }
+  }
+  sh_a[j] = hw;
+  sh_b[j] = slots;
+  sh_c[j] = pw;
+  __syncthreads();
+  if (j == 0) {  // exclusive prefixes
+    uint32_t a = 0, b = 0, c = 0;
+    for (int i = 0; i < nodes; ++i) {
+      const uint32_t x = sh_a[i], y = sh_b[i], z = sh_c[i];
+      sh_a[i] = a;
+      sh_b[i] = b;
+      sh_c[i] = c;
+      a += x;
+      b += y;
+      c += z;
+    }
+    ts->l_hist_wgs = a;
+    ts->l_part_wgs = c;
+    ts->l_nodes = nodes;
+    ts->l_owner_local = lf;
+    if (ts->nnodes < 4 * nodes - 1) ts->nnodes = 4 * nodes - 1;  // children of the level exist
+    ts->part_epoch++;
+  }
+  __syncthreads();
+  if (j < nodes) {
+    ln.slot_base = sh_b[j];
+    ln.part_first = sh_c[j];
+    ln.pad = 0;
+    for (uint32_t x = 0; x < hw; ++x) hist_map[sh_a[j] + x] = ((uint32_t)j << 16) | x;
+    for (uint32_t w = 0; w < pw; ++w) part_map[sh_c[j] + w] = (uint32_t)j;
+    ts->lnode[j] = ln;
+  }
 }
 
 __global__ void k_obl_reset(QrTreeState *ts, int maxnodes, u64 minls) {
@@ -1680,16 +1884,6 @@ int qr_k_tree_apply(qr_ctx *c) {
 }
 
 
-static int launch_partition(qr_ctx *c) {
-  const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
-  const int use_mask = c->world > 1;
-  hipLaunchKernelGGL(k_partition, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
-                     c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
-                     c->d_mask, use_mask, (u64 *)c->d_part_state, c->d_lambda, c->d_part_ss);
-  QR_CHECK(c, hipGetLastError());
-  return QR_OK;
-}
-
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
   const int maxnodes = (1 << (depth + 1)) - 1;
   hipLaunchKernelGGL(k_obl_reset, dim3((maxnodes + 255) / 256), dim3(256), 0, c->stream,
@@ -1697,7 +1891,15 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
   QR_CHECK(c, hipGetLastError());
   int rc = launch_hist_scan(c, 1);  // root histogram -> slot 0
   if (rc) return rc;
+  size_t cells = 0;
+  for (const auto &b : c->blocks) cells += (size_t)256 * b.fw;
+  const size_t lds = hist_lds(c);
+  const unsigned pgrid = (unsigned)c->lpart_cap, hgrid = (unsigned)c->lhist_cap;
+  // every level: choose the split, plan the level, then ONE partition, ONE
+  // histogram, ONE reduce and ONE scan launch for all of its nodes (the launches
+  // are sized for the worst case; surplus workgroups leave at once)
   for (int level = 0; level < (int)depth; ++level) {
+    const int nodes = 1 << level;
     hipLaunchKernelGGL(k_obl_fill, dim3(c->flocal), dim3(256), 0, c->stream, c->d_tree, level,
                        c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf,
                        c->d_scalars, c->d_featrec);
@@ -1706,13 +1908,29 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
                        (uint32_t)c->N, c->d_featrec, c->flocal, c->d_scalars);
     QR_CHECK(c, hipGetLastError());
     const int last = level == (int)depth - 1;
-    for (int i = 0; i < (1 << level); ++i) {
-      hipLaunchKernelGGL(k_obl_desc, dim3(1), dim3(64), 0, c->stream, c->d_tree, level, i, last,
-                         c->flocal, c->d_hcnt, c->d_thr, c->d_gf2lf);
-      QR_CHECK(c, hipGetLastError());
-      if ((rc = launch_partition(c))) return rc;
-      if (!last && (rc = launch_hist_scan(c, 0))) return rc;  // ot.cc:127: no histograms for leaves
-    }
+    hipLaunchKernelGGL(k_obl_plan, dim3(1), dim3(256), 0, c->stream, c->d_tree, level, last,
+                       c->ncu, c->flocal, c->d_hcnt, c->d_thr, c->d_gf2lf, c->d_blocks,
+                       c->nblocks, c->d_lhist_map, c->d_lpart_map);
+    QR_CHECK(c, hipGetLastError());
+    const unsigned pg = std::min<unsigned>(pgrid, (unsigned)(c->N / QR_PART_SLICE + nodes + 1));
+    hipLaunchKernelGGL(k_partition_level, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
+                       c->d_lpart_map, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
+                       (u64 *)c->d_lpart_state);
+    QR_CHECK(c, hipGetLastError());
+    if (last) break;  // ot.cc:127: no histograms for the leaves
+    const unsigned hg = std::min<unsigned>(hgrid, (unsigned)(c->ncu + nodes * (c->nblocks + 1)));
+    hipLaunchKernelGGL(k_hist_level, dim3(hg), dim3(1024), lds, c->stream, c->d_tree,
+                       c->d_lhist_map, c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
+                       c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_lpartials);
+    QR_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_reduce_level, dim3((unsigned)(cells / 64), (unsigned)nodes), dim3(512), 0,
+                       c->stream, c->d_tree, c->d_blocks, c->nblocks, (const u64 *)c->d_lpartials,
+                       c->d_lred_sum, c->d_lred_cnt, (uint32_t)cells);
+    QR_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_scan_level, dim3(c->flocal, (unsigned)nodes), dim3(256), 0, c->stream,
+                       c->d_tree, c->d_blocks, c->nblocks, c->d_lred_sum, c->d_lred_cnt,
+                       (uint32_t)cells, c->d_hsum, c->d_hcnt, c->flocal);
+    QR_CHECK(c, hipGetLastError());
   }
   return QR_OK;
 }

@@ -91,6 +91,9 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
   dfree(c->d_blkcnt); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_tree); dfree(c->d_leafpart);
+  dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
+  dfree(c->d_lred_sum); dfree(c->d_lred_cnt); dfree(c->d_lpart_state);
+  c->lhist_cap = c->lpart_cap = c->lslots_cap = c->lred_nodes = 0;
   c->binned = false;
   c->tree_valid = false;
   c->hist_slots = 0;
@@ -742,6 +745,42 @@ static int ensure_hist_slots(qr_ctx *c, size_t slots) {
   return QR_OK;
 }
 
+// scratch of the level-wise (oblivious) launches, sized for the widest level
+static int ensure_level_buffers(qr_ctx *c, size_t depth) {
+  const size_t nodes = (size_t)1 << (depth - 1);
+  if (nodes > QR_MAXLEVEL) QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
+  size_t cells = 0, wsum = 0;
+  for (const auto &b : c->blocks) {
+    cells += (size_t)256 * b.fw;
+    wsum += b.fw / 16;
+  }
+  const size_t G = (size_t)c->ncu;
+  const size_t hist_wgs = G + nodes * (size_t)(c->nblocks + 1);
+  const size_t part_wgs = c->N / QR_PART_SLICE + nodes + 2;
+  // docs per histogram workgroup <= wsum * N / G + QR_SLICE (k_obl_plan hands out
+  // workgroups in proportion to the node sizes), hence flushes per workgroup:
+  const size_t kmax = (wsum * c->N / G + QR_SLICE + QR_DPW - 1) / QR_DPW;
+  const size_t slots = hist_wgs * kmax;
+  if (hist_wgs > c->lhist_cap || part_wgs > c->lpart_cap || slots > c->lslots_cap ||
+      nodes > c->lred_nodes) {
+    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
+    dfree(c->d_lred_sum); dfree(c->d_lred_cnt); dfree(c->d_lpart_state);
+    QR_CHECK(c, dalloc(&c->d_lhist_map, hist_wgs));
+    QR_CHECK(c, dalloc(&c->d_lpart_map, part_wgs));
+    QR_CHECK(c, dalloc(&c->d_lpart_state, part_wgs));
+    QR_CHECK(c, hipMemset(c->d_lpart_state, 0, part_wgs * 8));
+    QR_CHECK(c, dalloc(&c->d_lpartials, slots * 256 * 64));
+    QR_CHECK(c, dalloc(&c->d_lred_sum, nodes * cells));
+    QR_CHECK(c, dalloc(&c->d_lred_cnt, nodes * cells));
+    c->lhist_cap = hist_wgs;
+    c->lpart_cap = part_wgs;
+    c->lslots_cap = slots;
+    c->lred_nodes = nodes;
+  }
+  return QR_OK;
+}
+
 int qr_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
   if (!c) return QR_ERR_ARG;
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
@@ -845,6 +884,7 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
   int rc = ensure_hist_slots(c, ((size_t)1 << (depth + 1)) - 1);
   if (rc) return rc;
+  if ((rc = ensure_level_buffers(c, depth))) return rc;
   c->tree_valid = false;
   c->tree_open = true;
   c->cur_maxnodes = ((size_t)1 << (depth + 1)) - 1;

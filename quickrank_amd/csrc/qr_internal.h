@@ -117,6 +117,22 @@ struct QrLocalSplit {
   uint32_t pad;
 };
 
+// Level-wise (oblivious) growth splits every node of a level with the same
+// (feature, slot): one descriptor per node, all served by single launches.
+#define QR_MAXLEVEL 256
+struct QrLevelNode {
+  int32_t active;
+  int32_t src_buf, dst_buf;
+  int32_t small_is_left;
+  uint32_t begin, end, lcount;     // the node's segment and its left count
+  uint32_t small_begin, small_n;   // directly built child
+  int32_t parent_slot, small_slot, big_slot;
+  int32_t G;                       // histogram workgroups planned for the node
+  uint32_t slot_base;              // first partial slot
+  uint32_t part_first;             // first partition workgroup (global index)
+  uint32_t pad;
+};
+
 struct QrTreeState {
   int32_t nleaves_req;
   int32_t nnodes;
@@ -137,6 +153,10 @@ struct QrTreeState {
   int32_t obl_done, obl_level;
   uint32_t obl_f, obl_t;
   double obl_score;
+  int32_t l_nodes;                 // nodes of the level being split
+  int32_t l_owner_local;           // local index of the level's feature
+  uint32_t l_hist_wgs, l_part_wgs; // workgroups the level's launches really use
+  QrLevelNode lnode[QR_MAXLEVEL];
   // leaves in DFS order
   int32_t nleaves;
   int32_t leaf_nodes[QR_MAXNODES];
@@ -252,6 +272,13 @@ struct qr_ctx {
   unsigned long long *d_part_state = nullptr;  // look-back granules {epoch, count}
   double *d_part_ss = nullptr;
   QrTreeState *d_tree = nullptr;
+  // level-wise growth: workgroup -> (node, local index) maps, per-node reduced arrays
+  uint32_t *d_lhist_map = nullptr, *d_lpart_map = nullptr;
+  size_t lhist_cap = 0, lpart_cap = 0, lslots_cap = 0, lred_nodes = 0;
+  uint64_t *d_lpartials = nullptr;
+  long long *d_lred_sum = nullptr;
+  uint32_t *d_lred_cnt = nullptr;
+  unsigned long long *d_lpart_state = nullptr;
   double *d_leafpart = nullptr;  // [slices][2] partial sums
   bool tree_valid = false;
   bool tree_open = false;

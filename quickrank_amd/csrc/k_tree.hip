@@ -143,13 +143,13 @@ __device__ __forceinline__ void hist_accumulate(
 // One workgroup's share of a node histogram: workgroup `wg` of the `G` that the
 // plan hands to a node of n documents; partial slots start at `slot_base`.
 __device__ __forceinline__ void hist_body(
-    u64 *hist, const uint32_t seg_begin, const uint32_t n, const int buf, const int G,
+    u64 *hist, const uint32_t seg_begin, const uint32_t n, const int buf, const uint32_t q,
     const int wg, const size_t slot_base, const QrBlock *__restrict__ blocks, const int nblocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const double scale, u64 *__restrict__ partials) {
   __shared__ QrPlan plan;
-  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, G, &plan);
+  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, q, &plan);
   __syncthreads();
   int b = -1;
   for (int i = 0; i < nblocks; ++i)
@@ -219,8 +219,10 @@ __global__ __launch_bounds__(1024) void k_hist(
     n = docmode ? ts->loc.small_n : ts->desc.small_n;
     buf = ts->desc.dst_buf;
   }
-  hist_body(hist, seg_begin, n, buf, (int)gridDim.x, (int)blockIdx.x, 0, blocks, nblocks, bins,
-            order0, order1, lambda, scal->scale, partials);
+  const uint32_t q =
+      qr_plan_quantum((unsigned long long)n * qr_plan_wsum(nblocks, blocks), (int)gridDim.x - nblocks);
+  hist_body(hist, seg_begin, n, buf, q, (int)blockIdx.x, 0, blocks, nblocks, bins, order0, order1,
+            lambda, scal->scale, partials);
 }
 
 // level-wise (oblivious) growth: the directly built children of ALL nodes of the
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(1024) void k_hist_level(
   if (ts->obl_done || blockIdx.x >= ts->l_hist_wgs) return;
   const uint32_t m = map[blockIdx.x];
   const QrLevelNode &ln = ts->lnode[m >> 16];
-  hist_body(hist, ln.small_begin, ln.small_n, ln.dst_buf, ln.G, (int)(m & 0xffffu), ln.slot_base,
+  hist_body(hist, ln.small_begin, ln.small_n, ln.dst_buf, ln.q, (int)(m & 0xffffu), ln.slot_base,
             blocks, nblocks, bins, order0, order1, lambda, scal->scale, partials);
 }
 
@@ -249,13 +251,13 @@ __global__ __launch_bounds__(1024) void k_hist_level(
 // sum of the partial slots [slot_base, ...) of a node of n documents planned with
 // G workgroups, for 64 consecutive cells starting at cellblock * 64
 __device__ __forceinline__ void reduce_body(
-    const uint32_t n, const int G, const size_t slot_base, const uint32_t cellblock,
+    const uint32_t n, const uint32_t q, const size_t slot_base, const uint32_t cellblock,
     const QrBlock *__restrict__ blocks, const int nblocks, const u64 *__restrict__ partials,
     long long *__restrict__ red_sum, uint32_t *__restrict__ red_cnt, const uint32_t cs) {
   __shared__ long long sh_s[512];
   __shared__ uint32_t sh_c[512];
   __shared__ QrPlan plan;
-  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, G, &plan);
+  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, q, &plan);
   __syncthreads();
   // which block does this workgroup's cell range belong to?
   uint32_t cell0 = cellblock * 64u;  // over the concatenation of 256*fw cells per block
@@ -345,7 +347,9 @@ __global__ __launch_bounds__(512) void k_reduce(
       tail[i] = v;
     }
   }
-  reduce_body(n, G, 0, blockIdx.x, blocks, nblocks, partials, red_sum, red_cnt, cs);
+  const uint32_t q =
+      qr_plan_quantum((unsigned long long)n * qr_plan_wsum(nblocks, blocks), G - nblocks);
+  reduce_body(n, q, 0, blockIdx.x, blocks, nblocks, partials, red_sum, red_cnt, cs);
 }
 
 // level-wise growth: grid (cell blocks, nodes of the level); per-node reduced
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(512) void k_reduce_level(
     uint32_t *__restrict__ red_cnt, const uint32_t cells_total) {
   if (ts->obl_done || (int)blockIdx.y >= ts->l_nodes) return;
   const QrLevelNode &ln = ts->lnode[blockIdx.y];
-  reduce_body(ln.small_n, ln.G, ln.slot_base, blockIdx.x, blocks, nblocks, partials,
+  reduce_body(ln.small_n, ln.q, ln.slot_base, blockIdx.x, blocks, nblocks, partials,
               red_sum + (size_t)blockIdx.y * cells_total, red_cnt + (size_t)blockIdx.y * cells_total,
               1u);
 }
@@ -1259,27 +1263,46 @@ __global__ __launch_bounds__(256) void k_partition_level(
 // ===========================================================================
 // Tree end: leaves, leaf outputs, score update
 // ===========================================================================
-__global__ __launch_bounds__(64) void k_finish(QrTreeState *__restrict__ ts) {
-  if (threadIdx.x != 0) return;
-  // RTNode::save_leaves (rtnode.cc:34-46): DFS, left first
-  int stack[QR_MAXNODES];
-  int sp = 0, nl = 0;
-  stack[sp++] = 0;
-  while (sp > 0) {
-    const int n = stack[--sp];
-    QrNode *nd = &ts->nodes[n];
-    if (nd->feature < 0) {
-      nd->leaf_id = nl;
-      ts->leaf_nodes[nl] = n;
-      ts->leaf_begin[nl] = nd->begin;  // DFS order == ascending positions
-      ++nl;
-    } else {
-      stack[sp++] = nd->right;
-      stack[sp++] = nd->left;
-    }
+__global__ __launch_bounds__(256) void k_finish(QrTreeState *__restrict__ ts) {
+  // RTNode::save_leaves (rtnode.cc:34-46): DFS, left first.  The links are staged
+  // in LDS by the whole workgroup; one lane walks them there.
+  __shared__ int32_t s_feat[QR_MAXNODES], s_left[QR_MAXNODES], s_right[QR_MAXNODES];
+  __shared__ int32_t s_leaf[QR_MAXNODES];  // DFS order -> node
+  __shared__ int32_t stack[QR_MAXNODES];
+  __shared__ int s_nl;
+  const int nn = ts->nnodes;
+  for (int i = threadIdx.x; i < nn; i += blockDim.x) {
+    s_feat[i] = ts->nodes[i].feature;
+    s_left[i] = ts->nodes[i].left;
+    s_right[i] = ts->nodes[i].right;
   }
-  ts->nleaves = nl;
-  ts->leaf_begin[nl] = ts->nodes[0].end;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int sp = 0, nl = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+      const int n = stack[--sp];
+      if (s_feat[n] < 0) {
+        s_leaf[nl++] = n;
+      } else {
+        stack[sp++] = s_right[n];
+        stack[sp++] = s_left[n];
+      }
+    }
+    s_nl = nl;
+  }
+  __syncthreads();
+  const int nl = s_nl;
+  for (int l = threadIdx.x; l < nl; l += blockDim.x) {
+    const int n = s_leaf[l];
+    ts->nodes[n].leaf_id = l;
+    ts->leaf_nodes[l] = n;
+    ts->leaf_begin[l] = ts->nodes[n].begin;  // DFS order == ascending positions
+  }
+  if (threadIdx.x == 0) {
+    ts->nleaves = nl;
+    ts->leaf_begin[nl] = ts->nodes[0].end;
+  }
 }
 
 __device__ __forceinline__ int leaf_of_pos(const uint32_t *lb, int nl, uint32_t p) {
@@ -1668,20 +1691,22 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     tot_small = s ? s : 1u;
   }
   __syncthreads();
-  // histogram workgroups in proportion to the node's share of the level's direct
-  // builds (ot.cc:127: no histograms for the leaves of the last level)
+  // One plan quantum for the whole level: every histogram workgroup of every node
+  // and block then carries the same load.  Total workgroups <= geff + nodes *
+  // nblocks, i.e. within the G compute units (a single round) while the level is
+  // narrow enough.  ot.cc:127: no histograms for the leaves of the last level.
   uint32_t hw = 0, slots = 0, pw = 0;
   if (j < nodes) {
     pw = (nseg + QR_PART_SLICE - 1) / QR_PART_SLICE;
+    ln.q = 0;
     if (!last_level) {
-      long long g = ((long long)G * ln.small_n + tot_small - 1) / tot_small;
-      ln.G = (int)(g < 1 ? 1 : (g > G ? G : g));
+      const int spare = G - nodes * nblocks;
+      ln.q = qr_plan_quantum((unsigned long long)tot_small * qr_plan_wsum(nblocks, blocks),
+                             spare > G / 4 ? spare : G / 4);
       QrPlan pl;
-      qr_make_plan(ln.small_n, nblocks, blocks, ln.G, &pl);
+      qr_make_plan(ln.small_n, nblocks, blocks, ln.q, &pl);
       hw = (uint32_t)pl.wg_start[nblocks];
       slots = hw * (uint32_t)pl.kmax;
-    } else {
-      ln.G = 0;
     }
   }
   sh_a[j] = hw;
@@ -1918,7 +1943,9 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
                        (u64 *)c->d_lpart_state);
     QR_CHECK(c, hipGetLastError());
     if (last) break;  // ot.cc:127: no histograms for the leaves
-    const unsigned hg = std::min<unsigned>(hgrid, (unsigned)(c->ncu + nodes * (c->nblocks + 1)));
+    // k_obl_plan keeps the total within ncu workgroups while nodes * nblocks <= 3/4 ncu
+    const unsigned hg = std::min<unsigned>(
+        hgrid, (unsigned)std::max(c->ncu, c->ncu / 4 + nodes * c->nblocks));
     hipLaunchKernelGGL(k_hist_level, dim3(hg), dim3(1024), lds, c->stream, c->d_tree,
                        c->d_lhist_map, c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
                        c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_lpartials);
@@ -1937,7 +1964,7 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
 
 int qr_k_tree_finish(qr_ctx *c, int newton) {
   const unsigned sgrid = (unsigned)((c->N + QR_SLICE - 1) / QR_SLICE);
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, c->stream, c->d_tree);
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, c->stream, c->d_tree);
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_leaf_sums, dim3(sgrid), dim3(256), 0, c->stream, c->d_tree,
                      c->d_order[0], c->d_order[1], c->d_lambda,

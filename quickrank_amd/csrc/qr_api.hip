@@ -434,7 +434,10 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, dalloc(&c->d_order[0], N));
   QR_CHECK(c, dalloc(&c->d_order[1], N));
   QrPlan plan;
-  qr_make_plan((uint32_t)N, c->nblocks, c->blocks.data(), c->ncu, &plan);
+  qr_make_plan((uint32_t)N, c->nblocks, c->blocks.data(),
+               qr_plan_quantum((unsigned long long)N * qr_plan_wsum(c->nblocks, c->blocks.data()),
+                               c->ncu - c->nblocks),
+               &plan);
   c->partial_slots = (size_t)c->ncu * plan.kmax;
   QR_CHECK(c, dalloc(&c->d_partials, c->partial_slots * 256 * 64));
   {
@@ -757,9 +760,9 @@ static int ensure_level_buffers(qr_ctx *c, size_t depth) {
   const size_t G = (size_t)c->ncu;
   const size_t hist_wgs = G + nodes * (size_t)(c->nblocks + 1);
   const size_t part_wgs = c->N / QR_PART_SLICE + nodes + 2;
-  // docs per histogram workgroup <= wsum * N / G + QR_SLICE (k_obl_plan hands out
-  // workgroups in proportion to the node sizes), hence flushes per workgroup:
-  const size_t kmax = (wsum * c->N / G + QR_SLICE + QR_DPW - 1) / QR_DPW;
+  // k_obl_plan's quantum is <= (N/2) * wsum / (G/4) + 1 units, so a workgroup gets at
+  // most 2 * wsum * N / G + 1 + QR_SLICE documents, hence flushes per workgroup:
+  const size_t kmax = (2 * wsum * c->N / G + 2 * QR_SLICE + QR_DPW - 1) / QR_DPW;
   const size_t slots = hist_wgs * kmax;
   if (hist_wgs > c->lhist_cap || part_wgs > c->lpart_cap || slots > c->lslots_cap ||
       nodes > c->lred_nodes) {

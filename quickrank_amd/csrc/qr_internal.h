@@ -43,23 +43,36 @@ struct alignas(16) QrPlan {
   int pad[2];               // sizeof == 528: keeps the dynamic-LDS base 16-B aligned
 };
 
-__host__ __device__ inline void qr_make_plan(uint32_t n, int nblocks,
-                                             const QrBlock *blk, int G,
-                                             QrPlan *p) {
+// The unit of histogram work is one document x 16 feature columns.  A launch is
+// planned by its quantum q = units per workgroup: a block of width fw gives each
+// of its workgroups ceil(q / (fw/16)) documents (rounded up to QR_SLICE), so every
+// workgroup of every block -- and, in level-wise growth, of every node of the
+// level -- carries the same load.
+__host__ __device__ inline uint32_t qr_plan_quantum(unsigned long long units_total, int G) {
+  if (G < 1) G = 1;
+  const unsigned long long q = (units_total + (unsigned)G - 1) / (unsigned)G;
+  return q < 1 ? 1u : (q > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)q);
+}
+__host__ __device__ inline int qr_plan_wsum(int nblocks, const QrBlock *blk) {
   int wsum = 0;
   for (int b = 0; b < nblocks; ++b) wsum += blk[b].fw / 16;
+  return wsum;
+}
+__host__ __device__ inline void qr_make_plan(uint32_t n, int nblocks,
+                                             const QrBlock *blk, uint32_t q,
+                                             QrPlan *p) {
   p->wg_start[0] = 0;
   p->kmax = 1;
   for (int b = 0; b < nblocks; ++b) {
-    int W = G * (blk[b].fw / 16) / wsum;
-    if (W < 1) W = 1;
-    uint32_t per = (n + W - 1) / W;
+    const uint32_t u = (uint32_t)(blk[b].fw / 16);
+    unsigned long long per = ((unsigned long long)q + u - 1) / u;
     per = (per + QR_SLICE - 1) / QR_SLICE * QR_SLICE;
     if (per == 0) per = QR_SLICE;
-    int weff = (int)((n + per - 1) / per);
-    p->per[b] = per;
+    if (per > 0x7FFFFC00ull) per = 0x7FFFFC00ull;
+    const int weff = (int)(((unsigned long long)n + per - 1) / per);
+    p->per[b] = (uint32_t)per;
     p->wg_start[b + 1] = p->wg_start[b] + weff;
-    int k = (int)((per + QR_DPW - 1) / QR_DPW);
+    const int k = (int)((per + QR_DPW - 1) / QR_DPW);
     if (k > p->kmax) p->kmax = k;
   }
 }
@@ -127,7 +140,7 @@ struct QrLevelNode {
   uint32_t begin, end, lcount;     // the node's segment and its left count
   uint32_t small_begin, small_n;   // directly built child
   int32_t parent_slot, small_slot, big_slot;
-  int32_t G;                       // histogram workgroups planned for the node
+  uint32_t q;                      // the level's plan quantum (same for all its nodes)
   uint32_t slot_base;              // first partial slot
   uint32_t part_first;             // first partition workgroup (global index)
   uint32_t pad;

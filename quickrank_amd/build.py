@@ -51,7 +51,7 @@ def build_host(force=False, verbose=False):
         return outs
     os.makedirs(BINDIR, exist_ok=True)
     cxx = os.environ.get("CXX", "g++")
-    common = [cxx, "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wno-unused-result"]
+    common = [cxx, "-std=c++17", "-O2", "-fPIC", "-fopenmp", "-Wall", "-Wno-unused-result"]
     core = [os.path.join(HOST, f) for f in HOST_SRCS]
     link = ["-L" + LIBDIR, "-lqr_hip", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,$ORIGIN"]
     cmds = [common + ["-shared", "-o", HOST_LIB] + core + [os.path.join(HOST, "host_capi.cc")] + link,

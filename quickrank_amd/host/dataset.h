@@ -2,6 +2,7 @@
 // reference): row-major f32 features, f32 labels, query offsets built from runs
 // of equal consecutive qids (dataset.cc:63-87).
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
@@ -43,6 +44,22 @@ class Dataset {
     }
     num_instances_++;
     offsets_.back() = num_instances_;
+  }
+
+  // bulk construction (parallel readers): rows are written in place through at()
+  // and set_label(); close_rows() then derives the queries from the qid column
+  // with the same rule as addInstance (a new query at every change of qid)
+  void set_label(size_t doc, Label l) { labels_[doc] = l; }
+  void close_rows(const std::vector<QueryID> &qids) {
+    for (size_t i = 0; i < qids.size() && i < max_instances_; ++i) {
+      if (i == 0 || last_instance_id_ != qids[i]) {
+        num_queries_++;
+        offsets_.push_back(0);
+        last_instance_id_ = qids[i];
+      }
+      offsets_.back() = i + 1;
+    }
+    num_instances_ = std::min(qids.size(), max_instances_);
   }
 
   Feature *at(size_t doc, size_t f) { return data_.data() + doc * num_features_ + f; }

@@ -1,118 +1,238 @@
+// svml.cc -- SVMLight / LETOR reader and writer.
+//
+// Grammar and exit codes are the reference's (src/io/svml.cc:38-161 with the
+// tokeniser of src/utils/strutils.cc:36-74); the implementation is not: the file is
+// read into memory once, cut into one chunk per thread at line boundaries, every
+// chunk is parsed independently into (label, qid, sparse features) runs, and the
+// dense row-major matrix is filled in a second parallel pass once the number of
+// features (the largest feature id of the whole file) is known.  The reference's
+// serial getline + sscanf loop is the end-to-end bottleneck once training runs on
+// the GPU.
+//
+// What a line means, restated (the reference works on a NUL-terminated copy of the
+// line, so a NUL byte ends the line early):
+//   * leading white space (" \t\n\v\f\r") is skipped; a line whose first other
+//     character is '#' is a comment;
+//   * the first token is the label (atof); a line without one -- blank lines
+//     included -- ends the program with status 2;
+//   * the next token must spell "qid:" as far as it goes (status 1), the rest is
+//     read like atoi; a negative value is status 3; a missing token is qid 0;
+//   * then feature tokens "id:value" up to a token that STARTS with '#'.  A '#'
+//     inside a token ends that token and is swallowed (what follows is parsed as
+//     more tokens).  A token that sscanf("%zu:%f") would not fully convert is
+//     status 4.  The value is rounded as strtof does; trailing junk in a token is
+//     ignored; the last occurrence of an id wins;
+//   * the number of features is the largest id seen; queries are runs of equal
+//     consecutive qids (dataset.cc:78-85).
+// Deliberate differences, both on inputs where the reference has undefined
+// behaviour: feature id 0 and signed feature ids (which %zu accepts and wraps
+// around) are reported as malformed tokens (status 4).
 #include "svml.h"
 
+#include <omp.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
-#include <fstream>
-#include <iomanip>
-#include <limits>
-#include <list>
 
 namespace quickrank {
 namespace io {
 
 namespace {
-inline bool isspc(char ch) { return ch == ' ' || ch == '\t' || ch == '\n' || ch == '\v' || ch == '\f' || ch == '\r'; }
 
-// strutils.cc:36-47: skip spaces, return the token closed at the next space; if
-// `exitch` is the first non-space the function returns immediately.
-char *read_token(char *&str, const char exitch = '\0') {
-  while (isspc(*str) && *str != '\0') ++str;
-  if (*str == exitch) return str;
-  char *token = str;
-  while (!isspc(*str) && *str != '\0' && *str != exitch) ++str;
-  if (*str != '\0') *str++ = '\0';
-  return token;
+inline bool blank(char ch) {
+  return ch == ' ' || ch == '\t' || ch == '\n' || ch == '\v' || ch == '\f' || ch == '\r';
 }
 
-// strutils.cc:63-74
-unsigned int atou(char *str, const char *sep) {
-  while (isspc(*str) && *str != '\0') ++str;
-  for (size_t i = 0; sep[i] != '\0' && *str != '\0'; ++i, ++str)
-    if (*str != sep[i]) exit(1);
-  int x = atoi(str);
-  if (x < 0) exit(3);
-  return (unsigned int)x;
+// everything one thread extracted from its share of the file
+struct Piece {
+  std::vector<float> label;
+  std::vector<unsigned> qid;
+  std::vector<size_t> first;   // index of the row's first (id, value) pair
+  std::vector<unsigned> fid;
+  std::vector<float> val;
+  size_t widest = 0;           // largest feature id
+  size_t bad_at = (size_t)-1;  // byte offset of the first malformed line
+  int bad_code = 0;
+};
+
+struct Cursor {
+  const char *p, *end;
+  void skip_blanks() {
+    while (p < end && blank(*p)) ++p;
+  }
+  // [p, q): up to the next blank, the end of the line or (optionally) '#'; one
+  // delimiter is consumed, whatever it is
+  const char *token(bool hash_ends, const char **stop) {
+    const char *b = p;
+    while (p < end && !blank(*p) && !(hash_ends && *p == '#')) ++p;
+    *stop = p;
+    if (p < end) ++p;
+    return b;
+  }
+};
+
+// returns 0 or the exit status the line calls for
+int parse_line(const char *b, const char *e, Piece &out) {
+  if (const void *nul = memchr(b, '\0', (size_t)(e - b))) e = (const char *)nul;
+  Cursor c{b, e};
+  c.skip_blanks();
+  if (c.p < c.end && *c.p == '#') return -1;  // comment
+  if (c.p == c.end) return 2;                 // the label is mandatory
+  const char *stop;
+  const char *tok = c.token(false, &stop);
+  const float label = (float)strtod(tok, nullptr);  // stops at the blank that ends the token
+  // qid
+  c.skip_blanks();
+  long long q = 0;
+  if (c.p < c.end) {
+    tok = c.token(false, &stop);
+    static const char want[] = "qid:";
+    const char *s = tok;
+    for (int i = 0; want[i] && s < stop; ++i, ++s)
+      if (*s != want[i]) return 1;
+    bool neg = false;
+    if (s < stop && (*s == '-' || *s == '+')) neg = *s++ == '-';
+    for (; s < stop && *s >= '0' && *s <= '9'; ++s) q = q * 10 + (*s - '0');
+    if (neg) q = -q;
+    if ((int)q < 0) return 3;
+  }
+  out.label.push_back(label);
+  out.qid.push_back((unsigned)(int)q);
+  out.first.push_back(out.fid.size());
+  // features
+  for (;;) {
+    c.skip_blanks();
+    if (c.p == c.end || *c.p == '#') break;  // end of line / trailing description
+    tok = c.token(true, &stop);
+    const char *s = tok;
+    size_t id = 0;
+    if (s == stop || *s < '0' || *s > '9') return 4;
+    for (; s < stop && *s >= '0' && *s <= '9'; ++s) id = id * 10 + (size_t)(*s - '0');
+    if (s == stop || *s != ':' || id == 0 || id > 0xFFFFFFFFull) return 4;
+    ++s;
+    if (s == stop) return 4;  // "id:" with nothing behind it
+    char *after;
+    const float v = strtof(s, &after);  // cannot run past `stop`: blanks and '#' end a number
+    if (after == s) return 4;
+    out.fid.push_back((unsigned)id);
+    out.val.push_back(v);
+    if (id > out.widest) out.widest = id;
+  }
+  return 0;
 }
+
+void parse_range(const char *base, size_t lo, size_t hi, Piece &out) {
+  size_t at = lo;
+  while (at < hi) {
+    const char *nl = (const char *)memchr(base + at, '\n', hi - at);
+    const size_t stop = nl ? (size_t)(nl - base) : hi;
+    // a '\n'-terminated empty line is a line (status 2); bytes after the last '\n'
+    // are a line only if there are any (getline returns -1 at end of file)
+    if (nl || stop > at) {
+      const int rc = parse_line(base + at, base + stop, out);
+      if (rc > 0) {
+        out.bad_at = at;
+        out.bad_code = rc;
+        return;
+      }
+    }
+    at = stop + 1;
+  }
+}
+
 }  // namespace
 
 std::unique_ptr<data::Dataset> Svml::read_horizontal(const std::string &filename) {
-  FILE *f = fopen(filename.c_str(), "r");
+  FILE *f = fopen(filename.c_str(), "rb");
   if (!f) {
     std::cerr << "!!! Error while opening file " << filename << "." << std::endl;
     exit(EXIT_FAILURE);
   }
-  struct stat filestatus;
-  stat(filename.c_str(), &filestatus);
-  file_size_ = filestatus.st_size;
-  auto t0 = std::chrono::high_resolution_clock::now();
-
-  size_t maxfid = 0;
-  std::list<size_t> data_qids;
-  std::list<Label> data_labels;
-  std::list<std::vector<Feature>> data_instances;
-
-  char *line = NULL;
-  size_t linelength = 0;
-  while (!feof(f)) {
-    ssize_t nread = getline(&line, &linelength, f);
-    if (nread <= 0) continue;
-    char *token = NULL, *pch = line;
-    while (isspc(*pch) && *pch != '\0') ++pch;
-    if (*pch == '#') continue;  // comment line
-    if (*(token = read_token(pch)) == '\0') exit(2);  // label is mandatory (ISEMPTY, strutils.h:44)
-    Label relevance = atof(token);
-    size_t qid = atou(read_token(pch), "qid:");
-    std::vector<Feature> curr_instance(maxfid);
-    while (*(token = read_token(pch, '#')) != '\0') {
-      if (*token == '#') {
-        *pch = '\0';  // trailing description
-      } else {
-        size_t fid = 0;
-        float fval = 0.0f;
-        if (sscanf(token, "%zu:%f", &fid, &fval) != 2) exit(4);
-        if (fid > maxfid) {
-          maxfid = fid;
-          curr_instance.resize(maxfid);
-        }
-        curr_instance[fid - 1] = fval;
-      }
-    }
-    data_qids.push_back(qid);
-    data_labels.push_back(relevance);
-    data_instances.push_back(std::move(curr_instance));
-  }
-  free(line);
+  struct stat st;
+  stat(filename.c_str(), &st);
+  file_size_ = st.st_size;
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  std::vector<char> text((size_t)file_size_ + 1);
+  const size_t got = fread(text.data(), 1, (size_t)file_size_, f);
   fclose(f);
-  auto t1 = std::chrono::high_resolution_clock::now();
+  text[got] = '\0';  // strtod / strtof may look one byte past the last token
 
-  auto dataset = std::unique_ptr<data::Dataset>(new data::Dataset(data_qids.size(), maxfid));
-  auto i_q = data_qids.begin();
-  auto i_l = data_labels.begin();
-  auto i_x = data_instances.begin();
-  for (; i_q != data_qids.end(); ++i_q, ++i_l, ++i_x)
-    dataset->addInstance((QueryID)*i_q, *i_l, *i_x);
-  auto t2 = std::chrono::high_resolution_clock::now();
+  int nthreads = omp_get_max_threads();
+  if ((size_t)nthreads > got / (1 << 16) + 1) nthreads = (int)(got / (1 << 16) + 1);
+  std::vector<size_t> cut(nthreads + 1, got);
+  cut[0] = 0;
+  for (int t = 1; t < nthreads; ++t) {  // chunk borders on line starts
+    size_t at = got / nthreads * t;
+    if (at < cut[t - 1]) at = cut[t - 1];
+    const char *nl = (const char *)memchr(text.data() + at, '\n', got - at);
+    cut[t] = nl ? (size_t)(nl - text.data()) + 1 : got;
+  }
+  std::vector<Piece> pieces(nthreads);
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+  for (int t = 0; t < nthreads; ++t) parse_range(text.data(), cut[t], cut[t + 1], pieces[t]);
+  // the reference stops at the FIRST malformed line of the file
+  for (const Piece &p : pieces)
+    if (p.bad_code) exit(p.bad_code);
+  const auto t1 = std::chrono::high_resolution_clock::now();
+
+  size_t rows = 0, width = 0;
+  std::vector<size_t> row0(nthreads + 1, 0);
+  for (int t = 0; t < nthreads; ++t) {
+    row0[t] = rows;
+    rows += pieces[t].label.size();
+    width = std::max(width, pieces[t].widest);
+  }
+  row0[nthreads] = rows;
+  auto dataset = std::unique_ptr<data::Dataset>(new data::Dataset(rows, width));
+  std::vector<QueryID> qids(rows);
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+  for (int t = 0; t < nthreads; ++t) {
+    const Piece &p = pieces[t];
+    for (size_t r = 0; r < p.label.size(); ++r) {
+      const size_t i = row0[t] + r;
+      qids[i] = p.qid[r];
+      Feature *row = dataset->at(i, 0);
+      const size_t hi = r + 1 < p.first.size() ? p.first[r + 1] : p.fid.size();
+      for (size_t k = p.first[r]; k < hi; ++k) row[p.fid[k] - 1] = p.val[k];  // later pairs win
+      dataset->set_label(i, p.label[r]);
+    }
+  }
+  dataset->close_rows(qids);
+  const auto t2 = std::chrono::high_resolution_clock::now();
   reading_time_ = std::chrono::duration<double>(t1 - t0).count();
   processing_time_ = std::chrono::duration<double>(t2 - t1).count();
   return dataset;
 }
 
-// svml.cc:163-188
+// Same bytes as svml.cc:163-188 produces through its iostream manipulators: the
+// very first label is printed in the default float format with precision 0
+// ("%.0g"); std::fixed then stays set, so every later label comes out as "%.0f";
+// feature values are "%.9f" (max_digits10 of float).
 void Svml::write(const data::Dataset &dataset, const std::string &file) {
-  std::ofstream out(file, std::ofstream::out | std::ofstream::trunc);
-  for (size_t q = 0; q < dataset.num_queries(); q++) {
-    for (size_t r = dataset.offset(q); r < dataset.offset(q + 1); r++) {
-      out << std::setprecision(0) << dataset.getLabel(r) << " qid:" << q + 1;
+  FILE *out = fopen(file.c_str(), "w");
+  if (!out) {
+    std::cerr << "!!! Error while opening file " << file << "." << std::endl;
+    exit(EXIT_FAILURE);
+  }
+  std::vector<char> line;
+  bool first = true;
+  for (size_t q = 0; q < dataset.num_queries(); ++q) {
+    for (size_t r = dataset.offset(q); r < dataset.offset(q + 1); ++r) {
+      line.resize(64 + dataset.num_features() * 96);  // FLT_MAX in %.9f is 49 characters
+      size_t n = (size_t)snprintf(line.data(), 64, first ? "%.0g qid:%zu" : "%.0f qid:%zu",
+                                  (double)dataset.getLabel(r), q + 1);
+      first = false;
       const Feature *x = dataset.at(r, 0);
-      for (size_t f = 0; f < dataset.num_features(); f++)
-        out << " " << f + 1 << ":" << std::fixed
-            << std::setprecision(std::numeric_limits<Feature>::max_digits10) << x[f];
-      out << std::endl;
+      for (size_t i = 0; i < dataset.num_features(); ++i)
+        n += (size_t)snprintf(line.data() + n, 96, " %zu:%.9f", i + 1, (double)x[i]);
+      line[n++] = '\n';
+      fwrite(line.data(), 1, n, out);
     }
   }
+  fclose(out);
 }
 
 }  // namespace io

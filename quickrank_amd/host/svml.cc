@@ -153,10 +153,10 @@ std::unique_ptr<data::Dataset> Svml::read_horizontal(const std::string &filename
   }
   struct stat st;
   stat(filename.c_str(), &st);
-  file_size_ = st.st_size;
+  stats_.bytes = st.st_size;
   const auto t0 = std::chrono::high_resolution_clock::now();
-  std::vector<char> text((size_t)file_size_ + 1);
-  const size_t got = fread(text.data(), 1, (size_t)file_size_, f);
+  std::vector<char> text((size_t)stats_.bytes + 1);
+  const size_t got = fread(text.data(), 1, (size_t)stats_.bytes, f);
   fclose(f);
   text[got] = '\0';  // strtod / strtof may look one byte past the last token
 
@@ -202,8 +202,8 @@ std::unique_ptr<data::Dataset> Svml::read_horizontal(const std::string &filename
   }
   dataset->close_rows(qids);
   const auto t2 = std::chrono::high_resolution_clock::now();
-  reading_time_ = std::chrono::duration<double>(t1 - t0).count();
-  processing_time_ = std::chrono::duration<double>(t2 - t1).count();
+  stats_.parse_s = std::chrono::duration<double>(t1 - t0).count();
+  stats_.fill_s = std::chrono::duration<double>(t2 - t1).count();
   return dataset;
 }
 

@@ -1,5 +1,6 @@
-// svml.h -- SVMLight / LETOR reader and writer with the reference's grammar
-// (src/io/svml.cc:38-188, src/utils/strutils.cc:36-74).
+// svml.h -- SVMLight / LETOR text format: parallel reader, writer.
+// Same grammar, exit statuses and public method names as the reference's io::Svml
+// (src/io/svml.cc:38-188); see svml.cc for what a line means.
 #pragma once
 #include <memory>
 #include <string>
@@ -10,18 +11,24 @@ namespace quickrank {
 namespace io {
 
 class Svml {
- public:
-  // Exits with the reference's codes on malformed input: 1 (missing "qid:"),
-  // 2 (missing label), 3 (negative qid), 4 (malformed feature token).
-  std::unique_ptr<data::Dataset> read_horizontal(const std::string &filename);
-  void write(const data::Dataset &dataset, const std::string &file);
-  double reading_time() const { return reading_time_; }
-  double processing_time() const { return processing_time_; }
-  long file_size() const { return file_size_; }
+  // seconds spent parsing the text / filling the dense matrix, bytes of the file
+  struct Stats {
+    double parse_s = 0.0, fill_s = 0.0;
+    long bytes = 0;
+  } stats_;
 
- private:
-  double reading_time_ = 0, processing_time_ = 0;
-  long file_size_ = 0;
+ public:
+  // Malformed input ends the program like the reference does: status 1 (a second
+  // token that is not "qid:..."), 2 (no label: blank lines included), 3 (negative
+  // qid), 4 (a feature token that is not "id:value").
+  std::unique_ptr<data::Dataset> read_horizontal(const std::string &path);
+
+  // one line per document: "<label> qid:<q> 1:<v1> 2:<v2> ..." (every feature, %.9f)
+  void write(const data::Dataset &dataset, const std::string &path);
+
+  double reading_time() const { return stats_.parse_s; }
+  double processing_time() const { return stats_.fill_s; }
+  long file_size() const { return stats_.bytes; }
 };
 
 }  // namespace io

@@ -293,40 +293,65 @@ void Mart::learn(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::
   }
   auto t_train0 = std::chrono::high_resolution_clock::now();
   std::vector<qr_node_t> nodes(obliv ? ((size_t)1 << (treedepth_ + 1)) : 2 * nleaves_ + 1);
-  for (size_t m = ensemble_model_.get_size(); m < ntrees_; ++m) {
+  // One table line (mart.cc:351-376): the best-model bookkeeping on the way.
+  auto report = [&](size_t iter, MetricScore on_training, const MetricScore *on_validation) {
+    std::cout << std::setw(7) << iter << std::setw(9) << on_training;
+    if (on_validation) {
+      std::cout << std::setw(9) << *on_validation;
+      if (*on_validation > best_metric_on_validation_) {
+        best_metric_on_training_ = on_training;
+        best_metric_on_validation_ = *on_validation;
+        best_model_ = iter - 1;
+        std::cout << " *";
+      }
+    } else if (on_training > best_metric_on_training_) {
+      best_metric_on_training_ = on_training;
+      best_model_ = iter - 1;
+      std::cout << " *";
+    }
+    std::cout << std::endl;
+  };
+  // Without a validation set nothing decided inside the loop depends on the
+  // training metric, and the lambda pass of iteration m+1 ranks exactly the scores
+  // whose metric iteration m reports (mart.cc:347 vs lambdamart.cc:104): the value
+  // is then a by-product of that pass (qr_metric_last) and the line of iteration m
+  // is printed one iteration late -- same numbers, one ranking pass per iteration
+  // instead of two, and no stream drain in between.
+  const bool lagged = lambda && !validation;
+  const size_t first = ensemble_model_.get_size();
+  for (size_t m = first; m < ntrees_; ++m) {
     if (validation && (valid_iterations_ && m > best_model_ + valid_iterations_)) break;
     if (lambda)
       QR(qr_lambda_compute(ctx_, mcode, cutoff));  // lambdamart.cc:62-152
     else
       QR(qr_residual_compute(ctx_));               // mart.cc:418-431
-    size_t nn = 0;
     if (obliv)
-      QR(qr_oblivious_fit(ctx_, treedepth_, minleafsupport_, lambda, nodes.data(), &nn));
+      QR(qr_oblivious_fit(ctx_, treedepth_, minleafsupport_, lambda, nullptr, nullptr));
     else
-      QR(qr_tree_fit(ctx_, nleaves_, minleafsupport_, lambda, nodes.data(), &nn));
-    ensemble_model_.push(tree_from_records(nodes.data(), 0), shrinkage_);  // mart.cc:342
+      QR(qr_tree_fit(ctx_, nleaves_, minleafsupport_, lambda, nullptr, nullptr));
     QR(qr_scores_update(ctx_, shrinkage_));                                // mart.cc:345, :356
-    MetricScore metric_on_training = 0;
-    QR(qr_metric_eval(ctx_, 0, mcode, cutoff, &metric_on_training));       // mart.cc:347
-    std::cout << std::setw(7) << m + 1 << std::setw(9) << metric_on_training;
-    if (validation) {
-      MetricScore metric_on_validation = 0;
-      QR(qr_metric_eval(ctx_, 1, mcode, cutoff, &metric_on_validation));   // mart.cc:359
-      std::cout << std::setw(9) << metric_on_validation;
-      if (metric_on_validation > best_metric_on_validation_) {
-        best_metric_on_training_ = metric_on_training;
-        best_metric_on_validation_ = metric_on_validation;
-        best_model_ = ensemble_model_.get_size() - 1;
-        std::cout << " *";
-      }
-    } else if (metric_on_training > best_metric_on_training_) {
-      best_metric_on_training_ = metric_on_training;
-      best_model_ = ensemble_model_.get_size() - 1;
-      std::cout << " *";
+    if (lagged && m > first) {
+      MetricScore prev = 0;
+      QR(qr_metric_last(ctx_, &prev));  // waits for this iteration's lambda pass only
+      report(m, prev, nullptr);
     }
-    std::cout << std::endl;
+    size_t nn = 0;
+    QR(qr_tree_nodes(ctx_, nodes.data(), &nn));                            // waits for the tree only
+    ensemble_model_.push(tree_from_records(nodes.data(), 0), shrinkage_);  // mart.cc:342
+    if (!lagged) {
+      MetricScore metric_on_training = 0, metric_on_validation = 0;
+      QR(qr_metric_eval(ctx_, 0, mcode, cutoff, &metric_on_training));     // mart.cc:347
+      if (validation)
+        QR(qr_metric_eval(ctx_, 1, mcode, cutoff, &metric_on_validation)); // mart.cc:359
+      report(m + 1, metric_on_training, validation ? &metric_on_validation : nullptr);
+    }
     if (partial_save != 0 && !output_basename.empty() && (m + 1) % partial_save == 0)
       save(output_basename, (int)(m + 1));
+  }
+  if (lagged && ensemble_model_.get_size() > first) {
+    MetricScore last = 0;
+    QR(qr_metric_eval(ctx_, 0, mcode, cutoff, &last));
+    report(ensemble_model_.get_size(), last, nullptr);
   }
   // rollback to the best model observed on the validation data (mart.cc:390-395)
   if (validation)

@@ -129,6 +129,8 @@ int qr_scores_reset(qr_ctx *ctx);                       /* zero train+valid     
 int qr_scores_set(qr_ctx *ctx, const double *scores);   /* host [N] -> device    */
 int qr_scores_get(qr_ctx *ctx, double *scores);         /* device -> host [N]    */
 int qr_valid_scores_get(qr_ctx *ctx, double *scores);
+/* restart from a loaded model (mart.cc:237-253): validation scores of that model */
+int qr_valid_scores_set(qr_ctx *ctx, const double *scores);
 int qr_pseudo_get(qr_ctx *ctx, double *lambda, double *weight); /* NULL = skip   */
 int qr_pseudo_set(qr_ctx *ctx, const double *lambda, const double *weight);
 

@@ -38,7 +38,7 @@ SYMBOLS = [
     "qr_prof_get", "qr_prof_enable", "qr_oblivious_upload", "qr_oblivious_score",
     "qr_ctx_set_doc_shard", "qr_bins_stats", "qr_thresholds_from_stats",
     "qr_bins_build_with", "qr_lambda_finish", "qr_tree_leaves_finish",
-    "qr_doc_exchange_buffers", "qr_tree_nodes",
+    "qr_doc_exchange_buffers", "qr_tree_nodes", "qr_valid_scores_set",
 ]
 
 _LIB = None
@@ -77,6 +77,7 @@ def lib():
     L.qr_scores_set.argtypes = [vp, vp]
     L.qr_scores_get.argtypes = [vp, vp]
     L.qr_valid_scores_get.argtypes = [vp, vp]
+    L.qr_valid_scores_set.argtypes = [vp, vp]
     L.qr_pseudo_get.argtypes = [vp, vp, vp]
     L.qr_pseudo_set.argtypes = [vp, vp, vp]
     L.qr_lambda_compute.argtypes = [vp, C.c_int, sz]
@@ -238,6 +239,11 @@ class Context:
         s = np.empty(self.N, np.float64)
         self._ck(self.L.qr_scores_get(self.h, _ptr(s)))
         return s
+
+    def set_valid_scores(self, s):
+        s = np.ascontiguousarray(s, np.float64)
+        assert len(s) == self.vN
+        self._ck(self.L.qr_valid_scores_set(self.h, _ptr(s)))
 
     def get_valid_scores(self):
         s = np.empty(self.vN, np.float64)

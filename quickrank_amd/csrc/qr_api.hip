@@ -573,6 +573,13 @@ int qr_scores_set(qr_ctx *c, const double *s) {
   QR_CHECK(c, hipMemcpy(c->d_scores, s, c->N * 8, hipMemcpyHostToDevice));
   return QR_OK;
 }
+int qr_valid_scores_set(qr_ctx *c, const double *s) {
+  if (!c || !s) return QR_ERR_ARG;
+  if (!c->d_vscores) QR_FAIL(c, QR_ERR_STATE, "no validation set uploaded");
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(c->d_vscores, s, c->vN * 8, hipMemcpyHostToDevice));
+  return QR_OK;
+}
 int qr_scores_get(qr_ctx *c, double *s) {
   if (!c || !c->d_scores || !s) return QR_ERR_ARG;
   QR_CHECK(c, hipStreamSynchronize(c->stream));

@@ -271,10 +271,10 @@ void Mart::learn(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::
     QR(qr_scores_set(ctx_, s.data()));
     QR(qr_metric_eval(ctx_, 0, mcode, cutoff, &best_metric_on_training_));
     if (validation) {
-      // validation scores live on the device: re-scoring them needs the same path
-      std::cerr << "!!! --restart-train with a validation set is not supported by the device build yet."
-                << std::endl;
-      exit(EXIT_FAILURE);
+      std::vector<Score> v(validation->num_instances());
+      score_dataset(*validation, v.data());
+      QR(qr_valid_scores_set(ctx_, v.data()));
+      QR(qr_metric_eval(ctx_, 1, mcode, cutoff, &best_metric_on_validation_));
     }
   }
   auto t_init1 = std::chrono::high_resolution_clock::now();

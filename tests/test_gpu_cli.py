@@ -131,3 +131,58 @@ def test_quicklearn_rejects_out_of_scope_and_bad_input(tools, tmp_path):
     open(bad, "w").write("1 qid:3 1:2 x:y\n")
     r = subprocess.run([tools["quicklearn"], "--train", bad], capture_output=True, text=True)
     assert r.returncode == 4            # svml.cc:112: malformed feature -> exit(4)
+
+
+@pytest.mark.parametrize("with_valid", [False, True])
+def test_restart_train_continues_the_same_model(tools, tmp_path, with_valid):
+    """--model-in + --restart-train (mart.cc:237-253): 3 trees, then 3 more on top of
+    the reloaded model == 6 trees in one go, with and without a validation set (its
+    scores are re-derived from the loaded model too)."""
+    x, labels, qoff = make_dataset(nq=120, docs_per_query=40, F=20, seed=11)
+    x = np.array([[np.float32(f"{float(v):.9g}") for v in row] for row in x], np.float32)
+    vx, vl, vq = make_dataset(nq=40, docs_per_query=30, F=20, seed=12)
+    tr, va = str(tmp_path / "train.svml"), str(tmp_path / "valid.svml")
+    _write_svml(tr, x, labels, qoff)
+    _write_svml(va, vx, vl, vq)
+    common = ["--algo", "LAMBDAMART", "--train", tr, "--num-leaves", "8", "--shrinkage", "0.1",
+              "--num-thresholds", "64", "--min-leaf-support", "5", "--end-after-rounds", "0"]
+    if with_valid:
+        common += ["--valid", va]
+    full, part, cont = (str(tmp_path / n) for n in ("full.xml", "part.xml", "cont.xml"))
+
+    def run(extra):
+        r = subprocess.run([tools["quicklearn"]] + common + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r.stdout
+    def table(out):
+        rows = {}
+        for ln in out.splitlines():
+            t = ln.replace("*", "").split()
+            if t and t[0].isdigit() and len(t) >= 2:
+                rows[int(t[0])] = tuple(t[1:])
+        return rows
+    t_full = table(run(["--num-trees", "6", "--model-out", full]))
+    if with_valid:
+        # with validation the saved model is rolled back to the best iteration
+        # (mart.cc:390-395): stop the first leg where nothing is rolled back
+        t_part = table(run(["--num-trees", "3", "--model-out", part, "--end-after-rounds", "0"]))
+        best = max(t_part, key=lambda i: (float(t_part[i][1]), -i))
+        kept = len(_load_model(tools, part)[0])
+        assert kept == best
+    else:
+        run(["--num-trees", "3", "--model-out", part])
+        kept = 3
+    t_cont = table(run(["--num-trees", "6", "--model-in", part, "--restart-train", "--model-out", cont]))
+    # the continued run prints the reloaded model's line, then the same metrics the
+    # one-go run printed for the iterations it adds
+    assert kept in t_cont
+    if kept == 3:
+        for i in (4, 5, 6):
+            assert t_cont[i] == t_full[i], (i, t_cont, t_full)
+    if not with_valid:
+        a, wa = _load_model(tools, full)
+        b, wb = _load_model(tools, cont)
+        assert len(a) == len(b) == 6 and np.array_equal(wa, wb)
+        for k in ("feature", "threshold", "left", "right"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.allclose(a["value"], b["value"], rtol=1e-12, atol=0)

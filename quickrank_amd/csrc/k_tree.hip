@@ -493,27 +493,31 @@ __global__ __launch_bounds__(256) void k_scan(
   {
     Best v = slot_gain(s, cn, tot_s[0], tot_c[0], t, tsize, minls, inv_scale);
     v = block_best(v, sh_b);
+    const int which = root_mode ? 0 : (small_is_left ? 0 : 1);
+    qr_split_t *o = &featrec[(size_t)which * flocal + lf];
     if (t == 0) {
-      const int which = root_mode ? 0 : (small_is_left ? 0 : 1);
-      qr_split_t *o = &featrec[(size_t)which * flocal + lf];
       o->score = v.score;
       o->feature = v.t == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)gf;
       o->thr_id = v.t;
-      o->lcount = 0;
-      o->rcount = 0;
+    }
+    if (t == (v.t == 0xFFFFFFFFu ? 0u : v.t)) {  // the winning slot knows its counts
+      o->lcount = v.t == 0xFFFFFFFFu ? 0 : cn;
+      o->rcount = v.t == 0xFFFFFFFFu ? 0 : tot_c[0] - cn;
     }
   }
   if (!root_mode) {
     Best v = slot_gain(bs, bc, tot_s[1], tot_c[1], t, tsize, minls, inv_scale);
     v = block_best(v, sh_b);
+    const int which = small_is_left ? 1 : 0;
+    qr_split_t *o = &featrec[(size_t)which * flocal + lf];
     if (t == 0) {
-      const int which = small_is_left ? 1 : 0;
-      qr_split_t *o = &featrec[(size_t)which * flocal + lf];
       o->score = v.score;
       o->feature = v.t == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)gf;
       o->thr_id = v.t;
-      o->lcount = 0;
-      o->rcount = 0;
+    }
+    if (t == (v.t == 0xFFFFFFFFu ? 0u : v.t)) {
+      o->lcount = v.t == 0xFFFFFFFFu ? 0 : bc;
+      o->rcount = v.t == 0xFFFFFFFFu ? 0 : tot_c[1] - bc;
     }
   }
 }
@@ -572,9 +576,8 @@ __global__ __launch_bounds__(256) void k_scan_level(
 // (rt.cc:297-306).  Also attaches lcount/rcount from the node histogram.
 // ===========================================================================
 // merge by one wave; every lane returns the same record
-__device__ qr_split_t wave_merge(const QrTreeState *ts, const int root_mode, const int which,
-                                 const qr_split_t *featrec, const int flocal,
-                                 const uint32_t *hcnt, const int32_t *gf2lf) {
+__device__ qr_split_t wave_merge(const int root_mode, const int which,
+                                 const qr_split_t *featrec, const int flocal) {
   const int lane = threadIdx.x & 63;
   qr_split_t best;
   best.score = -1.0;
@@ -587,34 +590,23 @@ __device__ qr_split_t wave_merge(const QrTreeState *ts, const int root_mode, con
     if (r.score > best.score) best = r;  // ascending lf within the lane
   }
   // max score over the wave, equal scores -> lowest feature index; the lane that
-  // holds the winner hands out its slot
-  {
-    const double m = wave_max(best.score);
-    const bool cand = best.score == m && best.feature != 0xFFFFFFFFu;
-    const uint32_t fmin = wave_min_u32(cand ? best.feature : 0xFFFFFFFFu);
-    const unsigned long long hit = __ballot(cand && best.feature == fmin);
-    if (hit) {
-      const int src = __ffsll((long long)hit) - 1;
-      best.score = m;
-      best.feature = fmin;
-      best.thr_id = (uint32_t)__builtin_amdgcn_readlane((int)best.thr_id, src);
-    } else {
-      best.score = -1.0;
-      best.feature = 0xFFFFFFFFu;
-      best.thr_id = 0xFFFFFFFFu;
-    }
-  }
-  if (best.feature != 0xFFFFFFFFu) {
-    int slot;
-    if (root_mode)
-      slot = 0;
-    else
-      slot = which == 0 ? (ts->desc.small_is_left ? ts->desc.small_slot : ts->desc.big_slot)
-                        : (ts->desc.small_is_left ? ts->desc.big_slot : ts->desc.small_slot);
-    const int lf = gf2lf[best.feature];
-    const size_t base = ((size_t)slot * flocal + lf) * 256;
-    best.lcount = hcnt[base + best.thr_id];
-    best.rcount = (u64)hcnt[base + 255] - best.lcount;
+  // holds the winner hands out its slot and the counts k_scan recorded with it
+  const double m = wave_max(best.score);
+  const bool cand = best.score == m && best.feature != 0xFFFFFFFFu;
+  const uint32_t fmin = wave_min_u32(cand ? best.feature : 0xFFFFFFFFu);
+  const unsigned long long hit = __ballot(cand && best.feature == fmin);
+  if (hit) {
+    const int src = __ffsll((long long)hit) - 1;
+    best.score = m;
+    best.feature = fmin;
+    best.thr_id = (uint32_t)__builtin_amdgcn_readlane((int)best.thr_id, src);
+    best.lcount = (u64)readlane_i64((long long)best.lcount, src);
+    best.rcount = (u64)readlane_i64((long long)best.rcount, src);
+  } else {
+    best.score = -1.0;
+    best.feature = 0xFFFFFFFFu;
+    best.thr_id = 0xFFFFFFFFu;
+    best.lcount = best.rcount = 0;
   }
   return best;
 }
@@ -627,7 +619,7 @@ __global__ __launch_bounds__(128) void k_merge(
     const int32_t *__restrict__ gf2lf, qr_split_t *__restrict__ recs_local) {
   if (!root_mode && !ts->desc.active) return;
   const int which = threadIdx.x >> 6;  // wave 0: left child (or root), wave 1: right
-  const qr_split_t best = wave_merge(ts, root_mode, which, featrec, flocal, hcnt, gf2lf);
+  const qr_split_t best = wave_merge(root_mode, which, featrec, flocal);
   if ((threadIdx.x & 63) == 0) recs_local[which] = best;
 }
 
@@ -823,13 +815,11 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
     st.desc = &ts->desc;
   }
   if (world == 1) {
-    if (w0 && (root_mode || active)) {
-      const qr_split_t a = wave_merge(ts, root_mode, 0, featrec, flocal, hcnt, gf2lf);
-      const qr_split_t b = wave_merge(ts, root_mode, 1, featrec, flocal, hcnt, gf2lf);
-      if (threadIdx.x == 0) {
-        own[0] = a;
-        own[1] = b;
-      }
+    // wave 0 merges the left child's (or the root's) records, wave 1 the right child's
+    if (threadIdx.x < 128 && (root_mode || active)) {
+      const int which = threadIdx.x >> 6;
+      const qr_split_t a = wave_merge(root_mode, which, featrec, flocal);
+      if ((threadIdx.x & 63) == 0) own[which] = a;
     }
     recs = own;
   }
@@ -940,7 +930,7 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
   }
 }
 
-__global__ __launch_bounds__(64) void k_decide(
+__global__ __launch_bounds__(128) void k_decide(
     QrTreeState *ts, const uint32_t N, const int flocal, const qr_split_t *recs,
     const int world, const QrScalars *__restrict__ scal,
     const double *__restrict__ part_ss, const float *__restrict__ thr,
@@ -1867,7 +1857,7 @@ int qr_k_tree_decide(qr_ctx *c) {
   // (Letting k_scan's last workgroup take the decision saves this launch but was
   // measured slower: the agent-scope release/acquire it needs writes back and
   // invalidates the XCD L2s, 22.8 us for the fused kernel against 6 + 9 us.)
-  hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, c->d_tree,
+  hipLaunchKernelGGL(k_decide, dim3(1), dim3(128), 0, c->stream, c->d_tree,
                      (uint32_t)c->N, c->flocal, recs, fshard ? c->world : 1,
                      c->d_scalars, c->d_part_ss, c->d_thr, c->d_gf2lf, c->d_featrec,
                      c->d_hcnt, c->dmode, (u64)c->Nglobal,

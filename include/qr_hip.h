@@ -166,6 +166,23 @@ int qr_tree_fit(qr_ctx *ctx, size_t nleaves, uint64_t minls, int newton,
 /* copy enqueued right behind the tree's kernels, so this waits for the tree      */
 /* only -- not for work enqueued after it (score update, the next lambdas).       */
 int qr_tree_nodes(qr_ctx *ctx, qr_node_t *nodes_out, size_t *nnodes_out);
+/* --subsample (mart.cc:287-329, lambdamart.cc:85-102): every iteration fits its  */
+/* tree on a fresh uniform sample of the training documents: subsample > 1 = that */
+/* many, < 1 = that fraction (rounded down), 1 = all.  The next                   */
+/* qr_lambda_compute / qr_residual_compute draws the sample; lambdas are computed */
+/* on the queries cleaned of the other documents, the tree and its leaf outputs   */
+/* see the sample only, qr_scores_update updates every document.  The reference   */
+/* shuffles with a clock-seeded engine (and indexes the cleaned scores without    */
+/* the query offset, lambdamart.cc:94); here the sample is a pure function of     */
+/* (seed, iteration) and the scores are the query's own.  Call after the bin      */
+/* build.  qr_metric_last then reports the cleaned rankings: use qr_metric_eval.  */
+int qr_subsample_set(qr_ctx *ctx, float subsample, uint64_t seed);
+/* --max-features (rt.cc:222-243): every node's split search sees a random       */
+/* subset of the features: max_features > 1 = that many, < 1 = that fraction     */
+/* (rounded up), 1 = all.  The reference draws it from a clock-seeded engine at  */
+/* every split; here it is a pure function of (seed, tree number, node, feature) */
+/* -- reproducible, identical on every rank.  Leaf-wise trees only.              */
+int qr_tree_set_max_features(qr_ctx *ctx, float max_features, uint64_t seed);
 /* ObliviousRT::fit (ot.cc:32-201): nodes_out in heap order (2i+1, 2i+2),        */
 /* capacity 2^(depth+1)-1; absent nodes have feature == -2.                      */
 int qr_oblivious_fit(qr_ctx *ctx, size_t depth, uint64_t minls, int newton,

@@ -39,6 +39,7 @@ SYMBOLS = [
     "qr_ctx_set_doc_shard", "qr_bins_stats", "qr_thresholds_from_stats",
     "qr_bins_build_with", "qr_lambda_finish", "qr_tree_leaves_finish",
     "qr_doc_exchange_buffers", "qr_tree_nodes", "qr_valid_scores_set",
+    "qr_tree_set_max_features", "qr_subsample_set",
 ]
 
 _LIB = None
@@ -111,6 +112,8 @@ def lib():
     L.qr_thresholds_from_stats.argtypes = [sz, sz, sz, vp, vp, vp, vp, vp]
     L.qr_bins_build_with.argtypes = [vp, vp, vp]
     L.qr_tree_nodes.argtypes = [vp, vp, C.POINTER(sz)]
+    L.qr_tree_set_max_features.argtypes = [vp, C.c_float, u64]
+    L.qr_subsample_set.argtypes = [vp, C.c_float, u64]
     L.qr_lambda_finish.argtypes = [vp]
     L.qr_tree_leaves_finish.argtypes = [vp, C.c_int, vp, C.POINTER(sz)]
     L.qr_doc_exchange_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp),
@@ -294,6 +297,12 @@ class Context:
         n = C.c_size_t()
         self._ck(self.L.qr_tree_nodes(self.h, _ptr(nodes), C.byref(n)))
         return nodes[:n.value].copy()
+
+    def set_subsample(self, subsample, seed=0):
+        self._ck(self.L.qr_subsample_set(self.h, float(subsample), int(seed)))
+
+    def set_max_features(self, max_features, seed=0):
+        self._ck(self.L.qr_tree_set_max_features(self.h, float(max_features), int(seed)))
 
     def fit_oblivious(self, depth=3, minls=1, newton=True):
         nodes = np.zeros((1 << (depth + 1)) - 1, NODE_DTYPE)

@@ -399,7 +399,8 @@ __global__ __launch_bounds__(64) void k_lambda(
     const double *__restrict__ ilg2, double *__restrict__ lambda,
     double *__restrict__ weight, double *__restrict__ qmetric,
     uint32_t *__restrict__ ranks_out, double *__restrict__ ssq,
-    QrScalars *__restrict__ scal, uint32_t nmax, uint32_t kacc, int mode) {
+    QrScalars *__restrict__ scal, uint32_t nmax, uint32_t kacc, int mode,
+    const uint8_t *__restrict__ present) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t q = blockIdx.x;
   const uint32_t lane = threadIdx.x;
@@ -411,7 +412,8 @@ __global__ __launch_bounds__(64) void k_lambda(
 #define QR_T(i)
 #endif
   const uint32_t off = qoff[q];
-  const uint32_t n = qoff[q + 1] - off;
+  const uint32_t n_full = qoff[q + 1] - off;
+  uint32_t n = n_full;
   double *s = reinterpret_cast<double *>(smem);          // [nmax] scores by doc
   double *sr = s + nmax;                                 // [nmax] scores by rank
   double *accl = sr + nmax;                              // [kacc] contributions to top ranks
@@ -428,6 +430,28 @@ __global__ __launch_bounds__(64) void k_lambda(
   int *stk = reinterpret_cast<int *>(unmap + nmax);      // [3 * 64]
   double *ilt = reinterpret_cast<double *>(stk + 3 * 64);  // [kacc] 1/log2(r+2), top ranks
   double *expt = ilt + kacc;                               // [64] 2^(j/64)
+  uint32_t *cmap = reinterpret_cast<uint32_t *>(expt + 64);  // [nmax] cleaned -> original doc
+  // --subsample (lambdamart.cc:85-102): the query is "cleaned" of the documents
+  // that are not in this iteration's sample; everything below then runs on the
+  // cleaned list, in its own numbering, exactly as on a shorter query.  Documents
+  // outside the sample get lambda = weight = 0.
+  if (present) {
+    uint32_t cnt = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t base = 0; base < n_full; base += 64) {
+      const uint32_t i = base + lane;
+      const bool in = i < n_full && present[off + i] != 0;
+      const unsigned long long m = __ballot(in);
+      if (in) cmap[cnt + __popcll(m & lt)] = i;
+      if (i < n_full && !in && mode == 0) {
+        lambda[off + i] = 0.0;
+        weight[off + i] = 0.0;
+      }
+      cnt += __popcll(m);
+    }
+    n = cnt;
+    __syncthreads();
+  }
   if (n == 0) {
     if (lane == 0) {
       qmetric[q] = 0.0;
@@ -436,8 +460,9 @@ __global__ __launch_bounds__(64) void k_lambda(
     return;
   }
   for (uint32_t i = lane; i < n; i += 64) {
-    s[i] = scores[off + i];
-    lab0[i] = labels[off + i];
+    const uint32_t di = present ? cmap[i] : i;
+    s[i] = scores[off + di];
+    lab0[i] = labels[off + di];
   }
   // NaN padding to a multiple of 4: compares false, so it never counts
   const uint32_t n4 = (n + 3) & ~3u;
@@ -483,11 +508,33 @@ __global__ __launch_bounds__(64) void k_lambda(
     const uint32_t d = unmap[r];
     sl[r] = lab0[d];
     sr[r] = s[d];
-    if (ranks_out) ranks_out[off + r] = d;
+    if (ranks_out) ranks_out[off + r] = present ? cmap[d] : d;
   }
   __syncthreads();
   const uint32_t size = cutoff < n ? cutoff : n;
-  const double my_idcg = metric == QR_METRIC_NDCG ? idcg[q] : 1.0;
+  double my_idcg = metric == QR_METRIC_NDCG ? idcg[q] : 1.0;
+  if (present && metric == QR_METRIC_NDCG) {
+    // Ndcg::compute_idcg (ndcg.cc:35-47) of the cleaned list: labels in descending
+    // order of their integer part (equal integer parts keep the list order -- for
+    // the usual integer grades any order gives the same value), then dcg.cc:33-39.
+    // ownl is free here (the sort is over, the accumulators are not live yet).
+    double *sorted_gain = ownl;
+    for (uint32_t j = lane; j < n; j += 64) {
+      const int lj = (int)lab0[j];
+      uint32_t r = 0;
+      for (uint32_t i = 0; i < n; ++i) {
+        const int li = (int)lab0[i];
+        r += (li > lj) || (li == lj && i < j);
+      }
+      sorted_gain[r] = pow2_label(lab0[j]) - 1.0;
+    }
+    __syncthreads();
+    double v = 0.0;
+    if (lane == 0)
+      for (uint32_t i = 0; i < size; ++i) v += sorted_gain[i] / lg2[i];
+    my_idcg = readlane_f64(v, 0);
+    __syncthreads();
+  }
   // ---- 3. metric of the current ranking (dcg.cc:33-39, ndcg.cc:49-58)
   if (lane == 0) {
     double dcg = 0.0;
@@ -502,7 +549,7 @@ __global__ __launch_bounds__(64) void k_lambda(
   // ---- 4. lambdas
   if (metric == QR_METRIC_NDCG && !(my_idcg > 0.0)) {
     // ndcg.cc:69-70: all-zero jacobian => lambdas and weights stay 0
-    for (uint32_t i = lane; i < n; i += 64) {
+    for (uint32_t i = lane; i < n_full; i += 64) {
       lambda[off + i] = 0.0;
       weight[off + i] = 0.0;
     }
@@ -568,7 +615,7 @@ __global__ __launch_bounds__(64) void k_lambda(
   QR_T(5);
   double mx = 0.0, sq = 0.0, sm = 0.0;
   for (uint32_t r = lane; r < n; r += 64) {
-    const uint32_t d = off + unmap[r];
+    const uint32_t d = off + (present ? cmap[unmap[r]] : unmap[r]);
     double l = ownl[r], w = ownw[r];
     if (r < size) {
       l += accl[r];
@@ -696,7 +743,7 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
 static size_t lambda_lds(size_t nmax, size_t kacc) {
   // s/sr[nmax] f64, accl/accw[kacc] f64, ownl/ownw[nmax] f64 (aliased by the sort
   // scratch), lab0/sl f32, unmap u32, stk, ilt[kacc] f64
-  return nmax * 16 + kacc * 16 + nmax * 16 + nmax * 12 + 3 * 64 * 4 + kacc * 8 + 64 * 8;
+  return nmax * 16 + kacc * 16 + nmax * 16 + nmax * 12 + 3 * 64 * 4 + kacc * 8 + 64 * 8 + nmax * 4;
 }
 
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
@@ -723,13 +770,14 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
                        c->d_scores, c->d_labels, c->d_qoff, metric, cut, c->d_idcg,
                        c->d_lg2, c->d_ilg2, c->d_lambda, c->d_weight, c->d_qmetric, c->d_ranks,
                        mode == 0 ? c->d_ssq : nullptr, c->d_scalars, (uint32_t)nmax,
-                       (uint32_t)kacc, mode);
+                       (uint32_t)kacc, mode,
+                       mode == 0 && c->sub_k ? c->d_present : (const uint8_t *)nullptr);
   } else {
     hipLaunchKernelGGL(k_lambda, dim3((unsigned)Q), dim3(64), lds, c->stream,
                        c->d_vscores, c->d_vlabels, c->d_vqoff, metric, cut,
                        c->d_vidcg, c->d_lg2, c->d_ilg2, (double *)nullptr, (double *)nullptr,
                        c->d_vqmetric, (uint32_t *)nullptr, (double *)nullptr,
-                       c->d_scalars, (uint32_t)nmax, (uint32_t)kacc, 1);
+                       c->d_scalars, (uint32_t)nmax, (uint32_t)kacc, 1, (const uint8_t *)nullptr);
   }
   QR_CHECK(c, hipGetLastError());
   return QR_OK;

@@ -204,14 +204,15 @@ __global__ __launch_bounds__(1024) void k_hist(
     const QrBlock *__restrict__ blocks, const int nblocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const QrScalars *__restrict__ scal, u64 *__restrict__ partials, const int docmode) {
+    const QrScalars *__restrict__ scal, u64 *__restrict__ partials, const int docmode,
+    const int root_buf) {
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
   uint32_t seg_begin, n;
   int buf;
-  if (root_mode) {
+  if (root_mode) {  // N documents: all of them (identity, buffer 2) or the sample's list
     seg_begin = 0;
     n = N;
-    buf = 2;
+    buf = root_buf;
   } else {
     if (!ts->desc.active) return;
     // document-sharded: the rank's own part of the directly built child
@@ -576,8 +577,32 @@ __global__ __launch_bounds__(256) void k_scan_level(
 // (rt.cc:297-306).  Also attaches lcount/rcount from the node histogram.
 // ===========================================================================
 // merge by one wave; every lane returns the same record
+// --max-features (rt.cc:222-243): a node's split search sees only a random subset
+// of mf_k features.  The reference shuffles the feature ids with a clock-seeded
+// engine at every split() call; here the subset of node `node` is the mf_k features
+// with the smallest keys hash(seed, node, f), so that a run is reproducible, every
+// rank of a multi-GPU run draws the same subset, and no state is carried around.
+__device__ __forceinline__ u64 mf_key(u64 seed, uint32_t node, uint32_t f) {
+  u64 z = seed + 0x9E3779B97F4A7C15ull * ((u64)node * 0x100000001ull + f + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ bool mf_allowed(u64 seed, uint32_t node, uint32_t f, uint32_t F,
+                                           uint32_t mf_k) {
+  const u64 mine = mf_key(seed, node, f);
+  uint32_t rank = 0;
+  for (uint32_t g = 0; g < F; ++g) {
+    const u64 k = mf_key(seed, node, g);
+    rank += (k < mine || (k == mine && g < f)) ? 1u : 0u;
+  }
+  return rank < mf_k;
+}
+
 __device__ qr_split_t wave_merge(const int root_mode, const int which,
-                                 const qr_split_t *featrec, const int flocal) {
+                                 const qr_split_t *featrec, const int flocal,
+                                 const uint32_t mf_k, const u64 mf_seed, const uint32_t mf_node,
+                                 const uint32_t F) {
   const int lane = threadIdx.x & 63;
   qr_split_t best;
   best.score = -1.0;
@@ -587,6 +612,8 @@ __device__ qr_split_t wave_merge(const int root_mode, const int which,
   if (root_mode && which == 1) return best;
   for (int lf = lane; lf < flocal; lf += 64) {
     const qr_split_t r = featrec[(size_t)which * flocal + lf];
+    if (mf_k && r.feature != 0xFFFFFFFFu && !mf_allowed(mf_seed, mf_node, r.feature, F, mf_k))
+      continue;
     if (r.score > best.score) best = r;  // ascending lf within the lane
   }
   // max score over the wave, equal scores -> lowest feature index; the lane that
@@ -616,10 +643,12 @@ __global__ __launch_bounds__(128) void k_merge(
     const QrTreeState *__restrict__ ts, const int root_mode,
     const qr_split_t *__restrict__ featrec, const int flocal,
     const long long *__restrict__ hsum, const uint32_t *__restrict__ hcnt,
-    const int32_t *__restrict__ gf2lf, qr_split_t *__restrict__ recs_local) {
+    const int32_t *__restrict__ gf2lf, qr_split_t *__restrict__ recs_local,
+    const uint32_t mf_k, const u64 mf_seed, const uint32_t F) {
   if (!root_mode && !ts->desc.active) return;
   const int which = threadIdx.x >> 6;  // wave 0: left child (or root), wave 1: right
-  const qr_split_t best = wave_merge(root_mode, which, featrec, flocal);
+  const uint32_t node = root_mode ? 0u : (uint32_t)(which ? ts->desc.right : ts->desc.left);
+  const qr_split_t best = wave_merge(root_mode, which, featrec, flocal, mf_k, mf_seed, node, F);
   if ((threadIdx.x & 63) == 0) recs_local[which] = best;
 }
 
@@ -773,7 +802,9 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
                             const qr_split_t *recs, const int world, const QrScalars *scal,
                             const double *part_ss, const float *thr, const int32_t *gf2lf,
                             const qr_split_t *featrec, const uint32_t *hcnt, const int docmode,
-                            const u64 Nglobal, const long long *tail, const int dworld) {
+                            const u64 Nglobal, const long long *tail, const int dworld,
+                            const uint32_t mf_k, const u64 mf_seed, const uint32_t F,
+                            const int root_buf) {
   const bool w0 = threadIdx.x < 64;
   // single GPU (and document-sharded, where every rank scans every feature of
   // the all-reduced histogram): the merge over features happens here (no k_merge
@@ -818,7 +849,8 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
     // wave 0 merges the left child's (or the root's) records, wave 1 the right child's
     if (threadIdx.x < 128 && (root_mode || active)) {
       const int which = threadIdx.x >> 6;
-      const qr_split_t a = wave_merge(root_mode, which, featrec, flocal);
+      const uint32_t node = root_mode ? 0u : (uint32_t)(which ? ts->desc.right : ts->desc.left);
+      const qr_split_t a = wave_merge(root_mode, which, featrec, flocal, mf_k, mf_seed, node, F);
       if ((threadIdx.x & 63) == 0) own[which] = a;
     }
     recs = own;
@@ -849,7 +881,7 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
       QrNode *root = &st.nodes[0];
       root->begin = 0;
       root->end = N;
-      root->buf = 2;
+      root->buf = root_buf;
       root->hslot = 0;
       root->feature = -1;
       root->thr_id = -1;
@@ -936,9 +968,10 @@ __global__ __launch_bounds__(128) void k_decide(
     const double *__restrict__ part_ss, const float *__restrict__ thr,
     const int32_t *__restrict__ gf2lf, const qr_split_t *__restrict__ featrec,
     const uint32_t *__restrict__ hcnt, const int docmode, const u64 Nglobal,
-    const long long *__restrict__ tail, const int dworld) {
+    const long long *__restrict__ tail, const int dworld, const uint32_t mf_k, const u64 mf_seed,
+    const uint32_t F, const int root_buf) {
   decide_body(ts, N, flocal, recs, world, scal, part_ss, thr, gf2lf, featrec, hcnt, docmode,
-              Nglobal, tail, dworld);
+              Nglobal, tail, dworld, mf_k, mf_seed, F, root_buf);
 }
 
 // ===========================================================================
@@ -1787,10 +1820,11 @@ static int launch_hist_scan(qr_ctx *c, int root_mode) {
     QR_CHECK(c, hipEventCreate(&e1));
     QR_CHECK(c, hipEventRecord(e0, c->stream));
   }
+  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);  // documents of the root node
   hipLaunchKernelGGL(k_hist, dim3(G), dim3(1024), lds, c->stream, c->d_tree,
-                     root_mode, (uint32_t)c->N, c->d_blocks, c->nblocks, c->d_bins,
+                     root_mode, rootn, c->d_blocks, c->nblocks, c->d_bins,
                      c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars,
-                     (u64 *)c->d_partials, c->dmode);
+                     (u64 *)c->d_partials, c->dmode, c->sub_k ? 0 : 2);
   QR_CHECK(c, hipGetLastError());
   if (prof) {
     QR_CHECK(c, hipEventRecord(e1, c->stream));
@@ -1799,7 +1833,7 @@ static int launch_hist_scan(qr_ctx *c, int root_mode) {
   size_t cells = 0;
   for (const auto &b : c->blocks) cells += (size_t)256 * b.fw;
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)(cells / 64)), dim3(512), 0, c->stream,
-                     c->d_tree, root_mode, (uint32_t)c->N, c->d_blocks, c->nblocks, G,
+                     c->d_tree, root_mode, rootn, c->d_blocks, c->nblocks, G,
                      (const u64 *)c->d_partials, c->d_red_sum, c->d_red_cnt, c->dmode,
                      c->d_part_ss, c->dmode ? c->d_xh + 2 * c->xh_cells : (long long *)nullptr,
                      c->rank, c->world);
@@ -1817,7 +1851,7 @@ static int launch_scan(qr_ctx *c, int root_mode) {
   if (c->world > 1 && !c->dmode) {
     hipLaunchKernelGGL(k_merge, dim3(1), dim3(128), 0, c->stream, c->d_tree, root_mode,
                        c->d_featrec, c->flocal, c->d_hsum, c->d_hcnt, c->d_gf2lf,
-                       c->d_recs_local);
+                       c->d_recs_local, c->mf_k, c->mf_seed + c->tree_counter, (uint32_t)c->F);
     QR_CHECK(c, hipGetLastError());
   }
   return QR_OK;
@@ -1839,6 +1873,7 @@ __global__ void k_tree_reset(QrTreeState *ts, int nleaves, u64 minls) {
 
 int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
   c->tree_step = 0;
+  c->tree_counter += 0x9E3779B97F4A7C15ull;  // a fresh feature-subset stream per tree
   hipLaunchKernelGGL(k_tree_reset, dim3(1), dim3(64), 0, c->stream, c->d_tree,
                      (int)nleaves, (u64)minls);
   QR_CHECK(c, hipGetLastError());
@@ -1858,11 +1893,12 @@ int qr_k_tree_decide(qr_ctx *c) {
   // measured slower: the agent-scope release/acquire it needs writes back and
   // invalidates the XCD L2s, 22.8 us for the fused kernel against 6 + 9 us.)
   hipLaunchKernelGGL(k_decide, dim3(1), dim3(128), 0, c->stream, c->d_tree,
-                     (uint32_t)c->N, c->flocal, recs, fshard ? c->world : 1,
+                     (uint32_t)(c->sub_k ? c->sub_k : c->N), c->flocal, recs, fshard ? c->world : 1,
                      c->d_scalars, c->d_part_ss, c->d_thr, c->d_gf2lf, c->d_featrec,
                      c->d_hcnt, c->dmode, (u64)c->Nglobal,
                      c->dmode ? c->d_xh + 2 * c->xh_cells : (const long long *)nullptr,
-                     c->world);
+                     c->world, c->mf_k, c->mf_seed + c->tree_counter, (uint32_t)c->F,
+                     c->sub_k ? 0 : 2);
   QR_CHECK(c, hipGetLastError());
   ++c->tree_step;
   if (fshard) {
@@ -1976,8 +2012,15 @@ int qr_k_tree_leaves_global(qr_ctx *c, int newton) {
 
 int qr_k_scores_update(qr_ctx *c, double shrinkage) {
   const unsigned grid = (unsigned)((c->N + 255) / 256);
-  hipLaunchKernelGGL(k_score_update, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
-                     c->d_order[0], c->d_order[1], shrinkage, c->d_scores);
+  if (c->sub_k) {
+    // the leaves hold the sample only; every training document is updated
+    // (mart.cc:345), so walk the tree on the raw features as for validation
+    hipLaunchKernelGGL(k_valid_update, dim3(grid), dim3(256), 0, c->stream, c->d_tree, c->d_raw,
+                       (uint32_t)c->N, (uint32_t)c->F, shrinkage, c->d_scores);
+  } else {
+    hipLaunchKernelGGL(k_score_update, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
+                       c->d_order[0], c->d_order[1], shrinkage, c->d_scores);
+  }
   QR_CHECK(c, hipGetLastError());
   if (c->vN) {
     const unsigned vgrid = (unsigned)((c->vN + 255) / 256);

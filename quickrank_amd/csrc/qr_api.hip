@@ -94,6 +94,11 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
   dfree(c->d_lred_sum); dfree(c->d_lred_cnt); dfree(c->d_lpart_state);
   c->lhist_cap = c->lpart_cap = c->lslots_cap = c->lred_nodes = 0;
+  dfree(c->d_present); dfree(c->d_sample_keys); dfree(c->d_sample_count);
+  if (c->d_sample_temp) (void)hipFree(c->d_sample_temp);
+  c->d_sample_temp = nullptr;
+  c->sub_k = 0;
+  c->mf_k = 0;
   c->binned = false;
   c->tree_valid = false;
   c->hist_slots = 0;
@@ -680,9 +685,11 @@ int qr_lambda_compute(qr_ctx *c, int metric, size_t cutoff) {
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "metric must be DCG or NDCG");
   int rc = ensure_idcg(c, 0, metric, cutoff);
   if (rc) return rc;
+  if (c->sub_k && (rc = qr_k_sample_draw(c))) return rc;  // this iteration's sample
   rc = qr_k_lambda(c, 0, metric, cutoff, 0);
   if (rc) return rc;
   // sum of squares / sum / quantisation scale and the metric of the ranking, one launch
+  // (documents outside a sample have lambda == 0: the sums are the sample's)
   if ((rc = qr_k_prep(c, c->Q, 1))) return rc;
   if (!c->dmode) return snapshot_scalars(c);
   return qr_k_prep_pack(c);  // then: all-reduce the scalar buffer, qr_lambda_finish
@@ -700,9 +707,15 @@ int qr_lambda_finish(qr_ctx *c) {
 int qr_residual_compute(qr_ctx *c) {
   if (!c) return QR_ERR_ARG;
   if (!c->d_scores) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
-  int rc = qr_k_residual(c);
-  if (rc) return rc;
-  if ((rc = qr_k_prep(c, (c->N + QR_SLICE - 1) / QR_SLICE, 0)) || !c->dmode) return rc;
+  int rc = 0;
+  if (c->sub_k && (rc = qr_k_sample_draw(c))) return rc;  // this iteration's sample
+  if ((rc = qr_k_residual(c))) return rc;  // every document (mart.cc:418-431)
+  size_t nss = (c->N + QR_SLICE - 1) / QR_SLICE;
+  if (c->sub_k) {  // the root's statistics run over the sample (rtnode_histogram.cc:199-203)
+    if ((rc = qr_k_sample_sums(c))) return rc;
+    nss = (c->sub_k + QR_SLICE - 1) / QR_SLICE;
+  }
+  if ((rc = qr_k_prep(c, nss, 0)) || !c->dmode) return rc;
   return qr_k_prep_pack(c);
 }
 
@@ -788,6 +801,43 @@ static int ensure_level_buffers(qr_ctx *c, size_t depth) {
     c->lslots_cap = slots;
     c->lred_nodes = nodes;
   }
+  return QR_OK;
+}
+
+int qr_subsample_set(qr_ctx *c, float subsample, uint64_t seed) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  if (c->world > 1 || c->dmode) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling is single-GPU in this round");
+  if (!(subsample > 0.0f)) QR_FAIL(c, QR_ERR_ARG, "subsample must be > 0");
+  // mart.cc:289-297: > 1 is a number of documents, < 1 a fraction (rounded down)
+  size_t k = subsample > 1.0f ? std::min((size_t)subsample, c->N)
+                              : (size_t)std::floor(subsample * (float)c->N);
+  if (subsample == 1.0f || k >= c->N) k = 0;  // the whole set: no sampling
+  if (subsample != 1.0f && k == 0 && (size_t)std::floor(subsample * (float)c->N) == 0 && subsample < 1.0f)
+    QR_FAIL(c, QR_ERR_ARG, "subsample leaves no document");
+  c->sub_k = k;
+  c->sub_seed = seed * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull;
+  c->sub_iter = 0;
+  if (k && !c->d_present) {
+    QR_CHECK(c, dalloc(&c->d_present, c->N));
+    QR_CHECK(c, dalloc(&c->d_sample_keys, 4 * c->N));
+    QR_CHECK(c, dalloc(&c->d_sample_count, (size_t)1));
+    c->sample_temp_bytes = qr_k_sample_temp_bytes(c->N);
+    QR_CHECK(c, hipMalloc(&c->d_sample_temp, c->sample_temp_bytes ? c->sample_temp_bytes : 1));
+  }
+  return QR_OK;
+}
+
+int qr_tree_set_max_features(qr_ctx *c, float max_features, uint64_t seed) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->F) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
+  if (!(max_features > 0.0f)) QR_FAIL(c, QR_ERR_ARG, "max_features must be > 0");
+  // rt.cc:227-233: > 1 is a number of features, < 1 a fraction (rounded up)
+  size_t k = max_features > 1.0f ? (size_t)max_features : (size_t)std::ceil(max_features * (float)c->F);
+  if (max_features == 1.0f || k >= c->F) k = 0;  // every feature: no sampling
+  c->mf_k = (uint32_t)k;
+  c->mf_seed = seed * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull;
+  c->tree_counter = 0;
   return QR_OK;
 }
 
@@ -890,6 +940,7 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
   if (c->world > 1 || c->dmode)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "oblivious trees are single-GPU in this round");
+  if (c->sub_k) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling applies to leaf-wise trees in this round");
   if (depth < 1 || ((size_t)1 << (depth + 1)) - 1 > QR_MAXNODES)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
   int rc = ensure_hist_slots(c, ((size_t)1 << (depth + 1)) - 1);

@@ -296,6 +296,16 @@ struct qr_ctx {
   bool tree_valid = false;
   bool tree_open = false;
   int tree_step = 0;             // decides issued for the open tree
+  // --subsample: documents per iteration (0 = all), the sampler's state and scratch
+  size_t sub_k = 0;
+  uint64_t sub_seed = 0, sub_iter = 0;
+  uint8_t *d_present = nullptr;
+  uint32_t *d_sample_keys = nullptr;  // 4 x N: keys, ids, sorted keys, sorted ids
+  void *d_sample_temp = nullptr;
+  size_t sample_temp_bytes = 0;
+  uint32_t *d_sample_count = nullptr;
+  uint32_t mf_k = 0;             // --max-features: features a node's split search sees (0 = all)
+  uint64_t mf_seed = 0, tree_counter = 0;
   size_t cur_nleaves = 0;
   // ensemble
   qr_node_t *d_ens = nullptr;
@@ -348,6 +358,9 @@ int qr_k_prep(qr_ctx *c, size_t nslices, int with_metric);
 int qr_k_prep_pack(qr_ctx *c);
 int qr_k_prep_global(qr_ctx *c);
 int qr_k_tree_leaves_global(qr_ctx *c, int newton);
+size_t qr_k_sample_temp_bytes(size_t N);
+int qr_k_sample_draw(qr_ctx *c);
+int qr_k_sample_sums(qr_ctx *c);
 int qr_k_metric_reduce(qr_ctx *c, int which);
 int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls);
 int qr_k_tree_decide(qr_ctx *c);

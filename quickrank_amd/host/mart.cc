@@ -263,6 +263,18 @@ void Mart::learn(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::
                        validation->offsets().data(), validation->num_queries()));
   QR(qr_bins_build(ctx_, nthresholds_, nullptr, nullptr));
   QR(qr_scores_reset(ctx_));
+  const bool sampling = subsample_ != 1.0f || max_features_ != 1.0f;
+  if (sampling) {
+    if (obliv) {
+      std::cerr << "!!! --subsample / --max-features apply to MART / LAMBDAMART in this build." << std::endl;
+      exit(EXIT_FAILURE);
+    }
+    unsigned long long seed = sampling_seed_;
+    if (seed == 0)  // the reference seeds from the clock at every draw
+      seed = (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count();
+    if (subsample_ != 1.0f) QR(qr_subsample_set(ctx_, subsample_, seed));
+    if (max_features_ != 1.0f) QR(qr_tree_set_max_features(ctx_, max_features_, seed));
+  }
   // restart from a previously saved model (mart.cc:237-253)
   if (ensemble_model_.is_notempty()) {
     best_model_ = ensemble_model_.get_size() - 1;
@@ -317,7 +329,7 @@ void Mart::learn(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::
   // is then a by-product of that pass (qr_metric_last) and the line of iteration m
   // is printed one iteration late -- same numbers, one ranking pass per iteration
   // instead of two, and no stream drain in between.
-  const bool lagged = lambda && !validation;
+  const bool lagged = lambda && !validation && subsample_ == 1.0f;  // sampled rankings are not the metric's
   const size_t first = ensemble_model_.get_size();
   for (size_t m = first; m < ntrees_; ++m) {
     if (validation && (valid_iterations_ && m > best_model_ + valid_iterations_)) break;

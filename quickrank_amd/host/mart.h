@@ -65,6 +65,13 @@ class Mart {
   ~Mart();
 
   std::string name() const { return algo_name(algo_); }
+  // --subsample / --max-features (mart.cc:287-329, rt.cc:222-243); seed 0 = from the
+  // clock, as the reference always does
+  void set_sampling(float subsample, float max_features, unsigned long long seed) {
+    subsample_ = subsample;
+    max_features_ = max_features;
+    sampling_seed_ = seed;
+  }
   void print(std::ostream &os) const;  // mart.cc:95-115 / obliviousmart.cc:42-57
 
   // mart.cc:208-416.  metric: "NDCG" | "DCG".
@@ -90,6 +97,7 @@ class Mart {
   size_t ntrees_, nthresholds_, nleaves_, minleafsupport_, valid_iterations_, treedepth_;
   double shrinkage_;
   float subsample_ = 1.0f, max_features_ = 1.0f, collapse_leaves_factor_ = 0.0f;
+  unsigned long long sampling_seed_ = 0;  // of the document / feature sampling streams
   Ensemble ensemble_model_;
   qr_ctx *ctx_ = nullptr;
   MetricScore best_metric_on_training_ = 0, best_metric_on_validation_ = 0;

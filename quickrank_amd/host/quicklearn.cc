@@ -43,6 +43,11 @@ const std::vector<std::pair<std::string, Opt>> kOptions = {
      {"set num. rounds with no gain in validation before ending (if 0 disabled).", "100", true}},
     {"num-leaves", {"set number of leaves [applies only to MART/LambdaMART].", "10", true}},
     {"tree-depth", {"set tree depth [applies only to ObliviousMART/ObliviousLambdaMART].", "3", true}},
+    {"subsample",
+     {"set documents per iteration: fraction if <= 1, count if > 1 [MART/LambdaMART].", "1", true}},
+    {"max-features",
+     {"set features per split search: fraction if <= 1, count if > 1 [MART/LambdaMART].", "1", true}},
+    {"seed", {"seed of the document / feature sampling (0: from the clock, like the reference).", "0", true}},
     {"test-metric", {"set test metric: [DCG|NDCG].", "NDCG", true}},
     {"test-cutoff", {"set test metric cutoff.", "10", true}},
     {"test", {"set testing file.", "", true}},
@@ -54,8 +59,8 @@ const std::set<std::string> kOutOfScope = {
     "best-on-train", "random-keep", "drop-on-best", "num-samples", "window-size", "reduction-factor",
     "max-iterations", "max-failed-valid", "adaptive", "train-partial", "valid-partial", "opt-algo",
     "opt-method", "opt-model", "opt-algo-model", "pruning-rate", "with-line-search",
-    "line-search-model", "detailed", "model-file", "code-file", "generator", "subsample",
-    "max-features", "collapse-leaves-factor"};
+    "line-search-model", "detailed", "model-file", "code-file", "generator",
+    "collapse-leaves-factor"};
 
 void help() {
   std::cout << "quicklearn (MI355X build): LambdaMART / MART / oblivious variants on the GPU\n\n";
@@ -141,6 +146,7 @@ int main(int argc, char *argv[]) {
                                   std::stoul(v["num-thresholds"]), std::stoul(v["num-leaves"]),
                                   std::stoul(v["min-leaf-support"]), std::stoul(v["end-after-rounds"]),
                                   std::stoul(v["tree-depth"]));
+    algo->set_sampling(std::stof(v["subsample"]), std::stof(v["max-features"]), std::stoull(v["seed"]));
     if (isset.count("model-in") && isset.count("restart-train")) {
       auto loaded = Mart::load_model_from_file(v["model-in"]);
       if (!loaded || !algo->import_model_state(*loaded)) {  // ltr_algorithm_factory.cc:249-258

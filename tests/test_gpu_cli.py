@@ -186,3 +186,32 @@ def test_restart_train_continues_the_same_model(tools, tmp_path, with_valid):
         for k in ("feature", "threshold", "left", "right"):
             assert np.array_equal(a[k], b[k]), k
         assert np.allclose(a["value"], b["value"], rtol=1e-12, atol=0)
+
+
+def test_quicklearn_sampling_flags(tools, tmp_path):
+    """--subsample / --max-features / --seed: accepted for the leaf-wise algorithms,
+    written to the model's <info>, reproducible for a given seed, different for another."""
+    x, labels, qoff = make_dataset(nq=100, docs_per_query=40, F=30, seed=17)
+    tr = str(tmp_path / "train.svml")
+    _write_svml(tr, x, labels, qoff)
+    base = [tools["quicklearn"], "--algo", "LAMBDAMART", "--train", tr, "--num-trees", "4", "--num-leaves", "8",
+            "--num-thresholds", "64", "--min-leaf-support", "2", "--subsample", "0.5", "--max-features", "0.4"]
+
+    def run(seed, name):
+        m = str(tmp_path / name)
+        r = subprocess.run(base + ["--seed", str(seed), "--model-out", m], capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return open(m).read(), r.stdout
+    a, out = run(5, "a.xml")
+    b, _ = run(5, "b.xml")
+    c, _ = run(6, "c.xml")
+    assert a == b and a != c
+    assert "<subsample>0.5</subsample>" in a and "<max_features>0.4" in a
+    assert "# subsample = 0.5" in out
+    # every iteration prints its training metric (evaluated on all documents)
+    rows = [ln.split() for ln in out.splitlines() if ln.split() and ln.split()[0].isdigit()]
+    assert [int(r[0]) for r in rows] == [1, 2, 3, 4] and all(0.0 < float(r[1]) <= 1.0 for r in rows)
+    r = subprocess.run([tools["quicklearn"], "--algo", "OBVLAMBDAMART", "--train", tr, "--subsample", "0.5",
+                        "--num-thresholds", "64"], capture_output=True, text=True)
+    assert r.returncode != 0 and "apply to MART / LAMBDAMART" in r.stderr

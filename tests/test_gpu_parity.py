@@ -308,3 +308,152 @@ def test_validation_early_stop_and_rollback(qr, ora):
 def test_no_device_index_is_an_error(qr):
     with pytest.raises(qr.QrError):
         qr.Context(63)
+
+
+# ---- --max-features (rt.cc:222-243) ------------------------------------------------
+M64 = (1 << 64) - 1
+
+
+def _mf_key(seed, node, f):
+    z = (seed + 0x9E3779B97F4A7C15 * ((node * 0x100000001 + f + 1) & M64)) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def _mf_allowed(user_seed, tree_no, node, F, k):
+    seed = (user_seed * 0xD1342543DE82EF95 + 0x2545F4914F6CDD1D + tree_no * 0x9E3779B97F4A7C15) & M64
+    keys = [(_mf_key(seed, node, f), f) for f in range(F)]
+    return {f for _, f in sorted(keys)[:k]}
+
+
+def test_max_features_subset_per_node(qr, ora):
+    x, labels, qoff = make_dataset(nq=80, docs_per_query=50, F=40, seed=31)
+    rng = np.random.default_rng(3)
+    lam, w = ora.lambdas(labels, rng.standard_normal(len(labels)) * 0.3, qoff, 10, 1)
+    c, thr, ts = _ctx(qr, x, labels, qoff, 64)
+    c.set_pseudo(lam, w)
+    base = c.fit_tree(12, 5, True)
+    c.set_max_features(1.0, seed=9)                 # all features: no sampling
+    same = c.fit_tree(12, 5, True)
+    for k in base.dtype.names:
+        assert np.array_equal(same[k], base[k]), k
+    F, K = 40, 12                                   # 0.3 * 40 = 12 features per node
+    c.set_max_features(0.3, seed=9)
+    t1 = c.fit_tree(12, 5, True)                    # tree number 1 of this stream
+    log = c.split_log()
+    # every split uses a feature of its node's subset, and it is the best split
+    # among that subset (first maximum: lowest feature, then lowest slot)
+    tsz = ts.astype(np.uint64)
+    for n in np.nonzero(t1["feature"] >= 0)[0]:
+        allowed = _mf_allowed(9, 1, int(n), F, K)
+        assert int(t1[n]["feature"]) in allowed, n
+        hs, hc = c.node_hist(int(n))
+        best = None
+        for f in sorted(allowed):
+            sp = ora.split_find(hs, hc, tsz, 5, f, f + 1)
+            if sp.feature != 2 ** 64 - 1 and (best is None or sp.score > best[0]):
+                best = (sp.score, int(sp.feature), int(sp.thr_id))
+        assert best is not None
+        assert (int(t1[n]["feature"]), int(t1[n]["thr_id"])) == best[1:], n
+    assert len(set(int(f) for f in t1["feature"] if f >= 0) - set(int(f) for f in base["feature"])) >= 0
+    # the stream is reproducible: same seed, same sequence of trees
+    c.set_max_features(0.3, seed=9)
+    again = c.fit_tree(12, 5, True)
+    for k in t1.dtype.names:
+        assert np.array_equal(again[k], t1[k]), k
+    second = c.fit_tree(12, 5, True)                # tree number 2: other subsets
+    c.set_max_features(0.3, seed=10)
+    other = c.fit_tree(12, 5, True)
+    assert not (np.array_equal(second["feature"], t1["feature"]) and np.array_equal(other["feature"], t1["feature"]))
+    # a count instead of a fraction; more than F means all
+    c.set_max_features(1000.0, seed=1)
+    full = c.fit_tree(12, 5, True)
+    assert np.array_equal(full["feature"], base["feature"])
+    c.close()
+
+
+# ---- --subsample (mart.cc:287-329, lambdamart.cc:85-102) ----------------------------
+def _subset_trainer(ora, full, x, S):
+    """Oracle tree machinery over the documents S with the thresholds of the WHOLE
+    set (Mart::init runs before any sampling)."""
+    t = ora.Trainer.__new__(ora.Trainer)
+    t.N, t.F = len(S), full.F
+    t.col = np.ascontiguousarray(x[S].T.astype(np.float32))
+    t.thr, t.thr_size, t.cap = full.thr, full.thr_size, full.cap
+    t.stmap, t.count0 = ora.binmap(t.col, t.thr, t.thr_size)
+    t._td = ora.TrainData(t.N, t.F, t.cap, t.col.ctypes.data, t.stmap.ctypes.data, t.thr.ctypes.data,
+                          t.thr_size.ctypes.data)
+    return t
+
+
+@pytest.mark.parametrize("algo", ["LAMBDAMART", "MART"])
+@pytest.mark.parametrize("subsample", [0.5, 700.0])
+def test_subsample_iteration(qr, ora, algo, subsample):
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=40, F=24, seed=37, ragged=True)
+    N = len(labels)
+    c, thr, ts = _ctx(qr, x, labels, qoff, 64)
+    full = ora.Trainer(x, 64)
+    rng = np.random.default_rng(5)
+    scores = np.round(rng.standard_normal(N), 1)            # ties inside queries
+    c.set_scores(scores)
+    c.set_subsample(subsample, seed=3)
+    k = int(subsample) if subsample > 1 else int(np.floor(np.float32(subsample) * np.float32(N)))
+    seen = []
+    for it in range(3):
+        s0 = c.get_scores()
+        if algo == "LAMBDAMART":
+            c.compute_lambdas("NDCG", 10)
+        else:
+            c.compute_residuals()
+        lam, w = c.get_pseudo()
+        nodes = c.fit_tree(8, 2, algo == "LAMBDAMART")
+        # the leaves partition the sample (the root's own list is recycled by its
+        # grandchildren: the two document lists ping-pong)
+        parts = [c.node_samples(int(i)).astype(np.int64) for i in np.nonzero(nodes["feature"] < 0)[0]]
+        assert all(np.all(np.diff(p) > 0) for p in parts)
+        S = np.sort(np.concatenate(parts))
+        assert len(S) == k == nodes[0]["nsamples"] and np.all(np.diff(S) > 0)
+        seen.append(S)
+        if algo == "LAMBDAMART":
+            # the queries cleaned of the other documents (lambdamart.cc:85-102)
+            present = np.zeros(N, bool)
+            present[S] = True
+            cq = np.concatenate([[0], np.cumsum([present[int(qoff[q]):int(qoff[q + 1])].sum()
+                                                 for q in range(len(qoff) - 1)])]).astype(np.uint64)
+            olam, ow = ora.lambdas(labels[S], s0[S], cq, 10, 1)
+            assert np.allclose(lam[S], olam, rtol=1e-10, atol=1e-14)
+            assert np.allclose(w[S], ow, rtol=1e-10, atol=1e-14)
+            assert not lam[~present].any() and not w[~present].any()
+            pl, pw = olam, ow
+        else:
+            assert np.allclose(lam, labels.astype(np.float64) - s0, rtol=0, atol=0)   # every document
+            pl, pw = lam[S], None
+        st = _subset_trainer(ora, full, x, S)
+        ot = st.fit_tree(pl, nleaves=8, minls=2)
+        st.update_output(ot, pl, pw)
+        assert_tree_parity(st.stmap, ot["nodes"], nodes, value_rtol=1e-9)
+        # every training document is updated, in or out of the sample (mart.cc:345)
+        c.update_scores(0.1)
+        walk = np.zeros(N, np.int64)
+        while True:
+            nd = nodes[walk]
+            idx = np.nonzero(nd["feature"] >= 0)[0]
+            if not len(idx):
+                break
+            go = x[idx, nd["feature"][idx]] <= nd["threshold"][idx]
+            walk[idx] = np.where(go, nd["left"][idx], nd["right"][idx])
+        assert np.array_equal(c.get_scores(), s0 + 0.1 * nodes["value"][walk])
+    assert not np.array_equal(seen[0], seen[1])             # a fresh sample every iteration
+    # reproducible stream
+    c.set_scores(scores)
+    c.set_subsample(subsample, seed=3)
+    c.compute_residuals() if algo == "MART" else c.compute_lambdas("NDCG", 10)
+    again = c.fit_tree(8, 2, algo == "LAMBDAMART")
+    assert np.array_equal(np.sort(np.concatenate([c.node_samples(int(i)).astype(np.int64)
+                                                  for i in np.nonzero(again["feature"] < 0)[0]])), seen[0])
+    # subsample 1 (or >= N documents) switches it off
+    c.set_subsample(1.0)
+    c.compute_lambdas("NDCG", 10)
+    assert c.fit_tree(8, 2, True)[0]["nsamples"] == N
+    c.close()

@@ -46,7 +46,7 @@ class Mart:
 
     def __init__(self, algo="LAMBDAMART", ntrees=1000, shrinkage=0.1, nthresholds=0,
                  nleaves=10, minls=1, esr=100, metric="NDCG", cutoff=10, device=0,
-                 ctx=None, dist=None, depth=3):
+                 ctx=None, dist=None, depth=3, subsample=1.0, max_features=1.0, seed=0):
         if algo not in ALGOS:
             raise ValueError(f"unsupported algorithm {algo}")
         self.algo, self.ntrees, self.shrinkage = algo, ntrees, shrinkage
@@ -55,6 +55,8 @@ class Mart:
         self.ctx = ctx if ctx is not None else Context(device)
         self.dist = dist
         self.depth = depth
+        # --subsample / --max-features (mart.cc:287-329, rt.cc:222-243), reproducible streams
+        self.subsample, self.max_features, self.seed = subsample, max_features, seed
         self.oblivious = algo.startswith("OBV")  # obliviousmart.cc / obliviouslambdamart.cc
         self.ensemble = Ensemble((1 << (depth + 1)) - 1 if self.oblivious else 2 * nleaves + 1)
         self.thr = self.thr_size = None
@@ -68,6 +70,10 @@ class Mart:
             self.ctx.upload_valid(*valid)
         self.thr, self.thr_size = self.ctx.build_bins(self.nthresholds)
         self.ctx.reset_scores()
+        if self.subsample != 1.0:
+            self.ctx.set_subsample(self.subsample, self.seed)
+        if self.max_features != 1.0:
+            self.ctx.set_max_features(self.max_features, self.seed)
 
     def _fit_tree(self, newton):
         if self.oblivious:
@@ -86,7 +92,7 @@ class Mart:
         # scores it ranks (= the previous iteration's, mart.cc:347) falls out of it:
         # without a validation set the bookkeeping of mart.cc:369-375 simply runs
         # one iteration late (same values, same best model at the end).
-        fused = lam and valid is None
+        fused = lam and valid is None and self.subsample == 1.0  # a sampled ranking is not the metric's
         for m in range(self.ntrees):
             if valid is not None and self.esr and m > self.best_model + self.esr:
                 break

@@ -18,10 +18,14 @@ N > 1 (quickrank_amd/dist.py), two layouts:
                     queries, all features; seed 42 + rank): the job is N x 1M documents,
                     one int64 all-reduce per node histogram, per-GPU work fixed
                     -> "scaling": "weak"; value = all ranks' documents / time.
+                    The same run then also measures BASELINE.json's configs[2] as it
+                    is written (object "config2_feature_sharded": the SAME 1M set on
+                    every rank, feature blocks sharded, "strong"); --no-config2 skips it.
   --shard features  the 1M-document set replicated, feature blocks of the bin
-                    matrix sharded -> "scaling": "strong" (DESIGN.md section 6 on why
-                    this cannot beat one GPU at 1M documents).
-Prints ONE JSON line on rank 0.
+                    matrix sharded -> "scaling": "strong" as the headline (DESIGN.md
+                    section 6 on why this cannot beat one GPU at 1M documents).
+Prints ONE JSON line on rank 0 (stdout carries nothing else: library banners are
+routed to stderr).
 """
 import argparse
 import json
@@ -125,9 +129,17 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=2500)
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--shard", choices=["docs", "features"], default="docs")
+    ap.add_argument("--no-config2", action="store_true",
+                    help="N > 1, --shard docs: skip the extra feature-sharded (config 2) measurement")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (process group, sharded driver) with one rank")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON): libraries that print banners to
+    # file descriptor 1 (RCCL does at communicator creation) go to stderr instead
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -222,6 +234,44 @@ def main():
     prof = ctx.prof_get()
     ctx.prof_enable(False)
 
+    # BASELINE.json configs[2] literally: the SAME 1M x 136 set on every rank, feature
+    # blocks of the bin matrix sharded, total work fixed ("strong").  Reported next
+    # to the headline when the headline is the document-sharded layout.
+    config2 = None
+    if docs_mode and not args.no_config2:
+        from quickrank_amd.dist import ShardedTreeFitter
+        xf, lf, qf = synth(args.queries, args.docs_per_query, args.features, seed=42)
+        c2 = Context(local_rank, rank=rank, world=world, stream=stream)
+        c2.upload(xf, lf, qf)
+        c2.build_bins(args.nthresholds)
+        c2.reset_scores()
+        f2 = ShardedTreeFitter(c2)
+
+        def step2():
+            c2.compute_lambdas("NDCG", 10)
+            f2.fit_tree(c2, args.nleaves, 1, True, read=False)
+            c2.update_scores(0.1)
+            c2.metric_last()
+            c2.tree_nodes()
+        for _ in range(args.warmup):
+            step2()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step2()
+        sync()
+        e2 = time.perf_counter() - t0
+        t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e2 = float(t.item())
+        config2 = {"workload": f"the same {len(lf)} docs x {xf.shape[1]} features on every rank",
+                   "parallelism": f"feature-block sharding x{world}: best-split records all-gather + "
+                                  "go-left mask all-reduce per split",
+                   "scaling": "strong", "value": len(lf) * args.steps / e2, "unit": "docs/s",
+                   "ms_per_step": e2 / args.steps * 1e3}
+        c2.close()
+        del xf, lf, qf
+
     def tree_shape(t):
         # sigma = documents whose histogram is built directly per
         # tree / N (we build the smaller child; the reference always the left one),
@@ -273,11 +323,16 @@ def main():
                        "pi": round(float(np.mean([tree_shape(t)[2] for t in trees[-args.steps:]])), 3)},
             "roofline": roof,
         }
+        if config2 is not None:
+            out["config2_feature_sharded"] = config2
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x, labels, qoff, args)
         if world == 1 and not args.no_scoring:
             out["ensemble_scoring"] = scoring_metric(ctx, args, torch)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -41,12 +41,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def synth(nq, dpq, F, seed=42):
+def synth(nq, dpq, F, seed=42, sparse_cols=0, zero_frac=0.9):
     """MSLR-shaped synthetic data: U[0,1) f32 features, labels 0..4 driven by
-    the first four features."""
+    the first four features.  sparse_cols > 0 turns the LAST
+    that many columns into MSLR-like count features: zero with probability
+    zero_frac, else one of 32 integer levels (the "uniques <= nthresholds" threshold
+    branch, and one very hot bin per column)."""
     rng = np.random.default_rng(seed)
     N = nq * dpq
     x = rng.random((N, F), dtype=np.float32)
+    if sparse_cols:
+        c0 = F - sparse_cols
+        lv = np.floor(x[:, c0:] * 32).astype(np.float32) + 1
+        lv[rng.random((N, sparse_cols), dtype=np.float32) < zero_frac] = 0
+        x[:, c0:] = lv
     labels = np.minimum(4, np.floor(1.25 * x[:, :4].sum(axis=1, dtype=np.float64))).astype(np.float32)
     qoff = (np.arange(nq + 1, dtype=np.uint64) * dpq)
     return x, labels, qoff
@@ -128,6 +136,9 @@ def main():
     ap.add_argument("--score-docs", type=int, default=10000000)
     ap.add_argument("--cpu-queries", type=int, default=2500)
     ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--sparse-cols", type=int, default=0,
+                    help="make the last K feature columns MSLR-like sparse counts (robustness runs)")
+    ap.add_argument("--zero-frac", type=float, default=0.9)
     ap.add_argument("--shard", choices=["docs", "features"], default="docs")
     ap.add_argument("--no-config2", action="store_true",
                     help="N > 1, --shard docs: skip the extra feature-sharded (config 2) measurement")
@@ -168,7 +179,8 @@ def main():
 
     docs_mode = multi and args.shard == "docs"
     x, labels, qoff = synth(args.queries, args.docs_per_query, args.features,
-                            seed=42 + rank if docs_mode else 42)
+                            seed=42 + rank if docs_mode else 42, sparse_cols=args.sparse_cols,
+                            zero_frac=args.zero_frac)
     N, F = x.shape
     n_job = N * world if docs_mode else N        # documents one step processes
     stream = torch.cuda.current_stream().cuda_stream if multi else None
@@ -313,7 +325,9 @@ def main():
                                    f"{args.queries * (world if docs_mode else 1)} queries"
                                    + (f" ({N} docs per GPU)" if docs_mode else "") + ", "
                                    f"LambdaMART {args.nleaves} leaves, {args.nthresholds} thresholds, "
-                                   "NDCG@10, shrinkage 0.1, min-leaf-support 1",
+                                   "NDCG@10, shrinkage 0.1, min-leaf-support 1"
+                                   + (f", last {args.sparse_cols} columns sparse counts ({args.zero_frac:.0%} zeros)"
+                                      if args.sparse_cols else ""),
                        "parallelism": "1 GPU" if world == 1 else
                                       (f"document sharding x{world}: one int64 all-reduce per node histogram"
                                        if docs_mode else f"feature-block sharding x{world}"),

@@ -9,6 +9,8 @@
 // model through LDS in batches of trees; one lane walks one doc.  The per-doc
 // sum runs over the trees in ensemble order with a separate multiply and add
 // (no FMA contraction), so scores are bit-identical to the reference's.
+#include <algorithm>
+
 #include "qr_internal.h"
 
 struct DevNode {   // 16 B
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void k_doc_bins(const float *__restrict__ x, c
                                                   const float *__restrict__ thr,
                                                   const uint32_t *__restrict__ thr_cnt,
                                                   const uint32_t tmax, const uint32_t lds_thr,
-                                                  BT *__restrict__ out) {
+                                                  BT *__restrict__ out, const uint32_t nan_low) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *lt = reinterpret_cast<float *>(smem);                       // [DB_FG][tmax] when lds_thr
   BT *tile = reinterpret_cast<BT *>(smem + (lds_thr ? (size_t)DB_FG * tmax * 4 : 0));  // [DB_FG][64]
@@ -234,7 +236,9 @@ __global__ __launch_bounds__(256) void k_doc_bins(const float *__restrict__ x, c
           else
             hi = mid;
         }
-        if (v != v) lo = cnt[f];  // NaN: x <= thr is false for every threshold
+        // NaN: `x <= thr` is false for every threshold (tree walk: always right) and so
+        // is `x > thr` (the oblivious scorer's test: always left)
+        if (v != v) lo = nan_low ? 0u : cnt[f];
         b = (BT)lo;
       }
       tile[f * 64 + r] = b;
@@ -401,7 +405,7 @@ static int launch_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, 
   hipLaunchKernelGGL(k_doc_bins<BT>,
                      dim3((unsigned)((nblk + DB_BLOCKS - 1) / DB_BLOCKS), (unsigned)((F + DB_FG - 1) / DB_FG)),
                      dim3(256), lds_a, c->stream, d_x, (uint32_t)N, (uint32_t)F, (uint32_t)xstride,
-                     c->d_sb_thr, c->d_sb_thr_cnt, (uint32_t)c->sb_tmax, lds_thr, (BT *)c->d_sb_bins);
+                     c->d_sb_thr, c->d_sb_thr_cnt, (uint32_t)c->sb_tmax, lds_thr, (BT *)c->d_sb_bins, 0u);
   QR_CHECK(c, hipGetLastError());
   switch (nw) {
     case 16: return launch_binned_nw<BT, 16>(c, d_x, N, xstride, d_out, tbatch);
@@ -409,6 +413,133 @@ static int launch_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, 
     case 8: return launch_binned_nw<BT, 8>(c, d_x, N, xstride, d_out, tbatch);
     default: return launch_binned_nw<BT, 4>(c, d_x, N, xstride, d_out, tbatch);
   }
+}
+
+// ===========================================================================
+// Oblivious ensembles on binned documents (generate_oblivious.cc:237-324): every
+// level of a tree tests ONE (feature, threshold) for all documents, so with the
+// documents' bins in LDS as [feature][lane] a level costs one conflict-free byte
+// read, a compare and a shift-or; the (feature, threshold index) pairs are uniform
+// over the wave.  `x > thr`  <=>  bin(x) > index(thr)  (NaN -> bin 0 -> false, as
+// the f32 comparison).  Four trees are in flight per lane; leaf * weight (f32
+// weight promoted, :312-324) is added strictly in tree order.
+// ===========================================================================
+template <typename BT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_obl_score_bin(
+    const BT *__restrict__ bins, const uint32_t N, const uint32_t F,
+    const uint32_t *__restrict__ fk, const double *__restrict__ leaves,
+    const float *__restrict__ weights, const uint32_t *__restrict__ depths,
+    const uint32_t ntrees, const uint32_t D, const uint32_t tbatch, double *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t doc_bytes = ((size_t)F * 64 * sizeof(BT) + 15) & ~(size_t)15;
+  BT *mybins = reinterpret_cast<BT *>(smem + wave * doc_bytes);
+  const uint32_t nl = 1u << D;
+  double *lv = reinterpret_cast<double *>(smem + NW * doc_bytes);  // [tbatch][nl]
+  uint32_t *lfk = reinterpret_cast<uint32_t *>(lv + (size_t)tbatch * nl);  // [tbatch][D]
+  float *lw = reinterpret_cast<float *>(lfk + (size_t)tbatch * D);         // [tbatch]
+  uint32_t *lm = reinterpret_cast<uint32_t *>(lw + tbatch);                // [tbatch] actual depth
+  const uint32_t nblk = (N + 63) / 64;
+  const uint32_t blk = blockIdx.x * NW + wave;
+  const bool live = blk < nblk;
+  if (live) {
+    const BT *src = bins + (size_t)blk * F * 64;
+    for (uint32_t i = lane; i < F * 64; i += 64) mybins[i] = src[i];
+  }
+  double score = 0.0;
+  for (uint32_t t0 = 0; t0 < ntrees; t0 += tbatch) {
+    const uint32_t tb = t0 + tbatch <= ntrees ? tbatch : ntrees - t0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < tb * nl; i += NW * 64) lv[i] = leaves[(size_t)t0 * nl + i];
+    for (uint32_t i = threadIdx.x; i < tb * D; i += NW * 64) lfk[i] = fk[(size_t)t0 * D + i];
+    for (uint32_t i = threadIdx.x; i < tb; i += NW * 64) {
+      lw[i] = weights[t0 + i];
+      lm[i] = depths ? depths[t0 + i] : D;
+    }
+    __syncthreads();
+    if (!live) continue;
+    uint32_t t = 0;
+    for (; t + 4 <= tb; t += 4) {
+      uint32_t idx[4] = {0, 0, 0, 0};
+      uint32_t m[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) m[u] = lm[t + u];
+      for (uint32_t l = 0; l < D; ++l) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (l < m[u]) {  // uniform over the wave
+            const uint32_t v = lfk[(t + u) * D + l];
+            const uint32_t b = mybins[(v & 0xffffu) * 64 + lane];
+            idx[u] |= (uint32_t)(b > (v >> 16)) << (m[u] - 1 - l);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double v = (double)lw[t + u] * lv[(size_t)(t + u) * nl + idx[u]];
+        score = score + v;
+      }
+    }
+    for (; t < tb; ++t) {
+      const uint32_t m = lm[t];
+      uint32_t idx = 0;
+      for (uint32_t l = 0; l < m; ++l) {
+        const uint32_t v = lfk[t * D + l];
+        const uint32_t b = mybins[(v & 0xffffu) * 64 + lane];
+        idx |= (uint32_t)(b > (v >> 16)) << (m - 1 - l);
+      }
+      const double v = (double)lw[t] * lv[(size_t)t * nl + idx];
+      score = score + v;
+    }
+  }
+  if (live && blk * 64 + lane < N) out[(size_t)blk * 64 + lane] = score;
+}
+
+template <typename BT>
+static int launch_obl_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, double *d_out) {
+  constexpr int NW = 8;
+  const size_t F = c->ob_F;
+  const size_t doc_bytes = (F * 64 * sizeof(BT) + 15) & ~(size_t)15;
+  const size_t nl = (size_t)1 << c->obl_depth;
+  const size_t per_tree = nl * 8 + c->obl_depth * 4 + 8;
+  const size_t budget = 150 * 1024;
+  if (NW * doc_bytes + 4 * per_tree + 64 > budget) return -1;  // caller falls back
+  size_t tbatch = (budget - NW * doc_bytes - 64) / per_tree;
+  tbatch = std::min<size_t>(tbatch, 128) & ~(size_t)3;
+  if (tbatch > c->obl_trees) tbatch = (c->obl_trees + 3) & ~(size_t)3;
+  const size_t nblk = (N + 63) / 64;
+  const size_t need = nblk * 64 * F * sizeof(BT);
+  if (need > c->sb_bins_bytes) {
+    if (c->d_sb_bins) (void)hipFree(c->d_sb_bins);
+    c->d_sb_bins = nullptr;
+    QR_CHECK(c, hipMalloc(&c->d_sb_bins, need));
+    c->sb_bins_bytes = need;
+  }
+  const uint32_t lds_thr = (size_t)DB_FG * c->ob_tmax * 4 <= 96 * 1024 ? 1 : 0;
+  const size_t lds_a = (lds_thr ? (size_t)DB_FG * c->ob_tmax * 4 : 0) + DB_FG * 64 * sizeof(BT);
+  if (lds_a > 64 * 1024)
+    QR_CHECK(c, hipFuncSetAttribute((const void *)k_doc_bins<BT>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+  hipLaunchKernelGGL(k_doc_bins<BT>,
+                     dim3((unsigned)((nblk + DB_BLOCKS - 1) / DB_BLOCKS), (unsigned)((F + DB_FG - 1) / DB_FG)),
+                     dim3(256), lds_a, c->stream, d_x, (uint32_t)N, (uint32_t)F, (uint32_t)xstride,
+                     c->d_ob_thr, c->d_ob_thr_cnt, (uint32_t)c->ob_tmax, lds_thr, (BT *)c->d_sb_bins, 1u);
+  QR_CHECK(c, hipGetLastError());
+  const size_t lds = NW * doc_bytes + tbatch * per_tree + 64;
+  QR_CHECK(c, hipFuncSetAttribute((const void *)k_obl_score_bin<BT, NW>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_obl_score_bin<BT, NW>), dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds,
+                     c->stream, (const BT *)c->d_sb_bins, (uint32_t)N, (uint32_t)F, c->d_ob_fk,
+                     c->d_obl_leaves, c->d_obl_w, c->d_obl_depths, (uint32_t)c->obl_trees,
+                     (uint32_t)c->obl_depth, (uint32_t)tbatch, d_out);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+int qr_k_obl_score_fast(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out) {
+  if (!c->ob_ready || F < c->ob_F) return -1;
+  return c->ob_u8 ? launch_obl_binned<uint8_t>(c, d_x, N, F, d_out)
+                  : launch_obl_binned<uint16_t>(c, d_x, N, F, d_out);
 }
 
 int qr_k_ensemble_score_fast(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out) {

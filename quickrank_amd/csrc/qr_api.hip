@@ -122,7 +122,7 @@ void qr_ctx_destroy(qr_ctx *c) {
   if (c->ev_nodes) (void)hipEventDestroy(c->ev_nodes);
   dfree(c->d_keys); dfree(c->d_tied);
   dfree(c->d_obl_feat); dfree(c->d_obl_thr); dfree(c->d_obl_leaves); dfree(c->d_obl_w);
-  dfree(c->d_obl_depths);
+  dfree(c->d_obl_depths); dfree(c->d_ob_fk); dfree(c->d_ob_thr); dfree(c->d_ob_thr_cnt);
   if (c->d_sb_nodes) (void)hipFree(c->d_sb_nodes);
   if (c->d_sb_bins) (void)hipFree(c->d_sb_bins);
   dfree(c->d_sb_leaves); dfree(c->d_sb_root); dfree(c->d_sb_thr); dfree(c->d_sb_thr_cnt);
@@ -1236,6 +1236,46 @@ int qr_oblivious_upload(qr_ctx *c, const uint32_t *feat, const float *thr,
   }
   c->obl_trees = ntrees;
   c->obl_depth = depth;
+  // binned form: per feature the sorted distinct thresholds the ensemble tests; per
+  // (tree, level) the feature and the index of its threshold among them
+  c->ob_ready = false;
+  dfree(c->d_ob_fk); dfree(c->d_ob_thr); dfree(c->d_ob_thr_cnt);
+  uint32_t maxf = 0;
+  for (size_t i = 0; i < ntrees * depth; ++i) maxf = std::max(maxf, feat[i]);
+  if (maxf < 65535) {
+    const size_t F = (size_t)maxf + 1;
+    std::vector<std::vector<float>> tv(F);
+    for (size_t i = 0; i < ntrees * depth; ++i) tv[feat[i]].push_back(thr[i]);
+    size_t tmax = 1;
+    for (auto &v : tv) {
+      std::sort(v.begin(), v.end());
+      v.erase(std::unique(v.begin(), v.end()), v.end());
+      tmax = std::max(tmax, v.size());
+    }
+    if (tmax <= 65535) {
+      std::vector<uint32_t> fk(ntrees * depth), tc(F);
+      std::vector<float> tt(F * tmax, 0.0f);
+      for (size_t i = 0; i < ntrees * depth; ++i) {
+        const auto &v = tv[feat[i]];
+        const size_t k = std::lower_bound(v.begin(), v.end(), thr[i]) - v.begin();
+        fk[i] = feat[i] | (uint32_t)(k << 16);
+      }
+      for (size_t f = 0; f < F; ++f) {
+        tc[f] = (uint32_t)tv[f].size();
+        std::copy(tv[f].begin(), tv[f].end(), tt.begin() + f * tmax);
+      }
+      QR_CHECK(c, dalloc(&c->d_ob_fk, fk.size()));
+      QR_CHECK(c, dalloc(&c->d_ob_thr, tt.size()));
+      QR_CHECK(c, dalloc(&c->d_ob_thr_cnt, tc.size()));
+      QR_CHECK(c, hipMemcpy(c->d_ob_fk, fk.data(), fk.size() * 4, hipMemcpyHostToDevice));
+      QR_CHECK(c, hipMemcpy(c->d_ob_thr, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
+      QR_CHECK(c, hipMemcpy(c->d_ob_thr_cnt, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
+      c->ob_F = F;
+      c->ob_tmax = tmax;
+      c->ob_u8 = tmax <= 255;
+      c->ob_ready = true;
+    }
+  }
   return QR_OK;
 }
 
@@ -1251,7 +1291,8 @@ int qr_oblivious_score(qr_ctx *c, const float *x, size_t N, size_t F, double *ou
   QR_CHECK(c, hipEventCreate(&e0));
   QR_CHECK(c, hipEventCreate(&e1));
   QR_CHECK(c, hipEventRecord(e0, c->stream));
-  int rc = qr_k_obl_score(c, d_x, N, F, d_o);
+  int rc = qr_k_obl_score_fast(c, d_x, N, F, d_o);  // binned, document-parallel
+  if (rc < 0) rc = qr_k_obl_score(c, d_x, N, F, d_o);  // general fallback (f32 rows in LDS)
   QR_CHECK(c, hipEventRecord(e1, c->stream));
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   if (!rc) {

@@ -324,6 +324,12 @@ struct qr_ctx {
   float *d_obl_thr = nullptr, *d_obl_w = nullptr;
   double *d_obl_leaves = nullptr;
   size_t obl_trees = 0, obl_depth = 0;
+  // binned form of the oblivious ensemble (k_obl_score_bin)
+  bool ob_ready = false, ob_u8 = false;
+  size_t ob_F = 0, ob_tmax = 0;
+  uint32_t *d_ob_fk = nullptr;      // [trees][depth]: feature | threshold index << 16
+  float *d_ob_thr = nullptr;        // [ob_F][ob_tmax] sorted distinct thresholds per feature
+  uint32_t *d_ob_thr_cnt = nullptr;
   // profiling
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -372,3 +378,4 @@ int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
                         double *d_out);
 int qr_k_obl_score(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);
 int qr_k_ensemble_score_fast(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);
+int qr_k_obl_score_fast(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);

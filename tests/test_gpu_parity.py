@@ -291,6 +291,46 @@ def test_oblivious_bit_interleaved_scoring(qr, ora):
     c.close()
 
 
+@pytest.mark.parametrize("T,D,F,pool", [(41, 6, 50, None), (300, 4, 20, None), (64, 8, 9, 3),
+                                        (1000, 6, 136, None), (1200, 6, 5, None)])   # the last one: u16 indices
+def test_oblivious_scoring_binned_edge_cases(qr, T, D, F, pool):
+    """The binned document-parallel scorer against a numpy statement of
+    generate_oblivious.cc:305-324: NaN / +-inf / -0.0 inputs (`x > thr` is false for
+    NaN), values equal to a threshold, u16 threshold indices (more than 255 distinct
+    thresholds on a feature), trees shallower than the array depth, rows wider
+    than the features the model tests, a document count that is not a multiple of 64."""
+    rng = np.random.default_rng(T + D)
+    N = 64 * 37 + 5
+    feat = rng.integers(0, F, (T, D)).astype(np.uint32)
+    if pool:
+        thr = rng.choice(np.array([0.25, 0.5, 0.75], np.float32), (T, D))
+    else:
+        thr = rng.random((T, D)).astype(np.float32)
+    leaves = rng.standard_normal((T, 1 << D))
+    w = (rng.random(T) * 0.2).astype(np.float32)
+    depths = np.sort(rng.integers(1, D + 1, T)).astype(np.uint32)      # stably ordered by depth
+    x = rng.random((N, F + 3), dtype=np.float32)
+    x[::7, 1] = np.nan
+    x[1::11, 2] = np.inf
+    x[2::13, 0] = -np.inf
+    x[3::5, 3] = thr[0, 0]                                             # equal to a threshold
+    x[4::9, 4] = -0.0
+    c = qr.Context(0)
+    for dp in (None, depths):
+        c.upload_oblivious(feat, thr, leaves, w, dp)
+        got, _ = c.score_oblivious(x)
+        want = np.zeros(N)
+        for t in range(T):
+            m = D if dp is None else int(dp[t])
+            idx = np.zeros(N, np.int64)
+            with np.errstate(invalid="ignore"):
+                for l in range(m):
+                    idx |= (x[:, feat[t, l]] > thr[t, l]).astype(np.int64) << (m - 1 - l)
+            want = want + np.float64(w[t]) * leaves[t, idx]
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), dp is None
+    c.close()
+
+
 def test_validation_early_stop_and_rollback(qr, ora):
     from quickrank_amd.trainer import Mart
     x, labels, qoff = make_dataset(nq=40, docs_per_query=30, F=20, seed=7)

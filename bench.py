@@ -80,12 +80,14 @@ def cpu_baseline(x, labels, qoff, args):
                       f"OpenMP x{cores}"}
 
 
-def scoring_metric(ctx, args, torch):
+def scoring_metric(ctx, args, torch, rank=0, world=1, dist=None):
     """Second metric of BASELINE.json ("ensemble-score docs/sec") on config 5 at full
     size by default: 10,000 trees x 64 leaves over 10M docs x 200 f32 features.  The
     8 GB of features are generated on the device (seed 43) and handed over as a
     device pointer (qr_ensemble_score_device); timed with HIP events on the
-    context's stream, after one warm-up pass."""
+    context's stream, after one warm-up pass.  N > 1: the documents are sharded over
+    the ranks (every rank holds the whole model, no collective in the data path):
+    "strong" scaling, value = all documents / the slowest rank's time."""
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     from score_bench import make_model
@@ -93,14 +95,16 @@ def scoring_metric(ctx, args, torch):
     rng = np.random.default_rng(43)
     nodes, w = make_model(args.score_trees, 6, 200, rng)
     g = torch.Generator(device="cuda")
-    g.manual_seed(43)
-    xs = torch.rand((args.score_docs, 200), generator=g, device="cuda", dtype=torch.float32)
-    out = torch.empty(args.score_docs, device="cuda", dtype=torch.float64)
+    g.manual_seed(43 + rank)
+    per = (args.score_docs + world - 1) // world
+    ndocs = max(0, min(per, args.score_docs - rank * per))      # this rank's shard
+    xs = torch.rand((max(ndocs, 1), 200), generator=g, device="cuda", dtype=torch.float32)
+    out = torch.empty(max(ndocs, 1), device="cuda", dtype=torch.float64)
     sc = Context(torch.cuda.current_device(), stream=torch.cuda.current_stream().cuda_stream)
     sc.upload_ensemble(nodes, w)
 
     def run():
-        sc._ck(sc.L.qr_ensemble_score_device(sc.h, C.c_void_p(xs.data_ptr()), args.score_docs, 200,
+        sc._ck(sc.L.qr_ensemble_score_device(sc.h, C.c_void_p(xs.data_ptr()), max(ndocs, 1), 200,
                                              C.c_void_p(out.data_ptr())))
     run()
     torch.cuda.synchronize()
@@ -113,11 +117,16 @@ def scoring_metric(ctx, args, torch):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     sc.close()
+    if dist is not None:
+        t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
     return {"metric": "ensemble-score docs/sec", "value": args.score_docs / ms * 1e3, "unit": "docs/s",
             "node_visits_per_s": args.score_docs * args.score_trees * 6 / ms * 1e3,
             "workload": f"{args.score_trees} trees x 64 leaves (depth 6) over {args.score_docs} docs x 200 "
-                        "features, synthetic, features resident on the device",
-            "ms": ms}
+                        "features, synthetic, features resident on the device"
+                        + (f", documents sharded over {world} GPUs" if world > 1 else ""),
+            "scaling": "strong", "n_gpus": world, "ms": ms}
 
 
 def main():
@@ -295,6 +304,10 @@ def main():
         return (np.minimum(nl, nr).sum() / tot, nl.sum() / tot,
                 t["nsamples"][internal].astype(np.float64).sum() / tot)
 
+    scoring = None
+    if not args.no_scoring:   # every rank takes part (its shard of the documents)
+        scoring = scoring_metric(ctx, args, torch, rank, world, dist)
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = n_job * args.steps / elapsed
@@ -341,8 +354,8 @@ def main():
             out["config2_feature_sharded"] = config2
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x, labels, qoff, args)
-        if world == 1 and not args.no_scoring:
-            out["ensemble_scoring"] = scoring_metric(ctx, args, torch)
+        if scoring is not None:
+            out["ensemble_scoring"] = scoring
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)

@@ -424,12 +424,14 @@ static int launch_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, 
 // the f32 comparison).  Four trees are in flight per lane; leaf * weight (f32
 // weight promoted, :312-324) is added strictly in tree order.
 // ===========================================================================
-template <typename BT, int NW>
+// DC: the array depth when it is a compile-time constant (unrolled level loop), 0 = any
+template <typename BT, int NW, int DC>
 __global__ __launch_bounds__(NW * 64) void k_obl_score_bin(
     const BT *__restrict__ bins, const uint32_t N, const uint32_t F,
     const uint32_t *__restrict__ fk, const double *__restrict__ leaves,
     const float *__restrict__ weights, const uint32_t *__restrict__ depths,
-    const uint32_t ntrees, const uint32_t D, const uint32_t tbatch, double *__restrict__ out) {
+    const uint32_t ntrees, const uint32_t Drt, const uint32_t tbatch, double *__restrict__ out) {
+  const uint32_t D = DC ? (uint32_t)DC : Drt;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t doc_bytes = ((size_t)F * 64 * sizeof(BT) + 15) & ~(size_t)15;
@@ -463,16 +465,23 @@ __global__ __launch_bounds__(NW * 64) void k_obl_score_bin(
       uint32_t idx[4] = {0, 0, 0, 0};
       uint32_t m[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) m[u] = lm[t + u];
-      for (uint32_t l = 0; l < D; ++l) {
+      for (int u = 0; u < 4; ++u) m[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lm[t + u]);
+      auto level = [&](const uint32_t l) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (l < m[u]) {  // uniform over the wave
-            const uint32_t v = lfk[(t + u) * D + l];
+            // (feature, index) is the same for every lane: keep it in scalar registers
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)lfk[(t + u) * D + l]);
             const uint32_t b = mybins[(v & 0xffffu) * 64 + lane];
             idx[u] |= (uint32_t)(b > (v >> 16)) << (m[u] - 1 - l);
           }
         }
+      };
+      if constexpr (DC != 0) {
+#pragma unroll
+        for (uint32_t l = 0; l < (uint32_t)DC; ++l) level(l);
+      } else {
+        for (uint32_t l = 0; l < D; ++l) level(l);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -504,7 +513,11 @@ static int launch_obl_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstri
   const size_t per_tree = nl * 8 + c->obl_depth * 4 + 8;
   const size_t budget = 150 * 1024;
   if (NW * doc_bytes + 4 * per_tree + 64 > budget) return -1;  // caller falls back
-  size_t tbatch = (budget - NW * doc_bytes - 64) / per_tree;
+  // two workgroups per CU when the document tiles allow it (occupancy hides the
+  // dependent LDS reads of the level loop); the rest of the LDS goes to the tree batch
+  const size_t half = 78 * 1024;
+  const size_t room = NW * doc_bytes + 8 * per_tree + 64 <= half ? half : budget;
+  size_t tbatch = (room - NW * doc_bytes - 64) / per_tree;
   tbatch = std::min<size_t>(tbatch, 128) & ~(size_t)3;
   if (tbatch > c->obl_trees) tbatch = (c->obl_trees + 3) & ~(size_t)3;
   const size_t nblk = (N + 63) / 64;
@@ -526,14 +539,24 @@ static int launch_obl_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstri
                      c->d_ob_thr, c->d_ob_thr_cnt, (uint32_t)c->ob_tmax, lds_thr, (BT *)c->d_sb_bins, 1u);
   QR_CHECK(c, hipGetLastError());
   const size_t lds = NW * doc_bytes + tbatch * per_tree + 64;
-  QR_CHECK(c, hipFuncSetAttribute((const void *)k_obl_score_bin<BT, NW>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_obl_score_bin<BT, NW>), dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds,
-                     c->stream, (const BT *)c->d_sb_bins, (uint32_t)N, (uint32_t)F, c->d_ob_fk,
-                     c->d_obl_leaves, c->d_obl_w, c->d_obl_depths, (uint32_t)c->obl_trees,
-                     (uint32_t)c->obl_depth, (uint32_t)tbatch, d_out);
-  QR_CHECK(c, hipGetLastError());
-  return QR_OK;
+  auto launch = [&](auto kernel) -> int {
+    QR_CHECK(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds, c->stream,
+                       (const BT *)c->d_sb_bins, (uint32_t)N, (uint32_t)F, c->d_ob_fk, c->d_obl_leaves,
+                       c->d_obl_w, c->d_obl_depths, (uint32_t)c->obl_trees, (uint32_t)c->obl_depth,
+                       (uint32_t)tbatch, d_out);
+    QR_CHECK(c, hipGetLastError());
+    return QR_OK;
+  };
+  switch (c->obl_depth) {  // the depths quicklearn's --tree-depth usually takes
+    case 3: return launch(k_obl_score_bin<BT, NW, 3>);
+    case 4: return launch(k_obl_score_bin<BT, NW, 4>);
+    case 5: return launch(k_obl_score_bin<BT, NW, 5>);
+    case 6: return launch(k_obl_score_bin<BT, NW, 6>);
+    case 8: return launch(k_obl_score_bin<BT, NW, 8>);
+    default: return launch(k_obl_score_bin<BT, NW, 0>);
+  }
 }
 
 int qr_k_obl_score_fast(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out) {

@@ -160,7 +160,7 @@ class Context:
             raise QrError(f"qr_ctx_create: {self.L.qr_last_error(None).decode()} (code {rc})")
         self.h = h
         self.N = self.F = self.Q = 0
-        self.vN = 0
+        self.vN = self.vQ = 0
         if stream is not None:
             self._ck(self.L.qr_ctx_set_stream(self.h, C.c_void_p(stream)))
         if doc_shard is not None:
@@ -201,6 +201,7 @@ class Context:
         labels = np.ascontiguousarray(labels, np.float32)
         qoff = np.ascontiguousarray(qoff, np.uint64)
         self.vN = x.shape[0]
+        self.vQ = len(qoff) - 1
         self._ck(self.L.qr_valid_upload(self.h, _ptr(x), self.vN, _ptr(labels), _ptr(qoff),
                                         len(qoff) - 1))
 

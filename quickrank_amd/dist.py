@@ -143,6 +143,25 @@ class DocShardedTrainer:
         return ctx.tree_leaves_finish(nleaves, newton, read=read)
 
 
+    def metric_eval(self, which=0, metric="NDCG", cutoff=10):
+        """Metric::evaluate_dataset (metric.h:77-106) over ALL ranks' queries of the
+        training (0) or validation (1) set: every rank evaluates its own queries on
+        the device; the per-rank (sum, count) pairs are all-gathered and added in
+        rank order."""
+        local = self.ctx.metric_eval(which, metric, cutoff)
+        nq = self.ctx.Q if which == 0 else self.ctx.vQ
+        t = self.torch.zeros(2 * self.world, dtype=self.torch.float64)
+        t[2 * self.rank] = local * nq
+        t[2 * self.rank + 1] = nq
+        if self.hist.is_cuda:
+            t = t.to(self.hist.device)
+        self._sum(t)
+        t = t.cpu().numpy().reshape(self.world, 2)
+        total = sum(float(a) for a in t[:, 0])
+        count = sum(float(a) for a in t[:, 1])
+        return total / count if count else 0.0
+
+
 def gather_thresholds(ctx, nthresholds, group=None):
     """Thresholds of the whole (document-sharded) training set: every rank's column
     statistics are all-gathered and merged with the reference's rule."""

@@ -32,8 +32,10 @@ def _worker(rank, world, port, q, layout):
     N, Q = len(labels), len(qoff) - 1
     stream = torch.cuda.current_stream().cuda_stream
     ok = True
+    vx, vl, vq = make_dataset(nq=30, docs_per_query=25, F=70, seed=30)
     single = qr.Context(0)
     single.upload(x, labels, qoff)
+    single.upload_valid(vx, vl, vq)
     single.build_bins(64)
     single.reset_scores()
     if layout == "docs":
@@ -41,6 +43,9 @@ def _worker(rank, world, port, q, layout):
         d0, d1 = int(qoff[cut[0]]), int(qoff[cut[1]])
         c = qr.Context(0, rank=rank, world=world, stream=stream, doc_shard=(N, Q))
         c.upload(x[d0:d1], labels[d0:d1], qoff[cut[0]:cut[1] + 1] - qoff[cut[0]])
+        vcut = [0, 11, len(vq) - 1][rank:rank + 2]                 # the validation set is sharded too
+        v0, v1 = int(vq[vcut[0]]), int(vq[vcut[1]])
+        c.upload_valid(vx[v0:v1], vl[v0:v1], vq[vcut[0]:vcut[1] + 1] - vq[vcut[0]])
         c.build_bins_with(*gather_thresholds(c, 64))
         c.reset_scores()
         tr = DocShardedTrainer(c)
@@ -55,7 +60,11 @@ def _worker(rank, world, port, q, layout):
                 ok = ok and np.array_equal(got[k], want[k])
             ok = ok and np.allclose(got["value"], want["value"], rtol=1e-11, atol=1e-14)
             ok = ok and abs(c.metric_last() - single.metric_last()) < 1e-12
+            # training / validation metric over all ranks' queries
+            ok = ok and abs(tr.metric_eval(0) - single.metric_eval(0)) < 1e-12
+            ok = ok and abs(tr.metric_eval(1) - single.metric_eval(1)) < 1e-12
         ok = ok and np.allclose(c.get_scores(), single.get_scores()[d0:d1], rtol=1e-10, atol=1e-13)
+        ok = ok and np.allclose(c.get_valid_scores(), single.get_valid_scores()[v0:v1], rtol=1e-10, atol=1e-13)
     else:
         c = qr.Context(0, rank=rank, world=world, stream=stream)
         c.upload(x, labels, qoff)

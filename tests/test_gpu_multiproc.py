@@ -104,3 +104,63 @@ def test_two_processes_one_gpu(layout):
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+def test_train_multi_gpu_script_matches_quicklearn(tmp_path):
+    """scripts/train_multi_gpu.py with two ranks (gloo, one GPU) writes the same model
+    -- same splits, leaf outputs to rounding -- as the single-GPU quicklearn binary on
+    the same SVMLight files, validation early-stop bookkeeping included."""
+    import subprocess
+    import ctypes as C
+    from datagen import make_dataset
+    from quickrank_amd import build, _capi
+    from test_gpu_cli import _write_svml
+    build.build()
+    build.build_host()
+    x, labels, qoff = make_dataset(nq=120, docs_per_query=40, F=30, seed=51)
+    x = np.array([[np.float32(f"{float(v):.9g}") for v in row] for row in x], np.float32)
+    vx, vl, vq = make_dataset(nq=40, docs_per_query=30, F=30, seed=52)
+    tr, va = str(tmp_path / "train.svml"), str(tmp_path / "valid.svml")
+    _write_svml(tr, x, labels, qoff)
+    _write_svml(va, vx, vl, vq)
+    common = ["--algo", "LAMBDAMART", "--train", tr, "--valid", va, "--num-trees", "8", "--num-leaves", "8",
+              "--num-thresholds", "64", "--min-leaf-support", "5", "--end-after-rounds", "0"]
+    m1, m2 = str(tmp_path / "one.xml"), str(tmp_path / "two.xml")
+    r = subprocess.run([os.path.join(ROOT, "quickrank_amd", "bin", "quicklearn")] + common + ["--model-out", m1],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    port = 33500 + os.getpid() % 2000
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "scripts", "train_multi_gpu.py")] + common
+                                      + ["--model-out", m2, "--backend", "gloo"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    L = C.CDLL(build.HOST_LIB)
+    sz = C.c_size_t
+    L.qrh_model_read.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(sz), C.POINTER(sz), sz, sz]
+
+    def load(path):
+        nt, mn = sz(), sz()
+        assert L.qrh_model_read(path.encode(), None, None, C.byref(nt), C.byref(mn), 0, 0) == 0
+        nodes = np.zeros((nt.value, mn.value), _capi.NODE_DTYPE)
+        w = np.zeros(nt.value)
+        assert L.qrh_model_read(path.encode(), nodes.ctypes.data, w.ctypes.data, C.byref(nt), C.byref(mn),
+                                nodes.size, nt.value) == 0
+        return nodes, w
+    a, wa = load(m1)
+    b, wb = load(m2)
+    assert a.shape == b.shape and np.array_equal(wa, wb)
+    for k in ("feature", "threshold", "left", "right"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.allclose(a["value"], b["value"], rtol=1e-10, atol=1e-13)
+
+    def table(out):
+        return [ln.replace("*", "").split() for ln in out.splitlines() if ln.split() and ln.split()[0].isdigit()]
+    t1, t2 = table(r.stdout), table(outs[0][0])
+    assert len(t1) == len(t2) == 8
+    for u, v in zip(t1, t2):
+        assert u[0] == v[0] and abs(float(u[1]) - float(v[1])) < 2e-4 and abs(float(u[2]) - float(v[2])) < 2e-4

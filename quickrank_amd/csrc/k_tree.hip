@@ -1512,6 +1512,36 @@ __global__ __launch_bounds__(256) void k_score_update(
   scores[id] = scores[id] + add;
 }
 
+// The same update in document order: walk the tree on the feature-major bins
+// (x <= threshold  <=>  bin <= slot).  Scores are read and written coalesced, a
+// level costs one byte per document out of a row that neighbouring documents share;
+// the membership version above touches scores[id] through the leaves' document
+// lists, i.e. one 32-byte sector per 8-byte score.  Needs every feature on this
+// rank; also the update of a --subsample iteration, whose leaves hold the sample only.
+__global__ __launch_bounds__(256) void k_score_update_walk(
+    const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm, const uint32_t N,
+    const int32_t *__restrict__ gf2lf, const double shrinkage, double *__restrict__ scores) {
+  __shared__ int32_t s_lf[QR_MAXNODES], s_thr[QR_MAXNODES], s_left[QR_MAXNODES], s_right[QR_MAXNODES];
+  __shared__ double s_val[QR_MAXNODES];
+  const int nn = ts->nnodes;
+  for (int i = threadIdx.x; i < nn; i += 256) {
+    const int f = ts->nodes[i].feature;
+    s_lf[i] = f >= 0 ? gf2lf[f] : -1;
+    s_thr[i] = ts->nodes[i].thr_id;
+    s_left[i] = ts->nodes[i].left;
+    s_right[i] = ts->nodes[i].right;
+    s_val[i] = ts->nodes[i].value;
+  }
+  __syncthreads();
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= N) return;
+  int n = 0;
+  while (s_lf[n] >= 0)
+    n = (int)fm[(size_t)s_lf[n] * N + d] <= s_thr[n] ? s_left[n] : s_right[n];
+  const double add = shrinkage * s_val[n];
+  scores[d] = scores[d] + add;
+}
+
 // mart.cc:447-457: validation scores by walking the tree on raw f32 rows
 __global__ __launch_bounds__(256) void k_valid_update(
     const QrTreeState *__restrict__ ts, const float *__restrict__ raw,
@@ -2012,11 +2042,12 @@ int qr_k_tree_leaves_global(qr_ctx *c, int newton) {
 
 int qr_k_scores_update(qr_ctx *c, double shrinkage) {
   const unsigned grid = (unsigned)((c->N + 255) / 256);
-  if (c->sub_k) {
-    // the leaves hold the sample only; every training document is updated
-    // (mart.cc:345), so walk the tree on the raw features as for validation
-    hipLaunchKernelGGL(k_valid_update, dim3(grid), dim3(256), 0, c->stream, c->d_tree, c->d_raw,
-                       (uint32_t)c->N, (uint32_t)c->F, shrinkage, c->d_scores);
+  if (c->flocal == (int)c->F) {
+    // every feature is here (single GPU, document-sharded): document-order walk;
+    // also what a --subsample iteration needs (its leaves hold the sample only,
+    // every training document is updated, mart.cc:345)
+    hipLaunchKernelGGL(k_score_update_walk, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
+                       c->d_bins_fm, (uint32_t)c->N, c->d_gf2lf, shrinkage, c->d_scores);
   } else {
     hipLaunchKernelGGL(k_score_update, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
                        c->d_order[0], c->d_order[1], shrinkage, c->d_scores);

@@ -497,3 +497,53 @@ def test_subsample_iteration(qr, ora, algo, subsample):
     c.compute_lambdas("NDCG", 10)
     assert c.fit_tree(8, 2, True)[0]["nsamples"] == N
     c.close()
+
+
+def test_error_paths_return_codes_not_crashes(qr):
+    """Every misuse of the C-ABI comes back as a QrError with a message (the host
+    prints it and exits, as the reference does): nothing asserts or segfaults."""
+    x, labels, qoff = make_dataset(nq=10, docs_per_query=20, F=6, seed=1)
+    c = qr.Context(0)
+    with pytest.raises(qr.QrError, match="no dataset"):
+        c.build_bins(16)
+    with pytest.raises(qr.QrError):
+        c.fit_tree(4, 1, True)
+    with pytest.raises(qr.QrError, match="follows qr_lambda_compute"):
+        c.metric_last()
+    c.upload(x, labels, qoff)
+    with pytest.raises(qr.QrError, match="nthresholds <= 255"):
+        c.build_bins(300)
+    with pytest.raises(qr.QrError, match="bins not built"):
+        c.set_subsample(0.5)
+    c.build_bins(16)
+    with pytest.raises(qr.QrError, match="already built"):
+        c.build_bins(16)
+    with pytest.raises(qr.QrError, match="nleaves must be"):
+        c.fit_tree(5000, 1, True)
+    with pytest.raises(qr.QrError, match="tree depth"):
+        c.fit_oblivious(12, 1, True)
+    with pytest.raises(qr.QrError, match="no fitted tree"):
+        c.update_scores(0.1)
+    with pytest.raises(qr.QrError, match="must be > 0"):
+        c.set_max_features(0.0)
+    with pytest.raises(qr.QrError, match="no validation set"):
+        c.set_valid_scores(np.zeros(0))
+    with pytest.raises(qr.QrError, match="metric must be"):
+        c._ck(c.L.qr_lambda_compute(c.h, 7, 10))
+    bad_q = qoff.copy()
+    bad_q[3] = bad_q[2] - 1
+    with pytest.raises(qr.QrError, match="non-decreasing"):
+        c.upload(x, labels, bad_q)
+    # a sharded context must be driven through the phase calls
+    s = qr.Context(0, rank=0, world=2)
+    s.upload(x, labels, qoff)
+    s.build_bins(16)
+    s.set_pseudo(np.ones(len(labels)), np.ones(len(labels)))
+    with pytest.raises(qr.QrError, match="phase|begin/decide"):
+        s.fit_tree(4, 1, True)
+    with pytest.raises(qr.QrError, match="single-GPU"):
+        s.set_subsample(0.5)
+    with pytest.raises(qr.QrError):
+        qr.Context(0, rank=3, world=2)
+    s.close()
+    c.close()

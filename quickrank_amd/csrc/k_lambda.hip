@@ -392,6 +392,11 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
 // mode 0: lambdas + metric, mode 1: metric only.
 // lg2[r] = log2(r + 2) and ilg2[r] = 1.0 / lg2[r] are host-built tables (glibc
 // log2, IEEE division): the same values the reference computes inline.
+// LONG = false: one workgroup per query, working set in LDS; queries flagged in
+// `long_flag` (too long for the LDS) are left to the LONG = true launch, which
+// runs the same code on a per-query slice of a global scratch buffer
+// (`long_list[blockIdx.x]` names the query) -- slow, but any length up to 65535.
+template <bool LONG>
 __global__ __launch_bounds__(64) void k_lambda(
     const double *__restrict__ scores, const float *__restrict__ labels,
     const uint32_t *__restrict__ qoff, int metric, uint32_t cutoff,
@@ -400,9 +405,12 @@ __global__ __launch_bounds__(64) void k_lambda(
     double *__restrict__ weight, double *__restrict__ qmetric,
     uint32_t *__restrict__ ranks_out, double *__restrict__ ssq,
     QrScalars *__restrict__ scal, uint32_t nmax, uint32_t kacc, int mode,
-    const uint8_t *__restrict__ present) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint32_t q = blockIdx.x;
+    const uint8_t *__restrict__ present, const uint8_t *__restrict__ long_flag,
+    const uint32_t *__restrict__ long_list, char *__restrict__ lscratch, const size_t lstride) {
+  extern __shared__ __attribute__((aligned(16))) char lds_mem[];
+  const uint32_t q = LONG ? long_list[blockIdx.x] : blockIdx.x;
+  if (!LONG && long_flag && long_flag[q]) return;
+  char *smem = LONG ? lscratch + (size_t)blockIdx.x * lstride : lds_mem;
   const uint32_t lane = threadIdx.x;
 #ifdef QR_LAMBDA_TIMING
   long long tq[8];
@@ -750,36 +758,89 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   const size_t Q = which ? c->vQ : c->Q;
   const size_t maxq = which ? c->vmaxq : c->maxq;
   if (Q == 0) return QR_OK;
+  if (maxq > 65535)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "queries of more than 65535 documents are not supported");
   const uint32_t cut = cutoff == 0 ? NO_CUTOFF : (uint32_t)cutoff;
   size_t kacc = cutoff == 0 || cutoff > maxq ? maxq : cutoff;
   if (kacc == 0) kacc = 1;
-  const size_t nmax = (maxq + 3) & ~(size_t)3;
   kacc = (kacc + 1) & ~(size_t)1;
-  const size_t lds = lambda_lds(nmax, kacc);
-  if (lds > 160 * 1024 - 512 || maxq > 65535)
-    QR_FAIL(c, QR_ERR_UNSUPPORTED,
-            "query too long for the LDS-resident lambda kernel (max ~3600 docs)");
+  const size_t limit = 160 * 1024 - 512;
+  size_t nmax = (maxq + 3) & ~(size_t)3;
+  // queries whose working set does not fit the LDS run out of a global scratch
+  // slice each (second launch); an unbounded cutoff on a long query would also need
+  // the per-rank accumulators there, so it takes the same route
+  const uint8_t *d_flag = nullptr;
+  size_t nlong = 0, nmax_long = 0, lstride = 0;
+  if (lambda_lds(nmax, kacc) > limit) {
+    nmax_long = nmax;
+    size_t kshort = kacc;
+    while (nmax > 4 && lambda_lds(nmax, std::min(kshort, nmax)) > limit) nmax -= 4;
+    const std::vector<uint64_t> &qo = which ? c->h_vqoff : c->h_qoff;
+    int &tag = which ? c->long_tag[1] : c->long_tag[0];
+    std::vector<uint32_t> &list = which ? c->h_long_list[1] : c->h_long_list[0];
+    if (tag != (int)nmax) {  // (re)build the flag / list for this capacity
+      std::vector<uint8_t> flag(Q, 0);
+      list.clear();
+      for (size_t q = 0; q < Q; ++q)
+        if (qo[q + 1] - qo[q] > nmax) {
+          flag[q] = 1;
+          list.push_back((uint32_t)q);
+        }
+      QR_CHECK(c, hipStreamSynchronize(c->stream));
+      uint8_t *&df = which ? c->d_long_flag[1] : c->d_long_flag[0];
+      uint32_t *&dl = which ? c->d_long_list[1] : c->d_long_list[0];
+      if (df) (void)hipFree(df);
+      if (dl) (void)hipFree(dl);
+      df = nullptr;
+      dl = nullptr;
+      QR_CHECK(c, hipMalloc((void **)&df, Q));
+      QR_CHECK(c, hipMalloc((void **)&dl, (list.size() + 1) * 4));
+      QR_CHECK(c, hipMemcpy(df, flag.data(), Q, hipMemcpyHostToDevice));
+      QR_CHECK(c, hipMemcpy(dl, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+      tag = (int)nmax;
+    }
+    nlong = list.size();
+    d_flag = which ? c->d_long_flag[1] : c->d_long_flag[0];
+    lstride = (lambda_lds(nmax_long, std::min(kacc, nmax_long)) + 255) & ~(size_t)255;
+    if (nlong * lstride > c->lscratch_bytes) {
+      QR_CHECK(c, hipStreamSynchronize(c->stream));
+      if (c->d_lscratch) (void)hipFree(c->d_lscratch);
+      c->d_lscratch = nullptr;
+      QR_CHECK(c, hipMalloc((void **)&c->d_lscratch, nlong * lstride));
+      c->lscratch_bytes = nlong * lstride;
+    }
+  }
+  const size_t kshort = std::min(kacc, nmax);  // nmax is a multiple of 4: stays even
+  const size_t lds = lambda_lds(nmax, kshort);
   static size_t attr_lds = 64 * 1024;
   if (lds > attr_lds) {
-    QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda,
+    QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_lds = lds;
   }
-  if (which == 0) {
-    hipLaunchKernelGGL(k_lambda, dim3((unsigned)Q), dim3(64), lds, c->stream,
-                       c->d_scores, c->d_labels, c->d_qoff, metric, cut, c->d_idcg,
-                       c->d_lg2, c->d_ilg2, c->d_lambda, c->d_weight, c->d_qmetric, c->d_ranks,
-                       mode == 0 ? c->d_ssq : nullptr, c->d_scalars, (uint32_t)nmax,
-                       (uint32_t)kacc, mode,
-                       mode == 0 && c->sub_k ? c->d_present : (const uint8_t *)nullptr);
-  } else {
-    hipLaunchKernelGGL(k_lambda, dim3((unsigned)Q), dim3(64), lds, c->stream,
-                       c->d_vscores, c->d_vlabels, c->d_vqoff, metric, cut,
-                       c->d_vidcg, c->d_lg2, c->d_ilg2, (double *)nullptr, (double *)nullptr,
-                       c->d_vqmetric, (uint32_t *)nullptr, (double *)nullptr,
-                       c->d_scalars, (uint32_t)nmax, (uint32_t)kacc, 1, (const uint8_t *)nullptr);
-  }
+  const double *sc = which ? c->d_vscores : c->d_scores;
+  const float *lb = which ? c->d_vlabels : c->d_labels;
+  const uint32_t *qo = which ? c->d_vqoff : c->d_qoff;
+  const double *idcg = which ? c->d_vidcg : c->d_idcg;
+  double *lam = which ? nullptr : c->d_lambda, *wgt = which ? nullptr : c->d_weight;
+  double *qm = which ? c->d_vqmetric : c->d_qmetric;
+  uint32_t *ranks = which ? nullptr : c->d_ranks;
+  double *ssq = (!which && mode == 0) ? c->d_ssq : nullptr;
+  const int md = which ? 1 : mode;
+  const uint8_t *present = (!which && mode == 0 && c->sub_k) ? c->d_present : nullptr;
+  const uint32_t *dlist = which ? c->d_long_list[1] : c->d_long_list[0];
+  hipLaunchKernelGGL(k_lambda<false>, dim3((unsigned)Q), dim3(64), lds, c->stream, sc, lb, qo, metric, cut,
+                     idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars, (uint32_t)nmax,
+                     (uint32_t)kshort, md, present, d_flag, (const uint32_t *)nullptr, (char *)nullptr,
+                     (size_t)0);
   QR_CHECK(c, hipGetLastError());
+  if (nlong) {
+    hipLaunchKernelGGL(k_lambda<true>, dim3((unsigned)nlong), dim3(64), 0, c->stream, sc, lb, qo, metric,
+                       cut, idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars,
+                       (uint32_t)nmax_long, (uint32_t)std::min(kacc, nmax_long), md, present,
+                       (const uint8_t *)nullptr, dlist, c->d_lscratch, lstride);
+    QR_CHECK(c, hipGetLastError());
+  }
   return QR_OK;
 }
 

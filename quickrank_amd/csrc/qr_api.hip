@@ -74,7 +74,10 @@ int qr_ctx_create(int device, qr_ctx **out) {
   return QR_OK;
 }
 
+static void free_long(qr_ctx *c, int which);
+
 static void free_train(qr_ctx *c) {
+  free_long(c, 0);
   dfree(c->d_raw); dfree(c->d_labels); dfree(c->d_qoff);
   dfree(c->d_scores); dfree(c->d_lambda); dfree(c->d_weight);
   dfree(c->d_idcg); dfree(c->d_qmetric); dfree(c->d_ranks); dfree(c->d_ssq);
@@ -103,7 +106,16 @@ static void free_train(qr_ctx *c) {
   c->tree_valid = false;
   c->hist_slots = 0;
 }
+static void free_long(qr_ctx *c, int which) {
+  if (c->d_long_flag[which]) (void)hipFree(c->d_long_flag[which]);
+  if (c->d_long_list[which]) (void)hipFree(c->d_long_list[which]);
+  c->d_long_flag[which] = nullptr;
+  c->d_long_list[which] = nullptr;
+  c->long_tag[which] = -1;
+}
+
 static void free_valid(qr_ctx *c) {
+  free_long(c, 1);
   dfree(c->d_vraw); dfree(c->d_vlabels); dfree(c->d_vqoff); dfree(c->d_vscores);
   dfree(c->d_vidcg); dfree(c->d_vqmetric); dfree(c->d_vranks);
   c->vN = c->vQ = 0;
@@ -117,6 +129,7 @@ void qr_ctx_destroy(qr_ctx *c) {
   free_valid(c);
   dfree(c->d_lg2); dfree(c->d_ilg2); dfree(c->d_scalars); dfree(c->d_ens); dfree(c->d_ens_w);
   dfree(c->d_nodes_out);
+  if (c->d_lscratch) (void)hipFree(c->d_lscratch);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->ev_scal) (void)hipEventDestroy(c->ev_scal);
   if (c->ev_nodes) (void)hipEventDestroy(c->ev_nodes);

@@ -260,6 +260,14 @@ struct qr_ctx {
   uint32_t *d_keys = nullptr;    // #strictly-greater scores per doc (k_rank)
   uint32_t *d_tied = nullptr;    // queue of queries with tied scores; [tied_cap] = count
   size_t tied_cap = 0, keys_cap = 0;
+  // queries too long for the LDS-resident lambda kernel: flags / lists per set
+  // (0 = training, 1 = validation) and the global scratch they run out of
+  uint8_t *d_long_flag[2] = {nullptr, nullptr};
+  uint32_t *d_long_list[2] = {nullptr, nullptr};
+  std::vector<uint32_t> h_long_list[2];
+  int long_tag[2] = {-1, -1};
+  char *d_lscratch = nullptr;
+  size_t lscratch_bytes = 0;
   double *d_ssq = nullptr;       // per-slice sum of squares partials
   QrScalars *d_scalars = nullptr;
   QrPinned *h_pin = nullptr;

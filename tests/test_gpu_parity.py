@@ -547,3 +547,31 @@ def test_error_paths_return_codes_not_crashes(qr):
         qr.Context(0, rank=3, world=2)
     s.close()
     c.close()
+
+
+def test_queries_longer_than_the_lds(qr, ora):
+    """Queries whose working set does not fit the LDS (> ~3300 documents) run out of
+    a global scratch slice: same ranks (ties included), metric, lambdas and weights;
+    short queries of the same set keep the LDS path."""
+    rng = np.random.default_rng(8)
+    lens = [50, 5000, 7, 3400, 120]
+    qoff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    N = int(qoff[-1])
+    x = rng.random((N, 5), dtype=np.float32)
+    labels = rng.integers(0, 5, N).astype(np.float32)
+    scores = np.round(rng.standard_normal(N), 2)            # plenty of ties
+    c, _, _ = _ctx(qr, x, labels, qoff, 16)
+    c.set_scores(scores)
+    for metric, cutoff in (("NDCG", 10), ("DCG", 0)):
+        c.compute_lambdas(metric, cutoff)
+        lam, w = c.get_pseudo()
+        olam, ow = ora.lambdas(labels, scores, qoff, cutoff, 1 if metric == "NDCG" else 0)
+        assert np.allclose(lam, olam, rtol=1e-10, atol=1e-14)
+        assert np.allclose(w, ow, rtol=1e-10, atol=1e-14)
+        ranks = c.ranks()
+        for q in range(len(lens)):
+            a, b = int(qoff[q]), int(qoff[q + 1])
+            assert np.array_equal(ranks[a:b], ora.rank_by_score(scores[a:b]).astype(np.uint32)), (metric, q)
+        assert c.metric_last() == pytest.approx(
+            ora.eval_dataset(labels, scores, qoff, cutoff, 1 if metric == "NDCG" else 0), rel=1e-13)
+    c.close()

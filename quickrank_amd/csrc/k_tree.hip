@@ -668,7 +668,7 @@ struct DecideState {
   qr_split_t *split_log;
 };
 
-__device__ void heap_push(DecideState &st, double key, int32_t val) {
+__device__ __forceinline__ void heap_push(DecideState &st, double key, int32_t val) {
   // maxheap.h:58-68 (arr[0] is a DBL_MAX sentinel)
   size_t p = (size_t)(++st.heap_size);
   while (key > st.heap[p >> 1].key) {
@@ -679,7 +679,7 @@ __device__ void heap_push(DecideState &st, double key, int32_t val) {
   st.heap[p].val = val;
 }
 
-__device__ void heap_pop(DecideState &st) {
+__device__ __forceinline__ void heap_pop(DecideState &st) {
   // maxheap.h:71-84
   const QrHeapItem last = st.heap[st.heap_size--];
   size_t child, p = 1;
@@ -697,7 +697,7 @@ __device__ void heap_pop(DecideState &st) {
 }
 
 // RTNode(sampleids, hist): rtnode.h:97-107
-__device__ void node_stats(QrNode *nd, double sum, double ss, u64 count) {
+__device__ __forceinline__ void node_stats(QrNode *nd, double sum, double ss, u64 count) {
   // `sum` is the f64 sum of the node's pseudo-responses (not the fixed-point
   // histogram total): a one-document node must come out with deviance == 0
   // exactly, as in the reference, because `deviance > 0` gates the split.
@@ -708,7 +708,7 @@ __device__ void node_stats(QrNode *nd, double sum, double ss, u64 count) {
   nd->deviance = ss - nd->sum * nd->sum / (double)count;
 }
 
-__device__ void node_set_best(QrNode *nd, const qr_split_t *recs, int world,
+__device__ __forceinline__ void node_set_best(QrNode *nd, const qr_split_t *recs, int world,
                               int which) {
   // deterministic merge over ranks: max score, ties -> lowest feature
   nd->best_score = -1.0;
@@ -729,12 +729,12 @@ __device__ void node_set_best(QrNode *nd, const qr_split_t *recs, int world,
   }
 }
 
-__device__ bool node_splittable(const QrNode *nd) {
+__device__ __forceinline__ bool node_splittable(const QrNode *nd) {
   // rt.cc:212 (deviance > 0.0f) and :312 (best_score == initvar => unsplittable)
   return nd->deviance > 0.0 && nd->best_f != 0xFFFFFFFFu;
 }
 
-__device__ void make_desc(DecideState &st, int node, const float *thr,
+__device__ __forceinline__ void make_desc(DecideState &st, int node, const float *thr,
                           const int32_t *gf2lf) {
   QrNode *nd = &st.nodes[node];
   QrSplitDesc *d = st.desc;
@@ -787,6 +787,82 @@ __device__ void make_desc(DecideState &st, int node, const float *thr,
   lg->thr_id = nd->best_t;
   lg->lcount = nd->best_lc;
   lg->rcount = nd->best_rc;
+}
+
+// The lane's control step on the state `st` points at.  Force-inlined into two call
+// sites (LDS-staged / device-resident) so that each gets the memory instructions
+// of its address space.
+__device__ __forceinline__ void decide_logic(DecideState &st, QrTreeState *ts, const bool root_mode,
+                                             const int32_t active, const uint32_t N,
+                                             const qr_split_t *recs, const int world,
+                                             const QrScalars *scal, const float *thr,
+                                             const int32_t *gf2lf, const int docmode, const u64 Nglobal,
+                                             const double sum_small, const double ss_small,
+                                             const int root_buf) {
+  if (root_mode) {
+    QrNode *root = &st.nodes[0];
+    root->begin = 0;
+    root->end = N;
+    root->buf = root_buf;
+    root->hslot = 0;
+    root->feature = -1;
+    root->thr_id = -1;
+    root->threshold = 0.f;
+    root->left = root->right = root->parent = -1;
+    root->leaf_id = -1;
+    node_stats(root, scal->root_sum, scal->root_ss, docmode ? Nglobal : (u64)N);
+    node_set_best(root, recs, world, 0);
+    st.nnodes = 1;
+    st.heap_size = 0;
+    st.heap[0].key = 1.7976931348623157e308;  // DBL_MAX sentinel
+    st.heap[0].val = -1;
+    st.taken = 0;
+    st.done = 0;
+    st.nsplits = 0;
+    st.desc->active = 0;
+    if (node_splittable(root))
+      make_desc(st, 0, thr, gf2lf);
+    else
+      st.done = 1;
+    st.step = 1;
+  } else {
+    if (active) {
+      // children of the split just applied
+      const QrSplitDesc d = *st.desc;
+      QrNode *P = &st.nodes[d.node];
+      QrNode *S = &st.nodes[d.small_node], *B = &st.nodes[d.big_node];
+      // directly accumulated child, sibling by subtraction
+      // (rtnode_histogram.cc:65-69, 79-86)
+      node_stats(S, sum_small, ss_small, d.small_n);
+      node_stats(B, P->sum - sum_small, P->ss - ss_small, P->count - d.small_n);
+      if (docmode) {
+        // the children's local segments: known only after the local partition
+        QrNode *L = &st.nodes[d.left], *R = &st.nodes[d.right];
+        L->end = R->begin = P->begin + ts->loc.lcount;
+      }
+      node_set_best(&st.nodes[d.left], recs, world, 0);
+      node_set_best(&st.nodes[d.right], recs, world, 1);
+      heap_push(st, st.nodes[d.left].deviance, d.left);    // rt.cc:76-77
+      heap_push(st, st.nodes[d.right].deviance, d.right);
+      st.desc->active = 0;
+    }
+    st.step++;
+    if (!st.done) {
+      bool found = false;
+      while (st.heap_size > 0 &&
+             (st.nleaves_req == 0 || st.taken + st.heap_size < st.nleaves_req)) {
+        const int node = st.heap[1].val;
+        heap_pop(st);
+        if (node_splittable(&st.nodes[node])) {
+          make_desc(st, node, thr, gf2lf);
+          found = true;
+          break;
+        }
+        ++st.taken;
+      }
+      if (!found) st.done = 1;
+    }
+  }
 }
 
 #define QR_DECIDE_LDS_NODES 96  /* trees of up to 47 leaves are staged in LDS */
@@ -877,69 +953,18 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (root_mode) {
-      QrNode *root = &st.nodes[0];
-      root->begin = 0;
-      root->end = N;
-      root->buf = root_buf;
-      root->hslot = 0;
-      root->feature = -1;
-      root->thr_id = -1;
-      root->threshold = 0.f;
-      root->left = root->right = root->parent = -1;
-      root->leaf_id = -1;
-      node_stats(root, scal->root_sum, scal->root_ss, docmode ? Nglobal : (u64)N);
-      node_set_best(root, recs, world, 0);
-      st.nnodes = 1;
-      st.heap_size = 0;
-      st.heap[0].key = 1.7976931348623157e308;  // DBL_MAX sentinel
-      st.heap[0].val = -1;
-      st.taken = 0;
-      st.done = 0;
-      st.nsplits = 0;
-      st.desc->active = 0;
-      if (node_splittable(root))
-        make_desc(st, 0, thr, gf2lf);
-      else
-        st.done = 1;
-      st.step = 1;
+    if (staged) {
+      st.nodes = sh_nodes;
+      st.heap = sh_heap;
+      st.desc = &sh_desc;
+      decide_logic(st, ts, root_mode, active, N, recs, world, scal, thr, gf2lf, docmode, Nglobal,
+                   sum_small, ss_small, root_buf);
     } else {
-      if (active) {
-        // children of the split just applied
-        const QrSplitDesc d = *st.desc;
-        QrNode *P = &st.nodes[d.node];
-        QrNode *S = &st.nodes[d.small_node], *B = &st.nodes[d.big_node];
-        // directly accumulated child, sibling by subtraction
-        // (rtnode_histogram.cc:65-69, 79-86)
-        node_stats(S, sum_small, ss_small, d.small_n);
-        node_stats(B, P->sum - sum_small, P->ss - ss_small, P->count - d.small_n);
-        if (docmode) {
-          // the children's local segments: known only after the local partition
-          QrNode *L = &st.nodes[d.left], *R = &st.nodes[d.right];
-          L->end = R->begin = P->begin + ts->loc.lcount;
-        }
-        node_set_best(&st.nodes[d.left], recs, world, 0);
-        node_set_best(&st.nodes[d.right], recs, world, 1);
-        heap_push(st, st.nodes[d.left].deviance, d.left);    // rt.cc:76-77
-        heap_push(st, st.nodes[d.right].deviance, d.right);
-        st.desc->active = 0;
-      }
-      st.step++;
-      if (!st.done) {
-        bool found = false;
-        while (st.heap_size > 0 &&
-               (st.nleaves_req == 0 || st.taken + st.heap_size < st.nleaves_req)) {
-          const int node = st.heap[1].val;
-          heap_pop(st);
-          if (node_splittable(&st.nodes[node])) {
-            make_desc(st, node, thr, gf2lf);
-            found = true;
-            break;
-          }
-          ++st.taken;
-        }
-        if (!found) st.done = 1;
-      }
+      st.nodes = ts->nodes;
+      st.heap = ts->heap;
+      st.desc = &ts->desc;
+      decide_logic(st, ts, root_mode, active, N, recs, world, scal, thr, gf2lf, docmode, Nglobal,
+                   sum_small, ss_small, root_buf);
     }
     ts->nnodes = st.nnodes;
     ts->taken = st.taken;

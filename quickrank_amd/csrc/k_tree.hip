@@ -8,19 +8,24 @@
 // (mart.cc:447-468).
 //
 // Kernels (one stream, no host round trip inside a tree):
-//   k_hist     histogram build of one node over the rank's 64-feature blocks:
-//              LDS-resident [bin][feature] cells, one ds_add_u64 per
-//              (doc, feature) carrying gradient AND count (fixed point, see
-//              qr_internal.h), bank-conflict-free by construction
-//   k_scan     per feature: reduce the workgroup partials, prefix-sum over the
-//              256 slots, derive the sibling (parent - child), evaluate the
-//              split gain of every slot and keep the first best one
-//   k_merge    best (feature, slot) over the local features (lowest f wins ties)
-//   k_decide   single-lane control: node statistics, max-deviance heap growth,
-//              next split descriptor
-//   k_mask / k_part_count / k_part_scatter   stable partition of the node's
-//              doc list (ascending doc ids are preserved)
-//   k_finish / k_leaf_sums / k_leaf_final / k_score_update / k_valid_update
+//   k_hist       histogram build of one node over the rank's 64-feature blocks:
+//                LDS-resident [bin][feature] cells, one ds_add_u64 per
+//                (doc, feature) carrying gradient AND count (fixed point, see
+//                qr_internal.h), bank-conflict-free by construction
+//   k_reduce     sum of the workgroup partials in their native cell order
+//   k_scan       per feature: prefix-sum over the 256 slots, sibling (parent -
+//                child), split gain of every slot, first best one
+//   k_decide     control: merge of the per-feature bests (two waves), node
+//                statistics, max-deviance heap growth, next split descriptor
+//                (k_merge publishes the rank's bests instead on feature-sharded runs)
+//   k_partition  single-pass stable partition of the node's document list with a
+//                look-back chain (k_part_count / k_part_scatter: two-pass variant of
+//                document-sharded runs; k_mask: the owner's go-left bits on
+//                feature-sharded runs)
+//   k_finish / k_leaf_sums / k_leaf_final (k_leaf_global) / k_score_update(_walk) /
+//   k_valid_update: leaves, leaf outputs, score updates
+//   k_obl_fill / k_obl_level / k_obl_plan + k_partition_level / k_hist_level /
+//   k_reduce_level / k_scan_level: level-batched oblivious growth (ot.cc:32-201)
 #include <algorithm>
 
 #include "qr_internal.h"

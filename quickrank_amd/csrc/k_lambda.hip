@@ -295,6 +295,7 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
         }
         --depth;
         // __move_median_to_first(first, first+1, mid, last-1): uniform
+        uint32_t p;  // the pivot's key (the element that ends up at `first`)
         {
           const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
           const uint32_t ka = pk(a[ia]), kb = pk(a[ib]), kc = pk(a[ic]);
@@ -306,6 +307,7 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
           } else if (ka < kc) pick = ia;
           else if (kb < kc) pick = ic;
           else pick = ib;
+          p = pick == ia ? ka : (pick == ib ? kb : kc);
           __syncthreads();
           if (lane == 0) {
             const uint32_t t = a[first];
@@ -314,53 +316,97 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
           }
           __syncthreads();
         }
-        const uint32_t p = pk(a[first]);
         const int lo0 = first + 1;
-        // LB: ascending positions with key >= p
-        int nl = 0;
-        for (int base = lo0; base < last; base += 64) {
-          const int x = base + lane;
-          const bool in = x < last;
-          const bool lb = in && !(pk(a[in ? x : first]) < p);
-          const unsigned long long m = __ballot(lb);
-          if (lb) LB[nl + __popcll(m & lt)] = (uint32_t)x;
-          nl += __popcll(m);
-        }
-        // RB: descending positions with key <= p
-        int nr = 0;
-        for (int top = last; top > lo0; top -= 64) {
-          const int x = top - 1 - lane;
-          const bool in = x >= lo0;
-          const bool rb = in && !(p < pk(a[in ? x : first]));
-          const unsigned long long m = __ballot(rb);
-          if (rb) RB[nr + __popcll(m & lt)] = (uint32_t)x;
-          nr += __popcll(m);
-        }
-        __syncthreads();
-        const int np = nl < nr ? nl : nr;
-        int K = 0;
-        for (int base = 0; base < np; base += 64) {
-          const int k = base + lane;
-          const bool v = k < np && LB[k] < RB[k];
-          const unsigned long long m = __ballot(v);
-          K += __popcll(m);
-          if (m != ~0ull) break;
-        }
+        int nl = 0, nr = 0, K = 0;
         uint32_t cut;
-        if (K > 0) {
-          const uint32_t c1 = K < nl ? LB[K] : 0xFFFFFFFFu;
-          const uint32_t c2 = RB[K - 1];
-          cut = c1 < c2 ? c1 : c2;
-        } else
-          cut = nl > 0 ? LB[0] : (uint32_t)last;
-        __syncthreads();
-        for (int k = lane; k < K; k += 64) {
-          const uint32_t x = LB[k], y = RB[k];
-          const uint32_t t = a[x];
-          a[x] = a[y];
-          a[y] = t;
+        if (last - lo0 <= 128) {
+          // Ranges of at most two 64-lane chunks (every range of a 100-document
+          // query): each position is read once, the four ballots stay in scalar
+          // registers, and the lanes keep their (LB[k], RB[k]) pair for the swap.
+          const unsigned long long gt = lane == 63 ? 0ull : (~0ull << (lane + 1));
+          const int x0 = lo0 + lane, x1 = lo0 + 64 + lane;
+          const bool in0 = x0 < last, in1 = x1 < last;
+          const uint32_t k0 = pk(a[in0 ? x0 : first]), k1 = pk(a[in1 ? x1 : first]);
+          const bool lb0 = in0 && !(k0 < p), lb1 = in1 && !(k1 < p);  // key >= p
+          const bool rb0 = in0 && !(p < k0), rb1 = in1 && !(p < k1);  // key <= p
+          const unsigned long long mlb0 = __ballot(lb0), mlb1 = __ballot(lb1);
+          const unsigned long long mrb0 = __ballot(rb0), mrb1 = __ballot(rb1);
+          nl = __popcll(mlb0) + __popcll(mlb1);
+          nr = __popcll(mrb0) + __popcll(mrb1);
+          // LB ascending, RB descending (index = flagged positions to my right)
+          if (lb0) LB[__popcll(mlb0 & lt)] = (uint32_t)x0;
+          if (lb1) LB[__popcll(mlb0) + __popcll(mlb1 & lt)] = (uint32_t)x1;
+          if (rb0) RB[__popcll(mrb1) + __popcll(mrb0 & gt)] = (uint32_t)x0;
+          if (rb1) RB[__popcll(mrb1 & gt)] = (uint32_t)x1;
+          __syncthreads();
+          const int np = nl < nr ? nl : nr;
+          const int q0 = lane, q1 = lane + 64;
+          const uint32_t L0 = q0 < np ? LB[q0] : 0u, R0 = q0 < np ? RB[q0] : 0u;
+          const uint32_t L1 = q1 < np ? LB[q1] : 0u, R1 = q1 < np ? RB[q1] : 0u;
+          const bool v0 = q0 < np && L0 < R0, v1 = q1 < np && L1 < R1;
+          const unsigned long long mv0 = __ballot(v0), mv1 = __ballot(v1);
+          // the pairs cross once: true ... true false ... false
+          K = mv0 == ~0ull ? 64 + __popcll(mv1) : __popcll(mv0);
+          if (K > 0) {
+            const uint32_t c1 = K < nl ? LB[K] : 0xFFFFFFFFu;
+            const uint32_t c2 = RB[K - 1];
+            cut = c1 < c2 ? c1 : c2;
+          } else
+            cut = nl > 0 ? LB[0] : (uint32_t)last;
+          if (v0) {
+            const uint32_t t = a[L0];
+            a[L0] = a[R0];
+            a[R0] = t;
+          }
+          if (v1 && mv0 == ~0ull) {
+            const uint32_t t = a[L1];
+            a[L1] = a[R1];
+            a[R1] = t;
+          }
+          __syncthreads();
+        } else {
+          // LB: ascending positions with key >= p
+          for (int base = lo0; base < last; base += 64) {
+            const int x = base + lane;
+            const bool in = x < last;
+            const bool lb = in && !(pk(a[in ? x : first]) < p);
+            const unsigned long long m = __ballot(lb);
+            if (lb) LB[nl + __popcll(m & lt)] = (uint32_t)x;
+            nl += __popcll(m);
+          }
+          // RB: descending positions with key <= p
+          for (int top = last; top > lo0; top -= 64) {
+            const int x = top - 1 - lane;
+            const bool in = x >= lo0;
+            const bool rb = in && !(p < pk(a[in ? x : first]));
+            const unsigned long long m = __ballot(rb);
+            if (rb) RB[nr + __popcll(m & lt)] = (uint32_t)x;
+            nr += __popcll(m);
+          }
+          __syncthreads();
+          const int np = nl < nr ? nl : nr;
+          for (int base = 0; base < np; base += 64) {
+            const int k = base + lane;
+            const bool v = k < np && LB[k] < RB[k];
+            const unsigned long long m = __ballot(v);
+            K += __popcll(m);
+            if (m != ~0ull) break;
+          }
+          if (K > 0) {
+            const uint32_t c1 = K < nl ? LB[K] : 0xFFFFFFFFu;
+            const uint32_t c2 = RB[K - 1];
+            cut = c1 < c2 ? c1 : c2;
+          } else
+            cut = nl > 0 ? LB[0] : (uint32_t)last;
+          __syncthreads();
+          for (int k = lane; k < K; k += 64) {
+            const uint32_t x = LB[k], y = RB[k];
+            const uint32_t t = a[x];
+            a[x] = a[y];
+            a[y] = t;
+          }
+          __syncthreads();
         }
-        __syncthreads();
         // recurse on [cut, last) (pushed), loop on [first, cut)
         if (lane == 0) {
           stk[3 * sp] = (int)cut;
@@ -375,15 +421,15 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
   }
   // final insertion sort == stable sort by key of the current arrangement
   // (a[n .. n4) is padded with key 0xFFFF by the caller: never counted)
+  // The key IS the number of strictly greater scores, so the elements of key k end
+  // up in positions k, k+1, ...: only the equal-key elements standing before x in
+  // the current arrangement have to be counted.
   const int n4 = (n + 3) & ~3;
   for (int x = lane; x < n; x += 64) {
     const uint32_t kx = pk(a[x]);
-    uint32_t r = 0;
+    uint32_t r = kx;
 #pragma unroll 4
-    for (int y = 0; y < n4; ++y) {
-      const uint32_t ky = pk(a[y]);
-      r += (ky < kx) || (ky == kx && y < x);
-    }
+    for (int y = 0; y < n4; ++y) r += (pk(a[y]) == kx) & (y < x);
     out[r] = a[x] & 0xFFFFu;
   }
   __syncthreads();

@@ -1,13 +1,13 @@
 """BASELINE.json config 5 at full size: 10,000 trees x 64 leaves over 10M docs x 200
 features (8 GB of f32 features generated ON the device, seed 43), through
-qr_ensemble_score_device.  Checks a sample of documents bit for bit against the oracle."""
+qr_ensemble_score_device.  Checks a sample of documents bit for bit against a numpy tree walk."""
 import argparse, ctypes as C, json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import torch
 torch.cuda.init()
 from quickrank_amd._capi import Context
-from score_bench import make_model
+from score_bench import make_model, numpy_score
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--trees", type=int, default=10000)
@@ -41,12 +41,7 @@ res = {"workload": f"{a.trees} trees x 64 leaves, {a.docs} docs x {a.features} f
        "ms": ms, "docs_per_s": a.docs / ms * 1e3, "node_visits_per_s": a.docs * a.trees * 6 / ms * 1e3,
        "hbm_alg_GBps": (a.docs * a.features * 4 + a.docs * 8) / ms / 1e6}
 if a.check:
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-    import oracle
     idx = torch.linspace(0, a.docs - 1, a.check, device="cuda").long()
-    xs = x[idx].cpu().numpy()
-    model = dict(nodes=nodes, nnodes=np.full(a.trees, nodes.shape[1], np.uint64), ntrees=a.trees,
-                 max_nodes=nodes.shape[1], shrinkage=0.1)
-    want = oracle.ensemble_score(model, xs)
-    res["bit_exact_vs_oracle_docs"] = int(a.check) if np.array_equal(out[idx].cpu().numpy(), want) else 0
+    want = numpy_score(nodes, w, x[idx].cpu().numpy())
+    res["bit_exact_vs_numpy_walk_docs"] = int(a.check) if np.array_equal(out[idx].cpu().numpy(), want) else 0
 print(json.dumps(res))

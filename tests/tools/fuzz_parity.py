@@ -1,9 +1,9 @@
 """Randomised parity sweep (TEST TOOL): random dataset shapes / thresholds / leaves /
 min leaf support / depths, a few boosting iterations each, device trees vs the
 oracle's with the tie-aware walker of tests/parity_util.py.  Run on a GPU box:
-    python scripts/fuzz_parity.py [n_configs] [seed]"""
+    python tests/tools/fuzz_parity.py [n_configs] [seed]"""
 import os, sys, time
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch

@@ -55,3 +55,31 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("quickrank_amd has no CPU fallback", ""), \
                     f"{f} mentions the oracle"
+
+
+def test_oracle_users_are_only_the_allowed_ones():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch
+    oracle/: scripts/ must not, bench.py imports it inside cpu_baseline only, and
+    __graft_entry__ outside build() (which compiles the checker) only in smoke()."""
+    import ast
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    for dirpath, _, files in os.walk(os.path.join(root, "scripts")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cc")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle", src, re.M), f
+
+    def importers(path):
+        tree = ast.parse(open(path).read())
+        found = set()
+        for fn in ast.walk(tree):
+            if isinstance(fn, (ast.FunctionDef, ast.Module)):
+                for node in (fn.body if isinstance(fn, ast.Module) else ast.walk(fn)):
+                    if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                        found.add(getattr(fn, "name", "<module>"))
+                    if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                        found.add(getattr(fn, "name", "<module>"))
+        return found
+    assert importers(os.path.join(root, "bench.py")) <= {"cpu_baseline"}
+    assert importers(os.path.join(root, "__graft_entry__.py")) <= {"build", "smoke"}

@@ -105,7 +105,7 @@ int main(int argc, char *argv[]) {
     a = a.substr(2);
     if (kOutOfScope.count(a)) {
       std::cerr << "!!! option --" << a << " belongs to a subsystem outside this build's scope "
-                << "(see DESIGN.md section 8)." << std::endl;
+                << "(see DESIGN.md section 9)." << std::endl;
       return EXIT_FAILURE;
     }
     bool found = false;

@@ -26,6 +26,8 @@
 //   k_valid_update: leaves, leaf outputs, score updates
 //   k_obl_fill / k_obl_level / k_obl_plan + k_partition_level / k_hist_level /
 //   k_reduce_level / k_scan_level: level-batched oblivious growth (ot.cc:32-201)
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 
 #include "qr_internal.h"
@@ -1873,22 +1875,26 @@ static int launch_hist_scan(qr_ctx *c, int root_mode) {
     attr_lds = lds;
   }
   const int G = c->ncu;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool prof = c->prof_on && root_mode;
+  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);  // documents of the root node
   if (prof) {
+    // bench.py's roofline: the two events are attached to the launch itself (they
+    // take the kernel's own begin / end timestamps, like the profiler's trace)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     QR_CHECK(c, hipEventCreate(&e0));
     QR_CHECK(c, hipEventCreate(&e1));
-    QR_CHECK(c, hipEventRecord(e0, c->stream));
-  }
-  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);  // documents of the root node
-  hipLaunchKernelGGL(k_hist, dim3(G), dim3(1024), lds, c->stream, c->d_tree,
-                     root_mode, rootn, c->d_blocks, c->nblocks, c->d_bins,
-                     c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars,
-                     (u64 *)c->d_partials, c->dmode, c->sub_k ? 0 : 2);
-  QR_CHECK(c, hipGetLastError());
-  if (prof) {
-    QR_CHECK(c, hipEventRecord(e1, c->stream));
+    hipExtLaunchKernelGGL(k_hist, dim3(G), dim3(1024), lds, c->stream, e0, e1, 0, c->d_tree,
+                          root_mode, rootn, c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
+                          c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_partials, c->dmode,
+                          c->sub_k ? 0 : 2);
+    QR_CHECK(c, hipGetLastError());
     c->prof_events.push_back({e0, e1});
+  } else {
+    hipLaunchKernelGGL(k_hist, dim3(G), dim3(1024), lds, c->stream, c->d_tree,
+                       root_mode, rootn, c->d_blocks, c->nblocks, c->d_bins,
+                       c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars,
+                       (u64 *)c->d_partials, c->dmode, c->sub_k ? 0 : 2);
+    QR_CHECK(c, hipGetLastError());
   }
   size_t cells = 0;
   for (const auto &b : c->blocks) cells += (size_t)256 * b.fw;

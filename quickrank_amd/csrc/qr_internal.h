@@ -66,8 +66,8 @@ __host__ __device__ inline void qr_make_plan(uint32_t n, int nblocks,
   for (int b = 0; b < nblocks; ++b) {
     const uint32_t u = (uint32_t)(blk[b].fw / 16);
     unsigned long long per = ((unsigned long long)q + u - 1) / u;
-    per = (per + QR_SLICE - 1) / QR_SLICE * QR_SLICE;
-    if (per == 0) per = QR_SLICE;
+    per = (per + 255) / 256 * 256;      // fine enough to fill the CUs evenly ...
+    if (per < QR_SLICE) per = QR_SLICE;  // ... but never less than 1024 documents per workgroup
     if (per > 0x7FFFFC00ull) per = 0x7FFFFC00ull;
     const int weff = (int)(((unsigned long long)n + per - 1) / per);
     p->per[b] = (uint32_t)per;

@@ -164,3 +164,33 @@ def test_train_multi_gpu_script_matches_quicklearn(tmp_path):
     assert len(t1) == len(t2) == 8
     for u, v in zip(t1, t2):
         assert u[0] == v[0] and abs(float(u[1]) - float(v[1])) < 2e-4 and abs(float(u[2]) - float(v[2])) < 2e-4
+
+
+def test_train_multi_gpu_script_one_rank_rccl(tmp_path):
+    """The same script over the production transport (nccl == RCCL), one rank: the
+    tree table must match quicklearn's line for line."""
+    import subprocess
+    from datagen import make_dataset
+    from quickrank_amd import build
+    from test_gpu_cli import _write_svml
+    build.build()
+    build.build_host()
+    x, labels, qoff = make_dataset(nq=80, docs_per_query=40, F=20, seed=61)
+    tr = str(tmp_path / "train.svml")
+    _write_svml(tr, x, labels, qoff)
+    common = ["--algo", "LAMBDAMART", "--train", tr, "--num-trees", "5", "--num-leaves", "8",
+              "--num-thresholds", "64", "--min-leaf-support", "5"]
+    r1 = subprocess.run([os.path.join(ROOT, "quickrank_amd", "bin", "quicklearn")] + common,
+                        capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(34500 + os.getpid() % 2000))
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_multi_gpu.py")] + common,
+                        env=env, capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr
+
+    def table(out):
+        return [ln.replace("*", "").split() for ln in out.splitlines() if ln.split() and ln.split()[0].isdigit()]
+    t1, t2 = table(r1.stdout), table(r2.stdout)
+    assert len(t1) == len(t2) == 5
+    for u, v in zip(t1, t2):
+        assert u[0] == v[0] and abs(float(u[1]) - float(v[1])) < 1e-4

@@ -746,7 +746,8 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
                                                const double *__restrict__ qmetric,
                                                uint32_t nq,
                                                QrScalars *__restrict__ scal,
-                                               const int reset_max) {
+                                               const int reset_max,
+                                               QrScalars *__restrict__ host_copy) {
   __shared__ double red[16];
   double a = 0.0, b = 0.0, a2 = 0.0;
   for (uint32_t i = threadIdx.x; i < nss; i += 1024) {
@@ -790,6 +791,9 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
       // have to pack it for the exchange: k_scal_global clears it there)
       if (reset_max) scal->maxabs_bits = 0;
     }
+    // read-back without a copy launch: the finished scalars go straight into the
+    // pinned host block (qr_metric_last waits for this kernel's event)
+    if (host_copy) *host_copy = *scal;
   }
 }
 
@@ -901,11 +905,12 @@ int qr_k_residual(qr_ctx *c) {
 
 // nss > 0: reduce ssq[nss] into root_ss and derive the scale; the per-query
 // metric of set `which` (encoded in the sign: nss == 0 means metric only).
-int qr_k_prep(qr_ctx *c, size_t nss, int with_metric) {
+int qr_k_prep(qr_ctx *c, size_t nss, int with_metric, int publish) {
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, c->stream,
                      nss ? c->d_ssq : (const double *)nullptr, (uint32_t)nss,
                      with_metric ? c->d_qmetric : (const double *)nullptr,
-                     with_metric ? (uint32_t)c->Q : 0u, c->d_scalars, c->dmode ? 0 : 1);
+                     with_metric ? (uint32_t)c->Q : 0u, c->d_scalars, c->dmode ? 0 : 1,
+                     publish ? &c->d_pin->scal : (QrScalars *)nullptr);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -930,7 +935,7 @@ __global__ void k_scal_pack(const QrScalars *__restrict__ scal, long long *__res
 }
 
 __global__ void k_scal_global(QrScalars *__restrict__ scal, const long long *__restrict__ x,
-                              const int world) {
+                              const int world, QrScalars *__restrict__ host_copy) {
   if (threadIdx.x != 0) return;
   double mx = 0.0, ss = 0.0, sm = 0.0, ms = 0.0;
   for (int r = 0; r < world; ++r) {
@@ -950,6 +955,7 @@ __global__ void k_scal_global(QrScalars *__restrict__ scal, const long long *__r
   scal->scale_exp = e;
   scal->scale = ldexp(1.0, e);
   scal->inv_scale = ldexp(1.0, -e);
+  *host_copy = *scal;
 }
 
 // local reductions (sum of squares / sum / metric) + pack for the exchange
@@ -963,7 +969,7 @@ int qr_k_prep_pack(qr_ctx *c) {
 
 int qr_k_prep_global(qr_ctx *c) {
   hipLaunchKernelGGL(k_scal_global, dim3(1), dim3(64), 0, c->stream, c->d_scalars,
-                     c->d_xscal, c->world);
+                     c->d_xscal, c->world, &c->d_pin->scal);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -972,7 +978,7 @@ int qr_k_metric_reduce(qr_ctx *c, int which) {
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, c->stream,
                      (const double *)nullptr, 0u,
                      which ? c->d_vqmetric : c->d_qmetric,
-                     (uint32_t)(which ? c->vQ : c->Q), c->d_scalars, 0);
+                     (uint32_t)(which ? c->vQ : c->Q), c->d_scalars, 0, (QrScalars *)nullptr);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

@@ -2064,14 +2064,14 @@ int qr_k_tree_finish(qr_ctx *c, int newton) {
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_leaf_final, dim3(1), dim3(1024), 0, c->stream, c->d_tree,
                      c->d_leafpart, newton, c->dmode, c->d_xleaf, c->rank, c->world,
-                     (int)(2 * c->cur_nleaves), c->d_nodes_out);
+                     (int)(2 * c->cur_nleaves), &c->d_pin->tree);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
 
 int qr_k_tree_leaves_global(qr_ctx *c, int newton) {
   hipLaunchKernelGGL(k_leaf_global, dim3(1), dim3(1024), 0, c->stream, c->d_tree,
-                     c->d_xleaf, newton, c->world, (int)(2 * c->cur_nleaves), c->d_nodes_out);
+                     c->d_xleaf, newton, c->world, (int)(2 * c->cur_nleaves), &c->d_pin->tree);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

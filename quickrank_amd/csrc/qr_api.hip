@@ -62,7 +62,7 @@ int qr_ctx_create(int device, qr_ctx **out) {
   }
   (void)hipMemset(c->d_scalars, 0, sizeof(QrScalars));
   if (hipHostMalloc((void **)&c->h_pin, sizeof(QrPinned), hipHostMallocDefault) != hipSuccess ||
-      dalloc(&c->d_nodes_out, 1) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&c->d_pin, c->h_pin, 0) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_scal, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_nodes, hipEventDisableTiming) != hipSuccess) {
     qr_ctx_destroy(c);
@@ -128,7 +128,6 @@ void qr_ctx_destroy(qr_ctx *c) {
   free_train(c);
   free_valid(c);
   dfree(c->d_lg2); dfree(c->d_ilg2); dfree(c->d_scalars); dfree(c->d_ens); dfree(c->d_ens_w);
-  dfree(c->d_nodes_out);
   if (c->d_lscratch) (void)hipFree(c->d_lscratch);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->ev_scal) (void)hipEventDestroy(c->ev_scal);
@@ -684,8 +683,8 @@ static int ensure_idcg(qr_ctx *c, int which, int metric, size_t cutoff) {
 // snapshot of the per-iteration scalars into pinned host memory, stream-ordered:
 // qr_metric_last waits for this event only, not for the work enqueued after it
 static int snapshot_scalars(qr_ctx *c) {
-  QR_CHECK(c, hipMemcpyAsync(&c->h_pin->scal, c->d_scalars, sizeof(QrScalars),
-                             hipMemcpyDeviceToHost, c->stream));
+  // the kernel that finished the scalars has written them into the pinned block
+  // itself (no copy launch): the event marks that kernel
   QR_CHECK(c, hipEventRecord(c->ev_scal, c->stream));
   c->scal_pending = true;
   return QR_OK;
@@ -703,7 +702,7 @@ int qr_lambda_compute(qr_ctx *c, int metric, size_t cutoff) {
   if (rc) return rc;
   // sum of squares / sum / quantisation scale and the metric of the ranking, one launch
   // (documents outside a sample have lambda == 0: the sums are the sample's)
-  if ((rc = qr_k_prep(c, c->Q, 1))) return rc;
+  if ((rc = qr_k_prep(c, c->Q, 1, c->dmode ? 0 : 1))) return rc;
   if (!c->dmode) return snapshot_scalars(c);
   return qr_k_prep_pack(c);  // then: all-reduce the scalar buffer, qr_lambda_finish
 }
@@ -888,9 +887,7 @@ int qr_tree_apply(qr_ctx *c) {
 // the finished tree's compact records travel to pinned host memory behind the
 // kernels that produced them; qr_tree_nodes waits for that copy only
 static int snapshot_nodes(qr_ctx *c) {
-  const size_t bytes = offsetof(QrNodesOut, nodes) + c->cur_maxnodes * sizeof(qr_node_t);
-  QR_CHECK(c, hipMemcpyAsync(&c->h_pin->tree, c->d_nodes_out, bytes, hipMemcpyDeviceToHost,
-                             c->stream));
+  // k_leaf_final / k_leaf_global wrote the records into the pinned block directly
   QR_CHECK(c, hipEventRecord(c->ev_nodes, c->stream));
   c->nodes_pending = true;
   return QR_OK;

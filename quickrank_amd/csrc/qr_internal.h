@@ -270,8 +270,8 @@ struct qr_ctx {
   size_t lscratch_bytes = 0;
   double *d_ssq = nullptr;       // per-slice sum of squares partials
   QrScalars *d_scalars = nullptr;
-  QrPinned *h_pin = nullptr;
-  QrNodesOut *d_nodes_out = nullptr;  // compact records of the tree just finished
+  QrPinned *h_pin = nullptr;     // pinned host memory the kernels write the read-backs into
+  QrPinned *d_pin = nullptr;     // the same memory through its device address
   hipEvent_t ev_scal = nullptr, ev_nodes = nullptr;
   bool scal_pending = false, nodes_pending = false;
   size_t cur_maxnodes = 0;
@@ -368,7 +368,7 @@ int qr_k_colstats(qr_ctx *c, const float *col, size_t N, size_t F, uint32_t limi
 int qr_k_binning(qr_ctx *c);
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode);
 int qr_k_residual(qr_ctx *c);
-int qr_k_prep(qr_ctx *c, size_t nslices, int with_metric);
+int qr_k_prep(qr_ctx *c, size_t nslices, int with_metric, int publish = 0);
 int qr_k_prep_pack(qr_ctx *c);
 int qr_k_prep_global(qr_ctx *c);
 int qr_k_tree_leaves_global(qr_ctx *c, int newton);

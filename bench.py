@@ -323,7 +323,7 @@ def main():
             if (os.path.exists(pmc) and world == 1 and N == 1000000 and F == 136
                     and args.nthresholds == 255):
                 traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
-            roof = {"bound": "hbm", "kernel": "k_hist (root histogram build)",
+            roof = {"bound": "hbm", "kernel": "k_hist_root (root histogram build)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": prof["alg_bytes"],

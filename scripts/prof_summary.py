@@ -27,4 +27,4 @@ if len(idx) >= 3:
     for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"  {k:24s} x{n:3d} {t/1e3:8.1f} us")
 hist = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if r["Kernel_Name"].startswith("k_hist")]
-print("\nk_hist launch durations of the last tree (us):", [round(x, 1) for x in hist[-10:]])
+print("\nk_hist_root + k_hist launch durations of the last tree (us):", [round(x, 1) for x in hist[-10:]])

@@ -62,6 +62,7 @@ __device__ __forceinline__ void hist_accumulate(
     u64 *__restrict__ hist, const uint8_t *__restrict__ bins_b,
     const uint32_t *__restrict__ order, const uint32_t seg_begin, const uint32_t r0,
     const uint32_t r1, const double *__restrict__ lambda, const double scale) {
+  // (the caller has NOT zeroed `hist`: that happens below, behind the first loads)
   constexpr int FW = 16 * CH;
   constexpr int DW = 64 / CH;
   const int lane = threadIdx.x & 63;
@@ -134,6 +135,12 @@ __device__ __forceinline__ void hist_accumulate(
   }
 #pragma unroll
   for (int i = 0; i < NS; ++i) id[i] = get_id(clampp(p0 + (NS + i) * step));
+  // zero the cells while the first tiles are on their way
+  for (uint32_t i = threadIdx.x * 2; i < 256u * FW; i += blockDim.x * 2) {
+    hist[i] = 0;
+    hist[i + 1] = 0;
+  }
+  __syncthreads();
   uint32_t pos = p0;
   for (uint32_t tile = r0 + wave * DW; tile < r1; tile += NS * step, pos += NS * step) {
 #pragma unroll
@@ -174,11 +181,6 @@ __device__ __forceinline__ void hist_body(
   uint32_t k = 0;
   for (uint32_t s0 = r0; s0 < r1; s0 += QR_DPW, ++k) {
     const uint32_t s1 = (s0 + QR_DPW < r1) ? s0 + QR_DPW : r1;
-    for (uint32_t i = threadIdx.x * 2; i < cells; i += blockDim.x * 2) {
-      hist[i] = 0;
-      hist[i + 1] = 0;
-    }
-    __syncthreads();
     if (identity) {
       switch (fw) {
         case 16: hist_accumulate<1, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;

@@ -19,9 +19,9 @@
 //                statistics, max-deviance heap growth, next split descriptor
 //                (k_merge publishes the rank's bests instead on feature-sharded runs)
 //   k_partition  single-pass stable partition of the node's document list with a
-//                look-back chain (k_part_count / k_part_scatter: two-pass variant of
-//                document-sharded runs; k_mask: the owner's go-left bits on
-//                feature-sharded runs)
+//                look-back chain (k_mask: the owner's go-left bits on feature-sharded
+//                runs; document-sharded runs take the rank's own left count from
+//                the prefix of its local counts, k_scan)
 //   k_finish / k_leaf_sums / k_leaf_final (k_leaf_global) / k_score_update(_walk) /
 //   k_valid_update: leaves, leaf outputs, score updates
 //   k_obl_fill / k_obl_level / k_obl_plan + k_partition_level / k_hist_level /
@@ -277,7 +277,8 @@ __global__ __launch_bounds__(1024) void k_hist_level(
 __device__ __forceinline__ void reduce_body(
     const uint32_t n, const uint32_t q, const size_t slot_base, const uint32_t cellblock,
     const QrBlock *__restrict__ blocks, const int nblocks, const u64 *__restrict__ partials,
-    long long *__restrict__ red_sum, uint32_t *__restrict__ red_cnt, const uint32_t cs) {
+    long long *__restrict__ red_sum, uint32_t *__restrict__ red_cnt, const uint32_t cs,
+    uint32_t *__restrict__ red_cnt_loc) {
   __shared__ long long sh_s[512];
   __shared__ uint32_t sh_c[512];
   __shared__ QrPlan plan;
@@ -332,6 +333,7 @@ __device__ __forceinline__ void reduce_body(
     }
     red_sum[base + cell0 + c] = s;
     red_cnt[(size_t)(base + cell0 + c) * cs] = cn;
+    if (red_cnt_loc) red_cnt_loc[base + cell0 + c] = cn;  // survives the all-reduce
   }
 }
 
@@ -340,7 +342,8 @@ __global__ __launch_bounds__(512) void k_reduce(
     const QrBlock *__restrict__ blocks, const int nblocks, const int G,
     const u64 *__restrict__ partials, long long *__restrict__ red_sum,
     uint32_t *__restrict__ red_cnt, const int docmode, const double *__restrict__ part_ss,
-    long long *__restrict__ tail, const int rank, const int world) {
+    long long *__restrict__ tail, const int rank, const int world,
+    uint32_t *__restrict__ red_cnt_loc) {
   uint32_t n;
   if (root_mode) {
     n = N;
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(512) void k_reduce(
   }
   const uint32_t q =
       qr_plan_quantum((unsigned long long)n * qr_plan_wsum(nblocks, blocks), G - nblocks);
-  reduce_body(n, q, 0, blockIdx.x, blocks, nblocks, partials, red_sum, red_cnt, cs);
+  reduce_body(n, q, 0, blockIdx.x, blocks, nblocks, partials, red_sum, red_cnt, cs, red_cnt_loc);
 }
 
 // level-wise growth: grid (cell blocks, nodes of the level); per-node reduced
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(512) void k_reduce_level(
   const QrLevelNode &ln = ts->lnode[blockIdx.y];
   reduce_body(ln.small_n, ln.q, ln.slot_base, blockIdx.x, blocks, nblocks, partials,
               red_sum + (size_t)blockIdx.y * cells_total, red_cnt + (size_t)blockIdx.y * cells_total,
-              1u);
+              1u, nullptr);
 }
 
 // ===========================================================================
@@ -446,9 +449,10 @@ __global__ __launch_bounds__(256) void k_scan(
     const long long *__restrict__ red_sum, const uint32_t *__restrict__ red_cnt,
     long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
     const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
-    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec, const uint32_t cs) {
+    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec, const uint32_t cs,
+    const uint32_t *__restrict__ red_cnt_loc, uint32_t *__restrict__ hcnt_loc) {
   __shared__ long long sh_s[4];
-  __shared__ uint32_t sh_c[4];
+  __shared__ uint32_t sh_c[4], sh_l[4];
   __shared__ long long tot_s[2];
   __shared__ uint32_t tot_c[2];
   __shared__ Best sh_b[4];
@@ -480,20 +484,28 @@ __global__ __launch_bounds__(256) void k_scan(
   uint32_t cn = red_cnt[(size_t)(mybase + t * fw + col) * cs];
   // inclusive scan over the 256 slots (exact integers: any association)
   const int lane = t & 63, wave = t >> 6;
+  // document-sharded: the same prefix over THIS rank's counts (kept aside by
+  // k_reduce before the all-reduce) tells the partition how many of the rank's own
+  // documents go left at any (feature, slot) -- no counting pass
+  uint32_t cl = hcnt_loc ? red_cnt_loc[mybase + t * fw + col] : 0u;
   s = wave_scan_i64(s);
   cn = wave_scan_u32(cn);
+  if (hcnt_loc) cl = wave_scan_u32(cl);
   if (lane == 63) {
     sh_s[wave] = s;
     sh_c[wave] = cn;
+    sh_l[wave] = cl;
   }
   __syncthreads();
   for (int w = 0; w < wave; ++w) {
     s += sh_s[w];
     cn += sh_c[w];
+    cl += sh_l[w];
   }
   const size_t hidx = ((size_t)small_slot * flocal + lf) * 256 + t;
   hsum[hidx] = s;
   hcnt[hidx] = cn;
+  if (hcnt_loc) hcnt_loc[hidx] = cl;
   long long bs = 0;
   uint32_t bc = 0;
   if (!root_mode) {
@@ -503,6 +515,7 @@ __global__ __launch_bounds__(256) void k_scan(
     const size_t bidx = ((size_t)big_slot * flocal + lf) * 256 + t;
     hsum[bidx] = bs;
     hcnt[bidx] = bc;
+    if (hcnt_loc) hcnt_loc[bidx] = hcnt_loc[pidx] - cl;
   }
   if (t == 255) {
     tot_s[0] = s;
@@ -689,6 +702,11 @@ struct DecideState {
   QrNode *nodes;
   QrSplitDesc *desc;
   qr_split_t *split_log;
+  // document-sharded only: this rank's cumulative counts and where to put the
+  // local view of the split
+  const uint32_t *hcnt_loc;
+  QrLocalSplit *loc;
+  int flocal;
 };
 
 __device__ __forceinline__ void heap_push(DecideState &st, double key, int32_t val) {
@@ -793,6 +811,16 @@ __device__ __forceinline__ void make_desc(DecideState &st, int node, const float
   QrNode *L = &st.nodes[li], *R = &st.nodes[ri];
   L->begin = nd->begin;
   L->end = nd->begin + d->lcount;
+  if (st.hcnt_loc) {
+    // [begin, end) are positions in the rank's own lists; the counts above are global
+    const uint32_t ll =
+        st.hcnt_loc[((size_t)nd->hslot * st.flocal + d->owner_local) * 256 + nd->best_t];
+    const uint32_t ln = nd->end - nd->begin;
+    L->end = nd->begin + ll;
+    st.loc->lcount = ll;
+    st.loc->small_begin = d->small_is_left ? nd->begin : nd->begin + ll;
+    st.loc->small_n = d->small_is_left ? ll : ln - ll;
+  }
   R->begin = L->end;
   R->end = nd->end;
   L->buf = R->buf = d->dst_buf;
@@ -858,11 +886,6 @@ __device__ __forceinline__ void decide_logic(DecideState &st, QrTreeState *ts, c
       // (rtnode_histogram.cc:65-69, 79-86)
       node_stats(S, sum_small, ss_small, d.small_n);
       node_stats(B, P->sum - sum_small, P->ss - ss_small, P->count - d.small_n);
-      if (docmode) {
-        // the children's local segments: known only after the local partition
-        QrNode *L = &st.nodes[d.left], *R = &st.nodes[d.right];
-        L->end = R->begin = P->begin + ts->loc.lcount;
-      }
       node_set_best(&st.nodes[d.left], recs, world, 0);
       node_set_best(&st.nodes[d.right], recs, world, 1);
       heap_push(st, st.nodes[d.left].deviance, d.left);    // rt.cc:76-77
@@ -900,7 +923,7 @@ __device__ __forceinline__ void wave_copy8(void *dst, const void *src, size_t by
 __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
                             const qr_split_t *recs, const int world, const QrScalars *scal,
                             const double *part_ss, const float *thr, const int32_t *gf2lf,
-                            const qr_split_t *featrec, const uint32_t *hcnt, const int docmode,
+                            const qr_split_t *featrec, const uint32_t *hcnt_loc, const int docmode,
                             const u64 Nglobal, const long long *tail, const int dworld,
                             const uint32_t mf_k, const u64 mf_seed, const uint32_t F,
                             const int root_buf) {
@@ -925,6 +948,9 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
   st.heap_size = ts->heap_size;
   st.part_epoch = ts->part_epoch;
   st.split_log = ts->split_log;
+  st.hcnt_loc = docmode ? hcnt_loc : nullptr;
+  st.loc = &ts->loc;
+  st.flocal = flocal;
   const int32_t active = ts->desc.active;
   const int root_mode = st.step == 0;
   // everything this step can touch: the live nodes + 2 new ones, the heap + 2
@@ -1015,10 +1041,10 @@ __global__ __launch_bounds__(128) void k_decide(
     const int world, const QrScalars *__restrict__ scal,
     const double *__restrict__ part_ss, const float *__restrict__ thr,
     const int32_t *__restrict__ gf2lf, const qr_split_t *__restrict__ featrec,
-    const uint32_t *__restrict__ hcnt, const int docmode, const u64 Nglobal,
+    const uint32_t *__restrict__ hcnt_loc, const int docmode, const u64 Nglobal,
     const long long *__restrict__ tail, const int dworld, const uint32_t mf_k, const u64 mf_seed,
     const uint32_t F, const int root_buf) {
-  decide_body(ts, N, flocal, recs, world, scal, part_ss, thr, gf2lf, featrec, hcnt, docmode,
+  decide_body(ts, N, flocal, recs, world, scal, part_ss, thr, gf2lf, featrec, hcnt_loc, docmode,
               Nglobal, tail, dworld, mf_k, mf_seed, F, root_buf);
 }
 
@@ -1070,123 +1096,6 @@ __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *sh) {
 }
 
 #define PART_PER_THREAD (QR_PART_SLICE / 256)
-
-__global__ __launch_bounds__(256) void k_part_count(
-    const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm,
-    const uint32_t Nfm,
-    const uint32_t *__restrict__ order0, const uint32_t *__restrict__ order1,
-    const uint32_t *__restrict__ mask, const int use_mask,
-    uint32_t *__restrict__ blkcnt) {
-  __shared__ uint32_t sh[4];
-  const QrSplitDesc d = ts->desc;
-  if (!d.active) return;
-  const uint32_t n = d.end - d.begin;
-  const uint32_t base = blockIdx.x * QR_PART_SLICE;
-  if (base >= n) return;
-  const uint32_t *order = d.src_buf == 0 ? order0 : order1;
-  uint32_t cnt = 0;
-  for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
-    const uint32_t p = base + threadIdx.x * PART_PER_THREAD + k;
-    if (p < n) {
-      const uint32_t id = d.src_buf == 2 ? d.begin + p : order[d.begin + p];
-      cnt += go_left(d, p, id, fm, Nfm, mask, use_mask) ? 1u : 0u;
-    }
-  }
-  const uint32_t tot = block_sum_u32(cnt, sh);
-  if (threadIdx.x == 0) blkcnt[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(256) void k_part_scatter(
-    const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm,
-    const uint32_t Nfm,
-    uint32_t *__restrict__ order0, uint32_t *__restrict__ order1,
-    const uint32_t *__restrict__ mask, const int use_mask,
-    const uint32_t *__restrict__ blkcnt, const double *__restrict__ lambda,
-    double *__restrict__ part_ss, QrLocalSplit *__restrict__ loc) {
-  __shared__ uint32_t sh[4];
-  __shared__ uint32_t wave_off[4];
-  __shared__ double shd[4], shs[4];
-  const QrSplitDesc d = ts->desc;
-  if (!d.active) return;
-  const uint32_t n = d.end - d.begin;
-  const uint32_t base = blockIdx.x * QR_PART_SLICE;
-  if (base >= n && blockIdx.x != 0) return;
-  // lefts in the slices before mine, and in the whole (local) segment: the
-  // document-sharded path cannot take the latter from the (global) histogram
-  const uint32_t nwg = (n + QR_PART_SLICE - 1) / QR_PART_SLICE;
-  uint32_t pre = 0, all = 0;
-  for (uint32_t i = threadIdx.x; i < nwg; i += 256) {
-    const uint32_t v = blkcnt[i];
-    all += v;
-    if (i < blockIdx.x) pre += v;
-  }
-  const uint32_t left_before = block_sum_u32(pre, sh);
-  const uint32_t left_total = block_sum_u32(all, sh);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    loc->lcount = left_total;
-    loc->small_begin = d.small_is_left ? d.begin : d.begin + left_total;
-    loc->small_n = d.small_is_left ? left_total : n - left_total;
-  }
-  if (base >= n) return;
-  const uint32_t *src = d.src_buf == 0 ? order0 : order1;
-  uint32_t *dst = d.dst_buf == 0 ? order0 : order1;
-  uint32_t ids[PART_PER_THREAD];
-  bool fl[PART_PER_THREAD];
-  uint32_t cnt = 0;
-  for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
-    const uint32_t p = base + threadIdx.x * PART_PER_THREAD + k;
-    fl[k] = false;
-    ids[k] = 0;
-    if (p < n) {
-      ids[k] = d.src_buf == 2 ? d.begin + p : src[d.begin + p];
-      fl[k] = go_left(d, p, ids[k], fm, Nfm, mask, use_mask);
-      cnt += fl[k] ? 1u : 0u;
-    }
-  }
-  // exclusive scan of cnt over the 256 threads
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t inc = wave_scan_u32(cnt);
-  __syncthreads();
-  if (lane == 63) wave_off[wave] = inc;
-  __syncthreads();
-  uint32_t woff = 0;
-  for (int w = 0; w < wave; ++w) woff += wave_off[w];
-  uint32_t lpos = left_before + woff + inc - cnt;  // lefts before my first doc
-  const uint32_t first_p = base + threadIdx.x * PART_PER_THREAD;
-  double sq = 0.0, sm = 0.0;
-  for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
-    const uint32_t p = first_p + k;
-    if (p < n) {
-      uint32_t o;
-      if (fl[k]) {
-        o = d.begin + lpos;
-        ++lpos;
-      } else {
-        o = d.begin + left_total + (p - lpos);
-      }
-      dst[o] = ids[k];
-      if (fl[k] == (d.small_is_left != 0)) {
-        const double l = lambda[ids[k]];
-        sq += l * l;
-        sm += l;
-      }
-    }
-  }
-  // squares_sum_ of the directly built child (rtnode_histogram.cc:65-69),
-  // fixed reduction tree
-  sq = wave_sum(sq);
-  sm = wave_sum(sm);
-  __syncthreads();
-  if (lane == 0) {
-    shd[wave] = sq;
-    shs[wave] = sm;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    part_ss[2 * blockIdx.x] = (shd[0] + shd[1]) + (shd[2] + shd[3]);
-    part_ss[2 * blockIdx.x + 1] = (shs[0] + shs[1]) + (shs[2] + shs[3]);
-  }
-}
 
 // Single-pass stable partition with a look-back chain over the slice workgroups.
 // Workgroup w publishes ONE 8-byte granule {tag = epoch, value = #lefts in its
@@ -1294,13 +1203,13 @@ __global__ __launch_bounds__(256) void k_partition(
     uint32_t *__restrict__ order0, uint32_t *__restrict__ order1,
     const uint32_t *__restrict__ mask, const int use_mask,
     u64 *__restrict__ state, const double *__restrict__ lambda,
-    double *__restrict__ part_ss) {
+    double *__restrict__ part_ss, const int docmode) {
   const QrSplitDesc d = ts->desc;
   if (!d.active) return;
   PartNode pn;
   pn.begin = d.begin;
   pn.n = d.end - d.begin;
-  pn.lcount = d.lcount;
+  pn.lcount = docmode ? ts->loc.lcount : d.lcount;
   pn.src_buf = d.src_buf;
   pn.dst_buf = d.dst_buf;
   pn.small_is_left = d.small_is_left;
@@ -1928,7 +1837,7 @@ static int launch_hist_scan(qr_ctx *c, int root_mode) {
                      c->d_tree, root_mode, rootn, c->d_blocks, c->nblocks, G,
                      (const u64 *)c->d_partials, c->d_red_sum, c->d_red_cnt, c->dmode,
                      c->d_part_ss, c->dmode ? c->d_xh + 2 * c->xh_cells : (long long *)nullptr,
-                     c->rank, c->world);
+                     c->rank, c->world, c->dmode ? c->d_red_cnt_loc : (uint32_t *)nullptr);
   QR_CHECK(c, hipGetLastError());
   if (c->dmode) return QR_OK;  // the scan follows the all-reduce (launch_scan)
   return launch_scan(c, root_mode);
@@ -1938,7 +1847,9 @@ static int launch_scan(qr_ctx *c, int root_mode) {
   hipLaunchKernelGGL(k_scan, dim3(c->flocal), dim3(256), 0, c->stream, c->d_tree,
                      root_mode, (uint32_t)c->N, c->d_blocks, c->nblocks, c->d_red_sum,
                      c->d_red_cnt, c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size,
-                     c->d_lf2gf, c->d_scalars, c->d_featrec, c->dmode ? 2u : 1u);
+                     c->d_lf2gf, c->d_scalars, c->d_featrec, c->dmode ? 2u : 1u,
+                     c->dmode ? c->d_red_cnt_loc : (const uint32_t *)nullptr,
+                     c->dmode ? c->d_hcnt_loc : (uint32_t *)nullptr);
   QR_CHECK(c, hipGetLastError());
   if (c->world > 1 && !c->dmode) {
     hipLaunchKernelGGL(k_merge, dim3(1), dim3(128), 0, c->stream, c->d_tree, root_mode,
@@ -1987,7 +1898,7 @@ int qr_k_tree_decide(qr_ctx *c) {
   hipLaunchKernelGGL(k_decide, dim3(1), dim3(128), 0, c->stream, c->d_tree,
                      (uint32_t)(c->sub_k ? c->sub_k : c->N), c->flocal, recs, fshard ? c->world : 1,
                      c->d_scalars, c->d_part_ss, c->d_thr, c->d_gf2lf, c->d_featrec,
-                     c->d_hcnt, c->dmode, (u64)c->Nglobal,
+                     c->d_hcnt_loc, c->dmode, (u64)c->Nglobal,
                      c->dmode ? c->d_xh + 2 * c->xh_cells : (const long long *)nullptr,
                      c->world, c->mf_k, c->mf_seed + c->tree_counter, (uint32_t)c->F,
                      c->sub_k ? 0 : 2);
@@ -2006,22 +1917,11 @@ int qr_k_tree_decide(qr_ctx *c) {
 int qr_k_tree_apply(qr_ctx *c) {
   const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
   const int use_mask = c->world > 1 && !c->dmode;
-  if (c->dmode) {
-    // the local left count is not in the (global) histogram: count, then scatter
-    hipLaunchKernelGGL(k_part_count, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
-                       c->d_mask, 0, c->d_blkcnt);
-    QR_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_part_scatter, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
-                       c->d_mask, 0, c->d_blkcnt, c->d_lambda, c->d_part_ss,
-                       &c->d_tree->loc);
-    QR_CHECK(c, hipGetLastError());
-    return launch_hist_scan(c, 0);
-  }
+  // (document-sharded: the rank's own left count comes from its local prefix counts)
   hipLaunchKernelGGL(k_partition, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
                      c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
-                     c->d_mask, use_mask, (u64 *)c->d_part_state, c->d_lambda, c->d_part_ss);
+                     c->d_mask, use_mask, (u64 *)c->d_part_state, c->d_lambda, c->d_part_ss,
+                     c->dmode);
   QR_CHECK(c, hipGetLastError());
   return launch_hist_scan(c, 0);
 }

@@ -93,7 +93,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_red_sum); dfree(c->d_red_cnt);
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
-  dfree(c->d_blkcnt); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_tree); dfree(c->d_leafpart);
+  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_tree); dfree(c->d_leafpart);
   dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
   dfree(c->d_lred_sum); dfree(c->d_lred_cnt); dfree(c->d_lpart_state);
   c->lhist_cap = c->lpart_cap = c->lslots_cap = c->lred_nodes = 0;
@@ -470,6 +470,7 @@ static int bins_finish(qr_ctx *c) {
       QR_CHECK(c, hipMemset(c->d_xh, 0, c->xh_len * 8));
       c->d_red_sum = c->d_xh;
       c->d_red_cnt = reinterpret_cast<uint32_t *>(c->d_xh + cells);
+      QR_CHECK(c, dalloc(&c->d_red_cnt_loc, cells));  // this rank's counts, kept aside
       QR_CHECK(c, dalloc(&c->d_xscal, 4 * (size_t)c->world));
       QR_CHECK(c, hipMemset(c->d_xscal, 0, 4 * (size_t)c->world * 8));
     } else {
@@ -482,7 +483,6 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, dalloc(&c->d_recs_all, 2 * (size_t)c->world));
   c->mask_words = (N + 31) / 32;
   QR_CHECK(c, dalloc(&c->d_mask, c->mask_words));
-  QR_CHECK(c, dalloc(&c->d_blkcnt, N / QR_PART_SLICE + 2));
   QR_CHECK(c, dalloc(&c->d_part_state, N / QR_PART_SLICE + 2));
   QR_CHECK(c, hipMemset(c->d_part_state, 0, (N / QR_PART_SLICE + 2) * 8));
   QR_CHECK(c, dalloc(&c->d_part_ss, 2 * (N / QR_PART_SLICE + 2)));
@@ -776,6 +776,10 @@ static int ensure_hist_slots(qr_ctx *c, size_t slots) {
   dfree(c->d_hcnt);
   QR_CHECK(c, dalloc(&c->d_hsum, slots * c->flocal * 256));
   QR_CHECK(c, dalloc(&c->d_hcnt, slots * c->flocal * 256));
+  if (c->dmode) {
+    dfree(c->d_hcnt_loc);
+    QR_CHECK(c, dalloc(&c->d_hcnt_loc, slots * c->flocal * 256));
+  }
   c->hist_slots = slots;
   return QR_OK;
 }

@@ -289,7 +289,8 @@ struct qr_ctx {
   qr_split_t *d_recs_all = nullptr;    // [world][2]
   uint32_t *d_mask = nullptr;
   size_t mask_words = 0;
-  uint32_t *d_blkcnt = nullptr;
+  uint32_t *d_red_cnt_loc = nullptr;  // document-sharded: the rank's own reduced counts ...
+  uint32_t *d_hcnt_loc = nullptr;     // ... and their prefix per (node slot, feature, threshold slot)
   unsigned long long *d_part_state = nullptr;  // look-back granules {epoch, count}
   double *d_part_ss = nullptr;
   QrTreeState *d_tree = nullptr;

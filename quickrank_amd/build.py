@@ -38,12 +38,12 @@ def build(force=False, verbose=False):
 
 HOST = os.path.join(HERE, "host")
 BINDIR = os.path.join(HERE, "bin")
-HOST_SRCS = ["svml.cc", "xml.cc", "mart.cc"]
+HOST_SRCS = ["svml.cc", "xml.cc", "mart.cc", "codegen.cc"]
 HOST_LIB = os.path.join(LIBDIR, "libqr_host.so")
 
 
 def build_host(force=False, verbose=False):
-    """C++ host mirror (Mart/LambdaMart, SVMLight, XML) + the quicklearn/quickscore CLIs."""
+    """C++ host mirror (Mart/LambdaMart, SVMLight, XML, code generators) + the quicklearn/quickscore CLIs."""
     outs = [HOST_LIB, os.path.join(BINDIR, "quicklearn"), os.path.join(BINDIR, "quickscore")]
     srcs = [os.path.join(HOST, f) for f in os.listdir(HOST)]
     if not force and all(os.path.exists(o) for o in outs) and \

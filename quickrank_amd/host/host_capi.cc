@@ -2,6 +2,7 @@
 // SVMLight reader and the XML model round trip; no device calls here.
 #include <cstring>
 
+#include "codegen.h"
 #include "mart.h"
 #include "svml.h"
 
@@ -94,6 +95,11 @@ int qrh_model_read(const char *path, qr_node_t *nodes, double *weights, size_t *
     memcpy(weights, w.data(), w.size() * sizeof(double));
   }
   return 0;
+}
+
+// `--model-file / --code-file / --generator` without the command line
+int qrh_codegen(const char *generator, const char *model_file, const char *code_file) {
+  return io::generate(generator, model_file, code_file);
 }
 
 }  // extern "C"

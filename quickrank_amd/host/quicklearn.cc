@@ -2,8 +2,8 @@
 // algorithms this build accelerates (src/quicklearn.cc:89-507 and
 // src/driver/driver.cc:45-226 of the reference): same option names, defaults
 // and phase order (load -> train -> save -> test -> scores file).  Options of
-// out-of-scope subsystems (DART, CLEAVER, linear rankers, code generators) are
-// recognised and rejected with a message.
+// out-of-scope subsystems (DART, CLEAVER, linear rankers) are recognised and
+// rejected with a message.
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -12,6 +12,7 @@
 #include <map>
 #include <set>
 
+#include "codegen.h"
 #include "mart.h"
 #include "svml.h"
 
@@ -52,6 +53,9 @@ const std::vector<std::pair<std::string, Opt>> kOptions = {
     {"test-cutoff", {"set test metric cutoff.", "10", true}},
     {"test", {"set testing file.", "", true}},
     {"scores", {"set output scores file.", "", true}},
+    {"model-file", {"set XML model file path [code generation].", "", true}},
+    {"code-file", {"set C code file path [code generation].", "", true}},
+    {"generator", {"set C code generation strategy: [condop|oblivious|vpred].", "condop", true}},
 };
 const std::set<std::string> kOutOfScope = {
     "meta-algo", "final-num-trees", "opt-last-only", "meta-end-after-rounds", "meta-verbose",
@@ -59,8 +63,7 @@ const std::set<std::string> kOutOfScope = {
     "best-on-train", "random-keep", "drop-on-best", "num-samples", "window-size", "reduction-factor",
     "max-iterations", "max-failed-valid", "adaptive", "train-partial", "valid-partial", "opt-algo",
     "opt-method", "opt-model", "opt-algo-model", "pruning-rate", "with-line-search",
-    "line-search-model", "detailed", "model-file", "code-file", "generator",
-    "collapse-leaves-factor"};
+    "line-search-model", "detailed", "collapse-leaves-factor"};
 
 void help() {
   std::cout << "quicklearn (MI355X build): LambdaMART / MART / oblivious variants on the GPU\n\n";
@@ -126,10 +129,18 @@ int main(int argc, char *argv[]) {
       return EXIT_FAILURE;
     }
   }
-  if (!isset.count("train") && !isset.count("test")) {  // driver.cc:47-51
+  if (!isset.count("train") && !isset.count("test") && !isset.count("model-file")) {  // driver.cc:47-51
     help();
     return EXIT_FAILURE;
   }
+  // code generation follows the training / test phases when both are asked for
+  // (driver.cc:197-224)
+  auto codegen = [&]() {
+    if (isset.count("model-file") && isset.count("code-file"))
+      return io::generate(v["generator"], v["model-file"], v["code-file"]);
+    return (int)EXIT_SUCCESS;
+  };
+  if (!isset.count("train") && !isset.count("test")) return codegen();
   // ltr_algorithm_factory.cc:41-261 for the in-scope names
   std::shared_ptr<Mart> algo;
   if (isset.count("model-in") && !isset.count("restart-train") &&
@@ -192,5 +203,5 @@ int main(int argc, char *argv[]) {
       std::cout << "# Scores written to file: " << v["scores"] << std::endl;
     }
   }
-  return EXIT_SUCCESS;
+  return codegen();
 }

@@ -234,3 +234,160 @@ def test_svml_parallel_reader_large_file(host, oracle_lib, tmp_path):
     for u, v in zip(a, b):
         assert u.shape == v.shape and np.array_equal(u.view(np.uint32) if u.dtype == np.float32 else u,
                                                      v.view(np.uint32) if v.dtype == np.float32 else v)
+
+
+# ---------------------------------------------------------------------------
+# Code generators (driver.cc:197-224): known answers derived from the reference's
+# printing rules, and the emitted C compiled and run against an independent walk.
+# The reference's own generators need pugixml (un-vendored): parity unpinned.
+def _codegen(host, generator, model, out):
+    host.qrh_codegen.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    return host.qrh_codegen(generator.encode(), str(model).encode(), str(out).encode())
+
+
+def _toy_model(host, tmp_path):
+    from quickrank_amd import _capi
+    p = tmp_path / "toy.xml"
+    host.qrh_model_write(str(p).encode(), 1, 100, 0.1, 255, 10, 1, 100, 3, _toy_nodes(_capi).ctypes.data, 2, 5)
+    return p
+
+
+def test_codegen_condop_known_answer(host, tmp_path):
+    out = tmp_path / "r.c"
+    assert _codegen(host, "condop", _toy_model(host, tmp_path), out) == 0
+    # weight through a float with 3 decimals + "f"; threshold text + "f"; leaves verbatim
+    assert open(out).read() == (
+        "double ranker(float* v) {\n\treturn 0.0 \n"
+        "\t\t + 0.100f * ( v[2] <= 0.100000001f ? -1.5 : ( v[0] <= 3.40282347e+38f ? "
+        "0.10000000000000001 : 0.33333333333333331 ) )\n"
+        "\t\t + 0.100f * 2;\n}\n")
+    # an integer-looking threshold gets ".0" before the suffix
+    xml = open(_toy_model(host, tmp_path)).read().replace("<threshold>0.100000001</threshold>",
+                                                          "<threshold> 7 </threshold>")
+    m2 = tmp_path / "int.xml"
+    open(m2, "w").write(xml)
+    assert _codegen(host, "condop", m2, out) == 0 and "v[2] <= 7.0f ?" in open(out).read()
+
+
+def test_codegen_vpred_known_answer(host, tmp_path):
+    out = tmp_path / "v.txt"
+    assert _codegen(host, "vpred", _toy_model(host, tmp_path), out) == 0
+    # breadth first; ids below 2^depth - 1 are inner slots (a leaf there is printed as a
+    # node carrying its parent's feature); leaf values are shrinkage * output in %g
+    assert open(out).read() == (
+        "2\n"
+        "2\nroot 0 2 0.100000001\nnode 1 0 2 1 -0.15\nnode 2 0 0 0 3.40282347e+38\n"
+        "leaf 3 2 1 0.01\nleaf 4 2 0 0.0333333\nend\n"
+        "0\nleaf 0 4294967295 0 0.2\nend\n")
+    bad = tmp_path / "bad.xml"
+    open(bad, "w").write("<ranker><info>")
+    assert _codegen(host, "vpred", bad, out) == 1
+    assert _codegen(host, "vpred", "", out) == 1
+
+
+def _compile_ranker(src, tmp_path, name):
+    import subprocess
+    so = str(tmp_path / (name + ".so"))
+    subprocess.check_call(["gcc", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-x", "c", str(src), "-o", so])
+    L = C.CDLL(so)
+    L.ranker.restype = C.c_double
+    L.ranker.argtypes = [C.c_void_p]
+    return L
+
+
+def _scripts():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+    import score_bench
+    return score_bench
+
+
+def test_codegen_condop_runs_like_the_ensemble(host, tmp_path):
+    sb = _scripts()
+    rng = np.random.default_rng(5)
+    nodes, w = sb.make_model(40, 4, 12, rng)
+    # ragged trees: cut some subtrees to leaves
+    for t in range(0, 40, 3):
+        nodes[t, 2]["feature"] = -1
+        nodes[t, 2]["value"] = rng.standard_normal()
+    m = tmp_path / "m.xml"
+    host.qrh_model_write(str(m).encode(), 1, 40, 0.1, 255, 16, 1, 100, 3, nodes.ctypes.data, 40, nodes.shape[1])
+    src = tmp_path / "ranker.c"
+    assert _codegen(host, "condop", m, src) == 0
+    L = _compile_ranker(src, tmp_path, "condop")
+    x = rng.random((500, 12), dtype=np.float32)
+    got = np.array([L.ranker(x[i].ctypes.data) for i in range(len(x))])
+    wf = np.full(40, np.float64(np.float32(0.1)))            # "0.100f"
+    assert np.array_equal(got, sb.numpy_score(nodes, wf, x))
+
+
+def _oblivious_nodes(T, depths, F, rng, capi):
+    """heap-ordered symmetric trees (ot.cc:139-140); depths[t] levels for tree t"""
+    D = max(depths)
+    nn = (1 << (D + 1)) - 1
+    nodes = np.zeros((T, nn), capi.NODE_DTYPE)
+    nodes["feature"] = -1
+    nodes["left"] = nodes["right"] = -1
+    for t in range(T):
+        d = depths[t]
+        f = rng.integers(0, F, d)
+        th = rng.random(d, dtype=np.float32)
+        for i in range((1 << d) - 1):
+            lvl = int(np.log2(i + 1))
+            nodes[t, i]["feature"] = f[lvl]
+            nodes[t, i]["threshold"] = th[lvl]
+            nodes[t, i]["left"] = 2 * i + 1
+            nodes[t, i]["right"] = 2 * i + 2
+        nodes["value"][t, (1 << d) - 1:(1 << (d + 1)) - 1] = rng.standard_normal(1 << d)
+    return nodes
+
+
+@pytest.mark.parametrize("T,mixed", [(12, False), (12, True), (60, True)])
+def test_codegen_oblivious_runs_like_the_ensemble(host, tmp_path, T, mixed):
+    from quickrank_amd import _capi
+    sb = _scripts()
+    rng = np.random.default_rng(6 + T)
+    depths = [int(d) for d in (rng.integers(1, 5, T) if mixed else np.full(T, 4))]
+    if mixed:
+        depths[0] = 4
+    nodes = _oblivious_nodes(T, depths, 9, rng, _capi)
+    m = tmp_path / "o.xml"
+    host.qrh_model_write(str(m).encode(), 3, T, 0.05, 16, 16, 1, 100, 4, nodes.ctypes.data, T, nodes.shape[1])
+    src = tmp_path / "obl.c"
+    assert _codegen(host, "oblivious", m, src) == 0
+    text = open(src).read()
+    assert text.startswith(f"#define N {T} // no. of trees\n#define M 4 // max tree depth\n"
+                           "#define F 16 // max number of leaves\n\nconst float tree_weights[N] = { 0.050000001, ")
+    # one scoring loop per depth, shallow trees first, populations adding up to N
+    import re
+    pops = [int(v) for v in re.findall(r"for \(int j = 0; j < (\d+); \+\+j\)", text)]
+    assert sum(pops) == T and len(pops) == max(depths)
+    assert pops == [depths.count(d) for d in range(1, max(depths) + 1)]
+    L = _compile_ranker(src, tmp_path, f"obl{T}{mixed}")
+    x = rng.random((400, 9), dtype=np.float32)
+    got = np.array([L.ranker(x[i].ctypes.data) for i in range(len(x))])
+    wf = np.full(T, np.float64(np.float32(0.05)))
+    want = sb.numpy_score(nodes, wf, x)                      # bit = 1 <=> x > threshold <=> right
+    if T <= 16 and not mixed:
+        assert np.array_equal(got, want)                     # same tree order, same sum
+    else:
+        assert np.allclose(got, want, rtol=1e-13, atol=1e-13)  # trees regrouped by depth
+
+
+def test_codegen_through_quicklearn_flags(host, tmp_path):
+    """`quicklearn --model-file X --code-file Y [--generator G]` alone generates and
+    exits 0 (driver.cc:47-51, 197-224); without --code-file nothing is written."""
+    import subprocess
+    from quickrank_amd import build
+    exe = os.path.join(build.BINDIR, "quicklearn")
+    m = _toy_model(host, tmp_path)
+    out = tmp_path / "cli.c"
+    r = subprocess.run([exe, "--model-file", str(m), "--code-file", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and "applying conditional operators strategy for C code generation to: " in r.stdout
+    assert open(out).read().startswith("double ranker(float* v) {")
+    out2 = tmp_path / "cli.v"
+    r = subprocess.run([exe, "--model-file", str(m), "--code-file", str(out2), "--generator", "vpred"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and open(out2).read().startswith("2\n2\nroot 0 2 ")
+    r = subprocess.run([exe, "--model-file", str(m)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == ""

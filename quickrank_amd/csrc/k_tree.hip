@@ -266,6 +266,21 @@ __global__ __launch_bounds__(1024) void k_hist_level(
             blocks, nblocks, bins, order0, order1, lambda, scal->scale, partials);
 }
 
+// batched leaf-wise growth: the directly built children of the batch's nodes
+__global__ __launch_bounds__(1024) void k_hist_batch(
+    const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ map,
+    const QrBlock *__restrict__ blocks, const int nblocks,
+    const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
+    const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
+    const QrScalars *__restrict__ scal, u64 *__restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) u64 hist[];
+  if (blockIdx.x >= ts->l_hist_wgs) return;
+  const uint32_t m = map[blockIdx.x];
+  const QrLevelNode &ln = ts->lnode[m >> 16];
+  hist_body(hist, ln.small_begin, ln.small_n, ln.dst_buf, ln.q, (int)(m & 0xffffu), ln.slot_base,
+            blocks, nblocks, bins, order0, order1, lambda, scal->scale, partials);
+}
+
 // ===========================================================================
 // k_reduce: sum the workgroup partials of one histogram launch, in the native
 // [bin][fw] cell order (fully coalesced 8-byte reads), unpacking count and sum.
@@ -392,6 +407,17 @@ __global__ __launch_bounds__(512) void k_reduce_level(
               1u, nullptr);
 }
 
+__global__ __launch_bounds__(512) void k_reduce_batch(
+    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks, const int nblocks,
+    const u64 *__restrict__ partials, long long *__restrict__ red_sum,
+    uint32_t *__restrict__ red_cnt, const uint32_t cells_total) {
+  if ((int)blockIdx.y >= ts->l_nodes) return;
+  const QrLevelNode &ln = ts->lnode[blockIdx.y];
+  reduce_body(ln.small_n, ln.q, ln.slot_base, blockIdx.x, blocks, nblocks, partials,
+              red_sum + (size_t)blockIdx.y * cells_total, red_cnt + (size_t)blockIdx.y * cells_total,
+              1u, nullptr);
+}
+
 // ===========================================================================
 // k_scan
 // ===========================================================================
@@ -443,8 +469,10 @@ __device__ __forceinline__ Best slot_gain(long long cs, uint32_t cc, long long S
   return b;
 }
 
-__global__ __launch_bounds__(256) void k_scan(
-    const QrTreeState *__restrict__ ts, const int root_mode, const uint32_t N,
+// One feature of one node: workgroup of 256 threads, thread = slot.
+__device__ __forceinline__ void scan_body(
+    const int root_mode, const int small_slot, const int big_slot, const int parent_slot,
+    const int small_is_left, const u64 minls, const int lf,
     const QrBlock *__restrict__ blocks, const int nblocks,
     const long long *__restrict__ red_sum, const uint32_t *__restrict__ red_cnt,
     long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
@@ -456,18 +484,6 @@ __global__ __launch_bounds__(256) void k_scan(
   __shared__ long long tot_s[2];
   __shared__ uint32_t tot_c[2];
   __shared__ Best sh_b[4];
-  int small_slot, big_slot = -1, parent_slot = -1, small_is_left = 1;
-  u64 minls = ts->minls;
-  if (root_mode) {
-    small_slot = 0;
-  } else {
-    if (!ts->desc.active) return;
-    small_slot = ts->desc.small_slot;
-    big_slot = ts->desc.big_slot;
-    parent_slot = ts->desc.parent_slot;
-    small_is_left = ts->desc.small_is_left;
-  }
-  const int lf = blockIdx.x;
   int b = 0;
   uint32_t base = 0, mybase = 0;
   for (int i = 0; i < nblocks; ++i) {
@@ -557,6 +573,45 @@ __global__ __launch_bounds__(256) void k_scan(
       o->rcount = v.t == 0xFFFFFFFFu ? 0 : tot_c[1] - bc;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_scan(
+    const QrTreeState *__restrict__ ts, const int root_mode, const uint32_t N,
+    const QrBlock *__restrict__ blocks, const int nblocks,
+    const long long *__restrict__ red_sum, const uint32_t *__restrict__ red_cnt,
+    long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
+    const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
+    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec, const uint32_t cs,
+    const uint32_t *__restrict__ red_cnt_loc, uint32_t *__restrict__ hcnt_loc) {
+  int small_slot, big_slot = -1, parent_slot = -1, small_is_left = 1;
+  if (root_mode) {
+    small_slot = 0;
+  } else {
+    if (!ts->desc.active) return;
+    small_slot = ts->desc.small_slot;
+    big_slot = ts->desc.big_slot;
+    parent_slot = ts->desc.parent_slot;
+    small_is_left = ts->desc.small_is_left;
+  }
+  scan_body(root_mode, small_slot, big_slot, parent_slot, small_is_left, ts->minls, blockIdx.x,
+            blocks, nblocks, red_sum, red_cnt, hsum, hcnt, flocal, thr_size, lf2gf, scal, featrec,
+            cs, red_cnt_loc, hcnt_loc);
+}
+
+// batched leaf-wise growth: grid = (features, nodes of the batch); node y's records
+// go to featrec[2y] (left child) and featrec[2y + 1] (right child)
+__global__ __launch_bounds__(256) void k_scan_batch(
+    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks, const int nblocks,
+    const long long *__restrict__ red_sum, const uint32_t *__restrict__ red_cnt,
+    const uint32_t cells_total, long long *__restrict__ hsum, uint32_t *__restrict__ hcnt,
+    const int flocal, const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
+    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec) {
+  if ((int)blockIdx.y >= ts->l_nodes) return;
+  const QrLevelNode &ln = ts->lnode[blockIdx.y];
+  scan_body(0, ln.small_slot, ln.big_slot, ln.parent_slot, ln.small_is_left, ts->minls, blockIdx.x,
+            blocks, nblocks, red_sum + (size_t)blockIdx.y * cells_total,
+            red_cnt + (size_t)blockIdx.y * cells_total, hsum, hcnt, flocal, thr_size, lf2gf, scal,
+            featrec + (size_t)2 * blockIdx.y * flocal, 1u, nullptr, nullptr);
 }
 
 // level-wise growth: prefix of the directly built child + sibling by subtraction
@@ -1049,6 +1104,382 @@ __global__ __launch_bounds__(128) void k_decide(
 }
 
 // ===========================================================================
+// k_decide_batch: RegressionTree::fit with up to QR_BATCH splits applied per step.
+//
+// The reference's loop (rt.cc:58-90) pops the heap's maximum, splits it, pushes
+// the children, and repeats: one split per step, each a chain of dependent
+// launches here.  A node's best split is known as soon as its histogram exists and
+// does not depend on what else happens to the tree, so a step can ALSO apply the
+// split of the most promising other candidate of the heap ("ahead of its turn"):
+// its partition writes the other list buffer and its children live under
+// provisional node ids, so nothing the reference's order of events can observe
+// changes.  When the loop later pops that node, the split is already there: the
+// children are moved to the ids the sequential order assigns (histogram slots stay
+// where they are) and the loop carries on without a round trip; if the loop never
+// pops it (leaf budget exhausted), the node stays the leaf it was.  Heap pushes and
+// pops, node numbering and the split log are exactly the sequential ones.
+// ===========================================================================
+__device__ __forceinline__ void batch_child_init(QrNode *ch, uint32_t b, uint32_t e, int buf,
+                                                 int slot, int parent) {
+  ch->begin = b;
+  ch->end = e;
+  ch->buf = buf;
+  ch->hslot = slot;
+  ch->feature = -1;
+  ch->thr_id = -1;
+  ch->threshold = 0.f;
+  ch->left = ch->right = -1;
+  ch->parent = parent;
+  ch->leaf_id = -1;
+  ch->pre = 0;
+  ch->pre_l = ch->pre_r = -1;
+}
+
+// the split of `node` becomes part of the tree, with children li / ri
+__device__ __forceinline__ void batch_commit(DecideState &st, int node, int li, int ri,
+                                             const float *thr) {
+  QrNode *nd = &st.nodes[node];
+  nd->feature = (int32_t)nd->best_f;
+  nd->thr_id = (int32_t)nd->best_t;
+  nd->threshold = thr[(size_t)nd->best_f * QR_MAX_BINS + nd->best_t];
+  nd->left = li;
+  nd->right = ri;
+  qr_split_t *lg = &st.split_log[st.nsplits++];
+  lg->score = nd->best_score;
+  lg->feature = nd->best_f;
+  lg->thr_id = nd->best_t;
+  lg->lcount = nd->best_lc;
+  lg->rcount = nd->best_rc;
+}
+
+// what the control lane carries besides DecideState
+struct BatchState {
+  int32_t next_prov, next_slot, spec_made, spec_used;
+  QrLevelNode *ln;  // the next batch's descriptors
+};
+
+// job j of the next batch: apply the best split of `node`
+__device__ __forceinline__ void batch_make_job(DecideState &st, BatchState &bs, int j, int node,
+                                               bool in_turn, const float *thr,
+                                               const int32_t *gf2lf) {
+  QrNode *nd = &st.nodes[node];
+  int li;
+  if (in_turn) {
+    li = st.nnodes;
+    st.nnodes += 2;
+  } else {
+    li = bs.next_prov;
+    bs.next_prov += 2;
+  }
+  const int ri = li + 1;
+  const int sl = bs.next_slot, sr = sl + 1;
+  bs.next_slot += 2;
+  const uint32_t lc = (uint32_t)nd->best_lc, rc = (uint32_t)nd->best_rc;
+  const int dst = nd->buf == 0 ? 1 : 0;
+  batch_child_init(&st.nodes[li], nd->begin, nd->begin + lc, dst, sl, node);
+  batch_child_init(&st.nodes[ri], nd->begin + lc, nd->end, dst, sr, node);
+  QrLevelNode *ln = &bs.ln[j];
+  ln->active = 1;
+  ln->src_buf = nd->buf;
+  ln->dst_buf = dst;
+  ln->small_is_left = lc <= rc;
+  ln->begin = nd->begin;
+  ln->end = nd->end;
+  ln->lcount = lc;
+  ln->small_begin = ln->small_is_left ? nd->begin : nd->begin + lc;
+  ln->small_n = ln->small_is_left ? lc : rc;
+  ln->parent_slot = nd->hslot;
+  ln->small_slot = ln->small_is_left ? sl : sr;
+  ln->big_slot = ln->small_is_left ? sr : sl;
+  ln->q = 0;
+  ln->slot_base = 0;
+  ln->part_first = 0;
+  ln->owner_local = gf2lf[nd->best_f];
+  ln->thr_id = nd->best_t;
+  ln->node = node;
+  ln->left = li;
+  ln->right = ri;
+  ln->spec = in_turn ? 0 : 1;
+  ln->pad = 0;
+  if (in_turn) {
+    batch_commit(st, node, li, ri, thr);
+  } else {
+    nd->pre = 1;
+    nd->pre_l = li;
+    nd->pre_r = ri;
+    bs.spec_made++;
+  }
+}
+
+// the control lane's step on the state `st` points at (force-inlined into an
+// LDS-staged and a device-resident call site, like decide_logic)
+__device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, const bool root_mode,
+                                           const int njobs, const QrLevelNode *prev,
+                                           const uint32_t N, const qr_split_t *own,
+                                           const double *sum_small, const double *ss_small,
+                                           const QrScalars *scal, const float *thr,
+                                           const int32_t *gf2lf, const int root_buf) {
+  int nj = 0;
+  if (root_mode) {
+    QrNode *root = &st.nodes[0];
+    batch_child_init(root, 0, N, root_buf, 0, -1);
+    node_stats(root, scal->root_sum, scal->root_ss, (u64)N);
+    node_set_best(root, own, 1, 0);
+    st.nnodes = 1;
+    st.heap_size = 0;
+    st.heap[0].key = 1.7976931348623157e308;  // DBL_MAX sentinel
+    st.heap[0].val = -1;
+    st.taken = 0;
+    st.done = 0;
+    st.nsplits = 0;
+    st.step = 1;
+    bs.next_prov = 2 * st.nleaves_req + 1;
+    bs.next_slot = 1;
+    bs.spec_made = bs.spec_used = 0;
+    if (node_splittable(root)) {
+      batch_make_job(st, bs, 0, 0, true, thr, gf2lf);
+      nj = 1;
+    } else {
+      st.done = 1;
+    }
+  } else {
+    // children of the batch just applied: directly accumulated child, sibling by
+    // subtraction (rtnode_histogram.cc:65-69, 79-86)
+    for (int j = 0; j < njobs; ++j) {
+      const QrLevelNode &ln = prev[j];
+      const QrNode *P = &st.nodes[ln.node];
+      QrNode *L = &st.nodes[ln.left], *R = &st.nodes[ln.right];
+      QrNode *S = ln.small_is_left ? L : R, *B = ln.small_is_left ? R : L;
+      node_stats(S, sum_small[j], ss_small[j], ln.small_n);
+      node_stats(B, P->sum - sum_small[j], P->ss - ss_small[j], P->count - ln.small_n);
+      node_set_best(L, own + 2 * j, 1, 0);
+      node_set_best(R, own + 2 * j, 1, 1);
+    }
+    if (njobs > 0) {  // job 0 was the split the sequential loop was waiting for
+      const int l0 = prev[0].left, r0 = prev[0].right;
+      heap_push(st, st.nodes[l0].deviance, l0);  // rt.cc:76-77
+      heap_push(st, st.nodes[r0].deviance, r0);
+    }
+    st.step++;
+    if (!st.done) {
+      bool found = false;
+      while (st.heap_size > 0 &&
+             (st.nleaves_req == 0 || st.taken + st.heap_size < st.nleaves_req)) {
+        const int node = st.heap[1].val;
+        heap_pop(st);
+        QrNode *nd = &st.nodes[node];
+        if (!node_splittable(nd)) {
+          ++st.taken;
+          continue;
+        }
+        if (nd->pre) {  // applied ahead of its turn: the children take their final ids
+          const int li = st.nnodes, ri = li + 1;
+          st.nnodes += 2;
+          st.nodes[li] = st.nodes[nd->pre_l];
+          st.nodes[ri] = st.nodes[nd->pre_r];
+          nd->pre = 0;
+          batch_commit(st, node, li, ri, thr);
+          heap_push(st, st.nodes[li].deviance, li);
+          heap_push(st, st.nodes[ri].deviance, ri);
+          bs.spec_used++;
+          continue;
+        }
+        batch_make_job(st, bs, 0, node, true, thr, gf2lf);
+        nj = 1;
+        found = true;
+        break;
+      }
+      if (!found) st.done = 1;
+    }
+  }
+  // candidates applied ahead of their turn: the largest deviances left in the heap,
+  // as long as the leaf budget can still reach them
+  if (nj == 1) {
+    while (nj < QR_BATCH) {
+      if (st.nleaves_req != 0 && st.nleaves_req - (st.taken + st.heap_size + 2) < nj) break;
+      int pick = -1;
+      double key = 0.0;
+      for (int i = 1; i <= st.heap_size; ++i) {
+        const int v = st.heap[i].val;
+        const QrNode *cand = &st.nodes[v];
+        if (cand->pre || !node_splittable(cand)) continue;
+        if (pick < 0 || st.heap[i].key > key) {
+          pick = v;
+          key = st.heap[i].key;
+        }
+      }
+      if (pick < 0) break;
+      batch_make_job(st, bs, nj, pick, false, thr, gf2lf);
+      ++nj;
+    }
+  }
+  return nj;
+}
+
+__global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
+    QrTreeState *ts, const uint32_t N, const int flocal, const QrScalars *__restrict__ scal,
+    const double *__restrict__ part_ss, const float *__restrict__ thr,
+    const int32_t *__restrict__ gf2lf, const qr_split_t *__restrict__ featrec, const uint32_t F,
+    const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
+    uint32_t *__restrict__ hist_map, uint32_t *__restrict__ part_map) {
+  __shared__ qr_split_t own[2 * QR_BATCH];
+  __shared__ double sh_sum[QR_BATCH], sh_ss[QR_BATCH];
+  __shared__ uint32_t sh_hw0[QR_BATCH + 1], sh_pw0[QR_BATCH + 1];
+  __shared__ int sh_nj, sh_hi, sh_hs;
+  __shared__ QrNode sh_nodes[QR_DECIDE_LDS_NODES];
+  __shared__ QrHeapItem sh_heap[QR_DECIDE_LDS_NODES + 2];
+  __shared__ QrLevelNode sh_prev[QR_BATCH], sh_next[QR_BATCH];
+  static_assert(sizeof(QrLevelNode) % 4 == 0, "copied as 4-byte words");
+  const int root_mode = ts->step == 0;
+  const int njobs = root_mode ? 0 : ts->l_nodes;  // the batch that has just been applied
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // everything this step can touch: the final and provisional nodes + the new ones
+  const int lo_hi = root_mode ? 0 : ts->next_prov;
+  const int heap_n = root_mode ? 0 : ts->heap_size;
+  const bool staged = (root_mode ? 2 * ts->nleaves_req + 1 : lo_hi) + 2 * QR_BATCH <= QR_DECIDE_LDS_NODES;
+  if (staged) {
+    const u64 *src = reinterpret_cast<const u64 *>(ts->nodes);
+    u64 *dst = reinterpret_cast<u64 *>(sh_nodes);
+    for (size_t i = threadIdx.x; i < (size_t)lo_hi * sizeof(QrNode) / 8; i += blockDim.x) dst[i] = src[i];
+    const u64 *hs = reinterpret_cast<const u64 *>(ts->heap);
+    u64 *hd = reinterpret_cast<u64 *>(sh_heap);
+    for (size_t i = threadIdx.x; i < (size_t)(heap_n + 1) * sizeof(QrHeapItem) / 8; i += blockDim.x)
+      hd[i] = hs[i];
+  }
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(ts->lnode);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(sh_prev);
+    for (size_t i = threadIdx.x; i < (size_t)njobs * sizeof(QrLevelNode) / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  // wave 2j + which merges the per-feature records of job j's left / right child
+  if (root_mode ? wave == 0 : wave < 2 * njobs) {
+    const qr_split_t a = wave_merge(0, wave, featrec, flocal, 0, 0, 0, F);
+    if (lane == 0) own[wave] = a;
+  }
+  // sums of the directly built children: fixed-order reduction of the partition
+  // workgroups' partials, one wave per job
+  if (wave < njobs) {
+    const QrLevelNode &ln = ts->lnode[wave];
+    const uint32_t nwg = (ln.end - ln.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
+    double a = 0.0, b = 0.0;
+    for (uint32_t i = lane; i < nwg; i += 64) {
+      a += part_ss[2 * (size_t)(ln.part_first + i)];
+      b += part_ss[2 * (size_t)(ln.part_first + i) + 1];
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) {
+      sh_ss[wave] = a;
+      sh_sum[wave] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    DecideState st;
+    st.nleaves_req = ts->nleaves_req;
+    st.nnodes = ts->nnodes;
+    st.taken = ts->taken;
+    st.done = ts->done;
+    st.step = ts->step;
+    st.nsplits = ts->nsplits;
+    st.heap_size = ts->heap_size;
+    st.part_epoch = ts->part_epoch;
+    st.split_log = ts->split_log;
+    st.desc = &ts->desc;
+    st.hcnt_loc = nullptr;
+    st.loc = &ts->loc;
+    st.flocal = flocal;
+    BatchState bs;
+    bs.next_prov = ts->next_prov;
+    bs.next_slot = ts->next_slot;
+    bs.spec_made = ts->spec_made;
+    bs.spec_used = ts->spec_used;
+    bs.ln = sh_next;
+    int nj;
+    if (staged) {
+      st.nodes = sh_nodes;
+      st.heap = sh_heap;
+      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, sh_sum, sh_ss, scal, thr, gf2lf,
+                       root_buf);
+    } else {
+      st.nodes = ts->nodes;
+      st.heap = ts->heap;
+      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, sh_sum, sh_ss, scal, thr, gf2lf,
+                       root_buf);
+    }
+    // one plan quantum for the whole batch (as for a level of an oblivious tree)
+    uint32_t hw0 = 0, slot0 = 0, pw0 = 0;
+    if (nj > 0) {
+      unsigned long long tot_small = 0;
+      for (int j = 0; j < nj; ++j) tot_small += sh_next[j].small_n;
+      if (tot_small == 0) tot_small = 1;
+      const int spare = G - nj * nblocks;
+      const uint32_t q = qr_plan_quantum(tot_small * qr_plan_wsum(nblocks, blocks),
+                                         spare > G / 4 ? spare : G / 4);
+      for (int j = 0; j < nj; ++j) {
+        QrLevelNode *ln = &sh_next[j];
+        int kmax;
+        const uint32_t hw = qr_plan_wgs(ln->small_n, nblocks, blocks, q, &kmax);
+        ln->q = q;
+        ln->slot_base = slot0;
+        ln->part_first = pw0;
+        sh_hw0[j] = hw0;
+        sh_pw0[j] = pw0;
+        hw0 += hw;
+        slot0 += hw * (uint32_t)kmax;
+        pw0 += (ln->end - ln->begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
+      }
+      st.part_epoch++;
+    }
+    sh_hw0[nj] = hw0;
+    sh_pw0[nj] = pw0;
+    sh_nj = nj;
+    sh_hi = bs.next_prov;
+    sh_hs = st.heap_size;
+    ts->l_nodes = nj;
+    ts->l_hist_wgs = hw0;
+    ts->l_part_wgs = pw0;
+    ts->nnodes = st.nnodes;
+    ts->taken = st.taken;
+    ts->done = st.done;
+    ts->step = st.step;
+    ts->nsplits = st.nsplits;
+    ts->heap_size = st.heap_size;
+    ts->part_epoch = st.part_epoch;
+    ts->next_prov = bs.next_prov;
+    ts->next_slot = bs.next_slot;
+    ts->spec_made = bs.spec_made;
+    ts->spec_used = bs.spec_used;
+  }
+  __syncthreads();
+  const int nj = sh_nj;
+  if (staged) {
+    u64 *dst = reinterpret_cast<u64 *>(ts->nodes);
+    const u64 *src = reinterpret_cast<const u64 *>(sh_nodes);
+    for (size_t i = threadIdx.x; i < (size_t)sh_hi * sizeof(QrNode) / 8; i += blockDim.x) dst[i] = src[i];
+    u64 *hd = reinterpret_cast<u64 *>(ts->heap);
+    const u64 *hs = reinterpret_cast<const u64 *>(sh_heap);
+    for (size_t i = threadIdx.x; i < (size_t)(sh_hs + 1) * sizeof(QrHeapItem) / 8; i += blockDim.x)
+      hd[i] = hs[i];
+  }
+  {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(ts->lnode);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sh_next);
+    for (size_t i = threadIdx.x; i < (size_t)nj * sizeof(QrLevelNode) / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  for (uint32_t x = threadIdx.x; x < sh_hw0[nj]; x += blockDim.x) {
+    int j = 0;
+    while (j + 1 < nj && x >= sh_hw0[j + 1]) ++j;
+    hist_map[x] = ((uint32_t)j << 16) | (x - sh_hw0[j]);
+  }
+  for (uint32_t w = threadIdx.x; w < sh_pw0[nj]; w += blockDim.x) {
+    int j = 0;
+    while (j + 1 < nj && w >= sh_pw0[j + 1]) ++j;
+    part_map[w] = (uint32_t)j;
+  }
+}
+
+// ===========================================================================
 // Partition (rt.cc:325-334): stable, x <= threshold  <=>  bin <= thr_id.
 // ===========================================================================
 __device__ __forceinline__ bool go_left(const QrSplitDesc &d, uint32_t p, uint32_t id,
@@ -1238,6 +1669,29 @@ __global__ __launch_bounds__(256) void k_partition_level(
   gl.thr_id = ts->obl_t;
   partition_body(pn, gl, blockIdx.x - ln.part_first, ln.part_first, ts->part_epoch, fm, Nfm,
                  order0, order1, nullptr, 0, state, nullptr, nullptr);
+}
+
+// batched leaf-wise growth: every node of the batch has its own (feature, slot) and
+// needs the sums of its directly built child
+__global__ __launch_bounds__(256) void k_partition_batch(
+    const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ map,
+    const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
+    uint32_t *__restrict__ order1, u64 *__restrict__ state, const double *__restrict__ lambda,
+    double *__restrict__ part_ss) {
+  if (blockIdx.x >= ts->l_part_wgs) return;
+  const QrLevelNode &ln = ts->lnode[map[blockIdx.x]];
+  PartNode pn;
+  pn.begin = ln.begin;
+  pn.n = ln.end - ln.begin;
+  pn.lcount = ln.lcount;
+  pn.src_buf = ln.src_buf;
+  pn.dst_buf = ln.dst_buf;
+  pn.small_is_left = ln.small_is_left;
+  QrSplitDesc gl;
+  gl.owner_local = ln.owner_local;
+  gl.thr_id = ln.thr_id;
+  partition_body(pn, gl, blockIdx.x - ln.part_first, ln.part_first, ts->part_epoch, fm, Nfm,
+                 order0, order1, nullptr, 0, state, lambda, part_ss);
 }
 
 // ===========================================================================
@@ -1872,6 +2326,7 @@ __global__ void k_tree_reset(QrTreeState *ts, int nleaves, u64 minls) {
   ts->heap_size = 0;
   ts->desc.active = 0;
   ts->nleaves = 0;
+  ts->l_nodes = 0;
 }
 
 int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
@@ -1926,6 +2381,51 @@ int qr_k_tree_apply(qr_ctx *c) {
   return launch_hist_scan(c, 0);
 }
 
+
+// Leaf-wise tree with up to QR_BATCH splits per step (k_decide_batch): the whole fit is
+// enqueued at once; steps the tree does not need leave at once.
+int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
+  c->tree_step = 0;
+  c->tree_counter += 0x9E3779B97F4A7C15ull;
+  hipLaunchKernelGGL(k_tree_reset, dim3(1), dim3(64), 0, c->stream, c->d_tree, (int)nleaves,
+                     (u64)minls);
+  QR_CHECK(c, hipGetLastError());
+  int rc = launch_hist_scan(c, 1);  // root histogram -> slot 0, records -> featrec[0]
+  if (rc) return rc;
+  size_t cells = 0;
+  for (const auto &b : c->blocks) cells += (size_t)256 * b.fw;
+  const size_t lds = hist_lds(c);
+  const unsigned pg = (unsigned)std::min<size_t>(c->lpart_cap, c->N / QR_PART_SLICE + QR_BATCH + 1);
+  const unsigned hg = (unsigned)std::min<size_t>(
+      c->lhist_cap, (size_t)std::max(c->ncu, c->ncu / 4 + QR_BATCH * c->nblocks));
+  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);
+  for (size_t s = 0; s < nleaves; ++s) {
+    hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(128 * QR_BATCH), 0, c->stream, c->d_tree, rootn,
+                       c->flocal, c->d_scalars, c->d_lpart_ss, c->d_thr, c->d_gf2lf, c->d_featrec,
+                       (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks,
+                       c->d_lhist_map, c->d_lpart_map);
+    QR_CHECK(c, hipGetLastError());
+    if (s + 1 == nleaves) break;  // the last call only accounts for the last batch
+    hipLaunchKernelGGL(k_partition_batch, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
+                       c->d_lpart_map, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
+                       (u64 *)c->d_lpart_state, c->d_lambda, c->d_lpart_ss);
+    QR_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, c->d_tree,
+                       c->d_lhist_map, c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
+                       c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_lpartials);
+    QR_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_reduce_batch, dim3((unsigned)(cells / 64), QR_BATCH), dim3(512), 0,
+                       c->stream, c->d_tree, c->d_blocks, c->nblocks, (const u64 *)c->d_lpartials,
+                       c->d_lred_sum, c->d_lred_cnt, (uint32_t)cells);
+    QR_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_scan_batch, dim3(c->flocal, QR_BATCH), dim3(256), 0, c->stream, c->d_tree,
+                       c->d_blocks, c->nblocks, c->d_lred_sum, c->d_lred_cnt, (uint32_t)cells,
+                       c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars,
+                       c->d_featrec);
+    QR_CHECK(c, hipGetLastError());
+  }
+  return QR_OK;
+}
 
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
   const int maxnodes = (1 << (depth + 1)) - 1;

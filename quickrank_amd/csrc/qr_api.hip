@@ -44,6 +44,7 @@ int qr_ctx_create(int device, qr_ctx **out) {
     return QR_ERR_HIP;
   }
   qr_ctx *c = new qr_ctx();
+  c->no_batch = getenv("QR_NO_BATCH") != nullptr;
   c->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -93,7 +94,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_red_sum); dfree(c->d_red_cnt);
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
-  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_tree); dfree(c->d_leafpart);
+  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_tree); dfree(c->d_leafpart);
   dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
   dfree(c->d_lred_sum); dfree(c->d_lred_cnt); dfree(c->d_lpart_state);
   c->lhist_cap = c->lpart_cap = c->lslots_cap = c->lred_nodes = 0;
@@ -488,7 +489,8 @@ static int bins_finish(qr_ctx *c) {
       QR_CHECK(c, dalloc(&c->d_red_cnt, cells));
     }
   }
-  QR_CHECK(c, dalloc(&c->d_featrec, 2 * (size_t)c->flocal));
+  QR_CHECK(c, dalloc(&c->d_featrec, 2 * QR_BATCH * (size_t)c->flocal));
+  QR_CHECK(c, dalloc(&c->d_lpart_ss, 2 * (N / QR_PART_SLICE + QR_BATCH + 2)));
   QR_CHECK(c, dalloc(&c->d_recs_local, (size_t)2));
   QR_CHECK(c, dalloc(&c->d_recs_all, 2 * (size_t)c->world));
   c->mask_words = (N + 31) / 32;
@@ -948,6 +950,22 @@ int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
     QR_FAIL(c, QR_ERR_STATE,
             "sharded contexts must drive qr_tree_begin/decide/apply/end "
             "with the collectives in between");
+  // up to QR_BATCH splits per step (k_decide_batch); per-node feature subsets are keyed by
+  // the node's final index, which a split applied ahead of its turn does not know yet
+  if (!c->mf_k && !c->no_batch && nleaves >= 2 && 4 * nleaves + 1 <= QR_MAXNODES) {
+    if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+    int rc = ensure_hist_slots(c, 4 * nleaves + 1);
+    if (rc) return rc;
+    size_t depth = 1;
+    while (((size_t)1 << (depth - 1)) < QR_BATCH) ++depth;
+    if ((rc = ensure_level_buffers(c, depth))) return rc;
+    c->cur_nleaves = nleaves;
+    c->cur_maxnodes = 2 * nleaves + 1;
+    c->tree_open = true;
+    c->tree_valid = false;
+    if ((rc = qr_k_tree_fit_batch(c, nleaves, minls))) return rc;
+    return qr_tree_end(c, newton, nodes_out, nnodes_out);
+  }
   int rc = qr_tree_begin(c, nleaves, minls);
   if (rc) return rc;
   for (size_t s = 0; s + 1 < nleaves; ++s) {

@@ -77,6 +77,24 @@ __host__ __device__ inline void qr_make_plan(uint32_t n, int nblocks,
   }
 }
 
+// what a planner needs of qr_make_plan: the workgroups and flushes per workgroup it hands out
+__host__ __device__ inline uint32_t qr_plan_wgs(uint32_t n, int nblocks, const QrBlock *blk,
+                                                uint32_t q, int *kmax) {
+  uint32_t wgs = 0;
+  *kmax = 1;
+  for (int b = 0; b < nblocks; ++b) {
+    const uint32_t u = (uint32_t)(blk[b].fw / 16);
+    unsigned long long per = ((unsigned long long)q + u - 1) / u;
+    per = (per + 255) / 256 * 256;
+    if (per < QR_SLICE) per = QR_SLICE;
+    if (per > 0x7FFFFC00ull) per = 0x7FFFFC00ull;
+    wgs += (uint32_t)(((unsigned long long)n + per - 1) / per);
+    const int k = (int)((per + QR_DPW - 1) / QR_DPW);
+    if (k > *kmax) *kmax = k;
+  }
+  return wgs;
+}
+
 // Node bookkeeping of the tree under construction (device resident).
 struct QrNode {
   uint32_t begin, end;   // segment of positions in the order buffers
@@ -92,7 +110,10 @@ struct QrNode {
   uint32_t best_f, best_t;
   uint64_t best_lc, best_rc;
   int32_t leaf_id;       // DFS leaf index, -1 for internal
-  int32_t pad;
+  // batched growth (QR_BATCH): 1 = this node's split has been applied ahead of its
+  // turn; its children wait under the provisional indices pre_l / pre_r
+  int32_t pre;
+  int32_t pre_l, pre_r;
 };
 
 struct QrHeapItem {
@@ -143,8 +164,17 @@ struct QrLevelNode {
   uint32_t q;                      // the level's plan quantum (same for all its nodes)
   uint32_t slot_base;              // first partial slot
   uint32_t part_first;             // first partition workgroup (global index)
-  uint32_t pad;
+  // batched leaf-wise growth: every node of the batch has its own split
+  int32_t owner_local;             // local index of the split feature
+  uint32_t thr_id;
+  int32_t node, left, right;       // the split node and its children (final or provisional ids)
+  int32_t spec;                    // 1 = applied ahead of its turn
+  int32_t pad;
 };
+
+// Leaf-wise growth applies up to QR_BATCH splits per step: the one the reference's
+// loop needs next plus the most promising other candidates of the heap.
+#define QR_BATCH 2
 
 struct QrTreeState {
   int32_t nleaves_req;
@@ -170,6 +200,8 @@ struct QrTreeState {
   int32_t l_owner_local;           // local index of the level's feature
   uint32_t l_hist_wgs, l_part_wgs; // workgroups the level's launches really use
   QrLevelNode lnode[QR_MAXLEVEL];
+  int32_t next_prov, next_slot;    // batched growth: provisional node ids / histogram slots handed out
+  int32_t spec_made, spec_used;    // statistics: splits applied ahead of their turn / later taken
   // leaves in DFS order
   int32_t nleaves;
   int32_t leaf_nodes[QR_MAXNODES];
@@ -289,6 +321,8 @@ struct qr_ctx {
   qr_split_t *d_recs_all = nullptr;    // [world][2]
   uint32_t *d_mask = nullptr;
   size_t mask_words = 0;
+  double *d_lpart_ss = nullptr;       // batched growth: child sums per partition workgroup
+  bool no_batch = false;              // QR_NO_BATCH=1: one split per step (debugging aid)
   uint32_t *d_red_cnt_loc = nullptr;  // document-sharded: the rank's own reduced counts ...
   uint32_t *d_hcnt_loc = nullptr;     // ... and their prefix per (node slot, feature, threshold slot)
   unsigned long long *d_part_state = nullptr;  // look-back granules {epoch, count}
@@ -383,6 +417,7 @@ int qr_k_tree_apply(qr_ctx *c);
 int qr_k_tree_finish(qr_ctx *c, int newton);
 int qr_k_scores_update(qr_ctx *c, double shrinkage);
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls);
+int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls);
 int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
                         double *d_out);
 int qr_k_obl_score(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);

@@ -1136,12 +1136,11 @@ __device__ __forceinline__ void batch_child_init(QrNode *ch, uint32_t b, uint32_
 }
 
 // the split of `node` becomes part of the tree, with children li / ri
-__device__ __forceinline__ void batch_commit(DecideState &st, int node, int li, int ri,
-                                             const float *thr) {
+__device__ __forceinline__ void batch_commit(DecideState &st, int node, int li, int ri) {
   QrNode *nd = &st.nodes[node];
   nd->feature = (int32_t)nd->best_f;
   nd->thr_id = (int32_t)nd->best_t;
-  nd->threshold = thr[(size_t)nd->best_f * QR_MAX_BINS + nd->best_t];
+  nd->threshold = nd->best_thr;
   nd->left = li;
   nd->right = ri;
   qr_split_t *lg = &st.split_log[st.nsplits++];
@@ -1160,8 +1159,7 @@ struct BatchState {
 
 // job j of the next batch: apply the best split of `node`
 __device__ __forceinline__ void batch_make_job(DecideState &st, BatchState &bs, int j, int node,
-                                               bool in_turn, const float *thr,
-                                               const int32_t *gf2lf) {
+                                               bool in_turn) {
   QrNode *nd = &st.nodes[node];
   int li;
   if (in_turn) {
@@ -1194,7 +1192,7 @@ __device__ __forceinline__ void batch_make_job(DecideState &st, BatchState &bs, 
   ln->q = 0;
   ln->slot_base = 0;
   ln->part_first = 0;
-  ln->owner_local = gf2lf[nd->best_f];
+  ln->owner_local = nd->best_lf;
   ln->thr_id = nd->best_t;
   ln->node = node;
   ln->left = li;
@@ -1202,7 +1200,7 @@ __device__ __forceinline__ void batch_make_job(DecideState &st, BatchState &bs, 
   ln->spec = in_turn ? 0 : 1;
   ln->pad = 0;
   if (in_turn) {
-    batch_commit(st, node, li, ri, thr);
+    batch_commit(st, node, li, ri);
   } else {
     nd->pre = 1;
     nd->pre_l = li;
@@ -1217,14 +1215,16 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
                                            const int njobs, const QrLevelNode *prev,
                                            const uint32_t N, const qr_split_t *own,
                                            const double *sum_small, const double *ss_small,
-                                           const QrScalars *scal, const float *thr,
-                                           const int32_t *gf2lf, const int root_buf) {
+                                           const QrScalars *scal, const int32_t *own_lf,
+                                           const float *own_thr, const int root_buf) {
   int nj = 0;
   if (root_mode) {
     QrNode *root = &st.nodes[0];
     batch_child_init(root, 0, N, root_buf, 0, -1);
     node_stats(root, scal->root_sum, scal->root_ss, (u64)N);
     node_set_best(root, own, 1, 0);
+    root->best_lf = own_lf[0];
+    root->best_thr = own_thr[0];
     st.nnodes = 1;
     st.heap_size = 0;
     st.heap[0].key = 1.7976931348623157e308;  // DBL_MAX sentinel
@@ -1237,7 +1237,7 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
     bs.next_slot = 1;
     bs.spec_made = bs.spec_used = 0;
     if (node_splittable(root)) {
-      batch_make_job(st, bs, 0, 0, true, thr, gf2lf);
+      batch_make_job(st, bs, 0, 0, true);
       nj = 1;
     } else {
       st.done = 1;
@@ -1254,6 +1254,10 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
       node_stats(B, P->sum - sum_small[j], P->ss - ss_small[j], P->count - ln.small_n);
       node_set_best(L, own + 2 * j, 1, 0);
       node_set_best(R, own + 2 * j, 1, 1);
+      L->best_lf = own_lf[2 * j];
+      L->best_thr = own_thr[2 * j];
+      R->best_lf = own_lf[2 * j + 1];
+      R->best_thr = own_thr[2 * j + 1];
     }
     if (njobs > 0) {  // job 0 was the split the sequential loop was waiting for
       const int l0 = prev[0].left, r0 = prev[0].right;
@@ -1278,13 +1282,13 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
           st.nodes[li] = st.nodes[nd->pre_l];
           st.nodes[ri] = st.nodes[nd->pre_r];
           nd->pre = 0;
-          batch_commit(st, node, li, ri, thr);
+          batch_commit(st, node, li, ri);
           heap_push(st, st.nodes[li].deviance, li);
           heap_push(st, st.nodes[ri].deviance, ri);
           bs.spec_used++;
           continue;
         }
-        batch_make_job(st, bs, 0, node, true, thr, gf2lf);
+        batch_make_job(st, bs, 0, node, true);
         nj = 1;
         found = true;
         break;
@@ -1309,7 +1313,7 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
         }
       }
       if (pick < 0) break;
-      batch_make_job(st, bs, nj, pick, false, thr, gf2lf);
+      batch_make_job(st, bs, nj, pick, false);
       ++nj;
     }
   }
@@ -1329,7 +1333,11 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   __shared__ QrNode sh_nodes[QR_DECIDE_LDS_NODES];
   __shared__ QrHeapItem sh_heap[QR_DECIDE_LDS_NODES + 2];
   __shared__ QrLevelNode sh_prev[QR_BATCH], sh_next[QR_BATCH];
+  __shared__ int32_t own_lf[2 * QR_BATCH];
+  __shared__ float own_thr[2 * QR_BATCH];
+  __shared__ QrBlock sh_blk[QR_MAXBLK];
   static_assert(sizeof(QrLevelNode) % 4 == 0, "copied as 4-byte words");
+  static_assert(QR_DECIDE_LDS_NODES * sizeof(QrNode) / 8 <= 8 * 128 * QR_BATCH, "staging copy unroll");
   const int root_mode = ts->step == 0;
   const int njobs = root_mode ? 0 : ts->l_nodes;  // the batch that has just been applied
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1338,14 +1346,28 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   const int heap_n = root_mode ? 0 : ts->heap_size;
   const bool staged = (root_mode ? 2 * ts->nleaves_req + 1 : lo_hi) + 2 * QR_BATCH <= QR_DECIDE_LDS_NODES;
   if (staged) {
+    // all loads first, then the stores: one memory round trip for the whole copy
     const u64 *src = reinterpret_cast<const u64 *>(ts->nodes);
     u64 *dst = reinterpret_cast<u64 *>(sh_nodes);
-    for (size_t i = threadIdx.x; i < (size_t)lo_hi * sizeof(QrNode) / 8; i += blockDim.x) dst[i] = src[i];
+    const size_t nw = (size_t)lo_hi * sizeof(QrNode) / 8;
+    u64 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t i = threadIdx.x + (size_t)k * blockDim.x;
+      v[k] = i < nw ? src[i] : 0;
+    }
     const u64 *hs = reinterpret_cast<const u64 *>(ts->heap);
     u64 *hd = reinterpret_cast<u64 *>(sh_heap);
-    for (size_t i = threadIdx.x; i < (size_t)(heap_n + 1) * sizeof(QrHeapItem) / 8; i += blockDim.x)
-      hd[i] = hs[i];
+    const size_t nh = (size_t)(heap_n + 1) * sizeof(QrHeapItem) / 8;
+    const u64 h0 = threadIdx.x < nh ? hs[threadIdx.x] : 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t i = threadIdx.x + (size_t)k * blockDim.x;
+      if (i < nw) dst[i] = v[k];
+    }
+    if (threadIdx.x < nh) hd[threadIdx.x] = h0;
   }
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) sh_blk[b] = blocks[b];
   {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(ts->lnode);
     uint32_t *dst = reinterpret_cast<uint32_t *>(sh_prev);
@@ -1354,7 +1376,12 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   // wave 2j + which merges the per-feature records of job j's left / right child
   if (root_mode ? wave == 0 : wave < 2 * njobs) {
     const qr_split_t a = wave_merge(0, wave, featrec, flocal, 0, 0, 0, F);
-    if (lane == 0) own[wave] = a;
+    if (lane == 0) {
+      own[wave] = a;
+      const bool ok = a.feature != 0xFFFFFFFFu;
+      own_lf[wave] = ok ? gf2lf[a.feature] : -1;
+      own_thr[wave] = ok ? thr[(size_t)a.feature * QR_MAX_BINS + a.thr_id] : 0.f;
+    }
   }
   // sums of the directly built children: fixed-order reduction of the partition
   // workgroups' partials, one wave per job
@@ -1399,13 +1426,13 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     if (staged) {
       st.nodes = sh_nodes;
       st.heap = sh_heap;
-      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, sh_sum, sh_ss, scal, thr, gf2lf,
-                       root_buf);
+      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, sh_sum, sh_ss, scal, own_lf,
+                       own_thr, root_buf);
     } else {
       st.nodes = ts->nodes;
       st.heap = ts->heap;
-      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, sh_sum, sh_ss, scal, thr, gf2lf,
-                       root_buf);
+      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, sh_sum, sh_ss, scal, own_lf,
+                       own_thr, root_buf);
     }
     // one plan quantum for the whole batch (as for a level of an oblivious tree)
     uint32_t hw0 = 0, slot0 = 0, pw0 = 0;
@@ -1414,12 +1441,12 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
       for (int j = 0; j < nj; ++j) tot_small += sh_next[j].small_n;
       if (tot_small == 0) tot_small = 1;
       const int spare = G - nj * nblocks;
-      const uint32_t q = qr_plan_quantum(tot_small * qr_plan_wsum(nblocks, blocks),
+      const uint32_t q = qr_plan_quantum(tot_small * qr_plan_wsum(nblocks, sh_blk),
                                          spare > G / 4 ? spare : G / 4);
       for (int j = 0; j < nj; ++j) {
         QrLevelNode *ln = &sh_next[j];
         int kmax;
-        const uint32_t hw = qr_plan_wgs(ln->small_n, nblocks, blocks, q, &kmax);
+        const uint32_t hw = qr_plan_wgs(ln->small_n, nblocks, sh_blk, q, &kmax);
         ln->q = q;
         ln->slot_base = slot0;
         ln->part_first = pw0;

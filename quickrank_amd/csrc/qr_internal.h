@@ -114,6 +114,9 @@ struct QrNode {
   // turn; its children wait under the provisional indices pre_l / pre_r
   int32_t pre;
   int32_t pre_l, pre_r;
+  // batched growth keeps what applying the best split needs next to it
+  int32_t best_lf;       // local index of best_f
+  float best_thr;        // thresholds[best_f][best_t]
 };
 
 struct QrHeapItem {

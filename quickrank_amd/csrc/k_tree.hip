@@ -154,6 +154,13 @@ __device__ __forceinline__ void hist_accumulate(
   }
 }
 
+__device__ __forceinline__ void hist_run(
+    u64 *hist, const uint32_t seg_begin, const uint32_t r0, const uint32_t r1, const int buf,
+    const int b, const size_t slot0, const QrBlock *__restrict__ blocks,
+    const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
+    const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
+    const double scale, u64 *__restrict__ partials);
+
 // One workgroup's share of a node histogram: workgroup `wg` of the `G` that the
 // plan hands to a node of n documents; partial slots start at `slot_base`.
 __device__ __forceinline__ void hist_body(
@@ -173,6 +180,18 @@ __device__ __forceinline__ void hist_body(
   const uint32_t per = plan.per[b];
   const uint32_t r0 = j * per;
   const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
+  hist_run(hist, seg_begin, r0, r1, buf, b, slot_base + (size_t)wg * plan.kmax, blocks, bins, order0,
+           order1, lambda, scale, partials);
+}
+
+// positions [r0, r1) of the segment at seg_begin, for feature block b; partial slots
+// slot0, slot0 + 1, ... (one per QR_DPW documents)
+__device__ __forceinline__ void hist_run(
+    u64 *hist, const uint32_t seg_begin, const uint32_t r0, const uint32_t r1, const int buf,
+    const int b, const size_t slot0, const QrBlock *__restrict__ blocks,
+    const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
+    const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
+    const double scale, u64 *__restrict__ partials) {
   const int fw = blocks[b].fw;
   const uint8_t *bins_b = bins + blocks[b].off;
   const uint32_t *order = buf == 0 ? order0 : order1;
@@ -197,7 +216,7 @@ __device__ __forceinline__ void hist_body(
       }
     }
     __syncthreads();
-    u64 *dst = partials + (slot_base + (size_t)wg * plan.kmax + k) * (256u * 64u);
+    u64 *dst = partials + (slot0 + k) * (256u * 64u);
     for (uint32_t i = threadIdx.x * 2; i < cells; i += blockDim.x * 2) {
       ulonglong2 v;
       v.x = hist[i];
@@ -268,17 +287,15 @@ __global__ __launch_bounds__(1024) void k_hist_level(
 
 // batched leaf-wise growth: the directly built children of the batch's nodes
 __global__ __launch_bounds__(1024) void k_hist_batch(
-    const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ map,
-    const QrBlock *__restrict__ blocks, const int nblocks,
+    const QrHistWg *__restrict__ wgs, const QrBlock *__restrict__ blocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const QrScalars *__restrict__ scal, u64 *__restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
-  if (blockIdx.x >= ts->l_hist_wgs) return;
-  const uint32_t m = map[blockIdx.x];
-  const QrLevelNode &ln = ts->lnode[m >> 16];
-  hist_body(hist, ln.small_begin, ln.small_n, ln.dst_buf, ln.q, (int)(m & 0xffffu), ln.slot_base,
-            blocks, nblocks, bins, order0, order1, lambda, scal->scale, partials);
+  const QrHistWg d = wgs[blockIdx.x];
+  if (d.count == 0) return;
+  hist_run(hist, d.begin, 0, d.count, d.buf, d.block, d.slot, blocks, bins, order0, order1, lambda,
+           scal->scale, partials);
 }
 
 // ===========================================================================
@@ -293,12 +310,15 @@ __device__ __forceinline__ void reduce_body(
     const uint32_t n, const uint32_t q, const size_t slot_base, const uint32_t cellblock,
     const QrBlock *__restrict__ blocks, const int nblocks, const u64 *__restrict__ partials,
     long long *__restrict__ red_sum, uint32_t *__restrict__ red_cnt, const uint32_t cs,
-    uint32_t *__restrict__ red_cnt_loc) {
+    uint32_t *__restrict__ red_cnt_loc, const QrPlan *__restrict__ given = nullptr) {
   __shared__ long long sh_s[512];
   __shared__ uint32_t sh_c[512];
-  __shared__ QrPlan plan;
-  if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, q, &plan);
-  __syncthreads();
+  __shared__ QrPlan sh_plan;
+  if (!given) {
+    if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, q, &sh_plan);
+    __syncthreads();
+  }
+  const QrPlan &plan = given ? *given : sh_plan;
   // which block does this workgroup's cell range belong to?
   uint32_t cell0 = cellblock * 64u;  // over the concatenation of 256*fw cells per block
   int b = -1;
@@ -408,14 +428,15 @@ __global__ __launch_bounds__(512) void k_reduce_level(
 }
 
 __global__ __launch_bounds__(512) void k_reduce_batch(
-    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks, const int nblocks,
+    const QrTreeState *__restrict__ ts, const QrPlan *__restrict__ plans,
+    const QrBlock *__restrict__ blocks, const int nblocks,
     const u64 *__restrict__ partials, long long *__restrict__ red_sum,
     uint32_t *__restrict__ red_cnt, const uint32_t cells_total) {
   if ((int)blockIdx.y >= ts->l_nodes) return;
   const QrLevelNode &ln = ts->lnode[blockIdx.y];
   reduce_body(ln.small_n, ln.q, ln.slot_base, blockIdx.x, blocks, nblocks, partials,
               red_sum + (size_t)blockIdx.y * cells_total, red_cnt + (size_t)blockIdx.y * cells_total,
-              1u, nullptr);
+              1u, nullptr, plans + blockIdx.y);
 }
 
 // ===========================================================================
@@ -1325,7 +1346,9 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     const double *__restrict__ part_ss, const float *__restrict__ thr,
     const int32_t *__restrict__ gf2lf, const qr_split_t *__restrict__ featrec, const uint32_t F,
     const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
-    uint32_t *__restrict__ hist_map, uint32_t *__restrict__ part_map) {
+    QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
+    const uint32_t part_grid, QrPlan *__restrict__ plans) {
+  __shared__ QrPlan sh_plan[QR_BATCH];
   __shared__ qr_split_t own[2 * QR_BATCH];
   __shared__ double sh_sum[QR_BATCH], sh_ss[QR_BATCH];
   __shared__ uint32_t sh_hw0[QR_BATCH + 1], sh_pw0[QR_BATCH + 1];
@@ -1445,8 +1468,9 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
                                          spare > G / 4 ? spare : G / 4);
       for (int j = 0; j < nj; ++j) {
         QrLevelNode *ln = &sh_next[j];
-        int kmax;
-        const uint32_t hw = qr_plan_wgs(ln->small_n, nblocks, sh_blk, q, &kmax);
+        qr_make_plan(ln->small_n, nblocks, sh_blk, q, &sh_plan[j]);
+        const int kmax = sh_plan[j].kmax;
+        const uint32_t hw = (uint32_t)sh_plan[j].wg_start[nblocks];
         ln->q = q;
         ln->slot_base = slot0;
         ln->part_first = pw0;
@@ -1494,15 +1518,60 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sh_next);
     for (size_t i = threadIdx.x; i < (size_t)nj * sizeof(QrLevelNode) / 4; i += blockDim.x) dst[i] = src[i];
   }
-  for (uint32_t x = threadIdx.x; x < sh_hw0[nj]; x += blockDim.x) {
-    int j = 0;
-    while (j + 1 < nj && x >= sh_hw0[j + 1]) ++j;
-    hist_map[x] = ((uint32_t)j << 16) | (x - sh_hw0[j]);
+  // the plans (k_reduce_batch reads them) and every workgroup's share of the next
+  // partition / histogram launches; workgroups beyond the batch's needs get an empty one
+  {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(plans);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sh_plan);
+    for (size_t i = threadIdx.x; i < (size_t)nj * sizeof(QrPlan) / 4; i += blockDim.x) dst[i] = src[i];
   }
-  for (uint32_t w = threadIdx.x; w < sh_pw0[nj]; w += blockDim.x) {
-    int j = 0;
-    while (j + 1 < nj && w >= sh_pw0[j + 1]) ++j;
-    part_map[w] = (uint32_t)j;
+  for (uint32_t x = threadIdx.x; x < hist_grid; x += blockDim.x) {
+    QrHistWg d;
+    d.begin = d.count = d.slot = 0;
+    d.block = 0;
+    d.buf = d.job = 0;
+    if (x < sh_hw0[nj]) {
+      int j = 0;
+      while (j + 1 < nj && x >= sh_hw0[j + 1]) ++j;
+      const QrLevelNode &ln = sh_next[j];
+      const QrPlan &pl = sh_plan[j];
+      const uint32_t xw = x - sh_hw0[j];
+      int b = 0;
+      while (b + 1 < nblocks && (int)xw >= pl.wg_start[b + 1]) ++b;
+      const uint32_t per = pl.per[b];
+      const uint32_t r0 = (xw - (uint32_t)pl.wg_start[b]) * per;
+      const uint32_t r1 = r0 + per < ln.small_n ? r0 + per : ln.small_n;
+      d.begin = ln.small_begin + r0;
+      d.count = r1 > r0 ? r1 - r0 : 0u;
+      d.slot = ln.slot_base + xw * (uint32_t)pl.kmax;
+      d.block = (uint16_t)b;
+      d.buf = (uint8_t)ln.dst_buf;
+      d.job = (uint8_t)j;
+    }
+    hist_wg[x] = d;
+  }
+  for (uint32_t w = threadIdx.x; w < part_grid; w += blockDim.x) {
+    QrPartWg d;
+    d.begin = d.n = d.lcount = d.first = d.w = 0;
+    d.owner_local = 0;
+    d.thr_id = 0;
+    d.src_buf = d.dst_buf = d.small_is_left = d.pad = 0;
+    if (w < sh_pw0[nj]) {
+      int j = 0;
+      while (j + 1 < nj && w >= sh_pw0[j + 1]) ++j;
+      const QrLevelNode &ln = sh_next[j];
+      d.begin = ln.begin;
+      d.n = ln.end - ln.begin;
+      d.lcount = ln.lcount;
+      d.first = ln.part_first;
+      d.w = w - ln.part_first;
+      d.owner_local = ln.owner_local;
+      d.thr_id = ln.thr_id;
+      d.src_buf = (uint8_t)ln.src_buf;
+      d.dst_buf = (uint8_t)ln.dst_buf;
+      d.small_is_left = (uint8_t)ln.small_is_left;
+    }
+    part_wg[w] = d;
   }
 }
 
@@ -1701,24 +1770,24 @@ __global__ __launch_bounds__(256) void k_partition_level(
 // batched leaf-wise growth: every node of the batch has its own (feature, slot) and
 // needs the sums of its directly built child
 __global__ __launch_bounds__(256) void k_partition_batch(
-    const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ map,
+    const QrTreeState *__restrict__ ts, const QrPartWg *__restrict__ wgs,
     const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
     uint32_t *__restrict__ order1, u64 *__restrict__ state, const double *__restrict__ lambda,
     double *__restrict__ part_ss) {
-  if (blockIdx.x >= ts->l_part_wgs) return;
-  const QrLevelNode &ln = ts->lnode[map[blockIdx.x]];
+  const QrPartWg d = wgs[blockIdx.x];
+  if (d.n == 0) return;
   PartNode pn;
-  pn.begin = ln.begin;
-  pn.n = ln.end - ln.begin;
-  pn.lcount = ln.lcount;
-  pn.src_buf = ln.src_buf;
-  pn.dst_buf = ln.dst_buf;
-  pn.small_is_left = ln.small_is_left;
+  pn.begin = d.begin;
+  pn.n = d.n;
+  pn.lcount = d.lcount;
+  pn.src_buf = d.src_buf;
+  pn.dst_buf = d.dst_buf;
+  pn.small_is_left = d.small_is_left;
   QrSplitDesc gl;
-  gl.owner_local = ln.owner_local;
-  gl.thr_id = ln.thr_id;
-  partition_body(pn, gl, blockIdx.x - ln.part_first, ln.part_first, ts->part_epoch, fm, Nfm,
-                 order0, order1, nullptr, 0, state, lambda, part_ss);
+  gl.owner_local = d.owner_local;
+  gl.thr_id = d.thr_id;
+  partition_body(pn, gl, d.w, d.first, ts->part_epoch, fm, Nfm, order0, order1, nullptr, 0, state,
+                 lambda, part_ss);
 }
 
 // ===========================================================================
@@ -2430,20 +2499,20 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
     hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(128 * QR_BATCH), 0, c->stream, c->d_tree, rootn,
                        c->flocal, c->d_scalars, c->d_lpart_ss, c->d_thr, c->d_gf2lf, c->d_featrec,
                        (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks,
-                       c->d_lhist_map, c->d_lpart_map);
+                       c->d_lhist_wg, hg, c->d_lpart_wg, pg, c->d_lplan);
     QR_CHECK(c, hipGetLastError());
     if (s + 1 == nleaves) break;  // the last call only accounts for the last batch
     hipLaunchKernelGGL(k_partition_batch, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_lpart_map, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
+                       c->d_lpart_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
                        (u64 *)c->d_lpart_state, c->d_lambda, c->d_lpart_ss);
     QR_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, c->d_tree,
-                       c->d_lhist_map, c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
-                       c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_lpartials);
+    hipLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, c->d_lhist_wg,
+                       c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
+                       c->d_scalars, (u64 *)c->d_lpartials);
     QR_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(k_reduce_batch, dim3((unsigned)(cells / 64), QR_BATCH), dim3(512), 0,
-                       c->stream, c->d_tree, c->d_blocks, c->nblocks, (const u64 *)c->d_lpartials,
-                       c->d_lred_sum, c->d_lred_cnt, (uint32_t)cells);
+                       c->stream, c->d_tree, c->d_lplan, c->d_blocks, c->nblocks,
+                       (const u64 *)c->d_lpartials, c->d_lred_sum, c->d_lred_cnt, (uint32_t)cells);
     QR_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(k_scan_batch, dim3(c->flocal, QR_BATCH), dim3(256), 0, c->stream, c->d_tree,
                        c->d_blocks, c->nblocks, c->d_lred_sum, c->d_lred_cnt, (uint32_t)cells,

@@ -97,6 +97,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_tree); dfree(c->d_leafpart);
   dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
   dfree(c->d_lred_sum); dfree(c->d_lred_cnt); dfree(c->d_lpart_state);
+  dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
   c->lhist_cap = c->lpart_cap = c->lslots_cap = c->lred_nodes = 0;
   dfree(c->d_present); dfree(c->d_sample_keys); dfree(c->d_sample_count);
   if (c->d_sample_temp) (void)hipFree(c->d_sample_temp);
@@ -817,6 +818,10 @@ static int ensure_level_buffers(qr_ctx *c, size_t depth) {
     QR_CHECK(c, hipStreamSynchronize(c->stream));
     dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
     dfree(c->d_lred_sum); dfree(c->d_lred_cnt); dfree(c->d_lpart_state);
+    dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
+    QR_CHECK(c, dalloc(&c->d_lhist_wg, hist_wgs));
+    QR_CHECK(c, dalloc(&c->d_lpart_wg, part_wgs));
+    QR_CHECK(c, dalloc(&c->d_lplan, nodes));
     QR_CHECK(c, dalloc(&c->d_lhist_map, hist_wgs));
     QR_CHECK(c, dalloc(&c->d_lpart_map, part_wgs));
     QR_CHECK(c, dalloc(&c->d_lpart_state, part_wgs));

@@ -175,6 +175,25 @@ struct QrLevelNode {
   int32_t pad;
 };
 
+// Batched growth hands every workgroup of a step's launches its share ready-made
+// (written by the control kernel), so a workgroup starts loading after ONE dependent
+// read instead of map -> node descriptor -> plan.
+struct QrHistWg {      // one histogram workgroup
+  uint32_t begin;      // first position of its share in the list buffer
+  uint32_t count;      // documents (0: nothing to do)
+  uint32_t slot;       // first partial slot
+  uint16_t block;      // feature block
+  uint8_t buf;         // list buffer (0 / 1)
+  uint8_t job;
+};
+struct QrPartWg {      // one partition workgroup
+  uint32_t begin, n, lcount;   // the node's segment and left count (n == 0: nothing to do)
+  uint32_t first, w;           // the node's first workgroup, this one's index within the node
+  int32_t owner_local;
+  uint32_t thr_id;
+  uint8_t src_buf, dst_buf, small_is_left, pad;
+};
+
 // Leaf-wise growth applies up to QR_BATCH splits per step: the one the reference's
 // loop needs next plus the most promising other candidates of the heap.
 #define QR_BATCH 2
@@ -325,6 +344,9 @@ struct qr_ctx {
   uint32_t *d_mask = nullptr;
   size_t mask_words = 0;
   double *d_lpart_ss = nullptr;       // batched growth: child sums per partition workgroup
+  QrHistWg *d_lhist_wg = nullptr;     // ... per-workgroup shares of the step's launches
+  QrPartWg *d_lpart_wg = nullptr;
+  QrPlan *d_lplan = nullptr;          // ... and the plan of every node of the batch
   bool no_batch = false;              // QR_NO_BATCH=1: one split per step (debugging aid)
   uint32_t *d_red_cnt_loc = nullptr;  // document-sharded: the rank's own reduced counts ...
   uint32_t *d_hcnt_loc = nullptr;     // ... and their prefix per (node slot, feature, threshold slot)

@@ -499,12 +499,15 @@ __device__ __forceinline__ void scan_body(
     long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
     const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
     const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec, const uint32_t cs,
-    const uint32_t *__restrict__ red_cnt_loc, uint32_t *__restrict__ hcnt_loc) {
+    const uint32_t *__restrict__ red_cnt_loc, uint32_t *__restrict__ hcnt_loc,
+    const float *__restrict__ thr = nullptr, float *__restrict__ featthr = nullptr) {
   __shared__ long long sh_s[4];
   __shared__ uint32_t sh_c[4], sh_l[4];
   __shared__ long long tot_s[2];
   __shared__ uint32_t tot_c[2];
   __shared__ Best sh_b[4];
+  // the slot's threshold value travels with the record (requested now, used at the end)
+  const float my_thr = featthr ? thr[(size_t)lf2gf[lf] * QR_MAX_BINS + threadIdx.x] : 0.f;
   int b = 0;
   uint32_t base = 0, mybase = 0;
   for (int i = 0; i < nblocks; ++i) {
@@ -577,6 +580,7 @@ __device__ __forceinline__ void scan_body(
     if (t == (v.t == 0xFFFFFFFFu ? 0u : v.t)) {  // the winning slot knows its counts
       o->lcount = v.t == 0xFFFFFFFFu ? 0 : cn;
       o->rcount = v.t == 0xFFFFFFFFu ? 0 : tot_c[0] - cn;
+      if (featthr) featthr[(size_t)which * flocal + lf] = my_thr;
     }
   }
   if (!root_mode) {
@@ -592,6 +596,7 @@ __device__ __forceinline__ void scan_body(
     if (t == (v.t == 0xFFFFFFFFu ? 0u : v.t)) {
       o->lcount = v.t == 0xFFFFFFFFu ? 0 : bc;
       o->rcount = v.t == 0xFFFFFFFFu ? 0 : tot_c[1] - bc;
+      if (featthr) featthr[(size_t)which * flocal + lf] = my_thr;
     }
   }
 }
@@ -603,7 +608,8 @@ __global__ __launch_bounds__(256) void k_scan(
     long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
     const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
     const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec, const uint32_t cs,
-    const uint32_t *__restrict__ red_cnt_loc, uint32_t *__restrict__ hcnt_loc) {
+    const uint32_t *__restrict__ red_cnt_loc, uint32_t *__restrict__ hcnt_loc,
+    const float *__restrict__ thr, float *__restrict__ featthr) {
   int small_slot, big_slot = -1, parent_slot = -1, small_is_left = 1;
   if (root_mode) {
     small_slot = 0;
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(256) void k_scan(
   }
   scan_body(root_mode, small_slot, big_slot, parent_slot, small_is_left, ts->minls, blockIdx.x,
             blocks, nblocks, red_sum, red_cnt, hsum, hcnt, flocal, thr_size, lf2gf, scal, featrec,
-            cs, red_cnt_loc, hcnt_loc);
+            cs, red_cnt_loc, hcnt_loc, thr, featthr);
 }
 
 // batched leaf-wise growth: grid = (features, nodes of the batch); node y's records
@@ -626,13 +632,15 @@ __global__ __launch_bounds__(256) void k_scan_batch(
     const long long *__restrict__ red_sum, const uint32_t *__restrict__ red_cnt,
     const uint32_t cells_total, long long *__restrict__ hsum, uint32_t *__restrict__ hcnt,
     const int flocal, const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
-    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec) {
+    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec,
+    const float *__restrict__ thr, float *__restrict__ featthr) {
   if ((int)blockIdx.y >= ts->l_nodes) return;
   const QrLevelNode &ln = ts->lnode[blockIdx.y];
   scan_body(0, ln.small_slot, ln.big_slot, ln.parent_slot, ln.small_is_left, ts->minls, blockIdx.x,
             blocks, nblocks, red_sum + (size_t)blockIdx.y * cells_total,
             red_cnt + (size_t)blockIdx.y * cells_total, hsum, hcnt, flocal, thr_size, lf2gf, scal,
-            featrec + (size_t)2 * blockIdx.y * flocal, 1u, nullptr, nullptr);
+            featrec + (size_t)2 * blockIdx.y * flocal, 1u, nullptr, nullptr, thr,
+            featthr + (size_t)2 * blockIdx.y * flocal);
 }
 
 // level-wise growth: prefix of the directly built child + sibling by subtraction
@@ -714,8 +722,9 @@ __device__ __forceinline__ bool mf_allowed(u64 seed, uint32_t node, uint32_t f, 
 __device__ qr_split_t wave_merge(const int root_mode, const int which,
                                  const qr_split_t *featrec, const int flocal,
                                  const uint32_t mf_k, const u64 mf_seed, const uint32_t mf_node,
-                                 const uint32_t F) {
+                                 const uint32_t F, int *lf_out = nullptr) {
   const int lane = threadIdx.x & 63;
+  int best_lf = -1;
   qr_split_t best;
   best.score = -1.0;
   best.feature = 0xFFFFFFFFu;
@@ -726,7 +735,10 @@ __device__ qr_split_t wave_merge(const int root_mode, const int which,
     const qr_split_t r = featrec[(size_t)which * flocal + lf];
     if (mf_k && r.feature != 0xFFFFFFFFu && !mf_allowed(mf_seed, mf_node, r.feature, F, mf_k))
       continue;
-    if (r.score > best.score) best = r;  // ascending lf within the lane
+    if (r.score > best.score) {  // ascending lf within the lane
+      best = r;
+      best_lf = lf;
+    }
   }
   // max score over the wave, equal scores -> lowest feature index; the lane that
   // holds the winner hands out its slot and the counts k_scan recorded with it
@@ -741,7 +753,9 @@ __device__ qr_split_t wave_merge(const int root_mode, const int which,
     best.thr_id = (uint32_t)__builtin_amdgcn_readlane((int)best.thr_id, src);
     best.lcount = (u64)readlane_i64((long long)best.lcount, src);
     best.rcount = (u64)readlane_i64((long long)best.rcount, src);
+    if (lf_out) *lf_out = __builtin_amdgcn_readlane(best_lf, src);
   } else {
+    if (lf_out) *lf_out = -1;
     best.score = -1.0;
     best.feature = 0xFFFFFFFFu;
     best.thr_id = 0xFFFFFFFFu;
@@ -1341,17 +1355,22 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
   return nj;
 }
 
+// One workgroup; `root` = first call of a tree; `stage_nodes` > 0: the node records
+// [0, stage_nodes) and the heap fit the LDS copies (host: 4 * nleaves + 1 <= 96).
+// Everything the kernel needs from memory is requested up front, before any of it is
+// used: the launch is one link of the per-step chain, and a dependent global round
+// trip costs it ~1 us.
 __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
-    QrTreeState *ts, const uint32_t N, const int flocal, const QrScalars *__restrict__ scal,
-    const double *__restrict__ part_ss, const float *__restrict__ thr,
-    const int32_t *__restrict__ gf2lf, const qr_split_t *__restrict__ featrec, const uint32_t F,
+    QrTreeState *ts, const int root_mode, const int stage_nodes, const uint32_t N, const int flocal,
+    const QrScalars *__restrict__ scal, const double *__restrict__ part_ss,
+    const qr_split_t *__restrict__ featrec, const float *__restrict__ featthr, const uint32_t F,
     const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
     QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
     const uint32_t part_grid, QrPlan *__restrict__ plans) {
   __shared__ QrPlan sh_plan[QR_BATCH];
   __shared__ qr_split_t own[2 * QR_BATCH];
   __shared__ double sh_sum[QR_BATCH], sh_ss[QR_BATCH];
-  __shared__ uint32_t sh_hw0[QR_BATCH + 1], sh_pw0[QR_BATCH + 1];
+  __shared__ uint32_t sh_hw0[QR_BATCH + 1], sh_pw0[QR_BATCH + 1], sh_q;
   __shared__ int sh_nj, sh_hi, sh_hs;
   __shared__ QrNode sh_nodes[QR_DECIDE_LDS_NODES];
   __shared__ QrHeapItem sh_heap[QR_DECIDE_LDS_NODES + 2];
@@ -1361,60 +1380,56 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   __shared__ QrBlock sh_blk[QR_MAXBLK];
   static_assert(sizeof(QrLevelNode) % 4 == 0, "copied as 4-byte words");
   static_assert(QR_DECIDE_LDS_NODES * sizeof(QrNode) / 8 <= 8 * 128 * QR_BATCH, "staging copy unroll");
-  const int root_mode = ts->step == 0;
-  const int njobs = root_mode ? 0 : ts->l_nodes;  // the batch that has just been applied
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // everything this step can touch: the final and provisional nodes + the new ones
-  const int lo_hi = root_mode ? 0 : ts->next_prov;
-  const int heap_n = root_mode ? 0 : ts->heap_size;
-  const bool staged = (root_mode ? 2 * ts->nleaves_req + 1 : lo_hi) + 2 * QR_BATCH <= QR_DECIDE_LDS_NODES;
-  if (staged) {
-    // all loads first, then the stores: one memory round trip for the whole copy
+  const bool staged = stage_nodes > 0;
+  // ---- requests: header, the previous batch's descriptors, node records, heap
+  const int njobs_raw = ts->l_nodes;
+  const QrLevelNode myln = ts->lnode[wave < QR_BATCH ? wave : 0];
+  u64 v[8];
+  u64 h0 = 0;
+  const size_t nw = staged && !root_mode ? (size_t)stage_nodes * sizeof(QrNode) / 8 : 0;
+  const size_t nh = staged && !root_mode ? (size_t)(stage_nodes + 2) * sizeof(QrHeapItem) / 8 : 0;
+  {
     const u64 *src = reinterpret_cast<const u64 *>(ts->nodes);
-    u64 *dst = reinterpret_cast<u64 *>(sh_nodes);
-    const size_t nw = (size_t)lo_hi * sizeof(QrNode) / 8;
-    u64 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const size_t i = threadIdx.x + (size_t)k * blockDim.x;
       v[k] = i < nw ? src[i] : 0;
     }
     const u64 *hs = reinterpret_cast<const u64 *>(ts->heap);
-    u64 *hd = reinterpret_cast<u64 *>(sh_heap);
-    const size_t nh = (size_t)(heap_n + 1) * sizeof(QrHeapItem) / 8;
-    const u64 h0 = threadIdx.x < nh ? hs[threadIdx.x] : 0;
+    h0 = threadIdx.x < nh ? hs[threadIdx.x] : 0;
+  }
+  // wave 2j + which: the per-feature records of job j's left / right child (stale
+  // records of a job that does not exist are merged too and ignored)
+  int my_lf = -1;
+  const qr_split_t mine = wave_merge(0, wave, featrec, flocal, 0, 0, 0, F, &my_lf);
+  const float my_thr = my_lf >= 0 ? featthr[(size_t)wave * flocal + my_lf] : 0.f;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) sh_blk[b] = blocks[b];
+  // ---- uses
+  const int njobs = root_mode ? 0 : njobs_raw;  // the batch that has just been applied
+  {
+    u64 *dst = reinterpret_cast<u64 *>(sh_nodes);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const size_t i = threadIdx.x + (size_t)k * blockDim.x;
       if (i < nw) dst[i] = v[k];
     }
-    if (threadIdx.x < nh) hd[threadIdx.x] = h0;
+    if (threadIdx.x < nh) reinterpret_cast<u64 *>(sh_heap)[threadIdx.x] = h0;
   }
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) sh_blk[b] = blocks[b];
-  {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(ts->lnode);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(sh_prev);
-    for (size_t i = threadIdx.x; i < (size_t)njobs * sizeof(QrLevelNode) / 4; i += blockDim.x) dst[i] = src[i];
+  if (lane == 0) {
+    own[wave] = mine;
+    own_lf[wave] = my_lf;
+    own_thr[wave] = my_thr;
   }
-  // wave 2j + which merges the per-feature records of job j's left / right child
-  if (root_mode ? wave == 0 : wave < 2 * njobs) {
-    const qr_split_t a = wave_merge(0, wave, featrec, flocal, 0, 0, 0, F);
-    if (lane == 0) {
-      own[wave] = a;
-      const bool ok = a.feature != 0xFFFFFFFFu;
-      own_lf[wave] = ok ? gf2lf[a.feature] : -1;
-      own_thr[wave] = ok ? thr[(size_t)a.feature * QR_MAX_BINS + a.thr_id] : 0.f;
-    }
-  }
+  if (wave < njobs && lane == 0) sh_prev[wave] = myln;
   // sums of the directly built children: fixed-order reduction of the partition
   // workgroups' partials, one wave per job
   if (wave < njobs) {
-    const QrLevelNode &ln = ts->lnode[wave];
-    const uint32_t nwg = (ln.end - ln.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
+    const uint32_t nwg = (myln.end - myln.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
     double a = 0.0, b = 0.0;
     for (uint32_t i = lane; i < nwg; i += 64) {
-      a += part_ss[2 * (size_t)(ln.part_first + i)];
-      b += part_ss[2 * (size_t)(ln.part_first + i) + 1];
+      a += part_ss[2 * (size_t)(myln.part_first + i)];
+      b += part_ss[2 * (size_t)(myln.part_first + i) + 1];
     }
     a = wave_sum(a);
     b = wave_sum(b);
@@ -1458,38 +1473,19 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
                        own_thr, root_buf);
     }
     // one plan quantum for the whole batch (as for a level of an oblivious tree)
-    uint32_t hw0 = 0, slot0 = 0, pw0 = 0;
     if (nj > 0) {
       unsigned long long tot_small = 0;
       for (int j = 0; j < nj; ++j) tot_small += sh_next[j].small_n;
       if (tot_small == 0) tot_small = 1;
       const int spare = G - nj * nblocks;
-      const uint32_t q = qr_plan_quantum(tot_small * qr_plan_wsum(nblocks, sh_blk),
-                                         spare > G / 4 ? spare : G / 4);
-      for (int j = 0; j < nj; ++j) {
-        QrLevelNode *ln = &sh_next[j];
-        qr_make_plan(ln->small_n, nblocks, sh_blk, q, &sh_plan[j]);
-        const int kmax = sh_plan[j].kmax;
-        const uint32_t hw = (uint32_t)sh_plan[j].wg_start[nblocks];
-        ln->q = q;
-        ln->slot_base = slot0;
-        ln->part_first = pw0;
-        sh_hw0[j] = hw0;
-        sh_pw0[j] = pw0;
-        hw0 += hw;
-        slot0 += hw * (uint32_t)kmax;
-        pw0 += (ln->end - ln->begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
-      }
+      sh_q = qr_plan_quantum(tot_small * qr_plan_wsum(nblocks, sh_blk),
+                             spare > G / 4 ? spare : G / 4);
       st.part_epoch++;
     }
-    sh_hw0[nj] = hw0;
-    sh_pw0[nj] = pw0;
     sh_nj = nj;
     sh_hi = bs.next_prov;
     sh_hs = st.heap_size;
     ts->l_nodes = nj;
-    ts->l_hist_wgs = hw0;
-    ts->l_part_wgs = pw0;
     ts->nnodes = st.nnodes;
     ts->taken = st.taken;
     ts->done = st.done;
@@ -1504,7 +1500,9 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   }
   __syncthreads();
   const int nj = sh_nj;
-  if (staged) {
+  // the plans of the batch's nodes, one lane each
+  if (lane == 0 && wave < nj) qr_make_plan(sh_next[wave].small_n, nblocks, sh_blk, sh_q, &sh_plan[wave]);
+  if (staged) {  // (while they compute: the node records and the heap go back)
     u64 *dst = reinterpret_cast<u64 *>(ts->nodes);
     const u64 *src = reinterpret_cast<const u64 *>(sh_nodes);
     for (size_t i = threadIdx.x; i < (size_t)sh_hi * sizeof(QrNode) / 8; i += blockDim.x) dst[i] = src[i];
@@ -1513,17 +1511,37 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     for (size_t i = threadIdx.x; i < (size_t)(sh_hs + 1) * sizeof(QrHeapItem) / 8; i += blockDim.x)
       hd[i] = hs[i];
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t hw0 = 0, slot0 = 0, pw0 = 0;
+    for (int j = 0; j < nj; ++j) {
+      QrLevelNode *ln = &sh_next[j];
+      const uint32_t hw = (uint32_t)sh_plan[j].wg_start[nblocks];
+      ln->q = sh_q;
+      ln->slot_base = slot0;
+      ln->part_first = pw0;
+      sh_hw0[j] = hw0;
+      sh_pw0[j] = pw0;
+      hw0 += hw;
+      slot0 += hw * (uint32_t)sh_plan[j].kmax;
+      pw0 += (ln->end - ln->begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
+    }
+    sh_hw0[nj] = hw0;
+    sh_pw0[nj] = pw0;
+    ts->l_hist_wgs = hw0;
+    ts->l_part_wgs = pw0;
+  }
+  __syncthreads();
+  // the descriptors and plans (k_reduce_batch, k_scan_batch read them) and every
+  // workgroup's share of the next partition / histogram launches; workgroups beyond
+  // the batch's needs get an empty one
   {
     uint32_t *dst = reinterpret_cast<uint32_t *>(ts->lnode);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sh_next);
     for (size_t i = threadIdx.x; i < (size_t)nj * sizeof(QrLevelNode) / 4; i += blockDim.x) dst[i] = src[i];
-  }
-  // the plans (k_reduce_batch reads them) and every workgroup's share of the next
-  // partition / histogram launches; workgroups beyond the batch's needs get an empty one
-  {
-    uint32_t *dst = reinterpret_cast<uint32_t *>(plans);
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(sh_plan);
-    for (size_t i = threadIdx.x; i < (size_t)nj * sizeof(QrPlan) / 4; i += blockDim.x) dst[i] = src[i];
+    uint32_t *pd = reinterpret_cast<uint32_t *>(plans);
+    const uint32_t *ps = reinterpret_cast<const uint32_t *>(sh_plan);
+    for (size_t i = threadIdx.x; i < (size_t)nj * sizeof(QrPlan) / 4; i += blockDim.x) pd[i] = ps[i];
   }
   for (uint32_t x = threadIdx.x; x < hist_grid; x += blockDim.x) {
     QrHistWg d;
@@ -2399,7 +2417,7 @@ static int launch_scan(qr_ctx *c, int root_mode) {
                      c->d_red_cnt, c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size,
                      c->d_lf2gf, c->d_scalars, c->d_featrec, c->dmode ? 2u : 1u,
                      c->dmode ? c->d_red_cnt_loc : (const uint32_t *)nullptr,
-                     c->dmode ? c->d_hcnt_loc : (uint32_t *)nullptr);
+                     c->dmode ? c->d_hcnt_loc : (uint32_t *)nullptr, c->d_thr, c->d_featthr);
   QR_CHECK(c, hipGetLastError());
   if (c->world > 1 && !c->dmode) {
     hipLaunchKernelGGL(k_merge, dim3(1), dim3(128), 0, c->stream, c->d_tree, root_mode,
@@ -2495,11 +2513,13 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
   const unsigned hg = (unsigned)std::min<size_t>(
       c->lhist_cap, (size_t)std::max(c->ncu, c->ncu / 4 + QR_BATCH * c->nblocks));
   const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);
+  // final ids [0, 2 nleaves + 1) + provisional ones [.., 4 nleaves + 1)
+  const int stage_nodes = 4 * nleaves + 1 <= QR_DECIDE_LDS_NODES ? (int)(4 * nleaves + 1) : 0;
   for (size_t s = 0; s < nleaves; ++s) {
-    hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(128 * QR_BATCH), 0, c->stream, c->d_tree, rootn,
-                       c->flocal, c->d_scalars, c->d_lpart_ss, c->d_thr, c->d_gf2lf, c->d_featrec,
-                       (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks,
-                       c->d_lhist_wg, hg, c->d_lpart_wg, pg, c->d_lplan);
+    hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(128 * QR_BATCH), 0, c->stream, c->d_tree,
+                       s == 0 ? 1 : 0, stage_nodes, rootn, c->flocal, c->d_scalars, c->d_lpart_ss,
+                       c->d_featrec, c->d_featthr, (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu,
+                       c->d_blocks, c->nblocks, c->d_lhist_wg, hg, c->d_lpart_wg, pg, c->d_lplan);
     QR_CHECK(c, hipGetLastError());
     if (s + 1 == nleaves) break;  // the last call only accounts for the last batch
     hipLaunchKernelGGL(k_partition_batch, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
@@ -2517,7 +2537,7 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
     hipLaunchKernelGGL(k_scan_batch, dim3(c->flocal, QR_BATCH), dim3(256), 0, c->stream, c->d_tree,
                        c->d_blocks, c->nblocks, c->d_lred_sum, c->d_lred_cnt, (uint32_t)cells,
                        c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars,
-                       c->d_featrec);
+                       c->d_featrec, c->d_thr, c->d_featthr);
     QR_CHECK(c, hipGetLastError());
   }
   return QR_OK;

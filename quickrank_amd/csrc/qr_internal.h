@@ -64,35 +64,18 @@ __host__ __device__ inline void qr_make_plan(uint32_t n, int nblocks,
   p->wg_start[0] = 0;
   p->kmax = 1;
   for (int b = 0; b < nblocks; ++b) {
+    // (32-bit arithmetic throughout: the control lane of k_decide_batch runs this, and
+    // 64-bit divisions cost it ~200 cycles each)
     const uint32_t u = (uint32_t)(blk[b].fw / 16);
-    unsigned long long per = ((unsigned long long)q + u - 1) / u;
-    per = (per + 255) / 256 * 256;      // fine enough to fill the CUs evenly ...
+    uint32_t per = q / u + (q % u ? 1u : 0u);                 // ceil(q / u)
+    per = per > 0x7FFFFC00u ? 0x7FFFFC00u : ((per + 255u) & ~255u);  // fine enough to fill the CUs evenly ...
     if (per < QR_SLICE) per = QR_SLICE;  // ... but never less than 1024 documents per workgroup
-    if (per > 0x7FFFFC00ull) per = 0x7FFFFC00ull;
-    const int weff = (int)(((unsigned long long)n + per - 1) / per);
-    p->per[b] = (uint32_t)per;
+    const int weff = (int)(n / per + (n % per ? 1u : 0u));    // ceil(n / per)
+    p->per[b] = per;
     p->wg_start[b + 1] = p->wg_start[b] + weff;
     const int k = (int)((per + QR_DPW - 1) / QR_DPW);
     if (k > p->kmax) p->kmax = k;
   }
-}
-
-// what a planner needs of qr_make_plan: the workgroups and flushes per workgroup it hands out
-__host__ __device__ inline uint32_t qr_plan_wgs(uint32_t n, int nblocks, const QrBlock *blk,
-                                                uint32_t q, int *kmax) {
-  uint32_t wgs = 0;
-  *kmax = 1;
-  for (int b = 0; b < nblocks; ++b) {
-    const uint32_t u = (uint32_t)(blk[b].fw / 16);
-    unsigned long long per = ((unsigned long long)q + u - 1) / u;
-    per = (per + 255) / 256 * 256;
-    if (per < QR_SLICE) per = QR_SLICE;
-    if (per > 0x7FFFFC00ull) per = 0x7FFFFC00ull;
-    wgs += (uint32_t)(((unsigned long long)n + per - 1) / per);
-    const int k = (int)((per + QR_DPW - 1) / QR_DPW);
-    if (k > *kmax) *kmax = k;
-  }
-  return wgs;
 }
 
 // Node bookkeeping of the tree under construction (device resident).
@@ -343,6 +326,7 @@ struct qr_ctx {
   qr_split_t *d_recs_all = nullptr;    // [world][2]
   uint32_t *d_mask = nullptr;
   size_t mask_words = 0;
+  float *d_featthr = nullptr;         // threshold value of every per-feature best record
   double *d_lpart_ss = nullptr;       // batched growth: child sums per partition workgroup
   QrHistWg *d_lhist_wg = nullptr;     // ... per-workgroup shares of the step's launches
   QrPartWg *d_lpart_wg = nullptr;

@@ -268,8 +268,14 @@ __device__ __forceinline__ double pow2_label(float l) {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t pk(uint32_t v) { return v >> 16; }
 
+//  * a range whose keys are pairwise distinct is left alone: whatever arrangement
+//    the partition phase would give it, the final stable sort by key puts its
+//    elements in the same places (ranges are ordered by key among themselves, so
+//    an equal key in ANOTHER range is on a known side).  `dupk[key]` != 0 marks the
+//    keys that occur more than once; with a few tied pairs in a query only the
+//    ranges on the way down to them are partitioned.
 __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *RB,
-                              int *stk, uint32_t *out) {
+                              int *stk, uint32_t *out, const uint8_t *dupk) {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
   if (n > 16) {
@@ -288,6 +294,11 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
       int first = stk[3 * sp], last = stk[3 * sp + 1], depth = stk[3 * sp + 2];
       __syncthreads();
       while (last - first > 16) {
+        {
+          bool dup = false;
+          for (int x = first + lane; x < last; x += 64) dup |= dupk[pk(a[x])] != 0;
+          if (!__any(dup)) break;
+        }
         if (depth == 0) {
           if (lane == 0) g_heapsort(a + first, last - first, PackedCmp());
           __syncthreads();
@@ -485,6 +496,7 @@ __global__ __launch_bounds__(64) void k_lambda(
   double *ilt = reinterpret_cast<double *>(stk + 3 * 64);  // [kacc] 1/log2(r+2), top ranks
   double *expt = ilt + kacc;                               // [64] 2^(j/64)
   uint32_t *cmap = reinterpret_cast<uint32_t *>(expt + 64);  // [nmax] cleaned -> original doc
+  uint8_t *dupk = reinterpret_cast<uint8_t *>(cmap + nmax);  // [nmax] key occurs more than once
   // --subsample (lambdamart.cc:85-102): the query is "cleaned" of the documents
   // that are not in this iteration's sample; everything below then runs on the
   // cleaned list, in its own numbering, exactly as on a shorter query.  Documents
@@ -528,7 +540,10 @@ __global__ __launch_bounds__(64) void k_lambda(
   //         and one add per (j, doc).  Without ties g is a permutation of 0..n-1;
   //         a tie makes two docs collide on the same slot, which the check below
   //         detects (the loser does not find itself in unmap[g]).
-  for (uint32_t r = lane; r < n; r += 64) unmap[r] = 0xFFFFFFFFu;
+  for (uint32_t r = lane; r < n; r += 64) {
+    unmap[r] = 0xFFFFFFFFu;
+    dupk[r] = 0;
+  }
   __syncthreads();
   bool tie = false;
   for (uint32_t ib = lane; ib < n; ib += 128) {
@@ -550,13 +565,18 @@ __global__ __launch_bounds__(64) void k_lambda(
     }
   }
   __syncthreads();
-  for (uint32_t i = lane; i < n; i += 64) tie |= unmap[pa[i] >> 16] != i;
+  for (uint32_t i = lane; i < n; i += 64) {
+    const uint32_t key = pa[i] >> 16;
+    const bool lost = unmap[key] != i;  // somebody else holds my slot: the key is shared
+    if (lost) dupk[key] = 1;
+    tie |= lost;
+  }
   if (lane < n4 - n) pa[n + lane] = 0xFFFFFFFFu;
   const bool anytie = __any(tie);
   __syncthreads();
   QR_T(2);
   // ---- 2. with ties the permutation is what GNU std::sort leaves
-  if (anytie) wave_gnu_sort(pa, (int)n, LB, RB, stk, unmap);
+  if (anytie) wave_gnu_sort(pa, (int)n, LB, RB, stk, unmap, dupk);
   QR_T(3);
   for (uint32_t r = lane; r < n; r += 64) {
     const uint32_t d = unmap[r];
@@ -801,7 +821,8 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
 static size_t lambda_lds(size_t nmax, size_t kacc) {
   // s/sr[nmax] f64, accl/accw[kacc] f64, ownl/ownw[nmax] f64 (aliased by the sort
   // scratch), lab0/sl f32, unmap u32, stk, ilt[kacc] f64
-  return nmax * 16 + kacc * 16 + nmax * 16 + nmax * 12 + 3 * 64 * 4 + kacc * 8 + 64 * 8 + nmax * 4;
+  return nmax * 16 + kacc * 16 + nmax * 16 + nmax * 12 + 3 * 64 * 4 + kacc * 8 + 64 * 8 + nmax * 4 +
+         ((nmax + 7) & ~(size_t)7);
 }
 
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {

@@ -60,6 +60,17 @@ def lib():
             f"{path} is missing: build the HIP extension first "
             "(python -m quickrank_amd.build, or __graft_entry__.build()). "
             "quickrank_amd has no CPU fallback.")
+    # torch ships its own HIP runtime under the SONAME of /opt/rocm's: whichever copy
+    # is mapped first serves the whole process, and torch does not find its GPUs
+    # through the system copy (nor this library its own afterwards).  So if torch is
+    # there, it goes first -- whatever order the caller imports things in.
+    if not os.environ.get("QR_NO_TORCH"):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
     L = C.CDLL(path)
     vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
     L.qr_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]

@@ -1384,6 +1384,12 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   const bool staged = stage_nodes > 0;
   // ---- requests: header, the previous batch's descriptors, node records, heap
   const int njobs_raw = ts->l_nodes;
+  const int32_t h_nleaves_req = ts->nleaves_req, h_nnodes = ts->nnodes, h_taken = ts->taken,
+                h_done = ts->done, h_step = ts->step, h_nsplits = ts->nsplits,
+                h_heap_size = ts->heap_size, h_next_prov = ts->next_prov,
+                h_next_slot = ts->next_slot, h_spec_made = ts->spec_made,
+                h_spec_used = ts->spec_used;
+  const uint32_t h_part_epoch = ts->part_epoch;
   const QrLevelNode myln = ts->lnode[wave < QR_BATCH ? wave : 0];
   u64 v[8];
   u64 h0 = 0;
@@ -1441,24 +1447,24 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   __syncthreads();
   if (threadIdx.x == 0) {
     DecideState st;
-    st.nleaves_req = ts->nleaves_req;
-    st.nnodes = ts->nnodes;
-    st.taken = ts->taken;
-    st.done = ts->done;
-    st.step = ts->step;
-    st.nsplits = ts->nsplits;
-    st.heap_size = ts->heap_size;
-    st.part_epoch = ts->part_epoch;
+    st.nleaves_req = h_nleaves_req;
+    st.nnodes = h_nnodes;
+    st.taken = h_taken;
+    st.done = h_done;
+    st.step = h_step;
+    st.nsplits = h_nsplits;
+    st.heap_size = h_heap_size;
+    st.part_epoch = h_part_epoch;
     st.split_log = ts->split_log;
     st.desc = &ts->desc;
     st.hcnt_loc = nullptr;
     st.loc = &ts->loc;
     st.flocal = flocal;
     BatchState bs;
-    bs.next_prov = ts->next_prov;
-    bs.next_slot = ts->next_slot;
-    bs.spec_made = ts->spec_made;
-    bs.spec_used = ts->spec_used;
+    bs.next_prov = h_next_prov;
+    bs.next_slot = h_next_slot;
+    bs.spec_made = h_spec_made;
+    bs.spec_used = h_spec_used;
     bs.ln = sh_next;
     int nj;
     if (staged) {

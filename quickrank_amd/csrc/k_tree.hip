@@ -1244,6 +1244,24 @@ __device__ __forceinline__ void batch_make_job(DecideState &st, BatchState &bs, 
   }
 }
 
+// One child of the batch just applied: directly accumulated child or sibling by
+// subtraction (rtnode_histogram.cc:65-69, 79-86), and its best split.
+__device__ __forceinline__ void batch_child_stats(QrNode *nodes, const QrLevelNode &ln,
+                                                  const int which, const qr_split_t *own2,
+                                                  const double sum_small, const double ss_small,
+                                                  const int32_t lf, const float thrv) {
+  const QrNode *P = &nodes[ln.node];
+  QrNode *C = &nodes[which ? ln.right : ln.left];
+  const bool is_small = (which == 0) == (ln.small_is_left != 0);
+  if (is_small)
+    node_stats(C, sum_small, ss_small, ln.small_n);
+  else
+    node_stats(C, P->sum - sum_small, P->ss - ss_small, P->count - ln.small_n);
+  node_set_best(C, own2, 1, which);
+  C->best_lf = lf;
+  C->best_thr = thrv;
+}
+
 // the control lane's step on the state `st` points at (force-inlined into an
 // LDS-staged and a device-resident call site, like decide_logic)
 __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, const bool root_mode,
@@ -1278,22 +1296,8 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
       st.done = 1;
     }
   } else {
-    // children of the batch just applied: directly accumulated child, sibling by
-    // subtraction (rtnode_histogram.cc:65-69, 79-86)
-    for (int j = 0; j < njobs; ++j) {
-      const QrLevelNode &ln = prev[j];
-      const QrNode *P = &st.nodes[ln.node];
-      QrNode *L = &st.nodes[ln.left], *R = &st.nodes[ln.right];
-      QrNode *S = ln.small_is_left ? L : R, *B = ln.small_is_left ? R : L;
-      node_stats(S, sum_small[j], ss_small[j], ln.small_n);
-      node_stats(B, P->sum - sum_small[j], P->ss - ss_small[j], P->count - ln.small_n);
-      node_set_best(L, own + 2 * j, 1, 0);
-      node_set_best(R, own + 2 * j, 1, 1);
-      L->best_lf = own_lf[2 * j];
-      L->best_thr = own_thr[2 * j];
-      R->best_lf = own_lf[2 * j + 1];
-      R->best_thr = own_thr[2 * j + 1];
-    }
+    // (the children of the batch just applied got their statistics and best splits
+    // from batch_child_stats, one lane per child)
     if (njobs > 0) {  // job 0 was the split the sequential loop was waiting for
       const int l0 = prev[0].left, r0 = prev[0].right;
       heap_push(st, st.nodes[l0].deviance, l0);  // rt.cc:76-77
@@ -1443,6 +1447,12 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
       sh_ss[wave] = a;
       sh_sum[wave] = b;
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * njobs) {  // one lane per child of the batch just applied
+    const int j = threadIdx.x >> 1, which = threadIdx.x & 1;
+    batch_child_stats(staged ? sh_nodes : ts->nodes, sh_prev[j], which, own + 2 * j, sh_sum[j],
+                      sh_ss[j], own_lf[2 * j + which], own_thr[2 * j + which]);
   }
   __syncthreads();
   if (threadIdx.x == 0) {

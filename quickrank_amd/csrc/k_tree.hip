@@ -1267,7 +1267,6 @@ __device__ __forceinline__ void batch_child_stats(QrNode *nodes, const QrLevelNo
 __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, const bool root_mode,
                                            const int njobs, const QrLevelNode *prev,
                                            const uint32_t N, const qr_split_t *own,
-                                           const double *sum_small, const double *ss_small,
                                            const QrScalars *scal, const int32_t *own_lf,
                                            const float *own_thr, const int root_buf) {
   int nj = 0;
@@ -1480,13 +1479,11 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     if (staged) {
       st.nodes = sh_nodes;
       st.heap = sh_heap;
-      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, sh_sum, sh_ss, scal, own_lf,
-                       own_thr, root_buf);
+      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, scal, own_lf, own_thr, root_buf);
     } else {
       st.nodes = ts->nodes;
       st.heap = ts->heap;
-      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, sh_sum, sh_ss, scal, own_lf,
-                       own_thr, root_buf);
+      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, scal, own_lf, own_thr, root_buf);
     }
     // one plan quantum for the whole batch (as for a level of an oblivious tree)
     if (nj > 0) {

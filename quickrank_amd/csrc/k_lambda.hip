@@ -492,11 +492,12 @@ __global__ __launch_bounds__(64) void k_lambda(
   uint32_t *pa = reinterpret_cast<uint32_t *>(ownl);     // packed (key << 16 | doc)
   uint32_t *LB = pa + nmax;
   uint32_t *RB = LB + nmax;
-  int *stk = reinterpret_cast<int *>(unmap + nmax);      // [3 * 64]
-  double *ilt = reinterpret_cast<double *>(stk + 3 * 64);  // [kacc] 1/log2(r+2), top ranks
+  int *stk = reinterpret_cast<int *>(unmap + nmax);      // [3 * 40]: at most 2 lg n + 1 ranges wait
+  double *ilt = reinterpret_cast<double *>(stk + 3 * 40);  // [kacc] 1/log2(r+2), top ranks
   double *expt = ilt + kacc;                               // [64] 2^(j/64)
-  uint32_t *cmap = reinterpret_cast<uint32_t *>(expt + 64);  // [nmax] cleaned -> original doc
-  uint8_t *dupk = reinterpret_cast<uint8_t *>(cmap + nmax);  // [nmax] key occurs more than once
+  uint8_t *dupk = reinterpret_cast<uint8_t *>(expt + 64);  // [nmax, padded to 8] key occurs more than once
+  // [nmax] cleaned -> original doc; only there when a sample is drawn (`present`)
+  uint32_t *cmap = reinterpret_cast<uint32_t *>(dupk + ((nmax + 7) & ~7u));
   // --subsample (lambdamart.cc:85-102): the query is "cleaned" of the documents
   // that are not in this iteration's sample; everything below then runs on the
   // cleaned list, in its own numbering, exactly as on a shorter query.  Documents
@@ -818,11 +819,11 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
 }
 
 // ---------------------------------------------------------------------------
-static size_t lambda_lds(size_t nmax, size_t kacc) {
+static size_t lambda_lds(size_t nmax, size_t kacc, bool sampled) {
   // s/sr[nmax] f64, accl/accw[kacc] f64, ownl/ownw[nmax] f64 (aliased by the sort
-  // scratch), lab0/sl f32, unmap u32, stk, ilt[kacc] f64
-  return nmax * 16 + kacc * 16 + nmax * 16 + nmax * 12 + 3 * 64 * 4 + kacc * 8 + 64 * 8 + nmax * 4 +
-         ((nmax + 7) & ~(size_t)7);
+  // scratch), lab0/sl f32, unmap u32, stk, ilt[kacc] f64, expt, dupk, (cmap u32)
+  return nmax * 16 + kacc * 16 + nmax * 16 + nmax * 12 + 3 * 40 * 4 + kacc * 8 + 64 * 8 +
+         ((nmax + 7) & ~(size_t)7) + (sampled ? nmax * 4 : 0);
 }
 
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
@@ -836,16 +837,17 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   if (kacc == 0) kacc = 1;
   kacc = (kacc + 1) & ~(size_t)1;
   const size_t limit = 160 * 1024 - 512;
+  const bool sampled = which == 0 && c->sub_k != 0;
   size_t nmax = (maxq + 3) & ~(size_t)3;
   // queries whose working set does not fit the LDS run out of a global scratch
   // slice each (second launch); an unbounded cutoff on a long query would also need
   // the per-rank accumulators there, so it takes the same route
   const uint8_t *d_flag = nullptr;
   size_t nlong = 0, nmax_long = 0, lstride = 0;
-  if (lambda_lds(nmax, kacc) > limit) {
+  if (lambda_lds(nmax, kacc, sampled) > limit) {
     nmax_long = nmax;
     size_t kshort = kacc;
-    while (nmax > 4 && lambda_lds(nmax, std::min(kshort, nmax)) > limit) nmax -= 4;
+    while (nmax > 4 && lambda_lds(nmax, std::min(kshort, nmax), sampled) > limit) nmax -= 4;
     const std::vector<uint64_t> &qo = which ? c->h_vqoff : c->h_qoff;
     int &tag = which ? c->long_tag[1] : c->long_tag[0];
     std::vector<uint32_t> &list = which ? c->h_long_list[1] : c->h_long_list[0];
@@ -872,7 +874,7 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     }
     nlong = list.size();
     d_flag = which ? c->d_long_flag[1] : c->d_long_flag[0];
-    lstride = (lambda_lds(nmax_long, std::min(kacc, nmax_long)) + 255) & ~(size_t)255;
+    lstride = (lambda_lds(nmax_long, std::min(kacc, nmax_long), sampled) + 255) & ~(size_t)255;
     if (nlong * lstride > c->lscratch_bytes) {
       QR_CHECK(c, hipStreamSynchronize(c->stream));
       if (c->d_lscratch) (void)hipFree(c->d_lscratch);
@@ -882,7 +884,7 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     }
   }
   const size_t kshort = std::min(kacc, nmax);  // nmax is a multiple of 4: stays even
-  const size_t lds = lambda_lds(nmax, kshort);
+  const size_t lds = lambda_lds(nmax, kshort, sampled);
   static size_t attr_lds = 64 * 1024;
   if (lds > attr_lds) {
     QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false>,

@@ -575,3 +575,29 @@ def test_queries_longer_than_the_lds(qr, ora):
         assert c.metric_last() == pytest.approx(
             ora.eval_dataset(labels, scores, qoff, cutoff, 1 if metric == "NDCG" else 0), rel=1e-13)
     c.close()
+
+
+@pytest.mark.parametrize("nleaves", [24, 255, 256])
+def test_leaf_counts_around_the_batched_growth_limits(qr, ora, nleaves):
+    """Two splits per step with the control state in LDS (<= 23 leaves), in device memory
+    (<= 255), one split per step beyond: same trees, and the
+    split log in the reference's order."""
+    x, labels, qoff = make_dataset(nq=150, docs_per_query=40, F=20, seed=nleaves)
+    rng = np.random.default_rng(nleaves)
+    scores = rng.standard_normal(len(labels)) * 0.3
+    olam, ow = ora.lambdas(labels, scores, qoff, 10, 1)
+    c, thr, ts = _ctx(qr, x, labels, qoff, 64)
+    c.set_pseudo(olam, ow)
+    nodes = c.fit_tree(nleaves, 1, True)
+    tr = ora.Trainer(x, 64)
+    ot = tr.fit_tree(olam, nleaves=nleaves, minls=1)
+    tr.update_output(ot, olam, ow)
+    on = ot["nodes"][:ot["nnodes"]] if "nnodes" in ot else ot["nodes"]
+    assert len(nodes) == len(on) and (nodes["feature"] < 0).sum() == nleaves
+    ties = assert_tree_parity(tr.stmap, on, nodes, value_rtol=1e-9)
+    log, olog = c.split_log(), ot["splits"]
+    assert len(log) == len(olog) == nleaves - 1
+    if ties == 0:
+        assert np.array_equal(log["feature"].astype(np.uint64), olog["feature"])
+        assert np.array_equal(log["thr_id"].astype(np.uint64), olog["thr_id"])
+    c.close()

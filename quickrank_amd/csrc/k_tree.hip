@@ -159,7 +159,7 @@ __device__ __forceinline__ void hist_run(
     const int b, const size_t slot0, const QrBlock *__restrict__ blocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const double scale, u64 *__restrict__ partials);
+    const double scale, u64 *__restrict__ partials, const bool tr = false);
 
 // One workgroup's share of a node histogram: workgroup `wg` of the `G` that the
 // plan hands to a node of n documents; partial slots start at `slot_base`.
@@ -168,7 +168,7 @@ __device__ __forceinline__ void hist_body(
     const int wg, const size_t slot_base, const QrBlock *__restrict__ blocks, const int nblocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const double scale, u64 *__restrict__ partials) {
+    const double scale, u64 *__restrict__ partials, const bool tr = false) {
   __shared__ QrPlan plan;
   if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, q, &plan);
   __syncthreads();
@@ -181,7 +181,7 @@ __device__ __forceinline__ void hist_body(
   const uint32_t r0 = j * per;
   const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
   hist_run(hist, seg_begin, r0, r1, buf, b, slot_base + (size_t)wg * plan.kmax, blocks, bins, order0,
-           order1, lambda, scale, partials);
+           order1, lambda, scale, partials, tr);
 }
 
 // positions [r0, r1) of the segment at seg_begin, for feature block b; partial slots
@@ -191,7 +191,7 @@ __device__ __forceinline__ void hist_run(
     const int b, const size_t slot0, const QrBlock *__restrict__ blocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const double scale, u64 *__restrict__ partials) {
+    const double scale, u64 *__restrict__ partials, const bool tr) {
   const int fw = blocks[b].fw;
   const uint8_t *bins_b = bins + blocks[b].off;
   const uint32_t *order = buf == 0 ? order0 : order1;
@@ -217,6 +217,23 @@ __device__ __forceinline__ void hist_run(
     }
     __syncthreads();
     u64 *dst = partials + (slot0 + k) * (256u * 64u);
+    if (tr) {
+      // feature-major slot [column][256 bins] for k_redscan, which reads one column
+      // of every slot.  A wave moves a tile of 16 columns x 8 bins: lane = (column
+      // f, bin pair b); the 16 lanes of an LDS lane group read 16 consecutive
+      // columns of one bin (conflict-free), and the 4 lanes of a column write 64
+      // contiguous bytes.
+      const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+      const uint32_t nct = (uint32_t)fw / 16;
+      for (uint32_t tile = wave; tile < 32u * nct; tile += nw) {
+        const uint32_t col = (tile % nct) * 16 + (lane & 15);
+        const uint32_t bin = (tile / nct) * 8 + (lane >> 4) * 2;
+        ulonglong2 v;
+        v.x = hist[bin * fw + col];
+        v.y = hist[(bin + 1) * fw + col];
+        *reinterpret_cast<ulonglong2 *>(dst + col * 256u + bin) = v;
+      }
+    } else
     for (uint32_t i = threadIdx.x * 2; i < cells; i += blockDim.x * 2) {
       ulonglong2 v;
       v.x = hist[i];
@@ -260,12 +277,12 @@ __global__ __launch_bounds__(1024) void k_hist_root(
     const uint32_t N, const QrBlock *__restrict__ blocks, const int nblocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const double *__restrict__ lambda, const QrScalars *__restrict__ scal,
-    u64 *__restrict__ partials, const int root_buf) {
+    u64 *__restrict__ partials, const int root_buf, const int tr) {
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
   const uint32_t q =
       qr_plan_quantum((unsigned long long)N * qr_plan_wsum(nblocks, blocks), (int)gridDim.x - nblocks);
   hist_body(hist, 0, N, root_buf, q, (int)blockIdx.x, 0, blocks, nblocks, bins, order0, order0, lambda,
-            scal->scale, partials);
+            scal->scale, partials, tr != 0);
 }
 
 // level-wise (oblivious) growth: the directly built children of ALL nodes of the
@@ -295,7 +312,7 @@ __global__ __launch_bounds__(1024) void k_hist_batch(
   const QrHistWg d = wgs[blockIdx.x];
   if (d.count == 0) return;
   hist_run(hist, d.begin, 0, d.count, d.buf, d.block, d.slot, blocks, bins, order0, order1, lambda,
-           scal->scale, partials);
+           scal->scale, partials, true);
 }
 
 // ===========================================================================
@@ -427,18 +444,6 @@ __global__ __launch_bounds__(512) void k_reduce_level(
               1u, nullptr);
 }
 
-__global__ __launch_bounds__(512) void k_reduce_batch(
-    const QrTreeState *__restrict__ ts, const QrPlan *__restrict__ plans,
-    const QrBlock *__restrict__ blocks, const int nblocks,
-    const u64 *__restrict__ partials, long long *__restrict__ red_sum,
-    uint32_t *__restrict__ red_cnt, const uint32_t cells_total) {
-  if ((int)blockIdx.y >= ts->l_nodes) return;
-  const QrLevelNode &ln = ts->lnode[blockIdx.y];
-  reduce_body(ln.small_n, ln.q, ln.slot_base, blockIdx.x, blocks, nblocks, partials,
-              red_sum + (size_t)blockIdx.y * cells_total, red_cnt + (size_t)blockIdx.y * cells_total,
-              1u, nullptr, plans + blockIdx.y);
-}
-
 // ===========================================================================
 // k_scan
 // ===========================================================================
@@ -490,6 +495,14 @@ __device__ __forceinline__ Best slot_gain(long long cs, uint32_t cc, long long S
   return b;
 }
 
+__device__ __forceinline__ void scan_core(
+    const int root_mode, const int small_slot, const int big_slot, const int parent_slot,
+    const int small_is_left, const u64 minls, const int lf, long long s, uint32_t cn, uint32_t cl,
+    long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
+    const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
+    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec,
+    uint32_t *__restrict__ hcnt_loc, const float my_thr, float *__restrict__ featthr);
+
 // One feature of one node: workgroup of 256 threads, thread = slot.
 __device__ __forceinline__ void scan_body(
     const int root_mode, const int small_slot, const int big_slot, const int parent_slot,
@@ -501,11 +514,6 @@ __device__ __forceinline__ void scan_body(
     const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec, const uint32_t cs,
     const uint32_t *__restrict__ red_cnt_loc, uint32_t *__restrict__ hcnt_loc,
     const float *__restrict__ thr = nullptr, float *__restrict__ featthr = nullptr) {
-  __shared__ long long sh_s[4];
-  __shared__ uint32_t sh_c[4], sh_l[4];
-  __shared__ long long tot_s[2];
-  __shared__ uint32_t tot_c[2];
-  __shared__ Best sh_b[4];
   // the slot's threshold value travels with the record (requested now, used at the end)
   const float my_thr = featthr ? thr[(size_t)lf2gf[lf] * QR_MAX_BINS + threadIdx.x] : 0.f;
   int b = 0;
@@ -520,14 +528,32 @@ __device__ __forceinline__ void scan_body(
   const int col = lf - blocks[b].lf0;
   const int fw = blocks[b].fw;
   const uint32_t t = threadIdx.x;
-  long long s = red_sum[mybase + t * fw + col];
-  uint32_t cn = red_cnt[(size_t)(mybase + t * fw + col) * cs];
-  // inclusive scan over the 256 slots (exact integers: any association)
-  const int lane = t & 63, wave = t >> 6;
+  const long long s = red_sum[mybase + t * fw + col];
+  const uint32_t cn = red_cnt[(size_t)(mybase + t * fw + col) * cs];
   // document-sharded: the same prefix over THIS rank's counts (kept aside by
   // k_reduce before the all-reduce) tells the partition how many of the rank's own
   // documents go left at any (feature, slot) -- no counting pass
-  uint32_t cl = hcnt_loc ? red_cnt_loc[mybase + t * fw + col] : 0u;
+  const uint32_t cl = hcnt_loc ? red_cnt_loc[mybase + t * fw + col] : 0u;
+  scan_core(root_mode, small_slot, big_slot, parent_slot, small_is_left, minls, lf, s, cn, cl, hsum,
+            hcnt, flocal, thr_size, lf2gf, scal, featrec, hcnt_loc, my_thr, featthr);
+}
+
+// thread t of 256 holds the reduced cell (s, cn[, cl]) of slot t of feature lf
+__device__ __forceinline__ void scan_core(
+    const int root_mode, const int small_slot, const int big_slot, const int parent_slot,
+    const int small_is_left, const u64 minls, const int lf, long long s, uint32_t cn, uint32_t cl,
+    long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
+    const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
+    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec,
+    uint32_t *__restrict__ hcnt_loc, const float my_thr, float *__restrict__ featthr) {
+  __shared__ long long sh_s[4];
+  __shared__ uint32_t sh_c[4], sh_l[4];
+  __shared__ long long tot_s[2];
+  __shared__ uint32_t tot_c[2];
+  __shared__ Best sh_b[4];
+  const uint32_t t = threadIdx.x;
+  // inclusive scan over the 256 slots (exact integers: any association)
+  const int lane = t & 63, wave = t >> 6;
   s = wave_scan_i64(s);
   cn = wave_scan_u32(cn);
   if (hcnt_loc) cl = wave_scan_u32(cl);
@@ -625,22 +651,86 @@ __global__ __launch_bounds__(256) void k_scan(
             cs, red_cnt_loc, hcnt_loc, thr, featthr);
 }
 
-// batched leaf-wise growth: grid = (features, nodes of the batch); node y's records
-// go to featrec[2y] (left child) and featrec[2y + 1] (right child)
-__global__ __launch_bounds__(256) void k_scan_batch(
-    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks, const int nblocks,
-    const long long *__restrict__ red_sum, const uint32_t *__restrict__ red_cnt,
-    const uint32_t cells_total, long long *__restrict__ hsum, uint32_t *__restrict__ hcnt,
-    const int flocal, const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
-    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec,
-    const float *__restrict__ thr, float *__restrict__ featthr) {
-  if ((int)blockIdx.y >= ts->l_nodes) return;
-  const QrLevelNode &ln = ts->lnode[blockIdx.y];
-  scan_body(0, ln.small_slot, ln.big_slot, ln.parent_slot, ln.small_is_left, ts->minls, blockIdx.x,
-            blocks, nblocks, red_sum + (size_t)blockIdx.y * cells_total,
-            red_cnt + (size_t)blockIdx.y * cells_total, hsum, hcnt, flocal, thr_size, lf2gf, scal,
-            featrec + (size_t)2 * blockIdx.y * flocal, 1u, nullptr, nullptr, thr,
-            featthr + (size_t)2 * blockIdx.y * flocal);
+// Batched leaf-wise growth: k_reduce and k_scan in one launch.  Grid = (features,
+// nodes of the batch), 1024 threads = 4 slot groups x 256 bins: the partial slots are
+// feature-major here (hist_run, tr), so a workgroup reads its column of every slot
+// as contiguous 2 KB rows; the four groups' sums meet in LDS and the first 256
+// threads carry on with the scan.  Node y's records go to featrec[2y] (left child)
+// and featrec[2y + 1] (right child).  `root`: the root node (slot 0, n = rootn).
+__global__ __launch_bounds__(1024) void k_redscan(
+    const QrTreeState *__restrict__ ts, const int root, const uint32_t rootn,
+    const QrPlan *__restrict__ plans, const QrBlock *__restrict__ blocks, const int nblocks,
+    const int G, const u64 *__restrict__ partials, long long *__restrict__ hsum,
+    uint32_t *__restrict__ hcnt, const int flocal, const uint32_t *__restrict__ thr_size,
+    const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
+    qr_split_t *__restrict__ featrec, const float *__restrict__ thr,
+    float *__restrict__ featthr) {
+  __shared__ long long cs_s[3][256];
+  __shared__ uint32_t cs_c[3][256];
+  __shared__ QrPlan sh_plan;
+  if (!root && (int)blockIdx.y >= ts->l_nodes) return;
+  const int lf = blockIdx.x;
+  const uint32_t t = threadIdx.x & 255, g = threadIdx.x >> 8;
+  const float my_thr = thr[(size_t)lf2gf[lf] * QR_MAX_BINS + t];
+  int small_slot = 0, big_slot = -1, parent_slot = -1, small_is_left = 1;
+  uint32_t n = rootn;
+  size_t slot_base = 0;
+  if (root) {
+    if (threadIdx.x == 0)
+      qr_make_plan(rootn, nblocks, blocks,
+                   qr_plan_quantum((unsigned long long)rootn * qr_plan_wsum(nblocks, blocks), G - nblocks),
+                   &sh_plan);
+    __syncthreads();
+  } else {
+    const QrLevelNode &ln = ts->lnode[blockIdx.y];
+    small_slot = ln.small_slot;
+    big_slot = ln.big_slot;
+    parent_slot = ln.parent_slot;
+    small_is_left = ln.small_is_left;
+    n = ln.small_n;
+    slot_base = ln.slot_base;
+  }
+  const QrPlan &plan = root ? sh_plan : plans[blockIdx.y];
+  int b = 0;
+  for (int i = 0; i < nblocks; ++i)
+    if (lf >= blocks[i].lf0 && lf < blocks[i].lf0 + blocks[i].nreal) b = i;
+  const uint32_t col = (uint32_t)(lf - blocks[b].lf0);
+  const uint32_t per = plan.per[b];
+  const int W = plan.wg_start[b + 1] - plan.wg_start[b];
+  const int kmax = plan.kmax;
+  const int total = W * kmax;
+  const u64 *src = partials + (slot_base + (size_t)plan.wg_start[b] * kmax) * (256u * 64u) + col * 256u + t;
+  long long s = 0;
+  uint32_t cn = 0;
+#pragma unroll 8
+  for (int idx = (int)g; idx < total; idx += 4) {
+    bool valid = true;
+    if (kmax > 1) {  // workgroup j flushed only ceil(docs_j / QR_DPW) slots
+      const int j = idx / kmax, k = idx - j * kmax;
+      const uint32_t r0 = j * per;
+      const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
+      valid = r0 < n && k < (int)((r1 - r0 + QR_DPW - 1) / QR_DPW);
+    }
+    if (valid) {
+      const u64 cell = src[(size_t)idx * (256u * 64u)];
+      const u64 cnt = (cell + (1ull << (QR_SB - 1))) >> QR_SB;
+      s += (long long)(cell - (cnt << QR_SB));
+      cn += (uint32_t)cnt;
+    }
+  }
+  if (g > 0) {
+    cs_s[g - 1][t] = s;
+    cs_c[g - 1][t] = cn;
+  }
+  __syncthreads();
+  if (g > 0) return;  // whole waves leave; the barriers below count the remaining four
+  for (int i = 0; i < 3; ++i) {
+    s += cs_s[i][t];
+    cn += cs_c[i][t];
+  }
+  scan_core(root, small_slot, big_slot, parent_slot, small_is_left, ts->minls, lf, s, cn, 0u, hsum,
+            hcnt, flocal, thr_size, lf2gf, scal, featrec + (size_t)2 * (root ? 0 : blockIdx.y) * flocal,
+            nullptr, my_thr, featthr + (size_t)2 * (root ? 0 : blockIdx.y) * flocal);
 }
 
 // level-wise growth: prefix of the directly built child + sibling by subtraction
@@ -1545,7 +1635,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     ts->l_part_wgs = pw0;
   }
   __syncthreads();
-  // the descriptors and plans (k_reduce_batch, k_scan_batch read them) and every
+  // the descriptors and plans (k_redscan reads them) and every
   // workgroup's share of the next partition / histogram launches; workgroups beyond
   // the batch's needs get an empty one
   {
@@ -2371,7 +2461,7 @@ static size_t hist_lds(const qr_ctx *c) {
 
 static int launch_scan(qr_ctx *c, int root_mode);
 
-static int launch_hist_scan(qr_ctx *c, int root_mode) {
+static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
   const size_t lds = hist_lds(c);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
@@ -2396,13 +2486,13 @@ static int launch_hist_scan(qr_ctx *c, int root_mode) {
       QR_CHECK(c, hipEventCreate(&e1));
       hipExtLaunchKernelGGL(k_hist_root, dim3(G), dim3(1024), lds, c->stream, e0, e1, 0, rootn,
                             c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_lambda,
-                            c->d_scalars, (u64 *)c->d_partials, root_buf);
+                            c->d_scalars, (u64 *)c->d_partials, root_buf, fused ? 1 : 0);
       QR_CHECK(c, hipGetLastError());
       c->prof_events.push_back({e0, e1});
     } else {
       hipLaunchKernelGGL(k_hist_root, dim3(G), dim3(1024), lds, c->stream, rootn, c->d_blocks,
                          c->nblocks, c->d_bins, c->d_order[0], c->d_lambda, c->d_scalars,
-                         (u64 *)c->d_partials, root_buf);
+                         (u64 *)c->d_partials, root_buf, fused ? 1 : 0);
       QR_CHECK(c, hipGetLastError());
     }
   } else {
@@ -2411,6 +2501,14 @@ static int launch_hist_scan(qr_ctx *c, int root_mode) {
                        c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars,
                        (u64 *)c->d_partials, c->dmode, c->sub_k ? 0 : 2);
     QR_CHECK(c, hipGetLastError());
+  }
+  if (fused) {  // batched growth: feature-major partials, reduce + scan in one launch
+    hipLaunchKernelGGL(k_redscan, dim3(c->flocal, 1), dim3(1024), 0, c->stream, c->d_tree, 1, rootn,
+                       c->d_lplan, c->d_blocks, c->nblocks, G, (const u64 *)c->d_partials, c->d_hsum,
+                       c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec,
+                       c->d_thr, c->d_featthr);
+    QR_CHECK(c, hipGetLastError());
+    return QR_OK;
   }
   size_t cells = 0;
   for (const auto &b : c->blocks) cells += (size_t)256 * b.fw;
@@ -2517,10 +2615,8 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
   hipLaunchKernelGGL(k_tree_reset, dim3(1), dim3(64), 0, c->stream, c->d_tree, (int)nleaves,
                      (u64)minls);
   QR_CHECK(c, hipGetLastError());
-  int rc = launch_hist_scan(c, 1);  // root histogram -> slot 0, records -> featrec[0]
+  int rc = launch_hist_scan(c, 1, true);  // root histogram -> slot 0, records -> featrec[0]
   if (rc) return rc;
-  size_t cells = 0;
-  for (const auto &b : c->blocks) cells += (size_t)256 * b.fw;
   const size_t lds = hist_lds(c);
   const unsigned pg = (unsigned)std::min<size_t>(c->lpart_cap, c->N / QR_PART_SLICE + QR_BATCH + 1);
   const unsigned hg = (unsigned)std::min<size_t>(
@@ -2543,12 +2639,8 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
                        c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
                        c->d_scalars, (u64 *)c->d_lpartials);
     QR_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_reduce_batch, dim3((unsigned)(cells / 64), QR_BATCH), dim3(512), 0,
-                       c->stream, c->d_tree, c->d_lplan, c->d_blocks, c->nblocks,
-                       (const u64 *)c->d_lpartials, c->d_lred_sum, c->d_lred_cnt, (uint32_t)cells);
-    QR_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_scan_batch, dim3(c->flocal, QR_BATCH), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_blocks, c->nblocks, c->d_lred_sum, c->d_lred_cnt, (uint32_t)cells,
+    hipLaunchKernelGGL(k_redscan, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_tree, 0,
+                       rootn, c->d_lplan, c->d_blocks, c->nblocks, c->ncu, (const u64 *)c->d_lpartials,
                        c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars,
                        c->d_featrec, c->d_thr, c->d_featthr);
     QR_CHECK(c, hipGetLastError());

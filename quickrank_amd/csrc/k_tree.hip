@@ -501,7 +501,8 @@ __device__ __forceinline__ void scan_core(
     long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
     const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
     const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec,
-    uint32_t *__restrict__ hcnt_loc, const float my_thr, float *__restrict__ featthr);
+    uint32_t *__restrict__ hcnt_loc, const float my_thr, float *__restrict__ featthr,
+    const bool pre = false, const long long pre_s = 0, const uint32_t pre_c = 0);
 
 // One feature of one node: workgroup of 256 threads, thread = slot.
 __device__ __forceinline__ void scan_body(
@@ -545,7 +546,8 @@ __device__ __forceinline__ void scan_core(
     long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
     const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
     const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec,
-    uint32_t *__restrict__ hcnt_loc, const float my_thr, float *__restrict__ featthr) {
+    uint32_t *__restrict__ hcnt_loc, const float my_thr, float *__restrict__ featthr,
+    const bool pre, const long long pre_s, const uint32_t pre_c) {
   __shared__ long long sh_s[4];
   __shared__ uint32_t sh_c[4], sh_l[4];
   __shared__ long long tot_s[2];
@@ -576,8 +578,8 @@ __device__ __forceinline__ void scan_core(
   uint32_t bc = 0;
   if (!root_mode) {
     const size_t pidx = ((size_t)parent_slot * flocal + lf) * 256 + t;
-    bs = hsum[pidx] - s;
-    bc = hcnt[pidx] - cn;
+    bs = (pre ? pre_s : hsum[pidx]) - s;  // (pre: the caller fetched the parent's cell early)
+    bc = (pre ? pre_c : hcnt[pidx]) - cn;
     const size_t bidx = ((size_t)big_slot * flocal + lf) * 256 + t;
     hsum[bidx] = bs;
     hcnt[bidx] = bc;
@@ -664,42 +666,54 @@ __global__ __launch_bounds__(1024) void k_redscan(
     uint32_t *__restrict__ hcnt, const int flocal, const uint32_t *__restrict__ thr_size,
     const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
     qr_split_t *__restrict__ featrec, const float *__restrict__ thr,
-    float *__restrict__ featthr) {
+    float *__restrict__ featthr, const QrScanWg *__restrict__ descs) {
   __shared__ long long cs_s[3][256];
   __shared__ uint32_t cs_c[3][256];
   __shared__ QrPlan sh_plan;
-  if (!root && (int)blockIdx.y >= ts->l_nodes) return;
   const int lf = blockIdx.x;
   const uint32_t t = threadIdx.x & 255, g = threadIdx.x >> 8;
+  // a node of the batch: everything comes ready-made from the control kernel (ONE
+  // dependent read before the partials can be requested)
+  QrScanWg d;
+  if (!root) {
+    d = descs[(size_t)blockIdx.y * flocal + lf];
+    if (!d.active) return;
+  }
   const float my_thr = thr[(size_t)lf2gf[lf] * QR_MAX_BINS + t];
-  int small_slot = 0, big_slot = -1, parent_slot = -1, small_is_left = 1;
-  uint32_t n = rootn;
-  size_t slot_base = 0;
+  const u64 minls = ts->minls;
   if (root) {
     if (threadIdx.x == 0)
       qr_make_plan(rootn, nblocks, blocks,
                    qr_plan_quantum((unsigned long long)rootn * qr_plan_wsum(nblocks, blocks), G - nblocks),
                    &sh_plan);
     __syncthreads();
-  } else {
-    const QrLevelNode &ln = ts->lnode[blockIdx.y];
-    small_slot = ln.small_slot;
-    big_slot = ln.big_slot;
-    parent_slot = ln.parent_slot;
-    small_is_left = ln.small_is_left;
-    n = ln.small_n;
-    slot_base = ln.slot_base;
+    int b = 0;
+    for (int i = 0; i < nblocks; ++i)
+      if (lf >= blocks[i].lf0 && lf < blocks[i].lf0 + blocks[i].nreal) b = i;
+    d.slot0 = (uint32_t)(sh_plan.wg_start[b] * sh_plan.kmax);
+    d.total = (uint32_t)((sh_plan.wg_start[b + 1] - sh_plan.wg_start[b]) * sh_plan.kmax);
+    d.per = sh_plan.per[b];
+    d.n = rootn;
+    d.kmax = sh_plan.kmax;
+    d.small_slot = 0;
+    d.big_slot = d.parent_slot = -1;
+    d.small_is_left = 1;
+    d.col = (uint32_t)(lf - blocks[b].lf0);
   }
-  const QrPlan &plan = root ? sh_plan : plans[blockIdx.y];
-  int b = 0;
-  for (int i = 0; i < nblocks; ++i)
-    if (lf >= blocks[i].lf0 && lf < blocks[i].lf0 + blocks[i].nreal) b = i;
-  const uint32_t col = (uint32_t)(lf - blocks[b].lf0);
-  const uint32_t per = plan.per[b];
-  const int W = plan.wg_start[b + 1] - plan.wg_start[b];
-  const int kmax = plan.kmax;
-  const int total = W * kmax;
-  const u64 *src = partials + (slot_base + (size_t)plan.wg_start[b] * kmax) * (256u * 64u) + col * 256u + t;
+  const int small_slot = d.small_slot, big_slot = d.big_slot, parent_slot = d.parent_slot;
+  const int small_is_left = d.small_is_left;
+  const uint32_t n = d.n, per = d.per;
+  const int kmax = d.kmax;
+  const int total = (int)d.total;
+  // the parent's cumulative cell, for the sibling (requested with the partials)
+  long long par_s = 0;
+  uint32_t par_c = 0;
+  if (!root && g == 0) {
+    const size_t pidx = ((size_t)parent_slot * flocal + lf) * 256 + t;
+    par_s = hsum[pidx];
+    par_c = hcnt[pidx];
+  }
+  const u64 *src = partials + (size_t)d.slot0 * (256u * 64u) + d.col * 256u + t;
   long long s = 0;
   uint32_t cn = 0;
 #pragma unroll 8
@@ -728,9 +742,10 @@ __global__ __launch_bounds__(1024) void k_redscan(
     s += cs_s[i][t];
     cn += cs_c[i][t];
   }
-  scan_core(root, small_slot, big_slot, parent_slot, small_is_left, ts->minls, lf, s, cn, 0u, hsum,
+  scan_core(root, small_slot, big_slot, parent_slot, small_is_left, minls, lf, s, cn, 0u, hsum,
             hcnt, flocal, thr_size, lf2gf, scal, featrec + (size_t)2 * (root ? 0 : blockIdx.y) * flocal,
-            nullptr, my_thr, featthr + (size_t)2 * (root ? 0 : blockIdx.y) * flocal);
+            nullptr, my_thr, featthr + (size_t)2 * (root ? 0 : blockIdx.y) * flocal, !root, par_s,
+            par_c);
 }
 
 // level-wise growth: prefix of the directly built child + sibling by subtraction
@@ -1459,7 +1474,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     const qr_split_t *__restrict__ featrec, const float *__restrict__ featthr, const uint32_t F,
     const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
     QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
-    const uint32_t part_grid, QrPlan *__restrict__ plans) {
+    const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg) {
   __shared__ QrPlan sh_plan[QR_BATCH];
   __shared__ qr_split_t own[2 * QR_BATCH];
   __shared__ double sh_sum[QR_BATCH], sh_ss[QR_BATCH];
@@ -1670,6 +1685,33 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
       d.job = (uint8_t)j;
     }
     hist_wg[x] = d;
+  }
+  for (uint32_t x = threadIdx.x; x < (uint32_t)(QR_BATCH * flocal); x += blockDim.x) {
+    const int j = (int)x / flocal, lf = (int)x - j * flocal;
+    QrScanWg d;
+    d.active = 0;
+    d.slot0 = d.total = d.per = d.n = d.col = d.pad = 0;
+    d.kmax = 1;
+    d.small_slot = d.big_slot = d.parent_slot = d.small_is_left = 0;
+    if (j < nj) {
+      const QrLevelNode &ln = sh_next[j];
+      const QrPlan &pl = sh_plan[j];
+      int b = 0;
+      for (int i = 0; i < nblocks; ++i)
+        if (lf >= sh_blk[i].lf0 && lf < sh_blk[i].lf0 + sh_blk[i].nreal) b = i;
+      d.active = 1;
+      d.slot0 = ln.slot_base + (uint32_t)(pl.wg_start[b] * pl.kmax);
+      d.total = (uint32_t)((pl.wg_start[b + 1] - pl.wg_start[b]) * pl.kmax);
+      d.per = pl.per[b];
+      d.n = ln.small_n;
+      d.kmax = pl.kmax;
+      d.small_slot = ln.small_slot;
+      d.big_slot = ln.big_slot;
+      d.parent_slot = ln.parent_slot;
+      d.small_is_left = ln.small_is_left;
+      d.col = (uint32_t)(lf - sh_blk[b].lf0);
+    }
+    scan_wg[x] = d;
   }
   for (uint32_t w = threadIdx.x; w < part_grid; w += blockDim.x) {
     QrPartWg d;
@@ -2506,7 +2548,7 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
     hipLaunchKernelGGL(k_redscan, dim3(c->flocal, 1), dim3(1024), 0, c->stream, c->d_tree, 1, rootn,
                        c->d_lplan, c->d_blocks, c->nblocks, G, (const u64 *)c->d_partials, c->d_hsum,
                        c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec,
-                       c->d_thr, c->d_featthr);
+                       c->d_thr, c->d_featthr, (const QrScanWg *)nullptr);
     QR_CHECK(c, hipGetLastError());
     return QR_OK;
   }
@@ -2628,7 +2670,8 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
     hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(128 * QR_BATCH), 0, c->stream, c->d_tree,
                        s == 0 ? 1 : 0, stage_nodes, rootn, c->flocal, c->d_scalars, c->d_lpart_ss,
                        c->d_featrec, c->d_featthr, (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu,
-                       c->d_blocks, c->nblocks, c->d_lhist_wg, hg, c->d_lpart_wg, pg, c->d_lplan);
+                       c->d_blocks, c->nblocks, c->d_lhist_wg, hg, c->d_lpart_wg, pg, c->d_lplan,
+                       c->d_lscan_wg);
     QR_CHECK(c, hipGetLastError());
     if (s + 1 == nleaves) break;  // the last call only accounts for the last batch
     hipLaunchKernelGGL(k_partition_batch, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
@@ -2642,7 +2685,7 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
     hipLaunchKernelGGL(k_redscan, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_tree, 0,
                        rootn, c->d_lplan, c->d_blocks, c->nblocks, c->ncu, (const u64 *)c->d_lpartials,
                        c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars,
-                       c->d_featrec, c->d_thr, c->d_featthr);
+                       c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg);
     QR_CHECK(c, hipGetLastError());
   }
   return QR_OK;

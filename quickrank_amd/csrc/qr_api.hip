@@ -92,7 +92,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_xh); dfree(c->d_xscal); dfree(c->d_xleaf);
   c->xleaf_cap = 0;
   dfree(c->d_red_sum); dfree(c->d_red_cnt);
-  dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec); dfree(c->d_featthr);
+  dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec); dfree(c->d_featthr); dfree(c->d_lscan_wg);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
   dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_tree); dfree(c->d_leafpart);
   dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
@@ -492,6 +492,8 @@ static int bins_finish(qr_ctx *c) {
   }
   QR_CHECK(c, dalloc(&c->d_featrec, 2 * QR_BATCH * (size_t)c->flocal));
   QR_CHECK(c, dalloc(&c->d_featthr, 2 * QR_BATCH * (size_t)c->flocal));
+  QR_CHECK(c, dalloc(&c->d_lscan_wg, QR_BATCH * (size_t)c->flocal));
+  QR_CHECK(c, hipMemset(c->d_lscan_wg, 0, QR_BATCH * (size_t)c->flocal * sizeof(QrScanWg)));
   QR_CHECK(c, dalloc(&c->d_lpart_ss, 2 * (N / QR_PART_SLICE + QR_BATCH + 2)));
   QR_CHECK(c, dalloc(&c->d_recs_local, (size_t)2));
   QR_CHECK(c, dalloc(&c->d_recs_all, 2 * (size_t)c->world));

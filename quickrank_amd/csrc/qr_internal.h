@@ -177,6 +177,17 @@ struct QrPartWg {      // one partition workgroup
   uint8_t src_buf, dst_buf, small_is_left, pad;
 };
 
+struct QrScanWg {      // one (node of the batch, feature) workgroup of k_redscan
+  uint32_t active;     // 0: nothing to do
+  uint32_t slot0;      // first partial slot of the feature's block for this node
+  uint32_t total;      // slots to sum (workgroups of the block x flushes per workgroup)
+  uint32_t per, n;     // documents per workgroup / of the node (which slots were flushed)
+  int32_t kmax;
+  int32_t small_slot, big_slot, parent_slot, small_is_left;
+  uint32_t col;        // column of the feature inside its block
+  uint32_t pad;
+};
+
 // Leaf-wise growth applies up to QR_BATCH splits per step: the one the reference's
 // loop needs next plus the most promising other candidates of the heap.
 #define QR_BATCH 2
@@ -330,6 +341,7 @@ struct qr_ctx {
   double *d_lpart_ss = nullptr;       // batched growth: child sums per partition workgroup
   QrHistWg *d_lhist_wg = nullptr;     // ... per-workgroup shares of the step's launches
   QrPartWg *d_lpart_wg = nullptr;
+  QrScanWg *d_lscan_wg = nullptr;     // ... [QR_BATCH][flocal]
   QrPlan *d_lplan = nullptr;          // ... and the plan of every node of the batch
   bool no_batch = false;              // QR_NO_BATCH=1: one split per step (debugging aid)
   uint32_t *d_red_cnt_loc = nullptr;  // document-sharded: the rank's own reduced counts ...

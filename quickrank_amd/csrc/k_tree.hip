@@ -716,20 +716,31 @@ __global__ __launch_bounds__(1024) void k_redscan(
   const u64 *src = partials + (size_t)d.slot0 * (256u * 64u) + d.col * 256u + t;
   long long s = 0;
   uint32_t cn = 0;
-#pragma unroll 8
-  for (int idx = (int)g; idx < total; idx += 4) {
-    bool valid = true;
-    if (kmax > 1) {  // workgroup j flushed only ceil(docs_j / QR_DPW) slots
-      const int j = idx / kmax, k = idx - j * kmax;
-      const uint32_t r0 = j * per;
-      const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
-      valid = r0 < n && k < (int)((r1 - r0 + QR_DPW - 1) / QR_DPW);
+  // eight slots per round: all eight requests leave before the first cell is used
+  // (unconditional loads of clamped slots, so that no branch separates them)
+  for (int base = (int)g; base < total; base += 32) {
+    u64 cell[8];
+    bool ok[8];
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+      const int idx = base + 4 * k8;
+      bool valid = idx < total;
+      if (valid && kmax > 1) {  // workgroup j flushed only ceil(docs_j / QR_DPW) slots
+        const int j = idx / kmax, k = idx - j * kmax;
+        const uint32_t r0 = j * per;
+        const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
+        valid = r0 < n && k < (int)((r1 - r0 + QR_DPW - 1) / QR_DPW);
+      }
+      ok[k8] = valid;
+      cell[k8] = src[(size_t)(valid ? idx : 0) * (256u * 64u)];
     }
-    if (valid) {
-      const u64 cell = src[(size_t)idx * (256u * 64u)];
-      const u64 cnt = (cell + (1ull << (QR_SB - 1))) >> QR_SB;
-      s += (long long)(cell - (cnt << QR_SB));
-      cn += (uint32_t)cnt;
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+      if (ok[k8]) {
+        const u64 cnt = (cell[k8] + (1ull << (QR_SB - 1))) >> QR_SB;
+        s += (long long)(cell[k8] - (cnt << QR_SB));
+        cn += (uint32_t)cnt;
+      }
     }
   }
   if (g > 0) {

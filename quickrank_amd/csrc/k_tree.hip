@@ -26,6 +26,8 @@
 //   k_valid_update: leaves, leaf outputs, score updates
 //   k_obl_fill / k_obl_level / k_obl_plan + k_partition_level / k_hist_level /
 //   k_reduce_level / k_scan_level: level-batched oblivious growth (ot.cc:32-201)
+//   k_decide_batch + k_partition_batch / k_hist_batch / k_redscan: leaf-wise growth on
+//   one GPU, up to QR_BATCH splits per step, reduce + scan in one launch
 #include <hip/hip_ext.h>
 
 #include <algorithm>

@@ -201,3 +201,26 @@ def test_config5_model_shape_vs_oracle(big, oracle_lib):
     full, _ = c.score(x)
     assert np.array_equal(full[:4096], want)
     c.close()
+
+
+def test_batched_growth_equals_one_split_per_step_at_full_size(big, monkeypatch):
+    """Two splits per step (k_decide_batch, feature-major partials, k_redscan) against the
+    one-split-per-step kernels the sharded layouts use: the two paths share only the
+    accumulation loop, and must build the same tree bit for bit."""
+    qr, c = big["qr"], big["c"]
+    c.reset_scores()
+    c.compute_lambdas("NDCG", 10)
+    lam, w = c.get_pseudo()
+    want = c.fit_tree(10, 1, True)
+    monkeypatch.setenv("QR_NO_BATCH", "1")
+    s = qr.Context(0)
+    monkeypatch.delenv("QR_NO_BATCH")
+    s.upload(big["x"], big["labels"], big["qoff"])
+    s.build_bins(255)
+    s.set_pseudo(lam, w)
+    got = s.fit_tree(10, 1, True)
+    for k in ("feature", "thr_id", "left", "right", "nsamples", "threshold"):
+        assert np.array_equal(got[k], want[k]), k
+    # set_pseudo derives the f64 node sums on the host: leaf values agree to rounding
+    assert np.allclose(got["value"], want["value"], rtol=1e-12, atol=1e-15)
+    s.close()

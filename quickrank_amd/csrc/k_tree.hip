@@ -25,7 +25,7 @@
 //   k_finish / k_leaf_sums / k_leaf_final (k_leaf_global) / k_score_update(_walk) /
 //   k_valid_update: leaves, leaf outputs, score updates
 //   k_obl_fill / k_obl_level / k_obl_plan + k_partition_level / k_hist_level /
-//   k_reduce_level / k_scan_level: level-batched oblivious growth (ot.cc:32-201)
+//   k_redscan_level: level-batched oblivious growth (ot.cc:32-201)
 //   k_decide_batch + k_partition_batch / k_hist_batch / k_redscan: leaf-wise growth on
 //   one GPU, up to QR_BATCH splits per step, reduce + scan in one launch
 #include <hip/hip_ext.h>
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(1024) void k_hist_level(
   const uint32_t m = map[blockIdx.x];
   const QrLevelNode &ln = ts->lnode[m >> 16];
   hist_body(hist, ln.small_begin, ln.small_n, ln.dst_buf, ln.q, (int)(m & 0xffffu), ln.slot_base,
-            blocks, nblocks, bins, order0, order1, lambda, scal->scale, partials);
+            blocks, nblocks, bins, order0, order1, lambda, scal->scale, partials, true);
 }
 
 // batched leaf-wise growth: the directly built children of the batch's nodes
@@ -431,19 +431,6 @@ __global__ __launch_bounds__(512) void k_reduce(
   const uint32_t q =
       qr_plan_quantum((unsigned long long)n * qr_plan_wsum(nblocks, blocks), G - nblocks);
   reduce_body(n, q, 0, blockIdx.x, blocks, nblocks, partials, red_sum, red_cnt, cs, red_cnt_loc);
-}
-
-// level-wise growth: grid (cell blocks, nodes of the level); per-node reduced
-// arrays of `cells_total` entries each
-__global__ __launch_bounds__(512) void k_reduce_level(
-    const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks, const int nblocks,
-    const u64 *__restrict__ partials, long long *__restrict__ red_sum,
-    uint32_t *__restrict__ red_cnt, const uint32_t cells_total) {
-  if (ts->obl_done || (int)blockIdx.y >= ts->l_nodes) return;
-  const QrLevelNode &ln = ts->lnode[blockIdx.y];
-  reduce_body(ln.small_n, ln.q, ln.slot_base, blockIdx.x, blocks, nblocks, partials,
-              red_sum + (size_t)blockIdx.y * cells_total, red_cnt + (size_t)blockIdx.y * cells_total,
-              1u, nullptr);
 }
 
 // ===========================================================================
@@ -655,6 +642,40 @@ __global__ __launch_bounds__(256) void k_scan(
             cs, red_cnt_loc, hcnt_loc, thr, featthr);
 }
 
+// Sum of one cell over the partial slots idx = g, g + 4, ... < total of a node of n
+// documents (feature-major slots, `src` points at the cell in slot 0).  Eight slots
+// per round: all eight requests leave before the first cell is used (unconditional
+// loads of clamped slots, so that no branch separates them).
+__device__ __forceinline__ void column_sum(const u64 *__restrict__ src, const int total,
+                                           const int kmax, const uint32_t per, const uint32_t n,
+                                           const int g, long long &s, uint32_t &cn) {
+  for (int base = g; base < total; base += 32) {
+    u64 cell[8];
+    bool ok[8];
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+      const int idx = base + 4 * k8;
+      bool valid = idx < total;
+      if (valid && kmax > 1) {  // workgroup j flushed only ceil(docs_j / QR_DPW) slots
+        const int j = idx / kmax, k = idx - j * kmax;
+        const uint32_t r0 = j * per;
+        const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
+        valid = r0 < n && k < (int)((r1 - r0 + QR_DPW - 1) / QR_DPW);
+      }
+      ok[k8] = valid;
+      cell[k8] = src[(size_t)(valid ? idx : 0) * (256u * 64u)];
+    }
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+      if (ok[k8]) {
+        const u64 cnt = (cell[k8] + (1ull << (QR_SB - 1))) >> QR_SB;
+        s += (long long)(cell[k8] - (cnt << QR_SB));
+        cn += (uint32_t)cnt;
+      }
+    }
+  }
+}
+
 // Batched leaf-wise growth: k_reduce and k_scan in one launch.  Grid = (features,
 // nodes of the batch), 1024 threads = 4 slot groups x 256 bins: the partial slots are
 // feature-major here (hist_run, tr), so a workgroup reads its column of every slot
@@ -718,33 +739,7 @@ __global__ __launch_bounds__(1024) void k_redscan(
   const u64 *src = partials + (size_t)d.slot0 * (256u * 64u) + d.col * 256u + t;
   long long s = 0;
   uint32_t cn = 0;
-  // eight slots per round: all eight requests leave before the first cell is used
-  // (unconditional loads of clamped slots, so that no branch separates them)
-  for (int base = (int)g; base < total; base += 32) {
-    u64 cell[8];
-    bool ok[8];
-#pragma unroll
-    for (int k8 = 0; k8 < 8; ++k8) {
-      const int idx = base + 4 * k8;
-      bool valid = idx < total;
-      if (valid && kmax > 1) {  // workgroup j flushed only ceil(docs_j / QR_DPW) slots
-        const int j = idx / kmax, k = idx - j * kmax;
-        const uint32_t r0 = j * per;
-        const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
-        valid = r0 < n && k < (int)((r1 - r0 + QR_DPW - 1) / QR_DPW);
-      }
-      ok[k8] = valid;
-      cell[k8] = src[(size_t)(valid ? idx : 0) * (256u * 64u)];
-    }
-#pragma unroll
-    for (int k8 = 0; k8 < 8; ++k8) {
-      if (ok[k8]) {
-        const u64 cnt = (cell[k8] + (1ull << (QR_SB - 1))) >> QR_SB;
-        s += (long long)(cell[k8] - (cnt << QR_SB));
-        cn += (uint32_t)cnt;
-      }
-    }
-  }
+  column_sum(src, total, kmax, per, n, (int)g, s, cn);
   if (g > 0) {
     cs_s[g - 1][t] = s;
     cs_c[g - 1][t] = cn;
@@ -761,35 +756,56 @@ __global__ __launch_bounds__(1024) void k_redscan(
             par_c);
 }
 
-// level-wise growth: prefix of the directly built child + sibling by subtraction
-// for every node of the level (grid = features x nodes); the gains are summed over
-// the level by k_obl_fill, not here
-__global__ __launch_bounds__(256) void k_scan_level(
+// Level-wise (oblivious) growth: sum of the workgroup partials, prefix of the directly
+// built child and sibling by subtraction for every node of the level, in one launch over
+// feature-major partials (see k_redscan): grid = (features, nodes of the level), 4 slot
+// groups x 256 bins; the gains are summed over the level by k_obl_fill, not here
+__global__ __launch_bounds__(1024) void k_redscan_level(
     const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks, const int nblocks,
-    const long long *__restrict__ red_sum, const uint32_t *__restrict__ red_cnt,
-    const uint32_t cells_total, long long *__restrict__ hsum, uint32_t *__restrict__ hcnt,
+    const u64 *__restrict__ partials, long long *__restrict__ hsum, uint32_t *__restrict__ hcnt,
     const int flocal) {
+  __shared__ long long cs_s[3][256];
+  __shared__ uint32_t cs_c[3][256];
   __shared__ long long sh_s[4];
   __shared__ uint32_t sh_c[4];
+  __shared__ QrPlan plan;
   if (ts->obl_done || (int)blockIdx.y >= ts->l_nodes) return;
   const QrLevelNode &ln = ts->lnode[blockIdx.y];
   if (!ln.active) return;
   const int lf = blockIdx.x;
-  int b = 0;
-  uint32_t base = 0, mybase = 0;
-  for (int i = 0; i < nblocks; ++i) {
-    if (lf >= blocks[i].lf0 && lf < blocks[i].lf0 + blocks[i].nreal) {
-      b = i;
-      mybase = base;
-    }
-    base += 256u * blocks[i].fw;
+  const uint32_t t = threadIdx.x & 255, g = threadIdx.x >> 8;
+  if (threadIdx.x == 0) qr_make_plan(ln.small_n, nblocks, blocks, ln.q, &plan);
+  const size_t pidx = ((size_t)ln.parent_slot * flocal + lf) * 256 + t;
+  long long par_s = 0;
+  uint32_t par_c = 0;
+  if (g == 0) {
+    par_s = hsum[pidx];
+    par_c = hcnt[pidx];
   }
-  const int col = lf - blocks[b].lf0;
-  const int fw = blocks[b].fw;
-  const uint32_t t = threadIdx.x;
-  const size_t roff = (size_t)blockIdx.y * cells_total + mybase + t * fw + col;
-  long long s = wave_scan_i64(red_sum[roff]);
-  uint32_t cn = wave_scan_u32(red_cnt[roff]);
+  __syncthreads();
+  int b = 0;
+  for (int i = 0; i < nblocks; ++i)
+    if (lf >= blocks[i].lf0 && lf < blocks[i].lf0 + blocks[i].nreal) b = i;
+  const uint32_t col = (uint32_t)(lf - blocks[b].lf0);
+  const int kmax = plan.kmax;
+  const int total = (plan.wg_start[b + 1] - plan.wg_start[b]) * kmax;
+  const u64 *src = partials + ((size_t)ln.slot_base + (size_t)plan.wg_start[b] * kmax) * (256u * 64u) +
+                   col * 256u + t;
+  long long s = 0;
+  uint32_t cn = 0;
+  column_sum(src, total, kmax, plan.per[b], ln.small_n, (int)g, s, cn);
+  if (g > 0) {
+    cs_s[g - 1][t] = s;
+    cs_c[g - 1][t] = cn;
+  }
+  __syncthreads();
+  if (g > 0) return;  // whole waves leave; the barrier below counts the remaining four
+  for (int i = 0; i < 3; ++i) {
+    s += cs_s[i][t];
+    cn += cs_c[i][t];
+  }
+  s = wave_scan_i64(s);
+  cn = wave_scan_u32(cn);
   const int lane = t & 63, wave = t >> 6;
   if (lane == 63) {
     sh_s[wave] = s;
@@ -801,12 +817,11 @@ __global__ __launch_bounds__(256) void k_scan_level(
     cn += sh_c[w];
   }
   const size_t hidx = ((size_t)ln.small_slot * flocal + lf) * 256 + t;
-  const size_t pidx = ((size_t)ln.parent_slot * flocal + lf) * 256 + t;
   const size_t bidx = ((size_t)ln.big_slot * flocal + lf) * 256 + t;
   hsum[hidx] = s;
   hcnt[hidx] = cn;
-  hsum[bidx] = hsum[pidx] - s;
-  hcnt[bidx] = hcnt[pidx] - cn;
+  hsum[bidx] = par_s - s;
+  hcnt[bidx] = par_c - cn;
 }
 
 // ===========================================================================
@@ -2711,8 +2726,6 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
   QR_CHECK(c, hipGetLastError());
   int rc = launch_hist_scan(c, 1);  // root histogram -> slot 0
   if (rc) return rc;
-  size_t cells = 0;
-  for (const auto &b : c->blocks) cells += (size_t)256 * b.fw;
   const size_t lds = hist_lds(c);
   const unsigned pgrid = (unsigned)c->lpart_cap, hgrid = (unsigned)c->lhist_cap;
   // every level: choose the split, plan the level, then ONE partition, ONE
@@ -2745,13 +2758,9 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
                        c->d_lhist_map, c->d_blocks, c->nblocks, c->d_bins, c->d_order[0],
                        c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_lpartials);
     QR_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_reduce_level, dim3((unsigned)(cells / 64), (unsigned)nodes), dim3(512), 0,
-                       c->stream, c->d_tree, c->d_blocks, c->nblocks, (const u64 *)c->d_lpartials,
-                       c->d_lred_sum, c->d_lred_cnt, (uint32_t)cells);
-    QR_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_scan_level, dim3(c->flocal, (unsigned)nodes), dim3(256), 0, c->stream,
-                       c->d_tree, c->d_blocks, c->nblocks, c->d_lred_sum, c->d_lred_cnt,
-                       (uint32_t)cells, c->d_hsum, c->d_hcnt, c->flocal);
+    hipLaunchKernelGGL(k_redscan_level, dim3(c->flocal, (unsigned)nodes), dim3(1024), 0, c->stream,
+                       c->d_tree, c->d_blocks, c->nblocks, (const u64 *)c->d_lpartials, c->d_hsum,
+                       c->d_hcnt, c->flocal);
     QR_CHECK(c, hipGetLastError());
   }
   return QR_OK;

@@ -96,7 +96,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
   dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_tree); dfree(c->d_leafpart);
   dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
-  dfree(c->d_lred_sum); dfree(c->d_lred_cnt); dfree(c->d_lpart_state);
+  dfree(c->d_lpart_state);
   dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
   c->lhist_cap = c->lpart_cap = c->lslots_cap = c->lred_nodes = 0;
   dfree(c->d_present); dfree(c->d_sample_keys); dfree(c->d_sample_count);
@@ -804,11 +804,8 @@ static int ensure_hist_slots(qr_ctx *c, size_t slots) {
 static int ensure_level_buffers(qr_ctx *c, size_t depth) {
   const size_t nodes = (size_t)1 << (depth - 1);
   if (nodes > QR_MAXLEVEL) QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
-  size_t cells = 0, wsum = 0;
-  for (const auto &b : c->blocks) {
-    cells += (size_t)256 * b.fw;
-    wsum += b.fw / 16;
-  }
+  size_t wsum = 0;
+  for (const auto &b : c->blocks) wsum += b.fw / 16;
   const size_t G = (size_t)c->ncu;
   const size_t hist_wgs = G + nodes * (size_t)(c->nblocks + 1);
   const size_t part_wgs = c->N / QR_PART_SLICE + nodes + 2;
@@ -820,7 +817,7 @@ static int ensure_level_buffers(qr_ctx *c, size_t depth) {
       nodes > c->lred_nodes) {
     QR_CHECK(c, hipStreamSynchronize(c->stream));
     dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
-    dfree(c->d_lred_sum); dfree(c->d_lred_cnt); dfree(c->d_lpart_state);
+    dfree(c->d_lpart_state);
     dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
     QR_CHECK(c, dalloc(&c->d_lhist_wg, hist_wgs));
     QR_CHECK(c, dalloc(&c->d_lpart_wg, part_wgs));
@@ -830,8 +827,6 @@ static int ensure_level_buffers(qr_ctx *c, size_t depth) {
     QR_CHECK(c, dalloc(&c->d_lpart_state, part_wgs));
     QR_CHECK(c, hipMemset(c->d_lpart_state, 0, part_wgs * 8));
     QR_CHECK(c, dalloc(&c->d_lpartials, slots * 256 * 64));
-    QR_CHECK(c, dalloc(&c->d_lred_sum, nodes * cells));
-    QR_CHECK(c, dalloc(&c->d_lred_cnt, nodes * cells));
     c->lhist_cap = hist_wgs;
     c->lpart_cap = part_wgs;
     c->lslots_cap = slots;

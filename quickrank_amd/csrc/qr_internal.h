@@ -353,8 +353,6 @@ struct qr_ctx {
   uint32_t *d_lhist_map = nullptr, *d_lpart_map = nullptr;
   size_t lhist_cap = 0, lpart_cap = 0, lslots_cap = 0, lred_nodes = 0;
   uint64_t *d_lpartials = nullptr;
-  long long *d_lred_sum = nullptr;
-  uint32_t *d_lred_cnt = nullptr;
   unsigned long long *d_lpart_state = nullptr;
   double *d_leafpart = nullptr;  // [slices][2] partial sums
   bool tree_valid = false;

@@ -24,7 +24,7 @@
 //                the prefix of its local counts, k_scan)
 //   k_finish / k_leaf_sums / k_leaf_final (k_leaf_global) / k_score_update(_walk) /
 //   k_valid_update: leaves, leaf outputs, score updates
-//   k_obl_fill / k_obl_level / k_obl_plan + k_partition_level / k_hist_level /
+//   k_obl_fill / k_obl_plan + k_partition_level / k_hist_level /
 //   k_redscan_level: level-batched oblivious growth (ot.cc:32-201)
 //   k_decide_batch + k_partition_batch / k_hist_batch / k_redscan: leaf-wise growth on
 //   one GPU, up to QR_BATCH splits per step, reduce + scan in one launch
@@ -2311,12 +2311,15 @@ __global__ __launch_bounds__(256) void k_obl_fill(
   }
 }
 
-// choose the level's (feature, slot): first maximum over features (ot.cc:84-95)
-__global__ __launch_bounds__(64) void k_obl_level(QrTreeState *__restrict__ ts,
-                                                  const int level, const uint32_t N,
-                                                  const qr_split_t *__restrict__ featrec,
-                                                  const int flocal,
-                                                  const QrScalars *__restrict__ scal) {
+// choose the level's (feature, slot): first maximum over features (ot.cc:84-95).
+// Run by the first wave of k_obl_plan; the choice goes out through `pick` (LDS) for
+// the rest of the workgroup: {done, feature, slot}.
+__device__ __forceinline__ void obl_level_body(QrTreeState *__restrict__ ts, const int level,
+                                               const uint32_t N,
+                                               const qr_split_t *__restrict__ featrec,
+                                               const int flocal,
+                                               const QrScalars *__restrict__ scal,
+                                               uint32_t *pick) {
   const int lane = threadIdx.x;
   if (level == 0 && lane == 0) {
     QrNode *root = &ts->nodes[0];
@@ -2335,7 +2338,12 @@ __global__ __launch_bounds__(64) void k_obl_level(QrTreeState *__restrict__ ts,
     ts->nsplits = 0;
     ts->desc.active = 0;
   }
-  if (ts->obl_done) return;
+  // (lane 0 wrote obl_done = 0 above at level 0; the others may still see the old value)
+  const int was_done = level == 0 ? 0 : ts->obl_done;
+  if (was_done) {
+    if (lane == 0) pick[0] = 1;
+    return;
+  }
   qr_split_t best;
   best.score = -1.0;
   best.feature = 0xFFFFFFFFu;
@@ -2358,8 +2366,12 @@ __global__ __launch_bounds__(64) void k_obl_level(QrTreeState *__restrict__ ts,
   ts->obl_level = level;
   if (best.feature == 0xFFFFFFFFu) {  // ot.cc:96: node is unsplittable
     ts->obl_done = 1;
+    pick[0] = 1;
     return;
   }
+  pick[0] = 0;
+  pick[1] = best.feature;
+  pick[2] = best.thr_id;
   ts->obl_f = best.feature;
   ts->obl_t = best.thr_id;
   ts->obl_score = best.score;
@@ -2378,13 +2390,17 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     QrTreeState *__restrict__ ts, const int level, const int last_level, const int G,
     const int flocal, const uint32_t *__restrict__ hcnt, const float *__restrict__ thr,
     const int32_t *__restrict__ gf2lf, const QrBlock *__restrict__ blocks, const int nblocks,
-    uint32_t *__restrict__ hist_map, uint32_t *__restrict__ part_map) {
+    uint32_t *__restrict__ hist_map, uint32_t *__restrict__ part_map, const uint32_t N,
+    const qr_split_t *__restrict__ featrec, const QrScalars *__restrict__ scal) {
   __shared__ uint32_t sh_a[QR_MAXLEVEL], sh_b[QR_MAXLEVEL], sh_c[QR_MAXLEVEL];
   __shared__ uint32_t tot_small;
-  if (ts->obl_done) return;
+  __shared__ uint32_t pick[3];
+  if (threadIdx.x < 64) obl_level_body(ts, level, N, featrec, flocal, scal, pick);
+  __syncthreads();
+  if (pick[0]) return;
   const int nodes = 1 << level;
   const int j = threadIdx.x;
-  const uint32_t f = ts->obl_f, t = ts->obl_t;
+  const uint32_t f = pick[1], t = pick[2];
   const int lf = gf2lf[f];
   QrLevelNode ln;
   ln.active = 0;
@@ -2737,13 +2753,11 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
                        c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf,
                        c->d_scalars, c->d_featrec);
     QR_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_obl_level, dim3(1), dim3(64), 0, c->stream, c->d_tree, level,
-                       (uint32_t)c->N, c->d_featrec, c->flocal, c->d_scalars);
-    QR_CHECK(c, hipGetLastError());
     const int last = level == (int)depth - 1;
     hipLaunchKernelGGL(k_obl_plan, dim3(1), dim3(256), 0, c->stream, c->d_tree, level, last,
                        c->ncu, c->flocal, c->d_hcnt, c->d_thr, c->d_gf2lf, c->d_blocks,
-                       c->nblocks, c->d_lhist_map, c->d_lpart_map);
+                       c->nblocks, c->d_lhist_map, c->d_lpart_map, (uint32_t)c->N, c->d_featrec,
+                       c->d_scalars);
     QR_CHECK(c, hipGetLastError());
     const unsigned pg = std::min<unsigned>(pgrid, (unsigned)(c->N / QR_PART_SLICE + nodes + 1));
     hipLaunchKernelGGL(k_partition_level, dim3(pg), dim3(256), 0, c->stream, c->d_tree,

@@ -689,7 +689,7 @@ __global__ __launch_bounds__(1024) void k_redscan(
     uint32_t *__restrict__ hcnt, const int flocal, const uint32_t *__restrict__ thr_size,
     const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
     qr_split_t *__restrict__ featrec, const float *__restrict__ thr,
-    float *__restrict__ featthr, const QrScanWg *__restrict__ descs) {
+    float *__restrict__ featthr, const QrScanWg *__restrict__ descs, const u64 minls) {
   __shared__ long long cs_s[3][256];
   __shared__ uint32_t cs_c[3][256];
   __shared__ QrPlan sh_plan;
@@ -703,7 +703,6 @@ __global__ __launch_bounds__(1024) void k_redscan(
     if (!d.active) return;
   }
   const float my_thr = thr[(size_t)lf2gf[lf] * QR_MAX_BINS + t];
-  const u64 minls = ts->minls;
   if (root) {
     if (threadIdx.x == 0)
       qr_make_plan(rootn, nblocks, blocks,
@@ -1497,7 +1496,8 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
 // used: the launch is one link of the per-step chain, and a dependent global round
 // trip costs it ~1 us.
 __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
-    QrTreeState *ts, const int root_mode, const int stage_nodes, const uint32_t N, const int flocal,
+    QrTreeState *ts, const int root_mode, const int nleaves_arg, const u64 minls_arg,
+    const int stage_nodes, const uint32_t N, const int flocal,
     const QrScalars *__restrict__ scal, const double *__restrict__ part_ss,
     const qr_split_t *__restrict__ featrec, const float *__restrict__ featthr, const uint32_t F,
     const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
@@ -1520,7 +1520,8 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   const bool staged = stage_nodes > 0;
   // ---- requests: header, the previous batch's descriptors, node records, heap
   const int njobs_raw = ts->l_nodes;
-  const int32_t h_nleaves_req = ts->nleaves_req, h_nnodes = ts->nnodes, h_taken = ts->taken,
+  // (the first call of a tree starts from its arguments, not from what the last tree left)
+  const int32_t h_nleaves_req = root_mode ? nleaves_arg : ts->nleaves_req, h_nnodes = ts->nnodes, h_taken = ts->taken,
                 h_done = ts->done, h_step = ts->step, h_nsplits = ts->nsplits,
                 h_heap_size = ts->heap_size, h_next_prov = ts->next_prov,
                 h_next_slot = ts->next_slot, h_spec_made = ts->spec_made,
@@ -1631,6 +1632,12 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     sh_nj = nj;
     sh_hi = bs.next_prov;
     sh_hs = st.heap_size;
+    if (root_mode) {  // what k_tree_reset does for the one-split-per-step path
+      ts->nleaves_req = nleaves_arg;
+      ts->minls = minls_arg;
+      ts->desc.active = 0;
+      ts->nleaves = 0;
+    }
     ts->l_nodes = nj;
     ts->nnodes = st.nnodes;
     ts->taken = st.taken;
@@ -2592,7 +2599,7 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
     hipLaunchKernelGGL(k_redscan, dim3(c->flocal, 1), dim3(1024), 0, c->stream, c->d_tree, 1, rootn,
                        c->d_lplan, c->d_blocks, c->nblocks, G, (const u64 *)c->d_partials, c->d_hsum,
                        c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec,
-                       c->d_thr, c->d_featthr, (const QrScanWg *)nullptr);
+                       c->d_thr, c->d_featthr, (const QrScanWg *)nullptr, (u64)c->cur_minls);
     QR_CHECK(c, hipGetLastError());
     return QR_OK;
   }
@@ -2698,9 +2705,8 @@ int qr_k_tree_apply(qr_ctx *c) {
 int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
   c->tree_step = 0;
   c->tree_counter += 0x9E3779B97F4A7C15ull;
-  hipLaunchKernelGGL(k_tree_reset, dim3(1), dim3(64), 0, c->stream, c->d_tree, (int)nleaves,
-                     (u64)minls);
-  QR_CHECK(c, hipGetLastError());
+  c->cur_minls = minls;
+  // (no reset launch: the first k_decide_batch call starts from its arguments)
   int rc = launch_hist_scan(c, 1, true);  // root histogram -> slot 0, records -> featrec[0]
   if (rc) return rc;
   const size_t lds = hist_lds(c);
@@ -2712,7 +2718,8 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
   const int stage_nodes = 4 * nleaves + 1 <= QR_DECIDE_LDS_NODES ? (int)(4 * nleaves + 1) : 0;
   for (size_t s = 0; s < nleaves; ++s) {
     hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(128 * QR_BATCH), 0, c->stream, c->d_tree,
-                       s == 0 ? 1 : 0, stage_nodes, rootn, c->flocal, c->d_scalars, c->d_lpart_ss,
+                       s == 0 ? 1 : 0, (int)nleaves, (u64)minls, stage_nodes, rootn, c->flocal,
+                       c->d_scalars, c->d_lpart_ss,
                        c->d_featrec, c->d_featthr, (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu,
                        c->d_blocks, c->nblocks, c->d_lhist_wg, hg, c->d_lpart_wg, pg, c->d_lplan,
                        c->d_lscan_wg);
@@ -2729,7 +2736,7 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
     hipLaunchKernelGGL(k_redscan, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_tree, 0,
                        rootn, c->d_lplan, c->d_blocks, c->nblocks, c->ncu, (const u64 *)c->d_lpartials,
                        c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars,
-                       c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg);
+                       c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg, (u64)minls);
     QR_CHECK(c, hipGetLastError());
   }
   return QR_OK;

@@ -338,6 +338,7 @@ struct qr_ctx {
   uint32_t *d_mask = nullptr;
   size_t mask_words = 0;
   float *d_featthr = nullptr;         // threshold value of every per-feature best record
+  uint64_t cur_minls = 1;             // min leaf support of the tree being fitted (batched growth)
   double *d_lpart_ss = nullptr;       // batched growth: child sums per partition workgroup
   QrHistWg *d_lhist_wg = nullptr;     // ... per-workgroup shares of the step's launches
   QrPartWg *d_lpart_wg = nullptr;

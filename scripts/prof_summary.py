@@ -12,7 +12,8 @@ for r in rows:
           f"{float(r['AverageNs'])/1e3:.2f} | {int(r['MinNs'])/1e3:.2f} | {int(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |")
 tr = list(csv.DictReader(open(f"{d}/{pre}_kernel_trace.csv")))
 tr.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(tr) if r["Kernel_Name"].startswith("k_tree_reset")]
+# one iteration = from one lambda kernel to the next (the first launch of a boosting iteration)
+idx = [i for i, r in enumerate(tr) if "k_lambda" in r["Kernel_Name"] or r["Kernel_Name"].startswith("k_residual")]
 if len(idx) >= 3:
     a, b = idx[-3], idx[-2]
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr[a:b])

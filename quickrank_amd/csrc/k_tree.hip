@@ -924,6 +924,7 @@ struct DecideState {
   QrNode *nodes;
   QrSplitDesc *desc;
   qr_split_t *split_log;
+  qr_split_t *split_log2;  // batched growth: second copy of the tree state (or null)
   // document-sharded only: this rank's cumulative counts and where to put the
   // local view of the split
   const uint32_t *hcnt_loc;
@@ -1170,6 +1171,7 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
   st.heap_size = ts->heap_size;
   st.part_epoch = ts->part_epoch;
   st.split_log = ts->split_log;
+  st.split_log2 = nullptr;
   st.hcnt_loc = docmode ? hcnt_loc : nullptr;
   st.loc = &ts->loc;
   st.flocal = flocal;
@@ -1310,12 +1312,15 @@ __device__ __forceinline__ void batch_commit(DecideState &st, int node, int li, 
   nd->threshold = nd->best_thr;
   nd->left = li;
   nd->right = ri;
-  qr_split_t *lg = &st.split_log[st.nsplits++];
-  lg->score = nd->best_score;
-  lg->feature = nd->best_f;
-  lg->thr_id = nd->best_t;
-  lg->lcount = nd->best_lc;
-  lg->rcount = nd->best_rc;
+  qr_split_t lg;
+  lg.score = nd->best_score;
+  lg.feature = nd->best_f;
+  lg.thr_id = nd->best_t;
+  lg.lcount = nd->best_lc;
+  lg.rcount = nd->best_rc;
+  if (st.split_log) st.split_log[st.nsplits] = lg;
+  if (st.split_log2) st.split_log2[st.nsplits] = lg;
+  ++st.nsplits;
 }
 
 // what the control lane carries besides DecideState
@@ -1490,27 +1495,42 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
   return nj;
 }
 
-// One workgroup; `root` = first call of a tree; `stage_nodes` > 0: the node records
-// [0, stage_nodes) and the heap fit the LDS copies (host: 4 * nleaves + 1 <= 96).
-// Everything the kernel needs from memory is requested up front, before any of it is
-// used: the launch is one link of the per-step chain, and a dependent global round
-// trip costs it ~1 us.
-__global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
-    QrTreeState *ts, const int root_mode, const int nleaves_arg, const u64 minls_arg,
+// The control step of a batch, run by one workgroup of 128 * QR_BATCH threads.
+// `root_mode` = first call of a tree; `stage_nodes` > 0: the node records [0,
+// stage_nodes) and the heap fit the LDS copies (host: 4 * nleaves + 1 <= 96).
+// Everything the step needs from memory is requested up front, before any of it is
+// used: it is one link of the per-step chain, and a dependent global round trip costs
+// it ~1 us.
+//   FUSED = false (k_decide_batch): the state is updated in place (tin == tout).
+//   FUSED = true (k_decide_part): EVERY workgroup of the partition launch runs the
+//   step redundantly on its own LDS copy (the step is deterministic) and then
+//   partitions its slice, which saves the launch boundary between the two; only
+//   the `writer` workgroup publishes the new state -- into `tout`, a second copy of
+//   the tree state, because the others may still be reading `tin` (the split log,
+//   append-only, goes to both copies: `tlog2`).  Needs the staged mode; the epoch of
+//   the partition's look-back granules comes from the host (`epoch_arg`).
+// Out (LDS, for the caller): sh_next / sh_pw0 / sh_njp = the new batch's nodes, the
+// prefix of their partition workgroups, their number; sh_epoch.
+template <bool FUSED>
+__device__ __forceinline__ void batch_step(
+    const QrTreeState *tin, QrTreeState *tout, QrTreeState *tlog2, const bool writer,
+    const uint32_t epoch_arg, QrLevelNode *sh_next, uint32_t *sh_pw0, int *sh_njp,
+    uint32_t *sh_epoch, const int root_mode, const int nleaves_arg, const u64 minls_arg,
     const int stage_nodes, const uint32_t N, const int flocal,
     const QrScalars *__restrict__ scal, const double *__restrict__ part_ss,
     const qr_split_t *__restrict__ featrec, const float *__restrict__ featthr, const uint32_t F,
     const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
     QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
     const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg) {
+  QrTreeState *const ts = tout;  // where the writer publishes
   __shared__ QrPlan sh_plan[QR_BATCH];
   __shared__ qr_split_t own[2 * QR_BATCH];
   __shared__ double sh_sum[QR_BATCH], sh_ss[QR_BATCH];
-  __shared__ uint32_t sh_hw0[QR_BATCH + 1], sh_pw0[QR_BATCH + 1], sh_q;
+  __shared__ uint32_t sh_hw0[QR_BATCH + 1], sh_q;
   __shared__ int sh_nj, sh_hi, sh_hs;
   __shared__ QrNode sh_nodes[QR_DECIDE_LDS_NODES];
   __shared__ QrHeapItem sh_heap[QR_DECIDE_LDS_NODES + 2];
-  __shared__ QrLevelNode sh_prev[QR_BATCH], sh_next[QR_BATCH];
+  __shared__ QrLevelNode sh_prev[QR_BATCH];
   __shared__ int32_t own_lf[2 * QR_BATCH];
   __shared__ float own_thr[2 * QR_BATCH];
   __shared__ QrBlock sh_blk[QR_MAXBLK];
@@ -1519,27 +1539,27 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool staged = stage_nodes > 0;
   // ---- requests: header, the previous batch's descriptors, node records, heap
-  const int njobs_raw = ts->l_nodes;
+  const int njobs_raw = tin->l_nodes;
   // (the first call of a tree starts from its arguments, not from what the last tree left)
-  const int32_t h_nleaves_req = root_mode ? nleaves_arg : ts->nleaves_req, h_nnodes = ts->nnodes, h_taken = ts->taken,
-                h_done = ts->done, h_step = ts->step, h_nsplits = ts->nsplits,
-                h_heap_size = ts->heap_size, h_next_prov = ts->next_prov,
-                h_next_slot = ts->next_slot, h_spec_made = ts->spec_made,
-                h_spec_used = ts->spec_used;
-  const uint32_t h_part_epoch = ts->part_epoch;
-  const QrLevelNode myln = ts->lnode[wave < QR_BATCH ? wave : 0];
+  const int32_t h_nleaves_req = root_mode ? nleaves_arg : tin->nleaves_req, h_nnodes = tin->nnodes, h_taken = tin->taken,
+                h_done = tin->done, h_step = tin->step, h_nsplits = tin->nsplits,
+                h_heap_size = tin->heap_size, h_next_prov = tin->next_prov,
+                h_next_slot = tin->next_slot, h_spec_made = tin->spec_made,
+                h_spec_used = tin->spec_used;
+  const uint32_t h_part_epoch = tin->part_epoch;
+  const QrLevelNode myln = tin->lnode[wave < QR_BATCH ? wave : 0];
   u64 v[8];
   u64 h0 = 0;
   const size_t nw = staged && !root_mode ? (size_t)stage_nodes * sizeof(QrNode) / 8 : 0;
   const size_t nh = staged && !root_mode ? (size_t)(stage_nodes + 2) * sizeof(QrHeapItem) / 8 : 0;
   {
-    const u64 *src = reinterpret_cast<const u64 *>(ts->nodes);
+    const u64 *src = reinterpret_cast<const u64 *>(tin->nodes);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const size_t i = threadIdx.x + (size_t)k * blockDim.x;
       v[k] = i < nw ? src[i] : 0;
     }
-    const u64 *hs = reinterpret_cast<const u64 *>(ts->heap);
+    const u64 *hs = reinterpret_cast<const u64 *>(tin->heap);
     h0 = threadIdx.x < nh ? hs[threadIdx.x] : 0;
   }
   // wave 2j + which: the per-feature records of job j's left / right child (stale
@@ -1598,7 +1618,8 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     st.nsplits = h_nsplits;
     st.heap_size = h_heap_size;
     st.part_epoch = h_part_epoch;
-    st.split_log = ts->split_log;
+    st.split_log = writer ? ts->split_log : nullptr;
+    st.split_log2 = (writer && tlog2) ? tlog2->split_log : nullptr;
     st.desc = &ts->desc;
     st.hcnt_loc = nullptr;
     st.loc = &ts->loc;
@@ -1629,30 +1650,47 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
                              spare > G / 4 ? spare : G / 4);
       st.part_epoch++;
     }
+    {  // the partition workgroups of the batch's nodes
+      uint32_t pw0 = 0;
+      for (int j = 0; j < nj; ++j) {
+        sh_next[j].part_first = pw0;
+        sh_pw0[j] = pw0;
+        pw0 += (sh_next[j].end - sh_next[j].begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
+      }
+      sh_pw0[nj] = pw0;
+    }
     sh_nj = nj;
+    *sh_njp = nj;
+    *sh_epoch = FUSED ? epoch_arg : st.part_epoch;
     sh_hi = bs.next_prov;
     sh_hs = st.heap_size;
-    if (root_mode) {  // what k_tree_reset does for the one-split-per-step path
-      ts->nleaves_req = nleaves_arg;
-      ts->minls = minls_arg;
-      ts->desc.active = 0;
-      ts->nleaves = 0;
+    if (writer) {
+      if (root_mode) {  // what k_tree_reset does for the one-split-per-step path
+        ts->nleaves_req = nleaves_arg;
+        ts->minls = minls_arg;
+        ts->desc.active = 0;
+        ts->nleaves = 0;
+      } else if (FUSED) {
+        ts->nleaves_req = h_nleaves_req;
+      }
+      ts->l_nodes = nj;
+      ts->nnodes = st.nnodes;
+      ts->taken = st.taken;
+      ts->done = st.done;
+      ts->step = st.step;
+      ts->nsplits = st.nsplits;
+      ts->heap_size = st.heap_size;
+      ts->part_epoch = st.part_epoch;
+      ts->next_prov = bs.next_prov;
+      ts->next_slot = bs.next_slot;
+      ts->spec_made = bs.spec_made;
+      ts->spec_used = bs.spec_used;
+      ts->l_part_wgs = sh_pw0[nj];
     }
-    ts->l_nodes = nj;
-    ts->nnodes = st.nnodes;
-    ts->taken = st.taken;
-    ts->done = st.done;
-    ts->step = st.step;
-    ts->nsplits = st.nsplits;
-    ts->heap_size = st.heap_size;
-    ts->part_epoch = st.part_epoch;
-    ts->next_prov = bs.next_prov;
-    ts->next_slot = bs.next_slot;
-    ts->spec_made = bs.spec_made;
-    ts->spec_used = bs.spec_used;
   }
   __syncthreads();
   const int nj = sh_nj;
+  if (!writer) return;  // (workgroup-uniform) the rest publishes the new state
   // the plans of the batch's nodes, one lane each
   if (lane == 0 && wave < nj) qr_make_plan(sh_next[wave].small_n, nblocks, sh_blk, sh_q, &sh_plan[wave]);
   if (staged) {  // (while they compute: the node records and the heap go back)
@@ -1666,23 +1704,18 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t hw0 = 0, slot0 = 0, pw0 = 0;
+    uint32_t hw0 = 0, slot0 = 0;
     for (int j = 0; j < nj; ++j) {
       QrLevelNode *ln = &sh_next[j];
       const uint32_t hw = (uint32_t)sh_plan[j].wg_start[nblocks];
       ln->q = sh_q;
       ln->slot_base = slot0;
-      ln->part_first = pw0;
       sh_hw0[j] = hw0;
-      sh_pw0[j] = pw0;
       hw0 += hw;
       slot0 += hw * (uint32_t)sh_plan[j].kmax;
-      pw0 += (ln->end - ln->begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
     }
     sh_hw0[nj] = hw0;
-    sh_pw0[nj] = pw0;
     ts->l_hist_wgs = hw0;
-    ts->l_part_wgs = pw0;
   }
   __syncthreads();
   // the descriptors and plans (k_redscan reads them) and every
@@ -1748,6 +1781,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     }
     scan_wg[x] = d;
   }
+  if (!FUSED)
   for (uint32_t w = threadIdx.x; w < part_grid; w += blockDim.x) {
     QrPartWg d;
     d.begin = d.n = d.lcount = d.first = d.w = 0;
@@ -1771,6 +1805,25 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     }
     part_wg[w] = d;
   }
+}
+
+__global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
+    QrTreeState *ts, const int root_mode, const int nleaves_arg, const u64 minls_arg,
+    const int stage_nodes, const uint32_t N, const int flocal,
+    const QrScalars *__restrict__ scal, const double *__restrict__ part_ss,
+    const qr_split_t *__restrict__ featrec, const float *__restrict__ featthr, const uint32_t F,
+    const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
+    QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
+    const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
+    const QrTreeState *tin) {
+  __shared__ QrLevelNode sh_next[QR_BATCH];
+  __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
+  __shared__ int sh_nj;
+  // (tin != ts: the last call of a tree grown by k_decide_part, whose state ping-pongs)
+  batch_step<false>(tin ? tin : ts, ts, nullptr, true, 0u, sh_next, sh_pw0, &sh_nj, &sh_epoch,
+                    root_mode, nleaves_arg, minls_arg, stage_nodes, N, flocal, scal, part_ss, featrec,
+                    featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, part_wg, part_grid,
+                    plans, scan_wg);
 }
 
 // ===========================================================================
@@ -2722,7 +2775,7 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
                        c->d_scalars, c->d_lpart_ss,
                        c->d_featrec, c->d_featthr, (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu,
                        c->d_blocks, c->nblocks, c->d_lhist_wg, hg, c->d_lpart_wg, pg, c->d_lplan,
-                       c->d_lscan_wg);
+                       c->d_lscan_wg, (const QrTreeState *)nullptr);
     QR_CHECK(c, hipGetLastError());
     if (s + 1 == nleaves) break;  // the last call only accounts for the last batch
     hipLaunchKernelGGL(k_partition_batch, dim3(pg), dim3(256), 0, c->stream, c->d_tree,

@@ -2041,6 +2041,47 @@ __global__ __launch_bounds__(256) void k_partition_batch(
                  lambda, part_ss);
 }
 
+// The control step and the partition in one launch (batch_step<true>): every
+// workgroup decides for itself, workgroup 0 publishes, all of them partition.
+static_assert(128 * QR_BATCH == 256, "k_decide_part partitions with 256 threads per workgroup");
+__global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
+    const QrTreeState *tin, QrTreeState *tout, QrTreeState *tlog2, const uint32_t epoch,
+    const int root_mode, const int nleaves_arg, const u64 minls_arg, const int stage_nodes,
+    const uint32_t N, const int flocal, const QrScalars *__restrict__ scal,
+    const double *__restrict__ part_ss_in, const qr_split_t *__restrict__ featrec,
+    const float *__restrict__ featthr, const uint32_t F, const int root_buf, const int G,
+    const QrBlock *__restrict__ blocks, const int nblocks, QrHistWg *__restrict__ hist_wg,
+    const uint32_t hist_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
+    const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
+    uint32_t *__restrict__ order1, u64 *__restrict__ state, const double *__restrict__ lambda,
+    double *__restrict__ part_ss_out) {
+  __shared__ QrLevelNode sh_next[QR_BATCH];
+  __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
+  __shared__ int sh_nj;
+  batch_step<true>(tin, tout, tlog2, blockIdx.x == 0, epoch, sh_next, sh_pw0, &sh_nj, &sh_epoch,
+                   root_mode, nleaves_arg, minls_arg, stage_nodes, N, flocal, scal, part_ss_in, featrec,
+                   featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, nullptr, 0u, plans,
+                   scan_wg);
+  __syncthreads();  // (the writer comes back later than the others; sh_* are final for all)
+  const int nj = sh_nj;
+  if (blockIdx.x >= sh_pw0[nj]) return;
+  int j = 0;
+  while (j + 1 < nj && blockIdx.x >= sh_pw0[j + 1]) ++j;
+  const QrLevelNode &ln = sh_next[j];
+  PartNode pn;
+  pn.begin = ln.begin;
+  pn.n = ln.end - ln.begin;
+  pn.lcount = ln.lcount;
+  pn.src_buf = ln.src_buf;
+  pn.dst_buf = ln.dst_buf;
+  pn.small_is_left = ln.small_is_left;
+  QrSplitDesc gl;
+  gl.owner_local = ln.owner_local;
+  gl.thr_id = ln.thr_id;
+  partition_body(pn, gl, blockIdx.x - sh_pw0[j], sh_pw0[j], (u64)sh_epoch, fm, Nfm, order0, order1,
+                 nullptr, 0, state, lambda, part_ss_out);
+}
+
 // ===========================================================================
 // Tree end: leaves, leaf outputs, score update
 // ===========================================================================
@@ -2769,19 +2810,39 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
   const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);
   // final ids [0, 2 nleaves + 1) + provisional ones [.., 4 nleaves + 1)
   const int stage_nodes = 4 * nleaves + 1 <= QR_DECIDE_LDS_NODES ? (int)(4 * nleaves + 1) : 0;
+  // Staged trees: the control step runs inside the partition launch (k_decide_part) and
+  // the tree state ping-pongs between two copies, arranged so that the last call
+  // (control step only: it accounts for the last batch) writes c->d_tree.
+  const bool fused = stage_nodes > 0 && c->d_tree2 != nullptr;
+  QrTreeState *const T[2] = {c->d_tree, c->d_tree2};
+  double *const PSS[2] = {c->d_lpart_ss, c->d_lpart_ss2};
   for (size_t s = 0; s < nleaves; ++s) {
-    hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(128 * QR_BATCH), 0, c->stream, c->d_tree,
-                       s == 0 ? 1 : 0, (int)nleaves, (u64)minls, stage_nodes, rootn, c->flocal,
-                       c->d_scalars, c->d_lpart_ss,
-                       c->d_featrec, c->d_featthr, (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu,
-                       c->d_blocks, c->nblocks, c->d_lhist_wg, hg, c->d_lpart_wg, pg, c->d_lplan,
-                       c->d_lscan_wg, (const QrTreeState *)nullptr);
-    QR_CHECK(c, hipGetLastError());
-    if (s + 1 == nleaves) break;  // the last call only accounts for the last batch
-    hipLaunchKernelGGL(k_partition_batch, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_lpart_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
-                       (u64 *)c->d_lpart_state, c->d_lambda, c->d_lpart_ss);
-    QR_CHECK(c, hipGetLastError());
+    QrTreeState *tout = fused ? T[(nleaves - 1 - s) & 1] : c->d_tree;
+    QrTreeState *tin = fused ? T[(nleaves - s) & 1] : c->d_tree;  // what call s - 1 wrote
+    const double *pss_in = fused ? PSS[(s + 1) & 1] : c->d_lpart_ss;
+    if (!fused || s + 1 == nleaves) {
+      hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(128 * QR_BATCH), 0, c->stream, tout,
+                         s == 0 ? 1 : 0, (int)nleaves, (u64)minls, stage_nodes, rootn, c->flocal,
+                         c->d_scalars, pss_in, c->d_featrec, c->d_featthr, (uint32_t)c->F,
+                         c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, hg,
+                         c->d_lpart_wg, pg, c->d_lplan, c->d_lscan_wg,
+                         fused ? (const QrTreeState *)tin : (const QrTreeState *)nullptr);
+      QR_CHECK(c, hipGetLastError());
+      if (s + 1 == nleaves) break;  // the last call only accounts for the last batch
+      hipLaunchKernelGGL(k_partition_batch, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
+                         c->d_lpart_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
+                         (u64 *)c->d_lpart_state, c->d_lambda, c->d_lpart_ss);
+      QR_CHECK(c, hipGetLastError());
+    } else {
+      hipLaunchKernelGGL(k_decide_part, dim3(pg), dim3(128 * QR_BATCH), 0, c->stream,
+                         (const QrTreeState *)tin, tout, T[(nleaves - s) & 1], ++c->bepoch,
+                         s == 0 ? 1 : 0, (int)nleaves, (u64)minls, stage_nodes, rootn, c->flocal,
+                         c->d_scalars, pss_in, c->d_featrec, c->d_featthr, (uint32_t)c->F,
+                         c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, hg,
+                         c->d_lplan, c->d_lscan_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0],
+                         c->d_order[1], (u64 *)c->d_bpart_state, c->d_lambda, PSS[s & 1]);
+      QR_CHECK(c, hipGetLastError());
+    }
     hipLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, c->d_lhist_wg,
                        c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
                        c->d_scalars, (u64 *)c->d_lpartials);

@@ -94,7 +94,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_red_sum); dfree(c->d_red_cnt);
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec); dfree(c->d_featthr); dfree(c->d_lscan_wg);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
-  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_tree); dfree(c->d_leafpart);
+  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_lpart_ss2); dfree(c->d_bpart_state); dfree(c->d_tree); dfree(c->d_tree2); dfree(c->d_leafpart);
   dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
   dfree(c->d_lpart_state);
   dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
@@ -495,6 +495,10 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, dalloc(&c->d_lscan_wg, QR_BATCH * (size_t)c->flocal));
   QR_CHECK(c, hipMemset(c->d_lscan_wg, 0, QR_BATCH * (size_t)c->flocal * sizeof(QrScanWg)));
   QR_CHECK(c, dalloc(&c->d_lpart_ss, 2 * (N / QR_PART_SLICE + QR_BATCH + 2)));
+  QR_CHECK(c, dalloc(&c->d_lpart_ss2, 2 * (N / QR_PART_SLICE + QR_BATCH + 2)));
+  QR_CHECK(c, dalloc(&c->d_bpart_state, N / QR_PART_SLICE + QR_BATCH + 2));
+  QR_CHECK(c, hipMemset(c->d_bpart_state, 0, (N / QR_PART_SLICE + QR_BATCH + 2) * 8));
+  c->bepoch = 0;
   QR_CHECK(c, dalloc(&c->d_recs_local, (size_t)2));
   QR_CHECK(c, dalloc(&c->d_recs_all, 2 * (size_t)c->world));
   c->mask_words = (N + 31) / 32;
@@ -504,6 +508,8 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, dalloc(&c->d_part_ss, 2 * (N / QR_PART_SLICE + 2)));
   QR_CHECK(c, dalloc(&c->d_tree, (size_t)1));
   QR_CHECK(c, hipMemset(c->d_tree, 0, sizeof(QrTreeState)));
+  QR_CHECK(c, dalloc(&c->d_tree2, (size_t)1));
+  QR_CHECK(c, hipMemset(c->d_tree2, 0, sizeof(QrTreeState)));
   QR_CHECK(c, dalloc(&c->d_leafpart, 2 * (N / QR_SLICE + QR_MAXNODES + 4)));
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   c->binned = true;

@@ -340,6 +340,10 @@ struct qr_ctx {
   float *d_featthr = nullptr;         // threshold value of every per-feature best record
   uint64_t cur_minls = 1;             // min leaf support of the tree being fitted (batched growth)
   double *d_lpart_ss = nullptr;       // batched growth: child sums per partition workgroup
+  double *d_lpart_ss2 = nullptr;      // ... second copy (k_decide_part reads one, writes the other)
+  QrTreeState *d_tree2 = nullptr;     // ... second copy of the tree state (same reason)
+  unsigned long long *d_bpart_state = nullptr;  // ... look-back granules of k_decide_part
+  uint32_t bepoch = 0;                // ... their epoch, counted on the host
   QrHistWg *d_lhist_wg = nullptr;     // ... per-workgroup shares of the step's launches
   QrPartWg *d_lpart_wg = nullptr;
   QrScanWg *d_lscan_wg = nullptr;     // ... [QR_BATCH][flocal]

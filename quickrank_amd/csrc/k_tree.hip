@@ -26,8 +26,9 @@
 //   k_valid_update: leaves, leaf outputs, score updates
 //   k_obl_fill / k_obl_plan + k_partition_level / k_hist_level /
 //   k_redscan_level: level-batched oblivious growth (ot.cc:32-201)
-//   k_decide_batch + k_partition_batch / k_hist_batch / k_redscan: leaf-wise growth on
-//   one GPU, up to QR_BATCH splits per step, reduce + scan in one launch
+//   k_decide_part (k_decide_batch + k_partition_batch for larger trees) / k_hist_batch /
+//   k_redscan: leaf-wise growth on one GPU, up to QR_BATCH splits per step; control step
+//   and partition in one launch, reduce and scan in one launch
 #include <hip/hip_ext.h>
 
 #include <algorithm>

@@ -1512,7 +1512,12 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
 //   the partition's look-back granules comes from the host (`epoch_arg`).
 // Out (LDS, for the caller): sh_next / sh_pw0 / sh_njp = the new batch's nodes, the
 // prefix of their partition workgroups, their number; sh_epoch.
-template <bool FUSED>
+// CAP = node records the LDS copy holds: 96 (trees of up to 22 leaves: 4 L + 1 final
+// and provisional ids + what a step can add) or 264 (up to 64 leaves) -- two
+// instantiations, because the larger footprint costs the small trees ~7 us per iteration
+#define QR_BATCH_LDS_SMALL 96
+#define QR_BATCH_LDS_LARGE 264
+template <bool FUSED, int CAP>
 __device__ __forceinline__ void batch_step(
     const QrTreeState *tin, QrTreeState *tout, QrTreeState *tlog2, const bool writer,
     const uint32_t epoch_arg, QrLevelNode *sh_next, uint32_t *sh_pw0, int *sh_njp,
@@ -1529,14 +1534,15 @@ __device__ __forceinline__ void batch_step(
   __shared__ double sh_sum[QR_BATCH], sh_ss[QR_BATCH];
   __shared__ uint32_t sh_hw0[QR_BATCH + 1], sh_q;
   __shared__ int sh_nj, sh_hi, sh_hs;
-  __shared__ QrNode sh_nodes[QR_DECIDE_LDS_NODES];
-  __shared__ QrHeapItem sh_heap[QR_DECIDE_LDS_NODES + 2];
+  __shared__ QrNode sh_nodes[CAP];
+  __shared__ QrHeapItem sh_heap[CAP + 2];
   __shared__ QrLevelNode sh_prev[QR_BATCH];
   __shared__ int32_t own_lf[2 * QR_BATCH];
   __shared__ float own_thr[2 * QR_BATCH];
   __shared__ QrBlock sh_blk[QR_MAXBLK];
   static_assert(sizeof(QrLevelNode) % 4 == 0, "copied as 4-byte words");
-  static_assert(QR_DECIDE_LDS_NODES * sizeof(QrNode) / 8 <= 8 * 128 * QR_BATCH, "staging copy unroll");
+  constexpr int NV = (int)((CAP * sizeof(QrNode) / 8 + 128 * QR_BATCH - 1) / (128 * QR_BATCH));
+  constexpr int NH = (int)(((CAP + 2) * sizeof(QrHeapItem) / 8 + 128 * QR_BATCH - 1) / (128 * QR_BATCH));
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool staged = stage_nodes > 0;
   // ---- requests: header, the previous batch's descriptors, node records, heap
@@ -1549,19 +1555,23 @@ __device__ __forceinline__ void batch_step(
                 h_spec_used = tin->spec_used;
   const uint32_t h_part_epoch = tin->part_epoch;
   const QrLevelNode myln = tin->lnode[wave < QR_BATCH ? wave : 0];
-  u64 v[8];
-  u64 h0 = 0;
+  u64 v[NV];
+  u64 hv[NH];
   const size_t nw = staged && !root_mode ? (size_t)stage_nodes * sizeof(QrNode) / 8 : 0;
   const size_t nh = staged && !root_mode ? (size_t)(stage_nodes + 2) * sizeof(QrHeapItem) / 8 : 0;
   {
     const u64 *src = reinterpret_cast<const u64 *>(tin->nodes);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const size_t i = threadIdx.x + (size_t)k * blockDim.x;
       v[k] = i < nw ? src[i] : 0;
     }
     const u64 *hs = reinterpret_cast<const u64 *>(tin->heap);
-    h0 = threadIdx.x < nh ? hs[threadIdx.x] : 0;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const size_t i = threadIdx.x + (size_t)k * blockDim.x;
+      hv[k] = i < nh ? hs[i] : 0;
+    }
   }
   // wave 2j + which: the per-feature records of job j's left / right child (stale
   // records of a job that does not exist are merged too and ignored)
@@ -1574,11 +1584,15 @@ __device__ __forceinline__ void batch_step(
   {
     u64 *dst = reinterpret_cast<u64 *>(sh_nodes);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const size_t i = threadIdx.x + (size_t)k * blockDim.x;
       if (i < nw) dst[i] = v[k];
     }
-    if (threadIdx.x < nh) reinterpret_cast<u64 *>(sh_heap)[threadIdx.x] = h0;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const size_t i = threadIdx.x + (size_t)k * blockDim.x;
+      if (i < nh) reinterpret_cast<u64 *>(sh_heap)[i] = hv[k];
+    }
   }
   if (lane == 0) {
     own[wave] = mine;
@@ -1808,6 +1822,7 @@ __device__ __forceinline__ void batch_step(
   }
 }
 
+template <int CAP>
 __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     QrTreeState *ts, const int root_mode, const int nleaves_arg, const u64 minls_arg,
     const int stage_nodes, const uint32_t N, const int flocal,
@@ -1821,7 +1836,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
   __shared__ int sh_nj;
   // (tin != ts: the last call of a tree grown by k_decide_part, whose state ping-pongs)
-  batch_step<false>(tin ? tin : ts, ts, nullptr, true, 0u, sh_next, sh_pw0, &sh_nj, &sh_epoch,
+  batch_step<false, CAP>(tin ? tin : ts, ts, nullptr, true, 0u, sh_next, sh_pw0, &sh_nj, &sh_epoch,
                     root_mode, nleaves_arg, minls_arg, stage_nodes, N, flocal, scal, part_ss, featrec,
                     featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, part_wg, part_grid,
                     plans, scan_wg);
@@ -2045,6 +2060,7 @@ __global__ __launch_bounds__(256) void k_partition_batch(
 // The control step and the partition in one launch (batch_step<true>): every
 // workgroup decides for itself, workgroup 0 publishes, all of them partition.
 static_assert(128 * QR_BATCH == 256, "k_decide_part partitions with 256 threads per workgroup");
+template <int CAP>
 __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
     const QrTreeState *tin, QrTreeState *tout, QrTreeState *tlog2, const uint32_t epoch,
     const int root_mode, const int nleaves_arg, const u64 minls_arg, const int stage_nodes,
@@ -2059,7 +2075,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
   __shared__ int sh_nj;
-  batch_step<true>(tin, tout, tlog2, blockIdx.x == 0, epoch, sh_next, sh_pw0, &sh_nj, &sh_epoch,
+  batch_step<true, CAP>(tin, tout, tlog2, blockIdx.x == 0, epoch, sh_next, sh_pw0, &sh_nj, &sh_epoch,
                    root_mode, nleaves_arg, minls_arg, stage_nodes, N, flocal, scal, part_ss_in, featrec,
                    featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, nullptr, 0u, plans,
                    scan_wg);
@@ -2810,7 +2826,8 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
       c->lhist_cap, (size_t)std::max(c->ncu, c->ncu / 4 + QR_BATCH * c->nblocks));
   const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);
   // final ids [0, 2 nleaves + 1) + provisional ones [.., 4 nleaves + 1)
-  const int stage_nodes = 4 * nleaves + 1 <= QR_DECIDE_LDS_NODES ? (int)(4 * nleaves + 1) : 0;
+  const bool small = 4 * nleaves + 1 + 2 * QR_BATCH <= QR_BATCH_LDS_SMALL;
+  const int stage_nodes = 4 * nleaves + 1 + 2 * QR_BATCH <= QR_BATCH_LDS_LARGE ? (int)(4 * nleaves + 1) : 0;
   // Staged trees: the control step runs inside the partition launch (k_decide_part) and
   // the tree state ping-pongs between two copies, arranged so that the last call
   // (control step only: it accounts for the last batch) writes c->d_tree.
@@ -2822,7 +2839,8 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
     QrTreeState *tin = fused ? T[(nleaves - s) & 1] : c->d_tree;  // what call s - 1 wrote
     const double *pss_in = fused ? PSS[(s + 1) & 1] : c->d_lpart_ss;
     if (!fused || s + 1 == nleaves) {
-      hipLaunchKernelGGL(k_decide_batch, dim3(1), dim3(128 * QR_BATCH), 0, c->stream, tout,
+      hipLaunchKernelGGL(small ? k_decide_batch<QR_BATCH_LDS_SMALL> : k_decide_batch<QR_BATCH_LDS_LARGE>,
+                         dim3(1), dim3(128 * QR_BATCH), 0, c->stream, tout,
                          s == 0 ? 1 : 0, (int)nleaves, (u64)minls, stage_nodes, rootn, c->flocal,
                          c->d_scalars, pss_in, c->d_featrec, c->d_featthr, (uint32_t)c->F,
                          c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, hg,
@@ -2835,7 +2853,8 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
                          (u64 *)c->d_lpart_state, c->d_lambda, c->d_lpart_ss);
       QR_CHECK(c, hipGetLastError());
     } else {
-      hipLaunchKernelGGL(k_decide_part, dim3(pg), dim3(128 * QR_BATCH), 0, c->stream,
+      hipLaunchKernelGGL(small ? k_decide_part<QR_BATCH_LDS_SMALL> : k_decide_part<QR_BATCH_LDS_LARGE>,
+                         dim3(pg), dim3(128 * QR_BATCH), 0, c->stream,
                          (const QrTreeState *)tin, tout, T[(nleaves - s) & 1], ++c->bepoch,
                          s == 0 ? 1 : 0, (int)nleaves, (u64)minls, stage_nodes, rootn, c->flocal,
                          c->d_scalars, pss_in, c->d_featrec, c->d_featthr, (uint32_t)c->F,

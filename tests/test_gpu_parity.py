@@ -577,11 +577,12 @@ def test_queries_longer_than_the_lds(qr, ora):
     c.close()
 
 
-@pytest.mark.parametrize("nleaves", [24, 255, 256])
+@pytest.mark.parametrize("nleaves", [22, 23, 64, 65, 255, 256])
 def test_leaf_counts_around_the_batched_growth_limits(qr, ora, nleaves):
-    """Two splits per step with the control state in LDS (<= 23 leaves), in device memory
-    (<= 255), one split per step beyond: same trees, and the
-    split log in the reference's order."""
+    """Two splits per step with the control step inside the partition launch and its state
+    in the small (<= 22 leaves) or the large (<= 64) LDS copy, as its own launch on device
+    memory (<= 255), one split per step beyond: same trees, and
+    the split log in the reference's order."""
     x, labels, qoff = make_dataset(nq=150, docs_per_query=40, F=20, seed=nleaves)
     rng = np.random.default_rng(nleaves)
     scores = rng.standard_normal(len(labels)) * 0.3

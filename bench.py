@@ -132,8 +132,8 @@ def scoring_metric(ctx, args, torch, rank=0, world=1, dist=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--queries", type=int, default=10000)
     ap.add_argument("--docs-per-query", type=int, default=100)
     ap.add_argument("--features", type=int, default=136)

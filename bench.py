@@ -10,7 +10,7 @@ root histogram, tree fit (split scans, partitions, child histograms), leaf
 outputs, training-score update and training NDCG@10 -- all on the device,
 inputs resident in HBM before the timed region starts.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 60 --warmup 5   (the defaults)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1 (quickrank_amd/dist.py), two layouts:

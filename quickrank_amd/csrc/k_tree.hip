@@ -2058,7 +2058,7 @@ __global__ __launch_bounds__(256) void k_partition_batch(
 }
 
 // The control step and the partition in one launch (batch_step<true>): every
-// workgroup decides for itself, workgroup 0 publishes, all of them partition.
+// workgroup decides for itself, the last one publishes, the others partition.
 static_assert(128 * QR_BATCH == 256, "k_decide_part partitions with 256 threads per workgroup");
 template <int CAP>
 __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
@@ -2075,7 +2075,9 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
   __shared__ int sh_nj;
-  batch_step<true, CAP>(tin, tout, tlog2, blockIdx.x == 0, epoch, sh_next, sh_pw0, &sh_nj, &sh_epoch,
+  // the LAST workgroup publishes: the grid is sized for the worst case plus one, so it
+  // never has a slice to partition, and nobody's look-back chain waits for it
+  batch_step<true, CAP>(tin, tout, tlog2, blockIdx.x == gridDim.x - 1, epoch, sh_next, sh_pw0, &sh_nj, &sh_epoch,
                    root_mode, nleaves_arg, minls_arg, stage_nodes, N, flocal, scal, part_ss_in, featrec,
                    featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, nullptr, 0u, plans,
                    scan_wg);

@@ -162,7 +162,8 @@ __device__ __forceinline__ void hist_run(
     const int b, const size_t slot0, const QrBlock *__restrict__ blocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const double scale, u64 *__restrict__ partials, const bool tr = false);
+    const double scale, u64 *__restrict__ partials, const bool tr = false, const int fw_known = 0,
+    const size_t off_known = 0);
 
 // One workgroup's share of a node histogram: workgroup `wg` of the `G` that the
 // plan hands to a node of n documents; partial slots start at `slot_base`.
@@ -194,9 +195,12 @@ __device__ __forceinline__ void hist_run(
     const int b, const size_t slot0, const QrBlock *__restrict__ blocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const double scale, u64 *__restrict__ partials, const bool tr) {
-  const int fw = blocks[b].fw;
-  const uint8_t *bins_b = bins + blocks[b].off;
+    const double scale, u64 *__restrict__ partials, const bool tr, const int fw_known,
+    const size_t off_known) {
+  // (batched growth hands the block's geometry over with the workgroup's share: one
+  // dependent read less before the first bins can be requested)
+  const int fw = fw_known ? fw_known : blocks[b].fw;
+  const uint8_t *bins_b = bins + (fw_known ? off_known : blocks[b].off);
   const uint32_t *order = buf == 0 ? order0 : order1;
   const bool identity = buf == 2;
   const uint32_t cells = 256u * fw;
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(1024) void k_hist_batch(
   const QrHistWg d = wgs[blockIdx.x];
   if (d.count == 0) return;
   hist_run(hist, d.begin, 0, d.count, d.buf, d.block, d.slot, blocks, bins, order0, order1, lambda,
-           scal->scale, partials, true);
+           scal->scale, partials, true, (int)d.fw, (size_t)d.off256 << 8);
 }
 
 // ===========================================================================
@@ -1748,7 +1752,8 @@ __device__ __forceinline__ void batch_step(
     QrHistWg d;
     d.begin = d.count = d.slot = 0;
     d.block = 0;
-    d.buf = d.job = 0;
+    d.buf = d.fw = 0;
+    d.off256 = d.pad = 0;
     if (x < sh_hw0[nj]) {
       int j = 0;
       while (j + 1 < nj && x >= sh_hw0[j + 1]) ++j;
@@ -1765,7 +1770,8 @@ __device__ __forceinline__ void batch_step(
       d.slot = ln.slot_base + xw * (uint32_t)pl.kmax;
       d.block = (uint16_t)b;
       d.buf = (uint8_t)ln.dst_buf;
-      d.job = (uint8_t)j;
+      d.fw = (uint8_t)sh_blk[b].fw;
+      d.off256 = (uint32_t)(sh_blk[b].off >> 8);
     }
     hist_wg[x] = d;
   }

@@ -165,9 +165,11 @@ struct QrHistWg {      // one histogram workgroup
   uint32_t begin;      // first position of its share in the list buffer
   uint32_t count;      // documents (0: nothing to do)
   uint32_t slot;       // first partial slot
-  uint16_t block;      // feature block
+  uint16_t block;      // feature block ...
   uint8_t buf;         // list buffer (0 / 1)
-  uint8_t job;
+  uint8_t fw;          // ... its width ...
+  uint32_t off256;     // ... and where its bins start (in units of 256 bytes)
+  uint32_t pad;
 };
 struct QrPartWg {      // one partition workgroup
   uint32_t begin, n, lcount;   // the node's segment and left count (n == 0: nothing to do)

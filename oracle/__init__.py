@@ -140,6 +140,8 @@ def lib():
     L.qro_oblivious_score.argtypes = [u32p, f32p, f64p, f32p, sz, sz, f32p, sz,
                                       sz, f64p]
     L.qro_set_threads.argtypes = [C.c_int]
+    L.qro_heap_trace.argtypes = [f64p, i32p, sz, sz, i32p, u64p]
+    L.qro_sym_index.argtypes = [sz, u64p]
     _LIB = L
     return L
 
@@ -169,6 +171,8 @@ def ref():
                                  C.POINTER(C.c_double)]
     R.ref_svml_read.argtypes = [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.c_void_p,
                                 C.c_void_p, C.c_void_p]
+    R.ref_heap_trace.argtypes = [f64p, i32p, sz, sz, i32p, u64p]
+    R.ref_sym_index.argtypes = [sz, u64p]
     R.ref_svml_write.argtypes = [C.c_char_p, f32p, f32p, u64p, sz, sz]
     _REF = R
     return R

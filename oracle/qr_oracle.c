@@ -647,6 +647,27 @@ static void heap_pop(heap_t *h) {
   h->arr[p] = last;
 }
 
+/* test hooks: the heap and the packed index as the tree / jacobian code uses them,
+ * pinned against the reference's own headers by tests/test_oracle_vs_ref.py */
+void qro_heap_trace(const double *keys, const int32_t *ops, size_t n, size_t initsize,
+                    int32_t *top_out, uint64_t *size_out) {
+  heap_t h;
+  heap_init(&h, initsize);
+  for (size_t i = 0; i < n; ++i) {
+    if (ops[i] >= 0)
+      heap_push(&h, keys[i], ops[i]);
+    else if (h.size != 0)
+      heap_pop(&h);
+    top_out[i] = h.size != 0 ? h.arr[1].val : -1;
+    size_out[i] = h.size;
+  }
+  free(h.arr);
+}
+void qro_sym_index(size_t size, uint64_t *out) {
+  for (size_t i = 0; i < size; ++i)
+    for (size_t j = 0; j < size; ++j) out[i * size + j] = sym_at(i, j, size);
+}
+
 static void live_free(live_t *lv) {
   free(lv->hsum);
   free(lv->hcount);

@@ -40,6 +40,11 @@ void qro_rank_by_score(const double *scores, size_t n, uint64_t *idx);
 void qro_sort_labels_desc_int(float *labels, size_t n);
 /* std::partial_sort(first,last,last) == the introsort depth-limit fallback   */
 void qro_heapsort_by_score(const double *scores, size_t n, uint64_t *idx);
+/* maxheap.h:58-88 driven by a push (ops[i] >= 0: value) / pop (ops[i] < 0) sequence;  */
+/* symmatrix.h:29-89 packed index of every (i, j).  Test hooks for the pins.           */
+void qro_heap_trace(const double *keys, const int32_t *ops, size_t n, size_t initsize,
+                    int32_t *top_out, uint64_t *size_out);
+void qro_sym_index(size_t size, uint64_t *out);
 
 /* ---- metric (dcg.cc:33-57, ndcg.cc:35-58, metric.h:77-106) --------------- */
 double qro_dcg(const float *labels, size_t len, size_t cutoff);

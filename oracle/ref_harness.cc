@@ -6,6 +6,8 @@
 //   src/data/{dataset,vertical_dataset,queryresults,rankedresults}.cc
 //   src/metric/ir/{dcg,ndcg}.cc   src/learning/tree/rtnode_histogram.cc
 //   src/utils/radix.cc   src/io/svml.cc   src/utils/strutils.cc
+// and instantiates the header-only include/utils/maxheap.h (the growth-order heap of
+// RegressionTree::fit) and include/utils/symmatrix.h (the jacobian's packed index)
 // (the subset of the hot path that compiles from its own files; everything that
 // includes learning/tree/rtnode.h needs the un-vendored pugixml submodule and is
 // treated as unbuildable -- no stand-in headers are written).
@@ -26,6 +28,8 @@
 #include "metric/ir/ndcg.h"
 #include "io/svml.h"
 #include "utils/radix.h"
+#include "utils/maxheap.h"
+#include "utils/symmatrix.h"
 
 using namespace quickrank;
 
@@ -205,6 +209,31 @@ int ref_svml_write(const char *path, const float *x, const float *labels, const 
   auto ds = make_dataset(x, labels, qoff, Q, F);
   io::Svml().write(ds, path);
   return 0;
+}
+
+// MaxHeap<int> (maxheap.h:58-88), driven by a sequence of operations: ops[i] >= 0 =
+// push(keys[i], ops[i]); ops[i] < 0 = pop.  top_out[i] = top() after operation i (-1
+// when the heap is empty), size_out[i] = get_size().  The constructor's initial size
+// (RegressionTree::fit passes the leaf count, rt.cc:57) only decides when it reallocs.
+void ref_heap_trace(const double *keys, const int32_t *ops, size_t n, size_t initsize,
+                    int32_t *top_out, uint64_t *size_out) {
+  MaxHeap<int> h(initsize);
+  for (size_t i = 0; i < n; ++i) {
+    if (ops[i] >= 0)
+      h.push(keys[i], ops[i]);
+    else if (h.is_notempty())
+      h.pop();
+    top_out[i] = h.is_notempty() ? h.top() : -1;
+    size_out[i] = h.get_size();
+  }
+}
+
+// SymMatrix<double>::at(i, j) (symmatrix.h:29-89): position of (i, j) in the packed
+// array, for every pair; out is [size][size]
+void ref_sym_index(size_t size, uint64_t *out) {
+  SymMatrix<double> m(size);
+  for (size_t i = 0; i < size; ++i)
+    for (size_t j = 0; j < size; ++j) out[i * size + j] = (uint64_t)(m.vectat(i, j) - m.vectat(0, 0));
 }
 
 }  // extern "C"

@@ -69,8 +69,36 @@ def make(name, cutoff, nthr, score_kind, **case):
                         left_sum=ls, left_count=lc, left_ss=lss.value)
 
 
+def make_heap(name):
+    """MaxHeap<int> traces (maxheap.h:58-88): push / pop sequences with equal, few-valued
+    and random keys; top and size after every operation, from the reference's header."""
+    R = oracle.ref()
+    rng = np.random.default_rng(321)
+    out = {}
+    for kind in ("equal", "few", "random"):
+        n = 40
+        pool = {"equal": np.zeros(n), "few": rng.integers(0, 3, n).astype(np.float64),
+                "random": rng.standard_normal(n)}[kind]
+        keys, ops, size = [], [], 0
+        for v, k in enumerate(pool):
+            keys.append(k); ops.append(v); size += 1
+            if size >= 2 and rng.random() < 0.4:
+                keys.append(0.0); ops.append(-1); size -= 1
+        keys += [0.0] * size
+        ops += [-1] * size
+        keys, ops = np.asarray(keys, np.float64), np.asarray(ops, np.int32)
+        top, sz_ = np.zeros(len(ops), np.int32), np.zeros(len(ops), np.uint64)
+        R.ref_heap_trace(keys, ops, len(ops), 10, top, sz_)
+        out.update({f"{kind}_keys": keys, f"{kind}_ops": ops, f"{kind}_top": top, f"{kind}_size": sz_})
+    idx = np.zeros((17, 17), np.uint64)
+    R.ref_sym_index(17, idx)
+    out["sym17"] = idx
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
 if __name__ == "__main__":
     oracle.build(ref=True)
+    make_heap("heap_sym.npz")
     make("g1_ties_zero.npz", 10, 16, "zero", nq=12, docs_per_query=40, F=6, seed=31, ragged=True)
     make("g2_ties_few.npz", 10, 255, "few", nq=10, docs_per_query=50, F=8, seed=32, adversarial=True)
     make("g3_random.npz", 3, 8, "random", nq=8, docs_per_query=100, F=5, seed=33, ragged=True)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from datagen import make_dataset
-from parity_util import assert_tree_parity
+from parity_util import assert_split_log_parity, assert_tree_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -149,25 +149,17 @@ def test_root_histogram_and_tree(qr, ora, case, nthr, nleaves, minls):
     # split sequence and structure
     on = ot["nodes"]
     ties = assert_tree_parity(tr.stmap, on, nodes, value_rtol=1e-9)
-    log = c.split_log()
-    olog = ot["splits"]
-    assert len(log) == len(olog)
-    if ties == 0:
-        assert np.array_equal(log["lcount"], olog["lcount"])
-        assert np.array_equal(log["rcount"], olog["rcount"])
-        assert np.array_equal(log["feature"].astype(np.uint64), olog["feature"])
-        assert np.array_equal(log["thr_id"].astype(np.uint64), olog["thr_id"])
-        assert np.allclose(log["score"], olog["score"], rtol=1e-9)
-    leaf = nodes["feature"] < 0
-    if ties == 0:
-        assert np.allclose(nodes["deviance"], on["deviance"], rtol=1e-6, atol=1e-9)
-    # leaf membership (stable partition => ascending doc ids)
-    for li, n in enumerate(np.nonzero(leaf)[0]):
-        ids = c.node_samples(int(n))
+    # ties (equal-partition candidates in nodes of <= TIE_MAX_DOCS documents) are
+    # counted by the walker; everything below is compared modulo them, never skipped
+    assert_split_log_parity(c.split_log(), ot["splits"], ties)
+    for oi, gi in ties.node_map.items():
+        assert np.isclose(nodes[gi]["deviance"], on[oi]["deviance"], rtol=1e-6, atol=1e-9), (oi, gi)
+    # leaf membership (stable partition => ascending doc ids), through the node map
+    for li, on_leaf in enumerate(ot["leaf_nodes"]):
+        ids = c.node_samples(ties.node_map[int(on_leaf)])
         assert np.all(np.diff(ids.astype(np.int64)) > 0)
-        if ties == 0:
-            want = np.nonzero(ot["leaf_of_doc"] == list(ot["leaf_nodes"]).index(n))[0]
-            assert np.array_equal(ids, want.astype(np.uint32))
+        want = np.nonzero(ot["leaf_of_doc"] == li)[0]
+        assert np.array_equal(ids, want.astype(np.uint32))
     # score update through the leaf membership
     c.set_scores(scores)
     c.update_scores(0.1)
@@ -245,10 +237,12 @@ def test_oblivious_tree(qr, ora, case, nthr, depth, minls):
     ties = assert_tree_parity(tr.stmap, on, nodes, value_rtol=1e-9)
     log, olog = c.split_log(), ot["splits"]
     assert len(log) == len(olog)
+    # one (feature, slot) per level: a tie-resolved level may name another candidate
+    same = (log["feature"].astype(np.uint64) == olog["feature"]) & (log["thr_id"].astype(np.uint64) == olog["thr_id"])
+    assert int((~same).sum()) <= (1 if ties else 0) * len(log)
     if ties == 0:
-        assert np.array_equal(log["feature"].astype(np.uint64), olog["feature"])
-        assert np.array_equal(log["thr_id"].astype(np.uint64), olog["thr_id"])
-        assert np.allclose(log["score"], olog["score"], rtol=1e-9)
+        assert same.all()
+    assert np.allclose(log["score"], olog["score"], rtol=1e-9)
     c.set_scores(scores)
     c.update_scores(0.1)
     s2 = scores.copy()
@@ -598,7 +592,5 @@ def test_leaf_counts_around_the_batched_growth_limits(qr, ora, nleaves):
     ties = assert_tree_parity(tr.stmap, on, nodes, value_rtol=1e-9)
     log, olog = c.split_log(), ot["splits"]
     assert len(log) == len(olog) == nleaves - 1
-    if ties == 0:
-        assert np.array_equal(log["feature"].astype(np.uint64), olog["feature"])
-        assert np.array_equal(log["thr_id"].astype(np.uint64), olog["thr_id"])
+    assert_split_log_parity(log, olog, ties)
     c.close()

@@ -185,3 +185,63 @@ def test_histograms(libs, oracle_lib, nthr, transform):
     L.qro_hist_subtract(F, ts, cap, os_, oc, ols, olc, ors, orc)
     assert np.array_equal(ors[mask].view(np.uint64), gs[mask].view(np.uint64))
     assert np.array_equal(orc[mask], gc[mask]) and (oss - olss) == gss.value
+
+
+def _heap_ops(rng, n, kind):
+    """A push / pop sequence like RegressionTree::fit's (two pushes per pop), with
+    keys of the given tie structure.  ops[i] >= 0: push value ops[i]; -1: pop."""
+    if kind == "equal":
+        pool = np.zeros(n)
+    elif kind == "few":
+        pool = rng.integers(0, 3, n).astype(np.float64)
+    elif kind == "zero_and_pos":     # many pure nodes (deviance 0) next to positive ones
+        pool = np.where(rng.random(n) < 0.5, 0.0, rng.random(n))
+    elif kind == "ascending":
+        pool = np.arange(n, dtype=np.float64)
+    elif kind == "descending":
+        pool = -np.arange(n, dtype=np.float64)
+    else:
+        pool = rng.standard_normal(n)
+    keys, ops, val, size = [], [], 0, 0
+    for k in pool:
+        keys.append(k)
+        ops.append(val)
+        val += 1
+        size += 1
+        if size >= 2 and rng.random() < 0.4:   # pop now and then (and never on empty)
+            keys.append(0.0)
+            ops.append(-1)
+            size -= 1
+    while size > 0:                            # drain: the full pop order
+        keys.append(0.0)
+        ops.append(-1)
+        size -= 1
+    return np.asarray(keys, np.float64), np.asarray(ops, np.int32)
+
+
+@pytest.mark.parametrize("kind", ["equal", "few", "zero_and_pos", "ascending", "descending", "random"])
+def test_maxheap_push_pop_order(libs, kind):
+    """maxheap.h:58-88 decides the growth order of RegressionTree::fit, including
+    among equal deviances: the restatement's heap against MaxHeap<int> itself, top and
+    size after every operation."""
+    L, R = libs
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 3, 7, 10, 31, 64, 200, 1023):
+        for initsize in (0, 10, n):
+            keys, ops = _heap_ops(rng, n, kind)
+            ta, tb = np.zeros(len(ops), np.int32), np.zeros(len(ops), np.int32)
+            sa, sb = np.zeros(len(ops), np.uint64), np.zeros(len(ops), np.uint64)
+            L.qro_heap_trace(keys, ops, len(ops), initsize, ta, sa)
+            R.ref_heap_trace(keys, ops, len(ops), initsize, tb, sb)
+            assert np.array_equal(ta, tb) and np.array_equal(sa, sb), (kind, n, initsize)
+
+
+def test_symmatrix_index(libs):
+    """symmatrix.h:29-89: the packed position of every (i, j), both triangles."""
+    L, R = libs
+    for size in (1, 2, 3, 16, 17, 100, 257):
+        a, b = np.zeros((size, size), np.uint64), np.zeros((size, size), np.uint64)
+        L.qro_sym_index(size, a)
+        R.ref_sym_index(size, b)
+        assert np.array_equal(a, b), size
+        assert np.array_equal(a, a.T) and a.max() == size * (size + 1) // 2 - 1

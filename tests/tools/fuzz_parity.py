@@ -1,108 +1,124 @@
 """Randomised parity sweep (TEST TOOL): random dataset shapes / thresholds / leaves /
 min leaf support / depths, a few boosting iterations each, device trees vs the
-oracle's with the tie-aware walker of tests/parity_util.py.  Run on a GPU box:
+oracle's with the tie-aware walker of tests/parity_util.py.  `sweep()` is what
+tests/test_gpu_fuzz.py runs inside `pytest -m gpu`; as a script on a GPU box:
     python tests/tools/fuzz_parity.py [n_configs] [seed]"""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import torch
-if torch.cuda.is_available():
-    torch.cuda.init()
-import oracle
-from datagen import make_dataset
-from parity_util import assert_tree_parity
-from quickrank_amd.trainer import Mart
 
-n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-oracle.build(ref=False)
-t0 = time.time()
-ties_total = 0
-gain_ties = 0
-flips_total = 0
-for i in range(n_cfg):
-    F = int(rng.choice([5, 9, 16, 17, 40, 64, 65, 136, 200]))
-    nq = int(rng.integers(5, 400))
-    dpq = int(rng.choice([1, 3, 16, 17, 40, 100, 250]))
-    nthr = int(rng.choice([2, 8, 16, 64, 255]))
-    algo = str(rng.choice(["LAMBDAMART", "MART", "OBVLAMBDAMART", "OBVMART"]))
-    minls = int(rng.choice([1, 1, 2, 5, 20]))
-    kw = dict(ntrees=int(rng.integers(2, 6)), shrinkage=0.1, nthresholds=nthr, minls=minls, esr=0)
-    if algo.startswith("OBV"):
-        kw["depth"] = int(rng.integers(1, 7))
-    else:
-        kw["nleaves"] = int(rng.choice([2, 3, 8, 10, 31, 64]))
-    x, labels, qoff = make_dataset(nq=nq, docs_per_query=dpq, F=F, seed=int(rng.integers(1 << 30)),
-                                   ragged=bool(rng.integers(2)), adversarial=bool(rng.integers(2)))
-    if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != i:
-        continue
-    desc = f"[{i}] {algo} N={len(labels)} F={F} nthr={nthr} minls={minls} {kw.get('nleaves', '')}{kw.get('depth', '')}"
-    om = oracle.train(x, labels, qoff, algo=algo, **kw)
-    gm = Mart(algo=algo, **kw).learn(x, labels, qoff)
-    assert len(gm.ensemble) == om["ntrees_built"], desc
-    tr = oracle.Trainer(x, nthr)
-    ties = 0
-    diverged = False
-    for t in range(om["ntrees_built"]):
-        n = int(om["nnodes"][t])
-        try:
-            ties += assert_tree_parity(tr.stmap, om["nodes"][t][:n], gm.ensemble.trees[t][:n])
-        except AssertionError as e:
-            # The one legitimate way to get here: two DIFFERENT partitions of a small
-            # node whose gains are equal in exact arithmetic (discrete residuals,
-            # equal left counts and left sums); the reference picks by the rounding
-            # noise of its summation order.  Verified through the children's
-            # deviances (equal gains <=> equal sums of child deviances); everything
-            # after this tree then differs legitimately.
-            o, g = om["nodes"][t][:n], gm.ensemble.trees[t][:n]
-            ok = False
-            if e.args and isinstance(e.args[0], tuple) and e.args[0][0] == "different partition at oracle node":
-                oi = e.args[0][1]
-                cand = [k for k in range(len(g)) if g[k]["feature"] >= 0 and g[k]["nsamples"] == o[oi]["nsamples"]
-                        and abs(g[k]["deviance"] - o[oi]["deviance"]) <= 1e-9 * max(1.0, abs(o[oi]["deviance"]))]
-                for k in cand:
-                    so = o[o[oi]["left"]]["deviance"] + o[o[oi]["right"]]["deviance"]
-                    sg = g[g[k]["left"]]["deviance"] + g[g[k]["right"]]["deviance"]
-                    if abs(so - sg) <= 1e-9 * max(1.0, abs(o[oi]["deviance"])):
-                        ok = True
-            # ... or a node whose true deviance is 0 (all pseudo-responses equal): the
-            # `deviance > 0` gate (rt.cc:212) is then decided by rounding noise
-            if not ok and e.args and isinstance(e.args[0], tuple) and len(e.args[0]) == 2 \
-                    and all(isinstance(v, (int, np.integer)) for v in e.args[0]):
-                oi, gi = e.args[0]
-                eps = 1e-9 * max(1.0, abs(o[0]["deviance"]))
-                if abs(o[oi]["deviance"]) <= eps and abs(g[gi]["deviance"]) <= eps:
-                    ok = True
-            if not ok:
-                print(desc, "TREE", t, "MISMATCH", e)
-                if os.environ.get("FUZZ_ONLY"):
-                    for nm, arr in (("oracle", o), ("device", g)):
-                        print(nm, [(k, int(a["feature"]), int(a["thr_id"]), int(a["left"]), int(a["nsamples"]),
-                                    float(a["deviance"])) for k, a in enumerate(arr)])
-                raise SystemExit(1)
-            gain_ties += 1
-            diverged = True
-            break
-    if diverged:
-        print(desc, "ok up to a split decided by rounding noise (exact gain tie / zero deviance) in tree", t, flush=True)
+
+def sweep(n_cfg=30, seed=0, only=None, verbose=True):
+    """Returns one record per configuration: dict(i, desc, status, ties, tie_sizes,
+    flips, tree) with status "ok", or "gain_tie" / "zero_deviance" for a run cut short
+    at a split the reference decides by the rounding noise of its summation order
+    (verified to be exactly that, see below).  Any other difference raises."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+    import oracle
+    from datagen import make_dataset
+    from parity_util import assert_tree_parity
+    from quickrank_amd.trainer import Mart
+    rng = np.random.default_rng(seed)
+    oracle.build(ref=False)
+    out = []
+    for i in range(n_cfg):
+        F = int(rng.choice([5, 9, 16, 17, 40, 64, 65, 136, 200]))
+        nq = int(rng.integers(5, 400))
+        dpq = int(rng.choice([1, 3, 16, 17, 40, 100, 250]))
+        nthr = int(rng.choice([2, 8, 16, 64, 255]))
+        algo = str(rng.choice(["LAMBDAMART", "MART", "OBVLAMBDAMART", "OBVMART"]))
+        minls = int(rng.choice([1, 1, 2, 5, 20]))
+        kw = dict(ntrees=int(rng.integers(2, 6)), shrinkage=0.1, nthresholds=nthr, minls=minls, esr=0)
+        if algo.startswith("OBV"):
+            kw["depth"] = int(rng.integers(1, 7))
+        else:
+            kw["nleaves"] = int(rng.choice([2, 3, 8, 10, 31, 64]))
+        x, labels, qoff = make_dataset(nq=nq, docs_per_query=dpq, F=F, seed=int(rng.integers(1 << 30)),
+                                       ragged=bool(rng.integers(2)), adversarial=bool(rng.integers(2)))
+        if only is not None and only != i:
+            continue
+        desc = f"[{i}] {algo} N={len(labels)} F={F} nthr={nthr} minls={minls} {kw.get('nleaves', '')}{kw.get('depth', '')}"
+        rec = dict(i=i, desc=desc, status="ok", ties=0, tie_sizes=[], flips=0, tree=None)
+        om = oracle.train(x, labels, qoff, algo=algo, **kw)
+        gm = Mart(algo=algo, **kw).learn(x, labels, qoff)
+        assert len(gm.ensemble) == om["ntrees_built"], desc
+        tr = oracle.Trainer(x, nthr)
+        for t in range(om["ntrees_built"]):
+            n = int(om["nnodes"][t])
+            try:
+                tt = assert_tree_parity(tr.stmap, om["nodes"][t][:n], gm.ensemble.trees[t][:n])
+                rec["ties"] += int(tt)
+                rec["tie_sizes"] += list(tt.sizes)
+            except AssertionError as e:
+                # The one legitimate way to get here: two DIFFERENT partitions of a small
+                # node whose gains are equal in exact arithmetic (discrete residuals,
+                # equal left counts and left sums); the reference picks by the rounding
+                # noise of its summation order.  Verified through the children's
+                # deviances (equal gains <=> equal sums of child deviances); everything
+                # after this tree then differs legitimately.
+                o, g = om["nodes"][t][:n], gm.ensemble.trees[t][:n]
+                status = None
+                if e.args and isinstance(e.args[0], tuple) and e.args[0][0] == "different partition at oracle node":
+                    oi = e.args[0][1]
+                    cand = [k for k in range(len(g)) if g[k]["feature"] >= 0 and g[k]["nsamples"] == o[oi]["nsamples"]
+                            and abs(g[k]["deviance"] - o[oi]["deviance"]) <= 1e-9 * max(1.0, abs(o[oi]["deviance"]))]
+                    for k in cand:
+                        so = o[o[oi]["left"]]["deviance"] + o[o[oi]["right"]]["deviance"]
+                        sg = g[g[k]["left"]]["deviance"] + g[g[k]["right"]]["deviance"]
+                        if abs(so - sg) <= 1e-9 * max(1.0, abs(o[oi]["deviance"])):
+                            status = "gain_tie"
+                # ... or a node whose true deviance is 0 (all pseudo-responses equal): the
+                # `deviance > 0` gate (rt.cc:212) is then decided by rounding noise
+                if status is None and e.args and isinstance(e.args[0], tuple) and len(e.args[0]) == 2 \
+                        and all(isinstance(v, (int, np.integer)) for v in e.args[0]):
+                    oi, gi = e.args[0]
+                    eps = 1e-9 * max(1.0, abs(o[0]["deviance"]))
+                    if abs(o[oi]["deviance"]) <= eps and abs(g[gi]["deviance"]) <= eps:
+                        status = "zero_deviance"
+                if status is None:
+                    print(desc, "TREE", t, "MISMATCH", e)
+                    if only is not None:
+                        for nm, arr in (("oracle", o), ("device", g)):
+                            print(nm, [(k, int(a["feature"]), int(a["thr_id"]), int(a["left"]), int(a["nsamples"]),
+                                        float(a["deviance"])) for k, a in enumerate(arr)])
+                    raise AssertionError((desc, "tree", t, e.args))
+                rec["status"], rec["tree"] = status, t
+                break
+        if rec["status"] != "ok":
+            if verbose:
+                print(desc, "ok up to a split decided by rounding noise (exact gain tie / zero deviance) in tree",
+                      rec["tree"], flush=True)
+            gm.ctx.close()
+            out.append(rec)
+            continue
+        # Scores agree to rounding; the METRIC is then bit-exact for the same scores, but
+        # two documents whose scores differ only by summation-order noise (leaf means
+        # are summed in a different order on the device) may swap ranks: checked as
+        # "the oracle's metric of the device's own scores" instead of a loose tolerance.
+        gs = gm.ctx.get_scores()
+        if not np.allclose(gm.train_metric, om["train_metric"], rtol=1e-9):
+            rec["flips"] = 1
+        final = oracle.eval_dataset(labels, gs, qoff, 10)
+        assert abs(final - gm.train_metric[-1]) <= 1e-12 * max(1.0, abs(final)), (desc, final, gm.train_metric[-1])
+        assert np.allclose(gs, om["train_scores"], rtol=1e-7, atol=1e-9), desc
         gm.ctx.close()
-        continue
-    # Scores agree to rounding; the METRIC is then bit-exact for the same scores, but
-    # two documents whose scores differ only by summation-order noise (leaf means
-    # are summed in a different order on the device) may swap ranks: checked as
-    # "the oracle's metric of the device's own scores" instead of a loose tolerance.
-    gs = gm.ctx.get_scores()
-    flips = 0
-    if not np.allclose(gm.train_metric, om["train_metric"], rtol=1e-9):
-        flips = 1
-    final = oracle.eval_dataset(labels, gs, qoff, 10)
-    assert abs(final - gm.train_metric[-1]) <= 1e-12 * max(1.0, abs(final)), (desc, final, gm.train_metric[-1])
-    flips_total += flips
-    assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-7, atol=1e-9), desc
-    gm.ctx.close()
-    ties_total += ties
-    print(desc, "ok", f"(ties {ties})", flush=True)
-print(f"{n_cfg} configurations, {ties_total} equal-partition ties, {flips_total} runs with a rank flip "
-      f"between scores equal to rounding, {gain_ties} runs cut short at an exact gain tie between "
-      f"different partitions, {time.time() - t0:.0f} s")
+        if verbose:
+            print(desc, "ok", f"(ties {rec['ties']})", flush=True)
+        out.append(rec)
+    return out
+
+
+if __name__ == "__main__":
+    n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    t0 = time.time()
+    only = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None
+    res = sweep(n_cfg, int(sys.argv[2]) if len(sys.argv) > 2 else 0, only)
+    print(f"{n_cfg} configurations, {sum(r['ties'] for r in res)} equal-partition ties "
+          f"(largest node {max([0] + [max(r['tie_sizes'] or [0]) for r in res])} documents), "
+          f"{sum(r['flips'] for r in res)} runs with a rank flip between scores equal to rounding, "
+          f"{sum(r['status'] != 'ok' for r in res)} runs cut short at an exact gain tie between "
+          f"different partitions / a zero-deviance gate: {[r['i'] for r in res if r['status'] != 'ok']}, "
+          f"{time.time() - t0:.0f} s")

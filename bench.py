@@ -13,17 +13,26 @@ inputs resident in HBM before the timed region starts.
   python bench.py --gpus 1 --steps 60 --warmup 5   (the defaults)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (quickrank_amd/dist.py), two layouts:
-  --shard docs      (default) every rank holds its OWN 1M-document shard (whole
-                    queries, all features; seed 42 + rank): the job is N x 1M documents,
-                    one int64 all-reduce per node histogram, per-GPU work fixed
-                    -> "scaling": "weak"; value = all ranks' documents / time.
-                    The same run then also measures BASELINE.json's configs[2] as it
-                    is written (object "config2_feature_sharded": the SAME 1M set on
-                    every rank, feature blocks sharded, "strong"); --no-config2 skips it.
-  --shard features  the 1M-document set replicated, feature blocks of the bin
-                    matrix sharded -> "scaling": "strong" as the headline (DESIGN.md
-                    section 6 on why this cannot beat one GPU at 1M documents).
+N = 1 adds to the line: `roofline` (root histogram launch, HIP events on the launch),
+`roofline_iteration` (algorithmic bytes of the whole iteration from the measured tree
+shape / ms_per_step), `roofline_child_hist` (the child-histogram launches, a separate
+short pass), `cpu_baseline` (the oracle on the whole set, all cores and 8 threads),
+`ensemble_scoring` (config 5 at full size, with its own CPU baseline) and `strong_8M`
+(the same training on 8M documents, the 1-GPU point of the larger scaling set).
+
+N > 1 (quickrank_amd/dist.py): the headline is BASELINE.json configs[2] -- the SAME 1M
+set, total work fixed ("scaling": "strong").  Both layouts are measured with K steps
+each and the faster one is the headline (`config.parallelism` names it, both are under
+`strong_layouts`):
+  document_sharded  rank r holds queries [r Q/N, (r+1) Q/N) and every feature of them;
+                    one int64 all-reduce per node histogram, everything else local
+  feature_sharded   north_star's layout: every rank holds all documents and 1/N of the
+                    feature columns of the bin matrix; best-split records all-gather +
+                    go-left mask all-reduce per split (DESIGN.md section 6 on why it
+                    cannot beat one GPU at 1M documents)
+Extra keys: `weak_scaling` (every rank its own 1M shard, N x 1M documents in all) and
+`strong_8M` (8M documents, the shards of the document-sharded layout), `--extra-steps`
+timed steps each.  A run aborts if the ranks' trees differ.
 Prints ONE JSON line on rank 0 (stdout carries nothing else: library banners are
 routed to stderr).
 """
@@ -60,23 +69,82 @@ def synth(nq, dpq, F, seed=42, sparse_cols=0, zero_frac=0.9):
     return x, labels, qoff
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+REFERENCE_8CORE_S_PER_ITER = 0.298   # the reference itself, 8 Xeon cores, this workload
+
+
 def cpu_baseline(x, labels, qoff, args):
     """The oracle (C + OpenMP restatement of the reference's loop, bit-exact to
-    it on the fixtures) timed on this host's cores on a bounded sample."""
+    it on the fixtures) timed on this host's cores on the FULL workload (SURVEY.md
+    section 8d): all cores it may use, and again with 8 threads; a handful of
+    iterations, the first discarded (about 10-20 s of CPU work in all, most of it
+    the one-time argsort / threshold / bin-map initialisation)."""
     import oracle
     cores = oracle.available_cores()
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    nq = min(len(qoff) - 1, args.cpu_queries)
+    nq = min(len(qoff) - 1, args.cpu_queries) if args.cpu_queries else len(qoff) - 1
     n = int(qoff[nq])
     iters = args.cpu_iters
-    m = oracle.train(x[:n], labels[:n], qoff[:nq + 1], algo="LAMBDAMART", ntrees=iters,
-                     shrinkage=0.1, nthresholds=args.nthresholds, nleaves=args.nleaves, minls=1,
-                     esr=0, threads=cores)
-    sec = float(np.mean(m["iter_seconds"][1:])) if iters > 1 else float(m["iter_seconds"][0])
-    return {"value": n / sec, "unit": "docs/s per boosting iteration", "cores": cores,
-            "kind": "port",
-            "sample": f"first {nq} queries ({n} docs x {x.shape[1]} features) of the same synthetic "
-                      f"set, {iters} iterations, first discarded, {sec * 1e3:.1f} ms/iteration, "
+
+    def run(threads):
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        m = oracle.train(x[:n], labels[:n], qoff[:nq + 1], algo="LAMBDAMART", ntrees=iters,
+                         shrinkage=0.1, nthresholds=args.nthresholds, nleaves=args.nleaves, minls=1,
+                         esr=0, threads=threads)
+        sec = float(np.mean(m["iter_seconds"][1:])) if iters > 1 else float(m["iter_seconds"][0])
+        return sec, m
+    sec_all, m = run(cores)
+    out = {"value": n / sec_all, "unit": "docs/s per boosting iteration", "cores": cores,
+           "cpu_model": cpu_model(), "kind": "port",
+           "sample": ("the whole" if nq == len(qoff) - 1 else f"first {nq} queries of the") +
+                     f" synthetic set ({n} docs x {x.shape[1]} features), {iters} iterations, first "
+                     f"discarded, {sec_all * 1e3:.1f} ms/iteration, OpenMP x{cores}",
+           "ms_per_iteration": sec_all * 1e3,
+           "ndcg10_after": {str(iters): float(m["train_metric"][-1])},
+           # how the port compares with the reference itself: BASELINE.md section 2 timed the
+           # reference's own build at 0.298 s per iteration on 8 Xeon cores (another box);
+           # the port needs 0.19-0.25 s there (VERDICT r1) -- i.e. it is not a slower stand-in
+           "reference_built_8core_other_box": {"s_per_iteration": REFERENCE_8CORE_S_PER_ITER,
+                                               "docs_per_s": 1e6 / REFERENCE_8CORE_S_PER_ITER,
+                                               "source": "BASELINE.md section 2"}}
+    if cores != 8:
+        sec8, _ = run(min(8, cores))
+        out["threads8"] = {"value": n / sec8, "cores": min(8, cores), "ms_per_iteration": sec8 * 1e3,
+                           "port_vs_reference_same_threads": REFERENCE_8CORE_S_PER_ITER / sec8}
+    else:
+        out["port_vs_reference_same_threads"] = REFERENCE_8CORE_S_PER_ITER / sec_all
+    return out
+
+
+def cpu_scoring_baseline(args, make_model):
+    """Scoring baseline (LTR_Algorithm::score_dataset, ltr_algorithm.cc:44-52: OpenMP over
+    the documents, per-tree walk): the oracle's restatement on a bounded sample of
+    config 5 -- the whole 10,000-tree model over the first `cpu_score_docs` documents."""
+    import time as _t
+    import oracle
+    cores = oracle.available_cores()
+    oracle.lib().qro_set_threads(cores)
+    rng = np.random.default_rng(43)
+    nodes, w = make_model(args.score_trees, 6, 200, rng)
+    nd = args.cpu_score_docs
+    x = np.random.default_rng(44).random((nd, 200), dtype=np.float32)
+    model = dict(nodes=nodes, nnodes=np.full(len(nodes), nodes.shape[1], np.uint64), ntrees=len(nodes),
+                 max_nodes=nodes.shape[1], shrinkage=0.1)
+    oracle.ensemble_score(model, x[:256])
+    t0 = _t.perf_counter()
+    oracle.ensemble_score(model, x)
+    sec = _t.perf_counter() - t0
+    return {"value": nd / sec, "unit": "docs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "node_visits_per_s": nd * args.score_trees * 6 / sec,
+            "sample": f"{args.score_trees} trees x 64 leaves over {nd} docs x 200 features, {sec:.1f} s, "
                       f"OpenMP x{cores}"}
 
 
@@ -129,6 +197,139 @@ def scoring_metric(ctx, args, torch, rank=0, world=1, dist=None):
             "scaling": "strong", "n_gpus": world, "ms": ms}
 
 
+def tree_shape(t):
+    """sigma = documents whose histogram is built directly per tree / N
+    (we build the smaller child; the reference always the left one), pi = documents
+    partitioned per tree / N."""
+    internal = np.nonzero(t["feature"] >= 0)[0]
+    nl = t["nsamples"][t["left"][internal]].astype(np.float64)
+    nr = t["nsamples"][t["right"][internal]].astype(np.float64)
+    tot = float(t["nsamples"][0])
+    return (np.minimum(nl, nr).sum() / tot, nl.sum() / tot,
+            t["nsamples"][internal].astype(np.float64).sum() / tot)
+
+
+def iteration_alg_bytes(N, F, L, sigma, pi):
+    """Algorithmic bytes of one boosting iteration (SURVEY.md 8d "whole iteration"):
+    lambdas 28 N + root histogram (N F + 8 N) + child histograms sigma N (F + 12) + split
+    scans (2 (L - 1) + 1) F 256 16 + partition 12 pi N + leaf outputs 20 N + score update
+    16 N + NDCG 12 N."""
+    return (28.0 * N + (N * F + 8.0 * N) + sigma * N * (F + 12) + (2 * (L - 1) + 1) * F * 256 * 16
+            + 12.0 * pi * N + 20.0 * N + 16.0 * N + 12.0 * N)
+
+
+class Run:
+    """One timed configuration: a layout over this rank's part of a data set."""
+
+    def __init__(self, torch, dist, layout, x, labels, qoff, n_global, q_global, args, rank, world,
+                 local_rank):
+        from quickrank_amd._capi import Context
+        self.torch, self.dist, self.args, self.layout = torch, dist, args, layout
+        self.n_global = n_global
+        stream = torch.cuda.current_stream().cuda_stream if layout != "single" else None
+        self.trainer = self.fitter = None
+        if layout == "docs":
+            from quickrank_amd.dist import DocShardedTrainer, gather_thresholds
+            self.ctx = Context(local_rank, rank=rank, world=world, stream=stream,
+                               doc_shard=(n_global, q_global))
+            self.ctx.upload(x, labels, qoff)
+            self.ctx.build_bins_with(*gather_thresholds(self.ctx, args.nthresholds))
+            self.ctx.reset_scores()
+            self.trainer = DocShardedTrainer(self.ctx)
+            self.comm = self.trainer.direct
+        else:
+            self.ctx = Context(local_rank, rank=rank if layout == "features" else 0,
+                               world=world if layout == "features" else 1, stream=stream)
+            self.ctx.upload(x, labels, qoff)
+            self.ctx.build_bins(args.nthresholds)
+            self.ctx.reset_scores()
+            self.comm = None
+            if layout == "features":
+                from quickrank_amd.dist import ShardedTreeFitter
+                self.fitter = ShardedTreeFitter(self.ctx)
+                self.comm = self.fitter.direct
+        self.ndcg, self.trees = [], []
+
+    def step(self):
+        # ranking + NDCG@10 of the current scores (= the training metric the
+        # reference evaluates at the end of the previous iteration, mart.cc:347)
+        # + lambdas/weights in one pass over the queries; tree; leaf outputs; score
+        # update.  Everything is enqueued first; the metric and the tree records are
+        # read last (pinned snapshots + events), so the host never drains the stream
+        # in the middle of an iteration.
+        a, ctx = self.args, self.ctx
+        if self.trainer is not None:
+            self.trainer.compute_lambdas("NDCG", 10)
+            self.trainer.fit_tree(a.nleaves, 1, True, read=False)
+        else:
+            ctx.compute_lambdas("NDCG", 10)
+            if self.fitter is not None:
+                self.fitter.fit_tree(ctx, a.nleaves, 1, True, read=False)
+            else:
+                ctx.fit_tree(a.nleaves, 1, True, read=False)
+        ctx.update_scores(0.1)
+        self.ndcg.append(ctx.metric_last())
+        self.trees.append(ctx.tree_nodes())
+
+    def sync(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, prof=False):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both
+        sides; returns the max over ranks of the elapsed seconds."""
+        for _ in range(warmup):
+            self.step()
+        if prof:
+            self.ctx.prof_enable(True)
+            self.ctx.prof_reset()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        self.steps, self.elapsed = steps, elapsed
+        return elapsed
+
+    def trees_identical_across_ranks(self):
+        """Every rank must have built the same trees (structure bit for bit)."""
+        if self.dist is None:
+            return True
+        import hashlib
+        h = hashlib.sha256()
+        for t in self.trees:
+            for k in ("feature", "thr_id", "left", "right", "nsamples"):
+                h.update(np.ascontiguousarray(t[k]).tobytes())
+        parts = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(parts, h.hexdigest())
+        return len(set(parts)) == 1
+
+    def summary(self, what, parallelism):
+        sh = [tree_shape(t) for t in self.trees[-self.steps:]]
+        return {"workload": what, "parallelism": parallelism,
+                "value": self.n_global * self.steps / self.elapsed, "unit": "docs/s",
+                "ms_per_step": self.elapsed / self.steps * 1e3, "steps": self.steps,
+                "ndcg10_last": self.ndcg[-1] if self.ndcg else None,
+                "sigma_built": round(float(np.mean([a[0] for a in sh])), 3),
+                "sigma_reference_left": round(float(np.mean([a[1] for a in sh])), 3),
+                "pi": round(float(np.mean([a[2] for a in sh])), 3),
+                "collectives": ("rccl-direct on the context's stream, nranks "
+                                f"{self.comm.nranks}" if self.comm is not None else
+                                ("torch.distributed" if self.dist is not None and self.layout != "single"
+                                 else "none"))}
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+        self.ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,16 +344,19 @@ def main():
     ap.add_argument("--no-scoring", action="store_true")
     ap.add_argument("--score-trees", type=int, default=10000)
     ap.add_argument("--score-docs", type=int, default=10000000)
-    ap.add_argument("--cpu-queries", type=int, default=2500)
+    ap.add_argument("--cpu-queries", type=int, default=0, help="0 = the whole set")
+    ap.add_argument("--cpu-score-docs", type=int, default=20000)
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--sparse-cols", type=int, default=0,
                     help="make the last K feature columns MSLR-like sparse counts (robustness runs)")
     ap.add_argument("--zero-frac", type=float, default=0.9)
-    ap.add_argument("--shard", choices=["docs", "features"], default="docs")
-    ap.add_argument("--no-config2", action="store_true",
-                    help="N > 1, --shard docs: skip the extra feature-sharded (config 2) measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline measurement (no weak-scaling / 8M / child-histogram passes)")
+    ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of the extra measurements")
+    ap.add_argument("--big-blocks", type=int, default=8,
+                    help="the larger strong-scaling set: this many 1M-document blocks (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="run the N > 1 code path (process group, sharded driver) with one rank")
+                    help="run the N > 1 code path (process group, sharded drivers) with one rank")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): libraries that print banners to
@@ -184,183 +388,164 @@ def main():
         qbuild.build()
     if dist is not None:
         dist.barrier()
-    from quickrank_amd._capi import Context
 
-    docs_mode = multi and args.shard == "docs"
-    x, labels, qoff = synth(args.queries, args.docs_per_query, args.features,
-                            seed=42 + rank if docs_mode else 42, sparse_cols=args.sparse_cols,
-                            zero_frac=args.zero_frac)
-    N, F = x.shape
-    n_job = N * world if docs_mode else N        # documents one step processes
-    stream = torch.cuda.current_stream().cuda_stream if multi else None
-    fitter = trainer = None
-    if docs_mode:
-        from quickrank_amd.dist import DocShardedTrainer, gather_thresholds
-        ctx = Context(local_rank, rank=rank, world=world, stream=stream,
-                      doc_shard=(n_job, args.queries * world))
-        ctx.upload(x, labels, qoff)
-        ctx.build_bins_with(*gather_thresholds(ctx, args.nthresholds))
-        ctx.reset_scores()
-        trainer = DocShardedTrainer(ctx)
-    else:
-        ctx = Context(local_rank, rank=rank, world=world, stream=stream)
-        ctx.upload(x, labels, qoff)
-        ctx.build_bins(args.nthresholds)
-        ctx.reset_scores()
-        if multi:
-            from quickrank_amd.dist import ShardedTreeFitter
-            fitter = ShardedTreeFitter(ctx)
+    Q, DPQ, F = args.queries, args.docs_per_query, args.features
+    x, labels, qoff = synth(Q, DPQ, F, seed=42, sparse_cols=args.sparse_cols, zero_frac=args.zero_frac)
+    N = len(labels)
+    desc = (f"LambdaMART {args.nleaves} leaves, {args.nthresholds} thresholds, NDCG@10, shrinkage 0.1, "
+            "min-leaf-support 1"
+            + (f", last {args.sparse_cols} columns sparse counts ({args.zero_frac:.0%} zeros)"
+               if args.sparse_cols else ""))
+    same_set = f"synthetic {N} docs x {F} features x {Q} queries"
 
-    ndcg, trees = [], []
+    def doc_slice(nq_total, r, w):
+        """Whole queries [q0, q1) of rank r of w."""
+        per = (nq_total + w - 1) // w
+        return min(nq_total, per * r), min(nq_total, per * (r + 1))
 
-    def step():
-        # ranking + NDCG@10 of the current scores (= the training metric the
-        # reference evaluates at the end of the previous iteration, mart.cc:347)
-        # + lambdas/weights in one pass over the queries; tree; leaf outputs; score
-        # update.  Everything is enqueued first; the metric and the tree records are
-        # read last (pinned snapshots + events), so the host never drains the stream
-        # in the middle of an iteration.
-        if trainer is not None:
-            trainer.compute_lambdas("NDCG", 10)
-            trainer.fit_tree(args.nleaves, 1, True, read=False)
-        else:
-            ctx.compute_lambdas("NDCG", 10)
-            if fitter is not None:
-                fitter.fit_tree(ctx, args.nleaves, 1, True, read=False)
-            else:
-                ctx.fit_tree(args.nleaves, 1, True, read=False)
-        ctx.update_scores(0.1)
-        ndcg.append(ctx.metric_last())
-        trees.append(ctx.tree_nodes())
+    def mk(layout, xx, ll, qq, n_global, q_global):
+        return Run(torch, dist, layout, xx, ll, qq, n_global, q_global, args, rank, world, local_rank)
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    ctx.prof_enable(True)
-    ctx.prof_reset()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    prof = ctx.prof_get()
-    ctx.prof_enable(False)
-
-    # BASELINE.json configs[2] literally: the SAME 1M x 136 set on every rank, feature
-    # blocks of the bin matrix sharded, total work fixed ("strong").  Reported next
-    # to the headline when the headline is the document-sharded layout.
-    config2 = None
-    if docs_mode and not args.no_config2:
-        from quickrank_amd.dist import ShardedTreeFitter
-        xf, lf, qf = synth(args.queries, args.docs_per_query, args.features, seed=42)
-        c2 = Context(local_rank, rank=rank, world=world, stream=stream)
-        c2.upload(xf, lf, qf)
-        c2.build_bins(args.nthresholds)
-        c2.reset_scores()
-        f2 = ShardedTreeFitter(c2)
-
-        def step2():
-            c2.compute_lambdas("NDCG", 10)
-            f2.fit_tree(c2, args.nleaves, 1, True, read=False)
-            c2.update_scores(0.1)
-            c2.metric_last()
-            c2.tree_nodes()
-        for _ in range(args.warmup):
-            step2()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step2()
-        sync()
-        e2 = time.perf_counter() - t0
-        t = torch.tensor([e2], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        e2 = float(t.item())
-        config2 = {"workload": f"the same {len(lf)} docs x {xf.shape[1]} features on every rank",
-                   "parallelism": f"feature-block sharding x{world}: best-split records all-gather + "
-                                  "go-left mask all-reduce per split",
-                   "scaling": "strong", "value": len(lf) * args.steps / e2, "unit": "docs/s",
-                   "ms_per_step": e2 / args.steps * 1e3}
-        c2.close()
-        del xf, lf, qf
-
-    def tree_shape(t):
-        # sigma = documents whose histogram is built directly per
-        # tree / N (we build the smaller child; the reference always the left one),
-        # pi = documents partitioned per tree / N
-        internal = np.nonzero(t["feature"] >= 0)[0]
-        nl = t["nsamples"][t["left"][internal]].astype(np.float64)
-        nr = t["nsamples"][t["right"][internal]].astype(np.float64)
-        tot = float(t["nsamples"][0])
-        return (np.minimum(nl, nr).sum() / tot, nl.sum() / tot,
-                t["nsamples"][internal].astype(np.float64).sum() / tot)
-
-    scoring = None
-    if not args.no_scoring:   # every rank takes part (its shard of the documents)
-        scoring = scoring_metric(ctx, args, torch, rank, world, dist)
-
-    if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = n_job * args.steps / elapsed
-        roof = None
+    extras, roof, roof_child, roof_iter = {}, None, None, None
+    if not multi:
+        # ---- N = 1: BASELINE.json configs[1] on one GPU ---------------------------
+        head = mk("single", x, labels, qoff, N, Q)
+        head.timed(args.steps, args.warmup, prof=True)
+        prof = head.ctx.prof_get()
+        head.ctx.prof_enable(False)
+        hs = head.summary(same_set + ", " + desc, "1 GPU")
+        scaling = None
         if prof["launches"]:
             sec = prof["total_ms"] / prof["launches"] * 1e-3
             ach = prof["alg_bytes"] / sec / 1e9
-            # HBM bytes per launch from the PMC passes committed under profiles/
-            # (collected separately: counters cannot be read inside this process);
-            # only quoted when it was measured on this very workload
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hist.json")
-            if (os.path.exists(pmc) and world == 1 and N == 1000000 and F == 136
-                    and args.nthresholds == 255):
+            # HBM bytes per launch from the PMC passes committed under profiles/ (counters
+            # cannot be read inside this process): quoted with its source, and only when it
+            # was collected on this very workload with the kernel as it is now
+            traffic, tsrc = None, None
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_hist.json")
+            if os.path.exists(pmc) and N == 1000000 and F == 136 and args.nthresholds == 255 \
+                    and not args.sparse_cols:
                 traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+                tsrc = "profiles/r02_pmc_hist.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
             roof = {"bound": "hbm", "kernel": "k_hist_root (root histogram build)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                     "alg_bytes_per_launch": prof["alg_bytes"],
                     "avg_launch_us": round(sec * 1e6, 2), "launches": prof["launches"]}
+        ib = iteration_alg_bytes(N, F, args.nleaves, hs["sigma_built"], hs["pi"])
+        ia = ib / (hs["ms_per_step"] * 1e-3) / 1e9
+        roof_iter = {"bound": "hbm", "what": "whole boosting iteration (every kernel, launch gaps included)",
+                     "alg_bytes_per_step": ib, "achieved": round(ia, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(ia / HBM_PEAK_GBS, 4)}
+        if not args.no_extras:
+            # child-histogram launches, timed with HIP events on the launches in a
+            # separate short pass (the events would perturb the headline's host loop)
+            head.ctx.prof_enable(True, children=True)
+            head.ctx.prof_reset()
+            n0 = len(head.trees)
+            for _ in range(args.extra_steps):
+                head.step()
+            pc = head.ctx.prof_get_child()
+            head.ctx.prof_enable(False)
+            built = sum(tree_shape(t)[0] for t in head.trees[n0:]) * N   # documents built directly
+            if pc["launches"]:
+                cb = built * (F + 12) + sum(int((t["feature"] >= 0).sum()) for t in head.trees[n0:]) * F * 256 * 16
+                ca = cb / (pc["total_ms"] * 1e-3) / 1e9
+                roof_child = {"bound": "hbm", "kernel": "k_hist_batch (child histograms, all launches of a tree)",
+                              "alg_bytes_per_tree": cb / args.extra_steps, "achieved": round(ca, 1),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ca / HBM_PEAK_GBS, 4),
+                              "launches_per_tree": pc["launches"] / args.extra_steps,
+                              "us_per_tree": round(pc["total_ms"] * 1e3 / args.extra_steps, 1)}
+    else:
+        # ---- N > 1: the SAME set, strong scaling (BASELINE.json configs[2]) ---------
+        q0, q1 = doc_slice(Q, rank, world)
+        a, b = int(qoff[q0]), int(qoff[q1])
+        runs = {}
+        r = mk("docs", x[a:b], labels[a:b], qoff[q0:q1 + 1] - qoff[q0], N, Q)
+        r.timed(args.steps, args.warmup)
+        runs["document_sharded"] = (r.summary(same_set + f" ({b - a} docs on rank {rank}), " + desc,
+                                              f"document sharding x{world}: one int64 all-reduce per node "
+                                              "histogram (12 per iteration)"), r.trees_identical_across_ranks())
+        r.close()
+        r = mk("features", x, labels, qoff, N, Q)
+        r.timed(args.steps, args.warmup)
+        runs["feature_sharded"] = (r.summary(same_set + " on every rank, " + desc,
+                                             f"feature-block sharding x{world} (north_star's layout): best-split "
+                                             "records all-gather + go-left mask all-reduce per split"),
+                                   r.trees_identical_across_ranks())
+        r.close()
+        for k, (sm, same) in runs.items():
+            if not same:
+                raise SystemExit(f"bench.py: ranks built different trees in the {k} layout -- refusing to report")
+            sm["trees_identical_across_ranks"] = True
+        best = max(runs, key=lambda k: runs[k][0]["value"])
+        hs = runs[best][0]
+        scaling = "strong"
+        extras["strong_layouts"] = {k: v[0] for k, v in runs.items()}
+    if not args.no_extras and (multi or args.big_blocks):
+        es = args.extra_steps
+        if multi:
+            # weak scaling: every rank its OWN 1M-document shard (seed 42 + rank)
+            xw, lw, qw = synth(Q, DPQ, F, seed=42 + rank)
+            r = mk("docs", xw, lw, qw, N * world, Q * world)
+            r.timed(es, args.warmup)
+            extras["weak_scaling"] = dict(r.summary(f"synthetic {N * world} docs ({N} per GPU) x {F} features, " + desc,
+                                                    f"document sharding x{world}"), scaling="weak")
+            r.close()
+            del xw, lw, qw
+        if args.big_blocks:
+            # a larger strong-scaling set (blocks of 1M documents, seeds 142 + block): at 1M
+            # documents an iteration is a chain of ~40 launches of a few microseconds each and
+            # no layout can divide that; here the per-document work dominates
+            nb = args.big_blocks
+            b0, b1 = doc_slice(nb, rank, world) if multi else (0, nb)
+            parts = [synth(Q, DPQ, F, seed=142 + blk) for blk in range(b0, b1)]
+            xb = np.concatenate([p_[0] for p_ in parts]) if parts else x[:0]
+            lb = np.concatenate([p_[1] for p_ in parts]) if parts else labels[:0]
+            qb = np.arange(len(lb) // DPQ + 1, dtype=np.uint64) * DPQ
+            del parts
+            r = mk("docs" if multi else "single", xb, lb, qb, N * nb, Q * nb)
+            r.timed(es, min(args.warmup, 3))
+            extras[f"strong_{nb}M"] = dict(
+                r.summary(f"synthetic {N * nb} docs x {F} features x {Q * nb} queries"
+                          + (f" ({len(lb)} on rank {rank})" if multi else "") + ", " + desc,
+                          f"document sharding x{world}" if multi else "1 GPU"), scaling="strong")
+            r.close()
+            del xb, lb, qb
+
+    scoring = None
+    if not args.no_scoring:   # every rank takes part (its shard of the documents)
+        scoring = scoring_metric(None, args, torch, rank, world, dist if world > 1 else None)
+
+    if rank == 0:
         out = {
             "metric": "docs/sec per LambdaMART boosting iter (1Mx136)",
-            "value": value, "unit": "docs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak" if docs_mode or world == 1 else "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic {n_job} docs x {F} features x "
-                                   f"{args.queries * (world if docs_mode else 1)} queries"
-                                   + (f" ({N} docs per GPU)" if docs_mode else "") + ", "
-                                   f"LambdaMART {args.nleaves} leaves, {args.nthresholds} thresholds, "
-                                   "NDCG@10, shrinkage 0.1, min-leaf-support 1"
-                                   + (f", last {args.sparse_cols} columns sparse counts ({args.zero_frac:.0%} zeros)"
-                                      if args.sparse_cols else ""),
-                       "parallelism": "1 GPU" if world == 1 else
-                                      (f"document sharding x{world}: one int64 all-reduce per node histogram"
-                                       if docs_mode else f"feature-block sharding x{world}"),
-                       "ndcg10_last": ndcg[-1] if ndcg else None,
-                       "sigma_built": round(float(np.mean([tree_shape(t)[0] for t in trees[-args.steps:]])), 3),
-                       "sigma_reference_left": round(float(np.mean([tree_shape(t)[1] for t in trees[-args.steps:]])), 3),
-                       "pi": round(float(np.mean([tree_shape(t)[2] for t in trees[-args.steps:]])), 3)},
+            "value": hs["value"], "unit": "docs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": hs["ms_per_step"], "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {k: hs[k] for k in ("workload", "parallelism", "ndcg10_last", "sigma_built",
+                                          "sigma_reference_left", "pi", "collectives")},
             "roofline": roof,
         }
-        if config2 is not None:
-            out["config2_feature_sharded"] = config2
-        if world == 1 and not args.no_cpu_baseline:
+        if roof_iter is not None:
+            out["roofline_iteration"] = roof_iter
+        if roof_child is not None:
+            out["roofline_child_hist"] = roof_child
+        out.update(extras)
+        if world == 1 and not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x, labels, qoff, args)
         if scoring is not None:
+            if world == 1 and not args.no_cpu_baseline:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                from score_bench import make_model
+                scoring["cpu_baseline"] = cpu_scoring_baseline(args, make_model)
             out["ensemble_scoring"] = scoring
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    ctx.close()
+    if not multi:
+        head.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -94,8 +94,12 @@ int qr_synchronize(qr_ctx *ctx);
 /* rowmajor: host f32 [N][F] (Dataset::at, dataset.h:65-67); qoff: [Q+1]         */
 int qr_dataset_upload(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
                       const float *labels, const uint64_t *qoff, size_t Q);
-/* optional validation set (mart.cc:231-233, 354-360)                            */
-int qr_valid_upload(qr_ctx *ctx, const float *rowmajor, size_t N,
+/* optional validation set (mart.cc:231-233, 354-360).  rowmajor: host f32 [N][F]  */
+/* with the validation file's OWN width F (the SVMLight reader sets it to the       */
+/* largest feature id of each file): columns the training set has and this one      */
+/* lacks read as 0 (SVMLight's meaning of an absent feature), columns beyond the     */
+/* training width are never tested by a tree and are dropped.                        */
+int qr_valid_upload(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
                     const float *labels, const uint64_t *qoff, size_t Q);
 /* thresholds + uint8 bin map.  nthresholds in [1,255], or 0 (= every unique     */
 /* value) if no feature has more than 255 uniques (else QR_ERR_UNSUPPORTED).     */
@@ -258,12 +262,21 @@ int qr_ranks_read(qr_ctx *ctx, uint32_t *out);
 int qr_ensemble_upload(qr_ctx *ctx, const qr_node_t *nodes, size_t ntrees,
                        size_t max_nodes, const double *weights);
 /* rowmajor: HOST f32 [N][F]; scores_out: host f64 [N].  Timing of the kernel    */
-/* alone (features resident) is returned in *kernel_ms when non-NULL.            */
+/* alone (features resident) is returned in *kernel_ms when non-NULL.  A matrix   */
+/* narrower than the model's largest tested feature is zero-padded on the way up   */
+/* (an absent SVMLight feature is 0); wider is fine.                              */
 int qr_ensemble_score(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
                       double *scores_out, float *kernel_ms);
-/* same, features already resident on the device (device pointer)               */
+/* same, features already resident on the device (device pointer); F must cover   */
+/* every feature the model tests (QR_ERR_ARG otherwise: nothing to pad in place)  */
 int qr_ensemble_score_device(qr_ctx *ctx, const void *d_rowmajor, size_t N,
                              size_t F, void *d_scores_out);
+
+/* Ensemble::partial_scores_instance (ensemble.cc:120-131), the per-tree outputs     */
+/* behind `--detailed` (driver.cc:326-347, 411-445): out is host f64 [N][ntrees],    */
+/* out[d][t] = tree_t(x_d) * weight_t, or tree_t(x_d) alone when ignore_weights.      */
+int qr_ensemble_partial_scores(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
+                               int ignore_weights, double *out);
 
 /* ---- oblivious ensembles: the bit-interleaved scorer `quicklearn --generator    */
 /*      oblivious` emits (generate_oblivious.cc:237-324).  feat/thr: [ntrees][depth]*/
@@ -282,7 +295,12 @@ int qr_oblivious_score(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
 int qr_prof_reset(qr_ctx *ctx);
 int qr_prof_get(qr_ctx *ctx, uint64_t *launches, double *total_ms,
                 double *alg_bytes_per_launch);
+/* on: bit 0 = time the root histogram launches, bit 1 = also the child launches  */
 int qr_prof_enable(qr_ctx *ctx, int on);
+/* child-histogram launches (k_hist_batch) since the last reset; their algorithmic */
+/* bytes depend on the trees: sum over splits of n_small * (F + 12), from the       */
+/* records qr_tree_nodes returns                                                     */
+int qr_prof_get_child(qr_ctx *ctx, uint64_t *launches, double *total_ms);
 
 #ifdef __cplusplus
 }

@@ -39,7 +39,8 @@ SYMBOLS = [
     "qr_ctx_set_doc_shard", "qr_bins_stats", "qr_thresholds_from_stats",
     "qr_bins_build_with", "qr_lambda_finish", "qr_tree_leaves_finish",
     "qr_doc_exchange_buffers", "qr_tree_nodes", "qr_valid_scores_set",
-    "qr_tree_set_max_features", "qr_subsample_set",
+    "qr_tree_set_max_features", "qr_subsample_set", "qr_ensemble_partial_scores",
+    "qr_prof_get_child",
 ]
 
 _LIB = None
@@ -82,7 +83,7 @@ def lib():
     L.qr_ctx_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.qr_synchronize.argtypes = [vp]
     L.qr_dataset_upload.argtypes = [vp, vp, sz, sz, vp, vp, sz]
-    L.qr_valid_upload.argtypes = [vp, vp, sz, vp, vp, sz]
+    L.qr_valid_upload.argtypes = [vp, vp, sz, sz, vp, vp, sz]
     L.qr_bins_build.argtypes = [vp, sz, vp, vp]
     L.qr_bins_read.argtypes = [vp, vp]
     L.qr_scores_reset.argtypes = [vp]
@@ -113,11 +114,13 @@ def lib():
     L.qr_ensemble_upload.argtypes = [vp, vp, sz, sz, vp]
     L.qr_ensemble_score.argtypes = [vp, vp, sz, sz, vp, C.POINTER(C.c_float)]
     L.qr_ensemble_score_device.argtypes = [vp, vp, sz, sz, vp]
+    L.qr_ensemble_partial_scores.argtypes = [vp, vp, sz, sz, C.c_int, vp]
     L.qr_oblivious_upload.argtypes = [vp, vp, vp, vp, vp, vp, sz, sz]
     L.qr_oblivious_score.argtypes = [vp, vp, sz, sz, vp, C.POINTER(C.c_float)]
     L.qr_prof_reset.argtypes = [vp]
     L.qr_prof_get.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.qr_prof_enable.argtypes = [vp, C.c_int]
+    L.qr_prof_get_child.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double)]
     L.qr_ctx_set_doc_shard.argtypes = [vp, C.c_int, C.c_int, u64, u64]
     L.qr_bins_stats.argtypes = [vp, sz, vp, vp, vp]
     L.qr_thresholds_from_stats.argtypes = [sz, sz, sz, vp, vp, vp, vp, vp]
@@ -172,8 +175,9 @@ class Context:
         self.h = h
         self.N = self.F = self.Q = 0
         self.vN = self.vQ = 0
+        self.stream = None          # None: the context's own stream
         if stream is not None:
-            self._ck(self.L.qr_ctx_set_stream(self.h, C.c_void_p(stream)))
+            self.set_stream(stream)
         if doc_shard is not None:
             self._ck(self.L.qr_ctx_set_doc_shard(self.h, rank, world, int(doc_shard[0]),
                                                  int(doc_shard[1])))
@@ -185,6 +189,11 @@ class Context:
     def _ck(self, rc):
         if rc:
             raise QrError(f"{self.L.qr_last_error(self.h).decode()} (code {rc})")
+
+    def set_stream(self, stream):
+        """Run every launch on the caller's HIP stream (qr_ctx_set_stream)."""
+        self._ck(self.L.qr_ctx_set_stream(self.h, C.c_void_p(stream)))
+        self.stream = stream
 
     def close(self):
         if getattr(self, "h", None):
@@ -213,8 +222,8 @@ class Context:
         qoff = np.ascontiguousarray(qoff, np.uint64)
         self.vN = x.shape[0]
         self.vQ = len(qoff) - 1
-        self._ck(self.L.qr_valid_upload(self.h, _ptr(x), self.vN, _ptr(labels), _ptr(qoff),
-                                        len(qoff) - 1))
+        self._ck(self.L.qr_valid_upload(self.h, _ptr(x), self.vN, x.shape[1], _ptr(labels),
+                                        _ptr(qoff), len(qoff) - 1))
 
     def build_bins(self, nthresholds):
         thr = np.empty((self.F, QR_MAX_BINS), np.float32)
@@ -423,6 +432,14 @@ class Context:
                                           C.byref(ms)))
         return out, ms.value
 
+    def partial_scores(self, x, ntrees, ignore_weights=False):
+        """Ensemble::partial_scores_instance for every row: f64 [N][ntrees]."""
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty((x.shape[0], ntrees), np.float64)
+        self._ck(self.L.qr_ensemble_partial_scores(self.h, _ptr(x), x.shape[0], x.shape[1],
+                                                   int(ignore_weights), _ptr(out)))
+        return out
+
     def upload_oblivious(self, feat, thr, leaves, weights, depths=None):
         feat = np.ascontiguousarray(feat, np.uint32)
         thr = np.ascontiguousarray(thr, np.float32)
@@ -443,8 +460,13 @@ class Context:
         return out, ms.value
 
     # -- instrumentation ------------------------------------------------------
-    def prof_enable(self, on=True):
-        self._ck(self.L.qr_prof_enable(self.h, int(on)))
+    def prof_enable(self, on=True, children=False):
+        self._ck(self.L.qr_prof_enable(self.h, int(bool(on)) | (2 if children else 0)))
+
+    def prof_get_child(self):
+        n, ms = C.c_uint64(), C.c_double()
+        self._ck(self.L.qr_prof_get_child(self.h, C.byref(n), C.byref(ms)))
+        return dict(launches=n.value, total_ms=ms.value)
 
     def prof_reset(self):
         self._ck(self.L.qr_prof_reset(self.h))

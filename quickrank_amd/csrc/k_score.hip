@@ -25,7 +25,9 @@ __global__ __launch_bounds__(SC_DOCS) void k_ensemble_score(
     const float *__restrict__ x, const uint32_t N, const uint32_t F,
     const qr_node_t *__restrict__ nodes, const double *__restrict__ weights,
     const uint32_t ntrees, const uint32_t max_nodes, const uint32_t tbatch,
-    double *__restrict__ out) {
+    double *__restrict__ out, double *__restrict__ partial, const int ignore_weights) {
+  // partial != null: Ensemble::partial_scores_instance (ensemble.cc:120-131) -- the
+  // per-tree outputs [N][ntrees], times the tree weight unless ignore_weights
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *rows = reinterpret_cast<float *>(smem);                 // [SC_DOCS][F+1]
   const uint32_t fs = F | 1;                                     // odd stride
@@ -64,16 +66,22 @@ __global__ __launch_bounds__(SC_DOCS) void k_ensemble_score(
           n = my[cur.feat] <= cur.thr ? cur.left : cur.right;
           cur = tr[n];
         }
+        if (partial) {
+          double pv = tval[t * max_nodes + n];
+          if (!ignore_weights) pv *= weights[t0 + t];
+          partial[(size_t)(d0 + threadIdx.x) * ntrees + t0 + t] = pv;
+          continue;
+        }
         const double v = tval[t * max_nodes + n] * weights[t0 + t];
         sum = sum + v;
       }
     }
   }
-  if (threadIdx.x < nd) out[d0 + threadIdx.x] = sum;
+  if (threadIdx.x < nd && out) out[d0 + threadIdx.x] = sum;
 }
 
 int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
-                        double *d_out) {
+                        double *d_out, double *d_partial, int ignore_weights) {
   if (!c->d_ens) QR_FAIL(c, QR_ERR_STATE, "no ensemble uploaded");
   const size_t fs = F | 1;
   const size_t rows_bytes = ((size_t)SC_DOCS * fs * 4 + 15) & ~(size_t)15;
@@ -92,7 +100,7 @@ int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
   hipLaunchKernelGGL(k_ensemble_score, dim3(grid), dim3(SC_DOCS), lds, c->stream,
                      d_x, (uint32_t)N, (uint32_t)F, c->d_ens, c->d_ens_w,
                      (uint32_t)c->ens_trees, (uint32_t)c->ens_maxnodes,
-                     (uint32_t)tbatch, d_out);
+                     (uint32_t)tbatch, d_out, d_partial, ignore_weights);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

@@ -2871,6 +2871,15 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
                          c->d_order[1], (u64 *)c->d_bpart_state, c->d_lambda, PSS[s & 1]);
       QR_CHECK(c, hipGetLastError());
     }
+    if (c->prof_on && c->prof_child) {  // bench.py's roofline_child_hist: events on the launch itself
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      QR_CHECK(c, hipEventCreate(&e0));
+      QR_CHECK(c, hipEventCreate(&e1));
+      hipExtLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, e0, e1, 0, c->d_lhist_wg,
+                            c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
+                            c->d_scalars, (u64 *)c->d_lpartials);
+      c->prof_events_child.push_back({e0, e1});
+    } else
     hipLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, c->d_lhist_wg,
                        c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
                        c->d_scalars, (u64 *)c->d_lpartials);

@@ -144,6 +144,10 @@ void qr_ctx_destroy(qr_ctx *c) {
     (void)hipEventDestroy(p.first);
     (void)hipEventDestroy(p.second);
   }
+  for (auto &p : c->prof_events_child) {
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -278,15 +282,28 @@ int qr_dataset_upload(qr_ctx *c, const float *x, size_t N, size_t F,
   return ensure_lg2(c);
 }
 
-int qr_valid_upload(qr_ctx *c, const float *x, size_t N, const float *labels,
+// rows of width F re-laid to width Fto: missing columns read 0, surplus ones are dropped
+static std::vector<float> repad_rows(const float *x, size_t N, size_t F, size_t Fto) {
+  std::vector<float> out(N * Fto, 0.0f);
+  const size_t w = std::min(F, Fto);
+  for (size_t i = 0; i < N; ++i) memcpy(&out[i * Fto], x + i * F, w * sizeof(float));
+  return out;
+}
+
+int qr_valid_upload(qr_ctx *c, const float *x, size_t N, size_t F, const float *labels,
                     const uint64_t *qoff, size_t Q) {
   if (!c) return QR_ERR_ARG;
   if (!c->F) QR_FAIL(c, QR_ERR_STATE, "upload the training set first");
-  if (!x || !labels || !qoff || N == 0) QR_FAIL(c, QR_ERR_ARG, "empty validation set");
+  if (!x || !labels || !qoff || N == 0 || F == 0) QR_FAIL(c, QR_ERR_ARG, "empty validation set");
   free_valid(c);
   c->vN = N; c->vQ = Q;
   QR_CHECK(c, dalloc(&c->d_vraw, N * c->F));
-  QR_CHECK(c, hipMemcpy(c->d_vraw, x, N * c->F * 4, hipMemcpyHostToDevice));
+  if (F == c->F) {
+    QR_CHECK(c, hipMemcpy(c->d_vraw, x, N * c->F * 4, hipMemcpyHostToDevice));
+  } else {  // the validation file's own width: re-laid to the training stride
+    const std::vector<float> padded = repad_rows(x, N, F, c->F);
+    QR_CHECK(c, hipMemcpy(c->d_vraw, padded.data(), N * c->F * 4, hipMemcpyHostToDevice));
+  }
   QR_CHECK(c, dalloc(&c->d_vlabels, N));
   QR_CHECK(c, hipMemcpy(c->d_vlabels, labels, N * 4, hipMemcpyHostToDevice));
   c->h_vlabels.assign(labels, labels + N);
@@ -1217,12 +1234,18 @@ int qr_ensemble_upload(qr_ctx *c, const qr_node_t *nodes, size_t ntrees,
   QR_CHECK(c, hipMemcpy(c->d_ens_w, weights, ntrees * 8, hipMemcpyHostToDevice));
   c->ens_trees = ntrees;
   c->ens_maxnodes = max_nodes;
+  c->ens_maxf = -1;
+  for (size_t i = 0; i < ntrees * max_nodes; ++i) c->ens_maxf = std::max(c->ens_maxf, (int)nodes[i].feature);
   return build_binned_model(c, nodes, ntrees, max_nodes);
 }
 
 // features with index >= sb_F are never tested by the model, so a wider matrix
 // is fine for the fast path as long as the row stride is passed along
 static int score_any(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out) {
+  if (!c->d_ens) QR_FAIL(c, QR_ERR_STATE, "no ensemble uploaded");
+  if (c->ens_maxf >= 0 && F <= (size_t)c->ens_maxf)
+    QR_FAIL(c, QR_ERR_ARG, "the model tests feature " + std::to_string(c->ens_maxf + 1) +
+                               " but the matrix has only " + std::to_string(F) + " columns");
   if (c->sb_ready && F >= c->sb_F) {
     const int rc = qr_k_ensemble_score_fast(c, d_x, N, F, d_out);
     if (rc >= 0) return rc;
@@ -1240,14 +1263,23 @@ int qr_ensemble_score(qr_ctx *c, const float *x, size_t N, size_t F, double *out
   if (!c || !x || !out || !N || !F) return QR_ERR_ARG;
   float *d_x = nullptr;
   double *d_o = nullptr;
-  QR_CHECK(c, dalloc(&d_x, N * F));
+  // a test file narrower than the model (its largest feature id is smaller): the
+  // missing columns are zeros, as for any absent SVMLight feature
+  size_t Fd = F;
+  if (c->ens_maxf >= 0 && F <= (size_t)c->ens_maxf) Fd = (size_t)c->ens_maxf + 1;
+  QR_CHECK(c, dalloc(&d_x, N * Fd));
   QR_CHECK(c, dalloc(&d_o, N));
-  QR_CHECK(c, hipMemcpy(d_x, x, N * F * 4, hipMemcpyHostToDevice));
+  if (Fd == F) {
+    QR_CHECK(c, hipMemcpy(d_x, x, N * F * 4, hipMemcpyHostToDevice));
+  } else {
+    const std::vector<float> padded = repad_rows(x, N, F, Fd);
+    QR_CHECK(c, hipMemcpy(d_x, padded.data(), N * Fd * 4, hipMemcpyHostToDevice));
+  }
   hipEvent_t e0, e1;
   QR_CHECK(c, hipEventCreate(&e0));
   QR_CHECK(c, hipEventCreate(&e1));
   QR_CHECK(c, hipEventRecord(e0, c->stream));
-  int rc = score_any(c, d_x, N, F, d_o);
+  int rc = score_any(c, d_x, N, Fd, d_o);
   QR_CHECK(c, hipEventRecord(e1, c->stream));
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   if (!rc) {
@@ -1258,6 +1290,38 @@ int qr_ensemble_score(qr_ctx *c, const float *x, size_t N, size_t F, double *out
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  dfree(d_x);
+  dfree(d_o);
+  return rc;
+}
+
+int qr_ensemble_partial_scores(qr_ctx *c, const float *x, size_t N, size_t F, int ignore_weights,
+                               double *out) {
+  if (!c || !x || !out || !N || !F) return QR_ERR_ARG;
+  if (!c->d_ens) QR_FAIL(c, QR_ERR_STATE, "no ensemble uploaded");
+  float *d_x = nullptr;
+  double *d_o = nullptr;
+  size_t Fd = F;
+  if (c->ens_maxf >= 0 && F <= (size_t)c->ens_maxf) Fd = (size_t)c->ens_maxf + 1;
+  const size_t T = c->ens_trees;
+  // [N][T] f64 on the device, in slabs of at most 1 GB
+  const size_t slab = std::max<size_t>(1, std::min(N, ((size_t)1 << 30) / (T * 8)));
+  QR_CHECK(c, dalloc(&d_x, slab * Fd));
+  QR_CHECK(c, dalloc(&d_o, slab * T));
+  int rc = QR_OK;
+  for (size_t d0 = 0; d0 < N && !rc; d0 += slab) {
+    const size_t n = std::min(slab, N - d0);
+    if (Fd == F) {
+      QR_CHECK(c, hipMemcpy(d_x, x + d0 * F, n * F * 4, hipMemcpyHostToDevice));
+    } else {
+      const std::vector<float> padded = repad_rows(x + d0 * F, n, F, Fd);
+      QR_CHECK(c, hipMemcpy(d_x, padded.data(), n * Fd * 4, hipMemcpyHostToDevice));
+    }
+    rc = qr_k_ensemble_score(c, d_x, n, Fd, nullptr, d_o, ignore_weights);
+    if (rc) break;
+    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    QR_CHECK(c, hipMemcpy(out + d0 * T, d_o, n * T * 8, hipMemcpyDeviceToHost));
+  }
   dfree(d_x);
   dfree(d_o);
   return rc;
@@ -1293,6 +1357,7 @@ int qr_oblivious_upload(qr_ctx *c, const uint32_t *feat, const float *thr,
   dfree(c->d_ob_fk); dfree(c->d_ob_thr); dfree(c->d_ob_thr_cnt);
   uint32_t maxf = 0;
   for (size_t i = 0; i < ntrees * depth; ++i) maxf = std::max(maxf, feat[i]);
+  c->obl_maxf = maxf;
   if (maxf < 65535) {
     const size_t F = (size_t)maxf + 1;
     std::vector<std::vector<float>> tv(F);
@@ -1333,11 +1398,19 @@ int qr_oblivious_upload(qr_ctx *c, const uint32_t *feat, const float *thr,
 int qr_oblivious_score(qr_ctx *c, const float *x, size_t N, size_t F, double *out,
                        float *kernel_ms) {
   if (!c || !x || !out || !N || !F) return QR_ERR_ARG;
+  if (!c->d_obl_feat) QR_FAIL(c, QR_ERR_STATE, "no oblivious ensemble uploaded");
   float *d_x = nullptr;
   double *d_o = nullptr;
+  const size_t Fin = F;
+  if (F <= (size_t)c->obl_maxf) F = (size_t)c->obl_maxf + 1;  // absent features are zeros
   QR_CHECK(c, dalloc(&d_x, N * F));
   QR_CHECK(c, dalloc(&d_o, N));
-  QR_CHECK(c, hipMemcpy(d_x, x, N * F * 4, hipMemcpyHostToDevice));
+  if (F == Fin) {
+    QR_CHECK(c, hipMemcpy(d_x, x, N * F * 4, hipMemcpyHostToDevice));
+  } else {
+    const std::vector<float> padded = repad_rows(x, N, Fin, F);
+    QR_CHECK(c, hipMemcpy(d_x, padded.data(), N * F * 4, hipMemcpyHostToDevice));
+  }
   hipEvent_t e0, e1;
   QR_CHECK(c, hipEventCreate(&e0));
   QR_CHECK(c, hipEventCreate(&e1));
@@ -1362,31 +1435,35 @@ int qr_oblivious_score(qr_ctx *c, const float *x, size_t N, size_t F, double *ou
 // ---------------------------------------------------------------------------
 int qr_prof_enable(qr_ctx *c, int on) {
   if (!c) return QR_ERR_ARG;
-  c->prof_on = on != 0;
+  c->prof_on = (on & 1) != 0;
+  c->prof_child = (on & 2) != 0;
   return QR_OK;
 }
 
 static int prof_drain(qr_ctx *c) {
-  if (c->prof_events.empty()) return QR_OK;
+  if (c->prof_events.empty() && c->prof_events_child.empty()) return QR_OK;
   QR_CHECK(c, hipStreamSynchronize(c->stream));
-  for (auto &p : c->prof_events) {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
-      c->prof_ms += ms;
-      c->prof_launches++;
+  for (int k = 0; k < 2; ++k) {
+    auto &ev = k ? c->prof_events_child : c->prof_events;
+    for (auto &p : ev) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+        (k ? c->prof_ms_child : c->prof_ms) += ms;
+        (k ? c->prof_launches_child : c->prof_launches)++;
+      }
+      (void)hipEventDestroy(p.first);
+      (void)hipEventDestroy(p.second);
     }
-    (void)hipEventDestroy(p.first);
-    (void)hipEventDestroy(p.second);
+    ev.clear();
   }
-  c->prof_events.clear();
   return QR_OK;
 }
 
 int qr_prof_reset(qr_ctx *c) {
   if (!c) return QR_ERR_ARG;
   int rc = prof_drain(c);
-  c->prof_ms = 0;
-  c->prof_launches = 0;
+  c->prof_ms = c->prof_ms_child = 0;
+  c->prof_launches = c->prof_launches_child = 0;
   return rc;
 }
 
@@ -1400,6 +1477,15 @@ int qr_prof_get(qr_ctx *c, uint64_t *launches, double *total_ms, double *alg_byt
   // F_loc*256*16 (result); no sample ids at the root.
   if (alg_bytes)
     *alg_bytes = (double)c->N * c->flocal + (double)c->N * 8 + (double)c->flocal * 256 * 16;
+  return QR_OK;
+}
+
+int qr_prof_get_child(qr_ctx *c, uint64_t *launches, double *total_ms) {
+  if (!c) return QR_ERR_ARG;
+  int rc = prof_drain(c);
+  if (rc) return rc;
+  if (launches) *launches = c->prof_launches_child;
+  if (total_ms) *total_ms = c->prof_ms_child;
   return QR_OK;
 }
 

@@ -380,6 +380,7 @@ struct qr_ctx {
   qr_node_t *d_ens = nullptr;
   double *d_ens_w = nullptr;
   size_t ens_trees = 0, ens_maxnodes = 0;
+  int ens_maxf = -1;             // largest feature index the ensemble tests
   // compact binned form of the ensemble (k_score_bin)
   bool sb_ready = false, sb_u8 = false;
   size_t sb_F = 0, sb_NI = 0, sb_NL = 0, sb_tmax = 0, sb_bins_bytes = 0;
@@ -393,6 +394,7 @@ struct qr_ctx {
   float *d_obl_thr = nullptr, *d_obl_w = nullptr;
   double *d_obl_leaves = nullptr;
   size_t obl_trees = 0, obl_depth = 0;
+  uint32_t obl_maxf = 0;
   // binned form of the oblivious ensemble (k_obl_score_bin)
   bool ob_ready = false, ob_u8 = false;
   size_t ob_F = 0, ob_tmax = 0;
@@ -401,9 +403,11 @@ struct qr_ctx {
   uint32_t *d_ob_thr_cnt = nullptr;
   // profiling
   bool prof_on = false;
+  bool prof_child = false;       // also time the child-histogram launches (qr_prof_enable(ctx, 2 | 1))
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-  uint64_t prof_launches = 0;
-  double prof_ms = 0.0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events_child;
+  uint64_t prof_launches = 0, prof_launches_child = 0;
+  double prof_ms = 0.0, prof_ms_child = 0.0;
   double prof_bytes = 0.0;
 };
 
@@ -445,7 +449,7 @@ int qr_k_scores_update(qr_ctx *c, double shrinkage);
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls);
 int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls);
 int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
-                        double *d_out);
+                        double *d_out, double *d_partial = nullptr, int ignore_weights = 0);
 int qr_k_obl_score(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);
 int qr_k_ensemble_score_fast(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);
 int qr_k_obl_score_fast(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);

@@ -31,6 +31,32 @@ class _DevArray:
             "data": (int(ptr), False), "version": 2}
 
 
+def _bind_stream(ctx, torch):
+    """The collectives below are enqueued on torch's current stream, the kernels on the
+    context's: both must be ONE stream, or the exchange buffers race with the kernels
+    that fill them.  Real contexts are moved onto torch's current stream here."""
+    if hasattr(ctx, "host_buffers") or not torch.cuda.is_available():
+        return None
+    s = torch.cuda.current_stream().cuda_stream
+    if getattr(ctx, "stream", None) != s:
+        ctx.set_stream(s)
+    return s
+
+
+def _direct_comm(ctx, torch, dist, group, stream):
+    """RCCL straight on the context's stream (RcclComm) unless QR_DIRECT_RCCL=0 or the
+    communicator cannot be created -- then torch.distributed carries the collectives."""
+    import os
+    import sys
+    if stream is None or os.environ.get("QR_DIRECT_RCCL", "1") == "0" or dist.get_backend(group) != "nccl":
+        return None
+    try:
+        return RcclComm(dist.get_rank(group), dist.get_world_size(group), stream, group)
+    except Exception as e:  # noqa: BLE001 -- any failure falls back to torch's path, loudly
+        print(f"quickrank_amd.dist: direct RCCL unavailable ({e}); using torch.distributed", file=sys.stderr)
+        return None
+
+
 class ShardedTreeFitter:
     """Drives qr_tree_begin/decide/apply/end with the collectives in between."""
 
@@ -42,27 +68,40 @@ class ShardedTreeFitter:
         self.rank = dist.get_rank(group)
         b = ctx.exchange_buffers()
         self.rec_bytes = b["rec_bytes"]
+        self.direct = None
         if hasattr(ctx, "host_buffers"):        # CPU protocol stand-in (tests)
             hb = ctx.host_buffers()
             self.recs_local = torch.from_numpy(hb["recs_local"])
             self.recs_all = torch.from_numpy(hb["recs_all"])
             self.mask = torch.from_numpy(hb["mask"])
         else:
+            stream = _bind_stream(ctx, torch)
             dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
             self.recs_local = torch.as_tensor(_DevArray(b["recs_local"], self.rec_bytes), device=dev)
             self.recs_all = torch.as_tensor(_DevArray(b["recs_all"], self.rec_bytes * self.world),
                                             device=dev)
             self.mask = torch.as_tensor(_DevArray(b["mask"], b["mask_bytes"], "<i4", 4), device=dev)
+            self.direct = _direct_comm(ctx, torch, dist, group, stream)
+            self._b = b
 
     def _gather_records(self):
+        if self.direct is not None:
+            self.direct.all_gather_bytes(self._b["recs_local"], self._b["recs_all"], self.rec_bytes)
+            return
         self.dist.all_gather_into_tensor(self.recs_all, self.recs_local, group=self.group)
+
+    def _reduce_mask(self):
+        if self.direct is not None:
+            self.direct.all_reduce_i32(self._b["mask"], self._b["mask_bytes"] // 4)
+            return
+        self.dist.all_reduce(self.mask, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def fit_tree(self, ctx, nleaves, minls, newton, read=True):
         ctx.tree_begin(nleaves, minls)
         self._gather_records()
         for _ in range(nleaves - 1):
             ctx.tree_decide()
-            self.dist.all_reduce(self.mask, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._reduce_mask()
             ctx.tree_apply()
             self._gather_records()
         ctx.tree_decide()
@@ -73,12 +112,11 @@ class ShardedTreeFitter:
 
 
 class RcclComm:
-    """ncclAllReduce straight from the library torch already loaded, on the context's
-    OWN stream: no hop to torch's collective stream, hence none of the cross-stream
-    event waits a torch.distributed call brackets every collective with (~6 us of
-    bubble each on this GPU).  torch.distributed is used once, to hand out the
-    ncclUniqueId.  Opt-in (QR_DIRECT_RCCL=1): exercised with one rank here, not yet
-    on several GPUs."""
+    """ncclAllReduce / ncclAllGather straight from the RCCL torch already loaded, on the
+    context's OWN stream: no hop to torch's collective stream, hence none of the
+    cross-stream event waits a torch.distributed call brackets every collective with
+    (~6 us of bubble each on this GPU).  torch.distributed is used once, to hand out the
+    ncclUniqueId.  The default on GPU runs (QR_DIRECT_RCCL=0 turns it off)."""
 
     def __init__(self, rank, world, stream, group=None):
         import ctypes as C
@@ -105,6 +143,11 @@ class RcclComm:
         self._ck(L.ncclCommInitRank(C.byref(self.comm), world, u, rank))
         L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p]
+        L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        n = C.c_int(0)
+        L.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._ck(L.ncclCommCount(self.comm, C.byref(n)))
+        self.nranks = n.value
 
     def _ck(self, rc):
         if rc:
@@ -114,6 +157,16 @@ class RcclComm:
         NCCL_INT64, NCCL_SUM = 4, 0
         self._ck(self.L.ncclAllReduce(self.C.c_void_p(ptr), self.C.c_void_p(ptr), count, NCCL_INT64,
                                       NCCL_SUM, self.comm, self.stream))
+
+    def all_reduce_i32(self, ptr, count):
+        NCCL_INT32, NCCL_SUM = 2, 0
+        self._ck(self.L.ncclAllReduce(self.C.c_void_p(ptr), self.C.c_void_p(ptr), count, NCCL_INT32,
+                                      NCCL_SUM, self.comm, self.stream))
+
+    def all_gather_bytes(self, send_ptr, recv_ptr, nbytes):
+        NCCL_INT8 = 0
+        self._ck(self.L.ncclAllGather(self.C.c_void_p(send_ptr), self.C.c_void_p(recv_ptr), nbytes,
+                                      NCCL_INT8, self.comm, self.stream))
 
     def close(self):
         if self.comm:
@@ -147,18 +200,15 @@ class DocShardedTrainer:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = device
+        stream = _bind_stream(ctx, torch)
         b = ctx.doc_exchange_buffers()
         self.hist = self._view(b["hist"], b["hist_n"], "hist")
         self.scal = self._view(b["scal"], b["scal_n"], "scal")
         self.leaf = None
         self.leaf_n = 0
-        # optional: collectives straight on the context's stream (see RcclComm)
-        self.direct = None
-        self._ptr = {id(self.hist): (b["hist"], b["hist_n"]), id(self.scal): (b["scal"], b["scal_n"])}
-        import os
-        if os.environ.get("QR_DIRECT_RCCL") == "1" and not hasattr(ctx, "host_buffers") \
-                and dist.get_backend(group) == "nccl":
-            self.direct = RcclComm(self.rank, self.world, torch.cuda.current_stream().cuda_stream, group)
+        # device (pointer, count) of the named exchange buffers, for the direct path
+        self._ptr = {"hist": (b["hist"], b["hist_n"]), "scal": (b["scal"], b["scal_n"])}
+        self.direct = None if hasattr(ctx, "host_buffers") else _direct_comm(ctx, torch, dist, group, stream)
 
     def _view(self, ptr, n, name):
         torch = self.torch
@@ -168,38 +218,40 @@ class DocShardedTrainer:
             torch.device("cuda", torch.cuda.current_device())
         return torch.as_tensor(_DevArray(ptr, n * 8, "<i8", 8), device=dev)
 
-    def _sum(self, t):
-        if self.direct is not None and id(t) in self._ptr:
-            self.direct.all_reduce_i64(*self._ptr[id(t)])
+    def _sum(self, t, name=None):
+        """Sum all-reduce of one of the context's exchange buffers (`name`) or of a
+        temporary tensor (name None: always through torch.distributed)."""
+        if self.direct is not None and name is not None:
+            self.direct.all_reduce_i64(*self._ptr[name])
             return
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def compute_lambdas(self, metric="NDCG", cutoff=10):
         self.ctx.compute_lambdas(metric, cutoff)
-        self._sum(self.scal)
+        self._sum(self.scal, "scal")
         self.ctx.lambda_finish()
 
     def compute_residuals(self):
         self.ctx.compute_residuals()
-        self._sum(self.scal)
+        self._sum(self.scal, "scal")
         self.ctx.lambda_finish()
 
     def fit_tree(self, nleaves, minls, newton, read=True):
         ctx = self.ctx
         ctx.tree_begin(nleaves, minls)
-        self._sum(self.hist)
+        self._sum(self.hist, "hist")
         for _ in range(nleaves - 1):
             ctx.tree_decide()
             ctx.tree_apply()
-            self._sum(self.hist)
+            self._sum(self.hist, "hist")
         ctx.tree_decide()
         ctx.tree_end_local(newton)
         b = ctx.doc_exchange_buffers()
         if self.leaf is None or self.leaf_n != b["leaf_n"]:
             self.leaf = self._view(b["leaf"], b["leaf_n"], "leaf")
             self.leaf_n = b["leaf_n"]
-            self._ptr[id(self.leaf)] = (b["leaf"], b["leaf_n"])
-        self._sum(self.leaf)
+            self._ptr["leaf"] = (b["leaf"], b["leaf_n"])
+        self._sum(self.leaf, "leaf")
         return ctx.tree_leaves_finish(nleaves, newton, read=read)
 
 

@@ -259,7 +259,8 @@ void Mart::learn(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::
   QR(qr_dataset_upload(ctx_, training->at(0, 0), training->num_instances(), training->num_features(),
                        training->labels(), training->offsets().data(), training->num_queries()));
   if (validation)
-    QR(qr_valid_upload(ctx_, validation->at(0, 0), validation->num_instances(), validation->labels(),
+    QR(qr_valid_upload(ctx_, validation->at(0, 0), validation->num_instances(), validation->num_features(),
+                       validation->labels(),
                        validation->offsets().data(), validation->num_queries()));
   QR(qr_bins_build(ctx_, nthresholds_, nullptr, nullptr));
   QR(qr_scores_reset(ctx_));
@@ -392,6 +393,31 @@ void Mart::score_dataset(const data::Dataset &dataset, Score *scores, float *ker
   QR(qr_ensemble_upload(ctx_, nodes.data(), weights.size(), max_nodes, weights.data()));
   QR(qr_ensemble_score(ctx_, dataset.at(0, 0), dataset.num_instances(), dataset.num_features(), scores,
                        kernel_ms));
+}
+
+std::shared_ptr<data::Dataset> Mart::partial_scores(const data::Dataset &dataset, bool ignore_weights) {
+  ensure_ctx();
+  std::vector<qr_node_t> nodes;
+  std::vector<double> weights;
+  const size_t max_nodes = ensemble_model_.flatten(&nodes, &weights);
+  const size_t T = weights.size(), N = dataset.num_instances();
+  if (T == 0) {
+    std::cerr << "# ## ERROR!! Only Ensemble methods support the export of detailed score tree by tree"
+              << std::endl;  // driver.cc:426-430
+    exit(EXIT_FAILURE);
+  }
+  QR(qr_ensemble_upload(ctx_, nodes.data(), T, max_nodes, weights.data()));
+  std::vector<double> part(N * T);
+  QR(qr_ensemble_partial_scores(ctx_, dataset.at(0, 0), N, dataset.num_features(), ignore_weights ? 1 : 0,
+                                part.data()));
+  auto out = std::make_shared<data::Dataset>(N, T);
+  std::vector<Feature> row(T);
+  for (size_t q = 0; q < dataset.num_queries(); ++q)
+    for (size_t i = dataset.offset(q); i < dataset.offset(q + 1); ++i) {
+      for (size_t t = 0; t < T; ++t) row[t] = (Feature)part[i * T + t];  // Score -> Feature (driver.cc:436-438)
+      out->addInstance((QueryID)q, dataset.getLabel(i), row);
+    }
+  return out;
 }
 
 MetricScore Mart::evaluate(const data::Dataset &dataset, const Score *scores, const std::string &metric,

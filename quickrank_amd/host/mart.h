@@ -80,6 +80,10 @@ class Mart {
              const std::string &output_basename);
   // ltr_algorithm.cc:44-52 on the device
   void score_dataset(const data::Dataset &dataset, Score *scores, float *kernel_ms = nullptr);
+  // Driver::extract_partial_scores (driver.cc:411-445) over Ensemble::partial_scores_instance
+  // (ensemble.cc:120-131): a dataset of ntrees "features" = the per-tree scores cast to
+  // Feature (f32), labels and query boundaries of `dataset`
+  std::shared_ptr<data::Dataset> partial_scores(const data::Dataset &dataset, bool ignore_weights = false);
   // metric.h:77-106 on the host scores of a loaded dataset (device evaluation)
   MetricScore evaluate(const data::Dataset &dataset, const Score *scores, const std::string &metric,
                        size_t cutoff);

@@ -53,6 +53,7 @@ const std::vector<std::pair<std::string, Opt>> kOptions = {
     {"test-cutoff", {"set test metric cutoff.", "10", true}},
     {"test", {"set testing file.", "", true}},
     {"scores", {"set output scores file.", "", true}},
+    {"detailed", {"enable detailed testing [applies only to ensemble models].", "", false}},
     {"model-file", {"set XML model file path [code generation].", "", true}},
     {"code-file", {"set C code file path [code generation].", "", true}},
     {"generator", {"set C code generation strategy: [condop|oblivious|vpred].", "condop", true}},
@@ -63,7 +64,7 @@ const std::set<std::string> kOutOfScope = {
     "best-on-train", "random-keep", "drop-on-best", "num-samples", "window-size", "reduction-factor",
     "max-iterations", "max-failed-valid", "adaptive", "train-partial", "valid-partial", "opt-algo",
     "opt-method", "opt-model", "opt-algo-model", "pruning-rate", "with-line-search",
-    "line-search-model", "detailed", "collapse-leaves-factor"};
+    "line-search-model", "collapse-leaves-factor"};
 
 void help() {
   std::cout << "quicklearn (MI355X build): LambdaMART / MART / oblivious variants on the GPU\n\n";
@@ -179,6 +180,9 @@ int main(int argc, char *argv[]) {
     auto training = load_dataset(v["train"], "training");
     std::shared_ptr<data::Dataset> validation;
     if (!v["valid"].empty()) validation = load_dataset(v["valid"], "validation");
+    if (!v["features"].empty())  // driver.cc:108-110: the reference reads the flag and does nothing with it
+      std::cout << "# --features " << v["features"] << ": accepted and not used, as in the reference "
+                << "(driver.cc:108-110 is a TODO)" << std::endl;
     algo->learn(training, validation, v["train-metric"], std::stoul(v["train-cutoff"]),
                 std::stoul(v["partial"]), v["model-out"]);  // driver.cc:228-246
     if (!v["model-out"].empty()) {
@@ -189,8 +193,22 @@ int main(int argc, char *argv[]) {
   if (isset.count("test")) {  // driver.cc:326-385
     auto test = load_dataset(v["test"], "test");
     std::vector<Score> scores(test->num_instances(), 0.0);
-    algo->score_dataset(*test, scores.data());
     const size_t k = std::stoul(v["test-cutoff"]);
+    if (isset.count("detailed")) {  // driver.cc:335-358: tree-by-tree scores as an SVMLight file
+      auto part = algo->partial_scores(*test);
+      const size_t T = part->num_features();
+      for (size_t i = 0; i < part->num_instances(); ++i) {
+        const Feature *row = part->at(i, 0);
+        for (size_t t = 0; t < T; ++t) scores[i] += row[t];  // f32 per-tree scores summed in f64 (driver.cc:345-347)
+      }
+      MetricScore s = algo->evaluate(*test, scores.data(), v["test-metric"], k);
+      std::cout << v["test-metric"] << "@" << k << " on test data = " << std::setprecision(4) << s << std::endl
+                << std::endl;
+      io::Svml().write(*part, v["scores"]);
+      std::cout << "# Partial Scores written to file: " << v["scores"] << std::endl;
+      return codegen();
+    }
+    algo->score_dataset(*test, scores.data());
     MetricScore s = algo->evaluate(*test, scores.data(), v["test-metric"], k);
     std::cout << std::endl << v["test-metric"] << "@" << k << " on test data = " << std::setprecision(4)
               << s << std::endl << std::endl;

@@ -215,3 +215,72 @@ def test_quicklearn_sampling_flags(tools, tmp_path):
     r = subprocess.run([tools["quicklearn"], "--algo", "OBVLAMBDAMART", "--train", tr, "--subsample", "0.5",
                         "--num-thresholds", "64"], capture_output=True, text=True)
     assert r.returncode != 0 and "apply to MART / LAMBDAMART" in r.stderr
+
+
+def test_detailed_partial_scores_and_narrow_files(tools, oracle_lib, tmp_path):
+    """--detailed (driver.cc:326-358 over Ensemble::partial_scores_instance,
+    ensemble.cc:120-131): per-tree scores as an SVMLight file whose row sums are the
+    document scores.  The validation / test files are NARROWER than the training file
+    (their largest feature id is smaller, so the reader gives them fewer columns):
+    the missing columns read as 0, exactly like an absent SVMLight feature."""
+    import quickrank_amd as qr
+    x, labels, qoff = make_dataset(nq=80, docs_per_query=30, F=12, seed=51)
+    vx, vl, vq = make_dataset(nq=30, docs_per_query=20, F=12, seed=52)
+    vx[:, 9:] = 0                                           # written sparse below: F = 9 in the file
+    tr, va = str(tmp_path / "train.svml"), str(tmp_path / "valid.svml")
+    _write_svml(tr, x, labels, qoff)
+    with open(va, "w") as f:
+        for q in range(len(vq) - 1):
+            for i in range(int(vq[q]), int(vq[q + 1])):
+                feats = " ".join(f"{j + 1}:{float(v):.9g}" for j, v in enumerate(vx[i, :9]))
+                f.write(f"{int(vl[i])} qid:{q + 1} {feats}\n")
+    x = np.array([[np.float32(f"{float(v):.9g}") for v in row] for row in x], np.float32)
+    vx = np.array([[np.float32(f"{float(v):.9g}") for v in row] for row in vx], np.float32)
+    model, part = str(tmp_path / "model.xml"), str(tmp_path / "partial.svml")
+    cmd = [tools["quicklearn"], "--algo", "LAMBDAMART", "--train", tr, "--valid", va, "--test", va,
+           "--num-trees", "5", "--num-leaves", "6", "--num-thresholds", "32", "--min-leaf-support", "5",
+           "--end-after-rounds", "0", "--model-out", model, "--scores", part, "--detailed",
+           "--features", "ignored.txt"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "# Partial Scores written to file" in out.stdout and "accepted and not used" in out.stdout
+    # the oracle trained with the zero-padded validation set sees the same validation metric
+    om = oracle_lib.train(x, labels, qoff, algo="LAMBDAMART", ntrees=5, shrinkage=0.1, nthresholds=32,
+                          nleaves=6, minls=5, esr=0, valid=(vx, vl, vq))
+    last = [l for l in out.stdout.splitlines() if l.strip().startswith("5 ")][0].split()
+    assert abs(float(last[2]) - om["valid_metric"][4]) < 5e-5   # the table prints 4 decimals
+    nodes, w = _load_model(tools, model)
+    # file: label qid:q+1 t:score ... (svml.cc:163-188); rows sum to the document scores
+    rows = [l.split() for l in open(part)]
+    assert len(rows) == len(vl) and all(len(r) == 2 + 5 for r in rows)
+    got = np.array([[float(t.split(":")[1]) for t in r[2:]] for r in rows])
+    c = qr.Context(0)
+    c.upload_ensemble(nodes, w)
+    p = c.partial_scores(vx, 5)
+    pn = c.partial_scores(vx[:, :9], 5)                     # narrower than the model: padded on the way up
+    assert np.array_equal(p, pn)
+    praw = c.partial_scores(vx, 5, ignore_weights=True)
+    assert np.array_equal(p, praw * 0.1)
+    s, _ = c.score(vx)
+    sn, _ = c.score(vx[:, :9])
+    assert np.array_equal(s, sn)
+    acc = np.zeros(len(vl))
+    for t in range(5):                                      # ensemble.cc:111-118: tree order, f64
+        acc = acc + p[:, t]
+    assert np.array_equal(acc, s)
+    assert np.allclose(got, p.astype(np.float32), rtol=0, atol=5e-9)   # 9 printed decimals of the f32 cast
+    # per-tree outputs against the oracle's walk of each single tree
+    for t in range(5):
+        one = dict(nodes=nodes[t:t + 1], nnodes=np.full(1, nodes.shape[1], np.uint64), ntrees=1,
+                   max_nodes=nodes.shape[1], shrinkage=0.1)
+        assert np.array_equal(p[:, t], oracle_lib.ensemble_score(one, vx))
+    # a device matrix that does not cover the model's features is refused, not mis-read
+    import torch
+    d = torch.zeros((4, 3), device="cuda", dtype=torch.float32)
+    o = torch.zeros(4, device="cuda", dtype=torch.float64)
+    torch.cuda.synchronize()
+    maxf = int(nodes["feature"].max())
+    if maxf >= 3:
+        rc = c.L.qr_ensemble_score_device(c.h, C.c_void_p(d.data_ptr()), 4, 3, C.c_void_p(o.data_ptr()))
+        assert rc == 3                                      # QR_ERR_ARG
+    c.close()

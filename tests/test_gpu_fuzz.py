@@ -21,10 +21,11 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
 
 # configuration index -> what the sweep reported on the round-1 state
-KNOWN_ROUNDING_DECIDED = {15: "MART N=3097 F=200 nthr=255 minls=5 64 leaves",
-                          55: "MART N=12 F=16 nthr=64 minls=1 10 leaves",
-                          258: "MART N=8 F=136 nthr=2 minls=2 3 leaves",
-                          268: "MART N=201 F=17 nthr=64 minls=2 64 leaves"}
+KNOWN_ROUNDING_DECIDED = {58: "MART N=1035 F=200 nthr=16 minls=2 64",
+                          67: "MART N=393 F=200 nthr=64 minls=2 64",
+                          174: "MART N=23 F=136 nthr=255 minls=2 31",
+                          204: "MART N=158 F=65 nthr=64 minls=5 31",
+                          214: "MART"}
 
 
 def test_fuzz_sweep_seed0():
@@ -36,6 +37,8 @@ def test_fuzz_sweep_seed0():
     assert set(cut) == set(KNOWN_ROUNDING_DECIDED), {i: r["desc"] for i, r in cut.items()}
     for i, r in cut.items():
         assert r["desc"].split()[1] == "MART", r["desc"]       # only discrete residuals tie exactly
+        assert KNOWN_ROUNDING_DECIDED[i] in r["desc"], r["desc"]
+        print("rounding-decided:", r["desc"], r["status"], "tree", r["tree"])
     sizes = [s for r in res for s in r["tie_sizes"]]
     assert all(s <= TIE_MAX_DOCS for s in sizes)
     # ties are the exception, not the rule: far fewer than one per run

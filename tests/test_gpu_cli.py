@@ -250,27 +250,29 @@ def test_detailed_partial_scores_and_narrow_files(tools, oracle_lib, tmp_path):
     last = [l for l in out.stdout.splitlines() if l.strip().startswith("5 ")][0].split()
     assert abs(float(last[2]) - om["valid_metric"][4]) < 5e-5   # the table prints 4 decimals
     nodes, w = _load_model(tools, model)
+    T = len(nodes)                                          # rolled back to the best model on validation
+    assert T == om["best_model"] + 1
     # file: label qid:q+1 t:score ... (svml.cc:163-188); rows sum to the document scores
     rows = [l.split() for l in open(part)]
-    assert len(rows) == len(vl) and all(len(r) == 2 + 5 for r in rows)
+    assert len(rows) == len(vl) and all(len(r) == 2 + T for r in rows)
     got = np.array([[float(t.split(":")[1]) for t in r[2:]] for r in rows])
     c = qr.Context(0)
     c.upload_ensemble(nodes, w)
-    p = c.partial_scores(vx, 5)
-    pn = c.partial_scores(vx[:, :9], 5)                     # narrower than the model: padded on the way up
+    p = c.partial_scores(vx, T)
+    pn = c.partial_scores(vx[:, :9], T)                     # narrower than the model: padded on the way up
     assert np.array_equal(p, pn)
-    praw = c.partial_scores(vx, 5, ignore_weights=True)
+    praw = c.partial_scores(vx, T, ignore_weights=True)
     assert np.array_equal(p, praw * 0.1)
     s, _ = c.score(vx)
     sn, _ = c.score(vx[:, :9])
     assert np.array_equal(s, sn)
     acc = np.zeros(len(vl))
-    for t in range(5):                                      # ensemble.cc:111-118: tree order, f64
+    for t in range(T):                                      # ensemble.cc:111-118: tree order, f64
         acc = acc + p[:, t]
     assert np.array_equal(acc, s)
     assert np.allclose(got, p.astype(np.float32), rtol=0, atol=5e-9)   # 9 printed decimals of the f32 cast
     # per-tree outputs against the oracle's walk of each single tree
-    for t in range(5):
+    for t in range(T):
         one = dict(nodes=nodes[t:t + 1], nnodes=np.full(1, nodes.shape[1], np.uint64), ntrees=1,
                    max_nodes=nodes.shape[1], shrinkage=0.1)
         assert np.array_equal(p[:, t], oracle_lib.ensemble_score(one, vx))

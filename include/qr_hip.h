@@ -123,6 +123,19 @@ int qr_thresholds_from_stats(size_t F, size_t nthresholds, size_t nranks,
                              uint32_t *thr_size_out);
 /* bin map for caller-supplied thresholds ([F][QR_MAX_BINS], rows end in FLT_MAX) */
 int qr_bins_build_with(qr_ctx *ctx, const float *thr, const uint32_t *thr_size);
+/* More than 255 thresholds per feature -- QuickRank's default `--num-thresholds 0` on   */
+/* real-valued columns (every distinct value a candidate, quicklearn.cc:103,              */
+/* mart.cc:147-158) and any --num-thresholds > 255 (mart.cc:159-169).  Same thresholds,   */
+/* same bin rule; rows are ragged: feature f has thr_size[f] slots, *cells_out in all,    */
+/* the longest *max_slots_out.  u32 bins, histograms of any row length (k_wide.hip);      */
+/* single-GPU contexts.  Everything after the bin build -- lambdas, qr_tree_fit,          */
+/* qr_oblivious_fit, score updates, metrics -- is called as on a u8 context.              */
+int qr_bins_build_wide(qr_ctx *ctx, size_t nthresholds, size_t *cells_out, size_t *max_slots_out);
+/* thresholds of a binned context (u8 or wide) as ragged rows: thr_out holds              */
+/* sum(thr_size) floats, feature after feature; thr_size_out [F].  NULL = skip.           */
+int qr_thresholds_read(qr_ctx *ctx, float *thr_out, uint32_t *thr_size_out);
+/* debug/parity: bin ids as u32 [N][F] row-major (u8 or wide contexts)                    */
+int qr_bins_read_u32(qr_ctx *ctx, uint32_t *out);
 /* debug/parity: bin ids as u8 [N][F] row-major (global features; features this  */
 /* rank does not own read back as 0xFF)                                          */
 int qr_bins_read(qr_ctx *ctx, uint8_t *out);
@@ -245,6 +258,8 @@ int qr_doc_exchange_buffers(qr_ctx *ctx, void **hist, size_t *hist_i64, void **s
 /* sums; sum_out = fixed * 2^-scale_exp.                                         */
 int qr_node_hist_read(qr_ctx *ctx, int node, double *sum_out,
                       uint64_t *count_out);
+/* the same as ragged rows (sum(thr_size) cells, feature after feature): u8 or wide */
+int qr_node_hist_read_ragged(qr_ctx *ctx, int node, double *sum_out, uint64_t *count_out);
 /* sample ids (ascending doc ids) of a node of the last fitted tree              */
 int qr_node_samples_read(qr_ctx *ctx, int node, uint32_t *ids_out,
                          size_t *n_out);

@@ -40,7 +40,8 @@ SYMBOLS = [
     "qr_bins_build_with", "qr_lambda_finish", "qr_tree_leaves_finish",
     "qr_doc_exchange_buffers", "qr_tree_nodes", "qr_valid_scores_set",
     "qr_tree_set_max_features", "qr_subsample_set", "qr_ensemble_partial_scores",
-    "qr_prof_get_child",
+    "qr_prof_get_child", "qr_bins_build_wide", "qr_thresholds_read", "qr_bins_read_u32",
+    "qr_node_hist_read_ragged",
 ]
 
 _LIB = None
@@ -86,6 +87,10 @@ def lib():
     L.qr_valid_upload.argtypes = [vp, vp, sz, sz, vp, vp, sz]
     L.qr_bins_build.argtypes = [vp, sz, vp, vp]
     L.qr_bins_read.argtypes = [vp, vp]
+    L.qr_bins_build_wide.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz)]
+    L.qr_thresholds_read.argtypes = [vp, vp, vp]
+    L.qr_bins_read_u32.argtypes = [vp, vp]
+    L.qr_node_hist_read_ragged.argtypes = [vp, C.c_int, vp, vp]
     L.qr_scores_reset.argtypes = [vp]
     L.qr_scores_set.argtypes = [vp, vp]
     L.qr_scores_get.argtypes = [vp, vp]
@@ -225,11 +230,56 @@ class Context:
         self._ck(self.L.qr_valid_upload(self.h, _ptr(x), self.vN, x.shape[1], _ptr(labels),
                                         _ptr(qoff), len(qoff) - 1))
 
-    def build_bins(self, nthresholds):
-        thr = np.empty((self.F, QR_MAX_BINS), np.float32)
+    def build_bins(self, nthresholds, wide=None):
+        """Thresholds + bin map (Mart::init, mart.cc:117-176).  Up to 255 thresholds per
+        feature take the u8 path; more -- `nthresholds` > 255, or 0 ("every distinct
+        value") on a column with more than 255 of them -- the wide one (u32 bins, ragged
+        rows).  Returns (thr [F][cap] padded with FLT_MAX, thr_size [F]); cap is 256 on
+        the u8 path.  wide=True / False forces the path."""
+        self.wide = False
+        if wide is not True and nthresholds <= 255:
+            thr = np.empty((self.F, QR_MAX_BINS), np.float32)
+            ts = np.empty(self.F, np.uint32)
+            rc = self.L.qr_bins_build(self.h, nthresholds, _ptr(thr), _ptr(ts))
+            if rc == 0:
+                return thr, ts
+            if rc != 5 or nthresholds != 0 or wide is False:   # QR_ERR_UNSUPPORTED: too many distinct values
+                self._ck(rc)
+        elif wide is False:
+            raise QrError("more than 255 thresholds need the wide path")
+        cells, cap = C.c_size_t(), C.c_size_t()
+        self._ck(self.L.qr_bins_build_wide(self.h, nthresholds, C.byref(cells), C.byref(cap)))
+        self.wide = True
+        return self.thresholds()
+
+    def thresholds(self):
+        """(thr [F][cap] padded with FLT_MAX, thr_size [F]) of a binned context."""
         ts = np.empty(self.F, np.uint32)
-        self._ck(self.L.qr_bins_build(self.h, nthresholds, _ptr(thr), _ptr(ts)))
+        self._ck(self.L.qr_thresholds_read(self.h, None, _ptr(ts)))
+        flat = np.empty(int(ts.sum()), np.float32)
+        self._ck(self.L.qr_thresholds_read(self.h, _ptr(flat), _ptr(ts)))
+        cap = max(int(ts.max()), QR_MAX_BINS)
+        thr = np.full((self.F, cap), np.finfo(np.float32).max, np.float32)
+        o = 0
+        for f in range(self.F):
+            thr[f, :ts[f]] = flat[o:o + ts[f]]
+            o += int(ts[f])
         return thr, ts
+
+    def read_bins_u32(self):
+        out = np.empty((self.N, self.F), np.uint32)
+        self._ck(self.L.qr_bins_read_u32(self.h, _ptr(out)))
+        return out
+
+    def node_hist_ragged(self, node):
+        """(sum, count) of a node as lists of per-feature rows (any context)."""
+        ts = np.empty(self.F, np.uint32)
+        self._ck(self.L.qr_thresholds_read(self.h, None, _ptr(ts)))
+        n = int(ts.sum())
+        s, c = np.zeros(n, np.float64), np.zeros(n, np.uint64)
+        self._ck(self.L.qr_node_hist_read_ragged(self.h, node, _ptr(s), _ptr(c)))
+        off = np.concatenate([[0], np.cumsum(ts)]).astype(np.int64)
+        return [s[off[f]:off[f + 1]] for f in range(self.F)], [c[off[f]:off[f + 1]] for f in range(self.F)]
 
     def bins_stats(self, nthresholds):
         """Column statistics of this rank's documents (see qr_bins_stats)."""

@@ -35,8 +35,7 @@
 
 #include "qr_internal.h"
 #include "qr_wave.h"
-
-typedef unsigned long long u64;
+#include "qr_dev.h"
 
 // ===========================================================================
 // k_hist
@@ -50,11 +49,6 @@ typedef unsigned long long u64;
 //   multiple of 16, 8-byte cells) that is 16 distinct bank pairs whatever the
 //   bins are.  Same-cell collisions between groups / waves are what the
 //   atomic is for.
-__device__ __forceinline__ long long quantize(double x) {
-  // round-to-nearest-even of |x| < 2^51 via the 1.5*2^52 trick
-  const double magic = 6755399441055744.0;
-  return __double_as_longlong(x + magic) - __double_as_longlong(magic);
-}
 
 #ifndef QR_HIST_SETS
 #define QR_HIST_SETS 3
@@ -441,17 +435,6 @@ __global__ __launch_bounds__(512) void k_reduce(
 // ===========================================================================
 // k_scan
 // ===========================================================================
-struct Best {
-  double score;
-  uint32_t t;
-};
-
-__device__ __forceinline__ Best best_pick(Best a, Best b) {
-  // first max: higher score wins, equal scores -> lower slot (rt.cc:285)
-  if (b.score > a.score || (b.score == a.score && b.t < a.t)) return b;
-  return a;
-}
-
 __device__ __forceinline__ Best block_best(Best v, Best *sh) {
   // lanes are in slot order, so the first lane holding the wave maximum is the
   // first maximum (rt.cc:285); scores are >= 0 or the -1 of "no valid slot"
@@ -466,27 +449,6 @@ __device__ __forceinline__ Best block_best(Best v, Best *sh) {
   Best r = sh[0];
   for (int i = 1; i < 4; ++i) r = best_pick(r, sh[i]);
   return r;
-}
-
-// gain of slot t of a node: rt.cc:268-291
-__device__ __forceinline__ Best slot_gain(long long cs, uint32_t cc, long long S,
-                                          uint32_t C, uint32_t t, uint32_t tsize,
-                                          u64 minls, double inv_scale) {
-  Best b;
-  b.score = -1.0;
-  b.t = 0xFFFFFFFFu;
-  const u64 lc = cc, rc = (u64)C - cc;
-  if (t < tsize && lc >= minls && rc >= minls) {
-    const double s = (double)S * inv_scale;
-    const double lsum = (double)cs * inv_scale;
-    const double rsum = s - lsum;
-    const double score = lsum * lsum / (double)lc + rsum * rsum / (double)rc;
-    if (score > -1.0) {
-      b.score = score;
-      b.t = t;
-    }
-  }
-  return b;
 }
 
 __device__ __forceinline__ void scan_core(
@@ -1003,8 +965,9 @@ __device__ __forceinline__ bool node_splittable(const QrNode *nd) {
   return nd->deviance > 0.0 && nd->best_f != 0xFFFFFFFFu;
 }
 
+// (thr_off: wide-bin contexts keep ragged threshold rows, feature f at thr[thr_off[f]])
 __device__ __forceinline__ void make_desc(DecideState &st, int node, const float *thr,
-                          const int32_t *gf2lf) {
+                          const int32_t *gf2lf, const uint32_t *thr_off = nullptr) {
   QrNode *nd = &st.nodes[node];
   QrSplitDesc *d = st.desc;
   const int li = st.nnodes, ri = st.nnodes + 1;
@@ -1033,7 +996,7 @@ __device__ __forceinline__ void make_desc(DecideState &st, int node, const float
   d->small_n = d->small_is_left ? d->lcount : d->rcount;
   nd->feature = (int32_t)nd->best_f;
   nd->thr_id = (int32_t)nd->best_t;
-  nd->threshold = thr[(size_t)nd->best_f * QR_MAX_BINS + nd->best_t];
+  nd->threshold = thr[(thr_off ? (size_t)thr_off[nd->best_f] : (size_t)nd->best_f * QR_MAX_BINS) + nd->best_t];
   nd->left = li;
   nd->right = ri;
   QrNode *L = &st.nodes[li], *R = &st.nodes[ri];
@@ -1077,7 +1040,7 @@ __device__ __forceinline__ void decide_logic(DecideState &st, QrTreeState *ts, c
                                              const QrScalars *scal, const float *thr,
                                              const int32_t *gf2lf, const int docmode, const u64 Nglobal,
                                              const double sum_small, const double ss_small,
-                                             const int root_buf) {
+                                             const int root_buf, const uint32_t *thr_off = nullptr) {
   if (root_mode) {
     QrNode *root = &st.nodes[0];
     root->begin = 0;
@@ -1100,7 +1063,7 @@ __device__ __forceinline__ void decide_logic(DecideState &st, QrTreeState *ts, c
     st.nsplits = 0;
     st.desc->active = 0;
     if (node_splittable(root))
-      make_desc(st, 0, thr, gf2lf);
+      make_desc(st, 0, thr, gf2lf, thr_off);
     else
       st.done = 1;
     st.step = 1;
@@ -1128,7 +1091,7 @@ __device__ __forceinline__ void decide_logic(DecideState &st, QrTreeState *ts, c
         const int node = st.heap[1].val;
         heap_pop(st);
         if (node_splittable(&st.nodes[node])) {
-          make_desc(st, node, thr, gf2lf);
+          make_desc(st, node, thr, gf2lf, thr_off);
           found = true;
           break;
         }
@@ -1154,7 +1117,7 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
                             const qr_split_t *featrec, const uint32_t *hcnt_loc, const int docmode,
                             const u64 Nglobal, const long long *tail, const int dworld,
                             const uint32_t mf_k, const u64 mf_seed, const uint32_t F,
-                            const int root_buf) {
+                            const int root_buf, const uint32_t *thr_off) {
   const bool w0 = threadIdx.x < 64;
   // single GPU (and document-sharded, where every rank scans every feature of
   // the all-reduced histogram): the merge over features happens here (no k_merge
@@ -1236,13 +1199,13 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
       st.heap = sh_heap;
       st.desc = &sh_desc;
       decide_logic(st, ts, root_mode, active, N, recs, world, scal, thr, gf2lf, docmode, Nglobal,
-                   sum_small, ss_small, root_buf);
+                   sum_small, ss_small, root_buf, thr_off);
     } else {
       st.nodes = ts->nodes;
       st.heap = ts->heap;
       st.desc = &ts->desc;
       decide_logic(st, ts, root_mode, active, N, recs, world, scal, thr, gf2lf, docmode, Nglobal,
-                   sum_small, ss_small, root_buf);
+                   sum_small, ss_small, root_buf, thr_off);
     }
     ts->nnodes = st.nnodes;
     ts->taken = st.taken;
@@ -1272,9 +1235,9 @@ __global__ __launch_bounds__(128) void k_decide(
     const int32_t *__restrict__ gf2lf, const qr_split_t *__restrict__ featrec,
     const uint32_t *__restrict__ hcnt_loc, const int docmode, const u64 Nglobal,
     const long long *__restrict__ tail, const int dworld, const uint32_t mf_k, const u64 mf_seed,
-    const uint32_t F, const int root_buf) {
+    const uint32_t F, const int root_buf, const uint32_t *__restrict__ thr_off) {
   decide_body(ts, N, flocal, recs, world, scal, part_ss, thr, gf2lf, featrec, hcnt_loc, docmode,
-              Nglobal, tail, dworld, mf_k, mf_seed, F, root_buf);
+              Nglobal, tail, dworld, mf_k, mf_seed, F, root_buf, thr_off);
 }
 
 // ===========================================================================
@@ -1854,6 +1817,8 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
 __device__ __forceinline__ bool go_left(const QrSplitDesc &d, uint32_t p, uint32_t id,
                                         const uint8_t *fm, uint32_t N,
                                         const uint32_t *mask, int use_mask) {
+  if (use_mask == 2)  // wide-bin contexts: u32 bins, feature-major (k_wide.hip)
+    return reinterpret_cast<const uint32_t *>(fm)[(size_t)d.owner_local * N + id] <= d.thr_id;
   if (use_mask) return (mask[p >> 5] >> (p & 31)) & 1u;
   // feature-major copy of the bins: one byte per document, 32 neighbouring
   // documents per 32-byte sector (the block-row layout costs a 64-byte sector per
@@ -2022,7 +1987,7 @@ __global__ __launch_bounds__(256) void k_partition(
 __global__ __launch_bounds__(256) void k_partition_level(
     const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ map,
     const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
-    uint32_t *__restrict__ order1, u64 *__restrict__ state) {
+    uint32_t *__restrict__ order1, u64 *__restrict__ state, const int wide) {
   if (ts->obl_done || blockIdx.x >= ts->l_part_wgs) return;
   const QrLevelNode &ln = ts->lnode[map[blockIdx.x]];
   if (!ln.active) return;
@@ -2037,7 +2002,7 @@ __global__ __launch_bounds__(256) void k_partition_level(
   gl.owner_local = ts->l_owner_local;
   gl.thr_id = ts->obl_t;
   partition_body(pn, gl, blockIdx.x - ln.part_first, ln.part_first, ts->part_epoch, fm, Nfm,
-                 order0, order1, nullptr, 0, state, nullptr, nullptr);
+                 order0, order1, nullptr, wide ? 2 : 0, state, nullptr, nullptr);
 }
 
 // batched leaf-wise growth: every node of the batch has its own (feature, slot) and
@@ -2344,7 +2309,8 @@ __global__ __launch_bounds__(256) void k_score_update(
 // rank; also the update of a --subsample iteration, whose leaves hold the sample only.
 __global__ __launch_bounds__(256) void k_score_update_walk(
     const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm, const uint32_t N,
-    const int32_t *__restrict__ gf2lf, const double shrinkage, double *__restrict__ scores) {
+    const int32_t *__restrict__ gf2lf, const double shrinkage, double *__restrict__ scores,
+    const int wide) {
   __shared__ int32_t s_lf[QR_MAXNODES], s_thr[QR_MAXNODES], s_left[QR_MAXNODES], s_right[QR_MAXNODES];
   __shared__ double s_val[QR_MAXNODES];
   const int nn = ts->nnodes;
@@ -2360,8 +2326,14 @@ __global__ __launch_bounds__(256) void k_score_update_walk(
   const uint32_t d = blockIdx.x * 256 + threadIdx.x;
   if (d >= N) return;
   int n = 0;
-  while (s_lf[n] >= 0)
-    n = (int)fm[(size_t)s_lf[n] * N + d] <= s_thr[n] ? s_left[n] : s_right[n];
+  if (wide) {  // u32 bins (k_wide.hip)
+    const uint32_t *fw = reinterpret_cast<const uint32_t *>(fm);
+    while (s_lf[n] >= 0)
+      n = fw[(size_t)s_lf[n] * N + d] <= (uint32_t)s_thr[n] ? s_left[n] : s_right[n];
+  } else {
+    while (s_lf[n] >= 0)
+      n = (int)fm[(size_t)s_lf[n] * N + d] <= s_thr[n] ? s_left[n] : s_right[n];
+  }
   const double add = shrinkage * s_val[n];
   scores[d] = scores[d] + add;
 }
@@ -2517,7 +2489,10 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     const int flocal, const uint32_t *__restrict__ hcnt, const float *__restrict__ thr,
     const int32_t *__restrict__ gf2lf, const QrBlock *__restrict__ blocks, const int nblocks,
     uint32_t *__restrict__ hist_map, uint32_t *__restrict__ part_map, const uint32_t N,
-    const qr_split_t *__restrict__ featrec, const QrScalars *__restrict__ scal) {
+    const qr_split_t *__restrict__ featrec, const QrScalars *__restrict__ scal,
+    const uint32_t *__restrict__ woff, const size_t wcells) {
+  // (woff != null: wide-bin context -- ragged rows, no histogram plan: k_wide.hip's
+  // launches are sized on the host)
   __shared__ uint32_t sh_a[QR_MAXLEVEL], sh_b[QR_MAXLEVEL], sh_c[QR_MAXLEVEL];
   __shared__ uint32_t tot_small;
   __shared__ uint32_t pick[3];
@@ -2535,9 +2510,10 @@ __global__ __launch_bounds__(256) void k_obl_plan(
   if (j < nodes) {
     const int node = nodes - 1 + j;
     QrNode *nd = &ts->nodes[node];
-    const size_t base = ((size_t)nd->hslot * flocal + lf) * 256;
+    const size_t base = woff ? (size_t)nd->hslot * wcells + woff[lf] : ((size_t)nd->hslot * flocal + lf) * 256;
+    const uint32_t lastt = woff ? woff[lf + 1] - woff[lf] - 1 : 255u;
     const uint32_t lcount = hcnt[base + t];
-    const uint32_t rcount = hcnt[base + 255] - lcount;
+    const uint32_t rcount = hcnt[base + lastt] - lcount;
     const int li = 2 * node + 1, ri = 2 * node + 2;
     ln.active = 1;
     ln.begin = nd->begin;
@@ -2554,7 +2530,7 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     nseg = nd->end - nd->begin;
     nd->feature = (int32_t)f;
     nd->thr_id = (int32_t)t;
-    nd->threshold = thr[(size_t)f * QR_MAX_BINS + t];
+    nd->threshold = thr[(woff ? (size_t)woff[f] : (size_t)f * QR_MAX_BINS) + t];
     nd->left = li;
     nd->right = ri;
     QrNode *L = &ts->nodes[li], *R = &ts->nodes[ri];
@@ -2592,7 +2568,7 @@ __global__ __launch_bounds__(256) void k_obl_plan(
   if (j < nodes) {
     pw = (nseg + QR_PART_SLICE - 1) / QR_PART_SLICE;
     ln.q = 0;
-    if (!last_level) {
+    if (!last_level && !woff) {
       const int spare = G - nodes * nblocks;
       ln.q = qr_plan_quantum((unsigned long long)tot_small * qr_plan_wsum(nblocks, blocks),
                              spare > G / 4 ? spare : G / 4);
@@ -2674,6 +2650,7 @@ static size_t hist_lds(const qr_ctx *c) {
 static int launch_scan(qr_ctx *c, int root_mode);
 
 static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
+  if (c->wide) return qr_k_whist_scan(c, root_mode);  // more than 255 thresholds: k_wide.hip
   const size_t lds = hist_lds(c);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
@@ -2789,11 +2766,11 @@ int qr_k_tree_decide(qr_ctx *c) {
   // invalidates the XCD L2s, 22.8 us for the fused kernel against 6 + 9 us.)
   hipLaunchKernelGGL(k_decide, dim3(1), dim3(128), 0, c->stream, c->d_tree,
                      (uint32_t)(c->sub_k ? c->sub_k : c->N), c->flocal, recs, fshard ? c->world : 1,
-                     c->d_scalars, c->d_part_ss, c->d_thr, c->d_gf2lf, c->d_featrec,
+                     c->d_scalars, c->d_part_ss, c->wide ? c->d_wthr : c->d_thr, c->d_gf2lf, c->d_featrec,
                      c->d_hcnt_loc, c->dmode, (u64)c->Nglobal,
                      c->dmode ? c->d_xh + 2 * c->xh_cells : (const long long *)nullptr,
                      c->world, c->mf_k, c->mf_seed + c->tree_counter, (uint32_t)c->F,
-                     c->sub_k ? 0 : 2);
+                     c->sub_k ? 0 : 2, c->wide ? c->d_woff : (const uint32_t *)nullptr);
   QR_CHECK(c, hipGetLastError());
   ++c->tree_step;
   if (fshard) {
@@ -2808,10 +2785,11 @@ int qr_k_tree_decide(qr_ctx *c) {
 
 int qr_k_tree_apply(qr_ctx *c) {
   const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
-  const int use_mask = c->world > 1 && !c->dmode;
+  const int use_mask = c->wide ? 2 : (c->world > 1 && !c->dmode);
   // (document-sharded: the rank's own left count comes from its local prefix counts)
   hipLaunchKernelGGL(k_partition, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
-                     c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
+                     c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm,
+                     (uint32_t)c->N, c->d_order[0], c->d_order[1],
                      c->d_mask, use_mask, (u64 *)c->d_part_state, c->d_lambda, c->d_part_ss,
                      c->dmode);
   QR_CHECK(c, hipGetLastError());
@@ -2900,29 +2878,40 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
   QR_CHECK(c, hipGetLastError());
   int rc = launch_hist_scan(c, 1);  // root histogram -> slot 0
   if (rc) return rc;
-  const size_t lds = hist_lds(c);
+  const size_t lds = c->wide ? 0 : hist_lds(c);
   const unsigned pgrid = (unsigned)c->lpart_cap, hgrid = (unsigned)c->lhist_cap;
   // every level: choose the split, plan the level, then ONE partition, ONE
   // histogram, ONE reduce and ONE scan launch for all of its nodes (the launches
   // are sized for the worst case; surplus workgroups leave at once)
   for (int level = 0; level < (int)depth; ++level) {
     const int nodes = 1 << level;
-    hipLaunchKernelGGL(k_obl_fill, dim3(c->flocal), dim3(256), 0, c->stream, c->d_tree, level,
-                       c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf,
-                       c->d_scalars, c->d_featrec);
-    QR_CHECK(c, hipGetLastError());
+    if (c->wide) {
+      if ((rc = qr_k_wobl_fill(c, level))) return rc;
+    } else {
+      hipLaunchKernelGGL(k_obl_fill, dim3(c->flocal), dim3(256), 0, c->stream, c->d_tree, level,
+                         c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf,
+                         c->d_scalars, c->d_featrec);
+      QR_CHECK(c, hipGetLastError());
+    }
     const int last = level == (int)depth - 1;
     hipLaunchKernelGGL(k_obl_plan, dim3(1), dim3(256), 0, c->stream, c->d_tree, level, last,
-                       c->ncu, c->flocal, c->d_hcnt, c->d_thr, c->d_gf2lf, c->d_blocks,
-                       c->nblocks, c->d_lhist_map, c->d_lpart_map, (uint32_t)c->N, c->d_featrec,
-                       c->d_scalars);
+                       c->ncu, c->flocal, c->d_hcnt, c->wide ? c->d_wthr : c->d_thr, c->d_gf2lf,
+                       c->d_blocks, c->nblocks, c->d_lhist_map, c->d_lpart_map, (uint32_t)c->N,
+                       c->d_featrec, c->d_scalars, c->wide ? c->d_woff : (const uint32_t *)nullptr,
+                       c->wcells);
     QR_CHECK(c, hipGetLastError());
     const unsigned pg = std::min<unsigned>(pgrid, (unsigned)(c->N / QR_PART_SLICE + nodes + 1));
     hipLaunchKernelGGL(k_partition_level, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_lpart_map, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
-                       (u64 *)c->d_lpart_state);
+                       c->d_lpart_map,
+                       c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm,
+                       (uint32_t)c->N, c->d_order[0], c->d_order[1], (u64 *)c->d_lpart_state,
+                       c->wide ? 1 : 0);
     QR_CHECK(c, hipGetLastError());
     if (last) break;  // ot.cc:127: no histograms for the leaves
+    if (c->wide) {
+      if ((rc = qr_k_wobl_hist(c, nodes))) return rc;
+      continue;
+    }
     // k_obl_plan keeps the total within ncu workgroups while nodes * nblocks <= 3/4 ncu
     const unsigned hg = std::min<unsigned>(
         hgrid, (unsigned)std::max(c->ncu, c->ncu / 4 + nodes * c->nblocks));
@@ -2967,7 +2956,8 @@ int qr_k_scores_update(qr_ctx *c, double shrinkage) {
     // also what a --subsample iteration needs (its leaves hold the sample only,
     // every training document is updated, mart.cc:345)
     hipLaunchKernelGGL(k_score_update_walk, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_bins_fm, (uint32_t)c->N, c->d_gf2lf, shrinkage, c->d_scores);
+                       c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm,
+                       (uint32_t)c->N, c->d_gf2lf, shrinkage, c->d_scores, c->wide ? 1 : 0);
   } else {
     hipLaunchKernelGGL(k_score_update, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
                        c->d_order[0], c->d_order[1], shrinkage, c->d_scores);

@@ -1,0 +1,546 @@
+// k_wide.hip -- more than 255 thresholds per feature (gfx950).
+//
+// QuickRank's default is `--num-thresholds 0`: every distinct value of a feature is a
+// threshold candidate (quicklearn.cc:103, mart.cc:147-158) -- tens of thousands of
+// slots on a real-valued column -- and any `--num-thresholds` above 255 gives the
+// equal-width branch (mart.cc:159-169) that many.  The u8 bins and 256-slot LDS
+// histograms of k_tree.hip cannot hold that.  This file is the same path with no bound
+// on the slots of a feature (4 G cells in all):
+//
+//   thresholds   every column is radix-sorted on the device (the order of radix.cc:28-73);
+//                the host runs mart.cc:140-169 over the sorted values with the reference's
+//                own f32 operations.  Rows are ragged: feature f owns cells
+//                [woff[f], woff[f + 1]) of one flat array.
+//   bins         u32, feature-major [F][N]: bin = first slot with x <= threshold
+//                (rtnode_histogram.cc:241-251), a binary search per (document, feature)
+//   k_whist      node histogram: one workgroup = one feature x a range of the node's
+//                documents.  Rows of up to 8192 slots are accumulated in LDS (i64 sum +
+//                u32 count per slot, two LDS atomics per document) and flushed with one
+//                global atomic per touched cell; longer rows go straight to global
+//                atomics.  Integer sums: any order, same bits (as k_tree.hip).
+//   k_wscan      per feature: prefix over the slots in chunks of 1024 with a carry,
+//                sibling = parent - child on the cumulative arrays
+//                (rtnode_histogram.cc:72-87, 206-217), gain of every slot and the first
+//                maximum (rt.cc:257-292) -- the records k_decide merges
+//   k_wobl_*     the same for level-wise (oblivious) growth, ot.cc:32-201
+// Growth itself -- k_decide, k_partition, k_finish, the leaf and score kernels -- is
+// k_tree.hip's one-split-per-step path, reading u32 bins and ragged thresholds.
+// Single GPU.  The u8 path keeps its kernels and its speed; this one is the general
+// one: ~10x the u8 path's time per tree at 1024 slots, still far from the CPU's.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "qr_internal.h"
+#include "qr_wave.h"
+#include "qr_dev.h"
+
+#define QR_WLDS_SLOTS 8192u   /* rows up to this many slots are accumulated in LDS (96 KB) */
+#define QR_WDOCS 32768u       /* documents per histogram workgroup                          */
+
+// ---------------------------------------------------------------------------
+// thresholds
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t w_flip(uint32_t x) {
+  return x ^ ((uint32_t)(-(int32_t)(x >> 31)) | 0x80000000u);  // radix.cc:28-30
+}
+static inline uint32_t h_unflip(uint32_t x) { return x ^ (((x >> 31) - 1) | 0x80000000u); }
+static inline float bits2f(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+__global__ __launch_bounds__(256) void k_wkeys(const float *__restrict__ col, const uint32_t N,
+                                               uint32_t *__restrict__ keys) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N) keys[i] = w_flip(__float_as_uint(col[i]));
+}
+
+// col: device [F][N] column-major.  Fills c->h_wthr / h_woff / h_thr_size (global
+// features; this path owns every feature).
+int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds) {
+  const size_t N = c->N, F = c->F;
+  uint32_t *d_keys = nullptr, *d_sorted = nullptr;
+  void *d_temp = nullptr;
+  size_t temp_bytes = 0;
+  QR_CHECK(c, hipMalloc((void **)&d_keys, N * 4));
+  QR_CHECK(c, hipMalloc((void **)&d_sorted, N * 4));
+  QR_CHECK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, d_keys, d_sorted, (int)N));
+  QR_CHECK(c, hipMalloc(&d_temp, temp_bytes ? temp_bytes : 1));
+  std::vector<uint32_t> h(N);
+  c->h_wthr.clear();
+  c->h_woff.assign(F + 1, 0);
+  c->h_thr_size.assign(F, 0);
+  std::vector<float> uniqs;
+  for (size_t f = 0; f < F; ++f) {
+    hipLaunchKernelGGL(k_wkeys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream,
+                       d_col + f * N, (uint32_t)N, d_keys);
+    QR_CHECK(c, hipGetLastError());
+    size_t tb = temp_bytes;
+    QR_CHECK(c, hipcub::DeviceRadixSort::SortKeys(d_temp, tb, d_keys, d_sorted, (int)N, 0, 32, c->stream));
+    QR_CHECK(c, hipMemcpyAsync(h.data(), d_sorted, N * 4, hipMemcpyDeviceToHost, c->stream));
+    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    // mart.cc:140-152: the distinct values in sorted order, early stop once there are
+    // nthresholds + 1 of them (a strict `<` decides "distinct": -0.0 and 0.0 are one
+    // value, a NaN is never appended behind a number)
+    uniqs.clear();
+    uniqs.push_back(bits2f(h_unflip(h[0])));
+    for (size_t j = 1; j < N && (nthresholds == 0 || uniqs.size() != nthresholds + 1); ++j) {
+      const float v = bits2f(h_unflip(h[j]));
+      if (uniqs.back() < v) uniqs.push_back(v);
+    }
+    c->h_woff[f] = (uint32_t)c->h_wthr.size();
+    if (uniqs.size() <= nthresholds || nthresholds == 0) {  // mart.cc:155-158
+      c->h_wthr.insert(c->h_wthr.end(), uniqs.begin(), uniqs.end());
+      c->h_wthr.push_back(FLT_MAX);
+      c->h_thr_size[f] = (uint32_t)uniqs.size() + 1;
+    } else {  // mart.cc:159-169: equal width, a running f32 sum
+      float t = bits2f(h_unflip(h[0]));
+      const float step = (float)fabs(bits2f(h_unflip(h[N - 1])) - t) / nthresholds;
+      for (size_t j = 0; j != nthresholds; t += step, ++j) c->h_wthr.push_back(t);
+      c->h_wthr.push_back(FLT_MAX);
+      c->h_thr_size[f] = (uint32_t)nthresholds + 1;
+    }
+    if (c->h_wthr.size() >= 0xFFFFFFF0ull) {
+      (void)hipFree(d_keys); (void)hipFree(d_sorted); (void)hipFree(d_temp);
+      QR_FAIL(c, QR_ERR_UNSUPPORTED, "more than 2^32 threshold slots in all");
+    }
+  }
+  c->h_woff[F] = (uint32_t)c->h_wthr.size();
+  (void)hipFree(d_keys);
+  (void)hipFree(d_sorted);
+  (void)hipFree(d_temp);
+  return QR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// bins: first slot t with x <= thr[t] (lower bound over the non-decreasing row);
+// NaN and anything above the last finite threshold land in the FLT_MAX slot
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wbinning(const float *__restrict__ col, const uint32_t N,
+                                                  const float *__restrict__ thr,
+                                                  const uint32_t *__restrict__ woff,
+                                                  uint32_t *__restrict__ bins) {
+  const uint32_t f = blockIdx.y;
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= N) return;
+  const float x = col[(size_t)f * N + d];
+  const float *t = thr + woff[f];
+  const uint32_t size = woff[f + 1] - woff[f];
+  uint32_t lo = 0, hi = size;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (x <= t[mid])
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  bins[(size_t)f * N + d] = lo > size - 1 ? size - 1 : lo;
+}
+
+int qr_k_wide_binning(qr_ctx *c, const float *d_col) {
+  hipLaunchKernelGGL(k_wbinning, dim3((unsigned)((c->N + 255) / 256), (unsigned)c->F), dim3(256), 0,
+                     c->stream, d_col, (uint32_t)c->N, c->d_wthr, c->d_woff, c->d_wbins);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// node histograms
+// ---------------------------------------------------------------------------
+// what a launch works on: the root (every document or the sample's list), the directly
+// built child of the current split (leaf-wise growth), or that of node `j` of a level
+struct WSeg {
+  uint32_t begin, n;
+  int buf, slot;
+  bool active;
+};
+__device__ __forceinline__ WSeg w_segment(const QrTreeState *ts, const int mode, const uint32_t rootn,
+                                          const int root_buf, const uint32_t j) {
+  WSeg s;
+  if (mode == 0) {          // root
+    s.begin = 0;
+    s.n = rootn;
+    s.buf = root_buf;
+    s.slot = 0;
+    s.active = true;
+  } else if (mode == 1) {   // the split being applied
+    s.active = ts->desc.active != 0;
+    s.begin = ts->desc.small_begin;
+    s.n = ts->desc.small_n;
+    s.buf = ts->desc.dst_buf;
+    s.slot = ts->desc.small_slot;
+  } else {                  // node j of the level
+    const QrLevelNode &ln = ts->lnode[j];
+    s.active = !ts->obl_done && (int)j < ts->l_nodes && ln.active;
+    s.begin = ln.small_begin;
+    s.n = ln.small_n;
+    s.buf = ln.dst_buf;
+    s.slot = ln.small_slot;
+  }
+  return s;
+}
+
+// the raw (not yet cumulative) cells of the segment's slot start at zero
+__global__ __launch_bounds__(256) void k_wzero(const QrTreeState *__restrict__ ts, const int mode,
+                                               const size_t cells, long long *__restrict__ hsum,
+                                               uint32_t *__restrict__ hcnt) {
+  const WSeg s = w_segment(ts, mode, 0, 0, blockIdx.y);
+  if (!s.active) return;
+  const size_t base = (size_t)s.slot * cells;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (size_t)gridDim.x * 256) {
+    hsum[base + i] = 0;
+    hcnt[base + i] = 0;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_whist(
+    const QrTreeState *__restrict__ ts, const int mode, const uint32_t rootn, const int root_buf,
+    const uint32_t N, const uint32_t *__restrict__ bins, const uint32_t *__restrict__ woff,
+    const size_t cells, const uint32_t *__restrict__ order0, const uint32_t *__restrict__ order1,
+    const double *__restrict__ lambda, const QrScalars *__restrict__ scal,
+    long long *__restrict__ hsum, uint32_t *__restrict__ hcnt) {
+  extern __shared__ __attribute__((aligned(16))) char wlds[];
+  const WSeg s = w_segment(ts, mode, rootn, root_buf, blockIdx.z);
+  if (!s.active) return;
+  const uint32_t r0 = blockIdx.x * QR_WDOCS;
+  if (r0 >= s.n) return;
+  const uint32_t r1 = r0 + QR_WDOCS < s.n ? r0 + QR_WDOCS : s.n;
+  const uint32_t lf = blockIdx.y;
+  const uint32_t base = woff[lf], size = woff[lf + 1] - base;
+  const uint32_t *order = s.buf == 0 ? order0 : order1;
+  const uint32_t *row = bins + (size_t)lf * N;
+  const double scale = scal->scale;
+  long long *gs = hsum + (size_t)s.slot * cells + base;
+  uint32_t *gc = hcnt + (size_t)s.slot * cells + base;
+  const bool in_lds = size <= QR_WLDS_SLOTS;
+  long long *ls = reinterpret_cast<long long *>(wlds);
+  uint32_t *lc = reinterpret_cast<uint32_t *>(ls + (in_lds ? size : 0));
+  if (in_lds) {
+    for (uint32_t i = threadIdx.x; i < size; i += 1024) {
+      ls[i] = 0;
+      lc[i] = 0;
+    }
+    __syncthreads();
+  }
+  for (uint32_t p = r0 + threadIdx.x; p < r1; p += 1024) {
+    const uint32_t id = s.buf == 2 ? s.begin + p : order[s.begin + p];
+    const uint32_t b = row[id];
+    const long long q = quantize(lambda[id] * scale);
+    if (in_lds) {
+      atomicAdd(reinterpret_cast<u64 *>(&ls[b]), (u64)q);
+      atomicAdd(&lc[b], 1u);
+    } else {
+      atomicAdd(reinterpret_cast<u64 *>(&gs[b]), (u64)q);
+      atomicAdd(&gc[b], 1u);
+    }
+  }
+  if (!in_lds) return;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < size; i += 1024) {
+    const uint32_t cn = lc[i];
+    if (cn) {
+      atomicAdd(reinterpret_cast<u64 *>(&gs[i]), (u64)ls[i]);
+      atomicAdd(&gc[i], cn);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// scan: prefix, sibling, gains, first maximum
+// ---------------------------------------------------------------------------
+// inclusive scan of (s, cn) over the 1024 threads of the workgroup, plus the carry
+__device__ __forceinline__ void w_block_scan(long long &s, uint32_t &cn, long long &carry_s,
+                                             uint32_t &carry_c, long long *sh_s, uint32_t *sh_c) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  s = wave_scan_i64(s);
+  cn = wave_scan_u32(cn);
+  __syncthreads();  // (the previous round's readers of sh_* are done)
+  if (lane == 63) {
+    sh_s[wave] = s;
+    sh_c[wave] = cn;
+  }
+  __syncthreads();
+  long long ps = carry_s;
+  uint32_t pc = carry_c;
+  for (int w = 0; w < wave; ++w) {
+    ps += sh_s[w];
+    pc += sh_c[w];
+  }
+  s += ps;
+  cn += pc;
+  long long ts_ = carry_s;
+  uint32_t tc_ = carry_c;
+  for (int w = 0; w < 16; ++w) {
+    ts_ += sh_s[w];
+    tc_ += sh_c[w];
+  }
+  carry_s = ts_;
+  carry_c = tc_;
+}
+
+// first maximum over the workgroup: highest score, equal scores -> lowest slot
+__device__ __forceinline__ Best w_block_best(Best v, Best *sh) {
+  const double m = wave_max(v.score);
+  const uint32_t t = wave_min_u32(v.score == m && v.t != 0xFFFFFFFFu ? v.t : 0xFFFFFFFFu);
+  Best w;
+  w.score = t != 0xFFFFFFFFu ? m : -1.0;
+  w.t = t;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+  __syncthreads();
+  Best r = sh[0];
+  for (int i = 1; i < 16; ++i) r = best_pick(r, sh[i]);
+  return r;
+}
+
+__device__ __forceinline__ void w_record(qr_split_t *o, float *othr, const Best v, const int gf,
+                                         const uint32_t *cnt_row, const uint32_t total_c,
+                                         const float *thr_row) {
+  if (threadIdx.x != 0) return;
+  o->score = v.score;
+  o->feature = v.t == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)gf;
+  o->thr_id = v.t;
+  o->lcount = v.t == 0xFFFFFFFFu ? 0 : cnt_row[v.t];
+  o->rcount = v.t == 0xFFFFFFFFu ? 0 : total_c - cnt_row[v.t];
+  *othr = v.t == 0xFFFFFFFFu ? 0.f : thr_row[v.t];
+}
+
+// One feature of the node just accumulated (mode 0: root, 1: the split being applied):
+// cumulative arrays of the directly built child in place, the sibling's by subtraction,
+// and the per-feature best-split record of each (featrec[which * flocal + lf], which =
+// 0 left / root, 1 right), as k_scan leaves them for k_decide.
+__global__ __launch_bounds__(1024) void k_wscan(
+    const QrTreeState *__restrict__ ts, const int mode, const uint32_t *__restrict__ woff,
+    const size_t cells, long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
+    const int32_t *__restrict__ lf2gf, const float *__restrict__ thr,
+    const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec,
+    float *__restrict__ featthr) {
+  __shared__ long long sh_s[16];
+  __shared__ uint32_t sh_c[16];
+  __shared__ Best sh_b[16];
+  int small_slot = 0, big_slot = -1, parent_slot = -1, small_is_left = 1;
+  if (mode == 1) {
+    if (!ts->desc.active) return;
+    small_slot = ts->desc.small_slot;
+    big_slot = ts->desc.big_slot;
+    parent_slot = ts->desc.parent_slot;
+    small_is_left = ts->desc.small_is_left;
+  }
+  const int lf = blockIdx.x;
+  const uint32_t base = woff[lf], size = woff[lf + 1] - base;
+  long long *ss = hsum + (size_t)small_slot * cells + base;
+  uint32_t *sc = hcnt + (size_t)small_slot * cells + base;
+  long long *bs = mode == 1 ? hsum + (size_t)big_slot * cells + base : nullptr;
+  uint32_t *bc = mode == 1 ? hcnt + (size_t)big_slot * cells + base : nullptr;
+  const long long *ps = mode == 1 ? hsum + (size_t)parent_slot * cells + base : nullptr;
+  const uint32_t *pc = mode == 1 ? hcnt + (size_t)parent_slot * cells + base : nullptr;
+  // pass 1: prefix over the slots (exact integers: any association), sibling
+  long long carry_s = 0;
+  uint32_t carry_c = 0;
+  for (uint32_t t0 = 0; t0 < size; t0 += 1024) {
+    const uint32_t t = t0 + threadIdx.x;
+    long long s = t < size ? ss[t] : 0;
+    uint32_t cn = t < size ? sc[t] : 0u;
+    w_block_scan(s, cn, carry_s, carry_c, sh_s, sh_c);
+    if (t < size) {
+      ss[t] = s;
+      sc[t] = cn;
+      if (mode == 1) {
+        bs[t] = ps[t] - s;
+        bc[t] = pc[t] - cn;
+      }
+    }
+  }
+  __syncthreads();
+  // pass 2: gains (rt.cc:268-291) and the first maximum (rt.cc:285)
+  const u64 minls = ts->minls;
+  const double inv_scale = scal->inv_scale;
+  const int gf = lf2gf[lf];
+  const long long S0 = carry_s;
+  const uint32_t C0 = carry_c;
+  const long long S1 = mode == 1 ? ps[size - 1] - S0 : 0;
+  const uint32_t C1 = mode == 1 ? pc[size - 1] - C0 : 0u;
+  Best a, b;
+  a.score = b.score = -1.0;
+  a.t = b.t = 0xFFFFFFFFu;
+  for (uint32_t t = threadIdx.x; t < size; t += 1024) {  // ascending t per thread: strict > keeps the first
+    const Best v = slot_gain(ss[t], sc[t], S0, C0, t, size, minls, inv_scale);
+    if (v.score > a.score) a = v;
+    if (mode == 1) {
+      const Best w = slot_gain(bs[t], bc[t], S1, C1, t, size, minls, inv_scale);
+      if (w.score > b.score) b = w;
+    }
+  }
+  a = w_block_best(a, sh_b);
+  const int wa = mode == 0 ? 0 : (small_is_left ? 0 : 1);
+  w_record(&featrec[(size_t)wa * flocal + lf], &featthr[(size_t)wa * flocal + lf], a, gf, sc, C0,
+           thr + base);
+  if (mode == 1) {
+    b = w_block_best(b, sh_b);
+    const int wb = small_is_left ? 1 : 0;
+    w_record(&featrec[(size_t)wb * flocal + lf], &featthr[(size_t)wb * flocal + lf], b, gf, bc, C1,
+             thr + base);
+  }
+}
+
+// level-wise growth: prefix + sibling for every node of the level (no gains here:
+// k_wobl_fill sums them over the level)
+__global__ __launch_bounds__(1024) void k_wscan_level(
+    const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ woff, const size_t cells,
+    long long *__restrict__ hsum, uint32_t *__restrict__ hcnt) {
+  __shared__ long long sh_s[16];
+  __shared__ uint32_t sh_c[16];
+  if (ts->obl_done || (int)blockIdx.y >= ts->l_nodes) return;
+  const QrLevelNode &ln = ts->lnode[blockIdx.y];
+  if (!ln.active) return;
+  const int lf = blockIdx.x;
+  const uint32_t base = woff[lf], size = woff[lf + 1] - base;
+  long long *ss = hsum + (size_t)ln.small_slot * cells + base;
+  uint32_t *sc = hcnt + (size_t)ln.small_slot * cells + base;
+  long long *bs = hsum + (size_t)ln.big_slot * cells + base;
+  uint32_t *bc = hcnt + (size_t)ln.big_slot * cells + base;
+  const long long *ps = hsum + (size_t)ln.parent_slot * cells + base;
+  const uint32_t *pc = hcnt + (size_t)ln.parent_slot * cells + base;
+  long long carry_s = 0;
+  uint32_t carry_c = 0;
+  for (uint32_t t0 = 0; t0 < size; t0 += 1024) {
+    const uint32_t t = t0 + threadIdx.x;
+    long long s = t < size ? ss[t] : 0;
+    uint32_t cn = t < size ? sc[t] : 0u;
+    w_block_scan(s, cn, carry_s, carry_c, sh_s, sh_c);
+    if (t < size) {
+      ss[t] = s;
+      sc[t] = cn;
+      bs[t] = ps[t] - s;
+      bc[t] = pc[t] - cn;
+    }
+  }
+}
+
+// fill() + argmax of one level for one feature (ot.cc:177-201, 67-92), any row length:
+// the gain of slot t summed over the level's nodes in node order, sticky `invalid`,
+// only sums > 0 compete, first maximum
+__global__ __launch_bounds__(1024) void k_wobl_fill(
+    const QrTreeState *__restrict__ ts, const int level, const uint32_t *__restrict__ woff,
+    const size_t cells, const long long *__restrict__ hsum, const uint32_t *__restrict__ hcnt,
+    const int flocal, const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
+    qr_split_t *__restrict__ featrec) {
+  __shared__ Best sh_b[16];
+  if (ts->obl_done) return;
+  const int lf = blockIdx.x;
+  const uint32_t base = woff[lf], size = woff[lf + 1] - base;
+  const u64 minls = ts->minls;
+  const double inv_scale = scal->inv_scale;
+  const int lbegin = (1 << level) - 1, lend = (1 << (level + 1)) - 1;
+  Best best;
+  best.score = -1.0;
+  best.t = 0xFFFFFFFFu;
+  for (uint32_t t = threadIdx.x; t < size; t += 1024) {
+    double sum = 0.0;
+    bool invalid = false;
+    for (int i = lbegin; i < lend; ++i) {
+      const size_t nb = (size_t)ts->nodes[i].hslot * cells + base;
+      const long long cs = hsum[nb + t], S = hsum[nb + size - 1];
+      const u64 lc = hcnt[nb + t], C = hcnt[nb + size - 1];
+      const u64 rc = C - lc;
+      if (lc >= minls && rc >= minls) {
+        const double s = (double)S * inv_scale;
+        const double lsum = (double)cs * inv_scale;
+        const double rsum = s - lsum;
+        sum += lsum * lsum / (double)lc + rsum * rsum / (double)rc;
+      } else
+        invalid = true;
+    }
+    if (!invalid && sum > 0.0 && sum > best.score) {  // NaN fails the comparisons, as in ot.cc:77-78
+      best.score = sum;
+      best.t = t;
+    }
+  }
+  best = w_block_best(best, sh_b);
+  if (threadIdx.x == 0) {
+    qr_split_t *o = &featrec[lf];
+    o->score = best.score;
+    o->feature = best.t == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)lf2gf[lf];
+    o->thr_id = best.t;
+    o->lcount = o->rcount = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------
+static size_t whist_lds(const qr_ctx *c) {
+  const size_t s = std::min<size_t>(c->wmax, QR_WLDS_SLOTS);
+  return s * 12 + 16;
+}
+
+static int whist_attr(qr_ctx *c) {
+  static size_t attr = 0;
+  const size_t lds = whist_lds(c);
+  if (lds > attr) {
+    QR_CHECK(c, hipFuncSetAttribute((const void *)k_whist, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    attr = lds;
+  }
+  return QR_OK;
+}
+
+// mode 0: root histogram -> slot 0; mode 1: the directly built child of the split being
+// applied (+ its sibling); then the per-feature records for k_decide
+int qr_k_whist_scan(qr_ctx *c, int root_mode) {
+  int rc = whist_attr(c);
+  if (rc) return rc;
+  const int mode = root_mode ? 0 : 1;
+  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);
+  const size_t maxn = root_mode ? rootn : rootn / 2 + 1;  // the smaller child
+  const unsigned zg = (unsigned)std::min<size_t>((c->wcells + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_wzero, dim3(zg, 1), dim3(256), 0, c->stream, c->d_tree, mode, c->wcells, c->d_hsum,
+                     c->d_hcnt);
+  QR_CHECK(c, hipGetLastError());
+  const unsigned chunks = (unsigned)((maxn + QR_WDOCS - 1) / QR_WDOCS);
+  hipLaunchKernelGGL(k_whist, dim3(chunks, (unsigned)c->flocal, 1), dim3(1024), whist_lds(c), c->stream,
+                     c->d_tree, mode, rootn, c->sub_k ? 0 : 2, (uint32_t)c->N, c->d_wbins, c->d_woff,
+                     c->wcells, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, c->d_hsum,
+                     c->d_hcnt);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_wscan, dim3((unsigned)c->flocal), dim3(1024), 0, c->stream, c->d_tree, mode,
+                     c->d_woff, c->wcells, c->d_hsum, c->d_hcnt, c->flocal, c->d_lf2gf, c->d_wthr,
+                     c->d_scalars, c->d_featrec, c->d_featthr);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+// level-wise growth: the level's per-feature sums (before its split is chosen) ...
+int qr_k_wobl_fill(qr_ctx *c, int level) {
+  hipLaunchKernelGGL(k_wobl_fill, dim3((unsigned)c->flocal), dim3(1024), 0, c->stream, c->d_tree, level,
+                     c->d_woff, c->wcells, c->d_hsum, c->d_hcnt, c->flocal, c->d_lf2gf, c->d_scalars,
+                     c->d_featrec);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+// ... and the histograms of the level's children once it is partitioned
+int qr_k_wobl_hist(qr_ctx *c, int nodes) {
+  int rc = whist_attr(c);
+  if (rc) return rc;
+  const unsigned zg = (unsigned)std::min<size_t>((c->wcells + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_wzero, dim3(zg, (unsigned)nodes), dim3(256), 0, c->stream, c->d_tree, 2, c->wcells,
+                     c->d_hsum, c->d_hcnt);
+  QR_CHECK(c, hipGetLastError());
+  // the directly built child of a node holds at most half of its documents
+  const unsigned chunks = (unsigned)((c->N / 2 + QR_WDOCS) / QR_WDOCS);
+  hipLaunchKernelGGL(k_whist, dim3(chunks, (unsigned)c->flocal, (unsigned)nodes), dim3(1024), whist_lds(c),
+                     c->stream, c->d_tree, 2, (uint32_t)c->N, 2, (uint32_t)c->N, c->d_wbins, c->d_woff,
+                     c->wcells, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, c->d_hsum,
+                     c->d_hcnt);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_wscan_level, dim3((unsigned)c->flocal, (unsigned)nodes), dim3(1024), 0, c->stream,
+                     c->d_tree, c->d_woff, c->wcells, c->d_hsum, c->d_hcnt);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}

@@ -84,6 +84,10 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_idcg); dfree(c->d_qmetric); dfree(c->d_ranks); dfree(c->d_ssq);
   dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins); dfree(c->d_bins_fm);
   dfree(c->d_thr); dfree(c->d_thr_size);
+  dfree(c->d_woff); dfree(c->d_wthr); dfree(c->d_wbins);
+  c->wide = false;
+  c->wcells = 0;
+  c->wmax = 0;
   dfree(c->d_order[0]); dfree(c->d_order[1]); dfree(c->d_partials);
   if (c->d_xh) {  // document-sharded: the reduced histogram lives in the exchange buffer
     c->d_red_sum = nullptr;
@@ -602,9 +606,108 @@ int qr_bins_build_with(qr_ctx *c, const float *thr, const uint32_t *thr_size) {
   return bins_finish(c);
 }
 
+// ---- more than 255 thresholds per feature (k_wide.hip) --------------------------
+int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t *max_slots_out) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->d_raw) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
+  if (c->binned) QR_FAIL(c, QR_ERR_STATE, "bins already built: upload the dataset again first");
+  if (c->world > 1 || c->dmode)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED,
+            "more than 255 thresholds per feature: single-GPU contexts only (sharded contexts use u8 bins)");
+  QR_CHECK(c, hipSetDevice(c->device));
+  const size_t N = c->N, F = c->F;
+  float *d_col = nullptr;
+  QR_CHECK(c, dalloc(&d_col, N * F));
+  int rc = qr_k_transpose(c, c->d_raw, d_col, N, F);
+  if (!rc) rc = qr_k_wide_thresholds(c, d_col, nthresholds);
+  if (rc) {
+    dfree(d_col);
+    return rc;
+  }
+  c->wcells = c->h_wthr.size();
+  c->wmax = 0;
+  for (size_t f = 0; f < F; ++f) c->wmax = std::max(c->wmax, c->h_thr_size[f]);
+  // every feature is local: identity maps, no u8 blocks
+  c->blocks.clear();
+  c->nblocks = 0;
+  c->flocal = (int)F;
+  c->h_gf2lf.resize(F);
+  c->h_lf2gf.resize(F);
+  for (size_t f = 0; f < F; ++f) c->h_gf2lf[f] = c->h_lf2gf[f] = (int32_t)f;
+  QR_CHECK(c, dalloc(&c->d_lf2gf, F));
+  QR_CHECK(c, dalloc(&c->d_gf2lf, F));
+  QR_CHECK(c, hipMemcpy(c->d_lf2gf, c->h_lf2gf.data(), F * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_gf2lf, c->h_gf2lf.data(), F * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, dalloc(&c->d_thr_size, F));
+  QR_CHECK(c, hipMemcpy(c->d_thr_size, c->h_thr_size.data(), F * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, dalloc(&c->d_woff, F + 1));
+  QR_CHECK(c, hipMemcpy(c->d_woff, c->h_woff.data(), (F + 1) * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, dalloc(&c->d_wthr, c->wcells));
+  QR_CHECK(c, hipMemcpy(c->d_wthr, c->h_wthr.data(), c->wcells * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, dalloc(&c->d_wbins, N * F));
+  rc = qr_k_wide_binning(c, d_col);
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  dfree(d_col);
+  if (rc) return rc;
+  // ---- tree working set of the one-split-per-step path
+  QR_CHECK(c, dalloc(&c->d_order[0], N));
+  QR_CHECK(c, dalloc(&c->d_order[1], N));
+  QR_CHECK(c, dalloc(&c->d_featrec, 2 * QR_BATCH * F));
+  QR_CHECK(c, dalloc(&c->d_featthr, 2 * QR_BATCH * F));
+  QR_CHECK(c, dalloc(&c->d_recs_local, (size_t)2));
+  QR_CHECK(c, dalloc(&c->d_recs_all, (size_t)2));
+  c->mask_words = (N + 31) / 32;
+  QR_CHECK(c, dalloc(&c->d_mask, c->mask_words));
+  QR_CHECK(c, dalloc(&c->d_part_state, N / QR_PART_SLICE + 2));
+  QR_CHECK(c, hipMemset(c->d_part_state, 0, (N / QR_PART_SLICE + 2) * 8));
+  QR_CHECK(c, dalloc(&c->d_part_ss, 2 * (N / QR_PART_SLICE + 2)));
+  QR_CHECK(c, dalloc(&c->d_tree, (size_t)1));
+  QR_CHECK(c, hipMemset(c->d_tree, 0, sizeof(QrTreeState)));
+  QR_CHECK(c, dalloc(&c->d_leafpart, 2 * (N / QR_SLICE + QR_MAXNODES + 4)));
+  c->wide = true;
+  c->binned = true;
+  if (cells_out) *cells_out = c->wcells;
+  if (max_slots_out) *max_slots_out = c->wmax;
+  return QR_OK;
+}
+
+int qr_thresholds_read(qr_ctx *c, float *thr_out, uint32_t *thr_size_out) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  if (thr_size_out) memcpy(thr_size_out, c->h_thr_size.data(), c->F * 4);
+  if (!thr_out) return QR_OK;
+  if (c->wide) {
+    memcpy(thr_out, c->h_wthr.data(), c->wcells * 4);
+  } else {
+    size_t o = 0;
+    for (size_t f = 0; f < c->F; ++f)
+      for (uint32_t t = 0; t < c->h_thr_size[f]; ++t) thr_out[o++] = c->h_thr[f * QR_MAX_BINS + t];
+  }
+  return QR_OK;
+}
+
+int qr_bins_read_u32(qr_ctx *c, uint32_t *out) {
+  if (!c || !out) return QR_ERR_ARG;
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  if (c->wide) {
+    std::vector<uint32_t> h(c->N * c->F);
+    QR_CHECK(c, hipMemcpy(h.data(), c->d_wbins, h.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t f = 0; f < c->F; ++f)
+      for (size_t d = 0; d < c->N; ++d) out[d * c->F + f] = h[f * c->N + d];
+    return QR_OK;
+  }
+  std::vector<uint8_t> b(c->N * c->F);
+  const int rc = qr_bins_read(c, b.data());
+  if (rc) return rc;
+  for (size_t i = 0; i < b.size(); ++i) out[i] = b[i] == 0xFF && c->h_gf2lf[i % c->F] < 0 ? 0xFFFFFFFFu : b[i];
+  return QR_OK;
+}
+
 int qr_bins_read(qr_ctx *c, uint8_t *out) {
   if (!c || !out) return QR_ERR_ARG;
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  if (c->wide) QR_FAIL(c, QR_ERR_STATE, "this context has more than 255 thresholds per feature: qr_bins_read_u32");
   std::vector<uint8_t> h(c->bins_bytes);
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   QR_CHECK(c, hipMemcpy(h.data(), c->d_bins, c->bins_bytes, hipMemcpyDeviceToHost));
@@ -813,8 +916,9 @@ static int ensure_hist_slots(qr_ctx *c, size_t slots) {
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   dfree(c->d_hsum);
   dfree(c->d_hcnt);
-  QR_CHECK(c, dalloc(&c->d_hsum, slots * c->flocal * 256));
-  QR_CHECK(c, dalloc(&c->d_hcnt, slots * c->flocal * 256));
+  const size_t per_slot = c->wide ? c->wcells : (size_t)c->flocal * 256;
+  QR_CHECK(c, dalloc(&c->d_hsum, slots * per_slot));
+  QR_CHECK(c, dalloc(&c->d_hcnt, slots * per_slot));
   if (c->dmode) {
     dfree(c->d_hcnt_loc);
     QR_CHECK(c, dalloc(&c->d_hcnt_loc, slots * c->flocal * 256));
@@ -978,7 +1082,7 @@ int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
             "with the collectives in between");
   // up to QR_BATCH splits per step (k_decide_batch); per-node feature subsets are keyed by
   // the node's final index, which a split applied ahead of its turn does not know yet
-  if (!c->mf_k && !c->no_batch && nleaves >= 2 && 4 * nleaves + 1 <= QR_MAXNODES) {
+  if (!c->mf_k && !c->no_batch && !c->wide && nleaves >= 2 && 4 * nleaves + 1 <= QR_MAXNODES) {
     if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
     int rc = ensure_hist_slots(c, 4 * nleaves + 1);
     if (rc) return rc;
@@ -1068,6 +1172,7 @@ int qr_node_hist_read(qr_ctx *c, int node, double *sum_out, uint64_t *count_out)
   if (rc) return rc;
   const QrTreeState &ts = *reinterpret_cast<QrTreeState *>(buf.data());
   if (node < 0 || node >= ts.nnodes) QR_FAIL(c, QR_ERR_ARG, "node out of range");
+  if (c->wide) QR_FAIL(c, QR_ERR_STATE, "this context has more than 255 thresholds per feature: qr_node_hist_read_ragged");
   QrScalars s;
   QR_CHECK(c, hipMemcpy(&s, c->d_scalars, sizeof(s), hipMemcpyDeviceToHost));
   const size_t n = (size_t)c->flocal * 256;
@@ -1085,6 +1190,40 @@ int qr_node_hist_read(qr_ctx *c, int node, double *sum_out, uint64_t *count_out)
       if (count_out) count_out[gf * 256 + t] = hc[(size_t)lf * 256 + t];
     }
   }
+  return QR_OK;
+}
+
+int qr_node_hist_read_ragged(qr_ctx *c, int node, double *sum_out, uint64_t *count_out) {
+  if (!c) return QR_ERR_ARG;
+  std::vector<char> buf;
+  int rc = read_tree(c, buf);
+  if (rc) return rc;
+  const QrTreeState &ts = *reinterpret_cast<QrTreeState *>(buf.data());
+  if (node < 0 || node >= ts.nnodes) QR_FAIL(c, QR_ERR_ARG, "node out of range");
+  QrScalars s;
+  QR_CHECK(c, hipMemcpy(&s, c->d_scalars, sizeof(s), hipMemcpyDeviceToHost));
+  const size_t slot = (size_t)ts.nodes[node].hslot;
+  if (c->wide) {
+    const size_t n = c->wcells;
+    std::vector<long long> hs(n);
+    std::vector<uint32_t> hc(n);
+    QR_CHECK(c, hipMemcpy(hs.data(), c->d_hsum + slot * n, n * 8, hipMemcpyDeviceToHost));
+    QR_CHECK(c, hipMemcpy(hc.data(), c->d_hcnt + slot * n, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+      if (sum_out) sum_out[i] = (double)hs[i] * s.inv_scale;
+      if (count_out) count_out[i] = hc[i];
+    }
+    return QR_OK;
+  }
+  std::vector<double> ps(c->F * 256);
+  std::vector<uint64_t> pc(c->F * 256);
+  if ((rc = qr_node_hist_read(c, node, ps.data(), pc.data()))) return rc;
+  size_t o = 0;
+  for (size_t f = 0; f < c->F; ++f)
+    for (uint32_t t = 0; t < c->h_thr_size[f]; ++t, ++o) {
+      if (sum_out) sum_out[o] = ps[f * 256 + t];
+      if (count_out) count_out[o] = pc[f * 256 + t];
+    }
   return QR_OK;
 }
 

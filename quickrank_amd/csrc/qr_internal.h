@@ -292,6 +292,16 @@ struct qr_ctx {
   uint8_t *d_bins = nullptr;
   size_t bins_bytes = 0;
   uint8_t *d_bins_fm = nullptr;  // feature-major copy [flocal][N] for the partition
+  // more than 255 thresholds per feature (k_wide.hip): ragged threshold rows (feature f
+  // owns cells [woff[f], woff[f + 1]) of every per-node histogram), u32 bins
+  bool wide = false;
+  size_t wcells = 0;             // cells of one node histogram
+  uint32_t wmax = 0;             // longest row
+  uint32_t *d_woff = nullptr;    // [F + 1]
+  float *d_wthr = nullptr;       // [wcells]
+  uint32_t *d_wbins = nullptr;   // [F][N] feature-major
+  std::vector<uint32_t> h_woff;
+  std::vector<float> h_wthr;
   float *d_thr = nullptr;        // [F][256]
   uint32_t *d_thr_size = nullptr;
   std::vector<float> h_thr;
@@ -431,6 +441,11 @@ int qr_k_transpose(qr_ctx *c, const float *raw, float *col, size_t N, size_t F);
 int qr_k_colstats(qr_ctx *c, const float *col, size_t N, size_t F, uint32_t limit,
                   uint32_t *d_vals, uint32_t *d_cnt, uint32_t *d_minmax);
 int qr_k_binning(qr_ctx *c);
+int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds);
+int qr_k_wide_binning(qr_ctx *c, const float *d_col);
+int qr_k_whist_scan(qr_ctx *c, int root_mode);
+int qr_k_wobl_fill(qr_ctx *c, int level);
+int qr_k_wobl_hist(qr_ctx *c, int nodes);
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode);
 int qr_k_residual(qr_ctx *c);
 int qr_k_prep(qr_ctx *c, size_t nslices, int with_metric, int publish = 0);

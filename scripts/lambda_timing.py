@@ -1,13 +1,34 @@
-import os, sys, shutil
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+"""k_lambda under the microscope (TEST TOOL, GPU box): per-section cycle counts of one
+wave (build with -DQR_LAMBDA_TIMING: the kernel prints them for queries 0 and 5000) and
+the kernel's duration per boosting iteration (HIP events around qr_lambda_compute) as
+the scores lose their ties.   python scripts/lambda_timing.py [iterations]"""
+import os, subprocess, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
 import numpy as np
+import torch
+torch.cuda.init()
 import quickrank_amd.build as b
-b.LIB = "/root/repo/quickrank_amd/lib/libqr_timing.so"
+timing = os.path.join(b.LIBDIR, "libqr_timing.so")
+if os.environ.get("QR_LAMBDA_SECTIONS"):
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + b.FLAGS + ["-DQR_LAMBDA_TIMING", "-o", timing] +
+                          [os.path.join(b.CSRC, s) for s in b.SOURCES])
+    b.LIB = timing
 import quickrank_amd._capi as capi
 from bench import synth
 x, labels, qoff = synth(10000, 100, 136)
-c = capi.Context(0)
+c = capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 c.upload(x, labels, qoff); c.build_bins(255); c.reset_scores()
-for it in range(4):
-    c.compute_lambdas("NDCG", 10); c.synchronize()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+for it in range(n):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    c.compute_lambdas("NDCG", 10)
+    e1.record()
+    torch.cuda.synchronize()
+    if it in (0, 1, 2, 3, 5, 10, 20, 30, 40, 50, 59) or it == n - 1:
+        s = c.get_scores().reshape(10000, 100)
+        tied = (np.diff(np.sort(s, axis=1), axis=1) == 0).any(axis=1).mean()
+        print(f"iteration {it}: lambda + prep {e0.elapsed_time(e1) * 1e3:.1f} us, queries with a tied pair {tied:.3f}",
+              flush=True)
     c.fit_tree(10, 1, True); c.update_scores(0.1)

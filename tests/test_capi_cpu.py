@@ -81,5 +81,6 @@ def test_oracle_users_are_only_the_allowed_ones():
                     if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
                         found.add(getattr(fn, "name", "<module>"))
         return found
-    assert importers(os.path.join(root, "bench.py")) <= {"cpu_baseline"}
+    # the cpu_baseline leg: the training baseline and the scoring baseline of the same object
+    assert importers(os.path.join(root, "bench.py")) <= {"cpu_baseline", "cpu_scoring_baseline"}
     assert importers(os.path.join(root, "__graft_entry__.py")) <= {"build", "smoke"}

@@ -62,15 +62,6 @@ def test_thresholds_and_bins(qr, ora, case, nthr):
     c.close()
 
 
-def test_nthr0_too_many_uniques_is_an_error(qr):
-    x, labels, qoff = make_dataset(nq=20, docs_per_query=30, F=8, seed=0)
-    c = qr.Context(0)
-    c.upload(x, labels, qoff)
-    with pytest.raises(qr.QrError):
-        c.build_bins(0)
-    c.close()
-
-
 def _scores_for(kind, n, rng):
     if kind == "zero":
         return np.zeros(n)

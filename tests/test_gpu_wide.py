@@ -1,0 +1,188 @@
+"""More than 255 thresholds per feature (k_wide.hip) against the oracle: QuickRank's
+default `--num-thresholds 0` on real-valued columns -- every distinct value a
+candidate, mart.cc:147-158, the setup of the reference's own forest tests
+(catch-unit-tests/learning/forests/test-lambdamart.cc "all thresholds") -- and
+--num-thresholds above 255 (the equal-width branch, mart.cc:159-169)."""
+import numpy as np
+import pytest
+
+from datagen import make_dataset
+from parity_util import assert_split_log_parity, assert_tree_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qr():
+    import quickrank_amd
+    from quickrank_amd import build
+    build.build()
+    return quickrank_amd
+
+
+@pytest.fixture(scope="module")
+def ora(oracle_lib):
+    return oracle_lib
+
+
+CASES = [
+    dict(nq=40, docs_per_query=30, F=16, seed=0),
+    dict(nq=25, docs_per_query=60, F=136, seed=1, ragged=True),
+    dict(nq=30, docs_per_query=40, F=70, seed=2, adversarial=True),
+    dict(nq=12, docs_per_query=300, F=33, seed=3, ragged=True, adversarial=True),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("nthr", [0, 256, 1000, 5000])
+def test_wide_thresholds_and_bins(qr, ora, case, nthr):
+    x, labels, qoff = make_dataset(**case)
+    col = np.ascontiguousarray(x.T)
+    othr, ots = ora.thresholds(col, nthr)
+    c = qr.Context(0)
+    c.upload(x, labels, qoff)
+    thr, ts = c.build_bins(nthr)
+    assert c.wide
+    assert np.array_equal(ts.astype(np.uint64), ots)
+    for f in range(x.shape[1]):
+        n = int(ots[f])
+        assert np.array_equal(thr[f, :n].view(np.uint32), othr[f, :n].view(np.uint32)), f
+    stmap, _ = ora.binmap(col, othr, ots)
+    assert np.array_equal(c.read_bins_u32().T, stmap)
+    c.close()
+
+
+def test_wide_is_chosen_only_when_needed(qr):
+    x, labels, qoff = make_dataset(nq=20, docs_per_query=30, F=8, seed=0)
+    c = qr.Context(0)
+    c.upload(x, labels, qoff)
+    with pytest.raises(qr.QrError):      # 600 distinct values per column do not fit u8 bins ...
+        c.build_bins(0, wide=False)
+    c.build_bins(0)                      # ... so nthresholds = 0 takes the wide path
+    assert c.wide
+    c.close()
+    c = qr.Context(0)
+    c.upload(np.floor(x * 100) / 100, labels, qoff)
+    c.build_bins(0)                      # <= 255 distinct values: the u8 path, as before
+    assert not c.wide
+    c.close()
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("nthr,nleaves,minls", [(0, 10, 1), (1000, 16, 5), (300, 4, 1)])
+def test_wide_root_histogram_and_tree(qr, ora, case, nthr, nleaves, minls):
+    x, labels, qoff = make_dataset(**case)
+    rng = np.random.default_rng(11)
+    scores = rng.standard_normal(len(labels)) * 0.3
+    olam, ow = ora.lambdas(labels, scores, qoff, 10, 1)
+    c = qr.Context(0)
+    c.upload(x, labels, qoff)
+    c.build_bins(nthr)
+    c.set_pseudo(olam, ow)
+    nodes = c.fit_tree(nleaves, minls, True)
+    tr = ora.Trainer(x, nthr)
+    ot = tr.fit_tree(olam, nleaves=nleaves, minls=minls)
+    tr.update_output(ot, olam, ow)
+    hs, hc = c.node_hist_ragged(0)
+    os_, oc, _ = ora.hist_build(tr.stmap, tr.thr_size, tr.cap, olam)
+    tol = 2.0 ** -30 * max(1.0, np.abs(olam).max()) * np.sqrt(len(olam))
+    for f in range(x.shape[1]):
+        n = int(tr.thr_size[f])
+        assert np.array_equal(hc[f], oc[f, :n]), f
+        assert np.allclose(hs[f], os_[f, :n], rtol=0, atol=tol), f
+    on = ot["nodes"]
+    ties = assert_tree_parity(tr.stmap, on, nodes, value_rtol=1e-9)
+    assert_split_log_parity(c.split_log(), ot["splits"], ties)
+    for li, on_leaf in enumerate(ot["leaf_nodes"]):
+        ids = c.node_samples(ties.node_map[int(on_leaf)])
+        assert np.array_equal(ids, np.nonzero(ot["leaf_of_doc"] == li)[0].astype(np.uint32))
+    c.set_scores(scores)
+    c.update_scores(0.1)
+    s2 = scores.copy()
+    tr.update_scores(ot, 0.1, s2)
+    assert np.allclose(c.get_scores(), s2, rtol=1e-12, atol=1e-13)
+    c.close()
+
+
+@pytest.mark.parametrize("algo", ["LAMBDAMART", "MART"])
+@pytest.mark.parametrize("case,nthr,nleaves", [(CASES[0], 0, 10), (CASES[1], 0, 10), (CASES[2], 1000, 8),
+                                               (CASES[3], 0, 16)])
+def test_wide_training_loop(qr, ora, algo, case, nthr, nleaves):
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(**case)
+    ntrees = 8
+    kw = dict(ntrees=ntrees, shrinkage=0.1, nthresholds=nthr, nleaves=nleaves, minls=1, esr=0)
+    om = ora.train(x, labels, qoff, algo=algo, **kw)
+    gm = Mart(algo=algo, **kw).learn(x, labels, qoff)
+    assert gm.ctx.wide and len(gm.ensemble) == om["ntrees_built"]
+    tr = ora.Trainer(x, nthr)
+    for t in range(ntrees):
+        n = int(om["nnodes"][t])
+        assert_tree_parity(tr.stmap, om["nodes"][t][:n], gm.ensemble.trees[t][:n])
+    assert np.allclose(gm.train_metric, om["train_metric"], rtol=1e-9)
+    assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-8, atol=1e-10)
+    gm.ctx.close()
+
+
+@pytest.mark.parametrize("algo", ["LAMBDAMART", "MART"])
+def test_wide_training_loop_medium_exact(qr, ora, algo):
+    """The reference's default flags (`--num-thresholds 0`) on 20k documents x 136
+    real-valued features: up to 20001 slots per feature; the (feature, slot) sequence
+    must match the oracle bit for bit."""
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(nq=200, docs_per_query=100, F=136, seed=21)
+    kw = dict(ntrees=5, shrinkage=0.1, nthresholds=0, nleaves=10, minls=50, esr=0)
+    om = ora.train(x, labels, qoff, algo=algo, **kw)
+    gm = Mart(algo=algo, **kw).learn(x, labels, qoff)
+    tr = ora.Trainer(x, 0)
+    for t in range(kw["ntrees"]):
+        n = int(om["nnodes"][t])
+        assert assert_tree_parity(tr.stmap, om["nodes"][t][:n], gm.ensemble.trees[t][:n], exact=True) == 0
+    assert np.allclose(gm.train_metric, om["train_metric"], rtol=1e-10)
+    assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-9, atol=1e-11)
+    gm.ctx.close()
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("nthr,depth,minls", [(0, 3, 1), (1000, 4, 5), (300, 6, 1)])
+def test_wide_oblivious_tree(qr, ora, case, nthr, depth, minls):
+    x, labels, qoff = make_dataset(**case)
+    rng = np.random.default_rng(13)
+    scores = rng.standard_normal(len(labels)) * 0.3
+    olam, ow = ora.lambdas(labels, scores, qoff, 10, 1)
+    c = qr.Context(0)
+    c.upload(x, labels, qoff)
+    c.build_bins(nthr)
+    c.set_pseudo(olam, ow)
+    nodes = c.fit_oblivious(depth, minls, True)
+    tr = ora.Trainer(x, nthr)
+    ot = tr.fit_tree(olam, minls=minls, oblivious_depth=depth)
+    tr.update_output(ot, olam, ow)
+    on = ot["nodes"]
+    assert len(nodes) == len(on)
+    assert np.array_equal(nodes["feature"] == -2, on["feature"] == -2)
+    ties = assert_tree_parity(tr.stmap, on, nodes, value_rtol=1e-9)
+    log, olog = c.split_log(), ot["splits"]
+    assert len(log) == len(olog)
+    if ties == 0:
+        assert np.array_equal(log["feature"].astype(np.uint64), olog["feature"])
+        assert np.array_equal(log["thr_id"].astype(np.uint64), olog["thr_id"])
+    assert np.allclose(log["score"], olog["score"], rtol=1e-9)
+    c.close()
+
+
+@pytest.mark.parametrize("algo", ["OBVLAMBDAMART", "OBVMART"])
+def test_wide_oblivious_training_loop(qr, ora, algo):
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(nq=120, docs_per_query=60, F=40, seed=23)
+    kw = dict(ntrees=6, shrinkage=0.1, nthresholds=0, minls=10, esr=0)
+    om = ora.train(x, labels, qoff, algo=algo, depth=4, **kw)
+    gm = Mart(algo=algo, depth=4, **kw).learn(x, labels, qoff)
+    assert gm.ctx.wide
+    tr = ora.Trainer(x, 0)
+    for t in range(kw["ntrees"]):
+        n = int(om["nnodes"][t])
+        assert_tree_parity(tr.stmap, om["nodes"][t][:n], gm.ensemble.trees[t][:n])
+    assert np.allclose(gm.train_metric, om["train_metric"], rtol=1e-9)
+    assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-8, atol=1e-10)
+    gm.ctx.close()

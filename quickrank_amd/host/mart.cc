@@ -262,7 +262,18 @@ void Mart::learn(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::
     QR(qr_valid_upload(ctx_, validation->at(0, 0), validation->num_instances(), validation->num_features(),
                        validation->labels(),
                        validation->offsets().data(), validation->num_queries()));
-  QR(qr_bins_build(ctx_, nthresholds_, nullptr, nullptr));
+  // Up to 255 thresholds per feature: u8 bins.  More -- --num-thresholds above 255, or the
+  // default 0 ("every distinct value", quicklearn.cc:103) on a column with more than 255 of
+  // them -- the wide path (u32 bins, ragged threshold rows): same trees, slower kernels.
+  int brc = nthresholds_ <= 255 ? qr_bins_build(ctx_, nthresholds_, nullptr, nullptr) : QR_ERR_UNSUPPORTED;
+  if (brc == QR_ERR_UNSUPPORTED && (nthresholds_ == 0 || nthresholds_ > 255)) {
+    size_t cells = 0, cap = 0;
+    brc = qr_bins_build_wide(ctx_, nthresholds_, &cells, &cap);
+    if (brc == QR_OK)
+      std::cout << "# " << cells << " threshold slots over " << training->num_features()
+                << " features (up to " << cap << " per feature): 32-bit bins" << std::endl;
+  }
+  QR(brc);
   QR(qr_scores_reset(ctx_));
   const bool sampling = subsample_ != 1.0f || max_features_ != 1.0f;
   if (sampling) {

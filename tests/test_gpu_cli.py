@@ -286,3 +286,43 @@ def test_detailed_partial_scores_and_narrow_files(tools, oracle_lib, tmp_path):
         rc = c.L.qr_ensemble_score_device(c.h, C.c_void_p(d.data_ptr()), 4, 3, C.c_void_p(o.data_ptr()))
         assert rc == 3                                      # QR_ERR_ARG
     c.close()
+
+
+def test_quicklearn_default_thresholds_all_distinct_values(tools, oracle_lib, tmp_path):
+    """quicklearn with the reference's DEFAULT --num-thresholds (0: every distinct value of
+    a feature is a candidate, quicklearn.cc:103 -- the only setting the reference's own
+    forest tests use): real-valued columns need thousands of slots, so the wide path runs.
+    Every split of the saved model cuts its node into the oracle's two sets, on the same
+    feature; leaf values and the scores file agree."""
+    x, labels, qoff = make_dataset(nq=100, docs_per_query=40, F=20, seed=61)
+    tr = str(tmp_path / "train.svml")
+    _write_svml(tr, x, labels, qoff)
+    x = np.array([[np.float32(f"{float(v):.9g}") for v in row] for row in x], np.float32)
+    model, scores = str(tmp_path / "model.xml"), str(tmp_path / "scores.txt")
+    cmd = [tools["quicklearn"], "--algo", "LAMBDAMART", "--train", tr, "--test", tr, "--num-trees", "5",
+           "--num-leaves", "8", "--min-leaf-support", "5", "--model-out", model, "--scores", scores]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "32-bit bins" in out.stdout
+    nodes, w = _load_model(tools, model)
+    om = oracle_lib.train(x, labels, qoff, algo="LAMBDAMART", ntrees=5, shrinkage=0.1, nthresholds=0,
+                          nleaves=8, minls=5, esr=0)
+    t = oracle_lib.Trainer(x, 0)
+    for i in range(5):
+        o, g = om["nodes"][i][:int(om["nnodes"][i])], nodes[i]
+        stack = [(0, 0, np.arange(len(labels)))]
+        while stack:
+            oi, gi, d = stack.pop()
+            assert (o[oi]["feature"] < 0) == (g[gi]["feature"] < 0)
+            if o[oi]["feature"] < 0:
+                assert np.isclose(g[gi]["value"], o[oi]["value"], rtol=1e-7, atol=1e-10)
+                continue
+            assert g[gi]["feature"] == o[oi]["feature"]
+            f = int(o[oi]["feature"])
+            ol = t.stmap[f, d] <= o[oi]["thr_id"]
+            gl = x[d, f] <= g[gi]["threshold"]           # the model carries the value, not the slot
+            assert np.array_equal(ol, gl), (i, oi)
+            stack.append((int(o[oi]["left"]), int(g[gi]["left"]), d[ol]))
+            stack.append((int(o[oi]["right"]), int(g[gi]["right"]), d[~ol]))
+    s = np.loadtxt(scores)
+    assert np.allclose(s, om["train_scores"], rtol=1e-7, atol=1e-10)

@@ -320,3 +320,29 @@ def test_config1_mslr_standin_vs_oracle(oracle_lib):
     # stay far inside north_star's 1e-5
     _compare_run(gm, om, x, 255, 100, metric_rtol=1e-10, score_rtol=1e-8, value_rtol=1e-8)
     gm.ctx.close()
+
+
+def test_config1_mslr_standin_1024_thresholds_vs_oracle(oracle_lib):
+    """The MSLR-shaped stand-in with more than 255 thresholds (k_wide.hip): 1024
+    equal-width thresholds on the 96 real-valued columns (mart.cc:159-169), every
+    distinct value on the 40 count columns; 10 LambdaMART iterations, 10 leaves."""
+    import torch
+    torch.cuda.init()
+    from datagen import make_mslr_like
+    from parity_util import assert_tree_parity
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_mslr_like()
+    kw = dict(ntrees=10, shrinkage=0.1, nthresholds=1024, nleaves=10, minls=1, esr=0)
+    om = oracle_lib.train(x, labels, qoff, algo="LAMBDAMART", **kw)
+    gm = Mart(algo="LAMBDAMART", **kw).learn(x, labels, qoff)
+    assert gm.ctx.wide and len(gm.ensemble) == 10
+    tr = oracle_lib.Trainer(x, 1024)
+    nties = 0
+    for t in range(10):
+        n = int(om["nnodes"][t])
+        nties += int(assert_tree_parity(tr.stmap, om["nodes"][t][:n], gm.ensemble.trees[t][:n], value_rtol=1e-8,
+                                        tie_max_docs=len(labels)))
+    assert nties <= 9          # empty adjacent slots in sibling histograms (see test_gpu_wide.py)
+    assert np.allclose(gm.train_metric, om["train_metric"], rtol=1e-10, atol=0)
+    assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-8, atol=1e-12)
+    gm.ctx.close()

@@ -237,6 +237,16 @@ __device__ __forceinline__ double qr_exp(double x, const double *T) {
   return ldexp(fma(t, e, t), k >> 6);
 }
 
+// 1 / x for x >= 1 (the logistic's denominator): hardware seed + two Newton steps, a few
+// ulp -- the lambdas' bar is 1e-5 (north_star), the tests ask 1e-11; a correctly rounded
+// f64 division costs four times the instructions
+__device__ __forceinline__ double qr_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 // pow(2.0, label) of dcg.cc:37 / ndcg.cc:80: exact for the integral relevance
 // grades LETOR data carries.
 __device__ __forceinline__ double pow2_label(float l) {
@@ -435,13 +445,41 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
   // The key IS the number of strictly greater scores, so the elements of key k end
   // up in positions k, k+1, ...: only the equal-key elements standing before x in
   // the current arrangement have to be counted.
-  const int n4 = (n + 3) & ~3;
-  for (int x = lane; x < n; x += 64) {
-    const uint32_t kx = pk(a[x]);
-    uint32_t r = kx;
+  // A key that occurs once is its own position.  The duplicated keys are handled one
+  // distinct value at a time (uniform loop): the ballots of "my key == k" over the 64-
+  // position chunks give every holder the number of equal keys standing before it.
+  // Early boosting iterations have a handful of distinct scores per query, later ones
+  // few duplicates: either way far fewer steps than comparing every pair of positions.
+  if (n <= 128) {
+    const int x0 = lane, x1 = lane + 64;
+    const bool in0 = x0 < n, in1 = x1 < n;
+    const uint32_t v0 = in0 ? a[x0] : 0xFFFFFFFFu, v1 = in1 ? a[x1] : 0xFFFFFFFFu;
+    const uint32_t k0 = pk(v0), k1 = pk(v1);
+    uint32_t r0 = k0, r1 = k1;
+    unsigned long long todo0 = __ballot(in0 && dupk[in0 ? k0 : 0] != 0);
+    unsigned long long todo1 = __ballot(in1 && dupk[in1 ? k1 : 0] != 0);
+    while (todo0 | todo1) {
+      const int src = todo0 ? __ffsll((long long)todo0) - 1 : __ffsll((long long)todo1) - 1;
+      const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)(todo0 ? k0 : k1), src);
+      const unsigned long long m0 = __ballot(in0 && k0 == k), m1 = __ballot(in1 && k1 == k);
+      if (in0 && k0 == k) r0 = k + (uint32_t)__popcll(m0 & lt);
+      if (in1 && k1 == k) r1 = k + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & lt);
+      todo0 &= ~m0;
+      todo1 &= ~m1;
+    }
+    if (in0) out[r0] = v0 & 0xFFFFu;
+    if (in1) out[r1] = v1 & 0xFFFFu;
+  } else {
+    const int n4 = (n + 3) & ~3;
+    for (int x = lane; x < n; x += 64) {
+      const uint32_t kx = pk(a[x]);
+      uint32_t r = kx;
+      if (dupk[kx]) {
 #pragma unroll 4
-    for (int y = 0; y < n4; ++y) r += (pk(a[y]) == kx) & (y < x);
-    out[r] = a[x] & 0xFFFFu;
+        for (int y = 0; y < n4; ++y) r += (pk(a[y]) == kx) & (y < x);
+      }
+      out[r] = a[x] & 0xFFFFu;
+    }
   }
   __syncthreads();
 }
@@ -611,13 +649,21 @@ __global__ __launch_bounds__(64) void k_lambda(
     __syncthreads();
   }
   // ---- 3. metric of the current ranking (dcg.cc:33-39, ndcg.cc:49-58)
-  if (lane == 0) {
+  {
+    // the terms in parallel (one IEEE division per lane), the sum in rank order -- the
+    // summation order of dcg.cc:36-38, so the value is bit for bit the sequential one
     double dcg = 0.0;
-    for (uint32_t i = 0; i < size; ++i)
-      dcg += (pow2_label(sl[i]) - 1.0) / lg2[i];
-    double m = dcg;
-    if (metric == QR_METRIC_NDCG) m = my_idcg > 0 ? dcg / my_idcg : 0.0;
-    qmetric[q] = m;
+    for (uint32_t base = 0; base < size; base += 64) {
+      const uint32_t i = base + lane;
+      const double term = i < size ? (pow2_label(sl[i]) - 1.0) / lg2[i] : 0.0;
+      const uint32_t m = size - base < 64 ? size - base : 64;
+      for (uint32_t k = 0; k < m; ++k) dcg += readlane_f64(term, (int)k);
+    }
+    if (lane == 0) {
+      double m = dcg;
+      if (metric == QR_METRIC_NDCG) m = my_idcg > 0 ? dcg / my_idcg : 0.0;
+      qmetric[q] = m;
+    }
   }
   QR_T(4);
   if (mode == 1) return;
@@ -641,6 +687,77 @@ __global__ __launch_bounds__(64) void k_lambda(
   __syncthreads();
   const double *pw = s;
   const uint32_t nbatch = (n + 63) / 64;
+  const double inv_idcg = metric == QR_METRIC_NDCG ? 1.0 / my_idcg : 1.0;  // (ndcg.cc:81: / idcg, to an ulp)
+  // one pair term (lambdamart.cc:120-141 with the closed form of ndcg.cc:76-88): rank r1
+  // (uniform over the wave) against this lane's rank r2 > r1
+  auto pair_term = [&](const float l1, const double p1, const double inv1, const double s1,
+                       const float l2, const double p2, const double il2, const double s2, double &lam,
+                       double &del, bool &hi1) {
+    const double j = (il2 - inv1) * (p1 - p2);   // il2 == 0 beyond the cutoff (ndcg.cc:84-86)
+    const double d = fabs(j * inv_idcg);
+    hi1 = l1 > l2;  // the higher label plays "j" in lambdamart.cc:127
+    const double diff = hi1 ? s1 - s2 : s2 - s1;
+    const double rho = qr_rcp(1.0 + qr_exp(diff, expt));
+    lam = rho * d;
+    del = rho * (1.0 - rho) * d;
+  };
+  if (n <= 128) {
+    // Every lane keeps its two ranks (lane, lane + 64) -- label, 2^label, discount,
+    // score and the two accumulators -- in registers for the whole sweep; the only
+    // memory traffic of a step is the broadcast read of rank r1's four values, and the
+    // two ranks' terms are independent instruction chains.  Same additions in the same
+    // order as the general loop below.
+    const uint32_t ra = lane, rb = lane + 64;
+    const bool ina = ra < n, inb = rb < n;
+    const float la = ina ? sl[ra] : 0.f, lb = inb ? sl[rb] : 0.f;
+    const double pa_ = ina ? pw[ra] : 0.0, pb_ = inb ? pw[rb] : 0.0;
+    const double ia = ra < size ? ilt[ra] : 0.0, ib = rb < size ? ilt[rb] : 0.0;
+    const double sa = ina ? sr[ra] : 0.0, sb = inb ? sr[rb] : 0.0;
+    double ola = 0.0, owa = 0.0, olb = 0.0, owb = 0.0;
+    for (uint32_t r1 = 0; r1 < size; ++r1) {
+      const float l1 = sl[r1];
+      const double p1 = pw[r1], inv1 = ilt[r1], s1 = sr[r1];
+      double c1 = 0.0, cw = 0.0;
+      const bool va = ina && ra > r1 && l1 != la, vb = inb && rb > r1 && l1 != lb;
+      if (va) {
+        double lam, del;
+        bool hi1;
+        pair_term(l1, p1, inv1, s1, la, pa_, ia, sa, lam, del, hi1);
+        c1 += hi1 ? lam : -lam;
+        cw += del;
+        ola += hi1 ? -lam : lam;
+        owa += del;
+      }
+      if (vb) {
+        double lam, del;
+        bool hi1;
+        pair_term(l1, p1, inv1, s1, lb, pb_, ib, sb, lam, del, hi1);
+        c1 += hi1 ? lam : -lam;
+        cw += del;
+        olb += hi1 ? -lam : lam;
+        owb += del;
+      }
+      if (__any(c1 != 0.0 || cw != 0.0)) {
+        const double t1 = wave_sum(c1);
+        const double tw = wave_sum(cw);
+        if (lane == 0) {
+          accl[r1] = t1;
+          accw[r1] = tw;
+        }
+      } else if (lane == 0) {
+        accl[r1] = 0.0;
+        accw[r1] = 0.0;
+      }
+    }
+    if (ina) {
+      ownl[ra] = ola;
+      ownw[ra] = owa;
+    }
+    if (inb) {
+      ownl[rb] = olb;
+      ownw[rb] = owb;
+    }
+  } else
   for (uint32_t r1 = 0; r1 < size; ++r1) {
     // uniform over the wave
     const float l1 = sl[r1];
@@ -653,20 +770,9 @@ __global__ __launch_bounds__(64) void k_lambda(
       if (r2 < n && r2 > r1) {
         const float l2 = sl[r2];
         if (l1 != l2) {
-          const double p2 = pw[r2];
-          double j;
-          if (r2 < size)
-            j = (ilt[r2] - inv1) * (p1 - p2);
-          else
-            j = (-inv1) * (p1 - p2);
-          if (metric == QR_METRIC_NDCG) j = j / my_idcg;
-          const double d = fabs(j);
-          const bool hi1 = l1 > l2;  // the higher label plays "j" in lambdamart.cc:127
-          const double s2 = sr[r2];
-          const double diff = hi1 ? s1 - s2 : s2 - s1;
-          const double rho = 1.0 / (1.0 + qr_exp(diff, expt));
-          const double lam = rho * d;
-          const double del = rho * (1.0 - rho) * d;
+          double lam, del;
+          bool hi1;
+          pair_term(l1, p1, inv1, s1, l2, pw[r2], r2 < size ? ilt[r2] : 0.0, sr[r2], lam, del, hi1);
           c1 += hi1 ? lam : -lam;
           cw += del;
           ownl[r2] += hi1 ? -lam : lam;  // only this lane touches rank r2

@@ -496,8 +496,10 @@ def test_error_paths_return_codes_not_crashes(qr):
     with pytest.raises(qr.QrError, match="follows qr_lambda_compute"):
         c.metric_last()
     c.upload(x, labels, qoff)
+    with pytest.raises(qr.QrError, match="wide path"):
+        c.build_bins(300, wide=False)      # more than 255 thresholds are the wide path's (test_gpu_wide.py)
     with pytest.raises(qr.QrError, match="nthresholds <= 255"):
-        c.build_bins(300)
+        c._ck(c.L.qr_bins_build(c.h, 300, None, None))
     with pytest.raises(qr.QrError, match="bins not built"):
         c.set_subsample(0.5)
     c.build_bins(16)

@@ -76,6 +76,9 @@ void qr_ctx_destroy(qr_ctx *ctx);
 const char *qr_last_error(const qr_ctx *ctx);
 /* run every launch on the caller's HIP stream (e.g. torch's current stream)    */
 int qr_ctx_set_stream(qr_ctx *ctx, void *hip_stream);
+/* the HIP stream the context launches on (a hipStream_t): what a host hands to      */
+/* ncclAllReduce / ncclAllGather for the exchanges of the multi-GPU protocols below   */
+int qr_ctx_stream(qr_ctx *ctx, void **hip_stream_out);
 /* feature-block sharding for the multi-GPU path: this   */
 /* rank owns features [rank*ceil(F/world), (rank+1)*ceil(F/world)) of the bins.  */
 /* Must be called before qr_bins_build.  Default rank 0 / world 1.              */

@@ -41,7 +41,7 @@ SYMBOLS = [
     "qr_doc_exchange_buffers", "qr_tree_nodes", "qr_valid_scores_set",
     "qr_tree_set_max_features", "qr_subsample_set", "qr_ensemble_partial_scores",
     "qr_prof_get_child", "qr_bins_build_wide", "qr_thresholds_read", "qr_bins_read_u32",
-    "qr_node_hist_read_ragged",
+    "qr_node_hist_read_ragged", "qr_ctx_stream",
 ]
 
 _LIB = None
@@ -81,6 +81,7 @@ def lib():
     L.qr_last_error.argtypes = [vp]
     L.qr_last_error.restype = C.c_char_p
     L.qr_ctx_set_stream.argtypes = [vp, vp]
+    L.qr_ctx_stream.argtypes = [vp, C.POINTER(vp)]
     L.qr_ctx_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.qr_synchronize.argtypes = [vp]
     L.qr_dataset_upload.argtypes = [vp, vp, sz, sz, vp, vp, sz]

@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
 
 HOST = os.path.join(HERE, "host")
 BINDIR = os.path.join(HERE, "bin")
-HOST_SRCS = ["svml.cc", "xml.cc", "mart.cc", "codegen.cc"]
+HOST_SRCS = ["svml.cc", "xml.cc", "mart.cc", "mart_multi.cc", "codegen.cc"]
 HOST_LIB = os.path.join(LIBDIR, "libqr_host.so")
 
 
@@ -52,9 +52,14 @@ def build_host(force=False, verbose=False):
         return outs
     os.makedirs(BINDIR, exist_ok=True)
     cxx = os.environ.get("CXX", "g++")
-    common = [cxx, "-std=c++17", "-O2", "-fPIC", "-fopenmp", "-Wall", "-Wno-unused-result"]
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    # (mart_multi.cc calls RCCL: its header needs HIP's types, which g++ gets with the
+    # platform macro HIP itself defines under hipcc)
+    common = [cxx, "-std=c++17", "-O2", "-fPIC", "-fopenmp", "-pthread", "-Wall", "-Wno-unused-result",
+              "-Wno-deprecated-declarations", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include")]
     core = [os.path.join(HOST, f) for f in HOST_SRCS]
-    link = ["-L" + LIBDIR, "-lqr_hip", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,$ORIGIN"]
+    link = ["-L" + LIBDIR, "-lqr_hip", "-L" + os.path.join(rocm, "lib"), "-lrccl",
+            "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
     cmds = [common + ["-shared", "-o", HOST_LIB] + core + [os.path.join(HOST, "host_capi.cc")] + link,
             common + ["-o", outs[1]] + core + [os.path.join(HOST, "quicklearn.cc")] + link,
             common + ["-o", outs[2]] + core + [os.path.join(HOST, "quickscore.cc")] + link]

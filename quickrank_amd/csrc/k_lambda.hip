@@ -991,7 +991,7 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   }
   const size_t kshort = std::min(kacc, nmax);  // nmax is a multiple of 4: stays even
   const size_t lds = lambda_lds(nmax, kshort, sampled);
-  static size_t attr_lds = 64 * 1024;
+  size_t &attr_lds = c->attr_lambda_lds;
   if (lds > attr_lds) {
     QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -2652,7 +2652,7 @@ static int launch_scan(qr_ctx *c, int root_mode);
 static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
   if (c->wide) return qr_k_whist_scan(c, root_mode);  // more than 255 thresholds: k_wide.hip
   const size_t lds = hist_lds(c);
-  static size_t attr_lds = 0;
+  size_t &attr_lds = c->attr_hist_lds;
   if (lds > attr_lds) {
     QR_CHECK(c, hipFuncSetAttribute((const void *)k_hist,
                                     hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -480,7 +480,7 @@ static size_t whist_lds(const qr_ctx *c) {
 }
 
 static int whist_attr(qr_ctx *c) {
-  static size_t attr = 0;
+  size_t &attr = c->attr_whist_lds;
   const size_t lds = whist_lds(c);
   if (lds > attr) {
     QR_CHECK(c, hipFuncSetAttribute((const void *)k_whist, hipFuncAttributeMaxDynamicSharedMemorySize,

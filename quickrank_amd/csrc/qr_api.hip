@@ -169,6 +169,12 @@ int qr_ctx_set_stream(qr_ctx *c, void *s) {
   return QR_OK;
 }
 
+int qr_ctx_stream(qr_ctx *c, void **stream_out) {
+  if (!c || !stream_out) return QR_ERR_ARG;
+  *stream_out = (void *)c->stream;
+  return QR_OK;
+}
+
 int qr_ctx_set_shard(qr_ctx *c, int rank, int world) {
   if (!c) return QR_ERR_ARG;
   if (world < 1 || rank < 0 || rank >= world) QR_FAIL(c, QR_ERR_ARG, "bad rank/world");

@@ -411,6 +411,9 @@ struct qr_ctx {
   uint32_t *d_ob_fk = nullptr;      // [trees][depth]: feature | threshold index << 16
   float *d_ob_thr = nullptr;        // [ob_F][ob_tmax] sorted distinct thresholds per feature
   uint32_t *d_ob_thr_cnt = nullptr;
+  // largest dynamic-LDS size announced to the runtime per kernel family (a function
+  // attribute is a per-device setting: one process may drive several devices)
+  size_t attr_hist_lds = 0, attr_lambda_lds = 64 * 1024, attr_whist_lds = 0;
   // profiling
   bool prof_on = false;
   bool prof_child = false;       // also time the child-histogram launches (qr_prof_enable(ctx, 2 | 1))

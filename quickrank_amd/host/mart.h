@@ -78,6 +78,11 @@ class Mart {
   void learn(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::Dataset> validation,
              const std::string &metric, size_t cutoff, size_t partial_save,
              const std::string &output_basename);
+  // The same on `ngpus` GPUs of one node (host/mart_multi.cc): a host thread per GPU,
+  // RCCL on the contexts' streams; documents (default) or feature blocks sharded.
+  void learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::Dataset> validation,
+                   const std::string &metric, size_t cutoff, size_t partial_save,
+                   const std::string &output_basename, int ngpus, bool feature_sharded);
   // ltr_algorithm.cc:44-52 on the device
   void score_dataset(const data::Dataset &dataset, Score *scores, float *kernel_ms = nullptr);
   // Driver::extract_partial_scores (driver.cc:411-445) over Ensemble::partial_scores_instance
@@ -106,6 +111,9 @@ class Mart {
   qr_ctx *ctx_ = nullptr;
   MetricScore best_metric_on_training_ = 0, best_metric_on_validation_ = 0;
   size_t best_model_ = 0;
+  // learn_multi: every rank's thread keeps the (identical) best-model bookkeeping
+  std::vector<MetricScore> best_train_r_, best_valid_r_;
+  std::vector<size_t> best_model_r_;
 };
 
 }  // namespace forests

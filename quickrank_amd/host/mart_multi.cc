@@ -1,0 +1,388 @@
+// mart_multi.cc -- Mart::learn on the GPUs of one node: `quicklearn --gpus N`.
+//
+// One process, one host thread per GPU; every thread drives its own device context
+// (include/qr_hip.h) on its own HIP stream and calls RCCL (ncclAllReduce /
+// ncclAllGather over xGMI) on that same stream between the phase calls, so no
+// collective ever waits on the host.  Two layouts:
+//
+//   documents  rank r holds the queries [r Q/N, (r+1) Q/N) and every feature of them.
+//              What is exchanged is the node histogram itself -- exact fixed-point
+//              integers, so ONE int64 sum all-reduce per histogram gives every rank the
+//              bits one GPU would have accumulated over all documents; scan, gains, heap
+//              and partition then run redundantly / locally and agree without another
+//              exchange.  Thresholds come from the whole set (column statistics gathered
+//              over the ranks, mart.cc:147-169 over their union).  The default.
+//   features   north_star's layout: every rank holds all documents and the feature
+//              columns [r F/N, (r+1) F/N) of the bin matrix; per split an all-gather of
+//              the ranks' best-split records and a sum all-reduce of the go-left bit mask
+//              (only the owner of the winning feature contributes non-zero words).
+//
+// The boosting loop is Mart::learn's (mart.cc:307-395): validation, early stop, rollback
+// and --partial saves included.  Rank 0 keeps the ensemble; every other rank checks that
+// it built the same tree and the run stops if one did not.
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <mutex>
+#include <thread>
+
+#include "mart.h"
+
+namespace quickrank {
+namespace learning {
+namespace forests {
+
+namespace {
+
+class Barrier {  // reusable; std::barrier is C++20
+ public:
+  explicit Barrier(int n) : n_(n) {}
+  void wait() {
+    std::unique_lock<std::mutex> lk(m_);
+    const size_t gen = gen_;
+    if (++count_ == n_) {
+      count_ = 0;
+      ++gen_;
+      cv_.notify_all();
+    } else {
+      cv_.wait(lk, [&] { return gen != gen_; });
+    }
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  int n_, count_ = 0;
+  size_t gen_ = 0;
+};
+
+[[noreturn]] void die(qr_ctx *c, const char *what) {
+  std::cerr << "!!! " << what << ": " << qr_last_error(c) << std::endl;
+  exit(EXIT_FAILURE);
+}
+#define QRM(c, call)                           \
+  do {                                         \
+    if ((call) != QR_OK) die(c, #call);        \
+  } while (0)
+#define NCCL(call)                                                                     \
+  do {                                                                                 \
+    const ncclResult_t r_ = (call);                                                    \
+    if (r_ != ncclSuccess) {                                                           \
+      std::cerr << "!!! " #call ": " << ncclGetErrorString(r_) << std::endl;           \
+      exit(EXIT_FAILURE);                                                              \
+    }                                                                                  \
+  } while (0)
+
+struct Shared {
+  int world;
+  Barrier bar;
+  // thresholds of the whole set (document layout): per-rank column statistics
+  std::vector<uint32_t> vals, cnt, mm;
+  // per-rank (sum of per-query metrics, queries) of the training / validation set
+  std::vector<double> msum[2], mq[2];
+  // rank 0's tree of the iteration, for the cross-rank check
+  std::vector<qr_node_t> nodes0;
+  size_t nn0 = 0;
+  explicit Shared(int w) : world(w), bar(w) {
+    for (int k = 0; k < 2; ++k) {
+      msum[k].assign(w, 0.0);
+      mq[k].assign(w, 0.0);
+    }
+  }
+};
+
+int metric_code_of(const std::string &m) {
+  if (m == "NDCG") return QR_METRIC_NDCG;
+  if (m == "DCG") return QR_METRIC_DCG;
+  std::cerr << " !! Train Metric was not set properly" << std::endl;  // driver.cc:114-117
+  exit(EXIT_FAILURE);
+}
+
+// whole queries [q0, q1) of rank r
+void query_slice(size_t Q, int r, int w, size_t *q0, size_t *q1) {
+  const size_t per = (Q + (size_t)w - 1) / (size_t)w;
+  *q0 = std::min(Q, per * (size_t)r);
+  *q1 = std::min(Q, per * (size_t)(r + 1));
+}
+
+}  // namespace
+
+void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::Dataset> validation,
+                       const std::string &metric, size_t cutoff, size_t partial_save,
+                       const std::string &output_basename, int ngpus, bool feature_sharded) {
+  if (algo_ >= OBVMART) {
+    std::cerr << "!!! --gpus > 1 trains MART / LAMBDAMART (oblivious trees are single-GPU)." << std::endl;
+    exit(EXIT_FAILURE);
+  }
+  if (subsample_ != 1.0f || max_features_ != 1.0f || ensemble_model_.is_notempty() || nthresholds_ > 255 ||
+      nthresholds_ == 0) {
+    // (nthresholds 0 = every distinct value: fine on one GPU, where the wide path takes over
+    // when a column has more than 255 of them; the sharded contexts use u8 bins)
+    if (nthresholds_ == 0 || nthresholds_ > 255)
+      std::cerr << "!!! --gpus > 1 needs --num-thresholds in [1, 255]." << std::endl;
+    else
+      std::cerr << "!!! --gpus > 1 does not combine with --subsample / --max-features / --restart-train."
+                << std::endl;
+    exit(EXIT_FAILURE);
+  }
+  const int W = ngpus;
+  const int mcode = metric_code_of(metric);
+  const bool lambda = algo_ == LAMBDAMART;
+  const size_t N = training->num_instances(), F = training->num_features(), Q = training->num_queries();
+  if ((size_t)W > Q || (feature_sharded && (size_t)W > F)) {
+    std::cerr << "!!! more GPUs than " << (feature_sharded ? "features" : "queries") << std::endl;
+    exit(EXIT_FAILURE);
+  }
+  std::cout << "# Initialization";
+  std::cout.flush();
+  auto t_init0 = std::chrono::high_resolution_clock::now();
+  std::vector<ncclComm_t> comms(W);
+  std::vector<int> devs(W);
+  for (int r = 0; r < W; ++r) devs[r] = r;
+  NCCL(ncclCommInitAll(comms.data(), W, devs.data()));
+  Shared sh(W);
+  const uint32_t limit = (uint32_t)nthresholds_ + 1;
+  if (!feature_sharded) {
+    sh.vals.assign((size_t)W * F * (limit + 1), 0);
+    sh.cnt.assign((size_t)W * F, 0);
+    sh.mm.assign((size_t)W * 2 * F, 0);
+  }
+  best_metric_on_validation_ = std::numeric_limits<double>::lowest();
+  best_metric_on_training_ = std::numeric_limits<double>::lowest();
+  best_model_ = 0;
+  ensemble_model_.set_capacity(ntrees_);
+  const size_t maxnodes = 2 * nleaves_ + 1;
+  sh.nodes0.resize(maxnodes);
+  std::chrono::high_resolution_clock::time_point t_train0;
+
+  auto worker = [&](const int r) {
+    qr_ctx *c = nullptr;
+    if (qr_ctx_create(r, &c) != QR_OK) die(nullptr, "qr_ctx_create");
+    void *sv = nullptr;
+    QRM(c, qr_ctx_stream(c, &sv));
+    hipStream_t stream = (hipStream_t)sv;
+    ncclComm_t comm = comms[r];
+    int nranks = 0;
+    NCCL(ncclCommCount(comm, &nranks));
+    // ---- data
+    size_t tq0 = 0, tq1 = Q, vq0 = 0, vq1 = validation ? validation->num_queries() : 0;
+    if (feature_sharded) {
+      QRM(c, qr_ctx_set_shard(c, r, W));
+    } else {
+      query_slice(Q, r, W, &tq0, &tq1);
+      if (validation) query_slice(validation->num_queries(), r, W, &vq0, &vq1);
+      QRM(c, qr_ctx_set_doc_shard(c, r, W, N, Q));
+    }
+    auto upload = [&](const data::Dataset &ds, size_t q0, size_t q1, bool valid) {
+      const size_t d0 = ds.offset(q0), d1 = ds.offset(q1);
+      std::vector<uint64_t> qo(q1 - q0 + 1);
+      for (size_t q = q0; q <= q1; ++q) qo[q - q0] = ds.offset(q) - d0;
+      if (d1 == d0) return;  // (a rank without validation queries: nothing to upload)
+      if (valid)
+        QRM(c, qr_valid_upload(c, ds.at(d0, 0), d1 - d0, ds.num_features(), ds.labels() + d0, qo.data(),
+                               q1 - q0));
+      else
+        QRM(c, qr_dataset_upload(c, ds.at(d0, 0), d1 - d0, ds.num_features(), ds.labels() + d0, qo.data(),
+                                 q1 - q0));
+    };
+    upload(*training, tq0, tq1, false);
+    const bool has_valid = validation && vq1 > vq0;
+    if (has_valid) upload(*validation, vq0, vq1, true);
+    // ---- Mart::init: thresholds + bin map
+    if (feature_sharded) {
+      QRM(c, qr_bins_build(c, nthresholds_, nullptr, nullptr));
+    } else {
+      QRM(c, qr_bins_stats(c, nthresholds_, &sh.vals[(size_t)r * F * (limit + 1)], &sh.cnt[(size_t)r * F],
+                           &sh.mm[(size_t)r * 2 * F]));
+      sh.bar.wait();
+      std::vector<float> thr(F * QR_MAX_BINS);
+      std::vector<uint32_t> ts(F);
+      if (qr_thresholds_from_stats(F, nthresholds_, W, sh.vals.data(), sh.cnt.data(), sh.mm.data(), thr.data(),
+                                   ts.data()) != QR_OK)
+        die(c, "qr_thresholds_from_stats");
+      QRM(c, qr_bins_build_with(c, thr.data(), ts.data()));
+    }
+    QRM(c, qr_scores_reset(c));
+    void *x_hist = nullptr, *x_scal = nullptr, *x_leaf = nullptr, *recs_local = nullptr, *recs_all = nullptr,
+         *mask = nullptr;
+    size_t n_hist = 0, n_scal = 0, n_leaf = 0, rec_bytes = 0, mask_bytes = 0;
+    if (feature_sharded)
+      QRM(c, qr_exchange_buffers(c, &recs_local, &recs_all, &rec_bytes, &mask, &mask_bytes));
+    else
+      QRM(c, qr_doc_exchange_buffers(c, &x_hist, &n_hist, &x_scal, &n_scal, nullptr, nullptr));
+    auto sum64 = [&](void *p, size_t n) { NCCL(ncclAllReduce(p, p, n, ncclInt64, ncclSum, comm, stream)); };
+    sh.bar.wait();
+    if (r == 0) {
+      auto t_init1 = std::chrono::high_resolution_clock::now();
+      std::cout << ": " << std::setprecision(2) << std::chrono::duration<double>(t_init1 - t_init0).count()
+                << " s." << std::endl;
+      std::cout << "# " << W << " GPUs (RCCL communicator of " << nranks << " ranks), "
+                << (feature_sharded ? "feature-block" : "document") << " sharding" << std::endl;
+      std::cout << std::fixed << std::setprecision(4);
+      std::cout << "# Training:" << std::endl << "# -------------------------" << std::endl
+                << "# iter. training validation" << std::endl << "# -------------------------" << std::endl;
+      t_train0 = std::chrono::high_resolution_clock::now();
+    }
+    // the metric of set `which` over all ranks' queries (metric.h:77-106), the same bits on
+    // every rank: per-rank sums added in rank order
+    auto metric_all = [&](int which) -> MetricScore {
+      if (feature_sharded) {  // replicated documents: every rank evaluates everything
+        MetricScore v = 0;
+        QRM(c, qr_metric_eval(c, which, mcode, cutoff, &v));
+        return v;
+      }
+      const size_t nq = which ? vq1 - vq0 : tq1 - tq0;
+      MetricScore v = 0;
+      if (nq) QRM(c, qr_metric_eval(c, which, mcode, cutoff, &v));
+      sh.msum[which][r] = v * (double)nq;
+      sh.mq[which][r] = (double)nq;
+      sh.bar.wait();
+      double s = 0.0, n = 0.0;
+      for (int k = 0; k < W; ++k) {
+        s += sh.msum[which][k];
+        n += sh.mq[which][k];
+      }
+      sh.bar.wait();  // (everybody has read before the next call overwrites)
+      return n > 0 ? s / n : 0.0;
+    };
+    auto report = [&](size_t iter, MetricScore on_training, const MetricScore *on_validation) {
+      // best-model bookkeeping on every rank (same values), one table line from rank 0
+      bool star = false;
+      if (on_validation) {
+        if (*on_validation > best_valid_r_[r]) {
+          best_train_r_[r] = on_training;
+          best_valid_r_[r] = *on_validation;
+          best_model_r_[r] = iter - 1;
+          star = true;
+        }
+      } else if (on_training > best_train_r_[r]) {
+        best_train_r_[r] = on_training;
+        best_model_r_[r] = iter - 1;
+        star = true;
+      }
+      if (r == 0) {
+        std::cout << std::setw(7) << iter << std::setw(9) << on_training;
+        if (on_validation) std::cout << std::setw(9) << *on_validation;
+        if (star) std::cout << " *";
+        std::cout << std::endl;
+      }
+    };
+    std::vector<qr_node_t> nodes(maxnodes);
+    const bool lagged = lambda && !validation;  // as Mart::learn: the metric rides with the next lambda pass
+    size_t built = 0;
+    for (size_t m = 0; m < ntrees_; ++m) {
+      if (validation && (valid_iterations_ && m > best_model_r_[r] + valid_iterations_)) break;
+      // ---- pseudo-responses
+      if (lambda)
+        QRM(c, qr_lambda_compute(c, mcode, cutoff));  // lambdamart.cc:62-152
+      else
+        QRM(c, qr_residual_compute(c));               // mart.cc:418-431
+      if (!feature_sharded) {
+        sum64(x_scal, n_scal);
+        QRM(c, qr_lambda_finish(c));
+      }
+      // ---- tree
+      size_t nn = 0;
+      QRM(c, qr_tree_begin(c, nleaves_, minleafsupport_));
+      if (feature_sharded) {
+        NCCL(ncclAllGather(recs_local, recs_all, rec_bytes, ncclInt8, comm, stream));
+        for (size_t s = 0; s + 1 < nleaves_; ++s) {
+          QRM(c, qr_tree_decide(c));
+          NCCL(ncclAllReduce(mask, mask, mask_bytes / 4, ncclInt32, ncclSum, comm, stream));
+          QRM(c, qr_tree_apply(c));
+          NCCL(ncclAllGather(recs_local, recs_all, rec_bytes, ncclInt8, comm, stream));
+        }
+        QRM(c, qr_tree_decide(c));
+        QRM(c, qr_tree_end(c, lambda, nodes.data(), &nn));
+      } else {
+        sum64(x_hist, n_hist);
+        for (size_t s = 0; s + 1 < nleaves_; ++s) {
+          QRM(c, qr_tree_decide(c));
+          QRM(c, qr_tree_apply(c));
+          sum64(x_hist, n_hist);
+        }
+        QRM(c, qr_tree_decide(c));
+        QRM(c, qr_tree_end(c, lambda, nullptr, nullptr));
+        QRM(c, qr_doc_exchange_buffers(c, nullptr, nullptr, nullptr, nullptr, &x_leaf, &n_leaf));
+        sum64(x_leaf, n_leaf);
+        QRM(c, qr_tree_leaves_finish(c, lambda, nodes.data(), &nn));
+      }
+      QRM(c, qr_scores_update(c, shrinkage_));  // mart.cc:345, :356
+      // ---- every rank must have built rank 0's tree
+      if (r == 0) {
+        memcpy(sh.nodes0.data(), nodes.data(), nn * sizeof(qr_node_t));
+        sh.nn0 = nn;
+      }
+      sh.bar.wait();
+      if (r != 0) {
+        bool same = nn == sh.nn0;
+        for (size_t i = 0; same && i < nn; ++i)
+          same = nodes[i].feature == sh.nodes0[i].feature && nodes[i].thr_id == sh.nodes0[i].thr_id &&
+                 nodes[i].left == sh.nodes0[i].left && nodes[i].right == sh.nodes0[i].right &&
+                 nodes[i].nsamples == sh.nodes0[i].nsamples;
+        if (!same) {
+          std::cerr << "!!! rank " << r << " built a different tree than rank 0 in iteration " << m + 1
+                    << std::endl;
+          exit(EXIT_FAILURE);
+        }
+      }
+      sh.bar.wait();
+      if (r == 0) ensemble_model_.push(tree_from_records(nodes.data(), 0), shrinkage_);  // mart.cc:342
+      ++built;
+      // ---- metrics, best model, early stop (mart.cc:347-376)
+      if (lagged) {
+        if (m > 0) {
+          MetricScore prev = 0;
+          QRM(c, qr_metric_last(c, &prev));  // of the scores this iteration's lambda pass ranked
+          report(m, prev, nullptr);
+        }
+      } else {
+        const MetricScore mt = metric_all(0);
+        MetricScore mv = 0;
+        if (validation) mv = metric_all(1);
+        report(m + 1, mt, validation ? &mv : nullptr);
+      }
+      if (r == 0 && partial_save != 0 && !output_basename.empty() && (m + 1) % partial_save == 0)
+        save(output_basename, (int)(m + 1));
+    }
+    if (lagged && built) {
+      const MetricScore last = metric_all(0);
+      report(built, last, nullptr);
+    }
+    QRM(c, qr_synchronize(c));
+    sh.bar.wait();
+    qr_ctx_destroy(c);
+  };
+
+  best_train_r_.assign(W, std::numeric_limits<double>::lowest());
+  best_valid_r_.assign(W, std::numeric_limits<double>::lowest());
+  best_model_r_.assign(W, 0);
+  std::vector<std::thread> threads;
+  for (int r = 0; r < W; ++r) threads.emplace_back(worker, r);
+  for (auto &t : threads) t.join();
+  for (int r = 0; r < W; ++r) ncclCommDestroy(comms[r]);
+  best_metric_on_training_ = best_train_r_[0];
+  best_metric_on_validation_ = best_valid_r_[0];
+  best_model_ = best_model_r_[0];
+  // rollback to the best model observed on the validation data (mart.cc:390-395)
+  if (validation)
+    while (ensemble_model_.is_notempty() && ensemble_model_.get_size() > best_model_ + 1) ensemble_model_.pop();
+  auto t_train1 = std::chrono::high_resolution_clock::now();
+  std::cout << std::endl;
+  std::cout << metric << "@" << cutoff << " on training data = " << best_metric_on_training_ << std::endl;
+  if (validation)
+    std::cout << metric << "@" << cutoff << " on validation data = " << best_metric_on_validation_
+              << std::endl;
+  std::cout << std::endl
+            << "#\t Training Time: " << std::setprecision(2)
+            << std::chrono::duration<double>(t_train1 - t_train0).count() << " s." << std::endl;
+}
+
+}  // namespace forests
+}  // namespace learning
+}  // namespace quickrank

@@ -48,6 +48,8 @@ const std::vector<std::pair<std::string, Opt>> kOptions = {
      {"set documents per iteration: fraction if <= 1, count if > 1 [MART/LambdaMART].", "1", true}},
     {"max-features",
      {"set features per split search: fraction if <= 1, count if > 1 [MART/LambdaMART].", "1", true}},
+    {"gpus", {"train on this many GPUs of the node (RCCL over xGMI) [MART/LambdaMART].", "1", true}},
+    {"shard", {"what the GPUs split: [docs|features] (documents, or feature blocks of the bin matrix).", "docs", true}},
     {"seed", {"seed of the document / feature sampling (0: from the clock, like the reference).", "0", true}},
     {"test-metric", {"set test metric: [DCG|NDCG].", "NDCG", true}},
     {"test-cutoff", {"set test metric cutoff.", "10", true}},
@@ -183,8 +185,17 @@ int main(int argc, char *argv[]) {
     if (!v["features"].empty())  // driver.cc:108-110: the reference reads the flag and does nothing with it
       std::cout << "# --features " << v["features"] << ": accepted and not used, as in the reference "
                 << "(driver.cc:108-110 is a TODO)" << std::endl;
-    algo->learn(training, validation, v["train-metric"], std::stoul(v["train-cutoff"]),
-                std::stoul(v["partial"]), v["model-out"]);  // driver.cc:228-246
+    const int gpus = std::stoi(v["gpus"]);
+    if (gpus < 1 || (v["shard"] != "docs" && v["shard"] != "features")) {
+      std::cerr << "!!! --gpus needs a positive count, --shard docs or features" << std::endl;
+      return EXIT_FAILURE;
+    }
+    if (gpus > 1 || isset.count("shard"))  // (--shard with one GPU runs the sharded protocol on one rank)
+      algo->learn_multi(training, validation, v["train-metric"], std::stoul(v["train-cutoff"]),
+                        std::stoul(v["partial"]), v["model-out"], gpus, v["shard"] == "features");
+    else
+      algo->learn(training, validation, v["train-metric"], std::stoul(v["train-cutoff"]),
+                  std::stoul(v["partial"]), v["model-out"]);  // driver.cc:228-246
     if (!v["model-out"].empty()) {
       std::cout << std::endl << "# Writing model to file: " << v["model-out"] << std::endl << std::endl;
       algo->save(v["model-out"]);

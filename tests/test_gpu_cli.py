@@ -326,3 +326,37 @@ def test_quicklearn_default_thresholds_all_distinct_values(tools, oracle_lib, tm
             stack.append((int(o[oi]["right"]), int(g[gi]["right"]), d[~ol]))
     s = np.loadtxt(scores)
     assert np.allclose(s, om["train_scores"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("shard", ["docs", "features"])
+@pytest.mark.parametrize("algo", ["LAMBDAMART", "MART"])
+def test_quicklearn_gpus_flag_runs_the_sharded_protocol(tools, tmp_path, algo, shard):
+    """`quicklearn --gpus N --shard docs|features` (host/mart_multi.cc: a host thread per GPU,
+    RCCL on the contexts' streams).  This box has one GPU: the sharded protocol runs with a
+    communicator of one rank and must give the single-GPU model -- same splits; leaf values
+    to rounding (the document layout adds the node sums per rank)."""
+    x, labels, qoff = make_dataset(nq=120, docs_per_query=40, F=30, seed=71)
+    vx, vl, vq = make_dataset(nq=30, docs_per_query=30, F=30, seed=72)
+    tr, va = str(tmp_path / "train.svml"), str(tmp_path / "valid.svml")
+    _write_svml(tr, x, labels, qoff)
+    _write_svml(va, vx, vl, vq)
+    base = ["--algo", algo, "--train", tr, "--valid", va, "--num-trees", "6", "--num-leaves", "8",
+            "--num-thresholds", "64", "--min-leaf-support", "5", "--end-after-rounds", "0"]
+    m1, m2 = str(tmp_path / "single.xml"), str(tmp_path / "multi.xml")
+    a = subprocess.run([tools["quicklearn"]] + base + ["--model-out", m1], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run([tools["quicklearn"]] + base + ["--model-out", m2, "--gpus", "1", "--shard", shard],
+                       capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stdout + b.stderr
+    assert "RCCL communicator of 1 ranks" in b.stdout
+    n1, w1 = _load_model(tools, m1)
+    n2, w2 = _load_model(tools, m2)
+    assert n1.shape == n2.shape and np.array_equal(w1, w2)
+    for k in ("feature", "left", "right"):
+        assert np.array_equal(n1[k], n2[k]), k
+    assert np.array_equal(n1["threshold"].view(np.uint32), n2["threshold"].view(np.uint32))
+    assert np.allclose(n1["value"], n2["value"], rtol=1e-9, atol=1e-12)
+    # the same table (4 decimals) on both
+    t1 = [l for l in a.stdout.splitlines() if l[:7].strip().isdigit()]
+    t2 = [l for l in b.stdout.splitlines() if l[:7].strip().isdigit()]
+    assert t1 == t2 and len(t1) == 6

@@ -30,7 +30,9 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    # (QR_HIP_EXTRA_FLAGS + QR_HIP_LIB: experiment builds next to the product library)
+    cmd = [hipcc] + FLAGS + os.environ.get("QR_HIP_EXTRA_FLAGS", "").split() + ["-o", LIB] + \
+          [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

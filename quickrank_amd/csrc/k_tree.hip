@@ -1494,7 +1494,8 @@ __device__ __forceinline__ void batch_step(
     const qr_split_t *__restrict__ featrec, const float *__restrict__ featthr, const uint32_t F,
     const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
     QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
-    const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg) {
+    const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
+    const int final_call = 0) {
   QrTreeState *const ts = tout;  // where the writer publishes
   __shared__ QrPlan sh_plan[QR_BATCH];
   __shared__ qr_split_t own[2 * QR_BATCH];
@@ -1519,8 +1520,9 @@ __device__ __forceinline__ void batch_step(
                 h_done = tin->done, h_step = tin->step, h_nsplits = tin->nsplits,
                 h_heap_size = tin->heap_size, h_next_prov = tin->next_prov,
                 h_next_slot = tin->next_slot, h_spec_made = tin->spec_made,
-                h_spec_used = tin->spec_used;
+                h_spec_used = tin->spec_used, h_real_steps = root_mode ? 0 : tin->real_steps;
   const uint32_t h_part_epoch = tin->part_epoch;
+  const u64 h_minls = root_mode ? minls_arg : tin->minls;
   const QrLevelNode myln = tin->lnode[wave < QR_BATCH ? wave : 0];
   u64 v[NV];
   u64 hv[NH];
@@ -1648,13 +1650,12 @@ __device__ __forceinline__ void batch_step(
     sh_hs = st.heap_size;
     if (writer) {
       if (root_mode) {  // what k_tree_reset does for the one-split-per-step path
-        ts->nleaves_req = nleaves_arg;
-        ts->minls = minls_arg;
         ts->desc.active = 0;
         ts->nleaves = 0;
-      } else if (FUSED) {
-        ts->nleaves_req = h_nleaves_req;
       }
+      // (the state ping-pongs between two copies: the tree's parameters travel with it)
+      ts->nleaves_req = h_nleaves_req;
+      ts->minls = h_minls;
       ts->l_nodes = nj;
       ts->nnodes = st.nnodes;
       ts->taken = st.taken;
@@ -1667,6 +1668,10 @@ __device__ __forceinline__ void batch_step(
       ts->next_slot = bs.next_slot;
       ts->spec_made = bs.spec_made;
       ts->spec_used = bs.spec_used;
+      ts->real_steps = h_real_steps + (nj > 0 ? 1 : 0);
+      // the last control call of the enqueued sequence still found a batch to apply: the
+      // host guessed too few steps (the leaf / score kernels leave, the host carries on)
+      ts->incomplete = final_call && nj > 0 ? 1 : 0;
       ts->l_part_wgs = sh_pw0[nj];
     }
   }
@@ -1800,7 +1805,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
     QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
     const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
-    const QrTreeState *tin) {
+    const QrTreeState *tin, const int final_call) {
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
   __shared__ int sh_nj;
@@ -1808,7 +1813,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   batch_step<false, CAP>(tin ? tin : ts, ts, nullptr, true, 0u, sh_next, sh_pw0, &sh_nj, &sh_epoch,
                     root_mode, nleaves_arg, minls_arg, stage_nodes, N, flocal, scal, part_ss, featrec,
                     featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, part_wg, part_grid,
-                    plans, scan_wg);
+                    plans, scan_wg, final_call);
 }
 
 // ===========================================================================
@@ -2011,7 +2016,8 @@ __global__ __launch_bounds__(256) void k_partition_batch(
     const QrTreeState *__restrict__ ts, const QrPartWg *__restrict__ wgs,
     const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
     uint32_t *__restrict__ order1, u64 *__restrict__ state, const double *__restrict__ lambda,
-    double *__restrict__ part_ss) {
+    double *__restrict__ part_ss, const uint32_t epoch_host) {
+  // (epoch_host != 0: the granules' tag is counted on the host, as for k_decide_part)
   const QrPartWg d = wgs[blockIdx.x];
   if (d.n == 0) return;
   PartNode pn;
@@ -2024,8 +2030,8 @@ __global__ __launch_bounds__(256) void k_partition_batch(
   QrSplitDesc gl;
   gl.owner_local = d.owner_local;
   gl.thr_id = d.thr_id;
-  partition_body(pn, gl, d.w, d.first, ts->part_epoch, fm, Nfm, order0, order1, nullptr, 0, state,
-                 lambda, part_ss);
+  partition_body(pn, gl, d.w, d.first, epoch_host ? (u64)epoch_host : (u64)ts->part_epoch, fm, Nfm, order0,
+                 order1, nullptr, 0, state, lambda, part_ss);
 }
 
 // The control step and the partition in one launch (batch_step<true>): every
@@ -2136,6 +2142,7 @@ __global__ __launch_bounds__(256) void k_leaf_sums(
     const double *__restrict__ weight, double *__restrict__ leafpart) {
   __shared__ double sh1[4], sh2[4];
   __shared__ uint32_t lb[QR_MAXNODES + 1];
+  if (ts->incomplete) return;  // (the last batch is not applied yet: its children's lists are not there)
   const int nl = ts->nleaves;
   for (int i = threadIdx.x; i <= nl; i += 256) lb[i] = ts->leaf_begin[i];
   __syncthreads();
@@ -2199,7 +2206,11 @@ __device__ __forceinline__ void nodes_out_write(const QrTreeState *ts, QrNodesOu
     d.nsamples = s.count;
     out->nodes[i] = d;
   }
-  if (threadIdx.x == 0) out->nnodes = nn;
+  if (threadIdx.x == 0) {
+    out->nnodes = nn;
+    out->pad[0] = ts->incomplete;
+    out->pad[1] = ts->real_steps;
+  }
 }
 
 // rt.cc:165-207
@@ -2210,6 +2221,13 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
                                                      const int rank, const int world,
                                                      const int stride,
                                                      QrNodesOut *__restrict__ nodes_out) {
+  if (ts->incomplete) {  // tell the host, which carries the tree on (qr_k_tree_continue)
+    if (threadIdx.x == 0) {
+      nodes_out->pad[0] = 1;
+      nodes_out->pad[1] = ts->real_steps;
+    }
+    return;
+  }
   const int nl = ts->nleaves;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (docmode) {  // own slot <- local sums, zeros elsewhere (all-reduce == all-gather)
@@ -2313,6 +2331,7 @@ __global__ __launch_bounds__(256) void k_score_update_walk(
     const int wide) {
   __shared__ int32_t s_lf[QR_MAXNODES], s_thr[QR_MAXNODES], s_left[QR_MAXNODES], s_right[QR_MAXNODES];
   __shared__ double s_val[QR_MAXNODES];
+  if (ts->incomplete) return;  // the host carries the tree on and enqueues this update again
   const int nn = ts->nnodes;
   for (int i = threadIdx.x; i < nn; i += 256) {
     const int f = ts->nodes[i].feature;
@@ -2344,7 +2363,7 @@ __global__ __launch_bounds__(256) void k_valid_update(
     const uint32_t vN, const uint32_t F, const double shrinkage,
     double *__restrict__ vscores) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= vN) return;
+  if (i >= vN || ts->incomplete) return;
   const float *x = raw + (size_t)i * F;
   int n = 0;
   while (ts->nodes[n].feature >= 0)
@@ -2635,6 +2654,8 @@ __global__ void k_obl_reset(QrTreeState *ts, int maxnodes, u64 minls) {
     ts->nleaves = 0;
     ts->obl_done = 0;
     ts->obl_level = 0;
+    ts->incomplete = 0;
+    ts->real_steps = 0;
   }
 }
 
@@ -2741,6 +2762,8 @@ __global__ void k_tree_reset(QrTreeState *ts, int nleaves, u64 minls) {
   ts->desc.active = 0;
   ts->nleaves = 0;
   ts->l_nodes = 0;
+  ts->incomplete = 0;
+  ts->real_steps = 0;
 }
 
 int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
@@ -2799,6 +2822,76 @@ int qr_k_tree_apply(qr_ctx *c) {
 
 // Leaf-wise tree with up to QR_BATCH splits per step (k_decide_batch): the whole fit is
 // enqueued at once; steps the tree does not need leave at once.
+// the launches of one growth step behind its control call: the batch's child histograms,
+// then reduce + scan
+static int launch_batch_hist_scan(qr_ctx *c, const unsigned hg, const uint32_t rootn, const uint64_t minls) {
+  const size_t lds = hist_lds(c);
+  if (c->prof_on && c->prof_child) {  // bench.py's roofline_child_hist: events on the launch itself
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    QR_CHECK(c, hipEventCreate(&e0));
+    QR_CHECK(c, hipEventCreate(&e1));
+    hipExtLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, e0, e1, 0, c->d_lhist_wg,
+                          c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
+                          c->d_scalars, (u64 *)c->d_lpartials);
+    c->prof_events_child.push_back({e0, e1});
+  } else
+    hipLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, c->d_lhist_wg,
+                       c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
+                       c->d_scalars, (u64 *)c->d_lpartials);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_redscan, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_tree, 0,
+                     rootn, c->d_lplan, c->d_blocks, c->nblocks, c->ncu, (const u64 *)c->d_lpartials,
+                     c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars,
+                     c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg, (u64)minls);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+struct BatchGeom {
+  unsigned pg, hg;
+  uint32_t rootn;
+  bool small, fused;
+  int stage_nodes;
+};
+static BatchGeom batch_geom(const qr_ctx *c, size_t nleaves) {
+  BatchGeom g;
+  g.pg = (unsigned)std::min<size_t>(c->lpart_cap, c->N / QR_PART_SLICE + QR_BATCH + 1);
+  g.hg = (unsigned)std::min<size_t>(c->lhist_cap, (size_t)std::max(c->ncu, c->ncu / 4 + QR_BATCH * c->nblocks));
+  g.rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);
+  // final ids [0, 2 nleaves + 1) + provisional ones [.., 4 nleaves + 1)
+  g.small = 4 * nleaves + 1 + 2 * QR_BATCH <= QR_BATCH_LDS_SMALL;
+  g.stage_nodes = 4 * nleaves + 1 + 2 * QR_BATCH <= QR_BATCH_LDS_LARGE ? (int)(4 * nleaves + 1) : 0;
+  // Staged trees: the control step runs inside the partition launch (k_decide_part) and
+  // the tree state ping-pongs between two copies, arranged so that the last call
+  // (control step only: it accounts for the last batch) writes c->d_tree.
+  g.fused = g.stage_nodes > 0 && c->d_tree2 != nullptr;
+  return g;
+}
+
+// a control call on its own (k_decide_batch): the first of a tree (root), one between two
+// steps of a tree whose state does not fit the LDS copies, or the last of the enqueued
+// sequence (`final_call`: accounts for the last batch and tells whether more is to come)
+static int launch_decide_batch(qr_ctx *c, const BatchGeom &g, size_t nleaves, uint64_t minls, int root,
+                               QrTreeState *tout, const QrTreeState *tin, const double *pss_in,
+                               int final_call) {
+  hipLaunchKernelGGL(g.small ? k_decide_batch<QR_BATCH_LDS_SMALL> : k_decide_batch<QR_BATCH_LDS_LARGE>,
+                     dim3(1), dim3(128 * QR_BATCH), 0, c->stream, tout, root, (int)nleaves, (u64)minls,
+                     g.stage_nodes, g.rootn, c->flocal, c->d_scalars, pss_in, c->d_featrec, c->d_featthr,
+                     (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, g.hg,
+                     c->d_lpart_wg, g.pg, c->d_lplan, c->d_lscan_wg, tin, final_call);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+// Leaf-wise tree with up to QR_BATCH splits per step (k_decide_batch): the whole fit is
+// enqueued at once.  A tree of L leaves needs at most L - 1 steps and usually far fewer
+// (two splits per step; 5-6 of 9 on the bench workload), but how many is only known on
+// the device, and a surplus step still costs three launches (~14 us).  So the host
+// enqueues a GUESS -- the previous tree's steps + 1 (c->steps_hint) -- and the last control
+// call of the sequence says whether it was enough (QrTreeState::incomplete).  If not
+// (rare: consecutive trees have similar shapes), the leaf and score kernels behind it
+// leave at once and qr_k_tree_continue carries the tree on when the host fetches the
+// records.  The first tree of a context enqueues the worst case.
 int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
   c->tree_step = 0;
   c->tree_counter += 0x9E3779B97F4A7C15ull;
@@ -2806,67 +2899,64 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
   // (no reset launch: the first k_decide_batch call starts from its arguments)
   int rc = launch_hist_scan(c, 1, true);  // root histogram -> slot 0, records -> featrec[0]
   if (rc) return rc;
-  const size_t lds = hist_lds(c);
-  const unsigned pg = (unsigned)std::min<size_t>(c->lpart_cap, c->N / QR_PART_SLICE + QR_BATCH + 1);
-  const unsigned hg = (unsigned)std::min<size_t>(
-      c->lhist_cap, (size_t)std::max(c->ncu, c->ncu / 4 + QR_BATCH * c->nblocks));
-  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);
-  // final ids [0, 2 nleaves + 1) + provisional ones [.., 4 nleaves + 1)
-  const bool small = 4 * nleaves + 1 + 2 * QR_BATCH <= QR_BATCH_LDS_SMALL;
-  const int stage_nodes = 4 * nleaves + 1 + 2 * QR_BATCH <= QR_BATCH_LDS_LARGE ? (int)(4 * nleaves + 1) : 0;
-  // Staged trees: the control step runs inside the partition launch (k_decide_part) and
-  // the tree state ping-pongs between two copies, arranged so that the last call
-  // (control step only: it accounts for the last batch) writes c->d_tree.
-  const bool fused = stage_nodes > 0 && c->d_tree2 != nullptr;
+  const BatchGeom g = batch_geom(c, nleaves);
+  size_t steps = nleaves - 1;
+  if (c->steps_force >= 0)
+    steps = std::min<size_t>(steps, (size_t)std::max<long>(c->steps_force, 1));
+  else if (c->steps_hint)
+    steps = std::min(steps, c->steps_hint);
+  if (steps < 1) steps = 1;
+  c->tree_step = (int)steps;
   QrTreeState *const T[2] = {c->d_tree, c->d_tree2};
   double *const PSS[2] = {c->d_lpart_ss, c->d_lpart_ss2};
-  for (size_t s = 0; s < nleaves; ++s) {
-    QrTreeState *tout = fused ? T[(nleaves - 1 - s) & 1] : c->d_tree;
-    QrTreeState *tin = fused ? T[(nleaves - s) & 1] : c->d_tree;  // what call s - 1 wrote
-    const double *pss_in = fused ? PSS[(s + 1) & 1] : c->d_lpart_ss;
-    if (!fused || s + 1 == nleaves) {
-      hipLaunchKernelGGL(small ? k_decide_batch<QR_BATCH_LDS_SMALL> : k_decide_batch<QR_BATCH_LDS_LARGE>,
-                         dim3(1), dim3(128 * QR_BATCH), 0, c->stream, tout,
-                         s == 0 ? 1 : 0, (int)nleaves, (u64)minls, stage_nodes, rootn, c->flocal,
-                         c->d_scalars, pss_in, c->d_featrec, c->d_featthr, (uint32_t)c->F,
-                         c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, hg,
-                         c->d_lpart_wg, pg, c->d_lplan, c->d_lscan_wg,
-                         fused ? (const QrTreeState *)tin : (const QrTreeState *)nullptr);
-      QR_CHECK(c, hipGetLastError());
-      if (s + 1 == nleaves) break;  // the last call only accounts for the last batch
-      hipLaunchKernelGGL(k_partition_batch, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
+  // calls 0 .. steps: call s < steps decides and partitions step s; call `steps` only decides
+  for (size_t s = 0; s <= steps; ++s) {
+    QrTreeState *tout = g.fused ? T[(steps - s) & 1] : c->d_tree;
+    QrTreeState *tin = g.fused ? T[(steps + 1 - s) & 1] : c->d_tree;  // what call s - 1 wrote
+    const double *pss_in = g.fused ? PSS[(s + 1) & 1] : c->d_lpart_ss;
+    if (!g.fused || s == steps) {
+      if ((rc = launch_decide_batch(c, g, nleaves, minls, s == 0 ? 1 : 0, tout,
+                                    g.fused ? (const QrTreeState *)tin : (const QrTreeState *)nullptr, pss_in,
+                                    s == steps ? 1 : 0)))
+        return rc;
+      if (s == steps) break;  // the last call only accounts for the last batch
+      hipLaunchKernelGGL(k_partition_batch, dim3(g.pg), dim3(256), 0, c->stream, c->d_tree,
                          c->d_lpart_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
-                         (u64 *)c->d_lpart_state, c->d_lambda, c->d_lpart_ss);
+                         (u64 *)c->d_bpart_state, c->d_lambda, c->d_lpart_ss, ++c->bepoch);
       QR_CHECK(c, hipGetLastError());
     } else {
-      hipLaunchKernelGGL(small ? k_decide_part<QR_BATCH_LDS_SMALL> : k_decide_part<QR_BATCH_LDS_LARGE>,
-                         dim3(pg), dim3(128 * QR_BATCH), 0, c->stream,
-                         (const QrTreeState *)tin, tout, T[(nleaves - s) & 1], ++c->bepoch,
-                         s == 0 ? 1 : 0, (int)nleaves, (u64)minls, stage_nodes, rootn, c->flocal,
+      hipLaunchKernelGGL(g.small ? k_decide_part<QR_BATCH_LDS_SMALL> : k_decide_part<QR_BATCH_LDS_LARGE>,
+                         dim3(g.pg), dim3(128 * QR_BATCH), 0, c->stream,
+                         (const QrTreeState *)tin, tout, T[(steps + 1 - s) & 1], ++c->bepoch,
+                         s == 0 ? 1 : 0, (int)nleaves, (u64)minls, g.stage_nodes, g.rootn, c->flocal,
                          c->d_scalars, pss_in, c->d_featrec, c->d_featthr, (uint32_t)c->F,
-                         c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, hg,
+                         c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, g.hg,
                          c->d_lplan, c->d_lscan_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0],
                          c->d_order[1], (u64 *)c->d_bpart_state, c->d_lambda, PSS[s & 1]);
       QR_CHECK(c, hipGetLastError());
     }
-    if (c->prof_on && c->prof_child) {  // bench.py's roofline_child_hist: events on the launch itself
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      QR_CHECK(c, hipEventCreate(&e0));
-      QR_CHECK(c, hipEventCreate(&e1));
-      hipExtLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, e0, e1, 0, c->d_lhist_wg,
-                            c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
-                            c->d_scalars, (u64 *)c->d_lpartials);
-      c->prof_events_child.push_back({e0, e1});
-    } else
-    hipLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, c->d_lhist_wg,
-                       c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
-                       c->d_scalars, (u64 *)c->d_lpartials);
+    if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls))) return rc;
+  }
+  return QR_OK;
+}
+
+// The guess was too low: c->d_tree holds a consistent state with the next batch ready
+// (the last control call prepared it like any other).  Apply it and carry on, one control
+// call per step on the device-resident state, for the worst case that is left; the last
+// call is final again (and cannot be incomplete: the leaf budget is exhausted by then).
+int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_done) {
+  const BatchGeom g = batch_geom(c, nleaves);
+  const size_t left = nleaves - 1 > steps_done ? nleaves - 1 - steps_done : 1;
+  int rc;
+  for (size_t r = 0; r < left; ++r) {
+    hipLaunchKernelGGL(k_partition_batch, dim3(g.pg), dim3(256), 0, c->stream, c->d_tree,
+                       c->d_lpart_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
+                       (u64 *)c->d_bpart_state, c->d_lambda, c->d_lpart_ss, ++c->bepoch);
     QR_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_redscan, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_tree, 0,
-                       rootn, c->d_lplan, c->d_blocks, c->nblocks, c->ncu, (const u64 *)c->d_lpartials,
-                       c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars,
-                       c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg, (u64)minls);
-    QR_CHECK(c, hipGetLastError());
+    if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls))) return rc;
+    if ((rc = launch_decide_batch(c, g, nleaves, minls, 0, c->d_tree, (const QrTreeState *)nullptr,
+                                  c->d_lpart_ss, r + 1 == left ? 1 : 0)))
+      return rc;
   }
   return QR_OK;
 }

@@ -26,6 +26,7 @@ static void dfree(T *&p) {
 extern "C" {
 
 void qr_ctx_destroy(qr_ctx *c);
+static int tree_settle(qr_ctx *c);
 
 int qr_ctx_create(int device, qr_ctx **out) {
   if (out) *out = nullptr;
@@ -45,6 +46,7 @@ int qr_ctx_create(int device, qr_ctx **out) {
   }
   qr_ctx *c = new qr_ctx();
   c->no_batch = getenv("QR_NO_BATCH") != nullptr;
+  if (const char *e = getenv("QR_STEPS_HINT")) c->steps_force = atol(e);  // steps to enqueue, whatever the tree
   c->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -108,6 +110,8 @@ static void free_train(qr_ctx *c) {
   c->d_sample_temp = nullptr;
   c->sub_k = 0;
   c->mf_k = 0;
+  c->spec_pending = c->spec_scores_enqueued = false;
+  c->steps_hint = 0;
   c->binned = false;
   c->tree_valid = false;
   c->hist_slots = 0;
@@ -129,6 +133,9 @@ static void free_valid(qr_ctx *c) {
 
 void qr_ctx_destroy(qr_ctx *c) {
   if (!c) return;
+  if (getenv("QR_SPEC_DEBUG") && c->spec_trees)
+    fprintf(stderr, "qr: %llu trees with a guessed step count, %llu continued (guess too low), last hint %zu\n",
+            (unsigned long long)c->spec_trees, (unsigned long long)c->spec_misses, c->steps_hint);
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_train(c);
@@ -200,6 +207,7 @@ int qr_ctx_set_doc_shard(qr_ctx *c, int rank, int world, uint64_t n_global,
 }
 
 int qr_synchronize(qr_ctx *c) {
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   return QR_OK;
 }
@@ -728,12 +736,14 @@ int qr_bins_read(qr_ctx *c, uint8_t *out) {
 // ---------------------------------------------------------------------------
 int qr_scores_reset(qr_ctx *c) {
   if (!c || !c->d_scores) return QR_ERR_STATE;
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   QR_CHECK(c, hipMemsetAsync(c->d_scores, 0, c->N * 8, c->stream));
   if (c->d_vscores) QR_CHECK(c, hipMemsetAsync(c->d_vscores, 0, c->vN * 8, c->stream));
   return QR_OK;
 }
 int qr_scores_set(qr_ctx *c, const double *s) {
   if (!c || !c->d_scores || !s) return QR_ERR_ARG;
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   QR_CHECK(c, hipMemcpy(c->d_scores, s, c->N * 8, hipMemcpyHostToDevice));
   return QR_OK;
@@ -747,18 +757,21 @@ int qr_valid_scores_set(qr_ctx *c, const double *s) {
 }
 int qr_scores_get(qr_ctx *c, double *s) {
   if (!c || !c->d_scores || !s) return QR_ERR_ARG;
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   QR_CHECK(c, hipMemcpy(s, c->d_scores, c->N * 8, hipMemcpyDeviceToHost));
   return QR_OK;
 }
 int qr_valid_scores_get(qr_ctx *c, double *s) {
   if (!c || !c->d_vscores || !s) return QR_ERR_ARG;
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   QR_CHECK(c, hipMemcpy(s, c->d_vscores, c->vN * 8, hipMemcpyDeviceToHost));
   return QR_OK;
 }
 int qr_pseudo_get(qr_ctx *c, double *l, double *w) {
   if (!c || !c->d_lambda) return QR_ERR_ARG;
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   if (l) QR_CHECK(c, hipMemcpy(l, c->d_lambda, c->N * 8, hipMemcpyDeviceToHost));
   if (w) QR_CHECK(c, hipMemcpy(w, c->d_weight, c->N * 8, hipMemcpyDeviceToHost));
@@ -768,6 +781,7 @@ int qr_pseudo_get(qr_ctx *c, double *l, double *w) {
 // host side of the scale derivation for caller-supplied pseudo-responses
 int qr_pseudo_set(qr_ctx *c, const double *l, const double *w) {
   if (!c || !c->d_lambda || !l) return QR_ERR_ARG;
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   QR_CHECK(c, hipMemcpy(c->d_lambda, l, c->N * 8, hipMemcpyHostToDevice));
   if (w) QR_CHECK(c, hipMemcpy(c->d_weight, w, c->N * 8, hipMemcpyHostToDevice));
@@ -841,6 +855,7 @@ static int snapshot_scalars(qr_ctx *c) {
 int qr_lambda_compute(qr_ctx *c, int metric, size_t cutoff) {
   if (!c) return QR_ERR_ARG;
   if (!c->d_scores) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   if (metric != QR_METRIC_NDCG && metric != QR_METRIC_DCG)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "metric must be DCG or NDCG");
   int rc = ensure_idcg(c, 0, metric, cutoff);
@@ -867,6 +882,7 @@ int qr_lambda_finish(qr_ctx *c) {
 int qr_residual_compute(qr_ctx *c) {
   if (!c) return QR_ERR_ARG;
   if (!c->d_scores) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   int rc = 0;
   if (c->sub_k && (rc = qr_k_sample_draw(c))) return rc;  // this iteration's sample
   if ((rc = qr_k_residual(c))) return rc;  // every document (mart.cc:418-431)
@@ -894,6 +910,7 @@ static int metric_finish(qr_ctx *c, int which, double *out) {
 int qr_metric_eval(qr_ctx *c, int which, int metric, size_t cutoff, double *out) {
   if (!c || !out) return QR_ERR_ARG;
   if (which ? !c->d_vscores : !c->d_scores) QR_FAIL(c, QR_ERR_STATE, "dataset not uploaded");
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   int rc = ensure_idcg(c, which, metric, cutoff);
   if (rc) return rc;
   rc = qr_k_lambda(c, which, metric, cutoff, 1);
@@ -1010,7 +1027,9 @@ int qr_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
   if (nleaves < 1 || 2 * nleaves + 1 > QR_MAXNODES)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "nleaves must be in [1, 511]");
-  int rc = ensure_hist_slots(c, 2 * nleaves + 1);
+  int rc = tree_settle(c);
+  if (rc) return rc;
+  rc = ensure_hist_slots(c, 2 * nleaves + 1);
   if (rc) return rc;
   if (c->dmode && 2 * nleaves * (size_t)c->world > c->xleaf_cap) {
     QR_CHECK(c, hipStreamSynchronize(c->stream));
@@ -1045,9 +1064,37 @@ static int snapshot_nodes(qr_ctx *c) {
   return QR_OK;
 }
 
+// Batched growth enqueues a guessed number of steps (qr_k_tree_fit_batch).  Waits for the
+// tree's records; if the device reports that the guess was too low, carries the tree on,
+// repeats the leaf kernels (and the score update, if it was enqueued behind them: it left
+// at once on the incomplete tree) and waits again.  Everything that consumes the tree or
+// the scores calls this first; in the usual loop qr_tree_nodes does.
+static int tree_settle(qr_ctx *c) {
+  if (!c->spec_pending) return QR_OK;
+  QR_CHECK(c, hipEventSynchronize(c->ev_nodes));
+  c->spec_pending = false;
+  ++c->spec_trees;
+  if (c->h_pin->tree.pad[0]) {  // incomplete
+    ++c->spec_misses;
+    int rc = qr_k_tree_continue(c, c->cur_nleaves, c->cur_minls, (size_t)c->tree_step);
+    if (rc) return rc;
+    if ((rc = qr_k_tree_finish(c, c->spec_newton))) return rc;
+    QR_CHECK(c, hipEventRecord(c->ev_nodes, c->stream));
+    if (c->spec_scores_enqueued && (rc = qr_k_scores_update(c, c->spec_shrinkage))) return rc;
+    QR_CHECK(c, hipEventSynchronize(c->ev_nodes));
+    if (c->h_pin->tree.pad[0]) QR_FAIL(c, QR_ERR_STATE, "internal: tree still incomplete after its last step");
+  }
+  c->spec_scores_enqueued = false;
+  // the next tree: as many steps as this one needed, plus one
+  c->steps_hint = (size_t)c->h_pin->tree.pad[1] + 1;
+  return QR_OK;
+}
+
 int qr_tree_nodes(qr_ctx *c, qr_node_t *nodes_out, size_t *nnodes_out) {
   if (!c) return QR_ERR_ARG;
   if (!c->nodes_pending) QR_FAIL(c, QR_ERR_STATE, "no fitted tree");
+  int rc = tree_settle(c);
+  if (rc) return rc;
   QR_CHECK(c, hipEventSynchronize(c->ev_nodes));
   const size_t n = (size_t)c->h_pin->tree.nnodes;
   if (nodes_out) memcpy(nodes_out, c->h_pin->tree.nodes, n * sizeof(qr_node_t));
@@ -1086,6 +1133,10 @@ int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
     QR_FAIL(c, QR_ERR_STATE,
             "sharded contexts must drive qr_tree_begin/decide/apply/end "
             "with the collectives in between");
+  {
+    const int src = tree_settle(c);
+    if (src) return src;
+  }
   // up to QR_BATCH splits per step (k_decide_batch); per-node feature subsets are keyed by
   // the node's final index, which a split applied ahead of its turn does not know yet
   if (!c->mf_k && !c->no_batch && !c->wide && nleaves >= 2 && 4 * nleaves + 1 <= QR_MAXNODES) {
@@ -1100,6 +1151,10 @@ int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
     c->tree_open = true;
     c->tree_valid = false;
     if ((rc = qr_k_tree_fit_batch(c, nleaves, minls))) return rc;
+    // (the records say how many steps the tree took and whether the enqueued ones sufficed)
+    c->spec_pending = true;
+    c->spec_scores_enqueued = false;
+    c->spec_newton = newton;
     return qr_tree_end(c, newton, nodes_out, nnodes_out);
   }
   int rc = qr_tree_begin(c, nleaves, minls);
@@ -1116,6 +1171,7 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
                      qr_node_t *nodes_out, size_t *nnodes_out) {
   if (!c) return QR_ERR_ARG;
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   if (c->world > 1 || c->dmode)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "oblivious trees are single-GPU in this round");
   if (c->sub_k) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling applies to leaf-wise trees in this round");
@@ -1134,6 +1190,10 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
 int qr_scores_update(qr_ctx *c, double shrinkage) {
   if (!c) return QR_ERR_ARG;
   if (!c->tree_valid) QR_FAIL(c, QR_ERR_STATE, "no fitted tree");
+  if (c->spec_pending) {  // (if the tree turns out incomplete, tree_settle repeats this update)
+    c->spec_scores_enqueued = true;
+    c->spec_shrinkage = shrinkage;
+  }
   return qr_k_scores_update(c, shrinkage);
 }
 
@@ -1165,6 +1225,7 @@ int qr_doc_exchange_buffers(qr_ctx *c, void **hist, size_t *hist_i64, void **sca
 // ---------------------------------------------------------------------------
 static int read_tree(qr_ctx *c, std::vector<char> &buf) {
   if (!c->tree_valid) QR_FAIL(c, QR_ERR_STATE, "no fitted tree");
+  { const int src_ = tree_settle(c); if (src_) return src_; }
   buf.resize(sizeof(QrTreeState));
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   QR_CHECK(c, hipMemcpy(buf.data(), c->d_tree, sizeof(QrTreeState), hipMemcpyDeviceToHost));

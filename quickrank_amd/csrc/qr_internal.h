@@ -220,6 +220,11 @@ struct QrTreeState {
   QrLevelNode lnode[QR_MAXLEVEL];
   int32_t next_prov, next_slot;    // batched growth: provisional node ids / histogram slots handed out
   int32_t spec_made, spec_used;    // statistics: splits applied ahead of their turn / later taken
+  // The host enqueues a GUESSED number of steps (the previous tree's + 1, qr_k_tree_fit_batch):
+  // steps that applied a batch, and whether the last control call of the enqueued sequence
+  // still had a batch to apply -- the leaf / score kernels then leave and the host carries
+  // the tree on (qr_k_tree_continue) when it fetches the records.
+  int32_t real_steps, incomplete;
   // leaves in DFS order
   int32_t nleaves;
   int32_t leaf_nodes[QR_MAXNODES];
@@ -361,6 +366,15 @@ struct qr_ctx {
   QrScanWg *d_lscan_wg = nullptr;     // ... [QR_BATCH][flocal]
   QrPlan *d_lplan = nullptr;          // ... and the plan of every node of the batch
   bool no_batch = false;              // QR_NO_BATCH=1: one split per step (debugging aid)
+  // guessed step count of batched growth: steps to enqueue for the next tree (0 = the worst
+  // case nleaves - 1), whether the tree just enqueued may turn out incomplete, and what the
+  // continuation has to repeat (leaf kernels with `newton`, the score update with `shrinkage`)
+  size_t steps_hint = 0;
+  long steps_force = -1;              // QR_STEPS_HINT=k: always enqueue k steps (tests the continuation)
+  bool spec_pending = false, spec_scores_enqueued = false;
+  int spec_newton = 0;
+  double spec_shrinkage = 0.0;
+  uint64_t spec_trees = 0, spec_misses = 0;
   uint32_t *d_red_cnt_loc = nullptr;  // document-sharded: the rank's own reduced counts ...
   uint32_t *d_hcnt_loc = nullptr;     // ... and their prefix per (node slot, feature, threshold slot)
   unsigned long long *d_part_state = nullptr;  // look-back granules {epoch, count}
@@ -466,6 +480,7 @@ int qr_k_tree_finish(qr_ctx *c, int newton);
 int qr_k_scores_update(qr_ctx *c, double shrinkage);
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls);
 int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls);
+int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_done);
 int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
                         double *d_out, double *d_partial = nullptr, int ignore_weights = 0);
 int qr_k_obl_score(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);

@@ -587,3 +587,26 @@ def test_leaf_counts_around_the_batched_growth_limits(qr, ora, nleaves):
     assert len(log) == len(olog) == nleaves - 1
     assert_split_log_parity(log, olog, ties)
     c.close()
+
+
+@pytest.mark.parametrize("hint", ["1", "2", "4"])
+def test_guessed_step_count_and_continuation(qr, ora, monkeypatch, hint):
+    """Batched growth enqueues a GUESSED number of steps per tree (the previous tree's + 1)
+    and carries a tree on from the host when the device reports that the guess was too low
+    (qr_k_tree_fit_batch / qr_k_tree_continue).  QR_STEPS_HINT forces a guess that is too
+    low for every tree: every tree then goes through the continuation, with the score
+    update enqueued behind it repeated -- same trees, metrics and scores as the oracle's."""
+    from quickrank_amd.trainer import Mart
+    monkeypatch.setenv("QR_STEPS_HINT", hint)
+    x, labels, qoff = make_dataset(nq=150, docs_per_query=60, F=40, seed=91)
+    kw = dict(ntrees=6, shrinkage=0.1, nthresholds=64, nleaves=12, minls=5, esr=0)
+    om = ora.train(x, labels, qoff, algo="LAMBDAMART", **kw)
+    gm = Mart(algo="LAMBDAMART", **kw).learn(x, labels, qoff)
+    monkeypatch.delenv("QR_STEPS_HINT")
+    tr = ora.Trainer(x, 64)
+    for t in range(kw["ntrees"]):
+        n = int(om["nnodes"][t])
+        assert_tree_parity(tr.stmap, om["nodes"][t][:n], gm.ensemble.trees[t][:n])
+    assert np.allclose(gm.train_metric, om["train_metric"], rtol=1e-9)
+    assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-8, atol=1e-10)
+    gm.ctx.close()

@@ -223,8 +223,8 @@ __device__ const double QR_EXP_T[64] = {
 };
 
 __device__ __forceinline__ double qr_exp(double x, const double *T) {
-  x = x > 709.7 ? 709.7 : x;
-  x = x < -745.1 ? -745.1 : x;
+  x = fmin(x, 709.7);   // (one v_min / v_max each; the arguments are never NaN)
+  x = fmax(x, -745.1);
   const double kd = rint(x * 92.33248261689366);                   // 64 / ln2
   const int k = (int)kd;
   double r = fma(-kd, 0x1.62e42fef00000p-7, x);                    // ln2/64, high part
@@ -690,15 +690,22 @@ __global__ __launch_bounds__(64) void k_lambda(
   const double inv_idcg = metric == QR_METRIC_NDCG ? 1.0 / my_idcg : 1.0;  // (ndcg.cc:81: / idcg, to an ulp)
   // one pair term (lambdamart.cc:120-141 with the closed form of ndcg.cc:76-88): rank r1
   // (uniform over the wave) against this lane's rank r2 > r1
+  // `flip(v, f)`: f ? -v : v, as one integer op on the sign bit
+  auto flip = [](const double v, const bool f) {
+    return __hiloint2double(__double2hiint(v) ^ (f ? (int)0x80000000 : 0), __double2loint(v));
+  };
+  // one pair term (lambdamart.cc:120-141 with the closed form of ndcg.cc:76-88): rank r1
+  // (uniform over the wave) against this lane's rank r2 > r1.  slam = the pair's lambda with
+  // the sign it enters rank r1's sum with (the higher label plays "j", lambdamart.cc:127).
   auto pair_term = [&](const float l1, const double p1, const double inv1, const double s1,
-                       const float l2, const double p2, const double il2, const double s2, double &lam,
-                       double &del, bool &hi1) {
+                       const float l2, const double p2, const double il2, const double s2, double &slam,
+                       double &del) {
     const double j = (il2 - inv1) * (p1 - p2);   // il2 == 0 beyond the cutoff (ndcg.cc:84-86)
     const double d = fabs(j * inv_idcg);
-    hi1 = l1 > l2;  // the higher label plays "j" in lambdamart.cc:127
-    const double diff = hi1 ? s1 - s2 : s2 - s1;
+    const bool lo1 = l1 < l2;
+    const double diff = flip(s1 - s2, lo1);      // s_hi - s_lo
     const double rho = qr_rcp(1.0 + qr_exp(diff, expt));
-    lam = rho * d;
+    slam = flip(rho * d, lo1);
     del = rho * (1.0 - rho) * d;
   };
   if (n <= 128) {
@@ -720,21 +727,19 @@ __global__ __launch_bounds__(64) void k_lambda(
       double c1 = 0.0, cw = 0.0;
       const bool va = ina && ra > r1 && l1 != la, vb = inb && rb > r1 && l1 != lb;
       if (va) {
-        double lam, del;
-        bool hi1;
-        pair_term(l1, p1, inv1, s1, la, pa_, ia, sa, lam, del, hi1);
-        c1 += hi1 ? lam : -lam;
+        double slam, del;
+        pair_term(l1, p1, inv1, s1, la, pa_, ia, sa, slam, del);
+        c1 += slam;
         cw += del;
-        ola += hi1 ? -lam : lam;
+        ola -= slam;
         owa += del;
       }
       if (vb) {
-        double lam, del;
-        bool hi1;
-        pair_term(l1, p1, inv1, s1, lb, pb_, ib, sb, lam, del, hi1);
-        c1 += hi1 ? lam : -lam;
+        double slam, del;
+        pair_term(l1, p1, inv1, s1, lb, pb_, ib, sb, slam, del);
+        c1 += slam;
         cw += del;
-        olb += hi1 ? -lam : lam;
+        olb -= slam;
         owb += del;
       }
       if (__any(c1 != 0.0 || cw != 0.0)) {
@@ -770,12 +775,11 @@ __global__ __launch_bounds__(64) void k_lambda(
       if (r2 < n && r2 > r1) {
         const float l2 = sl[r2];
         if (l1 != l2) {
-          double lam, del;
-          bool hi1;
-          pair_term(l1, p1, inv1, s1, l2, pw[r2], r2 < size ? ilt[r2] : 0.0, sr[r2], lam, del, hi1);
-          c1 += hi1 ? lam : -lam;
+          double slam, del;
+          pair_term(l1, p1, inv1, s1, l2, pw[r2], r2 < size ? ilt[r2] : 0.0, sr[r2], slam, del);
+          c1 += slam;
           cw += del;
-          ownl[r2] += hi1 ? -lam : lam;  // only this lane touches rank r2
+          ownl[r2] -= slam;  // only this lane touches rank r2
           ownw[r2] += del;
         }
       }

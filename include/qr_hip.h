@@ -231,6 +231,21 @@ int qr_exchange_buffers(qr_ctx *ctx, void **recs_local, void **recs_all,
                         size_t *rec_bytes_per_rank, void **mask,
                         size_t *mask_bytes);
 
+/* Feature-sharded OBLIVIOUS trees (ot.cc:32-201), one exchange pair per level:        */
+/*   qr_obl_begin -> for level in 0 .. depth-1 { qr_obl_propose -> [all_gather recs] ->  */
+/*   qr_obl_mark -> [all_reduce mask, int32 sum] -> qr_obl_apply } -> qr_tree_end        */
+/* recs: the buffers of qr_exchange_buffers (every rank's best (feature, slot) of the    */
+/* level; all ranks then pick the same one).  mask: here the go-left bit of every        */
+/* DOCUMENT (all nodes of a level take the same split) followed by the left count of     */
+/* every node of the level -- qr_obl_exchange_buffers gives the pointer and the size     */
+/* (a multiple of 4 bytes) to reduce; only the owner of the chosen feature contributes.  */
+int qr_obl_begin(qr_ctx *ctx, size_t depth, uint64_t minls);
+int qr_obl_propose(qr_ctx *ctx, size_t level);
+int qr_obl_mark(qr_ctx *ctx, size_t level);
+int qr_obl_apply(qr_ctx *ctx, size_t level);
+int qr_obl_exchange_buffers(qr_ctx *ctx, void **recs_local, void **recs_all,
+                            size_t *rec_bytes_per_rank, void **mask, size_t *mask_bytes);
+
 /* ---- document-sharded protocol ------------------------------------------------*/
 /* Each rank holds its own queries and all features; what is exchanged is the    */
 /* node histogram itself -- exact fixed-point integers, so ONE int64 sum          */

@@ -41,7 +41,8 @@ SYMBOLS = [
     "qr_doc_exchange_buffers", "qr_tree_nodes", "qr_valid_scores_set",
     "qr_tree_set_max_features", "qr_subsample_set", "qr_ensemble_partial_scores",
     "qr_prof_get_child", "qr_bins_build_wide", "qr_thresholds_read", "qr_bins_read_u32",
-    "qr_node_hist_read_ragged", "qr_ctx_stream",
+    "qr_node_hist_read_ragged", "qr_ctx_stream", "qr_obl_begin", "qr_obl_propose", "qr_obl_mark",
+    "qr_obl_apply", "qr_obl_exchange_buffers",
 ]
 
 _LIB = None
@@ -107,6 +108,12 @@ def lib():
     L.qr_oblivious_fit.argtypes = [vp, sz, u64, C.c_int, vp, C.POINTER(sz)]
     L.qr_scores_update.argtypes = [vp, C.c_double]
     L.qr_tree_begin.argtypes = [vp, sz, u64]
+    L.qr_obl_begin.argtypes = [vp, sz, u64]
+    L.qr_obl_propose.argtypes = [vp, sz]
+    L.qr_obl_mark.argtypes = [vp, sz]
+    L.qr_obl_apply.argtypes = [vp, sz]
+    L.qr_obl_exchange_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz),
+                                          C.POINTER(vp), C.POINTER(sz)]
     L.qr_tree_decide.argtypes = [vp]
     L.qr_tree_apply.argtypes = [vp]
     L.qr_tree_end.argtypes = [vp, C.c_int, vp, C.POINTER(sz)]
@@ -401,6 +408,36 @@ class Context:
         n = C.c_size_t()
         self._ck(self.L.qr_tree_end(self.h, int(newton), _ptr(nodes), C.byref(n)))
         return nodes[:n.value].copy()
+
+    # feature-sharded oblivious trees, phase by phase
+    def obl_begin(self, depth, minls=1):
+        self._ck(self.L.qr_obl_begin(self.h, depth, minls))
+
+    def obl_propose(self, level):
+        self._ck(self.L.qr_obl_propose(self.h, level))
+
+    def obl_mark(self, level):
+        self._ck(self.L.qr_obl_mark(self.h, level))
+
+    def obl_apply(self, level):
+        self._ck(self.L.qr_obl_apply(self.h, level))
+
+    def obl_end(self, depth, newton=True, read=True):
+        if not read:
+            self._ck(self.L.qr_tree_end(self.h, int(newton), None, None))
+            return None
+        nodes = np.zeros((1 << (depth + 1)) - 1, NODE_DTYPE)
+        n = C.c_size_t()
+        self._ck(self.L.qr_tree_end(self.h, int(newton), _ptr(nodes), C.byref(n)))
+        return nodes[:n.value].copy()
+
+    def obl_exchange_buffers(self):
+        a, b, m = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rb, mb = C.c_size_t(), C.c_size_t()
+        self._ck(self.L.qr_obl_exchange_buffers(self.h, C.byref(a), C.byref(b), C.byref(rb),
+                                                C.byref(m), C.byref(mb)))
+        return dict(recs_local=a.value, recs_all=b.value, rec_bytes=rb.value,
+                    mask=m.value, mask_bytes=mb.value)
 
     def lambda_finish(self):
         self._ck(self.L.qr_lambda_finish(self.h))

@@ -1822,6 +1822,8 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
 __device__ __forceinline__ bool go_left(const QrSplitDesc &d, uint32_t p, uint32_t id,
                                         const uint8_t *fm, uint32_t N,
                                         const uint32_t *mask, int use_mask) {
+  if (use_mask == 3)  // feature-sharded level-wise growth: go-left bits by DOCUMENT (k_obl_mark)
+    return (mask[id >> 5] >> (id & 31)) & 1u;
   if (use_mask == 2)  // wide-bin contexts: u32 bins, feature-major (k_wide.hip)
     return reinterpret_cast<const uint32_t *>(fm)[(size_t)d.owner_local * N + id] <= d.thr_id;
   if (use_mask) return (mask[p >> 5] >> (p & 31)) & 1u;
@@ -1992,7 +1994,8 @@ __global__ __launch_bounds__(256) void k_partition(
 __global__ __launch_bounds__(256) void k_partition_level(
     const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ map,
     const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
-    uint32_t *__restrict__ order1, u64 *__restrict__ state, const int wide) {
+    uint32_t *__restrict__ order1, u64 *__restrict__ state, const int wide,
+    const uint32_t *__restrict__ docmask) {
   if (ts->obl_done || blockIdx.x >= ts->l_part_wgs) return;
   const QrLevelNode &ln = ts->lnode[map[blockIdx.x]];
   if (!ln.active) return;
@@ -2007,7 +2010,7 @@ __global__ __launch_bounds__(256) void k_partition_level(
   gl.owner_local = ts->l_owner_local;
   gl.thr_id = ts->obl_t;
   partition_body(pn, gl, blockIdx.x - ln.part_first, ln.part_first, ts->part_epoch, fm, Nfm,
-                 order0, order1, nullptr, wide ? 2 : 0, state, nullptr, nullptr);
+                 order0, order1, docmask, docmask ? 3 : (wide ? 2 : 0), state, nullptr, nullptr);
 }
 
 // batched leaf-wise growth: every node of the batch has its own (feature, slot) and
@@ -2431,12 +2434,41 @@ __global__ __launch_bounds__(256) void k_obl_fill(
 // choose the level's (feature, slot): first maximum over features (ot.cc:84-95).
 // Run by the first wave of k_obl_plan; the choice goes out through `pick` (LDS) for
 // the rest of the workgroup: {done, feature, slot}.
+// first maximum over a list of records: highest score, equal scores -> lowest feature
+// (the list is the rank's per-feature records, or -- feature-sharded -- one record per rank)
+__device__ __forceinline__ qr_split_t obl_pick(const qr_split_t *__restrict__ recs, const int n,
+                                               const int stride) {
+  const int lane = threadIdx.x & 63;
+  qr_split_t best;
+  best.score = -1.0;
+  best.feature = 0xFFFFFFFFu;
+  best.thr_id = 0xFFFFFFFFu;
+  best.lcount = best.rcount = 0;
+  for (int i = lane; i < n; i += 64) {
+    const qr_split_t r = recs[(size_t)i * stride];
+    if (r.feature != 0xFFFFFFFFu && (r.score > best.score || (r.score == best.score && r.feature < best.feature)))
+      best = r;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double os = __shfl_xor(best.score, off, 64);
+    const uint32_t of = __shfl_xor(best.feature, off, 64);
+    const uint32_t ot = __shfl_xor(best.thr_id, off, 64);
+    if (of != 0xFFFFFFFFu && (os > best.score || (os == best.score && of < best.feature))) {
+      best.score = os;
+      best.feature = of;
+      best.thr_id = ot;
+    }
+  }
+  return best;
+}
+
 __device__ __forceinline__ void obl_level_body(QrTreeState *__restrict__ ts, const int level,
                                                const uint32_t N,
                                                const qr_split_t *__restrict__ featrec,
                                                const int flocal,
                                                const QrScalars *__restrict__ scal,
-                                               uint32_t *pick) {
+                                               uint32_t *pick, const qr_split_t *__restrict__ recs_all,
+                                               const int world) {
   const int lane = threadIdx.x;
   if (level == 0 && lane == 0) {
     QrNode *root = &ts->nodes[0];
@@ -2461,24 +2493,8 @@ __device__ __forceinline__ void obl_level_body(QrTreeState *__restrict__ ts, con
     if (lane == 0) pick[0] = 1;
     return;
   }
-  qr_split_t best;
-  best.score = -1.0;
-  best.feature = 0xFFFFFFFFu;
-  best.thr_id = 0xFFFFFFFFu;
-  for (int lf = lane; lf < flocal; lf += 64) {
-    const qr_split_t r = featrec[lf];
-    if (r.score > best.score) best = r;
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    const double os = __shfl_xor(best.score, off, 64);
-    const uint32_t of = __shfl_xor(best.feature, off, 64);
-    const uint32_t ot = __shfl_xor(best.thr_id, off, 64);
-    if (os > best.score || (os == best.score && of < best.feature)) {
-      best.score = os;
-      best.feature = of;
-      best.thr_id = ot;
-    }
-  }
+  // (feature-sharded: the ranks' bests were all-gathered, slot 0 of every rank's pair)
+  const qr_split_t best = recs_all ? obl_pick(recs_all, world, 2) : obl_pick(featrec, flocal, 1);
   if (lane != 0) return;
   ts->obl_level = level;
   if (best.feature == 0xFFFFFFFFu) {  // ot.cc:96: node is unsplittable
@@ -2509,13 +2525,15 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     const int32_t *__restrict__ gf2lf, const QrBlock *__restrict__ blocks, const int nblocks,
     uint32_t *__restrict__ hist_map, uint32_t *__restrict__ part_map, const uint32_t N,
     const qr_split_t *__restrict__ featrec, const QrScalars *__restrict__ scal,
-    const uint32_t *__restrict__ woff, const size_t wcells) {
+    const uint32_t *__restrict__ woff, const size_t wcells, const qr_split_t *__restrict__ recs_all,
+    const int world, const uint32_t *__restrict__ lcounts) {
   // (woff != null: wide-bin context -- ragged rows, no histogram plan: k_wide.hip's
-  // launches are sized on the host)
+  // launches are sized on the host.  recs_all / lcounts != null: feature-sharded -- the level's
+  // split is the best of the ranks' records, and the nodes' left counts came with the mask)
   __shared__ uint32_t sh_a[QR_MAXLEVEL], sh_b[QR_MAXLEVEL], sh_c[QR_MAXLEVEL];
   __shared__ uint32_t tot_small;
   __shared__ uint32_t pick[3];
-  if (threadIdx.x < 64) obl_level_body(ts, level, N, featrec, flocal, scal, pick);
+  if (threadIdx.x < 64) obl_level_body(ts, level, N, featrec, flocal, scal, pick, recs_all, world);
   __syncthreads();
   if (pick[0]) return;
   const int nodes = 1 << level;
@@ -2529,9 +2547,12 @@ __global__ __launch_bounds__(256) void k_obl_plan(
   if (j < nodes) {
     const int node = nodes - 1 + j;
     QrNode *nd = &ts->nodes[node];
-    const size_t base = woff ? (size_t)nd->hslot * wcells + woff[lf] : ((size_t)nd->hslot * flocal + lf) * 256;
-    const uint32_t lastt = woff ? woff[lf + 1] - woff[lf] - 1 : 255u;
-    const uint32_t lcount = hcnt[base + t];
+    // (a rank that does not own the feature: the count of ANY of its features' last slot is
+    // the node's size)
+    const int lfc = lf >= 0 ? lf : 0;
+    const size_t base = woff ? (size_t)nd->hslot * wcells + woff[lfc] : ((size_t)nd->hslot * flocal + lfc) * 256;
+    const uint32_t lastt = woff ? woff[lfc + 1] - woff[lfc] - 1 : 255u;
+    const uint32_t lcount = lcounts ? lcounts[j] : hcnt[base + t];
     const uint32_t rcount = hcnt[base + lastt] - lcount;
     const int li = 2 * node + 1, ri = 2 * node + 2;
     ln.active = 1;
@@ -2627,6 +2648,69 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     for (uint32_t x = 0; x < hw; ++x) hist_map[sh_a[j] + x] = ((uint32_t)j << 16) | x;
     for (uint32_t w = 0; w < pw; ++w) part_map[sh_c[j] + w] = (uint32_t)j;
     ts->lnode[j] = ln;
+  }
+}
+
+// Feature-sharded level-wise growth (SURVEY.md section 8e applied to ot.cc:32-201).  Every
+// rank sums the level's gains over ITS features (k_obl_fill) and publishes its best
+// (k_obl_propose); after the all-gather every rank picks the same (feature, slot)
+// (obl_pick); the owner of that feature publishes, for the all-reduce that doubles as a
+// broadcast, the go-left bit of every DOCUMENT (all nodes of the level take the same
+// split) and the left count of every node of the level (k_obl_mark); then every rank
+// partitions all nodes with the mask and builds the children's histograms of its own
+// features (k_obl_plan, k_partition_level, k_hist_level, k_redscan_level).
+__global__ __launch_bounds__(64) void k_obl_propose(const QrTreeState *__restrict__ ts, const int level,
+                                                    const qr_split_t *__restrict__ featrec,
+                                                    const int flocal, qr_split_t *__restrict__ recs_local) {
+  qr_split_t best;
+  if (level > 0 && ts->obl_done) {
+    best.score = -1.0;
+    best.feature = 0xFFFFFFFFu;
+    best.thr_id = 0xFFFFFFFFu;
+    best.lcount = best.rcount = 0;
+  } else
+    best = obl_pick(featrec, flocal, 1);
+  if (threadIdx.x == 0) {
+    best.lcount = best.rcount = 0;
+    recs_local[0] = best;
+    recs_local[1] = best;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_obl_mark(
+    const QrTreeState *__restrict__ ts, const int level, const qr_split_t *__restrict__ recs_all,
+    const int world, const int32_t *__restrict__ gf2lf, const uint32_t N,
+    const uint32_t *__restrict__ hcnt, const int flocal, const uint8_t *__restrict__ fm,
+    uint32_t *__restrict__ mask, const uint32_t mask_words) {
+  __shared__ uint32_t sh_f, sh_t;
+  if (threadIdx.x < 64) {
+    const qr_split_t best = obl_pick(recs_all, world, 2);
+    if (threadIdx.x == 0) {
+      sh_f = best.feature;
+      sh_t = best.thr_id;
+    }
+  }
+  __syncthreads();
+  const uint32_t f = sh_f, t = sh_t;
+  const int lf = f == 0xFFFFFFFFu ? -1 : gf2lf[f];
+  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+  if (w < mask_words) {
+    uint32_t bits = 0;
+    if (lf >= 0)
+      for (uint32_t k = 0; k < 32; ++k) {
+        const uint32_t d = w * 32 + k;
+        if (d < N && fm[(size_t)lf * N + d] <= t) bits |= 1u << k;
+      }
+    mask[w] = bits;
+  }
+  // the nodes' left counts ride behind the bits (QR_MAXLEVEL words)
+  if (blockIdx.x == 0) {
+    const int nodes = 1 << level;
+    for (int j = threadIdx.x; j < QR_MAXLEVEL; j += 256) {
+      uint32_t v = 0;
+      if (lf >= 0 && j < nodes) v = hcnt[((size_t)(nodes - 1 + j) * flocal + lf) * 256 + t];  // hslot == node index
+      mask[mask_words + j] = v;
+    }
   }
 }
 
@@ -2988,14 +3072,14 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
                        c->ncu, c->flocal, c->d_hcnt, c->wide ? c->d_wthr : c->d_thr, c->d_gf2lf,
                        c->d_blocks, c->nblocks, c->d_lhist_map, c->d_lpart_map, (uint32_t)c->N,
                        c->d_featrec, c->d_scalars, c->wide ? c->d_woff : (const uint32_t *)nullptr,
-                       c->wcells);
+                       c->wcells, (const qr_split_t *)nullptr, 1, (const uint32_t *)nullptr);
     QR_CHECK(c, hipGetLastError());
     const unsigned pg = std::min<unsigned>(pgrid, (unsigned)(c->N / QR_PART_SLICE + nodes + 1));
     hipLaunchKernelGGL(k_partition_level, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
                        c->d_lpart_map,
                        c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm,
                        (uint32_t)c->N, c->d_order[0], c->d_order[1], (u64 *)c->d_lpart_state,
-                       c->wide ? 1 : 0);
+                       c->wide ? 1 : 0, (const uint32_t *)nullptr);
     QR_CHECK(c, hipGetLastError());
     if (last) break;  // ot.cc:127: no histograms for the leaves
     if (c->wide) {
@@ -3014,6 +3098,60 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
                        c->d_hcnt, c->flocal);
     QR_CHECK(c, hipGetLastError());
   }
+  return QR_OK;
+}
+
+// ---- feature-sharded level-wise growth, phase by phase (the host puts the all-gather of
+// the records and the all-reduce of mask + counts in between) ---------------------------
+int qr_k_obl_begin(qr_ctx *c, size_t depth, uint64_t minls) {
+  const int maxnodes = (1 << (depth + 1)) - 1;
+  hipLaunchKernelGGL(k_obl_reset, dim3((maxnodes + 255) / 256), dim3(256), 0, c->stream, c->d_tree,
+                     maxnodes, (u64)minls);
+  QR_CHECK(c, hipGetLastError());
+  return launch_hist_scan(c, 1);  // root histogram of the rank's features -> slot 0
+}
+
+int qr_k_obl_propose(qr_ctx *c, int level) {
+  hipLaunchKernelGGL(k_obl_fill, dim3(c->flocal), dim3(256), 0, c->stream, c->d_tree, level, c->d_hsum,
+                     c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_obl_propose, dim3(1), dim3(64), 0, c->stream, c->d_tree, level, c->d_featrec,
+                     c->flocal, c->d_recs_local);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+int qr_k_obl_mark(qr_ctx *c, int level) {
+  const unsigned grid = (unsigned)((c->mask_words + 255) / 256);
+  hipLaunchKernelGGL(k_obl_mark, dim3(grid), dim3(256), 0, c->stream, c->d_tree, level, c->d_recs_all,
+                     c->world, c->d_gf2lf, (uint32_t)c->N, c->d_hcnt, c->flocal, c->d_bins_fm, c->d_mask,
+                     (uint32_t)c->mask_words);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+int qr_k_obl_apply(qr_ctx *c, int level, int last) {
+  const int nodes = 1 << level;
+  hipLaunchKernelGGL(k_obl_plan, dim3(1), dim3(256), 0, c->stream, c->d_tree, level, last, c->ncu,
+                     c->flocal, c->d_hcnt, c->d_thr, c->d_gf2lf, c->d_blocks, c->nblocks, c->d_lhist_map,
+                     c->d_lpart_map, (uint32_t)c->N, c->d_featrec, c->d_scalars, (const uint32_t *)nullptr,
+                     (size_t)0, c->d_recs_all, c->world, c->d_mask + c->mask_words);
+  QR_CHECK(c, hipGetLastError());
+  const unsigned pg = std::min<unsigned>((unsigned)c->lpart_cap, (unsigned)(c->N / QR_PART_SLICE + nodes + 1));
+  hipLaunchKernelGGL(k_partition_level, dim3(pg), dim3(256), 0, c->stream, c->d_tree, c->d_lpart_map,
+                     c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1], (u64 *)c->d_lpart_state, 0,
+                     c->d_mask);
+  QR_CHECK(c, hipGetLastError());
+  if (last) return QR_OK;  // ot.cc:127: no histograms for the leaves
+  const unsigned hg = std::min<unsigned>((unsigned)c->lhist_cap,
+                                         (unsigned)std::max(c->ncu, c->ncu / 4 + nodes * c->nblocks));
+  hipLaunchKernelGGL(k_hist_level, dim3(hg), dim3(1024), hist_lds(c), c->stream, c->d_tree, c->d_lhist_map,
+                     c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
+                     c->d_scalars, (u64 *)c->d_lpartials);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_redscan_level, dim3(c->flocal, (unsigned)nodes), dim3(1024), 0, c->stream, c->d_tree,
+                     c->d_blocks, c->nblocks, (const u64 *)c->d_lpartials, c->d_hsum, c->d_hcnt, c->flocal);
+  QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
 
@@ -3048,6 +3186,11 @@ int qr_k_scores_update(qr_ctx *c, double shrinkage) {
     hipLaunchKernelGGL(k_score_update_walk, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
                        c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm,
                        (uint32_t)c->N, c->d_gf2lf, shrinkage, c->d_scores, c->wide ? 1 : 0);
+  } else if (c->sub_k) {
+    // a feature-sharded rank under --subsample: the leaves hold the sample only and its bins
+    // cover its own features only, but the raw rows are replicated: walk them (mart.cc:345)
+    hipLaunchKernelGGL(k_valid_update, dim3(grid), dim3(256), 0, c->stream, c->d_tree, c->d_raw,
+                       (uint32_t)c->N, (uint32_t)c->F, shrinkage, c->d_scores);
   } else {
     hipLaunchKernelGGL(k_score_update, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
                        c->d_order[0], c->d_order[1], shrinkage, c->d_scores);

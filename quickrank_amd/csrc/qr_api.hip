@@ -537,7 +537,9 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, dalloc(&c->d_recs_local, (size_t)2));
   QR_CHECK(c, dalloc(&c->d_recs_all, 2 * (size_t)c->world));
   c->mask_words = (N + 31) / 32;
-  QR_CHECK(c, dalloc(&c->d_mask, c->mask_words));
+  // (+ QR_MAXLEVEL words behind the bits: the left counts of a level's nodes, k_obl_mark)
+  QR_CHECK(c, dalloc(&c->d_mask, c->mask_words + QR_MAXLEVEL));
+  QR_CHECK(c, hipMemset(c->d_mask, 0, (c->mask_words + QR_MAXLEVEL) * 4));
   QR_CHECK(c, dalloc(&c->d_part_state, N / QR_PART_SLICE + 2));
   QR_CHECK(c, hipMemset(c->d_part_state, 0, (N / QR_PART_SLICE + 2) * 8));
   QR_CHECK(c, dalloc(&c->d_part_ss, 2 * (N / QR_PART_SLICE + 2)));
@@ -988,7 +990,9 @@ static int ensure_level_buffers(qr_ctx *c, size_t depth) {
 int qr_subsample_set(qr_ctx *c, float subsample, uint64_t seed) {
   if (!c) return QR_ERR_ARG;
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
-  if (c->world > 1 || c->dmode) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling is single-GPU in this round");
+  // feature-sharded ranks hold every document: each draws the same sample (a pure function of
+  // seed and iteration).  Document-sharded ranks would need a global k-th key: not built.
+  if (c->dmode) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling: single-GPU and feature-sharded contexts only");
   if (!(subsample > 0.0f)) QR_FAIL(c, QR_ERR_ARG, "subsample must be > 0");
   // mart.cc:289-297: > 1 is a number of documents, < 1 a fraction (rounded down)
   size_t k = subsample > 1.0f ? std::min((size_t)subsample, c->N)
@@ -1173,7 +1177,9 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
   { const int src_ = tree_settle(c); if (src_) return src_; }
   if (c->world > 1 || c->dmode)
-    QR_FAIL(c, QR_ERR_UNSUPPORTED, "oblivious trees are single-GPU in this round");
+    QR_FAIL(c, QR_ERR_STATE,
+            "sharded contexts grow oblivious trees phase by phase (feature-sharded: qr_obl_begin / "
+            "propose / mark / apply with the collectives in between; document-sharded: not built)");
   if (c->sub_k) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling applies to leaf-wise trees in this round");
   if (depth < 1 || ((size_t)1 << (depth + 1)) - 1 > QR_MAXNODES)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
@@ -1185,6 +1191,49 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
   c->cur_maxnodes = ((size_t)1 << (depth + 1)) - 1;
   if ((rc = qr_k_oblivious_fit(c, depth, minls))) return rc;
   return qr_tree_end(c, newton, nodes_out, nnodes_out);
+}
+
+// ---- feature-sharded oblivious trees, phase by phase ------------------------------------
+int qr_obl_begin(qr_ctx *c, size_t depth, uint64_t minls) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  if (c->dmode) QR_FAIL(c, QR_ERR_UNSUPPORTED, "oblivious trees: single-GPU and feature-sharded contexts only");
+  if (c->wide) QR_FAIL(c, QR_ERR_UNSUPPORTED, "the phase calls use u8 bins");
+  if (c->sub_k) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling applies to leaf-wise trees in this round");
+  if (depth < 1 || ((size_t)1 << (depth + 1)) - 1 > QR_MAXNODES)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
+  int rc = tree_settle(c);
+  if (rc) return rc;
+  if ((rc = ensure_hist_slots(c, ((size_t)1 << (depth + 1)) - 1))) return rc;
+  if ((rc = ensure_level_buffers(c, depth))) return rc;
+  c->tree_valid = false;
+  c->tree_open = true;
+  c->cur_depth = depth;
+  c->cur_maxnodes = ((size_t)1 << (depth + 1)) - 1;
+  return qr_k_obl_begin(c, depth, minls);
+}
+int qr_obl_propose(qr_ctx *c, size_t level) {
+  if (!c || !c->tree_open || level >= c->cur_depth) return QR_ERR_STATE;
+  return qr_k_obl_propose(c, (int)level);
+}
+int qr_obl_mark(qr_ctx *c, size_t level) {
+  if (!c || !c->tree_open || level >= c->cur_depth) return QR_ERR_STATE;
+  return qr_k_obl_mark(c, (int)level);
+}
+int qr_obl_apply(qr_ctx *c, size_t level) {
+  if (!c || !c->tree_open || level >= c->cur_depth) return QR_ERR_STATE;
+  return qr_k_obl_apply(c, (int)level, level + 1 == c->cur_depth);
+}
+int qr_obl_exchange_buffers(qr_ctx *c, void **recs_local, void **recs_all, size_t *rec_bytes_per_rank,
+                            void **mask, size_t *mask_bytes) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  if (recs_local) *recs_local = c->d_recs_local;
+  if (recs_all) *recs_all = c->d_recs_all;
+  if (rec_bytes_per_rank) *rec_bytes_per_rank = 2 * sizeof(qr_split_t);
+  if (mask) *mask = c->d_mask;
+  if (mask_bytes) *mask_bytes = (c->mask_words + QR_MAXLEVEL) * 4;
+  return QR_OK;
 }
 
 int qr_scores_update(qr_ctx *c, double shrinkage) {

@@ -400,6 +400,7 @@ struct qr_ctx {
   uint32_t mf_k = 0;             // --max-features: features a node's split search sees (0 = all)
   uint64_t mf_seed = 0, tree_counter = 0;
   size_t cur_nleaves = 0;
+  size_t cur_depth = 0;          // of the open feature-sharded oblivious tree
   // ensemble
   qr_node_t *d_ens = nullptr;
   double *d_ens_w = nullptr;
@@ -479,6 +480,10 @@ int qr_k_tree_apply(qr_ctx *c);
 int qr_k_tree_finish(qr_ctx *c, int newton);
 int qr_k_scores_update(qr_ctx *c, double shrinkage);
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls);
+int qr_k_obl_begin(qr_ctx *c, size_t depth, uint64_t minls);
+int qr_k_obl_propose(qr_ctx *c, int level);
+int qr_k_obl_mark(qr_ctx *c, int level);
+int qr_k_obl_apply(qr_ctx *c, int level, int last);
 int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls);
 int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_done);
 int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,

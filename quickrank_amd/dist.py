@@ -110,6 +110,31 @@ class ShardedTreeFitter:
             return None
         return ctx.tree_end(nleaves, newton)
 
+    def fit_oblivious(self, ctx, depth, minls, newton, read=True):
+        """ObliviousRT::fit (ot.cc:32-201) on feature-sharded ranks: per level an
+        all-gather of the ranks' best (feature, slot) of the level and a sum all-reduce
+        of the owner's go-left bits (one per DOCUMENT: every node of a level takes the
+        same split) + the level's left counts."""
+        if not hasattr(self, "_ob"):
+            b = ctx.obl_exchange_buffers()
+            self._ob = b
+            if hasattr(ctx, "host_buffers"):
+                self._omask = self.torch.from_numpy(ctx.host_buffers()["obl_mask"])
+            else:
+                dev = self.recs_local.device
+                self._omask = self.torch.as_tensor(_DevArray(b["mask"], b["mask_bytes"], "<i4", 4), device=dev)
+        ctx.obl_begin(depth, minls)
+        for level in range(depth):
+            ctx.obl_propose(level)
+            self._gather_records()
+            ctx.obl_mark(level)
+            if self.direct is not None:
+                self.direct.all_reduce_i32(self._ob["mask"], self._ob["mask_bytes"] // 4)
+            else:
+                self.dist.all_reduce(self._omask, op=self.dist.ReduceOp.SUM, group=self.group)
+            ctx.obl_apply(level)
+        return ctx.obl_end(depth, newton, read=read)
+
 
 class RcclComm:
     """ncclAllReduce / ncclAllGather straight from the RCCL torch already loaded, on the

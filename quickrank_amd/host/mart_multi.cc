@@ -17,6 +17,9 @@
 //              the ranks' best-split records and a sum all-reduce of the go-left bit mask
 //              (only the owner of the winning feature contributes non-zero words).
 //
+// Oblivious trees (one all-gather of the ranks' level records + one all-reduce of the
+// go-left bits by document per level) and --subsample (every rank draws the same sample)
+// run in the feature layout, where every rank holds every document.
 // The boosting loop is Mart::learn's (mart.cc:307-395): validation, early stop, rollback
 // and --partial saves included.  Rank 0 keeps the ensemble; every other rank checks that
 // it built the same tree and the run stops if one did not.
@@ -115,24 +118,26 @@ void query_slice(size_t Q, int r, int w, size_t *q0, size_t *q1) {
 void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::Dataset> validation,
                        const std::string &metric, size_t cutoff, size_t partial_save,
                        const std::string &output_basename, int ngpus, bool feature_sharded) {
-  if (algo_ >= OBVMART) {
-    std::cerr << "!!! --gpus > 1 trains MART / LAMBDAMART (oblivious trees are single-GPU)." << std::endl;
+  const bool obliv = algo_ >= OBVMART;
+  if ((obliv || subsample_ != 1.0f) && !feature_sharded) {
+    std::cerr << "!!! --gpus with oblivious trees or --subsample needs --shard features (every rank then "
+                 "holds every document)." << std::endl;
     exit(EXIT_FAILURE);
   }
-  if (subsample_ != 1.0f || max_features_ != 1.0f || ensemble_model_.is_notempty() || nthresholds_ > 255 ||
-      nthresholds_ == 0) {
+  if (max_features_ != 1.0f || ensemble_model_.is_notempty() || nthresholds_ > 255 || nthresholds_ == 0 ||
+      (obliv && subsample_ != 1.0f)) {
     // (nthresholds 0 = every distinct value: fine on one GPU, where the wide path takes over
     // when a column has more than 255 of them; the sharded contexts use u8 bins)
     if (nthresholds_ == 0 || nthresholds_ > 255)
       std::cerr << "!!! --gpus > 1 needs --num-thresholds in [1, 255]." << std::endl;
     else
-      std::cerr << "!!! --gpus > 1 does not combine with --subsample / --max-features / --restart-train."
-                << std::endl;
+      std::cerr << "!!! --gpus > 1 does not combine with --max-features / --restart-train, nor oblivious "
+                   "trees with --subsample." << std::endl;
     exit(EXIT_FAILURE);
   }
   const int W = ngpus;
   const int mcode = metric_code_of(metric);
-  const bool lambda = algo_ == LAMBDAMART;
+  const bool lambda = algo_ == LAMBDAMART || algo_ == OBVLAMBDAMART;
   const size_t N = training->num_instances(), F = training->num_features(), Q = training->num_queries();
   if ((size_t)W > Q || (feature_sharded && (size_t)W > F)) {
     std::cerr << "!!! more GPUs than " << (feature_sharded ? "features" : "queries") << std::endl;
@@ -156,8 +161,11 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
   best_metric_on_training_ = std::numeric_limits<double>::lowest();
   best_model_ = 0;
   ensemble_model_.set_capacity(ntrees_);
-  const size_t maxnodes = 2 * nleaves_ + 1;
+  const size_t maxnodes = obliv ? ((size_t)1 << (treedepth_ + 1)) : 2 * nleaves_ + 1;
   sh.nodes0.resize(maxnodes);
+  unsigned long long sample_seed = sampling_seed_;
+  if (subsample_ != 1.0f && sample_seed == 0)  // the reference seeds from the clock at every draw
+    sample_seed = (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count();
   std::chrono::high_resolution_clock::time_point t_train0;
 
   auto worker = [&](const int r) {
@@ -208,10 +216,13 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       QRM(c, qr_bins_build_with(c, thr.data(), ts.data()));
     }
     QRM(c, qr_scores_reset(c));
+    if (subsample_ != 1.0f) QRM(c, qr_subsample_set(c, subsample_, sample_seed));  // the same draw on every rank
     void *x_hist = nullptr, *x_scal = nullptr, *x_leaf = nullptr, *recs_local = nullptr, *recs_all = nullptr,
          *mask = nullptr;
     size_t n_hist = 0, n_scal = 0, n_leaf = 0, rec_bytes = 0, mask_bytes = 0;
-    if (feature_sharded)
+    if (feature_sharded && obliv)
+      QRM(c, qr_obl_exchange_buffers(c, &recs_local, &recs_all, &rec_bytes, &mask, &mask_bytes));
+    else if (feature_sharded)
       QRM(c, qr_exchange_buffers(c, &recs_local, &recs_all, &rec_bytes, &mask, &mask_bytes));
     else
       QRM(c, qr_doc_exchange_buffers(c, &x_hist, &n_hist, &x_scal, &n_scal, nullptr, nullptr));
@@ -273,7 +284,8 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       }
     };
     std::vector<qr_node_t> nodes(maxnodes);
-    const bool lagged = lambda && !validation;  // as Mart::learn: the metric rides with the next lambda pass
+    // as Mart::learn: the metric rides with the next lambda pass (a sampled ranking is not the metric's)
+    const bool lagged = lambda && !validation && subsample_ == 1.0f;
     size_t built = 0;
     for (size_t m = 0; m < ntrees_; ++m) {
       if (validation && (valid_iterations_ && m > best_model_r_[r] + valid_iterations_)) break;
@@ -288,8 +300,18 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       }
       // ---- tree
       size_t nn = 0;
-      QRM(c, qr_tree_begin(c, nleaves_, minleafsupport_));
-      if (feature_sharded) {
+      if (obliv) {  // ot.cc:32-201, level by level (feature-sharded)
+        QRM(c, qr_obl_begin(c, treedepth_, minleafsupport_));
+        for (size_t level = 0; level < treedepth_; ++level) {
+          QRM(c, qr_obl_propose(c, level));
+          NCCL(ncclAllGather(recs_local, recs_all, rec_bytes, ncclInt8, comm, stream));
+          QRM(c, qr_obl_mark(c, level));
+          NCCL(ncclAllReduce(mask, mask, mask_bytes / 4, ncclInt32, ncclSum, comm, stream));
+          QRM(c, qr_obl_apply(c, level));
+        }
+        QRM(c, qr_tree_end(c, lambda, nodes.data(), &nn));
+      } else if (feature_sharded) {
+        QRM(c, qr_tree_begin(c, nleaves_, minleafsupport_));
         NCCL(ncclAllGather(recs_local, recs_all, rec_bytes, ncclInt8, comm, stream));
         for (size_t s = 0; s + 1 < nleaves_; ++s) {
           QRM(c, qr_tree_decide(c));
@@ -300,6 +322,7 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
         QRM(c, qr_tree_decide(c));
         QRM(c, qr_tree_end(c, lambda, nodes.data(), &nn));
       } else {
+        QRM(c, qr_tree_begin(c, nleaves_, minleafsupport_));
         sum64(x_hist, n_hist);
         for (size_t s = 0; s + 1 < nleaves_; ++s) {
           QRM(c, qr_tree_decide(c));

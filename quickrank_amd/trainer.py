@@ -77,6 +77,8 @@ class Mart:
 
     def _fit_tree(self, newton):
         if self.oblivious:
+            if self.dist is not None:     # feature-sharded ranks (ShardedTreeFitter)
+                return self.dist.fit_oblivious(self.ctx, self.depth, self.minls, newton)
             return self.ctx.fit_oblivious(self.depth, self.minls, newton)
         if self.dist is not None:
             return self.dist.fit_tree(self.ctx, self.nleaves, self.minls, newton)

@@ -360,3 +360,31 @@ def test_quicklearn_gpus_flag_runs_the_sharded_protocol(tools, tmp_path, algo, s
     t1 = [l for l in a.stdout.splitlines() if l[:7].strip().isdigit()]
     t2 = [l for l in b.stdout.splitlines() if l[:7].strip().isdigit()]
     assert t1 == t2 and len(t1) == 6
+
+
+@pytest.mark.parametrize("extra", [["--algo", "OBVLAMBDAMART", "--tree-depth", "4"],
+                                   ["--algo", "LAMBDAMART", "--num-leaves", "8", "--subsample", "0.5", "--seed", "5"]])
+def test_quicklearn_gpus_features_oblivious_and_subsample(tools, tmp_path, extra):
+    """Oblivious trees and --subsample on the multi-GPU host run in the feature layout
+    (`--shard features`: every rank holds every document); with one rank the model must be
+    the single-GPU one.  The document layout refuses both with a message."""
+    x, labels, qoff = make_dataset(nq=120, docs_per_query=40, F=30, seed=73)
+    tr = str(tmp_path / "train.svml")
+    _write_svml(tr, x, labels, qoff)
+    base = ["--train", tr, "--num-trees", "5", "--num-thresholds", "64", "--min-leaf-support", "5"] + extra
+    m1, m2 = str(tmp_path / "single.xml"), str(tmp_path / "multi.xml")
+    a = subprocess.run([tools["quicklearn"]] + base + ["--model-out", m1], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run([tools["quicklearn"]] + base + ["--model-out", m2, "--gpus", "1", "--shard", "features"],
+                       capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stdout + b.stderr
+    n1, w1 = _load_model(tools, m1)
+    n2, w2 = _load_model(tools, m2)
+    assert n1.shape == n2.shape and np.array_equal(w1, w2)
+    for k in ("feature", "left", "right"):
+        assert np.array_equal(n1[k], n2[k]), k
+    assert np.array_equal(n1["threshold"].view(np.uint32), n2["threshold"].view(np.uint32))
+    assert np.allclose(n1["value"], n2["value"], rtol=1e-9, atol=1e-12)
+    r = subprocess.run([tools["quicklearn"]] + base + ["--gpus", "1", "--shard", "docs"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "--shard features" in r.stderr

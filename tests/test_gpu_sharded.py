@@ -130,3 +130,162 @@ def test_torch_distributed_fitter_world1(oracle_lib):
         c.close()
     finally:
         dist.destroy_process_group()
+
+
+def _sharded_obl_fit(torch, ctxs, depth, minls):
+    """The oblivious protocol of ShardedTreeFitter.fit_oblivious with the two collectives of
+    a level replaced by explicit copies / sums between the contexts' buffers."""
+    from quickrank_amd.dist import _DevArray
+    world = len(ctxs)
+    dev = torch.device("cuda", 0)
+    v = []
+    for c in ctxs:
+        b = c.obl_exchange_buffers()
+        v.append(dict(loc=torch.as_tensor(_DevArray(b["recs_local"], b["rec_bytes"]), device=dev),
+                      all=torch.as_tensor(_DevArray(b["recs_all"], b["rec_bytes"] * world), device=dev),
+                      mask=torch.as_tensor(_DevArray(b["mask"], b["mask_bytes"], "<i4", 4), device=dev)))
+
+    def sync():
+        for c in ctxs:
+            c.synchronize()
+        torch.cuda.synchronize()
+
+    for c in ctxs:
+        c.obl_begin(depth, minls)
+    for level in range(depth):
+        for c in ctxs:
+            c.obl_propose(level)
+        sync()
+        cat = torch.cat([x["loc"] for x in v])
+        for x in v:
+            x["all"].copy_(cat)
+        sync()
+        for c in ctxs:
+            c.obl_mark(level)
+        sync()
+        tot = v[0]["mask"].clone()
+        for x in v[1:]:
+            tot += x["mask"]
+        for x in v:
+            x["mask"].copy_(tot)
+        sync()
+        for c in ctxs:
+            c.obl_apply(level)
+    return [c.obl_end(depth, True) for c in ctxs]
+
+
+@pytest.mark.parametrize("world,F,depth,minls", [(2, 136, 4, 1), (3, 70, 6, 3), (8, 136, 5, 1), (2, 9, 3, 20)])
+def test_sharded_oblivious_equal_single(world, F, depth, minls, oracle_lib):
+    """Feature-sharded oblivious trees (qr_obl_begin / propose / mark / apply): every rank's
+    tree is bit-identical to the single-context one -- level splits, node counts, leaf
+    values -- and so are the updated scores."""
+    import torch
+    import quickrank_amd as qr
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=50, F=F, seed=19, adversarial=True)
+    rng = np.random.default_rng(3)
+    lam, w = oracle_lib.lambdas(labels, rng.standard_normal(len(labels)) * 0.3, qoff)
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(255)
+    single.set_pseudo(lam, w)
+    want = single.fit_oblivious(depth, minls, True)
+    single.set_scores(np.zeros(len(labels)))
+    single.update_scores(0.1)
+    want_scores = single.get_scores()
+    ctxs = []
+    for r in range(world):
+        c = qr.Context(0, rank=r, world=world)
+        c.upload(x, labels, qoff)
+        c.build_bins(255)
+        c.set_pseudo(lam, w)
+        ctxs.append(c)
+    got = _sharded_obl_fit(torch, ctxs, depth, minls)
+    for g in got:
+        assert len(g) == len(want)
+        for k in want.dtype.names:
+            assert np.array_equal(g[k], want[k]), k
+    for c in ctxs:
+        c.set_scores(np.zeros(len(labels)))
+        c.update_scores(0.1)
+        assert np.array_equal(c.get_scores(), want_scores)
+        c.close()
+    single.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_subsample_equal_single(world, oracle_lib):
+    """--subsample on feature-sharded ranks: every rank holds every document and draws the
+    same sample (a pure function of seed and iteration); trees and the scores of ALL
+    documents (mart.cc:345) equal the single-context run over three iterations."""
+    import torch
+    import quickrank_amd as qr
+    x, labels, qoff = make_dataset(nq=80, docs_per_query=40, F=33, seed=23)
+
+    def run(ctxs):
+        trees = []
+        for c in ctxs:
+            c.reset_scores()
+            c.set_subsample(0.5, 77)
+        for it in range(3):
+            for c in ctxs:
+                c.compute_lambdas("NDCG", 10)
+            if len(ctxs) == 1 and ctxs[0].world == 1:
+                t = [ctxs[0].fit_tree(8, 2, True)]
+            else:
+                t = _sharded_fit(torch, ctxs, 8, 2)
+            for c in ctxs:
+                c.update_scores(0.1)
+            trees.append(t)
+        return trees, [c.get_scores() for c in ctxs]
+
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(64)
+    want_t, want_s = run([single])
+    ctxs = []
+    for r in range(world):
+        c = qr.Context(0, rank=r, world=world)
+        c.upload(x, labels, qoff)
+        c.build_bins(64)
+        ctxs.append(c)
+    got_t, got_s = run(ctxs)
+    for it in range(3):
+        for g in got_t[it]:
+            for k in ("feature", "thr_id", "left", "right", "nsamples"):
+                assert np.array_equal(g[k], want_t[it][0][k]), (it, k)
+            assert np.allclose(g["value"], want_t[it][0]["value"], rtol=1e-12, atol=1e-15)
+    for s in got_s:
+        assert np.allclose(s, want_s[0], rtol=1e-12, atol=1e-15)
+    for c in ctxs + [single]:
+        c.close()
+
+
+def test_torch_distributed_oblivious_world1(oracle_lib):
+    """ShardedTreeFitter.fit_oblivious over RCCL with one rank == the single-context tree."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import quickrank_amd as qr
+    from quickrank_amd.dist import ShardedTreeFitter
+    x, labels, qoff = make_dataset(nq=50, docs_per_query=40, F=40, seed=6)
+    lam, w = oracle_lib.lambdas(labels, np.zeros(len(labels)), qoff)
+    ref = qr.Context(0)
+    ref.upload(x, labels, qoff)
+    ref.build_bins(64)
+    ref.set_pseudo(lam, w)
+    want = ref.fit_oblivious(4, 2, True)
+    ref.close()
+    torch.cuda.set_device(0)
+    port = 29700 + os.getpid() % 1000
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        c = qr.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        c.upload(x, labels, qoff)
+        c.build_bins(64)
+        c.set_pseudo(lam, w)
+        got = ShardedTreeFitter(c).fit_oblivious(c, 4, 2, True)
+        for k in want.dtype.names:
+            assert np.array_equal(got[k], want[k]), k
+        c.close()
+    finally:
+        dist.destroy_process_group()

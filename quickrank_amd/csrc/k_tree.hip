@@ -1367,6 +1367,14 @@ __device__ __forceinline__ void batch_child_stats(QrNode *nodes, const QrLevelNo
   C->best_thr = thrv;
 }
 
+// Splits applied ahead of their turn shorten the chain of dependent launches at the price
+// of child histograms that are sometimes never used: that pays while a step is bound by its
+// launches, not by the documents it moves.  Measured (scripts/spec_bench.py, ms per
+// iteration with / without early splits): 1M documents 0.553 / 0.629, 2M 0.859 / 0.940,
+// 4M 1.553 / 1.563, 8M 2.925 / 2.860.
+#ifndef QR_SPEC_MAX_DOCS
+#define QR_SPEC_MAX_DOCS 6000000u
+#endif
 // the control lane's step on the state `st` points at (force-inlined into an
 // LDS-staged and a device-resident call site, like decide_logic)
 __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, const bool root_mode,
@@ -1441,7 +1449,7 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
   }
   // candidates applied ahead of their turn: the largest deviances left in the heap,
   // as long as the leaf budget can still reach them
-  if (nj == 1) {
+  if (nj == 1 && N < QR_SPEC_MAX_DOCS) {
     while (nj < QR_BATCH) {
       if (st.nleaves_req != 0 && st.nleaves_req - (st.taken + st.heap_size + 2) < nj) break;
       int pick = -1;

@@ -503,7 +503,9 @@ __global__ __launch_bounds__(64) void k_lambda(
     const uint8_t *__restrict__ present, const uint8_t *__restrict__ long_flag,
     const uint32_t *__restrict__ long_list, char *__restrict__ lscratch, const size_t lstride) {
   extern __shared__ __attribute__((aligned(16))) char lds_mem[];
-  const uint32_t q = LONG ? long_list[blockIdx.x] : blockIdx.x;
+  // (LONG = false: `long_list`, when given, is the launch's size class -- the queries whose
+  // working set fits THIS launch's LDS)
+  const uint32_t q = long_list ? long_list[blockIdx.x] : blockIdx.x;
   if (!LONG && long_flag && long_flag[q]) return;
   char *smem = LONG ? lscratch + (size_t)blockIdx.x * lstride : lds_mem;
   const uint32_t lane = threadIdx.x;
@@ -936,6 +938,9 @@ static size_t lambda_lds(size_t nmax, size_t kacc, bool sampled) {
          ((nmax + 7) & ~(size_t)7) + (sampled ? nmax * 4 : 0);
 }
 
+// size classes of the LDS-resident launches: a query goes to the first class that holds it
+static const uint32_t kClassBound[] = {128, 256, 512, 1024, 2048, 0xFFFFFFFFu};
+
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   const size_t Q = which ? c->vQ : c->Q;
   const size_t maxq = which ? c->vmaxq : c->maxq;
@@ -948,42 +953,63 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   kacc = (kacc + 1) & ~(size_t)1;
   const size_t limit = 160 * 1024 - 512;
   const bool sampled = which == 0 && c->sub_k != 0;
-  size_t nmax = (maxq + 3) & ~(size_t)3;
-  // queries whose working set does not fit the LDS run out of a global scratch
-  // slice each (second launch); an unbounded cutoff on a long query would also need
-  // the per-rank accumulators there, so it takes the same route
-  const uint8_t *d_flag = nullptr;
-  size_t nlong = 0, nmax_long = 0, lstride = 0;
-  if (lambda_lds(nmax, kacc, sampled) > limit) {
-    nmax_long = nmax;
-    size_t kshort = kacc;
-    while (nmax > 4 && lambda_lds(nmax, std::min(kshort, nmax), sampled) > limit) nmax -= 4;
-    const std::vector<uint64_t> &qo = which ? c->h_vqoff : c->h_qoff;
-    int &tag = which ? c->long_tag[1] : c->long_tag[0];
-    std::vector<uint32_t> &list = which ? c->h_long_list[1] : c->h_long_list[0];
-    if (tag != (int)nmax) {  // (re)build the flag / list for this capacity
-      std::vector<uint8_t> flag(Q, 0);
-      list.clear();
-      for (size_t q = 0; q < Q; ++q)
-        if (qo[q + 1] - qo[q] > nmax) {
-          flag[q] = 1;
-          list.push_back((uint32_t)q);
-        }
-      QR_CHECK(c, hipStreamSynchronize(c->stream));
-      uint8_t *&df = which ? c->d_long_flag[1] : c->d_long_flag[0];
-      uint32_t *&dl = which ? c->d_long_list[1] : c->d_long_list[0];
-      if (df) (void)hipFree(df);
-      if (dl) (void)hipFree(dl);
-      df = nullptr;
-      dl = nullptr;
-      QR_CHECK(c, hipMalloc((void **)&df, Q));
-      QR_CHECK(c, hipMalloc((void **)&dl, (list.size() + 1) * 4));
-      QR_CHECK(c, hipMemcpy(df, flag.data(), Q, hipMemcpyHostToDevice));
-      QR_CHECK(c, hipMemcpy(dl, list.data(), list.size() * 4, hipMemcpyHostToDevice));
-      tag = (int)nmax;
+  // the longest query the LDS holds; longer ones run out of a global scratch slice each
+  // (LONG launch); an unbounded cutoff on a long query would also need the per-rank
+  // accumulators there, so it takes the same route
+  size_t nmax_lds = (maxq + 3) & ~(size_t)3;
+  while (nmax_lds > 4 && lambda_lds(nmax_lds, std::min(kacc, nmax_lds), sampled) > limit) nmax_lds -= 4;
+  const std::vector<uint64_t> &qo = which ? c->h_vqoff : c->h_qoff;
+  int &tag = which ? c->long_tag[which] : c->long_tag[0];
+  std::vector<uint32_t> &llist = which ? c->h_long_list[1] : c->h_long_list[0];
+  std::vector<qr_ctx::QClass> &classes = c->h_qclass[which];
+  if (tag != (int)nmax_lds) {  // (re)build the classes and the long list for this capacity
+    std::vector<std::vector<uint32_t>> by(sizeof(kClassBound) / sizeof(kClassBound[0]));
+    std::vector<uint32_t> cmax(by.size(), 0);
+    llist.clear();
+    for (size_t q = 0; q < Q; ++q) {
+      const size_t n = qo[q + 1] - qo[q];
+      if (n > nmax_lds) {
+        llist.push_back((uint32_t)q);
+        continue;
+      }
+      size_t k = 0;
+      while (n > kClassBound[k]) ++k;
+      by[k].push_back((uint32_t)q);
+      cmax[k] = std::max(cmax[k], (uint32_t)n);
     }
-    nlong = list.size();
-    d_flag = which ? c->d_long_flag[1] : c->d_long_flag[0];
+    std::vector<uint32_t> flat;
+    classes.clear();
+    for (size_t k = 0; k < by.size(); ++k)
+      if (!by[k].empty()) {
+        classes.push_back({(uint32_t)flat.size(), (uint32_t)by[k].size(), cmax[k]});
+        flat.insert(flat.end(), by[k].begin(), by[k].end());
+      }
+    // small classes join their larger neighbour: a launch is worth ~5 us
+    for (size_t k = 0; k + 1 < classes.size();)
+      if (classes[k].count < 64) {
+        classes[k + 1].first = classes[k].first;
+        classes[k + 1].count += classes[k].count;
+        classes.erase(classes.begin() + k);
+      } else
+        ++k;
+    c->qclass_identity[which] = classes.size() == 1 && classes[0].count == Q;
+    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    uint32_t *&dq = c->d_qclass[which];
+    uint32_t *&dl = c->d_long_list[which];
+    if (dq) (void)hipFree(dq);
+    if (dl) (void)hipFree(dl);
+    dq = nullptr;
+    dl = nullptr;
+    QR_CHECK(c, hipMalloc((void **)&dq, (flat.size() + 1) * 4));
+    QR_CHECK(c, hipMalloc((void **)&dl, (llist.size() + 1) * 4));
+    QR_CHECK(c, hipMemcpy(dq, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+    QR_CHECK(c, hipMemcpy(dl, llist.data(), llist.size() * 4, hipMemcpyHostToDevice));
+    tag = (int)nmax_lds;
+  }
+  const size_t nlong = llist.size();
+  size_t lstride = 0, nmax_long = 0;
+  if (nlong) {
+    nmax_long = (maxq + 3) & ~(size_t)3;
     lstride = (lambda_lds(nmax_long, std::min(kacc, nmax_long), sampled) + 255) & ~(size_t)255;
     if (nlong * lstride > c->lscratch_bytes) {
       QR_CHECK(c, hipStreamSynchronize(c->stream));
@@ -993,17 +1019,9 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
       c->lscratch_bytes = nlong * lstride;
     }
   }
-  const size_t kshort = std::min(kacc, nmax);  // nmax is a multiple of 4: stays even
-  const size_t lds = lambda_lds(nmax, kshort, sampled);
-  size_t &attr_lds = c->attr_lambda_lds;
-  if (lds > attr_lds) {
-    QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_lds = lds;
-  }
   const double *sc = which ? c->d_vscores : c->d_scores;
   const float *lb = which ? c->d_vlabels : c->d_labels;
-  const uint32_t *qo = which ? c->d_vqoff : c->d_qoff;
+  const uint32_t *qoffd = which ? c->d_vqoff : c->d_qoff;
   const double *idcg = which ? c->d_vidcg : c->d_idcg;
   double *lam = which ? nullptr : c->d_lambda, *wgt = which ? nullptr : c->d_weight;
   double *qm = which ? c->d_vqmetric : c->d_qmetric;
@@ -1011,19 +1029,67 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   double *ssq = (!which && mode == 0) ? c->d_ssq : nullptr;
   const int md = which ? 1 : mode;
   const uint8_t *present = (!which && mode == 0 && c->sub_k) ? c->d_present : nullptr;
-  const uint32_t *dlist = which ? c->d_long_list[1] : c->d_long_list[0];
-  hipLaunchKernelGGL(k_lambda<false>, dim3((unsigned)Q), dim3(64), lds, c->stream, sc, lb, qo, metric, cut,
-                     idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars, (uint32_t)nmax,
-                     (uint32_t)kshort, md, present, d_flag, (const uint32_t *)nullptr, (char *)nullptr,
-                     (size_t)0);
-  QR_CHECK(c, hipGetLastError());
-  if (nlong) {
-    hipLaunchKernelGGL(k_lambda<true>, dim3((unsigned)nlong), dim3(64), 0, c->stream, sc, lb, qo, metric,
-                       cut, idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars,
-                       (uint32_t)nmax_long, (uint32_t)std::min(kacc, nmax_long), md, present,
-                       (const uint8_t *)nullptr, dlist, c->d_lscratch, lstride);
+  // One launch per size class (its LDS sized for the class's longest query), the launches
+  // side by side on auxiliary streams when there are several: the few long queries of a
+  // ragged set no longer dictate the occupancy of the many short ones.
+  const size_t nlaunch = classes.size() + (nlong ? 1 : 0);
+  const bool fork = nlaunch > 1;
+  if (fork) {
+    if (!c->aux_fork) QR_CHECK(c, hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
+    QR_CHECK(c, hipEventRecord(c->aux_fork, c->stream));
+  }
+  size_t li = 0;  // launch index: 0 stays on the context's stream
+  auto stream_for = [&](size_t i, hipStream_t *out) -> int {
+    if (i == 0) {
+      *out = c->stream;
+      return QR_OK;
+    }
+    const size_t a = (i - 1) % 4;
+    if (!c->aux_stream[a]) {
+      QR_CHECK(c, hipStreamCreateWithFlags(&c->aux_stream[a], hipStreamNonBlocking));
+      QR_CHECK(c, hipEventCreateWithFlags(&c->aux_join[a], hipEventDisableTiming));
+    }
+    if (i <= 4) QR_CHECK(c, hipStreamWaitEvent(c->aux_stream[a], c->aux_fork, 0));
+    *out = c->aux_stream[a];
+    return QR_OK;
+  };
+  // the longest-running launches first: the largest class, then down
+  for (size_t k = classes.size(); k-- > 0;) {
+    const qr_ctx::QClass &cl = classes[k];
+    const size_t nmax = ((size_t)cl.nmax + 3) & ~(size_t)3;
+    const size_t kshort = std::min(kacc, nmax);  // nmax is a multiple of 4: stays even
+    const size_t lds = lambda_lds(nmax, kshort, sampled);
+    if (lds > c->attr_lambda_lds) {
+      QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      c->attr_lambda_lds = lds;
+    }
+    hipStream_t st;
+    int rc = stream_for(li++, &st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_lambda<false>, dim3(cl.count), dim3(64), lds, st, sc, lb, qoffd, metric, cut, idcg,
+                       c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars, (uint32_t)nmax,
+                       (uint32_t)kshort, md, present, (const uint8_t *)nullptr,
+                       c->qclass_identity[which] ? (const uint32_t *)nullptr
+                                                 : (const uint32_t *)(c->d_qclass[which] + cl.first),
+                       (char *)nullptr, (size_t)0);
     QR_CHECK(c, hipGetLastError());
   }
+  if (nlong) {
+    hipStream_t st;
+    int rc = stream_for(li++, &st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_lambda<true>, dim3((unsigned)nlong), dim3(64), 0, st, sc, lb, qoffd, metric, cut,
+                       idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars,
+                       (uint32_t)nmax_long, (uint32_t)std::min(kacc, nmax_long), md, present,
+                       (const uint8_t *)nullptr, (const uint32_t *)c->d_long_list[which], c->d_lscratch, lstride);
+    QR_CHECK(c, hipGetLastError());
+  }
+  if (fork)  // join: the context's stream carries on when every launch is done
+    for (size_t a = 0; a < std::min<size_t>(4, li - 1); ++a) {
+      QR_CHECK(c, hipEventRecord(c->aux_join[a], c->aux_stream[a]));
+      QR_CHECK(c, hipStreamWaitEvent(c->stream, c->aux_join[a], 0));
+    }
   return QR_OK;
 }
 

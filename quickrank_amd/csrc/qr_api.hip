@@ -122,6 +122,9 @@ static void free_long(qr_ctx *c, int which) {
   c->d_long_flag[which] = nullptr;
   c->d_long_list[which] = nullptr;
   c->long_tag[which] = -1;
+  if (c->d_qclass[which]) (void)hipFree(c->d_qclass[which]);
+  c->d_qclass[which] = nullptr;
+  c->h_qclass[which].clear();
 }
 
 static void free_valid(qr_ctx *c) {
@@ -142,6 +145,11 @@ void qr_ctx_destroy(qr_ctx *c) {
   free_valid(c);
   dfree(c->d_lg2); dfree(c->d_ilg2); dfree(c->d_scalars); dfree(c->d_ens); dfree(c->d_ens_w);
   if (c->d_lscratch) (void)hipFree(c->d_lscratch);
+  for (int i = 0; i < 4; ++i) {
+    if (c->aux_stream[i]) (void)hipStreamDestroy(c->aux_stream[i]);
+    if (c->aux_join[i]) (void)hipEventDestroy(c->aux_join[i]);
+  }
+  if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->ev_scal) (void)hipEventDestroy(c->ev_scal);
   if (c->ev_nodes) (void)hipEventDestroy(c->ev_nodes);

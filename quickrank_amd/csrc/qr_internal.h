@@ -331,6 +331,16 @@ struct qr_ctx {
   uint32_t *d_long_list[2] = {nullptr, nullptr};
   std::vector<uint32_t> h_long_list[2];
   int long_tag[2] = {-1, -1};
+  // ... and the others by size class (k_lambda keeps a query's working set in LDS, sized for
+  // the longest query of ITS launch: one launch per class keeps the short queries -- the
+  // many -- at full occupancy).  [which]: class lists concatenated on the device, per class
+  // (first, count, longest query).
+  uint32_t *d_qclass[2] = {nullptr, nullptr};
+  struct QClass { uint32_t first, count, nmax; };
+  std::vector<QClass> h_qclass[2];
+  bool qclass_identity[2] = {false, false};  // one class holding every query in order
+  hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t aux_fork = nullptr, aux_join[4] = {nullptr, nullptr, nullptr, nullptr};
   char *d_lscratch = nullptr;
   size_t lscratch_bytes = 0;
   double *d_ssq = nullptr;       // per-slice sum of squares partials

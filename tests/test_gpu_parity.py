@@ -528,8 +528,14 @@ def test_error_paths_return_codes_not_crashes(qr):
     s.set_pseudo(np.ones(len(labels)), np.ones(len(labels)))
     with pytest.raises(qr.QrError, match="phase|begin/decide"):
         s.fit_tree(4, 1, True)
-    with pytest.raises(qr.QrError, match="single-GPU"):
-        s.set_subsample(0.5)
+    with pytest.raises(qr.QrError, match="phase by phase"):
+        s.fit_oblivious(3, 1, True)
+    d = qr.Context(0, rank=0, world=1, doc_shard=(len(labels), len(qoff) - 1))
+    d.upload(x, labels, qoff)
+    d.build_bins_with(*qr._capi.thresholds_from_stats(x.shape[1], 16, *[a[None] for a in d.bins_stats(16)]))
+    with pytest.raises(qr.QrError, match="feature-sharded contexts only"):
+        d.set_subsample(0.5)             # document-sharded ranks would need a global k-th key
+    d.close()
     with pytest.raises(qr.QrError):
         qr.Context(0, rank=3, world=2)
     s.close()

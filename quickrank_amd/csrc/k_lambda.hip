@@ -284,8 +284,24 @@ __device__ __forceinline__ uint32_t pk(uint32_t v) { return v >> 16; }
 //    an equal key in ANOTHER range is on a known side).  `dupk[key]` != 0 marks the
 //    keys that occur more than once; with a few tied pairs in a query only the
 //    ranges on the way down to them are partitioned.
+// The partition phase is ONE wave's work.  BS = true: the workgroup is that wave (its
+// __syncthreads are wave barriers); BS = false: wave 0 of a larger workgroup runs it alone
+// while the others wait at the caller's barrier -- inside a wave the LDS operations are
+// already in program order, so a compiler-level fence is all that is needed.
+template <bool BS>
+__device__ __forceinline__ void sort_sync() {
+  if (BS) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
+template <bool BS>
 __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *RB,
-                              int *stk, uint32_t *out, const uint8_t *dupk) {
+                              int *stk, const uint8_t *dupk) {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
   if (n > 16) {
@@ -298,11 +314,11 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
       stk[2] = 2 * lg;
     }
     sp = 1;
-    __syncthreads();
+    sort_sync<BS>();
     while (sp > 0) {
       --sp;
       int first = stk[3 * sp], last = stk[3 * sp + 1], depth = stk[3 * sp + 2];
-      __syncthreads();
+      sort_sync<BS>();
       while (last - first > 16) {
         {
           bool dup = false;
@@ -311,7 +327,7 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
         }
         if (depth == 0) {
           if (lane == 0) g_heapsort(a + first, last - first, PackedCmp());
-          __syncthreads();
+          sort_sync<BS>();
           break;
         }
         --depth;
@@ -329,13 +345,13 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
           else if (kb < kc) pick = ic;
           else pick = ib;
           p = pick == ia ? ka : (pick == ib ? kb : kc);
-          __syncthreads();
+          sort_sync<BS>();
           if (lane == 0) {
             const uint32_t t = a[first];
             a[first] = a[pick];
             a[pick] = t;
           }
-          __syncthreads();
+          sort_sync<BS>();
         }
         const int lo0 = first + 1;
         int nl = 0, nr = 0, K = 0;
@@ -359,7 +375,7 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
           if (lb1) LB[__popcll(mlb0) + __popcll(mlb1 & lt)] = (uint32_t)x1;
           if (rb0) RB[__popcll(mrb1) + __popcll(mrb0 & gt)] = (uint32_t)x0;
           if (rb1) RB[__popcll(mrb1 & gt)] = (uint32_t)x1;
-          __syncthreads();
+          sort_sync<BS>();
           const int np = nl < nr ? nl : nr;
           const int q0 = lane, q1 = lane + 64;
           const uint32_t L0 = q0 < np ? LB[q0] : 0u, R0 = q0 < np ? RB[q0] : 0u;
@@ -384,7 +400,7 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
             a[L1] = a[R1];
             a[R1] = t;
           }
-          __syncthreads();
+          sort_sync<BS>();
         } else {
           // LB: ascending positions with key >= p
           for (int base = lo0; base < last; base += 64) {
@@ -404,7 +420,7 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
             if (rb) RB[nr + __popcll(m & lt)] = (uint32_t)x;
             nr += __popcll(m);
           }
-          __syncthreads();
+          sort_sync<BS>();
           const int np = nl < nr ? nl : nr;
           for (int base = 0; base < np; base += 64) {
             const int k = base + lane;
@@ -419,14 +435,14 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
             cut = c1 < c2 ? c1 : c2;
           } else
             cut = nl > 0 ? LB[0] : (uint32_t)last;
-          __syncthreads();
+          sort_sync<BS>();
           for (int k = lane; k < K; k += 64) {
             const uint32_t x = LB[k], y = RB[k];
             const uint32_t t = a[x];
             a[x] = a[y];
             a[y] = t;
           }
-          __syncthreads();
+          sort_sync<BS>();
         }
         // recurse on [cut, last) (pushed), loop on [first, cut)
         if (lane == 0) {
@@ -436,10 +452,19 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
         }
         ++sp;
         last = (int)cut;
-        __syncthreads();
+        sort_sync<BS>();
       }
     }
   }
+}
+
+// The final insertion sort of std::sort == a stable sort by key of the arrangement the
+// partition phase left, by every thread of the workgroup (T = its size).
+template <int W>
+__device__ __forceinline__ void sort_placement(const uint32_t *a, const int n, uint32_t *out,
+                                               const uint8_t *dupk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   // final insertion sort == stable sort by key of the current arrangement
   // (a[n .. n4) is padded with key 0xFFFF by the caller: never counted)
   // The key IS the number of strictly greater scores, so the elements of key k end
@@ -451,6 +476,7 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
   // Early boosting iterations have a handful of distinct scores per query, later ones
   // few duplicates: either way far fewer steps than comparing every pair of positions.
   if (n <= 128) {
+    if (wave != 0) return;
     const int x0 = lane, x1 = lane + 64;
     const bool in0 = x0 < n, in1 = x1 < n;
     const uint32_t v0 = in0 ? a[x0] : 0xFFFFFFFFu, v1 = in1 ? a[x1] : 0xFFFFFFFFu;
@@ -471,7 +497,7 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
     if (in1) out[r1] = v1 & 0xFFFFu;
   } else {
     const int n4 = (n + 3) & ~3;
-    for (int x = lane; x < n; x += 64) {
+    for (int x = (int)threadIdx.x; x < n; x += 64 * W) {
       const uint32_t kx = pk(a[x]);
       uint32_t r = kx;
       if (dupk[kx]) {
@@ -481,7 +507,6 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
       out[r] = a[x] & 0xFFFFu;
     }
   }
-  __syncthreads();
 }
 
 // mode 0: lambdas + metric, mode 1: metric only.
@@ -491,8 +516,14 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
 // `long_flag` (too long for the LDS) are left to the LONG = true launch, which
 // runs the same code on a per-query slice of a global scratch buffer
 // (`long_list[blockIdx.x]` names the query) -- slow, but any length up to 65535.
-template <bool LONG>
-__global__ __launch_bounds__(64) void k_lambda(
+// W = waves per workgroup: 1 for the usual queries; 4 for the size classes of long queries
+// (more than 256 documents), whose O(n^2 / 64) phases -- the counting rank, the placement
+// of tied keys, the pair sweep -- are then shared by four waves (the partition phase of the
+// sort emulation stays one wave's work).  The per-rank sums of a W = 4 query are added
+// per wave and then over the waves in a fixed order: deterministic, and within an ulp or
+// two of the one-wave order.
+template <bool LONG, int W>
+__global__ __launch_bounds__(64 * W) void k_lambda(
     const double *__restrict__ scores, const float *__restrict__ labels,
     const uint32_t *__restrict__ qoff, int metric, uint32_t cutoff,
     const double *__restrict__ idcg, const double *__restrict__ lg2,
@@ -508,7 +539,9 @@ __global__ __launch_bounds__(64) void k_lambda(
   const uint32_t q = long_list ? long_list[blockIdx.x] : blockIdx.x;
   if (!LONG && long_flag && long_flag[q]) return;
   char *smem = LONG ? lscratch + (size_t)blockIdx.x * lstride : lds_mem;
-  const uint32_t lane = threadIdx.x;
+  constexpr uint32_t T = 64 * W;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ double sh_part[2][4][2], sh_red[4][3];
 #ifdef QR_LAMBDA_TIMING
   long long tq[8];
   tq[0] = clock64();
@@ -560,20 +593,20 @@ __global__ __launch_bounds__(64) void k_lambda(
     __syncthreads();
   }
   if (n == 0) {
-    if (lane == 0) {
+    if (tid == 0) {
       qmetric[q] = 0.0;
       if (mode == 0 && ssq) ssq[2 * q] = ssq[2 * q + 1] = 0.0;
     }
     return;
   }
-  for (uint32_t i = lane; i < n; i += 64) {
+  for (uint32_t i = tid; i < n; i += T) {
     const uint32_t di = present ? cmap[i] : i;
     s[i] = scores[off + di];
     lab0[i] = labels[off + di];
   }
   // NaN padding to a multiple of 4: compares false, so it never counts
   const uint32_t n4 = (n + 3) & ~3u;
-  if (lane < n4 - n) s[n + lane] = __longlong_as_double(0x7ff8000000000000LL);
+  if (tid < n4 - n) s[n + tid] = __longlong_as_double(0x7ff8000000000000LL);
   __syncthreads();
   QR_T(1);
   // ---- 1. rank by counting: g = #docs with a strictly greater score.  Two docs
@@ -581,14 +614,14 @@ __global__ __launch_bounds__(64) void k_lambda(
   //         and one add per (j, doc).  Without ties g is a permutation of 0..n-1;
   //         a tie makes two docs collide on the same slot, which the check below
   //         detects (the loser does not find itself in unmap[g]).
-  for (uint32_t r = lane; r < n; r += 64) {
+  for (uint32_t r = tid; r < n; r += T) {
     unmap[r] = 0xFFFFFFFFu;
     dupk[r] = 0;
   }
   __syncthreads();
   bool tie = false;
-  for (uint32_t ib = lane; ib < n; ib += 128) {
-    const uint32_t i0 = ib, i1 = ib + 64;
+  for (uint32_t ib = tid; ib < n; ib += 2 * T) {
+    const uint32_t i0 = ib, i1 = ib + T;
     const bool has1 = i1 < n;
     const double a0 = s[i0], a1 = has1 ? s[i1] : 0.0;
     uint32_t g0 = 0, g1 = 0;
@@ -606,20 +639,30 @@ __global__ __launch_bounds__(64) void k_lambda(
     }
   }
   __syncthreads();
-  for (uint32_t i = lane; i < n; i += 64) {
+  for (uint32_t i = tid; i < n; i += T) {
     const uint32_t key = pa[i] >> 16;
     const bool lost = unmap[key] != i;  // somebody else holds my slot: the key is shared
     if (lost) dupk[key] = 1;
     tie |= lost;
   }
-  if (lane < n4 - n) pa[n + lane] = 0xFFFFFFFFu;
-  const bool anytie = __any(tie);
+  if (tid < n4 - n) pa[n + tid] = 0xFFFFFFFFu;
+  const bool anytie = W == 1 ? (bool)__any(tie) : (bool)__syncthreads_or(tie);
   __syncthreads();
   QR_T(2);
-  // ---- 2. with ties the permutation is what GNU std::sort leaves
-  if (anytie) wave_gnu_sort(pa, (int)n, LB, RB, stk, unmap, dupk);
+  // ---- 2. with ties the permutation is what GNU std::sort leaves: the partition phase by
+  //         one wave, the stable placement that ends it by all
+  if (anytie) {
+    if (W == 1) {
+      wave_gnu_sort<true>(pa, (int)n, LB, RB, stk, dupk);
+    } else {
+      if (wave == 0) wave_gnu_sort<false>(pa, (int)n, LB, RB, stk, dupk);
+      __syncthreads();
+    }
+    sort_placement<W>(pa, (int)n, unmap, dupk);
+    __syncthreads();
+  }
   QR_T(3);
-  for (uint32_t r = lane; r < n; r += 64) {
+  for (uint32_t r = tid; r < n; r += T) {
     const uint32_t d = unmap[r];
     sl[r] = lab0[d];
     sr[r] = s[d];
@@ -651,7 +694,7 @@ __global__ __launch_bounds__(64) void k_lambda(
     __syncthreads();
   }
   // ---- 3. metric of the current ranking (dcg.cc:33-39, ndcg.cc:49-58)
-  {
+  if (W == 1 || wave == 0) {
     // the terms in parallel (one IEEE division per lane), the sum in rank order -- the
     // summation order of dcg.cc:36-38, so the value is bit for bit the sequential one
     double dcg = 0.0;
@@ -672,20 +715,20 @@ __global__ __launch_bounds__(64) void k_lambda(
   // ---- 4. lambdas
   if (metric == QR_METRIC_NDCG && !(my_idcg > 0.0)) {
     // ndcg.cc:69-70: all-zero jacobian => lambdas and weights stay 0
-    for (uint32_t i = lane; i < n_full; i += 64) {
+    for (uint32_t i = tid; i < n_full; i += T) {
       lambda[off + i] = 0.0;
       weight[off + i] = 0.0;
     }
-    if (lane == 0 && ssq) ssq[2 * q] = ssq[2 * q + 1] = 0.0;
+    if (tid == 0 && ssq) ssq[2 * q] = ssq[2 * q + 1] = 0.0;
     return;
   }
-  for (uint32_t i = lane; i < n; i += 64) {
+  for (uint32_t i = tid; i < n; i += T) {
     ownl[i] = 0.0;
     ownw[i] = 0.0;
     s[i] = pow2_label(sl[i]);  // 2^label by rank (scores by doc are no longer needed)
   }
-  for (uint32_t i = lane; i < size; i += 64) ilt[i] = ilg2[i];
-  expt[lane] = QR_EXP_T[lane];
+  for (uint32_t i = tid; i < size; i += T) ilt[i] = ilg2[i];
+  if (tid < 64) expt[tid] = QR_EXP_T[tid];
   __syncthreads();
   const double *pw = s;
   const uint32_t nbatch = (n + 63) / 64;
@@ -711,6 +754,7 @@ __global__ __launch_bounds__(64) void k_lambda(
     del = rho * (1.0 - rho) * d;
   };
   if (n <= 128) {
+    if (W == 1 || wave == 0) {
     // Every lane keeps its two ranks (lane, lane + 64) -- label, 2^label, discount,
     // score and the two accumulators -- in registers for the whole sweep; the only
     // memory traffic of a step is the broadcast read of rank r1's four values, and the
@@ -764,6 +808,7 @@ __global__ __launch_bounds__(64) void k_lambda(
       ownl[rb] = olb;
       ownw[rb] = owb;
     }
+    }
   } else
   for (uint32_t r1 = 0; r1 < size; ++r1) {
     // uniform over the wave
@@ -772,7 +817,7 @@ __global__ __launch_bounds__(64) void k_lambda(
     const double inv1 = ilt[r1];
     const double s1 = sr[r1];
     double c1 = 0.0, cw = 0.0;
-    for (uint32_t bt = r1 / 64; bt < nbatch; ++bt) {
+    for (uint32_t bt = r1 / 64 + (W > 1 ? wave : 0u); bt < nbatch; bt += W) {  // a wave's batches
       const uint32_t r2 = bt * 64 + lane;
       if (r2 < n && r2 > r1) {
         const float l2 = sl[r2];
@@ -786,22 +831,32 @@ __global__ __launch_bounds__(64) void k_lambda(
         }
       }
     }
+    double t1 = 0.0, tw = 0.0;
     if (__any(c1 != 0.0 || cw != 0.0)) {
-      const double t1 = wave_sum(c1);
-      const double tw = wave_sum(cw);
+      t1 = wave_sum(c1);
+      tw = wave_sum(cw);
+    }
+    if (W == 1) {
       if (lane == 0) {
         accl[r1] = t1;
         accw[r1] = tw;
       }
-    } else if (lane == 0) {
-      accl[r1] = 0.0;
-      accw[r1] = 0.0;
+    } else {  // the waves' sums, added in wave order (two buffers: one barrier per rank)
+      if (lane == 0) {
+        sh_part[r1 & 1][wave][0] = t1;
+        sh_part[r1 & 1][wave][1] = tw;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        accl[r1] = (sh_part[r1 & 1][0][0] + sh_part[r1 & 1][1][0]) + (sh_part[r1 & 1][2][0] + sh_part[r1 & 1][3][0]);
+        accw[r1] = (sh_part[r1 & 1][0][1] + sh_part[r1 & 1][1][1]) + (sh_part[r1 & 1][2][1] + sh_part[r1 & 1][3][1]);
+      }
     }
   }
   __syncthreads();
   QR_T(5);
   double mx = 0.0, sq = 0.0, sm = 0.0;
-  for (uint32_t r = lane; r < n; r += 64) {
+  for (uint32_t r = tid; r < n; r += T) {
     const uint32_t d = off + (present ? cmap[unmap[r]] : unmap[r]);
     double l = ownl[r], w = ownw[r];
     if (r < size) {
@@ -818,7 +873,18 @@ __global__ __launch_bounds__(64) void k_lambda(
   mx = wave_max(mx);
   sq = wave_sum(sq);
   sm = wave_sum(sm);
-  if (lane == 0) {
+  if (W > 1) {  // over the waves, in wave order
+    if (lane == 0) {
+      sh_red[wave][0] = mx;
+      sh_red[wave][1] = sq;
+      sh_red[wave][2] = sm;
+    }
+    __syncthreads();
+    mx = fmax(fmax(sh_red[0][0], sh_red[1][0]), fmax(sh_red[2][0], sh_red[3][0]));
+    sq = (sh_red[0][1] + sh_red[1][1]) + (sh_red[2][1] + sh_red[3][1]);
+    sm = (sh_red[0][2] + sh_red[1][2]) + (sh_red[2][2] + sh_red[3][2]);
+  }
+  if (tid == 0) {
     atomicMax(&scal->maxabs_bits, (unsigned long long)__double_as_longlong(mx));
     if (ssq) {
       ssq[2 * q] = sq;
@@ -1060,26 +1126,35 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     const size_t kshort = std::min(kacc, nmax);  // nmax is a multiple of 4: stays even
     const size_t lds = lambda_lds(nmax, kshort, sampled);
     if (lds > c->attr_lambda_lds) {
-      QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false>,
+      QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false, 1>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       c->attr_lambda_lds = lds;
     }
     hipStream_t st;
     int rc = stream_for(li++, &st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_lambda<false>, dim3(cl.count), dim3(64), lds, st, sc, lb, qoffd, metric, cut, idcg,
-                       c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars, (uint32_t)nmax,
-                       (uint32_t)kshort, md, present, (const uint8_t *)nullptr,
-                       c->qclass_identity[which] ? (const uint32_t *)nullptr
-                                                 : (const uint32_t *)(c->d_qclass[which] + cl.first),
-                       (char *)nullptr, (size_t)0);
+    const uint32_t *qlist = c->qclass_identity[which] ? (const uint32_t *)nullptr
+                                                      : (const uint32_t *)(c->d_qclass[which] + cl.first);
+    // long queries: four waves each (not with a sample: the cleaning is one wave's code)
+    if (cl.nmax > 256 && !sampled)
+      hipLaunchKernelGGL((k_lambda<false, 4>), dim3(cl.count), dim3(256), lds, st, sc, lb, qoffd, metric, cut,
+                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars, (uint32_t)nmax,
+                         (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
+                         (size_t)0);
+    else
+      hipLaunchKernelGGL((k_lambda<false, 1>), dim3(cl.count), dim3(64), lds, st, sc, lb, qoffd, metric, cut,
+                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars, (uint32_t)nmax,
+                         (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
+                         (size_t)0);
     QR_CHECK(c, hipGetLastError());
   }
   if (nlong) {
     hipStream_t st;
     int rc = stream_for(li++, &st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_lambda<true>, dim3((unsigned)nlong), dim3(64), 0, st, sc, lb, qoffd, metric, cut,
+    hipLaunchKernelGGL((k_lambda<true, 1>), dim3((unsigned)nlong), dim3(64), 0, st, sc, lb, qoffd, metric, cut,
                        idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars,
                        (uint32_t)nmax_long, (uint32_t)std::min(kacc, nmax_long), md, present,
                        (const uint8_t *)nullptr, (const uint32_t *)c->d_long_list[which], c->d_lscratch, lstride);

@@ -1,0 +1,57 @@
+"""bench.py's contract (the driver parses its one JSON line): a reduced workload through
+the N = 1 path and through the N > 1 code path with one rank (`--force-dist`: process
+group, both sharded layouts over RCCL on the context's stream, the cross-rank tree check)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 500))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout           # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_one_gpu():
+    d = _run(["--queries", "2000", "--steps", "4", "--warmup", "2", "--score-docs", "20000", "--score-trees", "200",
+              "--cpu-iters", "3", "--cpu-score-docs", "500", "--big-blocks", "0", "--extra-steps", "3"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] is None and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["higher_is_better"] is True
+    assert abs(d["value"] - 200000 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches"] == 4 and r["traffic"] is None      # PMC traffic is quoted for the full workload only
+    assert d["roofline_iteration"]["frac"] > 0 and d["roofline_child_hist"]["frac"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "cpu_model" in c
+    assert d["ensemble_scoring"]["value"] > 0 and d["ensemble_scoring"]["cpu_baseline"]["value"] > 0
+    assert 0.0 < d["config"]["ndcg10_last"] <= 1.0
+
+
+def test_bench_line_distributed_path_one_rank():
+    d = _run(["--force-dist", "--queries", "2000", "--steps", "3", "--warmup", "1", "--no-scoring",
+              "--big-blocks", "2", "--extra-steps", "2"])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and "cpu_baseline" not in d
+    lay = d["strong_layouts"]
+    assert set(lay) == {"document_sharded", "feature_sharded"}
+    for v in lay.values():
+        assert v["trees_identical_across_ranks"] is True and "nranks 1" in v["collectives"]
+    # the same data, the same trees: both layouts end at the same NDCG@10 (document sharding
+    # adds its node sums per rank: to rounding)
+    a, b = lay["document_sharded"]["ndcg10_last"], lay["feature_sharded"]["ndcg10_last"]
+    assert abs(a - b) < 1e-12
+    assert d["value"] == max(v["value"] for v in lay.values())
+    assert d["weak_scaling"]["scaling"] == "weak" and d["strong_2M"]["scaling"] == "strong"

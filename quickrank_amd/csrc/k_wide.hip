@@ -14,10 +14,11 @@
 //   bins         u32, feature-major [F][N]: bin = first slot with x <= threshold
 //                (rtnode_histogram.cc:241-251), a binary search per (document, feature)
 //   k_whist      node histogram: one workgroup = one feature x a range of the node's
-//                documents.  Rows of up to 8192 slots are accumulated in LDS (i64 sum +
-//                u32 count per slot, two LDS atomics per document) and flushed with one
-//                global atomic per touched cell; longer rows go straight to global
-//                atomics.  Integer sums: any order, same bits (as k_tree.hip).
+//                documents.  Rows of up to 16384 slots are accumulated in LDS (the packed
+//                count + sum cell of k_tree.hip: one LDS atomic per document; the lanes of a
+//                wave that share a hot slot are summed in registers first) and flushed with
+//                global atomics per touched cell; longer rows go straight to global atomics.
+//                Integer sums: any order, same bits (as k_tree.hip).
 //   k_wscan      per feature: prefix over the slots in chunks of 1024 with a carry,
 //                sibling = parent - child on the cumulative arrays
 //                (rtnode_histogram.cc:72-87, 206-217), gain of every slot and the first
@@ -26,7 +27,7 @@
 // Growth itself -- k_decide, k_partition, k_finish, the leaf and score kernels -- is
 // k_tree.hip's one-split-per-step path, reading u32 bins and ragged thresholds.
 // Single GPU.  The u8 path keeps its kernels and its speed; this one is the general
-// one: on a 713k-document set 2.2x the u8 path's time per iteration at 1024 slots per
+// one: on a 713k-document set 1.9x the u8 path's time per iteration at 1024 slots per
 // feature, 55x with every distinct value a threshold (67 M cells per node histogram).
 #include <hipcub/hipcub.hpp>
 
@@ -39,8 +40,9 @@
 #include "qr_wave.h"
 #include "qr_dev.h"
 
-#define QR_WLDS_SLOTS 8192u   /* rows up to this many slots are accumulated in LDS (96 KB) */
-#define QR_WDOCS 32768u       /* documents per histogram workgroup                          */
+#define QR_WLDS_SLOTS 16384u  /* rows up to this many slots are accumulated in LDS (128 KB)          */
+#define QR_WDOCS 16384u       /* documents per histogram workgroup: an LDS cell is the packed   */
+                              /* count * 2^QR_SB + sum of k_tree.hip, good for QR_DPW documents */
 
 // ---------------------------------------------------------------------------
 // thresholds
@@ -219,34 +221,55 @@ __global__ __launch_bounds__(1024) void k_whist(
   long long *gs = hsum + (size_t)s.slot * cells + base;
   uint32_t *gc = hcnt + (size_t)s.slot * cells + base;
   const bool in_lds = size <= QR_WLDS_SLOTS;
-  long long *ls = reinterpret_cast<long long *>(wlds);
-  uint32_t *lc = reinterpret_cast<uint32_t *>(ls + (in_lds ? size : 0));
+  u64 *cell = reinterpret_cast<u64 *>(wlds);  // [size] packed count * 2^QR_SB + sum (qr_internal.h)
   if (in_lds) {
-    for (uint32_t i = threadIdx.x; i < size; i += 1024) {
-      ls[i] = 0;
-      lc[i] = 0;
-    }
+    for (uint32_t i = threadIdx.x; i < size; i += 1024) cell[i] = 0;
     __syncthreads();
   }
-  for (uint32_t p = r0 + threadIdx.x; p < r1; p += 1024) {
-    const uint32_t id = s.buf == 2 ? s.begin + p : order[s.begin + p];
-    const uint32_t b = row[id];
-    const long long q = quantize(lambda[id] * scale);
-    if (in_lds) {
-      atomicAdd(reinterpret_cast<u64 *>(&ls[b]), (u64)q);
-      atomicAdd(&lc[b], 1u);
-    } else {
-      atomicAdd(reinterpret_cast<u64 *>(&gs[b]), (u64)q);
-      atomicAdd(&gc[b], 1u);
+  const int lane = threadIdx.x & 63;
+  for (uint32_t p0 = r0 + (threadIdx.x & ~63u); p0 < r1; p0 += 1024) {  // wave-uniform trip count
+    const uint32_t p = p0 + lane;
+    const bool in = p < r1;
+    const uint32_t id = in ? (s.buf == 2 ? s.begin + p : order[s.begin + p]) : 0u;
+    const uint32_t b = in ? row[id] : 0xFFFFFFFFu;
+    long long q = in ? quantize(lambda[id] * scale) : 0;
+    uint32_t cnt = in ? 1u : 0u;
+    // A hot slot (the zeros of a count feature: most of a wave's documents) would make the
+    // lanes' atomics queue on one address: the lanes that share the first active lane's
+    // slot add up in registers and their leader issues one atomic for all of them.
+    const unsigned long long act = __ballot(in);
+    if (act) {
+      const int first = __ffsll((long long)act) - 1;
+      const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, first);
+      const unsigned long long same = __ballot(in && b == b0);
+      if (__popcll(same) >= 8) {
+        const bool mine = in && b == b0;
+        const long long tot = readlane_i64(wave_scan_i64(mine ? q : 0), 63);
+        if (lane == first) {
+          q = tot;
+          cnt = (uint32_t)__popcll(same);
+        } else if (mine) {
+          cnt = 0;  // carried by the leader
+        }
+      }
+    }
+    if (cnt) {
+      if (in_lds) {
+        atomicAdd(&cell[b], ((u64)cnt << QR_SB) + (u64)q);
+      } else {
+        atomicAdd(reinterpret_cast<u64 *>(&gs[b]), (u64)q);
+        atomicAdd(&gc[b], cnt);
+      }
     }
   }
   if (!in_lds) return;
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < size; i += 1024) {
-    const uint32_t cn = lc[i];
-    if (cn) {
-      atomicAdd(reinterpret_cast<u64 *>(&gs[i]), (u64)ls[i]);
-      atomicAdd(&gc[i], cn);
+    const u64 v = cell[i];
+    if (v) {
+      const u64 cn = (v + (1ull << (QR_SB - 1))) >> QR_SB;
+      atomicAdd(reinterpret_cast<u64 *>(&gs[i]), v - (cn << QR_SB));
+      atomicAdd(&gc[i], (uint32_t)cn);
     }
   }
 }
@@ -477,7 +500,7 @@ __global__ __launch_bounds__(1024) void k_wobl_fill(
 // ---------------------------------------------------------------------------
 static size_t whist_lds(const qr_ctx *c) {
   const size_t s = std::min<size_t>(c->wmax, QR_WLDS_SLOTS);
-  return s * 12 + 16;
+  return s * 8 + 16;
 }
 
 static int whist_attr(qr_ctx *c) {

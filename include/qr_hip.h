@@ -185,6 +185,9 @@ int qr_tree_fit(qr_ctx *ctx, size_t nleaves, uint64_t minls, int newton,
 /* records of the last fitted tree.  They reach pinned host memory by an async   */
 /* copy enqueued right behind the tree's kernels, so this waits for the tree      */
 /* only -- not for work enqueued after it (score update, the next lambdas).       */
+/* The step count of an enqueued tree is a guess; a tree the guess   */
+/* cut short is completed here -- and by every other call that reads or builds on */
+/* its results -- before anything is returned: callers never see a partial tree.  */
 int qr_tree_nodes(qr_ctx *ctx, qr_node_t *nodes_out, size_t *nnodes_out);
 /* --subsample (mart.cc:287-329, lambdamart.cc:85-102): every iteration fits its  */
 /* tree on a fresh uniform sample of the training documents: subsample > 1 = that */

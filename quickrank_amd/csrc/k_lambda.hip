@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
     const double *__restrict__ idcg, const double *__restrict__ lg2,
     const double *__restrict__ ilg2, double *__restrict__ lambda,
     double *__restrict__ weight, double *__restrict__ qmetric,
-    uint32_t *__restrict__ ranks_out, double *__restrict__ ssq,
+    uint32_t *__restrict__ ranks_out, double *__restrict__ ssq, double *__restrict__ qmax,
     QrScalars *__restrict__ scal, uint32_t nmax, uint32_t kacc, int mode,
     const uint8_t *__restrict__ present, const uint8_t *__restrict__ long_flag,
     const uint32_t *__restrict__ long_list, char *__restrict__ lscratch, const size_t lstride) {
@@ -546,6 +546,8 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   long long tq[8];
   tq[0] = clock64();
 #define QR_T(i) tq[i] = clock64()
+#elif defined(QR_LAMBDA_STOP)  // ablation builds (scripts/lambda_ablation.sh): leave after section i
+#define QR_T(i) if (QR_LAMBDA_STOP == (i)) return
 #else
 #define QR_T(i)
 #endif
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   if (n == 0) {
     if (tid == 0) {
       qmetric[q] = 0.0;
-      if (mode == 0 && ssq) ssq[2 * q] = ssq[2 * q + 1] = 0.0;
+      if (mode == 0 && ssq) ssq[2 * q] = ssq[2 * q + 1] = qmax[q] = 0.0;
     }
     return;
   }
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       lambda[off + i] = 0.0;
       weight[off + i] = 0.0;
     }
-    if (tid == 0 && ssq) ssq[2 * q] = ssq[2 * q + 1] = 0.0;
+    if (tid == 0 && ssq) ssq[2 * q] = ssq[2 * q + 1] = qmax[q] = 0.0;
     return;
   }
   for (uint32_t i = tid; i < n; i += T) {
@@ -884,12 +886,12 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
     sq = (sh_red[0][1] + sh_red[1][1]) + (sh_red[2][1] + sh_red[3][1]);
     sm = (sh_red[0][2] + sh_red[1][2]) + (sh_red[2][2] + sh_red[3][2]);
   }
-  if (tid == 0) {
-    atomicMax(&scal->maxabs_bits, (unsigned long long)__double_as_longlong(mx));
-    if (ssq) {
-      ssq[2 * q] = sq;
-      ssq[2 * q + 1] = sm;
-    }
+  // (the query's max |lambda| goes to its own slot and k_prep takes the maximum: ten
+  // thousand atomicMax on one address queued up for half of this launch's duration)
+  if (tid == 0 && ssq) {
+    ssq[2 * q] = sq;
+    ssq[2 * q + 1] = sm;
+    qmax[q] = mx;
   }
 #ifdef QR_LAMBDA_TIMING
   QR_T(6);
@@ -905,7 +907,7 @@ __global__ __launch_bounds__(256) void k_residual(const float *__restrict__ labe
                                                   const double *__restrict__ scores,
                                                   double *__restrict__ out, uint32_t N,
                                                   double *__restrict__ ssq,
-                                                  QrScalars *__restrict__ scal) {
+                                                  double *__restrict__ qmax) {
   __shared__ double red[4], redm[4], reds[4];
   const uint32_t base = blockIdx.x * QR_SLICE;
   double sq = 0.0, mx = 0.0, sm = 0.0;
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(256) void k_residual(const float *__restrict__ labe
     ssq[2 * blockIdx.x + 1] = (reds[0] + reds[1]) + (reds[2] + reds[3]);
     double m = redm[0];
     for (int i = 1; i < 4; ++i) m = redm[i] > m ? redm[i] : m;
-    atomicMax(&scal->maxabs_bits, (unsigned long long)__double_as_longlong(m));
+    qmax[blockIdx.x] = m;
   }
 }
 
@@ -944,6 +946,7 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
                                                uint32_t nss,
                                                const double *__restrict__ qmetric,
                                                uint32_t nq,
+                                               const double *__restrict__ qmax, uint32_t nmx,
                                                QrScalars *__restrict__ scal,
                                                const int reset_max,
                                                QrScalars *__restrict__ host_copy) {
@@ -954,6 +957,11 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
     a2 += ssq[2 * i + 1];
   }
   for (uint32_t i = threadIdx.x; i < nq; i += 1024) b += qmetric[i];
+  double m = 0.0;  // max |pseudo-response| over the per-query / per-slice maxima
+  for (uint32_t i = threadIdx.x; i < nmx; i += 1024) m = fmax(m, qmax[i]);
+  m = wave_max(m);
+  __shared__ double redm[16];
+  if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = m;
   a = wave_sum(a);
   a2 = wave_sum(a2);
   b = wave_sum(b);
@@ -979,7 +987,10 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
     }
     if (qmetric) scal->metric_sum = tb;
     if (ssq) {
-      const double mx = __longlong_as_double((long long)scal->maxabs_bits);
+      // (maxabs_bits: what qr_pseudo_set or a document-sharded exchange put there)
+      double mx = __longlong_as_double((long long)scal->maxabs_bits);
+      for (int i = 0; i < 16; ++i) mx = fmax(mx, redm[i]);
+      scal->maxabs_bits = (unsigned long long)__double_as_longlong(mx);
       int x = 0;
       if (mx > 0.0) frexp(mx, &x);  // mx = m * 2^x, m in [0.5, 1)  =>  mx < 2^x
       const int e = QR_QBITS - x;
@@ -1093,6 +1104,7 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   double *qm = which ? c->d_vqmetric : c->d_qmetric;
   uint32_t *ranks = which ? nullptr : c->d_ranks;
   double *ssq = (!which && mode == 0) ? c->d_ssq : nullptr;
+  if (ssq) c->nqmax = c->Q;
   const int md = which ? 1 : mode;
   const uint8_t *present = (!which && mode == 0 && c->sub_k) ? c->d_present : nullptr;
   // One launch per size class (its LDS sized for the class's longest query), the launches
@@ -1140,12 +1152,12 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     // long queries: four waves each (not with a sample: the cleaning is one wave's code)
     if (cl.nmax > 256 && !sampled)
       hipLaunchKernelGGL((k_lambda<false, 4>), dim3(cl.count), dim3(256), lds, st, sc, lb, qoffd, metric, cut,
-                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars, (uint32_t)nmax,
+                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
                          (size_t)0);
     else
       hipLaunchKernelGGL((k_lambda<false, 1>), dim3(cl.count), dim3(64), lds, st, sc, lb, qoffd, metric, cut,
-                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars, (uint32_t)nmax,
+                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
                          (size_t)0);
     QR_CHECK(c, hipGetLastError());
@@ -1155,7 +1167,7 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     int rc = stream_for(li++, &st);
     if (rc) return rc;
     hipLaunchKernelGGL((k_lambda<true, 1>), dim3((unsigned)nlong), dim3(64), 0, st, sc, lb, qoffd, metric, cut,
-                       idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_scalars,
+                       idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars,
                        (uint32_t)nmax_long, (uint32_t)std::min(kacc, nmax_long), md, present,
                        (const uint8_t *)nullptr, (const uint32_t *)c->d_long_list[which], c->d_lscratch, lstride);
     QR_CHECK(c, hipGetLastError());
@@ -1171,8 +1183,8 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
 int qr_k_residual(qr_ctx *c) {
   const unsigned grid = (unsigned)((c->N + QR_SLICE - 1) / QR_SLICE);
   hipLaunchKernelGGL(k_residual, dim3(grid), dim3(256), 0, c->stream, c->d_labels,
-                     c->d_scores, c->d_lambda, (uint32_t)c->N, c->d_ssq,
-                     c->d_scalars);
+                     c->d_scores, c->d_lambda, (uint32_t)c->N, c->d_ssq, c->d_qmax);
+  c->nqmax = grid;
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -1183,7 +1195,8 @@ int qr_k_prep(qr_ctx *c, size_t nss, int with_metric, int publish) {
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, c->stream,
                      nss ? c->d_ssq : (const double *)nullptr, (uint32_t)nss,
                      with_metric ? c->d_qmetric : (const double *)nullptr,
-                     with_metric ? (uint32_t)c->Q : 0u, c->d_scalars, c->dmode ? 0 : 1,
+                     with_metric ? (uint32_t)c->Q : 0u, nss ? c->d_qmax : (const double *)nullptr,
+                     nss ? (uint32_t)c->nqmax : 0u, c->d_scalars, c->dmode ? 0 : 1,
                      publish ? &c->d_pin->scal : (QrScalars *)nullptr);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
@@ -1252,7 +1265,8 @@ int qr_k_metric_reduce(qr_ctx *c, int which) {
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, c->stream,
                      (const double *)nullptr, 0u,
                      which ? c->d_vqmetric : c->d_qmetric,
-                     (uint32_t)(which ? c->vQ : c->Q), c->d_scalars, 0, (QrScalars *)nullptr);
+                     (uint32_t)(which ? c->vQ : c->Q), (const double *)nullptr, 0u, c->d_scalars, 0,
+                     (QrScalars *)nullptr);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

@@ -83,7 +83,7 @@ static void free_train(qr_ctx *c) {
   free_long(c, 0);
   dfree(c->d_raw); dfree(c->d_labels); dfree(c->d_qoff);
   dfree(c->d_scores); dfree(c->d_lambda); dfree(c->d_weight);
-  dfree(c->d_idcg); dfree(c->d_qmetric); dfree(c->d_ranks); dfree(c->d_ssq);
+  dfree(c->d_idcg); dfree(c->d_qmetric); dfree(c->d_ranks); dfree(c->d_ssq); dfree(c->d_qmax);
   dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins); dfree(c->d_bins_fm);
   dfree(c->d_thr); dfree(c->d_thr_size);
   dfree(c->d_woff); dfree(c->d_wthr); dfree(c->d_wbins);
@@ -304,6 +304,7 @@ int qr_dataset_upload(qr_ctx *c, const float *x, size_t N, size_t F,
   QR_CHECK(c, dalloc(&c->d_qmetric, Q));
   QR_CHECK(c, dalloc(&c->d_ranks, N));
   QR_CHECK(c, dalloc(&c->d_ssq, 2 * std::max(Q, N / QR_SLICE + 2)));
+  QR_CHECK(c, dalloc(&c->d_qmax, std::max(Q, N / QR_SLICE + 2)));
   c->idcg_metric = -1;
   return ensure_lg2(c);
 }
@@ -810,6 +811,7 @@ int qr_pseudo_set(qr_ctx *c, const double *l, const double *w) {
   memcpy(&s.maxabs_bits, &mx, 8);
   QR_CHECK(c, hipMemcpy(c->d_scalars, &s, sizeof(s), hipMemcpyHostToDevice));
   QR_CHECK(c, hipMemcpy(c->d_ssq, ssq.data(), 2 * ns * 8, hipMemcpyHostToDevice));
+  c->nqmax = 0;  // the maximum is in the scalars already
   int rc = qr_k_prep(c, ns, 0);
   if (rc || !c->dmode) return rc;
   return qr_k_prep_pack(c);  // then: all-reduce the scalar buffer, qr_lambda_finish

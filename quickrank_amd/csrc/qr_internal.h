@@ -344,6 +344,8 @@ struct qr_ctx {
   char *d_lscratch = nullptr;
   size_t lscratch_bytes = 0;
   double *d_ssq = nullptr;       // per-slice sum of squares partials
+  double *d_qmax = nullptr;      // per-query / per-slice max |pseudo-response| (k_prep takes the maximum)
+  size_t nqmax = 0;              // entries of d_qmax the last lambda / residual pass wrote
   QrScalars *d_scalars = nullptr;
   QrPinned *h_pin = nullptr;     // pinned host memory the kernels write the read-backs into
   QrPinned *d_pin = nullptr;     // the same memory through its device address

@@ -952,13 +952,19 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
                                                QrScalars *__restrict__ host_copy) {
   __shared__ double red[16];
   double a = 0.0, b = 0.0, a2 = 0.0;
-  for (uint32_t i = threadIdx.x; i < nss; i += 1024) {
-    a += ssq[2 * i];
-    a2 += ssq[2 * i + 1];
-  }
-  for (uint32_t i = threadIdx.x; i < nq; i += 1024) b += qmetric[i];
   double m = 0.0;  // max |pseudo-response| over the per-query / per-slice maxima
-  for (uint32_t i = threadIdx.x; i < nmx; i += 1024) m = fmax(m, qmax[i]);
+  // one loop, so that the three arrays' loads are in flight together (same additions in
+  // the same order per accumulator as three loops)
+  const uint32_t nall = nss > nq ? (nss > nmx ? nss : nmx) : (nq > nmx ? nq : nmx);
+  for (uint32_t i = threadIdx.x; i < nall; i += 1024) {
+    if (i < nss) {
+      const double2 v = *reinterpret_cast<const double2 *>(ssq + 2 * i);
+      a += v.x;
+      a2 += v.y;
+    }
+    if (i < nq) b += qmetric[i];
+    if (i < nmx) m = fmax(m, qmax[i]);
+  }
   m = wave_max(m);
   __shared__ double redm[16];
   if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = m;

@@ -248,6 +248,15 @@ int qr_obl_mark(qr_ctx *ctx, size_t level);
 int qr_obl_apply(qr_ctx *ctx, size_t level);
 int qr_obl_exchange_buffers(qr_ctx *ctx, void **recs_local, void **recs_all,
                             size_t *rec_bytes_per_rank, void **mask, size_t *mask_bytes);
+/* Document-sharded OBLIVIOUS trees: every rank holds every feature of its own documents, */
+/* so what a level exchanges is its directly built children's histogram cells:              */
+/*   qr_obl_begin -> [all_reduce hist (qr_doc_exchange_buffers), int64 sum] ->              */
+/*   for level in 0 .. depth-1 { qr_obl_propose -> qr_obl_apply ->                          */
+/*     [all_reduce the level's cells (qr_obl_level_exchange), int64 sum; not after the last */
+/*      level: ot.cc:127 builds no histograms for the leaves] } ->                          */
+/*   qr_tree_end -> [all_reduce leaf] -> qr_tree_leaves_finish                               */
+/* (qr_obl_mark is not part of this protocol: the partition is local.)                      */
+int qr_obl_level_exchange(qr_ctx *ctx, size_t level, void **cells, size_t *cells_i64);
 
 /* ---- document-sharded protocol ------------------------------------------------*/
 /* Each rank holds its own queries and all features; what is exchanged is the    */

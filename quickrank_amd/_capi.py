@@ -42,7 +42,7 @@ SYMBOLS = [
     "qr_tree_set_max_features", "qr_subsample_set", "qr_ensemble_partial_scores",
     "qr_prof_get_child", "qr_bins_build_wide", "qr_thresholds_read", "qr_bins_read_u32",
     "qr_node_hist_read_ragged", "qr_ctx_stream", "qr_obl_begin", "qr_obl_propose", "qr_obl_mark",
-    "qr_obl_apply", "qr_obl_exchange_buffers",
+    "qr_obl_apply", "qr_obl_exchange_buffers", "qr_obl_level_exchange",
 ]
 
 _LIB = None
@@ -114,6 +114,7 @@ def lib():
     L.qr_obl_apply.argtypes = [vp, sz]
     L.qr_obl_exchange_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz),
                                           C.POINTER(vp), C.POINTER(sz)]
+    L.qr_obl_level_exchange.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz)]
     L.qr_tree_decide.argtypes = [vp]
     L.qr_tree_apply.argtypes = [vp]
     L.qr_tree_end.argtypes = [vp, C.c_int, vp, C.POINTER(sz)]
@@ -438,6 +439,12 @@ class Context:
                                                 C.byref(m), C.byref(mb)))
         return dict(recs_local=a.value, recs_all=b.value, rec_bytes=rb.value,
                     mask=m.value, mask_bytes=mb.value)
+
+    def obl_level_exchange(self, level):
+        """document-sharded: (device pointer, int64 count) of the level's cells to sum"""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self.L.qr_obl_level_exchange(self.h, level, C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     def lambda_finish(self):
         self._ck(self.L.qr_lambda_finish(self.h))

@@ -656,7 +656,8 @@ __global__ __launch_bounds__(1024) void k_redscan(
     uint32_t *__restrict__ hcnt, const int flocal, const uint32_t *__restrict__ thr_size,
     const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
     qr_split_t *__restrict__ featrec, const float *__restrict__ thr,
-    float *__restrict__ featthr, const QrScanWg *__restrict__ descs, const u64 minls) {
+    float *__restrict__ featthr, const QrScanWg *__restrict__ descs, const u64 minls,
+    const double *__restrict__ part_ss, double *__restrict__ jobsum) {
   __shared__ long long cs_s[3][256];
   __shared__ uint32_t cs_c[3][256];
   __shared__ QrPlan sh_plan;
@@ -705,7 +706,27 @@ __global__ __launch_bounds__(1024) void k_redscan(
   const u64 *src = partials + (size_t)d.slot0 * (256u * 64u) + d.col * 256u + t;
   long long s = 0;
   uint32_t cn = 0;
+  // (feature 0's workgroup, last wave) sum and sum of squares of the node's directly
+  // built child: fixed-order reduction of the partition workgroups' partials, for the
+  // next control step, requested together with the column's cells
+  const bool sums_wave = !root && lf == 0 && (threadIdx.x >> 6) == 15;
+  double pa = 0.0, pb = 0.0;
+  if (sums_wave) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t i = lane; i < d.part_nwg; i += 64) {
+      pa += part_ss[2 * (size_t)(d.part_first + i)];
+      pb += part_ss[2 * (size_t)(d.part_first + i) + 1];
+    }
+  }
   column_sum(src, total, kmax, per, n, (int)g, s, cn);
+  if (sums_wave) {
+    pa = wave_sum(pa);
+    pb = wave_sum(pb);
+    if ((threadIdx.x & 63) == 0) {
+      jobsum[2 * blockIdx.y] = pa;
+      jobsum[2 * blockIdx.y + 1] = pb;
+    }
+  }
   if (g > 0) {
     cs_s[g - 1][t] = s;
     cs_c[g - 1][t] = cn;
@@ -726,10 +747,43 @@ __global__ __launch_bounds__(1024) void k_redscan(
 // built child and sibling by subtraction for every node of the level, in one launch over
 // feature-major partials (see k_redscan): grid = (features, nodes of the level), 4 slot
 // groups x 256 bins; the gains are summed over the level by k_obl_fill, not here
+// (the first 256 threads) cumulative cells of a directly built child from its per-slot
+// values (s, cn), and the sibling by subtraction from the parent's (par_s, par_c)
+__device__ __forceinline__ void level_prefix_write(long long s, uint32_t cn, const long long par_s,
+                                                   const uint32_t par_c, const QrLevelNode &ln,
+                                                   const int lf, const uint32_t t, const int flocal,
+                                                   long long *__restrict__ hsum, uint32_t *__restrict__ hcnt,
+                                                   long long *sh_s, uint32_t *sh_c) {
+  s = wave_scan_i64(s);
+  cn = wave_scan_u32(cn);
+  const int lane = t & 63, wave = t >> 6;
+  if (lane == 63) {
+    sh_s[wave] = s;
+    sh_c[wave] = cn;
+  }
+  __syncthreads();
+  for (int w = 0; w < wave; ++w) {
+    s += sh_s[w];
+    cn += sh_c[w];
+  }
+  const size_t hidx = ((size_t)ln.small_slot * flocal + lf) * 256 + t;
+  const size_t bidx = ((size_t)ln.big_slot * flocal + lf) * 256 + t;
+  if (hsum) {
+    hsum[hidx] = s;
+    hsum[bidx] = par_s - s;
+  }
+  hcnt[hidx] = cn;
+  hcnt[bidx] = par_c - cn;
+}
+
+// xl != null: a document-sharded rank.  The per-slot sums of the rank's own documents go
+// to the level's exchange buffer [node][feature][slot][sum, count] (int64: the all-reduce
+// adds them up, k_level_finish_doc takes the prefix), and the rank's own cumulative COUNTS
+// -- where its partition of the next level cuts its lists -- to hcnt_loc.
 __global__ __launch_bounds__(1024) void k_redscan_level(
     const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks, const int nblocks,
     const u64 *__restrict__ partials, long long *__restrict__ hsum, uint32_t *__restrict__ hcnt,
-    const int flocal) {
+    const int flocal, long long *__restrict__ xl, uint32_t *__restrict__ hcnt_loc) {
   __shared__ long long cs_s[3][256];
   __shared__ uint32_t cs_c[3][256];
   __shared__ long long sh_s[4];
@@ -745,8 +799,8 @@ __global__ __launch_bounds__(1024) void k_redscan_level(
   long long par_s = 0;
   uint32_t par_c = 0;
   if (g == 0) {
-    par_s = hsum[pidx];
-    par_c = hcnt[pidx];
+    par_s = xl ? 0 : hsum[pidx];
+    par_c = xl ? hcnt_loc[pidx] : hcnt[pidx];
   }
   __syncthreads();
   int b = 0;
@@ -770,24 +824,33 @@ __global__ __launch_bounds__(1024) void k_redscan_level(
     s += cs_s[i][t];
     cn += cs_c[i][t];
   }
-  s = wave_scan_i64(s);
-  cn = wave_scan_u32(cn);
-  const int lane = t & 63, wave = t >> 6;
-  if (lane == 63) {
-    sh_s[wave] = s;
-    sh_c[wave] = cn;
+  if (xl) {
+    const size_t x = (((size_t)blockIdx.y * flocal + lf) * 256 + t) * 2;
+    xl[x] = s;
+    xl[x + 1] = (long long)cn;
+    level_prefix_write(0, cn, 0, par_c, ln, lf, t, flocal, nullptr, hcnt_loc, sh_s, sh_c);
+    return;
   }
-  __syncthreads();
-  for (int w = 0; w < wave; ++w) {
-    s += sh_s[w];
-    cn += sh_c[w];
-  }
-  const size_t hidx = ((size_t)ln.small_slot * flocal + lf) * 256 + t;
-  const size_t bidx = ((size_t)ln.big_slot * flocal + lf) * 256 + t;
-  hsum[hidx] = s;
-  hcnt[hidx] = cn;
-  hsum[bidx] = par_s - s;
-  hcnt[bidx] = par_c - cn;
+  level_prefix_write(s, cn, par_s, par_c, ln, lf, t, flocal, hsum, hcnt, sh_s, sh_c);
+}
+
+// document-sharded level-wise growth, after the all-reduce of the level's exchange buffer:
+// cumulative cells of every directly built child over ALL ranks' documents, siblings by
+// subtraction.  Grid = (features, nodes of the level), 256 threads.
+__global__ __launch_bounds__(256) void k_level_finish_doc(
+    const QrTreeState *__restrict__ ts, const long long *__restrict__ xl,
+    long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal) {
+  __shared__ long long sh_s[4];
+  __shared__ uint32_t sh_c[4];
+  if (ts->obl_done || (int)blockIdx.y >= ts->l_nodes) return;
+  const QrLevelNode &ln = ts->lnode[blockIdx.y];
+  if (!ln.active) return;
+  const int lf = blockIdx.x;
+  const uint32_t t = threadIdx.x;
+  const size_t pidx = ((size_t)ln.parent_slot * flocal + lf) * 256 + t;
+  const size_t x = (((size_t)blockIdx.y * flocal + lf) * 256 + t) * 2;
+  level_prefix_write(xl[x], (uint32_t)xl[x + 1], hsum[pidx], hcnt[pidx], ln, lf, t, flocal, hsum, hcnt,
+                     sh_s, sh_c);
 }
 
 // ===========================================================================
@@ -821,9 +884,13 @@ __device__ __forceinline__ bool mf_allowed(u64 seed, uint32_t node, uint32_t f, 
 __device__ qr_split_t wave_merge(const int root_mode, const int which,
                                  const qr_split_t *featrec, const int flocal,
                                  const uint32_t mf_k, const u64 mf_seed, const uint32_t mf_node,
-                                 const uint32_t F, int *lf_out = nullptr) {
+                                 const uint32_t F, int *lf_out = nullptr,
+                                 const float *featthr = nullptr, float *thr_out = nullptr) {
+  // (featthr: the threshold VALUE of every feature's record rides along, so that the
+  // caller has the winner's without a second, dependent read)
   const int lane = threadIdx.x & 63;
   int best_lf = -1;
+  float best_thr = 0.f;
   qr_split_t best;
   best.score = -1.0;
   best.feature = 0xFFFFFFFFu;
@@ -832,11 +899,13 @@ __device__ qr_split_t wave_merge(const int root_mode, const int which,
   if (root_mode && which == 1) return best;
   for (int lf = lane; lf < flocal; lf += 64) {
     const qr_split_t r = featrec[(size_t)which * flocal + lf];
+    const float tv = featthr ? featthr[(size_t)which * flocal + lf] : 0.f;
     if (mf_k && r.feature != 0xFFFFFFFFu && !mf_allowed(mf_seed, mf_node, r.feature, F, mf_k))
       continue;
     if (r.score > best.score) {  // ascending lf within the lane
       best = r;
       best_lf = lf;
+      best_thr = tv;
     }
   }
   // max score over the wave, equal scores -> lowest feature index; the lane that
@@ -853,8 +922,10 @@ __device__ qr_split_t wave_merge(const int root_mode, const int which,
     best.lcount = (u64)readlane_i64((long long)best.lcount, src);
     best.rcount = (u64)readlane_i64((long long)best.rcount, src);
     if (lf_out) *lf_out = __builtin_amdgcn_readlane(best_lf, src);
+    if (thr_out) *thr_out = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_thr), src));
   } else {
     if (lf_out) *lf_out = -1;
+    if (thr_out) *thr_out = 0.f;
     best.score = -1.0;
     best.feature = 0xFFFFFFFFu;
     best.thr_id = 0xFFFFFFFFu;
@@ -1521,6 +1592,13 @@ __device__ __forceinline__ void batch_step(
   constexpr int NH = (int)(((CAP + 2) * sizeof(QrHeapItem) / 8 + 128 * QR_BATCH - 1) / (128 * QR_BATCH));
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool staged = stage_nodes > 0;
+#ifdef QR_STEP_TIMING
+  long long bt[6];
+  bt[0] = clock64();
+#define QR_BT(i) bt[i] = clock64()
+#else
+#define QR_BT(i)
+#endif
   // ---- requests: header, the previous batch's descriptors, node records, heap
   const int njobs_raw = tin->l_nodes;
   // (the first call of a tree starts from its arguments, not from what the last tree left)
@@ -1532,6 +1610,10 @@ __device__ __forceinline__ void batch_step(
   const uint32_t h_part_epoch = tin->part_epoch;
   const u64 h_minls = root_mode ? minls_arg : tin->minls;
   const QrLevelNode myln = tin->lnode[wave < QR_BATCH ? wave : 0];
+  // sums of the directly built children of the batch just applied: k_redscan has added
+  // up the partition workgroups' partials (one dependent read less on this chain)
+  const double js_ss = part_ss[2 * (wave < QR_BATCH ? wave : 0)];
+  const double js_sum = part_ss[2 * (wave < QR_BATCH ? wave : 0) + 1];
   u64 v[NV];
   u64 hv[NH];
   const size_t nw = staged && !root_mode ? (size_t)stage_nodes * sizeof(QrNode) / 8 : 0;
@@ -1553,8 +1635,8 @@ __device__ __forceinline__ void batch_step(
   // wave 2j + which: the per-feature records of job j's left / right child (stale
   // records of a job that does not exist are merged too and ignored)
   int my_lf = -1;
-  const qr_split_t mine = wave_merge(0, wave, featrec, flocal, 0, 0, 0, F, &my_lf);
-  const float my_thr = my_lf >= 0 ? featthr[(size_t)wave * flocal + my_lf] : 0.f;
+  float my_thr = 0.f;
+  const qr_split_t mine = wave_merge(0, wave, featrec, flocal, 0, 0, 0, F, &my_lf, featthr, &my_thr);
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) sh_blk[b] = blocks[b];
   // ---- uses
   const int njobs = root_mode ? 0 : njobs_raw;  // the batch that has just been applied
@@ -1577,29 +1659,19 @@ __device__ __forceinline__ void batch_step(
     own_thr[wave] = my_thr;
   }
   if (wave < njobs && lane == 0) sh_prev[wave] = myln;
-  // sums of the directly built children: fixed-order reduction of the partition
-  // workgroups' partials, one wave per job
-  if (wave < njobs) {
-    const uint32_t nwg = (myln.end - myln.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
-    double a = 0.0, b = 0.0;
-    for (uint32_t i = lane; i < nwg; i += 64) {
-      a += part_ss[2 * (size_t)(myln.part_first + i)];
-      b += part_ss[2 * (size_t)(myln.part_first + i) + 1];
-    }
-    a = wave_sum(a);
-    b = wave_sum(b);
-    if (lane == 0) {
-      sh_ss[wave] = a;
-      sh_sum[wave] = b;
-    }
+  if (wave < njobs && lane == 0) {
+    sh_ss[wave] = js_ss;
+    sh_sum[wave] = js_sum;
   }
   __syncthreads();
+  QR_BT(1);
   if (threadIdx.x < 2 * njobs) {  // one lane per child of the batch just applied
     const int j = threadIdx.x >> 1, which = threadIdx.x & 1;
     batch_child_stats(staged ? sh_nodes : ts->nodes, sh_prev[j], which, own + 2 * j, sh_sum[j],
                       sh_ss[j], own_lf[2 * j + which], own_thr[2 * j + which]);
   }
   __syncthreads();
+  QR_BT(2);
   if (threadIdx.x == 0) {
     DecideState st;
     st.nleaves_req = h_nleaves_req;
@@ -1684,7 +1756,13 @@ __device__ __forceinline__ void batch_step(
     }
   }
   __syncthreads();
+  QR_BT(3);
   const int nj = sh_nj;
+#ifdef QR_STEP_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("batch_step wg0: loads %lld child stats %lld logic %lld (nj %d)\n", bt[1] - bt[0], bt[2] - bt[1],
+           bt[3] - bt[2], sh_nj);
+#endif
   if (!writer) return;  // (workgroup-uniform) the rest publishes the new state
   // the plans of the batch's nodes, one lane each
   if (lane == 0 && wave < nj) qr_make_plan(sh_next[wave].small_n, nblocks, sh_blk, sh_q, &sh_plan[wave]);
@@ -1755,7 +1833,7 @@ __device__ __forceinline__ void batch_step(
     const int j = (int)x / flocal, lf = (int)x - j * flocal;
     QrScanWg d;
     d.active = 0;
-    d.slot0 = d.total = d.per = d.n = d.col = d.pad = 0;
+    d.slot0 = d.total = d.per = d.n = d.col = d.part_first = d.part_nwg = d.pad = 0;
     d.kmax = 1;
     d.small_slot = d.big_slot = d.parent_slot = d.small_is_left = 0;
     if (j < nj) {
@@ -1775,6 +1853,8 @@ __device__ __forceinline__ void batch_step(
       d.parent_slot = ln.parent_slot;
       d.small_is_left = ln.small_is_left;
       d.col = (uint32_t)(lf - sh_blk[b].lf0);
+      d.part_first = ln.part_first;
+      d.part_nwg = (ln.end - ln.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
     }
     scan_wg[x] = d;
   }
@@ -2063,6 +2143,9 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
   __shared__ int sh_nj;
+#ifdef QR_STEP_TIMING
+  const long long tq0 = clock64();
+#endif
   // the LAST workgroup publishes: the grid is sized for the worst case plus one, so it
   // never has a slice to partition, and nobody's look-back chain waits for it
   batch_step<true, CAP>(tin, tout, tlog2, blockIdx.x == gridDim.x - 1, epoch, sh_next, sh_pw0, &sh_nj, &sh_epoch,
@@ -2071,6 +2154,11 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
                    scan_wg);
   __syncthreads();  // (the writer comes back later than the others; sh_* are final for all)
   const int nj = sh_nj;
+#ifdef QR_STEP_TIMING
+  const long long tq1 = clock64();
+  if (threadIdx.x == 0 && (blockIdx.x == gridDim.x - 1))
+    printf("decide_part writer: control+publish %lld cycles, nj %d part wgs %u\n", tq1 - tq0, nj, sh_pw0[nj]);
+#endif
   if (blockIdx.x >= sh_pw0[nj]) return;
   int j = 0;
   while (j + 1 < nj && blockIdx.x >= sh_pw0[j + 1]) ++j;
@@ -2087,6 +2175,11 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
   gl.thr_id = ln.thr_id;
   partition_body(pn, gl, blockIdx.x - sh_pw0[j], sh_pw0[j], (u64)sh_epoch, fm, Nfm, order0, order1,
                  nullptr, 0, state, lambda, part_ss_out);
+#ifdef QR_STEP_TIMING
+  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x + 1 == sh_pw0[nj]))
+    printf("decide_part wg %u of %u: control %lld partition %lld cycles (node n %u)\n", blockIdx.x, sh_pw0[nj],
+           tq1 - tq0, clock64() - tq1, pn.n);
+#endif
 }
 
 // ===========================================================================
@@ -2476,7 +2569,7 @@ __device__ __forceinline__ void obl_level_body(QrTreeState *__restrict__ ts, con
                                                const int flocal,
                                                const QrScalars *__restrict__ scal,
                                                uint32_t *pick, const qr_split_t *__restrict__ recs_all,
-                                               const int world) {
+                                               const int world, const u64 Nglobal) {
   const int lane = threadIdx.x;
   if (level == 0 && lane == 0) {
     QrNode *root = &ts->nodes[0];
@@ -2489,7 +2582,7 @@ __device__ __forceinline__ void obl_level_body(QrTreeState *__restrict__ ts, con
     root->threshold = 0.f;
     root->left = root->right = root->parent = -1;
     root->leaf_id = -1;
-    node_stats(root, scal->root_sum, scal->root_ss, N);
+    node_stats(root, scal->root_sum, scal->root_ss, Nglobal ? Nglobal : (u64)N);
     ts->nnodes = 1;
     ts->obl_done = 0;
     ts->nsplits = 0;
@@ -2534,14 +2627,18 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     uint32_t *__restrict__ hist_map, uint32_t *__restrict__ part_map, const uint32_t N,
     const qr_split_t *__restrict__ featrec, const QrScalars *__restrict__ scal,
     const uint32_t *__restrict__ woff, const size_t wcells, const qr_split_t *__restrict__ recs_all,
-    const int world, const uint32_t *__restrict__ lcounts) {
+    const int world, const uint32_t *__restrict__ lcounts, const uint32_t *__restrict__ hcnt_loc,
+    const u64 Nglobal) {
   // (woff != null: wide-bin context -- ragged rows, no histogram plan: k_wide.hip's
   // launches are sized on the host.  recs_all / lcounts != null: feature-sharded -- the level's
   // split is the best of the ranks' records, and the nodes' left counts came with the mask)
   __shared__ uint32_t sh_a[QR_MAXLEVEL], sh_b[QR_MAXLEVEL], sh_c[QR_MAXLEVEL];
   __shared__ uint32_t tot_small;
   __shared__ uint32_t pick[3];
-  if (threadIdx.x < 64) obl_level_body(ts, level, N, featrec, flocal, scal, pick, recs_all, world);
+  // (hcnt_loc != null: document-sharded -- hcnt holds the counts over ALL ranks' documents,
+  // which decide the split, the smaller side and the nodes' sizes; where the rank's own lists
+  // are cut is a matter of its own counts)
+  if (threadIdx.x < 64) obl_level_body(ts, level, N, featrec, flocal, scal, pick, recs_all, world, Nglobal);
   __syncthreads();
   if (pick[0]) return;
   const int nodes = 1 << level;
@@ -2560,22 +2657,23 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     const int lfc = lf >= 0 ? lf : 0;
     const size_t base = woff ? (size_t)nd->hslot * wcells + woff[lfc] : ((size_t)nd->hslot * flocal + lfc) * 256;
     const uint32_t lastt = woff ? woff[lfc + 1] - woff[lfc] - 1 : 255u;
-    const uint32_t lcount = lcounts ? lcounts[j] : hcnt[base + t];
-    const uint32_t rcount = hcnt[base + lastt] - lcount;
+    const uint32_t lcount_all = lcounts ? lcounts[j] : hcnt[base + t];
+    const uint32_t rcount_all = hcnt[base + lastt] - lcount_all;
+    const uint32_t lcount = hcnt_loc ? hcnt_loc[base + t] : lcount_all;  // of the rank's own list
     const int li = 2 * node + 1, ri = 2 * node + 2;
+    nseg = nd->end - nd->begin;
     ln.active = 1;
     ln.begin = nd->begin;
     ln.end = nd->end;
     ln.src_buf = nd->buf;
     ln.dst_buf = nd->buf == 0 ? 1 : 0;
     ln.lcount = lcount;
-    ln.small_is_left = lcount <= rcount;
+    ln.small_is_left = lcount_all <= rcount_all;
     ln.parent_slot = nd->hslot;
     ln.small_slot = ln.small_is_left ? li : ri;
     ln.big_slot = ln.small_is_left ? ri : li;
     ln.small_begin = ln.small_is_left ? nd->begin : nd->begin + lcount;
-    ln.small_n = ln.small_is_left ? lcount : rcount;
-    nseg = nd->end - nd->begin;
+    ln.small_n = ln.small_is_left ? lcount : nseg - lcount;
     nd->feature = (int32_t)f;
     nd->thr_id = (int32_t)t;
     nd->threshold = thr[(woff ? (size_t)woff[f] : (size_t)f * QR_MAX_BINS) + t];
@@ -2595,8 +2693,8 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     L->left = L->right = R->left = R->right = -1;
     L->parent = R->parent = node;
     L->leaf_id = R->leaf_id = -1;
-    L->count = lcount;
-    R->count = rcount;
+    L->count = lcount_all;
+    R->count = rcount_all;
     L->sum = R->sum = L->ss = R->ss = L->deviance = R->deviance = 0.0;
     L->value = R->value = 0.0;  // overwritten by update_output (ot.cc:141-149)
   }
@@ -2808,7 +2906,8 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
     hipLaunchKernelGGL(k_redscan, dim3(c->flocal, 1), dim3(1024), 0, c->stream, c->d_tree, 1, rootn,
                        c->d_lplan, c->d_blocks, c->nblocks, G, (const u64 *)c->d_partials, c->d_hsum,
                        c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec,
-                       c->d_thr, c->d_featthr, (const QrScanWg *)nullptr, (u64)c->cur_minls);
+                       c->d_thr, c->d_featthr, (const QrScanWg *)nullptr, (u64)c->cur_minls,
+                       (const double *)nullptr, (double *)nullptr);
     QR_CHECK(c, hipGetLastError());
     return QR_OK;
   }
@@ -2916,7 +3015,8 @@ int qr_k_tree_apply(qr_ctx *c) {
 // enqueued at once; steps the tree does not need leave at once.
 // the launches of one growth step behind its control call: the batch's child histograms,
 // then reduce + scan
-static int launch_batch_hist_scan(qr_ctx *c, const unsigned hg, const uint32_t rootn, const uint64_t minls) {
+static int launch_batch_hist_scan(qr_ctx *c, const unsigned hg, const uint32_t rootn, const uint64_t minls,
+                                  const double *pss) {
   const size_t lds = hist_lds(c);
   if (c->prof_on && c->prof_child) {  // bench.py's roofline_child_hist: events on the launch itself
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -2934,7 +3034,7 @@ static int launch_batch_hist_scan(qr_ctx *c, const unsigned hg, const uint32_t r
   hipLaunchKernelGGL(k_redscan, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_tree, 0,
                      rootn, c->d_lplan, c->d_blocks, c->nblocks, c->ncu, (const u64 *)c->d_lpartials,
                      c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars,
-                     c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg, (u64)minls);
+                     c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg, (u64)minls, pss, c->d_jobsum);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -2968,7 +3068,7 @@ static int launch_decide_batch(qr_ctx *c, const BatchGeom &g, size_t nleaves, ui
                                int final_call) {
   hipLaunchKernelGGL(g.small ? k_decide_batch<QR_BATCH_LDS_SMALL> : k_decide_batch<QR_BATCH_LDS_LARGE>,
                      dim3(1), dim3(128 * QR_BATCH), 0, c->stream, tout, root, (int)nleaves, (u64)minls,
-                     g.stage_nodes, g.rootn, c->flocal, c->d_scalars, pss_in, c->d_featrec, c->d_featthr,
+                     g.stage_nodes, g.rootn, c->flocal, c->d_scalars, c->d_jobsum, c->d_featrec, c->d_featthr,
                      (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, g.hg,
                      c->d_lpart_wg, g.pg, c->d_lplan, c->d_lscan_wg, tin, final_call);
   QR_CHECK(c, hipGetLastError());
@@ -3021,13 +3121,13 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
                          dim3(g.pg), dim3(128 * QR_BATCH), 0, c->stream,
                          (const QrTreeState *)tin, tout, T[(steps + 1 - s) & 1], ++c->bepoch,
                          s == 0 ? 1 : 0, (int)nleaves, (u64)minls, g.stage_nodes, g.rootn, c->flocal,
-                         c->d_scalars, pss_in, c->d_featrec, c->d_featthr, (uint32_t)c->F,
+                         c->d_scalars, c->d_jobsum, c->d_featrec, c->d_featthr, (uint32_t)c->F,
                          c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, g.hg,
                          c->d_lplan, c->d_lscan_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0],
                          c->d_order[1], (u64 *)c->d_bpart_state, c->d_lambda, PSS[s & 1]);
       QR_CHECK(c, hipGetLastError());
     }
-    if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls))) return rc;
+    if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls, g.fused ? PSS[s & 1] : c->d_lpart_ss))) return rc;
   }
   return QR_OK;
 }
@@ -3045,7 +3145,7 @@ int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_d
                        c->d_lpart_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
                        (u64 *)c->d_bpart_state, c->d_lambda, c->d_lpart_ss, ++c->bepoch);
     QR_CHECK(c, hipGetLastError());
-    if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls))) return rc;
+    if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls, c->d_lpart_ss))) return rc;
     if ((rc = launch_decide_batch(c, g, nleaves, minls, 0, c->d_tree, (const QrTreeState *)nullptr,
                                   c->d_lpart_ss, r + 1 == left ? 1 : 0)))
       return rc;
@@ -3080,7 +3180,8 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
                        c->ncu, c->flocal, c->d_hcnt, c->wide ? c->d_wthr : c->d_thr, c->d_gf2lf,
                        c->d_blocks, c->nblocks, c->d_lhist_map, c->d_lpart_map, (uint32_t)c->N,
                        c->d_featrec, c->d_scalars, c->wide ? c->d_woff : (const uint32_t *)nullptr,
-                       c->wcells, (const qr_split_t *)nullptr, 1, (const uint32_t *)nullptr);
+                       c->wcells, (const qr_split_t *)nullptr, 1, (const uint32_t *)nullptr,
+                       (const uint32_t *)nullptr, (u64)0);
     QR_CHECK(c, hipGetLastError());
     const unsigned pg = std::min<unsigned>(pgrid, (unsigned)(c->N / QR_PART_SLICE + nodes + 1));
     hipLaunchKernelGGL(k_partition_level, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
@@ -3103,7 +3204,7 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
     QR_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(k_redscan_level, dim3(c->flocal, (unsigned)nodes), dim3(1024), 0, c->stream,
                        c->d_tree, c->d_blocks, c->nblocks, (const u64 *)c->d_lpartials, c->d_hsum,
-                       c->d_hcnt, c->flocal);
+                       c->d_hcnt, c->flocal, (long long *)nullptr, (uint32_t *)nullptr);
     QR_CHECK(c, hipGetLastError());
   }
   return QR_OK;
@@ -3120,9 +3221,23 @@ int qr_k_obl_begin(qr_ctx *c, size_t depth, uint64_t minls) {
 }
 
 int qr_k_obl_propose(qr_ctx *c, int level) {
+  if (c->dmode) {
+    // the exchange that precedes this call has summed the ranks' cells: the root's through
+    // the leaf-wise path's buffer (k_scan takes the prefix), a level's children through the
+    // level buffer
+    if (level == 0) {
+      const int rc = launch_scan(c, 1);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(k_level_finish_doc, dim3(c->flocal, 1u << (level - 1)), dim3(256), 0, c->stream,
+                         c->d_tree, c->d_xlevel, c->d_hsum, c->d_hcnt, c->flocal);
+      QR_CHECK(c, hipGetLastError());
+    }
+  }
   hipLaunchKernelGGL(k_obl_fill, dim3(c->flocal), dim3(256), 0, c->stream, c->d_tree, level, c->d_hsum,
                      c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec);
   QR_CHECK(c, hipGetLastError());
+  if (c->dmode) return QR_OK;  // every rank holds every feature of the summed histograms: no records to exchange
   hipLaunchKernelGGL(k_obl_propose, dim3(1), dim3(64), 0, c->stream, c->d_tree, level, c->d_featrec,
                      c->flocal, c->d_recs_local);
   QR_CHECK(c, hipGetLastError());
@@ -3143,12 +3258,14 @@ int qr_k_obl_apply(qr_ctx *c, int level, int last) {
   hipLaunchKernelGGL(k_obl_plan, dim3(1), dim3(256), 0, c->stream, c->d_tree, level, last, c->ncu,
                      c->flocal, c->d_hcnt, c->d_thr, c->d_gf2lf, c->d_blocks, c->nblocks, c->d_lhist_map,
                      c->d_lpart_map, (uint32_t)c->N, c->d_featrec, c->d_scalars, (const uint32_t *)nullptr,
-                     (size_t)0, c->d_recs_all, c->world, c->d_mask + c->mask_words);
+                     (size_t)0, c->dmode ? (const qr_split_t *)nullptr : c->d_recs_all, c->dmode ? 1 : c->world,
+                     c->dmode ? (const uint32_t *)nullptr : c->d_mask + c->mask_words,
+                     c->dmode ? c->d_hcnt_loc : (const uint32_t *)nullptr, c->dmode ? (u64)c->Nglobal : (u64)0);
   QR_CHECK(c, hipGetLastError());
   const unsigned pg = std::min<unsigned>((unsigned)c->lpart_cap, (unsigned)(c->N / QR_PART_SLICE + nodes + 1));
   hipLaunchKernelGGL(k_partition_level, dim3(pg), dim3(256), 0, c->stream, c->d_tree, c->d_lpart_map,
                      c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1], (u64 *)c->d_lpart_state, 0,
-                     c->d_mask);
+                     c->dmode ? (const uint32_t *)nullptr : c->d_mask);
   QR_CHECK(c, hipGetLastError());
   if (last) return QR_OK;  // ot.cc:127: no histograms for the leaves
   const unsigned hg = std::min<unsigned>((unsigned)c->lhist_cap,
@@ -3158,7 +3275,9 @@ int qr_k_obl_apply(qr_ctx *c, int level, int last) {
                      c->d_scalars, (u64 *)c->d_lpartials);
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_redscan_level, dim3(c->flocal, (unsigned)nodes), dim3(1024), 0, c->stream, c->d_tree,
-                     c->d_blocks, c->nblocks, (const u64 *)c->d_lpartials, c->d_hsum, c->d_hcnt, c->flocal);
+                     c->d_blocks, c->nblocks, (const u64 *)c->d_lpartials, c->d_hsum, c->d_hcnt, c->flocal,
+                     c->dmode ? c->d_xlevel : (long long *)nullptr,
+                     c->dmode ? c->d_hcnt_loc : (uint32_t *)nullptr);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

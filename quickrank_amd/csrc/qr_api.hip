@@ -95,12 +95,12 @@ static void free_train(qr_ctx *c) {
     c->d_red_sum = nullptr;
     c->d_red_cnt = nullptr;
   }
-  dfree(c->d_xh); dfree(c->d_xscal); dfree(c->d_xleaf);
+  dfree(c->d_xh); dfree(c->d_xscal); dfree(c->d_xleaf); dfree(c->d_xlevel);
   c->xleaf_cap = 0;
   dfree(c->d_red_sum); dfree(c->d_red_cnt);
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec); dfree(c->d_featthr); dfree(c->d_lscan_wg);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
-  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_lpart_ss2); dfree(c->d_bpart_state); dfree(c->d_tree); dfree(c->d_tree2); dfree(c->d_leafpart);
+  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_lpart_ss2); dfree(c->d_jobsum); dfree(c->d_bpart_state); dfree(c->d_tree); dfree(c->d_tree2); dfree(c->d_leafpart);
   dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
   dfree(c->d_lpart_state);
   dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
@@ -540,6 +540,7 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, hipMemset(c->d_lscan_wg, 0, QR_BATCH * (size_t)c->flocal * sizeof(QrScanWg)));
   QR_CHECK(c, dalloc(&c->d_lpart_ss, 2 * (N / QR_PART_SLICE + QR_BATCH + 2)));
   QR_CHECK(c, dalloc(&c->d_lpart_ss2, 2 * (N / QR_PART_SLICE + QR_BATCH + 2)));
+  QR_CHECK(c, dalloc(&c->d_jobsum, 2 * QR_BATCH));
   QR_CHECK(c, dalloc(&c->d_bpart_state, N / QR_PART_SLICE + QR_BATCH + 2));
   QR_CHECK(c, hipMemset(c->d_bpart_state, 0, (N / QR_PART_SLICE + QR_BATCH + 2) * 8));
   c->bepoch = 0;
@@ -1188,8 +1189,8 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
   { const int src_ = tree_settle(c); if (src_) return src_; }
   if (c->world > 1 || c->dmode)
     QR_FAIL(c, QR_ERR_STATE,
-            "sharded contexts grow oblivious trees phase by phase (feature-sharded: qr_obl_begin / "
-            "propose / mark / apply with the collectives in between; document-sharded: not built)");
+            "sharded contexts grow oblivious trees phase by phase (qr_obl_begin / propose / [mark] / "
+            "apply with the collectives in between)");
   if (c->sub_k) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling applies to leaf-wise trees in this round");
   if (depth < 1 || ((size_t)1 << (depth + 1)) - 1 > QR_MAXNODES)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
@@ -1207,7 +1208,6 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
 int qr_obl_begin(qr_ctx *c, size_t depth, uint64_t minls) {
   if (!c) return QR_ERR_ARG;
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
-  if (c->dmode) QR_FAIL(c, QR_ERR_UNSUPPORTED, "oblivious trees: single-GPU and feature-sharded contexts only");
   if (c->wide) QR_FAIL(c, QR_ERR_UNSUPPORTED, "the phase calls use u8 bins");
   if (c->sub_k) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling applies to leaf-wise trees in this round");
   if (depth < 1 || ((size_t)1 << (depth + 1)) - 1 > QR_MAXNODES)
@@ -1220,6 +1220,27 @@ int qr_obl_begin(qr_ctx *c, size_t depth, uint64_t minls) {
   c->tree_open = true;
   c->cur_depth = depth;
   c->cur_maxnodes = ((size_t)1 << (depth + 1)) - 1;
+  if (c->dmode) {
+    // document-sharded: the level's exchange buffer ([node][feature][slot][sum, count] for the
+    // widest level that builds histograms) and the leaves' (as qr_tree_begin)
+    const size_t nodes = depth >= 2 ? (size_t)1 << (depth - 2) : 1;
+    const size_t need = nodes * (size_t)c->flocal * 256 * 2;
+    const size_t leaves = (size_t)1 << depth;
+    if (need > c->xlevel_cap || 2 * leaves * (size_t)c->world > c->xleaf_cap) QR_CHECK(c, hipStreamSynchronize(c->stream));
+    if (need > c->xlevel_cap) {
+      dfree(c->d_xlevel);
+      QR_CHECK(c, dalloc(&c->d_xlevel, need));
+      QR_CHECK(c, hipMemset(c->d_xlevel, 0, need * 8));
+      c->xlevel_cap = need;
+    }
+    if (2 * leaves * (size_t)c->world > c->xleaf_cap) {
+      dfree(c->d_xleaf);
+      c->xleaf_cap = 2 * leaves * (size_t)c->world;
+      QR_CHECK(c, dalloc(&c->d_xleaf, c->xleaf_cap));
+      QR_CHECK(c, hipMemset(c->d_xleaf, 0, c->xleaf_cap * 8));
+    }
+    c->cur_nleaves = leaves;
+  }
   return qr_k_obl_begin(c, depth, minls);
 }
 int qr_obl_propose(qr_ctx *c, size_t level) {
@@ -1228,11 +1249,19 @@ int qr_obl_propose(qr_ctx *c, size_t level) {
 }
 int qr_obl_mark(qr_ctx *c, size_t level) {
   if (!c || !c->tree_open || level >= c->cur_depth) return QR_ERR_STATE;
+  if (c->dmode) QR_FAIL(c, QR_ERR_STATE, "document-sharded ranks partition their own documents: no mask to exchange");
   return qr_k_obl_mark(c, (int)level);
 }
 int qr_obl_apply(qr_ctx *c, size_t level) {
   if (!c || !c->tree_open || level >= c->cur_depth) return QR_ERR_STATE;
   return qr_k_obl_apply(c, (int)level, level + 1 == c->cur_depth);
+}
+int qr_obl_level_exchange(qr_ctx *c, size_t level, void **cells, size_t *cells_i64) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->dmode || !c->d_xlevel) QR_FAIL(c, QR_ERR_STATE, "qr_obl_level_exchange follows qr_obl_begin on a document-sharded context");
+  if (cells) *cells = c->d_xlevel;
+  if (cells_i64) *cells_i64 = ((size_t)1 << level) * (size_t)c->flocal * 256 * 2;
+  return QR_OK;
 }
 int qr_obl_exchange_buffers(qr_ctx *c, void **recs_local, void **recs_all, size_t *rec_bytes_per_rank,
                             void **mask, size_t *mask_bytes) {

@@ -187,6 +187,7 @@ struct QrScanWg {      // one (node of the batch, feature) workgroup of k_redsca
   int32_t kmax;
   int32_t small_slot, big_slot, parent_slot, small_is_left;
   uint32_t col;        // column of the feature inside its block
+  uint32_t part_first, part_nwg;  // the node's partition workgroups (their child sums: feature 0 adds them up)
   uint32_t pad;
 };
 
@@ -269,6 +270,8 @@ struct qr_ctx {
   size_t xh_len = 0, xh_cells = 0;
   long long *d_xscal = nullptr;  // [world][4] f64 bits: maxabs, root_ss, root_sum, metric_sum
   long long *d_xleaf = nullptr;  // [world][2*nleaves] f64 bits: per-leaf (sum lambda, sum weight)
+  long long *d_xlevel = nullptr;  // document-sharded level-wise growth: [node][feature][slot][sum, count] of a level
+  size_t xlevel_cap = 0;
   size_t xleaf_cap = 0;
   int ncu = 256;
   // training data
@@ -370,6 +373,7 @@ struct qr_ctx {
   uint64_t cur_minls = 1;             // min leaf support of the tree being fitted (batched growth)
   double *d_lpart_ss = nullptr;       // batched growth: child sums per partition workgroup
   double *d_lpart_ss2 = nullptr;      // ... second copy (k_decide_part reads one, writes the other)
+  double *d_jobsum = nullptr;         // [QR_BATCH][ss, sum] of the batch's directly built children (k_redscan adds the partials up)
   QrTreeState *d_tree2 = nullptr;     // ... second copy of the tree state (same reason)
   unsigned long long *d_bpart_state = nullptr;  // ... look-back granules of k_decide_part
   uint32_t bepoch = 0;                // ... their epoch, counted on the host

@@ -272,13 +272,35 @@ class DocShardedTrainer:
         ctx.tree_decide()
         ctx.tree_end_local(newton)
         b = ctx.doc_exchange_buffers()
-        if self.leaf is None or self.leaf_n != b["leaf_n"]:
+        if self.leaf is None or self._ptr.get("leaf") != (b["leaf"], b["leaf_n"]):
             self.leaf = self._view(b["leaf"], b["leaf_n"], "leaf")
             self.leaf_n = b["leaf_n"]
             self._ptr["leaf"] = (b["leaf"], b["leaf_n"])
         self._sum(self.leaf, "leaf")
         return ctx.tree_leaves_finish(nleaves, newton, read=read)
 
+
+    def fit_oblivious(self, depth, minls, newton, read=True):
+        """ObliviousRT::fit (ot.cc:32-201) over document shards: ONE int64 all-reduce per
+        level -- the cells of all its directly built children -- after the root's."""
+        ctx = self.ctx
+        ctx.obl_begin(depth, minls)
+        self._sum(self.hist, "hist")
+        for level in range(depth):
+            ctx.obl_propose(level)
+            ctx.obl_apply(level)
+            if level + 1 < depth:           # ot.cc:127: no histograms for the leaves
+                ptr, n = ctx.obl_level_exchange(level)
+                self._ptr["level"] = (ptr, n)
+                self._sum(self._view(ptr, n, "level"), "level")
+        ctx.tree_end_local(newton)
+        b = ctx.doc_exchange_buffers()
+        if self.leaf is None or self._ptr.get("leaf") != (b["leaf"], b["leaf_n"]):
+            self.leaf = self._view(b["leaf"], b["leaf_n"], "leaf")
+            self.leaf_n = b["leaf_n"]
+            self._ptr["leaf"] = (b["leaf"], b["leaf_n"])
+        self._sum(self.leaf, "leaf")
+        return ctx.tree_leaves_finish((1 << depth), newton, read=read)
 
     def metric_eval(self, which=0, metric="NDCG", cutoff=10):
         """Metric::evaluate_dataset (metric.h:77-106) over ALL ranks' queries of the

@@ -119,9 +119,9 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
                        const std::string &metric, size_t cutoff, size_t partial_save,
                        const std::string &output_basename, int ngpus, bool feature_sharded) {
   const bool obliv = algo_ >= OBVMART;
-  if ((obliv || subsample_ != 1.0f) && !feature_sharded) {
-    std::cerr << "!!! --gpus with oblivious trees or --subsample needs --shard features (every rank then "
-                 "holds every document)." << std::endl;
+  if (subsample_ != 1.0f && !feature_sharded) {
+    std::cerr << "!!! --gpus with --subsample needs --shard features (every rank then holds every document)."
+              << std::endl;
     exit(EXIT_FAILURE);
   }
   if (max_features_ != 1.0f || ensemble_model_.is_notempty() || nthresholds_ > 255 || nthresholds_ == 0 ||
@@ -300,7 +300,24 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       }
       // ---- tree
       size_t nn = 0;
-      if (obliv) {  // ot.cc:32-201, level by level (feature-sharded)
+      if (obliv && !feature_sharded) {  // ot.cc:32-201 over document shards: one exchange per level
+        QRM(c, qr_obl_begin(c, treedepth_, minleafsupport_));
+        sum64(x_hist, n_hist);
+        for (size_t level = 0; level < treedepth_; ++level) {
+          QRM(c, qr_obl_propose(c, level));
+          QRM(c, qr_obl_apply(c, level));
+          if (level + 1 < treedepth_) {  // ot.cc:127: no histograms for the leaves
+            void *x_level = nullptr;
+            size_t n_level = 0;
+            QRM(c, qr_obl_level_exchange(c, level, &x_level, &n_level));
+            sum64(x_level, n_level);
+          }
+        }
+        QRM(c, qr_tree_end(c, lambda, nullptr, nullptr));
+        QRM(c, qr_doc_exchange_buffers(c, nullptr, nullptr, nullptr, nullptr, &x_leaf, &n_leaf));
+        sum64(x_leaf, n_leaf);
+        QRM(c, qr_tree_leaves_finish(c, lambda, nodes.data(), &nn));
+      } else if (obliv) {  // level by level, feature-sharded
         QRM(c, qr_obl_begin(c, treedepth_, minleafsupport_));
         for (size_t level = 0; level < treedepth_; ++level) {
           QRM(c, qr_obl_propose(c, level));

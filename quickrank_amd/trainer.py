@@ -77,7 +77,7 @@ class Mart:
 
     def _fit_tree(self, newton):
         if self.oblivious:
-            if self.dist is not None:     # feature-sharded ranks (ShardedTreeFitter)
+            if self.dist is not None:     # sharded ranks: level by level with the collectives in between
                 return self.dist.fit_oblivious(self.ctx, self.depth, self.minls, newton)
             return self.ctx.fit_oblivious(self.depth, self.minls, newton)
         if self.dist is not None:

@@ -365,9 +365,10 @@ def test_quicklearn_gpus_flag_runs_the_sharded_protocol(tools, tmp_path, algo, s
 @pytest.mark.parametrize("extra", [["--algo", "OBVLAMBDAMART", "--tree-depth", "4"],
                                    ["--algo", "LAMBDAMART", "--num-leaves", "8", "--subsample", "0.5", "--seed", "5"]])
 def test_quicklearn_gpus_features_oblivious_and_subsample(tools, tmp_path, extra):
-    """Oblivious trees and --subsample on the multi-GPU host run in the feature layout
+    """Oblivious trees and --subsample on the multi-GPU host in the feature layout
     (`--shard features`: every rank holds every document); with one rank the model must be
-    the single-GPU one.  The document layout refuses both with a message."""
+    the single-GPU one.  The document layout grows oblivious trees too (one exchange per
+    level) and refuses --subsample with a message."""
     x, labels, qoff = make_dataset(nq=120, docs_per_query=40, F=30, seed=73)
     tr = str(tmp_path / "train.svml")
     _write_svml(tr, x, labels, qoff)
@@ -385,6 +386,16 @@ def test_quicklearn_gpus_features_oblivious_and_subsample(tools, tmp_path, extra
         assert np.array_equal(n1[k], n2[k]), k
     assert np.array_equal(n1["threshold"].view(np.uint32), n2["threshold"].view(np.uint32))
     assert np.allclose(n1["value"], n2["value"], rtol=1e-9, atol=1e-12)
-    r = subprocess.run([tools["quicklearn"]] + base + ["--gpus", "1", "--shard", "docs"], capture_output=True,
-                       text=True, timeout=300)
-    assert r.returncode != 0 and "--shard features" in r.stderr
+    m3 = str(tmp_path / "docs.xml")
+    r = subprocess.run([tools["quicklearn"]] + base + ["--model-out", m3, "--gpus", "1", "--shard", "docs"],
+                       capture_output=True, text=True, timeout=300)
+    if "--subsample" in extra:
+        assert r.returncode != 0 and "--shard features" in r.stderr
+        return
+    assert r.returncode == 0, r.stdout + r.stderr
+    n3, w3 = _load_model(tools, m3)
+    assert n1.shape == n3.shape and np.array_equal(w1, w3)
+    for k in ("feature", "left", "right"):
+        assert np.array_equal(n1[k], n3[k]), k
+    assert np.array_equal(n1["threshold"].view(np.uint32), n3["threshold"].view(np.uint32))
+    assert np.allclose(n1["value"], n3["value"], rtol=1e-9, atol=1e-12)

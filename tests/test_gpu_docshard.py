@@ -48,6 +48,18 @@ class _Emu:
         self.sync()
 
 
+    def allreduce_raw(self, bufs):
+        """bufs: one (device pointer, int64 count) per context"""
+        self.sync()
+        views = [self.torch.as_tensor(self.DevArray(p, n * 8, "<i8", 8), device=self.dev) for p, n in bufs]
+        tot = views[0].clone()
+        for v in views[1:]:
+            tot += v
+        for v in views:
+            v.copy_(tot)
+        self.sync()
+
+
 def _make_ctxs(qr, x, labels, qoff, parts, nthr):
     from quickrank_amd._capi import thresholds_from_stats
     world = len(parts)
@@ -141,6 +153,78 @@ def test_doc_sharded_training_equals_single(world, cuts, nthr, F):
     single.close()
 
 
+def _doc_obl_fit(emu, ctxs, depth, minls, newton):
+    for c in ctxs:
+        c.obl_begin(depth, minls)
+    emu.allreduce("hist")
+    for level in range(depth):
+        for c in ctxs:
+            c.obl_propose(level)
+            c.obl_apply(level)
+        if level + 1 < depth:
+            emu.allreduce_raw([c.obl_level_exchange(level) for c in ctxs])
+    for c in ctxs:
+        c.tree_end_local(newton)
+    emu.allreduce("leaf")
+    return [c.tree_leaves_finish(1 << depth, newton) for c in ctxs]
+
+
+@pytest.mark.parametrize("world,cuts,depth,minls,F,algo", [
+    (2, [30], 4, 1, 136, "lambda"),
+    (3, [5, 41], 6, 2, 70, "lambda"),      # a small first shard, nodes that run empty on a rank
+    (4, [15, 30, 45], 3, 1, 20, "mart"),
+    (8, [7, 14, 22, 30, 38, 45, 52], 5, 1, 136, "lambda"),
+    (2, [30], 1, 1, 40, "lambda"),         # depth 1: no level exchange at all
+])
+def test_doc_sharded_oblivious_equals_single(world, cuts, depth, minls, F, algo):
+    """ObliviousRT::fit (ot.cc:32-201) over document shards: one exchange per level; the
+    tree's structure is the single-context tree bit for bit, leaf values to f64 rounding."""
+    import torch
+    import quickrank_amd as qr
+    from quickrank_amd import build
+    build.build()
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=50, F=F, seed=29, adversarial=True)
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(255)
+    single.reset_scores()
+    parts = _split_queries(qoff, cuts)
+    ctxs, thr, ts = _make_ctxs(qr, x, labels, qoff, parts, 255)
+    emu = _Emu(torch, ctxs)
+    for c in ctxs:
+        c.reset_scores()
+    newton = algo == "lambda"
+    for it in range(4):
+        if newton:
+            single.compute_lambdas("NDCG", 10)
+        else:
+            single.compute_residuals()
+        want = single.fit_oblivious(depth, minls, newton)
+        single.update_scores(0.1)
+        for c in ctxs:
+            c.compute_lambdas("NDCG", 10) if newton else c.compute_residuals()
+        emu.allreduce("scal")
+        for c in ctxs:
+            c.lambda_finish()
+        got = _doc_obl_fit(emu, ctxs, depth, minls, newton)
+        for c in ctxs:
+            c.update_scores(0.1)
+        for g in got:
+            assert len(g) == len(want), it
+            for k in ("feature", "thr_id", "left", "right", "nsamples", "threshold"):
+                assert np.array_equal(g[k], want[k]), (it, k)
+            assert np.allclose(g["value"], want["value"], rtol=1e-11, atol=1e-14), it
+        for g in got[1:]:
+            for k in want.dtype.names:
+                assert np.array_equal(g[k], got[0][k]), (it, k)
+    s1 = single.get_scores()
+    for c, (q0, q1) in zip(ctxs, parts):
+        d0, d1 = int(qoff[q0]), int(qoff[q1])
+        assert np.allclose(c.get_scores(), s1[d0:d1], rtol=1e-10, atol=1e-13)
+        c.close()
+    single.close()
+
+
 def test_doc_sharded_mart_residuals():
     """MART (mean leaves, residual pseudo-responses) through the same protocol."""
     import torch
@@ -212,6 +296,15 @@ def test_doc_sharded_trainer_over_rccl_world1():
             for k in want.dtype.names:
                 assert np.array_equal(got[k], want[k]), (it, k)
             assert c.metric_last() == ref.metric_last()
+        for it in range(2):                       # oblivious trees through the same trainer
+            ref.compute_lambdas("NDCG", 10)
+            want = ref.fit_oblivious(4, 1, True)
+            ref.update_scores(0.1)
+            tr.compute_lambdas("NDCG", 10)
+            got = tr.fit_oblivious(4, 1, True)
+            c.update_scores(0.1)
+            for k in want.dtype.names:
+                assert np.array_equal(got[k], want[k]), (it, k)
         assert np.array_equal(c.get_scores(), ref.get_scores())
         c.close()
     finally:

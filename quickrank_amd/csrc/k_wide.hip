@@ -22,13 +22,14 @@
 //   k_wscan      per feature: prefix over the slots in chunks of 1024 with a carry,
 //                sibling = parent - child on the cumulative arrays
 //                (rtnode_histogram.cc:72-87, 206-217), gain of every slot and the first
-//                maximum (rt.cc:257-292) -- the records k_decide merges
+//                maximum (rt.cc:257-292) -- the records k_decide merges; rows longer than
+//                QR_WCHUNK slots are scanned in chunks (k_wscan_tot / _chunk / _best)
 //   k_wobl_*     the same for level-wise (oblivious) growth, ot.cc:32-201
 // Growth itself -- k_decide, k_partition, k_finish, the leaf and score kernels -- is
 // k_tree.hip's one-split-per-step path, reading u32 bins and ragged thresholds.
 // Single GPU.  The u8 path keeps its kernels and its speed; this one is the general
 // one: on a 713k-document set 1.9x the u8 path's time per iteration at 1024 slots per
-// feature, 55x with every distinct value a threshold (67 M cells per node histogram).
+// feature, 28x with every distinct value a threshold (67 M cells per node histogram).
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -412,6 +413,219 @@ __global__ __launch_bounds__(1024) void k_wscan(
   }
 }
 
+// ---- the same scan for long rows, in chunks --------------------------------------------
+// A row of 10^5 - 10^6 slots (--num-thresholds 0 on a real-valued column) scanned by ONE
+// workgroup leaves the launch with as many busy CUs as there are long rows.  The chunked
+// scan cuts every row into pieces of QR_WCHUNK slots (table built once with the bins):
+//   k_wscan_tot    per chunk: total of its raw cells
+//   k_wscan_chunk  per chunk: carry-in = the totals of the row's earlier chunks, prefix,
+//                  sibling, gains with the row totals (= all of the row's chunk totals),
+//                  the chunk's best slot of each child
+//   k_wscan_best   per feature: first maximum over the row's chunks -> featrec
+// Exact integers and the first maximum in slot order: the same records as k_wscan.
+struct WChunk {
+  uint32_t lf, t0;
+};
+
+__device__ __forceinline__ void w_scan_setup(const QrTreeState *ts, const int mode, int &small_slot,
+                                             int &big_slot, int &parent_slot, int &small_is_left,
+                                             bool &active) {
+  small_slot = 0;
+  big_slot = parent_slot = -1;
+  small_is_left = 1;
+  active = true;
+  if (mode == 1) {
+    active = ts->desc.active != 0;
+    small_slot = ts->desc.small_slot;
+    big_slot = ts->desc.big_slot;
+    parent_slot = ts->desc.parent_slot;
+    small_is_left = ts->desc.small_is_left;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_wscan_tot(
+    const QrTreeState *__restrict__ ts, const int mode, const WChunk *__restrict__ chunks,
+    const uint32_t *__restrict__ woff, const size_t cells, const long long *__restrict__ hsum,
+    const uint32_t *__restrict__ hcnt, long long *__restrict__ tot_s, uint32_t *__restrict__ tot_c) {
+  __shared__ long long sh_s[16];
+  __shared__ uint32_t sh_c[16];
+  int small_slot, big_slot, parent_slot, small_is_left;
+  bool active;
+  w_scan_setup(ts, mode, small_slot, big_slot, parent_slot, small_is_left, active);
+  if (!active) return;
+  const WChunk ch = chunks[blockIdx.x];
+  const uint32_t base = woff[ch.lf], size = woff[ch.lf + 1] - base;
+  const uint32_t t1 = ch.t0 + QR_WCHUNK < size ? ch.t0 + QR_WCHUNK : size;
+  const long long *ss = hsum + (size_t)small_slot * cells + base;
+  const uint32_t *sc = hcnt + (size_t)small_slot * cells + base;
+  long long s = 0;
+  uint32_t cn = 0;
+  for (uint32_t t = ch.t0 + threadIdx.x; t < t1; t += 1024) {
+    s += ss[t];
+    cn += sc[t];
+  }
+  s = wave_scan_i64(s);   // (lane 63 holds the wave's sum)
+  cn = wave_scan_u32(cn);
+  if ((threadIdx.x & 63) == 63) {
+    sh_s[threadIdx.x >> 6] = s;
+    sh_c[threadIdx.x >> 6] = cn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long a = 0;
+    uint32_t b = 0;
+    for (int w = 0; w < 16; ++w) {
+      a += sh_s[w];
+      b += sh_c[w];
+    }
+    tot_s[blockIdx.x] = a;
+    tot_c[blockIdx.x] = b;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_wscan_chunk(
+    const QrTreeState *__restrict__ ts, const int mode, const WChunk *__restrict__ chunks,
+    const uint32_t *__restrict__ chunk0, const uint32_t *__restrict__ woff, const size_t cells,
+    long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const long long *__restrict__ tot_s,
+    const uint32_t *__restrict__ tot_c, const QrScalars *__restrict__ scal, Best *__restrict__ cbest) {
+  __shared__ long long sh_s[16];
+  __shared__ uint32_t sh_c[16];
+  __shared__ Best sh_b[16];
+  __shared__ long long row_s[2];
+  __shared__ uint32_t row_c[2];
+  int small_slot, big_slot, parent_slot, small_is_left;
+  bool active;
+  w_scan_setup(ts, mode, small_slot, big_slot, parent_slot, small_is_left, active);
+  if (!active) return;
+  const WChunk ch = chunks[blockIdx.x];
+  const uint32_t base = woff[ch.lf], size = woff[ch.lf + 1] - base;
+  const uint32_t t1 = ch.t0 + QR_WCHUNK < size ? ch.t0 + QR_WCHUNK : size;
+  long long *ss = hsum + (size_t)small_slot * cells + base;
+  uint32_t *sc = hcnt + (size_t)small_slot * cells + base;
+  long long *bs = mode == 1 ? hsum + (size_t)big_slot * cells + base : nullptr;
+  uint32_t *bc = mode == 1 ? hcnt + (size_t)big_slot * cells + base : nullptr;
+  const long long *ps = mode == 1 ? hsum + (size_t)parent_slot * cells + base : nullptr;
+  const uint32_t *pc = mode == 1 ? hcnt + (size_t)parent_slot * cells + base : nullptr;
+  // the row's chunk totals: those before this chunk are its carry, all of them the row total
+  const uint32_t c0 = chunk0[ch.lf], c1 = chunk0[ch.lf + 1], me = blockIdx.x;
+  long long a_s = 0, b_s = 0;
+  uint32_t a_c = 0, b_c = 0;
+  for (uint32_t k = c0 + threadIdx.x; k < c1; k += 1024) {
+    const long long v = tot_s[k];
+    const uint32_t w = tot_c[k];
+    b_s += v;
+    b_c += w;
+    if (k < me) {
+      a_s += v;
+      a_c += w;
+    }
+  }
+  // (rows have at most a few hundred chunks: the first wave's lanes hold everything)
+  a_s = wave_scan_i64(a_s);
+  a_c = wave_scan_u32(a_c);
+  b_s = wave_scan_i64(b_s);
+  b_c = wave_scan_u32(b_c);
+  if ((threadIdx.x & 63) == 63) {
+    sh_s[threadIdx.x >> 6] = a_s;
+    sh_c[threadIdx.x >> 6] = a_c;
+  }
+  __syncthreads();
+  long long carry_s = 0;
+  uint32_t carry_c = 0;
+  for (int w = 0; w < 16; ++w) {
+    carry_s += sh_s[w];
+    carry_c += sh_c[w];
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 63) {
+    sh_s[threadIdx.x >> 6] = b_s;
+    sh_c[threadIdx.x >> 6] = b_c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long x = 0;
+    uint32_t y = 0;
+    for (int w = 0; w < 16; ++w) {
+      x += sh_s[w];
+      y += sh_c[w];
+    }
+    row_s[0] = x;
+    row_c[0] = y;
+    row_s[1] = mode == 1 ? ps[size - 1] - x : 0;
+    row_c[1] = mode == 1 ? pc[size - 1] - y : 0u;
+  }
+  __syncthreads();
+  const long long S0 = row_s[0], S1 = row_s[1];
+  const uint32_t C0 = row_c[0], C1 = row_c[1];
+  const u64 minls = ts->minls;
+  const double inv_scale = scal->inv_scale;
+  Best a, b;
+  a.score = b.score = -1.0;
+  a.t = b.t = 0xFFFFFFFFu;
+  for (uint32_t r0 = ch.t0; r0 < t1; r0 += 1024) {
+    const uint32_t t = r0 + threadIdx.x;
+    long long s = t < t1 ? ss[t] : 0;
+    uint32_t cn = t < t1 ? sc[t] : 0u;
+    const long long par_s = (mode == 1 && t < t1) ? ps[t] : 0;
+    const uint32_t par_c = (mode == 1 && t < t1) ? pc[t] : 0u;
+    w_block_scan(s, cn, carry_s, carry_c, sh_s, sh_c);
+    if (t < t1) {
+      ss[t] = s;
+      sc[t] = cn;
+      const Best v = slot_gain(s, cn, S0, C0, t, size, minls, inv_scale);
+      if (v.score > a.score) a = v;  // ascending t per thread: strict > keeps the first
+      if (mode == 1) {
+        const long long gs = par_s - s;
+        const uint32_t gc = par_c - cn;
+        bs[t] = gs;
+        bc[t] = gc;
+        const Best w = slot_gain(gs, gc, S1, C1, t, size, minls, inv_scale);
+        if (w.score > b.score) b = w;
+      }
+    }
+  }
+  a = w_block_best(a, sh_b);
+  if (mode == 1) b = w_block_best(b, sh_b);
+  if (threadIdx.x == 0) {
+    cbest[2 * (size_t)blockIdx.x] = a;
+    cbest[2 * (size_t)blockIdx.x + 1] = b;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_wscan_best(
+    const QrTreeState *__restrict__ ts, const int mode, const uint32_t *__restrict__ chunk0,
+    const uint32_t *__restrict__ woff, const size_t cells, const uint32_t *__restrict__ hcnt,
+    const int flocal, const int32_t *__restrict__ lf2gf, const float *__restrict__ thr,
+    const Best *__restrict__ cbest, qr_split_t *__restrict__ featrec, float *__restrict__ featthr) {
+  int small_slot, big_slot, parent_slot, small_is_left;
+  bool active;
+  w_scan_setup(ts, mode, small_slot, big_slot, parent_slot, small_is_left, active);
+  if (!active) return;
+  const int lf = blockIdx.x;
+  const uint32_t base = woff[lf], size = woff[lf + 1] - base;
+  const uint32_t c0 = chunk0[lf], c1 = chunk0[lf + 1];
+  const uint32_t *sc = hcnt + (size_t)small_slot * cells + base;
+  const uint32_t *bc = mode == 1 ? hcnt + (size_t)big_slot * cells + base : nullptr;
+  for (int which = 0; which < (mode == 1 ? 2 : 1); ++which) {
+    Best v;
+    v.score = -1.0;
+    v.t = 0xFFFFFFFFu;
+    for (uint32_t k = c0 + threadIdx.x; k < c1; k += 64) {  // ascending chunks per lane
+      const Best w = cbest[2 * (size_t)k + which];
+      if (w.score > v.score) v = w;
+    }
+    const double m = wave_max(v.score);
+    const uint32_t t = wave_min_u32(v.score == m && v.t != 0xFFFFFFFFu ? v.t : 0xFFFFFFFFu);
+    Best r;
+    r.score = t != 0xFFFFFFFFu ? m : -1.0;
+    r.t = t;
+    const uint32_t *row = which == 0 ? sc : bc;
+    const int w = mode == 0 ? 0 : ((which == 0) == (small_is_left != 0) ? 0 : 1);
+    w_record(&featrec[(size_t)w * flocal + lf], &featthr[(size_t)w * flocal + lf], r, lf2gf[lf], row,
+             row[size - 1], thr + base);
+  }
+}
+
 // level-wise growth: prefix + sibling for every node of the level (no gains here:
 // k_wobl_fill sums them over the level)
 __global__ __launch_bounds__(1024) void k_wscan_level(
@@ -532,9 +746,25 @@ int qr_k_whist_scan(qr_ctx *c, int root_mode) {
                      c->wcells, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, c->d_hsum,
                      c->d_hcnt);
   QR_CHECK(c, hipGetLastError());
-  hipLaunchKernelGGL(k_wscan, dim3((unsigned)c->flocal), dim3(1024), 0, c->stream, c->d_tree, mode,
-                     c->d_woff, c->wcells, c->d_hsum, c->d_hcnt, c->flocal, c->d_lf2gf, c->d_wthr,
-                     c->d_scalars, c->d_featrec, c->d_featthr);
+  if (c->wmax <= QR_WCHUNK) {  // short rows: one workgroup per feature
+    hipLaunchKernelGGL(k_wscan, dim3((unsigned)c->flocal), dim3(1024), 0, c->stream, c->d_tree, mode,
+                       c->d_woff, c->wcells, c->d_hsum, c->d_hcnt, c->flocal, c->d_lf2gf, c->d_wthr,
+                       c->d_scalars, c->d_featrec, c->d_featthr);
+    QR_CHECK(c, hipGetLastError());
+    return QR_OK;
+  }
+  const unsigned nch = (unsigned)c->wchunks;
+  hipLaunchKernelGGL(k_wscan_tot, dim3(nch), dim3(1024), 0, c->stream, c->d_tree, mode,
+                     (const WChunk *)c->d_wchunk, c->d_woff, c->wcells, c->d_hsum, c->d_hcnt, c->d_wtot_s,
+                     c->d_wtot_c);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_wscan_chunk, dim3(nch), dim3(1024), 0, c->stream, c->d_tree, mode,
+                     (const WChunk *)c->d_wchunk, c->d_wchunk0, c->d_woff, c->wcells, c->d_hsum, c->d_hcnt,
+                     c->d_wtot_s, c->d_wtot_c, c->d_scalars, (Best *)c->d_wcbest);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_wscan_best, dim3((unsigned)c->flocal), dim3(64), 0, c->stream, c->d_tree, mode,
+                     c->d_wchunk0, c->d_woff, c->wcells, c->d_hcnt, c->flocal, c->d_lf2gf, c->d_wthr,
+                     (const Best *)c->d_wcbest, c->d_featrec, c->d_featthr);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

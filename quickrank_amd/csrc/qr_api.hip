@@ -87,6 +87,8 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins); dfree(c->d_bins_fm);
   dfree(c->d_thr); dfree(c->d_thr_size);
   dfree(c->d_woff); dfree(c->d_wthr); dfree(c->d_wbins);
+  dfree(c->d_wchunk); dfree(c->d_wchunk0); dfree(c->d_wtot_s); dfree(c->d_wtot_c); dfree(c->d_wcbest);
+  c->wchunks = 0;
   c->wide = false;
   c->wcells = 0;
   c->wmax = 0;
@@ -671,6 +673,26 @@ int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t 
   QR_CHECK(c, dalloc(&c->d_wthr, c->wcells));
   QR_CHECK(c, hipMemcpy(c->d_wthr, c->h_wthr.data(), c->wcells * 4, hipMemcpyHostToDevice));
   QR_CHECK(c, dalloc(&c->d_wbins, N * F));
+  {  // the chunk table of the chunked scan: (feature, first slot) of every QR_WCHUNK slots of a row
+    std::vector<uint32_t> ch, first(F + 1, 0);
+    for (size_t f = 0; f < F; ++f) {
+      first[f] = (uint32_t)(ch.size() / 2);
+      const uint32_t size = c->h_woff[f + 1] - c->h_woff[f];
+      for (uint32_t t0 = 0; t0 < size; t0 += QR_WCHUNK) {
+        ch.push_back((uint32_t)f);
+        ch.push_back(t0);
+      }
+    }
+    first[F] = (uint32_t)(ch.size() / 2);
+    c->wchunks = ch.size() / 2;
+    QR_CHECK(c, dalloc(&c->d_wchunk, ch.size()));
+    QR_CHECK(c, hipMemcpy(c->d_wchunk, ch.data(), ch.size() * 4, hipMemcpyHostToDevice));
+    QR_CHECK(c, dalloc(&c->d_wchunk0, first.size()));
+    QR_CHECK(c, hipMemcpy(c->d_wchunk0, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+    QR_CHECK(c, dalloc(&c->d_wtot_s, c->wchunks));
+    QR_CHECK(c, dalloc(&c->d_wtot_c, c->wchunks));
+    QR_CHECK(c, dalloc(&c->d_wcbest, 4 * c->wchunks));  // two 16-byte records per chunk
+  }
   rc = qr_k_wide_binning(c, d_col);
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   dfree(d_col);

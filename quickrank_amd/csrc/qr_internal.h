@@ -306,6 +306,10 @@ struct qr_ctx {
   size_t wcells = 0;             // cells of one node histogram
   uint32_t wmax = 0;             // longest row
   uint32_t *d_woff = nullptr;    // [F + 1]
+  // chunked scan of long rows (k_wide.hip): chunk table, per-chunk totals and bests
+  uint32_t *d_wchunk = nullptr, *d_wchunk0 = nullptr, *d_wtot_c = nullptr;
+  long long *d_wtot_s = nullptr, *d_wcbest = nullptr;
+  size_t wchunks = 0;
   float *d_wthr = nullptr;       // [wcells]
   uint32_t *d_wbins = nullptr;   // [F][N] feature-major
   std::vector<uint32_t> h_woff;
@@ -478,6 +482,7 @@ int qr_k_binning(qr_ctx *c);
 int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds);
 int qr_k_wide_binning(qr_ctx *c, const float *d_col);
 int qr_k_whist_scan(qr_ctx *c, int root_mode);
+#define QR_WCHUNK 8192u  /* slots per workgroup of the chunked scan of long rows (k_wide.hip) */
 int qr_k_wobl_fill(qr_ctx *c, int level);
 int qr_k_wobl_hist(qr_ctx *c, int nodes);
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode);

@@ -298,7 +298,10 @@ int qr_tree_split_log(qr_ctx *ctx, qr_split_t *out, size_t *n_out);
 /* per-query metric of the last qr_lambda_compute / qr_metric_eval(which=0)      */
 int qr_metric_per_query(qr_ctx *ctx, double *out);
 /* rank permutation (pos_of_rank, rankedresults.cc:27-41) of the last            */
-/* qr_lambda_compute: host u32 [N], query-local doc index per rank               */
+/* qr_lambda_compute: host u32 [N], query-local doc index per rank.  The first    */
+/* `cutoff` ranks of a query are std::sort's bit for bit; beyond the cutoff (where */
+/* no discount applies) the documents come in non-increasing score order with an  */
+/* unspecified order among equal scores, unless QR_EXACT_TAIL=1 is set.           */
 int qr_ranks_read(qr_ctx *ctx, uint32_t *out);
 
 /* ---- inference: Ensemble::score_instance (ensemble.cc:111-118) over           */

@@ -17,7 +17,8 @@
 //      The wave then re-ranks the query with a wave-parallel emulation of
 //      exactly that algorithm (wave_gnu_sort below; ties dominate the first
 //      boosting iterations, where all scores are 0 and the tie order decides the
-//      discounts, and never fully disappear).
+//      discounts, and never fully disappear).  Only the ranks the metric can see are
+//      ordered exactly -- the first `cutoff`; see `limit` at wave_gnu_sort.
 //   3. metric of the current ranking (lane 0, same summation order as
 //      dcg.cc:36-38) -- the training NDCG comes for free with the lambdas.
 //   4. pair loop: lane <-> rank r2, loop r1 over the top-`cutoff` ranks;
@@ -299,9 +300,16 @@ __device__ __forceinline__ void sort_sync() {
   }
 }
 
+//  * `limit`: only the first `limit` positions of the result are asked for (the metric's
+//    cutoff: ranks beyond it carry no discount, so neither the metric nor a lambda depends
+//    on the ORDER of the documents ranked there -- only on which documents they are).  The
+//    partition phase leaves the ranges ordered by key among themselves, and the final
+//    stable sort by key never moves an element out of its range; so position q of the
+//    result comes from the range that covers q, and a range that starts at or beyond
+//    `limit` need not be partitioned at all.  limit = n gives the whole permutation.
 template <bool BS>
 __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *RB,
-                              int *stk, const uint8_t *dupk) {
+                              int *stk, const uint8_t *dupk, const int limit) {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
   if (n > 16) {
@@ -444,13 +452,15 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
           }
           sort_sync<BS>();
         }
-        // recurse on [cut, last) (pushed), loop on [first, cut)
-        if (lane == 0) {
-          stk[3 * sp] = (int)cut;
-          stk[3 * sp + 1] = last;
-          stk[3 * sp + 2] = depth;
+        // recurse on [cut, last) (pushed, if any of it is asked for), loop on [first, cut)
+        if ((int)cut < limit) {
+          if (lane == 0) {
+            stk[3 * sp] = (int)cut;
+            stk[3 * sp + 1] = last;
+            stk[3 * sp + 2] = depth;
+          }
+          ++sp;
         }
-        ++sp;
         last = (int)cut;
         sort_sync<BS>();
       }
@@ -532,7 +542,8 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
     uint32_t *__restrict__ ranks_out, double *__restrict__ ssq, double *__restrict__ qmax,
     QrScalars *__restrict__ scal, uint32_t nmax, uint32_t kacc, int mode,
     const uint8_t *__restrict__ present, const uint8_t *__restrict__ long_flag,
-    const uint32_t *__restrict__ long_list, char *__restrict__ lscratch, const size_t lstride) {
+    const uint32_t *__restrict__ long_list, char *__restrict__ lscratch, const size_t lstride,
+    const int exact_tail) {
   extern __shared__ __attribute__((aligned(16))) char lds_mem[];
   // (LONG = false: `long_list`, when given, is the launch's size class -- the queries whose
   // working set fits THIS launch's LDS)
@@ -654,10 +665,11 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   // ---- 2. with ties the permutation is what GNU std::sort leaves: the partition phase by
   //         one wave, the stable placement that ends it by all
   if (anytie) {
+    const int limit = exact_tail ? (int)n : (int)(cutoff < n ? cutoff : n);
     if (W == 1) {
-      wave_gnu_sort<true>(pa, (int)n, LB, RB, stk, dupk);
+      wave_gnu_sort<true>(pa, (int)n, LB, RB, stk, dupk, limit);
     } else {
-      if (wave == 0) wave_gnu_sort<false>(pa, (int)n, LB, RB, stk, dupk);
+      if (wave == 0) wave_gnu_sort<false>(pa, (int)n, LB, RB, stk, dupk, limit);
       __syncthreads();
     }
     sort_placement<W>(pa, (int)n, unmap, dupk);
@@ -1160,12 +1172,12 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
       hipLaunchKernelGGL((k_lambda<false, 4>), dim3(cl.count), dim3(256), lds, st, sc, lb, qoffd, metric, cut,
                          idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
-                         (size_t)0);
+                         (size_t)0, c->exact_tail);
     else
       hipLaunchKernelGGL((k_lambda<false, 1>), dim3(cl.count), dim3(64), lds, st, sc, lb, qoffd, metric, cut,
                          idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
-                         (size_t)0);
+                         (size_t)0, c->exact_tail);
     QR_CHECK(c, hipGetLastError());
   }
   if (nlong) {
@@ -1175,7 +1187,8 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     hipLaunchKernelGGL((k_lambda<true, 1>), dim3((unsigned)nlong), dim3(64), 0, st, sc, lb, qoffd, metric, cut,
                        idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars,
                        (uint32_t)nmax_long, (uint32_t)std::min(kacc, nmax_long), md, present,
-                       (const uint8_t *)nullptr, (const uint32_t *)c->d_long_list[which], c->d_lscratch, lstride);
+                       (const uint8_t *)nullptr, (const uint32_t *)c->d_long_list[which], c->d_lscratch, lstride,
+                       c->exact_tail);
     QR_CHECK(c, hipGetLastError());
   }
   if (fork)  // join: the context's stream carries on when every launch is done

@@ -46,6 +46,7 @@ int qr_ctx_create(int device, qr_ctx **out) {
   }
   qr_ctx *c = new qr_ctx();
   c->no_batch = getenv("QR_NO_BATCH") != nullptr;
+  c->exact_tail = getenv("QR_EXACT_TAIL") != nullptr;
   if (const char *e = getenv("QR_STEPS_HINT")) c->steps_force = atol(e);  // steps to enqueue, whatever the tree
   c->device = device;
   hipDeviceProp_t prop;

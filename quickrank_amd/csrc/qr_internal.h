@@ -386,6 +386,7 @@ struct qr_ctx {
   QrScanWg *d_lscan_wg = nullptr;     // ... [QR_BATCH][flocal]
   QrPlan *d_lplan = nullptr;          // ... and the plan of every node of the batch
   bool no_batch = false;              // QR_NO_BATCH=1: one split per step (debugging aid)
+  int exact_tail = 0;                 // QR_EXACT_TAIL=1: the std::sort emulation orders the ranks beyond the cutoff too
   // guessed step count of batched growth: steps to enqueue for the next tree (0 = the worst
   // case nleaves - 1), whether the tree just enqueued may turn out incomplete, and what the
   // continuation has to repeat (leaf kernels with `newton`, the score update with `shrinkage`)

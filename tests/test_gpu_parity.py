@@ -74,10 +74,35 @@ def _scores_for(kind, n, rng):
     return rng.standard_normal(n)
 
 
+def _check_ranks(ora, ranks, scores, qoff, cutoff, exact_tail, tag=None):
+    """The rank permutation against the oracle's std::sort (pinned to libstdc++ through
+    oracle/_ref).  QR_EXACT_TAIL=1: the whole permutation, bit for bit, tie order included.
+    Default: the first `cutoff` ranks bit for bit -- the ones the metric and the lambdas can
+    see (ranks beyond the cutoff carry no discount) -- and beyond them the same documents in
+    non-increasing score order (the std::sort emulation does not partition ranges that lie
+    entirely beyond the cutoff, so equal scores there keep an unspecified order)."""
+    for q in range(len(qoff) - 1):
+        a, b = int(qoff[q]), int(qoff[q + 1])
+        want = ora.rank_by_score(scores[a:b]).astype(np.uint64)
+        got = ranks[a:b].astype(np.uint64)
+        size = b - a if (exact_tail or cutoff == 0) else min(cutoff, b - a)
+        assert np.array_equal(got[:size], want[:size]), (tag, q)
+        if size < b - a:
+            assert np.array_equal(np.sort(got[size:]), np.sort(want[size:])), (tag, q)
+            tail = scores[a:b][got[size:].astype(np.int64)]
+            assert np.all(np.diff(tail) <= 0), (tag, q)
+            assert np.array_equal(tail, scores[a:b][want[size:].astype(np.int64)]), (tag, q)
+
+
+@pytest.mark.parametrize("exact_tail", [False, True])
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("kind", ["zero", "few", "mixed", "random"])
 @pytest.mark.parametrize("metric,cutoff", [("NDCG", 10), ("NDCG", 3), ("NDCG", 0), ("DCG", 10)])
-def test_ranks_metric_lambdas(qr, ora, case, kind, metric, cutoff):
+def test_ranks_metric_lambdas(qr, ora, case, kind, metric, cutoff, exact_tail, monkeypatch):
+    if exact_tail:
+        monkeypatch.setenv("QR_EXACT_TAIL", "1")
+    else:
+        monkeypatch.delenv("QR_EXACT_TAIL", raising=False)
     x, labels, qoff = make_dataset(**case)
     rng = np.random.default_rng(5)
     scores = _scores_for(kind, len(labels), rng)
@@ -86,11 +111,8 @@ def test_ranks_metric_lambdas(qr, ora, case, kind, metric, cutoff):
     c.set_scores(scores)
     c.compute_lambdas(metric, cutoff)
     m = 1 if metric == "NDCG" else 0
-    # rank permutation: bit-exact incl. the std::sort tie order
-    ranks = c.ranks()
-    for q in range(len(qoff) - 1):
-        a, b = int(qoff[q]), int(qoff[q + 1])
-        assert np.array_equal(ranks[a:b].astype(np.uint64), ora.rank_by_score(scores[a:b])), q
+    # rank permutation: bit-exact incl. the std::sort tie order (see _check_ranks)
+    _check_ranks(ora, c.ranks(), scores, qoff, cutoff, exact_tail)
     # per-query metric: bit-exact (same ranking, host-built log2 table)
     pq = c.metric_per_query()
     L = ora.lib()
@@ -542,10 +564,15 @@ def test_error_paths_return_codes_not_crashes(qr):
     c.close()
 
 
-def test_queries_longer_than_the_lds(qr, ora):
+@pytest.mark.parametrize("exact_tail", [False, True])
+def test_queries_longer_than_the_lds(qr, ora, exact_tail, monkeypatch):
     """Queries whose working set does not fit the LDS (> ~3300 documents) run out of
     a global scratch slice: same ranks (ties included), metric, lambdas and weights;
     short queries of the same set keep the LDS path."""
+    if exact_tail:
+        monkeypatch.setenv("QR_EXACT_TAIL", "1")
+    else:
+        monkeypatch.delenv("QR_EXACT_TAIL", raising=False)
     rng = np.random.default_rng(8)
     lens = [50, 5000, 7, 3400, 120]
     qoff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
@@ -561,10 +588,7 @@ def test_queries_longer_than_the_lds(qr, ora):
         olam, ow = ora.lambdas(labels, scores, qoff, cutoff, 1 if metric == "NDCG" else 0)
         assert np.allclose(lam, olam, rtol=1e-10, atol=1e-14)
         assert np.allclose(w, ow, rtol=1e-10, atol=1e-14)
-        ranks = c.ranks()
-        for q in range(len(lens)):
-            a, b = int(qoff[q]), int(qoff[q + 1])
-            assert np.array_equal(ranks[a:b], ora.rank_by_score(scores[a:b]).astype(np.uint32)), (metric, q)
+        _check_ranks(ora, c.ranks(), scores, qoff, cutoff, exact_tail, metric)
         assert c.metric_last() == pytest.approx(
             ora.eval_dataset(labels, scores, qoff, cutoff, 1 if metric == "NDCG" else 0), rel=1e-13)
     c.close()

@@ -767,6 +767,22 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
     slam = flip(rho * d, lo1);
     del = rho * (1.0 - rho) * d;
   };
+  // The same term from per-document exponentials e = exp(score - max score of the query):
+  // 1 / (1 + exp(s_hi - s_lo)) = e_lo / (e_lo + e_hi), `lo` the document with the lower
+  // label -- n exponentials per query instead of one per pair (to a few ulp the same value;
+  // the lambdas are held to 1e-11).  Used when the query's scores span less than 690, so
+  // that no e underflows.
+  auto pair_term_e = [&](const float l1, const double p1, const double inv1, const double e1,
+                         const float l2, const double p2, const double il2, const double e2, double &slam,
+                         double &del) {
+    const double j = (il2 - inv1) * (p1 - p2);
+    const double d = fabs(j * inv_idcg);
+    const bool lo1 = l1 < l2;
+    const double r = qr_rcp(e1 + e2);
+    const double rho = (lo1 ? e1 : e2) * r;
+    slam = flip(rho * d, lo1);
+    del = rho * (1.0 - rho) * d;
+  };
   if (n <= 128) {
     if (W == 1 || wave == 0) {
     // Every lane keeps its two ranks (lane, lane + 64) -- label, 2^label, discount,
@@ -779,7 +795,21 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
     const float la = ina ? sl[ra] : 0.f, lb = inb ? sl[rb] : 0.f;
     const double pa_ = ina ? pw[ra] : 0.0, pb_ = inb ? pw[rb] : 0.0;
     const double ia = ra < size ? ilt[ra] : 0.0, ib = rb < size ? ilt[rb] : 0.0;
-    const double sa = ina ? sr[ra] : 0.0, sb = inb ? sr[rb] : 0.0;
+    // (ranks are in non-increasing score order: the query's scores span sr[0] - sr[n - 1])
+    const bool use_e = sr[0] - sr[n - 1] <= 690.0;
+    double sa = ina ? sr[ra] : 0.0, sb = inb ? sr[rb] : 0.0;
+    if (use_e) {
+      const double smax = sr[0];
+      sa = qr_exp(sa - smax, expt);
+      sb = qr_exp(sb - smax, expt);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (every lane has read sr[0], sr[n - 1])
+      __builtin_amdgcn_wave_barrier();
+      if (ina && ra < size) sr[ra] = sa;  // what the broadcast of rank r1 reads below
+      if (inb && rb < size) sr[rb] = sb;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     double ola = 0.0, owa = 0.0, olb = 0.0, owb = 0.0;
     for (uint32_t r1 = 0; r1 < size; ++r1) {
       const float l1 = sl[r1];
@@ -788,7 +818,10 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       const bool va = ina && ra > r1 && l1 != la, vb = inb && rb > r1 && l1 != lb;
       if (va) {
         double slam, del;
-        pair_term(l1, p1, inv1, s1, la, pa_, ia, sa, slam, del);
+        if (use_e)
+          pair_term_e(l1, p1, inv1, s1, la, pa_, ia, sa, slam, del);
+        else
+          pair_term(l1, p1, inv1, s1, la, pa_, ia, sa, slam, del);
         c1 += slam;
         cw += del;
         ola -= slam;
@@ -796,7 +829,10 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       }
       if (vb) {
         double slam, del;
-        pair_term(l1, p1, inv1, s1, lb, pb_, ib, sb, slam, del);
+        if (use_e)
+          pair_term_e(l1, p1, inv1, s1, lb, pb_, ib, sb, slam, del);
+        else
+          pair_term(l1, p1, inv1, s1, lb, pb_, ib, sb, slam, del);
         c1 += slam;
         cw += del;
         olb -= slam;

@@ -67,6 +67,8 @@ def _scores_for(kind, n, rng):
         return np.zeros(n)
     if kind == "few":
         return rng.integers(0, 5, n) * 0.1
+    if kind == "huge":      # scores that span more than exp() can take: the pair term's exp(s_hi - s_lo) path
+        return rng.standard_normal(n) * 800.0
     if kind == "mixed":
         s = rng.standard_normal(n)
         s[rng.integers(0, n, n // 4)] = 0.25
@@ -96,7 +98,7 @@ def _check_ranks(ora, ranks, scores, qoff, cutoff, exact_tail, tag=None):
 
 @pytest.mark.parametrize("exact_tail", [False, True])
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("kind", ["zero", "few", "mixed", "random"])
+@pytest.mark.parametrize("kind", ["zero", "few", "mixed", "random", "huge"])
 @pytest.mark.parametrize("metric,cutoff", [("NDCG", 10), ("NDCG", 3), ("NDCG", 0), ("DCG", 10)])
 def test_ranks_metric_lambdas(qr, ora, case, kind, metric, cutoff, exact_tail, monkeypatch):
     if exact_tail:

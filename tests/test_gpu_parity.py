@@ -142,6 +142,43 @@ def _oracle_tree(ora, x, nthr, lam, w, nleaves, minls):
     return tr, t
 
 
+@pytest.mark.parametrize("case", [CASES[0], CASES[-1]])
+@pytest.mark.parametrize("nthr,nleaves", [(255, 10), (32, 24)])
+def test_every_node_histogram_against_the_oracle(qr, ora, case, nthr, nleaves):
+    """RTNodeHistogram of EVERY node of a fitted tree (rtnode_histogram.cc:41-87): the
+    directly built child (the SMALLER one here, the left one in the reference) and the
+    sibling by subtraction -- counts exact, sums to the fixed-point resolution -- against the
+    oracle's histogram of the node's documents (the documents of the leaves below it)."""
+    x, labels, qoff = make_dataset(**case)
+    rng = np.random.default_rng(17)
+    scores = rng.standard_normal(len(labels)) * 0.3
+    olam, ow = ora.lambdas(labels, scores, qoff, 10, 1)
+    c, thr, ts = _ctx(qr, x, labels, qoff, nthr)
+    c.set_pseudo(olam, ow)
+    nodes = c.fit_tree(nleaves, 1, True)
+    tr = ora.Trainer(x, nthr)
+    docs = {}
+
+    def below(i):
+        if i not in docs:
+            n = nodes[i]
+            docs[i] = c.node_samples(i).astype(np.uint64) if n["feature"] < 0 else \
+                np.sort(np.concatenate([below(int(n["left"])), below(int(n["right"]))]))
+        return docs[i]
+
+    tol = 2.0 ** -30 * max(1.0, np.abs(olam).max()) * np.sqrt(len(olam))
+    for i in range(len(nodes)):
+        ids = below(i)
+        assert len(ids) == nodes[i]["nsamples"]
+        os_, oc, _ = ora.hist_build(tr.stmap, tr.thr_size, tr.cap, olam, sampleids=ids)
+        hs, hc = c.node_hist(i)
+        for f in range(x.shape[1]):
+            n = int(tr.thr_size[f])
+            assert np.array_equal(hc[f, :n], oc[f, :n]), (i, f)
+            assert np.allclose(hs[f, :n], os_[f, :n], rtol=0, atol=tol), (i, f)
+    c.close()
+
+
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("nthr,nleaves,minls", [(255, 10, 1), (32, 16, 5), (255, 4, 1), (8, 31, 2)])
 def test_root_histogram_and_tree(qr, ora, case, nthr, nleaves, minls):

@@ -200,6 +200,11 @@ int qr_tree_nodes(qr_ctx *ctx, qr_node_t *nodes_out, size_t *nnodes_out);
 /* (seed, iteration) and the scores are the query's own.  Call after the bin      */
 /* build.  qr_metric_last then reports the cleaned rankings: use qr_metric_eval.  */
 int qr_subsample_set(qr_ctx *ctx, float subsample, uint64_t seed);
+/* document-sharded contexts: `subsample` refers to ALL ranks' documents, of which   */
+/* this rank's are [first_doc, first_doc + N).  A document's key is a function of its  */
+/* GLOBAL index, so every rank finds the same sample (the one a single GPU draws from */
+/* the whole set) without an exchange, and keeps its own part of it.                  */
+int qr_subsample_set_doc(qr_ctx *ctx, float subsample, uint64_t seed, size_t first_doc);
 /* --max-features (rt.cc:222-243): every node's split search sees a random       */
 /* subset of the features: max_features > 1 = that many, < 1 = that fraction     */
 /* (rounded up), 1 = all.  The reference draws it from a clock-seeded engine at  */

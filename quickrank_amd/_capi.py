@@ -39,7 +39,7 @@ SYMBOLS = [
     "qr_ctx_set_doc_shard", "qr_bins_stats", "qr_thresholds_from_stats",
     "qr_bins_build_with", "qr_lambda_finish", "qr_tree_leaves_finish",
     "qr_doc_exchange_buffers", "qr_tree_nodes", "qr_valid_scores_set",
-    "qr_tree_set_max_features", "qr_subsample_set", "qr_ensemble_partial_scores",
+    "qr_tree_set_max_features", "qr_subsample_set", "qr_subsample_set_doc", "qr_ensemble_partial_scores",
     "qr_prof_get_child", "qr_bins_build_wide", "qr_thresholds_read", "qr_bins_read_u32",
     "qr_node_hist_read_ragged", "qr_ctx_stream", "qr_obl_begin", "qr_obl_propose", "qr_obl_mark",
     "qr_obl_apply", "qr_obl_exchange_buffers", "qr_obl_level_exchange",
@@ -142,6 +142,7 @@ def lib():
     L.qr_tree_nodes.argtypes = [vp, vp, C.POINTER(sz)]
     L.qr_tree_set_max_features.argtypes = [vp, C.c_float, u64]
     L.qr_subsample_set.argtypes = [vp, C.c_float, u64]
+    L.qr_subsample_set_doc.argtypes = [vp, C.c_float, u64, sz]
     L.qr_lambda_finish.argtypes = [vp]
     L.qr_tree_leaves_finish.argtypes = [vp, C.c_int, vp, C.POINTER(sz)]
     L.qr_doc_exchange_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp),
@@ -378,8 +379,12 @@ class Context:
         self._ck(self.L.qr_tree_nodes(self.h, _ptr(nodes), C.byref(n)))
         return nodes[:n.value].copy()
 
-    def set_subsample(self, subsample, seed=0):
-        self._ck(self.L.qr_subsample_set(self.h, float(subsample), int(seed)))
+    def set_subsample(self, subsample, seed=0, first_doc=None):
+        """first_doc: document-sharded contexts -- the global index of the rank's first document"""
+        if first_doc is None:
+            self._ck(self.L.qr_subsample_set(self.h, float(subsample), int(seed)))
+        else:
+            self._ck(self.L.qr_subsample_set_doc(self.h, float(subsample), int(seed), int(first_doc)))
 
     def set_max_features(self, max_features, seed=0):
         self._ck(self.L.qr_tree_set_max_features(self.h, float(max_features), int(seed)))

@@ -2875,7 +2875,7 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
   }
   const int G = c->ncu;
   const bool prof = c->prof_on && root_mode;
-  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);  // documents of the root node
+  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_n : c->N);  // documents of the root node
   if (root_mode) {
     const int root_buf = c->sub_k ? 0 : 2;  // the sample's list / every document
     if (prof) {
@@ -2979,9 +2979,9 @@ int qr_k_tree_decide(qr_ctx *c) {
   // measured slower: the agent-scope release/acquire it needs writes back and
   // invalidates the XCD L2s, 22.8 us for the fused kernel against 6 + 9 us.)
   hipLaunchKernelGGL(k_decide, dim3(1), dim3(128), 0, c->stream, c->d_tree,
-                     (uint32_t)(c->sub_k ? c->sub_k : c->N), c->flocal, recs, fshard ? c->world : 1,
+                     (uint32_t)(c->sub_k ? c->sub_n : c->N), c->flocal, recs, fshard ? c->world : 1,
                      c->d_scalars, c->d_part_ss, c->wide ? c->d_wthr : c->d_thr, c->d_gf2lf, c->d_featrec,
-                     c->d_hcnt_loc, c->dmode, (u64)c->Nglobal,
+                     c->d_hcnt_loc, c->dmode, (u64)(c->sub_k ? c->sub_k : c->Nglobal),
                      c->dmode ? c->d_xh + 2 * c->xh_cells : (const long long *)nullptr,
                      c->world, c->mf_k, c->mf_seed + c->tree_counter, (uint32_t)c->F,
                      c->sub_k ? 0 : 2, c->wide ? c->d_woff : (const uint32_t *)nullptr);
@@ -3049,7 +3049,7 @@ static BatchGeom batch_geom(const qr_ctx *c, size_t nleaves) {
   BatchGeom g;
   g.pg = (unsigned)std::min<size_t>(c->lpart_cap, c->N / QR_PART_SLICE + QR_BATCH + 1);
   g.hg = (unsigned)std::min<size_t>(c->lhist_cap, (size_t)std::max(c->ncu, c->ncu / 4 + QR_BATCH * c->nblocks));
-  g.rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);
+  g.rootn = (uint32_t)(c->sub_k ? c->sub_n : c->N);
   // final ids [0, 2 nleaves + 1) + provisional ones [.., 4 nleaves + 1)
   g.small = 4 * nleaves + 1 + 2 * QR_BATCH <= QR_BATCH_LDS_SMALL;
   g.stage_nodes = 4 * nleaves + 1 + 2 * QR_BATCH <= QR_BATCH_LDS_LARGE ? (int)(4 * nleaves + 1) : 0;

@@ -734,7 +734,7 @@ int qr_k_whist_scan(qr_ctx *c, int root_mode) {
   int rc = whist_attr(c);
   if (rc) return rc;
   const int mode = root_mode ? 0 : 1;
-  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_k : c->N);
+  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_n : c->N);
   const size_t maxn = root_mode ? rootn : rootn / 2 + 1;  // the smaller child
   const unsigned zg = (unsigned)std::min<size_t>((c->wcells + 255) / 256, 4096);
   hipLaunchKernelGGL(k_wzero, dim3(zg, 1), dim3(256), 0, c->stream, c->d_tree, mode, c->wcells, c->d_hsum,

@@ -925,7 +925,7 @@ int qr_residual_compute(qr_ctx *c) {
   size_t nss = (c->N + QR_SLICE - 1) / QR_SLICE;
   if (c->sub_k) {  // the root's statistics run over the sample (rtnode_histogram.cc:199-203)
     if ((rc = qr_k_sample_sums(c))) return rc;
-    nss = (c->sub_k + QR_SLICE - 1) / QR_SLICE;
+    nss = std::max<size_t>(1, (c->sub_n + QR_SLICE - 1) / QR_SLICE);
   }
   if ((rc = qr_k_prep(c, nss, 0)) || !c->dmode) return rc;
   return qr_k_prep_pack(c);
@@ -1021,30 +1021,47 @@ static int ensure_level_buffers(qr_ctx *c, size_t depth) {
   return QR_OK;
 }
 
-int qr_subsample_set(qr_ctx *c, float subsample, uint64_t seed) {
-  if (!c) return QR_ERR_ARG;
+// feature-sharded ranks hold every document: each draws the same sample (a pure function of
+// seed and iteration).  Document-sharded ranks (qr_subsample_set_doc) draw it from the keys of
+// ALL ranks' documents -- a function of the global document index, so every rank finds the same
+// sample without an exchange -- and keep their own part.
+static int subsample_set(qr_ctx *c, float subsample, uint64_t seed, size_t first_doc) {
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
-  // feature-sharded ranks hold every document: each draws the same sample (a pure function of
-  // seed and iteration).  Document-sharded ranks would need a global k-th key: not built.
-  if (c->dmode) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling: single-GPU and feature-sharded contexts only");
   if (!(subsample > 0.0f)) QR_FAIL(c, QR_ERR_ARG, "subsample must be > 0");
+  const size_t Nall = c->dmode ? (size_t)c->Nglobal : c->N;
+  if (c->dmode && first_doc + c->N > Nall) QR_FAIL(c, QR_ERR_ARG, "the rank's documents lie outside the global range");
   // mart.cc:289-297: > 1 is a number of documents, < 1 a fraction (rounded down)
-  size_t k = subsample > 1.0f ? std::min((size_t)subsample, c->N)
-                              : (size_t)std::floor(subsample * (float)c->N);
-  if (subsample == 1.0f || k >= c->N) k = 0;  // the whole set: no sampling
-  if (subsample != 1.0f && k == 0 && (size_t)std::floor(subsample * (float)c->N) == 0 && subsample < 1.0f)
+  size_t k = subsample > 1.0f ? std::min((size_t)subsample, Nall)
+                              : (size_t)std::floor(subsample * (float)Nall);
+  if (subsample == 1.0f || k >= Nall) k = 0;  // the whole set: no sampling
+  if (subsample != 1.0f && k == 0 && (size_t)std::floor(subsample * (float)Nall) == 0 && subsample < 1.0f)
     QR_FAIL(c, QR_ERR_ARG, "subsample leaves no document");
   c->sub_k = k;
+  c->sub_n = k;
+  c->sub_first = first_doc;
   c->sub_seed = seed * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull;
   c->sub_iter = 0;
   if (k && !c->d_present) {
     QR_CHECK(c, dalloc(&c->d_present, c->N));
-    QR_CHECK(c, dalloc(&c->d_sample_keys, 4 * c->N));
+    QR_CHECK(c, dalloc(&c->d_sample_keys, 4 * Nall));
     QR_CHECK(c, dalloc(&c->d_sample_count, (size_t)1));
-    c->sample_temp_bytes = qr_k_sample_temp_bytes(c->N);
+    c->sample_temp_bytes = qr_k_sample_temp_bytes(Nall);
     QR_CHECK(c, hipMalloc(&c->d_sample_temp, c->sample_temp_bytes ? c->sample_temp_bytes : 1));
   }
   return QR_OK;
+}
+
+int qr_subsample_set(qr_ctx *c, float subsample, uint64_t seed) {
+  if (!c) return QR_ERR_ARG;
+  if (c->dmode)
+    QR_FAIL(c, QR_ERR_STATE, "document-sharded contexts: qr_subsample_set_doc (it needs the rank's first document)");
+  return subsample_set(c, subsample, seed, 0);
+}
+
+int qr_subsample_set_doc(qr_ctx *c, float subsample, uint64_t seed, size_t first_doc) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->dmode) QR_FAIL(c, QR_ERR_STATE, "qr_subsample_set_doc is for document-sharded contexts");
+  return subsample_set(c, subsample, seed, first_doc);
 }
 
 int qr_tree_set_max_features(qr_ctx *c, float max_features, uint64_t seed) {

@@ -411,7 +411,9 @@ struct qr_ctx {
   bool tree_open = false;
   int tree_step = 0;             // decides issued for the open tree
   // --subsample: documents per iteration (0 = all), the sampler's state and scratch
-  size_t sub_k = 0;
+  size_t sub_k = 0;              // documents per sample (over ALL ranks' documents on a document-sharded context)
+  size_t sub_n = 0;              // ... of which this context's own (== sub_k unless document-sharded)
+  size_t sub_first = 0;          // document-sharded: global index of this rank's first document
   uint64_t sub_seed = 0, sub_iter = 0;
   uint8_t *d_present = nullptr;
   uint32_t *d_sample_keys = nullptr;  // 4 x N: keys, ids, sorted keys, sorted ids

@@ -119,11 +119,6 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
                        const std::string &metric, size_t cutoff, size_t partial_save,
                        const std::string &output_basename, int ngpus, bool feature_sharded) {
   const bool obliv = algo_ >= OBVMART;
-  if (subsample_ != 1.0f && !feature_sharded) {
-    std::cerr << "!!! --gpus with --subsample needs --shard features (every rank then holds every document)."
-              << std::endl;
-    exit(EXIT_FAILURE);
-  }
   if (max_features_ != 1.0f || ensemble_model_.is_notempty() || nthresholds_ > 255 || nthresholds_ == 0 ||
       (obliv && subsample_ != 1.0f)) {
     // (nthresholds 0 = every distinct value: fine on one GPU, where the wide path takes over
@@ -216,7 +211,14 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       QRM(c, qr_bins_build_with(c, thr.data(), ts.data()));
     }
     QRM(c, qr_scores_reset(c));
-    if (subsample_ != 1.0f) QRM(c, qr_subsample_set(c, subsample_, sample_seed));  // the same draw on every rank
+    // the same draw on every rank: feature-sharded ranks hold every document; document-sharded
+    // ones draw from the keys of all ranks' documents and keep their own part
+    if (subsample_ != 1.0f) {
+      if (feature_sharded)
+        QRM(c, qr_subsample_set(c, subsample_, sample_seed));
+      else
+        QRM(c, qr_subsample_set_doc(c, subsample_, sample_seed, training->offset(tq0)));
+    }
     void *x_hist = nullptr, *x_scal = nullptr, *x_leaf = nullptr, *recs_local = nullptr, *recs_all = nullptr,
          *mask = nullptr;
     size_t n_hist = 0, n_scal = 0, n_leaf = 0, rec_bytes = 0, mask_bytes = 0;

@@ -225,6 +225,61 @@ def test_doc_sharded_oblivious_equals_single(world, cuts, depth, minls, F, algo)
     single.close()
 
 
+@pytest.mark.parametrize("world,cuts,algo,subsample", [
+    (2, [30], "lambda", 0.5),
+    (3, [5, 41], "lambda", 0.3),       # a small first shard: few (or none) of the sample's documents
+    (4, [15, 30, 45], "mart", 900.0),  # a number of documents instead of a fraction
+])
+def test_doc_sharded_subsample_equals_single(world, cuts, algo, subsample):
+    """--subsample over document shards: the key of a document is a function of its GLOBAL
+    index, so every rank finds the sample a single GPU draws from the whole set and keeps
+    its own part; trees (structure bit for bit) and the scores of ALL documents (mart.cc:345)
+    equal the single-context run."""
+    import torch
+    import quickrank_amd as qr
+    from quickrank_amd import build
+    build.build()
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=50, F=40, seed=31)
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(64)
+    single.reset_scores()
+    single.set_subsample(subsample, seed=11)
+    parts = _split_queries(qoff, cuts)
+    ctxs, thr, ts = _make_ctxs(qr, x, labels, qoff, parts, 64)
+    emu = _Emu(torch, ctxs)
+    for c, (q0, q1) in zip(ctxs, parts):
+        c.reset_scores()
+        c.set_subsample(subsample, seed=11, first_doc=int(qoff[q0]))
+    newton = algo == "lambda"
+    for it in range(4):
+        single.compute_lambdas("NDCG", 10) if newton else single.compute_residuals()
+        want = single.fit_tree(8, 2, newton)
+        single.update_scores(0.1)
+        for c in ctxs:
+            c.compute_lambdas("NDCG", 10) if newton else c.compute_residuals()
+        emu.allreduce("scal")
+        for c in ctxs:
+            c.lambda_finish()
+        got = _doc_fit(emu, ctxs, 8, 2, newton)
+        for c in ctxs:
+            c.update_scores(0.1)
+        for g in got:
+            assert len(g) == len(want), it
+            for k in ("feature", "thr_id", "left", "right", "nsamples", "threshold"):
+                assert np.array_equal(g[k], want[k]), (it, k)
+            assert np.allclose(g["value"], want["value"], rtol=1e-11, atol=1e-14), it
+        for g in got[1:]:
+            for k in want.dtype.names:
+                assert np.array_equal(g[k], got[0][k]), (it, k)
+    s1 = single.get_scores()
+    for c, (q0, q1) in zip(ctxs, parts):
+        d0, d1 = int(qoff[q0]), int(qoff[q1])
+        assert np.allclose(c.get_scores(), s1[d0:d1], rtol=1e-10, atol=1e-13)
+        c.close()
+    single.close()
+
+
 def test_doc_sharded_mart_residuals():
     """MART (mean leaves, residual pseudo-responses) through the same protocol."""
     import torch

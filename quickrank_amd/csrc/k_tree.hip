@@ -2569,13 +2569,13 @@ __device__ __forceinline__ void obl_level_body(QrTreeState *__restrict__ ts, con
                                                const int flocal,
                                                const QrScalars *__restrict__ scal,
                                                uint32_t *pick, const qr_split_t *__restrict__ recs_all,
-                                               const int world, const u64 Nglobal) {
+                                               const int world, const u64 Nglobal, const int root_buf) {
   const int lane = threadIdx.x;
   if (level == 0 && lane == 0) {
     QrNode *root = &ts->nodes[0];
     root->begin = 0;
     root->end = N;
-    root->buf = 2;
+    root->buf = root_buf;  // 2: every document, 0: this iteration's sample (its list)
     root->hslot = 0;
     root->feature = -1;
     root->thr_id = -1;
@@ -2628,7 +2628,7 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     const qr_split_t *__restrict__ featrec, const QrScalars *__restrict__ scal,
     const uint32_t *__restrict__ woff, const size_t wcells, const qr_split_t *__restrict__ recs_all,
     const int world, const uint32_t *__restrict__ lcounts, const uint32_t *__restrict__ hcnt_loc,
-    const u64 Nglobal) {
+    const u64 Nglobal, const int root_buf) {
   // (woff != null: wide-bin context -- ragged rows, no histogram plan: k_wide.hip's
   // launches are sized on the host.  recs_all / lcounts != null: feature-sharded -- the level's
   // split is the best of the ranks' records, and the nodes' left counts came with the mask)
@@ -2638,7 +2638,7 @@ __global__ __launch_bounds__(256) void k_obl_plan(
   // (hcnt_loc != null: document-sharded -- hcnt holds the counts over ALL ranks' documents,
   // which decide the split, the smaller side and the nodes' sizes; where the rank's own lists
   // are cut is a matter of its own counts)
-  if (threadIdx.x < 64) obl_level_body(ts, level, N, featrec, flocal, scal, pick, recs_all, world, Nglobal);
+  if (threadIdx.x < 64) obl_level_body(ts, level, N, featrec, flocal, scal, pick, recs_all, world, Nglobal, root_buf);
   __syncthreads();
   if (pick[0]) return;
   const int nodes = 1 << level;
@@ -3178,10 +3178,11 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
     const int last = level == (int)depth - 1;
     hipLaunchKernelGGL(k_obl_plan, dim3(1), dim3(256), 0, c->stream, c->d_tree, level, last,
                        c->ncu, c->flocal, c->d_hcnt, c->wide ? c->d_wthr : c->d_thr, c->d_gf2lf,
-                       c->d_blocks, c->nblocks, c->d_lhist_map, c->d_lpart_map, (uint32_t)c->N,
+                       c->d_blocks, c->nblocks, c->d_lhist_map, c->d_lpart_map,
+                       (uint32_t)(c->sub_k ? c->sub_n : c->N),
                        c->d_featrec, c->d_scalars, c->wide ? c->d_woff : (const uint32_t *)nullptr,
                        c->wcells, (const qr_split_t *)nullptr, 1, (const uint32_t *)nullptr,
-                       (const uint32_t *)nullptr, (u64)0);
+                       (const uint32_t *)nullptr, (u64)c->sub_k, c->sub_k ? 0 : 2);
     QR_CHECK(c, hipGetLastError());
     const unsigned pg = std::min<unsigned>(pgrid, (unsigned)(c->N / QR_PART_SLICE + nodes + 1));
     hipLaunchKernelGGL(k_partition_level, dim3(pg), dim3(256), 0, c->stream, c->d_tree,
@@ -3257,10 +3258,11 @@ int qr_k_obl_apply(qr_ctx *c, int level, int last) {
   const int nodes = 1 << level;
   hipLaunchKernelGGL(k_obl_plan, dim3(1), dim3(256), 0, c->stream, c->d_tree, level, last, c->ncu,
                      c->flocal, c->d_hcnt, c->d_thr, c->d_gf2lf, c->d_blocks, c->nblocks, c->d_lhist_map,
-                     c->d_lpart_map, (uint32_t)c->N, c->d_featrec, c->d_scalars, (const uint32_t *)nullptr,
+                     c->d_lpart_map, (uint32_t)(c->sub_k ? c->sub_n : c->N), c->d_featrec, c->d_scalars, (const uint32_t *)nullptr,
                      (size_t)0, c->dmode ? (const qr_split_t *)nullptr : c->d_recs_all, c->dmode ? 1 : c->world,
                      c->dmode ? (const uint32_t *)nullptr : c->d_mask + c->mask_words,
-                     c->dmode ? c->d_hcnt_loc : (const uint32_t *)nullptr, c->dmode ? (u64)c->Nglobal : (u64)0);
+                     c->dmode ? c->d_hcnt_loc : (const uint32_t *)nullptr,
+                     c->sub_k ? (u64)c->sub_k : (c->dmode ? (u64)c->Nglobal : (u64)0), c->sub_k ? 0 : 2);
   QR_CHECK(c, hipGetLastError());
   const unsigned pg = std::min<unsigned>((unsigned)c->lpart_cap, (unsigned)(c->N / QR_PART_SLICE + nodes + 1));
   hipLaunchKernelGGL(k_partition_level, dim3(pg), dim3(256), 0, c->stream, c->d_tree, c->d_lpart_map,

@@ -1231,7 +1231,6 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
     QR_FAIL(c, QR_ERR_STATE,
             "sharded contexts grow oblivious trees phase by phase (qr_obl_begin / propose / [mark] / "
             "apply with the collectives in between)");
-  if (c->sub_k) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling applies to leaf-wise trees in this round");
   if (depth < 1 || ((size_t)1 << (depth + 1)) - 1 > QR_MAXNODES)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
   int rc = ensure_hist_slots(c, ((size_t)1 << (depth + 1)) - 1);
@@ -1249,7 +1248,6 @@ int qr_obl_begin(qr_ctx *c, size_t depth, uint64_t minls) {
   if (!c) return QR_ERR_ARG;
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
   if (c->wide) QR_FAIL(c, QR_ERR_UNSUPPORTED, "the phase calls use u8 bins");
-  if (c->sub_k) QR_FAIL(c, QR_ERR_UNSUPPORTED, "subsampling applies to leaf-wise trees in this round");
   if (depth < 1 || ((size_t)1 << (depth + 1)) - 1 > QR_MAXNODES)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
   int rc = tree_settle(c);

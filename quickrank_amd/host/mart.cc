@@ -277,8 +277,8 @@ void Mart::learn(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::
   QR(qr_scores_reset(ctx_));
   const bool sampling = subsample_ != 1.0f || max_features_ != 1.0f;
   if (sampling) {
-    if (obliv) {
-      std::cerr << "!!! --subsample / --max-features apply to MART / LAMBDAMART in this build." << std::endl;
+    if (obliv && max_features_ != 1.0f) {  // (ObliviousRT::fit, ot.cc:32-201, has no feature sampling)
+      std::cerr << "!!! --max-features applies to MART / LAMBDAMART." << std::endl;
       exit(EXIT_FAILURE);
     }
     unsigned long long seed = sampling_seed_;

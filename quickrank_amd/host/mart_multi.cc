@@ -119,15 +119,13 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
                        const std::string &metric, size_t cutoff, size_t partial_save,
                        const std::string &output_basename, int ngpus, bool feature_sharded) {
   const bool obliv = algo_ >= OBVMART;
-  if (max_features_ != 1.0f || ensemble_model_.is_notempty() || nthresholds_ > 255 || nthresholds_ == 0 ||
-      (obliv && subsample_ != 1.0f)) {
+  if (max_features_ != 1.0f || ensemble_model_.is_notempty() || nthresholds_ > 255 || nthresholds_ == 0) {
     // (nthresholds 0 = every distinct value: fine on one GPU, where the wide path takes over
     // when a column has more than 255 of them; the sharded contexts use u8 bins)
     if (nthresholds_ == 0 || nthresholds_ > 255)
       std::cerr << "!!! --gpus > 1 needs --num-thresholds in [1, 255]." << std::endl;
     else
-      std::cerr << "!!! --gpus > 1 does not combine with --max-features / --restart-train, nor oblivious "
-                   "trees with --subsample." << std::endl;
+      std::cerr << "!!! --gpus > 1 does not combine with --max-features / --restart-train." << std::endl;
     exit(EXIT_FAILURE);
   }
   const int W = ngpus;

@@ -280,6 +280,48 @@ def test_doc_sharded_subsample_equals_single(world, cuts, algo, subsample):
     single.close()
 
 
+@pytest.mark.parametrize("world,cuts", [(2, [30]), (3, [5, 41])])
+def test_doc_sharded_oblivious_subsample_equals_single(world, cuts):
+    """Oblivious trees on a sample over document shards (both round-2 additions at once)."""
+    import torch
+    import quickrank_amd as qr
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=50, F=40, seed=33)
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(64)
+    single.reset_scores()
+    single.set_subsample(0.5, seed=13)
+    parts = _split_queries(qoff, cuts)
+    ctxs, thr, ts = _make_ctxs(qr, x, labels, qoff, parts, 64)
+    emu = _Emu(torch, ctxs)
+    for c, (q0, q1) in zip(ctxs, parts):
+        c.reset_scores()
+        c.set_subsample(0.5, seed=13, first_doc=int(qoff[q0]))
+    for it in range(3):
+        single.compute_lambdas("NDCG", 10)
+        want = single.fit_oblivious(4, 2, True)
+        single.update_scores(0.1)
+        for c in ctxs:
+            c.compute_lambdas("NDCG", 10)
+        emu.allreduce("scal")
+        for c in ctxs:
+            c.lambda_finish()
+        got = _doc_obl_fit(emu, ctxs, 4, 2, True)
+        for c in ctxs:
+            c.update_scores(0.1)
+        for g in got:
+            assert len(g) == len(want), it
+            for k in ("feature", "thr_id", "left", "right", "nsamples", "threshold"):
+                assert np.array_equal(g[k], want[k]), (it, k)
+            assert np.allclose(g["value"], want["value"], rtol=1e-11, atol=1e-14), it
+    s1 = single.get_scores()
+    for c, (q0, q1) in zip(ctxs, parts):
+        d0, d1 = int(qoff[q0]), int(qoff[q1])
+        assert np.allclose(c.get_scores(), s1[d0:d1], rtol=1e-10, atol=1e-13)
+        c.close()
+    single.close()
+
+
 def test_doc_sharded_mart_residuals():
     """MART (mean leaves, residual pseudo-responses) through the same protocol."""
     import torch

@@ -545,6 +545,45 @@ def test_subsample_iteration(qr, ora, algo, subsample):
     c.close()
 
 
+@pytest.mark.parametrize("algo", ["OBVLAMBDAMART", "OBVMART"])
+def test_subsample_oblivious_iteration(qr, ora, algo):
+    """--subsample with oblivious trees (ObliviousMart inherits Mart::learn's sampling,
+    mart.cc:287-329): the level-wise tree is grown on the sample's list; given the sample,
+    the tree equals the oracle's on those documents and every document's score is updated."""
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=40, F=24, seed=41, ragged=True)
+    N = len(labels)
+    c, thr, ts = _ctx(qr, x, labels, qoff, 64)
+    full = ora.Trainer(x, 64)
+    rng = np.random.default_rng(6)
+    c.set_scores(np.round(rng.standard_normal(N), 1))
+    c.set_subsample(0.4, seed=8)
+    k = int(np.floor(np.float32(0.4) * np.float32(N)))
+    newton = algo == "OBVLAMBDAMART"
+    for it in range(3):
+        s0 = c.get_scores()
+        c.compute_lambdas("NDCG", 10) if newton else c.compute_residuals()
+        lam, w = c.get_pseudo()
+        nodes = c.fit_oblivious(4, 2, newton)
+        parts = [c.node_samples(int(i)).astype(np.int64) for i in np.nonzero(nodes["feature"] == -1)[0]]
+        S = np.sort(np.concatenate(parts))
+        assert len(S) == k == nodes[0]["nsamples"] and np.all(np.diff(S) > 0)
+        st = _subset_trainer(ora, full, x, S)
+        ot = st.fit_tree(lam[S], minls=2, oblivious_depth=4)
+        st.update_output(ot, lam[S], w[S] if newton else None)
+        assert_tree_parity(st.stmap, ot["nodes"], nodes, value_rtol=1e-9)
+        c.update_scores(0.1)
+        walk = np.zeros(N, np.int64)
+        while True:
+            nd = nodes[walk]
+            idx = np.nonzero(nd["feature"] >= 0)[0]
+            if not len(idx):
+                break
+            go = x[idx, nd["feature"][idx]] <= nd["threshold"][idx]
+            walk[idx] = np.where(go, nd["left"][idx], nd["right"][idx])
+        assert np.array_equal(c.get_scores(), s0 + 0.1 * nodes["value"][walk])
+    c.close()
+
+
 def test_error_paths_return_codes_not_crashes(qr):
     """Every misuse of the C-ABI comes back as a QrError with a message (the host
     prints it and exits, as the reference does): nothing asserts or segfaults."""

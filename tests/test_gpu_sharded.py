@@ -212,6 +212,50 @@ def test_sharded_oblivious_equal_single(world, F, depth, minls, oracle_lib):
     single.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_oblivious_subsample_equal_single(world, oracle_lib):
+    """Oblivious trees on a sample, feature-sharded: every rank draws the same sample and grows
+    the single-context tree; every document's score is updated."""
+    import torch
+    import quickrank_amd as qr
+    x, labels, qoff = make_dataset(nq=70, docs_per_query=40, F=33, seed=29)
+
+    def run(ctxs):
+        trees = []
+        for c in ctxs:
+            c.reset_scores()
+            c.set_subsample(0.5, 21)
+        for it in range(3):
+            for c in ctxs:
+                c.compute_lambdas("NDCG", 10)
+            t = [ctxs[0].fit_oblivious(4, 2, True)] if ctxs[0].world == 1 else _sharded_obl_fit(torch, ctxs, 4, 2)
+            for c in ctxs:
+                c.update_scores(0.1)
+            trees.append(t)
+        return trees, [c.get_scores() for c in ctxs]
+
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(64)
+    want_t, want_s = run([single])
+    ctxs = []
+    for r in range(world):
+        c = qr.Context(0, rank=r, world=world)
+        c.upload(x, labels, qoff)
+        c.build_bins(64)
+        ctxs.append(c)
+    got_t, got_s = run(ctxs)
+    for it in range(3):
+        for g in got_t[it]:
+            for k in ("feature", "thr_id", "left", "right", "nsamples"):
+                assert np.array_equal(g[k], want_t[it][0][k]), (it, k)
+            assert np.allclose(g["value"], want_t[it][0]["value"], rtol=1e-12, atol=1e-15)
+    for s_ in got_s:
+        assert np.allclose(s_, want_s[0], rtol=1e-12, atol=1e-15)
+    for c in ctxs + [single]:
+        c.close()
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_subsample_equal_single(world, oracle_lib):
     """--subsample on feature-sharded ranks: every rank holds every document and draws the

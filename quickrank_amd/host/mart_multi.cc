@@ -119,13 +119,15 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
                        const std::string &metric, size_t cutoff, size_t partial_save,
                        const std::string &output_basename, int ngpus, bool feature_sharded) {
   const bool obliv = algo_ >= OBVMART;
-  if (max_features_ != 1.0f || ensemble_model_.is_notempty() || nthresholds_ > 255 || nthresholds_ == 0) {
+  if ((max_features_ != 1.0f && obliv) || ensemble_model_.is_notempty() || nthresholds_ > 255 ||
+      nthresholds_ == 0) {
     // (nthresholds 0 = every distinct value: fine on one GPU, where the wide path takes over
     // when a column has more than 255 of them; the sharded contexts use u8 bins)
     if (nthresholds_ == 0 || nthresholds_ > 255)
       std::cerr << "!!! --gpus > 1 needs --num-thresholds in [1, 255]." << std::endl;
     else
-      std::cerr << "!!! --gpus > 1 does not combine with --max-features / --restart-train." << std::endl;
+      std::cerr << "!!! --gpus > 1 does not combine with --restart-train; --max-features applies to "
+                   "MART / LAMBDAMART." << std::endl;
     exit(EXIT_FAILURE);
   }
   const int W = ngpus;
@@ -157,7 +159,7 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
   const size_t maxnodes = obliv ? ((size_t)1 << (treedepth_ + 1)) : 2 * nleaves_ + 1;
   sh.nodes0.resize(maxnodes);
   unsigned long long sample_seed = sampling_seed_;
-  if (subsample_ != 1.0f && sample_seed == 0)  // the reference seeds from the clock at every draw
+  if ((subsample_ != 1.0f || max_features_ != 1.0f) && sample_seed == 0)  // the reference seeds from the clock at every draw
     sample_seed = (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count();
   std::chrono::high_resolution_clock::time_point t_train0;
 
@@ -209,6 +211,9 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       QRM(c, qr_bins_build_with(c, thr.data(), ts.data()));
     }
     QRM(c, qr_scores_reset(c));
+    // --max-features (rt.cc:222-243): a node's subset is a function of (seed, tree, node, feature):
+    // the same on every rank
+    if (max_features_ != 1.0f) QRM(c, qr_tree_set_max_features(c, max_features_, sample_seed));
     // the same draw on every rank: feature-sharded ranks hold every document; document-sharded
     // ones draw from the keys of all ranks' documents and keep their own part
     if (subsample_ != 1.0f) {

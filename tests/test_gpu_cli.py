@@ -364,7 +364,8 @@ def test_quicklearn_gpus_flag_runs_the_sharded_protocol(tools, tmp_path, algo, s
 
 @pytest.mark.parametrize("extra", [["--algo", "OBVLAMBDAMART", "--tree-depth", "4"],
                                    ["--algo", "LAMBDAMART", "--num-leaves", "8", "--subsample", "0.5", "--seed", "5"],
-                                   ["--algo", "OBVMART", "--tree-depth", "3", "--subsample", "0.6", "--seed", "9"]])
+                                   ["--algo", "OBVMART", "--tree-depth", "3", "--subsample", "0.6", "--seed", "9"],
+                                   ["--algo", "LAMBDAMART", "--num-leaves", "8", "--max-features", "0.4", "--seed", "3"]])
 def test_quicklearn_gpus_features_oblivious_and_subsample(tools, tmp_path, extra):
     """Oblivious trees and --subsample on the multi-GPU host in the feature layout
     (`--shard features`: every rank holds every document); with one rank the model must be

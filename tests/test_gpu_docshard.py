@@ -280,6 +280,42 @@ def test_doc_sharded_subsample_equals_single(world, cuts, algo, subsample):
     single.close()
 
 
+def test_doc_sharded_max_features_equals_single():
+    """--max-features over document shards: the same per-node feature subsets on every rank."""
+    import torch
+    import quickrank_amd as qr
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=50, F=40, seed=35)
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(64)
+    single.reset_scores()
+    single.set_max_features(0.3, seed=7)
+    parts = _split_queries(qoff, [20, 45])
+    ctxs, thr, ts = _make_ctxs(qr, x, labels, qoff, parts, 64)
+    emu = _Emu(torch, ctxs)
+    for c in ctxs:
+        c.reset_scores()
+        c.set_max_features(0.3, seed=7)
+    for it in range(3):
+        single.compute_lambdas("NDCG", 10)
+        want = single.fit_tree(8, 2, True)
+        single.update_scores(0.1)
+        for c in ctxs:
+            c.compute_lambdas("NDCG", 10)
+        emu.allreduce("scal")
+        for c in ctxs:
+            c.lambda_finish()
+        got = _doc_fit(emu, ctxs, 8, 2, True)
+        for c in ctxs:
+            c.update_scores(0.1)
+        for g in got:
+            for k in ("feature", "thr_id", "left", "right", "nsamples", "threshold"):
+                assert np.array_equal(g[k], want[k]), (it, k)
+            assert np.allclose(g["value"], want["value"], rtol=1e-11, atol=1e-14), it
+    for c in ctxs + [single]:
+        c.close()
+
+
 @pytest.mark.parametrize("world,cuts", [(2, [30]), (3, [5, 41])])
 def test_doc_sharded_oblivious_subsample_equals_single(world, cuts):
     """Oblivious trees on a sample over document shards (both round-2 additions at once)."""

@@ -213,6 +213,44 @@ def test_sharded_oblivious_equal_single(world, F, depth, minls, oracle_lib):
 
 
 @pytest.mark.parametrize("world", [2, 3])
+def test_sharded_max_features_equal_single(world, oracle_lib):
+    """--max-features on feature-sharded ranks: a node's feature subset is a function of
+    (seed, tree, node, feature), the same on every rank; trees equal the single-context ones."""
+    import torch
+    import quickrank_amd as qr
+    x, labels, qoff = make_dataset(nq=70, docs_per_query=40, F=33, seed=31)
+    rng = np.random.default_rng(4)
+    lam, w = oracle_lib.lambdas(labels, rng.standard_normal(len(labels)) * 0.3, qoff)
+
+    def run(ctxs):
+        out = []
+        for c in ctxs:
+            c.set_pseudo(lam, w)
+            c.set_max_features(0.3, seed=5)
+        for it in range(3):
+            out.append([ctxs[0].fit_tree(8, 2, True)] if ctxs[0].world == 1 else _sharded_fit(torch, ctxs, 8, 2))
+        return out
+
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(64)
+    want = run([single])
+    ctxs = []
+    for r in range(world):
+        c = qr.Context(0, rank=r, world=world)
+        c.upload(x, labels, qoff)
+        c.build_bins(64)
+        ctxs.append(c)
+    got = run(ctxs)
+    for it in range(3):
+        for g in got[it]:
+            for k in want[it][0].dtype.names:
+                assert np.array_equal(g[k], want[it][0][k]), (it, k)
+    for c in ctxs + [single]:
+        c.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
 def test_sharded_oblivious_subsample_equal_single(world, oracle_lib):
     """Oblivious trees on a sample, feature-sharded: every rank draws the same sample and grows
     the single-context tree; every document's score is updated."""

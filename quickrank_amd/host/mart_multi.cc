@@ -119,15 +119,13 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
                        const std::string &metric, size_t cutoff, size_t partial_save,
                        const std::string &output_basename, int ngpus, bool feature_sharded) {
   const bool obliv = algo_ >= OBVMART;
-  if ((max_features_ != 1.0f && obliv) || ensemble_model_.is_notempty() || nthresholds_ > 255 ||
-      nthresholds_ == 0) {
+  if ((max_features_ != 1.0f && obliv) || nthresholds_ > 255 || nthresholds_ == 0) {
     // (nthresholds 0 = every distinct value: fine on one GPU, where the wide path takes over
     // when a column has more than 255 of them; the sharded contexts use u8 bins)
     if (nthresholds_ == 0 || nthresholds_ > 255)
       std::cerr << "!!! --gpus > 1 needs --num-thresholds in [1, 255]." << std::endl;
     else
-      std::cerr << "!!! --gpus > 1 does not combine with --restart-train; --max-features applies to "
-                   "MART / LAMBDAMART." << std::endl;
+      std::cerr << "!!! --max-features applies to MART / LAMBDAMART." << std::endl;
     exit(EXIT_FAILURE);
   }
   const int W = ngpus;
@@ -162,6 +160,19 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
   if ((subsample_ != 1.0f || max_features_ != 1.0f) && sample_seed == 0)  // the reference seeds from the clock at every draw
     sample_seed = (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count();
   std::chrono::high_resolution_clock::time_point t_train0;
+
+  // restart from a previously saved model (mart.cc:237-253): its scores of the training and
+  // validation documents, computed once; every rank starts from its own part of them
+  const size_t first = ensemble_model_.get_size();
+  std::vector<Score> rs_train, rs_valid;
+  if (first) {
+    rs_train.resize(N);
+    score_dataset(*training, rs_train.data());
+    if (validation) {
+      rs_valid.resize(validation->num_instances());
+      score_dataset(*validation, rs_valid.data());
+    }
+  }
 
   auto worker = [&](const int r) {
     qr_ctx *c = nullptr;
@@ -211,6 +222,10 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       QRM(c, qr_bins_build_with(c, thr.data(), ts.data()));
     }
     QRM(c, qr_scores_reset(c));
+    if (first) {
+      QRM(c, qr_scores_set(c, rs_train.data() + (feature_sharded ? 0 : training->offset(tq0))));
+      if (has_valid) QRM(c, qr_valid_scores_set(c, rs_valid.data() + (feature_sharded ? 0 : validation->offset(vq0))));
+    }
     // --max-features (rt.cc:222-243): a node's subset is a function of (seed, tree, node, feature):
     // the same on every rank
     if (max_features_ != 1.0f) QRM(c, qr_tree_set_max_features(c, max_features_, sample_seed));
@@ -289,10 +304,23 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       }
     };
     std::vector<qr_node_t> nodes(maxnodes);
+    if (first) {  // the loaded model is the best one so far (mart.cc:244-253)
+      const MetricScore mt = metric_all(0);
+      MetricScore mv = 0;
+      if (validation) mv = metric_all(1);
+      best_train_r_[r] = mt;
+      if (validation) best_valid_r_[r] = mv;
+      best_model_r_[r] = first - 1;
+      if (r == 0) {
+        std::cout << std::setw(7) << first << std::setw(9) << mt;
+        if (validation) std::cout << std::setw(9) << mv;
+        std::cout << " *" << std::endl;
+      }
+    }
     // as Mart::learn: the metric rides with the next lambda pass (a sampled ranking is not the metric's)
     const bool lagged = lambda && !validation && subsample_ == 1.0f;
     size_t built = 0;
-    for (size_t m = 0; m < ntrees_; ++m) {
+    for (size_t m = first; m < ntrees_; ++m) {
       if (validation && (valid_iterations_ && m > best_model_r_[r] + valid_iterations_)) break;
       // ---- pseudo-responses
       if (lambda)
@@ -381,7 +409,7 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       ++built;
       // ---- metrics, best model, early stop (mart.cc:347-376)
       if (lagged) {
-        if (m > 0) {
+        if (m > first) {
           MetricScore prev = 0;
           QRM(c, qr_metric_last(c, &prev));  // of the scores this iteration's lambda pass ranked
           report(m, prev, nullptr);
@@ -397,7 +425,7 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
     }
     if (lagged && built) {
       const MetricScore last = metric_all(0);
-      report(built, last, nullptr);
+      report(first + built, last, nullptr);
     }
     QRM(c, qr_synchronize(c));
     sh.bar.wait();

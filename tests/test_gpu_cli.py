@@ -188,6 +188,40 @@ def test_restart_train_continues_the_same_model(tools, tmp_path, with_valid):
         assert np.allclose(a["value"], b["value"], rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("shard", ["docs", "features"])
+def test_restart_train_on_the_multi_gpu_host(tools, tmp_path, shard):
+    """--restart-train with --gpus N: the loaded model's scores (training and validation) are
+    computed once and every rank starts from its part of them; the continued model equals
+    the single-GPU continuation."""
+    x, labels, qoff = make_dataset(nq=100, docs_per_query=40, F=20, seed=13)
+    x = np.array([[np.float32(f"{float(v):.9g}") for v in row] for row in x], np.float32)
+    vx, vl, vq = make_dataset(nq=30, docs_per_query=30, F=20, seed=14)
+    tr, va = str(tmp_path / "train.svml"), str(tmp_path / "valid.svml")
+    _write_svml(tr, x, labels, qoff)
+    _write_svml(va, vx, vl, vq)
+    common = [tools["quicklearn"], "--algo", "LAMBDAMART", "--train", tr, "--valid", va, "--num-leaves", "8",
+              "--num-thresholds", "64", "--min-leaf-support", "5", "--end-after-rounds", "0"]
+    part, one, multi = (str(tmp_path / n) for n in ("part.xml", "one.xml", "multi.xml"))
+    r = subprocess.run(common + ["--num-trees", "3", "--model-out", part], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cont = ["--num-trees", "6", "--model-in", part, "--restart-train"]
+    a = subprocess.run(common + cont + ["--model-out", one], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run(common + cont + ["--model-out", multi, "--gpus", "1", "--shard", shard],
+                       capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stdout + b.stderr
+    t1 = [l for l in a.stdout.splitlines() if l[:7].strip().isdigit()]
+    t2 = [l for l in b.stdout.splitlines() if l[:7].strip().isdigit()]
+    assert t1 == t2 and len(t1) >= 2          # the reloaded model's line, then the added iterations
+    n1, w1 = _load_model(tools, one)
+    n2, w2 = _load_model(tools, multi)
+    assert n1.shape == n2.shape and np.array_equal(w1, w2)
+    for k in ("feature", "left", "right"):
+        assert np.array_equal(n1[k], n2[k]), k
+    assert np.array_equal(n1["threshold"].view(np.uint32), n2["threshold"].view(np.uint32))
+    assert np.allclose(n1["value"], n2["value"], rtol=1e-9, atol=1e-12)
+
+
 def test_quicklearn_sampling_flags(tools, tmp_path):
     """--subsample / --max-features / --seed: accepted for the leaf-wise algorithms,
     written to the model's <info>, reproducible for a given seed, different for another."""

@@ -246,9 +246,10 @@ def test_quicklearn_sampling_flags(tools, tmp_path):
     # every iteration prints its training metric (evaluated on all documents)
     rows = [ln.split() for ln in out.splitlines() if ln.split() and ln.split()[0].isdigit()]
     assert [int(r[0]) for r in rows] == [1, 2, 3, 4] and all(0.0 < float(r[1]) <= 1.0 for r in rows)
-    r = subprocess.run([tools["quicklearn"], "--algo", "OBVLAMBDAMART", "--train", tr, "--subsample", "0.5",
+    # oblivious trees take samples too; feature subsets are a leaf-wise notion (rt.cc:222-243)
+    r = subprocess.run([tools["quicklearn"], "--algo", "OBVLAMBDAMART", "--train", tr, "--max-features", "0.5",
                         "--num-thresholds", "64"], capture_output=True, text=True)
-    assert r.returncode != 0 and "apply to MART / LAMBDAMART" in r.stderr
+    assert r.returncode != 0 and "applies to MART / LAMBDAMART" in r.stderr
 
 
 def test_detailed_partial_scores_and_narrow_files(tools, oracle_lib, tmp_path):

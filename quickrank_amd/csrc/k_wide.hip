@@ -746,7 +746,8 @@ int qr_k_whist_scan(qr_ctx *c, int root_mode) {
                      c->wcells, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, c->d_hsum,
                      c->d_hcnt);
   QR_CHECK(c, hipGetLastError());
-  if (c->wmax <= QR_WCHUNK) {  // short rows: one workgroup per feature
+  const bool no_chunks = getenv("QR_WIDE_NO_CHUNKS") != nullptr;  // (A/B aid: same records either way)
+  if (c->wmax <= QR_WCHUNK || no_chunks) {  // short rows: one workgroup per feature
     hipLaunchKernelGGL(k_wscan, dim3((unsigned)c->flocal), dim3(1024), 0, c->stream, c->d_tree, mode,
                        c->d_woff, c->wcells, c->d_hsum, c->d_hcnt, c->flocal, c->d_lf2gf, c->d_wthr,
                        c->d_scalars, c->d_featrec, c->d_featthr);

@@ -346,3 +346,36 @@ def test_config1_mslr_standin_1024_thresholds_vs_oracle(oracle_lib):
     assert np.allclose(gm.train_metric, om["train_metric"], rtol=1e-10, atol=0)
     assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-8, atol=1e-12)
     gm.ctx.close()
+
+
+def test_wide_chunked_scan_equals_whole_row_scan(monkeypatch):
+    """--num-thresholds 0 on the MSLR-shaped stand-in (rows of up to ~700k slots, 67 M cells per
+    node histogram): the chunked scan of long rows (k_wscan_tot / _chunk / _best) leaves the
+    records of the one-workgroup-per-feature scan -- every field of every node of three trees."""
+    import quickrank_amd as qr
+    from datagen import make_mslr_like
+    x, labels, qoff = make_mslr_like()
+
+    def run():
+        c = qr.Context(0)
+        c.upload(x, labels, qoff)
+        thr, ts = c.build_bins(0)
+        assert c.wide and int(ts.max()) > 100000
+        c.reset_scores()
+        trees = []
+        for it in range(3):
+            c.compute_lambdas("NDCG", 10)
+            trees.append(c.fit_tree(10, 1, True))
+            c.update_scores(0.1)
+        s = c.get_scores()
+        c.close()
+        return trees, s
+
+    monkeypatch.delenv("QR_WIDE_NO_CHUNKS", raising=False)
+    a, sa = run()
+    monkeypatch.setenv("QR_WIDE_NO_CHUNKS", "1")
+    b, sb = run()
+    for ta, tb in zip(a, b):
+        for k in ta.dtype.names:
+            assert np.array_equal(ta[k], tb[k]), k
+    assert np.array_equal(sa, sb)

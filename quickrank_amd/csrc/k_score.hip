@@ -258,13 +258,21 @@ __global__ __launch_bounds__(256) void k_doc_bins(const float *__restrict__ x, c
   }
 }
 
-template <typename BT, int NW>
+// SELF: the node array of a tree holds its leaves too, as nodes that lead to themselves
+// ({offset 0, slot 0xffff, left = right = own index}, entries NIint .. NIint + NL), and an
+// internal node carries the BYTE OFFSET of its feature's bin row instead of the feature.  A
+// step is then the same four operations for every chain, finished or not -- node address,
+// bin address, compare, pick a child -- instead of twelve with the leaf test, the index
+// clamp and the field unpacking (the walk was VALU-bound: 12.6 wave instructions per node
+// visit); a wave's chains are done when the smallest index is a leaf's.  NI = entries per
+// tree in `cnodes` (internal + leaves).  Used whenever a feature row's offset fits 16 bits.
+template <typename BT, int NW, bool SELF>
 __global__ __launch_bounds__(NW * 64) void k_score_bin(
     const BT *__restrict__ bins, const uint32_t N, const uint32_t F,
     const CNode *__restrict__ cnodes, const double *__restrict__ cleaves,
     const uint16_t *__restrict__ root_code, const double *__restrict__ weights,
     const uint32_t ntrees, const uint32_t NI, const uint32_t NL, const uint32_t tbatch,
-    double *__restrict__ out) {
+    const uint32_t NIint, double *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t doc_bytes = ((size_t)F * 64 * sizeof(BT) + 15) & ~(size_t)15;
@@ -314,6 +322,45 @@ __global__ __launch_bounds__(NW * 64) void k_score_bin(
       return leaf ? c : nxt;
     };
     uint32_t t = 0;
+    if (SELF) {
+      const char *mybytes = reinterpret_cast<const char *>(mybins) + lane * sizeof(BT);
+      auto step2 = [&](const uint32_t c, const unsigned long long *nodes) -> uint32_t {
+        const uint2 nd = *reinterpret_cast<const uint2 *>(nodes + c);
+        const uint32_t bv = *reinterpret_cast<const BT *>(mybytes + (nd.x & 0xffffu));
+        return bv <= (nd.x >> 16) ? (nd.y & 0xffffu) : (nd.y >> 16);
+      };
+      for (; t + 8 <= nb; t += 8) {
+        uint32_t c[8];
+        const unsigned long long *nn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          c[j] = lr[t + j];
+          nn[j] = ln64 + (size_t)(t + j) * NI;
+        }
+        for (;;) {
+          uint32_t mn = c[0];
+#pragma unroll
+          for (int j = 1; j < 8; ++j) mn = mn < c[j] ? mn : c[j];
+          if (!__any(mn < NIint)) break;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) c[j] = step2(c[j], nn[j]);
+        }
+        const double *l0 = lv + (size_t)t * NL;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const double v = l0[j * NL + (c[j] - NIint)] * lw[t + j];
+          sum = sum + v;
+        }
+      }
+      for (; t < nb; ++t) {
+        uint32_t c0 = lr[t];
+        const unsigned long long *n0 = ln64 + (size_t)t * NI;
+        while (__any(c0 < NIint)) c0 = step2(c0, n0);
+        const double v0 = lv[(size_t)t * NL + (c0 - NIint)] * lw[t];
+        sum = sum + v0;
+      }
+      continue;
+    }
     for (; t + 8 <= nb; t += 8) {
       uint32_t c[8];
       const unsigned long long *nn[8];
@@ -372,15 +419,27 @@ static int launch_binned_nw(qr_ctx *c, const float *d_x, size_t N, size_t xstrid
                             size_t tbatch) {
   const size_t F = c->sb_F;
   const size_t doc_bytes = (F * 64 * sizeof(BT) + 15) & ~(size_t)15;
-  const size_t per_tree = c->sb_NL * 8 + c->sb_NI * 8 + 8 + 2;
+  const size_t NN = c->sb_self ? c->sb_NI + c->sb_NL : c->sb_NI;  // node entries per tree
+  const size_t per_tree = c->sb_NL * 8 + NN * 8 + 8 + 2;
   const size_t lds = NW * doc_bytes + tbatch * per_tree + 64;
   const size_t nblk = (N + 63) / 64;
-  QR_CHECK(c, hipFuncSetAttribute((const void *)k_score_bin<BT, NW>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_score_bin<BT, NW>), dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds,
-                     c->stream, (const BT *)c->d_sb_bins, (uint32_t)N, (uint32_t)F,
-                     (const CNode *)c->d_sb_nodes, c->d_sb_leaves, c->d_sb_root, c->d_ens_w,
-                     (uint32_t)c->ens_trees, (uint32_t)c->sb_NI, (uint32_t)c->sb_NL, (uint32_t)tbatch, d_out);
+  if (c->sb_self) {
+    QR_CHECK(c, hipFuncSetAttribute((const void *)k_score_bin<BT, NW, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_score_bin<BT, NW, true>), dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds,
+                       c->stream, (const BT *)c->d_sb_bins, (uint32_t)N, (uint32_t)F,
+                       (const CNode *)c->d_sb_nodes, c->d_sb_leaves, c->d_sb_root, c->d_ens_w,
+                       (uint32_t)c->ens_trees, (uint32_t)NN, (uint32_t)c->sb_NL, (uint32_t)tbatch,
+                       (uint32_t)c->sb_NI, d_out);
+  } else {
+    QR_CHECK(c, hipFuncSetAttribute((const void *)k_score_bin<BT, NW, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_score_bin<BT, NW, false>), dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds,
+                       c->stream, (const BT *)c->d_sb_bins, (uint32_t)N, (uint32_t)F,
+                       (const CNode *)c->d_sb_nodes, c->d_sb_leaves, c->d_sb_root, c->d_ens_w,
+                       (uint32_t)c->ens_trees, (uint32_t)NN, (uint32_t)c->sb_NL, (uint32_t)tbatch,
+                       (uint32_t)c->sb_NI, d_out);
+  }
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -389,7 +448,7 @@ template <typename BT>
 static int launch_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, double *d_out) {
   const size_t F = c->sb_F;  // features the model tests; the rows may be wider
   const size_t doc_bytes = (F * 64 * sizeof(BT) + 15) & ~(size_t)15;
-  const size_t per_tree = c->sb_NL * 8 + c->sb_NI * 8 + 8 + 2;
+  const size_t per_tree = c->sb_NL * 8 + (c->sb_self ? c->sb_NI + c->sb_NL : c->sb_NI) * 8 + 8 + 2;
   const size_t budget = 160 * 1024 - 1024;
   // tree batch: 16..32 trees; the rest of the LDS goes to document blocks (occupancy)
   size_t tbatch = 32;

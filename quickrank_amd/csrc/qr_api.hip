@@ -1505,23 +1505,38 @@ static int build_binned_model(qr_ctx *c, const qr_node_t *nodes, size_t ntrees, 
     tmax = std::max(tmax, v.size());
   }
   if (tmax > 65535) return QR_OK;
-  std::vector<uint16_t> cn(ntrees * NI * 4, 0), root(ntrees, 0);
+  // Self-looping leaves (k_score_bin<.., SELF>): the node array holds NI internal entries and
+  // NL leaf entries per tree, children are plain indices into it, and an internal node names
+  // the byte offset of its feature's bin row -- whenever that offset fits 16 bits.
+  const size_t bt_size = tmax <= 255 ? 1 : 2;
+  const bool self = (F - 1) * 64 * bt_size <= 0xffff && NI + NL <= 0xffff;
+  const size_t NN = self ? NI + NL : NI;
+  std::vector<uint16_t> cn(ntrees * NN * 4, 0), root(ntrees, 0);
   std::vector<double> leaves(ntrees * NL, 0.0);
   for (size_t t = 0; t < ntrees; ++t) {
     const qr_node_t *n = nodes + t * max_nodes;
     std::vector<int> idx(max_nodes, -1);
     size_t ni = 0, nl = 0;
-    for (int i : order[t]) idx[i] = n[i].feature >= 0 ? (int)ni++ : (int)(0x8000 | nl++);
+    for (int i : order[t])
+      idx[i] = n[i].feature >= 0 ? (int)ni++ : (self ? (int)(NI + nl++) : (int)(0x8000 | nl++));
     for (int i : order[t]) {
       if (n[i].feature >= 0) {
-        uint16_t *o = &cn[(t * NI + idx[i]) * 4];
+        uint16_t *o = &cn[(t * NN + idx[i]) * 4];
         const auto &v = thr[n[i].feature];
-        o[0] = (uint16_t)n[i].feature;
+        o[0] = self ? (uint16_t)((size_t)n[i].feature * 64 * bt_size) : (uint16_t)n[i].feature;
         o[1] = (uint16_t)(std::lower_bound(v.begin(), v.end(), n[i].threshold) - v.begin());
         o[2] = (uint16_t)idx[n[i].left];
         o[3] = (uint16_t)idx[n[i].right];
-      } else
-        leaves[t * NL + (idx[i] & 0x7fff)] = n[i].value;
+      } else {
+        const size_t li = self ? (size_t)idx[i] - NI : (size_t)(idx[i] & 0x7fff);
+        leaves[t * NL + li] = n[i].value;
+        if (self) {
+          uint16_t *o = &cn[(t * NN + idx[i]) * 4];
+          o[0] = 0;
+          o[1] = 0xffff;  // any bin <= 0xffff: the walk stays here
+          o[2] = o[3] = (uint16_t)idx[i];
+        }
+      }
     }
     root[t] = (uint16_t)idx[0];
   }
@@ -1549,6 +1564,7 @@ static int build_binned_model(qr_ctx *c, const qr_node_t *nodes, size_t ntrees, 
   c->sb_NL = NL;
   c->sb_tmax = tmax;
   c->sb_u8 = tmax <= 255;
+  c->sb_self = self;
   c->sb_ready = true;
   return QR_OK;
 }

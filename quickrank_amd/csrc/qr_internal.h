@@ -432,6 +432,7 @@ struct qr_ctx {
   // compact binned form of the ensemble (k_score_bin)
   bool sb_ready = false, sb_u8 = false;
   size_t sb_F = 0, sb_NI = 0, sb_NL = 0, sb_tmax = 0, sb_bins_bytes = 0;
+  bool sb_self = false;          // the node array holds the leaves too (self-looping), k_score.hip
   void *d_sb_nodes = nullptr, *d_sb_bins = nullptr;
   double *d_sb_leaves = nullptr;
   uint16_t *d_sb_root = nullptr;

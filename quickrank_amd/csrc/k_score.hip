@@ -414,6 +414,111 @@ __global__ __launch_bounds__(NW * 64) void k_score_bin(
   if (have && doc < N) out[doc] = sum;
 }
 
+// The same walk on 4-BYTE node records, for models with u8 bins, a bin-row offset that fits
+// 16 bits and trees of at most 255 nodes (any leaf-wise tree of up to 128 leaves trained with
+// up to 255 thresholds): {row offset : 16, slot : 8, left child : 8}, the nodes of a tree in
+// RIGHT-first preorder so that the right child of node c is node c + 1 and only the left one
+// needs naming; a leaf is {0, 255, itself} (every bin is <= 255: the walk stays).  Half the
+// LDS bytes per step of the 8-byte record, and the same five instructions (node address, bin
+// address and compare through SDWA sub-word operands, c + 1, pick).  There is no leaf
+// test at all: a group of trees runs for as many steps as its deepest tree has levels (known
+// from the model), finished chains idle on their leaves.  Leaf values sit at the leaves'
+// own positions (`cleaves` is [tree][NN]).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_score_p4(
+    const uint8_t *__restrict__ bins, const uint32_t N, const uint32_t F,
+    const uint32_t *__restrict__ cnodes, const double *__restrict__ cleaves,
+    const uint8_t *__restrict__ depths, const double *__restrict__ weights, const uint32_t ntrees,
+    const uint32_t NN, const uint32_t tbatch, double *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t doc_bytes = ((size_t)F * 64 + 15) & ~(size_t)15;
+  uint8_t *mybins = reinterpret_cast<uint8_t *>(smem + wave * doc_bytes);
+  char *tb = smem + NW * doc_bytes;
+  double *lv = reinterpret_cast<double *>(tb);                              // [tbatch][NN]
+  double *lw = lv + (size_t)tbatch * NN;                                    // [tbatch]
+  uint32_t *ln = reinterpret_cast<uint32_t *>(lw + tbatch);                 // [tbatch][NN]
+  uint8_t *ld = reinterpret_cast<uint8_t *>(ln + (size_t)tbatch * NN);      // [tbatch]
+  const uint32_t nblocks = (N + 63) / 64;
+  const uint32_t blk = blockIdx.x * NW + wave;
+  const bool have = blk < nblocks;
+  if (have) {
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(bins + (size_t)blk * 64 * F);
+    uint4 *d4 = reinterpret_cast<uint4 *>(mybins);
+    const uint32_t n16 = (uint32_t)(F * 64 / 16);
+    for (uint32_t i = lane; i < n16; i += 64) d4[i] = s4[i];
+  }
+  const uint32_t doc = blk * 64 + lane;
+  const uint8_t *mybytes = mybins + lane;
+  double sum = 0.0;
+  for (uint32_t t0 = 0; t0 < ntrees; t0 += tbatch) {
+    const uint32_t nb = t0 + tbatch <= ntrees ? tbatch : ntrees - t0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb * NN; i += NW * 64) {
+      lv[i] = cleaves[(size_t)t0 * NN + i];
+      ln[i] = cnodes[(size_t)t0 * NN + i];
+    }
+    for (uint32_t i = threadIdx.x; i < nb; i += NW * 64) {
+      lw[i] = weights[t0 + i];
+      ld[i] = depths[t0 + i];
+    }
+    __syncthreads();
+    if (!have) continue;
+    auto step = [&](const uint32_t c, const uint32_t *nodes) -> uint32_t {
+      const uint32_t nd = nodes[c];
+      const uint32_t bv = mybytes[nd & 0xffffu];
+      return bv <= ((nd >> 16) & 0xffu) ? (nd >> 24) : c + 1;
+    };
+    uint32_t t = 0;
+    for (; t + 8 <= nb; t += 8) {
+      uint32_t c[8];
+      const uint32_t *nn[8];
+      uint32_t steps = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        c[j] = 0;
+        nn[j] = ln + (size_t)(t + j) * NN;
+        steps = steps > ld[t + j] ? steps : (uint32_t)ld[t + j];
+      }
+      for (uint32_t k = 0; k < steps; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = step(c[j], nn[j]);
+      }
+      const double *l0 = lv + (size_t)t * NN;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double v = l0[j * NN + c[j]] * lw[t + j];
+        sum = sum + v;
+      }
+    }
+    for (; t < nb; ++t) {
+      uint32_t c0 = 0;
+      const uint32_t *n0 = ln + (size_t)t * NN;
+      for (uint32_t k = 0; k < ld[t]; ++k) c0 = step(c0, n0);
+      const double v0 = lv[(size_t)t * NN + c0] * lw[t];
+      sum = sum + v0;
+    }
+  }
+  if (have && doc < N) out[doc] = sum;
+}
+
+template <int NW>
+static int launch_p4_nw(qr_ctx *c, size_t N, double *d_out, size_t tbatch) {
+  const size_t F = c->sb_F;
+  const size_t doc_bytes = (F * 64 + 15) & ~(size_t)15;
+  const size_t per_tree = c->p4_NN * 12 + 8 + 1;
+  const size_t lds = NW * doc_bytes + tbatch * per_tree + 64;
+  const size_t nblk = (N + 63) / 64;
+  QR_CHECK(c, hipFuncSetAttribute((const void *)k_score_p4<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+  hipLaunchKernelGGL((k_score_p4<NW>), dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds, c->stream,
+                     (const uint8_t *)c->d_sb_bins, (uint32_t)N, (uint32_t)F, c->d_p4_nodes, c->d_p4_leaves,
+                     c->d_p4_depth, c->d_ens_w, (uint32_t)c->ens_trees, (uint32_t)c->p4_NN, (uint32_t)tbatch,
+                     d_out);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
 template <typename BT, int NW>
 static int launch_binned_nw(qr_ctx *c, const float *d_x, size_t N, size_t xstride, double *d_out,
                             size_t tbatch) {
@@ -474,6 +579,21 @@ static int launch_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, 
                      dim3(256), lds_a, c->stream, d_x, (uint32_t)N, (uint32_t)F, (uint32_t)xstride,
                      c->d_sb_thr, c->d_sb_thr_cnt, (uint32_t)c->sb_tmax, lds_thr, (BT *)c->d_sb_bins, 0u);
   QR_CHECK(c, hipGetLastError());
+  if (sizeof(BT) == 1 && c->p4_ready) {  // 4-byte node records (k_score_p4)
+    const size_t per4 = c->p4_NN * 12 + 8 + 1;
+    size_t tb4 = 32;
+    while (tb4 > 8 && 4 * doc_bytes + tb4 * per4 + 64 > budget) tb4 -= 8;
+    if (4 * doc_bytes + tb4 * per4 + 64 <= budget) {
+      size_t nw4 = (budget - tb4 * per4 - 64) / doc_bytes;
+      nw4 = nw4 >= 16 ? 16 : nw4 >= 12 ? 12 : nw4 >= 8 ? 8 : 4;
+      switch (nw4) {
+        case 16: return launch_p4_nw<16>(c, N, d_out, tb4);
+        case 12: return launch_p4_nw<12>(c, N, d_out, tb4);
+        case 8: return launch_p4_nw<8>(c, N, d_out, tb4);
+        default: return launch_p4_nw<4>(c, N, d_out, tb4);
+      }
+    }
+  }
   switch (nw) {
     case 16: return launch_binned_nw<BT, 16>(c, d_x, N, xstride, d_out, tbatch);
     case 12: return launch_binned_nw<BT, 12>(c, d_x, N, xstride, d_out, tbatch);

@@ -162,6 +162,7 @@ void qr_ctx_destroy(qr_ctx *c) {
   if (c->d_sb_nodes) (void)hipFree(c->d_sb_nodes);
   if (c->d_sb_bins) (void)hipFree(c->d_sb_bins);
   dfree(c->d_sb_leaves); dfree(c->d_sb_root); dfree(c->d_sb_thr); dfree(c->d_sb_thr_cnt);
+  dfree(c->d_p4_nodes); dfree(c->d_p4_leaves); dfree(c->d_p4_depth);
   for (auto &p : c->prof_events) {
     (void)hipEventDestroy(p.first);
     (void)hipEventDestroy(p.second);
@@ -1469,6 +1470,7 @@ int qr_ranks_read(qr_ctx *c, uint32_t *out) {
 // thresholds, internal nodes as {feature, threshold index, children}, leaves apart.
 static int build_binned_model(qr_ctx *c, const qr_node_t *nodes, size_t ntrees, size_t max_nodes) {
   c->sb_ready = false;
+  c->p4_ready = false;
   int maxf = -1;
   for (size_t i = 0; i < ntrees * max_nodes; ++i) maxf = std::max(maxf, nodes[i].feature);
   if (maxf < 0) return QR_OK;  // only leaves: the generic kernel handles it
@@ -1566,6 +1568,60 @@ static int build_binned_model(qr_ctx *c, const qr_node_t *nodes, size_t ntrees, 
   c->sb_u8 = tmax <= 255;
   c->sb_self = self;
   c->sb_ready = true;
+  // ---- the 4-byte records of k_score_p4, when the model allows them
+  c->p4_ready = false;
+  dfree(c->d_p4_nodes); dfree(c->d_p4_leaves); dfree(c->d_p4_depth);
+  size_t NN4 = 0;
+  for (size_t t = 0; t < ntrees; ++t) NN4 = std::max(NN4, order[t].size());
+  if (tmax <= 255 && (F - 1) * 64 <= 0xffff && NN4 <= 255) {
+    std::vector<uint32_t> w(ntrees * NN4, 0x00ff0000u);  // unused entries: harmless leaves of node 0
+    std::vector<double> lv(ntrees * NN4, 0.0);
+    std::vector<uint8_t> dep(ntrees, 0);
+    std::vector<int> pos(max_nodes), stack, dstack;
+    for (size_t t = 0; t < ntrees; ++t) {
+      const qr_node_t *n = nodes + t * max_nodes;
+      // right-first preorder: the right child of the node at position p sits at p + 1
+      stack.assign(1, 0);
+      dstack.assign(1, 0);
+      std::vector<int> seq;
+      int maxd = 0;
+      while (!stack.empty()) {
+        const int i = stack.back(), d = dstack.back();
+        stack.pop_back();
+        dstack.pop_back();
+        pos[i] = (int)seq.size();
+        seq.push_back(i);
+        if (n[i].feature >= 0) {
+          maxd = std::max(maxd, d + 1);
+          stack.push_back(n[i].left);
+          dstack.push_back(d + 1);
+          stack.push_back(n[i].right);  // popped first: position pos[i] + 1
+          dstack.push_back(d + 1);
+        }
+      }
+      if (maxd > 255) return QR_OK;  // (cannot happen with <= 255 nodes)
+      dep[t] = (uint8_t)maxd;
+      for (int i : seq) {
+        const size_t at = t * NN4 + (size_t)pos[i];
+        if (n[i].feature >= 0) {
+          const auto &v = thr[n[i].feature];
+          const uint32_t kb = (uint32_t)(std::lower_bound(v.begin(), v.end(), n[i].threshold) - v.begin());
+          w[at] = (uint32_t)((size_t)n[i].feature * 64) | (kb << 16) | ((uint32_t)pos[n[i].left] << 24);
+        } else {
+          w[at] = (255u << 16) | ((uint32_t)pos[i] << 24);
+          lv[at] = n[i].value;
+        }
+      }
+    }
+    QR_CHECK(c, dalloc(&c->d_p4_nodes, w.size()));
+    QR_CHECK(c, dalloc(&c->d_p4_leaves, lv.size()));
+    QR_CHECK(c, dalloc(&c->d_p4_depth, dep.size()));
+    QR_CHECK(c, hipMemcpy(c->d_p4_nodes, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    QR_CHECK(c, hipMemcpy(c->d_p4_leaves, lv.data(), lv.size() * 8, hipMemcpyHostToDevice));
+    QR_CHECK(c, hipMemcpy(c->d_p4_depth, dep.data(), dep.size(), hipMemcpyHostToDevice));
+    c->p4_NN = NN4;
+    c->p4_ready = true;
+  }
   return QR_OK;
 }
 

@@ -433,6 +433,12 @@ struct qr_ctx {
   bool sb_ready = false, sb_u8 = false;
   size_t sb_F = 0, sb_NI = 0, sb_NL = 0, sb_tmax = 0, sb_bins_bytes = 0;
   bool sb_self = false;          // the node array holds the leaves too (self-looping), k_score.hip
+  // 4-byte node records (k_score_p4): u8 bins, trees of <= 255 nodes, row offsets < 65536
+  bool p4_ready = false;
+  size_t p4_NN = 0;
+  uint32_t *d_p4_nodes = nullptr;
+  double *d_p4_leaves = nullptr;
+  uint8_t *d_p4_depth = nullptr;
   void *d_sb_nodes = nullptr, *d_sb_bins = nullptr;
   double *d_sb_leaves = nullptr;
   uint16_t *d_sb_root = nullptr;

@@ -319,6 +319,73 @@ def test_oblivious_training_loop(qr, ora, algo):
     gm.ctx.close()
 
 
+def _random_tree(rng, nleaves, F, pool, chain=False):
+    """(nodes in creation order) a random binary tree of `nleaves` leaves; chain: every split
+    keeps splitting its right child (depth = nleaves - 1)."""
+    from quickrank_amd._capi import NODE_DTYPE
+    n = np.zeros(2 * nleaves - 1, NODE_DTYPE)
+    n["feature"] = -1
+    n["left"] = n["right"] = -1
+    n["value"] = rng.standard_normal(len(n))
+    leaves, used = [0], 1
+    while len(leaves) < nleaves:
+        i = leaves.pop(-1 if chain else int(rng.integers(len(leaves))))
+        n[i]["feature"] = int(rng.integers(F))
+        n[i]["threshold"] = np.float32(rng.choice(pool))
+        n[i]["left"], n[i]["right"] = used, used + 1
+        leaves += [used, used + 1]
+        used += 2
+    return n
+
+
+@pytest.mark.parametrize("kind", ["p4", "self8", "u16", "wide_rows", "big_trees"])
+def test_ensemble_scoring_every_record_format(qr, ora, kind):
+    """Ensemble::score_instance (ensemble.cc:111-118) through each compact form of the model --
+    4-byte records (u8 bins, trees of up to 255 nodes), 8-byte records with self-looping
+    leaves, u16 bins, wide rows (fewer document blocks per workgroup), trees of more than 255 nodes -- with
+    single-leaf trees, chains and ragged shapes mixed in: bit-exact against the oracle's walk,
+    NaN / inf / -0.0 features included."""
+    rng = np.random.default_rng({"p4": 1, "self8": 2, "u16": 3, "wide_rows": 4, "big_trees": 5}[kind])
+    F = 400 if kind == "wide_rows" else 37      # (25 KB of u8 bins per 64 documents: fewer waves per workgroup)
+    npool = 5000 if kind == "u16" else 200
+    pool = np.unique(np.concatenate([rng.standard_normal(npool).astype(np.float32),
+                                     np.array([0.0, -0.0, 1.0], np.float32)]))
+    sizes = [1, 2, 3, 17, 64, 100, 128] * 3
+    if kind in ("self8", "big_trees"):
+        sizes += [200, 300]          # > 255 nodes: the 4-byte records do not apply
+    trees = [_random_tree(rng, m, F, pool, chain=(k % 5 == 0 and m <= 40)) for k, m in enumerate(sizes)]
+    maxn = max(len(t) for t in trees)
+    from quickrank_amd._capi import NODE_DTYPE
+    nodes = np.zeros((len(trees), maxn), NODE_DTYPE)
+    nodes["feature"] = -1
+    nodes["left"] = nodes["right"] = -1
+    for k, t in enumerate(trees):
+        nodes[k, :len(t)] = t
+    w = rng.random(len(trees)) + 0.5
+    x = rng.choice(pool, size=(3000, F)).astype(np.float32)
+    x[rng.integers(0, 3000, 40), rng.integers(0, F, 40)] = np.nan
+    x[rng.integers(0, 3000, 40), rng.integers(0, F, 40)] = np.inf
+    x[rng.integers(0, 3000, 40), rng.integers(0, F, 40)] = -np.inf
+    x[rng.integers(0, 3000, 40), rng.integers(0, F, 40)] = -0.0
+    c = qr.Context(0)
+    c.upload_ensemble(nodes, w)
+    got, _ = c.score(x)
+    # the reference's walk, restated: x[f] <= threshold goes left (NaN goes right)
+    want = np.zeros(len(x))
+    for k, t in enumerate(trees):
+        cur = np.zeros(len(x), np.int64)
+        while True:
+            nd = t[cur]
+            idx = np.nonzero(nd["feature"] >= 0)[0]
+            if not len(idx):
+                break
+            go = x[idx, nd["feature"][idx]] <= nd["threshold"][idx]
+            cur[idx] = np.where(go, nd["left"][idx], nd["right"][idx])
+        want = want + t["value"][cur] * w[k]
+    assert np.array_equal(got, want)
+    c.close()
+
+
 def test_oblivious_bit_interleaved_scoring(qr, ora):
     """generate_oblivious.cc:237-324 semantics (f32 tree weights, `>` = right)."""
     rng = np.random.default_rng(3)

@@ -581,15 +581,23 @@ static int launch_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, 
   QR_CHECK(c, hipGetLastError());
   if (sizeof(BT) == 1 && c->p4_ready) {  // 4-byte node records (k_score_p4)
     const size_t per4 = c->p4_NN * 12 + 8 + 1;
-    size_t tb4 = 32;
-    while (tb4 > 8 && 4 * doc_bytes + tb4 * per4 + 64 > budget) tb4 -= 8;
-    if (4 * doc_bytes + tb4 * per4 + 64 <= budget) {
-      size_t nw4 = (budget - tb4 * per4 - 64) / doc_bytes;
-      nw4 = nw4 >= 16 ? 16 : nw4 >= 12 ? 12 : nw4 >= 8 ? 8 : 4;
+    // waves per workgroup first (8 -> 10 document blocks: 257 -> 249 ms at config 5), then the
+    // tree batch (16 trees per barrier pair at least: 8 cost more in barriers than they free)
+    auto waves_for = [&](size_t tb) -> size_t {
+      if (4 * doc_bytes + tb * per4 + 64 > budget) return 0;
+      const size_t n = (budget - tb * per4 - 64) / doc_bytes;
+      return n >= 16 ? 16 : n >= 12 ? 12 : n >= 10 ? 10 : n >= 8 ? 8 : n >= 6 ? 6 : 4;
+    };
+    size_t tb4 = waves_for(16) > waves_for(32) ? 16 : 32;
+    while (tb4 > 8 && waves_for(tb4) == 0) tb4 -= 8;
+    if (waves_for(tb4)) {
+      const size_t nw4 = waves_for(tb4);
       switch (nw4) {
         case 16: return launch_p4_nw<16>(c, N, d_out, tb4);
         case 12: return launch_p4_nw<12>(c, N, d_out, tb4);
+        case 10: return launch_p4_nw<10>(c, N, d_out, tb4);
         case 8: return launch_p4_nw<8>(c, N, d_out, tb4);
+        case 6: return launch_p4_nw<6>(c, N, d_out, tb4);
         default: return launch_p4_nw<4>(c, N, d_out, tb4);
       }
     }

@@ -859,7 +859,16 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       ownw[rb] = owb;
     }
     }
-  } else
+  } else {
+  // (longer queries: the same per-document exponentials, in place of the scores by rank)
+  const bool use_e = sr[0] - sr[n - 1] <= 690.0;
+  {
+    const double smax = sr[0];
+    __syncthreads();  // (every thread has read sr[0], sr[n - 1])
+    if (use_e)
+      for (uint32_t r = tid; r < n; r += T) sr[r] = qr_exp(sr[r] - smax, expt);
+    __syncthreads();
+  }
   for (uint32_t r1 = 0; r1 < size; ++r1) {
     // uniform over the wave
     const float l1 = sl[r1];
@@ -873,7 +882,10 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
         const float l2 = sl[r2];
         if (l1 != l2) {
           double slam, del;
-          pair_term(l1, p1, inv1, s1, l2, pw[r2], r2 < size ? ilt[r2] : 0.0, sr[r2], slam, del);
+          if (use_e)
+            pair_term_e(l1, p1, inv1, s1, l2, pw[r2], r2 < size ? ilt[r2] : 0.0, sr[r2], slam, del);
+          else
+            pair_term(l1, p1, inv1, s1, l2, pw[r2], r2 < size ? ilt[r2] : 0.0, sr[r2], slam, del);
           c1 += slam;
           cw += del;
           ownl[r2] -= slam;  // only this lane touches rank r2
@@ -902,6 +914,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
         accw[r1] = (sh_part[r1 & 1][0][1] + sh_part[r1 & 1][1][1]) + (sh_part[r1 & 1][2][1] + sh_part[r1 & 1][3][1]);
       }
     }
+  }
   }
   __syncthreads();
   QR_T(5);

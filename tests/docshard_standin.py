@@ -174,7 +174,107 @@ class DocStandinContext:
         l = self.lam[d["small_ids"]]
         self._local_hist(d["small_ids"], (float(np.sum(l * l)), float(np.sum(l))))
 
+    # -- level-wise (oblivious) growth, ot.cc:32-201 over document shards -----------------
+    # One int64 all-reduce per level: the per-slot (sum, count) of every directly built
+    # child of the level over the rank's own documents (qr_obl_level_exchange).
+    def obl_begin(self, depth, minls):
+        self.depth, self.minls = depth, minls
+        self.nleaves = 1 << depth
+        if len(self.leaf) != 2 * self.nleaves * self.world:
+            self.leaf = np.zeros(2 * self.nleaves * self.world, np.int64)
+        self.nodes, self.obl_done, self.level_buf = [], False, np.zeros(0, np.int64)
+        self.pending = None
+        self._local_hist(np.arange(self.N), (0.0, 0.0))
+
+    def host_buffers(self):
+        return dict(hist=self.hist, scal=self.scal, leaf=self.leaf, level=getattr(self, "level_buf", None))
+
+    def obl_level_exchange(self, level):
+        return 0, len(self.level_buf)
+
+    def _level_pick(self, level):
+        """fill() + argmax (ot.cc:177-201, 67-92): gains summed over the level's nodes in node
+        order, a slot where any node violates minls is out, only sums > 0 compete, first max."""
+        lo, hi = (1 << level) - 1, (1 << (level + 1)) - 1
+        best = None
+        for f in range(self.F):
+            tsz = int(self.thr_size[f])
+            tot = np.zeros(tsz)
+            bad = np.zeros(tsz, bool)
+            for i in range(lo, hi):
+                s, c = self.nodes[i]["hist"]
+                cs = s[f, :tsz].astype(np.float64) * self.inv_scale
+                S = float(s[f, tsz - 1]) * self.inv_scale
+                lc = c[f, :tsz].astype(np.float64)
+                rc = float(c[f, tsz - 1]) - lc
+                ok = (lc >= self.minls) & (rc >= self.minls)
+                bad |= ~ok
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    g = cs * cs / lc + (S - cs) * (S - cs) / rc
+                tot = tot + np.where(ok, g, 0.0)
+            tot[bad] = -1.0
+            t = int(np.argmax(tot))
+            if tot[t] > 0.0 and (best is None or tot[t] > best[0]):
+                best = (float(tot[t]), f, t)
+        return best
+
+    def obl_propose(self, level):
+        if self.obl_done:
+            return
+        if level == 0:
+            s, c, _, _ = self._global_hist()
+            self.nodes = [self._node(np.arange(self.N), self.Ng, self.root_sum, self.root_ss, (s, c))]
+        else:
+            # the summed level buffer: per-slot values -> cumulative cells of the directly built
+            # children, siblings by exact subtraction
+            cells = self.level_buf.reshape(len(self.pending), self.F, self.cap, 2)
+            for j, d in enumerate(self.pending):
+                s = np.cumsum(cells[j, :, :, 0], axis=1)
+                c = np.cumsum(cells[j, :, :, 1], axis=1).astype(np.uint64)
+                ps, pc = self.nodes[d["node"]]["hist"]
+                self.nodes[d["small"]]["hist"] = (s, c)
+                self.nodes[d["big"]]["hist"] = (ps - s, pc - c)
+        self.pick = self._level_pick(level)
+        if self.pick is None:
+            self.obl_done = True
+
+    def obl_apply(self, level):
+        if self.obl_done:
+            return
+        _, f, t = self.pick
+        lo, hi = (1 << level) - 1, (1 << (level + 1)) - 1
+        last = level + 1 == self.depth
+        self.pending = []
+        while len(self.nodes) < 2 * hi + 1:
+            self.nodes.append(None)
+        for i in range(lo, hi):
+            nd = self.nodes[i]
+            s, c = nd["hist"]
+            tsz = int(self.thr_size[f])
+            lc_all, n_all = int(c[f, t]), int(c[f, tsz - 1])
+            rc_all = n_all - lc_all
+            go = self.stmap[f, nd["ids"]] <= t
+            lids, rids = nd["ids"][go], nd["ids"][~go]
+            nd["feature"], nd["thr_id"], nd["left"], nd["right"] = f, t, 2 * i + 1, 2 * i + 2
+            self.nodes[2 * i + 1] = self._node(lids, lc_all, 0.0, 0.0, None)
+            self.nodes[2 * i + 2] = self._node(rids, rc_all, 0.0, 0.0, None)
+            small_is_left = lc_all <= rc_all
+            self.pending.append(dict(node=i, small=2 * i + 1 if small_is_left else 2 * i + 2,
+                                     big=2 * i + 2 if small_is_left else 2 * i + 1))
+        if last:
+            return                                           # ot.cc:127: no histograms for the leaves
+        buf = np.zeros((len(self.pending), self.F, self.cap, 2), np.int64)
+        for j, d in enumerate(self.pending):
+            ids = self.nodes[d["small"]]["ids"]
+            for ff in range(self.F):
+                b = self.stmap[ff, ids]
+                np.add.at(buf[j, ff, :, 0], b, self.q[ids])
+                np.add.at(buf[j, ff, :, 1], b, 1)
+        self.level_buf = buf.ravel()
+
     def tree_end_local(self, newton=True):
+        while self.nodes and self.nodes[-1] is None:         # (level-wise growth reserves a level ahead)
+            self.nodes.pop()
         self.leaves = []
         stack = [0]
         while stack:                                         # DFS, left first (rtnode.cc:34-46)

@@ -61,6 +61,67 @@ def _worker(rank, world, port, q, cuts, ntrees):
     dist.destroy_process_group()
 
 
+def _worker_obl(rank, world, port, q, cuts, ntrees, depth):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from datagen import make_dataset
+    from parity_util import assert_tree_parity
+    from quickrank_amd.dist import DocShardedTrainer
+    from docshard_standin import DocStandinContext
+    x, labels, qoff = make_dataset(nq=24, docs_per_query=40, F=20, seed=37)
+    whole = oracle.Trainer(x, 64)
+    edges = [0] + list(cuts) + [len(qoff) - 1]
+    q0, q1 = edges[rank], edges[rank + 1]
+    d0, d1 = int(qoff[q0]), int(qoff[q1])
+    ctx = DocStandinContext(x[d0:d1], labels[d0:d1], qoff[q0:q1 + 1] - qoff[q0], whole.thr,
+                            whole.thr_size, rank, world, len(labels), len(qoff) - 1)
+    tr = DocShardedTrainer(ctx)
+    scores = np.zeros(len(labels))
+    ok = True
+    for it in range(ntrees):
+        tr.compute_lambdas("NDCG", 10)
+        nodes = tr.fit_oblivious(depth, 2, True)
+        ctx.update_scores(0.1)
+        lam, w = oracle.lambdas(labels, scores, qoff)
+        t = whole.fit_tree(lam, minls=2, oblivious_depth=depth)
+        whole.update_output(t, lam, w)
+        o = t["nodes"]
+        assert len(nodes) == len(o), (len(nodes), len(o))
+        assert_tree_parity(whole.stmap, o, nodes, value_rtol=1e-9)
+        scores = scores + 0.1 * o["value"][_leaf_of(whole, o)]
+        assert np.allclose(ctx.scores, scores[d0:d1], rtol=1e-9, atol=1e-12)
+        mine = torch.from_numpy(np.frombuffer(nodes.tobytes(), np.uint8).copy())
+        ref = mine.clone()
+        dist.broadcast(ref, 0)
+        ok = ok and torch.equal(mine, ref)
+    if rank == 0:
+        q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cuts", [(2, [9]), (3, [3, 15])])
+def test_doc_sharded_oblivious_equals_unsharded(world, cuts):
+    """DocShardedTrainer.fit_oblivious over gloo: root exchange, one exchange of the level's
+    child cells per level, leaf exchange -- the unsharded oracle's oblivious tree."""
+    import oracle
+    oracle.build(ref=False)
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 33500 + (os.getpid() + world * 13) % 2000
+    procs = [ctxm.Process(target=_worker_obl, args=(r, world, port, q, cuts, 3, 3)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def _leaf_of(tr, nodes):
     """leaf node index of every document: walk on the bin ids"""
     at = np.zeros(tr.N, np.int64)

@@ -62,6 +62,7 @@ class StandinContext:
         self.recs_local = np.zeros(2, SPLIT_DTYPE)
         self.recs_all = np.zeros(2 * world, SPLIT_DTYPE)
         self.mask = np.zeros((self.N + 31) // 32, np.int32)
+        self.obl_mask = np.zeros(len(self.mask) + 256, np.int32)   # go-left bits by document + the level's left counts
         self.lam = self.w = None
 
     # -- exchange buffers ------------------------------------------------------
@@ -189,6 +190,104 @@ class StandinContext:
         self.nodes += [L, R]
         self.recs_local[0] = self._local_best(ls, lc)
         self.recs_local[1] = self._local_best(rs, rc)
+
+    # -- level-wise (oblivious) growth, ot.cc:32-201, feature-sharded ----------------------
+    # Per level: all-gather of the ranks' best (feature, slot) of the level (slot 0 of the
+    # record pair), then a sum all-reduce of the owner's go-left bits by DOCUMENT followed by
+    # the left count of every node of the level (QR_MAXLEVEL = 256 words).
+    OBL_MAXLEVEL = 256
+
+    def obl_exchange_buffers(self):
+        return dict(mask=0, mask_bytes=(len(self.mask) + self.OBL_MAXLEVEL) * 4, recs_local=0, recs_all=0,
+                    rec_bytes=2 * SPLIT_DTYPE.itemsize)
+
+    def host_buffers(self):
+        return dict(recs_local=self.recs_local.view(np.uint8), recs_all=self.recs_all.view(np.uint8),
+                    mask=self.mask, obl_mask=getattr(self, "obl_mask", None))
+
+    def obl_begin(self, depth, minls):
+        self.depth, self.minls = depth, minls
+        ids = np.arange(self.N, dtype=np.uint64)
+        s, c, ss = self._hist(None)
+        self.nodes = [dict(ids=ids, n=self.N, hist=(s, c), feature=-1, thr_id=-1, left=-1, right=-1)]
+        self.obl_done = False
+
+    def obl_propose(self, level):
+        self.recs_local[0]["feature"], self.recs_local[0]["score"] = NONE, -1.0
+        self.recs_local[1]["feature"], self.recs_local[1]["score"] = NONE, -1.0
+        if self.obl_done:
+            return
+        lo, hi = (1 << level) - 1, (1 << (level + 1)) - 1
+        best = None
+        for f in self.own:
+            tsz = int(self.tr.thr_size[f])
+            tot = np.zeros(tsz)
+            bad = np.zeros(tsz, bool)
+            for i in range(lo, hi):
+                s, c = self.nodes[i]["hist"]
+                cs, S = s[f, :tsz], s[f, tsz - 1]
+                lc = c[f, :tsz].astype(np.float64)
+                rc = float(c[f, tsz - 1]) - lc
+                ok = (lc >= self.minls) & (rc >= self.minls)
+                bad |= ~ok
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    g = cs * cs / lc + (S - cs) * (S - cs) / rc
+                tot = tot + np.where(ok, g, 0.0)
+            tot[bad] = -1.0
+            t = int(np.argmax(tot))
+            if tot[t] > 0.0 and (best is None or tot[t] > best[0]):
+                best = (float(tot[t]), int(f), t)
+        if best is not None:
+            self.recs_local[0]["score"], self.recs_local[0]["feature"], self.recs_local[0]["thr_id"] = best
+
+    def obl_mark(self, level):
+        self.obl_mask[:] = 0
+        if self.obl_done:
+            return
+        pick = self._merge(0)
+        if pick is None:
+            self.obl_done = True
+            return
+        self.pick = (int(pick["feature"]), int(pick["thr_id"]))
+        f, t = self.pick
+        if f in self.own:
+            go = self.tr.stmap[f] <= t                       # by DOCUMENT: all nodes take the same split
+            bits = np.zeros(len(self.mask) * 32, np.uint8)
+            bits[:self.N] = go
+            self.obl_mask[:len(self.mask)] = np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4") \
+                .astype(np.uint32).view(np.int32).ravel()
+            lo, hi = (1 << level) - 1, (1 << (level + 1)) - 1
+            for j, i in enumerate(range(lo, hi)):
+                self.obl_mask[len(self.mask) + j] = int(self.nodes[i]["hist"][1][f, t])
+
+    def obl_apply(self, level):
+        if self.obl_done:
+            return
+        f, t = self.pick
+        w = self.obl_mask[:len(self.mask)].view(np.uint32)
+        lo, hi = (1 << level) - 1, (1 << (level + 1)) - 1
+        last = level + 1 == self.depth
+        while len(self.nodes) < 2 * hi + 1:
+            self.nodes.append(None)
+        for j, i in enumerate(range(lo, hi)):
+            nd = self.nodes[i]
+            d = nd["ids"].astype(np.int64)
+            go = ((w[d >> 5] >> (d & 31).astype(np.uint32)) & 1).astype(bool)
+            lids, rids = nd["ids"][go], nd["ids"][~go]
+            assert len(lids) == int(self.obl_mask[len(self.mask) + j])     # the counts came with the mask
+            nd["feature"], nd["thr_id"], nd["left"], nd["right"] = f, t, 2 * i + 1, 2 * i + 2
+            L = dict(ids=lids, n=len(lids), hist=None, feature=-1, thr_id=-1, left=-1, right=-1)
+            R = dict(ids=rids, n=len(rids), hist=None, feature=-1, thr_id=-1, left=-1, right=-1)
+            if not last:                                     # ot.cc:127: no histograms for the leaves
+                ls, lc, _ = self._hist(lids)
+                ps, pc = nd["hist"]
+                L["hist"], R["hist"] = (ls, lc), (ps - ls, pc - lc)
+            self.nodes[2 * i + 1], self.nodes[2 * i + 2] = L, R
+
+    def obl_end(self, depth, newton, read=True):
+        while self.nodes and self.nodes[-1] is None:
+            self.nodes.pop()
+        return self.tree_end(1 << depth, newton)
 
     def tree_end(self, nleaves, newton):
         out = np.zeros(len(self.nodes), NODE_DTYPE)

@@ -67,6 +67,59 @@ def test_sharded_fit_equals_unsharded(world, F):
     assert q.get(timeout=5) is True
 
 
+def _worker_obl(rank, world, port, q, depth, F):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from datagen import make_dataset
+    from quickrank_amd.dist import ShardedTreeFitter
+    from shard_standin import StandinContext
+    x, labels, qoff = make_dataset(nq=20, docs_per_query=50, F=F, seed=17)
+    rng = np.random.default_rng(5)
+    lam, w = oracle.lambdas(labels, rng.standard_normal(len(labels)) * 0.2, qoff)
+    ctx = StandinContext(x, 255, rank, world)
+    ctx.set_pseudo(lam, w)
+    fitter = ShardedTreeFitter(ctx)
+    nodes = fitter.fit_oblivious(ctx, depth, 3, True)
+    if rank == 0:
+        tr = oracle.Trainer(x, 255)
+        t = tr.fit_tree(lam, minls=3, oblivious_depth=depth)
+        tr.update_output(t, lam, w)
+        o = t["nodes"]
+        ok = (len(o) == len(nodes)
+              and all(np.array_equal(nodes[k], o[k]) for k in ("feature", "thr_id", "left", "right", "nsamples"))
+              and np.allclose(nodes["value"][o["feature"] < 0], o["value"][o["feature"] < 0], rtol=1e-12))
+        q.put(bool(ok))
+    t = torch.from_numpy(np.ascontiguousarray(nodes["feature"]).astype(np.int64))
+    ref = t.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(t, ref)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F,depth", [(2, 40, 3), (3, 70, 4)])
+def test_sharded_oblivious_fit_equals_unsharded(world, F, depth):
+    """ShardedTreeFitter.fit_oblivious over gloo: per level an all-gather of the ranks' best
+    (feature, slot) and a sum all-reduce of the owner's go-left bits by document + the level's
+    left counts; the unsharded oracle's oblivious tree."""
+    import oracle
+    oracle.build(ref=False)
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 35500 + (os.getpid() + world * 17 + F) % 2000
+    procs = [ctxm.Process(target=_worker_obl, args=(r, world, port, q, depth, F)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_owned_features_cover_and_match_capi_rule():
     from quickrank_amd.dist import owned_features
     for F in (1, 9, 64, 65, 136, 700):

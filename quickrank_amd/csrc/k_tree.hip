@@ -2199,7 +2199,25 @@ __global__ __launch_bounds__(256) void k_finish(QrTreeState *__restrict__ ts) {
     s_right[i] = ts->nodes[i].right;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  // A complete tree in level order (every oblivious tree: nodes 0 .. first - 1 internal, the
+  // rest leaves of one depth): the leaves' left-first DFS order is their index order -- no
+  // walk (one lane's walk over 127 nodes took 18 us of an Oblivious-LambdaMART iteration).
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  const int first = (nn - 1) / 2;
+  {
+    bool bad = (nn & 1) == 0 || ((nn + 1) & nn) != 0;  // nn = 2^k - 1
+    for (int i = threadIdx.x; i < nn; i += blockDim.x)
+      bad = bad || ((s_feat[i] >= 0) != (i < first)) ||
+            (i < first && (s_left[i] != 2 * i + 1 || s_right[i] != 2 * i + 2));
+    if (bad) s_bad = 1;
+  }
+  __syncthreads();
+  if (!s_bad) {
+    for (int l = threadIdx.x; l < nn - first; l += blockDim.x) s_leaf[l] = first + l;
+    if (threadIdx.x == 0) s_nl = nn - first;
+  } else if (threadIdx.x == 0) {
     int sp = 0, nl = 0;
     stack[sp++] = 0;
     while (sp > 0) {

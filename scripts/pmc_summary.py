@@ -16,6 +16,6 @@ for name in names:
         k = r["Kernel_Name"].split("(")[0]
         vals.setdefault(k, []).append(float(r["Counter_Value"]))
     for k, v in sorted(vals.items(), key=lambda kv: -max(kv[1])):
-        if k.startswith("k_hist") or k.startswith("k_reduce") or k.startswith("k_lambda"):
+        if k.startswith("k_hist") or k.startswith("k_reduce") or "k_lambda" in k:
             v2 = sorted(v, reverse=True)
             print(f"{name:12s} {k:16s} n={len(v):4d} max={v2[0]:.1f} top5={[round(x,1) for x in v2[:5]]} sum={sum(v):.1f}")

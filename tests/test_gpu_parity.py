@@ -700,8 +700,17 @@ def test_error_paths_return_codes_not_crashes(qr):
     d = qr.Context(0, rank=0, world=1, doc_shard=(len(labels), len(qoff) - 1))
     d.upload(x, labels, qoff)
     d.build_bins_with(*qr._capi.thresholds_from_stats(x.shape[1], 16, *[a[None] for a in d.bins_stats(16)]))
+    with pytest.raises(qr.QrError, match="document-sharded contexts"):
+        c.set_subsample(0.5, first_doc=0)            # ... and only they
+    with pytest.raises(qr.QrError, match="qr_obl_level_exchange follows"):
+        c.obl_level_exchange(0)
     with pytest.raises(qr.QrError, match="qr_subsample_set_doc"):
         d.set_subsample(0.5)             # document-sharded ranks say where their documents start
+    with pytest.raises(qr.QrError, match="qr_obl_level_exchange follows"):
+        d.obl_level_exchange(0)          # before qr_obl_begin
+    d.obl_begin(3, 1)
+    with pytest.raises(qr.QrError, match="no mask to exchange"):
+        d.obl_mark(0)
     with pytest.raises(qr.QrError, match="outside the global range"):
         d.set_subsample(0.5, first_doc=7)
     d.set_subsample(0.5, first_doc=0)

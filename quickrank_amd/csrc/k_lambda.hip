@@ -472,7 +472,7 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
 // partition phase left, by every thread of the workgroup (T = its size).
 template <int W>
 __device__ __forceinline__ void sort_placement(const uint32_t *a, const int n, uint32_t *out,
-                                               const uint8_t *dupk) {
+                                               const uint8_t *dupk, uint32_t *cnt, uint32_t *pos) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
   // final insertion sort == stable sort by key of the current arrangement
@@ -506,15 +506,52 @@ __device__ __forceinline__ void sort_placement(const uint32_t *a, const int n, u
     if (in0) out[r0] = v0 & 0xFFFFu;
     if (in1) out[r1] = v1 & 0xFFFFu;
   } else {
-    const int n4 = (n + 3) & ~3;
-    for (int x = (int)threadIdx.x; x < n; x += 64 * W) {
-      const uint32_t kx = pk(a[x]);
-      uint32_t r = kx;
-      if (dupk[kx]) {
-#pragma unroll 4
-        for (int y = 0; y < n4; ++y) r += (pk(a[y]) == kx) & (y < x);
+    // Long queries: the holders of a duplicated key k take the slots of pos[k .. k + c_k)
+    // in whatever order their atomics land, and the ORDER is then restored from the
+    // arrangement positions stored there -- deterministic whatever the atomics did.  A
+    // small group (fewer than 64 holders) is ranked by its own members (each counts the
+    // members standing before it); the few big ones (at most n / 64 of them) by one sweep
+    // of ballots over the arrangement each, dealt to the waves in turn.  Either way a few
+    // thousand instructions per wave, where comparing every holder with every position
+    // took 100 us on a 1200-document query of tied scores.
+    constexpr int T = 64 * W;
+    for (int x = (int)threadIdx.x; x < n; x += T) cnt[x] = 0;
+    __syncthreads();
+    for (int x = (int)threadIdx.x; x < n; x += T) {
+      const uint32_t v = a[x], k = pk(v);
+      if (!dupk[k])
+        out[k] = v & 0xFFFFu;
+      else
+        pos[k + atomicAdd(&cnt[k], 1u)] = (uint32_t)x;
+    }
+    __syncthreads();
+    for (int x = (int)threadIdx.x; x < n; x += T) {
+      const uint32_t v = a[x], k = pk(v);
+      if (!dupk[k]) continue;
+      const uint32_t c = cnt[k];
+      if (c >= 64) continue;
+      uint32_t r = k;
+      for (uint32_t t = 0; t < c; ++t) r += pos[k + t] < (uint32_t)x;
+      out[r] = v & 0xFFFFu;
+    }
+    int j = 0;
+    for (int kb = 0; kb < n; kb += 64) {
+      unsigned long long km = __ballot(kb + lane < n && cnt[kb + lane < n ? kb + lane : 0] >= 64);
+      while (km) {
+        const int bit = __ffsll((long long)km) - 1;
+        km &= km - 1ull;
+        if ((j++ % W) != wave) continue;
+        const uint32_t k = (uint32_t)(kb + bit);
+        uint32_t before = 0;
+        for (int base = 0; base < n; base += 64) {
+          const int x = base + lane;
+          const uint32_t v = x < n ? a[x] : 0xFFFFFFFFu;
+          const bool e = pk(v) == k;
+          const unsigned long long m = __ballot(e);
+          if (e) out[k + before + (uint32_t)__popcll(m & lt)] = v & 0xFFFFu;
+          before += (uint32_t)__popcll(m);
+        }
       }
-      out[r] = a[x] & 0xFFFFu;
     }
   }
 }
@@ -561,6 +598,11 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
 #define QR_T(i) if (QR_LAMBDA_STOP == (i)) return
 #else
 #define QR_T(i)
+#endif
+#ifdef QR_LAMBDA_STOP  // a section boundary of the ablation builds only
+#define QR_TS(i) QR_T(i)
+#else
+#define QR_TS(i)
 #endif
   const uint32_t off = qoff[q];
   const uint32_t n_full = qoff[q + 1] - off;
@@ -672,7 +714,8 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       if (wave == 0) wave_gnu_sort<false>(pa, (int)n, LB, RB, stk, dupk, limit);
       __syncthreads();
     }
-    sort_placement<W>(pa, (int)n, unmap, dupk);
+    QR_TS(8);
+    sort_placement<W>(pa, (int)n, unmap, dupk, LB, RB);
     __syncthreads();
   }
   QR_T(3);

@@ -7,7 +7,7 @@ import os, subprocess, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 import quickrank_amd.build as b
-STOPS = (1, 2, 3, 4, 5, 7)
+STOPS = (1, 2, 8, 3, 4, 5, 7)
 lib = lambda k: os.path.join(b.LIBDIR, f"libqr_stop{k}.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     ps = [subprocess.Popen([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + b.FLAGS + [f"-DQR_LAMBDA_STOP={k}", "-o", lib(k)] +
@@ -19,7 +19,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     b.LIB = lib(int(sys.argv[2]))
     import quickrank_amd._capi as capi
     from bench import synth
-    x, labels, qoff = synth(10000, 100, 136)
+    if os.environ.get("QR_ABL_MSLR"):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from datagen import make_mslr_like
+        x, labels, qoff = make_mslr_like()
+    else:
+        x, labels, qoff = synth(10000, 100, 136)
     c = capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     c.upload(x, labels, qoff); c.build_bins(255); c.reset_scores()
     for name in ("s0", "s30", "s90"):
@@ -37,14 +42,19 @@ import numpy as np, torch
 torch.cuda.init()
 import quickrank_amd._capi as capi
 from bench import synth
-x, labels, qoff = synth(10000, 100, 136)
+if os.environ.get("QR_ABL_MSLR"):     # the MSLR-shaped stand-in (ragged queries of 1..1146 documents)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from datagen import make_mslr_like
+    x, labels, qoff = make_mslr_like()
+else:
+    x, labels, qoff = synth(10000, 100, 136)
 c = capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 c.upload(x, labels, qoff); c.build_bins(255); c.reset_scores()
 for it in range(90):
     c.compute_lambdas("NDCG", 10); c.fit_tree(10, 1, True); c.update_scores(0.1)
     if it + 1 in (30, 90):
         s = c.get_scores(); np.save(f"/tmp/qr_abl_s{it + 1}.npy", s)
-        tied = (np.diff(np.sort(s.reshape(10000, 100), axis=1), axis=1) == 0).any(axis=1).mean()
+        tied = float('nan') if os.environ.get('QR_ABL_MSLR') else (np.diff(np.sort(s.reshape(10000, 100), axis=1), axis=1) == 0).any(axis=1).mean()
         print(f"after {it + 1} trees: queries with a tied pair {tied:.3f}", flush=True)
 del c
 for k in STOPS:

@@ -563,12 +563,12 @@ __device__ __forceinline__ void sort_placement(const uint32_t *a, const int n, u
 // `long_flag` (too long for the LDS) are left to the LONG = true launch, which
 // runs the same code on a per-query slice of a global scratch buffer
 // (`long_list[blockIdx.x]` names the query) -- slow, but any length up to 65535.
-// W = waves per workgroup: 1 for the usual queries; 4 for the size classes of long queries
-// (more than 256 documents), whose O(n^2 / 64) phases -- the counting rank, the placement
-// of tied keys, the pair sweep -- are then shared by four waves (the partition phase of the
-// sort emulation stays one wave's work).  The per-rank sums of a W = 4 query are added
-// per wave and then over the waves in a fixed order: deterministic, and within an ulp or
-// two of the one-wave order.
+// W = waves per workgroup: 1 for queries of up to 256 documents, 4 up to 512, 16 beyond
+// (the launch's size class decides), whose O(n^2 / 64) phases -- the counting rank, the
+// pair sweep -- and the placement of tied keys are then shared by the waves (the partition
+// phase of the sort emulation stays one wave's work).  The per-rank sums of a W > 1 query
+// are added per wave and then pairwise over the waves in a fixed order: deterministic, and
+// within an ulp or two of the one-wave order.
 template <bool LONG, int W>
 __global__ __launch_bounds__(64 * W) void k_lambda(
     const double *__restrict__ scores, const float *__restrict__ labels,
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   char *smem = LONG ? lscratch + (size_t)blockIdx.x * lstride : lds_mem;
   constexpr uint32_t T = 64 * W;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ double sh_part[2][4][2], sh_red[4][3];
+  __shared__ double sh_part[2][W][2], sh_red[W][3];
 #ifdef QR_LAMBDA_TIMING
   long long tq[8];
   tq[0] = clock64();
@@ -953,8 +953,22 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       }
       __syncthreads();
       if (tid == 0) {
-        accl[r1] = (sh_part[r1 & 1][0][0] + sh_part[r1 & 1][1][0]) + (sh_part[r1 & 1][2][0] + sh_part[r1 & 1][3][0]);
-        accw[r1] = (sh_part[r1 & 1][0][1] + sh_part[r1 & 1][1][1]) + (sh_part[r1 & 1][2][1] + sh_part[r1 & 1][3][1]);
+        // pairwise over the waves: ((w0 + w1) + (w2 + w3)) + ...
+        double vl[W], vw[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          vl[w] = sh_part[r1 & 1][w][0];
+          vw[w] = sh_part[r1 & 1][w][1];
+        }
+#pragma unroll
+        for (int st = 1; st < W; st *= 2)
+#pragma unroll
+          for (int w = 0; w < W; w += 2 * st) {
+            vl[w] += vl[w + st];
+            vw[w] += vw[w + st];
+          }
+        accl[r1] = vl[0];
+        accw[r1] = vw[0];
       }
     }
   }
@@ -986,9 +1000,24 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       sh_red[wave][2] = sm;
     }
     __syncthreads();
-    mx = fmax(fmax(sh_red[0][0], sh_red[1][0]), fmax(sh_red[2][0], sh_red[3][0]));
-    sq = (sh_red[0][1] + sh_red[1][1]) + (sh_red[2][1] + sh_red[3][1]);
-    sm = (sh_red[0][2] + sh_red[1][2]) + (sh_red[2][2] + sh_red[3][2]);
+    double vm[W], vq[W], vs[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      vm[w] = sh_red[w][0];
+      vq[w] = sh_red[w][1];
+      vs[w] = sh_red[w][2];
+    }
+#pragma unroll
+    for (int st = 1; st < W; st *= 2)
+#pragma unroll
+      for (int w = 0; w < W; w += 2 * st) {
+        vm[w] = fmax(vm[w], vm[w + st]);
+        vq[w] += vq[w + st];
+        vs[w] += vs[w + st];
+      }
+    mx = vm[0];
+    sq = vq[0];
+    sm = vs[0];
   }
   // (the query's max |lambda| goes to its own slot and k_prep takes the maximum: ten
   // thousand atomicMax on one address queued up for half of this launch's duration)
@@ -999,7 +1028,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   }
 #ifdef QR_LAMBDA_TIMING
   QR_T(6);
-  if (lane == 0 && (q == 0 || q == 5000))
+  if (tid == 0 && (q == 0 || q == 5000 || n > 1100))
     printf("k_lambda q=%u n=%u tie=%d: load %lld count %lld sort %lld rank/metric %lld pairs %lld out %lld total %lld\n",
            q, n, (int)anytie, tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4],
            tq[6] - tq[5], tq[6] - tq[0]);
@@ -1140,7 +1169,9 @@ static size_t lambda_lds(size_t nmax, size_t kacc, bool sampled) {
 }
 
 // size classes of the LDS-resident launches: a query goes to the first class that holds it
-static const uint32_t kClassBound[] = {128, 256, 512, 1024, 2048, 0xFFFFFFFFu};
+// (measured on the MSLR-shaped set: {128, 512, 2048} with four waves from 129 documents on is
+// 10 us slower per iteration, a 192 or 64 bound more, sixteen waves from 257 on 40 us)
+static const uint32_t kClassBound[] = {128, 256, 512, 2048, 0xFFFFFFFFu};
 
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   const size_t Q = which ? c->vQ : c->Q;
@@ -1266,6 +1297,8 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false, 16>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       c->attr_lambda_lds = lds;
     }
     hipStream_t st;
@@ -1274,7 +1307,12 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     const uint32_t *qlist = c->qclass_identity[which] ? (const uint32_t *)nullptr
                                                       : (const uint32_t *)(c->d_qclass[which] + cl.first);
     // long queries: four waves each (not with a sample: the cleaning is one wave's code)
-    if (cl.nmax > 256 && !sampled)
+    if (cl.nmax > 512 && !sampled)
+      hipLaunchKernelGGL((k_lambda<false, 16>), dim3(cl.count), dim3(1024), lds, st, sc, lb, qoffd, metric, cut,
+                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars, (uint32_t)nmax,
+                         (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
+                         (size_t)0, c->exact_tail);
+    else if (cl.nmax > 256 && !sampled)
       hipLaunchKernelGGL((k_lambda<false, 4>), dim3(cl.count), dim3(256), lds, st, sc, lb, qoffd, metric, cut,
                          idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,

@@ -1,14 +1,19 @@
 #!/bin/bash
 # kernel timeline (start, duration, gap to the previous end) of one boosting iteration on the
-# MSLR-shaped stand-in, 255 thresholds:  bash scripts/mslr_timeline.sh [iteration]
+# MSLR-shaped stand-in (QR_TL_BENCH=1: the bench workload), 255 thresholds:
+#   bash scripts/mslr_timeline.sh [iteration]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 cat > /tmp/mt.py <<'PY'
 import os, sys
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["GRAFT_REPO_ROOT"], "tests"))
 import torch; torch.cuda.init()
-from datagen import make_mslr_like
 from quickrank_amd._capi import Context
-x, l, q = make_mslr_like()
+if os.environ.get("QR_TL_BENCH"):  # the bench workload instead (1M x 136, 10000 queries of 100)
+    from bench import synth
+    x, l, q = synth(10000, 100, 136)
+else:
+    from datagen import make_mslr_like
+    x, l, q = make_mslr_like()
 c = Context(0); c.upload(x, l, q); c.build_bins(255); c.reset_scores()
 for it in range(40):
     c.compute_lambdas("NDCG", 10); c.fit_tree(10, 1, True, read=False); c.update_scores(0.1); c.metric_last(); c.tree_nodes()

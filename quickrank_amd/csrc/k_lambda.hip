@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
                                                const double *__restrict__ qmax, uint32_t nmx,
                                                QrScalars *__restrict__ scal,
                                                const int reset_max,
-                                               QrScalars *__restrict__ host_copy) {
+                                               QrScalars *__restrict__ host_copy, const int seq) {
   __shared__ double red[16];
   double a = 0.0, b = 0.0, a2 = 0.0;
   double m = 0.0;  // max |pseudo-response| over the per-query / per-slice maxima
@@ -1156,7 +1156,13 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
     }
     // read-back without a copy launch: the finished scalars go straight into the
     // pinned host block (qr_metric_last waits for this kernel's event)
-    if (host_copy) *host_copy = *scal;
+    // `pad` = the launch's sequence number, stored LAST behind a system-scope fence: the
+    // host polls it (wait_seq_impl in qr_api.hip) instead of waiting for an event
+    if (host_copy) {
+      *host_copy = *scal;
+      __threadfence_system();
+      __hip_atomic_store(&host_copy->pad, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1360,7 +1366,7 @@ int qr_k_prep(qr_ctx *c, size_t nss, int with_metric, int publish) {
                      with_metric ? c->d_qmetric : (const double *)nullptr,
                      with_metric ? (uint32_t)c->Q : 0u, nss ? c->d_qmax : (const double *)nullptr,
                      nss ? (uint32_t)c->nqmax : 0u, c->d_scalars, c->dmode ? 0 : 1,
-                     publish ? &c->d_pin->scal : (QrScalars *)nullptr);
+                     publish ? &c->d_pin->scal : (QrScalars *)nullptr, publish ? qr_next_scal_seq(c) : 0);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -1385,7 +1391,7 @@ __global__ void k_scal_pack(const QrScalars *__restrict__ scal, long long *__res
 }
 
 __global__ void k_scal_global(QrScalars *__restrict__ scal, const long long *__restrict__ x,
-                              const int world, QrScalars *__restrict__ host_copy) {
+                              const int world, QrScalars *__restrict__ host_copy, const int seq) {
   if (threadIdx.x != 0) return;
   double mx = 0.0, ss = 0.0, sm = 0.0, ms = 0.0;
   for (int r = 0; r < world; ++r) {
@@ -1406,6 +1412,8 @@ __global__ void k_scal_global(QrScalars *__restrict__ scal, const long long *__r
   scal->scale = ldexp(1.0, e);
   scal->inv_scale = ldexp(1.0, -e);
   *host_copy = *scal;
+  __threadfence_system();
+  __hip_atomic_store(&host_copy->pad, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // local reductions (sum of squares / sum / metric) + pack for the exchange
@@ -1419,7 +1427,7 @@ int qr_k_prep_pack(qr_ctx *c) {
 
 int qr_k_prep_global(qr_ctx *c) {
   hipLaunchKernelGGL(k_scal_global, dim3(1), dim3(64), 0, c->stream, c->d_scalars,
-                     c->d_xscal, c->world, &c->d_pin->scal);
+                     c->d_xscal, c->world, &c->d_pin->scal, qr_next_scal_seq(c));
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -1429,7 +1437,7 @@ int qr_k_metric_reduce(qr_ctx *c, int which) {
                      (const double *)nullptr, 0u,
                      which ? c->d_vqmetric : c->d_qmetric,
                      (uint32_t)(which ? c->vQ : c->Q), (const double *)nullptr, 0u, c->d_scalars, 0,
-                     (QrScalars *)nullptr);
+                     (QrScalars *)nullptr, 0);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

@@ -2313,7 +2313,13 @@ __global__ __launch_bounds__(256) void k_leaf_sums(
 
 // compact records of the finished tree (what crosses the C-ABI), written by the
 // whole workgroup once the leaf values are in place
-__device__ __forceinline__ void nodes_out_write(const QrTreeState *ts, QrNodesOut *out) {
+// `seq` (pad[2]) is stored LAST, behind a system-scope fence: the host polls it in the
+// pinned block instead of waiting for an event (see wait_seq_impl in qr_api.hip).
+__device__ __forceinline__ void nodes_out_publish(QrNodesOut *out, const long long seq) {
+  __threadfence_system();
+  __hip_atomic_store(&out->pad[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void nodes_out_write(const QrTreeState *ts, QrNodesOut *out, const long long seq) {
   const int nn = ts->nnodes;
   for (int i = threadIdx.x; i < nn; i += blockDim.x) {
     const QrNode &s = ts->nodes[i];
@@ -2328,10 +2334,13 @@ __device__ __forceinline__ void nodes_out_write(const QrTreeState *ts, QrNodesOu
     d.nsamples = s.count;
     out->nodes[i] = d;
   }
+  __threadfence_system();
+  __syncthreads();
   if (threadIdx.x == 0) {
     out->nnodes = nn;
     out->pad[0] = ts->incomplete;
     out->pad[1] = ts->real_steps;
+    nodes_out_publish(out, seq);
   }
 }
 
@@ -2342,11 +2351,13 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
                                                      long long *__restrict__ xleaf,
                                                      const int rank, const int world,
                                                      const int stride,
-                                                     QrNodesOut *__restrict__ nodes_out) {
+                                                     QrNodesOut *__restrict__ nodes_out,
+                                                     const long long seq) {
   if (ts->incomplete) {  // tell the host, which carries the tree on (qr_k_tree_continue)
     if (threadIdx.x == 0) {
       nodes_out->pad[0] = 1;
       nodes_out->pad[1] = ts->real_steps;
+      nodes_out_publish(nodes_out, seq);
     }
     return;
   }
@@ -2385,7 +2396,7 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
   }
   if (docmode) return;  // k_leaf_global writes the records after the exchange
   __syncthreads();
-  nodes_out_write(ts, nodes_out);
+  nodes_out_write(ts, nodes_out, seq);
 }
 
 // document-sharded: leaf outputs from the gathered per-rank sums, added in rank
@@ -2394,7 +2405,8 @@ __global__ __launch_bounds__(1024) void k_leaf_global(QrTreeState *__restrict__ 
                                                       const long long *__restrict__ xleaf,
                                                       const int newton, const int world,
                                                       const int stride,
-                                                      QrNodesOut *__restrict__ nodes_out) {
+                                                      QrNodesOut *__restrict__ nodes_out,
+                                                      const long long seq) {
   const int nl = ts->nleaves;
   for (int l = threadIdx.x; l < nl; l += 1024) {
     double s1 = 0.0, s2 = 0.0;
@@ -2412,7 +2424,7 @@ __global__ __launch_bounds__(1024) void k_leaf_global(QrTreeState *__restrict__ 
     ts->nodes[ts->leaf_nodes[l]].value = v;
   }
   __syncthreads();
-  nodes_out_write(ts, nodes_out);
+  nodes_out_write(ts, nodes_out, seq);
 }
 
 // mart.cc:459-468 through the leaf membership instead of a tree walk:
@@ -3312,14 +3324,15 @@ int qr_k_tree_finish(qr_ctx *c, int newton) {
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_leaf_final, dim3(1), dim3(1024), 0, c->stream, c->d_tree,
                      c->d_leafpart, newton, c->dmode, c->d_xleaf, c->rank, c->world,
-                     (int)(2 * c->cur_nleaves), &c->d_pin->tree);
+                     (int)(2 * c->cur_nleaves), &c->d_pin->tree, (long long)(c->dmode ? c->nodes_seq : ++c->nodes_seq));
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
 
 int qr_k_tree_leaves_global(qr_ctx *c, int newton) {
   hipLaunchKernelGGL(k_leaf_global, dim3(1), dim3(1024), 0, c->stream, c->d_tree,
-                     c->d_xleaf, newton, c->world, (int)(2 * c->cur_nleaves), &c->d_pin->tree);
+                     c->d_xleaf, newton, c->world, (int)(2 * c->cur_nleaves), &c->d_pin->tree,
+                     (long long)++c->nodes_seq);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

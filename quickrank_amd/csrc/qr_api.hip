@@ -28,6 +28,38 @@ extern "C" {
 void qr_ctx_destroy(qr_ctx *c);
 static int tree_settle(qr_ctx *c);
 
+// Wait for a read-back: the publishing kernel stores `want` into the pinned block after its
+// data (system-scope release).  Polls the word; every so often asks the stream whether it
+// has failed or drained, so that a faulted kernel ends the wait with an error and a
+// platform where the stores only land at the end of the kernel is merely slower.
+static int wait_seq_impl(qr_ctx *c, const void *word, const int bytes, const int64_t want, const char *what) {
+  auto reached = [&]() {
+    return bytes == 4 ? (int64_t)__atomic_load_n((const int32_t *)word, __ATOMIC_ACQUIRE) == want
+                      : __atomic_load_n((const int64_t *)word, __ATOMIC_ACQUIRE) == want;
+  };
+  for (unsigned spin = 1;; ++spin) {
+    if (reached()) return QR_OK;
+    if ((spin & 1023u) == 0) {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess) {  // everything enqueued has run
+        if (reached()) return QR_OK;
+        QR_CHECK(c, hipStreamSynchronize(c->stream));
+        if (reached()) return QR_OK;
+        c->err = std::string("internal: ") + what + " were not published";
+        return QR_ERR_STATE;
+      }
+      if (e != hipErrorNotReady) QR_CHECK(c, e);
+    }
+    __builtin_ia32_pause();
+  }
+}
+static int wait_seq32(qr_ctx *c, const int32_t *word, const int32_t want, const char *what) {
+  return wait_seq_impl(c, word, 4, want, what);
+}
+static int wait_seq64(qr_ctx *c, const int64_t *word, const int64_t want, const char *what) {
+  return wait_seq_impl(c, word, 8, want, what);
+}
+
 int qr_ctx_create(int device, qr_ctx **out) {
   if (out) *out = nullptr;
   int ndev = 0;
@@ -65,10 +97,9 @@ int qr_ctx_create(int device, qr_ctx **out) {
     return QR_ERR_HIP;
   }
   (void)hipMemset(c->d_scalars, 0, sizeof(QrScalars));
-  if (hipHostMalloc((void **)&c->h_pin, sizeof(QrPinned), hipHostMallocDefault) != hipSuccess ||
-      hipHostGetDevicePointer((void **)&c->d_pin, c->h_pin, 0) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_scal, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_nodes, hipEventDisableTiming) != hipSuccess) {
+  // (coherent = fine-grained: a kernel's stores are visible to the host while it runs)
+  if (hipHostMalloc((void **)&c->h_pin, sizeof(QrPinned), hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&c->d_pin, c->h_pin, 0) != hipSuccess) {
     qr_ctx_destroy(c);
     g_create_err = "allocating the read-back buffers failed";
     return QR_ERR_HIP;
@@ -154,8 +185,6 @@ void qr_ctx_destroy(qr_ctx *c) {
   }
   if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
-  if (c->ev_scal) (void)hipEventDestroy(c->ev_scal);
-  if (c->ev_nodes) (void)hipEventDestroy(c->ev_nodes);
   dfree(c->d_keys); dfree(c->d_tied);
   dfree(c->d_obl_feat); dfree(c->d_obl_thr); dfree(c->d_obl_leaves); dfree(c->d_obl_w);
   dfree(c->d_obl_depths); dfree(c->d_ob_fk); dfree(c->d_ob_thr); dfree(c->d_ob_thr_cnt);
@@ -880,11 +909,10 @@ static int ensure_idcg(qr_ctx *c, int which, int metric, size_t cutoff) {
 }
 
 // snapshot of the per-iteration scalars into pinned host memory, stream-ordered:
-// qr_metric_last waits for this event only, not for the work enqueued after it
+// qr_metric_last waits for the publishing kernel only, not for the work enqueued after it
 static int snapshot_scalars(qr_ctx *c) {
   // the kernel that finished the scalars has written them into the pinned block
-  // itself (no copy launch): the event marks that kernel
-  QR_CHECK(c, hipEventRecord(c->ev_scal, c->stream));
+  // itself (no copy launch), then its sequence number (c->scal_seq)
   c->scal_pending = true;
   return QR_OK;
 }
@@ -960,7 +988,7 @@ int qr_metric_last(qr_ctx *c, double *out) {
   if (!c->scal_pending)
     QR_FAIL(c, QR_ERR_STATE, "qr_metric_last follows qr_lambda_compute (+ qr_lambda_finish)");
   // waits for the lambda pass only; whatever was enqueued after it keeps running
-  QR_CHECK(c, hipEventSynchronize(c->ev_scal));
+  { const int wrc = wait_seq32(c, &c->h_pin->scal.pad, c->scal_seq, "the iteration's scalars"); if (wrc) return wrc; }
   const QrScalars &s = c->h_pin->scal;
   // metric.h:93-105: avg_score /= num_queries (0 queries -> 0.0)
   if (c->dmode)  // the sum over all ranks came with the scalar exchange
@@ -1114,8 +1142,8 @@ int qr_tree_apply(qr_ctx *c) {
 // the finished tree's compact records travel to pinned host memory behind the
 // kernels that produced them; qr_tree_nodes waits for that copy only
 static int snapshot_nodes(qr_ctx *c) {
-  // k_leaf_final / k_leaf_global wrote the records into the pinned block directly
-  QR_CHECK(c, hipEventRecord(c->ev_nodes, c->stream));
+  // k_leaf_final / k_leaf_global wrote the records into the pinned block directly, then
+  // their sequence number (c->nodes_seq)
   c->nodes_pending = true;
   return QR_OK;
 }
@@ -1127,7 +1155,7 @@ static int snapshot_nodes(qr_ctx *c) {
 // the scores calls this first; in the usual loop qr_tree_nodes does.
 static int tree_settle(qr_ctx *c) {
   if (!c->spec_pending) return QR_OK;
-  QR_CHECK(c, hipEventSynchronize(c->ev_nodes));
+  { const int wrc = wait_seq64(c, &c->h_pin->tree.pad[2], c->nodes_seq, "the tree's records"); if (wrc) return wrc; }
   c->spec_pending = false;
   ++c->spec_trees;
   if (c->h_pin->tree.pad[0]) {  // incomplete
@@ -1135,9 +1163,8 @@ static int tree_settle(qr_ctx *c) {
     int rc = qr_k_tree_continue(c, c->cur_nleaves, c->cur_minls, (size_t)c->tree_step);
     if (rc) return rc;
     if ((rc = qr_k_tree_finish(c, c->spec_newton))) return rc;
-    QR_CHECK(c, hipEventRecord(c->ev_nodes, c->stream));
     if (c->spec_scores_enqueued && (rc = qr_k_scores_update(c, c->spec_shrinkage))) return rc;
-    QR_CHECK(c, hipEventSynchronize(c->ev_nodes));
+    { const int wrc = wait_seq64(c, &c->h_pin->tree.pad[2], c->nodes_seq, "the tree's records"); if (wrc) return wrc; }
     if (c->h_pin->tree.pad[0]) QR_FAIL(c, QR_ERR_STATE, "internal: tree still incomplete after its last step");
   }
   c->spec_scores_enqueued = false;
@@ -1151,7 +1178,7 @@ int qr_tree_nodes(qr_ctx *c, qr_node_t *nodes_out, size_t *nnodes_out) {
   if (!c->nodes_pending) QR_FAIL(c, QR_ERR_STATE, "no fitted tree");
   int rc = tree_settle(c);
   if (rc) return rc;
-  QR_CHECK(c, hipEventSynchronize(c->ev_nodes));
+  { const int wrc = wait_seq64(c, &c->h_pin->tree.pad[2], c->nodes_seq, "the tree's records"); if (wrc) return wrc; }
   const size_t n = (size_t)c->h_pin->tree.nnodes;
   if (nodes_out) memcpy(nodes_out, c->h_pin->tree.nodes, n * sizeof(qr_node_t));
   if (nnodes_out) *nnodes_out = n;

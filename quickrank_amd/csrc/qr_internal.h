@@ -246,7 +246,8 @@ struct QrScalars {
   double metric_gsum;              // document-sharded: the same over all ranks
 };
 
-// Host-pinned landing zone of the per-iteration read-backs (async copies + events:
+// Host-pinned landing zone of the per-iteration read-backs (written by the kernels, each
+// followed by a sequence number the host polls -- QrScalars::pad, QrNodesOut::pad[2]:
 // the host never has to drain the stream to learn a metric or a tree).
 struct QrNodesOut {
   int64_t nnodes;
@@ -356,7 +357,12 @@ struct qr_ctx {
   QrScalars *d_scalars = nullptr;
   QrPinned *h_pin = nullptr;     // pinned host memory the kernels write the read-backs into
   QrPinned *d_pin = nullptr;     // the same memory through its device address
-  hipEvent_t ev_scal = nullptr, ev_nodes = nullptr;
+  // Read-backs: the kernel that finishes the scalars / the tree records writes them into the
+  // pinned block and then a sequence number behind a system-scope fence; the host polls that
+  // number (wait_seq_impl in qr_api.hip).  No event on the stream: an event record between two
+  // kernels was ~6 us of idle GPU each, and waking the host from hipEventSynchronize ~25 us.
+  int32_t scal_seq = 0;   // of the last launch that publishes the scalars
+  int64_t nodes_seq = 0;  // of the last launch that publishes tree records
   bool scal_pending = false, nodes_pending = false;
   size_t cur_maxnodes = 0;
   // tree
@@ -498,6 +504,10 @@ int qr_k_wobl_hist(qr_ctx *c, int nodes);
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode);
 int qr_k_residual(qr_ctx *c);
 int qr_k_prep(qr_ctx *c, size_t nslices, int with_metric, int publish = 0);
+inline int qr_next_scal_seq(qr_ctx *c) {  // never 0: the value the block starts with
+  c->scal_seq = c->scal_seq == 0x7fffffff ? 1 : c->scal_seq + 1;
+  return c->scal_seq;
+}
 int qr_k_prep_pack(qr_ctx *c);
 int qr_k_prep_global(qr_ctx *c);
 int qr_k_tree_leaves_global(qr_ctx *c, int newton);

@@ -1073,36 +1073,41 @@ __global__ __launch_bounds__(256) void k_residual(const float *__restrict__ labe
   }
 }
 
-// Fixed-order reduction of the per-query / per-slice partials + the
-// quantisation scale for the histogram accumulators (one workgroup).
-__global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
-                                               uint32_t nss,
-                                               const double *__restrict__ qmetric,
-                                               uint32_t nq,
-                                               const double *__restrict__ qmax, uint32_t nmx,
-                                               QrScalars *__restrict__ scal,
-                                               const int reset_max,
-                                               QrScalars *__restrict__ host_copy, const int seq) {
-  __shared__ double red[16];
+// Fixed-order reduction of the per-query / per-slice partials + the quantisation scale for
+// the histogram accumulators.  The order is the one a single workgroup of 1024 threads
+// gives -- thread t adds elements t, t + 1024, ..., a wave adds its lanes, the 16 waves'
+// sums are added in wave order -- but every "wave" is a workgroup of its own here (16
+// workgroups of 64 threads: one CU took 10 us to pull 10,000 queries' values through its
+// memory pipe, 34 us for 80,000), and the one that arrives last at the ticket adds the 16
+// partials and finishes the scalars.  Bit for bit the single-workgroup values.
+__global__ __launch_bounds__(64) void k_prep(const double *__restrict__ ssq,
+                                             uint32_t nss,
+                                             const double *__restrict__ qmetric,
+                                             uint32_t nq,
+                                             const double *__restrict__ qmax, uint32_t nmx,
+                                             QrScalars *__restrict__ scal,
+                                             const int reset_max,
+                                             QrScalars *__restrict__ host_copy, const int seq,
+                                             double *__restrict__ part, uint32_t *__restrict__ ticket) {
   double a = 0.0, b = 0.0, a2 = 0.0;
   double m = 0.0;  // max |pseudo-response| over the per-query / per-slice maxima
   // one loop, so that the three arrays' loads are in flight together (same additions in
   // the same order per accumulator as three loops)
   const uint32_t nall = nss > nq ? (nss > nmx ? nss : nmx) : (nq > nmx ? nq : nmx);
-  // eight rounds of loads leave together, then the additions in the usual order (the launch
-  // is one workgroup's latency chain: ~10 dependent rounds for 10,000 queries otherwise)
-  for (uint32_t i0 = threadIdx.x; i0 < nall; i0 += 8 * 1024) {
-    double2 v[8];
-    double w[8], x[8];
+  const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+  // sixteen rounds of loads leave together, then the additions in the usual order
+  for (uint32_t i0 = slot; i0 < nall; i0 += 16 * 1024) {
+    double2 v[16];
+    double w[16], x[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 16; ++k) {
       const uint32_t i = i0 + k * 1024;
       v[k] = i < nss ? *reinterpret_cast<const double2 *>(ssq + 2 * i) : make_double2(0.0, 0.0);
       w[k] = i < nq ? qmetric[i] : 0.0;
       x[k] = i < nmx ? qmax[i] : 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 16; ++k) {
       const uint32_t i = i0 + k * 1024;
       if (i < nss) {
         a += v[k].x;
@@ -1113,27 +1118,29 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
     }
   }
   m = wave_max(m);
-  __shared__ double redm[16];
-  if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = m;
   a = wave_sum(a);
   a2 = wave_sum(a2);
   b = wave_sum(b);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
-  __syncthreads();
-  double ta = 0.0, ta2 = 0.0;
-  if (threadIdx.x == 0)
-    for (int i = 0; i < 16; ++i) ta += red[i];
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a2;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    for (int i = 0; i < 16; ++i) ta2 += red[i];
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = b;
-  __syncthreads();
+  __shared__ uint32_t sh_last;
   if (threadIdx.x == 0) {
-    double tb = 0.0;
-    for (int i = 0; i < 16; ++i) tb += red[i];
+    // (agent scope: the sixteen workgroups sit on different XCDs, one L2 each)
+    __hip_atomic_store(&part[4 * blockIdx.x], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&part[4 * blockIdx.x + 1], a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&part[4 * blockIdx.x + 2], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&part[4 * blockIdx.x + 3], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+    double ta = 0.0, ta2 = 0.0, tb = 0.0, tm = 0.0;
+    for (uint32_t i = 0; i < gridDim.x; ++i) {
+      ta += __hip_atomic_load(&part[4 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ta2 += __hip_atomic_load(&part[4 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tb += __hip_atomic_load(&part[4 * i + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tm = fmax(tm, __hip_atomic_load(&part[4 * i + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
     if (ssq) {
       scal->root_ss = ta;
       scal->root_sum = ta2;
@@ -1141,8 +1148,7 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
     if (qmetric) scal->metric_sum = tb;
     if (ssq) {
       // (maxabs_bits: what qr_pseudo_set or a document-sharded exchange put there)
-      double mx = __longlong_as_double((long long)scal->maxabs_bits);
-      for (int i = 0; i < 16; ++i) mx = fmax(mx, redm[i]);
+      double mx = fmax(__longlong_as_double((long long)scal->maxabs_bits), tm);
       scal->maxabs_bits = (unsigned long long)__double_as_longlong(mx);
       int x = 0;
       if (mx > 0.0) frexp(mx, &x);  // mx = m * 2^x, m in [0.5, 1)  =>  mx < 2^x
@@ -1154,10 +1160,9 @@ __global__ __launch_bounds__(1024) void k_prep(const double *__restrict__ ssq,
       // have to pack it for the exchange: k_scal_global clears it there)
       if (reset_max) scal->maxabs_bits = 0;
     }
-    // read-back without a copy launch: the finished scalars go straight into the
-    // pinned host block (qr_metric_last waits for this kernel's event)
-    // `pad` = the launch's sequence number, stored LAST behind a system-scope fence: the
-    // host polls it (wait_seq_impl in qr_api.hip) instead of waiting for an event
+    // read-back without a copy launch: the finished scalars go straight into the pinned
+    // host block; `pad` = the launch's sequence number, stored LAST behind a system-scope
+    // fence: the host polls it (wait_seq_impl in qr_api.hip) instead of waiting for an event
     if (host_copy) {
       *host_copy = *scal;
       __threadfence_system();
@@ -1361,12 +1366,13 @@ int qr_k_residual(qr_ctx *c) {
 // nss > 0: reduce ssq[nss] into root_ss and derive the scale; the per-query
 // metric of set `which` (encoded in the sign: nss == 0 means metric only).
 int qr_k_prep(qr_ctx *c, size_t nss, int with_metric, int publish) {
-  hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, c->stream,
+  hipLaunchKernelGGL(k_prep, dim3(16), dim3(64), 0, c->stream,
                      nss ? c->d_ssq : (const double *)nullptr, (uint32_t)nss,
                      with_metric ? c->d_qmetric : (const double *)nullptr,
                      with_metric ? (uint32_t)c->Q : 0u, nss ? c->d_qmax : (const double *)nullptr,
                      nss ? (uint32_t)c->nqmax : 0u, c->d_scalars, c->dmode ? 0 : 1,
-                     publish ? &c->d_pin->scal : (QrScalars *)nullptr, publish ? qr_next_scal_seq(c) : 0);
+                     publish ? &c->d_pin->scal : (QrScalars *)nullptr, publish ? qr_next_scal_seq(c) : 0,
+                     c->d_prep_part, reinterpret_cast<uint32_t *>(c->d_prep_part + 64));
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -1433,11 +1439,11 @@ int qr_k_prep_global(qr_ctx *c) {
 }
 
 int qr_k_metric_reduce(qr_ctx *c, int which) {
-  hipLaunchKernelGGL(k_prep, dim3(1), dim3(1024), 0, c->stream,
+  hipLaunchKernelGGL(k_prep, dim3(16), dim3(64), 0, c->stream,
                      (const double *)nullptr, 0u,
                      which ? c->d_vqmetric : c->d_qmetric,
                      (uint32_t)(which ? c->vQ : c->Q), (const double *)nullptr, 0u, c->d_scalars, 0,
-                     (QrScalars *)nullptr, 0);
+                     (QrScalars *)nullptr, 0, c->d_prep_part, reinterpret_cast<uint32_t *>(c->d_prep_part + 64));
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

@@ -2321,6 +2321,11 @@ __device__ __forceinline__ void nodes_out_publish(QrNodesOut *out, const long lo
 }
 __device__ __forceinline__ void nodes_out_write(const QrTreeState *ts, QrNodesOut *out, const long long seq) {
   const int nn = ts->nnodes;
+  if (threadIdx.x == 0) {  // (the header with the records: ONE system-scope fence before the number)
+    out->nnodes = nn;
+    out->pad[0] = ts->incomplete;
+    out->pad[1] = ts->real_steps;
+  }
   for (int i = threadIdx.x; i < nn; i += blockDim.x) {
     const QrNode &s = ts->nodes[i];
     qr_node_t d;
@@ -2336,12 +2341,8 @@ __device__ __forceinline__ void nodes_out_write(const QrTreeState *ts, QrNodesOu
   }
   __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0) {
-    out->nnodes = nn;
-    out->pad[0] = ts->incomplete;
-    out->pad[1] = ts->real_steps;
-    nodes_out_publish(out, seq);
-  }
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&out->pad[2], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // rt.cc:165-207
@@ -2372,9 +2373,20 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
     double s1 = 0.0, s2 = 0.0;
     if (e > b) {
       const uint32_t sl0 = b / QR_SLICE, sl1 = (e - 1) / QR_SLICE;
-      for (uint32_t s = sl0 + lane; s <= sl1; s += 64) {
-        s1 += leafpart[2 * ((size_t)s + l)];
-        s2 += leafpart[2 * ((size_t)s + l) + 1];
+      // (eight rounds of loads in flight: 8M documents are 30 rounds per lane)
+      for (uint32_t s = sl0 + lane; s <= sl1; s += 8 * 64) {
+        double2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t sk = s + 64u * k;
+          v[k] = sk <= sl1 ? *reinterpret_cast<const double2 *>(leafpart + 2 * ((size_t)sk + l)) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (s + 64u * k <= sl1) {
+            s1 += v[k].x;
+            s2 += v[k].y;
+          }
       }
     }
     s1 = wave_sum(s1);
@@ -2476,19 +2488,42 @@ __global__ __launch_bounds__(256) void k_score_update_walk(
     s_val[i] = ts->nodes[i].value;
   }
   __syncthreads();
-  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= N) return;
-  int n = 0;
-  if (wide) {  // u32 bins (k_wide.hip)
-    const uint32_t *fw = reinterpret_cast<const uint32_t *>(fm);
-    while (s_lf[n] >= 0)
-      n = fw[(size_t)s_lf[n] * N + d] <= (uint32_t)s_thr[n] ? s_left[n] : s_right[n];
-  } else {
-    while (s_lf[n] >= 0)
-      n = (int)fm[(size_t)s_lf[n] * N + d] <= s_thr[n] ? s_left[n] : s_right[n];
+  // Four consecutive documents per thread: their walks are independent chains of dependent
+  // one-byte loads, so four are in flight per lane instead of one (the launch is bound by the
+  // latency of those chains: 90 us for 8M documents with one), and the scores move as two
+  // 16-byte accesses.
+  const uint32_t d0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (d0 >= N) return;
+  int n[4] = {0, 0, 0, 0};
+  const uint32_t *fw = reinterpret_cast<const uint32_t *>(fm);
+  for (bool any = s_lf[0] >= 0; any;) {
+    uint32_t b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lf = s_lf[n[k]];
+      const uint32_t d = d0 + k < N ? d0 + k : N - 1;
+      b[k] = lf < 0 ? 0u : (wide ? fw[(size_t)lf * N + d] : (uint32_t)fm[(size_t)lf * N + d]);
+    }
+    any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (s_lf[n[k]] >= 0) {
+        n[k] = b[k] <= (uint32_t)s_thr[n[k]] ? s_left[n[k]] : s_right[n[k]];
+        any |= s_lf[n[k]] >= 0;
+      }
   }
-  const double add = shrinkage * s_val[n];
-  scores[d] = scores[d] + add;
+  if (d0 + 3 < N && (reinterpret_cast<size_t>(scores) & 15) == 0) {
+    double2 *sp = reinterpret_cast<double2 *>(scores + d0);
+    double2 u = sp[0], v = sp[1];
+    u.x = u.x + shrinkage * s_val[n[0]];
+    u.y = u.y + shrinkage * s_val[n[1]];
+    v.x = v.x + shrinkage * s_val[n[2]];
+    v.y = v.y + shrinkage * s_val[n[3]];
+    sp[0] = u;
+    sp[1] = v;
+  } else {
+    for (int k = 0; k < 4 && d0 + k < N; ++k) scores[d0 + k] = scores[d0 + k] + shrinkage * s_val[n[k]];
+  }
 }
 
 // mart.cc:447-457: validation scores by walking the tree on raw f32 rows
@@ -3343,7 +3378,7 @@ int qr_k_scores_update(qr_ctx *c, double shrinkage) {
     // every feature is here (single GPU, document-sharded): document-order walk;
     // also what a --subsample iteration needs (its leaves hold the sample only,
     // every training document is updated, mart.cc:345)
-    hipLaunchKernelGGL(k_score_update_walk, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
+    hipLaunchKernelGGL(k_score_update_walk, dim3((unsigned)((c->N + 1023) / 1024)), dim3(256), 0, c->stream, c->d_tree,
                        c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm,
                        (uint32_t)c->N, c->d_gf2lf, shrinkage, c->d_scores, c->wide ? 1 : 0);
   } else if (c->sub_k) {

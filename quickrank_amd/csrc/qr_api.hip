@@ -99,7 +99,9 @@ int qr_ctx_create(int device, qr_ctx **out) {
   (void)hipMemset(c->d_scalars, 0, sizeof(QrScalars));
   // (coherent = fine-grained: a kernel's stores are visible to the host while it runs)
   if (hipHostMalloc((void **)&c->h_pin, sizeof(QrPinned), hipHostMallocCoherent) != hipSuccess ||
-      hipHostGetDevicePointer((void **)&c->d_pin, c->h_pin, 0) != hipSuccess) {
+      hipHostGetDevicePointer((void **)&c->d_pin, c->h_pin, 0) != hipSuccess ||
+      hipMalloc((void **)&c->d_prep_part, 72 * 8) != hipSuccess ||
+      hipMemset(c->d_prep_part, 0, 72 * 8) != hipSuccess) {
     qr_ctx_destroy(c);
     g_create_err = "allocating the read-back buffers failed";
     return QR_ERR_HIP;
@@ -185,6 +187,7 @@ void qr_ctx_destroy(qr_ctx *c) {
   }
   if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->d_prep_part) (void)hipFree(c->d_prep_part);
   dfree(c->d_keys); dfree(c->d_tied);
   dfree(c->d_obl_feat); dfree(c->d_obl_thr); dfree(c->d_obl_leaves); dfree(c->d_obl_w);
   dfree(c->d_obl_depths); dfree(c->d_ob_fk); dfree(c->d_ob_thr); dfree(c->d_ob_thr_cnt);

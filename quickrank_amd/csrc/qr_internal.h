@@ -361,6 +361,7 @@ struct qr_ctx {
   // pinned block and then a sequence number behind a system-scope fence; the host polls that
   // number (wait_seq_impl in qr_api.hip).  No event on the stream: an event record between two
   // kernels was ~6 us of idle GPU each, and waking the host from hipEventSynchronize ~25 us.
+  double *d_prep_part = nullptr;  // k_prep: [16][4] workgroup partials + its ticket
   int32_t scal_seq = 0;   // of the last launch that publishes the scalars
   int64_t nodes_seq = 0;  // of the last launch that publishes tree records
   bool scal_pending = false, nodes_pending = false;

@@ -10,12 +10,12 @@ import torch; torch.cuda.init()
 from quickrank_amd._capi import Context
 if os.environ.get("QR_TL_BENCH"):  # the bench workload instead (1M x 136, 10000 queries of 100)
     from bench import synth
-    x, l, q = synth(10000, 100, 136)
+    x, l, q = synth(int(os.environ.get("QR_TL_QUERIES", "10000")), 100, 136)
 else:
     from datagen import make_mslr_like
     x, l, q = make_mslr_like()
 c = Context(0); c.upload(x, l, q); c.build_bins(255); c.reset_scores()
-for it in range(40):
+for it in range(int(os.environ.get("QR_TL_ITERS", "40"))):
     c.compute_lambdas("NDCG", 10); c.fit_tree(10, 1, True, read=False); c.update_scores(0.1); c.metric_last(); c.tree_nodes()
 c.synchronize()
 PY

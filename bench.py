@@ -505,11 +505,25 @@ def main():
             qb = np.arange(len(lb) // DPQ + 1, dtype=np.uint64) * DPQ
             del parts
             r = mk("docs" if multi else "single", xb, lb, qb, N * nb, Q * nb)
-            r.timed(es, min(args.warmup, 3))
+            r.timed(es, min(args.warmup, 3), prof=not multi)
             extras[f"strong_{nb}M"] = dict(
                 r.summary(f"synthetic {N * nb} docs x {F} features x {Q * nb} queries"
                           + (f" ({len(lb)} on rank {rank})" if multi else "") + ", " + desc,
                           f"document sharding x{world}" if multi else "1 GPU"), scaling="strong")
+            if not multi:
+                # the root histogram launch at this size (HIP events on the launch, as above):
+                # nothing of it fits the 256 MB Infinity Cache, and the ~10 us of prologue,
+                # flush and dispatch weigh an eighth of what they do at 1M documents
+                pb = r.ctx.prof_get()
+                r.ctx.prof_enable(False)
+                if pb["launches"]:
+                    secb = pb["total_ms"] / pb["launches"] * 1e-3
+                    extras[f"strong_{nb}M"]["roofline"] = {
+                        "bound": "hbm", "kernel": "k_hist_root (root histogram build)",
+                        "achieved": round(pb["alg_bytes"] / secb / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(pb["alg_bytes"] / secb / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "alg_bytes_per_launch": pb["alg_bytes"], "avg_launch_us": round(secb * 1e6, 2),
+                        "launches": pb["launches"]}
             r.close()
             del xb, lb, qb
 

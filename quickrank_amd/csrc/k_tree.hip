@@ -2311,6 +2311,247 @@ __global__ __launch_bounds__(256) void k_leaf_sums(
   }
 }
 
+// ---- small trees (at most QR_LDOC leaves): the same sums in DOCUMENT order -----------------
+// k_leaf_sums reaches lambda[id] / weight[id] through the leaves' document lists: one 64-byte
+// sector per 8-byte value once the leaves interleave (16 us per 1M documents, 96 us per 8M).
+// Here every document finds its leaf itself -- by walking the tree on the feature-major bins
+// (WALK: every feature is on this rank), or from the byte k_leaf_ids_scatter wrote through
+// the lists (feature-sharded ranks) -- and lambda / weight stream in coalesced.  The leaf of
+// every document is kept in `leafb` for the score update (k_score_update_leaf).  A workgroup
+// takes QR_SLICE consecutive documents, four per thread; per leaf: the thread's members in
+// document order, the lanes by wave_sum, the four waves pairwise -- a fixed order that does
+// not depend on how the leaf was found, so every layout ends with the same bits.
+// part: [leaf][slice][2].  present: --subsample's mask (the sums are the sample's).
+#define QR_LDOC 16
+template <bool WALK>
+__global__ __launch_bounds__(256) void k_leaf_sums_doc(
+    const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm, const uint32_t N,
+    const int32_t *__restrict__ gf2lf, const int wide, uint8_t *__restrict__ leafb,
+    const double *__restrict__ lambda, const double *__restrict__ weight,
+    const uint8_t *__restrict__ present, double *__restrict__ part) {
+  constexpr int NN = 2 * QR_LDOC;  // nodes of a tree of QR_LDOC leaves (2 L - 1)
+  // s_rec[n]: what a step of the walk needs of node n in ONE LDS word -- bit 31 = leaf;
+  // a leaf: its DFS index; an internal node: left | right << 8 | index of its test << 16
+  __shared__ uint32_t s_rec[NN];
+  __shared__ int32_t s_ilf[QR_LDOC], s_ithr[QR_LDOC];  // the internal nodes' tests, compacted
+  __shared__ int s_ni;
+  __shared__ double sh1[QR_LDOC][16], sh2[QR_LDOC][16];
+#ifdef QR_LEAF_TIMING
+  long long tq[8]; tq[0] = clock64();
+#define LT(i) tq[i] = clock64()
+#else
+#define LT(i)
+#endif
+  // (everything the staging needs is requested before any of it is looked at)
+  const int incomplete = ts->incomplete;
+  const int nl = ts->nleaves;
+  const int nn_all = ts->nnodes;
+  int f = -1, thr = 0, left = 0, right = 0, leafid = 0;
+  if (WALK && threadIdx.x < NN) {
+    const QrNode &nd = ts->nodes[threadIdx.x];  // (inside the array whatever nnodes says)
+    f = nd.feature;
+    thr = nd.thr_id;
+    left = nd.left;
+    right = nd.right;
+    leafid = nd.leaf_id;
+  }
+  if (incomplete) return;  // (the host carries the tree on and enqueues the leaf kernels again)
+  const int nn = nn_all < NN ? nn_all : NN;
+  if (WALK && threadIdx.x < 64) {  // one wave: records + compaction of the tests by ballot
+    const int i = threadIdx.x;
+    const int lfv = i < nn && f >= 0 ? gf2lf[f] : -1;
+    const unsigned long long m = __ballot(lfv >= 0);
+    const int idx = __popcll(m & ((1ull << i) - 1ull));
+    const int ni = __popcll(m) < QR_LDOC ? __popcll(m) : QR_LDOC;
+    const int lf_first = m ? __shfl(lfv, __ffsll((long long)m) - 1) : 0;
+    if (i < nn)
+      s_rec[i] = lfv >= 0 ? ((uint32_t)left | ((uint32_t)right << 8) | ((uint32_t)idx << 16))
+                          : (0x80000000u | (uint32_t)leafid);
+    if (lfv >= 0 && idx < QR_LDOC) {
+      s_ilf[idx] = lfv;
+      s_ithr[idx] = thr;
+    }
+    if (i >= ni && i < QR_LDOC) {  // (padding: repeats a real test, never looked at)
+      s_ilf[i] = lf_first;
+      s_ithr[i] = 0;
+    }
+    if (i == 0) s_ni = ni;
+  }
+  const uint32_t d0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  // the values first: their loads ride under the tests
+  double v1[4], v2[4];
+  bool in[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t d = d0 + k < N ? d0 + k : N - 1;
+    in[k] = d0 + k < N && (!present || present[d] != 0);
+    v1[k] = lambda[d];
+    v2[k] = weight ? weight[d] : 0.0;
+  }
+  __syncthreads();
+  LT(1);
+  int l[4];
+  if (WALK) {
+    // EVERY test of the tree on the thread's four documents at once -- at most QR_LDOC - 1
+    // independent loads (one dword = the four documents' bins of a feature) -- instead of a
+    // walk whose every level waits for a load that depends on the level before (a chain tree
+    // of 10 leaves is 9 such round trips: 6 of the 10 us a 1M-document walk took).  Bit j of
+    // go[k]: document k goes left at the j-th internal node; the walk then runs on LDS.
+    uint32_t go[4] = {0, 0, 0, 0};
+    const bool quad = (N & 3u) == 0;  // (uniform) the rows start on dword boundaries
+    if (s_ni > 0) {
+      if (!wide) {
+        uint32_t w4[QR_LDOC - 1];
+        if (quad) {
+          const uint32_t dq = d0 < N ? d0 : N - 4;  // (unconditional loads: clamped)
+#pragma unroll
+          for (int j = 0; j < QR_LDOC - 1; ++j)
+            w4[j] = *reinterpret_cast<const uint32_t *>(fm + (size_t)s_ilf[j] * N + dq);
+        } else {
+#pragma unroll
+          for (int j = 0; j < QR_LDOC - 1; ++j) w4[j] = 0;
+#pragma unroll 1
+          for (int k = 0; k < 4; ++k) {  // (rare: N not a multiple of 4 -- a document at a time)
+            const uint32_t d = d0 + k < N ? d0 + k : N - 1;
+#pragma unroll
+            for (int j = 0; j < QR_LDOC - 1; ++j) w4[j] |= (uint32_t)fm[(size_t)s_ilf[j] * N + d] << (8 * k);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < QR_LDOC - 1; ++j) {
+          const uint32_t t = (uint32_t)s_ithr[j];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) go[k] |= (((w4[j] >> (8 * k)) & 0xffu) <= t ? 1u : 0u) << j;
+        }
+      } else {
+        const uint32_t *fw = reinterpret_cast<const uint32_t *>(fm);
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {  // (u32 bins: a document at a time, its tests together)
+          const uint32_t d = d0 + k < N ? d0 + k : N - 1;
+          uint32_t g = 0;
+#pragma unroll
+          for (int j = 0; j < QR_LDOC - 1; ++j)
+            g |= (fw[(size_t)s_ilf[j] * N + d] <= (uint32_t)s_ithr[j] ? 1u : 0u) << j;
+          go[k] = g;
+        }
+      }
+    }
+    LT(2);
+    uint32_t rec[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rec[k] = s_rec[0];
+    for (bool any = !(rec[0] >> 31); any;) {
+      any = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (!(rec[k] >> 31)) {
+          rec[k] = s_rec[(go[k] >> ((rec[k] >> 16) & 0xffu)) & 1u ? rec[k] & 0xffu : (rec[k] >> 8) & 0xffu];
+          any |= !(rec[k] >> 31);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) l[k] = (int)(rec[k] & 0xffu);
+    if (d0 + 3 < N)
+      *reinterpret_cast<uint32_t *>(leafb + d0) =
+          (uint32_t)l[0] | ((uint32_t)l[1] << 8) | ((uint32_t)l[2] << 16) | ((uint32_t)l[3] << 24);
+    else
+      for (int k = 0; k < 4 && d0 + k < N; ++k) leafb[d0 + k] = (uint8_t)l[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) l[k] = d0 + k < N ? (int)leafb[d0 + k] : -1;
+  }
+  LT(3);
+  // per leaf: the thread's members in document order, the 16 lanes of a DPP row by butterflies
+  // (every lane of the row ends with the row's total), the 16 rows of the workgroup by thread
+  // `leaf` in row order -- fixed, and cheaper than a full wave_sum per (leaf, value): its eight
+  // readlanes and scalar adds were a third of this kernel
+  const int lane = threadIdx.x & 63;
+  const int row = threadIdx.x >> 4;  // 16 rows of 16 lanes
+  for (int t = 0; t < nl; ++t) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (in[k] && l[k] == t) {
+        a += v1[k];
+        b += v2[k];
+      }
+    a += dpp_f64<0xB1>(a);   // quad_perm [1,0,3,2]
+    b += dpp_f64<0xB1>(b);
+    a += dpp_f64<0x4E>(a);   // quad_perm [2,3,0,1]
+    b += dpp_f64<0x4E>(b);
+    a += dpp_f64<0x141>(a);  // row_half_mirror
+    b += dpp_f64<0x141>(b);
+    a += dpp_f64<0x140>(a);  // row_mirror
+    b += dpp_f64<0x140>(b);
+    if ((lane & 15) == 0) {
+      sh1[t][row] = a;
+      sh2[t][row] = b;
+    }
+  }
+  LT(4);
+  __syncthreads();
+  if ((int)threadIdx.x < nl) {  // part[leaf][slice][2]: k_leaf_final reads a leaf's slices in a row
+    const int t = threadIdx.x;
+    const size_t e = (size_t)t * gridDim.x + blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < 16; r += 4) {  // a wave's four rows as wave_sum adds them, the waves in order
+      a += (sh1[t][r] + sh1[t][r + 1]) + (sh1[t][r + 2] + sh1[t][r + 3]);
+      b += (sh2[t][r] + sh2[t][r + 1]) + (sh2[t][r + 2] + sh2[t][r + 3]);
+    }
+    part[2 * e] = a;
+    part[2 * e + 1] = b;
+  }
+#ifdef QR_LEAF_TIMING
+  LT(5);
+  if (WALK && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 500))
+    printf("leaf_sums_doc wg %u: stage %lld tests %lld walk %lld reduce %lld store %lld total %lld\n", blockIdx.x, tq[1]-tq[0], tq[2]-tq[1], tq[3]-tq[2], tq[4]-tq[3], tq[5]-tq[4], tq[5]-tq[0]);
+#endif
+}
+
+// feature-sharded ranks: the leaf of every listed document, written through the lists
+__global__ __launch_bounds__(256) void k_leaf_ids_scatter(
+    const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ order0,
+    const uint32_t *__restrict__ order1, uint8_t *__restrict__ leafb) {
+  __shared__ uint32_t lb[QR_LDOC + 1];
+  __shared__ int lbuf[QR_LDOC];
+  if (ts->incomplete) return;
+  const int nl = ts->nleaves;
+  if ((int)threadIdx.x <= nl) lb[threadIdx.x] = ts->leaf_begin[threadIdx.x];
+  if ((int)threadIdx.x < nl) lbuf[threadIdx.x] = ts->nodes[ts->leaf_nodes[threadIdx.x]].buf;
+  __syncthreads();
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= lb[nl]) return;
+  const int l = leaf_of_pos(lb, nl, p);
+  const int buf = lbuf[l];
+  leafb[buf == 2 ? p : (buf == 0 ? order0[p] : order1[p])] = (uint8_t)l;
+}
+
+// mart.cc:459-468 from the leaf bytes: scores[d] += shrinkage * leaf_value[leaf(d)], four
+// documents per thread (f64 multiply, then add; no contraction)
+__global__ __launch_bounds__(256) void k_score_update_leaf(
+    const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ leafb, const uint32_t N,
+    const double shrinkage, double *__restrict__ scores) {
+  __shared__ double lv[QR_LDOC];
+  if (ts->incomplete) return;  // the host carries the tree on and enqueues this update again
+  if ((int)threadIdx.x < ts->nleaves) lv[threadIdx.x] = ts->leaf_value[threadIdx.x];
+  __syncthreads();
+  const uint32_t d0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (d0 >= N) return;
+  if (d0 + 3 < N) {
+    const uint32_t lw = *reinterpret_cast<const uint32_t *>(leafb + d0);
+    double2 *sp = reinterpret_cast<double2 *>(scores + d0);
+    double2 u = sp[0], v = sp[1];
+    u.x = u.x + shrinkage * lv[lw & 0xffu];
+    u.y = u.y + shrinkage * lv[(lw >> 8) & 0xffu];
+    v.x = v.x + shrinkage * lv[(lw >> 16) & 0xffu];
+    v.y = v.y + shrinkage * lv[lw >> 24];
+    sp[0] = u;
+    sp[1] = v;
+  } else {
+    for (int k = 0; k < 4 && d0 + k < N; ++k) scores[d0 + k] = scores[d0 + k] + shrinkage * lv[leafb[d0 + k]];
+  }
+}
+
 // compact records of the finished tree (what crosses the C-ABI), written by the
 // whole workgroup once the leaf values are in place
 // `seq` (pad[2]) is stored LAST, behind a system-scope fence: the host polls it in the
@@ -2353,7 +2594,7 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
                                                      const int rank, const int world,
                                                      const int stride,
                                                      QrNodesOut *__restrict__ nodes_out,
-                                                     const long long seq) {
+                                                     const long long seq, const uint32_t dense_slices) {
   if (ts->incomplete) {  // tell the host, which carries the tree on (qr_k_tree_continue)
     if (threadIdx.x == 0) {
       nodes_out->pad[0] = 1;
@@ -2371,7 +2612,24 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
   for (int l = wave; l < nl; l += 16) {  // one wave per leaf, fixed reduction tree
     const uint32_t b = ts->leaf_begin[l], e = ts->leaf_begin[l + 1];
     double s1 = 0.0, s2 = 0.0;
-    if (e > b) {
+    if (dense_slices) {  // k_leaf_sums_doc's [leaf][slice][2]: every slice may hold the leaf
+      for (uint32_t s = lane; s < dense_slices; s += 8 * 64) {
+        double2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t sk = s + 64u * k;
+          v[k] = sk < dense_slices
+                     ? *reinterpret_cast<const double2 *>(leafpart + 2 * ((size_t)l * dense_slices + sk))
+                     : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (s + 64u * k < dense_slices) {
+            s1 += v[k].x;
+            s2 += v[k].y;
+          }
+      }
+    } else if (e > b) {
       const uint32_t sl0 = b / QR_SLICE, sl1 = (e - 1) / QR_SLICE;
       // (eight rounds of loads in flight: 8M documents are 30 rounds per lane)
       for (uint32_t s = sl0 + lane; s <= sl1; s += 8 * 64) {
@@ -3353,13 +3611,35 @@ int qr_k_tree_finish(qr_ctx *c, int newton) {
   const unsigned sgrid = (unsigned)((c->N + QR_SLICE - 1) / QR_SLICE);
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, c->stream, c->d_tree);
   QR_CHECK(c, hipGetLastError());
-  hipLaunchKernelGGL(k_leaf_sums, dim3(sgrid), dim3(256), 0, c->stream, c->d_tree,
-                     c->d_order[0], c->d_order[1], c->d_lambda,
-                     newton ? c->d_weight : (const double *)nullptr, c->d_leafpart);
+  // trees of up to QR_LDOC leaves: sums in document order (k_leaf_sums_doc), the leaf bytes
+  // kept for the score update
+  const bool doc_path = c->leaf_cap >= 1 && c->leaf_cap <= QR_LDOC && c->d_leafb && !c->leaf_by_position;
+  const bool walk = c->flocal == (int)c->F;
+  const double *wgt = newton ? c->d_weight : (const double *)nullptr;
+  const uint8_t *present = c->sub_k ? c->d_present : (const uint8_t *)nullptr;
+  c->leafb_valid = false;
+  if (doc_path && walk) {
+    hipLaunchKernelGGL(k_leaf_sums_doc<true>, dim3(sgrid), dim3(256), 0, c->stream, c->d_tree,
+                       c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm, (uint32_t)c->N,
+                       c->d_gf2lf, c->wide ? 1 : 0, c->d_leafb, c->d_lambda, wgt, present, c->d_leafpart);
+    c->leafb_valid = true;  // every document has walked
+  } else if (doc_path) {
+    hipLaunchKernelGGL(k_leaf_ids_scatter, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_tree, c->d_order[0], c->d_order[1], c->d_leafb);
+    QR_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_leaf_sums_doc<false>, dim3(sgrid), dim3(256), 0, c->stream, c->d_tree,
+                       (const uint8_t *)nullptr, (uint32_t)c->N, (const int32_t *)nullptr, 0, c->d_leafb,
+                       c->d_lambda, wgt, present, c->d_leafpart);
+    c->leafb_valid = !c->sub_k;  // (a sample's lists do not hold every document)
+  } else {
+    hipLaunchKernelGGL(k_leaf_sums, dim3(sgrid), dim3(256), 0, c->stream, c->d_tree,
+                       c->d_order[0], c->d_order[1], c->d_lambda, wgt, c->d_leafpart);
+  }
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_leaf_final, dim3(1), dim3(1024), 0, c->stream, c->d_tree,
                      c->d_leafpart, newton, c->dmode, c->d_xleaf, c->rank, c->world,
-                     (int)(2 * c->cur_nleaves), &c->d_pin->tree, (long long)(c->dmode ? c->nodes_seq : ++c->nodes_seq));
+                     (int)(2 * c->cur_nleaves), &c->d_pin->tree, (long long)(c->dmode ? c->nodes_seq : ++c->nodes_seq),
+                     doc_path ? (uint32_t)sgrid : 0u);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -3374,7 +3654,11 @@ int qr_k_tree_leaves_global(qr_ctx *c, int newton) {
 
 int qr_k_scores_update(qr_ctx *c, double shrinkage) {
   const unsigned grid = (unsigned)((c->N + 255) / 256);
-  if (c->flocal == (int)c->F) {
+  if (c->leafb_valid) {
+    // the leaf of every document is known (k_leaf_sums_doc): no walk, no lists
+    hipLaunchKernelGGL(k_score_update_leaf, dim3((unsigned)((c->N + 1023) / 1024)), dim3(256), 0, c->stream,
+                       c->d_tree, c->d_leafb, (uint32_t)c->N, shrinkage, c->d_scores);
+  } else if (c->flocal == (int)c->F) {
     // every feature is here (single GPU, document-sharded): document-order walk;
     // also what a --subsample iteration needs (its leaves hold the sample only,
     // every training document is updated, mart.cc:345)

@@ -79,6 +79,7 @@ int qr_ctx_create(int device, qr_ctx **out) {
   qr_ctx *c = new qr_ctx();
   c->no_batch = getenv("QR_NO_BATCH") != nullptr;
   c->exact_tail = getenv("QR_EXACT_TAIL") != nullptr;
+  if (getenv("QR_LEAF_BY_POSITION")) c->leaf_by_position = true;
   if (const char *e = getenv("QR_STEPS_HINT")) c->steps_force = atol(e);  // steps to enqueue, whatever the tree
   c->device = device;
   hipDeviceProp_t prop;
@@ -136,7 +137,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_red_sum); dfree(c->d_red_cnt);
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec); dfree(c->d_featthr); dfree(c->d_lscan_wg);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
-  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_lpart_ss2); dfree(c->d_jobsum); dfree(c->d_bpart_state); dfree(c->d_tree); dfree(c->d_tree2); dfree(c->d_leafpart);
+  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_lpart_ss2); dfree(c->d_jobsum); dfree(c->d_bpart_state); dfree(c->d_tree); dfree(c->d_tree2); dfree(c->d_leafpart); dfree(c->d_leafb);
   dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
   dfree(c->d_lpart_state);
   dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
@@ -593,7 +594,8 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, hipMemset(c->d_tree, 0, sizeof(QrTreeState)));
   QR_CHECK(c, dalloc(&c->d_tree2, (size_t)1));
   QR_CHECK(c, hipMemset(c->d_tree2, 0, sizeof(QrTreeState)));
-  QR_CHECK(c, dalloc(&c->d_leafpart, 2 * (N / QR_SLICE + QR_MAXNODES + 4)));
+  QR_CHECK(c, dalloc(&c->d_leafpart, std::max<size_t>(2 * (N / QR_SLICE + QR_MAXNODES + 4), 32 * (N / QR_SLICE + 2))));
+  QR_CHECK(c, dalloc(&c->d_leafb, N + 16));
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   c->binned = true;
   return QR_OK;
@@ -745,7 +747,8 @@ int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t 
   QR_CHECK(c, dalloc(&c->d_part_ss, 2 * (N / QR_PART_SLICE + 2)));
   QR_CHECK(c, dalloc(&c->d_tree, (size_t)1));
   QR_CHECK(c, hipMemset(c->d_tree, 0, sizeof(QrTreeState)));
-  QR_CHECK(c, dalloc(&c->d_leafpart, 2 * (N / QR_SLICE + QR_MAXNODES + 4)));
+  QR_CHECK(c, dalloc(&c->d_leafpart, std::max<size_t>(2 * (N / QR_SLICE + QR_MAXNODES + 4), 32 * (N / QR_SLICE + 2))));
+  QR_CHECK(c, dalloc(&c->d_leafb, N + 16));
   c->wide = true;
   c->binned = true;
   if (cells_out) *cells_out = c->wcells;
@@ -1126,6 +1129,7 @@ int qr_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
     QR_CHECK(c, hipMemset(c->d_xleaf, 0, c->xleaf_cap * 8));
   }
   c->cur_nleaves = nleaves;
+  c->leaf_cap = nleaves;
   c->cur_maxnodes = 2 * nleaves + 1;
   c->tree_open = true;
   c->tree_valid = false;
@@ -1233,6 +1237,7 @@ int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
     while (((size_t)1 << (depth - 1)) < QR_BATCH) ++depth;
     if ((rc = ensure_level_buffers(c, depth))) return rc;
     c->cur_nleaves = nleaves;
+    c->leaf_cap = nleaves;
     c->cur_maxnodes = 2 * nleaves + 1;
     c->tree_open = true;
     c->tree_valid = false;
@@ -1269,6 +1274,7 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
   if ((rc = ensure_level_buffers(c, depth))) return rc;
   c->tree_valid = false;
   c->tree_open = true;
+  c->leaf_cap = (size_t)1 << depth;
   c->cur_maxnodes = ((size_t)1 << (depth + 1)) - 1;
   if ((rc = qr_k_oblivious_fit(c, depth, minls))) return rc;
   return qr_tree_end(c, newton, nodes_out, nnodes_out);
@@ -1287,6 +1293,7 @@ int qr_obl_begin(qr_ctx *c, size_t depth, uint64_t minls) {
   if ((rc = ensure_level_buffers(c, depth))) return rc;
   c->tree_valid = false;
   c->tree_open = true;
+  c->leaf_cap = (size_t)1 << depth;
   c->cur_depth = depth;
   c->cur_maxnodes = ((size_t)1 << (depth + 1)) - 1;
   if (c->dmode) {

@@ -413,7 +413,11 @@ struct qr_ctx {
   size_t lhist_cap = 0, lpart_cap = 0, lslots_cap = 0, lred_nodes = 0;
   uint64_t *d_lpartials = nullptr;
   unsigned long long *d_lpart_state = nullptr;
-  double *d_leafpart = nullptr;  // [slices][2] partial sums
+  double *d_leafpart = nullptr;  // [slices][2] partial sums (k_leaf_sums), or [slices][16][2] (k_leaf_sums_doc)
+  uint8_t *d_leafb = nullptr;    // [N] leaf of every document in the last small tree (k_leaf_sums_doc)
+  size_t leaf_cap = 0;           // leaves the tree under construction can have (<= 16: the document-order leaf kernels)
+  bool leafb_valid = false;      // d_leafb covers every document of the finished tree
+  bool leaf_by_position = false; // QR_LEAF_BY_POSITION=1: always k_leaf_sums (tests compare the two)
   bool tree_valid = false;
   bool tree_open = false;
   int tree_step = 0;             // decides issued for the open tree

@@ -797,3 +797,38 @@ def test_guessed_step_count_and_continuation(qr, ora, monkeypatch, hint):
     assert np.allclose(gm.train_metric, om["train_metric"], rtol=1e-9)
     assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-8, atol=1e-10)
     gm.ctx.close()
+
+
+@pytest.mark.parametrize("algo,nleaves,subsample", [("LAMBDAMART", 10, 1.0), ("LAMBDAMART", 16, 0.5),
+                                                     ("MART", 7, 1.0), ("OBVLAMBDAMART", 16, 1.0)])
+def test_leaf_sums_in_document_order_equal_the_position_order(qr, monkeypatch, algo, nleaves, subsample):
+    """Trees of up to 16 leaves take their leaf sums in document order (k_leaf_sums_doc: every
+    document finds its leaf by the tree's tests, lambda / weight stream in coalesced) and update
+    the scores from the leaf bytes; larger ones through the leaves' document lists (k_leaf_sums,
+    which QR_LEAF_BY_POSITION=1 forces).  Same trees -- structure bit for bit, leaf values and
+    scores to the rounding of two summation orders -- over several boosting iterations."""
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(nq=200, docs_per_query=53, F=24, seed=23, ragged=True)
+    kw = dict(ntrees=5, shrinkage=0.1, nthresholds=64, minls=3, esr=0)
+    if algo.startswith("OBV"):
+        kw["depth"] = 4
+    else:
+        kw["nleaves"] = nleaves
+    if subsample != 1.0:
+        kw["subsample"] = subsample
+    got = Mart(algo=algo, **kw).learn(x, labels, qoff)
+    monkeypatch.setenv("QR_LEAF_BY_POSITION", "1")
+    want = Mart(algo=algo, **kw).learn(x, labels, qoff)
+    monkeypatch.delenv("QR_LEAF_BY_POSITION")
+    for t in range(kw["ntrees"]):
+        g, w = got.ensemble.trees[t], want.ensemble.trees[t]
+        assert len(g) == len(w)
+        for k in ("feature", "thr_id", "threshold", "left", "right", "nsamples"):
+            assert np.array_equal(g[k], w[k]), (t, k)
+        # (a leaf's sum of lambdas cancels: the two orders agree to ~1e-16 of the sum of the
+        # magnitudes, not of the result -- the tolerance the oracle comparison uses)
+        assert np.allclose(g["value"], w["value"], rtol=1e-9, atol=1e-12), (t, np.abs(g["value"] - w["value"]).max())
+    assert np.allclose(got.ctx.get_scores(), want.ctx.get_scores(), rtol=1e-9, atol=1e-12)
+    assert np.allclose(got.train_metric, want.train_metric, rtol=1e-12)
+    got.ctx.close()
+    want.ctx.close()

@@ -254,22 +254,33 @@ class Run:
         # ranking + NDCG@10 of the current scores (= the training metric the
         # reference evaluates at the end of the previous iteration, mart.cc:347)
         # + lambdas/weights in one pass over the queries; tree; leaf outputs; score
-        # update.  Everything is enqueued first; the metric and the tree records are
-        # read last (pinned snapshots + events), so the host never drains the stream
-        # in the middle of an iteration.
+        # update.  Everything is enqueued first; the metric and the tree records are read
+        # from pinned snapshots the kernels publish, so the host never drains the stream in
+        # the middle of an iteration -- and the records of tree i are read after iteration
+        # i + 1's lambda pass is enqueued (qr_lambda_compute settles tree i on its last control
+        # call, ~35 us before its leaf kernels and score update have run; nothing of tree i is
+        # overwritten before the next fit_tree), so the GPU always has work queued.
         a, ctx = self.args, self.ctx
         if self.trainer is not None:
             self.trainer.compute_lambdas("NDCG", 10)
+            self.flush()
             self.trainer.fit_tree(a.nleaves, 1, True, read=False)
         else:
             ctx.compute_lambdas("NDCG", 10)
+            self.flush()
             if self.fitter is not None:
                 self.fitter.fit_tree(ctx, a.nleaves, 1, True, read=False)
             else:
                 ctx.fit_tree(a.nleaves, 1, True, read=False)
         ctx.update_scores(0.1)
+        self.tree_pending = True
         self.ndcg.append(ctx.metric_last())
-        self.trees.append(ctx.tree_nodes())
+
+    def flush(self):
+        """The records of the last enqueued tree (every tree is read exactly once)."""
+        if getattr(self, "tree_pending", False):
+            self.trees.append(self.ctx.tree_nodes())
+            self.tree_pending = False
 
     def sync(self):
         if self.dist is not None:
@@ -281,6 +292,7 @@ class Run:
         sides; returns the max over ranks of the elapsed seconds."""
         for _ in range(warmup):
             self.step()
+        self.flush()
         if prof:
             self.ctx.prof_enable(True)
             self.ctx.prof_reset()
@@ -288,6 +300,7 @@ class Run:
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
+        self.flush()
         self.sync()
         elapsed = time.perf_counter() - t0
         if self.dist is not None:

@@ -1893,7 +1893,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
     QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
     const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
-    const QrTreeState *tin, const int final_call) {
+    const QrTreeState *tin, const int final_call, int64_t *__restrict__ early, const long long early_seq) {
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
   __shared__ int sh_nj;
@@ -1902,6 +1902,15 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
                     root_mode, nleaves_arg, minls_arg, stage_nodes, N, flocal, scal, part_ss, featrec,
                     featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, part_wg, part_grid,
                     plans, scan_wg, final_call);
+  if (final_call && early) {  // QrPinned::early: the host settles the tree on this
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      early[0] = __hip_atomic_load(&ts->incomplete, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      early[1] = __hip_atomic_load(&ts->real_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(&early[2], (int64_t)early_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ===========================================================================
@@ -3393,7 +3402,8 @@ static int launch_decide_batch(qr_ctx *c, const BatchGeom &g, size_t nleaves, ui
                      dim3(1), dim3(128 * QR_BATCH), 0, c->stream, tout, root, (int)nleaves, (u64)minls,
                      g.stage_nodes, g.rootn, c->flocal, c->d_scalars, c->d_jobsum, c->d_featrec, c->d_featthr,
                      (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, g.hg,
-                     c->d_lpart_wg, g.pg, c->d_lplan, c->d_lscan_wg, tin, final_call);
+                     c->d_lpart_wg, g.pg, c->d_lplan, c->d_lscan_wg, tin, final_call,
+                     final_call ? c->d_pin->early : (int64_t *)nullptr, (long long)(final_call ? ++c->early_seq : 0));
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

@@ -1156,27 +1156,30 @@ static int snapshot_nodes(qr_ctx *c) {
 }
 
 // Batched growth enqueues a guessed number of steps (qr_k_tree_fit_batch).  Waits for the
-// tree's records; if the device reports that the guess was too low, carries the tree on,
+// tree's last control call; if the device reports that the guess was too low, carries the tree on,
 // repeats the leaf kernels (and the score update, if it was enqueued behind them: it left
 // at once on the incomplete tree) and waits again.  Everything that consumes the tree or
 // the scores calls this first; in the usual loop qr_tree_nodes does.
 static int tree_settle(qr_ctx *c) {
   if (!c->spec_pending) return QR_OK;
-  { const int wrc = wait_seq64(c, &c->h_pin->tree.pad[2], c->nodes_seq, "the tree's records"); if (wrc) return wrc; }
+  // (the last control call's word, QrPinned::early -- not the records: the leaf kernels and the
+  // score update behind that call are still running, and whatever the caller enqueues next
+  // lines up under them)
+  { const int wrc = wait_seq64(c, &c->h_pin->early[2], c->early_seq, "the tree's last control call"); if (wrc) return wrc; }
   c->spec_pending = false;
   ++c->spec_trees;
-  if (c->h_pin->tree.pad[0]) {  // incomplete
+  if (c->h_pin->early[0]) {  // incomplete
     ++c->spec_misses;
     int rc = qr_k_tree_continue(c, c->cur_nleaves, c->cur_minls, (size_t)c->tree_step);
     if (rc) return rc;
     if ((rc = qr_k_tree_finish(c, c->spec_newton))) return rc;
     if (c->spec_scores_enqueued && (rc = qr_k_scores_update(c, c->spec_shrinkage))) return rc;
-    { const int wrc = wait_seq64(c, &c->h_pin->tree.pad[2], c->nodes_seq, "the tree's records"); if (wrc) return wrc; }
-    if (c->h_pin->tree.pad[0]) QR_FAIL(c, QR_ERR_STATE, "internal: tree still incomplete after its last step");
+    { const int wrc = wait_seq64(c, &c->h_pin->early[2], c->early_seq, "the tree's last control call"); if (wrc) return wrc; }
+    if (c->h_pin->early[0]) QR_FAIL(c, QR_ERR_STATE, "internal: tree still incomplete after its last step");
   }
   c->spec_scores_enqueued = false;
   // the next tree: as many steps as this one needed, plus one
-  c->steps_hint = (size_t)c->h_pin->tree.pad[1] + 1;
+  c->steps_hint = (size_t)c->h_pin->early[1] + 1;
   return QR_OK;
 }
 

@@ -257,6 +257,12 @@ struct QrNodesOut {
 struct QrPinned {
   QrScalars scal;
   QrNodesOut tree;
+  // batched growth: what the LAST control call of the enqueued sequence found -- [0] the tree
+  // is incomplete (the guessed step count was too low), [1] the steps it took so far, [2] the
+  // call's sequence number (stored last, as QrNodesOut::pad[2]).  The host settles a tree on
+  // this, ~35 us before the leaf kernels and the score update behind it have run: the next
+  // iteration is enqueued under them.
+  int64_t early[4];
 };
 
 struct qr_ctx {
@@ -364,6 +370,7 @@ struct qr_ctx {
   double *d_prep_part = nullptr;  // k_prep: [16][4] workgroup partials + its ticket
   int32_t scal_seq = 0;   // of the last launch that publishes the scalars
   int64_t nodes_seq = 0;  // of the last launch that publishes tree records
+  int64_t early_seq = 0;  // of the last final control call (QrPinned::early)
   bool scal_pending = false, nodes_pending = false;
   size_t cur_maxnodes = 0;
   // tree

@@ -16,7 +16,9 @@ else:
     x, l, q = make_mslr_like()
 c = Context(0); c.upload(x, l, q); c.build_bins(255); c.reset_scores()
 for it in range(int(os.environ.get("QR_TL_ITERS", "40"))):
-    c.compute_lambdas("NDCG", 10); c.fit_tree(10, 1, True, read=False); c.update_scores(0.1); c.metric_last(); c.tree_nodes()
+    c.compute_lambdas("NDCG", 10)
+    if it: c.tree_nodes()  # (the previous tree's records, read under this iteration's lambda pass: bench.py's order)
+    c.fit_tree(10, 1, True, read=False); c.update_scores(0.1); c.metric_last()
 c.synchronize()
 PY
 rm -rf gpurun_out/mslr_tl

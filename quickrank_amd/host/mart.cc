@@ -343,12 +343,25 @@ void Mart::learn(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::
   // instead of two, and no stream drain in between.
   const bool lagged = lambda && !validation && subsample_ == 1.0f;  // sampled rankings are not the metric's
   const size_t first = ensemble_model_.get_size();
+  // The records of tree m are fetched after iteration m + 1's first pass is enqueued: the
+  // library settles a tree on its last control call, before its leaf kernels and score update
+  // have run, so that pass lines up under them and the device never waits for the host
+  // (nothing of tree m is overwritten before the next fit).
+  bool tree_pending = false;
+  auto take_tree = [&]() {
+    if (!tree_pending) return;
+    size_t nn = 0;
+    QR(qr_tree_nodes(ctx_, nodes.data(), &nn));                            // waits for the tree only
+    ensemble_model_.push(tree_from_records(nodes.data(), 0), shrinkage_);  // mart.cc:342
+    tree_pending = false;
+  };
   for (size_t m = first; m < ntrees_; ++m) {
     if (validation && (valid_iterations_ && m > best_model_ + valid_iterations_)) break;
     if (lambda)
       QR(qr_lambda_compute(ctx_, mcode, cutoff));  // lambdamart.cc:62-152
     else
       QR(qr_residual_compute(ctx_));               // mart.cc:418-431
+    take_tree();
     if (obliv)
       QR(qr_oblivious_fit(ctx_, treedepth_, minleafsupport_, lambda, nullptr, nullptr));
     else
@@ -359,19 +372,21 @@ void Mart::learn(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::
       QR(qr_metric_last(ctx_, &prev));  // waits for this iteration's lambda pass only
       report(m, prev, nullptr);
     }
-    size_t nn = 0;
-    QR(qr_tree_nodes(ctx_, nodes.data(), &nn));                            // waits for the tree only
-    ensemble_model_.push(tree_from_records(nodes.data(), 0), shrinkage_);  // mart.cc:342
+    tree_pending = true;
     if (!lagged) {
+      take_tree();
       MetricScore metric_on_training = 0, metric_on_validation = 0;
       QR(qr_metric_eval(ctx_, 0, mcode, cutoff, &metric_on_training));     // mart.cc:347
       if (validation)
         QR(qr_metric_eval(ctx_, 1, mcode, cutoff, &metric_on_validation)); // mart.cc:359
       report(m + 1, metric_on_training, validation ? &metric_on_validation : nullptr);
     }
-    if (partial_save != 0 && !output_basename.empty() && (m + 1) % partial_save == 0)
+    if (partial_save != 0 && !output_basename.empty() && (m + 1) % partial_save == 0) {
+      take_tree();
       save(output_basename, (int)(m + 1));
+    }
   }
+  take_tree();
   if (lagged && ensemble_model_.get_size() > first) {
     MetricScore last = 0;
     QR(qr_metric_eval(ctx_, 0, mcode, cutoff, &last));

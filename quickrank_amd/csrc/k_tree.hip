@@ -1905,10 +1905,12 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   if (final_call && early) {  // QrPinned::early: the host settles the tree on this
     __syncthreads();
     if (threadIdx.x == 0) {
-      early[0] = __hip_atomic_load(&ts->incomplete, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      early[1] = __hip_atomic_load(&ts->real_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
-      __hip_atomic_store(&early[2], (int64_t)early_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // ONE 8-byte word -- sequence number << 16 | steps << 1 | incomplete -- so that no fence
+      // (a PCIe round trip of ~3 us at the end of this launch) has to order it behind its data
+      const long long inc = __hip_atomic_load(&ts->incomplete, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+      const long long st = __hip_atomic_load(&ts->real_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x7fff;
+      __hip_atomic_store(&early[0], (int64_t)((early_seq << 16) | (st << 1) | inc), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

@@ -1160,26 +1160,52 @@ static int snapshot_nodes(qr_ctx *c) {
 // repeats the leaf kernels (and the score update, if it was enqueued behind them: it left
 // at once on the incomplete tree) and waits again.  Everything that consumes the tree or
 // the scores calls this first; in the usual loop qr_tree_nodes does.
+// (the word the last control call publishes: QrPinned::early)
+static int wait_early(qr_ctx *c, int64_t *word_out) {
+  for (unsigned spin = 1;; ++spin) {
+    const int64_t w = __atomic_load_n(&c->h_pin->early[0], __ATOMIC_ACQUIRE);
+    if ((w >> 16) == c->early_seq) {
+      *word_out = w;
+      return QR_OK;
+    }
+    if ((spin & 1023u) == 0) {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess) {  // everything enqueued has run
+        QR_CHECK(c, hipStreamSynchronize(c->stream));
+        const int64_t w2 = __atomic_load_n(&c->h_pin->early[0], __ATOMIC_ACQUIRE);
+        if ((w2 >> 16) == c->early_seq) {
+          *word_out = w2;
+          return QR_OK;
+        }
+        QR_FAIL(c, QR_ERR_STATE, "internal: the tree's last control call was not published");
+      }
+      if (e != hipErrorNotReady) QR_CHECK(c, e);
+    }
+    __builtin_ia32_pause();
+  }
+}
+
 static int tree_settle(qr_ctx *c) {
   if (!c->spec_pending) return QR_OK;
   // (the last control call's word, QrPinned::early -- not the records: the leaf kernels and the
   // score update behind that call are still running, and whatever the caller enqueues next
   // lines up under them)
-  { const int wrc = wait_seq64(c, &c->h_pin->early[2], c->early_seq, "the tree's last control call"); if (wrc) return wrc; }
+  int64_t w = 0;
+  int rc = wait_early(c, &w);
+  if (rc) return rc;
   c->spec_pending = false;
   ++c->spec_trees;
-  if (c->h_pin->early[0]) {  // incomplete
+  if (w & 1) {  // incomplete
     ++c->spec_misses;
-    int rc = qr_k_tree_continue(c, c->cur_nleaves, c->cur_minls, (size_t)c->tree_step);
-    if (rc) return rc;
+    if ((rc = qr_k_tree_continue(c, c->cur_nleaves, c->cur_minls, (size_t)c->tree_step))) return rc;
     if ((rc = qr_k_tree_finish(c, c->spec_newton))) return rc;
     if (c->spec_scores_enqueued && (rc = qr_k_scores_update(c, c->spec_shrinkage))) return rc;
-    { const int wrc = wait_seq64(c, &c->h_pin->early[2], c->early_seq, "the tree's last control call"); if (wrc) return wrc; }
-    if (c->h_pin->early[0]) QR_FAIL(c, QR_ERR_STATE, "internal: tree still incomplete after its last step");
+    if ((rc = wait_early(c, &w))) return rc;
+    if (w & 1) QR_FAIL(c, QR_ERR_STATE, "internal: tree still incomplete after its last step");
   }
   c->spec_scores_enqueued = false;
   // the next tree: as many steps as this one needed, plus one
-  c->steps_hint = (size_t)c->h_pin->early[1] + 1;
+  c->steps_hint = (size_t)((w >> 1) & 0x7fff) + 1;
   return QR_OK;
 }
 

@@ -257,11 +257,11 @@ struct QrNodesOut {
 struct QrPinned {
   QrScalars scal;
   QrNodesOut tree;
-  // batched growth: what the LAST control call of the enqueued sequence found -- [0] the tree
-  // is incomplete (the guessed step count was too low), [1] the steps it took so far, [2] the
-  // call's sequence number (stored last, as QrNodesOut::pad[2]).  The host settles a tree on
-  // this, ~35 us before the leaf kernels and the score update behind it have run: the next
-  // iteration is enqueued under them.
+  // batched growth: what the LAST control call of the enqueued sequence found, in ONE word
+  // (early[0]: the call's sequence number << 16 | the steps the tree took so far << 1 | the tree
+  // is incomplete, i.e. the guessed step count was too low).  The host settles a tree on this,
+  // ~35 us before the leaf kernels and the score update behind it have run: the next iteration
+  // is enqueued under them.
   int64_t early[4];
 };
 

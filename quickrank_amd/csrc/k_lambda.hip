@@ -1194,7 +1194,8 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   size_t kacc = cutoff == 0 || cutoff > maxq ? maxq : cutoff;
   if (kacc == 0) kacc = 1;
   kacc = (kacc + 1) & ~(size_t)1;
-  const size_t limit = 160 * 1024 - 512;
+  // (dynamic LDS; the static part is up to ~1 KB with sixteen waves: sh_part, sh_red)
+  const size_t limit = 160 * 1024 - 2048;
   const bool sampled = which == 0 && c->sub_k != 0;
   // the longest query the LDS holds; longer ones run out of a global scratch slice each
   // (LONG launch); an unbounded cutoff on a long query would also need the per-rank

@@ -832,3 +832,26 @@ def test_leaf_sums_in_document_order_equal_the_position_order(qr, monkeypatch, a
     assert np.allclose(got.train_metric, want.train_metric, rtol=1e-12)
     got.ctx.close()
     want.ctx.close()
+
+
+@pytest.mark.parametrize("n", [600, 2000, 3250, 3300])
+def test_one_query_at_the_lds_boundary(qr, ora, n):
+    """A single long query next to a short one: 600 documents take the sixteen-wave class,
+    3250-3300 sit at the largest working set the LDS holds (dynamic + the sixteen-wave
+    kernel's static part must stay inside 160 KB: a launch that asked for more was refused
+    with `invalid argument`), beyond that the global-scratch launch takes over."""
+    rng = np.random.default_rng(n)
+    N = n + 37
+    x = rng.random((N, 4), dtype=np.float32)
+    labels = rng.integers(0, 5, N).astype(np.float32)
+    qoff = np.array([0, n, N], np.uint64)
+    scores = np.round(rng.standard_normal(N), 1)
+    c, _, _ = _ctx(qr, x, labels, qoff, 16)
+    c.set_scores(scores)
+    c.compute_lambdas("NDCG", 10)
+    lam, w = c.get_pseudo()
+    olam, ow = ora.lambdas(labels, scores, qoff, 10, 1)
+    assert np.allclose(lam, olam, rtol=1e-10, atol=1e-14)
+    assert np.allclose(w, ow, rtol=1e-10, atol=1e-14)
+    assert c.metric_last() == pytest.approx(ora.eval_dataset(labels, scores, qoff, 10, 1), rel=1e-13)
+    c.close()

@@ -182,9 +182,11 @@ int qr_metric_last(qr_ctx *ctx, double *out);
 /* records later with qr_tree_nodes.                                             */
 int qr_tree_fit(qr_ctx *ctx, size_t nleaves, uint64_t minls, int newton,
                 qr_node_t *nodes_out, size_t *nnodes_out);
-/* records of the last fitted tree.  They reach pinned host memory by an async   */
-/* copy enqueued right behind the tree's kernels, so this waits for the tree      */
-/* only -- not for work enqueued after it (score update, the next lambdas).       */
+/* records of the last fitted tree.  The tree's last kernel writes them into      */
+/* pinned host memory, then a sequence number this call polls: it waits for the   */
+/* tree only -- not for work enqueued after it (score update, the next lambdas).  */
+/* They stay valid until the next tree is fitted: a host may enqueue the next      */
+/* iteration's qr_lambda_compute first and fetch them under it.   */
 /* The step count of an enqueued tree is a guess; a tree the guess   */
 /* cut short is completed here -- and by every other call that reads or builds on */
 /* its results -- before anything is returned: callers never see a partial tree.  */

@@ -389,7 +389,11 @@ class Context:
     def set_max_features(self, max_features, seed=0):
         self._ck(self.L.qr_tree_set_max_features(self.h, float(max_features), int(seed)))
 
-    def fit_oblivious(self, depth=3, minls=1, newton=True):
+    def fit_oblivious(self, depth=3, minls=1, newton=True, read=True):
+        """read=False: enqueue only; fetch the records later with tree_nodes()."""
+        if not read:
+            self._ck(self.L.qr_oblivious_fit(self.h, depth, minls, int(newton), None, None))
+            return None
         nodes = np.zeros((1 << (depth + 1)) - 1, NODE_DTYPE)
         n = C.c_size_t()
         self._ck(self.L.qr_oblivious_fit(self.h, depth, minls, int(newton), _ptr(nodes),

@@ -12,6 +12,7 @@ inputs resident in HBM before the timed region starts.
 
   python bench.py --gpus 1 --steps 60 --warmup 5   (the defaults)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N ...   (no launcher: bench.py starts the N ranks itself)
 
 N = 1 adds to the line: `roofline` (root histogram launch, HIP events on the launch),
 `roofline_iteration` (algorithmic bytes of the whole iteration from the measured tree
@@ -294,7 +295,9 @@ class Run:
             self.step()
         self.flush()
         if prof:
-            self.ctx.prof_enable(True)
+            # HIP events on every 4th root launch of the timed region: an evented launch costs
+            # the stream ~7.5 us (scripts/ubench/launch_chain.hip), which is the timed region's
+            self.ctx.prof_enable(True, every=4)
             self.ctx.prof_reset()
         self.sync()
         t0 = time.perf_counter()
@@ -370,7 +373,25 @@ def main():
                     help="the larger strong-scaling set: this many 1M-document blocks (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (process group, sharded drivers) with one rank")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="re-exec under torch.distributed.run even with --gpus 1 (what --gpus N > 1 does "
+                         "when no launcher started this process; tests)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start
+    # the N ranks ourselves, one process per GPU, exactly as the documented command line does
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_launch):
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        passed = [a for a in sys.argv[1:] if a != "--self-launch"]
+        if args.self_launch and "--force-dist" not in passed:
+            passed.append("--force-dist")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + passed
+        print("bench.py: no launcher environment, starting " + " ".join(cmd), file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
 
     # stdout carries exactly ONE line (the JSON): libraries that print banners to
     # file descriptor 1 (RCCL does at communicator creation) go to stderr instead
@@ -413,8 +434,7 @@ def main():
 
     def doc_slice(nq_total, r, w):
         """Whole queries [q0, q1) of rank r of w."""
-        per = (nq_total + w - 1) // w
-        return min(nq_total, per * r), min(nq_total, per * (r + 1))
+        return nq_total * r // w, nq_total * (r + 1) // w   # balanced: no rank is left empty while w <= nq_total
 
     def mk(layout, xx, ll, qq, n_global, q_global):
         return Run(torch, dist, layout, xx, ll, qq, n_global, q_global, args, rank, world, local_rank)
@@ -423,7 +443,7 @@ def main():
     if not multi:
         # ---- N = 1: BASELINE.json configs[1] on one GPU ---------------------------
         head = mk("single", x, labels, qoff, N, Q)
-        head.timed(args.steps, args.warmup, prof=True)
+        head.timed(args.steps, args.warmup, prof=not os.environ.get("QR_BENCH_NO_EVENTS"))
         prof = head.ctx.prof_get()
         head.ctx.prof_enable(False)
         hs = head.summary(same_set + ", " + desc, "1 GPU")

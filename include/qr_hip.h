@@ -350,7 +350,9 @@ int qr_oblivious_score(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
 int qr_prof_reset(qr_ctx *ctx);
 int qr_prof_get(qr_ctx *ctx, uint64_t *launches, double *total_ms,
                 double *alg_bytes_per_launch);
-/* on: bit 0 = time the root histogram launches, bit 1 = also the child launches  */
+/* on: bit 0 = time the root histogram launches, bit 1 = also the child launches; */
+/* bits 8..15 = k: events on every k-th root launch only (0 = every launch; an     */
+/* evented launch costs the stream ~7.5 us)                                          */
 int qr_prof_enable(qr_ctx *ctx, int on);
 /* child-histogram launches (k_hist_batch) since the last reset; their algorithmic */
 /* bytes depend on the trees: sum over splits of n_small * (F + 12), from the       */

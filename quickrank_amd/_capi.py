@@ -564,8 +564,10 @@ class Context:
         return out, ms.value
 
     # -- instrumentation ------------------------------------------------------
-    def prof_enable(self, on=True, children=False):
-        self._ck(self.L.qr_prof_enable(self.h, int(bool(on)) | (2 if children else 0)))
+    def prof_enable(self, on=True, children=False, every=1):
+        """HIP events on the root histogram launches (every `every`-th one), optionally on the
+        child launches too."""
+        self._ck(self.L.qr_prof_enable(self.h, int(bool(on)) | (2 if children else 0) | ((int(every) & 0xff) << 8)))
 
     def prof_get_child(self):
         n, ms = C.c_uint64(), C.c_double()

@@ -54,6 +54,25 @@
 #define QR_HIST_SETS 3
 #endif
 
+// the control lane's helpers: inlined, or (-DQR_CTRL_NOINLINE, an experiment) shared calls
+#ifdef QR_CTRL_NOINLINE
+#define QR_CTRL_FN __noinline__
+#else
+#define QR_CTRL_FN __forceinline__
+#endif
+
+// -DQR_STEP_TIMING (scripts/step_timing.py): clock64 stamps of one histogram workgroup's
+// sections, with the load queue drained at the first two so that they show the dependent
+// round trips (descriptor -> ids -> rows) one by one
+#ifdef QR_STEP_TIMING
+__device__ long long qr_ht[8];
+#define QR_HT(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) qr_ht[i] = clock64(); } while (0)
+#define QR_HT_WAIT(i) do { __builtin_amdgcn_s_waitcnt(0); QR_HT(i); } while (0)
+#else
+#define QR_HT(i)
+#define QR_HT_WAIT(i)
+#endif
+
 template <int CH, bool IDENTITY>
 __device__ __forceinline__ void hist_accumulate(
     u64 *__restrict__ hist, const uint8_t *__restrict__ bins_b,
@@ -125,11 +144,13 @@ __device__ __forceinline__ void hist_accumulate(
     v[i] = valid(p0 + i * step);
     id[i] = get_id(clampp(p0 + i * step));
   }
+  QR_HT_WAIT(1);   // (timing builds only: the ids have arrived)
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     row[i] = load_row(id[i]);
     lam[i] = lambda[id[i]];
   }
+  QR_HT_WAIT(2);   // (timing builds only: the first rows have arrived)
 #pragma unroll
   for (int i = 0; i < NS; ++i) id[i] = get_id(clampp(p0 + (NS + i) * step));
   // zero the cells while the first tiles are on their way
@@ -138,6 +159,7 @@ __device__ __forceinline__ void hist_accumulate(
     hist[i + 1] = 0;
   }
   __syncthreads();
+  QR_HT(3);
   uint32_t pos = p0;
   for (uint32_t tile = r0 + wave * DW; tile < r1; tile += NS * step, pos += NS * step) {
 #pragma unroll
@@ -217,6 +239,7 @@ __device__ __forceinline__ void hist_run(
       }
     }
     __syncthreads();
+    QR_HT(4);
     u64 *dst = partials + (slot0 + k) * (256u * 64u);
     if (tr) {
       // feature-major slot [column][256 bins] for k_redscan, which reads one column
@@ -242,6 +265,7 @@ __device__ __forceinline__ void hist_run(
       *reinterpret_cast<ulonglong2 *>(dst + i) = v;
     }
     __syncthreads();
+    QR_HT_WAIT(5);
   }
 }
 
@@ -310,10 +334,17 @@ __global__ __launch_bounds__(1024) void k_hist_batch(
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const QrScalars *__restrict__ scal, u64 *__restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
+  QR_HT(0);
   const QrHistWg d = wgs[blockIdx.x];
   if (d.count == 0) return;
   hist_run(hist, d.begin, 0, d.count, d.buf, d.block, d.slot, blocks, bins, order0, order1, lambda,
            scal->scale, partials, true, (int)d.fw, (size_t)d.off256 << 8);
+#ifdef QR_STEP_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("hist_batch wg0 (%u docs, grid %u): desc+ids %lld rows %lld zero %lld accumulate %lld flush %lld cycles\n",
+           d.count, gridDim.x, qr_ht[1] - qr_ht[0], qr_ht[2] - qr_ht[1], qr_ht[3] - qr_ht[2], qr_ht[4] - qr_ht[3],
+           qr_ht[5] - qr_ht[4]);
+#endif
 }
 
 // ===========================================================================
@@ -665,6 +696,9 @@ __global__ __launch_bounds__(1024) void k_redscan(
   const uint32_t t = threadIdx.x & 255, g = threadIdx.x >> 8;
   // a node of the batch: everything comes ready-made from the control kernel (ONE
   // dependent read before the partials can be requested)
+#ifdef QR_STEP_TIMING
+  const long long rt0 = clock64();
+#endif
   QrScanWg d;
   if (!root) {
     d = descs[(size_t)blockIdx.y * flocal + lf];
@@ -718,7 +752,14 @@ __global__ __launch_bounds__(1024) void k_redscan(
       pb += part_ss[2 * (size_t)(d.part_first + i) + 1];
     }
   }
+#ifdef QR_STEP_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  const long long rt1 = clock64();
+#endif
   column_sum(src, total, kmax, per, n, (int)g, s, cn);
+#ifdef QR_STEP_TIMING
+  const long long rt2 = clock64();
+#endif
   if (sums_wave) {
     pa = wave_sum(pa);
     pb = wave_sum(pb);
@@ -741,6 +782,11 @@ __global__ __launch_bounds__(1024) void k_redscan(
             hcnt, flocal, thr_size, lf2gf, scal, featrec + (size_t)2 * (root ? 0 : blockIdx.y) * flocal,
             nullptr, my_thr, featthr + (size_t)2 * (root ? 0 : blockIdx.y) * flocal, !root, par_s,
             par_c);
+#ifdef QR_STEP_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+    printf("redscan wg0 (root %d, %d slots): desc %lld partials %lld scan %lld cycles\n", root, total, rt1 - rt0,
+           rt2 - rt1, clock64() - rt2);
+#endif
 }
 
 // Level-wise (oblivious) growth: sum of the workgroup partials, prefix of the directly
@@ -970,7 +1016,7 @@ struct DecideState {
   int flocal;
 };
 
-__device__ __forceinline__ void heap_push(DecideState &st, double key, int32_t val) {
+__device__ QR_CTRL_FN void heap_push(DecideState &st, double key, int32_t val) {
   // maxheap.h:58-68 (arr[0] is a DBL_MAX sentinel)
   size_t p = (size_t)(++st.heap_size);
   while (key > st.heap[p >> 1].key) {
@@ -981,7 +1027,7 @@ __device__ __forceinline__ void heap_push(DecideState &st, double key, int32_t v
   st.heap[p].val = val;
 }
 
-__device__ __forceinline__ void heap_pop(DecideState &st) {
+__device__ QR_CTRL_FN void heap_pop(DecideState &st) {
   // maxheap.h:71-84
   const QrHeapItem last = st.heap[st.heap_size--];
   size_t child, p = 1;
@@ -1031,7 +1077,7 @@ __device__ __forceinline__ void node_set_best(QrNode *nd, const qr_split_t *recs
   }
 }
 
-__device__ __forceinline__ bool node_splittable(const QrNode *nd) {
+__device__ QR_CTRL_FN bool node_splittable(const QrNode *nd) {
   // rt.cc:212 (deviance > 0.0f) and :312 (best_score == initvar => unsplittable)
   return nd->deviance > 0.0 && nd->best_f != 0xFFFFFFFFu;
 }
@@ -1327,7 +1373,7 @@ __global__ __launch_bounds__(128) void k_decide(
 // pops it (leaf budget exhausted), the node stays the leaf it was.  Heap pushes and
 // pops, node numbering and the split log are exactly the sequential ones.
 // ===========================================================================
-__device__ __forceinline__ void batch_child_init(QrNode *ch, uint32_t b, uint32_t e, int buf,
+__device__ QR_CTRL_FN void batch_child_init(QrNode *ch, uint32_t b, uint32_t e, int buf,
                                                  int slot, int parent) {
   ch->begin = b;
   ch->end = e;
@@ -1344,7 +1390,7 @@ __device__ __forceinline__ void batch_child_init(QrNode *ch, uint32_t b, uint32_
 }
 
 // the split of `node` becomes part of the tree, with children li / ri
-__device__ __forceinline__ void batch_commit(DecideState &st, int node, int li, int ri) {
+__device__ QR_CTRL_FN void batch_commit(DecideState &st, int node, int li, int ri) {
   QrNode *nd = &st.nodes[node];
   nd->feature = (int32_t)nd->best_f;
   nd->thr_id = (int32_t)nd->best_t;
@@ -1369,7 +1415,7 @@ struct BatchState {
 };
 
 // job j of the next batch: apply the best split of `node`
-__device__ __forceinline__ void batch_make_job(DecideState &st, BatchState &bs, int j, int node,
+__device__ QR_CTRL_FN void batch_make_job(DecideState &st, BatchState &bs, int j, int node,
                                                bool in_turn) {
   QrNode *nd = &st.nodes[node];
   int li;
@@ -3208,7 +3254,7 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
     attr_lds = lds;
   }
   const int G = c->ncu;
-  const bool prof = c->prof_on && root_mode;
+  const bool prof = c->prof_on && root_mode && (c->prof_tick++ % c->prof_stride) == 0;
   const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_n : c->N);  // documents of the root node
   if (root_mode) {
     const int root_buf = c->sub_k ? 0 : 2;  // the sample's list / every document

@@ -1907,6 +1907,12 @@ int qr_prof_enable(qr_ctx *c, int on) {
   if (!c) return QR_ERR_ARG;
   c->prof_on = (on & 1) != 0;
   c->prof_child = (on & 2) != 0;
+  // bits 8..15: events on every k-th root launch only (0 / 1 = every launch).  A launch that
+  // carries a start and a stop event costs the stream ~7.5 us (scripts/ubench/launch_chain.hip),
+  // which a caller timing whole iterations around the launches may not want on each of them
+  c->prof_stride = (unsigned)((on >> 8) & 0xff);
+  if (c->prof_stride == 0) c->prof_stride = 1;
+  c->prof_tick = 0;
   return QR_OK;
 }
 

@@ -479,6 +479,7 @@ struct qr_ctx {
   size_t attr_hist_lds = 0, attr_lambda_lds = 64 * 1024, attr_whist_lds = 0;
   // profiling
   bool prof_on = false;
+  unsigned prof_stride = 1, prof_tick = 0;  // events on every prof_stride-th root launch
   bool prof_child = false;       // also time the child-histogram launches (qr_prof_enable(ctx, 2 | 1))
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events_child;

@@ -8,7 +8,16 @@
 
 using namespace quickrank;
 
+namespace quickrank { namespace learning { namespace forests {
+void multi_query_slice(size_t Q, int r, int w, size_t *q0, size_t *q1);  // mart_multi.cc
+}}}
+
 extern "C" {
+
+// whole queries [q0, q1) that rank r of w holds under `quicklearn --gpus w --shard docs`
+void qrh_query_slice(size_t Q, int r, int w, size_t *q0, size_t *q1) {
+  learning::forests::multi_query_slice(Q, r, w, q0, q1);
+}
 
 // reads `path`; returns N, F, Q through pointers, copies into caller buffers when
 // they are non-NULL (call once with NULLs to size them)

@@ -106,14 +106,17 @@ int metric_code_of(const std::string &m) {
   exit(EXIT_FAILURE);
 }
 
-// whole queries [q0, q1) of rank r
+// whole queries [q0, q1) of rank r: balanced boundaries Q r / w, so that no rank is left
+// without queries while w <= Q (ceil(Q / w)-sized slices would give rank 3 of 4 nothing at Q = 9)
 void query_slice(size_t Q, int r, int w, size_t *q0, size_t *q1) {
-  const size_t per = (Q + (size_t)w - 1) / (size_t)w;
-  *q0 = std::min(Q, per * (size_t)r);
-  *q1 = std::min(Q, per * (size_t)(r + 1));
+  *q0 = Q * (size_t)r / (size_t)w;
+  *q1 = Q * (size_t)(r + 1) / (size_t)w;
 }
 
 }  // namespace
+
+// (for the CPU tests: the slices of a world of w ranks, without a GPU)
+void multi_query_slice(size_t Q, int r, int w, size_t *q0, size_t *q1) { query_slice(Q, r, w, q0, q1); }
 
 void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<data::Dataset> validation,
                        const std::string &metric, size_t cutoff, size_t partial_save,
@@ -132,8 +135,9 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
   const int mcode = metric_code_of(metric);
   const bool lambda = algo_ == LAMBDAMART || algo_ == OBVLAMBDAMART;
   const size_t N = training->num_instances(), F = training->num_features(), Q = training->num_queries();
-  if ((size_t)W > Q || (feature_sharded && (size_t)W > F)) {
-    std::cerr << "!!! more GPUs than " << (feature_sharded ? "features" : "queries") << std::endl;
+  // (feature ranges are ceil(F / W) wide, qr_api.hip: the last rank must still own a feature)
+  if ((size_t)W > Q || (feature_sharded && ((F + (size_t)W - 1) / (size_t)W) * (size_t)(W - 1) >= F)) {
+    std::cerr << "!!! more GPUs than " << (feature_sharded ? "feature ranges" : "queries") << std::endl;
     exit(EXIT_FAILURE);
   }
   std::cout << "# Initialization";

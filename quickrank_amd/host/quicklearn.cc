@@ -4,6 +4,7 @@
 // and phase order (load -> train -> save -> test -> scores file).  Options of
 // out-of-scope subsystems (DART, CLEAVER, linear rankers) are recognised and
 // rejected with a message.
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -185,7 +186,13 @@ int main(int argc, char *argv[]) {
     if (!v["features"].empty())  // driver.cc:108-110: the reference reads the flag and does nothing with it
       std::cout << "# --features " << v["features"] << ": accepted and not used, as in the reference "
                 << "(driver.cc:108-110 is a TODO)" << std::endl;
-    const int gpus = std::stoi(v["gpus"]);
+    int gpus = 0;   // (checked parse: std::stoi throws on "--gpus two")
+    {
+      const std::string &g = v["gpus"];
+      char *endp = nullptr;
+      const long gl = std::strtol(g.c_str(), &endp, 10);
+      if (!g.empty() && endp && *endp == '\0' && gl >= 1 && gl <= 1024) gpus = (int)gl;
+    }
     if (gpus < 1 || (v["shard"] != "docs" && v["shard"] != "features")) {
       std::cerr << "!!! --gpus needs a positive count, --shard docs or features" << std::endl;
       return EXIT_FAILURE;

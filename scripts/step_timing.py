@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 torch.cuda.init()
 import quickrank_amd.build as b
-lib = os.path.join(b.LIBDIR, "libqr_steptiming.so")
+lib = os.path.join(b.LIBDIR, os.environ.get("QR_TIMING_LIB", "libqr_steptiming.so"))
 if not os.path.exists(lib):
     subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + b.FLAGS + ["-DQR_STEP_TIMING", "-o", lib] +
                           [os.path.join(b.CSRC, s) for s in b.SOURCES])

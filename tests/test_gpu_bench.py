@@ -33,7 +33,7 @@ def test_bench_line_one_gpu():
     assert abs(d["value"] - 200000 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["launches"] == 4 and r["traffic"] is None      # PMC traffic is quoted for the full workload only
+    assert r["launches"] == 1 and r["traffic"] is None      # events on every 4th root launch; PMC traffic for the full workload only
     assert d["roofline_iteration"]["frac"] > 0 and d["roofline_child_hist"]["frac"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "cpu_model" in c
@@ -55,3 +55,22 @@ def test_bench_line_distributed_path_one_rank():
     assert abs(a - b) < 1e-12
     assert d["value"] == max(v["value"] for v in lay.values())
     assert d["weak_scaling"]["scaling"] == "weak" and d["strong_2M"]["scaling"] == "strong"
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with no launcher environment must start the N ranks itself
+    (the driver invokes it that way).  One GPU here, so `--self-launch` takes the
+    same re-exec under torch.distributed.run with one rank; still exactly one JSON line."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE",
+                        "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--self-launch",
+                          "--queries", "1000", "--steps", "2", "--warmup", "1", "--no-scoring", "--no-extras"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "torch.distributed.run" in out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1
+    assert all("nranks 1" in v["collectives"] for v in d["strong_layouts"].values())

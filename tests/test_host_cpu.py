@@ -391,3 +391,24 @@ def test_codegen_through_quicklearn_flags(host, tmp_path):
     assert r.returncode == 0 and open(out2).read().startswith("2\n2\nroot 0 2 ")
     r = subprocess.run([exe, "--model-file", str(m)], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout == ""
+
+
+def test_multi_gpu_query_slices_are_balanced_and_never_empty(host):
+    """`quicklearn --gpus W --shard docs` (host/mart_multi.cc): the ranks' query slices tile
+    [0, Q) in order, differ by at most one query, and no rank is empty while W <= Q
+    (ceil(Q / W)-sized slices left rank 3 of 4 without queries at Q = 9: ADVICE r2)."""
+    sz = C.c_size_t
+    host.qrh_query_slice.argtypes = [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]
+    host.qrh_query_slice.restype = None
+    for Q in (1, 2, 7, 8, 9, 10, 63, 64, 65, 6000, 10000):
+        for W in (1, 2, 3, 4, 7, 8):
+            if W > Q:
+                continue
+            prev, sizes = 0, []
+            for r in range(W):
+                a, b = sz(), sz()
+                host.qrh_query_slice(Q, r, W, C.byref(a), C.byref(b))
+                assert a.value == prev and b.value > a.value, (Q, W, r)
+                sizes.append(b.value - a.value)
+                prev = b.value
+            assert prev == Q and max(sizes) - min(sizes) <= 1, (Q, W, sizes)

@@ -70,6 +70,34 @@ def synth(nq, dpq, F, seed=42, sparse_cols=0, zero_frac=0.9):
     return x, labels, qoff
 
 
+def synth_mslr(nq=6000, mean_q=120, F=136, sparse_cols=40, seed=7):
+    """Stand-in for MSLR-WEB10K fold 1 (BASELINE.json configs[0]; the files are not in the
+    image): ~nq * mean_q documents in ragged queries (log-normal sizes, mean ~mean_q,
+    clipped to [1, 1200]); the last `sparse_cols` columns are sparse count features (90 %
+    zeros, else one of 32 integer levels: the "uniques <= nthresholds" threshold branch
+    with one very hot bin per column), the others real-valued U[0,1); labels 0..4 with
+    MSLR's skew P = .52/.32/.13/.02/.01, driven by four real columns, two count columns
+    and noise."""
+    rng = np.random.default_rng(seed)
+    sizes = np.clip(np.round(rng.lognormal(np.log(mean_q) - 0.18, 0.6, nq)), 1, 1200).astype(np.int64)
+    qoff = np.zeros(nq + 1, np.uint64)
+    qoff[1:] = np.cumsum(sizes)
+    N = int(qoff[-1])
+    x = rng.random((N, F), dtype=np.float32)
+    if sparse_cols:
+        c0 = F - sparse_cols
+        lv = np.floor(x[:, c0:] * 32).astype(np.float32) + 1
+        lv[rng.random((N, sparse_cols), dtype=np.float32) < 0.9] = 0
+        x[:, c0:] = lv
+    rel = (0.5 * x[:, 0] + 0.4 * x[:, 1] + 0.3 * x[:, 2] + 0.2 * x[:, 3]).astype(np.float64)
+    if sparse_cols:
+        rel += 0.15 * (x[:, F - 1] > 0) + 0.1 * (x[:, F - 2] > 0)
+    rel += 0.3 * rng.standard_normal(N)
+    cuts = np.quantile(rel, [0.52, 0.84, 0.97, 0.99])
+    labels = np.searchsorted(cuts, rel).astype(np.float32)
+    return x, labels, qoff
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -119,9 +147,9 @@ def cpu_baseline(x, labels, qoff, args):
     if cores != 8:
         sec8, _ = run(min(8, cores))
         out["threads8"] = {"value": n / sec8, "cores": min(8, cores), "ms_per_iteration": sec8 * 1e3,
-                           "port_vs_reference_same_threads": REFERENCE_8CORE_S_PER_ITER / sec8}
+                           "port_vs_reference_8threads_other_box": REFERENCE_8CORE_S_PER_ITER / sec8}
     else:
-        out["port_vs_reference_same_threads"] = REFERENCE_8CORE_S_PER_ITER / sec_all
+        out["port_vs_reference_8threads_other_box"] = REFERENCE_8CORE_S_PER_ITER / sec_all
     return out
 
 
@@ -190,8 +218,21 @@ def scoring_metric(ctx, args, torch, rank=0, world=1, dist=None):
         t = torch.tensor([ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
+    visits = args.score_docs * args.score_trees * 6 / ms * 1e3
+    # what bounds the walk: per node visit one 4-byte node record and one bin
+    # byte, both at data-dependent LDS addresses = two dword-wide LDS accesses per lane;
+    # peak = ds_read_b32 at 128 B/clk/CU (MI355X_MICROARCH.md, LDS table) x 256 CUs x 2.4 GHz
+    lds_peak = 128.0 * 256 * 2.4   # GB/s
+    lds_ach = visits * 8.0 / 1e9 / max(world, 1)
     return {"metric": "ensemble-score docs/sec", "value": args.score_docs / ms * 1e3, "unit": "docs/s",
-            "node_visits_per_s": args.score_docs * args.score_trees * 6 / ms * 1e3,
+            "node_visits_per_s": visits,
+            "roofline": {"bound": "lds", "kernel": "k_score_p4 (binned tree walk out of LDS-staged tree tiles)",
+                         "achieved": round(lds_ach, 1), "peak": round(lds_peak, 1), "unit": "GB/s",
+                         "frac": round(lds_ach / lds_peak, 4), "lds_bytes_per_node_visit": 8,
+                         "note": "random-address ds_read_b32 (node record) + ds_read_u8 (bin) per (document, "
+                                 "tree, level); bank conflicts of the random rows and the 8-tree lockstep are "
+                                 "what separates achieved from peak; HBM traffic is the one 8 GB pass of "
+                                 "k_doc_bins (~2 ms of the total)"},
             "workload": f"{args.score_trees} trees x 64 leaves (depth 6) over {args.score_docs} docs x 200 "
                         "features, synthetic, features resident on the device"
                         + (f", documents sharded over {world} GPUs" if world > 1 else ""),
@@ -208,6 +249,28 @@ def tree_shape(t):
     tot = float(t["nsamples"][0])
     return (np.minimum(nl, nr).sum() / tot, nl.sum() / tot,
             t["nsamples"][internal].astype(np.float64).sum() / tot)
+
+
+def obl_shape(t):
+    """tree_shape for an oblivious tree (nodes in heap order 2i+1 / 2i+2, ot.cc): the children
+    of the LAST internal level are leaves and get no histogram (ot.cc:127)."""
+    internal = np.nonzero(t["feature"] >= 0)[0]
+    tot = float(t["nsamples"][0])
+    if len(internal) == 0:
+        return 0.0, 0.0, 0.0
+    last_level_first = (len(internal) + 1) // 2 - 1      # first internal node of the deepest internal level
+    upper = internal[internal < last_level_first]
+    nl = t["nsamples"][t["left"][upper]].astype(np.float64)
+    nr = t["nsamples"][t["right"][upper]].astype(np.float64)
+    return (np.minimum(nl, nr).sum() / tot, nl.sum() / tot,
+            t["nsamples"][internal].astype(np.float64).sum() / tot)
+
+
+def iteration_alg_bytes_obl(N, F, depth, sigma, pi):
+    """iteration_alg_bytes for level-wise growth: one gain scan per node histogram
+    (2^depth - 1 of them), no histograms for the leaves."""
+    return (28.0 * N + (N * F + 8.0 * N) + sigma * N * (F + 12) + ((1 << depth) - 1) * F * 256 * 16
+            + 12.0 * pi * N + 20.0 * N + 16.0 * N + 12.0 * N)
 
 
 def iteration_alg_bytes(N, F, L, sigma, pi):
@@ -241,8 +304,14 @@ class Run:
         else:
             self.ctx = Context(local_rank, rank=rank if layout == "features" else 0,
                                world=world if layout == "features" else 1, stream=stream)
+            t0 = time.perf_counter()
             self.ctx.upload(x, labels, qoff)
+            self.ctx.synchronize()
+            self.h2d_ms = (time.perf_counter() - t0) * 1e3      # host rows -> HBM (PCIe), outside the timed region
+            t0 = time.perf_counter()
             self.ctx.build_bins(args.nthresholds)
+            self.ctx.synchronize()
+            self.init_ms = (time.perf_counter() - t0) * 1e3     # Mart::init: thresholds + bin map
             self.ctx.reset_scores()
             self.comm = None
             if layout == "features":
@@ -262,6 +331,14 @@ class Run:
         # call, ~35 us before its leaf kernels and score update have run; nothing of tree i is
         # overwritten before the next fit_tree), so the GPU always has work queued.
         a, ctx = self.args, self.ctx
+        if getattr(self, "obl_depth", 0):     # Oblivious-LambdaMART (BASELINE.json configs[3])
+            ctx.compute_lambdas("NDCG", 10)
+            self.flush()
+            ctx.fit_oblivious(self.obl_depth, 1, True, read=False)
+            ctx.update_scores(0.1)
+            self.tree_pending = True
+            self.ndcg.append(ctx.metric_last())
+            return
         if self.trainer is not None:
             self.trainer.compute_lambdas("NDCG", 10)
             self.flush()
@@ -326,8 +403,8 @@ class Run:
         self.dist.all_gather_object(parts, h.hexdigest())
         return len(set(parts)) == 1
 
-    def summary(self, what, parallelism):
-        sh = [tree_shape(t) for t in self.trees[-self.steps:]]
+    def summary(self, what, parallelism, shape=None):
+        sh = [(shape or tree_shape)(t) for t in self.trees[-self.steps:]]
         return {"workload": what, "parallelism": parallelism,
                 "value": self.n_global * self.steps / self.elapsed, "unit": "docs/s",
                 "ms_per_step": self.elapsed / self.steps * 1e3, "steps": self.steps,
@@ -481,6 +558,33 @@ def main():
             pc = head.ctx.prof_get_child()
             head.ctx.prof_enable(False)
             built = sum(tree_shape(t)[0] for t in head.trees[n0:]) * N   # documents built directly
+            # BASELINE.json configs[3]: Oblivious-LambdaMART depth 6 on the same set (level-batched
+            # growth); configs[0]: the MSLR-WEB10K run, 100 trees x 10 leaves, on the
+            # MSLR-shaped stand-in (ragged queries, 40 sparse count columns; the files are not in
+            # the image).  Each with its own whole-iteration roofline.
+            def side_run(xx, ll, qq, what, steps, obl_depth=0):
+                r = mk("single", xx, ll, qq, len(ll), len(qq) - 1)
+                r.obl_depth = obl_depth
+                r.timed(steps, min(args.warmup, 3))
+                sm = r.summary(what, "1 GPU", obl_shape if obl_depth else None)
+                n_, f_ = len(ll), xx.shape[1]
+                ib_ = (iteration_alg_bytes_obl(n_, f_, obl_depth, sm["sigma_built"], sm["pi"]) if obl_depth
+                       else iteration_alg_bytes(n_, f_, args.nleaves, sm["sigma_built"], sm["pi"]))
+                ia_ = ib_ / (sm["ms_per_step"] * 1e-3) / 1e9
+                sm["roofline_iteration"] = {"bound": "hbm", "alg_bytes_per_step": ib_, "achieved": round(ia_, 1),
+                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ia_ / HBM_PEAK_GBS, 4)}
+                sm["h2d_ms"], sm["init_ms"] = round(r.h2d_ms, 1), round(r.init_ms, 1)
+                r.close()
+                return sm
+            extras["oblivious_d6"] = side_run(
+                x, labels, qoff, same_set + f", Oblivious-LambdaMART depth 6 (64 leaves), {args.nthresholds} "
+                "thresholds, NDCG@10, shrinkage 0.1, min-leaf-support 1", args.extra_steps, obl_depth=6)
+            xm, lm, qm = synth_mslr(F=F)
+            extras["mslr_shaped"] = side_run(
+                xm, lm, qm, f"MSLR-WEB10K-shaped stand-in: {len(lm)} docs x {F} features in {len(qm) - 1} ragged "
+                f"queries (1..{int(np.diff(qm.astype(np.int64)).max())} documents), 40 sparse count columns; "
+                f"100 trees, {desc}", 100)
+            del xm, lm, qm
             if pc["launches"]:
                 cb = built * (F + 12) + sum(int((t["feature"] >= 0).sum()) for t in head.trees[n0:]) * F * 256 * 16
                 ca = cb / (pc["total_ms"] * 1e-3) / 1e9
@@ -574,6 +678,14 @@ def main():
                                           "sigma_reference_left", "pi", "collectives")},
             "roofline": roof,
         }
+        if not multi:
+            # the quality gate next to cpu_baseline.ndcg10_after: NDCG@10 of the training set after
+            # `cpu_iters` trees on both sides (the device's list holds the metric BEFORE tree i)
+            if len(head.ndcg) > args.cpu_iters:
+                out["config"][f"ndcg10_after_{args.cpu_iters}"] = head.ndcg[args.cpu_iters]
+            # host rows -> HBM and Mart::init, outside the timed region (reported apart)
+            out["config"]["h2d_ms"] = round(head.h2d_ms, 1)
+            out["config"]["init_ms"] = round(head.init_ms, 1)
         if roof_iter is not None:
             out["roofline_iteration"] = roof_iter
         if roof_child is not None:

@@ -104,9 +104,12 @@ int qr_dataset_upload(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
 /* training width are never tested by a tree and are dropped.                        */
 int qr_valid_upload(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
                     const float *labels, const uint64_t *qoff, size_t Q);
-/* thresholds + uint8 bin map.  nthresholds in [1,255], or 0 (= every unique     */
-/* value) if no feature has more than 255 uniques (else QR_ERR_UNSUPPORTED).     */
-/* thr_out: host [F][QR_MAX_BINS] (padded with FLT_MAX), thr_size_out: [F].      */
+/* thresholds + uint8 bin map: the FAST path, for up to 255 thresholds per feature. */
+/* nthresholds in [1,255], or 0 (= every unique value) while no feature has more   */
+/* than 255 uniques.  Anything beyond that -- nthresholds > 255, or 0 on a column  */
+/* with more distinct values -- returns QR_ERR_UNSUPPORTED here and is served by   */
+/* qr_bins_build_wide below (the hosts fall through to it automatically).          */
+/* thr_out: host [F][QR_MAX_BINS] (padded with FLT_MAX), thr_size_out: [F].        */
 int qr_bins_build(qr_ctx *ctx, size_t nthresholds, float *thr_out,
                   uint32_t *thr_size_out);
 /* The same in three steps, for document-sharded contexts whose thresholds must   */

@@ -73,11 +73,20 @@ __device__ long long qr_ht[8];
 #define QR_HT_WAIT(i)
 #endif
 
-template <int CH, bool IDENTITY>
+// SUMS: the lanes of chunk 0 also add up their documents' pseudo-responses and squares
+// (sq, sm): the directly built child's `sum` / `squares_sum_` (rtnode.h:97-107) come out of
+// the pass that reads every lambda[id] of the child anyway, instead of a second gather of
+// them (8 bytes out of a cold 64-byte line each) in the partition.  The two accumulators do
+// not fit next to the sixteen precomputed column offsets in the 128 registers of a
+// 1024-thread workgroup, so this variant computes the column of a step on the fly (two
+// VALU instructions under an LDS-bound loop; the empty asm keeps the compiler from hoisting
+// them back into sixteen registers).
+template <int CH, bool IDENTITY, bool SUMS = false>
 __device__ __forceinline__ void hist_accumulate(
     u64 *__restrict__ hist, const uint8_t *__restrict__ bins_b,
     const uint32_t *__restrict__ order, const uint32_t seg_begin, const uint32_t r0,
-    const uint32_t r1, const double *__restrict__ lambda, const double scale) {
+    const uint32_t r1, const double *__restrict__ lambda, const double scale, double *sq = nullptr,
+    double *sm = nullptr) {
   // (the caller has NOT zeroed `hist`: that happens below, behind the first loads)
   constexpr int FW = 16 * CH;
   constexpr int DW = 64 / CH;
@@ -94,6 +103,14 @@ __device__ __forceinline__ void hist_accumulate(
   const int dr = r >> 2;       // dword rotation
   const uint32_t br = r & 3;   // byte rotation inside a dword
   auto process = [&](const uint4 &row, const double lam) {
+    uint32_t rr = (uint32_t)(16 * c + r);
+    if (SUMS) {
+      asm volatile("" : "+v"(rr));
+      if (c == 0) {
+        *sq += lam * lam;
+        *sm += lam;
+      }
+    }
     const u64 addend = (1ull << QR_SB) + (u64)quantize(lam * scale);
     // rotate the 16 bytes right by r so that byte k of R is byte (k+r)&15
     const uint32_t t0 = (dr & 1) ? row.y : row.x;
@@ -112,7 +129,9 @@ __device__ __forceinline__ void hist_accumulate(
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const uint32_t bin = (R[k >> 2] >> (8 * (k & 3))) & 0xffu;
-      atomicAdd(&hist[bin * FW + colk[k]], addend);
+      // (rr = 16 c + r with r < 16: the column of step k is 16 c + ((r + k) & 15))
+      const uint32_t col = SUMS ? ((rr & ~15u) | ((rr + (uint32_t)k) & 15u)) : colk[k];
+      atomicAdd(&hist[bin * FW + col], addend);
     }
   };
   // Software pipeline: NS register sets rotate, so NS-1 tiles of loads stay in
@@ -173,13 +192,14 @@ __device__ __forceinline__ void hist_accumulate(
   }
 }
 
+template <bool SUMS = false>
 __device__ __forceinline__ void hist_run(
     u64 *hist, const uint32_t seg_begin, const uint32_t r0, const uint32_t r1, const int buf,
     const int b, const size_t slot0, const QrBlock *__restrict__ blocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const double scale, u64 *__restrict__ partials, const bool tr = false, const int fw_known = 0,
-    const size_t off_known = 0);
+    const size_t off_known = 0, double *__restrict__ sums_out = nullptr);
 
 // One workgroup's share of a node histogram: workgroup `wg` of the `G` that the
 // plan hands to a node of n documents; partial slots start at `slot_base`.
@@ -205,14 +225,17 @@ __device__ __forceinline__ void hist_body(
 }
 
 // positions [r0, r1) of the segment at seg_begin, for feature block b; partial slots
-// slot0, slot0 + 1, ... (one per QR_DPW documents)
+// slot0, slot0 + 1, ... (one per QR_DPW documents).  SUMS (k_hist_batch: document lists
+// only): every workgroup also adds up its documents' pseudo-responses and their squares
+// and leaves the pair at sums_out[2 * slot0] (see hist_accumulate).
+template <bool SUMS>
 __device__ __forceinline__ void hist_run(
     u64 *hist, const uint32_t seg_begin, const uint32_t r0, const uint32_t r1, const int buf,
     const int b, const size_t slot0, const QrBlock *__restrict__ blocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const double scale, u64 *__restrict__ partials, const bool tr, const int fw_known,
-    const size_t off_known) {
+    const size_t off_known, double *__restrict__ sums_out) {
   // (batched growth hands the block's geometry over with the workgroup's share: one
   // dependent read less before the first bins can be requested)
   const int fw = fw_known ? fw_known : blocks[b].fw;
@@ -221,8 +244,17 @@ __device__ __forceinline__ void hist_run(
   const bool identity = buf == 2;
   const uint32_t cells = 256u * fw;
   uint32_t k = 0;
+  double sq = 0.0, sm = 0.0;  // (sums_out) this lane's documents of chunk 0, in list order
   for (uint32_t s0 = r0; s0 < r1; s0 += QR_DPW, ++k) {
     const uint32_t s1 = (s0 + QR_DPW < r1) ? s0 + QR_DPW : r1;
+    if (SUMS) {
+      switch (fw) {
+        case 16: hist_accumulate<1, false, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
+        case 32: hist_accumulate<2, false, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
+        case 48: hist_accumulate<3, false, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
+        default: hist_accumulate<4, false, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
+      }
+    } else
     if (identity) {
       switch (fw) {
         case 16: hist_accumulate<1, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
@@ -266,6 +298,28 @@ __device__ __forceinline__ void hist_run(
     }
     __syncthreads();
     QR_HT_WAIT(5);
+  }
+  if (SUMS) {
+    // a lane's documents in list order, the lanes of a wave by wave_sum, the sixteen waves
+    // in wave order: fixed, whatever the launch looks like.  One pair per workgroup, at its
+    // first partial slot (k_redscan adds the workgroups' pairs in slot order).
+    __shared__ double sh_sq[16], sh_sm[16];
+    sq = wave_sum(sq);
+    sm = wave_sum(sm);
+    if ((threadIdx.x & 63) == 0) {
+      sh_sq[threadIdx.x >> 6] = sq;
+      sh_sm[threadIdx.x >> 6] = sm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double a = 0.0, b2 = 0.0;
+      for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) {
+        a += sh_sq[w];
+        b2 += sh_sm[w];
+      }
+      sums_out[2 * slot0] = a;
+      sums_out[2 * slot0 + 1] = b2;
+    }
   }
 }
 
@@ -332,13 +386,15 @@ __global__ __launch_bounds__(1024) void k_hist_batch(
     const QrHistWg *__restrict__ wgs, const QrBlock *__restrict__ blocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const QrScalars *__restrict__ scal, u64 *__restrict__ partials) {
+    const QrScalars *__restrict__ scal, u64 *__restrict__ partials, double *__restrict__ histsum) {
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
   QR_HT(0);
   const QrHistWg d = wgs[blockIdx.x];
   if (d.count == 0) return;
-  hist_run(hist, d.begin, 0, d.count, d.buf, d.block, d.slot, blocks, bins, order0, order1, lambda,
-           scal->scale, partials, true, (int)d.fw, (size_t)d.off256 << 8);
+  // (every workgroup also adds up its documents' pseudo-responses -- k_redscan reads the pairs
+  // of feature block 0's workgroups; the others' are the same numbers and cost nothing)
+  hist_run<true>(hist, d.begin, 0, d.count, d.buf, d.block, d.slot, blocks, bins, order0, order1, lambda,
+                 scal->scale, partials, true, (int)d.fw, (size_t)d.off256 << 8, histsum);
 #ifdef QR_STEP_TIMING
   if (threadIdx.x == 0 && blockIdx.x == 0)
     printf("hist_batch wg0 (%u docs, grid %u): desc+ids %lld rows %lld zero %lld accumulate %lld flush %lld cycles\n",
@@ -489,7 +545,8 @@ __device__ __forceinline__ void scan_core(
     const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
     const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec,
     uint32_t *__restrict__ hcnt_loc, const float my_thr, float *__restrict__ featthr,
-    const bool pre = false, const long long pre_s = 0, const uint32_t pre_c = 0);
+    const bool pre = false, const long long pre_s = 0, const uint32_t pre_c = 0,
+    const int pre_gf = -1, const uint32_t pre_tsize = 0, const double pre_inv = 0.0);
 
 // One feature of one node: workgroup of 256 threads, thread = slot.
 __device__ __forceinline__ void scan_body(
@@ -534,7 +591,8 @@ __device__ __forceinline__ void scan_core(
     const uint32_t *__restrict__ thr_size, const int32_t *__restrict__ lf2gf,
     const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec,
     uint32_t *__restrict__ hcnt_loc, const float my_thr, float *__restrict__ featthr,
-    const bool pre, const long long pre_s, const uint32_t pre_c) {
+    const bool pre, const long long pre_s, const uint32_t pre_c, const int pre_gf,
+    const uint32_t pre_tsize, const double pre_inv) {
   __shared__ long long sh_s[4];
   __shared__ uint32_t sh_c[4], sh_l[4];
   __shared__ long long tot_s[2];
@@ -579,9 +637,11 @@ __device__ __forceinline__ void scan_core(
     tot_c[1] = bc;
   }
   __syncthreads();
-  const int gf = lf2gf[lf];
-  const uint32_t tsize = thr_size[gf];
-  const double inv_scale = scal->inv_scale;
+  // (pre_gf >= 0: the caller requested these at its top -- here, behind the barriers, the
+  // chain lf2gf -> thr_size would be two exposed round trips)
+  const int gf = pre_gf >= 0 ? pre_gf : lf2gf[lf];
+  const uint32_t tsize = pre_gf >= 0 ? pre_tsize : thr_size[gf];
+  const double inv_scale = pre_gf >= 0 ? pre_inv : scal->inv_scale;
   {
     Best v = slot_gain(s, cn, tot_s[0], tot_c[0], t, tsize, minls, inv_scale);
     v = block_best(v, sh_b);
@@ -699,12 +759,15 @@ __global__ __launch_bounds__(1024) void k_redscan(
 #ifdef QR_STEP_TIMING
   const long long rt0 = clock64();
 #endif
+  // everything that does not depend on the descriptor is requested with it: the feature's
+  // global index, its number of thresholds, the slot's threshold value, the scale
+  const int gf_top = lf2gf[lf];
+  const double inv_top = scal->inv_scale;
   QrScanWg d;
-  if (!root) {
-    d = descs[(size_t)blockIdx.y * flocal + lf];
-    if (!d.active) return;
-  }
-  const float my_thr = thr[(size_t)lf2gf[lf] * QR_MAX_BINS + t];
+  if (!root) d = descs[(size_t)blockIdx.y * flocal + lf];
+  const uint32_t tsize_top = thr_size[gf_top];
+  const float my_thr = thr[(size_t)gf_top * QR_MAX_BINS + t];
+  if (!root && !d.active) return;
   if (root) {
     if (threadIdx.x == 0)
       qr_make_plan(rootn, nblocks, blocks,
@@ -741,15 +804,17 @@ __global__ __launch_bounds__(1024) void k_redscan(
   long long s = 0;
   uint32_t cn = 0;
   // (feature 0's workgroup, last wave) sum and sum of squares of the node's directly
-  // built child: fixed-order reduction of the partition workgroups' partials, for the
-  // next control step, requested together with the column's cells
+  // built child: fixed-order reduction of the pairs the histogram workgroups of feature
+  // block 0 left at their first partial slot (hist_run, sums_out), for the next control
+  // step, requested together with the column's cells
   const bool sums_wave = !root && lf == 0 && (threadIdx.x >> 6) == 15;
   double pa = 0.0, pb = 0.0;
   if (sums_wave) {
     const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t i = lane; i < d.part_nwg; i += 64) {
-      pa += part_ss[2 * (size_t)(d.part_first + i)];
-      pb += part_ss[2 * (size_t)(d.part_first + i) + 1];
+    const uint32_t nw0 = d.total / (uint32_t)d.kmax;   // block 0's workgroups of this node
+    for (uint32_t i = lane; i < nw0; i += 64) {
+      pa += part_ss[2 * (size_t)(d.slot0 + i * (uint32_t)d.kmax)];
+      pb += part_ss[2 * (size_t)(d.slot0 + i * (uint32_t)d.kmax) + 1];
     }
   }
 #ifdef QR_STEP_TIMING
@@ -781,7 +846,7 @@ __global__ __launch_bounds__(1024) void k_redscan(
   scan_core(root, small_slot, big_slot, parent_slot, small_is_left, minls, lf, s, cn, 0u, hsum,
             hcnt, flocal, thr_size, lf2gf, scal, featrec + (size_t)2 * (root ? 0 : blockIdx.y) * flocal,
             nullptr, my_thr, featthr + (size_t)2 * (root ? 0 : blockIdx.y) * flocal, !root, par_s,
-            par_c);
+            par_c, gf_top, tsize_top, inv_top);
 #ifdef QR_STEP_TIMING
   if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
     printf("redscan wg0 (root %d, %d slots): desc %lld partials %lld scan %lld cycles\n", root, total, rt1 - rt0,
@@ -943,15 +1008,31 @@ __device__ qr_split_t wave_merge(const int root_mode, const int which,
   best.thr_id = 0xFFFFFFFFu;
   best.lcount = best.rcount = 0;
   if (root_mode && which == 1) return best;
-  for (int lf = lane; lf < flocal; lf += 64) {
-    const qr_split_t r = featrec[(size_t)which * flocal + lf];
-    const float tv = featthr ? featthr[(size_t)which * flocal + lf] : 0.f;
-    if (mf_k && r.feature != 0xFFFFFFFFu && !mf_allowed(mf_seed, mf_node, r.feature, F, mf_k))
-      continue;
-    if (r.score > best.score) {  // ascending lf within the lane
-      best = r;
-      best_lf = lf;
-      best_thr = tv;
+  // Four records per lane and round, ALL requested before the first is looked at (clamped,
+  // unconditional loads): the records are fresh from the scan launch, so every round trip is
+  // a cold miss of ~1 us, and a loop that waits for each record in turn put three of them
+  // in a row on the per-step chain (F = 136: lanes 0..7 hold three records).
+  for (int base = 0; base < flocal; base += 256) {
+    qr_split_t r[4];
+    float tv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lf = base + lane + 64 * k;
+      const int lc = lf < flocal ? lf : flocal - 1;
+      r[k] = featrec[(size_t)which * flocal + lc];
+      tv[k] = featthr ? featthr[(size_t)which * flocal + lc] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lf = base + lane + 64 * k;
+      if (lf >= flocal) continue;
+      if (mf_k && r[k].feature != 0xFFFFFFFFu && !mf_allowed(mf_seed, mf_node, r[k].feature, F, mf_k))
+        continue;
+      if (r[k].score > best.score) {  // ascending lf within the lane
+        best = r[k];
+        best_lf = lf;
+        best_thr = tv[k];
+      }
     }
   }
   // max score over the wave, equal scores -> lowest feature index; the lane that
@@ -1500,6 +1581,13 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
                                            const QrScalars *scal, const int32_t *own_lf,
                                            const float *own_thr, const int root_buf) {
   int nj = 0;
+#ifdef QR_STEP_TIMING
+  long long lt[5];
+  lt[0] = lt[1] = lt[2] = lt[3] = lt[4] = clock64();
+#define QR_LT(i) lt[i] = clock64()
+#else
+#define QR_LT(i)
+#endif
   if (root_mode) {
     QrNode *root = &st.nodes[0];
     batch_child_init(root, 0, N, root_buf, 0, -1);
@@ -1532,6 +1620,7 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
       heap_push(st, st.nodes[l0].deviance, l0);  // rt.cc:76-77
       heap_push(st, st.nodes[r0].deviance, r0);
     }
+    QR_LT(1);
     st.step++;
     if (!st.done) {
       bool found = false;
@@ -1564,6 +1653,7 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
       if (!found) st.done = 1;
     }
   }
+  QR_LT(2);
   // candidates applied ahead of their turn: the largest deviances left in the heap,
   // as long as the leaf budget can still reach them
   if (nj == 1 && N < QR_SPEC_MAX_DOCS) {
@@ -1585,6 +1675,12 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
       ++nj;
     }
   }
+#ifdef QR_STEP_TIMING
+  QR_LT(3);
+  if (blockIdx.x == 0)
+    printf("batch_logic wg0: pushes %lld pops+job0 %lld candidates+job1 %lld (heap %d)\n", lt[1] - lt[0], lt[2] - lt[1],
+           lt[3] - lt[2], st.heap_size);
+#endif
   return nj;
 }
 
@@ -1626,7 +1722,7 @@ __device__ __forceinline__ void batch_step(
   __shared__ qr_split_t own[2 * QR_BATCH];
   __shared__ double sh_sum[QR_BATCH], sh_ss[QR_BATCH];
   __shared__ uint32_t sh_hw0[QR_BATCH + 1], sh_q;
-  __shared__ int sh_nj, sh_hi, sh_hs;
+  __shared__ int sh_nj, sh_hi, sh_hs, sh_nn;
   __shared__ QrNode sh_nodes[CAP];
   __shared__ QrHeapItem sh_heap[CAP + 2];
   __shared__ QrLevelNode sh_prev[QR_BATCH];
@@ -1655,6 +1751,11 @@ __device__ __forceinline__ void batch_step(
                 h_spec_used = tin->spec_used, h_real_steps = root_mode ? 0 : tin->real_steps;
   const uint32_t h_part_epoch = tin->part_epoch;
   const u64 h_minls = root_mode ? minls_arg : tin->minls;
+#ifdef QR_STEP_TIMING_FINE
+  long long ft[5];
+  __builtin_amdgcn_s_waitcnt(0);
+  ft[0] = clock64();
+#endif
   const QrLevelNode myln = tin->lnode[wave < QR_BATCH ? wave : 0];
   // sums of the directly built children of the batch just applied: k_redscan has added
   // up the partition workgroups' partials (one dependent read less on this chain)
@@ -1678,12 +1779,27 @@ __device__ __forceinline__ void batch_step(
       hv[k] = i < nh ? hs[i] : 0;
     }
   }
+#ifdef QR_STEP_TIMING_FINE
+  __builtin_amdgcn_s_waitcnt(0);
+  ft[1] = clock64();
+#endif
   // wave 2j + which: the per-feature records of job j's left / right child (stale
   // records of a job that does not exist are merged too and ignored)
   int my_lf = -1;
   float my_thr = 0.f;
   const qr_split_t mine = wave_merge(0, wave, featrec, flocal, 0, 0, 0, F, &my_lf, featthr, &my_thr);
+#ifdef QR_STEP_TIMING_FINE
+  __builtin_amdgcn_s_waitcnt(0);
+  ft[2] = clock64();
+#endif
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) sh_blk[b] = blocks[b];
+#ifdef QR_STEP_TIMING_FINE
+  __builtin_amdgcn_s_waitcnt(0);
+  ft[3] = clock64();
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("batch_step wg0 loads: header %lld lnode+sums+nodes+heap %lld merge %lld blocks %lld\n", ft[0] - bt[0],
+           ft[1] - ft[0], ft[2] - ft[1], ft[3] - ft[2]);
+#endif
   // ---- uses
   const int njobs = root_mode ? 0 : njobs_raw;  // the batch that has just been applied
   {
@@ -1774,6 +1890,7 @@ __device__ __forceinline__ void batch_step(
     *sh_epoch = FUSED ? epoch_arg : st.part_epoch;
     sh_hi = bs.next_prov;
     sh_hs = st.heap_size;
+    sh_nn = st.nnodes;
     if (writer) {
       if (root_mode) {  // what k_tree_reset does for the one-split-per-step path
         ts->desc.active = 0;
@@ -1927,6 +2044,58 @@ __device__ __forceinline__ void batch_step(
       d.small_is_left = (uint8_t)ln.small_is_left;
     }
     part_wg[w] = d;
+  }
+  // The last control call of a staged tree also numbers the leaves (what k_finish does in
+  // a launch of its own, ~4.5 us): RTNode::save_leaves (rtnode.cc:34-46) visits them
+  // left first, and a node's left child holds the lower positions of its segment, so a
+  // leaf's DFS index is the number of leaves that begin before it -- no walk, one thread
+  // per node.  (A tree with an EMPTY leaf -- min-leaf-support 0 -- can tie two leaves on
+  // `begin`: one lane walks it instead, as k_finish does.)
+  if (!FUSED && final_call && staged && nj == 0) {
+    const int nn = sh_nn;
+    __shared__ int fin_nl, fin_tie;
+    __shared__ int32_t fin_leaf[CAP], fin_stack[CAP];
+    if (threadIdx.x == 0) fin_nl = fin_tie = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nn; i += blockDim.x) {
+      const bool leaf = sh_nodes[i].feature < 0;
+      if (leaf && sh_nodes[i].end == sh_nodes[i].begin) fin_tie = 1;
+      if (leaf) atomicAdd(&fin_nl, 1);
+    }
+    __syncthreads();
+    if (!fin_tie) {
+      for (int i = threadIdx.x; i < nn; i += blockDim.x) {
+        if (sh_nodes[i].feature >= 0) continue;
+        const uint32_t b = sh_nodes[i].begin;
+        int l = 0;
+        for (int j = 0; j < nn; ++j) l += (sh_nodes[j].feature < 0 && sh_nodes[j].begin < b) ? 1 : 0;
+        fin_leaf[l] = i;
+      }
+    } else if (threadIdx.x == 0) {
+      int sp = 0, nl = 0;
+      fin_stack[sp++] = 0;
+      while (sp > 0) {
+        const int n = fin_stack[--sp];
+        if (sh_nodes[n].feature < 0) {
+          fin_leaf[nl++] = n;
+        } else {
+          fin_stack[sp++] = sh_nodes[n].right;
+          fin_stack[sp++] = sh_nodes[n].left;
+        }
+      }
+    }
+    __syncthreads();
+    const int nl = fin_nl;
+    for (int l = threadIdx.x; l < nl; l += blockDim.x) {
+      const int n = fin_leaf[l];
+      ts->nodes[n].leaf_id = l;
+      ts->leaf_nodes[l] = n;
+      ts->leaf_begin[l] = sh_nodes[n].begin;
+    }
+    if (threadIdx.x == 0) {
+      ts->nleaves = nl;
+      ts->leaf_begin[nl] = sh_nodes[0].end;
+    }
   }
 }
 
@@ -3338,6 +3507,7 @@ __global__ void k_tree_reset(QrTreeState *ts, int nleaves, u64 minls) {
 }
 
 int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
+  c->finish_in_decide = false;
   c->tree_step = 0;
   c->tree_counter += 0x9E3779B97F4A7C15ull;  // a fresh feature-subset stream per tree
   hipLaunchKernelGGL(k_tree_reset, dim3(1), dim3(64), 0, c->stream, c->d_tree,
@@ -3404,17 +3574,17 @@ static int launch_batch_hist_scan(qr_ctx *c, const unsigned hg, const uint32_t r
     QR_CHECK(c, hipEventCreate(&e1));
     hipExtLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, e0, e1, 0, c->d_lhist_wg,
                           c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
-                          c->d_scalars, (u64 *)c->d_lpartials);
+                          c->d_scalars, (u64 *)c->d_lpartials, c->d_lhistsum);
     c->prof_events_child.push_back({e0, e1});
   } else
     hipLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, c->d_lhist_wg,
                        c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
-                       c->d_scalars, (u64 *)c->d_lpartials);
+                       c->d_scalars, (u64 *)c->d_lpartials, c->d_lhistsum);
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_redscan, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_tree, 0,
                      rootn, c->d_lplan, c->d_blocks, c->nblocks, c->ncu, (const u64 *)c->d_lpartials,
                      c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars,
-                     c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg, (u64)minls, pss, c->d_jobsum);
+                     c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg, (u64)minls, c->d_lhistsum, c->d_jobsum);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -3473,6 +3643,7 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
   int rc = launch_hist_scan(c, 1, true);  // root histogram -> slot 0, records -> featrec[0]
   if (rc) return rc;
   const BatchGeom g = batch_geom(c, nleaves);
+  c->finish_in_decide = g.stage_nodes > 0;
   size_t steps = nleaves - 1;
   if (c->steps_force >= 0)
     steps = std::min<size_t>(steps, (size_t)std::max<long>(c->steps_force, 1));
@@ -3495,7 +3666,7 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
       if (s == steps) break;  // the last call only accounts for the last batch
       hipLaunchKernelGGL(k_partition_batch, dim3(g.pg), dim3(256), 0, c->stream, c->d_tree,
                          c->d_lpart_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
-                         (u64 *)c->d_bpart_state, c->d_lambda, c->d_lpart_ss, ++c->bepoch);
+                         (u64 *)c->d_bpart_state, c->d_lambda, (double *)nullptr, ++c->bepoch);
       QR_CHECK(c, hipGetLastError());
     } else {
       hipLaunchKernelGGL(g.small ? k_decide_part<QR_BATCH_LDS_SMALL> : k_decide_part<QR_BATCH_LDS_LARGE>,
@@ -3505,7 +3676,7 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
                          c->d_scalars, c->d_jobsum, c->d_featrec, c->d_featthr, (uint32_t)c->F,
                          c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, g.hg,
                          c->d_lplan, c->d_lscan_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0],
-                         c->d_order[1], (u64 *)c->d_bpart_state, c->d_lambda, PSS[s & 1]);
+                         c->d_order[1], (u64 *)c->d_bpart_state, c->d_lambda, (double *)nullptr);
       QR_CHECK(c, hipGetLastError());
     }
     if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls, g.fused ? PSS[s & 1] : c->d_lpart_ss))) return rc;
@@ -3524,7 +3695,7 @@ int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_d
   for (size_t r = 0; r < left; ++r) {
     hipLaunchKernelGGL(k_partition_batch, dim3(g.pg), dim3(256), 0, c->stream, c->d_tree,
                        c->d_lpart_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
-                       (u64 *)c->d_bpart_state, c->d_lambda, c->d_lpart_ss, ++c->bepoch);
+                       (u64 *)c->d_bpart_state, c->d_lambda, (double *)nullptr, ++c->bepoch);
     QR_CHECK(c, hipGetLastError());
     if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls, c->d_lpart_ss))) return rc;
     if ((rc = launch_decide_batch(c, g, nleaves, minls, 0, c->d_tree, (const QrTreeState *)nullptr,
@@ -3535,6 +3706,7 @@ int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_d
 }
 
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
+  c->finish_in_decide = false;
   const int maxnodes = (1 << (depth + 1)) - 1;
   hipLaunchKernelGGL(k_obl_reset, dim3((maxnodes + 255) / 256), dim3(256), 0, c->stream,
                      c->d_tree, maxnodes, (u64)minls);
@@ -3595,6 +3767,7 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
 // ---- feature-sharded level-wise growth, phase by phase (the host puts the all-gather of
 // the records and the all-reduce of mask + counts in between) ---------------------------
 int qr_k_obl_begin(qr_ctx *c, size_t depth, uint64_t minls) {
+  c->finish_in_decide = false;
   const int maxnodes = (1 << (depth + 1)) - 1;
   hipLaunchKernelGGL(k_obl_reset, dim3((maxnodes + 255) / 256), dim3(256), 0, c->stream, c->d_tree,
                      maxnodes, (u64)minls);
@@ -3667,8 +3840,10 @@ int qr_k_obl_apply(qr_ctx *c, int level, int last) {
 
 int qr_k_tree_finish(qr_ctx *c, int newton) {
   const unsigned sgrid = (unsigned)((c->N + QR_SLICE - 1) / QR_SLICE);
-  hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, c->stream, c->d_tree);
-  QR_CHECK(c, hipGetLastError());
+  if (!c->finish_in_decide) {  // (batched, staged trees: the last control call numbered the leaves)
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, c->stream, c->d_tree);
+    QR_CHECK(c, hipGetLastError());
+  }
   // trees of up to QR_LDOC leaves: sums in document order (k_leaf_sums_doc), the leaf bytes
   // kept for the score update
   const bool doc_path = c->leaf_cap >= 1 && c->leaf_cap <= QR_LDOC && c->d_leafb && !c->leaf_by_position;

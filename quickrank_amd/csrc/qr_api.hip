@@ -138,7 +138,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec); dfree(c->d_featthr); dfree(c->d_lscan_wg);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
   dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_lpart_ss2); dfree(c->d_jobsum); dfree(c->d_bpart_state); dfree(c->d_tree); dfree(c->d_tree2); dfree(c->d_leafpart); dfree(c->d_leafb);
-  dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
+  dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials); dfree(c->d_lhistsum);
   dfree(c->d_lpart_state);
   dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
   c->lhist_cap = c->lpart_cap = c->lslots_cap = c->lred_nodes = 0;
@@ -1037,7 +1037,7 @@ static int ensure_level_buffers(qr_ctx *c, size_t depth) {
   if (hist_wgs > c->lhist_cap || part_wgs > c->lpart_cap || slots > c->lslots_cap ||
       nodes > c->lred_nodes) {
     QR_CHECK(c, hipStreamSynchronize(c->stream));
-    dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials);
+    dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials); dfree(c->d_lhistsum);
     dfree(c->d_lpart_state);
     dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
     QR_CHECK(c, dalloc(&c->d_lhist_wg, hist_wgs));
@@ -1048,6 +1048,7 @@ static int ensure_level_buffers(qr_ctx *c, size_t depth) {
     QR_CHECK(c, dalloc(&c->d_lpart_state, part_wgs));
     QR_CHECK(c, hipMemset(c->d_lpart_state, 0, part_wgs * 8));
     QR_CHECK(c, dalloc(&c->d_lpartials, slots * 256 * 64));
+    QR_CHECK(c, dalloc(&c->d_lhistsum, 2 * slots));
     c->lhist_cap = hist_wgs;
     c->lpart_cap = part_wgs;
     c->lslots_cap = slots;

@@ -419,6 +419,7 @@ struct qr_ctx {
   uint32_t *d_lhist_map = nullptr, *d_lpart_map = nullptr;
   size_t lhist_cap = 0, lpart_cap = 0, lslots_cap = 0, lred_nodes = 0;
   uint64_t *d_lpartials = nullptr;
+  double *d_lhistsum = nullptr;       // batched growth: [slot][ss, sum] of the child a histogram workgroup (block 0) read
   unsigned long long *d_lpart_state = nullptr;
   double *d_leafpart = nullptr;  // [slices][2] partial sums (k_leaf_sums), or [slices][16][2] (k_leaf_sums_doc)
   uint8_t *d_leafb = nullptr;    // [N] leaf of every document in the last small tree (k_leaf_sums_doc)
@@ -479,6 +480,7 @@ struct qr_ctx {
   size_t attr_hist_lds = 0, attr_lambda_lds = 64 * 1024, attr_whist_lds = 0;
   // profiling
   bool prof_on = false;
+  bool finish_in_decide = false;  // the tree's last control call numbered its leaves (no k_finish launch)
   unsigned prof_stride = 1, prof_tick = 0;  // events on every prof_stride-th root launch
   bool prof_child = false;       // also time the child-histogram launches (qr_prof_enable(ctx, 2 | 1))
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

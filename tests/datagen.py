@@ -39,28 +39,10 @@ def make_dataset(nq=40, docs_per_query=30, F=16, seed=0, ragged=False,
 
 
 def make_mslr_like(nq=6000, mean_q=120, F=136, sparse_cols=40, seed=7):
-    """Stand-in for MSLR-WEB10K fold 1 (BASELINE.json configs[0]; the files are not
-    in the image): ~nq * mean_q documents in ragged queries (log-normal sizes, mean
-    ~mean_q, clipped to [1, 1200]); the last `sparse_cols` columns are sparse count
-    features (90 % zeros, else one of 32 integer levels: the "uniques <= nthresholds"
-    threshold branch with one very hot bin per column), the others real-valued
-    U[0,1); labels 0..4 with MSLR's skew P = .52/.32/.13/.02/.01, driven by four
-    real columns, two count columns and noise."""
-    rng = np.random.default_rng(seed)
-    sizes = np.clip(np.round(rng.lognormal(np.log(mean_q) - 0.18, 0.6, nq)), 1, 1200).astype(np.int64)
-    qoff = np.zeros(nq + 1, np.uint64)
-    qoff[1:] = np.cumsum(sizes)
-    N = int(qoff[-1])
-    x = rng.random((N, F), dtype=np.float32)
-    if sparse_cols:
-        c0 = F - sparse_cols
-        lv = np.floor(x[:, c0:] * 32).astype(np.float32) + 1
-        lv[rng.random((N, sparse_cols), dtype=np.float32) < 0.9] = 0
-        x[:, c0:] = lv
-    rel = (0.5 * x[:, 0] + 0.4 * x[:, 1] + 0.3 * x[:, 2] + 0.2 * x[:, 3]).astype(np.float64)
-    if sparse_cols:
-        rel += 0.15 * (x[:, F - 1] > 0) + 0.1 * (x[:, F - 2] > 0)
-    rel += 0.3 * rng.standard_normal(N)
-    cuts = np.quantile(rel, [0.52, 0.84, 0.97, 0.99])
-    labels = np.searchsorted(cuts, rel).astype(np.float32)
-    return x, labels, qoff
+    """Stand-in for MSLR-WEB10K fold 1 (BASELINE.json configs[0]): the generator lives in
+    bench.py (`synth_mslr`), which reports the same set as `mslr_shaped`."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synth_mslr
+    return synth_mslr(nq=nq, mean_q=mean_q, F=F, sparse_cols=sparse_cols, seed=seed)

@@ -38,6 +38,16 @@ def test_bench_line_one_gpu():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "cpu_model" in c
     assert d["ensemble_scoring"]["value"] > 0 and d["ensemble_scoring"]["cpu_baseline"]["value"] > 0
+    sr = d["ensemble_scoring"]["roofline"]
+    assert sr["bound"] == "lds" and abs(sr["frac"] - sr["achieved"] / sr["peak"]) < 1e-3
+    # every BASELINE.json configuration that fits one GPU is in the line
+    for k in ("oblivious_d6", "mslr_shaped"):
+        assert d[k]["ms_per_step"] > 0 and 0 < d[k]["roofline_iteration"]["frac"] < 1 and d[k]["h2d_ms"] > 0
+    assert d["mslr_shaped"]["steps"] == 100 and d["oblivious_d6"]["steps"] == 3
+    assert d["config"]["h2d_ms"] > 0 and d["config"]["init_ms"] > 0
+    # the quality gate: the device after as many trees as the CPU baseline trained
+    assert abs(d["config"]["ndcg10_after_3"] - c["ndcg10_after"]["3"]) < 1e-5
+    assert "port_vs_reference_8threads_other_box" in c.get("threads8", c)
     assert 0.0 < d["config"]["ndcg10_last"] <= 1.0
 
 

@@ -210,6 +210,12 @@ class Context:
         self._ck(self.L.qr_ctx_set_stream(self.h, C.c_void_p(stream)))
         self.stream = stream
 
+    def stream_handle(self):
+        """The HIP stream the context launches on (qr_ctx_stream), as an integer."""
+        s = C.c_void_p()
+        self._ck(self.L.qr_ctx_stream(self.h, C.byref(s)))
+        return s.value or 0
+
     def close(self):
         if getattr(self, "h", None):
             self.L.qr_ctx_destroy(self.h)

@@ -1073,6 +1073,20 @@ __global__ __launch_bounds__(256) void k_residual(const float *__restrict__ labe
   }
 }
 
+// the scalars into the pinned host block, every field EXCEPT `pad`: that word is the
+// launch's sequence number and only ever moves forward (stored last, by the caller, behind a
+// system-scope fence); a whole-struct copy would first put the device's 0 over it
+__device__ __forceinline__ void scalars_to_host(QrScalars *__restrict__ host_copy, const QrScalars *__restrict__ scal) {
+  host_copy->maxabs_bits = scal->maxabs_bits;
+  host_copy->scale_exp = scal->scale_exp;
+  host_copy->scale = scal->scale;
+  host_copy->inv_scale = scal->inv_scale;
+  host_copy->root_ss = scal->root_ss;
+  host_copy->root_sum = scal->root_sum;
+  host_copy->metric_sum = scal->metric_sum;
+  host_copy->metric_gsum = scal->metric_gsum;
+}
+
 // Fixed-order reduction of the per-query / per-slice partials + the quantisation scale for
 // the histogram accumulators.  The order is the one a single workgroup of 1024 threads
 // gives -- thread t adds elements t, t + 1024, ..., a wave adds its lanes, the 16 waves'
@@ -1164,7 +1178,7 @@ __global__ __launch_bounds__(64) void k_prep(const double *__restrict__ ssq,
     // host block; `pad` = the launch's sequence number, stored LAST behind a system-scope
     // fence: the host polls it (wait_seq_impl in qr_api.hip) instead of waiting for an event
     if (host_copy) {
-      *host_copy = *scal;
+      scalars_to_host(host_copy, scal);
       __threadfence_system();
       __hip_atomic_store(&host_copy->pad, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1418,7 +1432,7 @@ __global__ void k_scal_global(QrScalars *__restrict__ scal, const long long *__r
   scal->scale_exp = e;
   scal->scale = ldexp(1.0, e);
   scal->inv_scale = ldexp(1.0, -e);
-  *host_copy = *scal;
+  scalars_to_host(host_copy, scal);
   __threadfence_system();
   __hip_atomic_store(&host_copy->pad, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

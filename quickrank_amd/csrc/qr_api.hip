@@ -23,6 +23,8 @@ static void dfree(T *&p) {
   p = nullptr;
 }
 
+#include <sched.h>
+
 extern "C" {
 
 void qr_ctx_destroy(qr_ctx *c);
@@ -32,6 +34,17 @@ static int tree_settle(qr_ctx *c);
 // data (system-scope release).  Polls the word; every so often asks the stream whether it
 // has failed or drained, so that a faulted kernel ends the wait with an error and a
 // platform where the stores only land at the end of the kernel is merely slower.
+static inline void cpu_relax(unsigned spin) {
+  // a short spin first (the word usually arrives within microseconds), then yield the core:
+  // with --gpus 8 there are eight of these waiting threads on the host
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#endif
+  if (spin > 20000u) sched_yield();
+}
+
 static int wait_seq_impl(qr_ctx *c, const void *word, const int bytes, const int64_t want, const char *what) {
   auto reached = [&]() {
     return bytes == 4 ? (int64_t)__atomic_load_n((const int32_t *)word, __ATOMIC_ACQUIRE) == want
@@ -50,7 +63,7 @@ static int wait_seq_impl(qr_ctx *c, const void *word, const int bytes, const int
       }
       if (e != hipErrorNotReady) QR_CHECK(c, e);
     }
-    __builtin_ia32_pause();
+    cpu_relax(spin);
   }
 }
 static int wait_seq32(qr_ctx *c, const int32_t *word, const int32_t want, const char *what) {
@@ -214,6 +227,9 @@ const char *qr_last_error(const qr_ctx *c) {
 
 int qr_ctx_set_stream(qr_ctx *c, void *s) {
   if (!c) return QR_ERR_ARG;
+  // (a tree with a guessed step count settles on the stream it was enqueued on: its
+  // continuation reads state captured at enqueue time -- ADVICE r2)
+  { const int src = tree_settle(c); if (src) return src; }
   (void)hipStreamSynchronize(c->stream);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   c->stream = (hipStream_t)s;
@@ -359,6 +375,7 @@ int qr_valid_upload(qr_ctx *c, const float *x, size_t N, size_t F, const float *
   if (!c) return QR_ERR_ARG;
   if (!c->F) QR_FAIL(c, QR_ERR_STATE, "upload the training set first");
   if (!x || !labels || !qoff || N == 0 || F == 0) QR_FAIL(c, QR_ERR_ARG, "empty validation set");
+  { const int src = tree_settle(c); if (src) return src; }  // (a pending score update walks the old rows)
   free_valid(c);
   c->vN = N; c->vQ = Q;
   QR_CHECK(c, dalloc(&c->d_vraw, N * c->F));
@@ -671,6 +688,9 @@ int qr_bins_build_with(qr_ctx *c, const float *thr, const uint32_t *thr_size) {
 }
 
 // ---- more than 255 thresholds per feature (k_wide.hip) --------------------------
+static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, size_t *cells_out,
+                                size_t *max_slots_out);
+
 int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t *max_slots_out) {
   if (!c) return QR_ERR_ARG;
   if (!c->d_raw) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
@@ -679,15 +699,36 @@ int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t 
     QR_FAIL(c, QR_ERR_UNSUPPORTED,
             "more than 255 thresholds per feature: single-GPU contexts only (sharded contexts use u8 bins)");
   QR_CHECK(c, hipSetDevice(c->device));
-  const size_t N = c->N, F = c->F;
   float *d_col = nullptr;
+  const int rc_all = bins_build_wide_impl(c, nthresholds, d_col, cells_out, max_slots_out);
+  dfree(d_col);  // (whatever happened: the transposed copy is one-time scratch)
+  if (rc_all != QR_OK) {
+    // nothing half-built stays behind: the wide tables and the tree working set go, the
+    // uploaded dataset (raw rows, labels, queries, scores) stays for another attempt
+    const std::string keep = c->err;
+    (void)hipStreamSynchronize(c->stream);
+    dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_thr_size);
+    dfree(c->d_woff); dfree(c->d_wthr); dfree(c->d_wbins);
+    dfree(c->d_wchunk); dfree(c->d_wchunk0); dfree(c->d_wtot_s); dfree(c->d_wtot_c); dfree(c->d_wcbest);
+    dfree(c->d_order[0]); dfree(c->d_order[1]); dfree(c->d_featrec); dfree(c->d_featthr);
+    dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask); dfree(c->d_part_state);
+    dfree(c->d_part_ss); dfree(c->d_tree); dfree(c->d_leafpart); dfree(c->d_leafb);
+    c->wchunks = 0;
+    c->wcells = 0;
+    c->wmax = 0;
+    c->wide = c->binned = false;
+    c->err = keep;
+  }
+  return rc_all;
+}
+
+static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, size_t *cells_out,
+                                size_t *max_slots_out) {
+  const size_t N = c->N, F = c->F;
   QR_CHECK(c, dalloc(&d_col, N * F));
   int rc = qr_k_transpose(c, c->d_raw, d_col, N, F);
   if (!rc) rc = qr_k_wide_thresholds(c, d_col, nthresholds);
-  if (rc) {
-    dfree(d_col);
-    return rc;
-  }
+  if (rc) return rc;
   c->wcells = c->h_wthr.size();
   c->wmax = 0;
   for (size_t f = 0; f < F; ++f) c->wmax = std::max(c->wmax, c->h_thr_size[f]);
@@ -731,7 +772,6 @@ int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t 
   }
   rc = qr_k_wide_binning(c, d_col);
   QR_CHECK(c, hipStreamSynchronize(c->stream));
-  dfree(d_col);
   if (rc) return rc;
   // ---- tree working set of the one-split-per-step path
   QR_CHECK(c, dalloc(&c->d_order[0], N));
@@ -1063,6 +1103,7 @@ static int ensure_level_buffers(qr_ctx *c, size_t depth) {
 // sample without an exchange -- and keep their own part.
 static int subsample_set(qr_ctx *c, float subsample, uint64_t seed, size_t first_doc) {
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  { const int src = tree_settle(c); if (src) return src; }  // (the pending tree's leaf kernels read the old sample)
   if (!(subsample > 0.0f)) QR_FAIL(c, QR_ERR_ARG, "subsample must be > 0");
   const size_t Nall = c->dmode ? (size_t)c->Nglobal : c->N;
   if (c->dmode && first_doc + c->N > Nall) QR_FAIL(c, QR_ERR_ARG, "the rank's documents lie outside the global range");
@@ -1104,6 +1145,7 @@ int qr_tree_set_max_features(qr_ctx *c, float max_features, uint64_t seed) {
   if (!c) return QR_ERR_ARG;
   if (!c->F) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
   if (!(max_features > 0.0f)) QR_FAIL(c, QR_ERR_ARG, "max_features must be > 0");
+  { const int src = tree_settle(c); if (src) return src; }
   // rt.cc:227-233: > 1 is a number of features, < 1 a fraction (rounded up)
   size_t k = max_features > 1.0f ? (size_t)max_features : (size_t)std::ceil(max_features * (float)c->F);
   if (max_features == 1.0f || k >= c->F) k = 0;  // every feature: no sampling
@@ -1182,7 +1224,7 @@ static int wait_early(qr_ctx *c, int64_t *word_out) {
       }
       if (e != hipErrorNotReady) QR_CHECK(c, e);
     }
-    __builtin_ia32_pause();
+    cpu_relax(spin);
   }
 }
 

@@ -60,10 +60,23 @@ def _direct_comm(ctx, torch, dist, group, stream):
 class ShardedTreeFitter:
     """Drives qr_tree_begin/decide/apply/end with the collectives in between."""
 
-    def __init__(self, ctx, group=None, device=None):
+    def __init__(self, ctx, group=None, device=None, transport=None):
+        """`transport`: a ready-made object with RcclComm's interface (rank, world, nranks,
+        all_reduce_i64 / all_reduce_i32 / all_gather_bytes on device pointers, close) -- the
+        collectives then go through it on the context's OWN stream and no process group is
+        touched (tests drive several rank contexts of one process in lockstep that way)."""
         import torch
+        self.torch, self.group = torch, group
+        if transport is not None:
+            self.dist = None
+            self.world, self.rank = transport.world, transport.rank
+            b = ctx.exchange_buffers()
+            self.rec_bytes = b["rec_bytes"]
+            self.direct, self._b = transport, b
+            self.recs_local = self.recs_all = self.mask = None
+            return
         import torch.distributed as dist
-        self.torch, self.dist, self.group = torch, dist, group
+        self.dist = dist
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         b = ctx.exchange_buffers()
@@ -120,6 +133,8 @@ class ShardedTreeFitter:
             self._ob = b
             if hasattr(ctx, "host_buffers"):
                 self._omask = self.torch.from_numpy(ctx.host_buffers()["obl_mask"])
+            elif self.dist is None:
+                self._omask = None          # (injected transport: device pointers only)
             else:
                 dev = self.recs_local.device
                 self._omask = self.torch.as_tensor(_DevArray(b["mask"], b["mask_bytes"], "<i4", 4), device=dev)
@@ -218,13 +233,25 @@ class DocShardedTrainer:
     sharded ShardedTreeFitter keeps every per-document step replicated.
     """
 
-    def __init__(self, ctx, group=None, device=None):
+    def __init__(self, ctx, group=None, device=None, transport=None):
+        """`transport`: see ShardedTreeFitter -- RcclComm's interface on the context's own
+        stream, no process group."""
         import torch
+        self.torch, self.group, self.ctx = torch, group, ctx
+        self.device = device
+        if transport is not None:
+            self.dist = None
+            self.world, self.rank = transport.world, transport.rank
+            b = ctx.doc_exchange_buffers()
+            self.hist = self.scal = self.leaf = None
+            self.leaf_n = 0
+            self._ptr = {"hist": (b["hist"], b["hist_n"]), "scal": (b["scal"], b["scal_n"])}
+            self.direct = transport
+            return
         import torch.distributed as dist
-        self.torch, self.dist, self.group, self.ctx = torch, dist, group, ctx
+        self.dist = dist
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.device = device
         stream = _bind_stream(ctx, torch)
         b = ctx.doc_exchange_buffers()
         self.hist = self._view(b["hist"], b["hist_n"], "hist")
@@ -237,6 +264,8 @@ class DocShardedTrainer:
 
     def _view(self, ptr, n, name):
         torch = self.torch
+        if self.dist is None:                        # injected transport: device pointers only
+            return None
         if hasattr(self.ctx, "host_buffers"):        # CPU protocol stand-in (tests)
             return torch.from_numpy(self.ctx.host_buffers()[name])
         dev = self.device if self.device is not None else \
@@ -249,6 +278,8 @@ class DocShardedTrainer:
         if self.direct is not None and name is not None:
             self.direct.all_reduce_i64(*self._ptr[name])
             return
+        if self.dist is None:
+            raise RuntimeError("an injected transport carries the context's exchange buffers only")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def compute_lambdas(self, metric="NDCG", cutoff=10):
@@ -309,6 +340,11 @@ class DocShardedTrainer:
         rank order."""
         local = self.ctx.metric_eval(which, metric, cutoff)
         nq = self.ctx.Q if which == 0 else self.ctx.vQ
+        if self.dist is None:   # injected transport: the per-rank pairs through its host-side gather
+            pairs = self.direct.all_gather_host((local * nq, float(nq)))
+            total = sum(float(a) for a, _ in pairs)
+            count = sum(float(b_) for _, b_ in pairs)
+            return total / count if count else 0.0
         t = self.torch.zeros(2 * self.world, dtype=self.torch.float64)
         t[2 * self.rank] = local * nq
         t[2 * self.rank + 1] = nq

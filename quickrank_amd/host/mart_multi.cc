@@ -64,9 +64,18 @@ class Barrier {  // reusable; std::barrier is C++20
   size_t gen_ = 0;
 };
 
+// A fatal error on one rank's thread while its siblings may be blocked inside an RCCL
+// collective or at the barrier: exit() would run the static and HIP / RCCL destructors next
+// to those in-flight collectives and can hang instead of terminating, so the process leaves
+// at once (streams flushed by hand, no destructors).
+[[noreturn]] void fatal_exit() {
+  std::cout.flush();
+  std::cerr.flush();
+  std::_Exit(EXIT_FAILURE);
+}
 [[noreturn]] void die(qr_ctx *c, const char *what) {
   std::cerr << "!!! " << what << ": " << qr_last_error(c) << std::endl;
-  exit(EXIT_FAILURE);
+  fatal_exit();
 }
 #define QRM(c, call)                           \
   do {                                         \
@@ -77,7 +86,7 @@ class Barrier {  // reusable; std::barrier is C++20
     const ncclResult_t r_ = (call);                                                    \
     if (r_ != ncclSuccess) {                                                           \
       std::cerr << "!!! " #call ": " << ncclGetErrorString(r_) << std::endl;           \
-      exit(EXIT_FAILURE);                                                              \
+      fatal_exit();                                                                    \
     }                                                                                  \
   } while (0)
 
@@ -405,7 +414,7 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
         if (!same) {
           std::cerr << "!!! rank " << r << " built a different tree than rank 0 in iteration " << m + 1
                     << std::endl;
-          exit(EXIT_FAILURE);
+          fatal_exit();
         }
       }
       sh.bar.wait();
@@ -442,7 +451,11 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
   std::vector<std::thread> threads;
   for (int r = 0; r < W; ++r) threads.emplace_back(worker, r);
   for (auto &t : threads) t.join();
-  for (int r = 0; r < W; ++r) ncclCommDestroy(comms[r]);
+  for (int r = 0; r < W; ++r) {
+    const ncclResult_t dr = ncclCommDestroy(comms[r]);
+    if (dr != ncclSuccess)
+      std::cerr << "!!! ncclCommDestroy (rank " << r << "): " << ncclGetErrorString(dr) << std::endl;
+  }
   best_metric_on_training_ = best_train_r_[0];
   best_metric_on_validation_ = best_valid_r_[0];
   best_model_ = best_model_r_[0];

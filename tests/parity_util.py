@@ -100,3 +100,24 @@ def assert_split_log_parity(log, olog, ties, score_rtol=1e-9):
     assert np.allclose(log["score"][got], olog["score"][want], rtol=score_rtol)
     if not ties.mirrored:  # same growth order: only the tie-resolved entries may name another candidate
         assert int((~same).sum()) <= int(ties)
+
+
+def assert_same_tree_records(got, want, node_sums_exact=True, where=None):
+    """Two device runs of the same tree (e.g. a sharded protocol against the single context).
+    Every field bit for bit, except -- `node_sums_exact=False` -- the bookkeeping that comes
+    from a node's f64 sums of pseudo-responses (`deviance` of every node, `value` of INTERNAL
+    nodes): batched single-GPU growth takes those sums from its histogram pass, the
+    one-split-per-step protocols from their partition pass -- two fixed summation orders, equal
+    to rounding (1e-11 here).  What leaves the trainer -- structure, thresholds, sample
+    counts, leaf outputs -- stays exact."""
+    assert len(got) == len(want), where
+    leaf = want["feature"] < 0
+    for k in want.dtype.names:
+        if not node_sums_exact and k in ("value", "deviance"):
+            if k == "value":
+                assert np.array_equal(got[k][leaf], want[k][leaf]), (where, "leaf outputs")
+            assert np.allclose(got[k], want[k], rtol=1e-11, atol=1e-13, equal_nan=True), (where, k)
+        elif want[k].dtype.kind == "f":
+            assert np.array_equal(got[k], want[k], equal_nan=True), (where, k)
+        else:
+            assert np.array_equal(got[k], want[k]), (where, k)

@@ -27,6 +27,7 @@ def _worker(rank, world, port, q, layout):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import quickrank_amd as qr
     from datagen import make_dataset
+    from parity_util import assert_same_tree_records
     from quickrank_amd.dist import DocShardedTrainer, ShardedTreeFitter, gather_thresholds
     x, labels, qoff = make_dataset(nq=90, docs_per_query=40, F=70, seed=29, adversarial=True)
     N, Q = len(labels), len(qoff) - 1
@@ -78,8 +79,10 @@ def _worker(rank, world, port, q, layout):
             c.compute_lambdas("NDCG", 10)
             got = fit.fit_tree(c, 10, 2, True)
             c.update_scores(0.1)
-            for k in want.dtype.names:
-                ok = ok and np.array_equal(got[k], want[k])
+            try:   # (internal nodes' f64 sums: two fixed summation orders, see parity_util)
+                assert_same_tree_records(got, want, node_sums_exact=False, where=it)
+            except AssertionError:
+                ok = False
         ok = ok and np.array_equal(c.get_scores(), single.get_scores())
     c.close()
     single.close()

@@ -146,10 +146,37 @@ __global__ __launch_bounds__(256) void k_wbinning(const float *__restrict__ col,
   bins[(size_t)f * N + d] = lo > size - 1 ? size - 1 : lo;
 }
 
+// Rows of up to QR_W16_SLOTS slots (--num-thresholds up to 1151, e.g. the common 1024): a second
+// copy of the bins as u16, row-major in groups of 16 features -- [group][doc][16], 32 bytes
+// per (document, group): one sector per gathered document -- for k_whist16.  Columns beyond
+// F are padded with slot 0 (never flushed).
+__global__ __launch_bounds__(256) void k_wbins16(const uint32_t *__restrict__ bins, const uint32_t N,
+                                                 const uint32_t F, uint16_t *__restrict__ out) {
+  const uint32_t g = blockIdx.y;
+  const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= N) return;
+  uint32_t w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t f0 = g * 16 + 2 * k, f1 = f0 + 1;
+    const uint32_t a = f0 < F ? bins[(size_t)f0 * N + d] : 0u;
+    const uint32_t b = f1 < F ? bins[(size_t)f1 * N + d] : 0u;
+    w[k] = (a & 0xffffu) | (b << 16);
+  }
+  uint4 *o = reinterpret_cast<uint4 *>(out + ((size_t)g * N + d) * 16);
+  o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
 int qr_k_wide_binning(qr_ctx *c, const float *d_col) {
   hipLaunchKernelGGL(k_wbinning, dim3((unsigned)((c->N + 255) / 256), (unsigned)c->F), dim3(256), 0,
                      c->stream, d_col, (uint32_t)c->N, c->d_wthr, c->d_woff, c->d_wbins);
   QR_CHECK(c, hipGetLastError());
+  if (c->d_wbins16) {
+    hipLaunchKernelGGL(k_wbins16, dim3((unsigned)((c->N + 255) / 256), (unsigned)((c->F + 15) / 16)), dim3(256), 0,
+                       c->stream, c->d_wbins, (uint32_t)c->N, (uint32_t)c->F, c->d_wbins16);
+    QR_CHECK(c, hipGetLastError());
+  }
   return QR_OK;
 }
 
@@ -273,6 +300,162 @@ __global__ __launch_bounds__(1024) void k_whist(
       atomicAdd(&gc[i], (uint32_t)cn);
     }
   }
+}
+
+// The same histogram for rows of up to QR_W16_SLOTS slots, the way k_tree.hip builds the
+// 256-slot ones: one workgroup = 16 features x a range of the node's documents, an LDS
+// histogram [slot][16] of packed cells, lane = document.  A lane loads the 16 u16 bins of its
+// document (32 bytes, one sector) and issues 16 LDS atomics; at step k it updates column
+// (k + lane) & 15, so the 16 lanes of an LDS lane group touch 16 distinct bank pairs whatever
+// the slots are -- k_whist's one atomic per 12 gathered bytes at random banks was 64 % of an
+// iteration with 1024 thresholds (787 of 1230 us, profiles/r03_wide.md).  The halfwords are
+// rotated in registers (dword rotation by selects, the odd halfword by v_alignbyte) so that
+// step k reads a fixed position.  Flush: global atomics per touched cell into the node's
+// ragged arrays, as k_whist does -- same integers, same bits.
+#define QR_W16_SLOTS 1152u
+#ifndef QR_W16_DOCS
+#define QR_W16_DOCS 8192u   /* documents per k_whist16 workgroup (<= QR_WDOCS: the cell's count bits) */
+#endif
+// first partial slot (in units of one document range) of node j of the launch: the ranges of
+// the active nodes before it (level-wise growth; a single node otherwise)
+__device__ __forceinline__ uint32_t w16_slot_base(const QrTreeState *ts, const int mode, const uint32_t j) {
+  if (mode != 2) return 0;
+  uint32_t b = 0;
+  for (uint32_t k = 0; k < j; ++k) {
+    const QrLevelNode &ln = ts->lnode[k];
+    if (ln.active) b += (ln.small_n + QR_W16_DOCS - 1) / QR_W16_DOCS;
+  }
+  return b;
+}
+__global__ __launch_bounds__(1024) void k_whist16(
+    const QrTreeState *__restrict__ ts, const int mode, const uint32_t rootn, const int root_buf,
+    const uint32_t N, const uint32_t F, const uint16_t *__restrict__ bins16,
+    const uint32_t *__restrict__ woff, const size_t cells, const uint32_t *__restrict__ order0,
+    const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
+    const QrScalars *__restrict__ scal, u64 *__restrict__ wpart, const uint32_t slots) {
+  extern __shared__ __attribute__((aligned(16))) char wlds[];
+  const WSeg s = w_segment(ts, mode, rootn, root_buf, blockIdx.z);
+  if (!s.active) return;
+  const uint32_t r0 = blockIdx.x * QR_W16_DOCS;
+  if (r0 >= s.n) return;
+  const uint32_t r1 = r0 + QR_W16_DOCS < s.n ? r0 + QR_W16_DOCS : s.n;
+  const uint32_t g = blockIdx.y;
+  const uint32_t *order = s.buf == 0 ? order0 : order1;
+  const bool identity = s.buf == 2;
+  const uint16_t *rows = bins16 + (size_t)g * N * 16;
+  const double scale = scal->scale;
+  u64 *cell = reinterpret_cast<u64 *>(wlds);  // [slots][16]
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t r = lane & 15, dr = r >> 1, hb = 2u * (r & 1u);
+  uint32_t colk8[16];  // byte offset of the column a step updates
+#pragma unroll
+  for (int k = 0; k < 16; ++k) colk8[k] = ((k + r) & 15u) * 8u;
+  auto get_id = [&](uint32_t p) -> uint32_t { return identity ? s.begin + p : order[s.begin + p]; };
+  const uint32_t plast = r1 - 1;
+  auto clampp = [&](uint32_t p) { return p < plast ? p : plast; };
+  auto process = [&](const uint4 &lo4, const uint4 &hi4, const double lam) {
+    const u64 addend = (1ull << QR_SB) + (u64)quantize(lam * scale);
+    const uint32_t w[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    uint32_t t[8], u[8], v[8], R[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (dr & 1) ? w[(i + 1) & 7] : w[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = (dr & 2) ? t[(i + 2) & 7] : t[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (dr & 4) ? u[(i + 4) & 7] : u[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) R[i] = __builtin_amdgcn_alignbyte(v[(i + 1) & 7], v[i], hb);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {  // halfword k of R = bin of column (k + r) & 15
+      const uint32_t bin = (k & 1) ? (R[k >> 1] >> 16) : (R[k >> 1] & 0xffffu);
+      atomicAdd(reinterpret_cast<u64 *>(wlds + bin * 128u + colk8[k]), addend);
+    }
+  };
+  // two register sets: the rows and gradients of the next tile are in flight behind the
+  // tile whose atomics are issuing (unconditional, clamped loads, as hist_accumulate)
+  const uint32_t step = 1024;
+  const uint32_t p0 = r0 + threadIdx.x;
+  uint4 a0, a1, b0, b1;
+  double la, lb;
+  uint32_t ida = get_id(clampp(p0)), idb = get_id(clampp(p0 + step));
+  {
+    const uint4 *ra = reinterpret_cast<const uint4 *>(rows + (size_t)ida * 16);
+    a0 = ra[0];
+    a1 = ra[1];
+    la = lambda[ida];
+    const uint4 *rb = reinterpret_cast<const uint4 *>(rows + (size_t)idb * 16);
+    b0 = rb[0];
+    b1 = rb[1];
+    lb = lambda[idb];
+  }
+  ida = get_id(clampp(p0 + 2 * step));
+  idb = get_id(clampp(p0 + 3 * step));
+  for (uint32_t i = threadIdx.x * 2; i < slots * 16; i += 2048) {
+    cell[i] = 0;
+    cell[i + 1] = 0;
+  }
+  __syncthreads();
+  const uint32_t wbase = r0 + (threadIdx.x & ~63u);
+  for (uint32_t wb = wbase; wb < r1; wb += 2 * step) {  // (wave-uniform trip count)
+    const uint32_t p = wb + lane;
+    if (p < r1) process(a0, a1, la);
+    {
+      const uint4 *ra = reinterpret_cast<const uint4 *>(rows + (size_t)ida * 16);
+      a0 = ra[0];
+      a1 = ra[1];
+      la = lambda[ida];
+      ida = get_id(clampp(p + 4 * step));
+    }
+    if (p + step < r1) process(b0, b1, lb);
+    {
+      const uint4 *rb = reinterpret_cast<const uint4 *>(rows + (size_t)idb * 16);
+      b0 = rb[0];
+      b1 = rb[1];
+      lb = lambda[idb];
+      idb = get_id(clampp(p + 5 * step));
+    }
+  }
+  __syncthreads();
+  // flush: the whole LDS histogram, as it is, into the workgroup's partial slot (plain
+  // coalesced stores; k_wreduce16 adds the node's slots up).  Global atomics per touched cell
+  // -- two per cell, ~13 M for a root of 713k documents -- were 90 % of this kernel's time.
+  u64 *dst = wpart + ((size_t)(w16_slot_base(ts, mode, blockIdx.z) + blockIdx.x) * gridDim.y + g) * ((size_t)slots * 16);
+  for (uint32_t i = threadIdx.x * 2; i < slots * 16; i += 2048) {
+    ulonglong2 v;
+    v.x = cell[i];
+    v.y = cell[i + 1];
+    *reinterpret_cast<ulonglong2 *>(dst + i) = v;
+  }
+}
+
+// sum of the partial slots of one node's launch, unpacked into the node's ragged arrays
+// (every cell of every row is written: no zeroing pass): grid = (cells / 256, groups, nodes)
+__global__ __launch_bounds__(256) void k_wreduce16(
+    const QrTreeState *__restrict__ ts, const int mode, const uint32_t rootn, const int root_buf,
+    const uint32_t F, const uint32_t *__restrict__ woff, const size_t cells,
+    const u64 *__restrict__ wpart, long long *__restrict__ hsum, uint32_t *__restrict__ hcnt,
+    const uint32_t slots) {
+  const WSeg s = w_segment(ts, mode, rootn, root_buf, blockIdx.z);
+  if (!s.active) return;
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= slots * 16) return;
+  const uint32_t g = blockIdx.y, t = i >> 4, c = i & 15u, f = g * 16 + c;
+  if (f >= F) return;
+  const uint32_t base = woff[f], size = woff[f + 1] - base;
+  if (t >= size) return;
+  const uint32_t nch = (s.n + QR_W16_DOCS - 1) / QR_W16_DOCS;
+  const u64 *src = wpart + ((size_t)w16_slot_base(ts, mode, blockIdx.z) * gridDim.y + g) * ((size_t)slots * 16) + i;
+  const size_t stride = (size_t)gridDim.y * slots * 16;
+  long long sum = 0;
+  uint32_t cn = 0;
+  for (uint32_t k = 0; k < nch; ++k) {
+    const u64 v = src[k * stride];
+    const u64 cc = (v + (1ull << (QR_SB - 1))) >> QR_SB;
+    sum += (long long)(v - (cc << QR_SB));
+    cn += (uint32_t)cc;
+  }
+  hsum[(size_t)s.slot * cells + base + t] = sum;
+  hcnt[(size_t)s.slot * cells + base + t] = cn;
 }
 
 // ---------------------------------------------------------------------------
@@ -723,8 +906,50 @@ static int whist_attr(qr_ctx *c) {
   if (lds > attr) {
     QR_CHECK(c, hipFuncSetAttribute((const void *)k_whist, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
+    if (c->d_wbins16)
+      QR_CHECK(c, hipFuncSetAttribute((const void *)k_whist16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(QR_W16_SLOTS * 128)));
     attr = lds;
   }
+  return QR_OK;
+}
+
+bool qr_k_wide_fast_rows(size_t max_slots) { return max_slots <= QR_W16_SLOTS; }
+static bool qr_k_wide_fast(const qr_ctx *c) { return c->d_wbins16 && !getenv("QR_WIDE_NO_FAST"); }
+
+// the node histograms of a launch: rows of up to QR_W16_SLOTS slots through the blocked u16
+// copy (k_whist16), longer ones feature by feature (k_whist)
+static int launch_whist(qr_ctx *c, const int mode, const uint32_t rootn, const int root_buf, const size_t maxn,
+                        const unsigned nodes) {
+  // (maxn: the most documents a node of the launch can hold)
+  const unsigned chunks = (unsigned)((maxn + (qr_k_wide_fast(c) ? QR_W16_DOCS : QR_WDOCS) - 1) /
+                                     (qr_k_wide_fast(c) ? QR_W16_DOCS : QR_WDOCS)) + (mode == 2 ? 1u : 0u);
+  if (qr_k_wide_fast(c)) {
+    const uint32_t slots = ((uint32_t)c->wmax + 1u) & ~1u;
+    const unsigned groups = (unsigned)((c->F + 15) / 16);
+    // partial slots: one per (document range, group); level-wise growth packs the nodes' ranges
+    const size_t need = ((size_t)chunks + nodes) * groups * slots * 16;
+    if (need > c->wpart_cap) {
+      QR_CHECK(c, hipStreamSynchronize(c->stream));
+      if (c->d_wpart) (void)hipFree(c->d_wpart);
+      c->d_wpart = nullptr;
+      QR_CHECK(c, hipMalloc((void **)&c->d_wpart, need * 8));
+      c->wpart_cap = need;
+    }
+    hipLaunchKernelGGL(k_whist16, dim3(chunks, groups, nodes), dim3(1024), (size_t)slots * 128, c->stream,
+                       c->d_tree, mode, rootn, root_buf, (uint32_t)c->N, (uint32_t)c->F, c->d_wbins16, c->d_woff,
+                       c->wcells, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_wpart,
+                       slots);
+    QR_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_wreduce16, dim3((slots * 16 + 255) / 256, groups, nodes), dim3(256), 0, c->stream,
+                       c->d_tree, mode, rootn, root_buf, (uint32_t)c->F, c->d_woff, c->wcells,
+                       (const u64 *)c->d_wpart, c->d_hsum, c->d_hcnt, slots);
+  } else {
+    hipLaunchKernelGGL(k_whist, dim3(chunks, (unsigned)c->flocal, nodes), dim3(1024), whist_lds(c), c->stream,
+                       c->d_tree, mode, rootn, root_buf, (uint32_t)c->N, c->d_wbins, c->d_woff, c->wcells,
+                       c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, c->d_hsum, c->d_hcnt);
+  }
+  QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
 
@@ -736,16 +961,13 @@ int qr_k_whist_scan(qr_ctx *c, int root_mode) {
   const int mode = root_mode ? 0 : 1;
   const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_n : c->N);
   const size_t maxn = root_mode ? rootn : rootn / 2 + 1;  // the smaller child
-  const unsigned zg = (unsigned)std::min<size_t>((c->wcells + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_wzero, dim3(zg, 1), dim3(256), 0, c->stream, c->d_tree, mode, c->wcells, c->d_hsum,
-                     c->d_hcnt);
-  QR_CHECK(c, hipGetLastError());
-  const unsigned chunks = (unsigned)((maxn + QR_WDOCS - 1) / QR_WDOCS);
-  hipLaunchKernelGGL(k_whist, dim3(chunks, (unsigned)c->flocal, 1), dim3(1024), whist_lds(c), c->stream,
-                     c->d_tree, mode, rootn, c->sub_k ? 0 : 2, (uint32_t)c->N, c->d_wbins, c->d_woff,
-                     c->wcells, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, c->d_hsum,
-                     c->d_hcnt);
-  QR_CHECK(c, hipGetLastError());
+  if (!qr_k_wide_fast(c)) {  // (the fast rows' reduce writes every cell: nothing to zero)
+    const unsigned zg = (unsigned)std::min<size_t>((c->wcells + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_wzero, dim3(zg, 1), dim3(256), 0, c->stream, c->d_tree, mode, c->wcells, c->d_hsum,
+                       c->d_hcnt);
+    QR_CHECK(c, hipGetLastError());
+  }
+  if ((rc = launch_whist(c, mode, rootn, c->sub_k ? 0 : 2, maxn, 1))) return rc;
   const bool no_chunks = getenv("QR_WIDE_NO_CHUNKS") != nullptr;  // (A/B aid: same records either way)
   if (c->wmax <= QR_WCHUNK || no_chunks) {  // short rows: one workgroup per feature
     hipLaunchKernelGGL(k_wscan, dim3((unsigned)c->flocal), dim3(1024), 0, c->stream, c->d_tree, mode,
@@ -783,17 +1005,14 @@ int qr_k_wobl_fill(qr_ctx *c, int level) {
 int qr_k_wobl_hist(qr_ctx *c, int nodes) {
   int rc = whist_attr(c);
   if (rc) return rc;
-  const unsigned zg = (unsigned)std::min<size_t>((c->wcells + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_wzero, dim3(zg, (unsigned)nodes), dim3(256), 0, c->stream, c->d_tree, 2, c->wcells,
-                     c->d_hsum, c->d_hcnt);
-  QR_CHECK(c, hipGetLastError());
+  if (!qr_k_wide_fast(c)) {
+    const unsigned zg = (unsigned)std::min<size_t>((c->wcells + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_wzero, dim3(zg, (unsigned)nodes), dim3(256), 0, c->stream, c->d_tree, 2, c->wcells,
+                       c->d_hsum, c->d_hcnt);
+    QR_CHECK(c, hipGetLastError());
+  }
   // the directly built child of a node holds at most half of its documents
-  const unsigned chunks = (unsigned)((c->N / 2 + QR_WDOCS) / QR_WDOCS);
-  hipLaunchKernelGGL(k_whist, dim3(chunks, (unsigned)c->flocal, (unsigned)nodes), dim3(1024), whist_lds(c),
-                     c->stream, c->d_tree, 2, (uint32_t)c->N, 2, (uint32_t)c->N, c->d_wbins, c->d_woff,
-                     c->wcells, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, c->d_hsum,
-                     c->d_hcnt);
-  QR_CHECK(c, hipGetLastError());
+  if ((rc = launch_whist(c, 2, (uint32_t)c->N, 2, c->N / 2, (unsigned)nodes))) return rc;
   hipLaunchKernelGGL(k_wscan_level, dim3((unsigned)c->flocal, (unsigned)nodes), dim3(1024), 0, c->stream,
                      c->d_tree, c->d_woff, c->wcells, c->d_hsum, c->d_hcnt);
   QR_CHECK(c, hipGetLastError());

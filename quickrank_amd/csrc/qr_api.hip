@@ -134,7 +134,10 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_idcg); dfree(c->d_qmetric); dfree(c->d_ranks); dfree(c->d_ssq); dfree(c->d_qmax);
   dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins); dfree(c->d_bins_fm);
   dfree(c->d_thr); dfree(c->d_thr_size);
-  dfree(c->d_woff); dfree(c->d_wthr); dfree(c->d_wbins);
+  dfree(c->d_woff); dfree(c->d_wthr); dfree(c->d_wbins); dfree(c->d_wbins16);
+  if (c->d_wpart) (void)hipFree(c->d_wpart);
+  c->d_wpart = nullptr;
+  c->wpart_cap = 0;
   dfree(c->d_wchunk); dfree(c->d_wchunk0); dfree(c->d_wtot_s); dfree(c->d_wtot_c); dfree(c->d_wcbest);
   c->wchunks = 0;
   c->wide = false;
@@ -708,7 +711,7 @@ int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t 
     const std::string keep = c->err;
     (void)hipStreamSynchronize(c->stream);
     dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_thr_size);
-    dfree(c->d_woff); dfree(c->d_wthr); dfree(c->d_wbins);
+    dfree(c->d_woff); dfree(c->d_wthr); dfree(c->d_wbins); dfree(c->d_wbins16);
     dfree(c->d_wchunk); dfree(c->d_wchunk0); dfree(c->d_wtot_s); dfree(c->d_wtot_c); dfree(c->d_wcbest);
     dfree(c->d_order[0]); dfree(c->d_order[1]); dfree(c->d_featrec); dfree(c->d_featthr);
     dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask); dfree(c->d_part_state);
@@ -750,6 +753,8 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
   QR_CHECK(c, dalloc(&c->d_wthr, c->wcells));
   QR_CHECK(c, hipMemcpy(c->d_wthr, c->h_wthr.data(), c->wcells * 4, hipMemcpyHostToDevice));
   QR_CHECK(c, dalloc(&c->d_wbins, N * F));
+  if (qr_k_wide_fast_rows(c->wmax))  // short rows: the blocked u16 copy the fast histogram kernel reads
+    QR_CHECK(c, dalloc(&c->d_wbins16, N * 16 * ((F + 15) / 16)));
   {  // the chunk table of the chunked scan: (feature, first slot) of every QR_WCHUNK slots of a row
     std::vector<uint32_t> ch, first(F + 1, 0);
     for (size_t f = 0; f < F; ++f) {

@@ -319,6 +319,9 @@ struct qr_ctx {
   size_t wchunks = 0;
   float *d_wthr = nullptr;       // [wcells]
   uint32_t *d_wbins = nullptr;   // [F][N] feature-major
+  uint16_t *d_wbins16 = nullptr; // rows of up to 1152 slots: [group of 16 features][N][16] (k_whist16)
+  uint64_t *d_wpart = nullptr;   // ... and its partial slots [document range][group][slots x 16] (k_wreduce16)
+  size_t wpart_cap = 0;
   std::vector<uint32_t> h_woff;
   std::vector<float> h_wthr;
   float *d_thr = nullptr;        // [F][256]
@@ -512,6 +515,7 @@ int qr_k_colstats(qr_ctx *c, const float *col, size_t N, size_t F, uint32_t limi
 int qr_k_binning(qr_ctx *c);
 int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds);
 int qr_k_wide_binning(qr_ctx *c, const float *d_col);
+bool qr_k_wide_fast_rows(size_t max_slots);
 int qr_k_whist_scan(qr_ctx *c, int root_mode);
 #define QR_WCHUNK 8192u  /* slots per workgroup of the chunked scan of long rows (k_wide.hip) */
 int qr_k_wobl_fill(qr_ctx *c, int level);

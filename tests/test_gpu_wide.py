@@ -202,3 +202,42 @@ def test_wide_oblivious_training_loop(qr, ora, algo):
     assert np.allclose(gm.train_metric, om["train_metric"], rtol=1e-9)
     assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-8, atol=1e-10)
     gm.ctx.close()
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[3]])
+@pytest.mark.parametrize("nthr", [300, 1100])
+def test_wide_fast_rows_equal_the_general_kernel(qr, ora, case, nthr, monkeypatch):
+    """Rows of up to 1152 slots take k_whist16 (blocked u16 bins, [slot][16] LDS histogram);
+    QR_WIDE_NO_FAST=1 sends the same context through the general k_whist.  Integer cells:
+    every node histogram, every tree record and the scores must be the same bits."""
+    x, labels, qoff = make_dataset(**case)
+
+    def run():
+        c = qr.Context(0)
+        c.upload(x, labels, qoff)
+        _, ts = c.build_bins(nthr)
+        assert c.wide and int(ts.max()) <= 1152
+        c.reset_scores()
+        trees, hists = [], []
+        for it in range(3):
+            c.compute_lambdas("NDCG", 10)
+            t = c.fit_tree(8, 2, True) if it < 2 else c.fit_oblivious(3, 2, True)
+            trees.append(t)
+            hists.append([c.node_hist_ragged(n) for n in range(min(len(t), 5))])
+            c.update_scores(0.1)
+        s = c.get_scores()
+        c.close()
+        return trees, hists, s
+
+    monkeypatch.delenv("QR_WIDE_NO_FAST", raising=False)
+    ta, ha, sa = run()
+    monkeypatch.setenv("QR_WIDE_NO_FAST", "1")
+    tb, hb, sb = run()
+    for a, b in zip(ta, tb):
+        for k in a.dtype.names:
+            assert np.array_equal(a[k], b[k], equal_nan=(a[k].dtype.kind == "f")), k
+    for la, lb in zip(ha, hb):
+        for (s1, c1), (s2, c2) in zip(la, lb):
+            for f in range(x.shape[1]):
+                assert np.array_equal(c1[f], c2[f]) and np.array_equal(s1[f], s2[f]), f
+    assert np.array_equal(sa, sb)

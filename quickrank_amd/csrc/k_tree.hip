@@ -78,9 +78,9 @@ __device__ long long qr_ht[8];
 // the pass that reads every lambda[id] of the child anyway, instead of a second gather of
 // them (8 bytes out of a cold 64-byte line each) in the partition.  The two accumulators do
 // not fit next to the sixteen precomputed column offsets in the 128 registers of a
-// 1024-thread workgroup, so this variant computes the column of a step on the fly (two
-// VALU instructions under an LDS-bound loop; the empty asm keeps the compiler from hoisting
-// them back into sixteen registers).
+// 1024-thread workgroup, so this variant keeps the columns packed, four to a register, and
+// extracts the one a step needs (one more VALU instruction under an LDS-bound loop; the
+// empty asm keeps the compiler from hoisting the extractions back into sixteen registers).
 template <int CH, bool IDENTITY, bool SUMS = false>
 __device__ __forceinline__ void hist_accumulate(
     u64 *__restrict__ hist, const uint8_t *__restrict__ bins_b,
@@ -102,15 +102,22 @@ __device__ __forceinline__ void hist_accumulate(
   for (int k = 0; k < 16; ++k) colk[k] = 16 * c + ((k + r) & 15);
   const int dr = r >> 2;       // dword rotation
   const uint32_t br = r & 3;   // byte rotation inside a dword
+  // (SUMS: the sixteen column indices packed into four registers, a byte each)
+  uint32_t cp[4] = {0, 0, 0, 0};
+  if (SUMS) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cp[k >> 2] |= colk[k] << (8 * (k & 3));
+  }
   auto process = [&](const uint4 &row, const double lam) {
-    uint32_t rr = (uint32_t)(16 * c + r);
+    uint32_t c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
     if (SUMS) {
-      asm volatile("" : "+v"(rr));
+      asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));  // (not hoisted back into sixteen registers)
       if (c == 0) {
         *sq += lam * lam;
         *sm += lam;
       }
     }
+    const uint32_t cpk[4] = {c0, c1, c2, c3};
     const u64 addend = (1ull << QR_SB) + (u64)quantize(lam * scale);
     // rotate the 16 bytes right by r so that byte k of R is byte (k+r)&15
     const uint32_t t0 = (dr & 1) ? row.y : row.x;
@@ -129,8 +136,7 @@ __device__ __forceinline__ void hist_accumulate(
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const uint32_t bin = (R[k >> 2] >> (8 * (k & 3))) & 0xffu;
-      // (rr = 16 c + r with r < 16: the column of step k is 16 c + ((r + k) & 15))
-      const uint32_t col = SUMS ? ((rr & ~15u) | ((rr + (uint32_t)k) & 15u)) : colk[k];
+      const uint32_t col = SUMS ? ((cpk[k >> 2] >> (8 * (k & 3))) & 0xffu) : colk[k];
       atomicAdd(&hist[bin * FW + col], addend);
     }
   };
@@ -3688,9 +3694,12 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
 // (the last control call prepared it like any other).  Apply it and carry on, one control
 // call per step on the device-resident state, for the worst case that is left; the last
 // call is final again (and cannot be incomplete: the leaf budget is exhausted by then).
-int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_done) {
+int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_done, size_t max_steps) {
   const BatchGeom g = batch_geom(c, nleaves);
-  const size_t left = nleaves - 1 > steps_done ? nleaves - 1 - steps_done : 1;
+  // (max_steps: the caller may take the rest in pieces and look again after each -- the
+  // worst case left is mostly launches that find nothing to do)
+  size_t left = nleaves - 1 > steps_done ? nleaves - 1 - steps_done : 1;
+  if (max_steps && left > max_steps) left = max_steps;
   int rc;
   for (size_t r = 0; r < left; ++r) {
     hipLaunchKernelGGL(k_partition_batch, dim3(g.pg), dim3(256), 0, c->stream, c->d_tree,

@@ -94,6 +94,8 @@ int qr_ctx_create(int device, qr_ctx **out) {
   c->exact_tail = getenv("QR_EXACT_TAIL") != nullptr;
   if (getenv("QR_LEAF_BY_POSITION")) c->leaf_by_position = true;
   if (const char *e = getenv("QR_STEPS_HINT")) c->steps_force = atol(e);  // steps to enqueue, whatever the tree
+  if (const char *e = getenv("QR_STEPS_PLUS")) c->steps_plus = (size_t)std::max(0l, atol(e));
+  if (const char *e = getenv("QR_CONT_STEPS")) c->cont_steps = (size_t)std::max(0l, atol(e));
   c->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -1243,17 +1245,25 @@ static int tree_settle(qr_ctx *c) {
   if (rc) return rc;
   c->spec_pending = false;
   ++c->spec_trees;
-  if (w & 1) {  // incomplete
-    ++c->spec_misses;
-    if ((rc = qr_k_tree_continue(c, c->cur_nleaves, c->cur_minls, (size_t)c->tree_step))) return rc;
+  if (w & 1) ++c->spec_misses;
+  // The guess was too low: the tree is carried on `cont_steps` steps at a time (default 1: the
+  // tree usually needs just one more, and the worst case left would be a dozen launches that
+  // find nothing to do), looking at the last control call's word after each piece.
+  size_t done = (size_t)c->tree_step;
+  while (w & 1) {
+    const size_t worst = c->cur_nleaves - 1 > done ? c->cur_nleaves - 1 - done : 1;
+    const size_t piece = c->cont_steps ? std::min(worst, c->cont_steps) : worst;
+    if ((rc = qr_k_tree_continue(c, c->cur_nleaves, c->cur_minls, done, piece))) return rc;
+    done += piece;
     if ((rc = qr_k_tree_finish(c, c->spec_newton))) return rc;
     if (c->spec_scores_enqueued && (rc = qr_k_scores_update(c, c->spec_shrinkage))) return rc;
     if ((rc = wait_early(c, &w))) return rc;
-    if (w & 1) QR_FAIL(c, QR_ERR_STATE, "internal: tree still incomplete after its last step");
+    if ((w & 1) && piece == worst) QR_FAIL(c, QR_ERR_STATE, "internal: tree still incomplete after its last step");
   }
   c->spec_scores_enqueued = false;
-  // the next tree: as many steps as this one needed, plus one
-  c->steps_hint = (size_t)((w >> 1) & 0x7fff) + 1;
+  // the next tree: as many steps as this one needed, plus `steps_plus` (QR_STEPS_PLUS)
+  c->steps_hint = (size_t)((w >> 1) & 0x7fff) + c->steps_plus;
+  if (c->steps_hint < 1) c->steps_hint = 1;
   return QR_OK;
 }
 

@@ -25,7 +25,9 @@
 #define QR_QBITS 33       /* |q| < 2^33                                      */
 #define QR_SLICE 1024u    /* doc-range alignment of hist workgroups          */
 #define QR_MAXBLK 64      /* max 64-feature blocks per rank (F <= 4096)      */
+#ifndef QR_PART_SLICE
 #define QR_PART_SLICE 2048u /* positions per partition workgroup             */
+#endif
 
 struct QrBlock {
   int f0;        // first global feature
@@ -409,6 +411,10 @@ struct qr_ctx {
   // continuation has to repeat (leaf kernels with `newton`, the score update with `shrinkage`)
   size_t steps_hint = 0;
   long steps_force = -1;              // QR_STEPS_HINT=k: always enqueue k steps (tests the continuation)
+  size_t steps_plus = 0;              // QR_STEPS_PLUS: spare steps enqueued beyond the previous tree's count (round 3: 0 --
+                                      // with the tree carried on a step at a time on a miss, a spare step's three launches
+                                      // that find nothing to do cost more than the misses: 1.91 -> 1.86 ms at 8M, ~ -2 us at 1M)
+  size_t cont_steps = 1;              // QR_CONT_STEPS: steps per piece when a tree is carried on (0 = all that could be left)
   bool spec_pending = false, spec_scores_enqueued = false;
   int spec_newton = 0;
   double spec_shrinkage = 0.0;
@@ -545,7 +551,7 @@ int qr_k_obl_propose(qr_ctx *c, int level);
 int qr_k_obl_mark(qr_ctx *c, int level);
 int qr_k_obl_apply(qr_ctx *c, int level, int last);
 int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls);
-int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_done);
+int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_done, size_t max_steps = 0);
 int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
                         double *d_out, double *d_partial = nullptr, int ignore_weights = 0);
 int qr_k_obl_score(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);

@@ -53,6 +53,10 @@
 #ifndef QR_HIST_SETS
 #define QR_HIST_SETS 3
 #endif
+// (the child launches' variant keeps its column offsets packed and has room for a deeper pipeline)
+#ifndef QR_HIST_SETS_CHILD
+#define QR_HIST_SETS_CHILD 3
+#endif
 
 // the control lane's helpers: inlined, or (-DQR_CTRL_NOINLINE, an experiment) shared calls
 #ifdef QR_CTRL_NOINLINE
@@ -145,7 +149,7 @@ __device__ __forceinline__ void hist_accumulate(
   // each set also keeps the document id of its NEXT tile in flight.  No register
   // copies between stages (a copy would wait for the load it forwards); the set
   // index is a compile-time constant everywhere, so the sets live in registers.
-  constexpr int NS = QR_HIST_SETS;
+  constexpr int NS = SUMS ? QR_HIST_SETS_CHILD : QR_HIST_SETS;
   const uint32_t step = nw * DW;
   const uint32_t p0 = r0 + wave * DW + dsub;
   auto valid = [&](uint32_t p) { return lane_ok && p < r1; };

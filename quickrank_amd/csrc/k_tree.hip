@@ -1204,7 +1204,10 @@ __device__ __forceinline__ void make_desc(DecideState &st, int node, const float
   d->small_n = d->small_is_left ? d->lcount : d->rcount;
   nd->feature = (int32_t)nd->best_f;
   nd->thr_id = (int32_t)nd->best_t;
-  nd->threshold = thr[(thr_off ? (size_t)thr_off[nd->best_f] : (size_t)nd->best_f * QR_MAX_BINS) + nd->best_t];
+  // (wide contexts: ragged rows indexed by LOCAL feature; the threshold of a feature another
+  // rank owns arrives behind the go-left mask, k_thr_patch)
+  nd->threshold = thr_off ? (d->owner_local >= 0 ? thr[(size_t)thr_off[d->owner_local] + nd->best_t] : 0.f)
+                          : thr[(size_t)nd->best_f * QR_MAX_BINS + nd->best_t];
   nd->left = li;
   nd->right = ri;
   QrNode *L = &st.nodes[li], *R = &st.nodes[ri];
@@ -2163,9 +2166,14 @@ __global__ __launch_bounds__(256) void k_mask(
     const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm,
     const uint32_t Nfm,
     const uint32_t *__restrict__ order0, const uint32_t *__restrict__ order1,
-    uint32_t *__restrict__ mask, const uint32_t mask_words) {
+    uint32_t *__restrict__ mask, const uint32_t mask_words, const int wide) {
   const QrSplitDesc d = ts->desc;
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (wide && w == 0) {
+    // wide-bin contexts: the owner also publishes the bits of the threshold VALUE (it alone
+    // holds the feature's row); zeros elsewhere, so the sum all-reduce hands it to every rank
+    mask[mask_words] = d.active && d.owner_local >= 0 ? __float_as_uint(ts->nodes[d.node].threshold) : 0u;
+  }
   if (w >= mask_words) return;
   uint32_t bits = 0;
   if (d.active && d.owner_local >= 0) {
@@ -2175,11 +2183,17 @@ __global__ __launch_bounds__(256) void k_mask(
       const uint32_t p = w * 32 + k;
       if (p < n) {
         const uint32_t id = d.src_buf == 2 ? d.begin + p : order[d.begin + p];
-        if (go_left(d, p, id, fm, Nfm, nullptr, 0)) bits |= 1u << k;
+        if (go_left(d, p, id, fm, Nfm, nullptr, wide ? 2 : 0)) bits |= 1u << k;
       }
     }
   }
   mask[w] = bits;
+}
+
+// after the mask all-reduce on a wide feature-sharded context: the split node's threshold
+__global__ void k_thr_patch(QrTreeState *__restrict__ ts, const uint32_t *__restrict__ word) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && ts->desc.active)
+    ts->nodes[ts->desc.node].threshold = __uint_as_float(*word);
 }
 
 __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *sh) {
@@ -3420,7 +3434,17 @@ static size_t hist_lds(const qr_ctx *c) {
 static int launch_scan(qr_ctx *c, int root_mode);
 
 static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
-  if (c->wide) return qr_k_whist_scan(c, root_mode);  // more than 255 thresholds: k_wide.hip
+  if (c->wide) {  // more than 255 thresholds: k_wide.hip
+    const int wrc = qr_k_whist_scan(c, root_mode);
+    if (wrc) return wrc;
+    if (c->world > 1 && !c->dmode) {  // feature-sharded: the rank's best records for the all-gather
+      hipLaunchKernelGGL(k_merge, dim3(1), dim3(128), 0, c->stream, c->d_tree, root_mode,
+                         c->d_featrec, c->flocal, c->d_hsum, c->d_hcnt, c->d_gf2lf,
+                         c->d_recs_local, c->mf_k, c->mf_seed + c->tree_counter, (uint32_t)c->F);
+      QR_CHECK(c, hipGetLastError());
+    }
+    return QR_OK;
+  }
   const size_t lds = hist_lds(c);
   size_t &attr_lds = c->attr_hist_lds;
   if (lds > attr_lds) {
@@ -3550,8 +3574,8 @@ int qr_k_tree_decide(qr_ctx *c) {
   if (fshard) {
     const unsigned grid = (unsigned)((c->mask_words + 255) / 256);
     hipLaunchKernelGGL(k_mask, dim3(grid), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_bins_fm, (uint32_t)c->N, c->d_order[0],
-                       c->d_order[1], c->d_mask, (uint32_t)c->mask_words);
+                       c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm, (uint32_t)c->N,
+                       c->d_order[0], c->d_order[1], c->d_mask, (uint32_t)c->mask_words, c->wide ? 1 : 0);
     QR_CHECK(c, hipGetLastError());
   }
   return QR_OK;
@@ -3559,7 +3583,13 @@ int qr_k_tree_decide(qr_ctx *c) {
 
 int qr_k_tree_apply(qr_ctx *c) {
   const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
-  const int use_mask = c->wide ? 2 : (c->world > 1 && !c->dmode);
+  const bool fshard = c->world > 1 && !c->dmode;
+  if (c->wide && fshard) {  // the threshold value that came with the reduced mask
+    hipLaunchKernelGGL(k_thr_patch, dim3(1), dim3(64), 0, c->stream, c->d_tree, c->d_mask + c->mask_words);
+    QR_CHECK(c, hipGetLastError());
+  }
+  // (feature-sharded: the reduced go-left bits, whatever the bins are; single-GPU wide: u32 bins)
+  const int use_mask = fshard ? 1 : (c->wide ? 2 : 0);
   // (document-sharded: the rank's own left count comes from its local prefix counts)
   hipLaunchKernelGGL(k_partition, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
                      c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm,

@@ -64,10 +64,12 @@ __global__ __launch_bounds__(256) void k_wkeys(const float *__restrict__ col, co
   if (i < N) keys[i] = w_flip(__float_as_uint(col[i]));
 }
 
-// col: device [F][N] column-major.  Fills c->h_wthr / h_woff / h_thr_size (global
-// features; this path owns every feature).
+// col: device [F][N] column-major.  Fills c->h_wthr / h_woff for the rank's OWN features
+// (c->h_lf2gf: every feature on one GPU, the rank's range on a feature-sharded context --
+// local index lf, rows concatenated in local order) and c->h_thr_size by GLOBAL feature
+// (0 for a feature another rank owns).
 int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds) {
-  const size_t N = c->N, F = c->F;
+  const size_t N = c->N, F = c->h_lf2gf.size();
   uint32_t *d_keys = nullptr, *d_sorted = nullptr;
   void *d_temp = nullptr;
   size_t temp_bytes = 0;
@@ -78,11 +80,12 @@ int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds) {
   std::vector<uint32_t> h(N);
   c->h_wthr.clear();
   c->h_woff.assign(F + 1, 0);
-  c->h_thr_size.assign(F, 0);
+  c->h_thr_size.assign(c->F, 0);
   std::vector<float> uniqs;
   for (size_t f = 0; f < F; ++f) {
+    const size_t gf = (size_t)c->h_lf2gf[f];
     hipLaunchKernelGGL(k_wkeys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream,
-                       d_col + f * N, (uint32_t)N, d_keys);
+                       d_col + gf * N, (uint32_t)N, d_keys);
     QR_CHECK(c, hipGetLastError());
     size_t tb = temp_bytes;
     QR_CHECK(c, hipcub::DeviceRadixSort::SortKeys(d_temp, tb, d_keys, d_sorted, (int)N, 0, 32, c->stream));
@@ -101,13 +104,13 @@ int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds) {
     if (uniqs.size() <= nthresholds || nthresholds == 0) {  // mart.cc:155-158
       c->h_wthr.insert(c->h_wthr.end(), uniqs.begin(), uniqs.end());
       c->h_wthr.push_back(FLT_MAX);
-      c->h_thr_size[f] = (uint32_t)uniqs.size() + 1;
+      c->h_thr_size[gf] = (uint32_t)uniqs.size() + 1;
     } else {  // mart.cc:159-169: equal width, a running f32 sum
       float t = bits2f(h_unflip(h[0]));
       const float step = (float)fabs(bits2f(h_unflip(h[N - 1])) - t) / nthresholds;
       for (size_t j = 0; j != nthresholds; t += step, ++j) c->h_wthr.push_back(t);
       c->h_wthr.push_back(FLT_MAX);
-      c->h_thr_size[f] = (uint32_t)nthresholds + 1;
+      c->h_thr_size[gf] = (uint32_t)nthresholds + 1;
     }
     if (c->h_wthr.size() >= 0xFFFFFFF0ull) {
       (void)hipFree(d_keys); (void)hipFree(d_sorted); (void)hipFree(d_temp);
@@ -128,11 +131,12 @@ int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds) {
 __global__ __launch_bounds__(256) void k_wbinning(const float *__restrict__ col, const uint32_t N,
                                                   const float *__restrict__ thr,
                                                   const uint32_t *__restrict__ woff,
-                                                  uint32_t *__restrict__ bins) {
-  const uint32_t f = blockIdx.y;
+                                                  uint32_t *__restrict__ bins,
+                                                  const int32_t *__restrict__ lf2gf) {
+  const uint32_t f = blockIdx.y;   // local feature
   const uint32_t d = blockIdx.x * 256 + threadIdx.x;
   if (d >= N) return;
-  const float x = col[(size_t)f * N + d];
+  const float x = col[(size_t)lf2gf[f] * N + d];
   const float *t = thr + woff[f];
   const uint32_t size = woff[f + 1] - woff[f];
   uint32_t lo = 0, hi = size;
@@ -169,12 +173,12 @@ __global__ __launch_bounds__(256) void k_wbins16(const uint32_t *__restrict__ bi
 }
 
 int qr_k_wide_binning(qr_ctx *c, const float *d_col) {
-  hipLaunchKernelGGL(k_wbinning, dim3((unsigned)((c->N + 255) / 256), (unsigned)c->F), dim3(256), 0,
-                     c->stream, d_col, (uint32_t)c->N, c->d_wthr, c->d_woff, c->d_wbins);
+  hipLaunchKernelGGL(k_wbinning, dim3((unsigned)((c->N + 255) / 256), (unsigned)c->flocal), dim3(256), 0,
+                     c->stream, d_col, (uint32_t)c->N, c->d_wthr, c->d_woff, c->d_wbins, c->d_lf2gf);
   QR_CHECK(c, hipGetLastError());
   if (c->d_wbins16) {
-    hipLaunchKernelGGL(k_wbins16, dim3((unsigned)((c->N + 255) / 256), (unsigned)((c->F + 15) / 16)), dim3(256), 0,
-                       c->stream, c->d_wbins, (uint32_t)c->N, (uint32_t)c->F, c->d_wbins16);
+    hipLaunchKernelGGL(k_wbins16, dim3((unsigned)((c->N + 255) / 256), (unsigned)((c->flocal + 15) / 16)), dim3(256), 0,
+                       c->stream, c->d_wbins, (uint32_t)c->N, (uint32_t)c->flocal, c->d_wbins16);
     QR_CHECK(c, hipGetLastError());
   }
   return QR_OK;
@@ -926,7 +930,7 @@ static int launch_whist(qr_ctx *c, const int mode, const uint32_t rootn, const i
                                      (qr_k_wide_fast(c) ? QR_W16_DOCS : QR_WDOCS)) + (mode == 2 ? 1u : 0u);
   if (qr_k_wide_fast(c)) {
     const uint32_t slots = ((uint32_t)c->wmax + 1u) & ~1u;
-    const unsigned groups = (unsigned)((c->F + 15) / 16);
+    const unsigned groups = (unsigned)((c->flocal + 15) / 16);
     // partial slots: one per (document range, group); level-wise growth packs the nodes' ranges
     const size_t need = ((size_t)chunks + nodes) * groups * slots * 16;
     if (need > c->wpart_cap) {
@@ -937,12 +941,12 @@ static int launch_whist(qr_ctx *c, const int mode, const uint32_t rootn, const i
       c->wpart_cap = need;
     }
     hipLaunchKernelGGL(k_whist16, dim3(chunks, groups, nodes), dim3(1024), (size_t)slots * 128, c->stream,
-                       c->d_tree, mode, rootn, root_buf, (uint32_t)c->N, (uint32_t)c->F, c->d_wbins16, c->d_woff,
+                       c->d_tree, mode, rootn, root_buf, (uint32_t)c->N, (uint32_t)c->flocal, c->d_wbins16, c->d_woff,
                        c->wcells, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_wpart,
                        slots);
     QR_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(k_wreduce16, dim3((slots * 16 + 255) / 256, groups, nodes), dim3(256), 0, c->stream,
-                       c->d_tree, mode, rootn, root_buf, (uint32_t)c->F, c->d_woff, c->wcells,
+                       c->d_tree, mode, rootn, root_buf, (uint32_t)c->flocal, c->d_woff, c->wcells,
                        (const u64 *)c->d_wpart, c->d_hsum, c->d_hcnt, slots);
   } else {
     hipLaunchKernelGGL(k_whist, dim3(chunks, (unsigned)c->flocal, nodes), dim3(1024), whist_lds(c), c->stream,

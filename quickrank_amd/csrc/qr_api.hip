@@ -700,9 +700,11 @@ int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t 
   if (!c) return QR_ERR_ARG;
   if (!c->d_raw) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
   if (c->binned) QR_FAIL(c, QR_ERR_STATE, "bins already built: upload the dataset again first");
-  if (c->world > 1 || c->dmode)
+  if (c->dmode)
     QR_FAIL(c, QR_ERR_UNSUPPORTED,
-            "more than 255 thresholds per feature: single-GPU contexts only (sharded contexts use u8 bins)");
+            "more than 255 thresholds per feature: single-GPU and feature-sharded contexts only (a "
+            "document-sharded histogram of every distinct value would be an all-reduce of 10^7 - 10^8 "
+            "cells per node)");
   QR_CHECK(c, hipSetDevice(c->device));
   float *d_col = nullptr;
   const int rc_all = bins_build_wide_impl(c, nthresholds, d_col, cells_out, max_slots_out);
@@ -730,6 +732,27 @@ int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t 
 static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, size_t *cells_out,
                                 size_t *max_slots_out) {
   const size_t N = c->N, F = c->F;
+  {
+    // the rank's own features: all of them on one GPU, the contiguous range
+    // [r ceil(F / world), (r + 1) ceil(F / world)) on a feature-sharded context (as the u8 path)
+    const size_t fworld = (size_t)c->world;
+    const size_t per_rank = (F + fworld - 1) / fworld;
+    const size_t f0 = std::min(F, per_rank * (size_t)c->rank), f1 = std::min(F, f0 + per_rank);
+    if (f1 <= f0) QR_FAIL(c, QR_ERR_ARG, "this rank owns no feature (world > F)");
+    c->blocks.clear();   // no u8 blocks
+    c->nblocks = 0;
+    c->flocal = (int)(f1 - f0);
+    c->h_gf2lf.assign(F, -1);
+    c->h_lf2gf.resize(f1 - f0);
+    for (size_t f = f0; f < f1; ++f) {
+      c->h_gf2lf[f] = (int32_t)(f - f0);
+      c->h_lf2gf[f - f0] = (int32_t)f;
+    }
+    QR_CHECK(c, dalloc(&c->d_lf2gf, (size_t)c->flocal));
+    QR_CHECK(c, dalloc(&c->d_gf2lf, F));
+    QR_CHECK(c, hipMemcpy(c->d_lf2gf, c->h_lf2gf.data(), c->h_lf2gf.size() * 4, hipMemcpyHostToDevice));
+    QR_CHECK(c, hipMemcpy(c->d_gf2lf, c->h_gf2lf.data(), F * 4, hipMemcpyHostToDevice));
+  }
   QR_CHECK(c, dalloc(&d_col, N * F));
   int rc = qr_k_transpose(c, c->d_raw, d_col, N, F);
   if (!rc) rc = qr_k_wide_thresholds(c, d_col, nthresholds);
@@ -737,29 +760,19 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
   c->wcells = c->h_wthr.size();
   c->wmax = 0;
   for (size_t f = 0; f < F; ++f) c->wmax = std::max(c->wmax, c->h_thr_size[f]);
-  // every feature is local: identity maps, no u8 blocks
-  c->blocks.clear();
-  c->nblocks = 0;
-  c->flocal = (int)F;
-  c->h_gf2lf.resize(F);
-  c->h_lf2gf.resize(F);
-  for (size_t f = 0; f < F; ++f) c->h_gf2lf[f] = c->h_lf2gf[f] = (int32_t)f;
-  QR_CHECK(c, dalloc(&c->d_lf2gf, F));
-  QR_CHECK(c, dalloc(&c->d_gf2lf, F));
-  QR_CHECK(c, hipMemcpy(c->d_lf2gf, c->h_lf2gf.data(), F * 4, hipMemcpyHostToDevice));
-  QR_CHECK(c, hipMemcpy(c->d_gf2lf, c->h_gf2lf.data(), F * 4, hipMemcpyHostToDevice));
+  const size_t FL = c->h_lf2gf.size();  // the rank's own features (all of them on one GPU)
   QR_CHECK(c, dalloc(&c->d_thr_size, F));
   QR_CHECK(c, hipMemcpy(c->d_thr_size, c->h_thr_size.data(), F * 4, hipMemcpyHostToDevice));
-  QR_CHECK(c, dalloc(&c->d_woff, F + 1));
-  QR_CHECK(c, hipMemcpy(c->d_woff, c->h_woff.data(), (F + 1) * 4, hipMemcpyHostToDevice));
+  QR_CHECK(c, dalloc(&c->d_woff, FL + 1));
+  QR_CHECK(c, hipMemcpy(c->d_woff, c->h_woff.data(), (FL + 1) * 4, hipMemcpyHostToDevice));
   QR_CHECK(c, dalloc(&c->d_wthr, c->wcells));
   QR_CHECK(c, hipMemcpy(c->d_wthr, c->h_wthr.data(), c->wcells * 4, hipMemcpyHostToDevice));
-  QR_CHECK(c, dalloc(&c->d_wbins, N * F));
+  QR_CHECK(c, dalloc(&c->d_wbins, N * FL));
   if (qr_k_wide_fast_rows(c->wmax))  // short rows: the blocked u16 copy the fast histogram kernel reads
-    QR_CHECK(c, dalloc(&c->d_wbins16, N * 16 * ((F + 15) / 16)));
+    QR_CHECK(c, dalloc(&c->d_wbins16, N * 16 * ((FL + 15) / 16)));
   {  // the chunk table of the chunked scan: (feature, first slot) of every QR_WCHUNK slots of a row
-    std::vector<uint32_t> ch, first(F + 1, 0);
-    for (size_t f = 0; f < F; ++f) {
+    std::vector<uint32_t> ch, first(FL + 1, 0);
+    for (size_t f = 0; f < FL; ++f) {
       first[f] = (uint32_t)(ch.size() / 2);
       const uint32_t size = c->h_woff[f + 1] - c->h_woff[f];
       for (uint32_t t0 = 0; t0 < size; t0 += QR_WCHUNK) {
@@ -767,7 +780,7 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
         ch.push_back(t0);
       }
     }
-    first[F] = (uint32_t)(ch.size() / 2);
+    first[FL] = (uint32_t)(ch.size() / 2);
     c->wchunks = ch.size() / 2;
     QR_CHECK(c, dalloc(&c->d_wchunk, ch.size()));
     QR_CHECK(c, hipMemcpy(c->d_wchunk, ch.data(), ch.size() * 4, hipMemcpyHostToDevice));
@@ -786,9 +799,12 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
   QR_CHECK(c, dalloc(&c->d_featrec, 2 * QR_BATCH * F));
   QR_CHECK(c, dalloc(&c->d_featthr, 2 * QR_BATCH * F));
   QR_CHECK(c, dalloc(&c->d_recs_local, (size_t)2));
-  QR_CHECK(c, dalloc(&c->d_recs_all, (size_t)2));
+  QR_CHECK(c, dalloc(&c->d_recs_all, 2 * (size_t)c->world));
   c->mask_words = (N + 31) / 32;
-  QR_CHECK(c, dalloc(&c->d_mask, c->mask_words));
+  // (+ 1 word on feature-sharded contexts: the winning slot's threshold VALUE rides behind the
+  // go-left bits -- only its owner knows it, every rank's tree records need it)
+  QR_CHECK(c, dalloc(&c->d_mask, c->mask_words + 2));
+  QR_CHECK(c, hipMemset(c->d_mask, 0, (c->mask_words + 2) * 4));
   QR_CHECK(c, dalloc(&c->d_part_state, N / QR_PART_SLICE + 2));
   QR_CHECK(c, hipMemset(c->d_part_state, 0, (N / QR_PART_SLICE + 2) * 8));
   QR_CHECK(c, dalloc(&c->d_part_ss, 2 * (N / QR_PART_SLICE + 2)));
@@ -823,10 +839,12 @@ int qr_bins_read_u32(qr_ctx *c, uint32_t *out) {
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   if (c->wide) {
-    std::vector<uint32_t> h(c->N * c->F);
+    std::vector<uint32_t> h(c->N * (size_t)c->flocal);
     QR_CHECK(c, hipMemcpy(h.data(), c->d_wbins, h.size() * 4, hipMemcpyDeviceToHost));
-    for (size_t f = 0; f < c->F; ++f)
-      for (size_t d = 0; d < c->N; ++d) out[d * c->F + f] = h[f * c->N + d];
+    for (size_t f = 0; f < c->F; ++f) {
+      const int lf = c->h_gf2lf[f];   // (-1: another rank's feature)
+      for (size_t d = 0; d < c->N; ++d) out[d * c->F + f] = lf < 0 ? 0xFFFFFFFFu : h[(size_t)lf * c->N + d];
+    }
     return QR_OK;
   }
   std::vector<uint8_t> b(c->N * c->F);
@@ -1371,7 +1389,7 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
 int qr_obl_begin(qr_ctx *c, size_t depth, uint64_t minls) {
   if (!c) return QR_ERR_ARG;
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
-  if (c->wide) QR_FAIL(c, QR_ERR_UNSUPPORTED, "the phase calls use u8 bins");
+  if (c->wide) QR_FAIL(c, QR_ERR_UNSUPPORTED, "level-wise growth on sharded contexts uses u8 bins (--num-thresholds in [1, 255])");
   if (depth < 1 || ((size_t)1 << (depth + 1)) - 1 > QR_MAXNODES)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "tree depth must be in [1, 9]");
   int rc = tree_settle(c);
@@ -1456,7 +1474,7 @@ int qr_exchange_buffers(qr_ctx *c, void **recs_local, void **recs_all,
   if (recs_all) *recs_all = c->d_recs_all;
   if (rec_bytes_per_rank) *rec_bytes_per_rank = 2 * sizeof(qr_split_t);
   if (mask) *mask = c->d_mask;
-  if (mask_bytes) *mask_bytes = c->mask_words * 4;
+  if (mask_bytes) *mask_bytes = (c->mask_words + (c->wide ? 1 : 0)) * 4;  // (wide: + the threshold word)
   return QR_OK;
 }
 

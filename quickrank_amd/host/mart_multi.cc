@@ -131,11 +131,17 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
                        const std::string &metric, size_t cutoff, size_t partial_save,
                        const std::string &output_basename, int ngpus, bool feature_sharded) {
   const bool obliv = algo_ >= OBVMART;
-  if ((max_features_ != 1.0f && obliv) || nthresholds_ > 255 || nthresholds_ == 0) {
-    // (nthresholds 0 = every distinct value: fine on one GPU, where the wide path takes over
-    // when a column has more than 255 of them; the sharded contexts use u8 bins)
-    if (nthresholds_ == 0 || nthresholds_ > 255)
-      std::cerr << "!!! --gpus > 1 needs --num-thresholds in [1, 255]." << std::endl;
+  // More than 255 thresholds per feature (--num-thresholds 0 = every distinct value, the
+  // reference's default, or any value above 255): feature-block sharding grows leaf-wise trees on
+  // them (every rank holds the whole rows of its own features; round 3).  A document-sharded
+  // histogram of every distinct value would be an all-reduce of 10^7 - 10^8 cells per node, and the
+  // level-wise phase calls use u8 bins: both refused.
+  const bool many = nthresholds_ > 255 || nthresholds_ == 0;
+  if ((max_features_ != 1.0f && obliv) || (many && (!feature_sharded || obliv))) {
+    if (many)
+      std::cerr << "!!! --gpus > 1 with --num-thresholds 0 or above 255 needs --shard features and MART / "
+                   "LAMBDAMART (document sharding and oblivious trees take --num-thresholds in [1, 255])."
+                << std::endl;
     else
       std::cerr << "!!! --max-features applies to MART / LAMBDAMART." << std::endl;
     exit(EXIT_FAILURE);
@@ -222,7 +228,13 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
     if (has_valid) upload(*validation, vq0, vq1, true);
     // ---- Mart::init: thresholds + bin map
     if (feature_sharded) {
-      QRM(c, qr_bins_build(c, nthresholds_, nullptr, nullptr));
+      // (u8 bins when every feature of the rank has at most 255 thresholds, else the wide path:
+      // every rank decides for its own features -- the kernels read a flag, the protocol is the same)
+      const int brc = qr_bins_build(c, nthresholds_, nullptr, nullptr);
+      if (brc == QR_ERR_UNSUPPORTED)
+        QRM(c, qr_bins_build_wide(c, nthresholds_, nullptr, nullptr));
+      else if (brc != QR_OK)
+        die(c, "qr_bins_build");
     } else {
       QRM(c, qr_bins_stats(c, nthresholds_, &sh.vals[(size_t)r * F * (limit + 1)], &sh.cnt[(size_t)r * F],
                            &sh.mm[(size_t)r * 2 * F]));

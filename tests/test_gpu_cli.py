@@ -433,3 +433,32 @@ def test_quicklearn_gpus_features_oblivious_and_subsample(tools, tmp_path, extra
         assert np.array_equal(n1[k], n3[k]), k
     assert np.array_equal(n1["threshold"].view(np.uint32), n3["threshold"].view(np.uint32))
     assert np.allclose(n1["value"], n3["value"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("nthr", ["0", "1000"])
+def test_quicklearn_gpus_features_with_the_reference_default_thresholds(tools, tmp_path, nthr):
+    """`--num-thresholds 0` -- QuickRank's default: every distinct value a threshold -- and values
+    above 255 on the multi-GPU host (missing 2): `--shard features` takes the wide
+    bins (one rank here: the model must be the single-GPU one); `--shard docs` refuses with a
+    message that says what to use instead."""
+    x, labels, qoff = make_dataset(nq=100, docs_per_query=40, F=20, seed=75)
+    tr = str(tmp_path / "train.svml")
+    _write_svml(tr, x, labels, qoff)
+    base = ["--algo", "LAMBDAMART", "--train", tr, "--num-trees", "4", "--num-leaves", "8", "--num-thresholds", nthr,
+            "--min-leaf-support", "3"]
+    m1, m2 = str(tmp_path / "single.xml"), str(tmp_path / "multi.xml")
+    a = subprocess.run([tools["quicklearn"]] + base + ["--model-out", m1], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run([tools["quicklearn"]] + base + ["--model-out", m2, "--gpus", "1", "--shard", "features"],
+                       capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stdout + b.stderr
+    n1, w1 = _load_model(tools, m1)
+    n2, w2 = _load_model(tools, m2)
+    assert n1.shape == n2.shape and np.array_equal(w1, w2)
+    for k in ("feature", "left", "right"):
+        assert np.array_equal(n1[k], n2[k]), k
+    assert np.array_equal(n1["threshold"].view(np.uint32), n2["threshold"].view(np.uint32))
+    assert np.allclose(n1["value"], n2["value"], rtol=1e-9, atol=1e-12)
+    r = subprocess.run([tools["quicklearn"]] + base + ["--model-out", m2, "--gpus", "1", "--shard", "docs"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--shard features" in r.stderr

@@ -368,3 +368,44 @@ def test_torch_distributed_oblivious_world1(oracle_lib):
         c.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F,nthr", [(2, 33, 0), (3, 70, 1000), (2, 16, 5000)])
+def test_sharded_contexts_with_more_than_255_thresholds(world, F, nthr, oracle_lib):
+    """The reference's default `--num-thresholds 0` (every distinct value a threshold) and any
+    value above 255 on FEATURE-sharded contexts (round 3): every rank builds the wide bins of
+    its own features, the protocol is the one of the u8 path -- records all-gather, go-left mask
+    all-reduce -- and the winning slot's threshold VALUE, which only its owner holds, rides behind
+    the mask.  Trees bit-identical to the single wide context (incl. the thresholds), scores too."""
+    import torch
+    import quickrank_amd as qr
+    x, labels, qoff = make_dataset(nq=40, docs_per_query=50, F=F, seed=29, adversarial=True)
+    rng = np.random.default_rng(4)
+    lam, w = oracle_lib.lambdas(labels, rng.standard_normal(len(labels)) * 0.3, qoff)
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(nthr)
+    assert single.wide
+    single.set_pseudo(lam, w)
+    want = single.fit_tree(10, 2, True)
+    single.set_scores(np.zeros(len(labels)))
+    single.update_scores(0.1)
+    want_scores = single.get_scores()
+    single.close()
+    ctxs = []
+    for r in range(world):
+        c = qr.Context(0, rank=r, world=world)
+        c.upload(x, labels, qoff)
+        c.build_bins(nthr)
+        assert c.wide
+        c.set_pseudo(lam, w)
+        ctxs.append(c)
+    got = _sharded_fit(torch, ctxs, 10, 2)
+    for g in got:
+        assert_same_tree_records(g, want)       # both sides grow one split per step: every field exact
+        assert np.all(g["threshold"][g["feature"] >= 0] != 0.0) or nthr == 0
+    for c in ctxs:
+        c.set_scores(np.zeros(len(labels)))
+        c.update_scores(0.1)
+        assert np.array_equal(c.get_scores(), want_scores)
+        c.close()

@@ -133,9 +133,13 @@ int qr_bins_build_with(qr_ctx *ctx, const float *thr, const uint32_t *thr_size);
 /* real-valued columns (every distinct value a candidate, quicklearn.cc:103,              */
 /* mart.cc:147-158) and any --num-thresholds > 255 (mart.cc:159-169).  Same thresholds,   */
 /* same bin rule; rows are ragged: feature f has thr_size[f] slots, *cells_out in all,    */
-/* the longest *max_slots_out.  u32 bins, histograms of any row length (k_wide.hip);      */
-/* single-GPU contexts.  Everything after the bin build -- lambdas, qr_tree_fit,          */
-/* qr_oblivious_fit, score updates, metrics -- is called as on a u8 context.              */
+/* the longest *max_slots_out.  u32 bins, histograms of any row length (k_wide.hip; rows   */
+/* of up to 1152 slots take the LDS-tiled kernel).  Single-GPU contexts and feature-      */
+/* sharded ones (qr_ctx_set_shard: the rank builds its own feature range, cells_out counts */
+/* its own cells; the phase calls qr_tree_begin / decide / apply / end work unchanged, the   */
+/* go-left mask carries one more word -- qr_exchange_buffers reports the size).  Document-   */
+/* sharded contexts: QR_ERR_UNSUPPORTED.  Everything after the bin build -- lambdas,         */
+/* qr_tree_fit, qr_oblivious_fit, score updates, metrics -- is called as on a u8 context.    */
 int qr_bins_build_wide(qr_ctx *ctx, size_t nthresholds, size_t *cells_out, size_t *max_slots_out);
 /* thresholds of a binned context (u8 or wide) as ragged rows: thr_out holds              */
 /* sum(thr_size) floats, feature after feature; thr_size_out [F].  NULL = skip.           */

@@ -3754,7 +3754,10 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
   hipLaunchKernelGGL(k_obl_reset, dim3((maxnodes + 255) / 256), dim3(256), 0, c->stream,
                      c->d_tree, maxnodes, (u64)minls);
   QR_CHECK(c, hipGetLastError());
-  int rc = launch_hist_scan(c, 1);  // root histogram -> slot 0
+  // root histogram -> slot 0 (u8 bins: reduce + scan in one launch over feature-major partials,
+  // as the batched leaf-wise path does)
+  c->cur_minls = minls;
+  int rc = launch_hist_scan(c, 1, !c->wide);
   if (rc) return rc;
   const size_t lds = c->wide ? 0 : hist_lds(c);
   const unsigned pgrid = (unsigned)c->lpart_cap, hgrid = (unsigned)c->lhist_cap;

@@ -532,11 +532,12 @@ def main():
             # cannot be read inside this process): quoted with its source, and only when it
             # was collected on this very workload with the kernel as it is now
             traffic, tsrc = None, None
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_hist.json")
+            pmc = os.path.join(ROOT, "profiles", "r03_pmc_hist.json")
             if os.path.exists(pmc) and N == 1000000 and F == 136 and args.nthresholds == 255 \
                     and not args.sparse_cols:
                 traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
-                tsrc = "profiles/r02_pmc_hist.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                tsrc = ("profiles/r03_pmc_hist.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                        "collected with scripts/collect_round_profiles.sh: counters cannot be read inside the process)")
             roof = {"bound": "hbm", "kernel": "k_hist_root (root histogram build)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,

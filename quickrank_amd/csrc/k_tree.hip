@@ -1940,8 +1940,10 @@ __device__ __forceinline__ void batch_step(
            bt[3] - bt[2], sh_nj);
 #endif
   if (!writer) return;  // (workgroup-uniform) the rest publishes the new state
-  // the plans of the batch's nodes, one lane each
-  if (lane == 0 && wave < nj) qr_make_plan(sh_next[wave].small_n, nblocks, sh_blk, sh_q, &sh_plan[wave]);
+  // the plans of the batch's nodes, one lane each (wide-bin contexts, nblocks == 0: their
+  // histogram and scan launches read the jobs themselves, k_wide.hip)
+  if (lane == 0 && wave < nj && nblocks > 0)
+    qr_make_plan(sh_next[wave].small_n, nblocks, sh_blk, sh_q, &sh_plan[wave]);
   if (staged) {  // (while they compute: the node records and the heap go back)
     u64 *dst = reinterpret_cast<u64 *>(ts->nodes);
     const u64 *src = reinterpret_cast<const u64 *>(sh_nodes);
@@ -1956,12 +1958,12 @@ __device__ __forceinline__ void batch_step(
     uint32_t hw0 = 0, slot0 = 0;
     for (int j = 0; j < nj; ++j) {
       QrLevelNode *ln = &sh_next[j];
-      const uint32_t hw = (uint32_t)sh_plan[j].wg_start[nblocks];
+      const uint32_t hw = nblocks > 0 ? (uint32_t)sh_plan[j].wg_start[nblocks] : 0u;
       ln->q = sh_q;
       ln->slot_base = slot0;
       sh_hw0[j] = hw0;
       hw0 += hw;
-      slot0 += hw * (uint32_t)sh_plan[j].kmax;
+      slot0 += nblocks > 0 ? hw * (uint32_t)sh_plan[j].kmax : 0u;
     }
     sh_hw0[nj] = hw0;
     ts->l_hist_wgs = hw0;
@@ -1976,9 +1978,11 @@ __device__ __forceinline__ void batch_step(
     for (size_t i = threadIdx.x; i < (size_t)nj * sizeof(QrLevelNode) / 4; i += blockDim.x) dst[i] = src[i];
     uint32_t *pd = reinterpret_cast<uint32_t *>(plans);
     const uint32_t *ps = reinterpret_cast<const uint32_t *>(sh_plan);
-    for (size_t i = threadIdx.x; i < (size_t)nj * sizeof(QrPlan) / 4; i += blockDim.x) pd[i] = ps[i];
+    if (nblocks > 0)
+      for (size_t i = threadIdx.x; i < (size_t)nj * sizeof(QrPlan) / 4; i += blockDim.x) pd[i] = ps[i];
   }
-  for (uint32_t x = threadIdx.x; x < hist_grid; x += blockDim.x) {
+  // (wide: no per-workgroup histogram / scan descriptors)
+  for (uint32_t x = threadIdx.x; nblocks > 0 && x < hist_grid; x += blockDim.x) {
     QrHistWg d;
     d.begin = d.count = d.slot = 0;
     d.block = 0;
@@ -2005,7 +2009,7 @@ __device__ __forceinline__ void batch_step(
     }
     hist_wg[x] = d;
   }
-  for (uint32_t x = threadIdx.x; x < (uint32_t)(QR_BATCH * flocal); x += blockDim.x) {
+  for (uint32_t x = threadIdx.x; nblocks > 0 && x < (uint32_t)(QR_BATCH * flocal); x += blockDim.x) {
     const int j = (int)x / flocal, lf = (int)x - j * flocal;
     QrScanWg d;
     d.active = 0;
@@ -2357,8 +2361,9 @@ __global__ __launch_bounds__(256) void k_partition_batch(
     const QrTreeState *__restrict__ ts, const QrPartWg *__restrict__ wgs,
     const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
     uint32_t *__restrict__ order1, u64 *__restrict__ state, const double *__restrict__ lambda,
-    double *__restrict__ part_ss, const uint32_t epoch_host) {
-  // (epoch_host != 0: the granules' tag is counted on the host, as for k_decide_part)
+    double *__restrict__ part_ss, const uint32_t epoch_host, const int wide) {
+  // (epoch_host != 0: the granules' tag is counted on the host, as for k_decide_part;
+  // wide: `fm` holds u32 bins, k_wide.hip)
   const QrPartWg d = wgs[blockIdx.x];
   if (d.n == 0) return;
   PartNode pn;
@@ -2372,7 +2377,7 @@ __global__ __launch_bounds__(256) void k_partition_batch(
   gl.owner_local = d.owner_local;
   gl.thr_id = d.thr_id;
   partition_body(pn, gl, d.w, d.first, epoch_host ? (u64)epoch_host : (u64)ts->part_epoch, fm, Nfm, order0,
-                 order1, nullptr, 0, state, lambda, part_ss);
+                 order1, nullptr, wide ? 2 : 0, state, lambda, part_ss);
 }
 
 // The control step and the partition in one launch (batch_step<true>): every
@@ -2389,7 +2394,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
     const uint32_t hist_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
     const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
     uint32_t *__restrict__ order1, u64 *__restrict__ state, const double *__restrict__ lambda,
-    double *__restrict__ part_ss_out) {
+    double *__restrict__ part_ss_out, const int wide) {
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
   __shared__ int sh_nj;
@@ -2424,7 +2429,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
   gl.owner_local = ln.owner_local;
   gl.thr_id = ln.thr_id;
   partition_body(pn, gl, blockIdx.x - sh_pw0[j], sh_pw0[j], (u64)sh_epoch, fm, Nfm, order0, order1,
-                 nullptr, 0, state, lambda, part_ss_out);
+                 nullptr, wide ? 2 : 0, state, lambda, part_ss_out);
 #ifdef QR_STEP_TIMING
   if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x + 1 == sh_pw0[nj]))
     printf("decide_part wg %u of %u: control %lld partition %lld cycles (node n %u)\n", blockIdx.x, sh_pw0[nj],
@@ -3606,7 +3611,10 @@ int qr_k_tree_apply(qr_ctx *c) {
 // the launches of one growth step behind its control call: the batch's child histograms,
 // then reduce + scan
 static int launch_batch_hist_scan(qr_ctx *c, const unsigned hg, const uint32_t rootn, const uint64_t minls,
-                                  const double *pss) {
+                                  const double *pss, const QrTreeState *ts_step = nullptr) {
+  // (wide-bin contexts: k_wide.hip's kernels on the step's jobs, read from the copy of the tree
+  // state the step's control call wrote; the child sums come from the partition, `pss`)
+  if (c->wide) return qr_k_whist_scan_batch(c, ts_step ? ts_step : c->d_tree, pss);
   const size_t lds = hist_lds(c);
   if (c->prof_on && c->prof_child) {  // bench.py's roofline_child_hist: events on the launch itself
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -3680,7 +3688,9 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
   c->tree_counter += 0x9E3779B97F4A7C15ull;
   c->cur_minls = minls;
   // (no reset launch: the first k_decide_batch call starts from its arguments)
+  c->batch_root = true;
   int rc = launch_hist_scan(c, 1, true);  // root histogram -> slot 0, records -> featrec[0]
+  c->batch_root = false;
   if (rc) return rc;
   const BatchGeom g = batch_geom(c, nleaves);
   c->finish_in_decide = g.stage_nodes > 0;
@@ -3693,6 +3703,8 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
   c->tree_step = (int)steps;
   QrTreeState *const T[2] = {c->d_tree, c->d_tree2};
   double *const PSS[2] = {c->d_lpart_ss, c->d_lpart_ss2};
+  // (the partition's byte per document: the u8 feature-major copy, or the wide path's u32 bins)
+  const uint8_t *const fm = c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm;
   // calls 0 .. steps: call s < steps decides and partitions step s; call `steps` only decides
   for (size_t s = 0; s <= steps; ++s) {
     QrTreeState *tout = g.fused ? T[(steps - s) & 1] : c->d_tree;
@@ -3705,8 +3717,9 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
         return rc;
       if (s == steps) break;  // the last call only accounts for the last batch
       hipLaunchKernelGGL(k_partition_batch, dim3(g.pg), dim3(256), 0, c->stream, c->d_tree,
-                         c->d_lpart_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
-                         (u64 *)c->d_bpart_state, c->d_lambda, (double *)nullptr, ++c->bepoch);
+                         c->d_lpart_wg, fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
+                         (u64 *)c->d_bpart_state, c->d_lambda, c->wide ? c->d_lpart_ss : (double *)nullptr,
+                         ++c->bepoch, c->wide ? 1 : 0);
       QR_CHECK(c, hipGetLastError());
     } else {
       hipLaunchKernelGGL(g.small ? k_decide_part<QR_BATCH_LDS_SMALL> : k_decide_part<QR_BATCH_LDS_LARGE>,
@@ -3715,11 +3728,12 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
                          s == 0 ? 1 : 0, (int)nleaves, (u64)minls, g.stage_nodes, g.rootn, c->flocal,
                          c->d_scalars, c->d_jobsum, c->d_featrec, c->d_featthr, (uint32_t)c->F,
                          c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, g.hg,
-                         c->d_lplan, c->d_lscan_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0],
-                         c->d_order[1], (u64 *)c->d_bpart_state, c->d_lambda, (double *)nullptr);
+                         c->d_lplan, c->d_lscan_wg, fm, (uint32_t)c->N, c->d_order[0],
+                         c->d_order[1], (u64 *)c->d_bpart_state, c->d_lambda,
+                         c->wide ? PSS[s & 1] : (double *)nullptr, c->wide ? 1 : 0);
       QR_CHECK(c, hipGetLastError());
     }
-    if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls, g.fused ? PSS[s & 1] : c->d_lpart_ss))) return rc;
+    if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls, g.fused ? PSS[s & 1] : c->d_lpart_ss, tout))) return rc;
   }
   return QR_OK;
 }
@@ -3737,10 +3751,11 @@ int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_d
   int rc;
   for (size_t r = 0; r < left; ++r) {
     hipLaunchKernelGGL(k_partition_batch, dim3(g.pg), dim3(256), 0, c->stream, c->d_tree,
-                       c->d_lpart_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
-                       (u64 *)c->d_bpart_state, c->d_lambda, (double *)nullptr, ++c->bepoch);
+                       c->d_lpart_wg, c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm,
+                       (uint32_t)c->N, c->d_order[0], c->d_order[1], (u64 *)c->d_bpart_state, c->d_lambda,
+                       c->wide ? c->d_lpart_ss : (double *)nullptr, ++c->bepoch, c->wide ? 1 : 0);
     QR_CHECK(c, hipGetLastError());
-    if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls, c->d_lpart_ss))) return rc;
+    if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls, c->d_lpart_ss, c->d_tree))) return rc;
     if ((rc = launch_decide_batch(c, g, nleaves, minls, 0, c->d_tree, (const QrTreeState *)nullptr,
                                   c->d_lpart_ss, r + 1 == left ? 1 : 0)))
       return rc;

@@ -209,9 +209,9 @@ __device__ __forceinline__ WSeg w_segment(const QrTreeState *ts, const int mode,
     s.n = ts->desc.small_n;
     s.buf = ts->desc.dst_buf;
     s.slot = ts->desc.small_slot;
-  } else {                  // node j of the level
+  } else {                  // node j of the level (2) / job j of a batched growth step (3)
     const QrLevelNode &ln = ts->lnode[j];
-    s.active = !ts->obl_done && (int)j < ts->l_nodes && ln.active;
+    s.active = (mode == 3 || !ts->obl_done) && (int)j < ts->l_nodes && ln.active;
     s.begin = ln.small_begin;
     s.n = ln.small_n;
     s.buf = ln.dst_buf;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(1024) void k_whist(
 // first partial slot (in units of one document range) of node j of the launch: the ranges of
 // the active nodes before it (level-wise growth; a single node otherwise)
 __device__ __forceinline__ uint32_t w16_slot_base(const QrTreeState *ts, const int mode, const uint32_t j) {
-  if (mode != 2) return 0;
+  if (mode < 2) return 0;
   uint32_t b = 0;
   for (uint32_t k = 0; k < j; ++k) {
     const QrLevelNode &ln = ts->lnode[k];
@@ -531,26 +531,59 @@ __global__ __launch_bounds__(1024) void k_wscan(
     const size_t cells, long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal,
     const int32_t *__restrict__ lf2gf, const float *__restrict__ thr,
     const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec,
-    float *__restrict__ featthr) {
+    float *__restrict__ featthr, const double *__restrict__ part_ss = nullptr,
+    double *__restrict__ jobsum = nullptr, const u64 minls_root = ~0ull) {
+  // mode 3: job blockIdx.y of a batched growth step (k_tree.hip, k_decide_part): the split's
+  // descriptor is ts->lnode[job], the records go to featrec[2 job + which], and feature 0's
+  // workgroup adds up the partition workgroups' sums of the directly built child (jobsum)
   __shared__ long long sh_s[16];
   __shared__ uint32_t sh_c[16];
   __shared__ Best sh_b[16];
   int small_slot = 0, big_slot = -1, parent_slot = -1, small_is_left = 1;
+  const bool child = mode != 0;
+  const uint32_t job = mode == 3 ? blockIdx.y : 0u;
+  uint32_t part_first = 0, part_nwg = 0;
   if (mode == 1) {
     if (!ts->desc.active) return;
     small_slot = ts->desc.small_slot;
     big_slot = ts->desc.big_slot;
     parent_slot = ts->desc.parent_slot;
     small_is_left = ts->desc.small_is_left;
+  } else if (mode == 3) {
+    if ((int)job >= ts->l_nodes) return;
+    const QrLevelNode &ln = ts->lnode[job];
+    if (!ln.active) return;
+    small_slot = ln.small_slot;
+    big_slot = ln.big_slot;
+    parent_slot = ln.parent_slot;
+    small_is_left = ln.small_is_left;
+    part_first = ln.part_first;
+    part_nwg = (ln.end - ln.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
+    featrec += (size_t)2 * job * flocal;
+    featthr += (size_t)2 * job * flocal;
   }
   const int lf = blockIdx.x;
+  if (mode == 3 && lf == 0 && (threadIdx.x >> 6) == 15 && jobsum) {
+    // fixed-order reduction of the partition workgroups' partials (lane-strided, wave_sum)
+    double pa = 0.0, pb = 0.0;
+    for (uint32_t i = threadIdx.x & 63; i < part_nwg; i += 64) {
+      pa += part_ss[2 * (size_t)(part_first + i)];
+      pb += part_ss[2 * (size_t)(part_first + i) + 1];
+    }
+    pa = wave_sum(pa);
+    pb = wave_sum(pb);
+    if ((threadIdx.x & 63) == 0) {
+      jobsum[2 * job] = pa;
+      jobsum[2 * job + 1] = pb;
+    }
+  }
   const uint32_t base = woff[lf], size = woff[lf + 1] - base;
   long long *ss = hsum + (size_t)small_slot * cells + base;
   uint32_t *sc = hcnt + (size_t)small_slot * cells + base;
-  long long *bs = mode == 1 ? hsum + (size_t)big_slot * cells + base : nullptr;
-  uint32_t *bc = mode == 1 ? hcnt + (size_t)big_slot * cells + base : nullptr;
-  const long long *ps = mode == 1 ? hsum + (size_t)parent_slot * cells + base : nullptr;
-  const uint32_t *pc = mode == 1 ? hcnt + (size_t)parent_slot * cells + base : nullptr;
+  long long *bs = child ? hsum + (size_t)big_slot * cells + base : nullptr;
+  uint32_t *bc = child ? hcnt + (size_t)big_slot * cells + base : nullptr;
+  const long long *ps = child ? hsum + (size_t)parent_slot * cells + base : nullptr;
+  const uint32_t *pc = child ? hcnt + (size_t)parent_slot * cells + base : nullptr;
   // pass 1: prefix over the slots (exact integers: any association), sibling
   long long carry_s = 0;
   uint32_t carry_c = 0;
@@ -562,7 +595,7 @@ __global__ __launch_bounds__(1024) void k_wscan(
     if (t < size) {
       ss[t] = s;
       sc[t] = cn;
-      if (mode == 1) {
+      if (child) {
         bs[t] = ps[t] - s;
         bc[t] = pc[t] - cn;
       }
@@ -570,20 +603,22 @@ __global__ __launch_bounds__(1024) void k_wscan(
   }
   __syncthreads();
   // pass 2: gains (rt.cc:268-291) and the first maximum (rt.cc:285)
-  const u64 minls = ts->minls;
+  // (the root of a batched tree: its state is only initialised by the first control call,
+  // behind this launch -- the host passes the tree's minimum leaf support)
+  const u64 minls = (mode == 0 && minls_root != ~0ull) ? minls_root : ts->minls;
   const double inv_scale = scal->inv_scale;
   const int gf = lf2gf[lf];
   const long long S0 = carry_s;
   const uint32_t C0 = carry_c;
-  const long long S1 = mode == 1 ? ps[size - 1] - S0 : 0;
-  const uint32_t C1 = mode == 1 ? pc[size - 1] - C0 : 0u;
+  const long long S1 = child ? ps[size - 1] - S0 : 0;
+  const uint32_t C1 = child ? pc[size - 1] - C0 : 0u;
   Best a, b;
   a.score = b.score = -1.0;
   a.t = b.t = 0xFFFFFFFFu;
   for (uint32_t t = threadIdx.x; t < size; t += 1024) {  // ascending t per thread: strict > keeps the first
     const Best v = slot_gain(ss[t], sc[t], S0, C0, t, size, minls, inv_scale);
     if (v.score > a.score) a = v;
-    if (mode == 1) {
+    if (child) {
       const Best w = slot_gain(bs[t], bc[t], S1, C1, t, size, minls, inv_scale);
       if (w.score > b.score) b = w;
     }
@@ -592,7 +627,7 @@ __global__ __launch_bounds__(1024) void k_wscan(
   const int wa = mode == 0 ? 0 : (small_is_left ? 0 : 1);
   w_record(&featrec[(size_t)wa * flocal + lf], &featthr[(size_t)wa * flocal + lf], a, gf, sc, C0,
            thr + base);
-  if (mode == 1) {
+  if (child) {
     b = w_block_best(b, sh_b);
     const int wb = small_is_left ? 1 : 0;
     w_record(&featrec[(size_t)wb * flocal + lf], &featthr[(size_t)wb * flocal + lf], b, gf, bc, C1,
@@ -924,10 +959,11 @@ static bool qr_k_wide_fast(const qr_ctx *c) { return c->d_wbins16 && !getenv("QR
 // the node histograms of a launch: rows of up to QR_W16_SLOTS slots through the blocked u16
 // copy (k_whist16), longer ones feature by feature (k_whist)
 static int launch_whist(qr_ctx *c, const int mode, const uint32_t rootn, const int root_buf, const size_t maxn,
-                        const unsigned nodes) {
+                        const unsigned nodes, const QrTreeState *ts = nullptr) {
+  if (!ts) ts = c->d_tree;  // (batched growth hands over the copy of the tree state its step wrote)
   // (maxn: the most documents a node of the launch can hold)
   const unsigned chunks = (unsigned)((maxn + (qr_k_wide_fast(c) ? QR_W16_DOCS : QR_WDOCS) - 1) /
-                                     (qr_k_wide_fast(c) ? QR_W16_DOCS : QR_WDOCS)) + (mode == 2 ? 1u : 0u);
+                                     (qr_k_wide_fast(c) ? QR_W16_DOCS : QR_WDOCS)) + (mode >= 2 ? 1u : 0u);
   if (qr_k_wide_fast(c)) {
     const uint32_t slots = ((uint32_t)c->wmax + 1u) & ~1u;
     const unsigned groups = (unsigned)((c->flocal + 15) / 16);
@@ -941,16 +977,16 @@ static int launch_whist(qr_ctx *c, const int mode, const uint32_t rootn, const i
       c->wpart_cap = need;
     }
     hipLaunchKernelGGL(k_whist16, dim3(chunks, groups, nodes), dim3(1024), (size_t)slots * 128, c->stream,
-                       c->d_tree, mode, rootn, root_buf, (uint32_t)c->N, (uint32_t)c->flocal, c->d_wbins16, c->d_woff,
+                       ts, mode, rootn, root_buf, (uint32_t)c->N, (uint32_t)c->flocal, c->d_wbins16, c->d_woff,
                        c->wcells, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_wpart,
                        slots);
     QR_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(k_wreduce16, dim3((slots * 16 + 255) / 256, groups, nodes), dim3(256), 0, c->stream,
-                       c->d_tree, mode, rootn, root_buf, (uint32_t)c->flocal, c->d_woff, c->wcells,
+                       ts, mode, rootn, root_buf, (uint32_t)c->flocal, c->d_woff, c->wcells,
                        (const u64 *)c->d_wpart, c->d_hsum, c->d_hcnt, slots);
   } else {
     hipLaunchKernelGGL(k_whist, dim3(chunks, (unsigned)c->flocal, nodes), dim3(1024), whist_lds(c), c->stream,
-                       c->d_tree, mode, rootn, root_buf, (uint32_t)c->N, c->d_wbins, c->d_woff, c->wcells,
+                       ts, mode, rootn, root_buf, (uint32_t)c->N, c->d_wbins, c->d_woff, c->wcells,
                        c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, c->d_hsum, c->d_hcnt);
   }
   QR_CHECK(c, hipGetLastError());
@@ -976,7 +1012,8 @@ int qr_k_whist_scan(qr_ctx *c, int root_mode) {
   if (c->wmax <= QR_WCHUNK || no_chunks) {  // short rows: one workgroup per feature
     hipLaunchKernelGGL(k_wscan, dim3((unsigned)c->flocal), dim3(1024), 0, c->stream, c->d_tree, mode,
                        c->d_woff, c->wcells, c->d_hsum, c->d_hcnt, c->flocal, c->d_lf2gf, c->d_wthr,
-                       c->d_scalars, c->d_featrec, c->d_featthr);
+                       c->d_scalars, c->d_featrec, c->d_featthr, (const double *)nullptr, (double *)nullptr,
+                       c->batch_root ? (u64)c->cur_minls : ~0ull);
     QR_CHECK(c, hipGetLastError());
     return QR_OK;
   }
@@ -992,6 +1029,28 @@ int qr_k_whist_scan(qr_ctx *c, int root_mode) {
   hipLaunchKernelGGL(k_wscan_best, dim3((unsigned)c->flocal), dim3(64), 0, c->stream, c->d_tree, mode,
                      c->d_wchunk0, c->d_woff, c->wcells, c->d_hcnt, c->flocal, c->d_lf2gf, c->d_wthr,
                      (const Best *)c->d_wcbest, c->d_featrec, c->d_featthr);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+// batched leaf-wise growth (k_tree.hip, qr_k_tree_fit_batch): the directly built children of the
+// step's jobs (ts->lnode[0 .. QR_BATCH), the copy of the tree state the step's control call
+// wrote), their siblings and the per-feature records of both -- rows short enough for k_wscan
+bool qr_k_wide_batch_ok(const qr_ctx *c) { return c->wide && c->wmax <= QR_WCHUNK; }
+int qr_k_whist_scan_batch(qr_ctx *c, const QrTreeState *ts, const double *pss) {
+  int rc = whist_attr(c);
+  if (rc) return rc;
+  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_n : c->N);
+  if (!qr_k_wide_fast(c)) {
+    const unsigned zg = (unsigned)std::min<size_t>((c->wcells + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_wzero, dim3(zg, QR_BATCH), dim3(256), 0, c->stream, ts, 3, c->wcells, c->d_hsum,
+                       c->d_hcnt);
+    QR_CHECK(c, hipGetLastError());
+  }
+  if ((rc = launch_whist(c, 3, rootn, 2, (size_t)rootn / 2 + 1, QR_BATCH, ts))) return rc;
+  hipLaunchKernelGGL(k_wscan, dim3((unsigned)c->flocal, QR_BATCH), dim3(1024), 0, c->stream, ts, 3, c->d_woff,
+                     c->wcells, c->d_hsum, c->d_hcnt, c->flocal, c->d_lf2gf, c->d_wthr, c->d_scalars,
+                     c->d_featrec, c->d_featthr, pss, c->d_jobsum);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

@@ -720,6 +720,7 @@ int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t 
     dfree(c->d_order[0]); dfree(c->d_order[1]); dfree(c->d_featrec); dfree(c->d_featthr);
     dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask); dfree(c->d_part_state);
     dfree(c->d_part_ss); dfree(c->d_tree); dfree(c->d_leafpart); dfree(c->d_leafb);
+    dfree(c->d_tree2); dfree(c->d_lpart_ss); dfree(c->d_lpart_ss2); dfree(c->d_jobsum); dfree(c->d_bpart_state);
     c->wchunks = 0;
     c->wcells = 0;
     c->wmax = 0;
@@ -810,6 +811,15 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
   QR_CHECK(c, dalloc(&c->d_part_ss, 2 * (N / QR_PART_SLICE + 2)));
   QR_CHECK(c, dalloc(&c->d_tree, (size_t)1));
   QR_CHECK(c, hipMemset(c->d_tree, 0, sizeof(QrTreeState)));
+  if (c->world == 1) {  // batched growth (two splits per step): second copy of the tree state, job sums
+    QR_CHECK(c, dalloc(&c->d_tree2, (size_t)1));
+    QR_CHECK(c, hipMemset(c->d_tree2, 0, sizeof(QrTreeState)));
+    QR_CHECK(c, dalloc(&c->d_lpart_ss, 2 * (N / QR_PART_SLICE + QR_BATCH + 2)));
+    QR_CHECK(c, dalloc(&c->d_lpart_ss2, 2 * (N / QR_PART_SLICE + QR_BATCH + 2)));
+    QR_CHECK(c, dalloc(&c->d_jobsum, 2 * QR_BATCH));
+    QR_CHECK(c, dalloc(&c->d_bpart_state, N / QR_PART_SLICE + QR_BATCH + 2));
+    QR_CHECK(c, hipMemset(c->d_bpart_state, 0, (N / QR_PART_SLICE + QR_BATCH + 2) * 8));
+  }
   QR_CHECK(c, dalloc(&c->d_leafpart, std::max<size_t>(2 * (N / QR_SLICE + QR_MAXNODES + 4), 32 * (N / QR_SLICE + 2))));
   QR_CHECK(c, dalloc(&c->d_leafb, N + 16));
   c->wide = true;
@@ -1334,7 +1344,11 @@ int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
   }
   // up to QR_BATCH splits per step (k_decide_batch); per-node feature subsets are keyed by
   // the node's final index, which a split applied ahead of its turn does not know yet
-  if (!c->mf_k && !c->no_batch && !c->wide && nleaves >= 2 && 4 * nleaves + 1 <= QR_MAXNODES) {
+  // (wide-bin contexts take the batched path too while their rows are short enough for the
+  // one-launch scan and the provisional children's histogram slots stay small: round 3)
+  const bool wide_ok = !c->wide || (qr_k_wide_batch_ok(c) && c->d_tree2 != nullptr &&
+                                    (4 * nleaves + 1) * c->wcells * 12 <= ((size_t)4 << 30));
+  if (!c->mf_k && !c->no_batch && wide_ok && nleaves >= 2 && 4 * nleaves + 1 <= QR_MAXNODES) {
     if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
     int rc = ensure_hist_slots(c, 4 * nleaves + 1);
     if (rc) return rc;

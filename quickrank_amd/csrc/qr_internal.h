@@ -489,6 +489,7 @@ struct qr_ctx {
   size_t attr_hist_lds = 0, attr_lambda_lds = 64 * 1024, attr_whist_lds = 0;
   // profiling
   bool prof_on = false;
+  bool batch_root = false;        // the root launches of a batched tree (no reset launch ran: minls travels as an argument)
   bool finish_in_decide = false;  // the tree's last control call numbered its leaves (no k_finish launch)
   unsigned prof_stride = 1, prof_tick = 0;  // events on every prof_stride-th root launch
   bool prof_child = false;       // also time the child-histogram launches (qr_prof_enable(ctx, 2 | 1))
@@ -522,6 +523,9 @@ int qr_k_binning(qr_ctx *c);
 int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds);
 int qr_k_wide_binning(qr_ctx *c, const float *d_col);
 bool qr_k_wide_fast_rows(size_t max_slots);
+struct QrTreeState;
+bool qr_k_wide_batch_ok(const qr_ctx *c);
+int qr_k_whist_scan_batch(qr_ctx *c, const QrTreeState *ts, const double *pss);
 int qr_k_whist_scan(qr_ctx *c, int root_mode);
 #define QR_WCHUNK 8192u  /* slots per workgroup of the chunked scan of long rows (k_wide.hip) */
 int qr_k_wobl_fill(qr_ctx *c, int level);

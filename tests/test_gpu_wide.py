@@ -241,3 +241,39 @@ def test_wide_fast_rows_equal_the_general_kernel(qr, ora, case, nthr, monkeypatc
             for f in range(x.shape[1]):
                 assert np.array_equal(c1[f], c2[f]) and np.array_equal(s1[f], s2[f]), f
     assert np.array_equal(sa, sb)
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[2]])
+@pytest.mark.parametrize("nthr", [0, 1000, 5000])
+def test_wide_batched_growth_equals_one_split_per_step(qr, case, nthr, monkeypatch):
+    """Wide-bin contexts whose rows fit the one-launch scan grow leaf-wise trees two splits per
+    step with the control step inside the partition launch (round 3), like the u8 path;
+    QR_NO_BATCH=1 (read when the context is created) keeps one split per step.  Same trees --
+    both take the child sums from the partition pass here, so every field bit for bit -- and
+    the same scores."""
+    x, labels, qoff = make_dataset(**case)
+
+    def run():
+        c = qr.Context(0)
+        c.upload(x, labels, qoff)
+        c.build_bins(nthr)
+        assert c.wide
+        c.reset_scores()
+        trees = []
+        for it in range(4):
+            c.compute_lambdas("NDCG", 10)
+            trees.append(c.fit_tree(12 if it < 3 else 40, 2, True))
+            c.update_scores(0.1)
+        s = c.get_scores()
+        c.close()
+        return trees, s
+
+    monkeypatch.delenv("QR_NO_BATCH", raising=False)
+    ta, sa = run()
+    monkeypatch.setenv("QR_NO_BATCH", "1")
+    tb, sb = run()
+    for a, b in zip(ta, tb):
+        assert len(a) == len(b)
+        for k in a.dtype.names:
+            assert np.array_equal(a[k], b[k], equal_nan=(a[k].dtype.kind == "f")), k
+    assert np.array_equal(sa, sb)

@@ -1036,7 +1036,11 @@ int qr_k_whist_scan(qr_ctx *c, int root_mode) {
 // batched leaf-wise growth (k_tree.hip, qr_k_tree_fit_batch): the directly built children of the
 // step's jobs (ts->lnode[0 .. QR_BATCH), the copy of the tree state the step's control call
 // wrote), their siblings and the per-feature records of both -- rows short enough for k_wscan
-bool qr_k_wide_batch_ok(const qr_ctx *c) { return c->wide && c->wmax <= QR_WCHUNK; }
+// (only the LDS-tiled rows: with the general histogram kernel the histograms of the splits
+// applied ahead of their turn cost more than the shorter chain saves -- 4096 thresholds on the
+// MSLR-shaped set: 1.63 ms per iteration batched against 1.47 over the first trees, 1.78 / 1.78
+// over 40)
+bool qr_k_wide_batch_ok(const qr_ctx *c) { return c->wide && c->d_wbins16 != nullptr && c->wmax <= QR_WCHUNK; }
 int qr_k_whist_scan_batch(qr_ctx *c, const QrTreeState *ts, const double *pss) {
   int rc = whist_attr(c);
   if (rc) return rc;

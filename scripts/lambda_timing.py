@@ -11,9 +11,10 @@ torch.cuda.init()
 import quickrank_amd.build as b
 timing = os.path.join(b.LIBDIR, "libqr_timing.so")
 if os.environ.get("QR_LAMBDA_SECTIONS"):
+  if not os.path.exists(timing) or os.path.getmtime(timing) < max(os.path.getmtime(os.path.join(b.CSRC, s_)) for s_ in b.SOURCES):
     subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + b.FLAGS + ["-DQR_LAMBDA_TIMING", "-o", timing] +
                           [os.path.join(b.CSRC, s) for s in b.SOURCES])
-    b.LIB = timing
+  b.LIB = timing
 import quickrank_amd._capi as capi
 from bench import synth
 if os.environ.get("QR_LT_MSLR"):  # the MSLR-shaped stand-in: the kernel also prints queries of more than 1100 documents

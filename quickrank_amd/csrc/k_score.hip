@@ -10,6 +10,7 @@
 // sum runs over the trees in ensemble order with a separate multiply and add
 // (no FMA contraction), so scores are bit-identical to the reference's.
 #include <algorithm>
+#include <cstdlib>
 
 #include "qr_internal.h"
 
@@ -414,109 +415,180 @@ __global__ __launch_bounds__(NW * 64) void k_score_bin(
   if (have && doc < N) out[doc] = sum;
 }
 
-// The same walk on 4-BYTE node records, for models with u8 bins, a bin-row offset that fits
-// 16 bits and trees of at most 255 nodes (any leaf-wise tree of up to 128 leaves trained with
-// up to 255 thresholds): {row offset : 16, slot : 8, left child : 8}, the nodes of a tree in
-// RIGHT-first preorder so that the right child of node c is node c + 1 and only the left one
-// needs naming; a leaf is {0, 255, itself} (every bin is <= 255: the walk stays).  Half the
-// LDS bytes per step of the 8-byte record, and the same five instructions (node address, bin
-// address and compare through SDWA sub-word operands, c + 1, pick).  There is no leaf
-// test at all: a group of trees runs for as many steps as its deepest tree has levels (known
-// from the model), finished chains idle on their leaves.  Leaf values sit at the leaves'
-// own positions (`cleaves` is [tree][NN]).
-template <int NW>
+// LDS reads at an integer address (address space 3; the host pass of hipcc only parses these).
+// A constant added to the address ends up in the instruction's offset field.
+__device__ __forceinline__ uint32_t lds_read_u32(const uint32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *(const __attribute__((address_space(3))) uint32_t *)(a);
+#else
+  return a;
+#endif
+}
+__device__ __forceinline__ uint32_t lds_read_u8(const uint32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *(const __attribute__((address_space(3))) uint8_t *)(a);
+#else
+  return a;
+#endif
+}
+__device__ __forceinline__ double lds_read_f64(const uint32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *(const __attribute__((address_space(3))) double *)(a);
+#else
+  return (double)a;
+#endif
+}
+__device__ __forceinline__ uint32_t lds_address(const void *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)(size_t)((const __attribute__((address_space(3))) char *)p);
+#else
+  return 0u;
+#endif
+}
+
+// k_score_p4: the same walk on 4-BYTE node records, for models with u8 bins, a bin-row offset
+// that fits 16 bits and trees of at most 255 nodes (any leaf-wise tree of up to 128 leaves
+// trained with up to 255 thresholds).  Round 3 rebuilt it around what the counters of the
+// round-2 version said (config 5: LDS array 35 % busy, VALU 39 %, the SIMDs' issue slots 65 %,
+// waves parked on `s_waitcnt` 57 % of their cycles: the walk is bound by the INSTRUCTIONS of a
+// node visit, then by the bank conflicts of its two LDS reads):
+//  * record = {row offset : 16, 255 - slot : 8, left child : 8}, the nodes of a tree in LEVEL
+//    order with siblings adjacent (right = left + 1).  `w = record + (bin << 16)`: the byte sum
+//    carries into the child field exactly when bin > slot, so BYTE 3 of w is the next node -- no
+//    compare, no select, no VCC (an SDWA compare that writes VCC costs two wait states before
+//    its reader).  A leaf is {0, 0, itself}: nothing carries, the walk stays.  There is no leaf
+//    test: a group of eight trees runs for as many steps as its deepest tree has levels (one
+//    byte per group, from the model); finished chains idle on their leaves.
+//  * the tiles of a batch (16 trees x NNP records, NNP = 128 or 256) sit at the START of the
+//    workgroup's LDS, so a tile's base is an immediate of the ds_read: a visit is
+//    `ds_read_b32 record, [4 * node] offset:tile` -> `row + lane base` -> `ds_read_u8` ->
+//    `w = (bin << 16) + record` -> `4 * node = byte 3 of w << 2`: three vector instructions
+//    (five in round 2), both groups of a batch unrolled.
+//  * both reads are laid out for the banks (ds_read_b32 / ds_read_u8: two groups of 32 lanes,
+//    bank = (address / 4) mod 32, MI355X_MICROARCH.md "LDS"): a wave's chains move in lockstep,
+//    one level per step, and the nodes of a level are consecutive dwords -- up to 32 nodes of a
+//    level never share a bank (depth-first order scatters a level over the tree's dwords: ~3
+//    addresses per bank at the deep levels); the bins of a wave's 64 documents sit as
+//    [feature / 4][lane][feature % 4], one dword per lane and feature quad, so lane l always
+//    reads bank l mod 32 whatever feature its node tests ([feature][lane] bytes put the four
+//    lanes of a quad on bank 16 * feature + quad: features of one parity collide).  A node's
+//    row offset is (feature / 4) * 256 + feature % 4.
+//  * leaf values sit at the leaves' own positions, already multiplied by the tree's weight
+//    (the same f64 product `tree(x) * weight` of ensemble.cc:111-118, done once per model, not
+//    once per document), and are added strictly in tree order.
+// The model tables are padded to whole batches ([T16][NNP]); `ntrees` says how many are real.
+#define P4_TB 16
+template <int NNP, int G>
+__device__ __forceinline__ void p4_walk_group(const uint32_t mybase, const uint32_t steps, const int cnt,
+                                              double &sum) {
+  constexpr uint32_t TILE = NNP * 4, LV0 = P4_TB * TILE, LVT = NNP * 8;
+  uint32_t a[8];  // 4 * node of each chain
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0;
+  for (uint32_t k = 0; k < steps; ++k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t nd = lds_read_u32(a[j] + (G * 8 + j) * TILE);
+      const uint32_t bv = lds_read_u8(mybase + (nd & 0xffffu));
+      const uint32_t w = nd + (bv << 16);
+      // a = (w >> 24) << 2
+      asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
+          : "=v"(a[j])
+          : "v"(w));
+    }
+  }
+  if (cnt >= 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum = sum + lds_read_f64(a[j] * 2 + (LV0 + (G * 8 + j) * LVT));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < cnt) sum = sum + lds_read_f64(a[j] * 2 + (LV0 + (G * 8 + j) * LVT));
+  }
+}
+
+template <int NW, int NNP>
 __global__ __launch_bounds__(NW * 64) void k_score_p4(
     const uint8_t *__restrict__ bins, const uint32_t N, const uint32_t F,
-    const uint32_t *__restrict__ cnodes, const double *__restrict__ cleaves,
-    const uint8_t *__restrict__ depths, const double *__restrict__ weights, const uint32_t ntrees,
-    const uint32_t NN, const uint32_t tbatch, double *__restrict__ out) {
+    const uint4 *__restrict__ cnodes, const uint4 *__restrict__ cleaves,
+    const uint8_t *__restrict__ gdepth, const uint32_t ntrees, double *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr uint32_t TILE = NNP * 4, LV0 = P4_TB * TILE, LVT = NNP * 8, DOCS0 = LV0 + P4_TB * LVT;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t doc_bytes = ((size_t)F * 64 + 15) & ~(size_t)15;
-  uint8_t *mybins = reinterpret_cast<uint8_t *>(smem + wave * doc_bytes);
-  char *tb = smem + NW * doc_bytes;
-  double *lv = reinterpret_cast<double *>(tb);                              // [tbatch][NN]
-  double *lw = lv + (size_t)tbatch * NN;                                    // [tbatch]
-  uint32_t *ln = reinterpret_cast<uint32_t *>(lw + tbatch);                 // [tbatch][NN]
-  uint8_t *ld = reinterpret_cast<uint8_t *>(ln + (size_t)tbatch * NN);      // [tbatch]
+  const uint32_t FQ = (F + 3) / 4;  // feature quads
+  const uint32_t doc_bytes = FQ * 256;
+  // the tiles' addresses are instruction immediates: the dynamic LDS must start at 0 (it does
+  // in a kernel without static __shared__ variables)
+  {
+    uint32_t sb = lds_address(smem);
+    asm volatile("" : "+v"(sb));  // (the address of a variable never compares equal to 0 at compile time)
+    if (sb != 0) __builtin_trap();
+  }
   const uint32_t nblocks = (N + 63) / 64;
   const uint32_t blk = blockIdx.x * NW + wave;
   const bool have = blk < nblocks;
   if (have) {
-    const uint4 *s4 = reinterpret_cast<const uint4 *>(bins + (size_t)blk * 64 * F);
-    uint4 *d4 = reinterpret_cast<uint4 *>(mybins);
-    const uint32_t n16 = (uint32_t)(F * 64 / 16);
-    for (uint32_t i = lane; i < n16; i += 64) d4[i] = s4[i];
+    // [feature][lane] bytes (k_doc_bins) -> [feature / 4][lane] dwords: once per wave and model
+    const uint8_t *src = bins + (size_t)blk * 64 * F + lane;
+    uint32_t *d = reinterpret_cast<uint32_t *>(smem + DOCS0 + wave * doc_bytes) + lane;
+    const uint32_t full = F / 4;
+#pragma unroll 4
+    for (uint32_t q = 0; q < full; ++q) {
+      const uint8_t *s4 = src + (size_t)q * 256;
+      d[q * 64] = (uint32_t)s4[0] | ((uint32_t)s4[64] << 8) | ((uint32_t)s4[128] << 16) | ((uint32_t)s4[192] << 24);
+    }
+    if (full < FQ) {
+      uint32_t w = 0;
+      for (uint32_t f = full * 4; f < F; ++f) w |= (uint32_t)src[(size_t)f * 64] << (8 * (f & 3));
+      d[full * 64] = w;
+    }
   }
   const uint32_t doc = blk * 64 + lane;
-  const uint8_t *mybytes = mybins + lane;
+  const uint32_t mybase = DOCS0 + wave * doc_bytes + lane * 4;
+  uint4 *lds4 = reinterpret_cast<uint4 *>(smem);
   double sum = 0.0;
-  for (uint32_t t0 = 0; t0 < ntrees; t0 += tbatch) {
-    const uint32_t nb = t0 + tbatch <= ntrees ? tbatch : ntrees - t0;
+  for (uint32_t t0 = 0; t0 < ntrees; t0 += P4_TB) {
+    const uint32_t d01 = *reinterpret_cast<const uint16_t *>(gdepth + (t0 >> 3));  // two groups' depths
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nb * NN; i += NW * 64) {
-      lv[i] = cleaves[(size_t)t0 * NN + i];
-      ln[i] = cnodes[(size_t)t0 * NN + i];
-    }
-    for (uint32_t i = threadIdx.x; i < nb; i += NW * 64) {
-      lw[i] = weights[t0 + i];
-      ld[i] = depths[t0 + i];
-    }
+    // one batch = P4_TB * TILE bytes of records, then P4_TB * LVT bytes of leaf values
+    const uint4 *sn = cnodes + (size_t)t0 * (TILE / 16);
+    for (uint32_t i = threadIdx.x; i < LV0 / 16; i += NW * 64) lds4[i] = sn[i];
+    const uint4 *sl = cleaves + (size_t)t0 * (LVT / 16);
+    for (uint32_t i = threadIdx.x; i < P4_TB * LVT / 16; i += NW * 64) lds4[LV0 / 16 + i] = sl[i];
     __syncthreads();
     if (!have) continue;
-    auto step = [&](const uint32_t c, const uint32_t *nodes) -> uint32_t {
-      const uint32_t nd = nodes[c];
-      const uint32_t bv = mybytes[nd & 0xffffu];
-      return bv <= ((nd >> 16) & 0xffu) ? (nd >> 24) : c + 1;
-    };
-    uint32_t t = 0;
-    for (; t + 8 <= nb; t += 8) {
-      uint32_t c[8];
-      const uint32_t *nn[8];
-      uint32_t steps = 0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        c[j] = 0;
-        nn[j] = ln + (size_t)(t + j) * NN;
-        steps = steps > ld[t + j] ? steps : (uint32_t)ld[t + j];
-      }
-      for (uint32_t k = 0; k < steps; ++k) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) c[j] = step(c[j], nn[j]);
-      }
-      const double *l0 = lv + (size_t)t * NN;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const double v = l0[j * NN + c[j]] * lw[t + j];
-        sum = sum + v;
-      }
-    }
-    for (; t < nb; ++t) {
-      uint32_t c0 = 0;
-      const uint32_t *n0 = ln + (size_t)t * NN;
-      for (uint32_t k = 0; k < ld[t]; ++k) c0 = step(c0, n0);
-      const double v0 = lv[(size_t)t * NN + c0] * lw[t];
-      sum = sum + v0;
-    }
+    const int left = (int)(ntrees - t0);
+    p4_walk_group<NNP, 0>(mybase, d01 & 0xffu, left, sum);
+    if (left > 8) p4_walk_group<NNP, 1>(mybase, d01 >> 8, left - 8, sum);
   }
   if (have && doc < N) out[doc] = sum;
 }
 
-template <int NW>
-static int launch_p4_nw(qr_ctx *c, size_t N, double *d_out, size_t tbatch) {
+template <int NW, int NNP>
+static int launch_p4_nw(qr_ctx *c, size_t N, double *d_out) {
   const size_t F = c->sb_F;
-  const size_t doc_bytes = (F * 64 + 15) & ~(size_t)15;
-  const size_t per_tree = c->p4_NN * 12 + 8 + 1;
-  const size_t lds = NW * doc_bytes + tbatch * per_tree + 64;
+  const size_t doc_bytes = ((F + 3) / 4) * 256;
+  const size_t lds = NW * doc_bytes + (size_t)P4_TB * NNP * 12;
   const size_t nblk = (N + 63) / 64;
-  QR_CHECK(c, hipFuncSetAttribute((const void *)k_score_p4<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  QR_CHECK(c, hipFuncSetAttribute((const void *)k_score_p4<NW, NNP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
-  hipLaunchKernelGGL((k_score_p4<NW>), dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds, c->stream,
-                     (const uint8_t *)c->d_sb_bins, (uint32_t)N, (uint32_t)F, c->d_p4_nodes, c->d_p4_leaves,
-                     c->d_p4_depth, c->d_ens_w, (uint32_t)c->ens_trees, (uint32_t)c->p4_NN, (uint32_t)tbatch,
-                     d_out);
+  hipLaunchKernelGGL((k_score_p4<NW, NNP>), dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds, c->stream,
+                     (const uint8_t *)c->d_sb_bins, (uint32_t)N, (uint32_t)F, (const uint4 *)c->d_p4_nodes,
+                     (const uint4 *)c->d_p4_leaves, c->d_p4_depth, (uint32_t)c->ens_trees, d_out);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
+}
+
+template <int NNP>
+static int launch_p4(qr_ctx *c, size_t N, double *d_out, size_t nw) {
+  switch (nw) {
+    case 16: return launch_p4_nw<16, NNP>(c, N, d_out);
+    case 12: return launch_p4_nw<12, NNP>(c, N, d_out);
+    case 10: return launch_p4_nw<10, NNP>(c, N, d_out);
+    case 8: return launch_p4_nw<8, NNP>(c, N, d_out);
+    case 6: return launch_p4_nw<6, NNP>(c, N, d_out);
+    default: return launch_p4_nw<4, NNP>(c, N, d_out);
+  }
 }
 
 template <typename BT, int NW>
@@ -580,26 +652,14 @@ static int launch_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, 
                      c->d_sb_thr, c->d_sb_thr_cnt, (uint32_t)c->sb_tmax, lds_thr, (BT *)c->d_sb_bins, 0u);
   QR_CHECK(c, hipGetLastError());
   if (sizeof(BT) == 1 && c->p4_ready) {  // 4-byte node records (k_score_p4)
-    const size_t per4 = c->p4_NN * 12 + 8 + 1;
-    // waves per workgroup first (8 -> 10 document blocks: 257 -> 249 ms at config 5), then the
-    // tree batch (16 trees per barrier pair at least: 8 cost more in barriers than they free)
-    auto waves_for = [&](size_t tb) -> size_t {
-      if (4 * doc_bytes + tb * per4 + 64 > budget) return 0;
-      const size_t n = (budget - tb * per4 - 64) / doc_bytes;
-      return n >= 16 ? 16 : n >= 12 ? 12 : n >= 10 ? 10 : n >= 8 ? 8 : n >= 6 ? 6 : 4;
-    };
-    size_t tb4 = waves_for(16) > waves_for(32) ? 16 : 32;
-    while (tb4 > 8 && waves_for(tb4) == 0) tb4 -= 8;
-    if (waves_for(tb4)) {
-      const size_t nw4 = waves_for(tb4);
-      switch (nw4) {
-        case 16: return launch_p4_nw<16>(c, N, d_out, tb4);
-        case 12: return launch_p4_nw<12>(c, N, d_out, tb4);
-        case 10: return launch_p4_nw<10>(c, N, d_out, tb4);
-        case 8: return launch_p4_nw<8>(c, N, d_out, tb4);
-        case 6: return launch_p4_nw<6>(c, N, d_out, tb4);
-        default: return launch_p4_nw<4>(c, N, d_out, tb4);
-      }
+    // as many 64-document blocks per workgroup as the LDS holds next to one batch of tiles
+    // (6 / 8 / 10 waves per CU: 353 / 257 / 249 ms at config 5 in round 2)
+    const size_t doc4 = ((F + 3) / 4) * 256;
+    const size_t tiles = (size_t)P4_TB * c->p4_NNP * 12;
+    if (tiles + 4 * doc4 <= budget) {
+      const size_t n = (budget - tiles) / doc4;
+      const size_t nw4 = n >= 16 ? 16 : n >= 12 ? 12 : n >= 10 ? 10 : n >= 8 ? 8 : n >= 6 ? 6 : 4;
+      return c->p4_NNP == 128 ? launch_p4<128>(c, N, d_out, nw4) : launch_p4<256>(c, N, d_out, nw4);
     }
   }
   switch (nw) {

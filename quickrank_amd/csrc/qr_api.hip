@@ -1624,7 +1624,8 @@ int qr_ranks_read(qr_ctx *c, uint32_t *out) {
 // ---------------------------------------------------------------------------
 // Compact binned form of the model for k_score_bin: per-feature sorted distinct
 // thresholds, internal nodes as {feature, threshold index, children}, leaves apart.
-static int build_binned_model(qr_ctx *c, const qr_node_t *nodes, size_t ntrees, size_t max_nodes) {
+static int build_binned_model(qr_ctx *c, const qr_node_t *nodes, size_t ntrees, size_t max_nodes,
+                              const double *weights) {
   c->sb_ready = false;
   c->p4_ready = false;
   int maxf = -1;
@@ -1729,53 +1730,54 @@ static int build_binned_model(qr_ctx *c, const qr_node_t *nodes, size_t ntrees, 
   dfree(c->d_p4_nodes); dfree(c->d_p4_leaves); dfree(c->d_p4_depth);
   size_t NN4 = 0;
   for (size_t t = 0; t < ntrees; ++t) NN4 = std::max(NN4, order[t].size());
-  if (tmax <= 255 && (F - 1) * 64 <= 0xffff && NN4 <= 255) {
-    std::vector<uint32_t> w(ntrees * NN4, 0x00ff0000u);  // unused entries: harmless leaves of node 0
-    std::vector<double> lv(ntrees * NN4, 0.0);
-    std::vector<uint8_t> dep(ntrees, 0);
-    std::vector<int> pos(max_nodes), stack, dstack;
+  if (tmax <= 255 && ((F - 1) / 4) * 256 + 3 <= 0xffff && NN4 <= 255) {
+    const size_t NNP = NN4 <= 128 ? 128 : 256, T16 = (ntrees + 15) / 16 * 16;
+    std::vector<uint32_t> w(T16 * NNP, 0u);  // unused entries and padding trees: {0, 0, node 0}
+    std::vector<double> lv(T16 * NNP, 0.0);
+    std::vector<uint8_t> dep(T16 / 8, 0);
+    std::vector<int> pos(max_nodes), seq, dseq;
     for (size_t t = 0; t < ntrees; ++t) {
       const qr_node_t *n = nodes + t * max_nodes;
-      // right-first preorder: the right child of the node at position p sits at p + 1
-      stack.assign(1, 0);
-      dstack.assign(1, 0);
-      std::vector<int> seq;
+      // level order, siblings adjacent: the right child sits at the left one's position + 1 and
+      // the nodes of a level are consecutive dwords (one bank each)
+      seq.assign(1, 0);
+      dseq.assign(1, 0);
       int maxd = 0;
-      while (!stack.empty()) {
-        const int i = stack.back(), d = dstack.back();
-        stack.pop_back();
-        dstack.pop_back();
-        pos[i] = (int)seq.size();
-        seq.push_back(i);
+      pos[0] = 0;
+      for (size_t h = 0; h < seq.size(); ++h) {
+        const int i = seq[h], d = dseq[h];
         if (n[i].feature >= 0) {
           maxd = std::max(maxd, d + 1);
-          stack.push_back(n[i].left);
-          dstack.push_back(d + 1);
-          stack.push_back(n[i].right);  // popped first: position pos[i] + 1
-          dstack.push_back(d + 1);
+          pos[n[i].left] = (int)seq.size();
+          seq.push_back(n[i].left);
+          dseq.push_back(d + 1);
+          pos[n[i].right] = (int)seq.size();
+          seq.push_back(n[i].right);
+          dseq.push_back(d + 1);
         }
       }
       if (maxd > 255) return QR_OK;  // (cannot happen with <= 255 nodes)
-      dep[t] = (uint8_t)maxd;
+      dep[t / 8] = std::max(dep[t / 8], (uint8_t)maxd);
       for (int i : seq) {
-        const size_t at = t * NN4 + (size_t)pos[i];
+        const size_t at = t * NNP + (size_t)pos[i];
         if (n[i].feature >= 0) {
           const auto &v = thr[n[i].feature];
           const uint32_t kb = (uint32_t)(std::lower_bound(v.begin(), v.end(), n[i].threshold) - v.begin());
-          w[at] = (uint32_t)((size_t)n[i].feature * 64) | (kb << 16) | ((uint32_t)pos[n[i].left] << 24);
+          const uint32_t row = (uint32_t)(n[i].feature / 4) * 256u + (uint32_t)(n[i].feature % 4);
+          w[at] = row | ((255u - kb) << 16) | ((uint32_t)pos[n[i].left] << 24);
         } else {
-          w[at] = (255u << 16) | ((uint32_t)pos[i] << 24);
-          lv[at] = n[i].value;
+          w[at] = (uint32_t)pos[i] << 24;
+          lv[at] = n[i].value * weights[t];  // ensemble.cc:111-118's product, once per model
         }
       }
     }
     QR_CHECK(c, dalloc(&c->d_p4_nodes, w.size()));
     QR_CHECK(c, dalloc(&c->d_p4_leaves, lv.size()));
-    QR_CHECK(c, dalloc(&c->d_p4_depth, dep.size()));
+    QR_CHECK(c, dalloc(&c->d_p4_depth, dep.size() + 2));
     QR_CHECK(c, hipMemcpy(c->d_p4_nodes, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     QR_CHECK(c, hipMemcpy(c->d_p4_leaves, lv.data(), lv.size() * 8, hipMemcpyHostToDevice));
     QR_CHECK(c, hipMemcpy(c->d_p4_depth, dep.data(), dep.size(), hipMemcpyHostToDevice));
-    c->p4_NN = NN4;
+    c->p4_NNP = NNP;
     c->p4_ready = true;
   }
   return QR_OK;
@@ -1796,7 +1798,7 @@ int qr_ensemble_upload(qr_ctx *c, const qr_node_t *nodes, size_t ntrees,
   c->ens_maxnodes = max_nodes;
   c->ens_maxf = -1;
   for (size_t i = 0; i < ntrees * max_nodes; ++i) c->ens_maxf = std::max(c->ens_maxf, (int)nodes[i].feature);
-  return build_binned_model(c, nodes, ntrees, max_nodes);
+  return build_binned_model(c, nodes, ntrees, max_nodes, weights);
 }
 
 // features with index >= sb_F are never tested by the model, so a wider matrix

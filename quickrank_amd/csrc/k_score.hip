@@ -476,8 +476,10 @@ __device__ __forceinline__ uint32_t lds_address(const void *p) {
 //  * leaf values sit at the leaves' own positions, already multiplied by the tree's weight
 //    (the same f64 product `tree(x) * weight` of ensemble.cc:111-118, done once per model, not
 //    once per document), and are added strictly in tree order.
-// The model tables are padded to whole batches ([T16][NNP]); `ntrees` says how many are real.
+// The model is stored batch by batch, as the LDS image of a batch (16 tiles of records, then the
+// 16 tiles of leaf values), padded to whole batches; `ntrees` says how many trees are real.
 #define P4_TB 16
+typedef uint32_t p4_u32x4 __attribute__((ext_vector_type(4)));  // (arrays of it stay in registers)
 template <int NNP, int G>
 __device__ __forceinline__ void p4_walk_group(const uint32_t mybase, const uint32_t steps, const int cnt,
                                               double &sum) {
@@ -510,10 +512,12 @@ __device__ __forceinline__ void p4_walk_group(const uint32_t mybase, const uint3
 template <int NW, int NNP>
 __global__ __launch_bounds__(NW * 64) void k_score_p4(
     const uint8_t *__restrict__ bins, const uint32_t N, const uint32_t F,
-    const uint4 *__restrict__ cnodes, const uint4 *__restrict__ cleaves,
-    const uint8_t *__restrict__ gdepth, const uint32_t ntrees, double *__restrict__ out) {
+    const p4_u32x4 *__restrict__ batches, const uint32_t *__restrict__ gdepth32, const uint32_t ntrees,
+    double *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr uint32_t TILE = NNP * 4, LV0 = P4_TB * TILE, LVT = NNP * 8, DOCS0 = LV0 + P4_TB * LVT;
+  constexpr uint32_t B16 = DOCS0 / 16;                          // 16-byte pieces of one batch
+  constexpr uint32_t PF = (B16 + NW * 64 - 1) / (NW * 64);      // ... per thread
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t FQ = (F + 3) / 4;  // feature quads
   const uint32_t doc_bytes = FQ * 256;
@@ -524,6 +528,19 @@ __global__ __launch_bounds__(NW * 64) void k_score_p4(
     asm volatile("" : "+v"(sb));  // (the address of a variable never compares equal to 0 at compile time)
     if (sb != 0) __builtin_trap();
   }
+  // The next batch travels from memory into registers while this one is walked: a workgroup has
+  // the CU to itself (its documents fill the LDS), so nothing else would hide that latency.
+  // (every thread loads PF pieces, the last ones clamped to the batch's end: no predicated
+  // register writes, the pieces stay in registers)
+  p4_u32x4 pf[PF];
+  uint32_t pfi[PF];
+#pragma unroll
+  for (uint32_t r = 0; r < PF; ++r) {
+    const uint32_t i = threadIdx.x + r * NW * 64;
+    pfi[r] = i < B16 ? i : B16 - 1;
+  }
+#pragma unroll
+  for (uint32_t r = 0; r < PF; ++r) pf[r] = batches[pfi[r]];
   const uint32_t nblocks = (N + 63) / 64;
   const uint32_t blk = blockIdx.x * NW + wave;
   const bool have = blk < nblocks;
@@ -545,17 +562,20 @@ __global__ __launch_bounds__(NW * 64) void k_score_p4(
   }
   const uint32_t doc = blk * 64 + lane;
   const uint32_t mybase = DOCS0 + wave * doc_bytes + lane * 4;
-  uint4 *lds4 = reinterpret_cast<uint4 *>(smem);
+  p4_u32x4 *lds4 = reinterpret_cast<p4_u32x4 *>(smem);
   double sum = 0.0;
   for (uint32_t t0 = 0; t0 < ntrees; t0 += P4_TB) {
-    const uint32_t d01 = *reinterpret_cast<const uint16_t *>(gdepth + (t0 >> 3));  // two groups' depths
+    // two groups' depths (t0 is a multiple of 16: the pair never straddles a dword)
+    const uint32_t d01 = (gdepth32[t0 >> 5] >> ((t0 & 16u) ? 16 : 0)) & 0xffffu;
+    __syncthreads();  // every wave is done with the previous batch's tiles
+#pragma unroll
+    for (uint32_t r = 0; r < PF; ++r) lds4[pfi[r]] = pf[r];  // (clamped pieces rewrite the last one)
     __syncthreads();
-    // one batch = P4_TB * TILE bytes of records, then P4_TB * LVT bytes of leaf values
-    const uint4 *sn = cnodes + (size_t)t0 * (TILE / 16);
-    for (uint32_t i = threadIdx.x; i < LV0 / 16; i += NW * 64) lds4[i] = sn[i];
-    const uint4 *sl = cleaves + (size_t)t0 * (LVT / 16);
-    for (uint32_t i = threadIdx.x; i < P4_TB * LVT / 16; i += NW * 64) lds4[LV0 / 16 + i] = sl[i];
-    __syncthreads();
+    if (t0 + P4_TB < ntrees) {
+      const p4_u32x4 *src = batches + (size_t)(t0 / P4_TB + 1) * B16;
+#pragma unroll
+      for (uint32_t r = 0; r < PF; ++r) pf[r] = src[pfi[r]];
+    }
     if (!have) continue;
     const int left = (int)(ntrees - t0);
     p4_walk_group<NNP, 0>(mybase, d01 & 0xffu, left, sum);
@@ -573,8 +593,8 @@ static int launch_p4_nw(qr_ctx *c, size_t N, double *d_out) {
   QR_CHECK(c, hipFuncSetAttribute((const void *)k_score_p4<NW, NNP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
   hipLaunchKernelGGL((k_score_p4<NW, NNP>), dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds, c->stream,
-                     (const uint8_t *)c->d_sb_bins, (uint32_t)N, (uint32_t)F, (const uint4 *)c->d_p4_nodes,
-                     (const uint4 *)c->d_p4_leaves, c->d_p4_depth, (uint32_t)c->ens_trees, d_out);
+                     (const uint8_t *)c->d_sb_bins, (uint32_t)N, (uint32_t)F, (const p4_u32x4 *)c->d_p4_batches,
+                     (const uint32_t *)c->d_p4_depth, (uint32_t)c->ens_trees, d_out);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

@@ -213,7 +213,7 @@ void qr_ctx_destroy(qr_ctx *c) {
   if (c->d_sb_nodes) (void)hipFree(c->d_sb_nodes);
   if (c->d_sb_bins) (void)hipFree(c->d_sb_bins);
   dfree(c->d_sb_leaves); dfree(c->d_sb_root); dfree(c->d_sb_thr); dfree(c->d_sb_thr_cnt);
-  dfree(c->d_p4_nodes); dfree(c->d_p4_leaves); dfree(c->d_p4_depth);
+  dfree(c->d_p4_batches); dfree(c->d_p4_depth);
   for (auto &p : c->prof_events) {
     (void)hipEventDestroy(p.first);
     (void)hipEventDestroy(p.second);
@@ -1727,7 +1727,7 @@ static int build_binned_model(qr_ctx *c, const qr_node_t *nodes, size_t ntrees, 
   c->sb_ready = true;
   // ---- the 4-byte records of k_score_p4, when the model allows them
   c->p4_ready = false;
-  dfree(c->d_p4_nodes); dfree(c->d_p4_leaves); dfree(c->d_p4_depth);
+  dfree(c->d_p4_batches); dfree(c->d_p4_depth);
   size_t NN4 = 0;
   for (size_t t = 0; t < ntrees; ++t) NN4 = std::max(NN4, order[t].size());
   if (tmax <= 255 && ((F - 1) / 4) * 256 + 3 <= 0xffff && NN4 <= 255) {
@@ -1771,11 +1771,16 @@ static int build_binned_model(qr_ctx *c, const qr_node_t *nodes, size_t ntrees, 
         }
       }
     }
-    QR_CHECK(c, dalloc(&c->d_p4_nodes, w.size()));
-    QR_CHECK(c, dalloc(&c->d_p4_leaves, lv.size()));
-    QR_CHECK(c, dalloc(&c->d_p4_depth, dep.size() + 2));
-    QR_CHECK(c, hipMemcpy(c->d_p4_nodes, w.data(), w.size() * 4, hipMemcpyHostToDevice));
-    QR_CHECK(c, hipMemcpy(c->d_p4_leaves, lv.data(), lv.size() * 8, hipMemcpyHostToDevice));
+    // batch by batch: the 16 record tiles, then the 16 value tiles (k_score_p4's LDS image)
+    const size_t bdw = 16 * NNP * 3;  // dwords per batch
+    std::vector<uint32_t> img(T16 / 16 * bdw);
+    for (size_t b = 0; b < T16 / 16; ++b) {
+      std::memcpy(&img[b * bdw], &w[b * 16 * NNP], 16 * NNP * 4);
+      std::memcpy(&img[b * bdw + 16 * NNP], &lv[b * 16 * NNP], 16 * NNP * 8);
+    }
+    QR_CHECK(c, dalloc(&c->d_p4_batches, img.size()));
+    QR_CHECK(c, dalloc(&c->d_p4_depth, dep.size() + 4));  // (read as dwords)
+    QR_CHECK(c, hipMemcpy(c->d_p4_batches, img.data(), img.size() * 4, hipMemcpyHostToDevice));
     QR_CHECK(c, hipMemcpy(c->d_p4_depth, dep.data(), dep.size(), hipMemcpyHostToDevice));
     c->p4_NNP = NNP;
     c->p4_ready = true;

@@ -462,11 +462,12 @@ struct qr_ctx {
   size_t sb_F = 0, sb_NI = 0, sb_NL = 0, sb_tmax = 0, sb_bins_bytes = 0;
   bool sb_self = false;          // the node array holds the leaves too (self-looping), k_score.hip
   // 4-byte node records (k_score_p4): u8 bins, trees of <= 255 nodes, row offsets < 65536;
-  // tables padded to whole batches of 16 trees, [T16][NNP] with NNP = 128 or 256
+  // NNP = 128 or 256 entries per tree
   bool p4_ready = false;
   size_t p4_NNP = 0;
-  uint32_t *d_p4_nodes = nullptr;   // {row offset : 16, 255 - slot : 8, left child : 8}, level order
-  double *d_p4_leaves = nullptr;    // leaf value * tree weight at the leaf's position
+  // per batch of 16 trees its LDS image: [16][NNP] records {row offset : 16, 255 - slot : 8, left
+  // child : 8} in level order, then [16][NNP] f64 leaf value * tree weight at the leaf's position
+  uint32_t *d_p4_batches = nullptr;
   uint8_t *d_p4_depth = nullptr;    // per group of 8 trees: levels of its deepest tree
   void *d_sb_nodes = nullptr, *d_sb_bins = nullptr;
   double *d_sb_leaves = nullptr;

@@ -480,32 +480,43 @@ __device__ __forceinline__ uint32_t lds_address(const void *p) {
 // 16 tiles of leaf values), padded to whole batches; `ntrees` says how many trees are real.
 #define P4_TB 16
 typedef uint32_t p4_u32x4 __attribute__((ext_vector_type(4)));  // (arrays of it stay in registers)
-template <int NNP, int G>
-__device__ __forceinline__ void p4_walk_group(const uint32_t mybase, const uint32_t steps, const int cnt,
-                                              double &sum) {
-  constexpr uint32_t TILE = NNP * 4, LV0 = P4_TB * TILE, LVT = NNP * 8;
-  uint32_t a[8];  // 4 * node of each chain
+// one step of chains J0 .. J0 + NJ - 1 of a batch (chain j walks tile j)
+template <int NNP, int J0, int NJ>
+__device__ __forceinline__ void p4_step(uint32_t (&a)[P4_TB], const uint32_t mybase) {
+  constexpr uint32_t TILE = NNP * 4;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) a[j] = 0;
-  for (uint32_t k = 0; k < steps; ++k) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t nd = lds_read_u32(a[j] + (G * 8 + j) * TILE);
-      const uint32_t bv = lds_read_u8(mybase + (nd & 0xffffu));
-      const uint32_t w = nd + (bv << 16);
-      // a = (w >> 24) << 2
-      asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
-          : "=v"(a[j])
-          : "v"(w));
-    }
+  for (int j = J0; j < J0 + NJ; ++j) {
+    const uint32_t nd = lds_read_u32(a[j] + j * TILE);
+    const uint32_t bv = lds_read_u8(mybase + (nd & 0xffffu));
+    const uint32_t w = nd + (bv << 16);
+    // a = (w >> 24) << 2
+    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
+        : "=v"(a[j])
+        : "v"(w));
   }
-  if (cnt >= 8) {
+}
+
+// A batch: sixteen chains in flight for the levels both groups of eight trees have, then the
+// deeper group alone (a group's depth is its deepest tree's: finished chains idle on their
+// leaves); the sixteen leaf values are added in tree order.
+template <int NNP>
+__device__ __forceinline__ void p4_walk_batch(const uint32_t mybase, const uint32_t d0, const uint32_t d1,
+                                              const int cnt, double &sum) {
+  constexpr uint32_t TILE = NNP * 4, LV0 = P4_TB * TILE, LVT = NNP * 8;
+  uint32_t a[P4_TB];  // 4 * node of each chain
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sum = sum + lds_read_f64(a[j] * 2 + (LV0 + (G * 8 + j) * LVT));
+  for (int j = 0; j < P4_TB; ++j) a[j] = 0;
+  const uint32_t both = d0 < d1 ? d0 : d1;
+  for (uint32_t k = 0; k < both; ++k) p4_step<NNP, 0, 16>(a, mybase);
+  for (uint32_t k = both; k < d0; ++k) p4_step<NNP, 0, 8>(a, mybase);
+  for (uint32_t k = both; k < d1; ++k) p4_step<NNP, 8, 8>(a, mybase);
+  if (cnt >= P4_TB) {
+#pragma unroll
+    for (int j = 0; j < P4_TB; ++j) sum = sum + lds_read_f64(a[j] * 2 + (LV0 + j * LVT));
   } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < cnt) sum = sum + lds_read_f64(a[j] * 2 + (LV0 + (G * 8 + j) * LVT));
+    for (int j = 0; j < P4_TB; ++j)
+      if (j < cnt) sum = sum + lds_read_f64(a[j] * 2 + (LV0 + j * LVT));
   }
 }
 
@@ -578,8 +589,7 @@ __global__ __launch_bounds__(NW * 64) void k_score_p4(
     }
     if (!have) continue;
     const int left = (int)(ntrees - t0);
-    p4_walk_group<NNP, 0>(mybase, d01 & 0xffu, left, sum);
-    if (left > 8) p4_walk_group<NNP, 1>(mybase, d01 >> 8, left - 8, sum);
+    p4_walk_batch<NNP>(mybase, d01 & 0xffu, d01 >> 8, left, sum);
   }
   if (have && doc < N) out[doc] = sum;
 }

@@ -229,10 +229,12 @@ def scoring_metric(ctx, args, torch, rank=0, world=1, dist=None):
             "roofline": {"bound": "lds", "kernel": "k_score_p4 (binned tree walk out of LDS-staged tree tiles)",
                          "achieved": round(lds_ach, 1), "peak": round(lds_peak, 1), "unit": "GB/s",
                          "frac": round(lds_ach / lds_peak, 4), "lds_bytes_per_node_visit": 8,
-                         "note": "random-address ds_read_b32 (node record) + ds_read_u8 (bin) per (document, "
-                                 "tree, level); bank conflicts of the random rows and the 8-tree lockstep are "
-                                 "what separates achieved from peak; HBM traffic is the one 8 GB pass of "
-                                 "k_doc_bins (~2 ms of the total)"},
+                         "note": "ds_read_b32 (node record, level order: one bank per node of a level) + "
+                                 "ds_read_u8 (bin, one dword per lane and feature quad: conflict-free) per "
+                                 "(document, tree, level) and three vector instructions between them; the PMC "
+                                 "passes (profiles/r03_score_pmc.md) put the LDS array at 52 % busy and the "
+                                 "SIMDs' issue slots at 70 %: a visit's five instructions are the other bound; "
+                                 "HBM traffic is the one 8 GB pass of k_doc_bins (~2 ms of the total)"},
             "workload": f"{args.score_trees} trees x 64 leaves (depth 6) over {args.score_docs} docs x 200 "
                         "features, synthetic, features resident on the device"
                         + (f", documents sharded over {world} GPUs" if world > 1 else ""),

@@ -789,6 +789,123 @@ __global__ __launch_bounds__(NW * 64) void k_obl_score_bin(
   if (live && blk * 64 + lane < N) out[(size_t)blk * 64 + lane] = score;
 }
 
+// k_obl_score_s: the same scorer with a tree's level tests in SCALAR registers (u8 bins, depth
+// <= 8).  k_obl_score_bin fetches every (feature, slot) pair from LDS and broadcasts it with
+// v_readfirstlane -- nine instructions and two waits per level test, 15 CU cycles per wave and
+// test; here a tree is sixteen dwords {row offset[8], slot[8]} that one s_load_dwordx16 brings
+// in, and a level test is `row + lane base` -> ds_read_u8 -> compare with the slot ->
+// `index = 2 * index + carry`: three vector instructions and one conflict-free LDS read (the
+// bins of a wave's 64 documents are [feature][lane] bytes: a level's feature is the same for
+// every lane).  Four trees are in flight per lane.  Leaf values are stored times the tree's
+// (f32, promoted) weight -- the product of generate_oblivious.cc:312-324, once per model -- and
+// are added strictly in tree order; shallower trees are padded at the END with levels that
+// are never true, their leaves stored at the shifted indices; the model is padded to whole
+// batches with all-zero trees (score + 0.0 == score: the sum is never -0.0).
+struct ObsTree {
+  uint32_t row[8], slot[8];
+};
+template <int NW, int D>
+__global__ __launch_bounds__(NW * 64) void k_obl_score_s(
+    const uint8_t *__restrict__ bins, const uint32_t N, const uint32_t F,
+    const ObsTree *__restrict__ trees, const p4_u32x4 *__restrict__ leaves, const uint32_t tpad,
+    const uint32_t tb, double *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr uint32_t NL8 = (1u << D) * 8;  // bytes of a tree's leaf values
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t tile = tb * NL8;                   // leaf values of a batch, at the start of the LDS
+  const uint32_t doc_bytes = (F * 64 + 15) & ~15u;
+  {
+    uint32_t sb = lds_address(smem);
+    asm volatile("" : "+v"(sb));
+    if (sb != 0) __builtin_trap();  // (LDS addresses below are absolute)
+  }
+  const uint32_t nblk = (N + 63) / 64;
+  const uint32_t blk = blockIdx.x * NW + wave;
+  const bool live = blk < nblk;
+  // the next batch's leaf values travel into registers while this one is walked
+  constexpr uint32_t PF = 4;  // 16-byte pieces per thread: tb * NL8 <= 16 KB + slack = 4 * NW * 64 * 16 at NW >= 4
+  const uint32_t b16 = tile / 16;
+  p4_u32x4 pf[PF];
+  uint32_t pfi[PF];
+#pragma unroll
+  for (uint32_t r = 0; r < PF; ++r) {
+    const uint32_t i = threadIdx.x + r * NW * 64;
+    pfi[r] = i < b16 ? i : b16 - 1;
+  }
+#pragma unroll
+  for (uint32_t r = 0; r < PF; ++r) pf[r] = leaves[pfi[r]];
+  if (live) {
+    const p4_u32x4 *src = reinterpret_cast<const p4_u32x4 *>(bins + (size_t)blk * F * 64);
+    p4_u32x4 *dst = reinterpret_cast<p4_u32x4 *>(smem + tile + wave * doc_bytes);
+    for (uint32_t i = lane; i < F * 4; i += 64) dst[i] = src[i];
+  }
+  const uint32_t mybase = tile + wave * doc_bytes + lane;
+  p4_u32x4 *lds4 = reinterpret_cast<p4_u32x4 *>(smem);
+  double score = 0.0;
+  for (uint32_t t0 = 0; t0 < tpad; t0 += tb) {
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < PF; ++r) lds4[pfi[r]] = pf[r];
+    __syncthreads();
+    if (t0 + tb < tpad) {
+      const p4_u32x4 *src = leaves + (size_t)(t0 + tb) * (NL8 / 16);
+#pragma unroll
+      for (uint32_t r = 0; r < PF; ++r) pf[r] = src[pfi[r]];
+    }
+    if (!live) continue;
+    for (uint32_t t = 0; t < tb; t += 4) {
+      ObsTree tr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) tr[u] = trees[t0 + t + u];  // uniform: scalar loads
+      uint32_t idx[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int l = 0; l < D; ++l) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t b = lds_read_u8(mybase + tr[u].row[l]);
+          // index = 2 * index + (bin > slot): compare into the carry, add with carry
+          asm("v_cmp_lt_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+              : "+v"(idx[u])
+              : "v"(b), "s"(tr[u].slot[l])
+              : "vcc");
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) score = score + lds_read_f64(idx[u] * 8 + (t + u) * NL8);
+    }
+  }
+  if (live && blk * 64 + lane < N) out[(size_t)blk * 64 + lane] = score;
+}
+
+template <int NW>
+static int launch_obl_s(qr_ctx *c, size_t N, double *d_out) {
+  const size_t F = c->ob_F;
+  const size_t doc_bytes = (F * 64 + 15) & ~(size_t)15;
+  const size_t nl8 = ((size_t)1 << c->obl_depth) * 8;
+  const size_t lds = c->obs_tb * nl8 + NW * doc_bytes;
+  const size_t nblk = (N + 63) / 64;
+  auto launch = [&](auto kernel) -> int {
+    QR_CHECK(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((nblk + NW - 1) / NW)), dim3(NW * 64), lds, c->stream,
+                       (const uint8_t *)c->d_sb_bins, (uint32_t)N, (uint32_t)F,
+                       (const ObsTree *)c->d_obs_trees, (const p4_u32x4 *)c->d_obs_leaves,
+                       (uint32_t)c->obs_tpad, (uint32_t)c->obs_tb, d_out);
+    QR_CHECK(c, hipGetLastError());
+    return QR_OK;
+  };
+  switch (c->obl_depth) {
+    case 1: return launch(k_obl_score_s<NW, 1>);
+    case 2: return launch(k_obl_score_s<NW, 2>);
+    case 3: return launch(k_obl_score_s<NW, 3>);
+    case 4: return launch(k_obl_score_s<NW, 4>);
+    case 5: return launch(k_obl_score_s<NW, 5>);
+    case 6: return launch(k_obl_score_s<NW, 6>);
+    case 7: return launch(k_obl_score_s<NW, 7>);
+    default: return launch(k_obl_score_s<NW, 8>);
+  }
+}
+
 template <typename BT>
 static int launch_obl_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, double *d_out) {
   constexpr int NW = 8;
@@ -823,6 +940,12 @@ static int launch_obl_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstri
                      dim3(256), lds_a, c->stream, d_x, (uint32_t)N, (uint32_t)F, (uint32_t)xstride,
                      c->d_ob_thr, c->d_ob_thr_cnt, (uint32_t)c->ob_tmax, lds_thr, (BT *)c->d_sb_bins, 1u);
   QR_CHECK(c, hipGetLastError());
+  if (sizeof(BT) == 1 && c->obs_ready && !getenv("QR_OBL_OLD")) {
+    // the workgroups' documents next to one batch of leaf values; two workgroups per CU
+    const size_t tile = c->obs_tb * (((size_t)1 << c->obl_depth) * 8);
+    if (tile + 8 * doc_bytes <= 80 * 1024) return launch_obl_s<8>(c, N, d_out);
+    if (tile + 4 * doc_bytes <= 80 * 1024) return launch_obl_s<4>(c, N, d_out);
+  }
   const size_t lds = NW * doc_bytes + tbatch * per_tree + 64;
   auto launch = [&](auto kernel) -> int {
     QR_CHECK(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -210,6 +210,7 @@ void qr_ctx_destroy(qr_ctx *c) {
   dfree(c->d_keys); dfree(c->d_tied);
   dfree(c->d_obl_feat); dfree(c->d_obl_thr); dfree(c->d_obl_leaves); dfree(c->d_obl_w);
   dfree(c->d_obl_depths); dfree(c->d_ob_fk); dfree(c->d_ob_thr); dfree(c->d_ob_thr_cnt);
+  dfree(c->d_obs_trees); dfree(c->d_obs_leaves);
   if (c->d_sb_nodes) (void)hipFree(c->d_sb_nodes);
   if (c->d_sb_bins) (void)hipFree(c->d_sb_bins);
   dfree(c->d_sb_leaves); dfree(c->d_sb_root); dfree(c->d_sb_thr); dfree(c->d_sb_thr_cnt);
@@ -1921,6 +1922,7 @@ int qr_oblivious_upload(qr_ctx *c, const uint32_t *feat, const float *thr,
   // binned form: per feature the sorted distinct thresholds the ensemble tests; per
   // (tree, level) the feature and the index of its threshold among them
   c->ob_ready = false;
+  c->obs_ready = false;
   dfree(c->d_ob_fk); dfree(c->d_ob_thr); dfree(c->d_ob_thr_cnt);
   uint32_t maxf = 0;
   for (size_t i = 0; i < ntrees * depth; ++i) maxf = std::max(maxf, feat[i]);
@@ -1957,6 +1959,43 @@ int qr_oblivious_upload(qr_ctx *c, const uint32_t *feat, const float *thr,
       c->ob_tmax = tmax;
       c->ob_u8 = tmax <= 255;
       c->ob_ready = true;
+      // ---- k_obl_score_s: the level tests of a tree as sixteen dwords for the scalar unit
+      c->obs_ready = false;
+      dfree(c->d_obs_trees); dfree(c->d_obs_leaves);
+      if (tmax <= 255 && depth <= 8 && (F - 1) * 64 <= 0xffff) {
+        // a batch of leaf values next to eight 64-document blocks in half of a CU's LDS, if it fits
+        const size_t docs8 = 8 * ((F * 64 + 15) & ~(size_t)15), half = 80 * 1024;
+        size_t tb = docs8 + 4 * nl * 8 <= half ? (half - docs8) / (nl * 8) : 16384 / (nl * 8);
+        tb = std::min<size_t>(32, std::max<size_t>(4, tb & ~(size_t)3));
+        const size_t tpad = (ntrees + tb - 1) / tb * tb;
+        // a tree shallower than `depth` gets levels that are never true (bin > 255) at its END:
+        // its leaf index comes out shifted left, and its leaf values are stored at the shifted places
+        std::vector<uint32_t> tr(tpad * 16);
+        std::vector<double> lw(tpad * nl, 0.0);
+        for (size_t t = 0; t < tpad; ++t)
+          for (size_t l = 0; l < 8; ++l) {
+            tr[t * 16 + l] = 0;
+            tr[t * 16 + 8 + l] = 255;
+          }
+        for (size_t t = 0; t < ntrees; ++t) {
+          const size_t m = depths ? std::min<size_t>(depths[t], depth) : depth;
+          for (size_t l = 0; l < m; ++l) {
+            const uint32_t v = fk[t * depth + l];
+            tr[t * 16 + l] = (v & 0xffffu) * 64u;
+            tr[t * 16 + 8 + l] = v >> 16;
+          }
+          // generate_oblivious.cc:312-324: f32 weight promoted, one f64 product per (tree, leaf)
+          for (size_t i = 0; i < ((size_t)1 << m); ++i)
+            lw[t * nl + (i << (depth - m))] = (double)weights[t] * leaves[t * nl + i];
+        }
+        QR_CHECK(c, dalloc(&c->d_obs_trees, tr.size()));
+        QR_CHECK(c, dalloc(&c->d_obs_leaves, lw.size()));
+        QR_CHECK(c, hipMemcpy(c->d_obs_trees, tr.data(), tr.size() * 4, hipMemcpyHostToDevice));
+        QR_CHECK(c, hipMemcpy(c->d_obs_leaves, lw.data(), lw.size() * 8, hipMemcpyHostToDevice));
+        c->obs_tb = tb;
+        c->obs_tpad = tpad;
+        c->obs_ready = true;
+      }
     }
   }
   return QR_OK;

@@ -484,6 +484,12 @@ struct qr_ctx {
   bool ob_ready = false, ob_u8 = false;
   size_t ob_F = 0, ob_tmax = 0;
   uint32_t *d_ob_fk = nullptr;      // [trees][depth]: feature | threshold index << 16
+  // k_obl_score_s (u8 bins, depth <= 8): per tree {row offset[8], slot[8]} for the scalar unit,
+  // leaf * weight per tree; both padded to whole batches of obs_tb trees
+  bool obs_ready = false;
+  size_t obs_tb = 0, obs_tpad = 0;
+  uint32_t *d_obs_trees = nullptr;
+  double *d_obs_leaves = nullptr;
   float *d_ob_thr = nullptr;        // [ob_F][ob_tmax] sorted distinct thresholds per feature
   uint32_t *d_ob_thr_cnt = nullptr;
   // largest dynamic-LDS size announced to the runtime per kernel family (a function

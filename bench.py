@@ -582,6 +582,25 @@ def main():
             extras["oblivious_d6"] = side_run(
                 x, labels, qoff, same_set + f", Oblivious-LambdaMART depth 6 (64 leaves), {args.nthresholds} "
                 "thresholds, NDCG@10, shrinkage 0.1, min-leaf-support 1", args.extra_steps, obl_depth=6)
+            # ... and configs[3]'s scoring path: a 1000-tree depth-6 oblivious ensemble (random, of
+            # the trained model's shape) over the same rows, generate_oblivious.cc's bit-interleaved
+            # scorer (k_doc_bins + k_obl_score_s: HIP events around the two kernels)
+            try:
+                from quickrank_amd._capi import Context as _Ctx
+                rg = np.random.default_rng(7)
+                oc = _Ctx(torch.cuda.current_device())
+                oc.upload_oblivious(rg.integers(0, F, (1000, 6)).astype(np.uint32),
+                                    rg.random((1000, 6), dtype=np.float32),
+                                    rg.standard_normal((1000, 64)), np.full(1000, 0.1, np.float32))
+                oc.score_oblivious(x)
+                oms = min(oc.score_oblivious(x)[1] for _ in range(3))
+                oc.close()
+                extras["oblivious_d6"]["scoring"] = {
+                    "workload": f"1000 oblivious trees of depth 6 over the same {N} docs x {F} features",
+                    "ms": round(oms, 3), "docs_per_s": N / oms * 1e3, "level_tests_per_s": N * 6000.0 / oms * 1e3,
+                    "what": "kernel time (k_doc_bins + k_obl_score_s), rows already on the device"}
+            except Exception as e:  # the side metric must not take the line down
+                extras["oblivious_d6"]["scoring"] = {"error": str(e)}
             xm, lm, qm = synth_mslr(F=F)
             extras["mslr_shaped"] = side_run(
                 xm, lm, qm, f"MSLR-WEB10K-shaped stand-in: {len(lm)} docs x {F} features in {len(qm) - 1} ragged "

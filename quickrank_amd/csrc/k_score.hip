@@ -823,8 +823,9 @@ __global__ __launch_bounds__(NW * 64) void k_obl_score_s(
   const uint32_t blk = blockIdx.x * NW + wave;
   const bool live = blk < nblk;
   // the next batch's leaf values travel into registers while this one is walked
-  constexpr uint32_t PF = 4;  // 16-byte pieces per thread: tb * NL8 <= 16 KB + slack = 4 * NW * 64 * 16 at NW >= 4
+  constexpr uint32_t PF = 4;  // 16-byte pieces per thread (the host sizes the batch for it)
   const uint32_t b16 = tile / 16;
+  if (b16 > PF * NW * 64) __builtin_trap();
   p4_u32x4 pf[PF];
   uint32_t pfi[PF];
 #pragma unroll
@@ -942,9 +943,8 @@ static int launch_obl_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstri
   QR_CHECK(c, hipGetLastError());
   if (sizeof(BT) == 1 && c->obs_ready && !getenv("QR_OBL_OLD")) {
     // the workgroups' documents next to one batch of leaf values; two workgroups per CU
-    const size_t tile = c->obs_tb * (((size_t)1 << c->obl_depth) * 8);
-    if (tile + 8 * doc_bytes <= 80 * 1024) return launch_obl_s<8>(c, N, d_out);
-    if (tile + 4 * doc_bytes <= 80 * 1024) return launch_obl_s<4>(c, N, d_out);
+    // (the batch was sized at upload for obs_nw 64-document blocks per workgroup)
+    return c->obs_nw == 8 ? launch_obl_s<8>(c, N, d_out) : launch_obl_s<4>(c, N, d_out);
   }
   const size_t lds = NW * doc_bytes + tbatch * per_tree + 64;
   auto launch = [&](auto kernel) -> int {

@@ -1963,10 +1963,20 @@ int qr_oblivious_upload(qr_ctx *c, const uint32_t *feat, const float *thr,
       c->obs_ready = false;
       dfree(c->d_obs_trees); dfree(c->d_obs_leaves);
       if (tmax <= 255 && depth <= 8 && (F - 1) * 64 <= 0xffff) {
-        // a batch of leaf values next to eight 64-document blocks in half of a CU's LDS, if it fits
-        const size_t docs8 = 8 * ((F * 64 + 15) & ~(size_t)15), half = 80 * 1024;
-        size_t tb = docs8 + 4 * nl * 8 <= half ? (half - docs8) / (nl * 8) : 16384 / (nl * 8);
-        tb = std::min<size_t>(32, std::max<size_t>(4, tb & ~(size_t)3));
+        // a batch of leaf values next to eight (else four) 64-document blocks in half of a CU's
+        // LDS; a thread carries four 16-byte pieces of the next batch (k_obl_score_s)
+        const size_t doc_bytes = (F * 64 + 15) & ~(size_t)15, half = 80 * 1024;
+        size_t tb = 0, nw = 0;
+        for (size_t w : {(size_t)8, (size_t)4}) {
+          if (w * doc_bytes + 4 * nl * 8 > half) continue;
+          const size_t cap = std::min(half - w * doc_bytes, 4 * w * 64 * 16);
+          tb = std::min<size_t>(32, (cap / (nl * 8)) & ~(size_t)3);
+          if (tb >= 4) {
+            nw = w;
+            break;
+          }
+        }
+        if (nw) {
         const size_t tpad = (ntrees + tb - 1) / tb * tb;
         // a tree shallower than `depth` gets levels that are never true (bin > 255) at its END:
         // its leaf index comes out shifted left, and its leaf values are stored at the shifted places
@@ -1993,8 +2003,10 @@ int qr_oblivious_upload(qr_ctx *c, const uint32_t *feat, const float *thr,
         QR_CHECK(c, hipMemcpy(c->d_obs_trees, tr.data(), tr.size() * 4, hipMemcpyHostToDevice));
         QR_CHECK(c, hipMemcpy(c->d_obs_leaves, lw.data(), lw.size() * 8, hipMemcpyHostToDevice));
         c->obs_tb = tb;
+        c->obs_nw = nw;
         c->obs_tpad = tpad;
         c->obs_ready = true;
+        }
       }
     }
   }

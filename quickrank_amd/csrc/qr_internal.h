@@ -487,7 +487,7 @@ struct qr_ctx {
   // k_obl_score_s (u8 bins, depth <= 8): per tree {row offset[8], slot[8]} for the scalar unit,
   // leaf * weight per tree; both padded to whole batches of obs_tb trees
   bool obs_ready = false;
-  size_t obs_tb = 0, obs_tpad = 0;
+  size_t obs_tb = 0, obs_tpad = 0, obs_nw = 0;
   uint32_t *d_obs_trees = nullptr;
   double *d_obs_leaves = nullptr;
   float *d_ob_thr = nullptr;        // [ob_F][ob_tmax] sorted distinct thresholds per feature

@@ -386,6 +386,73 @@ def test_ensemble_scoring_every_record_format(qr, ora, kind):
     c.close()
 
 
+@pytest.mark.parametrize("F,N,T,leaves", [(1, 1, 1, 2), (2, 63, 15, 5), (3, 65, 16, 8), (5, 129, 17, 3),
+                                          (7, 64, 33, 1), (200, 700, 48, 64), (9, 1000, 1, 128)])
+def test_scoring_walk_edge_shapes(qr, F, N, T, leaves):
+    """k_score_p4 on the shapes its layout has edges at: a feature count that is not a multiple of
+    four (the bins are one dword per lane and feature QUAD), fewer documents than a wave, document
+    counts around a block boundary, tree counts around the batch of sixteen (padding trees), single
+    leaves (a group of depth 0), the largest trees the 4-byte records hold.  Bit-exact against
+    the reference's walk restated in numpy (ensemble.cc:111-118)."""
+    rng = np.random.default_rng(1000 * F + N + T)
+    pool = np.unique(rng.standard_normal(60).astype(np.float32))
+    trees = [_random_tree(rng, leaves if (k % 3) else max(1, leaves // 2), F, pool, chain=(k % 4 == 1 and leaves <= 40))
+             for k in range(T)]
+    maxn = max(len(t) for t in trees)
+    from quickrank_amd._capi import NODE_DTYPE
+    nodes = np.zeros((T, maxn), NODE_DTYPE)
+    nodes["feature"] = -1
+    nodes["left"] = nodes["right"] = -1
+    for k, t in enumerate(trees):
+        nodes[k, :len(t)] = t
+    w = rng.random(T) + 0.5
+    x = rng.choice(pool, size=(N, F)).astype(np.float32)
+    c = qr.Context(0)
+    c.upload_ensemble(nodes, w)
+    got, _ = c.score(x)
+    want = np.zeros(N)
+    for k, t in enumerate(trees):
+        cur = np.zeros(N, np.int64)
+        while True:
+            nd = t[cur]
+            idx = np.nonzero(nd["feature"] >= 0)[0]
+            if not len(idx):
+                break
+            go = x[idx, nd["feature"][idx]] <= nd["threshold"][idx]
+            cur[idx] = np.where(go, nd["left"][idx], nd["right"][idx])
+        want = want + t["value"][cur] * w[k]
+    assert np.array_equal(got, want)
+    c.close()
+
+
+@pytest.mark.parametrize("T,D,F", [(1, 1, 1), (3, 2, 2), (5, 7, 11), (33, 8, 40), (64, 3, 136), (7, 5, 1)])
+def test_oblivious_scoring_scalar_kernel_shapes(qr, T, D, F):
+    """k_obl_score_s (level tests in scalar registers) at the edges of its layout: every depth it
+    takes (1 .. 8), tree counts that are not a multiple of the four trees in flight or of the
+    batch (all-zero padding trees), one feature, mixed actual depths."""
+    rng = np.random.default_rng(77 * T + D)
+    N = 64 * 3 + 7
+    feat = rng.integers(0, F, (T, D)).astype(np.uint32)
+    thr = rng.random((T, D)).astype(np.float32)
+    leaves = rng.standard_normal((T, 1 << D))
+    w = (rng.random(T) * 0.2 + 0.01).astype(np.float32)
+    depths = np.sort(rng.integers(1, D + 1, T)).astype(np.uint32)
+    x = rng.random((N, F), dtype=np.float32)
+    c = qr.Context(0)
+    for dp in (None, depths):
+        c.upload_oblivious(feat, thr, leaves, w, dp)
+        got, _ = c.score_oblivious(x)
+        want = np.zeros(N)
+        for t in range(T):
+            m = D if dp is None else int(dp[t])
+            idx = np.zeros(N, np.int64)
+            for l in range(m):
+                idx |= (x[:, feat[t, l]] > thr[t, l]).astype(np.int64) << (m - 1 - l)
+            want = want + np.float64(w[t]) * leaves[t, idx]
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), dp is None
+    c.close()
+
+
 def test_oblivious_bit_interleaved_scoring(qr, ora):
     """generate_oblivious.cc:237-324 semantics (f32 tree weights, `>` = right)."""
     rng = np.random.default_rng(3)

@@ -218,7 +218,10 @@ __global__ __launch_bounds__(256) void k_doc_bins(const float *__restrict__ x, c
                                                   BT *__restrict__ out, const uint32_t nan_low) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *lt = reinterpret_cast<float *>(smem);                       // [DB_FG][tmax] when lds_thr
-  BT *tile = reinterpret_cast<BT *>(smem + (lds_thr ? (size_t)DB_FG * tmax * 4 : 0));  // [DB_FG][64]
+  // [DB_FG][64], rows 4 bytes apart from a multiple of the bank row: the 32 features a wave
+  // writes for one document land in 32 banks (at a stride of 64 bytes they shared two)
+  constexpr uint32_t TS = 64 * sizeof(BT) + 4;
+  BT *tile = reinterpret_cast<BT *>(smem + (lds_thr ? (size_t)DB_FG * tmax * 4 : 0));
   __shared__ uint32_t cnt[DB_FG];
   const uint32_t f0 = blockIdx.y * DB_FG;
   const uint32_t nf = f0 + DB_FG <= F ? DB_FG : F - f0;
@@ -231,30 +234,47 @@ __global__ __launch_bounds__(256) void k_doc_bins(const float *__restrict__ x, c
     const uint32_t blk = blockIdx.x * DB_BLOCKS + bb;
     if (blk >= nblk) break;
     const uint32_t d0 = blk * 64;
-    for (uint32_t i = threadIdx.x; i < 64 * DB_FG; i += 256) {
-      const uint32_t r = i / DB_FG, f = i % DB_FG;
-      BT b = 0;
-      if (d0 + r < N && f < nf) {
-        const float v = x[(size_t)(d0 + r) * xstride + f0 + f];
-        const float *t = lds_thr ? lt + (size_t)f * tmax : thr + (size_t)(f0 + f) * tmax;
-        uint32_t lo = 0, hi = cnt[f];  // first index with t[idx] >= v
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (t[mid] < v)
-            lo = mid + 1;
-          else
-            hi = mid;
-        }
-        // NaN: `x <= thr` is false for every threshold (tree walk: always right) and so
-        // is `x > thr` (the oblivious scorer's test: always left)
-        if (v != v) lo = nan_low ? 0u : cnt[f];
-        b = (BT)lo;
-      }
-      tile[f * 64 + r] = b;
+    // a thread's eight (document, feature) pairs: the feature is the same for all of them
+    // (256 threads = 8 rows x 32 features), the eight loads are requested before the first search
+    constexpr uint32_t PP = 64 * DB_FG / 256;
+    const uint32_t f = threadIdx.x % DB_FG, rr = threadIdx.x / DB_FG;
+    float v[PP];
+#pragma unroll
+    for (uint32_t k = 0; k < PP; ++k) {
+      const uint32_t r = rr + k * (256 / DB_FG);
+      v[k] = (d0 + r < N && f < nf) ? x[(size_t)(d0 + r) * xstride + f0 + f] : 0.0f;
+    }
+    const float *t = lds_thr ? lt + (size_t)f * tmax : thr + (size_t)(f0 + (f < nf ? f : 0)) * tmax;
+    BT *trow = reinterpret_cast<BT *>(reinterpret_cast<char *>(tile) + f * TS);
+    const uint32_t cf = cnt[f];
+    // lower bound (first index with t[idx] >= v) without data-dependent branches: the trip count
+    // depends on the feature's threshold count only, so the eight searches advance together and
+    // their LDS reads are in flight together
+    uint32_t base[PP];
+#pragma unroll
+    for (uint32_t k = 0; k < PP; ++k) base[k] = 0;
+    uint32_t len = cf;
+    while (len > 1) {
+      const uint32_t half = len >> 1;
+#pragma unroll
+      for (uint32_t k = 0; k < PP; ++k) base[k] += t[base[k] + half - 1] < v[k] ? half : 0u;
+      len -= half;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PP; ++k) {
+      const uint32_t r = rr + k * (256 / DB_FG);
+      uint32_t lo = base[k] + ((len == 1 && t[base[k]] < v[k]) ? 1u : 0u);
+      // NaN: `x <= thr` is false for every threshold (tree walk: always right) and so
+      // is `x > thr` (the oblivious scorer's test: always left)
+      if (v[k] != v[k]) lo = nan_low ? 0u : cf;
+      trow[r] = (d0 + r < N && f < nf) ? (BT)lo : (BT)0;
     }
     __syncthreads();
-    BT *dst = out + ((size_t)blk * F + f0) * 64;
-    for (uint32_t i = threadIdx.x; i < 64 * nf; i += 256) dst[i] = tile[i];
+    // out as dwords: row f of the tile is 64 * sizeof(BT) / 4 of them
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + ((size_t)blk * F + f0) * 64);
+    constexpr uint32_t RW = 64 * sizeof(BT) / 4;
+    for (uint32_t i = threadIdx.x; i < RW * nf; i += 256)
+      dst[i] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(tile) + (i / RW) * TS + (i % RW) * 4);
     __syncthreads();
   }
 }
@@ -672,7 +692,7 @@ static int launch_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, 
     c->sb_bins_bytes = need;
   }
   const uint32_t lds_thr = (size_t)DB_FG * c->sb_tmax * 4 <= 96 * 1024 ? 1 : 0;
-  const size_t lds_a = (lds_thr ? (size_t)DB_FG * c->sb_tmax * 4 : 0) + DB_FG * 64 * sizeof(BT);
+  const size_t lds_a = (lds_thr ? (size_t)DB_FG * c->sb_tmax * 4 : 0) + DB_FG * (64 * sizeof(BT) + 4);
   if (lds_a > 64 * 1024)
     QR_CHECK(c, hipFuncSetAttribute((const void *)k_doc_bins<BT>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
@@ -932,7 +952,7 @@ static int launch_obl_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstri
     c->sb_bins_bytes = need;
   }
   const uint32_t lds_thr = (size_t)DB_FG * c->ob_tmax * 4 <= 96 * 1024 ? 1 : 0;
-  const size_t lds_a = (lds_thr ? (size_t)DB_FG * c->ob_tmax * 4 : 0) + DB_FG * 64 * sizeof(BT);
+  const size_t lds_a = (lds_thr ? (size_t)DB_FG * c->ob_tmax * 4 : 0) + DB_FG * (64 * sizeof(BT) + 4);
   if (lds_a > 64 * 1024)
     QR_CHECK(c, hipFuncSetAttribute((const void *)k_doc_bins<BT>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));

@@ -217,17 +217,19 @@ __global__ __launch_bounds__(256) void k_doc_bins(const float *__restrict__ x, c
                                                   const uint32_t tmax, const uint32_t lds_thr,
                                                   BT *__restrict__ out, const uint32_t nan_low) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *lt = reinterpret_cast<float *>(smem);                       // [DB_FG][tmax] when lds_thr
+  // [DB_FG][tmax | 1] when lds_thr: an odd row stride spreads the 32 features' rows over the banks
+  const uint32_t tstr = tmax | 1u;
+  float *lt = reinterpret_cast<float *>(smem);
   // [DB_FG][64], rows 4 bytes apart from a multiple of the bank row: the 32 features a wave
   // writes for one document land in 32 banks (at a stride of 64 bytes they shared two)
   constexpr uint32_t TS = 64 * sizeof(BT) + 4;
-  BT *tile = reinterpret_cast<BT *>(smem + (lds_thr ? (size_t)DB_FG * tmax * 4 : 0));
+  BT *tile = reinterpret_cast<BT *>(smem + (lds_thr ? (size_t)DB_FG * tstr * 4 : 0));
   __shared__ uint32_t cnt[DB_FG];
   const uint32_t f0 = blockIdx.y * DB_FG;
   const uint32_t nf = f0 + DB_FG <= F ? DB_FG : F - f0;
   if (threadIdx.x < DB_FG) cnt[threadIdx.x] = threadIdx.x < nf ? thr_cnt[f0 + threadIdx.x] : 0;
   if (lds_thr)
-    for (uint32_t i = threadIdx.x; i < nf * tmax; i += 256) lt[i] = thr[(size_t)f0 * tmax + i];
+    for (uint32_t i = threadIdx.x; i < nf * tmax; i += 256) lt[(i / tmax) * tstr + i % tmax] = thr[(size_t)f0 * tmax + i];
   __syncthreads();
   const uint32_t nblk = (N + 63) / 64;
   for (uint32_t bb = 0; bb < DB_BLOCKS; ++bb) {
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void k_doc_bins(const float *__restrict__ x, c
       const uint32_t r = rr + k * (256 / DB_FG);
       v[k] = (d0 + r < N && f < nf) ? x[(size_t)(d0 + r) * xstride + f0 + f] : 0.0f;
     }
-    const float *t = lds_thr ? lt + (size_t)f * tmax : thr + (size_t)(f0 + (f < nf ? f : 0)) * tmax;
+    const float *t = lds_thr ? lt + (size_t)f * tstr : thr + (size_t)(f0 + (f < nf ? f : 0)) * tmax;
     BT *trow = reinterpret_cast<BT *>(reinterpret_cast<char *>(tile) + f * TS);
     const uint32_t cf = cnt[f];
     // lower bound (first index with t[idx] >= v) without data-dependent branches: the trip count
@@ -691,8 +693,8 @@ static int launch_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, 
     QR_CHECK(c, hipMalloc(&c->d_sb_bins, need));
     c->sb_bins_bytes = need;
   }
-  const uint32_t lds_thr = (size_t)DB_FG * c->sb_tmax * 4 <= 96 * 1024 ? 1 : 0;
-  const size_t lds_a = (lds_thr ? (size_t)DB_FG * c->sb_tmax * 4 : 0) + DB_FG * (64 * sizeof(BT) + 4);
+  const uint32_t lds_thr = (size_t)DB_FG * (c->sb_tmax | 1) * 4 <= 96 * 1024 ? 1 : 0;
+  const size_t lds_a = (lds_thr ? (size_t)DB_FG * (c->sb_tmax | 1) * 4 : 0) + DB_FG * (64 * sizeof(BT) + 4);
   if (lds_a > 64 * 1024)
     QR_CHECK(c, hipFuncSetAttribute((const void *)k_doc_bins<BT>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
@@ -951,8 +953,8 @@ static int launch_obl_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstri
     QR_CHECK(c, hipMalloc(&c->d_sb_bins, need));
     c->sb_bins_bytes = need;
   }
-  const uint32_t lds_thr = (size_t)DB_FG * c->ob_tmax * 4 <= 96 * 1024 ? 1 : 0;
-  const size_t lds_a = (lds_thr ? (size_t)DB_FG * c->ob_tmax * 4 : 0) + DB_FG * (64 * sizeof(BT) + 4);
+  const uint32_t lds_thr = (size_t)DB_FG * (c->ob_tmax | 1) * 4 <= 96 * 1024 ? 1 : 0;
+  const size_t lds_a = (lds_thr ? (size_t)DB_FG * (c->ob_tmax | 1) * 4 : 0) + DB_FG * (64 * sizeof(BT) + 4);
   if (lds_a > 64 * 1024)
     QR_CHECK(c, hipFuncSetAttribute((const void *)k_doc_bins<BT>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));

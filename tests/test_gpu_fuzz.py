@@ -48,3 +48,13 @@ def test_fuzz_sweep_seed0():
     assert sum(r["ties"] for r in res) <= 150, sum(r["ties"] for r in res)
     print(f"fuzz: {sum(r['ties'] for r in res)} equal-partition ties over 300 runs, largest node "
           f"{max(sizes or [0])} documents; {len(cut)} runs decided by rounding noise")
+
+
+def test_scoring_fuzz_sweep_seed0():
+    """240 random ensembles / oblivious ensembles through every scoring kernel (4-byte and 8-byte
+    records, u8 and u16 bins, the general fallback, both oblivious scorers): bit-exact against
+    the reference's walks restated in numpy (tests/tools/fuzz_scoring.py)."""
+    from fuzz_scoring import sweep
+    res = sweep(240, 0, verbose=False)
+    assert len(res) == 240
+    assert all(r["ok"] for r in res), [r["desc"] for r in res if not r["ok"]]

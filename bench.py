@@ -213,6 +213,22 @@ def scoring_metric(ctx, args, torch, rank=0, world=1, dist=None):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
+    # the same walk on leaf-wise SHAPED trees (what LambdaMART with 64 leaves leaves behind: a group
+    # of trees runs for as many steps as its deepest member has levels), at a fifth of the size
+    from score_bench import make_leafwise_model
+    lt, ld = max(16, args.score_trees // 5), max(1, ndocs // 5)
+    ln_, lw_, lshape = make_leafwise_model(lt, 64, 200, np.random.default_rng(44))
+    sc.upload_ensemble(ln_, lw_)
+    def run2():
+        sc._ck(sc.L.qr_ensemble_score_device(sc.h, C.c_void_p(xs.data_ptr()), ld, 200, C.c_void_p(out.data_ptr())))
+    run2()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        run2()
+    e1.record()
+    torch.cuda.synchronize()
+    lms = e0.elapsed_time(e1) / reps
     sc.close()
     if dist is not None:
         t = torch.tensor([ms], dtype=torch.float64, device="cuda")
@@ -238,7 +254,12 @@ def scoring_metric(ctx, args, torch, rank=0, world=1, dist=None):
             "workload": f"{args.score_trees} trees x 64 leaves (depth 6) over {args.score_docs} docs x 200 "
                         "features, synthetic, features resident on the device"
                         + (f", documents sharded over {world} GPUs" if world > 1 else ""),
-            "scaling": "strong", "n_gpus": world, "ms": ms}
+            "scaling": "strong", "n_gpus": world, "ms": ms,
+            "leafwise_shaped": {"workload": f"{lt} leaf-wise shaped trees x 64 leaves over {ld} docs x 200 features "
+                                            "(this rank's)", "shape": lshape, "ms": lms,
+                                "docs_per_s_per_1000_trees": ld / lms * 1e3 * lt / 1000.0,
+                                "note": "a batch's trees walk in lockstep for as many steps as the deepest has "
+                                        "levels (DESIGN.md 3.6): cost follows the max depth, not the mean path"}}
 
 
 def tree_shape(t):

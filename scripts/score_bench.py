@@ -24,6 +24,35 @@ def make_model(T, depth, F, rng, pool=255):
     return nodes, np.full(T, 0.1)
 
 
+def make_leafwise_model(T, leaves, F, rng, pool=255):
+    """The shape a leaf-wise learner leaves (rt.cc:58-90 pops one leaf at a time): `leaves - 1`
+    splits of a randomly chosen leaf, nodes numbered in creation order; features / thresholds as
+    make_model.  Returns nodes, weights and the shape (max leaf depth per tree, mean leaf depth)."""
+    thr_pool = np.sort(rng.random((F, pool), dtype=np.float32), axis=1)
+    nodes = np.zeros((T, 2 * leaves - 1), NODE_DTYPE)
+    nodes["feature"] = -1
+    nodes["left"] = nodes["right"] = -1
+    nodes["value"] = rng.standard_normal(nodes.shape)
+    maxd, meand = [], []
+    for t in range(T):
+        open_, used, depth = [0], 1, {0: 0}
+        while len(open_) < leaves:
+            i = open_.pop(int(rng.integers(len(open_))))
+            f = int(rng.integers(F))
+            nodes[t, i]["feature"] = f
+            nodes[t, i]["threshold"] = thr_pool[f, int(rng.integers(pool))]
+            nodes[t, i]["left"], nodes[t, i]["right"] = used, used + 1
+            depth[used] = depth[used + 1] = depth[i] + 1
+            open_ += [used, used + 1]
+            used += 2
+        d = [depth[i] for i in open_]
+        maxd.append(max(d))
+        meand.append(float(np.mean(d)))
+    shape = {"max_depth_mean": round(float(np.mean(maxd)), 2), "max_depth_max": int(max(maxd)),
+             "leaf_depth_mean": round(float(np.mean(meand)), 2)}
+    return nodes, np.full(T, 0.1), shape
+
+
 def numpy_score(nodes, w, x):
     """ensemble.cc:111-118 in numpy: sum += tree(x) * weight, in tree order, f64."""
     out = np.zeros(len(x))

@@ -15,9 +15,15 @@ ap.add_argument("--docs", type=int, default=10_000_000)
 ap.add_argument("--features", type=int, default=200)
 ap.add_argument("--check", type=int, default=512)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--ragged", action="store_true",
+                help="leaf-wise shaped trees (a random leaf is split until 64: depth ~8-14) instead of complete depth-6 ones")
 a = ap.parse_args()
 rng = np.random.default_rng(43)
 nodes, w = make_model(a.trees, 6, a.features, rng)
+depth_stats = None
+if a.ragged:
+    from score_bench import make_leafwise_model
+    nodes, w, depth_stats = make_leafwise_model(a.trees, 64, a.features, rng)
 g = torch.Generator(device="cuda")
 g.manual_seed(43)
 x = torch.rand((a.docs, a.features), generator=g, device="cuda", dtype=torch.float32)
@@ -40,6 +46,8 @@ ms = e0.elapsed_time(e1) / a.reps
 res = {"workload": f"{a.trees} trees x 64 leaves, {a.docs} docs x {a.features} features (device-resident)",
        "ms": ms, "docs_per_s": a.docs / ms * 1e3, "node_visits_per_s": a.docs * a.trees * 6 / ms * 1e3,
        "hbm_alg_GBps": (a.docs * a.features * 4 + a.docs * 8) / ms / 1e6}
+if depth_stats:
+    res["shape"] = depth_stats
 if a.check:
     idx = torch.linspace(0, a.docs - 1, a.check, device="cuda").long()
     want = numpy_score(nodes, w, x[idx].cpu().numpy())

@@ -38,6 +38,7 @@ def test_bench_line_one_gpu():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "cpu_model" in c
     assert d["ensemble_scoring"]["value"] > 0 and d["ensemble_scoring"]["cpu_baseline"]["value"] > 0
+    assert d["ensemble_scoring"]["leafwise_shaped"]["ms"] > 0
     sr = d["ensemble_scoring"]["roofline"]
     assert sr["bound"] == "lds" and abs(sr["frac"] - sr["achieved"] / sr["peak"]) < 1e-3
     # every BASELINE.json configuration that fits one GPU is in the line

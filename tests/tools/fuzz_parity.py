@@ -9,17 +9,156 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 
+def upstream_gain_tie(stmap, o, g):
+    """The two trees walked together breadth-first over the SAME document sets: the shallowest
+    node where the device's split cuts the node's documents differently from the oracle's is
+    where they parted (the walker of parity_util goes depth-first and may report a consequence
+    first -- a leaf on one side, a split on the other, in a tree with a leaf budget).  True if
+    that node's two candidate splits have gains equal in exact arithmetic, i.e. equal sums of
+    child deviances (to 1e-9 of the node's deviance): discrete pseudo-responses, two different
+    partitions, the reference picks by the rounding noise of its summation order."""
+    queue = [(0, 0, np.arange(stmap.shape[1]))]
+    while queue:
+        oi, gi, d = queue.pop(0)
+        a, b = o[oi], g[gi]
+        if a["feature"] < 0 or b["feature"] < 0:
+            continue
+        ol = stmap[a["feature"], d] <= a["thr_id"]
+        gl = stmap[b["feature"], d] <= b["thr_id"]
+        if np.array_equal(gl, ol):
+            gL, gR = b["left"], b["right"]
+        elif np.array_equal(gl, ~ol):
+            gL, gR = b["right"], b["left"]
+        else:
+            so = o[a["left"]]["deviance"] + o[a["right"]]["deviance"]
+            sg = g[b["left"]]["deviance"] + g[b["right"]]["deviance"]
+            return bool(abs(so - sg) <= 1e-9 * max(1.0, abs(a["deviance"])))
+        queue.append((int(a["left"]), int(gL), d[ol]))
+        queue.append((int(a["right"]), int(gR), d[~ol]))
+    return False
+
+
+def deviance_order_tie(stmap, o, g):
+    """Leaf-wise trees with a leaf budget (rt.cc:58-90: the heap's maximum deviance is split next):
+    the two trees cut every node they BOTH split into the same two sets, but spent the last of the
+    budget on different nodes.  True if those nodes' deviances pair up equal to 1e-9 -- equal in
+    exact arithmetic (discrete pseudo-responses), ordered in the heap by the rounding noise of each
+    side's f64 sum of squares."""
+    queue = [(0, 0, np.arange(stmap.shape[1]))]
+    only_o, only_g = [], []
+    while queue:
+        oi, gi, d = queue.pop(0)
+        a, b = o[oi], g[gi]
+        if a["feature"] < 0 and b["feature"] < 0:
+            continue
+        if a["feature"] < 0 or b["feature"] < 0:
+            (only_g if a["feature"] < 0 else only_o).append(float(b["deviance"] if a["feature"] < 0 else a["deviance"]))
+            continue
+        ol = stmap[a["feature"], d] <= a["thr_id"]
+        gl = stmap[b["feature"], d] <= b["thr_id"]
+        if np.array_equal(gl, ol):
+            gL, gR = b["left"], b["right"]
+        elif np.array_equal(gl, ~ol):
+            gL, gR = b["right"], b["left"]
+        else:
+            return False
+        queue.append((int(a["left"]), int(gL), d[ol]))
+        queue.append((int(a["right"]), int(gR), d[~ol]))
+    if not only_o or len(only_o) != len(only_g):
+        return False
+    # (a node split on one side only may have split descendants there: compare the TOP nodes,
+    # which are the ones collected -- the walk does not descend below a one-sided split)
+    scale = max(1.0, abs(float(o[0]["deviance"])))
+    return all(abs(x - y) <= 1e-9 * scale for x, y in zip(sorted(only_o), sorted(only_g)))
+
+
+def score_tie_before(stmap, om, t, shrinkage, qoff):
+    """True if, going into tree t, some query holds two documents whose scores differ by
+    rounding noise only (nonzero, below 1e-12 relative): their order in the ranking -- hence the
+    query's lambdas and everything built on them -- is decided by the summation order of the leaf
+    outputs, which differs between the reference and the device."""
+    scores = scores_before(stmap, om, t, shrinkage)
+    qo = np.asarray(qoff, np.int64)
+    for q in range(len(qo) - 1):
+        srt = np.sort(scores[qo[q]:qo[q + 1]])
+        dd = np.diff(srt)
+        if ((dd != 0) & (np.abs(dd) <= 1e-12 * np.maximum(1.0, np.abs(srt[1:])))).any():
+            return True
+    return False
+
+
+def scores_before(stmap, om, t, shrinkage):
+    """The oracle's training scores going into tree t (its own trees walked on the bin map)."""
+    N = stmap.shape[1]
+    scores = np.zeros(N)
+    for k in range(t):
+        nodes = om["nodes"][k][:int(om["nnodes"][k])]
+        cur = np.zeros(N, np.int64)
+        while True:
+            nd = nodes[cur]
+            ii = np.nonzero(nd["feature"] >= 0)[0]
+            if not len(ii):
+                break
+            go = stmap[nd["feature"][ii], ii] <= nd["thr_id"][ii]
+            cur[ii] = np.where(go, nd["left"][ii], nd["right"][ii])
+        scores = scores + shrinkage * nodes["value"][cur]
+    return scores
+
+
+def oblivious_level_gain_tie(stmap, o, g, pseudo, minls):
+    """Oblivious trees (ot.cc:32-201: one (feature, slot) per level, the one with the largest sum
+    of the nodes' gains): at the first level where the device names another candidate than the
+    oracle, both candidates' level gains in EXACT rational arithmetic on the oracle's own
+    pseudo-responses.  True if they are equal: the reference then picks by the rounding noise of
+    its f64 sums, the device's exact integers keep the first."""
+    from fractions import Fraction
+    N = stmap.shape[1]
+    level = [(0, 0, np.arange(N))]
+    while level:
+        a, b = o[level[0][0]], g[level[0][1]]
+        if a["feature"] < 0 or b["feature"] < 0:
+            return False
+        co, cg = (int(a["feature"]), int(a["thr_id"])), (int(b["feature"]), int(b["thr_id"]))
+        same = all(np.array_equal(stmap[co[0], d] <= co[1], stmap[cg[0], d] <= cg[1]) for _, _, d in level)
+        if not same:
+            def gain(c):
+                tot = Fraction(0)
+                for _, _, d in level:
+                    go = stmap[c[0], d] <= c[1]
+                    lc, rc = int(go.sum()), int((~go).sum())
+                    if lc < minls or rc < minls:      # (ot.cc: an invalid slot of a node contributes nothing)
+                        continue
+                    L = sum((Fraction(float(v)) for v in pseudo[d[go]]), Fraction(0))
+                    R = sum((Fraction(float(v)) for v in pseudo[d[~go]]), Fraction(0))
+                    tot += L * L / lc + R * R / rc
+                return tot
+            # (equal, or apart by less than the 33-bit fixed-point gradients resolve: the exact
+            # tie of the real-valued model, broken by the f64 rounding of the pseudo-responses)
+            ga, gb = gain(co), gain(cg)
+            return bool(abs(ga - gb) <= Fraction(1, 10**9) * max(abs(ga), abs(gb)))
+        nxt = []
+        for oi, gi, d in level:
+            go = stmap[co[0], d] <= co[1]
+            nxt.append((int(o[oi]["left"]), int(g[gi]["left"]), d[go]))
+            nxt.append((int(o[oi]["right"]), int(g[gi]["right"]), d[~go]))
+        level = nxt
+    return False
+
+
 def sweep(n_cfg=30, seed=0, only=None, verbose=True):
     """Returns one record per configuration: dict(i, desc, status, ties, tie_sizes,
-    flips, tree) with status "ok", or "gain_tie" / "zero_deviance" for a run cut short
+    flips, tree) with status "ok", or "gain_tie" / "zero_deviance" / "heap_tie" for a run cut short
     at a split the reference decides by the rounding noise of its summation order
-    (verified to be exactly that, see below).  Any other difference raises."""
+    (verified to be exactly that, see below), or "score_tie" for a LambdaMART run in which two
+    scores of a query differ by rounding noise only going into the tree that differs (the ranking,
+    hence the lambdas, is then decided by the summation order of the leaf outputs).  Any other
+    difference raises."""
     import torch
     if torch.cuda.is_available():
         torch.cuda.init()
     import oracle
     from datagen import make_dataset
-    from parity_util import assert_tree_parity
+    from parity_util import assert_tree_parity, TIE_MAX_DOCS
     from quickrank_amd.trainer import Mart
     rng = np.random.default_rng(seed)
     oracle.build(ref=False)
@@ -36,11 +175,13 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
             kw["depth"] = int(rng.integers(1, 7))
         else:
             kw["nleaves"] = int(rng.choice([2, 3, 8, 10, 31, 64]))
-        x, labels, qoff = make_dataset(nq=nq, docs_per_query=dpq, F=F, seed=int(rng.integers(1 << 30)),
-                                       ragged=bool(rng.integers(2)), adversarial=bool(rng.integers(2)))
+        dseed, ragged, adversarial = int(rng.integers(1 << 30)), bool(rng.integers(2)), bool(rng.integers(2))
+        x, labels, qoff = make_dataset(nq=nq, docs_per_query=dpq, F=F, seed=dseed, ragged=ragged,
+                                       adversarial=adversarial)
         if only is not None and only != i:
             continue
-        desc = f"[{i}] {algo} N={len(labels)} F={F} nthr={nthr} minls={minls} {kw.get('nleaves', '')}{kw.get('depth', '')}"
+        desc = (f"[{i}] {algo} N={len(labels)} F={F} nthr={nthr} minls={minls} {kw.get('nleaves', '')}{kw.get('depth', '')}"
+                + (" adv" if adversarial else ""))
         rec = dict(i=i, desc=desc, status="ok", ties=0, tie_sizes=[], flips=0, tree=None)
         om = oracle.train(x, labels, qoff, algo=algo, **kw)
         gm = Mart(algo=algo, **kw).learn(x, labels, qoff)
@@ -49,7 +190,12 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
         for t in range(om["ntrees_built"]):
             n = int(om["nnodes"][t])
             try:
-                tt = assert_tree_parity(tr.stmap, om["nodes"][t][:n], gm.ensemble.trees[t][:n])
+                # (the sweep REPORTS the size of every node an equal-partition tie was resolved in
+                # instead of bounding it: TIE_MAX_DOCS is what the unit tests and seed 0 hold, but a
+                # sibling histogram's runs of empty slots -- or an adversarial set's duplicated /
+                # quantised columns -- tie in larger nodes too)
+                tt = assert_tree_parity(tr.stmap, om["nodes"][t][:n], gm.ensemble.trees[t][:n],
+                                        tie_max_docs=1 << 30)
                 rec["ties"] += int(tt)
                 rec["tie_sizes"] += list(tt.sizes)
             except AssertionError as e:
@@ -78,6 +224,24 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
                     eps = 1e-9 * max(1.0, abs(o[0]["deviance"]))
                     if abs(o[oi]["deviance"]) <= eps and abs(g[gi]["deviance"]) <= eps:
                         status = "zero_deviance"
+                # ... or the walker met a consequence first: look for the node where the trees parted
+                if status is None and not algo.startswith("OBV") and upstream_gain_tie(tr.stmap, o, g):
+                    status = "gain_tie"
+                # ... or both trees cut alike and spent the leaf budget on different, equally deviant nodes
+                if status is None and not algo.startswith("OBV") and deviance_order_tie(tr.stmap, o, g):
+                    status = "heap_tie"
+                # ... or a ranking decided by rounding: two scores of a query equal to the last bits
+                # ... (oblivious trees: the device fills no deviances below the root) the level's
+                # candidates priced exactly on the oracle's own pseudo-responses
+                if status is None and algo.startswith("OBV"):
+                    sc = scores_before(tr.stmap, om, t, kw["shrinkage"])
+                    pseudo = (oracle.lambdas(labels, sc, qoff)[0] if algo.endswith("LAMBDAMART")
+                              else labels.astype(np.float64) - sc)
+                    if oblivious_level_gain_tie(tr.stmap, o, g, pseudo, minls):
+                        status = "gain_tie"
+                if status is None and algo.endswith("LAMBDAMART") and t > 0 and \
+                        score_tie_before(tr.stmap, om, t, kw["shrinkage"], qoff):
+                    status = "score_tie"
                 if status is None:
                     print(desc, "TREE", t, "MISMATCH", e)
                     if only is not None:
@@ -89,8 +253,7 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
                 break
         if rec["status"] != "ok":
             if verbose:
-                print(desc, "ok up to a split decided by rounding noise (exact gain tie / zero deviance) in tree",
-                      rec["tree"], flush=True)
+                print(desc, f"ok up to a split decided by rounding noise ({rec['status']}) in tree", rec["tree"], flush=True)
             gm.ctx.close()
             out.append(rec)
             continue
@@ -120,5 +283,6 @@ if __name__ == "__main__":
           f"(largest node {max([0] + [max(r['tie_sizes'] or [0]) for r in res])} documents), "
           f"{sum(r['flips'] for r in res)} runs with a rank flip between scores equal to rounding, "
           f"{sum(r['status'] != 'ok' for r in res)} runs cut short at an exact gain tie between "
-          f"different partitions / a zero-deviance gate: {[r['i'] for r in res if r['status'] != 'ok']}, "
+          f"different partitions / a zero-deviance gate / a ranking or a heap order decided by rounding: "
+          f"{[(r['i'], r['status']) for r in res if r['status'] != 'ok']}, "
           f"{time.time() - t0:.0f} s")

@@ -33,6 +33,7 @@
 
 #include "qr_internal.h"
 #include "qr_wave.h"
+#include "qr_prep.h"
 
 #define NO_CUTOFF 0xFFFFFFFFu
 
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
     const double *__restrict__ ilg2, double *__restrict__ lambda,
     double *__restrict__ weight, double *__restrict__ qmetric,
     uint32_t *__restrict__ ranks_out, double *__restrict__ ssq, double *__restrict__ qmax,
-    QrScalars *__restrict__ scal, uint32_t nmax, uint32_t kacc, int mode,
+    unsigned long long *__restrict__ qslot, uint32_t nmax, uint32_t kacc, int mode,
     const uint8_t *__restrict__ present, const uint8_t *__restrict__ long_flag,
     const uint32_t *__restrict__ long_list, char *__restrict__ lscratch, const size_t lstride,
     const int exact_tail) {
@@ -1025,6 +1026,11 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
     ssq[2 * q] = sq;
     ssq[2 * q + 1] = sm;
     qmax[q] = mx;
+    // ... and into the iteration's slot set (qr_prep.h), for the launches that need the scale
+    // before the scalars are finished: one atomic that returns nothing, on one of 64 words
+    if (qslot && mx > 0.0)
+      (void)__hip_atomic_fetch_max(&qslot[q % QR_PREP_SLOTS], (unsigned long long)__double_as_longlong(mx),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #ifdef QR_LAMBDA_TIMING
   QR_T(6);
@@ -1076,114 +1082,10 @@ __global__ __launch_bounds__(256) void k_residual(const float *__restrict__ labe
 // the scalars into the pinned host block, every field EXCEPT `pad`: that word is the
 // launch's sequence number and only ever moves forward (stored last, by the caller, behind a
 // system-scope fence); a whole-struct copy would first put the device's 0 over it
-__device__ __forceinline__ void scalars_to_host(QrScalars *__restrict__ host_copy, const QrScalars *__restrict__ scal) {
-  host_copy->maxabs_bits = scal->maxabs_bits;
-  host_copy->scale_exp = scal->scale_exp;
-  host_copy->scale = scal->scale;
-  host_copy->inv_scale = scal->inv_scale;
-  host_copy->root_ss = scal->root_ss;
-  host_copy->root_sum = scal->root_sum;
-  host_copy->metric_sum = scal->metric_sum;
-  host_copy->metric_gsum = scal->metric_gsum;
-}
-
-// Fixed-order reduction of the per-query / per-slice partials + the quantisation scale for
-// the histogram accumulators.  The order is the one a single workgroup of 1024 threads
-// gives -- thread t adds elements t, t + 1024, ..., a wave adds its lanes, the 16 waves'
-// sums are added in wave order -- but every "wave" is a workgroup of its own here (16
-// workgroups of 64 threads: one CU took 10 us to pull 10,000 queries' values through its
-// memory pipe, 34 us for 80,000), and the one that arrives last at the ticket adds the 16
-// partials and finishes the scalars.  Bit for bit the single-workgroup values.
-__global__ __launch_bounds__(64) void k_prep(const double *__restrict__ ssq,
-                                             uint32_t nss,
-                                             const double *__restrict__ qmetric,
-                                             uint32_t nq,
-                                             const double *__restrict__ qmax, uint32_t nmx,
-                                             QrScalars *__restrict__ scal,
-                                             const int reset_max,
-                                             QrScalars *__restrict__ host_copy, const int seq,
-                                             double *__restrict__ part, uint32_t *__restrict__ ticket) {
-  double a = 0.0, b = 0.0, a2 = 0.0;
-  double m = 0.0;  // max |pseudo-response| over the per-query / per-slice maxima
-  // one loop, so that the three arrays' loads are in flight together (same additions in
-  // the same order per accumulator as three loops)
-  const uint32_t nall = nss > nq ? (nss > nmx ? nss : nmx) : (nq > nmx ? nq : nmx);
-  const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
-  // sixteen rounds of loads leave together, then the additions in the usual order
-  for (uint32_t i0 = slot; i0 < nall; i0 += 16 * 1024) {
-    double2 v[16];
-    double w[16], x[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint32_t i = i0 + k * 1024;
-      v[k] = i < nss ? *reinterpret_cast<const double2 *>(ssq + 2 * i) : make_double2(0.0, 0.0);
-      w[k] = i < nq ? qmetric[i] : 0.0;
-      x[k] = i < nmx ? qmax[i] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint32_t i = i0 + k * 1024;
-      if (i < nss) {
-        a += v[k].x;
-        a2 += v[k].y;
-      }
-      if (i < nq) b += w[k];
-      if (i < nmx) m = fmax(m, x[k]);
-    }
-  }
-  m = wave_max(m);
-  a = wave_sum(a);
-  a2 = wave_sum(a2);
-  b = wave_sum(b);
-  __shared__ uint32_t sh_last;
-  if (threadIdx.x == 0) {
-    // (agent scope: the sixteen workgroups sit on different XCDs, one L2 each)
-    __hip_atomic_store(&part[4 * blockIdx.x], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&part[4 * blockIdx.x + 1], a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&part[4 * blockIdx.x + 2], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&part[4 * blockIdx.x + 3], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!sh_last) return;
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-    double ta = 0.0, ta2 = 0.0, tb = 0.0, tm = 0.0;
-    for (uint32_t i = 0; i < gridDim.x; ++i) {
-      ta += __hip_atomic_load(&part[4 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ta2 += __hip_atomic_load(&part[4 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      tb += __hip_atomic_load(&part[4 * i + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      tm = fmax(tm, __hip_atomic_load(&part[4 * i + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
-    if (ssq) {
-      scal->root_ss = ta;
-      scal->root_sum = ta2;
-    }
-    if (qmetric) scal->metric_sum = tb;
-    if (ssq) {
-      // (maxabs_bits: what qr_pseudo_set or a document-sharded exchange put there)
-      double mx = fmax(__longlong_as_double((long long)scal->maxabs_bits), tm);
-      scal->maxabs_bits = (unsigned long long)__double_as_longlong(mx);
-      int x = 0;
-      if (mx > 0.0) frexp(mx, &x);  // mx = m * 2^x, m in [0.5, 1)  =>  mx < 2^x
-      const int e = QR_QBITS - x;
-      scal->scale_exp = e;
-      scal->scale = ldexp(1.0, e);
-      scal->inv_scale = ldexp(1.0, -e);
-      // ready for the next iteration's atomicMax (document-sharded contexts still
-      // have to pack it for the exchange: k_scal_global clears it there)
-      if (reset_max) scal->maxabs_bits = 0;
-    }
-    // read-back without a copy launch: the finished scalars go straight into the pinned
-    // host block; `pad` = the launch's sequence number, stored LAST behind a system-scope
-    // fence: the host polls it (wait_seq_impl in qr_api.hip) instead of waiting for an event
-    if (host_copy) {
-      scalars_to_host(host_copy, scal);
-      __threadfence_system();
-      __hip_atomic_store(&host_copy->pad, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
+// The per-iteration scalars in a launch of their own (qr_prep.h: prep_body; the batched and
+// level-wise growth paths let the same sixteen workgroups ride in their root scan launch
+// instead, k_tree.hip).
+__global__ __launch_bounds__(64) void k_prep(const QrPrepJob j) { prep_body<16>(j, blockIdx.x, gridDim.x); }
 
 // ---------------------------------------------------------------------------
 static size_t lambda_lds(size_t nmax, size_t kacc, bool sampled) {
@@ -1286,6 +1188,13 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   uint32_t *ranks = which ? nullptr : c->d_ranks;
   double *ssq = (!which && mode == 0) ? c->d_ssq : nullptr;
   if (ssq) c->nqmax = c->Q;
+  // the iteration's slot set (qr_prep.h): the sets alternate from one lambda pass to the next
+  // (document-sharded contexts exchange the maximum between the ranks first: no slots there)
+  unsigned long long *qslot = nullptr;
+  if (ssq && !c->dmode) {
+    c->prep_parity ^= 1;
+    qslot = qr_prep_slots(c, c->prep_parity);
+  }
   const int md = which ? 1 : mode;
   const uint8_t *present = (!which && mode == 0 && c->sub_k) ? c->d_present : nullptr;
   // One launch per size class (its LDS sized for the class's longest query), the launches
@@ -1335,17 +1244,17 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     // long queries: four waves each (not with a sample: the cleaning is one wave's code)
     if (cl.nmax > 512 && !sampled)
       hipLaunchKernelGGL((k_lambda<false, 16>), dim3(cl.count), dim3(1024), lds, st, sc, lb, qoffd, metric, cut,
-                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars, (uint32_t)nmax,
+                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
                          (size_t)0, c->exact_tail);
     else if (cl.nmax > 256 && !sampled)
       hipLaunchKernelGGL((k_lambda<false, 4>), dim3(cl.count), dim3(256), lds, st, sc, lb, qoffd, metric, cut,
-                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars, (uint32_t)nmax,
+                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
                          (size_t)0, c->exact_tail);
     else
       hipLaunchKernelGGL((k_lambda<false, 1>), dim3(cl.count), dim3(64), lds, st, sc, lb, qoffd, metric, cut,
-                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars, (uint32_t)nmax,
+                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
                          (size_t)0, c->exact_tail);
     QR_CHECK(c, hipGetLastError());
@@ -1355,7 +1264,7 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     int rc = stream_for(li++, &st);
     if (rc) return rc;
     hipLaunchKernelGGL((k_lambda<true, 1>), dim3((unsigned)nlong), dim3(64), 0, st, sc, lb, qoffd, metric, cut,
-                       idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, c->d_scalars,
+                       idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot,
                        (uint32_t)nmax_long, (uint32_t)std::min(kacc, nmax_long), md, present,
                        (const uint8_t *)nullptr, (const uint32_t *)c->d_long_list[which], c->d_lscratch, lstride,
                        c->exact_tail);
@@ -1380,16 +1289,41 @@ int qr_k_residual(qr_ctx *c) {
 
 // nss > 0: reduce ssq[nss] into root_ss and derive the scale; the per-query
 // metric of set `which` (encoded in the sign: nss == 0 means metric only).
+// the arguments of the prep workgroups for the scalars of this iteration (`nss` entries of
+// d_ssq / d_qmax; `with_metric`: the per-query metric too; `publish`: into the pinned block)
+void qr_k_prep_job(qr_ctx *c, size_t nss, int with_metric, int publish, QrPrepJob *j) {
+  j->ssq = nss ? c->d_ssq : (const double *)nullptr;
+  j->nss = (uint32_t)nss;
+  j->qmetric = with_metric ? c->d_qmetric : (const double *)nullptr;
+  j->nq = with_metric ? (uint32_t)c->Q : 0u;
+  j->qmax = nss ? c->d_qmax : (const double *)nullptr;
+  j->nmx = nss ? (uint32_t)c->nqmax : 0u;
+  j->scal = c->d_scalars;
+  j->reset_max = c->dmode ? 0 : 1;
+  j->host_copy = publish ? &c->d_pin->scal : (QrScalars *)nullptr;
+  j->seq = publish ? qr_next_scal_seq(c) : 0;
+  j->part = c->d_prep_part;
+  j->ticket = reinterpret_cast<uint32_t *>(c->d_prep_part + 64);
+  // (whoever finishes an iteration's scalars clears the set the NEXT lambda pass fills)
+  j->zero_slots = c->dmode ? (unsigned long long *)nullptr : qr_prep_slots(c, c->prep_parity ^ 1);
+  j->slots = nullptr;
+  j->nwg = 16;
+}
+
 int qr_k_prep(qr_ctx *c, size_t nss, int with_metric, int publish) {
-  hipLaunchKernelGGL(k_prep, dim3(16), dim3(64), 0, c->stream,
-                     nss ? c->d_ssq : (const double *)nullptr, (uint32_t)nss,
-                     with_metric ? c->d_qmetric : (const double *)nullptr,
-                     with_metric ? (uint32_t)c->Q : 0u, nss ? c->d_qmax : (const double *)nullptr,
-                     nss ? (uint32_t)c->nqmax : 0u, c->d_scalars, c->dmode ? 0 : 1,
-                     publish ? &c->d_pin->scal : (QrScalars *)nullptr, publish ? qr_next_scal_seq(c) : 0,
-                     c->d_prep_part, reinterpret_cast<uint32_t *>(c->d_prep_part + 64));
+  QrPrepJob j;
+  qr_k_prep_job(c, nss, with_metric, publish, &j);
+  hipLaunchKernelGGL(k_prep, dim3(16), dim3(64), 0, c->stream, j);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
+}
+
+// a lambda pass whose scalars have not been finished yet (qr_lambda_compute defers them to
+// the root scan launch of the tree that follows): finish them now, in a launch of their own
+int qr_k_prep_flush(qr_ctx *c) {
+  if (!c->prep_deferred) return QR_OK;
+  c->prep_deferred = false;
+  return qr_k_prep(c, c->prep_nss, c->prep_with_metric, c->prep_publish);
 }
 
 // ---------------------------------------------------------------------------
@@ -1454,11 +1388,13 @@ int qr_k_prep_global(qr_ctx *c) {
 }
 
 int qr_k_metric_reduce(qr_ctx *c, int which) {
-  hipLaunchKernelGGL(k_prep, dim3(16), dim3(64), 0, c->stream,
-                     (const double *)nullptr, 0u,
-                     which ? c->d_vqmetric : c->d_qmetric,
-                     (uint32_t)(which ? c->vQ : c->Q), (const double *)nullptr, 0u, c->d_scalars, 0,
-                     (QrScalars *)nullptr, 0, c->d_prep_part, reinterpret_cast<uint32_t *>(c->d_prep_part + 64));
+  QrPrepJob j;
+  qr_k_prep_job(c, 0, 0, 0, &j);
+  j.qmetric = which ? c->d_vqmetric : c->d_qmetric;
+  j.nq = (uint32_t)(which ? c->vQ : c->Q);
+  j.reset_max = 0;
+  j.zero_slots = nullptr;
+  hipLaunchKernelGGL(k_prep, dim3(16), dim3(64), 0, c->stream, j);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

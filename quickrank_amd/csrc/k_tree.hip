@@ -36,6 +36,7 @@
 #include "qr_internal.h"
 #include "qr_wave.h"
 #include "qr_dev.h"
+#include "qr_prep.h"
 
 // ===========================================================================
 // k_hist
@@ -89,9 +90,13 @@ template <int CH, bool IDENTITY, bool SUMS = false>
 __device__ __forceinline__ void hist_accumulate(
     u64 *__restrict__ hist, const uint8_t *__restrict__ bins_b,
     const uint32_t *__restrict__ order, const uint32_t seg_begin, const uint32_t r0,
-    const uint32_t r1, const double *__restrict__ lambda, const double scale, double *sq = nullptr,
-    double *sm = nullptr) {
+    const uint32_t r1, const double *__restrict__ lambda, const double scale_in, double *sq = nullptr,
+    double *sm = nullptr, const u64 slot_word = 0, const bool use_slot = false) {
   // (the caller has NOT zeroed `hist`: that happens below, behind the first loads)
+  // use_slot (the root launch when the iteration's scalars are not finished yet, qr_prep.h):
+  // the scale comes from the slot word this lane loaded at the top of the kernel; it is
+  // derived below, behind the first tiles' requests, so that no load waits for it
+  double scale = scale_in;
   constexpr int FW = 16 * CH;
   constexpr int DW = 64 / CH;
   const int lane = threadIdx.x & 63;
@@ -187,6 +192,7 @@ __device__ __forceinline__ void hist_accumulate(
     hist[i] = 0;
     hist[i + 1] = 0;
   }
+  if (use_slot) scale = ldexp(1.0, qr_slot_scale_exp(slot_word));
   __syncthreads();
   QR_HT(3);
   uint32_t pos = p0;
@@ -209,7 +215,8 @@ __device__ __forceinline__ void hist_run(
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const double scale, u64 *__restrict__ partials, const bool tr = false, const int fw_known = 0,
-    const size_t off_known = 0, double *__restrict__ sums_out = nullptr);
+    const size_t off_known = 0, double *__restrict__ sums_out = nullptr, const u64 slot_word = 0,
+    const bool use_slot = false);
 
 // One workgroup's share of a node histogram: workgroup `wg` of the `G` that the
 // plan hands to a node of n documents; partial slots start at `slot_base`.
@@ -218,7 +225,8 @@ __device__ __forceinline__ void hist_body(
     const int wg, const size_t slot_base, const QrBlock *__restrict__ blocks, const int nblocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const double scale, u64 *__restrict__ partials, const bool tr = false) {
+    const double scale, u64 *__restrict__ partials, const bool tr = false, const u64 slot_word = 0,
+    const bool use_slot = false) {
   __shared__ QrPlan plan;
   if (threadIdx.x == 0) qr_make_plan(n, nblocks, blocks, q, &plan);
   __syncthreads();
@@ -231,7 +239,7 @@ __device__ __forceinline__ void hist_body(
   const uint32_t r0 = j * per;
   const uint32_t r1 = (r0 + per < n) ? r0 + per : n;
   hist_run(hist, seg_begin, r0, r1, buf, b, slot_base + (size_t)wg * plan.kmax, blocks, bins, order0,
-           order1, lambda, scale, partials, tr);
+           order1, lambda, scale, partials, tr, 0, 0, nullptr, slot_word, use_slot);
 }
 
 // positions [r0, r1) of the segment at seg_begin, for feature block b; partial slots
@@ -245,7 +253,7 @@ __device__ __forceinline__ void hist_run(
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const double scale, u64 *__restrict__ partials, const bool tr, const int fw_known,
-    const size_t off_known, double *__restrict__ sums_out) {
+    const size_t off_known, double *__restrict__ sums_out, const u64 slot_word, const bool use_slot) {
   // (batched growth hands the block's geometry over with the workgroup's share: one
   // dependent read less before the first bins can be requested)
   const int fw = fw_known ? fw_known : blocks[b].fw;
@@ -267,17 +275,17 @@ __device__ __forceinline__ void hist_run(
     } else
     if (identity) {
       switch (fw) {
-        case 16: hist_accumulate<1, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
-        case 32: hist_accumulate<2, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
-        case 48: hist_accumulate<3, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
-        default: hist_accumulate<4, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
+        case 16: hist_accumulate<1, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, nullptr, nullptr, slot_word, use_slot); break;
+        case 32: hist_accumulate<2, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, nullptr, nullptr, slot_word, use_slot); break;
+        case 48: hist_accumulate<3, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, nullptr, nullptr, slot_word, use_slot); break;
+        default: hist_accumulate<4, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, nullptr, nullptr, slot_word, use_slot); break;
       }
     } else {
       switch (fw) {
-        case 16: hist_accumulate<1, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
-        case 32: hist_accumulate<2, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
-        case 48: hist_accumulate<3, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
-        default: hist_accumulate<4, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale); break;
+        case 16: hist_accumulate<1, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, nullptr, nullptr, slot_word, use_slot); break;
+        case 32: hist_accumulate<2, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, nullptr, nullptr, slot_word, use_slot); break;
+        case 48: hist_accumulate<3, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, nullptr, nullptr, slot_word, use_slot); break;
+        default: hist_accumulate<4, false>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, nullptr, nullptr, slot_word, use_slot); break;
       }
     }
     __syncthreads();
@@ -366,12 +374,17 @@ __global__ __launch_bounds__(1024) void k_hist_root(
     const uint32_t N, const QrBlock *__restrict__ blocks, const int nblocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const double *__restrict__ lambda, const QrScalars *__restrict__ scal,
-    u64 *__restrict__ partials, const int root_buf, const int tr) {
+    u64 *__restrict__ partials, const int root_buf, const int tr,
+    const unsigned long long *__restrict__ slots) {
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
+  // `slots`: the iteration's scalars are finished by workgroups of the scan launch BEHIND this
+  // one (qr_prep.h); the scale comes from the slot set the lambda pass filled, a word per lane
+  const u64 slot_word = slots ? slots[threadIdx.x & (QR_PREP_SLOTS - 1)] : 0ull;
+  const double scale = slots ? 0.0 : scal->scale;
   const uint32_t q =
       qr_plan_quantum((unsigned long long)N * qr_plan_wsum(nblocks, blocks), (int)gridDim.x - nblocks);
   hist_body(hist, 0, N, root_buf, q, (int)blockIdx.x, 0, blocks, nblocks, bins, order0, order0, lambda,
-            scal->scale, partials, tr != 0);
+            scale, partials, tr != 0, slot_word, slots != nullptr);
 }
 
 // level-wise (oblivious) growth: the directly built children of ALL nodes of the
@@ -758,10 +771,19 @@ __global__ __launch_bounds__(1024) void k_redscan(
     const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
     qr_split_t *__restrict__ featrec, const float *__restrict__ thr,
     float *__restrict__ featthr, const QrScanWg *__restrict__ descs, const u64 minls,
-    const double *__restrict__ part_ss, double *__restrict__ jobsum) {
+    const double *__restrict__ part_ss, double *__restrict__ jobsum, const QrPrepJob prep) {
   __shared__ long long cs_s[3][256];
   __shared__ uint32_t cs_c[3][256];
   __shared__ QrPlan sh_plan;
+  // the ROOT launch of an iteration whose scalars are not finished yet (prep.nwg > 0,
+  // qr_prep.h): prep.nwg more workgroups ride behind the features' -- one wave each, what k_prep
+  // does in a launch of its own -- and the features' workgroups take the scale from the slots
+  if (prep.nwg && (int)blockIdx.x >= flocal) {
+    if (threadIdx.x >= 64) return;
+    prep_body<8>(prep, blockIdx.x - (uint32_t)flocal, (uint32_t)prep.nwg);
+    return;
+  }
+  const u64 slot_word = prep.nwg ? prep.slots[threadIdx.x & (QR_PREP_SLOTS - 1)] : 0ull;
   const int lf = blockIdx.x;
   const uint32_t t = threadIdx.x & 255, g = threadIdx.x >> 8;
   // a node of the batch: everything comes ready-made from the control kernel (ONE
@@ -772,7 +794,7 @@ __global__ __launch_bounds__(1024) void k_redscan(
   // everything that does not depend on the descriptor is requested with it: the feature's
   // global index, its number of thresholds, the slot's threshold value, the scale
   const int gf_top = lf2gf[lf];
-  const double inv_top = scal->inv_scale;
+  double inv_top = prep.nwg ? 0.0 : scal->inv_scale;
   QrScanWg d;
   if (!root) d = descs[(size_t)blockIdx.y * flocal + lf];
   const uint32_t tsize_top = thr_size[gf_top];
@@ -853,6 +875,7 @@ __global__ __launch_bounds__(1024) void k_redscan(
     s += cs_s[i][t];
     cn += cs_c[i][t];
   }
+  if (prep.nwg) inv_top = ldexp(1.0, -qr_slot_scale_exp(slot_word));
   scan_core(root, small_slot, big_slot, parent_slot, small_is_left, minls, lf, s, cn, 0u, hsum,
             hcnt, flocal, thr_size, lf2gf, scal, featrec + (size_t)2 * (root ? 0 : blockIdx.y) * flocal,
             nullptr, my_thr, featthr + (size_t)2 * (root ? 0 : blockIdx.y) * flocal, !root, par_s,
@@ -3439,6 +3462,24 @@ static size_t hist_lds(const qr_ctx *c) {
 static int launch_scan(qr_ctx *c, int root_mode);
 
 static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
+  // The scalars of the lambda pass before this tree may still be unfinished (qr_lambda_compute
+  // defers them, qr_prep.h).  The fused root launches let the workgroups that finish them ride
+  // in the scan launch and take the scale from the iteration's slot set meanwhile; every other
+  // path has them finished first, in a launch of their own.
+  const bool ride = c->prep_deferred && root_mode && fused && !c->wide;
+  if (c->prep_deferred && !ride) {
+    const int frc = qr_k_prep_flush(c);
+    if (frc) return frc;
+  }
+  QrPrepJob prep{};
+  const unsigned long long *root_slots = nullptr;
+  if (ride) {
+    c->prep_deferred = false;
+    qr_k_prep_job(c, c->prep_nss, c->prep_with_metric, c->prep_publish, &prep);
+    root_slots = prep.slots = qr_prep_slots(c, c->prep_parity);
+  } else {
+    prep.nwg = 0;
+  }
   if (c->wide) {  // more than 255 thresholds: k_wide.hip
     const int wrc = qr_k_whist_scan(c, root_mode);
     if (wrc) return wrc;
@@ -3474,13 +3515,13 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
       QR_CHECK(c, hipEventCreate(&e1));
       hipExtLaunchKernelGGL(k_hist_root, dim3(G), dim3(1024), lds, c->stream, e0, e1, 0, rootn,
                             c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_lambda,
-                            c->d_scalars, (u64 *)c->d_partials, root_buf, fused ? 1 : 0);
+                            c->d_scalars, (u64 *)c->d_partials, root_buf, fused ? 1 : 0, root_slots);
       QR_CHECK(c, hipGetLastError());
       c->prof_events.push_back({e0, e1});
     } else {
       hipLaunchKernelGGL(k_hist_root, dim3(G), dim3(1024), lds, c->stream, rootn, c->d_blocks,
                          c->nblocks, c->d_bins, c->d_order[0], c->d_lambda, c->d_scalars,
-                         (u64 *)c->d_partials, root_buf, fused ? 1 : 0);
+                         (u64 *)c->d_partials, root_buf, fused ? 1 : 0, root_slots);
       QR_CHECK(c, hipGetLastError());
     }
   } else {
@@ -3491,11 +3532,11 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
     QR_CHECK(c, hipGetLastError());
   }
   if (fused) {  // batched growth: feature-major partials, reduce + scan in one launch
-    hipLaunchKernelGGL(k_redscan, dim3(c->flocal, 1), dim3(1024), 0, c->stream, c->d_tree, 1, rootn,
+    hipLaunchKernelGGL(k_redscan, dim3(c->flocal + prep.nwg, 1), dim3(1024), 0, c->stream, c->d_tree, 1, rootn,
                        c->d_lplan, c->d_blocks, c->nblocks, G, (const u64 *)c->d_partials, c->d_hsum,
                        c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec,
                        c->d_thr, c->d_featthr, (const QrScanWg *)nullptr, (u64)c->cur_minls,
-                       (const double *)nullptr, (double *)nullptr);
+                       (const double *)nullptr, (double *)nullptr, prep);
     QR_CHECK(c, hipGetLastError());
     return QR_OK;
   }
@@ -3632,7 +3673,8 @@ static int launch_batch_hist_scan(qr_ctx *c, const unsigned hg, const uint32_t r
   hipLaunchKernelGGL(k_redscan, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_tree, 0,
                      rootn, c->d_lplan, c->d_blocks, c->nblocks, c->ncu, (const u64 *)c->d_lpartials,
                      c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars,
-                     c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg, (u64)minls, c->d_lhistsum, c->d_jobsum);
+                     c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg, (u64)minls, c->d_lhistsum, c->d_jobsum,
+                     QrPrepJob{});
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

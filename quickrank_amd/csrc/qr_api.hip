@@ -91,6 +91,7 @@ int qr_ctx_create(int device, qr_ctx **out) {
   }
   qr_ctx *c = new qr_ctx();
   c->no_batch = getenv("QR_NO_BATCH") != nullptr;
+  c->no_defer = getenv("QR_NO_DEFER_PREP") != nullptr;
   c->exact_tail = getenv("QR_EXACT_TAIL") != nullptr;
   if (getenv("QR_LEAF_BY_POSITION")) c->leaf_by_position = true;
   if (const char *e = getenv("QR_STEPS_HINT")) c->steps_force = atol(e);  // steps to enqueue, whatever the tree
@@ -116,8 +117,8 @@ int qr_ctx_create(int device, qr_ctx **out) {
   // (coherent = fine-grained: a kernel's stores are visible to the host while it runs)
   if (hipHostMalloc((void **)&c->h_pin, sizeof(QrPinned), hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer((void **)&c->d_pin, c->h_pin, 0) != hipSuccess ||
-      hipMalloc((void **)&c->d_prep_part, 72 * 8) != hipSuccess ||
-      hipMemset(c->d_prep_part, 0, 72 * 8) != hipSuccess) {
+      hipMalloc((void **)&c->d_prep_part, QR_PREP_WORDS * 8) != hipSuccess ||
+      hipMemset(c->d_prep_part, 0, QR_PREP_WORDS * 8) != hipSuccess) {
     qr_ctx_destroy(c);
     g_create_err = "allocating the read-back buffers failed";
     return QR_ERR_HIP;
@@ -1012,6 +1013,15 @@ int qr_lambda_compute(qr_ctx *c, int metric, size_t cutoff) {
   if (rc) return rc;
   // sum of squares / sum / quantisation scale and the metric of the ranking, one launch
   // (documents outside a sample have lambda == 0: the sums are the sample's)
+  if (!c->dmode && !c->no_defer) {
+    // the launch that finishes them is deferred: the tree's root scan launch carries its
+    // workgroups (k_tree.hip: launch_hist_scan), anything else finishes them first
+    c->prep_deferred = true;
+    c->prep_nss = c->Q;
+    c->prep_with_metric = 1;
+    c->prep_publish = 1;
+    return snapshot_scalars(c);
+  }
   if ((rc = qr_k_prep(c, c->Q, 1, c->dmode ? 0 : 1))) return rc;
   if (!c->dmode) return snapshot_scalars(c);
   return qr_k_prep_pack(c);  // then: all-reduce the scalar buffer, qr_lambda_finish
@@ -1069,6 +1079,8 @@ int qr_metric_last(qr_ctx *c, double *out) {
   if (!c || !out) return QR_ERR_ARG;
   if (!c->scal_pending)
     QR_FAIL(c, QR_ERR_STATE, "qr_metric_last follows qr_lambda_compute (+ qr_lambda_finish)");
+  // (scalars nobody has finished yet: no tree followed the lambda pass)
+  { const int frc = qr_k_prep_flush(c); if (frc) return frc; }
   // waits for the lambda pass only; whatever was enqueued after it keeps running
   { const int wrc = wait_seq32(c, &c->h_pin->scal.pad, c->scal_seq, "the iteration's scalars"); if (wrc) return wrc; }
   const QrScalars &s = c->h_pin->scal;
@@ -1264,7 +1276,18 @@ static int wait_early(qr_ctx *c, int64_t *word_out) {
   }
 }
 
+// (a lambda pass whose scalars are still to be finished -- qr_lambda_compute defers them to the
+// root scan launch of the tree that follows, qr_prep.h -- gets them finished here, in a launch
+// of their own: whoever settles is about to read or change something they depend on.  The two
+// entry points that can let them ride, qr_tree_fit and qr_oblivious_fit, settle with
+// tree_settle_keep.)
+static int tree_settle_keep(qr_ctx *c);
 static int tree_settle(qr_ctx *c) {
+  const int rc = tree_settle_keep(c);
+  if (rc) return rc;
+  return qr_k_prep_flush(c);
+}
+static int tree_settle_keep(qr_ctx *c) {
   if (!c->spec_pending) return QR_OK;
   // (the last control call's word, QrPinned::early -- not the records: the leaf kernels and the
   // score update behind that call are still running, and whatever the caller enqueues next
@@ -1299,7 +1322,9 @@ static int tree_settle(qr_ctx *c) {
 int qr_tree_nodes(qr_ctx *c, qr_node_t *nodes_out, size_t *nnodes_out) {
   if (!c) return QR_ERR_ARG;
   if (!c->nodes_pending) QR_FAIL(c, QR_ERR_STATE, "no fitted tree");
-  int rc = tree_settle(c);
+  // (the hosts read tree i's records between iteration i + 1's lambda pass and its tree: the
+  // records do not depend on that pass's scalars, which stay deferred for the tree's root scan)
+  int rc = tree_settle_keep(c);
   if (rc) return rc;
   { const int wrc = wait_seq64(c, &c->h_pin->tree.pad[2], c->nodes_seq, "the tree's records"); if (wrc) return wrc; }
   const size_t n = (size_t)c->h_pin->tree.nnodes;
@@ -1340,7 +1365,7 @@ int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
             "sharded contexts must drive qr_tree_begin/decide/apply/end "
             "with the collectives in between");
   {
-    const int src = tree_settle(c);
+    const int src = tree_settle_keep(c);  // (deferred scalars ride in the root scan launch, or are flushed there)
     if (src) return src;
   }
   // up to QR_BATCH splits per step (k_decide_batch); per-node feature subsets are keyed by
@@ -1382,7 +1407,7 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
                      qr_node_t *nodes_out, size_t *nnodes_out) {
   if (!c) return QR_ERR_ARG;
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
-  { const int src_ = tree_settle(c); if (src_) return src_; }
+  { const int src_ = tree_settle_keep(c); if (src_) return src_; }
   if (c->world > 1 || c->dmode)
     QR_FAIL(c, QR_ERR_STATE,
             "sharded contexts grow oblivious trees phase by phase (qr_obl_begin / propose / [mark] / "

@@ -372,7 +372,16 @@ struct qr_ctx {
   // pinned block and then a sequence number behind a system-scope fence; the host polls that
   // number (wait_seq_impl in qr_api.hip).  No event on the stream: an event record between two
   // kernels was ~6 us of idle GPU each, and waking the host from hipEventSynchronize ~25 us.
-  double *d_prep_part = nullptr;  // k_prep: [16][4] workgroup partials + its ticket
+  double *d_prep_part = nullptr;  // k_prep: [16][4] workgroup partials + its ticket (word 64) + two slot sets (from word 72)
+  // qr_prep.h: the lambda pass leaves the iteration's max |pseudo-response| in a slot set;
+  // qr_lambda_compute DEFERS the launch that finishes the scalars: batched / level-wise growth
+  // lets its workgroups ride in the tree's root scan launch (one launch less per iteration),
+  // everything else that needs the scalars finishes them first (qr_k_prep_flush).
+  int prep_parity = 0;            // slot set of the last lambda pass
+  bool prep_deferred = false;     // the scalars of the last lambda pass are still to be finished
+  bool no_defer = false;          // QR_NO_DEFER_PREP=1: always a launch of its own (A/B, debugging)
+  size_t prep_nss = 0;
+  int prep_with_metric = 0, prep_publish = 0;
   int32_t scal_seq = 0;   // of the last launch that publishes the scalars
   int64_t nodes_seq = 0;  // of the last launch that publishes tree records
   int64_t early_seq = 0;  // of the last final control call (QrPinned::early)
@@ -541,6 +550,13 @@ int qr_k_wobl_hist(qr_ctx *c, int nodes);
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode);
 int qr_k_residual(qr_ctx *c);
 int qr_k_prep(qr_ctx *c, size_t nslices, int with_metric, int publish = 0);
+struct QrPrepJob;
+void qr_k_prep_job(qr_ctx *c, size_t nss, int with_metric, int publish, QrPrepJob *j);
+int qr_k_prep_flush(qr_ctx *c);
+#define QR_PREP_WORDS (72 + 2 * 64)  /* d_prep_part: partials, ticket, two slot sets of 64 words */
+inline unsigned long long *qr_prep_slots(qr_ctx *c, int parity) {
+  return reinterpret_cast<unsigned long long *>(c->d_prep_part + 72 + 64 * (parity & 1));
+}
 inline int qr_next_scal_seq(qr_ctx *c) {  // never 0: the value the block starts with
   c->scal_seq = c->scal_seq == 0x7fffffff ? 1 : c->scal_seq + 1;
   return c->scal_seq;

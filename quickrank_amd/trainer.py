@@ -101,18 +101,20 @@ class Mart:
             t0 = time.perf_counter()
             if lam:
                 self.ctx.compute_lambdas(self.metric, self.cutoff)
-                if fused and m > 0:
-                    mt = self.ctx.metric_last()
-                    self.train_metric.append(mt)
-                    if mt > best_train:
-                        best_train = mt
-                        self.best_model = m - 1
             else:
                 self.ctx.compute_residuals()
             nodes = self._fit_tree(newton=lam)
             self.ensemble.push(nodes, self.shrinkage)
             self.ctx.update_scores(self.shrinkage)
             if fused:
+                # (read AFTER the tree is enqueued: the scalars of the lambda pass are finished
+                # by workgroups riding in the tree's root scan launch, csrc/qr_prep.h)
+                if m > 0:
+                    mt = self.ctx.metric_last()
+                    self.train_metric.append(mt)
+                    if mt > best_train:
+                        best_train = mt
+                        self.best_model = m - 1
                 self.iter_seconds.append(time.perf_counter() - t0)
                 continue
             mt = self.ctx.metric_eval(0, self.metric, self.cutoff) if eval_every else 0.0

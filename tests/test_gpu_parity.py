@@ -866,6 +866,46 @@ def test_guessed_step_count_and_continuation(qr, ora, monkeypatch, hint):
     gm.ctx.close()
 
 
+@pytest.mark.parametrize("algo,subsample,ragged", [("LAMBDAMART", 1.0, False), ("LAMBDAMART", 1.0, True),
+                                                    ("LAMBDAMART", 0.6, True), ("OBVLAMBDAMART", 1.0, True)])
+def test_scalars_finished_in_the_root_scan_launch_equal_the_launch_of_their_own(qr, monkeypatch, algo,
+                                                                                subsample, ragged):
+    """qr_lambda_compute defers the launch that finishes the iteration's scalars (quantisation
+    scale, the root's sums, the metric): batched and level-wise growth let its workgroups ride in
+    the tree's root scan launch, and the root histogram / root scan take the scale from the slot
+    set the lambda pass filled (csrc/qr_prep.h).  QR_NO_DEFER_PREP=1 keeps the launch of its own.
+    Same additions in the same order: trees, metrics and scores bit for bit -- over enough
+    iterations for both slot sets to be reused, on ragged query sets (several lambda launches
+    fill one slot set) and with a sample."""
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(nq=180, docs_per_query=70, F=30, seed=57, ragged=ragged)
+    kw = dict(ntrees=7, shrinkage=0.1, nthresholds=64, minls=2, esr=0)
+    if algo.startswith("OBV"):
+        kw["depth"] = 4
+    else:
+        kw["nleaves"] = 9
+    if subsample != 1.0:
+        kw["subsample"] = subsample
+    got = Mart(algo=algo, **kw).learn(x, labels, qoff)
+    monkeypatch.setenv("QR_NO_DEFER_PREP", "1")
+    want = Mart(algo=algo, **kw).learn(x, labels, qoff)
+    monkeypatch.delenv("QR_NO_DEFER_PREP")
+    for t in range(kw["ntrees"]):
+        g, w = got.ensemble.trees[t], want.ensemble.trees[t]
+        assert len(g) == len(w)
+        for f in g.dtype.names:
+            assert np.array_equal(g[f], w[f]), (t, f)
+    assert np.array_equal(np.asarray(got.train_metric), np.asarray(want.train_metric))
+    assert np.array_equal(got.ctx.get_scores(), want.ctx.get_scores())
+    # a lambda pass that no tree follows: the scalars are finished on demand
+    got.ctx.compute_lambdas("NDCG", 10)
+    m1 = got.ctx.metric_last()
+    want.ctx.compute_lambdas("NDCG", 10)
+    assert m1 == want.ctx.metric_last()
+    got.ctx.close()
+    want.ctx.close()
+
+
 @pytest.mark.parametrize("algo,nleaves,subsample", [("LAMBDAMART", 10, 1.0), ("LAMBDAMART", 16, 0.5),
                                                      ("MART", 7, 1.0), ("OBVLAMBDAMART", 16, 1.0)])
 def test_leaf_sums_in_document_order_equal_the_position_order(qr, monkeypatch, algo, nleaves, subsample):

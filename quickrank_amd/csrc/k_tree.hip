@@ -3101,20 +3101,41 @@ __global__ __launch_bounds__(256) void k_obl_fill(
   const u64 minls = ts->minls;
   const double inv_scale = scal->inv_scale;
   const int lbegin = (1 << level) - 1, lend = (1 << (level + 1)) - 1;
+  // the level's histogram slots first, a node per thread: read inside the loop below, a node's
+  // slot is a dependent load in front of its cells (32 nodes: 28 us of round trips, one after
+  // the other); then the cells of eight nodes are requested together.  Same additions in node
+  // order.
+  __shared__ int32_t sh_slot[QR_MAXLEVEL];
+  const int nlev = lend - lbegin;
+  for (int i = (int)t; i < nlev; i += (int)blockDim.x) sh_slot[i] = ts->nodes[lbegin + i].hslot;
+  __syncthreads();
   double sum = 0.0;
   bool invalid = t >= tsize;
-  for (int i = lbegin; i < lend; ++i) {
-    const size_t base = ((size_t)ts->nodes[i].hslot * flocal + lf) * 256;
-    const long long cs = hsum[base + t], S = hsum[base + 255];
-    const u64 lc = hcnt[base + t], C = hcnt[base + 255];
-    const u64 rc = C - lc;
-    if (lc >= minls && rc >= minls) {
-      const double s = (double)S * inv_scale;
-      const double lsum = (double)cs * inv_scale;
-      const double rsum = s - lsum;
-      sum += lsum * lsum / (double)lc + rsum * rsum / (double)rc;
-    } else
-      invalid = true;
+  for (int i0 = 0; i0 < nlev; i0 += 8) {
+    long long cs[8], S[8];
+    uint32_t lc32[8], C32[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k < nlev ? i0 + k : nlev - 1;  // (clamped: unconditional loads)
+      const size_t base = ((size_t)sh_slot[i] * flocal + lf) * 256;
+      cs[k] = hsum[base + t];
+      S[k] = hsum[base + 255];
+      lc32[k] = hcnt[base + t];
+      C32[k] = hcnt[base + 255];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (i0 + k >= nlev) break;
+      const u64 lc = lc32[k], C = C32[k];
+      const u64 rc = C - lc;
+      if (lc >= minls && rc >= minls) {
+        const double s = (double)S[k] * inv_scale;
+        const double lsum = (double)cs[k] * inv_scale;
+        const double rsum = s - lsum;
+        sum += lsum * lsum / (double)lc + rsum * rsum / (double)rc;
+      } else
+        invalid = true;
+    }
   }
   Best v;
   v.score = -1.0;
@@ -3234,7 +3255,7 @@ __global__ __launch_bounds__(256) void k_obl_plan(
   // launches are sized on the host.  recs_all / lcounts != null: feature-sharded -- the level's
   // split is the best of the ranks' records, and the nodes' left counts came with the mask)
   __shared__ uint32_t sh_a[QR_MAXLEVEL], sh_b[QR_MAXLEVEL], sh_c[QR_MAXLEVEL];
-  __shared__ uint32_t tot_small;
+  __shared__ uint32_t tot_small, tot_hw, tot_pw;
   __shared__ uint32_t pick[3];
   // (hcnt_loc != null: document-sharded -- hcnt holds the counts over ALL ranks' documents,
   // which decide the split, the smaller side and the nodes' sizes; where the rank's own lists
@@ -3340,6 +3361,8 @@ __global__ __launch_bounds__(256) void k_obl_plan(
       b += y;
       c += z;
     }
+    tot_hw = a;
+    tot_pw = c;
     ts->l_hist_wgs = a;
     ts->l_part_wgs = c;
     ts->l_nodes = nodes;
@@ -3352,10 +3375,24 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     ln.slot_base = sh_b[j];
     ln.part_first = sh_c[j];
     ln.pad = 0;
-    for (uint32_t x = 0; x < hw; ++x) hist_map[sh_a[j] + x] = ((uint32_t)j << 16) | x;
-    for (uint32_t w = 0; w < pw; ++w) part_map[sh_c[j] + w] = (uint32_t)j;
     ts->lnode[j] = ln;
   }
+  // the workgroup -> node maps of the level's launches, by ALL threads (a thread per node
+  // writing its node's entries one after the other was 18 us at the root level: one lane, 750
+  // stores): entry x belongs to the last node whose first entry is not beyond x
+  auto owner = [&](const uint32_t *first, const uint32_t x) {
+    int lo = 0, hi = nodes;  // first[lo] <= x (first[0] == 0); answer in [lo, hi)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (first[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+  for (uint32_t x = threadIdx.x; x < tot_hw; x += blockDim.x) {
+    const int n = owner(sh_a, x);
+    hist_map[x] = ((uint32_t)n << 16) | (x - sh_a[n]);
+  }
+  for (uint32_t w = threadIdx.x; w < tot_pw; w += blockDim.x) part_map[w] = (uint32_t)owner(sh_c, w);
 }
 
 // Feature-sharded level-wise growth (SURVEY.md section 8e applied to ot.cc:32-201).  Every

@@ -757,6 +757,42 @@ __device__ __forceinline__ void column_sum(const u64 *__restrict__ src, const in
   }
 }
 
+// level-wise growth: the reset of the tree state (k_obl_reset) as one more workgroup of the
+// root scan launch, which does not look at the tree state
+struct QrResetJob {
+  QrTreeState *ts;
+  u64 minls;
+  int32_t maxnodes;  // 0: no reset workgroup in this launch
+  int32_t pad;
+};
+__device__ __forceinline__ void obl_reset_body(QrTreeState *ts, const int i, const int maxnodes, const u64 minls) {
+  if (i < maxnodes) {
+    ts->nodes[i].feature = -2;  // absent
+    ts->nodes[i].left = ts->nodes[i].right = -1;
+    ts->nodes[i].count = 0;
+    ts->nodes[i].value = 0.0;
+    ts->nodes[i].deviance = 0.0;
+    ts->nodes[i].threshold = 0.f;
+    ts->nodes[i].thr_id = -1;
+  }
+  if (i == 0) {
+    ts->nleaves_req = 0;
+    ts->nnodes = 0;
+    ts->taken = 0;
+    ts->done = 0;
+    ts->step = 0;
+    ts->nsplits = 0;
+    ts->minls = minls;
+    ts->heap_size = 0;
+    ts->desc.active = 0;
+    ts->nleaves = 0;
+    ts->obl_done = 0;
+    ts->obl_level = 0;
+    ts->incomplete = 0;
+    ts->real_steps = 0;
+  }
+}
+
 // Batched leaf-wise growth: k_reduce and k_scan in one launch.  Grid = (features,
 // nodes of the batch), 1024 threads = 4 slot groups x 256 bins: the partial slots are
 // feature-major here (hist_run, tr), so a workgroup reads its column of every slot
@@ -771,10 +807,17 @@ __global__ __launch_bounds__(1024) void k_redscan(
     const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
     qr_split_t *__restrict__ featrec, const float *__restrict__ thr,
     float *__restrict__ featthr, const QrScanWg *__restrict__ descs, const u64 minls,
-    const double *__restrict__ part_ss, double *__restrict__ jobsum, const QrPrepJob prep) {
+    const double *__restrict__ part_ss, double *__restrict__ jobsum, const QrPrepJob prep,
+    const QrResetJob reset) {
   __shared__ long long cs_s[3][256];
   __shared__ uint32_t cs_c[3][256];
   __shared__ QrPlan sh_plan;
+  // (level-wise growth, root launch: the LAST workgroup resets the tree state -- up to 1023
+  // node records, a thread each)
+  if (reset.maxnodes && blockIdx.x == gridDim.x - 1) {
+    obl_reset_body(reset.ts, (int)threadIdx.x, reset.maxnodes, reset.minls);
+    return;
+  }
   // the ROOT launch of an iteration whose scalars are not finished yet (prep.nwg > 0,
   // qr_prep.h): prep.nwg more workgroups ride behind the features' -- one wave each, what k_prep
   // does in a launch of its own -- and the features' workgroups take the scale from the slots
@@ -3023,6 +3066,26 @@ __global__ __launch_bounds__(256) void k_score_update_walk(
     s_right[i] = ts->nodes[i].right;
     s_val[i] = ts->nodes[i].value;
   }
+  // A complete tree in level order whose levels share one test each -- every oblivious tree
+  // (ot.cc: one (feature, threshold) per level) -- needs no walk: the levels' bytes are
+  // requested together (a dword = the thread's four documents) and the node index follows
+  // from the tests by arithmetic.  (The walk below is a chain of dependent loads, one per
+  // level: 12 us of a depth-6 iteration at 1M documents.)
+  __shared__ int s_notobl;
+  if (threadIdx.x == 0) s_notobl = 0;
+  __syncthreads();
+  const int first = (nn - 1) / 2;  // (internal nodes of a complete tree: 0 .. first - 1)
+  {
+    bool bad = wide || (N & 3u) != 0 || (nn & 1) == 0 || ((nn + 1) & nn) != 0 || nn > 1023;
+    for (int i = threadIdx.x; i < nn && !bad; i += 256) {
+      const int lv = 31 - __clz(i + 1);          // level of node i
+      const int head = (1 << lv) - 1;            // first node of that level
+      bad = ((s_lf[i] >= 0) != (i < first)) ||
+            (i < first && (s_left[i] != 2 * i + 1 || s_right[i] != 2 * i + 2 || s_lf[i] != s_lf[head] ||
+                           s_thr[i] != s_thr[head]));
+    }
+    if (bad) s_notobl = 1;
+  }
   __syncthreads();
   // Four consecutive documents per thread: their walks are independent chains of dependent
   // one-byte loads, so four are in flight per lane instead of one (the launch is bound by the
@@ -3032,6 +3095,22 @@ __global__ __launch_bounds__(256) void k_score_update_walk(
   if (d0 >= N) return;
   int n[4] = {0, 0, 0, 0};
   const uint32_t *fw = reinterpret_cast<const uint32_t *>(fm);
+  if (!s_notobl) {
+    const int depth = 31 - __clz(nn + 1) - 1;  // nn = 2^(depth + 1) - 1, depth <= 9
+    uint32_t w4[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) {
+      const int head = l < depth ? (1 << l) - 1 : 0;
+      w4[l] = l < depth ? *reinterpret_cast<const uint32_t *>(fm + (size_t)s_lf[head] * N + d0) : 0u;
+    }
+#pragma unroll
+    for (int l = 0; l < 9; ++l) {
+      if (l >= depth) break;
+      const uint32_t t = (uint32_t)s_thr[(1 << l) - 1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) n[k] = 2 * n[k] + (((w4[l] >> (8 * k)) & 0xffu) <= t ? 1 : 2);
+    }
+  } else
   for (bool any = s_lf[0] >= 0; any;) {
     uint32_t b[4];
 #pragma unroll
@@ -3086,14 +3165,15 @@ __global__ __launch_bounds__(256) void k_valid_update(
 // of slot t is summed over the nodes of the level in node order; a slot where any
 // node violates minls is invalid for the whole level; only sums > 0 compete and
 // the first maximum wins.
-__global__ __launch_bounds__(256) void k_obl_fill(
+// (returns false when the tree was finished at an earlier level: nothing to do)
+__device__ __forceinline__ bool obl_fill_body(
     const QrTreeState *__restrict__ ts, const int level,
     const long long *__restrict__ hsum, const uint32_t *__restrict__ hcnt,
     const int flocal, const uint32_t *__restrict__ thr_size,
     const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
     qr_split_t *__restrict__ featrec) {
   __shared__ Best sh_b[4];
-  if (ts->obl_done) return;
+  if (ts->obl_done) return false;
   const int lf = blockIdx.x;
   const uint32_t t = threadIdx.x;
   const int gf = lf2gf[lf];
@@ -3152,6 +3232,15 @@ __global__ __launch_bounds__(256) void k_obl_fill(
     o->thr_id = v.t;
     o->lcount = o->rcount = 0;
   }
+  return true;
+}
+__global__ __launch_bounds__(256) void k_obl_fill(
+    const QrTreeState *__restrict__ ts, const int level,
+    const long long *__restrict__ hsum, const uint32_t *__restrict__ hcnt,
+    const int flocal, const uint32_t *__restrict__ thr_size,
+    const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
+    qr_split_t *__restrict__ featrec) {
+  (void)obl_fill_body(ts, level, hsum, hcnt, flocal, thr_size, lf2gf, scal, featrec);
 }
 
 // choose the level's (feature, slot): first maximum over features (ot.cc:84-95).
@@ -3222,7 +3311,7 @@ __device__ __forceinline__ void obl_level_body(QrTreeState *__restrict__ ts, con
   ts->obl_level = level;
   if (best.feature == 0xFFFFFFFFu) {  // ot.cc:96: node is unsplittable
     ts->obl_done = 1;
-    pick[0] = 1;
+    pick[0] = 2;  // (finished at this level: obl_plan_body numbers the leaves)
     return;
   }
   pick[0] = 0;
@@ -3242,7 +3331,7 @@ __device__ __forceinline__ void obl_level_body(QrTreeState *__restrict__ ts, con
 // node), the children's records, and the work plan of the level's launches: how
 // many histogram workgroups / partial slots / partition workgroups each node gets
 // and the workgroup -> node maps.
-__global__ __launch_bounds__(256) void k_obl_plan(
+__device__ __forceinline__ void obl_plan_body(
     QrTreeState *__restrict__ ts, const int level, const int last_level, const int G,
     const int flocal, const uint32_t *__restrict__ hcnt, const float *__restrict__ thr,
     const int32_t *__restrict__ gf2lf, const QrBlock *__restrict__ blocks, const int nblocks,
@@ -3262,9 +3351,24 @@ __global__ __launch_bounds__(256) void k_obl_plan(
   // are cut is a matter of its own counts)
   if (threadIdx.x < 64) obl_level_body(ts, level, N, featrec, flocal, scal, pick, recs_all, world, Nglobal, root_buf);
   __syncthreads();
-  if (pick[0]) return;
   const int nodes = 1 << level;
   const int j = threadIdx.x;
+  if (pick[0]) {
+    // pick[0] == 2: the tree ends HERE (ot.cc:96) -- its leaves are this level's nodes, and
+    // RTNode::save_leaves' left-first order (rtnode.cc:34-46) is their index order: numbered
+    // now, so that the single-GPU path needs no k_finish launch
+    if (pick[0] == 2 && j < nodes) {
+      const int node = nodes - 1 + j;
+      ts->nodes[node].leaf_id = j;
+      ts->leaf_nodes[j] = node;
+      ts->leaf_begin[j] = ts->nodes[node].begin;
+      if (j == 0) {
+        ts->nleaves = nodes;
+        ts->leaf_begin[nodes] = ts->nodes[0].end;
+      }
+    }
+    return;
+  }
   const uint32_t f = pick[1], t = pick[2];
   const int lf = gf2lf[f];
   QrLevelNode ln;
@@ -3319,6 +3423,16 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     R->count = rcount_all;
     L->sum = R->sum = L->ss = R->ss = L->deviance = R->deviance = 0.0;
     L->value = R->value = 0.0;  // overwritten by update_output (ot.cc:141-149)
+    if (last_level) {  // the leaves, in left-first order = index order (see above)
+      L->leaf_id = 2 * j;
+      R->leaf_id = 2 * j + 1;
+      ts->leaf_nodes[2 * j] = li;
+      ts->leaf_nodes[2 * j + 1] = ri;
+      ts->leaf_begin[2 * j] = L->begin;
+      ts->leaf_begin[2 * j + 1] = R->begin;
+      if (j == 0) ts->nleaves = 2 * nodes;
+      if (j == nodes - 1) ts->leaf_begin[2 * nodes] = nd->end;
+    }
   }
   sh_a[j] = ln.small_n;
   __syncthreads();
@@ -3394,6 +3508,24 @@ __global__ __launch_bounds__(256) void k_obl_plan(
   }
   for (uint32_t w = threadIdx.x; w < tot_pw; w += blockDim.x) part_map[w] = (uint32_t)owner(sh_c, w);
 }
+__global__ __launch_bounds__(256) void k_obl_plan(
+    QrTreeState *__restrict__ ts, const int level, const int last_level, const int G,
+    const int flocal, const uint32_t *__restrict__ hcnt, const float *__restrict__ thr,
+    const int32_t *__restrict__ gf2lf, const QrBlock *__restrict__ blocks, const int nblocks,
+    uint32_t *__restrict__ hist_map, uint32_t *__restrict__ part_map, const uint32_t N,
+    const qr_split_t *__restrict__ featrec, const QrScalars *__restrict__ scal,
+    const uint32_t *__restrict__ woff, const size_t wcells, const qr_split_t *__restrict__ recs_all,
+    const int world, const uint32_t *__restrict__ lcounts, const uint32_t *__restrict__ hcnt_loc,
+    const u64 Nglobal, const int root_buf) {
+  obl_plan_body(ts, level, last_level, G, flocal, hcnt, thr, gf2lf, blocks, nblocks, hist_map, part_map, N,
+                featrec, scal, woff, wcells, recs_all, world, lcounts, hcnt_loc, Nglobal, root_buf);
+}
+
+// (Measured and not kept: k_obl_fill and k_obl_plan in ONE launch, the plan run by the workgroup
+// that arrives last at a ticket -- release by every arriving workgroup, acquire by the last.
+// 100.2 us for the six levels against 45.0 + 49.7 in two launches, 0.570 against 0.563 ms per
+// iteration at depth 6: the hand-over costs more than the launch it saves, as it did between
+// scan and control step of the leaf-wise path)
 
 // Feature-sharded level-wise growth (SURVEY.md section 8e applied to ot.cc:32-201).  Every
 // rank sums the level's gains over ITS features (k_obl_fill) and publishes its best
@@ -3459,32 +3591,7 @@ __global__ __launch_bounds__(256) void k_obl_mark(
 }
 
 __global__ void k_obl_reset(QrTreeState *ts, int maxnodes, u64 minls) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < maxnodes) {
-    ts->nodes[i].feature = -2;  // absent
-    ts->nodes[i].left = ts->nodes[i].right = -1;
-    ts->nodes[i].count = 0;
-    ts->nodes[i].value = 0.0;
-    ts->nodes[i].deviance = 0.0;
-    ts->nodes[i].threshold = 0.f;
-    ts->nodes[i].thr_id = -1;
-  }
-  if (i == 0) {
-    ts->nleaves_req = 0;
-    ts->nnodes = 0;
-    ts->taken = 0;
-    ts->done = 0;
-    ts->step = 0;
-    ts->nsplits = 0;
-    ts->minls = minls;
-    ts->heap_size = 0;
-    ts->desc.active = 0;
-    ts->nleaves = 0;
-    ts->obl_done = 0;
-    ts->obl_level = 0;
-    ts->incomplete = 0;
-    ts->real_steps = 0;
-  }
+  obl_reset_body(ts, (int)(blockIdx.x * blockDim.x + threadIdx.x), maxnodes, minls);
 }
 
 // ===========================================================================
@@ -3569,11 +3676,14 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
     QR_CHECK(c, hipGetLastError());
   }
   if (fused) {  // batched growth: feature-major partials, reduce + scan in one launch
-    hipLaunchKernelGGL(k_redscan, dim3(c->flocal + prep.nwg, 1), dim3(1024), 0, c->stream, c->d_tree, 1, rootn,
+    // (level-wise growth: one more workgroup, the last, resets the tree state -- c->obl_reset_nodes)
+    QrResetJob reset{c->d_tree, (u64)c->cur_minls, (int32_t)c->obl_reset_nodes, 0};
+    c->obl_reset_nodes = 0;
+    hipLaunchKernelGGL(k_redscan, dim3(c->flocal + prep.nwg + (reset.maxnodes ? 1 : 0), 1), dim3(1024), 0, c->stream, c->d_tree, 1, rootn,
                        c->d_lplan, c->d_blocks, c->nblocks, G, (const u64 *)c->d_partials, c->d_hsum,
                        c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec,
                        c->d_thr, c->d_featthr, (const QrScanWg *)nullptr, (u64)c->cur_minls,
-                       (const double *)nullptr, (double *)nullptr, prep);
+                       (const double *)nullptr, (double *)nullptr, prep, reset);
     QR_CHECK(c, hipGetLastError());
     return QR_OK;
   }
@@ -3711,7 +3821,7 @@ static int launch_batch_hist_scan(qr_ctx *c, const unsigned hg, const uint32_t r
                      rootn, c->d_lplan, c->d_blocks, c->nblocks, c->ncu, (const u64 *)c->d_lpartials,
                      c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars,
                      c->d_featrec, c->d_thr, c->d_featthr, c->d_lscan_wg, (u64)minls, c->d_lhistsum, c->d_jobsum,
-                     QrPrepJob{});
+                     QrPrepJob{}, QrResetJob{});
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -3843,11 +3953,16 @@ int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_d
 }
 
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
-  c->finish_in_decide = false;
+  // (k_obl_plan numbers the leaves of the level the tree ends at: no k_finish launch)
+  c->finish_in_decide = !c->obl_own_launches;
   const int maxnodes = (1 << (depth + 1)) - 1;
-  hipLaunchKernelGGL(k_obl_reset, dim3((maxnodes + 255) / 256), dim3(256), 0, c->stream,
-                     c->d_tree, maxnodes, (u64)minls);
-  QR_CHECK(c, hipGetLastError());
+  if (c->wide || c->obl_own_launches) {
+    hipLaunchKernelGGL(k_obl_reset, dim3((maxnodes + 255) / 256), dim3(256), 0, c->stream,
+                       c->d_tree, maxnodes, (u64)minls);
+    QR_CHECK(c, hipGetLastError());
+  } else {
+    c->obl_reset_nodes = maxnodes;  // (u8 bins: the last workgroup of the root scan launch does it)
+  }
   // root histogram -> slot 0 (u8 bins: reduce + scan in one launch over feature-major partials,
   // as the batched leaf-wise path does)
   c->cur_minls = minls;
@@ -3860,6 +3975,7 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
   // are sized for the worst case; surplus workgroups leave at once)
   for (int level = 0; level < (int)depth; ++level) {
     const int nodes = 1 << level;
+    const int last = level == (int)depth - 1;
     if (c->wide) {
       if ((rc = qr_k_wobl_fill(c, level))) return rc;
     } else {
@@ -3868,7 +3984,6 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
                          c->d_scalars, c->d_featrec);
       QR_CHECK(c, hipGetLastError());
     }
-    const int last = level == (int)depth - 1;
     hipLaunchKernelGGL(k_obl_plan, dim3(1), dim3(256), 0, c->stream, c->d_tree, level, last,
                        c->ncu, c->flocal, c->d_hcnt, c->wide ? c->d_wthr : c->d_thr, c->d_gf2lf,
                        c->d_blocks, c->nblocks, c->d_lhist_map, c->d_lpart_map,

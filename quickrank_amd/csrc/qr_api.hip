@@ -92,6 +92,7 @@ int qr_ctx_create(int device, qr_ctx **out) {
   qr_ctx *c = new qr_ctx();
   c->no_batch = getenv("QR_NO_BATCH") != nullptr;
   c->no_defer = getenv("QR_NO_DEFER_PREP") != nullptr;
+  c->obl_own_launches = getenv("QR_OBL_OWN_LAUNCHES") != nullptr;
   c->exact_tail = getenv("QR_EXACT_TAIL") != nullptr;
   if (getenv("QR_LEAF_BY_POSITION")) c->leaf_by_position = true;
   if (const char *e = getenv("QR_STEPS_HINT")) c->steps_force = atol(e);  // steps to enqueue, whatever the tree

@@ -2926,12 +2926,20 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
   }
   const int nl = ts->nleaves;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (docmode) {  // own slot <- local sums, zeros elsewhere (all-reduce == all-gather)
-    for (int i = threadIdx.x; i < world * stride; i += 1024) xleaf[i] = 0;
-    __syncthreads();
+  // the leaves' bounds and nodes first, by all threads: a tree of 64 leaves is four rounds of
+  // the loop below per wave, and a round that fetches its bounds itself waits for them before it
+  // can ask for its partials (15 us for an oblivious tree of depth 6)
+  __shared__ uint32_t sh_lb[QR_MAXNODES + 1];
+  __shared__ int32_t sh_ln[QR_MAXNODES];
+  for (int i = threadIdx.x; i <= nl && i <= QR_MAXNODES; i += 1024) {
+    sh_lb[i] = ts->leaf_begin[i];
+    if (i < nl) sh_ln[i] = ts->leaf_nodes[i];
   }
+  if (docmode)  // own slot <- local sums, zeros elsewhere (all-reduce == all-gather)
+    for (int i = threadIdx.x; i < world * stride; i += 1024) xleaf[i] = 0;
+  __syncthreads();
   for (int l = wave; l < nl; l += 16) {  // one wave per leaf, fixed reduction tree
-    const uint32_t b = ts->leaf_begin[l], e = ts->leaf_begin[l + 1];
+    const uint32_t b = sh_lb[l], e = sh_lb[l + 1];
     double s1 = 0.0, s2 = 0.0;
     if (dense_slices) {  // k_leaf_sums_doc's [leaf][slice][2]: every slice may hold the leaf
       for (uint32_t s = lane; s < dense_slices; s += 8 * 64) {
@@ -2982,7 +2990,7 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
       else
         v = s1 / (double)(e - b);
       ts->leaf_value[l] = v;
-      ts->nodes[ts->leaf_nodes[l]].value = v;
+      ts->nodes[sh_ln[l]].value = v;
     }
   }
   if (docmode) return;  // k_leaf_global writes the records after the exchange

@@ -165,6 +165,12 @@ int qr_pseudo_set(qr_ctx *ctx, const double *lambda, const double *weight);
 /* LambdaMart::compute_pseudoresponses (lambdamart.cc:62-152) for metric@cutoff. */
 /* cutoff 0 = no cutoff (metric.h:65-67).  Also leaves the training metric of    */
 /* the CURRENT scores in the context (same ranking), see qr_metric_last.         */
+/* (The iteration's scalars -- quantisation scale, the root's sums, that metric -- */
+/* are finished lazily: by workgroups riding in the root scan launch of the       */
+/* qr_tree_fit / qr_oblivious_fit that follows, or, when anything else asks first */
+/* (qr_metric_last, the phase calls, ...), in a launch of their own.  Nothing a   */
+/* caller can observe depends on which; a host that reads qr_metric_last AFTER it  */
+/* has enqueued the tree saves that launch.  csrc/qr_prep.h)                       */
 int qr_lambda_compute(qr_ctx *ctx, int metric, size_t cutoff);
 /* Mart::compute_pseudoresponses (mart.cc:418-431)                               */
 int qr_residual_compute(qr_ctx *ctx);

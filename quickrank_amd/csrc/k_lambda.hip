@@ -1100,6 +1100,9 @@ static size_t lambda_lds(size_t nmax, size_t kacc, bool sampled) {
 // 10 us slower per iteration, a 192 or 64 bound more, sixteen waves from 257 on 40 us)
 static const uint32_t kClassBound[] = {128, 256, 512, 2048, 0xFFFFFFFFu};
 
+#ifndef QR_LAMBDA_AUX
+#define QR_LAMBDA_AUX 2  /* auxiliary streams of a ragged set's size-class launches (at most 4) */
+#endif
 int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   const size_t Q = which ? c->vQ : c->Q;
   const size_t maxq = which ? c->vmaxq : c->maxq;
@@ -1212,12 +1215,17 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
       *out = c->stream;
       return QR_OK;
     }
-    const size_t a = (i - 1) % 4;
+    // TWO auxiliary streams: with the context's own that is three hardware queues, and HIP puts a
+    // third auxiliary stream on the queue of the second anyway (rocprofv3 trace of the MSLR-shaped
+    // set: the fourth launch waited for the third, 70 + 27 us in a row while the 51 us launch's
+    // queue sat empty).  The launches go out longest class first, so the fourth -- the short
+    // queries -- lines up behind the second: 51 + 27 us next to 70 and 70.
+    const size_t a = (i - 1) % QR_LAMBDA_AUX;
     if (!c->aux_stream[a]) {
       QR_CHECK(c, hipStreamCreateWithFlags(&c->aux_stream[a], hipStreamNonBlocking));
       QR_CHECK(c, hipEventCreateWithFlags(&c->aux_join[a], hipEventDisableTiming));
     }
-    if (i <= 4) QR_CHECK(c, hipStreamWaitEvent(c->aux_stream[a], c->aux_fork, 0));
+    if (i <= QR_LAMBDA_AUX) QR_CHECK(c, hipStreamWaitEvent(c->aux_stream[a], c->aux_fork, 0));
     *out = c->aux_stream[a];
     return QR_OK;
   };
@@ -1271,7 +1279,7 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     QR_CHECK(c, hipGetLastError());
   }
   if (fork)  // join: the context's stream carries on when every launch is done
-    for (size_t a = 0; a < std::min<size_t>(4, li - 1); ++a) {
+    for (size_t a = 0; a < std::min<size_t>(QR_LAMBDA_AUX, li - 1); ++a) {
       QR_CHECK(c, hipEventRecord(c->aux_join[a], c->aux_stream[a]));
       QR_CHECK(c, hipStreamWaitEvent(c->stream, c->aux_join[a], 0));
     }

@@ -1100,6 +1100,9 @@ static size_t lambda_lds(size_t nmax, size_t kacc, bool sampled) {
 // 10 us slower per iteration, a 192 or 64 bound more, sixteen waves from 257 on 40 us)
 static const uint32_t kClassBound[] = {128, 256, 512, 2048, 0xFFFFFFFFu};
 
+#ifndef QR_LAMBDA_W4_FROM
+#define QR_LAMBDA_W4_FROM 256  /* classes whose longest query is longer than this take four waves per query */
+#endif
 #ifndef QR_LAMBDA_AUX
 #define QR_LAMBDA_AUX 2  /* auxiliary streams of a ragged set's size-class launches (at most 4) */
 #endif
@@ -1255,7 +1258,7 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
                          idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
                          (size_t)0, c->exact_tail);
-    else if (cl.nmax > 256 && !sampled)
+    else if (cl.nmax > QR_LAMBDA_W4_FROM && !sampled)
       hipLaunchKernelGGL((k_lambda<false, 4>), dim3(cl.count), dim3(256), lds, st, sc, lb, qoffd, metric, cut,
                          idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,

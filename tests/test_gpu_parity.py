@@ -906,6 +906,38 @@ def test_scalars_finished_in_the_root_scan_launch_equal_the_launch_of_their_own(
     want.ctx.close()
 
 
+@pytest.mark.parametrize("depth,minls,subsample", [(1, 1, 1.0), (3, 1, 1.0), (6, 1, 1.0), (7, 2, 1.0),
+                                                    (6, 400, 1.0), (5, 3000, 1.0), (5, 1, 0.5)])
+def test_oblivious_launches_folded_into_their_neighbours(qr, monkeypatch, depth, minls, subsample):
+    """Single-GPU level-wise growth resets the tree state in the last workgroup of the root scan
+    launch, lets k_obl_plan number the leaves at the level the tree ENDS at (the last one, or the
+    first that finds no split: a large min-leaf-support ends trees early) and updates the scores of
+    a level-order tree without a walk.  QR_OBL_OWN_LAUNCHES=1 brings k_obl_reset and k_finish
+    back.  Same trees, metrics and scores bit for bit, whatever the depth the tree reaches."""
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(nq=120, docs_per_query=50, F=20, seed=77, ragged=True)
+    kw = dict(ntrees=5, shrinkage=0.1, nthresholds=32, minls=minls, esr=0, depth=depth)
+    if subsample != 1.0:
+        kw["subsample"] = subsample
+    got = Mart(algo="OBVLAMBDAMART", **kw).learn(x, labels, qoff)
+    monkeypatch.setenv("QR_OBL_OWN_LAUNCHES", "1")
+    want = Mart(algo="OBVLAMBDAMART", **kw).learn(x, labels, qoff)
+    monkeypatch.delenv("QR_OBL_OWN_LAUNCHES")
+    shallow = 0
+    for t in range(kw["ntrees"]):
+        g, w = got.ensemble.trees[t], want.ensemble.trees[t]
+        assert len(g) == len(w)
+        shallow += int(np.count_nonzero(g["nsamples"])) < (1 << (depth + 1)) - 1  # (padding: 0 samples)
+        for f in g.dtype.names:
+            assert np.array_equal(g[f], w[f]), (t, f)
+    if minls >= 400:
+        assert shallow > 0, "the case is meant to end trees before their last level"
+    assert np.array_equal(np.asarray(got.train_metric), np.asarray(want.train_metric))
+    assert np.array_equal(got.ctx.get_scores(), want.ctx.get_scores())
+    got.ctx.close()
+    want.ctx.close()
+
+
 @pytest.mark.parametrize("algo,nleaves,subsample", [("LAMBDAMART", 10, 1.0), ("LAMBDAMART", 16, 0.5),
                                                      ("MART", 7, 1.0), ("OBVLAMBDAMART", 16, 1.0)])
 def test_leaf_sums_in_document_order_equal_the_position_order(qr, monkeypatch, algo, nleaves, subsample):

@@ -1225,15 +1225,15 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     // queries -- lines up behind the second: 51 + 27 us next to 70 and 70.
     const size_t a = (i - 1) % QR_LAMBDA_AUX;
     if (!c->aux_stream[a]) {
-#ifdef QR_LAMBDA_PRIO
-      // (experiment) one auxiliary stream above, one below the context's priority: streams of
-      // different priorities never share a hardware queue, whatever else the process has created
+      // one auxiliary stream above, one below the context's priority: streams of different
+      // priorities never share a hardware queue, whatever else the process has created (with
+      // plain streams the MSLR-shaped set ran at 0.53 ms per iteration in a process of its own
+      // and at 0.57 inside bench.py, whose earlier contexts had shifted the round-robin of
+      // streams over hardware queues; with priorities 0.53 in both)
       int lo = 0, hi = 0;
       QR_CHECK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-      QR_CHECK(c, hipStreamCreateWithPriority(&c->aux_stream[a], hipStreamNonBlocking, a == 0 ? hi : lo));
-#else
-      QR_CHECK(c, hipStreamCreateWithFlags(&c->aux_stream[a], hipStreamNonBlocking));
-#endif
+      QR_CHECK(c, hipStreamCreateWithPriority(&c->aux_stream[a], hipStreamNonBlocking,
+                                              a == 0 ? hi : (a == 1 ? lo : 0)));
       QR_CHECK(c, hipEventCreateWithFlags(&c->aux_join[a], hipEventDisableTiming));
     }
     if (i <= QR_LAMBDA_AUX) QR_CHECK(c, hipStreamWaitEvent(c->aux_stream[a], c->aux_fork, 0));

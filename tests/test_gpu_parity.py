@@ -906,6 +906,63 @@ def test_scalars_finished_in_the_root_scan_launch_equal_the_launch_of_their_own(
     want.ctx.close()
 
 
+def test_deferred_scalars_survive_any_call_order(qr, monkeypatch):
+    """The scalars of a lambda pass stay unfinished until a tree's root scan launch or any call
+    that needs them (csrc/qr_prep.h).  Call orders a host is free to choose -- two lambda passes in
+    a row, the pseudo-responses read back, the metric asked for at once, a MART residual pass in
+    between, a tree through the phase calls, an oblivious tree, the scores replaced -- must give
+    what the launch of its own (QR_NO_DEFER_PREP=1) gives, bit for bit."""
+    from quickrank_amd._capi import Context
+    x, labels, qoff = make_dataset(nq=90, docs_per_query=40, F=18, seed=5, ragged=True)
+
+    def run():
+        c = Context(0)
+        c.upload(x, labels, qoff)
+        c.build_bins(64)
+        c.reset_scores()
+        out = []
+        c.compute_lambdas("NDCG", 10)
+        c.compute_lambdas("NDCG", 10)                 # the first pass's scalars: nobody's
+        out.append(c.fit_tree(8, 2, True)); c.update_scores(0.1)
+        c.compute_lambdas("NDCG", 10)
+        out.append(np.asarray(c.metric_last()))       # asked for before any tree
+        lam, w = c.get_pseudo()
+        out += [lam, w]
+        out.append(c.fit_tree(8, 2, True)); c.update_scores(0.1)
+        c.compute_lambdas("NDCG", 10)
+        c.compute_residuals()                         # MART pass over an unfinished lambda pass
+        out.append(c.fit_tree(6, 2, False)); c.update_scores(0.1)
+        c.compute_lambdas("NDCG", 10)
+        out.append(c.fit_oblivious(3, 2, True)); c.update_scores(0.1)
+        out.append(np.asarray(c.metric_last()))
+        c.compute_lambdas("NDCG", 10)
+        c.tree_begin(7, 2)                            # one split per step, through the phase calls
+        for _ in range(6):
+            c.tree_decide(); c.tree_apply()
+        c.tree_decide()
+        out.append(c.tree_end(7, True)); c.update_scores(0.1)
+        c.compute_lambdas("NDCG", 10)
+        c.set_scores(np.zeros(len(labels)))           # the scores replaced under an unfinished pass
+        c.compute_lambdas("NDCG", 10)
+        out.append(c.fit_tree(8, 2, True)); c.update_scores(0.1)
+        out.append(np.asarray(c.metric_eval(0)))
+        out.append(c.get_scores())
+        c.close()
+        return out
+
+    got = run()
+    monkeypatch.setenv("QR_NO_DEFER_PREP", "1")
+    want = run()
+    monkeypatch.delenv("QR_NO_DEFER_PREP")
+    assert len(got) == len(want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        if g.dtype.names:
+            for f in g.dtype.names:
+                assert np.array_equal(g[f], w[f]), (i, f)
+        else:
+            assert np.array_equal(g, w), i
+
+
 @pytest.mark.parametrize("depth,minls,subsample", [(1, 1, 1.0), (3, 1, 1.0), (6, 1, 1.0), (7, 2, 1.0),
                                                     (6, 400, 1.0), (5, 3000, 1.0), (5, 1, 0.5)])
 def test_oblivious_launches_folded_into_their_neighbours(qr, monkeypatch, depth, minls, subsample):

@@ -2853,15 +2853,26 @@ __global__ __launch_bounds__(256) void k_score_update_leaf(
     const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ leafb, const uint32_t N,
     const double shrinkage, double *__restrict__ scores) {
   __shared__ double lv[QR_LDOC];
-  if (ts->incomplete) return;  // the host carries the tree on and enqueues this update again
-  if ((int)threadIdx.x < ts->nleaves) lv[threadIdx.x] = ts->leaf_value[threadIdx.x];
-  __syncthreads();
+  // (everything is requested at once -- the tree's flag, the leaf values whatever their number,
+  // the thread's leaf bytes and scores: one round trip, where flag -> values -> barrier -> data
+  // were three)
+  const int incomplete = ts->incomplete;
+  const double my_lv = threadIdx.x < QR_LDOC ? ts->leaf_value[threadIdx.x] : 0.0;
   const uint32_t d0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool full = d0 + 3 < N;
+  uint32_t lw = 0;
+  double2 u = make_double2(0.0, 0.0), v = u;
+  double2 *sp = reinterpret_cast<double2 *>(scores + (full ? d0 : 0));
+  if (full) {
+    lw = *reinterpret_cast<const uint32_t *>(leafb + d0);
+    u = sp[0];
+    v = sp[1];
+  }
+  if (incomplete) return;  // the host carries the tree on and enqueues this update again
+  if (threadIdx.x < QR_LDOC) lv[threadIdx.x] = my_lv;
+  __syncthreads();
   if (d0 >= N) return;
-  if (d0 + 3 < N) {
-    const uint32_t lw = *reinterpret_cast<const uint32_t *>(leafb + d0);
-    double2 *sp = reinterpret_cast<double2 *>(scores + d0);
-    double2 u = sp[0], v = sp[1];
+  if (full) {
     u.x = u.x + shrinkage * lv[lw & 0xffu];
     u.y = u.y + shrinkage * lv[(lw >> 8) & 0xffu];
     v.x = v.x + shrinkage * lv[(lw >> 16) & 0xffu];
@@ -2916,7 +2927,18 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
                                                      const int stride,
                                                      QrNodesOut *__restrict__ nodes_out,
                                                      const long long seq, const uint32_t dense_slices) {
-  if (ts->incomplete) {  // tell the host, which carries the tree on (qr_k_tree_continue)
+  // the leaves' bounds and nodes first, by all threads: a tree of 64 leaves is four rounds of
+  // the loop below per wave, and a round that fetches its bounds itself waits for them before it
+  // can ask for its partials (15 us for an oblivious tree of depth 6).  A thread per entry of the
+  // two arrays, whatever the number of leaves turns out to be (entries beyond it are never
+  // looked at): the requests leave with the header's, not behind it.
+  static_assert(QR_MAXNODES == 1024, "one thread per leaf entry");
+  const int incomplete = ts->incomplete;
+  const int nl = ts->nleaves;
+  const uint32_t my_lb = ts->leaf_begin[threadIdx.x];
+  const int32_t my_ln = ts->leaf_nodes[threadIdx.x];
+  const uint32_t last_lb = threadIdx.x == 0 ? ts->leaf_begin[QR_MAXNODES] : 0u;
+  if (incomplete) {  // tell the host, which carries the tree on (qr_k_tree_continue)
     if (threadIdx.x == 0) {
       nodes_out->pad[0] = 1;
       nodes_out->pad[1] = ts->real_steps;
@@ -2924,17 +2946,12 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
     }
     return;
   }
-  const int nl = ts->nleaves;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the leaves' bounds and nodes first, by all threads: a tree of 64 leaves is four rounds of
-  // the loop below per wave, and a round that fetches its bounds itself waits for them before it
-  // can ask for its partials (15 us for an oblivious tree of depth 6)
   __shared__ uint32_t sh_lb[QR_MAXNODES + 1];
   __shared__ int32_t sh_ln[QR_MAXNODES];
-  for (int i = threadIdx.x; i <= nl && i <= QR_MAXNODES; i += 1024) {
-    sh_lb[i] = ts->leaf_begin[i];
-    if (i < nl) sh_ln[i] = ts->leaf_nodes[i];
-  }
+  sh_lb[threadIdx.x] = my_lb;
+  sh_ln[threadIdx.x] = my_ln;
+  if (threadIdx.x == 0) sh_lb[QR_MAXNODES] = last_lb;
   if (docmode)  // own slot <- local sums, zeros elsewhere (all-reduce == all-gather)
     for (int i = threadIdx.x; i < world * stride; i += 1024) xleaf[i] = 0;
   __syncthreads();

@@ -2249,12 +2249,28 @@ __global__ __launch_bounds__(256) void k_mask(
   if (d.active && d.owner_local >= 0) {
     const uint32_t n = d.end - d.begin;
     const uint32_t *order = d.src_buf == 0 ? order0 : order1;
-    for (uint32_t k = 0; k < 32; ++k) {
-      const uint32_t p = w * 32 + k;
-      if (p < n) {
-        const uint32_t id = d.src_buf == 2 ? d.begin + p : order[d.begin + p];
-        if (go_left(d, p, id, fm, Nfm, nullptr, wide ? 2 : 0)) bits |= 1u << k;
+    // eight positions at a time: their ids together, then the eight values their tests read
+    // (id -> value, position after position, is 64 dependent round trips per thread)
+    const uint8_t *col8 = fm + (size_t)d.owner_local * Nfm;
+    const uint32_t *col32 = reinterpret_cast<const uint32_t *>(fm) + (size_t)d.owner_local * Nfm;
+    for (uint32_t k0 = 0; k0 < 32 && w * 32 + k0 < n; k0 += 8) {
+      uint32_t id[8], tv[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t p = w * 32 + k0 + k;
+        const uint32_t pc = p < n ? p : n - 1;  // (clamped: unconditional loads)
+        id[k] = d.src_buf == 2 ? d.begin + pc : order[d.begin + pc];
       }
+      if (wide) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) tv[k] = col32[id[k]];
+      } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) tv[k] = col8[id[k]];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k)
+        if (w * 32 + k0 + k < n && tv[k] <= d.thr_id) bits |= 1u << (k0 + k);
     }
   }
   mask[w] = bits;
@@ -2309,13 +2325,52 @@ __device__ __forceinline__ void partition_body(
   uint32_t ids[PART_PER_THREAD];
   bool fl[PART_PER_THREAD];
   uint32_t cnt = 0;
-  for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
-    const uint32_t p = base + threadIdx.x * PART_PER_THREAD + k;
-    fl[k] = false;
-    ids[k] = 0;
-    if (p < n) {
-      ids[k] = d.src_buf == 2 ? d.begin + p : src[d.begin + p];
-      fl[k] = go_left(gl, p, ids[k], fm, Nfm, mask, use_mask);
+  // The thread's eight ids are requested together, then the eight words their tests read:
+  // TWO round trips.  (Written as one loop -- id, its test, the next id -- the compiler kept the
+  // order: sixteen dependent loads one after the other, each behind an `s_waitcnt vmcnt(0)`,
+  // with two waves per SIMD to hide them: most of the partition's 5 - 12 us.)  Loads are
+  // unconditional, of positions clamped into the node, so that no branch separates them.
+  {
+    const uint32_t p0 = base + threadIdx.x * PART_PER_THREAD;
+    const uint32_t plast = n - 1;  // (base < n: the node is not empty)
+    uint32_t pc[PART_PER_THREAD];
+#pragma unroll
+    for (uint32_t k = 0; k < PART_PER_THREAD; ++k) pc[k] = p0 + k < plast ? p0 + k : plast;
+    if (d.src_buf == 2) {
+#pragma unroll
+      for (uint32_t k = 0; k < PART_PER_THREAD; ++k) ids[k] = d.begin + pc[k];
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < PART_PER_THREAD; ++k) ids[k] = src[d.begin + pc[k]];
+    }
+    uint32_t tv[PART_PER_THREAD];  // the value the test compares / the mask word
+    if (use_mask == 0) {
+      const uint8_t *col = fm + (size_t)gl.owner_local * Nfm;
+#pragma unroll
+      for (uint32_t k = 0; k < PART_PER_THREAD; ++k) tv[k] = col[ids[k]];
+#pragma unroll
+      for (uint32_t k = 0; k < PART_PER_THREAD; ++k) fl[k] = tv[k] <= gl.thr_id;
+    } else if (use_mask == 2) {
+      const uint32_t *col = reinterpret_cast<const uint32_t *>(fm) + (size_t)gl.owner_local * Nfm;
+#pragma unroll
+      for (uint32_t k = 0; k < PART_PER_THREAD; ++k) tv[k] = col[ids[k]];
+#pragma unroll
+      for (uint32_t k = 0; k < PART_PER_THREAD; ++k) fl[k] = tv[k] <= gl.thr_id;
+    } else if (use_mask == 3) {
+#pragma unroll
+      for (uint32_t k = 0; k < PART_PER_THREAD; ++k) tv[k] = mask[ids[k] >> 5];
+#pragma unroll
+      for (uint32_t k = 0; k < PART_PER_THREAD; ++k) fl[k] = (tv[k] >> (ids[k] & 31)) & 1u;
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < PART_PER_THREAD; ++k) tv[k] = mask[pc[k] >> 5];
+#pragma unroll
+      for (uint32_t k = 0; k < PART_PER_THREAD; ++k) fl[k] = (tv[k] >> (pc[k] & 31)) & 1u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
+      fl[k] = fl[k] && p0 + k < n;
+      if (!(p0 + k < n)) ids[k] = 0;
       cnt += fl[k] ? 1u : 0u;
     }
   }
@@ -2585,29 +2640,43 @@ __global__ __launch_bounds__(256) void k_leaf_sums(
     const double *__restrict__ weight, double *__restrict__ leafpart) {
   __shared__ double sh1[4], sh2[4];
   __shared__ uint32_t lb[QR_MAXNODES + 1];
+  __shared__ int8_t lbuf[QR_MAXNODES];  // the list buffer every leaf's segment lives in
   if (ts->incomplete) return;  // (the last batch is not applied yet: its children's lists are not there)
   const int nl = ts->nleaves;
-  for (int i = threadIdx.x; i <= nl; i += 256) lb[i] = ts->leaf_begin[i];
+  // the leaves' bounds and buffers once per workgroup, a leaf per thread; then the thread's
+  // four ids together and their values together.  (A position at a time -- leaf -> its node ->
+  // the node's buffer -> id -> values -- was sixteen dependent round trips per thread: 20 us of
+  // an oblivious iteration at depth 6.)  Same values, same additions.
+  for (int i = threadIdx.x; i <= nl; i += 256) {
+    lb[i] = ts->leaf_begin[i];
+    if (i < nl) lbuf[i] = (int8_t)ts->nodes[ts->leaf_nodes[i]].buf;
+  }
   __syncthreads();
   const uint32_t N = lb[nl];
   const uint32_t base = blockIdx.x * QR_SLICE;
   if (base >= N) return;
   const uint32_t end = base + QR_SLICE < N ? base + QR_SLICE : N;
-  double v1[QR_SLICE / 256], v2[QR_SLICE / 256];
-  int lf[QR_SLICE / 256];
-  for (uint32_t k = 0; k < QR_SLICE / 256; ++k) {
+  constexpr int PT = QR_SLICE / 256;
+  double v1[PT], v2[PT];
+  int lf[PT];
+  uint32_t id[PT];
+#pragma unroll
+  for (int k = 0; k < PT; ++k) {  // (unconditional loads of positions clamped into the slice)
     const uint32_t p = base + k * 256 + threadIdx.x;
-    v1[k] = v2[k] = 0.0;
-    lf[k] = -1;
-    if (p < end) {
-      const int l = leaf_of_pos(lb, nl, p);
-      const int buf = ts->nodes[ts->leaf_nodes[l]].buf;
-      const uint32_t id = buf == 2 ? p : (buf == 0 ? order0[p] : order1[p]);
-      v1[k] = lambda[id];
-      v2[k] = weight ? weight[id] : 0.0;
-      lf[k] = l;
-    }
+    const uint32_t pc = p < end ? p : end - 1;
+    const int l = leaf_of_pos(lb, nl, pc);
+    const int buf = lbuf[l];
+    lf[k] = p < end ? l : -1;
+    id[k] = buf == 2 ? pc : (buf == 0 ? order0[pc] : order1[pc]);
   }
+#pragma unroll
+  for (int k = 0; k < PT; ++k) {
+    v1[k] = lambda[id[k]];
+    v2[k] = weight ? weight[id[k]] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < PT; ++k)
+    if (lf[k] < 0) v1[k] = v2[k] = 0.0;
   const int l0 = leaf_of_pos(lb, nl, base);
   for (int l = l0; l < nl && lb[l] < end; ++l) {
     double a = 0.0, b = 0.0;

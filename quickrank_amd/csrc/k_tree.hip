@@ -2399,6 +2399,14 @@ __device__ __forceinline__ void partition_body(
   uint32_t lpos = left_before + woff + inc - cnt;  // lefts before my first doc
   const uint32_t first_p = base + threadIdx.x * PART_PER_THREAD;
   double sq = 0.0, sm = 0.0;
+  // (wide-bin contexts take the directly built child's sums here: the eight pseudo-responses
+  // are requested together -- out-of-range slots hold id 0 -- and added in position order)
+  double lam[PART_PER_THREAD];
+  if (part_ss) {
+#pragma unroll
+    for (uint32_t k = 0; k < PART_PER_THREAD; ++k) lam[k] = lambda[ids[k]];
+  }
+#pragma unroll
   for (uint32_t k = 0; k < PART_PER_THREAD; ++k) {
     const uint32_t p = first_p + k;
     if (p < n) {
@@ -2411,7 +2419,7 @@ __device__ __forceinline__ void partition_body(
       }
       dst[o] = ids[k];
       if (part_ss && fl[k] == (d.small_is_left != 0)) {
-        const double l = lambda[ids[k]];
+        const double l = lam[k];
         sq += l * l;
         sm += l;
       }

@@ -3678,11 +3678,20 @@ __global__ __launch_bounds__(256) void k_obl_mark(
   const uint32_t w = blockIdx.x * 256 + threadIdx.x;
   if (w < mask_words) {
     uint32_t bits = 0;
-    if (lf >= 0)
+    if (lf >= 0) {
+      // the word's 32 bytes are requested together (positions clamped into the column: no
+      // branch between the loads; one at a time they were 32 round trips per thread)
+      const uint8_t *col = fm + (size_t)lf * N;
+      uint32_t bv[32];
+#pragma unroll
       for (uint32_t k = 0; k < 32; ++k) {
         const uint32_t d = w * 32 + k;
-        if (d < N && fm[(size_t)lf * N + d] <= t) bits |= 1u << k;
+        bv[k] = col[d < N ? d : N - 1];
       }
+#pragma unroll
+      for (uint32_t k = 0; k < 32; ++k)
+        if (w * 32 + k < N && bv[k] <= t) bits |= 1u << k;
+    }
     mask[w] = bits;
   }
   // the nodes' left counts ride behind the bits (QR_MAXLEVEL words)

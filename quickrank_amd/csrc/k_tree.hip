@@ -887,7 +887,24 @@ __global__ __launch_bounds__(1024) void k_redscan(
   if (sums_wave) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t nw0 = d.total / (uint32_t)d.kmax;   // block 0's workgroups of this node
-    for (uint32_t i = lane; i < nw0; i += 64) {
+    // (a lane's first four pairs are requested together -- up to 256 workgroups -- instead of a
+    // loop of load, add, load, add; measured: 0.4152 against 0.4150 ms per iteration, nothing --
+    // the wave's column sums behind it hide the second round trip)
+    double2 x[4] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+    if (nw0 > 0) {  // (wave-uniform; an empty child has no slot to read)
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t i = lane + 64 * k;
+        x[k] = *reinterpret_cast<const double2 *>(part_ss + 2 * (size_t)(d.slot0 + (i < nw0 ? i : 0u) * (uint32_t)d.kmax));
+      }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+      if (lane + 64 * k < nw0) {
+        pa += x[k].x;
+        pb += x[k].y;
+      }
+    for (uint32_t i = lane + 256; i < nw0; i += 64) {
       pa += part_ss[2 * (size_t)(d.slot0 + i * (uint32_t)d.kmax)];
       pb += part_ss[2 * (size_t)(d.slot0 + i * (uint32_t)d.kmax) + 1];
     }

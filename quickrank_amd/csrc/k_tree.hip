@@ -375,12 +375,23 @@ __global__ __launch_bounds__(1024) void k_hist_root(
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const double *__restrict__ lambda, const QrScalars *__restrict__ scal,
     u64 *__restrict__ partials, const int root_buf, const int tr,
-    const unsigned long long *__restrict__ slots) {
+    const unsigned long long *__restrict__ slots, const QrHistWg *__restrict__ wgs) {
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
   // `slots`: the iteration's scalars are finished by workgroups of the scan launch BEHIND this
   // one (qr_prep.h); the scale comes from the slot set the lambda pass filled, a word per lane
   const u64 slot_word = slots ? slots[threadIdx.x & (QR_PREP_SLOTS - 1)] : 0ull;
   const double scale = slots ? 0.0 : scal->scale;
+  // `wgs`: every workgroup's share of the root ready-made -- the root's plan depends on the
+  // number of documents and the blocks only, so the host makes it once (root_shares) and the
+  // workgroup asks for its first rows after ONE load, instead of thread 0 planning, a barrier
+  // and the block's geometry from memory
+  if (wgs) {
+    const QrHistWg d = wgs[blockIdx.x];
+    if (d.count == 0) return;
+    hist_run<false>(hist, d.begin, 0, d.count, d.buf, d.block, d.slot, blocks, bins, order0, order0, lambda, scale,
+                    partials, tr != 0, (int)d.fw, (size_t)d.off256 << 8, nullptr, slot_word, slots != nullptr);
+    return;
+  }
   const uint32_t q =
       qr_plan_quantum((unsigned long long)N * qr_plan_wsum(nblocks, blocks), (int)gridDim.x - nblocks);
   hist_body(hist, 0, N, root_buf, q, (int)blockIdx.x, 0, blocks, nblocks, bins, order0, order0, lambda,
@@ -3737,6 +3748,48 @@ static size_t hist_lds(const qr_ctx *c) {
 
 static int launch_scan(qr_ctx *c, int root_mode);
 
+// the root launch's per-workgroup shares (what hist_body derives per workgroup), made once per
+// (documents of the root, grid, list buffer) and kept on the device
+static int root_shares(qr_ctx *c, uint32_t rootn, int G, int root_buf) {
+  if (c->d_root_wg && c->root_wg_n == rootn && c->root_wg_g == G && c->root_wg_buf == root_buf) return QR_OK;
+  std::vector<QrHistWg> h((size_t)G);
+  QrPlan plan;
+  const uint32_t q = qr_plan_quantum((unsigned long long)rootn * qr_plan_wsum(c->nblocks, c->blocks.data()),
+                                     G - c->nblocks);
+  qr_make_plan(rootn, c->nblocks, c->blocks.data(), q, &plan);
+  for (int wg = 0; wg < G; ++wg) {
+    QrHistWg d{};
+    int b = -1;
+    for (int i = 0; i < c->nblocks; ++i)
+      if (wg >= plan.wg_start[i] && wg < plan.wg_start[i + 1]) b = i;
+    if (b >= 0) {
+      const uint32_t j = (uint32_t)(wg - plan.wg_start[b]), per = plan.per[b];
+      const uint32_t r0 = j * per, r1 = r0 + per < rootn ? r0 + per : rootn;
+      d.begin = r0;
+      d.count = r1 > r0 ? r1 - r0 : 0u;
+      d.slot = (uint32_t)wg * (uint32_t)plan.kmax;
+      d.block = (uint16_t)b;
+      d.buf = (uint8_t)root_buf;
+      d.fw = (uint8_t)c->blocks[b].fw;
+      d.off256 = (uint32_t)(c->blocks[b].off >> 8);
+    }
+    h[(size_t)wg] = d;
+  }
+  if (!c->d_root_wg || c->root_wg_g != G) {
+    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    if (c->d_root_wg) (void)hipFree(c->d_root_wg);
+    c->d_root_wg = nullptr;
+    QR_CHECK(c, hipMalloc((void **)&c->d_root_wg, (size_t)G * sizeof(QrHistWg)));
+  } else {
+    QR_CHECK(c, hipStreamSynchronize(c->stream));  // (a launch that reads the old shares may be in flight)
+  }
+  QR_CHECK(c, hipMemcpy(c->d_root_wg, h.data(), (size_t)G * sizeof(QrHistWg), hipMemcpyHostToDevice));
+  c->root_wg_n = rootn;
+  c->root_wg_g = G;
+  c->root_wg_buf = root_buf;
+  return QR_OK;
+}
+
 static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
   // The scalars of the lambda pass before this tree may still be unfinished (qr_lambda_compute
   // defers them, qr_prep.h).  The fused root launches let the workgroups that finish them ride
@@ -3783,6 +3836,12 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
   const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_n : c->N);  // documents of the root node
   if (root_mode) {
     const int root_buf = c->sub_k ? 0 : 2;  // the sample's list / every document
+    const QrHistWg *shares = nullptr;
+    if (!c->no_root_shares) {
+      const int src = root_shares(c, rootn, G, root_buf);
+      if (src) return src;
+      shares = c->d_root_wg;
+    }
     if (prof) {
       // bench.py's roofline: the two events are attached to the launch itself (they
       // take the kernel's own begin / end timestamps, like the profiler's trace)
@@ -3791,13 +3850,13 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
       QR_CHECK(c, hipEventCreate(&e1));
       hipExtLaunchKernelGGL(k_hist_root, dim3(G), dim3(1024), lds, c->stream, e0, e1, 0, rootn,
                             c->d_blocks, c->nblocks, c->d_bins, c->d_order[0], c->d_lambda,
-                            c->d_scalars, (u64 *)c->d_partials, root_buf, fused ? 1 : 0, root_slots);
+                            c->d_scalars, (u64 *)c->d_partials, root_buf, fused ? 1 : 0, root_slots, shares);
       QR_CHECK(c, hipGetLastError());
       c->prof_events.push_back({e0, e1});
     } else {
       hipLaunchKernelGGL(k_hist_root, dim3(G), dim3(1024), lds, c->stream, rootn, c->d_blocks,
                          c->nblocks, c->d_bins, c->d_order[0], c->d_lambda, c->d_scalars,
-                         (u64 *)c->d_partials, root_buf, fused ? 1 : 0, root_slots);
+                         (u64 *)c->d_partials, root_buf, fused ? 1 : 0, root_slots, shares);
       QR_CHECK(c, hipGetLastError());
     }
   } else {

@@ -92,6 +92,7 @@ int qr_ctx_create(int device, qr_ctx **out) {
   qr_ctx *c = new qr_ctx();
   c->no_batch = getenv("QR_NO_BATCH") != nullptr;
   c->no_defer = getenv("QR_NO_DEFER_PREP") != nullptr;
+  c->no_root_shares = getenv("QR_NO_ROOT_SHARES") != nullptr;
   c->obl_own_launches = getenv("QR_OBL_OWN_LAUNCHES") != nullptr;
   c->exact_tail = getenv("QR_EXACT_TAIL") != nullptr;
   if (getenv("QR_LEAF_BY_POSITION")) c->leaf_by_position = true;
@@ -209,6 +210,7 @@ void qr_ctx_destroy(qr_ctx *c) {
   if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->d_prep_part) (void)hipFree(c->d_prep_part);
+  if (c->d_root_wg) (void)hipFree(c->d_root_wg);
   dfree(c->d_keys); dfree(c->d_tied);
   dfree(c->d_obl_feat); dfree(c->d_obl_thr); dfree(c->d_obl_leaves); dfree(c->d_obl_w);
   dfree(c->d_obl_depths); dfree(c->d_ob_fk); dfree(c->d_ob_thr); dfree(c->d_ob_thr_cnt);

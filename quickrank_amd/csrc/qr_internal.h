@@ -380,6 +380,10 @@ struct qr_ctx {
   int prep_parity = 0;            // slot set of the last lambda pass
   bool prep_deferred = false;     // the scalars of the last lambda pass are still to be finished
   bool no_defer = false;          // QR_NO_DEFER_PREP=1: always a launch of its own (A/B, debugging)
+  QrHistWg *d_root_wg = nullptr;  // the root histogram launch's per-workgroup shares (k_tree.hip: root_shares)
+  uint32_t root_wg_n = 0;
+  int root_wg_g = 0, root_wg_buf = -1;
+  bool no_root_shares = false;    // QR_NO_ROOT_SHARES=1: every root workgroup plans for itself (A/B, debugging)
   int obl_reset_nodes = 0;        // level-wise growth: node records the root scan launch's last workgroup resets (0: none)
   bool obl_own_launches = false;  // QR_OBL_OWN_LAUNCHES=1: the tree-state reset and k_finish as launches of their own (A/B, debugging)
   size_t prep_nss = 0;

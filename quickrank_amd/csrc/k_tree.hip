@@ -850,11 +850,12 @@ __global__ __launch_bounds__(1024) void k_redscan(
   const int gf_top = lf2gf[lf];
   double inv_top = prep.nwg ? 0.0 : scal->inv_scale;
   QrScanWg d;
-  if (!root) d = descs[(size_t)blockIdx.y * flocal + lf];
+  // (root with `descs`: the feature's share of the root's plan ready-made, root_shares)
+  if (!root || descs) d = descs[(size_t)(root ? 0 : blockIdx.y) * flocal + lf];
   const uint32_t tsize_top = thr_size[gf_top];
   const float my_thr = thr[(size_t)gf_top * QR_MAX_BINS + t];
   if (!root && !d.active) return;
-  if (root) {
+  if (root && !descs) {
     if (threadIdx.x == 0)
       qr_make_plan(rootn, nblocks, blocks,
                    qr_plan_quantum((unsigned long long)rootn * qr_plan_wsum(nblocks, blocks), G - nblocks),
@@ -3775,6 +3776,36 @@ static int root_shares(qr_ctx *c, uint32_t rootn, int G, int root_buf) {
     }
     h[(size_t)wg] = d;
   }
+  // ... and the root scan launch's per-feature shares of the same plan (what k_redscan's root
+  // branch derives: thread 0 planning, a barrier, the block search)
+  std::vector<QrScanWg> hs((size_t)c->flocal);
+  for (int lf = 0; lf < c->flocal; ++lf) {
+    QrScanWg d{};
+    int b = 0;
+    for (int i = 0; i < c->nblocks; ++i)
+      if (lf >= c->blocks[i].lf0 && lf < c->blocks[i].lf0 + c->blocks[i].nreal) b = i;
+    d.active = 1;
+    d.slot0 = (uint32_t)(plan.wg_start[b] * plan.kmax);
+    d.total = (uint32_t)((plan.wg_start[b + 1] - plan.wg_start[b]) * plan.kmax);
+    d.per = plan.per[b];
+    d.n = rootn;
+    d.kmax = plan.kmax;
+    d.small_slot = 0;
+    d.big_slot = d.parent_slot = -1;
+    d.small_is_left = 1;
+    d.col = (uint32_t)(lf - c->blocks[b].lf0);
+    hs[(size_t)lf] = d;
+  }
+  if (!c->d_root_scan || c->root_scan_n != c->flocal) {
+    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    if (c->d_root_scan) (void)hipFree(c->d_root_scan);
+    c->d_root_scan = nullptr;
+    QR_CHECK(c, hipMalloc((void **)&c->d_root_scan, (size_t)c->flocal * sizeof(QrScanWg)));
+    c->root_scan_n = c->flocal;
+  } else {
+    QR_CHECK(c, hipStreamSynchronize(c->stream));
+  }
+  QR_CHECK(c, hipMemcpy(c->d_root_scan, hs.data(), (size_t)c->flocal * sizeof(QrScanWg), hipMemcpyHostToDevice));
   if (!c->d_root_wg || c->root_wg_g != G) {
     QR_CHECK(c, hipStreamSynchronize(c->stream));
     if (c->d_root_wg) (void)hipFree(c->d_root_wg);
@@ -3832,6 +3863,7 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
     attr_lds = lds;
   }
   const int G = c->ncu;
+  const QrScanWg *shares_scan = nullptr;  // (root: the scan launch's per-feature shares, root_shares)
   const bool prof = c->prof_on && root_mode && (c->prof_tick++ % c->prof_stride) == 0;
   const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_n : c->N);  // documents of the root node
   if (root_mode) {
@@ -3841,6 +3873,7 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
       const int src = root_shares(c, rootn, G, root_buf);
       if (src) return src;
       shares = c->d_root_wg;
+      shares_scan = c->d_root_scan;
     }
     if (prof) {
       // bench.py's roofline: the two events are attached to the launch itself (they
@@ -3873,7 +3906,7 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
     hipLaunchKernelGGL(k_redscan, dim3(c->flocal + prep.nwg + (reset.maxnodes ? 1 : 0), 1), dim3(1024), 0, c->stream, c->d_tree, 1, rootn,
                        c->d_lplan, c->d_blocks, c->nblocks, G, (const u64 *)c->d_partials, c->d_hsum,
                        c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec,
-                       c->d_thr, c->d_featthr, (const QrScanWg *)nullptr, (u64)c->cur_minls,
+                       c->d_thr, c->d_featthr, shares_scan, (u64)c->cur_minls,
                        (const double *)nullptr, (double *)nullptr, prep, reset);
     QR_CHECK(c, hipGetLastError());
     return QR_OK;

@@ -211,6 +211,7 @@ void qr_ctx_destroy(qr_ctx *c) {
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->d_prep_part) (void)hipFree(c->d_prep_part);
   if (c->d_root_wg) (void)hipFree(c->d_root_wg);
+  if (c->d_root_scan) (void)hipFree(c->d_root_scan);
   dfree(c->d_keys); dfree(c->d_tied);
   dfree(c->d_obl_feat); dfree(c->d_obl_thr); dfree(c->d_obl_leaves); dfree(c->d_obl_w);
   dfree(c->d_obl_depths); dfree(c->d_ob_fk); dfree(c->d_ob_thr); dfree(c->d_ob_thr_cnt);
@@ -515,6 +516,8 @@ static int bins_finish(qr_ctx *c) {
   const size_t per_rank = (F + fworld - 1) / fworld;
   const size_t f_lo = std::min(F, per_rank * frank);
   const size_t f_hi = std::min(F, f_lo + per_rank);
+  c->root_wg_n = 0;  // (the root launch's ready-made shares follow the blocks: rebuilt at the next root)
+  c->root_wg_g = 0;
   c->blocks.clear();
   c->h_gf2lf.assign(F, -1);
   c->h_lf2gf.clear();

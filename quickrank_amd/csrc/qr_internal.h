@@ -381,6 +381,8 @@ struct qr_ctx {
   bool prep_deferred = false;     // the scalars of the last lambda pass are still to be finished
   bool no_defer = false;          // QR_NO_DEFER_PREP=1: always a launch of its own (A/B, debugging)
   QrHistWg *d_root_wg = nullptr;  // the root histogram launch's per-workgroup shares (k_tree.hip: root_shares)
+  QrScanWg *d_root_scan = nullptr;  // ... and the root scan launch's per-feature shares
+  int root_scan_n = 0;
   uint32_t root_wg_n = 0;
   int root_wg_g = 0, root_wg_buf = -1;
   bool no_root_shares = false;    // QR_NO_ROOT_SHARES=1: every root workgroup plans for itself (A/B, debugging)

@@ -363,7 +363,10 @@ int qr_oblivious_score(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
 int qr_prof_reset(qr_ctx *ctx);
 int qr_prof_get(qr_ctx *ctx, uint64_t *launches, double *total_ms,
                 double *alg_bytes_per_launch);
-/* on: bit 0 = time the root histogram launches, bit 1 = also the child launches; */
+/* on: bit 0 = time the root histogram launches, bit 1 = also the child launches, */
+/* bit 2 (without bit 1) = the lambda pass's launch instead of the child launches  */
+/* (LambdaMart::compute_pseudoresponses, lambdamart.cc:62-152; equal-length query  */
+/* sets: one launch), read through qr_prof_get_child as well;                      */
 /* bits 8..15 = k: events on every k-th root launch only (0 = every launch; an     */
 /* evented launch costs the stream ~7.5 us)                                          */
 int qr_prof_enable(qr_ctx *ctx, int on);
@@ -371,6 +374,15 @@ int qr_prof_enable(qr_ctx *ctx, int on);
 /* bytes depend on the trees: sum over splits of n_small * (F + 12), from the       */
 /* records qr_tree_nodes returns                                                     */
 int qr_prof_get_child(qr_ctx *ctx, uint64_t *launches, double *total_ms);
+/* The second bound of the root histogram launch, measured in the caller's process   */
+/* (bench.py's roofline.lds_atomic_bound): the launch issues one ds_add_u64 per       */
+/* (document, accumulated column) -- rtnode_histogram.cc:172-204's `sumlbl[f][t] +=`  */
+/* and `count[f][t]++` in one LDS atomic -- and a CU retires them at the rate this    */
+/* microbenchmark reaches with nothing else in its loop: shader cycles per wave       */
+/* instruction, the shader clock under that load, their quotient in ns, and the wave  */
+/* instructions the root launch of the context's data set asks of one CU.             */
+int qr_prof_lds_atomic(qr_ctx *ctx, double *cycles_per_instr, double *shader_ghz,
+                       double *ns_per_instr, double *root_wave_instr_per_cu);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,11 @@
 // ref_harness.cc -- C-callable shim over the REFERENCE's own translation units.
 //
 // TEST INFRASTRUCTURE ONLY.  Buildable only where /root/reference exists (this
-// container); the GPU box only ever sees the prebuilt oracle/_ref/libqr_ref.so.
+// container), and LOADED only here: the CPU tests that pin the restatement
+// (tests/test_oracle_vs_ref.py) and tests/golden/make_golden.py.  Nothing that runs on
+// the GPU box -- the `-m gpu` tests, __graft_entry__.smoke(), bench.py -- loads
+// oracle/_ref/libqr_ref.so; they check against liboracle.so (the C restatement) and the
+// committed golden vectors.
 // It links the reference's unmodified sources
 //   src/data/{dataset,vertical_dataset,queryresults,rankedresults}.cc
 //   src/metric/ir/{dcg,ndcg}.cc   src/learning/tree/rtnode_histogram.cc

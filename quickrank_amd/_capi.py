@@ -3,8 +3,10 @@
 Fails loudly when the HIP library is missing or no GPU is visible: there is no
 CPU fallback anywhere in this package.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -42,10 +44,23 @@ SYMBOLS = [
     "qr_tree_set_max_features", "qr_subsample_set", "qr_subsample_set_doc", "qr_ensemble_partial_scores",
     "qr_prof_get_child", "qr_bins_build_wide", "qr_thresholds_read", "qr_bins_read_u32",
     "qr_node_hist_read_ragged", "qr_ctx_stream", "qr_obl_begin", "qr_obl_propose", "qr_obl_mark",
-    "qr_obl_apply", "qr_obl_exchange_buffers", "qr_obl_level_exchange",
+    "qr_obl_apply", "qr_obl_exchange_buffers", "qr_obl_level_exchange", "qr_prof_lds_atomic",
 ]
 
 _LIB = None
+# Live contexts, closed by an atexit hook while the interpreter and the HIP runtime are both
+# still whole: a Context that is only collected during interpreter shutdown (a global, a frame
+# of a failed test) would otherwise call qr_ctx_destroy -- stream syncs, hipFree, hipHostFree --
+# at a point where the order against the runtime's own exit handlers is not defined.
+_LIVE = None
+
+
+def _close_all():
+    for ctx in list(_LIVE or ()):
+        try:
+            ctx.close()
+        except Exception:
+            pass
 
 
 class QrError(RuntimeError):
@@ -75,6 +90,9 @@ def lib():
         except ImportError:
             pass
     L = C.CDLL(path)
+    global _LIVE
+    _LIVE = weakref.WeakSet()
+    atexit.register(_close_all)   # (registered after torch's own hooks: runs before them)
     vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
     L.qr_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.qr_ctx_destroy.argtypes = [vp]
@@ -135,6 +153,7 @@ def lib():
     L.qr_prof_get.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.qr_prof_enable.argtypes = [vp, C.c_int]
     L.qr_prof_get_child.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_double)]
+    L.qr_prof_lds_atomic.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
     L.qr_ctx_set_doc_shard.argtypes = [vp, C.c_int, C.c_int, u64, u64]
     L.qr_bins_stats.argtypes = [vp, sz, vp, vp, vp]
     L.qr_thresholds_from_stats.argtypes = [sz, sz, sz, vp, vp, vp, vp, vp]
@@ -188,6 +207,7 @@ class Context:
         if rc:
             raise QrError(f"qr_ctx_create: {self.L.qr_last_error(None).decode()} (code {rc})")
         self.h = h
+        _LIVE.add(self)
         self.N = self.F = self.Q = 0
         self.vN = self.vQ = 0
         self.stream = None          # None: the context's own stream
@@ -220,6 +240,7 @@ class Context:
         if getattr(self, "h", None):
             self.L.qr_ctx_destroy(self.h)
             self.h = None
+            _LIVE.discard(self)
 
     def __del__(self):
         try:
@@ -570,10 +591,12 @@ class Context:
         return out, ms.value
 
     # -- instrumentation ------------------------------------------------------
-    def prof_enable(self, on=True, children=False, every=1):
+    def prof_enable(self, on=True, children=False, every=1, lambdas=False):
         """HIP events on the root histogram launches (every `every`-th one), optionally on the
-        child launches too."""
-        self._ck(self.L.qr_prof_enable(self.h, int(bool(on)) | (2 if children else 0) | ((int(every) & 0xff) << 8)))
+        child launches too -- or (`lambdas`, instead of the children) on the lambda pass's launch;
+        both are read with prof_get_child()."""
+        self._ck(self.L.qr_prof_enable(self.h, int(bool(on)) | (2 if children else 0) | (4 if lambdas else 0)
+                                       | ((int(every) & 0xff) << 8)))
 
     def prof_get_child(self):
         n, ms = C.c_uint64(), C.c_double()
@@ -587,3 +610,10 @@ class Context:
         n, ms, b = C.c_uint64(), C.c_double(), C.c_double()
         self._ck(self.L.qr_prof_get(self.h, C.byref(n), C.byref(ms), C.byref(b)))
         return dict(launches=n.value, total_ms=ms.value, alg_bytes=b.value)
+
+    def prof_lds_atomic(self):
+        """qr_prof_lds_atomic: the bare ds_add_u64 rate of a CU, measured in this process."""
+        cyc, ghz, ns, wi = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self._ck(self.L.qr_prof_lds_atomic(self.h, C.byref(cyc), C.byref(ghz), C.byref(ns), C.byref(wi)))
+        return dict(cycles_per_instr=cyc.value, shader_ghz=ghz.value, ns_per_instr=ns.value,
+                    root_wave_instr_per_cu=wi.value)

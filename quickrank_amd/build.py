@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.environ.get("QR_HIP_LIB") or os.path.join(LIBDIR, "libqr_hip.so")
 SOURCES = ["qr_api.hip", "k_bins.hip", "k_lambda.hip", "k_tree.hip", "k_score.hip", "k_sample.hip",
-           "k_wide.hip"]
+           "k_wide.hip", "k_ubench.hip"]
 HEADERS = [os.path.join(CSRC, "qr_internal.h"), os.path.join(CSRC, "qr_wave.h"), os.path.join(CSRC, "qr_dev.h"),
            os.path.join(HERE, "..", "include", "qr_hip.h")]
 # -ffp-contract=off: the reference's arithmetic is separate multiply/add
@@ -17,22 +17,50 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+OBJDIR = os.path.join(LIBDIR, "obj")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _stale():
+    return _newer(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+
+
 def build(force=False, verbose=False):
+    """One object per .hip source (compiled side by side, only the stale ones), then the link:
+    a change to one kernel file costs that file's compile, not all eight."""
     if not force and not _stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(LIBDIR, exist_ok=True)
-    # (QR_HIP_EXTRA_FLAGS + QR_HIP_LIB: experiment builds next to the product library)
-    cmd = [hipcc] + FLAGS + os.environ.get("QR_HIP_EXTRA_FLAGS", "").split() + ["-o", LIB] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJDIR, exist_ok=True)
+    # (QR_HIP_EXTRA_FLAGS + QR_HIP_LIB: experiment builds next to the product library -- their
+    # objects are kept apart, keyed by the library's name)
+    extra = os.environ.get("QR_HIP_EXTRA_FLAGS", "").split()
+    tag = os.path.splitext(os.path.basename(LIB))[0]
+    cflags = [f for f in FLAGS if f != "-shared"] + extra
+    stamp = os.path.join(OBJDIR, tag + ".flags")
+    flags_changed = not os.path.exists(stamp) or open(stamp).read() != " ".join(cflags)
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, tag + "." + os.path.splitext(src)[0] + ".o")
+        path = os.path.join(CSRC, src)
+        if force or flags_changed or _newer(obj, [path] + HEADERS):
+            cmd = [hipcc] + cflags + ["-c", "-o", obj, path]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    with open(stamp, "w") as f:
+        f.write(" ".join(cflags))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -29,6 +29,8 @@
 // with glibc to ~1e-15 relative, not bitwise (SURVEY.md section 7 hard part 3); log2 discounts come from a
 // host-built table (glibc values) so the metric itself is bit-exact given the
 // ranking.
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 
 #include "qr_internal.h"
@@ -247,6 +249,30 @@ __device__ __forceinline__ double qr_rcp(double x) {
   r = fma(fma(-x, r, 1.0), r, r);
   r = fma(fma(-x, r, 1.0), r, r);
   return r;
+}
+
+// Batched wave reductions of the pair sweep (k_lambda, queries of up to 128 documents).
+// swap32_add(a, b): lanes 0..31 get a[l] + a[l + 32], lanes 32..63 get b[l - 32] + b[l] -- one
+// v_permlane32_swap per dword exchanges a's upper half with b's lower half.
+__device__ __forceinline__ double swap32_add(const double a, const double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)__double2loint(a), (uint32_t)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)__double2hiint(a), (uint32_t)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// swap16_add(a, b): even 16-lane rows get a[row] + a[row + 1], odd rows b[row - 1] + b[row]
+// (v_permlane16_swap: a's odd rows against b's even rows)
+__device__ __forceinline__ double swap16_add(const double a, const double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)__double2loint(a), (uint32_t)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)__double2hiint(a), (uint32_t)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// every lane its 16-lane row's total (the first four steps of wave_sum)
+__device__ __forceinline__ double row_sum(double v) {
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  return v;
 }
 
 // pow(2.0, label) of dcg.cc:37 / ndcg.cc:80: exact for the integral relevance
@@ -855,43 +881,65 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     double ola = 0.0, owa = 0.0, olb = 0.0, owb = 0.0;
-    for (uint32_t r1 = 0; r1 < size; ++r1) {
-      const float l1 = sl[r1];
-      const double p1 = pw[r1], inv1 = ilt[r1], s1 = sr[r1];
-      double c1 = 0.0, cw = 0.0;
-      const bool va = ina && ra > r1 && l1 != la, vb = inb && rb > r1 && l1 != lb;
-      if (va) {
-        double slam, del;
-        if (use_e)
-          pair_term_e(l1, p1, inv1, s1, la, pa_, ia, sa, slam, del);
-        else
-          pair_term(l1, p1, inv1, s1, la, pa_, ia, sa, slam, del);
-        c1 += slam;
-        cw += del;
-        ola -= slam;
-        owa += del;
-      }
-      if (vb) {
-        double slam, del;
-        if (use_e)
-          pair_term_e(l1, p1, inv1, s1, lb, pb_, ib, sb, slam, del);
-        else
-          pair_term(l1, p1, inv1, s1, lb, pb_, ib, sb, slam, del);
-        c1 += slam;
-        cw += del;
-        olb -= slam;
-        owb += del;
-      }
-      if (__any(c1 != 0.0 || cw != 0.0)) {
-        const double t1 = wave_sum(c1);
-        const double tw = wave_sum(cw);
-        if (lane == 0) {
-          accl[r1] = t1;
-          accw[r1] = tw;
+    // Five ranks r1 per round: their ten per-lane sums (c1, cw) are reduced TOGETHER -- a
+    // reduce-scatter over the wave's halves (v_permlane32_swap: the lower half carries on with
+    // the c1's, the upper with the cw's), one over the row pairs (v_permlane16_swap: even rows
+    // the even ranks of the round, odd rows the odd ones), then three row totals on DPP -- 60
+    // vector instructions per round where ten wave_sum calls took ~260 (a query's twenty wave
+    // sums were a third of the pair sweep).  Fixed association, as before; the
+    // totals land in lanes 0 / 16 / 32 / 48.
+    constexpr int RR = 5;
+    for (uint32_t rbase = 0; rbase < size; rbase += RR) {
+      double c1v[RR], cwv[RR];
+#pragma unroll
+      for (int u = 0; u < RR; ++u) {
+        const uint32_t r1 = rbase + u;
+        double c1 = 0.0, cw = 0.0;
+        if (r1 < size) {  // (wave-uniform)
+          const float l1 = sl[r1];
+          const double p1 = pw[r1], inv1 = ilt[r1], s1 = sr[r1];
+          const bool va = ina && ra > r1 && l1 != la, vb = inb && rb > r1 && l1 != lb;
+          if (va) {
+            double slam, del;
+            if (use_e)
+              pair_term_e(l1, p1, inv1, s1, la, pa_, ia, sa, slam, del);
+            else
+              pair_term(l1, p1, inv1, s1, la, pa_, ia, sa, slam, del);
+            c1 += slam;
+            cw += del;
+            ola -= slam;
+            owa += del;
+          }
+          if (vb) {
+            double slam, del;
+            if (use_e)
+              pair_term_e(l1, p1, inv1, s1, lb, pb_, ib, sb, slam, del);
+            else
+              pair_term(l1, p1, inv1, s1, lb, pb_, ib, sb, slam, del);
+            c1 += slam;
+            cw += del;
+            olb -= slam;
+            owb += del;
+          }
         }
-      } else if (lane == 0) {
-        accl[r1] = 0.0;
-        accw[r1] = 0.0;
+        c1v[u] = c1;
+        cwv[u] = cw;
+      }
+      // halves: lanes 0..31 x[u] = c1v[u][l] + c1v[u][l + 32], lanes 32..63 the same of cwv[u]
+      double x[RR];
+#pragma unroll
+      for (int u = 0; u < RR; ++u) x[u] = swap32_add(c1v[u], cwv[u]);
+      // row pairs: even rows (x[0], x[2], x[4]), odd rows (x[1], x[3], nothing)
+      double z0 = swap16_add(x[0], x[1]), z1 = swap16_add(x[2], x[3]), z2 = swap16_add(x[4], 0.0);
+      z0 = row_sum(z0);
+      z1 = row_sum(z1);
+      z2 = row_sum(z2);
+      if ((lane & 15u) == 0) {
+        double *acc = lane < 32 ? accl : accw;   // rows 0, 1: the lambdas' sums; rows 2, 3: the weights'
+        const uint32_t odd = (lane >> 4) & 1u;   // rows 1, 3: the odd ranks of the round
+        if (rbase + odd < size) acc[rbase + odd] = z0;
+        if (rbase + 2 + odd < size) acc[rbase + 2 + odd] = z1;
+        if (!odd && rbase + 4 < size) acc[rbase + 4] = z2;
       }
     }
     if (ina) {
@@ -1271,7 +1319,18 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
                          idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
                          (size_t)0, c->exact_tail);
-    else
+    else if (c->prof_on && c->prof_lambda && !fork && !which && mode == 0) {
+      // bench.py's roofline_lambda: HIP events on the launch itself (qr_prof_enable bit 2; read
+      // with qr_prof_get_child -- the two timings share the slot and exclude each other)
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      QR_CHECK(c, hipEventCreate(&e0));
+      QR_CHECK(c, hipEventCreate(&e1));
+      hipExtLaunchKernelGGL((k_lambda<false, 1>), dim3(cl.count), dim3(64), lds, st, e0, e1, 0, sc, lb, qoffd, metric,
+                            cut, idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
+                            (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
+                            (size_t)0, c->exact_tail);
+      c->prof_events_child.push_back({e0, e1});
+    } else
       hipLaunchKernelGGL((k_lambda<false, 1>), dim3(cl.count), dim3(64), lds, st, sc, lb, qoffd, metric, cut,
                          idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,

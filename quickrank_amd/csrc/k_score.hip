@@ -86,7 +86,7 @@ int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
   if (!c->d_ens) QR_FAIL(c, QR_ERR_STATE, "no ensemble uploaded");
   const size_t fs = F | 1;
   const size_t rows_bytes = ((size_t)SC_DOCS * fs * 4 + 15) & ~(size_t)15;
-  const size_t budget = 150 * 1024;
+  const size_t budget = c->lds_block - 10 * 1024;  // (150 KB of gfx950's 160: room for the static arrays)
   if (rows_bytes + c->ens_maxnodes * 24 > budget)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "feature rows / tree too large for LDS staging");
   size_t tbatch = (budget - rows_bytes) / (c->ens_maxnodes * 24);
@@ -163,7 +163,7 @@ int qr_k_obl_score(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_ou
   const size_t fs = F | 1;
   const size_t rows_bytes = ((size_t)SC_DOCS * fs * 4 + 15) & ~(size_t)15;
   const size_t per_tree = ((size_t)8 << c->obl_depth) + c->obl_depth * 8;
-  const size_t budget = 150 * 1024;
+  const size_t budget = c->lds_block - 10 * 1024;  // (150 KB of gfx950's 160: room for the static arrays)
   if (rows_bytes + per_tree > budget)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "feature rows / tree too large for LDS staging");
   size_t tbatch = (budget - rows_bytes) / per_tree;
@@ -678,7 +678,7 @@ static int launch_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstride, 
   const size_t F = c->sb_F;  // features the model tests; the rows may be wider
   const size_t doc_bytes = (F * 64 * sizeof(BT) + 15) & ~(size_t)15;
   const size_t per_tree = c->sb_NL * 8 + (c->sb_self ? c->sb_NI + c->sb_NL : c->sb_NI) * 8 + 8 + 2;
-  const size_t budget = 160 * 1024 - 1024;
+  const size_t budget = c->lds_block - 1024;
   // tree batch: 16..32 trees; the rest of the LDS goes to document blocks (occupancy)
   size_t tbatch = 32;
   while (tbatch > 8 && 4 * doc_bytes + tbatch * per_tree + 64 > budget) tbatch -= 8;
@@ -936,11 +936,11 @@ static int launch_obl_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstri
   const size_t doc_bytes = (F * 64 * sizeof(BT) + 15) & ~(size_t)15;
   const size_t nl = (size_t)1 << c->obl_depth;
   const size_t per_tree = nl * 8 + c->obl_depth * 4 + 8;
-  const size_t budget = 150 * 1024;
+  const size_t budget = c->lds_block - 10 * 1024;  // (150 KB of gfx950's 160: room for the static arrays)
   if (NW * doc_bytes + 4 * per_tree + 64 > budget) return -1;  // caller falls back
   // two workgroups per CU when the document tiles allow it (occupancy hides the
   // dependent LDS reads of the level loop); the rest of the LDS goes to the tree batch
-  const size_t half = 78 * 1024;
+  const size_t half = c->lds_cu / 2 - 2 * 1024;
   const size_t room = NW * doc_bytes + 8 * per_tree + 64 <= half ? half : budget;
   size_t tbatch = (room - NW * doc_bytes - 64) / per_tree;
   tbatch = std::min<size_t>(tbatch, 128) & ~(size_t)3;

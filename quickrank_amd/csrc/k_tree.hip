@@ -3752,7 +3752,13 @@ static int launch_scan(qr_ctx *c, int root_mode);
 // the root launch's per-workgroup shares (what hist_body derives per workgroup), made once per
 // (documents of the root, grid, list buffer) and kept on the device
 static int root_shares(qr_ctx *c, uint32_t rootn, int G, int root_buf) {
-  if (c->d_root_wg && c->root_wg_n == rootn && c->root_wg_g == G && c->root_wg_buf == root_buf) return QR_OK;
+  // (the key names everything the shares are made from -- the documents of the root, the
+  // grid, the list buffer AND the generation of c->blocks -- and validity is a flag of its own, so a
+  // root of 0 documents or a rebuild of the blocks by any path cannot be served stale shares)
+  if (c->root_wg_valid && c->d_root_wg && c->root_wg_n == rootn && c->root_wg_g == G &&
+      c->root_wg_buf == root_buf && c->root_wg_gen == c->blocks_gen)
+    return QR_OK;
+  c->root_wg_valid = false;
   std::vector<QrHistWg> h((size_t)G);
   QrPlan plan;
   const uint32_t q = qr_plan_quantum((unsigned long long)rootn * qr_plan_wsum(c->nblocks, c->blocks.data()),
@@ -3796,32 +3802,38 @@ static int root_shares(qr_ctx *c, uint32_t rootn, int G, int root_buf) {
     d.col = (uint32_t)(lf - c->blocks[b].lf0);
     hs[(size_t)lf] = d;
   }
+  // one wait (a launch that reads the old shares may be in flight), then both tables
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
   if (!c->d_root_scan || c->root_scan_n != c->flocal) {
-    QR_CHECK(c, hipStreamSynchronize(c->stream));
     if (c->d_root_scan) (void)hipFree(c->d_root_scan);
     c->d_root_scan = nullptr;
+    c->root_scan_n = 0;
     QR_CHECK(c, hipMalloc((void **)&c->d_root_scan, (size_t)c->flocal * sizeof(QrScanWg)));
     c->root_scan_n = c->flocal;
-  } else {
-    QR_CHECK(c, hipStreamSynchronize(c->stream));
   }
-  QR_CHECK(c, hipMemcpy(c->d_root_scan, hs.data(), (size_t)c->flocal * sizeof(QrScanWg), hipMemcpyHostToDevice));
   if (!c->d_root_wg || c->root_wg_g != G) {
-    QR_CHECK(c, hipStreamSynchronize(c->stream));
     if (c->d_root_wg) (void)hipFree(c->d_root_wg);
     c->d_root_wg = nullptr;
+    c->root_wg_g = 0;
     QR_CHECK(c, hipMalloc((void **)&c->d_root_wg, (size_t)G * sizeof(QrHistWg)));
-  } else {
-    QR_CHECK(c, hipStreamSynchronize(c->stream));  // (a launch that reads the old shares may be in flight)
+    c->root_wg_g = G;
   }
-  QR_CHECK(c, hipMemcpy(c->d_root_wg, h.data(), (size_t)G * sizeof(QrHistWg), hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpyAsync(c->d_root_scan, hs.data(), (size_t)c->flocal * sizeof(QrScanWg), hipMemcpyHostToDevice, c->stream));
+  QR_CHECK(c, hipMemcpyAsync(c->d_root_wg, h.data(), (size_t)G * sizeof(QrHistWg), hipMemcpyHostToDevice, c->stream));
+  QR_CHECK(c, hipStreamSynchronize(c->stream));  // (the host vectors go out of scope)
   c->root_wg_n = rootn;
   c->root_wg_g = G;
   c->root_wg_buf = root_buf;
+  c->root_wg_gen = c->blocks_gen;
+  c->root_wg_valid = true;
   return QR_OK;
 }
 
 static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
+  // (the request for a reset workgroup is consumed HERE, whatever path this call
+  // leaves by -- an early error return must not leave it set for the next tree's root scan)
+  const int reset_nodes = c->obl_reset_nodes;
+  c->obl_reset_nodes = 0;
   // The scalars of the lambda pass before this tree may still be unfinished (qr_lambda_compute
   // defers them, qr_prep.h).  The fused root launches let the workgroups that finish them ride
   // in the scan launch and take the scale from the iteration's slot set meanwhile; every other
@@ -3901,8 +3913,7 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
   }
   if (fused) {  // batched growth: feature-major partials, reduce + scan in one launch
     // (level-wise growth: one more workgroup, the last, resets the tree state -- c->obl_reset_nodes)
-    QrResetJob reset{c->d_tree, (u64)c->cur_minls, (int32_t)c->obl_reset_nodes, 0};
-    c->obl_reset_nodes = 0;
+    QrResetJob reset{c->d_tree, (u64)c->cur_minls, (int32_t)reset_nodes, 0};
     hipLaunchKernelGGL(k_redscan, dim3(c->flocal + prep.nwg + (reset.maxnodes ? 1 : 0), 1), dim3(1024), 0, c->stream, c->d_tree, 1, rootn,
                        c->d_lplan, c->d_blocks, c->nblocks, G, (const u64 *)c->d_partials, c->d_hsum,
                        c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf, c->d_scalars, c->d_featrec,

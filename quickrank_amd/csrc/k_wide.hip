@@ -953,7 +953,10 @@ static int whist_attr(qr_ctx *c) {
   return QR_OK;
 }
 
-bool qr_k_wide_fast_rows(size_t max_slots) { return max_slots <= QR_W16_SLOTS; }
+// (the LDS-tiled kernel holds a whole row group: QR_W16_SLOTS * 128 bytes -- only where a workgroup can have them)
+bool qr_k_wide_fast_rows(const qr_ctx *c, size_t max_slots) {
+  return max_slots <= QR_W16_SLOTS && c->lds_block >= (size_t)QR_W16_SLOTS * 128;
+}
 static bool qr_k_wide_fast(const qr_ctx *c) { return c->d_wbins16 && !getenv("QR_WIDE_NO_FAST"); }
 
 // the node histograms of a launch: rows of up to QR_W16_SLOTS slots through the blocked u16

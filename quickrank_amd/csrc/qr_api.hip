@@ -103,6 +103,21 @@ int qr_ctx_create(int device, qr_ctx **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
     c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    //  the LDS budgets of the fast paths follow the device: a workgroup's opt-in maximum
+    // and a CU's total.  gfx950 has 160 KB of both whatever the runtime's property fields say (the
+    // kernels were measured there); any other device gets what it reports.
+    size_t blk = std::max<size_t>(prop.sharedMemPerBlockOptin, prop.sharedMemPerBlock);
+    size_t cu = std::max<size_t>(prop.maxSharedMemoryPerMultiProcessor, blk);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) {
+      blk = std::max<size_t>(blk, 160 * 1024);
+      cu = std::max<size_t>(cu, 160 * 1024);
+    }
+    if (blk) c->lds_block = blk;
+    if (cu) c->lds_cu = cu;
+    if (getenv("QR_SPEC_DEBUG"))
+      fprintf(stderr, "qr: %s, %d CUs, LDS per workgroup %zu (optin %zu, default %zu), per CU %zu\n", prop.gcnArchName,
+              c->ncu, c->lds_block, (size_t)prop.sharedMemPerBlockOptin, (size_t)prop.sharedMemPerBlock,
+              (size_t)prop.maxSharedMemoryPerMultiProcessor);
   }
   if (hipStreamCreate(&c->stream) != hipSuccess) {
     delete c;
@@ -198,6 +213,13 @@ void qr_ctx_destroy(qr_ctx *c) {
     fprintf(stderr, "qr: %llu trees with a guessed step count, %llu continued (guess too low), last hint %zu\n",
             (unsigned long long)c->spec_trees, (unsigned long long)c->spec_misses, c->steps_hint);
   (void)hipSetDevice(c->device);
+  // Teardown order: every stream this context created is drained BEFORE any
+  // memory its kernels may touch is released -- the lambda pass's size classes run on the
+  // auxiliary streams and write the pinned read-back block's neighbours; they are joined to the
+  // main stream by events, but a join that was enqueued and never waited for (an error return
+  // between fork and join) would otherwise leave work behind hipHostFree / hipFree.
+  for (int i = 0; i < 4; ++i)
+    if (c->aux_stream[i]) (void)hipStreamSynchronize(c->aux_stream[i]);
   (void)hipStreamSynchronize(c->stream);
   free_train(c);
   free_valid(c);
@@ -516,8 +538,8 @@ static int bins_finish(qr_ctx *c) {
   const size_t per_rank = (F + fworld - 1) / fworld;
   const size_t f_lo = std::min(F, per_rank * frank);
   const size_t f_hi = std::min(F, f_lo + per_rank);
-  c->root_wg_n = 0;  // (the root launch's ready-made shares follow the blocks: rebuilt at the next root)
-  c->root_wg_g = 0;
+  c->root_wg_valid = false;  // (the root launch's ready-made shares follow the blocks: rebuilt at the next root)
+  ++c->blocks_gen;
   c->blocks.clear();
   c->h_gf2lf.assign(F, -1);
   c->h_lf2gf.clear();
@@ -777,7 +799,7 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
   QR_CHECK(c, dalloc(&c->d_wthr, c->wcells));
   QR_CHECK(c, hipMemcpy(c->d_wthr, c->h_wthr.data(), c->wcells * 4, hipMemcpyHostToDevice));
   QR_CHECK(c, dalloc(&c->d_wbins, N * FL));
-  if (qr_k_wide_fast_rows(c->wmax))  // short rows: the blocked u16 copy the fast histogram kernel reads
+  if (qr_k_wide_fast_rows(c, c->wmax))  // short rows: the blocked u16 copy the fast histogram kernel reads
     QR_CHECK(c, dalloc(&c->d_wbins16, N * 16 * ((FL + 15) / 16)));
   {  // the chunk table of the chunked scan: (feature, first slot) of every QR_WCHUNK slots of a row
     std::vector<uint32_t> ch, first(FL + 1, 0);
@@ -1307,10 +1329,14 @@ static int tree_settle_keep(qr_ctx *c) {
   // The guess was too low: the tree is carried on `cont_steps` steps at a time (default 1: the
   // tree usually needs just one more, and the worst case left would be a dozen launches that
   // find nothing to do), looking at the last control call's word after each piece.
+  // (the piece doubles on every further miss -- 1, 2, 4, ... steps -- so a deep tree
+  // behind a shallow one costs O(log k) host round trips, not k)
   size_t done = (size_t)c->tree_step;
+  size_t piece_len = c->cont_steps;
   while (w & 1) {
     const size_t worst = c->cur_nleaves - 1 > done ? c->cur_nleaves - 1 - done : 1;
-    const size_t piece = c->cont_steps ? std::min(worst, c->cont_steps) : worst;
+    const size_t piece = piece_len ? std::min(worst, piece_len) : worst;
+    piece_len *= 2;
     if ((rc = qr_k_tree_continue(c, c->cur_nleaves, c->cur_minls, done, piece))) return rc;
     done += piece;
     if ((rc = qr_k_tree_finish(c, c->spec_newton))) return rc;
@@ -1996,7 +2022,7 @@ int qr_oblivious_upload(qr_ctx *c, const uint32_t *feat, const float *thr,
       if (tmax <= 255 && depth <= 8 && (F - 1) * 64 <= 0xffff) {
         // a batch of leaf values next to eight (else four) 64-document blocks in half of a CU's
         // LDS; a thread carries four 16-byte pieces of the next batch (k_obl_score_s)
-        const size_t doc_bytes = (F * 64 + 15) & ~(size_t)15, half = 80 * 1024;
+        const size_t doc_bytes = (F * 64 + 15) & ~(size_t)15, half = c->lds_cu / 2;  // (two workgroups per CU)
         size_t tb = 0, nw = 0;
         for (size_t w : {(size_t)8, (size_t)4}) {
           if (w * doc_bytes + 4 * nl * 8 > half) continue;
@@ -2086,6 +2112,7 @@ int qr_prof_enable(qr_ctx *c, int on) {
   if (!c) return QR_ERR_ARG;
   c->prof_on = (on & 1) != 0;
   c->prof_child = (on & 2) != 0;
+  c->prof_lambda = (on & 4) != 0 && !c->prof_child;
   // bits 8..15: events on every k-th root launch only (0 / 1 = every launch).  A launch that
   // carries a start and a stop event costs the stream ~7.5 us (scripts/ubench/launch_chain.hip),
   // which a caller timing whole iterations around the launches may not want on each of them

@@ -283,6 +283,10 @@ struct qr_ctx {
   size_t xlevel_cap = 0;
   size_t xleaf_cap = 0;
   int ncu = 256;
+  // LDS the device really has (hipDeviceProp_t): a workgroup's opt-in maximum and a CU's total.  The
+  // fast paths that were sized for gfx950's 160 KB are taken only when they fit (qr_api.hip,
+  // k_wide.hip); everything else falls through to the general kernels.
+  size_t lds_block = 160 * 1024, lds_cu = 160 * 1024;
   // training data
   size_t N = 0, F = 0, Q = 0, maxq = 0;
   float *d_raw = nullptr;        // [N][F] row-major f32
@@ -385,6 +389,9 @@ struct qr_ctx {
   int root_scan_n = 0;
   uint32_t root_wg_n = 0;
   int root_wg_g = 0, root_wg_buf = -1;
+  bool root_wg_valid = false;      // the cached shares match (root_wg_n, root_wg_g, root_wg_buf, root_wg_gen)
+  uint64_t blocks_gen = 0;         // counts the rebuilds of c->blocks (bins_finish): part of the cache key
+  uint64_t root_wg_gen = 0;
   bool no_root_shares = false;    // QR_NO_ROOT_SHARES=1: every root workgroup plans for itself (A/B, debugging)
   int obl_reset_nodes = 0;        // level-wise growth: node records the root scan launch's last workgroup resets (0: none)
   bool obl_own_launches = false;  // QR_OBL_OWN_LAUNCHES=1: the tree-state reset and k_finish as launches of their own (A/B, debugging)
@@ -518,6 +525,7 @@ struct qr_ctx {
   bool finish_in_decide = false;  // the tree's last control call numbered its leaves (no k_finish launch)
   unsigned prof_stride = 1, prof_tick = 0;  // events on every prof_stride-th root launch
   bool prof_child = false;       // also time the child-histogram launches (qr_prof_enable(ctx, 2 | 1))
+  bool prof_lambda = false;      // ... or the lambda pass's launch instead (qr_prof_enable(ctx, 4 | 1)): same slot
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events_child;
   uint64_t prof_launches = 0, prof_launches_child = 0;
@@ -547,7 +555,7 @@ int qr_k_colstats(qr_ctx *c, const float *col, size_t N, size_t F, uint32_t limi
 int qr_k_binning(qr_ctx *c);
 int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds);
 int qr_k_wide_binning(qr_ctx *c, const float *d_col);
-bool qr_k_wide_fast_rows(size_t max_slots);
+bool qr_k_wide_fast_rows(const qr_ctx *c, size_t max_slots);
 struct QrTreeState;
 bool qr_k_wide_batch_ok(const qr_ctx *c);
 int qr_k_whist_scan_batch(qr_ctx *c, const QrTreeState *ts, const double *pss);

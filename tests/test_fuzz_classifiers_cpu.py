@@ -9,8 +9,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from fuzz_parity import (deviance_order_tie, oblivious_level_gain_tie, score_tie_before,  # noqa: E402
-                         upstream_gain_tie)
+from fuzz_parity import (deviance_order_tie, oblivious_level_gain_tie, parting_gains_exact,  # noqa: E402
+                         score_tie_before, upstream_gain_tie)
 from quickrank_amd._capi import NODE_DTYPE  # noqa: E402
 
 
@@ -88,3 +88,22 @@ def test_score_tie_before_wants_a_rounding_sized_gap_inside_one_query():
     two = np.array([0, 4, 8], np.uint64)                                          # the pair sits in DIFFERENT queries
     assert not score_tie_before(STMAP, model(1.0, 1.0 + 2.3e-16), 1, 1.0, two)
     assert not score_tie_before(STMAP, model(1.0, 1.0 + 2.3e-16), 0, 1.0, qoff)   # going into tree 0 all scores are 0
+
+
+def test_parting_gains_exact_prices_the_node_where_the_trees_part():
+    o = tree([(0, 0, 1, 2, 10.0, 8), (-1, 0, -1, -1, 3.0, 4), (-1, 0, -1, -1, 2.0, 4)])
+    g = tree([(2, 0, 1, 2, 10.0, 8), (-1, 0, -1, -1, 1.5, 4), (-1, 0, -1, -1, 3.5, 4)])
+    tie = np.array([0.5, 0.0, 1.5, 1.0, 0.5, 0.0, 0.5, 0.0])       # feature 0 cuts 3 | 1, feature 2 cuts 1 | 3
+    rel, docs = parting_gains_exact(STMAP, o, g, tie)
+    assert rel == 0.0 and docs == 8
+    near = tie.copy()
+    near[0] += 2.0 ** -40                                           # (3 + e)^2 + 1 against (1 + e)^2 + 9: apart by 4e
+    rel, _ = parting_gains_exact(STMAP, o, g, near)
+    assert 0.0 < rel < 1e-9
+    far = tie.copy()
+    far[0] = 1.0
+    rel, _ = parting_gains_exact(STMAP, o, g, far)
+    assert rel > 1e-3
+    assert parting_gains_exact(STMAP, o, o, tie) is None            # the same cuts everywhere: nothing parted
+    mirrored = tree([(1, 0, 1, 2, 10.0, 8), (-1, 0, -1, -1, 2.0, 4), (-1, 0, -1, -1, 3.0, 4)])
+    assert parting_gains_exact(STMAP, o, mirrored, tie) is None     # the same partition, mirrored

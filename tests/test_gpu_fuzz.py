@@ -22,6 +22,11 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
 
 # configuration index -> what the sweep reported on the round-1 state
+# runs of a sweep that may end at a split the reference decides by rounding noise (every one
+# classified): the ceiling the extra seeds are held to (rounds 2-3 measured 0.3 - 4.3 %
+# per 300-configuration seed, 1.9 % over 12,600 configurations)
+DIVERGENCE_CEILING = 0.05
+
 KNOWN_ROUNDING_DECIDED = {58: "MART N=1035 F=200 nthr=16 minls=2 64",
                           67: "MART N=393 F=200 nthr=64 minls=2 64",
                           174: "MART N=23 F=136 nthr=255 minls=2 31",
@@ -43,11 +48,45 @@ def test_fuzz_sweep_seed0():
         assert KNOWN_ROUNDING_DECIDED[i] in r["desc"], r["desc"]
         print("rounding-decided:", r["desc"], r["status"], "tree", r["tree"])
     sizes = [s for r in res for s in r["tie_sizes"]]
+    # (seed 0's ties happen to sit in nodes of <= TIE_MAX_DOCS documents; that is a regression
+    # marker for THIS seed, not a property of the design -- see the other seeds' test)
     assert all(s <= TIE_MAX_DOCS for s in sizes)
     # ties are the exception, not the rule: far fewer than one per run
     assert sum(r["ties"] for r in res) <= 150, sum(r["ties"] for r in res)
     print(f"fuzz: {sum(r['ties'] for r in res)} equal-partition ties over 300 runs, largest node "
           f"{max(sizes or [0])} documents; {len(cut)} runs decided by rounding noise")
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_sweep_more_seeds_divergence_rate(seed):
+    """two more seeds of the sweep inside `pytest -m gpu`, asserting what is TRUE
+    of the fixed-point design instead of a node-size bound that only seed 0 kept: (i) every run ends
+    in "ok" or in one of the CLASSIFIED kinds -- an exact gain tie between different partitions
+    (priced in exact rational arithmetic on the oracle's pseudo-responses), a gain difference below
+    the fixed-point gradients' resolution, a zero-deviance gate, a heap order or a ranking decided
+    by rounding (the latter verified causally: the device's tree is what the reference's algorithm
+    builds from the device's own scores); anything else raises inside sweep(); (ii) an
+    equal-partition tie is a split that cuts the node's documents into the SAME two sets as the
+    oracle's -- equal gains in exact arithmetic by construction -- whatever the node's size (the
+    walker verifies the sets; sizes are reported, not bounded: round 3's sweeps met 1376
+    documents); (iii) the runs cut short stay below the ceiling."""
+    from fuzz_parity import sweep
+    n = 200
+    res = sweep(n, seed, verbose=False)
+    assert len(res) == n
+    kinds = {}
+    for r in res:
+        kinds[r["status"]] = kinds.get(r["status"], 0) + 1
+    allowed = {"ok", "gain_tie", "gain_tie_fp", "zero_deviance", "heap_tie", "score_tie"}
+    assert set(kinds) <= allowed, kinds
+    cut = n - kinds.get("ok", 0)
+    sizes = [s for r in res for s in r["tie_sizes"]]
+    print(f"fuzz seed {seed}: {kinds}, {sum(r['ties'] for r in res)} equal-partition ties (largest node "
+          f"{max(sizes or [0])} documents), {sum(r['flips'] for r in res)} runs with a rank flip")
+    assert cut <= DIVERGENCE_CEILING * n, (cut, kinds, [r["desc"] for r in res if r["status"] != "ok"])
+    for r in res:   # a priced gain tie is exact (0.0) or below the fixed-point resolution
+        if r["status"] in ("gain_tie", "gain_tie_fp") and r["gain_rel"] is not None:
+            assert r["gain_rel"] <= 1e-9 and (r["status"] == "gain_tie_fp") == (r["gain_rel"] > 0.0), r
 
 
 def test_scoring_fuzz_sweep_seed0():

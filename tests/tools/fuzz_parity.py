@@ -105,6 +105,72 @@ def scores_before(stmap, om, t, shrinkage):
     return scores
 
 
+def parting_gains_exact(stmap, o, g, pseudo):
+    """The two trees walked together breadth-first over the same document sets to the first node
+    both split but cut DIFFERENTLY; there, the gain `L^2 / lc + R^2 / rc` (rt.cc:278-279) of the
+    oracle's and of the device's candidate in EXACT rational arithmetic on `pseudo` (the
+    pseudo-responses the oracle fitted this tree on).  Returns (relative difference as a float,
+    0.0 = equal in exact arithmetic; documents of the node), or None if the trees never part that way.
+    (the deviance-based comparison to 1e-9 claimed an exact tie without pricing one.)"""
+    from fractions import Fraction
+    queue = [(0, 0, np.arange(stmap.shape[1]))]
+    while queue:
+        oi, gi, d = queue.pop(0)
+        a, b = o[oi], g[gi]
+        if a["feature"] < 0 or b["feature"] < 0:
+            continue
+        ol = stmap[a["feature"], d] <= a["thr_id"]
+        gl = stmap[b["feature"], d] <= b["thr_id"]
+        if np.array_equal(gl, ol):
+            gL, gR = b["left"], b["right"]
+        elif np.array_equal(gl, ~ol):
+            gL, gR = b["right"], b["left"]
+        else:
+            def gain(go):
+                lc, rc = int(go.sum()), int((~go).sum())
+                L = sum((Fraction(float(v)) for v in pseudo[d[go]]), Fraction(0))
+                R = sum((Fraction(float(v)) for v in pseudo[d[~go]]), Fraction(0))
+                return L * L / lc + R * R / rc
+            ga, gb = gain(ol), gain(gl)
+            m = max(abs(ga), abs(gb))
+            return (float(abs(ga - gb) / m) if m else 0.0), len(d)
+        queue.append((int(a["left"]), int(gL), d[ol]))
+        queue.append((int(a["right"]), int(gR), d[~ol]))
+    return None
+
+
+def device_tree_follows_from_device_scores(tr, oracle, labels, qoff, gtrees, t, kw, algo):
+    """Causality of a `score_tie`: the device's tree t must be exactly what the
+    REFERENCE's algorithm builds from the device's OWN scores going into tree t -- its trees
+    0 .. t-1 walked on the bin map, the oracle's lambdas of those scores, the oracle's tree fit.
+    Then the difference from the oracle's run lies upstream, in two scores that differ by the
+    rounding of the leaf outputs' summation order, and nowhere else."""
+    from parity_util import assert_tree_parity
+    dev = {"nodes": [gtrees[k] for k in range(t)], "nnodes": [0] * t}
+    for k in range(t):   # (records beyond the tree's nodes are zero-filled with feature -1: count the reachable ones)
+        n, stack = 0, [0]
+        while stack:
+            i = stack.pop()
+            n = max(n, i + 1)
+            if gtrees[k][i]["feature"] >= 0:
+                stack += [int(gtrees[k][i]["left"]), int(gtrees[k][i]["right"])]
+        dev["nnodes"][k] = n
+    sc = scores_before(tr.stmap, dev, t, kw["shrinkage"])
+    lam = algo.endswith("LAMBDAMART")
+    if lam:
+        pseudo, weights = oracle.lambdas(labels, sc, qoff)[:2]
+    else:
+        pseudo, weights = labels.astype(np.float64) - sc, None
+    fit = tr.fit_tree(pseudo, nleaves=kw.get("nleaves", 10), minls=kw["minls"],
+                      oblivious_depth=kw.get("depth") if algo.startswith("OBV") else None)
+    tr.update_output(fit, pseudo, weights)   # rt.cc:165-207: the leaves' outputs, as the device's records carry them
+    try:
+        assert_tree_parity(tr.stmap, fit["nodes"], gtrees[t], tie_max_docs=1 << 30, value_rtol=1e-6)
+        return True
+    except AssertionError:
+        return False
+
+
 def oblivious_level_gain_tie(stmap, o, g, pseudo, minls):
     """Oblivious trees (ot.cc:32-201: one (feature, slot) per level, the one with the largest sum
     of the nodes' gains): at the first level where the device names another candidate than the
@@ -182,7 +248,8 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
             continue
         desc = (f"[{i}] {algo} N={len(labels)} F={F} nthr={nthr} minls={minls} {kw.get('nleaves', '')}{kw.get('depth', '')}"
                 + (" adv" if adversarial else ""))
-        rec = dict(i=i, desc=desc, status="ok", ties=0, tie_sizes=[], flips=0, tree=None)
+        rec = dict(i=i, desc=desc, status="ok", ties=0, tie_sizes=[], flips=0, tree=None, gain_rel=None,
+                   gain_node_docs=None)
         om = oracle.train(x, labels, qoff, algo=algo, **kw)
         gm = Mart(algo=algo, **kw).learn(x, labels, qoff)
         assert len(gm.ensemble) == om["ntrees_built"], desc
@@ -227,6 +294,21 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
                 # ... or the walker met a consequence first: look for the node where the trees parted
                 if status is None and not algo.startswith("OBV") and upstream_gain_tie(tr.stmap, o, g):
                     status = "gain_tie"
+                #  a gain tie is PRICED, not inferred from deviances: both candidates' gains at
+                # the node where the trees part, in exact rational arithmetic on the oracle's own
+                # pseudo-responses.  0 = an exact tie (the reference picks by rounding noise); up to 1e-9 =
+                # apart by less than the device's 33-bit fixed-point gradients resolve.
+                if status == "gain_tie" and not algo.startswith("OBV"):
+                    sc = scores_before(tr.stmap, om, t, kw["shrinkage"])
+                    pseudo = (oracle.lambdas(labels, sc, qoff)[0] if algo.endswith("LAMBDAMART")
+                              else labels.astype(np.float64) - sc)
+                    priced = parting_gains_exact(tr.stmap, o, g, pseudo)
+                    if priced is None or priced[0] > 1e-9:
+                        print(desc, "TREE", t, "gain tie NOT confirmed by exact pricing:", priced)
+                        raise AssertionError((desc, "tree", t, "gain tie not confirmed", priced))
+                    rec["gain_rel"], rec["gain_node_docs"] = priced
+                    if priced[0] > 0.0:
+                        status = "gain_tie_fp"
                 # ... or both trees cut alike and spent the leaf budget on different, equally deviant nodes
                 if status is None and not algo.startswith("OBV") and deviance_order_tie(tr.stmap, o, g):
                     status = "heap_tie"
@@ -239,8 +321,11 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
                               else labels.astype(np.float64) - sc)
                     if oblivious_level_gain_tie(tr.stmap, o, g, pseudo, minls):
                         status = "gain_tie"
+                # (a near-tie somewhere is not enough -- the device's tree must be what the
+                # REFERENCE's algorithm builds from the device's own scores)
                 if status is None and algo.endswith("LAMBDAMART") and t > 0 and \
-                        score_tie_before(tr.stmap, om, t, kw["shrinkage"], qoff):
+                        score_tie_before(tr.stmap, om, t, kw["shrinkage"], qoff) and \
+                        device_tree_follows_from_device_scores(tr, oracle, labels, qoff, gm.ensemble.trees, t, kw, algo):
                     status = "score_tie"
                 if status is None:
                     print(desc, "TREE", t, "MISMATCH", e)

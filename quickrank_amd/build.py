@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.environ.get("QR_HIP_LIB") or os.path.join(LIBDIR, "libqr_hip.so")
 SOURCES = ["qr_api.hip", "k_bins.hip", "k_lambda.hip", "k_tree.hip", "k_score.hip", "k_sample.hip",
-           "k_wide.hip", "k_ubench.hip"]
+           "k_wide.hip", "k_ubench.hip", "k_exact.hip"]
 HEADERS = [os.path.join(CSRC, "qr_internal.h"), os.path.join(CSRC, "qr_wave.h"), os.path.join(CSRC, "qr_dev.h"),
            os.path.join(HERE, "..", "include", "qr_hip.h")]
 # -ffp-contract=off: the reference's arithmetic is separate multiply/add

@@ -999,6 +999,7 @@ static int launch_whist(qr_ctx *c, const int mode, const uint32_t rootn, const i
 // mode 0: root histogram -> slot 0; mode 1: the directly built child of the split being
 // applied (+ its sibling); then the per-feature records for k_decide
 int qr_k_whist_scan(qr_ctx *c, int root_mode) {
+  if (qr_exact_active(c)) return qr_k_exact_scan(c, root_mode);  // long rows: the pre-sorted lists (k_exact.hip)
   int rc = whist_attr(c);
   if (rc) return rc;
   const int mode = root_mode ? 0 : 1;
@@ -1043,7 +1044,9 @@ int qr_k_whist_scan(qr_ctx *c, int root_mode) {
 // applied ahead of their turn cost more than the shorter chain saves -- 4096 thresholds on the
 // MSLR-shaped set: 1.63 ms per iteration batched against 1.47 over the first trees, 1.78 / 1.78
 // over 40)
-bool qr_k_wide_batch_ok(const qr_ctx *c) { return c->wide && c->d_wbins16 != nullptr && c->wmax <= QR_WCHUNK; }
+bool qr_k_wide_batch_ok(const qr_ctx *c) {
+  return c->wide && c->d_wbins16 != nullptr && c->wmax <= QR_WCHUNK && !qr_exact_active(c);
+}
 int qr_k_whist_scan_batch(qr_ctx *c, const QrTreeState *ts, const double *pss) {
   int rc = whist_attr(c);
   if (rc) return rc;

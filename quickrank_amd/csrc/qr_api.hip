@@ -159,6 +159,7 @@ static void free_train(qr_ctx *c) {
   c->d_wpart = nullptr;
   c->wpart_cap = 0;
   dfree(c->d_wchunk); dfree(c->d_wchunk0); dfree(c->d_wtot_s); dfree(c->d_wtot_c); dfree(c->d_wcbest);
+  qr_k_exact_free(c);
   c->wchunks = 0;
   c->wide = false;
   c->wcells = 0;
@@ -747,6 +748,7 @@ int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t 
     dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_thr_size);
     dfree(c->d_woff); dfree(c->d_wthr); dfree(c->d_wbins); dfree(c->d_wbins16);
     dfree(c->d_wchunk); dfree(c->d_wchunk0); dfree(c->d_wtot_s); dfree(c->d_wtot_c); dfree(c->d_wcbest);
+    qr_k_exact_free(c);
     dfree(c->d_order[0]); dfree(c->d_order[1]); dfree(c->d_featrec); dfree(c->d_featthr);
     dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask); dfree(c->d_part_state);
     dfree(c->d_part_ss); dfree(c->d_tree); dfree(c->d_leafpart); dfree(c->d_leafb);
@@ -824,6 +826,14 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
   rc = qr_k_wide_binning(c, d_col);
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   if (rc) return rc;
+  // rows of more than QR_X_MIN_SLOTS slots (the reference's default --num-thresholds 0 on real-valued
+  // columns): slot-indexed node histograms cost 0.8 GB of cells per node whatever its size; the
+  // pre-sorted lists of k_exact.hip cost 8 bytes per (document, feature) of the node.  Single-GPU
+  // contexts; 3 x F x N x 8 bytes of lists (QR_WIDE_EXACT=1 / QR_WIDE_NO_EXACT=1 force either way).
+  if (c->world == 1 && !c->dmode && !getenv("QR_WIDE_NO_EXACT") &&
+      (c->wmax > QR_X_MIN_SLOTS || getenv("QR_WIDE_EXACT")) && 3 * FL * N * 8 <= ((size_t)64 << 30)) {
+    if ((rc = qr_k_exact_build(c))) return rc;
+  }
   // ---- tree working set of the one-split-per-step path
   QR_CHECK(c, dalloc(&c->d_order[0], N));
   QR_CHECK(c, dalloc(&c->d_order[1], N));
@@ -1238,7 +1248,8 @@ int qr_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "nleaves must be in [1, 511]");
   int rc = tree_settle(c);
   if (rc) return rc;
-  rc = ensure_hist_slots(c, 2 * nleaves + 1);
+  // (pre-sorted wide contexts build no node histograms: k_exact.hip)
+  rc = qr_exact_active(c) ? QR_OK : ensure_hist_slots(c, 2 * nleaves + 1);
   if (rc) return rc;
   if (c->dmode && 2 * nleaves * (size_t)c->world > c->xleaf_cap) {
     QR_CHECK(c, hipStreamSynchronize(c->stream));
@@ -1611,6 +1622,9 @@ int qr_node_hist_read_ragged(qr_ctx *c, int node, double *sum_out, uint64_t *cou
   QrScalars s;
   QR_CHECK(c, hipMemcpy(&s, c->d_scalars, sizeof(s), hipMemcpyDeviceToHost));
   const size_t slot = (size_t)ts.nodes[node].hslot;
+  if (qr_exact_active(c))
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "this context grows its trees on pre-sorted lists (rows of more than "
+                                   "16384 slots): there are no node histograms to read");
   if (c->wide) {
     const size_t n = c->wcells;
     std::vector<long long> hs(n);

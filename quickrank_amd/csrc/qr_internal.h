@@ -328,6 +328,13 @@ struct qr_ctx {
   uint16_t *d_wbins16 = nullptr; // rows of up to 1152 slots: [group of 16 features][N][16] (k_whist16)
   uint64_t *d_wpart = nullptr;   // ... and its partial slots [document range][group][slots x 16] (k_wreduce16)
   size_t wpart_cap = 0;
+  // k_exact.hip: rows too long for slot-indexed node histograms (--num-thresholds 0 on real-valued
+  // columns) take the pre-sorted formulation -- per feature the documents sorted by slot, a node the
+  // same segment of every feature's list
+  bool xmode = false;
+  unsigned long long *d_xroot = nullptr;     // [flocal][N] {slot << 32 | document}: the root's lists, never overwritten
+  unsigned long long *d_xlist[2] = {nullptr, nullptr};  // the work lists the splits ping-pong between
+  long long *d_xtot = nullptr;               // [2] fixed-point gradient totals of the node(s) being scanned
   std::vector<uint32_t> h_woff;
   std::vector<float> h_wthr;
   float *d_thr = nullptr;        // [F][256]
@@ -560,6 +567,11 @@ struct QrTreeState;
 bool qr_k_wide_batch_ok(const qr_ctx *c);
 int qr_k_whist_scan_batch(qr_ctx *c, const QrTreeState *ts, const double *pss);
 int qr_k_whist_scan(qr_ctx *c, int root_mode);
+int qr_k_exact_build(qr_ctx *c);
+int qr_k_exact_scan(qr_ctx *c, int root_mode);
+void qr_k_exact_free(qr_ctx *c);
+#define QR_X_MIN_SLOTS 16384u  /* longest row from which a wide context takes the pre-sorted path (k_exact.hip) */
+inline bool qr_exact_active(const qr_ctx *c) { return c->xmode && !c->sub_k; }
 #define QR_WCHUNK 8192u  /* slots per workgroup of the chunked scan of long rows (k_wide.hip) */
 int qr_k_wobl_fill(qr_ctx *c, int level);
 int qr_k_wobl_hist(qr_ctx *c, int nodes);

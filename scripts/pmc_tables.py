@@ -23,14 +23,17 @@ def rows_of(d):
     return list(csv.DictReader(open(f[0])))
 
 
-def per_dispatch(rows, counter):
-    """[(dispatch id, kernel, value)] in dispatch order for one counter."""
-    out = {}
+def per_dispatch(rows, counter, with_us=False):
+    """[(dispatch id, kernel, value[, duration in us])] in dispatch order for one counter."""
+    out, dur = {}, {}
     for r in rows:
         if r["Counter_Name"] != counter:
             continue
         k = (int(r["Dispatch_Id"]), r["Kernel_Name"].split("(")[0].replace("void ", ""))
         out[k] = out.get(k, 0.0) + float(r["Counter_Value"])
+        dur[k] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+    if with_us:
+        return sorted((d, k, v, dur[(d, k)]) for (d, k), v in out.items())
     return sorted((d, k, v) for (d, k), v in out.items())
 
 
@@ -44,15 +47,17 @@ def hist(dir_fetch, dir_write, out):
                          "the row layout predicts (3 blocks x 1.75 64-B lines); WRITE_SIZE * 1024 uncalibrated"}
     per = {}
     for name, d in (("FETCH_SIZE", dir_fetch), ("WRITE_SIZE", dir_write)):
-        seq = per_dispatch(rows_of(d), name)
+        seq = per_dispatch(rows_of(d), name, with_us=True)
         # classes: position of a k_hist_batch dispatch after the last k_hist_root
         pos, trees = -1, 0
-        for _, k, v in seq:
+        for _, k, v, us in seq:
             if k.startswith("k_hist_root"):
                 pos, trees = 0, trees + 1
                 per.setdefault(("root", 0), {}).setdefault(name, []).append(v)
+                per[("root", 0)].setdefault("us", []).append(us)
             elif k.startswith("k_hist_batch") and pos >= 0:
                 per.setdefault(("child", pos), {}).setdefault(name, []).append(v)
+                per[("child", pos)].setdefault("us", []).append(us)
                 pos += 1
     root = per.get(("root", 0), {})
     if root:
@@ -70,7 +75,8 @@ def hist(dir_fetch, dir_write, out):
         f, w = v.get("FETCH_SIZE", []), v.get("WRITE_SIZE", [])
         classes.append({"position_in_tree": pos, "launches": len(f),
                         "FETCH_KB_per_launch": round(sum(f) / max(1, len(f)), 1),
-                        "WRITE_KB_per_launch": round(sum(w) / max(1, len(w)), 1)})
+                        "WRITE_KB_per_launch": round(sum(w) / max(1, len(w)), 1),
+                        "us_per_launch_under_counters": round(sum(v["us"]) / max(1, len(v["us"])), 1)})
         tf += sum(f)
         tw += sum(w)
     res["child_launches"] = {"kernel": "k_hist_batch", "classes": classes,

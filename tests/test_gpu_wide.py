@@ -277,3 +277,50 @@ def test_wide_batched_growth_equals_one_split_per_step(qr, case, nthr, monkeypat
         for k in a.dtype.names:
             assert np.array_equal(a[k], b[k], equal_nan=(a[k].dtype.kind == "f")), k
     assert np.array_equal(sa, sb)
+
+
+@pytest.mark.parametrize("algo", ["LAMBDAMART", "MART"])
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("nthr,minls", [(0, 1), (0, 7), (1000, 2)])
+def test_presorted_lists_equal_the_slot_histograms(qr, algo, case, nthr, minls, monkeypatch):
+    """k_exact.hip (round 4): rows of more than 16384 slots -- the reference's default
+    `--num-thresholds 0` on real-valued columns -- grow their trees on per-feature lists of the
+    documents sorted by slot instead of slot-indexed node histograms.  Same exact integers, same
+    first maximum in (feature, slot) order: forced on small sets (QR_WIDE_EXACT=1, read when the
+    bins are built) every record of every tree and every score must be the bits of the
+    histogram path (QR_WIDE_NO_EXACT=1, one split per step)."""
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(**case)
+    kw = dict(ntrees=4, shrinkage=0.1, nthresholds=nthr, nleaves=12, minls=minls, esr=0)
+
+    def run():
+        m = Mart(algo=algo, **kw).learn(x, labels, qoff)
+        assert m.ctx.wide
+        out = [t.copy() for t in m.ensemble.trees], m.ctx.get_scores(), list(m.train_metric)
+        m.ctx.close()
+        return out
+
+    monkeypatch.setenv("QR_NO_BATCH", "1")
+    monkeypatch.setenv("QR_WIDE_NO_EXACT", "1")
+    ta, sa, ma = run()
+    monkeypatch.delenv("QR_WIDE_NO_EXACT")
+    monkeypatch.setenv("QR_WIDE_EXACT", "1")
+    tb, sb, mb = run()
+    for a, b in zip(ta, tb):
+        for k in a.dtype.names:
+            assert np.array_equal(a[k], b[k], equal_nan=(a[k].dtype.kind == "f")), k
+    assert np.array_equal(sa, sb) and ma == mb
+
+
+def test_presorted_lists_refuse_node_histogram_reads(qr, monkeypatch):
+    monkeypatch.setenv("QR_WIDE_EXACT", "1")
+    x, labels, qoff = make_dataset(**CASES[0])
+    c = qr.Context(0)
+    c.upload(x, labels, qoff)
+    c.build_bins(0)
+    c.reset_scores()
+    c.compute_lambdas("NDCG", 10)
+    c.fit_tree(6, 1, True)
+    with pytest.raises(Exception, match="pre-sorted"):
+        c.node_hist_ragged(0)
+    c.close()

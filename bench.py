@@ -98,6 +98,27 @@ def synth_mslr(nq=6000, mean_q=120, F=136, sparse_cols=40, seed=7):
     return x, labels, qoff
 
 
+def synth_device(torch, blocks, nq, dpq, F, seed0=1142):
+    """The same MSLR-shaped rows as synth(), generated ON THE DEVICE in blocks of nq * dpq
+    documents (block b: torch generator seeded seed0 + b), so that a set too large to build and
+    ship from the host in the bench's time -- 32M documents x 136 features = 17.4 GB -- is
+    resident in HBM when the timed region starts.  Any rank that takes whole blocks gets the
+    rows every other world size would give those blocks.  Returns (rows: CUDA tensor [n][F] f32,
+    labels: host f32 [n], qoff: host u64)."""
+    nb = len(blocks)
+    n1 = nq * dpq
+    x = torch.empty((nb * n1, F), device="cuda", dtype=torch.float32)
+    lab = torch.empty(nb * n1, device="cuda", dtype=torch.float32)
+    for i, b in enumerate(blocks):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed0 + int(b))
+        xb = x[i * n1:(i + 1) * n1]
+        xb.copy_(torch.rand((n1, F), generator=g, device="cuda", dtype=torch.float32))
+        lab[i * n1:(i + 1) * n1] = torch.clamp(torch.floor(1.25 * xb[:, :4].to(torch.float64).sum(dim=1)), max=4.0).to(torch.float32)
+    qoff = np.arange(nb * nq + 1, dtype=np.uint64) * dpq
+    return x, lab.cpu().numpy(), qoff
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -319,7 +340,7 @@ class Run:
             from quickrank_amd.dist import DocShardedTrainer, gather_thresholds
             self.ctx = Context(local_rank, rank=rank, world=world, stream=stream,
                                doc_shard=(n_global, q_global))
-            self.ctx.upload(x, labels, qoff)
+            self._upload(x, labels, qoff)
             self.ctx.build_bins_with(*gather_thresholds(self.ctx, args.nthresholds))
             self.ctx.reset_scores()
             self.trainer = DocShardedTrainer(self.ctx)
@@ -328,7 +349,7 @@ class Run:
             self.ctx = Context(local_rank, rank=rank if layout == "features" else 0,
                                world=world if layout == "features" else 1, stream=stream)
             t0 = time.perf_counter()
-            self.ctx.upload(x, labels, qoff)
+            self._upload(x, labels, qoff)
             self.ctx.synchronize()
             self.h2d_ms = (time.perf_counter() - t0) * 1e3      # host rows -> HBM (PCIe), outside the timed region
             t0 = time.perf_counter()
@@ -342,6 +363,13 @@ class Run:
                 self.fitter = ShardedTreeFitter(self.ctx)
                 self.comm = self.fitter.direct
         self.ndcg, self.trees = [], []
+
+    def _upload(self, x, labels, qoff):
+        """Host rows (numpy) or rows generated on the device (a torch CUDA tensor)."""
+        if hasattr(x, "data_ptr"):
+            self.ctx.upload_device(x.data_ptr(), x.shape[0], x.shape[1], labels, qoff)
+        else:
+            self.ctx.upload(x, labels, qoff)
 
     def step(self):
         # ranking + NDCG@10 of the current scores (= the training metric the
@@ -471,6 +499,9 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of the extra measurements")
     ap.add_argument("--big-blocks", type=int, default=8,
                     help="the larger strong-scaling set: this many 1M-document blocks (0 = skip)")
+    ap.add_argument("--huge-blocks", type=int, default=32,
+                    help="the strong-scaling set at which >= 6x on 8 GPUs is arithmetically possible (DESIGN.md 6): "
+                         "this many 1M-document blocks generated on the device (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (process group, sharded drivers) with one rank")
     ap.add_argument("--self-launch", action="store_true",
@@ -776,6 +807,25 @@ def main():
                         "launches": pb["launches"]}
             r.close()
             del xb, lb, qb
+        if args.huge_blocks:
+            # a strong-scaling set large enough for the per-document kernels to
+            # carry the iteration (at 1M documents ~70 % of it is launch chain, which no layout
+            # divides; DESIGN.md 6 has the predicted 1 / 2 / 4 / 8 table this falsifies).  Generated
+            # on the device, whole 1M-document blocks per rank, document-sharded for N > 1.
+            nh = args.huge_blocks
+            h0, h1 = doc_slice(nh, rank, world) if multi else (0, nh)
+            xh, lh, qh = synth_device(torch, list(range(h0, h1)), Q, DPQ, F)
+            r = mk("docs" if multi else "single", xh, lh, qh, N * nh, Q * nh)
+            del xh
+            torch.cuda.empty_cache()
+            hsteps = max(4, min(es, 10))
+            r.timed(hsteps, 2)
+            extras[f"strong_{nh}M"] = dict(
+                r.summary(f"synthetic {N * nh} docs x {F} features x {Q * nh} queries, generated on the device"
+                          + (f" ({len(lh)} on rank {rank})" if multi else "") + ", " + desc,
+                          f"document sharding x{world}" if multi else "1 GPU"), scaling="strong")
+            r.close()
+            del lh, qh
 
     scoring = None
     if not args.no_scoring:   # every rank takes part (its shard of the documents)

@@ -94,7 +94,9 @@ int qr_synchronize(qr_ctx *ctx);
 /* ---- data: replaces Dataset -> VerticalDataset (vertical_dataset.cc:29-66)    */
 /*      and Mart::init (mart.cc:117-176) + RTRootHistogram (rtnode_histogram.cc */
 /*      :227-253)                                                                */
-/* rowmajor: host f32 [N][F] (Dataset::at, dataset.h:65-67); qoff: [Q+1]         */
+/* rowmajor: f32 [N][F] (Dataset::at, dataset.h:65-67) in host memory, or rows    */
+/* already resident on the context's device (copied either way); qoff: [Q+1];     */
+/* labels and qoff: host memory                                                   */
 int qr_dataset_upload(qr_ctx *ctx, const float *rowmajor, size_t N, size_t F,
                       const float *labels, const uint64_t *qoff, size_t Q);
 /* optional validation set (mart.cc:231-233, 354-360).  rowmajor: host f32 [N][F]  */

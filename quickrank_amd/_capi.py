@@ -258,6 +258,15 @@ class Context:
         self._ck(self.L.qr_dataset_upload(self.h, _ptr(x), self.N, self.F, _ptr(labels),
                                           _ptr(qoff), self.Q))
 
+    def upload_device(self, dev_ptr, n, f, labels, qoff):
+        """qr_dataset_upload with rows that already live on the context's device (a raw device
+        pointer to f32 [n][f]); labels and query offsets come from host arrays as always."""
+        labels = np.ascontiguousarray(labels, np.float32)
+        qoff = np.ascontiguousarray(qoff, np.uint64)
+        self.N, self.F, self.Q = int(n), int(f), len(qoff) - 1
+        self._ck(self.L.qr_dataset_upload(self.h, C.c_void_p(int(dev_ptr)), self.N, self.F, _ptr(labels),
+                                          _ptr(qoff), self.Q))
+
     def upload_valid(self, x, labels, qoff):
         x = np.ascontiguousarray(x, np.float32)
         labels = np.ascontiguousarray(labels, np.float32)

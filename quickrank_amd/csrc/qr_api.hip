@@ -374,7 +374,9 @@ int qr_dataset_upload(qr_ctx *c, const float *x, size_t N, size_t F,
   free_train(c);
   c->N = N; c->F = F; c->Q = Q;
   QR_CHECK(c, dalloc(&c->d_raw, N * F));
-  QR_CHECK(c, hipMemcpy(c->d_raw, x, N * F * 4, hipMemcpyHostToDevice));
+  // (hipMemcpyDefault: `x` may be a host buffer -- the reference's Dataset, dataset.h:65-67 -- or rows
+  // that already live on this device, e.g. bench.py's device-generated 32M-document set)
+  QR_CHECK(c, hipMemcpy(c->d_raw, x, N * F * 4, hipMemcpyDefault));
   QR_CHECK(c, dalloc(&c->d_labels, N));
   QR_CHECK(c, hipMemcpy(c->d_labels, labels, N * 4, hipMemcpyHostToDevice));
   c->h_labels.assign(labels, labels + N);

@@ -24,7 +24,7 @@ def _run(args):
 
 def test_bench_line_one_gpu():
     d = _run(["--queries", "2000", "--steps", "4", "--warmup", "2", "--score-docs", "20000", "--score-trees", "200",
-              "--cpu-iters", "3", "--cpu-score-docs", "500", "--big-blocks", "0", "--extra-steps", "3"])
+              "--cpu-iters", "3", "--cpu-score-docs", "500", "--big-blocks", "0", "--extra-steps", "3", "--huge-blocks", "1"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -58,11 +58,13 @@ def test_bench_line_one_gpu():
     assert abs(d["config"]["ndcg10_after_3"] - c["ndcg10_after"]["3"]) < 1e-5
     assert "port_vs_reference_8threads_other_box" in c.get("threads8", c)
     assert 0.0 < d["config"]["ndcg10_last"] <= 1.0
+    # the device-generated strong-scaling set (here: one block of the test's size)
+    assert d["strong_1M"]["ms_per_step"] > 0 and "generated on the device" in d["strong_1M"]["workload"]
 
 
 def test_bench_line_distributed_path_one_rank():
     d = _run(["--force-dist", "--queries", "2000", "--steps", "3", "--warmup", "1", "--no-scoring",
-              "--big-blocks", "2", "--extra-steps", "2"])
+              "--big-blocks", "2", "--extra-steps", "2", "--huge-blocks", "1"])
     assert d["scaling"] == "strong" and d["n_gpus"] == 1 and "cpu_baseline" not in d
     lay = d["strong_layouts"]
     assert set(lay) == {"document_sharded", "feature_sharded"}

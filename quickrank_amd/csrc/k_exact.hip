@@ -19,9 +19,15 @@
 //     candidates there are.  Exact integers, as in the histograms -- same records as k_wscan;
 //   * a split is a STABLE partition of every feature's segment by the go-left test of the split
 //     feature (`bin[f*][doc] <= t*`  <=>  `x <= threshold`, rt.cc:327-334): children stay sorted.
-// One workgroup per (feature, child) streams its segment from begin to end with a running carry,
-// so no launch needs another's partial results: k_xpart (F workgroups), k_xtotal (the children's
-// gradient totals, which the gain needs before the first candidate), k_xscan (F x 2 workgroups).
+// A segment is cut into TILES (4096 entries for the scan, 8192 for the partition), one workgroup
+// each, in ONE launch: a tile publishes its own aggregate (of gradients / of left-going entries) as
+// a self-validating 8-byte word {launch epoch : 16, value : 48} the moment it knows it, walks back
+// over its predecessors' words until it meets an inclusive prefix, and publishes its own (decoupled
+// look-back; tiles are dispatched feature-fastest, so the tiles a walk meets are resident or done)
+// -- every CU works on every node, and a document's gradient is gathered once.
+// k_xflag (go-left bytes), k_xpart (F x tiles), k_xtotal (the children's gradient totals, which
+// the gain needs before the first candidate), k_xscan (F x tiles x 2), k_xbest (F x 2: first
+// maximum over a feature's tiles).
 // Per tree the lists move (1 + pi) N F entries through the scans and pi N F through the
 // partitions (pi = documents partitioned / N, ~3.7 on the stand-in): ~10 GB against the ~150 GB
 // of cells the slot-indexed path touches.
@@ -34,9 +40,30 @@
 #include "qr_dev.h"
 
 #define QR_X_E 8u                      /* entries per thread and chunk */
-#define QR_X_CHUNK (1024u * QR_X_E)    /* entries per chunk of a 1024-thread workgroup */
+#define QR_X_CHUNK (1024u * QR_X_E)    /* entries per chunk of a 1024-thread workgroup (k_xpart) */
+#ifndef QR_XS_T
+#define QR_XS_T 512u                   /* k_xscan: threads per workgroup = entries per tile / 8 (measured: 256 / 512 / 1024 threads) */
+#endif
+#define QR_XS_W (QR_XS_T / 64u)
+#define QR_XS_CHUNK (QR_XS_T * QR_X_E)
 
 __device__ __forceinline__ uint32_t x_id(const u64 e) { return (uint32_t)e; }
+// the lists are read once per launch: streamed past the caches (non-temporal), so that what IS
+// re-read -- the gradients, the go-left bytes -- keeps its lines (-DQR_X_NO_NT: plain loads, A/B)
+__device__ __forceinline__ u64 x_load(const u64 *p) {
+#ifdef QR_X_NO_NT
+  return *p;
+#else
+  return __builtin_nontemporal_load(p);
+#endif
+}
+__device__ __forceinline__ void x_store(u64 *p, const u64 v) {
+#ifdef QR_X_NO_NT
+  *p = v;
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
 __device__ __forceinline__ uint32_t x_slot(const u64 e) { return (uint32_t)(e >> 32); }
 
 __global__ __launch_bounds__(256) void k_xiota(uint32_t *__restrict__ v, const uint32_t n) {
@@ -89,69 +116,138 @@ __device__ __forceinline__ void x_block_scan_i64(const long long v, long long &e
 }
 
 // ---------------------------------------------------------------------------
-// k_xpart: the split being applied (ts->desc), feature blockIdx.x's segment of the parent,
-// stable partition into the children's segments of the destination lists.  The go-left test is
-// the split feature's slot of the document (its column of the feature-major bins: 4 bytes per
-// document, a few MB -- it stays in the L2 while 136 workgroups read it).
+// k_xflag: the go-left byte of every document of the node being split, from the split feature's
+// own segment (sorted by slot: `slot <= t*`  <=>  `x <= threshold`, rt.cc:327-334).  A byte per
+// document: the 136 partition workgroups then gather from N bytes instead of the feature's
+// 4 N-byte column.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_xpart(const QrTreeState *__restrict__ ts, const u64 *__restrict__ xroot,
-                                                u64 *__restrict__ x0, u64 *__restrict__ x1, const size_t N,
-                                                const uint32_t *__restrict__ wbins) {
-  __shared__ uint32_t sh[16];
+__global__ __launch_bounds__(256) void k_xflag(const QrTreeState *__restrict__ ts, const u64 *__restrict__ xroot,
+                                               const u64 *__restrict__ x0, const u64 *__restrict__ x1, const size_t N,
+                                               uint8_t *__restrict__ goleft) {
   const QrSplitDesc d = ts->desc;
   if (!d.active || d.owner_local < 0) return;
+  const u64 *src = x_lists(d.src_buf, xroot, x0, x1) + (size_t)d.owner_local * N + d.begin;
+  const uint32_t n = d.end - d.begin;
+  for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    const u64 e = src[p];
+    goleft[x_id(e)] = x_slot(e) <= d.thr_id ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_xpart: the split being applied (ts->desc), feature blockIdx.x's segment of the parent,
+// stable partition into the children's segments of the destination lists.  Entries two chunks
+// ahead and the go-left bytes one chunk ahead are in flight while a chunk is placed.
+// ---------------------------------------------------------------------------
+// Decoupled look-back (one poller per tile).  A tile owns three 8-byte words, each self-validating
+// {launch epoch : 16, payload : 48} and written once per launch with a relaxed agent-scope store:
+//   [0] its own AGGREGATE, as soon as it knows it;
+//   [1], [2] its INCLUSIVE PREFIX (low 32 bits / the rest, signed), once its predecessors' are in.
+// The poller walks back from the tile before it: a prefix ends the walk, an aggregate is added and
+// the walk goes on, a word of an older launch is waited for.  Tiles are dispatched feature-fastest
+// (blockIdx.x = feature), so the tiles a walk meets are a dispatch row or two older: resident or
+// done -- the walk cannot wait for a workgroup that is not running yet.
+#define QR_X_PUBW 3u
+__device__ __forceinline__ bool x_word(const u64 *w, const u64 epoch, long long *payload) {
+  const u64 v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *payload = ((long long)(v << 16)) >> 16;  // sign-extended 48 bits
+  return (v >> 48) == epoch;
+}
+__device__ __forceinline__ void x_put(u64 *w, const u64 epoch, const long long payload) {
+  __hip_atomic_store(w, (epoch << 48) | ((u64)payload & 0xFFFFFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void x_publish_aggregate(u64 *row, const uint32_t tile, const u64 epoch, const long long v) {
+  x_put(row + (size_t)tile * QR_X_PUBW, epoch, v);
+}
+__device__ __forceinline__ void x_publish_prefix(u64 *row, const uint32_t tile, const u64 epoch, const long long v) {
+  x_put(row + (size_t)tile * QR_X_PUBW + 1, epoch, (long long)(uint32_t)v);
+  x_put(row + (size_t)tile * QR_X_PUBW + 2, epoch, v >> 32);
+}
+// sum of the aggregates of tiles [0, tile): ONE lane calls this
+__device__ __forceinline__ long long x_look_back(const u64 *row, const uint32_t tile, const u64 epoch) {
+  long long sum = 0;
+  for (uint32_t i = tile; i-- > 0;) {
+    const u64 *w = row + (size_t)i * QR_X_PUBW;
+    for (;;) {
+      long long lo, hi, ag;
+      if (x_word(w + 1, epoch, &lo) && x_word(w + 2, epoch, &hi)) return sum + ((hi << 32) | (lo & 0xFFFFFFFFll));
+      if (x_word(w, epoch, &ag)) {
+        sum += ag;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  return sum;
+}
+
+__global__ __launch_bounds__(1024) void k_xpart(const QrTreeState *__restrict__ ts, const u64 *__restrict__ xroot,
+                                                u64 *__restrict__ x0, u64 *__restrict__ x1, const size_t N,
+                                                const uint8_t *__restrict__ goleft, u64 *__restrict__ pub,
+                                                const uint32_t tiles, const u64 epoch) {
+  // Tile blockIdx.y of feature blockIdx.x.  Entry k of thread t sits at position c0 + k * 1024 + t:
+  // a wave's load is 512 contiguous bytes.  The rank of an entry among the tile's left-going ones:
+  // lanes before it in its wave (ballot), waves before it in its slab k and the slabs before (one
+  // scan of the 8 x 16 wave counts by the first wave); among the node's: + the tiles before.
+  __shared__ uint32_t sh_c[QR_X_E * 16], sh_p[QR_X_E * 16 + 1];
+  __shared__ uint32_t sh_before;
+  const QrSplitDesc d = ts->desc;
+  if (!d.active || d.owner_local < 0) return;
+  const uint32_t n = d.end - d.begin;
+  const uint32_t tile = blockIdx.y;
+  const uint32_t c0 = tile * QR_X_CHUNK;
+  if (c0 >= n) return;
   const size_t fo = (size_t)blockIdx.x * N;
   const u64 *src = x_lists(d.src_buf, xroot, x0, x1) + fo + d.begin;
   u64 *dst = (d.dst_buf == 0 ? x0 : x1) + fo;
-  const uint32_t *col = wbins + (size_t)d.owner_local * N;
-  const uint32_t n = d.end - d.begin;
-  uint32_t lcur = d.begin, rcur = d.begin + d.lcount;
-  // the next chunk's entries travel while this one is partitioned
-  u64 nx[QR_X_E];
-  auto fetch = [&](const uint32_t c0) {
+  u64 *mypub = pub + (size_t)blockIdx.x * tiles * QR_X_PUBW;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  u64 e[QR_X_E];
+  uint32_t fl[QR_X_E];
 #pragma unroll
-    for (uint32_t k = 0; k < QR_X_E; ++k) {
-      const uint32_t p = c0 + threadIdx.x * QR_X_E + k;
-      nx[k] = src[p < n ? p : n - 1];  // (clamped: unconditional loads)
+  for (uint32_t k = 0; k < QR_X_E; ++k) {
+    const uint32_t p = c0 + k * 1024u + threadIdx.x;
+    e[k] = x_load(src + (p < n ? p : n - 1));  // (clamped: unconditional loads)
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < QR_X_E; ++k) fl[k] = goleft[x_id(e[k])];
+  uint32_t lp[QR_X_E];  // left-going lanes before this one in its wave and slab
+  bool left[QR_X_E];
+#pragma unroll
+  for (uint32_t k = 0; k < QR_X_E; ++k) {
+    left[k] = c0 + k * 1024u + threadIdx.x < n && fl[k] != 0;
+    const unsigned long long m = __ballot(left[k]);
+    lp[k] = (uint32_t)__popcll(m & lt);
+    if (lane == 0) sh_c[k * 16 + wave] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (wave == 0) {  // exclusive prefix of the 128 counts in (slab, wave) order = position order
+    const uint32_t a0 = sh_c[2 * lane], a1 = sh_c[2 * lane + 1];
+    const uint32_t inc = wave_scan_u32(a0 + a1);
+    sh_p[2 * lane] = inc - a0 - a1;
+    sh_p[2 * lane + 1] = inc - a1;
+    const uint32_t ltot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    if (lane == 0) {  // the tile's aggregate, the walk over its predecessors, its inclusive prefix
+      x_publish_aggregate(mypub, tile, epoch, (long long)ltot);
+      const long long bef = x_look_back(mypub, tile, epoch);
+      x_publish_prefix(mypub, tile, epoch, bef + (long long)ltot);
+      sh_before = (uint32_t)bef;
     }
-  };
-  if (n == 0) return;
-  fetch(0);
-  for (uint32_t c0 = 0; c0 < n; c0 += QR_X_CHUNK) {
-    u64 e[QR_X_E];
-    uint32_t sl[QR_X_E];
+  }
+  __syncthreads();
+  const uint32_t before = sh_before;
+  const uint32_t lcur = d.begin + before, rcur = d.begin + d.lcount + (c0 - before);
 #pragma unroll
-    for (uint32_t k = 0; k < QR_X_E; ++k) e[k] = nx[k];
-#pragma unroll
-    for (uint32_t k = 0; k < QR_X_E; ++k) sl[k] = col[x_id(e[k])];
-    if (c0 + QR_X_CHUNK < n) fetch(c0 + QR_X_CHUNK);
-    const uint32_t p0 = c0 + threadIdx.x * QR_X_E;
-    uint32_t nl = 0, nv = 0;
-    bool left[QR_X_E];
-#pragma unroll
-    for (uint32_t k = 0; k < QR_X_E; ++k) {
-      const bool in = p0 + k < n;
-      left[k] = in && sl[k] <= d.thr_id;
-      nl += left[k] ? 1u : 0u;
-      nv += in ? 1u : 0u;
+  for (uint32_t k = 0; k < QR_X_E; ++k) {
+    const uint32_t pc = k * 1024u + threadIdx.x;  // entries of the tile before this one
+    if (c0 + pc < n) {
+      const uint32_t lb = sh_p[k * 16 + wave] + lp[k];  // ... of which go left
+      if (left[k])
+        x_store(dst + lcur + lb, e[k]);
+      else
+        x_store(dst + rcur + (pc - lb), e[k]);
     }
-    uint32_t lo, ltot;
-    x_block_scan_u32(nl, lo, ltot, sh);
-    // (entries before this thread's in the chunk: p0 - c0 of them, all valid when any of its own is)
-    uint32_t li = lcur + lo, ri = rcur + (threadIdx.x * QR_X_E - lo);
-#pragma unroll
-    for (uint32_t k = 0; k < QR_X_E; ++k) {
-      if (p0 + k < n) {
-        if (left[k])
-          dst[li++] = e[k];
-        else
-          dst[ri++] = e[k];
-      }
-    }
-    const uint32_t cn = n - c0 < QR_X_CHUNK ? n - c0 : QR_X_CHUNK;
-    lcur += ltot;
-    rcur += cn - ltot;
-    (void)nv;
   }
 }
 
@@ -189,18 +285,41 @@ __global__ __launch_bounds__(256) void k_xtotal(const QrTreeState *__restrict__ 
 // k_xscan: feature blockIdx.x of node blockIdx.y (0: the root / the left child, 1: the right
 // child): cumulative sums along the segment, the gain at every run end, the first maximum ->
 // featrec[which * flocal + lf] (+ the threshold value), as k_wscan leaves them for k_decide.
+//
+// With every distinct value a threshold nearly every entry ends a run, and the gain of rt.cc:278
+// is two IEEE f64 divisions (~80 vector instructions): evaluated for all of them it was most of
+// the kernel's time.  So a candidate is first PRICED -- the same expression with the hardware
+// reciprocal, good to ~1e-7 -- and only one that comes within 1e-5 of the best score the
+// workgroup has seen so far gets the exact evaluation that decides (a candidate that is not the
+// maximum to 1e-5 cannot be the first maximum; ties are within it).  Entries two chunks ahead and
+// gradients one chunk ahead are in flight while a chunk is evaluated; one barrier pair per chunk.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_xscan(
+struct XTileBest {
+  double score;
+  uint32_t t, lc;
+};
+
+__global__ __launch_bounds__(QR_XS_T) void k_xscan(
     const QrTreeState *__restrict__ ts, const int mode, const uint32_t rootn, const u64 *__restrict__ xroot,
     const u64 *__restrict__ x0, const u64 *__restrict__ x1, const size_t N, const double *__restrict__ lambda,
     const QrScalars *__restrict__ scal, const long long *__restrict__ tot, const uint32_t *__restrict__ woff,
-    const int flocal, const int32_t *__restrict__ lf2gf, const float *__restrict__ thr,
-    qr_split_t *__restrict__ featrec, float *__restrict__ featthr, const u64 minls_root) {
-  __shared__ long long sh_s[16];
-  __shared__ uint32_t sh_first[1024];
-  __shared__ Best sh_b[16];
-  __shared__ uint32_t sh_lc[16];
-  const int lf = blockIdx.x, which = blockIdx.y;
+    const int flocal, u64 *__restrict__ pub, const uint32_t tiles, const u64 epoch,
+    unsigned long long *__restrict__ gbest, XTileBest *__restrict__ tbest, const u64 minls_root) {
+  // Tile blockIdx.y of feature blockIdx.x of node blockIdx.z.  Entry k of thread t sits at position
+  // c0 + k * QR_XS_T + t (coalesced loads, as k_xpart): QR_X_E slabs of QR_XS_T consecutive
+  // positions, a wave scans its 64 positions of every slab on DPP, the first wave scans the
+  // QR_X_E x QR_XS_W wave totals in position order, publishes the tile's total and collects the
+  // totals of the tiles before it.
+  __shared__ long long sh_ws[QR_X_E * QR_XS_W], sh_pre[QR_X_E * QR_XS_W];
+  constexpr uint32_t NWT = QR_X_E * QR_XS_W;   // wave totals of a tile: 64 (512 threads) or 128 (1024)
+  __shared__ long long sh_carry;
+  __shared__ uint32_t sh_wf[QR_X_E * QR_XS_W + 1];  // the waves' first slots per slab, then the next tile's
+  __shared__ double sh_price[QR_XS_W];
+  __shared__ Best sh_b[QR_XS_W];
+  __shared__ uint32_t sh_lc[QR_XS_W];
+  static_assert(NWT <= 64 || NWT == 128, "the first wave scans one or two wave totals per lane");
+  const int lf = blockIdx.x, which = blockIdx.z;
+  const uint32_t tile = blockIdx.y;
   uint32_t begin = 0, n = rootn;
   const u64 *lst = xroot;
   if (mode == 1) {
@@ -210,115 +329,187 @@ __global__ __launch_bounds__(1024) void k_xscan(
     n = which == 0 ? d.lcount : d.end - d.begin - d.lcount;
     lst = d.dst_buf == 0 ? x0 : x1;
   }
+  const uint32_t c0 = tile * QR_XS_CHUNK;
+  if (c0 >= n) return;
   const u64 *src = lst + (size_t)lf * N + begin;
+  const size_t row = (size_t)which * flocal + lf;
+  u64 *mypub = pub + row * tiles * QR_X_PUBW;
   const u64 minls = (mode == 0 && minls_root != ~0ull) ? minls_root : ts->minls;
   const double scale = scal->scale, inv_scale = scal->inv_scale;
   const long long S = tot[which];
-  const uint32_t base = woff[lf], tsize = woff[lf + 1] - base;
+  const double s_d = (double)S * inv_scale;
+  const uint32_t tsize = woff[lf + 1] - woff[lf];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  u64 e[QR_X_E];
+#pragma unroll
+  for (uint32_t k = 0; k < QR_X_E; ++k) {
+    const uint32_t p = c0 + k * QR_XS_T + threadIdx.x;
+    e[k] = x_load(src + (p < n ? p : n - 1));
+  }
+  const bool more = c0 + QR_XS_CHUNK < n;
+  const u64 enext = src[more ? c0 + QR_XS_CHUNK : n - 1];  // (the run-end test of the tile's last entry)
+  double lam[QR_X_E];
+#pragma unroll
+  for (uint32_t k = 0; k < QR_X_E; ++k) lam[k] = lambda[x_id(e[k])];
+  const unsigned long long g0 = __hip_atomic_load(gbest + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  long long inc[QR_X_E];  // inclusive prefix over the wave's 64 positions of slab k
+#pragma unroll
+  for (uint32_t k = 0; k < QR_X_E; ++k) {
+    const long long q = c0 + k * QR_XS_T + threadIdx.x < n ? quantize(lam[k] * scale) : 0;
+    inc[k] = wave_scan_i64(q);
+    if (lane == 63) sh_ws[k * QR_XS_W + wave] = inc[k];
+    if (lane == 0) sh_wf[k * QR_XS_W + wave] = x_slot(e[k]);
+  }
+  if (threadIdx.x == 0) sh_wf[QR_X_E * QR_XS_W] = more ? x_slot(enext) : 0xFFFFFFFFu;
+  __syncthreads();
+  if (wave == 0) {  // the wave totals in (slab, wave) order = position order: one or two per lane
+    long long iv;
+    if (NWT <= 64) {
+      const long long v = lane < NWT ? sh_ws[lane < NWT ? lane : 0] : 0;
+      iv = wave_scan_i64(v);
+      if (lane < NWT) sh_pre[lane] = iv - v;
+    } else {
+      const long long a0 = sh_ws[2 * lane], a1 = sh_ws[2 * lane + 1];
+      iv = wave_scan_i64(a0 + a1);
+      sh_pre[2 * lane] = iv - a0 - a1;
+      sh_pre[2 * lane + 1] = iv - a1;
+    }
+    const long long total = readlane_i64(iv, 63);
+    if (lane == 0) {  // the tile's aggregate, the walk over its predecessors, its inclusive prefix
+      x_publish_aggregate(mypub, tile, epoch, total);
+      const long long bef = x_look_back(mypub, tile, epoch);
+      x_publish_prefix(mypub, tile, epoch, bef + total);
+      sh_carry = bef;
+    }
+  }
+  __syncthreads();
+  const long long carry = sh_carry;
+  // price every candidate (reciprocals instead of divisions: good to ~1e-14), then evaluate exactly
+  // only those within 1e-11 of the best price of the tile or of the best exact score an earlier
+  // tile has published.  (The margin matters: while many gradients are zero, runs of neighbouring
+  // candidates differ by 1 / lc ~ 1e-6 relative -- with a margin of 1e-5 three percent of all
+  // candidates took the exact path, and with them nearly every wave: 1.8 ms for the root.)
+  double price[QR_X_E];
+  long long cs[QR_X_E];
+  double pmax = -1.0;
+#pragma unroll
+  for (uint32_t k = 0; k < QR_X_E; ++k) {
+    const uint32_t p = c0 + k * QR_XS_T + threadIdx.x;
+    const uint32_t t = x_slot(e[k]);
+    // the slot behind this entry: the next lane's, the next wave's first, the next slab's, the next tile's
+    uint32_t tn = (uint32_t)__shfl_down((int)t, 1);
+    if (lane == 63) tn = sh_wf[k * QR_XS_W + wave + 1];
+    const uint32_t lc = p + 1, rc = n - lc;
+    price[k] = -1.0;
+    cs[k] = carry + sh_pre[k * QR_XS_W + wave] + inc[k];
+    if (p < n && (lc == n || tn != t) && t < tsize && lc >= minls && rc >= minls) {
+      const double lsum = (double)cs[k] * inv_scale, rsum = s_d - lsum;
+      // (hardware reciprocal + two Newton steps: a few ulp; the exact evaluation keeps IEEE divisions)
+      const double dl = (double)lc, dr = (double)rc;
+      double il = __builtin_amdgcn_rcp(dl), ir = __builtin_amdgcn_rcp(dr);
+      il = fma(fma(-dl, il, 1.0), il, il);
+      ir = fma(fma(-dr, ir, 1.0), ir, ir);
+      il = fma(fma(-dl, il, 1.0), il, il);
+      ir = fma(fma(-dr, ir, 1.0), ir, ir);
+      const double pr = lsum * lsum * il + rsum * rsum * ir;
+      price[k] = pr >= 0.0 ? pr : -1.0;  // (a NaN -- 0 / 0 -- is no candidate, as in slot_gain)
+      pmax = price[k] > pmax ? price[k] : pmax;
+    }
+  }
+  pmax = wave_max(pmax);
+  if (lane == 0) sh_price[wave] = pmax;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t w = 0; w < QR_XS_W; ++w) pmax = sh_price[w] > pmax ? sh_price[w] : pmax;
+  const double gb = __longlong_as_double((long long)g0);
+  const double prune = (gb > pmax ? gb : pmax) * (1.0 - 1e-11);
   Best best;
   best.score = -1.0;
   best.t = 0xFFFFFFFFu;
   uint32_t best_lc = 0;
-  long long carry = 0;
-  u64 nx[QR_X_E];
-  auto fetch = [&](const uint32_t c0) {
 #pragma unroll
-    for (uint32_t k = 0; k < QR_X_E; ++k) {
-      const uint32_t p = c0 + threadIdx.x * QR_X_E + k;
-      nx[k] = src[p < n ? p : (n ? n - 1 : 0)];
-    }
-  };
-  if (n) fetch(0);
-  for (uint32_t c0 = 0; c0 < n; c0 += QR_X_CHUNK) {
-    u64 e[QR_X_E];
-    long long q[QR_X_E];
-#pragma unroll
-    for (uint32_t k = 0; k < QR_X_E; ++k) e[k] = nx[k];
-    const uint32_t p0 = c0 + threadIdx.x * QR_X_E;
-    {
-      double lam[QR_X_E];
-#pragma unroll
-      for (uint32_t k = 0; k < QR_X_E; ++k) lam[k] = lambda[x_id(e[k])];
-      // the slot that follows the chunk's last entry (the run-end test of its last thread)
-      const bool more = c0 + QR_X_CHUNK < n;
-      if (more) fetch(c0 + QR_X_CHUNK);
-#pragma unroll
-      for (uint32_t k = 0; k < QR_X_E; ++k) q[k] = p0 + k < n ? quantize(lam[k] * scale) : 0;
-    }
-    long long run = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < QR_X_E; ++k) {
-      run += q[k];
-      q[k] = run;  // inclusive prefix inside the thread
-    }
-    sh_first[threadIdx.x] = x_slot(e[0]);
-    long long off, ctot;
-    x_block_scan_i64(run, off, ctot, sh_s);  // (its barriers also publish sh_first)
-    // slot of the entry behind this thread's last one: the next thread's first, or -- last thread
-    // -- the next chunk's first (already on its way: thread 0's first prefetched entry)
-    uint32_t nslot;
-    if (threadIdx.x < 1023u)
-      nslot = sh_first[threadIdx.x + 1];
-    else
-      nslot = 0xFFFFFFFFu;
-    {
-      // (the next chunk's first slot: thread 0 holds it in nx[0]; hand it to the last thread)
-      __syncthreads();
-      if (threadIdx.x == 0) sh_first[0] = c0 + QR_X_CHUNK < n ? x_slot(nx[0]) : 0xFFFFFFFFu;
-      __syncthreads();
-      if (threadIdx.x == 1023u) nslot = sh_first[0];
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < QR_X_E; ++k) {
-      const uint32_t p = p0 + k;
-      if (p < n) {
-        const uint32_t t = x_slot(e[k]);
-        const uint32_t tn = k + 1 < QR_X_E ? x_slot(e[k + 1]) : nslot;
-        const bool run_end = p + 1 == n || tn != t;
-        if (run_end) {
-          const Best v = slot_gain(carry + off + q[k], p + 1, S, n, t, tsize, minls, inv_scale);
-          if (v.score > best.score) {  // ascending positions per thread: strict > keeps the first
-            best = v;
-            best_lc = p + 1;
-          }
-        }
+  for (uint32_t k = 0; k < QR_X_E; ++k) {
+    if (price[k] >= 0.0 && price[k] >= prune) {
+      const uint32_t lc = c0 + k * QR_XS_T + threadIdx.x + 1;
+      const Best v = slot_gain(cs[k], lc, S, n, x_slot(e[k]), tsize, minls, inv_scale);
+      if (v.score > best.score) {  // ascending positions per thread: strict > keeps the first
+        best = v;
+        best_lc = lc;
       }
     }
-    carry += ctot;
-    __syncthreads();  // (sh_first is rewritten by the next round)
   }
-  // first maximum over the workgroup: highest score, then lowest slot
+  // first maximum over the tile: highest score, then lowest slot
   const double m = wave_max(best.score);
   const uint32_t tmin = wave_min_u32(best.score == m && best.t != 0xFFFFFFFFu ? best.t : 0xFFFFFFFFu);
   const unsigned long long holder = __ballot(best.score == m && best.t == tmin && tmin != 0xFFFFFFFFu);
   const uint32_t wlc = holder ? (uint32_t)__builtin_amdgcn_readlane((int)best_lc, __ffsll((long long)holder) - 1) : 0u;
-  __syncthreads();
-  if ((threadIdx.x & 63u) == 0) {
+  if (lane == 0) {
     Best w;
     w.score = tmin != 0xFFFFFFFFu ? m : -1.0;
     w.t = tmin;
-    sh_b[threadIdx.x >> 6] = w;
-    sh_lc[threadIdx.x >> 6] = wlc;
+    sh_b[wave] = w;
+    sh_lc[wave] = wlc;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     Best r = sh_b[0];
     uint32_t lc = sh_lc[0];
-    for (int i = 1; i < 16; ++i) {
+    for (int i = 1; i < (int)QR_XS_W; ++i) {
       const Best o = sh_b[i];
       if (o.score > r.score || (o.score == r.score && o.t < r.t)) {
         r = o;
         lc = sh_lc[i];
       }
     }
-    qr_split_t *o = &featrec[(size_t)which * flocal + lf];
-    const bool none = r.t == 0xFFFFFFFFu;
-    o->score = none ? -1.0 : r.score;
+    XTileBest tb;
+    tb.score = r.t == 0xFFFFFFFFu ? -1.0 : r.score;
+    tb.t = r.t;
+    tb.lc = lc;
+    tbest[row * tiles + tile] = tb;
+    if (tb.score > 0.0) atomicMax(gbest + row, (unsigned long long)__double_as_longlong(tb.score));
+  }
+}
+
+// first maximum over a feature's tiles (ascending tiles = ascending slots) -> featrec / featthr
+__global__ __launch_bounds__(64) void k_xbest(const QrTreeState *__restrict__ ts, const int mode, const uint32_t rootn,
+                                              const XTileBest *__restrict__ tbest, const uint32_t tiles,
+                                              const uint32_t *__restrict__ woff, const int flocal,
+                                              const int32_t *__restrict__ lf2gf, const float *__restrict__ thr,
+                                              qr_split_t *__restrict__ featrec, float *__restrict__ featthr) {
+  const int lf = blockIdx.x, which = blockIdx.y;
+  uint32_t n = rootn;
+  if (mode == 1) {
+    const QrSplitDesc d = ts->desc;
+    if (!d.active) return;
+    n = which == 0 ? d.lcount : d.end - d.begin - d.lcount;
+  }
+  const size_t row = (size_t)which * flocal + lf;
+  const uint32_t used = (n + QR_XS_CHUNK - 1) / QR_XS_CHUNK;
+  Best b;
+  b.score = -1.0;
+  b.t = 0xFFFFFFFFu;
+  uint32_t lc = 0;
+  for (uint32_t i = threadIdx.x; i < used; i += 64) {  // ascending tiles per lane: strict > keeps the first
+    const XTileBest v = tbest[row * tiles + i];
+    if (v.t != 0xFFFFFFFFu && v.score > b.score) {
+      b.score = v.score;
+      b.t = v.t;
+      lc = v.lc;
+    }
+  }
+  const double m = wave_max(b.score);
+  const uint32_t tmin = wave_min_u32(b.score == m && b.t != 0xFFFFFFFFu ? b.t : 0xFFFFFFFFu);
+  const unsigned long long holder = __ballot(b.score == m && b.t == tmin && tmin != 0xFFFFFFFFu);
+  if (threadIdx.x == 0) {
+    const bool none = !holder;
+    const uint32_t wlc = none ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)lc, __ffsll((long long)holder) - 1);
+    qr_split_t *o = &featrec[row];
+    o->score = none ? -1.0 : m;
     o->feature = none ? 0xFFFFFFFFu : (uint32_t)lf2gf[lf];
-    o->thr_id = r.t;
-    o->lcount = none ? 0 : lc;
-    o->rcount = none ? 0 : n - lc;
-    featthr[(size_t)which * flocal + lf] = none ? 0.f : thr[base + r.t];
+    o->thr_id = none ? 0xFFFFFFFFu : tmin;
+    o->lcount = none ? 0 : wlc;
+    o->rcount = none ? 0 : n - wlc;
+    featthr[row] = none ? 0.f : thr[woff[lf] + tmin];
   }
 }
 
@@ -330,8 +521,14 @@ void qr_k_exact_free(qr_ctx *c) {
   if (c->d_xlist[0]) (void)hipFree(c->d_xlist[0]);
   if (c->d_xlist[1]) (void)hipFree(c->d_xlist[1]);
   if (c->d_xtot) (void)hipFree(c->d_xtot);
+  if (c->d_xgoleft) (void)hipFree(c->d_xgoleft);
+  if (c->d_xpub) (void)hipFree(c->d_xpub);
+  if (c->d_xtbest) (void)hipFree(c->d_xtbest);
   c->d_xroot = c->d_xlist[0] = c->d_xlist[1] = nullptr;
+  c->d_xpub = nullptr;
   c->d_xtot = nullptr;
+  c->d_xgoleft = nullptr;
+  c->d_xtbest = nullptr;
   c->xmode = false;
 }
 
@@ -354,12 +551,22 @@ int qr_k_exact_build(qr_ctx *c) {
     c->err = what;
     return QR_ERR_HIP;
   };
+  // tiles a segment can have, and the words they publish: [2 nodes][F][scan tiles] then [F][partition tiles]
+  c->xtiles_s = (uint32_t)((N + QR_XS_CHUNK - 1) / QR_XS_CHUNK);
+  c->xtiles_p = (uint32_t)((N + QR_X_CHUNK - 1) / QR_X_CHUNK);
+  const size_t npub = (2 * FL * c->xtiles_s + FL * c->xtiles_p) * QR_X_PUBW;
   if (hipMalloc((void **)&d_iota, N * 4) != hipSuccess || hipMalloc((void **)&d_ks, N * 4) != hipSuccess ||
       hipMalloc((void **)&d_vs, N * 4) != hipSuccess)
     return fail("allocating the sort scratch of the pre-sorted lists failed");
   if (hipMalloc((void **)&c->d_xroot, FL * N * 8) != hipSuccess || hipMalloc((void **)&c->d_xlist[0], FL * N * 8) != hipSuccess ||
-      hipMalloc((void **)&c->d_xlist[1], FL * N * 8) != hipSuccess || hipMalloc((void **)&c->d_xtot, 16) != hipSuccess)
+      hipMalloc((void **)&c->d_xlist[1], FL * N * 8) != hipSuccess ||
+      hipMalloc((void **)&c->d_xtot, (2 + 2 * FL + 2) * 8) != hipSuccess ||  // [2] totals, then [2][F] best score bits (+ an experiment's counter)
+      hipMalloc((void **)&c->d_xgoleft, N + 16) != hipSuccess || hipMalloc((void **)&c->d_xpub, npub * 8) != hipSuccess ||
+      hipMalloc((void **)&c->d_xtbest, 2 * FL * c->xtiles_s * sizeof(XTileBest)) != hipSuccess)
     return fail("allocating the pre-sorted lists failed");
+  if (hipMemset(c->d_xpub, 0, npub * 8) != hipSuccess || hipMemset(c->d_xtot, 0, (2 + 2 * FL + 2) * 8) != hipSuccess)
+    return fail("clearing the tiles' words failed");
+  c->xepoch = 0;
   if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t *)c->d_wbins, d_ks,
                                          (const uint32_t *)d_iota, d_vs, (int)N, 0, bits, c->stream) != hipSuccess ||
       hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16) != hipSuccess)
@@ -388,19 +595,35 @@ int qr_k_exact_scan(qr_ctx *c, int root_mode) {
   u64 *x0 = (u64 *)c->d_xlist[0], *x1 = (u64 *)c->d_xlist[1];
   const unsigned F = (unsigned)c->flocal;
   const int mode = root_mode ? 0 : 1;
+  const unsigned nodes = root_mode ? 1 : 2;
+  u64 *pub_scan = (u64 *)c->d_xpub, *pub_part = (u64 *)c->d_xpub + (size_t)2 * F * c->xtiles_s * QR_X_PUBW;
+  // the launch epoch the tiles' words carry (16 bits, never 0: the words start as zeros)
+  if (++c->xepoch > 0xFFFFu) {
+    QR_CHECK(c, hipMemsetAsync(c->d_xpub, 0, ((size_t)2 * F * c->xtiles_s + (size_t)F * c->xtiles_p) * QR_X_PUBW * 8, c->stream));
+    c->xepoch = 1;
+  }
+  const u64 epoch = c->xepoch;
   if (!root_mode) {
-    hipLaunchKernelGGL(k_xpart, dim3(F), dim3(1024), 0, c->stream, c->d_tree, xr, x0, x1, c->N,
-                       (const uint32_t *)c->d_wbins);
+    const unsigned fg = (unsigned)std::min<size_t>((c->N + 2047) / 2048, 1024);
+    hipLaunchKernelGGL(k_xflag, dim3(fg), dim3(256), 0, c->stream, c->d_tree, xr, (const u64 *)x0, (const u64 *)x1,
+                       c->N, c->d_xgoleft);
+    QR_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_xpart, dim3(F, c->xtiles_p), dim3(1024), 0, c->stream, c->d_tree, xr, x0, x1, c->N,
+                       (const uint8_t *)c->d_xgoleft, pub_part, c->xtiles_p, epoch);
     QR_CHECK(c, hipGetLastError());
   }
-  QR_CHECK(c, hipMemsetAsync(c->d_xtot, 0, 16, c->stream));
-  hipLaunchKernelGGL(k_xtotal, dim3(64, root_mode ? 1 : 2), dim3(256), 0, c->stream, c->d_tree, mode, rootn, xr,
+  QR_CHECK(c, hipMemsetAsync(c->d_xtot, 0, (2 + 2 * (size_t)F) * 8, c->stream));
+  hipLaunchKernelGGL(k_xtotal, dim3(64, nodes), dim3(256), 0, c->stream, c->d_tree, mode, rootn, xr,
                      (const u64 *)x0, (const u64 *)x1, c->d_lambda, c->d_scalars, c->d_xtot);
   QR_CHECK(c, hipGetLastError());
-  hipLaunchKernelGGL(k_xscan, dim3(F, root_mode ? 1 : 2), dim3(1024), 0, c->stream, c->d_tree, mode, rootn, xr,
+  hipLaunchKernelGGL(k_xscan, dim3(F, c->xtiles_s, nodes), dim3(QR_XS_T), 0, c->stream, c->d_tree, mode, rootn, xr,
                      (const u64 *)x0, (const u64 *)x1, c->N, c->d_lambda, c->d_scalars, c->d_xtot, c->d_woff,
-                     c->flocal, c->d_lf2gf, c->d_wthr, c->d_featrec, c->d_featthr,
-                     c->batch_root ? (u64)c->cur_minls : ~0ull);
+                     c->flocal, pub_scan, c->xtiles_s, epoch, (unsigned long long *)(c->d_xtot + 2),
+                     (XTileBest *)c->d_xtbest, c->batch_root ? (u64)c->cur_minls : ~0ull);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_xbest, dim3(F, nodes), dim3(64), 0, c->stream, c->d_tree, mode, rootn,
+                     (const XTileBest *)c->d_xtbest, c->xtiles_s, c->d_woff, c->flocal, c->d_lf2gf, c->d_wthr,
+                     c->d_featrec, c->d_featthr);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }

@@ -335,6 +335,10 @@ struct qr_ctx {
   unsigned long long *d_xroot = nullptr;     // [flocal][N] {slot << 32 | document}: the root's lists, never overwritten
   unsigned long long *d_xlist[2] = {nullptr, nullptr};  // the work lists the splits ping-pong between
   long long *d_xtot = nullptr;               // [2] fixed-point gradient totals of the node(s) being scanned
+  uint8_t *d_xgoleft = nullptr;              // [N] go-left byte of the documents of the node being split
+  unsigned long long *d_xpub = nullptr;      // the tiles' published words {epoch : 16, value : 48} (scan tiles, then partition tiles)
+  void *d_xtbest = nullptr;                  // [2][flocal][scan tiles] best candidate of every tile
+  uint32_t xtiles_s = 0, xtiles_p = 0, xepoch = 0;
   std::vector<uint32_t> h_woff;
   std::vector<float> h_wthr;
   float *d_thr = nullptr;        // [F][256]

@@ -174,6 +174,20 @@ def cpu_baseline(x, labels, qoff, args):
     return out
 
 
+def cpu_baseline_wide(x, labels, qoff, args):
+    """The oracle with the reference's default `--num-thresholds 0` on the MSLR-shaped stand-in, all
+    cores, two iterations (the second is the one quoted): the CPU figure beside
+    `mslr_default_thresholds`."""
+    import oracle
+    cores = oracle.available_cores()
+    m = oracle.train(x, labels, qoff, algo="LAMBDAMART", ntrees=2, shrinkage=0.1, nthresholds=0,
+                     nleaves=args.nleaves, minls=1, esr=0, threads=cores)
+    sec = float(m["iter_seconds"][-1])
+    return {"value": len(labels) / sec, "unit": "docs/s per boosting iteration", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "ms_per_iteration": sec * 1e3,
+            "sample": f"the whole stand-in, 2 iterations, the second quoted, OpenMP x{cores}"}
+
+
 def cpu_scoring_baseline(args, make_model):
     """Scoring baseline (LTR_Algorithm::score_dataset, ltr_algorithm.cc:44-52: OpenMP over
     the documents, per-tree walk): the oracle's restatement on a bounded sample of
@@ -728,6 +742,43 @@ def main():
                 xm, lm, qm, f"MSLR-WEB10K-shaped stand-in: {len(lm)} docs x {F} features in {len(qm) - 1} ragged "
                 f"queries (1..{int(np.diff(qm.astype(np.int64)).max())} documents), 40 sparse count columns; "
                 f"100 trees, {desc}", 100)
+            # ... and the same stand-in with the reference's DEFAULT `--num-thresholds 0` (every distinct
+            # value a threshold, mart.cc:155-158: up to ~700k slots per real-valued column): the
+            # pre-sorted path of k_exact.hip, with the oracle's own time per iteration beside it
+            # (the CPU leg is two iterations of ~2.5 s on 16 cores)
+            try:
+                t0 = time.perf_counter()
+                from quickrank_amd._capi import Context as _Ctx
+                wc = _Ctx(torch.cuda.current_device())
+                wc.upload(xm, lm, qm)
+                _, wts = wc.build_bins(0)
+                wc.synchronize()
+                winit = time.perf_counter() - t0
+                wc.reset_scores()
+                wsteps = 10
+                for it in range(wsteps + 2):
+                    if it == 2:
+                        wc.synchronize()
+                        t0 = time.perf_counter()
+                    wc.compute_lambdas("NDCG", 10)
+                    wc.fit_tree(args.nleaves, 1, True, read=False)
+                    wc.update_scores(0.1)
+                    wc.metric_last()
+                    wc.tree_nodes()
+                wc.synchronize()
+                wms = (time.perf_counter() - t0) / wsteps * 1e3
+                wnd = wc.metric_eval(0, "NDCG", 10)
+                wc.close()
+                extras["mslr_default_thresholds"] = {
+                    "workload": f"the MSLR-shaped stand-in ({len(lm)} docs x {F} features) with --num-thresholds 0: "
+                                f"{int(wts.max())} slots in the longest row, {int(wts.sum())} in all; LambdaMART "
+                                f"{args.nleaves} leaves, NDCG@10", "path": "pre-sorted per-feature lists (k_exact.hip)",
+                    "ms_per_step": wms, "value": len(lm) / wms * 1e3, "unit": "docs/s", "steps": wsteps,
+                    "init_s": round(winit, 2), "ndcg10_last": wnd}
+                if not args.no_cpu_baseline:
+                    extras["mslr_default_thresholds"]["cpu_baseline"] = cpu_baseline_wide(xm, lm, qm, args)
+            except Exception as e:  # the side metric must not take the line down
+                extras["mslr_default_thresholds"] = {"error": str(e)}
             del xm, lm, qm
             if pc["launches"]:
                 cb = built * (F + 12) + sum(int((t["feature"] >= 0).sum()) for t in head.trees[n0:]) * F * 256 * 16

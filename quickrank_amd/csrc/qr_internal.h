@@ -24,6 +24,9 @@
 #define QR_DPW 16384u     /* docs per workgroup between flushes              */
 #define QR_QBITS 33       /* |q| < 2^33                                      */
 #define QR_SLICE 1024u    /* doc-range alignment of hist workgroups          */
+#ifndef QR_HIST_MIN_PER
+#define QR_HIST_MIN_PER QR_SLICE /* fewest documents a histogram workgroup takes (A/B: 512 / 2048) */
+#endif
 #define QR_MAXBLK 64      /* max 64-feature blocks per rank (F <= 4096)      */
 #ifndef QR_PART_SLICE
 #define QR_PART_SLICE 2048u /* positions per partition workgroup             */
@@ -71,7 +74,7 @@ __host__ __device__ inline void qr_make_plan(uint32_t n, int nblocks,
     const uint32_t u = (uint32_t)(blk[b].fw / 16);
     uint32_t per = q / u + (q % u ? 1u : 0u);                 // ceil(q / u)
     per = per > 0x7FFFFC00u ? 0x7FFFFC00u : ((per + 255u) & ~255u);  // fine enough to fill the CUs evenly ...
-    if (per < QR_SLICE) per = QR_SLICE;  // ... but never less than 1024 documents per workgroup
+    if (per < QR_HIST_MIN_PER) per = QR_HIST_MIN_PER;  // ... but never less than 1024 documents per workgroup
     const int weff = (int)(n / per + (n % per ? 1u : 0u));    // ceil(n / per)
     p->per[b] = per;
     p->wg_start[b + 1] = p->wg_start[b] + weff;

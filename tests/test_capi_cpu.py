@@ -82,5 +82,5 @@ def test_oracle_users_are_only_the_allowed_ones():
                         found.add(getattr(fn, "name", "<module>"))
         return found
     # the cpu_baseline leg: the training baseline and the scoring baseline of the same object
-    assert importers(os.path.join(root, "bench.py")) <= {"cpu_baseline", "cpu_scoring_baseline"}
+    assert importers(os.path.join(root, "bench.py")) <= {"cpu_baseline", "cpu_scoring_baseline", "cpu_baseline_wide"}
     assert importers(os.path.join(root, "__graft_entry__.py")) <= {"build", "smoke"}

@@ -52,6 +52,9 @@ def test_bench_line_one_gpu():
     for k in ("oblivious_d6", "mslr_shaped"):
         assert d[k]["ms_per_step"] > 0 and 0 < d[k]["roofline_iteration"]["frac"] < 1 and d[k]["h2d_ms"] > 0
     assert d["mslr_shaped"]["steps"] == 100 and d["oblivious_d6"]["steps"] == 3
+    # the reference's default --num-thresholds 0 on the same stand-in (pre-sorted lists), CPU figure beside it
+    w = d["mslr_default_thresholds"]
+    assert w["ms_per_step"] > 0 and "k_exact" in w["path"] and w["cpu_baseline"]["ms_per_iteration"] > w["ms_per_step"]
     assert d["oblivious_d6"]["scoring"]["ms"] > 0 and d["oblivious_d6"]["scoring"]["docs_per_s"] > 0
     assert d["config"]["h2d_ms"] > 0 and d["config"]["init_ms"] > 0
     # the quality gate: the device after as many trees as the CPU baseline trained

@@ -814,7 +814,7 @@ def main():
         hs = runs[best][0]
         scaling = "strong"
         extras["strong_layouts"] = {k: v[0] for k, v in runs.items()}
-    if not args.no_extras and (multi or args.big_blocks):
+    if not args.no_extras and (multi or args.big_blocks or args.huge_blocks):
         es = args.extra_steps
         if multi:
             # weak scaling: every rank its OWN 1M-document shard (seed 42 + rank)

@@ -81,40 +81,6 @@ __device__ __forceinline__ const u64 *x_lists(const int buf, const u64 *xroot, c
   return buf == 2 ? xroot : (buf == 0 ? x0 : x1);
 }
 
-// exclusive prefix of one value per thread over the 1024 threads of the workgroup, and the total
-__device__ __forceinline__ void x_block_scan_u32(const uint32_t v, uint32_t &excl, uint32_t &total, uint32_t *sh) {
-  const uint32_t inc = wave_scan_u32(v);
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  __syncthreads();  // (sh is free again)
-  if (lane == 63) sh[wave] = inc;
-  __syncthreads();
-  uint32_t before = 0, all = 0;
-#pragma unroll
-  for (uint32_t w = 0; w < 16; ++w) {
-    const uint32_t t = sh[w];
-    before += w < wave ? t : 0u;
-    all += t;
-  }
-  excl = before + inc - v;
-  total = all;
-}
-__device__ __forceinline__ void x_block_scan_i64(const long long v, long long &excl, long long &total, long long *sh) {
-  const long long inc = wave_scan_i64(v);
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 63) sh[wave] = inc;
-  __syncthreads();
-  long long before = 0, all = 0;
-#pragma unroll
-  for (uint32_t w = 0; w < 16; ++w) {
-    const long long t = sh[w];
-    before += w < wave ? t : 0;
-    all += t;
-  }
-  excl = before + inc - v;
-  total = all;
-}
-
 // ---------------------------------------------------------------------------
 // k_xflag: the go-left byte of every document of the node being split, from the split feature's
 // own segment (sorted by slot: `slot <= t*`  <=>  `x <= threshold`, rt.cc:327-334).  A byte per

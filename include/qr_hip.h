@@ -298,6 +298,28 @@ int qr_obl_level_exchange(qr_ctx *ctx, size_t level, void **cells, size_t *cells
 int qr_lambda_finish(qr_ctx *ctx);
 int qr_tree_leaves_finish(qr_ctx *ctx, int newton, qr_node_t *nodes_out,
                           size_t *nnodes_out);
+/* The same trees with up to TWO splits per exchange (what qr_tree_fit does on one GPU --  */
+/* rt.cc:58-90's loop with the most promising other heap entry split ahead of its turn,    */
+/* invisible in the result -- cut at the all-reduces).  A tree of L leaves then costs      */
+/* 1 + steps all-reduces (5-6 steps for L = 10) instead of L:                               */
+/*     qr_tree_batch_begin(&steps) -> [all_reduce hist] -> qr_tree_batch_root               */
+/*     steps x { qr_tree_batch_apply -> [all_reduce batch cells, qr_tree_batch_exchange]    */
+/*               -> qr_tree_batch_decide(last = the final one of the sequence) }            */
+/*     qr_tree_batch_settle(&incomplete): waits for the last control step; `steps` was a    */
+/*       guess (the previous tree's count; every rank grows the same trees, so every rank   */
+/*       guesses and settles alike) -- if incomplete, repeat { apply, all_reduce, decide }  */
+/*       with last = 1 on the piece's final step and settle again                           */
+/*     qr_tree_end(nodes_out = NULL) -> [all_reduce leaf] -> qr_tree_leaves_finish          */
+/* qr_tree_batch_supported: 1 if the context can grow a tree of `nleaves` this way (u8      */
+/* bins, no --max-features, 2 <= nleaves <= 255), else 0: use qr_tree_begin / decide / apply */
+int qr_tree_batch_supported(qr_ctx *ctx, size_t nleaves);
+int qr_tree_batch_begin(qr_ctx *ctx, size_t nleaves, uint64_t minls, size_t *steps_out);
+int qr_tree_batch_root(qr_ctx *ctx);
+int qr_tree_batch_apply(qr_ctx *ctx);
+int qr_tree_batch_decide(qr_ctx *ctx, int last);
+int qr_tree_batch_settle(qr_ctx *ctx, int *incomplete, size_t *steps_used);
+/* device pointer + int64 element count of the batch's cells (valid after batch_begin)     */
+int qr_tree_batch_exchange(qr_ctx *ctx, void **cells, size_t *cells_i64);
 /* device pointers + int64 element counts; hist/scal valid after the bin build,  */
 /* leaf after qr_tree_begin                                                      */
 int qr_doc_exchange_buffers(qr_ctx *ctx, void **hist, size_t *hist_i64, void **scal,

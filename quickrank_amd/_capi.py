@@ -45,6 +45,8 @@ SYMBOLS = [
     "qr_prof_get_child", "qr_bins_build_wide", "qr_thresholds_read", "qr_bins_read_u32",
     "qr_node_hist_read_ragged", "qr_ctx_stream", "qr_obl_begin", "qr_obl_propose", "qr_obl_mark",
     "qr_obl_apply", "qr_obl_exchange_buffers", "qr_obl_level_exchange", "qr_prof_lds_atomic",
+    "qr_tree_batch_supported", "qr_tree_batch_begin", "qr_tree_batch_root", "qr_tree_batch_apply",
+    "qr_tree_batch_decide", "qr_tree_batch_settle", "qr_tree_batch_exchange",
 ]
 
 _LIB = None
@@ -133,6 +135,13 @@ def lib():
     L.qr_obl_exchange_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz),
                                           C.POINTER(vp), C.POINTER(sz)]
     L.qr_obl_level_exchange.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz)]
+    L.qr_tree_batch_supported.argtypes = [vp, sz]
+    L.qr_tree_batch_begin.argtypes = [vp, sz, C.c_uint64, C.POINTER(sz)]
+    L.qr_tree_batch_root.argtypes = [vp]
+    L.qr_tree_batch_apply.argtypes = [vp]
+    L.qr_tree_batch_decide.argtypes = [vp, C.c_int]
+    L.qr_tree_batch_settle.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(sz)]
+    L.qr_tree_batch_exchange.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.qr_tree_decide.argtypes = [vp]
     L.qr_tree_apply.argtypes = [vp]
     L.qr_tree_end.argtypes = [vp, C.c_int, vp, C.POINTER(sz)]
@@ -493,6 +502,37 @@ class Context:
 
     def lambda_finish(self):
         self._ck(self.L.qr_lambda_finish(self.h))
+
+    # -- document-sharded trees, up to two splits per exchange (include/qr_hip.h)
+    def tree_batch_supported(self, nleaves):
+        return bool(self.L.qr_tree_batch_supported(self.h, nleaves))
+
+    def tree_batch_begin(self, nleaves, minls):
+        """root histogram enqueued; returns the number of steps to enqueue (a guess)"""
+        n = C.c_size_t()
+        self._ck(self.L.qr_tree_batch_begin(self.h, nleaves, minls, C.byref(n)))
+        return n.value
+
+    def tree_batch_root(self):
+        self._ck(self.L.qr_tree_batch_root(self.h))
+
+    def tree_batch_apply(self):
+        self._ck(self.L.qr_tree_batch_apply(self.h))
+
+    def tree_batch_decide(self, last):
+        self._ck(self.L.qr_tree_batch_decide(self.h, int(bool(last))))
+
+    def tree_batch_settle(self):
+        """(incomplete, steps the tree has used): waits for the last control step"""
+        inc, n = C.c_int(), C.c_size_t()
+        self._ck(self.L.qr_tree_batch_settle(self.h, C.byref(inc), C.byref(n)))
+        return bool(inc.value), n.value
+
+    def tree_batch_exchange(self):
+        """(device pointer, int64 count) of the batch's cells to sum"""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self.L.qr_tree_batch_exchange(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     def tree_end_local(self, newton=True):
         """document-sharded: local leaf sums only; all-reduce, then tree_leaves_finish"""

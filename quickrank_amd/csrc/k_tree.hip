@@ -1070,6 +1070,116 @@ __global__ __launch_bounds__(256) void k_level_finish_doc(
 }
 
 // ===========================================================================
+// Batched leaf-wise growth on DOCUMENT-SHARDED ranks: k_redscan cut in two around the
+// all-reduce.  The batch's exchange buffer `xb` holds, per job j, the per-slot cells of its
+// directly built child over this rank's documents -- [j][feature][slot][sum, count], int64 --
+// and, behind all jobs' cells, [j][2 * world] f64 bit patterns: the rank's (sum of squares,
+// sum) of that child in its own pair, zeros elsewhere, so that the sum all-reduce gathers them
+// (as k_reduce does for the one-split protocol).
+//   k_bd_reduce (before the all-reduce): column sums of the feature-major partial slots into
+//     xb, and the rank's own CUMULATIVE counts of both children into hcnt_loc -- where its
+//     partition of a later split cuts its lists.
+//   k_bd_scan (after): prefix over the slots of the summed cells, sibling by subtraction,
+//     best slot per feature for both children (scan_core: the one-GPU arithmetic on the
+//     one-GPU integers), and the children's sums in rank order into jobsum.
+// Grid = (features, QR_BATCH) for both.
+// ===========================================================================
+__global__ __launch_bounds__(1024) void k_bd_reduce(
+    const QrScanWg *__restrict__ descs, const u64 *__restrict__ partials, const int flocal,
+    long long *__restrict__ xb, uint32_t *__restrict__ hcnt_loc, const double *__restrict__ part_ss,
+    const int rank, const int world) {
+  __shared__ long long cs_s[3][256];
+  __shared__ uint32_t cs_c[3][256];
+  __shared__ long long sh_s[4];
+  __shared__ uint32_t sh_c[4];
+  const int lf = blockIdx.x;
+  const uint32_t t = threadIdx.x & 255, g = threadIdx.x >> 8;
+  const QrScanWg d = descs[(size_t)blockIdx.y * flocal + lf];
+  if (!d.active) return;  // (what the job's cells hold is not looked at: k_bd_scan leaves too)
+  uint32_t par_c = 0;
+  if (g == 0) par_c = hcnt_loc[((size_t)d.parent_slot * flocal + lf) * 256 + t];
+  const u64 *src = partials + (size_t)d.slot0 * (256u * 64u) + d.col * 256u + t;
+  long long s = 0;
+  uint32_t cn = 0;
+  // (feature 0's workgroup, last wave) the rank's sums of the directly built child, as k_redscan
+  const bool sums_wave = lf == 0 && (threadIdx.x >> 6) == 15;
+  double pa = 0.0, pb = 0.0;
+  if (sums_wave) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t nw0 = d.total / (uint32_t)d.kmax;
+    for (uint32_t i = lane; i < nw0; i += 64) {
+      pa += part_ss[2 * (size_t)(d.slot0 + i * (uint32_t)d.kmax)];
+      pb += part_ss[2 * (size_t)(d.slot0 + i * (uint32_t)d.kmax) + 1];
+    }
+  }
+  column_sum(src, (int)d.total, d.kmax, d.per, d.n, (int)g, s, cn);
+  if (sums_wave) {
+    pa = wave_sum(pa);
+    pb = wave_sum(pb);
+    long long *tail = xb + (size_t)QR_BATCH * flocal * 512 + (size_t)blockIdx.y * 2 * world;
+    for (int i = threadIdx.x & 63; i < 2 * world; i += 64) {
+      long long v = 0;
+      if (i == 2 * rank) v = __double_as_longlong(pa);
+      if (i == 2 * rank + 1) v = __double_as_longlong(pb);
+      tail[i] = v;
+    }
+  }
+  if (g > 0) {
+    cs_s[g - 1][t] = s;
+    cs_c[g - 1][t] = cn;
+  }
+  __syncthreads();
+  if (g > 0) return;  // whole waves leave; the barrier below counts the remaining four
+  for (int i = 0; i < 3; ++i) {
+    s += cs_s[i][t];
+    cn += cs_c[i][t];
+  }
+  const size_t x = (((size_t)blockIdx.y * flocal + lf) * 256 + t) * 2;
+  xb[x] = s;
+  xb[x + 1] = (long long)cn;
+  QrLevelNode ln;
+  ln.small_slot = d.small_slot;
+  ln.big_slot = d.big_slot;
+  level_prefix_write(0, cn, 0, par_c, ln, lf, t, flocal, nullptr, hcnt_loc, sh_s, sh_c);
+}
+
+__global__ __launch_bounds__(256) void k_bd_scan(
+    const QrScanWg *__restrict__ descs, const long long *__restrict__ xb, long long *__restrict__ hsum,
+    uint32_t *__restrict__ hcnt, const int flocal, const uint32_t *__restrict__ thr_size,
+    const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
+    qr_split_t *__restrict__ featrec, const float *__restrict__ thr, float *__restrict__ featthr,
+    const u64 minls, double *__restrict__ jobsum, const int world) {
+  const int lf = blockIdx.x;
+  const uint32_t t = threadIdx.x;
+  const int gf = lf2gf[lf];
+  const QrScanWg d = descs[(size_t)blockIdx.y * flocal + lf];
+  const uint32_t tsize = thr_size[gf];
+  const float my_thr = thr[(size_t)gf * QR_MAX_BINS + t];
+  const double inv = scal->inv_scale;
+  if (!d.active) return;
+  const size_t x = (((size_t)blockIdx.y * flocal + lf) * 256 + t) * 2;
+  const long long s = xb[x];
+  const uint32_t cn = (uint32_t)xb[x + 1];
+  const size_t pidx = ((size_t)d.parent_slot * flocal + lf) * 256 + t;
+  const long long par_s = hsum[pidx];
+  const uint32_t par_c = hcnt[pidx];
+  if (lf == 0 && t == 0) {
+    // the ranks' partial sums in rank order: every rank computes the same bits
+    const long long *tail = xb + (size_t)QR_BATCH * flocal * 512 + (size_t)blockIdx.y * 2 * world;
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < world; ++r) {
+      a += __longlong_as_double(tail[2 * r]);
+      b += __longlong_as_double(tail[2 * r + 1]);
+    }
+    jobsum[2 * blockIdx.y] = a;
+    jobsum[2 * blockIdx.y + 1] = b;
+  }
+  scan_core(0, d.small_slot, d.big_slot, d.parent_slot, d.small_is_left, minls, lf, s, cn, 0u, hsum, hcnt,
+            flocal, thr_size, lf2gf, scal, featrec + (size_t)2 * blockIdx.y * flocal, nullptr, my_thr,
+            featthr + (size_t)2 * blockIdx.y * flocal, true, par_s, par_c, gf, tsize, inv);
+}
+
+// ===========================================================================
 // k_merge: best over the local features; local features are in ascending
 // global order and the comparison is strict, so the lowest feature wins ties
 // (rt.cc:297-306).  Also attaches lcount/rcount from the node histogram.
@@ -1618,7 +1728,15 @@ __device__ QR_CTRL_FN void batch_make_job(DecideState &st, BatchState &bs, int j
   const int ri = li + 1;
   const int sl = bs.next_slot, sr = sl + 1;
   bs.next_slot += 2;
-  const uint32_t lc = (uint32_t)nd->best_lc, rc = (uint32_t)nd->best_rc;
+  // (document-sharded rank: [begin, end) are positions in its OWN lists -- its own left count comes
+  // from the prefix of its local counts, as make_desc does; which child is built directly, and the
+  // node statistics, follow the GLOBAL counts so that every rank takes the same decisions)
+  const bool lsmall = nd->best_lc <= nd->best_rc;
+  uint32_t lc = (uint32_t)nd->best_lc, rc = (uint32_t)nd->best_rc;
+  if (st.hcnt_loc) {
+    lc = st.hcnt_loc[((size_t)nd->hslot * st.flocal + nd->best_lf) * 256 + nd->best_t];
+    rc = (nd->end - nd->begin) - lc;
+  }
   const int dst = nd->buf == 0 ? 1 : 0;
   batch_child_init(&st.nodes[li], nd->begin, nd->begin + lc, dst, sl, node);
   batch_child_init(&st.nodes[ri], nd->begin + lc, nd->end, dst, sr, node);
@@ -1626,7 +1744,7 @@ __device__ QR_CTRL_FN void batch_make_job(DecideState &st, BatchState &bs, int j
   ln->active = 1;
   ln->src_buf = nd->buf;
   ln->dst_buf = dst;
-  ln->small_is_left = lc <= rc;
+  ln->small_is_left = lsmall;
   ln->begin = nd->begin;
   ln->end = nd->end;
   ln->lcount = lc;
@@ -1664,10 +1782,13 @@ __device__ __forceinline__ void batch_child_stats(QrNode *nodes, const QrLevelNo
   const QrNode *P = &nodes[ln.node];
   QrNode *C = &nodes[which ? ln.right : ln.left];
   const bool is_small = (which == 0) == (ln.small_is_left != 0);
+  // (the child's count over ALL ranks' documents: ln.small_n is this rank's own on a
+  // document-sharded context)
+  const u64 gsmall = ln.small_is_left ? P->best_lc : P->best_rc;
   if (is_small)
-    node_stats(C, sum_small, ss_small, ln.small_n);
+    node_stats(C, sum_small, ss_small, gsmall);
   else
-    node_stats(C, P->sum - sum_small, P->ss - ss_small, P->count - ln.small_n);
+    node_stats(C, P->sum - sum_small, P->ss - ss_small, P->count - gsmall);
   node_set_best(C, own2, 1, which);
   C->best_lf = lf;
   C->best_thr = thrv;
@@ -1687,7 +1808,8 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
                                            const int njobs, const QrLevelNode *prev,
                                            const uint32_t N, const qr_split_t *own,
                                            const QrScalars *scal, const int32_t *own_lf,
-                                           const float *own_thr, const int root_buf) {
+                                           const float *own_thr, const int root_buf, const u64 Ncount) {
+  // (Ncount: the root's documents over all ranks -- N itself except on a document-sharded rank)
   int nj = 0;
 #ifdef QR_STEP_TIMING
   long long lt[5];
@@ -1699,7 +1821,7 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
   if (root_mode) {
     QrNode *root = &st.nodes[0];
     batch_child_init(root, 0, N, root_buf, 0, -1);
-    node_stats(root, scal->root_sum, scal->root_ss, (u64)N);
+    node_stats(root, scal->root_sum, scal->root_ss, Ncount);
     node_set_best(root, own, 1, 0);
     root->best_lf = own_lf[0];
     root->best_thr = own_thr[0];
@@ -1764,7 +1886,7 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
   QR_LT(2);
   // candidates applied ahead of their turn: the largest deviances left in the heap,
   // as long as the leaf budget can still reach them
-  if (nj == 1 && N < QR_SPEC_MAX_DOCS) {
+  if (nj == 1 && Ncount < QR_SPEC_MAX_DOCS) {
     while (nj < QR_BATCH) {
       if (st.nleaves_req != 0 && st.nleaves_req - (st.taken + st.heap_size + 2) < nj) break;
       int pick = -1;
@@ -1824,7 +1946,7 @@ __device__ __forceinline__ void batch_step(
     const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
     QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
     const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
-    const int final_call = 0) {
+    const int final_call = 0, const uint32_t *__restrict__ hcnt_loc = nullptr, const u64 Nglobal = 0) {
   QrTreeState *const ts = tout;  // where the writer publishes
   __shared__ QrPlan sh_plan[QR_BATCH];
   __shared__ qr_split_t own[2 * QR_BATCH];
@@ -1955,7 +2077,7 @@ __device__ __forceinline__ void batch_step(
     st.split_log = writer ? ts->split_log : nullptr;
     st.split_log2 = (writer && tlog2) ? tlog2->split_log : nullptr;
     st.desc = &ts->desc;
-    st.hcnt_loc = nullptr;
+    st.hcnt_loc = hcnt_loc;   // (document-sharded ranks: their own cumulative counts, k_bd_reduce)
     st.loc = &ts->loc;
     st.flocal = flocal;
     BatchState bs;
@@ -1968,11 +2090,11 @@ __device__ __forceinline__ void batch_step(
     if (staged) {
       st.nodes = sh_nodes;
       st.heap = sh_heap;
-      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, scal, own_lf, own_thr, root_buf);
+      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, scal, own_lf, own_thr, root_buf, hcnt_loc ? Nglobal : (u64)N);
     } else {
       st.nodes = ts->nodes;
       st.heap = ts->heap;
-      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, scal, own_lf, own_thr, root_buf);
+      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, scal, own_lf, own_thr, root_buf, hcnt_loc ? Nglobal : (u64)N);
     }
     // one plan quantum for the whole batch (as for a level of an oblivious tree)
     if (nj > 0) {
@@ -2220,15 +2342,17 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
     QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
     const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
-    const QrTreeState *tin, const int final_call, int64_t *__restrict__ early, const long long early_seq) {
+    const QrTreeState *tin, const int final_call, int64_t *__restrict__ early, const long long early_seq,
+    const uint32_t *__restrict__ hcnt_loc, const u64 Nglobal) {
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
   __shared__ int sh_nj;
-  // (tin != ts: the last call of a tree grown by k_decide_part, whose state ping-pongs)
+  // (tin != ts: the last call of a tree grown by k_decide_part, whose state ping-pongs;
+  // hcnt_loc != null: a document-sharded rank, N = its own documents, Nglobal = everybody's)
   batch_step<false, CAP>(tin ? tin : ts, ts, nullptr, true, 0u, sh_next, sh_pw0, &sh_nj, &sh_epoch,
                     root_mode, nleaves_arg, minls_arg, stage_nodes, N, flocal, scal, part_ss, featrec,
                     featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, part_wg, part_grid,
-                    plans, scan_wg, final_call);
+                    plans, scan_wg, final_call, hcnt_loc, Nglobal);
   if (final_call && early) {  // QrPinned::early: the host settles the tree on this
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -4093,7 +4217,9 @@ static int launch_decide_batch(qr_ctx *c, const BatchGeom &g, size_t nleaves, ui
                      g.stage_nodes, g.rootn, c->flocal, c->d_scalars, c->d_jobsum, c->d_featrec, c->d_featthr,
                      (uint32_t)c->F, c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, g.hg,
                      c->d_lpart_wg, g.pg, c->d_lplan, c->d_lscan_wg, tin, final_call,
-                     final_call ? c->d_pin->early : (int64_t *)nullptr, (long long)(final_call ? ++c->early_seq : 0));
+                     final_call ? c->d_pin->early : (int64_t *)nullptr, (long long)(final_call ? ++c->early_seq : 0),
+                     c->dmode ? c->d_hcnt_loc : (const uint32_t *)nullptr,
+                     (u64)(c->sub_k ? c->sub_k : c->Nglobal));
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -4185,6 +4311,55 @@ int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_d
       return rc;
   }
   return QR_OK;
+}
+
+// ---- document-sharded ranks: the same growth, phase by phase, with the host's all-reduces
+// in between (dist.py DocShardedTrainer.fit_tree / host/mart_multi.cc):
+//   root_hist -> [all-reduce d_xh] -> root_decide -> { apply -> [all-reduce d_xb] -> decide } x steps
+// Every rank holds the same all-reduced integers and the same rank-ordered f64 sums, so the
+// control steps agree bit for bit without exchanging anything else.
+int qr_k_dbatch_root_hist(qr_ctx *c, size_t nleaves, uint64_t minls) {
+  c->tree_step = 0;
+  c->tree_counter += 0x9E3779B97F4A7C15ull;
+  c->cur_minls = minls;
+  const BatchGeom g = batch_geom(c, nleaves);
+  c->finish_in_decide = g.stage_nodes > 0;
+  return launch_hist_scan(c, 1);  // k_hist_root + k_reduce into the exchange buffer
+}
+
+int qr_k_dbatch_root_decide(qr_ctx *c, size_t nleaves, uint64_t minls) {
+  int rc = launch_scan(c, 1);  // slot 0 (sums, counts, the rank's own counts) + featrec[0]
+  if (rc) return rc;
+  const BatchGeom g = batch_geom(c, nleaves);
+  return launch_decide_batch(c, g, nleaves, minls, 1, c->d_tree, (const QrTreeState *)nullptr, c->d_jobsum, 0);
+}
+
+int qr_k_dbatch_apply(qr_ctx *c, size_t nleaves) {
+  const BatchGeom g = batch_geom(c, nleaves);
+  hipLaunchKernelGGL(k_partition_batch, dim3(g.pg), dim3(256), 0, c->stream, c->d_tree, c->d_lpart_wg,
+                     c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1], (u64 *)c->d_bpart_state,
+                     c->d_lambda, (double *)nullptr, ++c->bepoch, 0);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_hist_batch, dim3(g.hg), dim3(1024), hist_lds(c), c->stream, c->d_lhist_wg, c->d_blocks,
+                     c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_lpartials,
+                     c->d_lhistsum);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_bd_reduce, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_lscan_wg,
+                     (const u64 *)c->d_lpartials, c->flocal, c->d_xb, c->d_hcnt_loc, c->d_lhistsum, c->rank,
+                     c->world);
+  QR_CHECK(c, hipGetLastError());
+  ++c->tree_step;
+  return QR_OK;
+}
+
+int qr_k_dbatch_decide(qr_ctx *c, size_t nleaves, uint64_t minls, int final_call) {
+  hipLaunchKernelGGL(k_bd_scan, dim3(c->flocal, QR_BATCH), dim3(256), 0, c->stream, c->d_lscan_wg,
+                     (const long long *)c->d_xb, c->d_hsum, c->d_hcnt, c->flocal, c->d_thr_size, c->d_lf2gf,
+                     c->d_scalars, c->d_featrec, c->d_thr, c->d_featthr, (u64)minls, c->d_jobsum, c->world);
+  QR_CHECK(c, hipGetLastError());
+  const BatchGeom g = batch_geom(c, nleaves);
+  return launch_decide_batch(c, g, nleaves, minls, 0, c->d_tree, (const QrTreeState *)nullptr, c->d_jobsum,
+                             final_call);
 }
 
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {

@@ -169,7 +169,8 @@ static void free_train(qr_ctx *c) {
     c->d_red_sum = nullptr;
     c->d_red_cnt = nullptr;
   }
-  dfree(c->d_xh); dfree(c->d_xscal); dfree(c->d_xleaf); dfree(c->d_xlevel);
+  dfree(c->d_xh); dfree(c->d_xscal); dfree(c->d_xleaf); dfree(c->d_xlevel); dfree(c->d_xb);
+  c->xb_len = 0;
   c->xleaf_cap = 0;
   dfree(c->d_red_sum); dfree(c->d_red_cnt);
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec); dfree(c->d_featthr); dfree(c->d_lscan_wg);
@@ -1265,6 +1266,7 @@ int qr_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
   c->cur_maxnodes = 2 * nleaves + 1;
   c->tree_open = true;
   c->tree_valid = false;
+  c->dbatch = false;
   return qr_k_tree_begin(c, nleaves, minls);
 }
 
@@ -1468,6 +1470,99 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
   c->cur_maxnodes = ((size_t)1 << (depth + 1)) - 1;
   if ((rc = qr_k_oblivious_fit(c, depth, minls))) return rc;
   return qr_tree_end(c, newton, nodes_out, nnodes_out);
+}
+
+// ---- document-sharded leaf-wise trees with up to QR_BATCH splits per step -----------------
+// (what qr_tree_fit does on one GPU, cut at the all-reduces: include/qr_hip.h)
+int qr_tree_batch_supported(qr_ctx *c, size_t nleaves) {
+  if (!c || !c->binned || !c->dmode || c->wide || c->mf_k || c->no_batch) return 0;
+  return nleaves >= 2 && 4 * nleaves + 1 <= QR_MAXNODES ? 1 : 0;
+}
+
+int qr_tree_batch_begin(qr_ctx *c, size_t nleaves, uint64_t minls, size_t *steps_out) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  if (!qr_tree_batch_supported(c, nleaves))
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "qr_tree_batch_begin: a document-sharded context with u8 bins, every feature "
+                                   "at every node and 2 <= nleaves <= 255 (otherwise qr_tree_begin / decide / apply)");
+  int rc = tree_settle(c);
+  if (rc) return rc;
+  if ((rc = ensure_hist_slots(c, 4 * nleaves + 1))) return rc;
+  size_t depth = 1;
+  while (((size_t)1 << (depth - 1)) < QR_BATCH) ++depth;
+  if ((rc = ensure_level_buffers(c, depth))) return rc;
+  const size_t need = (size_t)QR_BATCH * c->flocal * 512 + (size_t)QR_BATCH * 2 * c->world;
+  if (need > c->xb_len || 2 * nleaves * (size_t)c->world > c->xleaf_cap) QR_CHECK(c, hipStreamSynchronize(c->stream));
+  if (need > c->xb_len) {
+    dfree(c->d_xb);
+    QR_CHECK(c, dalloc(&c->d_xb, need));
+    QR_CHECK(c, hipMemset(c->d_xb, 0, need * 8));
+    c->xb_len = need;
+  }
+  if (2 * nleaves * (size_t)c->world > c->xleaf_cap) {
+    dfree(c->d_xleaf);
+    c->xleaf_cap = 2 * nleaves * (size_t)c->world;
+    QR_CHECK(c, dalloc(&c->d_xleaf, c->xleaf_cap));
+    QR_CHECK(c, hipMemset(c->d_xleaf, 0, c->xleaf_cap * 8));
+  }
+  c->cur_nleaves = nleaves;
+  c->leaf_cap = nleaves;
+  c->cur_maxnodes = 2 * nleaves + 1;
+  c->tree_open = true;
+  c->tree_valid = false;
+  c->dbatch = true;
+  // the guess: as many steps as the last tree needed (+ QR_STEPS_PLUS); every rank grows the
+  // same trees, so every rank guesses the same number
+  size_t steps = nleaves - 1;
+  if (c->steps_force >= 0)
+    steps = std::min<size_t>(steps, (size_t)std::max<long>(c->steps_force, 1));
+  else if (c->steps_hint)
+    steps = std::min(steps, c->steps_hint);
+  if (steps < 1) steps = 1;
+  if (steps_out) *steps_out = steps;
+  return qr_k_dbatch_root_hist(c, nleaves, minls);
+}
+
+int qr_tree_batch_root(qr_ctx *c) {
+  if (!c || !c->tree_open || !c->dbatch) return QR_ERR_STATE;
+  return qr_k_dbatch_root_decide(c, c->cur_nleaves, c->cur_minls);
+}
+
+int qr_tree_batch_apply(qr_ctx *c) {
+  if (!c || !c->tree_open || !c->dbatch) return QR_ERR_STATE;
+  return qr_k_dbatch_apply(c, c->cur_nleaves);
+}
+
+int qr_tree_batch_decide(qr_ctx *c, int last) {
+  if (!c || !c->tree_open || !c->dbatch) return QR_ERR_STATE;
+  return qr_k_dbatch_decide(c, c->cur_nleaves, c->cur_minls, last ? 1 : 0);
+}
+
+int qr_tree_batch_exchange(qr_ctx *c, void **cells, size_t *cells_i64) {
+  if (!c) return QR_ERR_ARG;
+  if (!c->dmode || !c->d_xb) QR_FAIL(c, QR_ERR_STATE, "qr_tree_batch_exchange follows qr_tree_batch_begin on a document-sharded context");
+  if (cells) *cells = c->d_xb;
+  if (cells_i64) *cells_i64 = c->xb_len;
+  return QR_OK;
+}
+
+int qr_tree_batch_settle(qr_ctx *c, int *incomplete, size_t *steps_used) {
+  if (!c || !incomplete) return QR_ERR_ARG;
+  if (!c->tree_open || !c->dbatch) QR_FAIL(c, QR_ERR_STATE, "qr_tree_batch_settle follows qr_tree_batch_decide(last = 1)");
+  int64_t w = 0;
+  const int rc = wait_early(c, &w);
+  if (rc) return rc;
+  *incomplete = (int)(w & 1);
+  const size_t used = (size_t)((w >> 1) & 0x7fff);
+  if (steps_used) *steps_used = used;
+  if (!(w & 1)) {
+    ++c->spec_trees;
+    c->steps_hint = used + c->steps_plus;
+    if (c->steps_hint < 1) c->steps_hint = 1;
+  } else {
+    ++c->spec_misses;
+  }
+  return QR_OK;
 }
 
 // ---- feature-sharded oblivious trees, phase by phase ------------------------------------

@@ -284,6 +284,10 @@ struct qr_ctx {
   long long *d_xleaf = nullptr;  // [world][2*nleaves] f64 bits: per-leaf (sum lambda, sum weight)
   long long *d_xlevel = nullptr;  // document-sharded level-wise growth: [node][feature][slot][sum, count] of a level
   size_t xlevel_cap = 0;
+  // document-sharded batched growth: [QR_BATCH][feature][slot][sum, count] + [QR_BATCH][2 * world] f64 bits
+  long long *d_xb = nullptr;
+  size_t xb_len = 0;
+  bool dbatch = false;            // the open tree grows by qr_tree_batch_* (document-sharded)
   size_t xleaf_cap = 0;
   int ncu = 256;
   // LDS the device really has (hipDeviceProp_t): a workgroup's opt-in maximum and a CU's total.  The
@@ -615,6 +619,11 @@ int qr_k_obl_mark(qr_ctx *c, int level);
 int qr_k_obl_apply(qr_ctx *c, int level, int last);
 int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls);
 int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_done, size_t max_steps = 0);
+// (document-sharded ranks: the same growth phase by phase, the host's all-reduces in between)
+int qr_k_dbatch_root_hist(qr_ctx *c, size_t nleaves, uint64_t minls);
+int qr_k_dbatch_root_decide(qr_ctx *c, size_t nleaves, uint64_t minls);
+int qr_k_dbatch_apply(qr_ctx *c, size_t nleaves);
+int qr_k_dbatch_decide(qr_ctx *c, size_t nleaves, uint64_t minls, int final_call);
 int qr_k_ensemble_score(qr_ctx *c, const float *d_x, size_t N, size_t F,
                         double *d_out, double *d_partial = nullptr, int ignore_weights = 0);
 int qr_k_obl_score(qr_ctx *c, const float *d_x, size_t N, size_t F, double *d_out);

@@ -292,8 +292,15 @@ class DocShardedTrainer:
         self._sum(self.scal, "scal")
         self.ctx.lambda_finish()
 
-    def fit_tree(self, nleaves, minls, newton, read=True):
+    def fit_tree(self, nleaves, minls, newton, read=True, batched=None):
+        """`batched` (default: whenever the context can, QR_DOC_BATCH=0 turns it off): up to two
+        splits per exchange -- 1 + steps histogram all-reduces per tree instead of nleaves."""
         ctx = self.ctx
+        if batched is None:
+            import os
+            batched = os.environ.get("QR_DOC_BATCH", "1") != "0"
+        if batched and hasattr(ctx, "tree_batch_supported") and ctx.tree_batch_supported(nleaves):
+            return self._fit_tree_batched(nleaves, minls, newton, read)
         ctx.tree_begin(nleaves, minls)
         self._sum(self.hist, "hist")
         for _ in range(nleaves - 1):
@@ -310,6 +317,51 @@ class DocShardedTrainer:
         self._sum(self.leaf, "leaf")
         return ctx.tree_leaves_finish(nleaves, newton, read=read)
 
+
+    def _leaf_exchange(self, nleaves, newton, read):
+        ctx = self.ctx
+        ctx.tree_end_local(newton)
+        b = ctx.doc_exchange_buffers()
+        if self.leaf is None or self._ptr.get("leaf") != (b["leaf"], b["leaf_n"]):
+            self.leaf = self._view(b["leaf"], b["leaf_n"], "leaf")
+            self.leaf_n = b["leaf_n"]
+            self._ptr["leaf"] = (b["leaf"], b["leaf_n"])
+        self._sum(self.leaf, "leaf")
+        return ctx.tree_leaves_finish(nleaves, newton, read=read)
+
+    def _fit_tree_batched(self, nleaves, minls, newton, read):
+        """RegressionTree::fit (rt.cc:58-90) with up to two splits per exchange: the one-GPU
+        batched growth (qr_tree_fit) cut at the all-reduces.  The number of steps enqueued is a
+        guess (the previous tree's); the last control step tells whether it sufficed -- one host
+        wait per tree, where the one-split protocol has none but nleaves all-reduces."""
+        ctx = self.ctx
+        steps = ctx.tree_batch_begin(nleaves, minls)
+        self._sum(self.hist, "hist")
+        ctx.tree_batch_root()
+        ptr, n = ctx.tree_batch_exchange()
+        if self._ptr.get("batch") != (ptr, n):
+            self._ptr["batch"] = (ptr, n)
+            self.batch = self._view(ptr, n, "batch")
+        self.collectives = 1
+
+        def run(k):
+            for s in range(k):
+                ctx.tree_batch_apply()
+                self._sum(self.batch, "batch")
+                ctx.tree_batch_decide(s == k - 1)
+            self.collectives += k
+
+        run(steps)
+        done, piece = steps, 1
+        while True:
+            incomplete, _ = ctx.tree_batch_settle()
+            if not incomplete:
+                break
+            k = max(1, min(piece, nleaves - 1 - done))
+            run(k)
+            done += k
+            piece *= 2
+        return self._leaf_exchange(nleaves, newton, read)
 
     def fit_oblivious(self, depth, minls, newton, read=True):
         """ObliviousRT::fit (ot.cc:32-201) over document shards: ONE int64 all-reduce per

@@ -443,3 +443,150 @@ def test_doc_sharded_trainer_over_rccl_world1():
     finally:
         dist.destroy_process_group()
     ref.close()
+
+
+def _doc_fit_batched(emu, ctxs, nleaves, minls, newton, stats=None):
+    """the document-sharded protocol with up to two splits per exchange (include/qr_hip.h,
+    qr_tree_batch_*), the all-reduces replaced by explicit sums; what
+    DocShardedTrainer._fit_tree_batched drives"""
+    steps = [c.tree_batch_begin(nleaves, minls) for c in ctxs]
+    assert len(set(steps)) == 1            # every rank guesses the same number of steps
+    emu.allreduce("hist")
+    for c in ctxs:
+        c.tree_batch_root()
+    exchanges = 1
+
+    def run(k):
+        for s in range(k):
+            for c in ctxs:
+                c.tree_batch_apply()
+            emu.allreduce_raw([c.tree_batch_exchange() for c in ctxs])
+            for c in ctxs:
+                c.tree_batch_decide(s == k - 1)
+
+    run(steps[0])
+    exchanges += steps[0]
+    done, piece, misses = steps[0], 1, 0
+    while True:
+        res = [c.tree_batch_settle() for c in ctxs]
+        assert len(set(res)) == 1          # ... and settles alike
+        if not res[0][0]:
+            break
+        misses += 1
+        k = max(1, min(piece, nleaves - 1 - done))
+        run(k)
+        exchanges += k
+        done += k
+        piece *= 2
+    for c in ctxs:
+        c.tree_end_local(newton)
+    emu.allreduce("leaf")
+    if stats is not None:
+        stats.append((exchanges, res[0][1], misses))
+    return [c.tree_leaves_finish(nleaves, newton) for c in ctxs]
+
+
+@pytest.mark.parametrize("world,cuts,nthr,F,nleaves,minls,force", [
+    (2, [30], 255, 136, 10, 2, None),
+    (3, [5, 41], 255, 70, 10, 1, None),        # a small first shard: nodes that run empty on a rank
+    (4, [15, 30, 45], 16, 20, 16, 2, None),
+    (8, [7, 14, 22, 30, 38, 45, 52], 255, 136, 10, 2, None),
+    (2, [30], 255, 136, 10, 2, "1"),           # one step enqueued whatever the tree: every tree is carried on
+    (3, [20, 41], 64, 40, 31, 0, None),        # larger trees, empty leaves allowed
+    (2, [30], 255, 40, 2, 1, None),            # a stump
+])
+def test_doc_sharded_batched_training_equals_single(world, cuts, nthr, F, nleaves, minls, force, monkeypatch):
+    """Two splits per exchange on document shards: the trees are the single-context trees
+    (structure bit for bit, f64 sums to rounding: they are added in rank order), every rank holds
+    the same bits, and a tree costs 1 + steps histogram exchanges instead of nleaves."""
+    import torch
+    import quickrank_amd as qr
+    from quickrank_amd import build
+    build.build()
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=50, F=F, seed=37, adversarial=True)
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(nthr)
+    single.reset_scores()
+    if force is not None:
+        monkeypatch.setenv("QR_STEPS_HINT", force)
+    parts = _split_queries(qoff, cuts)
+    ctxs, thr, ts = _make_ctxs(qr, x, labels, qoff, parts, nthr)
+    monkeypatch.delenv("QR_STEPS_HINT", raising=False)
+    emu = _Emu(torch, ctxs)
+    for c in ctxs:
+        c.reset_scores()
+        assert c.tree_batch_supported(nleaves)
+    stats = []
+    for it in range(6):
+        single.compute_lambdas("NDCG", 10)
+        want = single.fit_tree(nleaves, minls, True)
+        single.update_scores(0.1)
+        for c in ctxs:
+            c.compute_lambdas("NDCG", 10)
+        emu.allreduce("scal")
+        for c in ctxs:
+            c.lambda_finish()
+        got = _doc_fit_batched(emu, ctxs, nleaves, minls, True, stats)
+        for c in ctxs:
+            c.update_scores(0.1)
+        for g in got:
+            assert len(g) == len(want), it
+            for k in ("feature", "thr_id", "left", "right", "nsamples", "threshold"):
+                assert np.array_equal(g[k], want[k]), (it, k)
+            assert np.allclose(g["value"], want["value"], rtol=1e-11, atol=1e-14), it
+            assert np.allclose(g["deviance"], want["deviance"], rtol=1e-9, atol=1e-12), it
+        for g in got[1:]:                      # every rank: the same bits
+            for k in want.dtype.names:
+                assert np.array_equal(g[k], got[0][k]), (it, k)
+        m1 = single.metric_last()
+        for c in ctxs:
+            assert c.metric_last() == pytest.approx(m1, rel=1e-12)
+    # exchanges per tree: root + steps (+ what a wrong guess adds), never more than nleaves
+    for ex, used, misses in stats:
+        assert ex <= nleaves, stats
+    if force is not None and nleaves > 3:
+        assert any(m > 0 for _, _, m in stats), stats      # the carried-on path has run
+    if force is None and nleaves >= 10:
+        assert min(ex for ex, _, _ in stats[1:]) < nleaves - 1, stats   # fewer exchanges than one per split
+    s1 = single.get_scores()
+    for c, (q0, q1) in zip(ctxs, parts):
+        d0, d1 = int(qoff[q0]), int(qoff[q1])
+        assert np.allclose(c.get_scores(), s1[d0:d1], rtol=1e-10, atol=1e-13)
+        c.close()
+    single.close()
+
+
+def test_doc_sharded_batched_equals_one_split_protocol():
+    """the two document-sharded protocols grow the same trees (structure bit for bit; the f64 sums
+    of a directly built child come from the partition's slices in one and from the histogram
+    workgroups in the other: rounding)"""
+    import torch
+    import quickrank_amd as qr
+    from quickrank_amd import build
+    build.build()
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=50, F=70, seed=41, adversarial=True)
+    parts = _split_queries(qoff, [11, 37])
+    a, _, _ = _make_ctxs(qr, x, labels, qoff, parts, 255)
+    b, _, _ = _make_ctxs(qr, x, labels, qoff, parts, 255)
+    ea, eb = _Emu(torch, a), _Emu(torch, b)
+    for c in a + b:
+        c.reset_scores()
+    for it in range(5):
+        for emu, ctxs in ((ea, a), (eb, b)):
+            for c in ctxs:
+                c.compute_lambdas("NDCG", 10)
+            emu.allreduce("scal")
+            for c in ctxs:
+                c.lambda_finish()
+        ta = _doc_fit(ea, a, 12, 2, True)
+        tb = _doc_fit_batched(eb, b, 12, 2, True)
+        for c in a + b:
+            c.update_scores(0.1)
+        for k in ("feature", "thr_id", "left", "right", "nsamples", "threshold"):
+            assert np.array_equal(ta[0][k], tb[0][k]), (it, k)
+        assert np.allclose(ta[0]["value"], tb[0]["value"], rtol=1e-11, atol=1e-14), it
+    for ca, cb in zip(a, b):
+        assert np.allclose(ca.get_scores(), cb.get_scores(), rtol=1e-10, atol=1e-13)
+        ca.close()
+        cb.close()

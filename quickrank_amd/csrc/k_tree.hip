@@ -3253,6 +3253,9 @@ __global__ __launch_bounds__(1024) void k_leaf_global(QrTreeState *__restrict__ 
                                                       const int stride,
                                                       QrNodesOut *__restrict__ nodes_out,
                                                       const long long seq) {
+  // (batched growth whose enqueued steps did not suffice: the host carries the tree on and
+  // enqueues the leaf kernels again, as on one GPU)
+  if (ts->incomplete) return;
   const int nl = ts->nleaves;
   for (int l = threadIdx.x; l < nl; l += 1024) {
     double s1 = 0.0, s2 = 0.0;

@@ -303,7 +303,9 @@ int qr_ctx_set_doc_shard(qr_ctx *c, int rank, int world, uint64_t n_global,
 }
 
 int qr_synchronize(qr_ctx *c) {
-  { const int src_ = tree_settle(c); if (src_) return src_; }
+  // (a document-sharded tree that waits for qr_tree_batch_settle: what is enqueued drains, the
+  // tree is carried on by the caller, with its all-reduces)
+  if (!c->dbatch_pending) { const int src_ = tree_settle(c); if (src_) return src_; }
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   return QR_OK;
 }
@@ -1331,6 +1333,21 @@ static int tree_settle(qr_ctx *c) {
   return qr_k_prep_flush(c);
 }
 static int tree_settle_keep(qr_ctx *c) {
+  if (c->dbatch_pending) {
+    // a document-sharded tree ended behind a guessed number of steps: carrying it on takes
+    // all-reduces, which only the caller can enqueue (qr_tree_batch_settle)
+    int64_t w = 0;
+    const int rc = wait_early(c, &w);
+    if (rc) return rc;
+    if (w & 1)
+      QR_FAIL(c, QR_ERR_STATE, "the last tree's enqueued steps did not suffice: qr_tree_batch_settle and the "
+                               "steps it asks for come first (include/qr_hip.h)");
+    c->dbatch_pending = c->dbatch_unsettled = false;
+    ++c->spec_trees;
+    c->steps_hint = (size_t)((w >> 1) & 0x7fff) + c->steps_plus;
+    if (c->steps_hint < 1) c->steps_hint = 1;
+    c->spec_scores_enqueued = false;
+  }
   if (!c->spec_pending) return QR_OK;
   // (the last control call's word, QrPinned::early -- not the records: the leaf kernels and the
   // score update behind that call are still running, and whatever the caller enqueues next
@@ -1385,7 +1402,11 @@ int qr_tree_end(qr_ctx *c, int newton, qr_node_t *nodes_out, size_t *nnodes_out)
   int rc = qr_k_tree_finish(c, newton);
   if (rc) return rc;
   c->tree_open = false;
-  if (c->dmode) return QR_OK;  // all-reduce the leaf buffer, then qr_tree_leaves_finish
+  if (c->dmode) {
+    // (batched growth ended before its last control call was looked at: settled later)
+    if (c->dbatch && c->dbatch_unsettled) c->dbatch_pending = true;
+    return QR_OK;  // all-reduce the leaf buffer, then qr_tree_leaves_finish
+  }
   c->tree_valid = true;
   if ((rc = snapshot_nodes(c))) return rc;
   if (nodes_out || nnodes_out) return qr_tree_nodes(c, nodes_out, nnodes_out);
@@ -1398,6 +1419,11 @@ int qr_tree_leaves_finish(qr_ctx *c, int newton, qr_node_t *nodes_out, size_t *n
     QR_FAIL(c, QR_ERR_STATE, "qr_tree_leaves_finish follows qr_tree_end on a document-sharded context");
   int rc = qr_k_tree_leaves_global(c, newton);
   if (rc) return rc;
+  if (c->dbatch_redo) {  // a carried-on tree: the score update enqueued behind its first end left at once
+    c->dbatch_redo = false;
+    if (c->spec_scores_enqueued && (rc = qr_k_scores_update(c, c->spec_shrinkage))) return rc;
+    c->spec_scores_enqueued = false;
+  }
   c->tree_valid = true;
   if ((rc = snapshot_nodes(c))) return rc;
   if (nodes_out || nnodes_out) return qr_tree_nodes(c, nodes_out, nnodes_out);
@@ -1511,6 +1537,7 @@ int qr_tree_batch_begin(qr_ctx *c, size_t nleaves, uint64_t minls, size_t *steps
   c->tree_open = true;
   c->tree_valid = false;
   c->dbatch = true;
+  c->dbatch_unsettled = c->dbatch_pending = c->dbatch_redo = false;
   // the guess: as many steps as the last tree needed (+ QR_STEPS_PLUS); every rank grows the
   // same trees, so every rank guesses the same number
   size_t steps = nleaves - 1;
@@ -1535,6 +1562,7 @@ int qr_tree_batch_apply(qr_ctx *c) {
 
 int qr_tree_batch_decide(qr_ctx *c, int last) {
   if (!c || !c->tree_open || !c->dbatch) return QR_ERR_STATE;
+  if (last) c->dbatch_unsettled = true;
   return qr_k_dbatch_decide(c, c->cur_nleaves, c->cur_minls, last ? 1 : 0);
 }
 
@@ -1548,10 +1576,15 @@ int qr_tree_batch_exchange(qr_ctx *c, void **cells, size_t *cells_i64) {
 
 int qr_tree_batch_settle(qr_ctx *c, int *incomplete, size_t *steps_used) {
   if (!c || !incomplete) return QR_ERR_ARG;
-  if (!c->tree_open || !c->dbatch) QR_FAIL(c, QR_ERR_STATE, "qr_tree_batch_settle follows qr_tree_batch_decide(last = 1)");
+  if (!c->dbatch || !c->dbatch_unsettled) {  // nothing to look at: the last tree is settled
+    *incomplete = 0;
+    if (steps_used) *steps_used = 0;
+    return QR_OK;
+  }
   int64_t w = 0;
   const int rc = wait_early(c, &w);
   if (rc) return rc;
+  c->dbatch_unsettled = false;
   *incomplete = (int)(w & 1);
   const size_t used = (size_t)((w >> 1) & 0x7fff);
   if (steps_used) *steps_used = used;
@@ -1559,8 +1592,19 @@ int qr_tree_batch_settle(qr_ctx *c, int *incomplete, size_t *steps_used) {
     ++c->spec_trees;
     c->steps_hint = used + c->steps_plus;
     if (c->steps_hint < 1) c->steps_hint = 1;
+    if (c->dbatch_pending) c->spec_scores_enqueued = false;  // (the tree was whole: so is its score update)
+    c->dbatch_pending = false;
   } else {
     ++c->spec_misses;
+    if (c->dbatch_pending) {
+      // the tree was ended behind the guess: its leaf kernels and score update left at once.
+      // Open again; the caller carries it on and ends it again (qr_tree_end -> all-reduce ->
+      // qr_tree_leaves_finish, which repeats the score update if one was enqueued)
+      c->dbatch_pending = false;
+      c->dbatch_redo = true;
+      c->tree_open = true;
+      c->tree_valid = false;
+    }
   }
   return QR_OK;
 }
@@ -1639,7 +1683,7 @@ int qr_obl_exchange_buffers(qr_ctx *c, void **recs_local, void **recs_all, size_
 int qr_scores_update(qr_ctx *c, double shrinkage) {
   if (!c) return QR_ERR_ARG;
   if (!c->tree_valid) QR_FAIL(c, QR_ERR_STATE, "no fitted tree");
-  if (c->spec_pending) {  // (if the tree turns out incomplete, tree_settle repeats this update)
+  if (c->spec_pending || c->dbatch_pending) {  // (if the tree turns out incomplete, settling it repeats this update)
     c->spec_scores_enqueued = true;
     c->spec_shrinkage = shrinkage;
   }

@@ -288,6 +288,10 @@ struct qr_ctx {
   long long *d_xb = nullptr;
   size_t xb_len = 0;
   bool dbatch = false;            // the open tree grows by qr_tree_batch_* (document-sharded)
+  // ... its last control call (qr_tree_batch_decide(last = 1)) has not been looked at yet; the tree
+  // was ended like that (leaf kernels and score update enqueued behind a guess: they leave at once
+  // if it was too low); a carried-on tree repeats the score update behind its leaf values
+  bool dbatch_unsettled = false, dbatch_pending = false, dbatch_redo = false;
   size_t xleaf_cap = 0;
   int ncu = 256;
   // LDS the device really has (hipDeviceProp_t): a workgroup's opt-in maximum and a CU's total.  The

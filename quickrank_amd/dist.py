@@ -283,11 +283,13 @@ class DocShardedTrainer:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def compute_lambdas(self, metric="NDCG", cutoff=10):
+        self.settle()
         self.ctx.compute_lambdas(metric, cutoff)
         self._sum(self.scal, "scal")
         self.ctx.lambda_finish()
 
     def compute_residuals(self):
+        self.settle()
         self.ctx.compute_residuals()
         self._sum(self.scal, "scal")
         self.ctx.lambda_finish()
@@ -296,6 +298,7 @@ class DocShardedTrainer:
         """`batched` (default: whenever the context can, QR_DOC_BATCH=0 turns it off): up to two
         splits per exchange -- 1 + steps histogram all-reduces per tree instead of nleaves."""
         ctx = self.ctx
+        self.settle()
         if batched is None:
             import os
             batched = os.environ.get("QR_DOC_BATCH", "1") != "0"
@@ -329,11 +332,45 @@ class DocShardedTrainer:
         self._sum(self.leaf, "leaf")
         return ctx.tree_leaves_finish(nleaves, newton, read=read)
 
+    def _batch_steps(self, k):
+        ctx = self.ctx
+        for s in range(k):
+            ctx.tree_batch_apply()
+            self._sum(self.batch, "batch")
+            ctx.tree_batch_decide(s == k - 1)
+        self.collectives += k
+
+    def _carry_on(self, nleaves, done):
+        """the enqueued steps did not suffice (the last control step said so): more of them, in
+        doubling pieces, looking at the last one of each"""
+        piece = 1
+        while True:
+            k = max(1, min(piece, nleaves - 1 - done))
+            self._batch_steps(k)
+            done += k
+            piece *= 2
+            if not self.ctx.tree_batch_settle()[0]:
+                return
+
+    def settle(self):
+        """A tree enqueued with read=False ends behind a GUESSED number of steps, with its leaf
+        kernels and score update already in the queue (they leave at once on an incomplete tree).
+        Whatever consumes the tree or the scores next looks at the tree's last control step here
+        and, if the guess was too low, carries the tree on and ends it again.  Every rank grows
+        the same trees, so every rank takes the same path."""
+        p, self._pending = getattr(self, "_pending", None), None
+        if p is None:
+            return
+        nleaves, newton, done = p
+        if self.ctx.tree_batch_settle()[0]:
+            self._carry_on(nleaves, done)
+            self._leaf_exchange(nleaves, newton, read=False)   # (repeats the score update if one was enqueued)
+
     def _fit_tree_batched(self, nleaves, minls, newton, read):
         """RegressionTree::fit (rt.cc:58-90) with up to two splits per exchange: the one-GPU
         batched growth (qr_tree_fit) cut at the all-reduces.  The number of steps enqueued is a
-        guess (the previous tree's); the last control step tells whether it sufficed -- one host
-        wait per tree, where the one-split protocol has none but nleaves all-reduces."""
+        guess (the previous tree's); the last control step tells whether it sufficed.  read=False
+        does not wait for it: see settle()."""
         ctx = self.ctx
         steps = ctx.tree_batch_begin(nleaves, minls)
         self._sum(self.hist, "hist")
@@ -343,30 +380,19 @@ class DocShardedTrainer:
             self._ptr["batch"] = (ptr, n)
             self.batch = self._view(ptr, n, "batch")
         self.collectives = 1
-
-        def run(k):
-            for s in range(k):
-                ctx.tree_batch_apply()
-                self._sum(self.batch, "batch")
-                ctx.tree_batch_decide(s == k - 1)
-            self.collectives += k
-
-        run(steps)
-        done, piece = steps, 1
-        while True:
-            incomplete, _ = ctx.tree_batch_settle()
-            if not incomplete:
-                break
-            k = max(1, min(piece, nleaves - 1 - done))
-            run(k)
-            done += k
-            piece *= 2
+        self._batch_steps(steps)
+        if read:
+            if ctx.tree_batch_settle()[0]:
+                self._carry_on(nleaves, steps)
+        else:
+            self._pending = (nleaves, newton, steps)
         return self._leaf_exchange(nleaves, newton, read)
 
     def fit_oblivious(self, depth, minls, newton, read=True):
         """ObliviousRT::fit (ot.cc:32-201) over document shards: ONE int64 all-reduce per
         level -- the cells of all its directly built children -- after the root's."""
         ctx = self.ctx
+        self.settle()
         ctx.obl_begin(depth, minls)
         self._sum(self.hist, "hist")
         for level in range(depth):
@@ -390,6 +416,7 @@ class DocShardedTrainer:
         training (0) or validation (1) set: every rank evaluates its own queries on
         the device; the per-rank (sum, count) pairs are all-gathered and added in
         rank order."""
+        self.settle()
         local = self.ctx.metric_eval(which, metric, cutoff)
         nq = self.ctx.Q if which == 0 else self.ctx.vQ
         if self.dist is None:   # injected transport: the per-rank pairs through its host-side gather

@@ -180,9 +180,10 @@ def test_feature_sharded_drivers_through_lockstep_transport(world, oracle_lib):
         c.close()
 
 
-@pytest.mark.parametrize("world,cuts", [(2, [30]), (3, [5, 41])])
-def test_document_sharded_drivers_through_lockstep_transport(world, cuts):
+@pytest.mark.parametrize("world,cuts,batched", [(2, [30], True), (3, [5, 41], True), (2, [30], False), (3, [5, 41], False)])
+def test_document_sharded_drivers_through_lockstep_transport(world, cuts, batched, monkeypatch):
     import torch
+    monkeypatch.setenv("QR_DOC_BATCH", "1" if batched else "0")
     import quickrank_amd as qr
     from quickrank_amd.dist import DocShardedTrainer
     from test_gpu_docshard import _make_ctxs, _split_queries
@@ -229,12 +230,95 @@ def test_document_sharded_drivers_through_lockstep_transport(world, cuts):
     hist = ("all_reduce_sum", "<i8", b["hist_n"])
     leaf = ("all_reduce_sum", "<i8", b["leaf_n"])
     marks = res[0][1]
-    # a leaf-wise iteration: scalars, one histogram per node (root + 7 splits), leaves
-    assert hub.calls[0][:marks[0]] == [scal] + [hist] * 8 + [leaf]
+    if batched:
+        # a leaf-wise iteration, two splits per exchange: scalars, the root's histogram, one buffer of
+        # batch cells per step, leaves.  The first tree of a context enqueues the worst case (one
+        # split per step), the second as many steps as the first turned out to need (+ what a low
+        # guess adds): never more exchanges than the one-split protocol
+        p, n = ctxs[0].tree_batch_exchange()
+        cells = ("all_reduce_sum", "<i8", n)
+        assert hub.calls[0][:marks[0]] == [scal, hist] + [cells] * 7 + [leaf]
+        second = hub.calls[0][marks[0]:marks[1]]
+        assert second[:2] == [scal, hist] and second[-1] == leaf and all(c == cells for c in second[2:-1])
+        assert 4 <= len(second) - 3 <= 7, second
+    else:
+        # a leaf-wise iteration: scalars, one histogram per node (root + 7 splits), leaves
+        assert hub.calls[0][:marks[0]] == [scal] + [hist] * 8 + [leaf]
     # the oblivious one: scalars, root, one LEVEL buffer per level but the last (ot.cc:127), leaves
     obl = hub.calls[0][marks[1]:marks[2]]
     assert obl[0] == scal and obl[1] == hist and len(obl) == 2 + 2 + 1
     assert all(c[0] == "all_reduce_sum" and c[1] == "<i8" for c in obl)
     assert hub.calls[0][marks[2]:] == [("all_gather_host", "obj", 0)]
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.parametrize("world,cuts,hint", [(2, [30], "1"), (3, [5, 41], "2"), (2, [30], None)])
+def test_document_sharded_lazy_trees_through_lockstep_transport(world, cuts, hint, monkeypatch):
+    """fit_tree(read=False) on document shards ends a tree behind a GUESSED number of steps, leaf
+    kernels and score update enqueued at once; the next call of the trainer looks at the tree's last
+    control step and carries the tree on if the guess was too low (QR_STEPS_HINT forces that for
+    every tree here).  The trees read afterwards, the scores and the metric are the single
+    context's; all ranks make the same calls."""
+    import torch
+    import quickrank_amd as qr
+    from quickrank_amd.dist import DocShardedTrainer
+    from test_gpu_docshard import _make_ctxs, _split_queries
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=50, F=40, seed=43, adversarial=True)
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    single.build_bins(255)
+    single.reset_scores()
+    want, want_ndcg = [], []
+    for it in range(5):
+        single.compute_lambdas("NDCG", 10)
+        want.append(single.fit_tree(10, 2, True))
+        single.update_scores(0.1)
+        want_ndcg.append(single.metric_last())
+    want_final = single.metric_eval(0, "NDCG", 10)
+    s1 = single.get_scores()
+    single.close()
+    parts = _split_queries(qoff, cuts)
+    if hint is not None:
+        monkeypatch.setenv("QR_STEPS_HINT", hint)
+    ctxs, _, _ = _make_ctxs(qr, x, labels, qoff, parts, 255)
+    monkeypatch.delenv("QR_STEPS_HINT", raising=False)
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    for c, s in zip(ctxs, streams):
+        c.set_stream(s.cuda_stream)
+        c.reset_scores()
+    hub = Hub(torch, world)
+
+    def body(r):
+        torch.cuda.set_device(0)
+        ctx = ctxs[r]
+        tr = DocShardedTrainer(ctx, transport=LockstepTransport(hub, r, ctx))
+        trees, ndcg = [], []
+        for it in range(5):
+            tr.compute_lambdas("NDCG", 10)           # (settles tree it - 1)
+            if it:
+                trees.append(ctx.tree_nodes())
+            assert tr.fit_tree(10, 2, True, read=False) is None
+            ctx.update_scores(0.1)
+            ndcg.append(ctx.metric_last())
+        final = tr.metric_eval(0, "NDCG", 10)         # (settles the last tree)
+        trees.append(ctx.tree_nodes())
+        return trees, ndcg, final, ctx.get_scores(), ctx.spec_stats() if hasattr(ctx, "spec_stats") else None
+    res = _run_ranks(world, body)
+    assert all(c == hub.calls[0] for c in hub.calls)
+    for (trees, ndcg, final, scores, _), (q0, q1) in zip(res, parts):
+        for t, wt in zip(trees, want):
+            _equal_trees(t, wt, values=False)
+            assert np.allclose(t["value"], wt["value"], rtol=1e-9, atol=1e-12, equal_nan=True)
+        assert np.allclose(ndcg, want_ndcg, rtol=1e-12)
+        assert abs(final - want_final) < 1e-12
+        d0, d1 = int(qoff[q0]), int(qoff[q1])
+        assert np.allclose(scores, s1[d0:d1], rtol=1e-10, atol=1e-13)
+    if hint is not None:
+        # every tree needs more than `hint` steps: the carried-on path ran, and its second leaf
+        # exchange shows in the call sequence (two per tree)
+        b = ctxs[0].doc_exchange_buffers()
+        leaf = ("all_reduce_sum", "<i8", b["leaf_n"])
+        assert sum(1 for c in hub.calls[0] if c == leaf) == 10
     for c in ctxs:
         c.close()

@@ -796,8 +796,11 @@ def main():
         r = mk("docs", x[a:b], labels[a:b], qoff[q0:q1 + 1] - qoff[q0], N, Q)
         r.timed(args.steps, args.warmup)
         runs["document_sharded"] = (r.summary(same_set + f" ({b - a} docs on rank {rank}), " + desc,
-                                              f"document sharding x{world}: one int64 all-reduce per node "
-                                              "histogram (12 per iteration)"), r.trees_identical_across_ranks())
+                                              f"document sharding x{world}: one int64 all-reduce per growth step of up "
+                                              "to two splits (scalars + root + steps + leaves: "
+                                              f"{2 + getattr(r.trainer, 'collectives', args.nleaves)} for the last tree; "
+                                              f"{2 + args.nleaves} with one split per exchange, QR_DOC_BATCH=0)"),
+                                    r.trees_identical_across_ranks())
         r.close()
         r = mk("features", x, labels, qoff, N, Q)
         r.timed(args.steps, args.warmup)

@@ -272,6 +272,8 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
     else
       QRM(c, qr_doc_exchange_buffers(c, &x_hist, &n_hist, &x_scal, &n_scal, nullptr, nullptr));
     auto sum64 = [&](void *p, size_t n) { NCCL(ncclAllReduce(p, p, n, ncclInt64, ncclSum, comm, stream)); };
+    // (QR_DOC_BATCH=0: one split per exchange, the protocol of rounds 1-3)
+    const bool doc_batch = !(getenv("QR_DOC_BATCH") && atoi(getenv("QR_DOC_BATCH")) == 0);
     sh.bar.wait();
     if (r == 0) {
       auto t_init1 = std::chrono::high_resolution_clock::now();
@@ -396,6 +398,39 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
         }
         QRM(c, qr_tree_decide(c));
         QRM(c, qr_tree_end(c, lambda, nodes.data(), &nn));
+      } else if (doc_batch && qr_tree_batch_supported(c, nleaves_)) {
+        // rt.cc:58-90 with up to two splits per exchange (include/qr_hip.h, qr_tree_batch_*): the
+        // root's histogram, then one buffer of batch cells per step.  The number of steps is a
+        // guess (the last tree's); the last control step says whether it sufficed -- the same
+        // on every rank, which grow the same trees.
+        size_t steps = 0;
+        QRM(c, qr_tree_batch_begin(c, nleaves_, minleafsupport_, &steps));
+        sum64(x_hist, n_hist);
+        QRM(c, qr_tree_batch_root(c));
+        void *x_batch = nullptr;
+        size_t n_batch = 0;
+        QRM(c, qr_tree_batch_exchange(c, &x_batch, &n_batch));
+        auto run = [&](size_t k) {
+          for (size_t s = 0; s < k; ++s) {
+            QRM(c, qr_tree_batch_apply(c));
+            sum64(x_batch, n_batch);
+            QRM(c, qr_tree_batch_decide(c, s + 1 == k ? 1 : 0));
+          }
+        };
+        run(steps);
+        int incomplete = 0;
+        QRM(c, qr_tree_batch_settle(c, &incomplete, nullptr));
+        for (size_t done = steps, piece = 1; incomplete; piece *= 2) {
+          const size_t left = nleaves_ - 1 > done ? nleaves_ - 1 - done : 1;
+          const size_t k = std::min(piece, left);
+          run(k);
+          done += k;
+          QRM(c, qr_tree_batch_settle(c, &incomplete, nullptr));
+        }
+        QRM(c, qr_tree_end(c, lambda, nullptr, nullptr));
+        QRM(c, qr_doc_exchange_buffers(c, nullptr, nullptr, nullptr, nullptr, &x_leaf, &n_leaf));
+        sum64(x_leaf, n_leaf);
+        QRM(c, qr_tree_leaves_finish(c, lambda, nodes.data(), &nn));
       } else {
         QRM(c, qr_tree_begin(c, nleaves_, minleafsupport_));
         sum64(x_hist, n_hist);

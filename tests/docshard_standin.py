@@ -49,7 +49,7 @@ class DocStandinContext:
                     leaf=0, leaf_n=len(self.leaf))
 
     def host_buffers(self):
-        return dict(hist=self.hist, scal=self.scal, leaf=self.leaf)
+        return dict(hist=self.hist, scal=self.scal, leaf=self.leaf, batch=getattr(self, "batch", None))
 
     # -- pseudo-responses --------------------------------------------------------
     def compute_lambdas(self, metric="NDCG", cutoff=10):
@@ -174,6 +174,146 @@ class DocStandinContext:
         l = self.lam[d["small_ids"]]
         self._local_hist(d["small_ids"], (float(np.sum(l * l)), float(np.sum(l))))
 
+    # -- leaf-wise growth with up to two splits per exchange (include/qr_hip.h, qr_tree_batch_*) ---
+    # A restatement of the device's control step (k_tree.hip batch_logic): rt.cc:58-90's loop, plus
+    # the split of the most promising OTHER heap entry applied ahead of its turn -- its children
+    # wait aside until the loop pops their parent and then take the ids the sequential order
+    # assigns.  Exchange: [job][feature][slot][sum, count] per-slot cells of each job's directly
+    # built child over the rank's own documents + [job][2 * world] f64 bits.
+    BATCH = 2
+
+    def tree_batch_supported(self, nleaves):
+        return nleaves >= 2
+
+    def tree_batch_exchange(self):
+        return 0, len(self.batch)
+
+    def tree_batch_begin(self, nleaves, minls):
+        self.tree_begin(nleaves, minls)
+        n = self.BATCH * self.F * self.cap * 2 + self.BATCH * 2 * self.world
+        if getattr(self, "batch", None) is None or len(self.batch) != n:
+            self.batch = np.zeros(n, np.int64)
+        self.jobs, self.real_steps, self.incomplete = [], 0, False
+        hint = getattr(self, "steps_force", None) or getattr(self, "steps_hint", 0)
+        return max(1, min(nleaves - 1, hint) if hint else nleaves - 1)
+
+    def _commit(self, i, L=None, R=None):
+        """the split of node i becomes part of the tree; its children take the next two ids"""
+        nd = self.nodes[i]
+        _, f, t, _, _ = nd["best"]
+        nd["feature"], nd["thr_id"] = f, t
+        nd["left"], nd["right"] = len(self.nodes), len(self.nodes) + 1
+        self.nodes += [L, R]
+
+    def _next_batch(self, root_mode):
+        jobs = []
+        if root_mode:
+            if self._splittable(self.nodes[0]):
+                self._commit(0)
+                jobs.append((0, True))
+            else:
+                self.done = True
+        elif not self.done:
+            found = False
+            while len(self.heap) > 0 and self.taken + len(self.heap) < self.nleaves:
+                i = self.heap.pop()
+                nd = self.nodes[i]
+                if not self._splittable(nd):
+                    self.taken += 1
+                    continue
+                if nd.get("pre") is not None:        # applied ahead of its turn: the children take their ids
+                    L, R = nd.pop("pre")
+                    self._commit(i, L, R)
+                    self.heap.push(L["dev"], nd["left"])
+                    self.heap.push(R["dev"], nd["right"])
+                    continue
+                self._commit(i)
+                jobs.append((i, True))
+                found = True
+                break
+            if not found:
+                self.done = True
+        if len(jobs) == 1:
+            while len(jobs) < self.BATCH:
+                if self.nleaves - (self.taken + len(self.heap) + 2) < len(jobs):
+                    break                              # the leaf budget cannot reach another candidate
+                pick, key = -1, 0.0
+                for k, v in self.heap.a[1:]:           # the largest deviance left, first in heap order
+                    cand = self.nodes[v]
+                    if cand.get("pre") is not None or not self._splittable(cand):
+                        continue
+                    if pick < 0 or k > key:
+                        pick, key = v, k
+                if pick < 0:
+                    break
+                jobs.append((pick, False))
+        self.jobs = jobs
+        if jobs:
+            self.real_steps += 1
+
+    def tree_batch_root(self):
+        s, c, _, _ = self._global_hist()
+        root = self._node(np.arange(self.N), self.Ng, self.root_sum, self.root_ss, (s, c))
+        root["best"] = self._best(s, c)
+        self.nodes = [root]
+        self.step = 1
+        self._next_batch(True)
+
+    def tree_batch_apply(self):
+        cells = self.batch[:self.BATCH * self.F * self.cap * 2].reshape(self.BATCH, self.F, self.cap, 2)
+        tails = self.batch[self.BATCH * self.F * self.cap * 2:].reshape(self.BATCH, 2 * self.world)
+        self.applied = []
+        for j, (i, in_turn) in enumerate(self.jobs):      # (a job that does not exist: stale cells, ignored)
+            nd = self.nodes[i]
+            _, f, t, lc, rc = nd["best"]
+            ids = nd["ids"]
+            go = self.stmap[f, ids] <= t
+            lids, rids = ids[go], ids[~go]
+            small_is_left = lc <= rc
+            sids, bids = (lids, rids) if small_is_left else (rids, lids)
+            cells[j] = 0
+            for ff in range(self.F):
+                b = self.stmap[ff, sids]
+                np.add.at(cells[j, ff, :, 0], b, self.q[sids])
+                np.add.at(cells[j, ff, :, 1], b, 1)
+            l = self.lam[sids]
+            tails[j] = 0
+            tails[j, 2 * self.rank] = _bits(float(np.sum(l * l)))
+            tails[j, 2 * self.rank + 1] = _bits(float(np.sum(l)))
+            self.applied.append(dict(node=i, in_turn=in_turn, small_is_left=small_is_left,
+                                     small_n=min(lc, rc), small_ids=sids, big_ids=bids))
+
+    def tree_batch_decide(self, last):
+        cells = self.batch[:self.BATCH * self.F * self.cap * 2].reshape(self.BATCH, self.F, self.cap, 2)
+        tails = self.batch[self.BATCH * self.F * self.cap * 2:].view(np.float64).reshape(self.BATCH, self.world, 2)
+        for j, d in enumerate(self.applied):
+            s = np.cumsum(cells[j, :, :, 0], axis=1)
+            c = np.cumsum(cells[j, :, :, 1], axis=1).astype(np.uint64)
+            ss_small = sum(float(a) for a in tails[j, :, 0])     # rank order
+            sum_small = sum(float(a) for a in tails[j, :, 1])
+            P = self.nodes[d["node"]]
+            ps, pc = P["hist"]
+            bs, bc = ps - s, pc - c
+            small = self._node(d["small_ids"], d["small_n"], sum_small, ss_small, (s, c))
+            big = self._node(d["big_ids"], P["n"] - d["small_n"], P["sum"] - sum_small, P["ss"] - ss_small, (bs, bc))
+            small["best"], big["best"] = self._best(s, c), self._best(bs, bc)
+            L, R = (small, big) if d["small_is_left"] else (big, small)
+            if d["in_turn"]:
+                self.nodes[P["left"]], self.nodes[P["right"]] = L, R
+                self.heap.push(L["dev"], P["left"])          # rt.cc:76-77
+                self.heap.push(R["dev"], P["right"])
+            else:
+                P["pre"] = (L, R)
+        self.applied = []
+        self.step += 1
+        self._next_batch(False)
+        self.incomplete = bool(last) and len(self.jobs) > 0
+
+    def tree_batch_settle(self):
+        if not self.incomplete:
+            self.steps_hint = max(1, self.real_steps)
+        return self.incomplete, self.real_steps
+
     # -- level-wise (oblivious) growth, ot.cc:32-201 over document shards -----------------
     # One int64 all-reduce per level: the per-slot (sum, count) of every directly built
     # child of the level over the rank's own documents (qr_obl_level_exchange).
@@ -187,7 +327,8 @@ class DocStandinContext:
         self._local_hist(np.arange(self.N), (0.0, 0.0))
 
     def host_buffers(self):
-        return dict(hist=self.hist, scal=self.scal, leaf=self.leaf, level=getattr(self, "level_buf", None))
+        return dict(hist=self.hist, scal=self.scal, leaf=self.leaf, level=getattr(self, "level_buf", None),
+                    batch=getattr(self, "batch", None))
 
     def obl_level_exchange(self, level):
         return 0, len(self.level_buf)
@@ -273,6 +414,11 @@ class DocStandinContext:
         self.level_buf = buf.ravel()
 
     def tree_end_local(self, newton=True):
+        if getattr(self, "incomplete", False):
+            # ended behind a guess that was too low (a tree read lazily): the device's leaf kernels and
+            # score update leave at once; the caller settles, carries the tree on and ends it again
+            self.redo = True
+            return
         while self.nodes and self.nodes[-1] is None:         # (level-wise growth reserves a level ahead)
             self.nodes.pop()
         self.leaves = []
@@ -292,6 +438,17 @@ class DocStandinContext:
             self.leaf[base + 2 * l + 1] = _bits(float(np.sum(self.w[ids])) if newton else 0.0)
 
     def tree_leaves_finish(self, nleaves, newton=True, read=True):
+        if getattr(self, "incomplete", False):
+            return None
+        out = self.last_tree = self._leaves_finish(nleaves, newton)
+        if getattr(self, "redo", False):                  # a carried-on tree repeats the score update
+            self.redo = False
+            if getattr(self, "pending_shrinkage", None) is not None:
+                self.update_scores(self.pending_shrinkage)
+        self.pending_shrinkage = None
+        return out
+
+    def _leaves_finish(self, nleaves, newton=True):
         v = self.leaf.view(np.float64).reshape(self.world, nleaves, 2)
         out = np.zeros(len(self.nodes), NODE_DTYPE)
         for i, nd in enumerate(self.nodes):
@@ -311,6 +468,9 @@ class DocStandinContext:
         return out
 
     def update_scores(self, shrinkage):
+        if getattr(self, "incomplete", False):
+            self.pending_shrinkage = shrinkage
+            return
         for i, val in self.leaf_value.items():
             ids = self.nodes[i]["ids"]
             self.scores[ids] = self.scores[ids] + shrinkage * val

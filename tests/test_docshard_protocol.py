@@ -15,12 +15,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _worker(rank, world, port, q, cuts, ntrees):
+def _worker(rank, world, port, q, cuts, ntrees, mode="batched"):
+    """mode: "one_split" (one histogram exchange per split), "batched" (up to two splits per
+    exchange, trees read at once) or "lazy" (batched, read=False, one step enqueued whatever the
+    tree: every tree is carried on when the trainer settles it)"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "2"
+    os.environ["QR_DOC_BATCH"] = "0" if mode == "one_split" else "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
     from datagen import make_dataset
@@ -37,10 +41,21 @@ def _worker(rank, world, port, q, cuts, ntrees):
     tr = DocShardedTrainer(ctx)
     scores = np.zeros(len(labels))
     ok = True
+    exchanges = []
+    if mode == "lazy":
+        ctx.steps_force = 1
     for it in range(ntrees):
         tr.compute_lambdas("NDCG", 10)
-        nodes = tr.fit_tree(8, 2, True)
-        ctx.update_scores(0.1)
+        if mode == "lazy":
+            assert tr.fit_tree(8, 2, True, read=False) is None
+            ctx.update_scores(0.1)            # (enqueued behind an incomplete tree: repeated when it is settled)
+            tr.settle()
+            nodes = ctx.last_tree
+        else:
+            nodes = tr.fit_tree(8, 2, True)
+            ctx.update_scores(0.1)
+        if mode != "one_split":
+            exchanges.append(tr.collectives)
         # unsharded oracle iteration on the same scores
         lam, w = oracle.lambdas(labels, scores, qoff)
         t = whole.fit_tree(lam, nleaves=8, minls=2)
@@ -56,6 +71,11 @@ def _worker(rank, world, port, q, cuts, ntrees):
         ref = mine.clone()
         dist.broadcast(ref, 0)
         ok = ok and torch.equal(mine, ref)
+    if mode == "batched":
+        # root + steps: the first tree enqueues the worst case, the next ones what the last needed
+        ok = ok and exchanges[0] == 8 and all(4 <= e <= 8 for e in exchanges[1:]) and min(exchanges) < 8
+    if mode == "lazy":
+        ok = ok and all(e > 2 for e in exchanges)      # one step was never enough for 8 leaves
     if rank == 0:
         q.put(bool(ok))
     dist.destroy_process_group()
@@ -135,14 +155,15 @@ def _leaf_of(tr, nodes):
         at[idx] = np.where(go, nd["left"][idx], nd["right"][idx])
 
 
-@pytest.mark.parametrize("world,cuts", [(2, [9]), (3, [3, 15])])
-def test_doc_sharded_training_equals_unsharded(world, cuts):
+@pytest.mark.parametrize("world,cuts,mode", [(2, [9], "batched"), (3, [3, 15], "batched"), (2, [9], "one_split"),
+                                             (3, [3, 15], "one_split"), (2, [9], "lazy"), (3, [3, 15], "lazy")])
+def test_doc_sharded_training_equals_unsharded(world, cuts, mode):
     import oracle
     oracle.build(ref=False)
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    port = 31500 + (os.getpid() + world * 11) % 2000
-    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, cuts, 3)) for r in range(world)]
+    port = 31500 + (os.getpid() + world * 11 + len(mode) * 101) % 2000
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, cuts, 4, mode)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -422,6 +422,8 @@ class Run:
     def flush(self):
         """The records of the last enqueued tree (every tree is read exactly once)."""
         if getattr(self, "tree_pending", False):
+            if self.trainer is not None:
+                self.trainer.settle()     # (a tree enqueued behind a guessed number of steps: carried on if needed)
             self.trees.append(self.ctx.tree_nodes())
             self.tree_pending = False
 

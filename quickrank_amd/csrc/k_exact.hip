@@ -25,12 +25,17 @@
 // over its predecessors' words until it meets an inclusive prefix, and publishes its own (decoupled
 // look-back; tiles are dispatched feature-fastest, so the tiles a walk meets are resident or done)
 // -- every CU works on every node, and a document's gradient is gathered once.
-// k_xflag (go-left bytes), k_xpart (F x tiles), k_xtotal (the children's gradient totals, which
-// the gain needs before the first candidate), k_xscan (F x tiles x 2), k_xbest (F x 2: first
-// maximum over a feature's tiles).
-// Per tree the lists move (1 + pi) N F entries through the scans and pi N F through the
-// partitions (pi = documents partitioned / N, ~3.7 on the stand-in): ~10 GB against the ~150 GB
-// of cells the slot-indexed path touches.
+// k_xflag (go-left bytes), k_xpart (F x tiles), k_xscan (F x tiles), k_xbest (F: first maximum over
+// a feature's tiles).
+// qr_tree_fit searches a node's split when the loop POPS it (qr_k_exact_fit; k_tree.hip k_xpop /
+// k_xapply), which is the reference's own order (rt.cc:58-90): the leaves a tree ends with are
+// never searched, and the children's gradient totals the gain needs come from the parent's search
+// (the winner's cumulative sum is the left child's).  Per tree the lists move pi N F entries
+// through the scans and pi N F through the partitions (pi = documents partitioned / N, ~3.7 on the
+// stand-in).  The phase API (qr_tree_begin / decide / apply; QR_X_EAGER=1) searches both children
+// behind every split: (1 + pi) N F entries and a pass for the totals (k_xtotal).
+// Measured on the MSLR-shaped stand-in (712,928 x 136, 67M slots): 22.4 ms per iteration on slot-
+// indexed histograms (round 3), 3.1-3.4 eager, 2.6 with the search at the pop.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -263,6 +268,7 @@ __global__ __launch_bounds__(256) void k_xtotal(const QrTreeState *__restrict__ 
 struct XTileBest {
   double score;
   uint32_t t, lc;
+  long long cs;   // the cumulative fixed-point sum at the candidate: the left child's total
 };
 
 __global__ __launch_bounds__(QR_XS_T) void k_xscan(
@@ -283,26 +289,34 @@ __global__ __launch_bounds__(QR_XS_T) void k_xscan(
   __shared__ double sh_price[QR_XS_W];
   __shared__ Best sh_b[QR_XS_W];
   __shared__ uint32_t sh_lc[QR_XS_W];
+  __shared__ long long sh_cs[QR_XS_W];
   static_assert(NWT <= 64 || NWT == 128, "the first wave scans one or two wave totals per lane");
   const int lf = blockIdx.x, which = blockIdx.z;
   const uint32_t tile = blockIdx.y;
   uint32_t begin = 0, n = rootn;
   const u64 *lst = xroot;
+  int tot_at = which;
   if (mode == 1) {
     const QrSplitDesc d = ts->desc;
     if (!d.active) return;
     begin = which == 0 ? d.begin : d.begin + d.lcount;
     n = which == 0 ? d.lcount : d.end - d.begin - d.lcount;
     lst = d.dst_buf == 0 ? x0 : x1;
+  } else if (mode == 2) {  // the node the loop has just popped (k_xpop); `tot` is indexed by node
+    tot_at = ts->xs_node;
+    if (tot_at < 0) return;
+    begin = ts->xs_begin;
+    n = ts->xs_n;
+    lst = x_lists(ts->xs_buf, xroot, x0, x1);
   }
   const uint32_t c0 = tile * QR_XS_CHUNK;
   if (c0 >= n) return;
   const u64 *src = lst + (size_t)lf * N + begin;
   const size_t row = (size_t)which * flocal + lf;
   u64 *mypub = pub + row * tiles * QR_X_PUBW;
-  const u64 minls = (mode == 0 && minls_root != ~0ull) ? minls_root : ts->minls;
+  const u64 minls = (mode != 1 && minls_root != ~0ull) ? minls_root : ts->minls;
   const double scale = scal->scale, inv_scale = scal->inv_scale;
-  const long long S = tot[which];
+  const long long S = tot[tot_at];
   const double s_d = (double)S * inv_scale;
   const uint32_t tsize = woff[lf + 1] - woff[lf];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -393,6 +407,7 @@ __global__ __launch_bounds__(QR_XS_T) void k_xscan(
   best.score = -1.0;
   best.t = 0xFFFFFFFFu;
   uint32_t best_lc = 0;
+  long long best_cs = 0;
 #pragma unroll
   for (uint32_t k = 0; k < QR_X_E; ++k) {
     if (price[k] >= 0.0 && price[k] >= prune) {
@@ -401,6 +416,7 @@ __global__ __launch_bounds__(QR_XS_T) void k_xscan(
       if (v.score > best.score) {  // ascending positions per thread: strict > keeps the first
         best = v;
         best_lc = lc;
+        best_cs = cs[k];
       }
     }
   }
@@ -409,28 +425,33 @@ __global__ __launch_bounds__(QR_XS_T) void k_xscan(
   const uint32_t tmin = wave_min_u32(best.score == m && best.t != 0xFFFFFFFFu ? best.t : 0xFFFFFFFFu);
   const unsigned long long holder = __ballot(best.score == m && best.t == tmin && tmin != 0xFFFFFFFFu);
   const uint32_t wlc = holder ? (uint32_t)__builtin_amdgcn_readlane((int)best_lc, __ffsll((long long)holder) - 1) : 0u;
+  const long long wcs = holder ? readlane_i64(best_cs, __ffsll((long long)holder) - 1) : 0ll;
   if (lane == 0) {
     Best w;
     w.score = tmin != 0xFFFFFFFFu ? m : -1.0;
     w.t = tmin;
     sh_b[wave] = w;
     sh_lc[wave] = wlc;
+    sh_cs[wave] = wcs;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     Best r = sh_b[0];
     uint32_t lc = sh_lc[0];
+    long long wc = sh_cs[0];
     for (int i = 1; i < (int)QR_XS_W; ++i) {
       const Best o = sh_b[i];
       if (o.score > r.score || (o.score == r.score && o.t < r.t)) {
         r = o;
         lc = sh_lc[i];
+        wc = sh_cs[i];
       }
     }
     XTileBest tb;
     tb.score = r.t == 0xFFFFFFFFu ? -1.0 : r.score;
     tb.t = r.t;
     tb.lc = lc;
+    tb.cs = wc;
     tbest[row * tiles + tile] = tb;
     if (tb.score > 0.0) atomicMax(gbest + row, (unsigned long long)__double_as_longlong(tb.score));
   }
@@ -441,13 +462,17 @@ __global__ __launch_bounds__(64) void k_xbest(const QrTreeState *__restrict__ ts
                                               const XTileBest *__restrict__ tbest, const uint32_t tiles,
                                               const uint32_t *__restrict__ woff, const int flocal,
                                               const int32_t *__restrict__ lf2gf, const float *__restrict__ thr,
-                                              qr_split_t *__restrict__ featrec, float *__restrict__ featthr) {
+                                              qr_split_t *__restrict__ featrec, float *__restrict__ featthr,
+                                              long long *__restrict__ xcs) {
   const int lf = blockIdx.x, which = blockIdx.y;
   uint32_t n = rootn;
   if (mode == 1) {
     const QrSplitDesc d = ts->desc;
     if (!d.active) return;
     n = which == 0 ? d.lcount : d.end - d.begin - d.lcount;
+  } else if (mode == 2) {
+    if (ts->xs_node < 0) return;
+    n = ts->xs_n;
   }
   const size_t row = (size_t)which * flocal + lf;
   const uint32_t used = (n + QR_XS_CHUNK - 1) / QR_XS_CHUNK;
@@ -455,12 +480,14 @@ __global__ __launch_bounds__(64) void k_xbest(const QrTreeState *__restrict__ ts
   b.score = -1.0;
   b.t = 0xFFFFFFFFu;
   uint32_t lc = 0;
+  long long wcs = 0;
   for (uint32_t i = threadIdx.x; i < used; i += 64) {  // ascending tiles per lane: strict > keeps the first
     const XTileBest v = tbest[row * tiles + i];
     if (v.t != 0xFFFFFFFFu && v.score > b.score) {
       b.score = v.score;
       b.t = v.t;
       lc = v.lc;
+      wcs = v.cs;
     }
   }
   const double m = wave_max(b.score);
@@ -469,6 +496,7 @@ __global__ __launch_bounds__(64) void k_xbest(const QrTreeState *__restrict__ ts
   if (threadIdx.x == 0) {
     const bool none = !holder;
     const uint32_t wlc = none ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)lc, __ffsll((long long)holder) - 1);
+    if (xcs) xcs[lf] = none ? 0ll : readlane_i64(wcs, __ffsll((long long)holder) - 1);
     qr_split_t *o = &featrec[row];
     o->score = none ? -1.0 : m;
     o->feature = none ? 0xFFFFFFFFu : (uint32_t)lf2gf[lf];
@@ -490,6 +518,9 @@ void qr_k_exact_free(qr_ctx *c) {
   if (c->d_xgoleft) (void)hipFree(c->d_xgoleft);
   if (c->d_xpub) (void)hipFree(c->d_xpub);
   if (c->d_xtbest) (void)hipFree(c->d_xtbest);
+  if (c->d_xnode_tot) (void)hipFree(c->d_xnode_tot);
+  c->d_xnode_tot = c->d_xcs = nullptr;
+  c->d_xgbest = nullptr;
   c->d_xroot = c->d_xlist[0] = c->d_xlist[1] = nullptr;
   c->d_xpub = nullptr;
   c->d_xtot = nullptr;
@@ -528,8 +559,11 @@ int qr_k_exact_build(qr_ctx *c) {
       hipMalloc((void **)&c->d_xlist[1], FL * N * 8) != hipSuccess ||
       hipMalloc((void **)&c->d_xtot, (2 + 2 * FL + 2) * 8) != hipSuccess ||  // [2] totals, then [2][F] best score bits (+ an experiment's counter)
       hipMalloc((void **)&c->d_xgoleft, N + 16) != hipSuccess || hipMalloc((void **)&c->d_xpub, npub * 8) != hipSuccess ||
-      hipMalloc((void **)&c->d_xtbest, 2 * FL * c->xtiles_s * sizeof(XTileBest)) != hipSuccess)
+      hipMalloc((void **)&c->d_xtbest, 2 * FL * c->xtiles_s * sizeof(XTileBest)) != hipSuccess ||
+      hipMalloc((void **)&c->d_xnode_tot, (QR_MAXNODES + FL) * 8) != hipSuccess)  // per-node totals, then [F] winners' sums
     return fail("allocating the pre-sorted lists failed");
+  c->d_xcs = c->d_xnode_tot + QR_MAXNODES;
+  c->d_xgbest = c->d_xtot + 2;
   if (hipMemset(c->d_xpub, 0, npub * 8) != hipSuccess || hipMemset(c->d_xtot, 0, (2 + 2 * FL + 2) * 8) != hipSuccess)
     return fail("clearing the tiles' words failed");
   c->xepoch = 0;
@@ -589,7 +623,73 @@ int qr_k_exact_scan(qr_ctx *c, int root_mode) {
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_xbest, dim3(F, nodes), dim3(64), 0, c->stream, c->d_tree, mode, rootn,
                      (const XTileBest *)c->d_xtbest, c->xtiles_s, c->d_woff, c->flocal, c->d_lf2gf, c->d_wthr,
-                     c->d_featrec, c->d_featthr);
+                     c->d_featrec, c->d_featthr, (long long *)nullptr);
   QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The whole tree with the split search at the pop (k_tree.hip k_xpop / k_xapply): per step
+//   k_xscan + k_xbest (the popped node) -> k_xapply -> k_partition (document-order lists, child
+//   sums) -> k_xflag -> k_xpart (every feature's segment) -> k_xpop (children, next pop)
+// Lists move (pi N F) entries through the scans instead of (1 + pi) N F, and no pass for the
+// children's gradient totals: the winner's cumulative sum is the left child's.
+// ---------------------------------------------------------------------------
+static int exact_step(qr_ctx *c, int root, int final_call) {
+  const u64 *xr = (const u64 *)c->d_xroot;
+  u64 *x0 = (u64 *)c->d_xlist[0], *x1 = (u64 *)c->d_xlist[1];
+  const unsigned F = (unsigned)c->flocal;
+  u64 *pub_scan = (u64 *)c->d_xpub, *pub_part = (u64 *)c->d_xpub + (size_t)2 * F * c->xtiles_s * QR_X_PUBW;
+  if (++c->xepoch > 0xFFFFu) {
+    QR_CHECK(c, hipMemsetAsync(c->d_xpub, 0, ((size_t)2 * F * c->xtiles_s + (size_t)F * c->xtiles_p) * QR_X_PUBW * 8, c->stream));
+    c->xepoch = 1;
+  }
+  const u64 epoch = c->xepoch;
+  hipLaunchKernelGGL(k_xscan, dim3(F, c->xtiles_s, 1), dim3(QR_XS_T), 0, c->stream, c->d_tree, 2, (uint32_t)c->N, xr,
+                     (const u64 *)x0, (const u64 *)x1, c->N, c->d_lambda, c->d_scalars, (const long long *)c->d_xnode_tot,
+                     c->d_woff, c->flocal, pub_scan, c->xtiles_s, epoch, (unsigned long long *)c->d_xgbest,
+                     (XTileBest *)c->d_xtbest, (u64)c->cur_minls);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_xbest, dim3(F, 1), dim3(64), 0, c->stream, c->d_tree, 2, (uint32_t)c->N,
+                     (const XTileBest *)c->d_xtbest, c->xtiles_s, c->d_woff, c->flocal, c->d_lf2gf, c->d_wthr,
+                     c->d_featrec, c->d_featthr, c->d_xcs);
+  QR_CHECK(c, hipGetLastError());
+  int rc = qr_k_xapply(c, root);
+  if (rc) return rc;
+  if ((rc = qr_k_xpartition(c))) return rc;
+  const unsigned fg = (unsigned)std::min<size_t>((c->N + 2047) / 2048, 1024);
+  hipLaunchKernelGGL(k_xflag, dim3(fg), dim3(256), 0, c->stream, c->d_tree, xr, (const u64 *)x0, (const u64 *)x1,
+                     c->N, c->d_xgoleft);
+  QR_CHECK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_xpart, dim3(F, c->xtiles_p), dim3(1024), 0, c->stream, c->d_tree, xr, x0, x1, c->N,
+                     (const uint8_t *)c->d_xgoleft, pub_part, c->xtiles_p, epoch);
+  QR_CHECK(c, hipGetLastError());
+  return qr_k_xpop(c, 0, c->cur_nleaves, c->cur_minls, final_call);
+}
+
+int qr_k_exact_fit(qr_ctx *c, size_t nleaves, uint64_t minls) {
+  c->finish_in_decide = false;
+  c->tree_counter += 0x9E3779B97F4A7C15ull;  // a fresh feature-subset stream per tree
+  c->cur_minls = minls;
+  const int frc = qr_k_prep_flush(c);  // (the iteration's scalars: the scans read the scale)
+  if (frc) return frc;
+  QR_CHECK(c, hipMemsetAsync(c->d_xnode_tot, 0, 8, c->stream));
+  hipLaunchKernelGGL(k_xtotal, dim3(64, 1), dim3(256), 0, c->stream, c->d_tree, 0, (uint32_t)c->N,
+                     (const u64 *)c->d_xroot, (const u64 *)c->d_xlist[0], (const u64 *)c->d_xlist[1], c->d_lambda,
+                     c->d_scalars, c->d_xnode_tot);
+  QR_CHECK(c, hipGetLastError());
+  int rc = qr_k_xpop(c, 1, nleaves, minls, 0);
+  if (rc) return rc;
+  const size_t steps = nleaves - 1;
+  for (size_t s = 0; s < steps; ++s)
+    if ((rc = exact_step(c, s == 0, s + 1 == steps))) return rc;
+  c->tree_step = (int)steps;
+  return QR_OK;
+}
+
+int qr_k_exact_continue(qr_ctx *c, size_t steps) {
+  int rc;
+  for (size_t s = 0; s < steps; ++s)
+    if ((rc = exact_step(c, 0, s + 1 == steps))) return rc;
   return QR_OK;
 }

@@ -1657,6 +1657,234 @@ __global__ __launch_bounds__(128) void k_decide(
 }
 
 // ===========================================================================
+// Pre-sorted lists (k_exact.hip): the split search of a node when the loop POPS it, as the
+// reference does (rt.cc:58-90: `split(node)` follows the pop) -- the ten nodes that end up as the
+// leaves of a ten-leaf tree are never searched, a fifth of the entries the eager order walks.
+// The heap is keyed on the deviance, which a node has from the moment its parent is split (sums
+// from the partition), so the order of pops is the reference's whatever is searched when.
+//   k_xpop   accounts for the children of the split just applied (statistics, heap pushes) and
+//            pops until it finds a node with deviance > 0: the step's scan target (ts->xs_*).
+//   [k_xscan + k_xbest on that node's segments -> featrec[0 .. flocal)]
+//   k_xapply merges the features' records: a valid split -> make_desc (the step's partition
+//            launches apply it); none -> the node is a leaf (`taken`), the next step pops on.
+// A step that finds no valid split has used one of the enqueued steps without splitting: the
+// last k_xpop of the sequence reports a tree that still has a node to search (QrPinned::early, as
+// batched growth does) and the host carries on (qr_k_exact_continue).
+// ===========================================================================
+__device__ __forceinline__ void xpop_logic(DecideState &st, const bool root_mode, const int32_t active,
+                                           const QrSplitDesc &d, const uint32_t N, const QrScalars *scal,
+                                           const double sum_small, const double ss_small, int *xs_out) {
+  int xs = -1;
+  if (root_mode) {
+    QrNode *root = &st.nodes[0];
+    root->begin = 0;
+    root->end = N;
+    root->buf = 2;
+    root->hslot = 0;
+    root->feature = -1;
+    root->thr_id = -1;
+    root->threshold = 0.f;
+    root->left = root->right = root->parent = -1;
+    root->leaf_id = -1;
+    node_stats(root, scal->root_sum, scal->root_ss, (u64)N);
+    root->best_score = -1.0;
+    root->best_f = root->best_t = 0xFFFFFFFFu;
+    root->best_lc = root->best_rc = 0;
+    st.nnodes = 1;
+    st.heap_size = 0;
+    st.heap[0].key = 1.7976931348623157e308;  // DBL_MAX sentinel
+    st.heap[0].val = -1;
+    st.taken = 0;
+    st.done = 0;
+    st.nsplits = 0;
+    st.step = 1;
+    if (root->deviance > 0.0)
+      xs = 0;
+    else
+      st.done = 1;
+  } else {
+    if (active) {  // children of the split just applied (rtnode_histogram.cc:65-69, 79-86)
+      QrNode *P = &st.nodes[d.node];
+      QrNode *S = &st.nodes[d.small_node], *B = &st.nodes[d.big_node];
+      node_stats(S, sum_small, ss_small, d.small_n);
+      node_stats(B, P->sum - sum_small, P->ss - ss_small, P->count - d.small_n);
+      for (int k = 0; k < 2; ++k) {
+        QrNode *C = &st.nodes[k ? d.right : d.left];
+        C->best_score = -1.0;
+        C->best_f = C->best_t = 0xFFFFFFFFu;
+        C->best_lc = C->best_rc = 0;
+      }
+      heap_push(st, st.nodes[d.left].deviance, d.left);    // rt.cc:76-77
+      heap_push(st, st.nodes[d.right].deviance, d.right);
+    }
+    st.step++;
+    if (!st.done) {
+      while (st.heap_size > 0 && (st.nleaves_req == 0 || st.taken + st.heap_size < st.nleaves_req)) {
+        const int node = st.heap[1].val;
+        heap_pop(st);
+        if (st.nodes[node].deviance > 0.0) {  // rt.cc:212; whether it has a split: k_xapply
+          xs = node;
+          break;
+        }
+        ++st.taken;
+      }
+      if (xs < 0) st.done = 1;
+    }
+  }
+  *xs_out = xs;
+}
+
+__global__ __launch_bounds__(128) void k_xpop(
+    QrTreeState *ts, const int root_mode, const int nleaves_arg, const u64 minls_arg, const uint32_t N,
+    const QrScalars *__restrict__ scal, const double *__restrict__ part_ss,
+    unsigned long long *__restrict__ gbest, const int flocal, const int final_call,
+    int64_t *__restrict__ early, const long long early_seq) {
+  __shared__ QrNode sh_nodes[QR_DECIDE_LDS_NODES];
+  __shared__ QrHeapItem sh_heap[QR_DECIDE_LDS_NODES + 2];
+  __shared__ int sh_nn, sh_hs;
+  const bool w0 = threadIdx.x < 64;
+  // (the best-score words of the scan launch that follows start at "none")
+  for (int i = threadIdx.x; i < flocal; i += blockDim.x) gbest[i] = 0ull;
+  DecideState st;
+  st.nleaves_req = root_mode ? nleaves_arg : ts->nleaves_req;
+  st.nnodes = root_mode ? 0 : ts->nnodes;
+  st.taken = root_mode ? 0 : ts->taken;
+  st.done = root_mode ? 0 : ts->done;
+  st.step = root_mode ? 0 : ts->step;
+  st.nsplits = root_mode ? 0 : ts->nsplits;
+  st.heap_size = root_mode ? 0 : ts->heap_size;
+  st.part_epoch = ts->part_epoch;
+  st.split_log = ts->split_log;
+  st.split_log2 = nullptr;
+  st.hcnt_loc = nullptr;
+  st.loc = &ts->loc;
+  st.flocal = flocal;
+  st.desc = &ts->desc;
+  const int32_t active = root_mode ? 0 : ts->desc.active;
+  const QrSplitDesc d = ts->desc;
+  const bool staged = !root_mode && st.nnodes + 2 <= QR_DECIDE_LDS_NODES &&
+                      st.heap_size + 3 <= QR_DECIDE_LDS_NODES + 2;
+  if (staged && w0) {
+    wave_copy8(sh_nodes, ts->nodes, (size_t)st.nnodes * sizeof(QrNode));
+    wave_copy8(sh_heap, ts->heap, (size_t)(st.heap_size + 1) * sizeof(QrHeapItem));
+  }
+  // squares_sum_ / sum of the directly built child: the partition workgroups' partials
+  double ss_small = 0.0, sum_small = 0.0;
+  if (w0 && active) {
+    const uint32_t nwg = (d.end - d.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
+    for (uint32_t i = threadIdx.x; i < nwg; i += 64) {
+      ss_small += part_ss[2 * i];
+      sum_small += part_ss[2 * i + 1];
+    }
+    ss_small = wave_sum(ss_small);
+    sum_small = wave_sum(sum_small);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int xs = -1;
+    if (staged) {
+      st.nodes = sh_nodes;
+      st.heap = sh_heap;
+      xpop_logic(st, root_mode, active, d, N, scal, sum_small, ss_small, &xs);
+    } else {
+      st.nodes = ts->nodes;
+      st.heap = ts->heap;
+      xpop_logic(st, root_mode, active, d, N, scal, sum_small, ss_small, &xs);
+    }
+    if (root_mode) {  // (what k_tree_reset does for the phase API)
+      ts->nleaves_req = nleaves_arg;
+      ts->minls = minls_arg;
+      ts->nleaves = 0;
+      ts->l_nodes = 0;
+      ts->real_steps = 0;
+    }
+    ts->desc.active = 0;
+    ts->nnodes = st.nnodes;
+    ts->taken = st.taken;
+    ts->done = st.done;
+    ts->step = st.step;
+    ts->nsplits = st.nsplits;
+    ts->heap_size = st.heap_size;
+    ts->xs_node = xs;
+    if (xs >= 0) {
+      const QrNode &nd = st.nodes[xs];
+      ts->xs_buf = nd.buf;
+      ts->xs_begin = nd.begin;
+      ts->xs_n = nd.end - nd.begin;
+    } else {
+      ts->xs_buf = 2;
+      ts->xs_begin = ts->xs_n = 0;
+    }
+    // the last control call of the enqueued sequence still has a node to search: the host
+    // carries the tree on; the leaf and score kernels behind this call leave at once
+    const int inc = final_call && xs >= 0 ? 1 : 0;
+    ts->incomplete = inc;
+    if (final_call && early)
+      __hip_atomic_store(&early[0], (int64_t)((early_seq << 16) | ((long long)(st.step & 0x7fff) << 1) | inc),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    sh_nn = st.nnodes;
+    sh_hs = st.heap_size;
+  }
+  if (staged) {
+    __syncthreads();
+    if (w0) {
+      wave_copy8(ts->nodes, sh_nodes, (size_t)sh_nn * sizeof(QrNode));
+      wave_copy8(ts->heap, sh_heap, (size_t)(sh_hs + 1) * sizeof(QrHeapItem));
+    }
+  }
+}
+
+// the records of the step's scan -> the popped node's best split -> the split being applied
+__global__ __launch_bounds__(64) void k_xapply(
+    QrTreeState *ts, const int root_mode, const int flocal, const qr_split_t *__restrict__ featrec,
+    const float *__restrict__ thr, const int32_t *__restrict__ gf2lf, const uint32_t *__restrict__ thr_off,
+    const uint32_t mf_k, const u64 mf_seed, const uint32_t F, const long long *__restrict__ xcs,
+    long long *__restrict__ node_tot) {
+  const int node = ts->xs_node;
+  if (node < 0) return;  // (workgroup-uniform; k_xpop left desc.active = 0)
+  const qr_split_t a = wave_merge(1, 0, featrec, flocal, mf_k, mf_seed, (uint32_t)node, F);
+  if (threadIdx.x != 0) return;
+  __shared__ qr_split_t own[2];
+  own[0] = a;
+  DecideState st;
+  st.nleaves_req = ts->nleaves_req;
+  st.nnodes = ts->nnodes;
+  st.taken = ts->taken;
+  st.done = ts->done;
+  st.step = ts->step;
+  st.nsplits = ts->nsplits;
+  st.heap_size = ts->heap_size;
+  st.part_epoch = ts->part_epoch;
+  st.split_log = ts->split_log;
+  st.split_log2 = nullptr;
+  st.hcnt_loc = nullptr;
+  st.loc = &ts->loc;
+  st.flocal = flocal;
+  st.nodes = ts->nodes;
+  st.heap = ts->heap;
+  st.desc = &ts->desc;
+  QrNode *nd = &ts->nodes[node];
+  node_set_best(nd, own, 1, 0);
+  if (nd->best_f != 0xFFFFFFFFu) {  // (deviance > 0: k_xpop)
+    make_desc(st, node, thr, gf2lf, thr_off);
+    // the children's fixed-point totals: the winner's cumulative sum IS the left child's
+    const long long sl = xcs[ts->desc.owner_local];
+    node_tot[ts->desc.left] = sl;
+    node_tot[ts->desc.right] = node_tot[node] - sl;
+    ts->real_steps = ts->real_steps + 1;
+  } else if (root_mode) {
+    st.done = 1;     // rt.cc:312: the root has no split
+  } else {
+    ++st.taken;      // a leaf after all; the next step pops on
+  }
+  ts->nnodes = st.nnodes;
+  ts->taken = st.taken;
+  ts->done = st.done;
+  ts->nsplits = st.nsplits;
+  ts->part_epoch = st.part_epoch;
+}
+
+// ===========================================================================
 // k_decide_batch: RegressionTree::fit with up to QR_BATCH splits applied per step.
 //
 // The reference's loop (rt.cc:58-90) pops the heap's maximum, splits it, pushes
@@ -4136,6 +4364,34 @@ int qr_k_tree_decide(qr_ctx *c) {
   return QR_OK;
 }
 
+int qr_k_xpop(qr_ctx *c, int root_mode, size_t nleaves, uint64_t minls, int final_call) {
+  hipLaunchKernelGGL(k_xpop, dim3(1), dim3(128), 0, c->stream, c->d_tree, root_mode, (int)nleaves, (u64)minls,
+                     (uint32_t)c->N, c->d_scalars, c->d_part_ss, (unsigned long long *)c->d_xgbest, c->flocal,
+                     final_call, final_call ? c->d_pin->early : (int64_t *)nullptr,
+                     (long long)(final_call ? ++c->early_seq : 0));
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+int qr_k_xapply(qr_ctx *c, int root_mode) {
+  hipLaunchKernelGGL(k_xapply, dim3(1), dim3(64), 0, c->stream, c->d_tree, root_mode, c->flocal, c->d_featrec,
+                     c->d_wthr, c->d_gf2lf, c->d_woff, c->mf_k, c->mf_seed + c->tree_counter, (uint32_t)c->F,
+                     (const long long *)c->d_xcs, c->d_xnode_tot);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+// the partition of the document-order lists for the split k_xapply made (as qr_k_tree_apply,
+// without the histogram launches behind it)
+int qr_k_xpartition(qr_ctx *c) {
+  const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
+  hipLaunchKernelGGL(k_partition, dim3(pgrid), dim3(256), 0, c->stream, c->d_tree,
+                     reinterpret_cast<const uint8_t *>(c->d_wbins), (uint32_t)c->N, c->d_order[0], c->d_order[1],
+                     c->d_mask, 2, (u64 *)c->d_part_state, c->d_lambda, c->d_part_ss, 0);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
 int qr_k_tree_apply(qr_ctx *c) {
   const unsigned pgrid = (unsigned)((c->N + QR_PART_SLICE - 1) / QR_PART_SLICE);
   const bool fshard = c->world > 1 && !c->dmode;
@@ -4205,7 +4461,7 @@ static BatchGeom batch_geom(const qr_ctx *c, size_t nleaves) {
   // Staged trees: the control step runs inside the partition launch (k_decide_part) and
   // the tree state ping-pongs between two copies, arranged so that the last call
   // (control step only: it accounts for the last batch) writes c->d_tree.
-  g.fused = g.stage_nodes > 0 && c->d_tree2 != nullptr;
+  g.fused = g.stage_nodes > 0 && c->d_tree2 != nullptr && c->N <= c->fuse_max_docs;
   return g;
 }
 

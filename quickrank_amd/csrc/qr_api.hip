@@ -96,6 +96,8 @@ int qr_ctx_create(int device, qr_ctx **out) {
   c->obl_own_launches = getenv("QR_OBL_OWN_LAUNCHES") != nullptr;
   c->exact_tail = getenv("QR_EXACT_TAIL") != nullptr;
   if (getenv("QR_LEAF_BY_POSITION")) c->leaf_by_position = true;
+  c->x_eager = getenv("QR_X_EAGER") != nullptr;
+  if (const char *e = getenv("QR_FUSE_MAX_DOCS")) c->fuse_max_docs = (size_t)std::max(0l, atol(e));
   if (const char *e = getenv("QR_STEPS_HINT")) c->steps_force = atol(e);  // steps to enqueue, whatever the tree
   if (const char *e = getenv("QR_STEPS_PLUS")) c->steps_plus = (size_t)std::max(0l, atol(e));
   if (const char *e = getenv("QR_CONT_STEPS")) c->cont_steps = (size_t)std::max(0l, atol(e));
@@ -1366,10 +1368,17 @@ static int tree_settle_keep(qr_ctx *c) {
   size_t done = (size_t)c->tree_step;
   size_t piece_len = c->cont_steps;
   while (w & 1) {
-    const size_t worst = c->cur_nleaves - 1 > done ? c->cur_nleaves - 1 - done : 1;
+    // (pre-sorted lists, split search at the pop: a step that found no valid split used one of the
+    // enqueued steps; every node is popped at most once, so 2 L + 1 steps bound the tree)
+    const size_t cap = c->spec_exact ? 2 * c->cur_nleaves + 2 : c->cur_nleaves - 1;
+    const size_t worst = cap > done ? cap - done : 1;
     const size_t piece = piece_len ? std::min(worst, piece_len) : worst;
     piece_len *= 2;
-    if ((rc = qr_k_tree_continue(c, c->cur_nleaves, c->cur_minls, done, piece))) return rc;
+    if (c->spec_exact)
+      rc = qr_k_exact_continue(c, piece);
+    else
+      rc = qr_k_tree_continue(c, c->cur_nleaves, c->cur_minls, done, piece);
+    if (rc) return rc;
     done += piece;
     if ((rc = qr_k_tree_finish(c, c->spec_newton))) return rc;
     if (c->spec_scores_enqueued && (rc = qr_k_scores_update(c, c->spec_shrinkage))) return rc;
@@ -1377,6 +1386,10 @@ static int tree_settle_keep(qr_ctx *c) {
     if ((w & 1) && piece == worst) QR_FAIL(c, QR_ERR_STATE, "internal: tree still incomplete after its last step");
   }
   c->spec_scores_enqueued = false;
+  if (c->spec_exact) {  // (always nleaves - 1 steps: nothing to learn from this tree)
+    c->spec_exact = false;
+    return QR_OK;
+  }
   // the next tree: as many steps as this one needed, plus `steps_plus` (QR_STEPS_PLUS)
   c->steps_hint = (size_t)((w >> 1) & 0x7fff) + c->steps_plus;
   if (c->steps_hint < 1) c->steps_hint = 1;
@@ -1462,6 +1475,23 @@ int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
     if ((rc = qr_k_tree_fit_batch(c, nleaves, minls))) return rc;
     // (the records say how many steps the tree took and whether the enqueued ones sufficed)
     c->spec_pending = true;
+    c->spec_scores_enqueued = false;
+    c->spec_newton = newton;
+    return qr_tree_end(c, newton, nodes_out, nnodes_out);
+  }
+  // pre-sorted lists: the split search of a node when the loop pops it (k_exact.hip qr_k_exact_fit)
+  if (qr_exact_active(c) && !c->x_eager && nleaves >= 2 && 2 * nleaves + 1 <= QR_MAXNODES) {
+    if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+    c->cur_nleaves = nleaves;
+    c->leaf_cap = nleaves;
+    c->cur_maxnodes = 2 * nleaves + 1;
+    c->tree_open = true;
+    c->tree_valid = false;
+    c->dbatch = false;
+    int xrc = qr_k_exact_fit(c, nleaves, minls);
+    if (xrc) return xrc;
+    c->spec_pending = true;   // (the last control call says whether the enqueued steps sufficed)
+    c->spec_exact = true;
     c->spec_scores_enqueued = false;
     c->spec_newton = newton;
     return qr_tree_end(c, newton, nodes_out, nnodes_out);

@@ -237,6 +237,10 @@ struct QrTreeState {
   uint32_t leaf_begin[QR_MAXNODES + 1];  // sorted by position
   int32_t leaf_at[QR_MAXNODES];          // node index per position-sorted leaf
   double leaf_value[QR_MAXNODES];        // per position-sorted leaf
+  // pre-sorted lists (k_exact.hip), split search when the loop pops a node (k_xpop / k_xapply):
+  // the node whose segments the step's scan launch walks (-1: none)
+  int32_t xs_node, xs_buf;
+  uint32_t xs_begin, xs_n;
 };
 
 // Per-iteration scalars produced on the device.
@@ -287,6 +291,11 @@ struct qr_ctx {
   // document-sharded batched growth: [QR_BATCH][feature][slot][sum, count] + [QR_BATCH][2 * world] f64 bits
   long long *d_xb = nullptr;
   size_t xb_len = 0;
+  // k_decide_part (control step inside the partition launch) up to this many documents: every
+  // workgroup of the launch runs the step on its own copy, which a launch of several rounds of
+  // workgroups pays once per round (QR_FUSE_MAX_DOCS; measured, ms per iteration fused / not:
+  // 1M 0.418 / 0.451, 2M 0.618 / 0.655, 4M 1.020 / 1.021, 8M 1.863 / 1.808)
+  size_t fuse_max_docs = 4000000;
   bool dbatch = false;            // the open tree grows by qr_tree_batch_* (document-sharded)
   // ... its last control call (qr_tree_batch_decide(last = 1)) has not been looked at yet; the tree
   // was ended like that (leaf kernels and score update enqueued behind a guess: they leave at once
@@ -348,6 +357,10 @@ struct qr_ctx {
   long long *d_xtot = nullptr;               // [2] fixed-point gradient totals of the node(s) being scanned
   uint8_t *d_xgoleft = nullptr;              // [N] go-left byte of the documents of the node being split
   unsigned long long *d_xpub = nullptr;      // the tiles' published words {epoch : 16, value : 48} (scan tiles, then partition tiles)
+  long long *d_xnode_tot = nullptr, *d_xcs = nullptr;  // lazy split search: fixed-point gradient total per node; the winners' cumulative sums per feature
+  long long *d_xgbest = nullptr;             // (= d_xtot + 2: best exact score seen per scan row)
+  bool spec_exact = false;                   // the pending tree was enqueued by qr_k_exact_fit (tree_settle carries it on with qr_k_exact_continue)
+  bool x_eager = false;                      // QR_X_EAGER: both children searched behind every split (the phase API's order)
   void *d_xtbest = nullptr;                  // [2][flocal][scan tiles] best candidate of every tile
   uint32_t xtiles_s = 0, xtiles_p = 0, xepoch = 0;
   std::vector<uint32_t> h_woff;
@@ -584,6 +597,12 @@ int qr_k_whist_scan_batch(qr_ctx *c, const QrTreeState *ts, const double *pss);
 int qr_k_whist_scan(qr_ctx *c, int root_mode);
 int qr_k_exact_build(qr_ctx *c);
 int qr_k_exact_scan(qr_ctx *c, int root_mode);
+int qr_k_exact_fit(qr_ctx *c, size_t nleaves, uint64_t minls);        // lazy split search: the whole tree enqueued
+int qr_k_exact_continue(qr_ctx *c, size_t steps);                      // ... carried on (tree_settle)
+// the two control launches of a lazy step (k_tree.hip, next to the helpers they share with k_decide)
+int qr_k_xpop(qr_ctx *c, int root_mode, size_t nleaves, uint64_t minls, int final_call);
+int qr_k_xapply(qr_ctx *c, int root_mode);
+int qr_k_xpartition(qr_ctx *c);
 void qr_k_exact_free(qr_ctx *c);
 #define QR_X_MIN_SLOTS 16384u  /* longest row from which a wide context takes the pre-sorted path (k_exact.hip) */
 inline bool qr_exact_active(const qr_ctx *c) { return c->xmode && !c->sub_k; }

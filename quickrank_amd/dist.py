@@ -366,6 +366,11 @@ class DocShardedTrainer:
             self._carry_on(nleaves, done)
             self._leaf_exchange(nleaves, newton, read=False)   # (repeats the score update if one was enqueued)
 
+    def tree_nodes(self):
+        """records of the last tree (settled first)"""
+        self.settle()
+        return self.ctx.tree_nodes()
+
     def _fit_tree_batched(self, nleaves, minls, newton, read):
         """RegressionTree::fit (rt.cc:58-90) with up to two splits per exchange: the one-GPU
         batched growth (qr_tree_fit) cut at the all-reduces.  The number of steps enqueued is a

@@ -324,3 +324,92 @@ def test_presorted_lists_refuse_node_histogram_reads(qr, monkeypatch):
     with pytest.raises(Exception, match="pre-sorted"):
         c.node_hist_ragged(0)
     c.close()
+
+
+def test_presorted_split_search_at_the_pop_equals_the_eager_order(qr, monkeypatch):
+    """qr_tree_fit on pre-sorted lists searches a node's split when the loop pops it (rt.cc:58-90's
+    own order; k_xpop / k_xapply); the phase API -- and QR_X_EAGER=1 -- search both children behind
+    every split.  Same pops, same trees, same bits."""
+    from quickrank_amd.trainer import Mart
+    monkeypatch.setenv("QR_WIDE_EXACT", "1")
+    x, labels, qoff = make_dataset(**CASES[1])
+    kw = dict(ntrees=5, shrinkage=0.1, nthresholds=0, nleaves=9, minls=3, esr=0)
+
+    def run():
+        m = Mart(algo="LAMBDAMART", **kw).learn(x, labels, qoff)
+        out = [t.copy() for t in m.ensemble.trees], m.ctx.get_scores()
+        m.ctx.close()
+        return out
+
+    ta, sa = run()
+    monkeypatch.setenv("QR_X_EAGER", "1")
+    tb, sb = run()
+    for a, b in zip(ta, tb):
+        for k in a.dtype.names:
+            assert np.array_equal(a[k], b[k], equal_nan=(a[k].dtype.kind == "f")), k
+    assert np.array_equal(sa, sb)
+    # the phase API on the same lists
+    monkeypatch.delenv("QR_X_EAGER")
+    c = qr.Context(0)
+    c.upload(x, labels, qoff)
+    c.build_bins(0)
+    c.reset_scores()
+    c.compute_lambdas("NDCG", 10)
+    c.tree_begin(9, 3)
+    for _ in range(8):
+        c.tree_decide()
+        c.tree_apply()
+    c.tree_decide()
+    t = c.tree_end(9, True)
+    for k in t.dtype.names:     # (the ensemble's records are padded to 2 L + 1 entries)
+        assert np.array_equal(t[k], ta[0][k][:len(t)], equal_nan=(t[k].dtype.kind == "f")), k
+    c.close()
+
+
+@pytest.mark.parametrize("nleaves,minls,nrows", [(3, 1, 2), (6, 1, 2), (6, 1, 3), (10, 2, 4), (4, 40, 4)])
+def test_presorted_steps_without_a_split_are_carried_on(qr, nleaves, minls, nrows, monkeypatch, capfd):
+    """Documents that share their whole feature row: a node of them has deviance > 0 and no valid
+    split, which the search at the pop only finds out after it used one of the enqueued steps.  The
+    last control call reports the tree unfinished and the host carries it on (tree_settle): the
+    trees are the histogram path's."""
+    rng = np.random.default_rng(5)
+    rows = rng.random((nrows, 12), dtype=np.float32)
+    nq, dpq = 30, 20
+    pick = rng.integers(0, nrows, nq * dpq)
+    x = rows[pick].copy()
+    labels = rng.integers(0, 5, nq * dpq).astype(np.float32)
+    qoff = np.arange(nq + 1, dtype=np.uint64) * dpq
+
+    def run():
+        c = qr.Context(0)
+        c.upload(x, labels, qoff)
+        c.build_bins(0, wide=True)
+        assert c.wide
+        c.reset_scores()
+        trees = []
+        for it in range(4):
+            c.compute_lambdas("NDCG", 10)
+            trees.append(c.fit_tree(nleaves, minls, True).copy())
+            c.update_scores(0.1)
+        s = c.get_scores()
+        c.close()
+        return trees, s
+
+    monkeypatch.setenv("QR_NO_BATCH", "1")
+    monkeypatch.setenv("QR_WIDE_NO_EXACT", "1")
+    ta, sa = run()
+    monkeypatch.delenv("QR_WIDE_NO_EXACT")
+    monkeypatch.setenv("QR_WIDE_EXACT", "1")
+    monkeypatch.setenv("QR_SPEC_DEBUG", "1")
+    capfd.readouterr()
+    tb, sb = run()
+    err = capfd.readouterr().err
+    for a, b in zip(ta, tb):
+        assert len(a) == len(b)
+        for k in a.dtype.names:
+            assert np.array_equal(a[k], b[k], equal_nan=(a[k].dtype.kind == "f")), k
+    assert np.array_equal(sa, sb)
+    if nrows == 2 and nleaves == 3:   # root split, then two children nobody can split: three pops, two enqueued steps
+        import re
+        m = re.search(r"(\d+) trees with a guessed step count, (\d+) continued", err)
+        assert m and int(m.group(2)) > 0, err      # the carried-on path has run

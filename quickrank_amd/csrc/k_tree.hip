@@ -2904,7 +2904,9 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
     const uint32_t hist_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
     const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
     uint32_t *__restrict__ order1, u64 *__restrict__ state, const double *__restrict__ lambda,
-    double *__restrict__ part_ss_out, const int wide) {
+    double *__restrict__ part_ss_out, const int wide, const uint32_t *__restrict__ hcnt_loc,
+    const u64 Nglobal) {
+  // (hcnt_loc != null: a document-sharded rank -- N its own documents, Nglobal everybody's)
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
   __shared__ int sh_nj;
@@ -2916,7 +2918,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
   batch_step<true, CAP>(tin, tout, tlog2, blockIdx.x == gridDim.x - 1, epoch, sh_next, sh_pw0, &sh_nj, &sh_epoch,
                    root_mode, nleaves_arg, minls_arg, stage_nodes, N, flocal, scal, part_ss_in, featrec,
                    featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, nullptr, 0u, plans,
-                   scan_wg);
+                   scan_wg, 0, hcnt_loc, Nglobal);
   __syncthreads();  // (the writer comes back later than the others; sh_* are final for all)
   const int nj = sh_nj;
 #ifdef QR_STEP_TIMING
@@ -4539,7 +4541,8 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
                          c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, g.hg,
                          c->d_lplan, c->d_lscan_wg, fm, (uint32_t)c->N, c->d_order[0],
                          c->d_order[1], (u64 *)c->d_bpart_state, c->d_lambda,
-                         c->wide ? PSS[s & 1] : (double *)nullptr, c->wide ? 1 : 0);
+                         c->wide ? PSS[s & 1] : (double *)nullptr, c->wide ? 1 : 0,
+                         (const uint32_t *)nullptr, (u64)0);
       QR_CHECK(c, hipGetLastError());
     }
     if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls, g.fused ? PSS[s & 1] : c->d_lpart_ss, tout))) return rc;
@@ -4586,19 +4589,45 @@ int qr_k_dbatch_root_hist(qr_ctx *c, size_t nleaves, uint64_t minls) {
   return launch_hist_scan(c, 1);  // k_hist_root + k_reduce into the exchange buffer
 }
 
+// (Staged trees: the control step of a growth step rides in the NEXT step's partition launch
+// (k_decide_part), as on one GPU; the tree state ping-pongs between c->d_tree and c->d_tree2
+// (c->dtree_cur = the copy the last control step wrote) and the last control call of a sequence --
+// a k_decide_batch of its own -- writes c->d_tree, where everything behind the growth looks.)
 int qr_k_dbatch_root_decide(qr_ctx *c, size_t nleaves, uint64_t minls) {
   int rc = launch_scan(c, 1);  // slot 0 (sums, counts, the rank's own counts) + featrec[0]
   if (rc) return rc;
   const BatchGeom g = batch_geom(c, nleaves);
+  c->dtree_cur = c->d_tree;
+  c->dbatch_first = g.fused;   // (fused: the root's control step is the first partition launch's)
+  c->dbatch_prepared = !g.fused;
+  if (g.fused) return QR_OK;
   return launch_decide_batch(c, g, nleaves, minls, 1, c->d_tree, (const QrTreeState *)nullptr, c->d_jobsum, 0);
 }
 
 int qr_k_dbatch_apply(qr_ctx *c, size_t nleaves) {
   const BatchGeom g = batch_geom(c, nleaves);
-  hipLaunchKernelGGL(k_partition_batch, dim3(g.pg), dim3(256), 0, c->stream, c->d_tree, c->d_lpart_wg,
-                     c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1], (u64 *)c->d_bpart_state,
-                     c->d_lambda, (double *)nullptr, ++c->bepoch, 0);
-  QR_CHECK(c, hipGetLastError());
+  // (dbatch_prepared: a control call of its own -- the root's on unstaged trees, the last one of a
+  // sequence that turned out too short -- has already made this step's batch: only apply it)
+  if (g.fused && !c->dbatch_prepared) {
+    QrTreeState *tin = c->dtree_cur, *tout = tin == c->d_tree ? c->d_tree2 : c->d_tree;
+    hipLaunchKernelGGL(g.small ? k_decide_part<QR_BATCH_LDS_SMALL> : k_decide_part<QR_BATCH_LDS_LARGE>,
+                       dim3(g.pg), dim3(128 * QR_BATCH), 0, c->stream, (const QrTreeState *)tin, tout, tin,
+                       ++c->bepoch, c->dbatch_first ? 1 : 0, (int)nleaves, (u64)c->cur_minls, g.stage_nodes, g.rootn,
+                       c->flocal, c->d_scalars, c->d_jobsum, c->d_featrec, c->d_featthr, (uint32_t)c->F,
+                       c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, g.hg, c->d_lplan,
+                       c->d_lscan_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
+                       (u64 *)c->d_bpart_state, c->d_lambda, (double *)nullptr, 0,
+                       (const uint32_t *)c->d_hcnt_loc, (u64)(c->sub_k ? c->sub_k : c->Nglobal));
+    QR_CHECK(c, hipGetLastError());
+    c->dtree_cur = tout;
+    c->dbatch_first = false;
+  } else {
+    hipLaunchKernelGGL(k_partition_batch, dim3(g.pg), dim3(256), 0, c->stream, c->d_tree, c->d_lpart_wg,
+                       c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1], (u64 *)c->d_bpart_state,
+                       c->d_lambda, (double *)nullptr, ++c->bepoch, 0);
+    QR_CHECK(c, hipGetLastError());
+    c->dbatch_prepared = false;
+  }
   hipLaunchKernelGGL(k_hist_batch, dim3(g.hg), dim3(1024), hist_lds(c), c->stream, c->d_lhist_wg, c->d_blocks,
                      c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_lpartials,
                      c->d_lhistsum);
@@ -4617,8 +4646,12 @@ int qr_k_dbatch_decide(qr_ctx *c, size_t nleaves, uint64_t minls, int final_call
                      c->d_scalars, c->d_featrec, c->d_thr, c->d_featthr, (u64)minls, c->d_jobsum, c->world);
   QR_CHECK(c, hipGetLastError());
   const BatchGeom g = batch_geom(c, nleaves);
-  return launch_decide_batch(c, g, nleaves, minls, 0, c->d_tree, (const QrTreeState *)nullptr, c->d_jobsum,
-                             final_call);
+  if (g.fused && !final_call) return QR_OK;  // (the control step: the next step's partition launch)
+  const QrTreeState *tin = g.fused && c->dtree_cur != c->d_tree ? c->dtree_cur : (const QrTreeState *)nullptr;
+  const int rc = launch_decide_batch(c, g, nleaves, minls, 0, c->d_tree, tin, c->d_jobsum, final_call);
+  c->dtree_cur = c->d_tree;
+  c->dbatch_prepared = true;  // (if the tree goes on, its next batch is ready in c->d_tree)
+  return rc;
 }
 
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {

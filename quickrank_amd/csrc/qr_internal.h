@@ -296,6 +296,9 @@ struct qr_ctx {
   // workgroups pays once per round (QR_FUSE_MAX_DOCS; measured, ms per iteration fused / not:
   // 1M 0.418 / 0.451, 2M 0.618 / 0.655, 4M 1.020 / 1.021, 8M 1.863 / 1.808)
   size_t fuse_max_docs = 4000000;
+  QrTreeState *dtree_cur = nullptr;  // document-sharded batched growth: the copy of the tree state the last control step wrote
+  bool dbatch_prepared = false;      // ... a control call of its own has made the next step's batch (its partition launch only applies it)
+  bool dbatch_first = false;         // ... the next partition launch carries the ROOT's control step
   bool dbatch = false;            // the open tree grows by qr_tree_batch_* (document-sharded)
   // ... its last control call (qr_tree_batch_decide(last = 1)) has not been looked at yet; the tree
   // was ended like that (leaf kernels and score update enqueued behind a guess: they leave at once

@@ -674,7 +674,8 @@ int qr_k_exact_fit(qr_ctx *c, size_t nleaves, uint64_t minls) {
   const int frc = qr_k_prep_flush(c);  // (the iteration's scalars: the scans read the scale)
   if (frc) return frc;
   QR_CHECK(c, hipMemsetAsync(c->d_xnode_tot, 0, 8, c->stream));
-  hipLaunchKernelGGL(k_xtotal, dim3(64, 1), dim3(256), 0, c->stream, c->d_tree, 0, (uint32_t)c->N,
+  const unsigned tg = (unsigned)std::min<size_t>((c->N + 2047) / 2048, 1024);
+  hipLaunchKernelGGL(k_xtotal, dim3(tg, 1), dim3(256), 0, c->stream, c->d_tree, 0, (uint32_t)c->N,
                      (const u64 *)c->d_xroot, (const u64 *)c->d_xlist[0], (const u64 *)c->d_xlist[1], c->d_lambda,
                      c->d_scalars, c->d_xnode_tot);
   QR_CHECK(c, hipGetLastError());

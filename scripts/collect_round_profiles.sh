@@ -21,6 +21,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o pmc --output-format
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $O/pmc_sq -o pmc --output-format csv -- $B --steps 20 --warmup 5 > /dev/null 2> $O/pmc_sq.err
 python scripts/prof_summary.py $O/prof bench > $O/summary.md 2>&1
 python scripts/prof_summary.py $O/prof8m bench > $O/summary8m.md 2>&1
+python scripts/child_classes.py $O/prof > $O/classes1m.txt 2>&1
+python scripts/child_classes.py $O/prof8m > $O/classes8m.txt 2>&1
+python scripts/doc_batch_bench.py 1 60 2>&1 | grep "per iteration" > $O/doc_protocol.txt
 python scripts/pmc_tables.py hist $O/pmc_fetch $O/pmc_write $O/pmc_hist.json > /dev/null 2> $O/pmc_hist.err
 python scripts/pmc_tables.py lambda $O/pmc_sq $O/lambda_pmc.json > /dev/null 2> $O/pmc_lambda.err
 WB_ITERS=13 WB_NTHR=255,1024,4096,0 python scripts/wide_bench.py > $O/wide_bench.txt 2>&1

@@ -264,6 +264,19 @@ def scoring_metric(ctx, args, torch, rank=0, world=1, dist=None):
     e1.record()
     torch.cuda.synchronize()
     lms = e0.elapsed_time(e1) / reps
+    # ... and with the trees walked AND SUMMED in ascending depth (opt-in: qr_ensemble_set_depth_order;
+    # the f64 sum in another order than ensemble.cc:111-118's: compared with the strict order here)
+    strict = out[:ld].clone()
+    sc.upload_ensemble(ln_, lw_, depth_order=True)
+    run2()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        run2()
+    e1.record()
+    torch.cuda.synchronize()
+    dms = e0.elapsed_time(e1) / reps
+    drel = float(((out[:ld] - strict).abs().max() / strict.abs().mean()).item())   # (against the scores' scale)
     sc.close()
     if dist is not None:
         t = torch.tensor([ms], dtype=torch.float64, device="cuda")
@@ -294,7 +307,13 @@ def scoring_metric(ctx, args, torch, rank=0, world=1, dist=None):
                                             "(this rank's)", "shape": lshape, "ms": lms,
                                 "docs_per_s_per_1000_trees": ld / lms * 1e3 * lt / 1000.0,
                                 "note": "a batch's trees walk in lockstep for as many steps as the deepest has "
-                                        "levels (DESIGN.md 3.6): cost follows the max depth, not the mean path"}}
+                                        "levels (DESIGN.md 3.6): cost follows the max depth, not the mean path",
+                                "depth_order": {"ms": dms, "docs_per_s_per_1000_trees": ld / dms * 1e3 * lt / 1000.0,
+                                                "max_abs_diff_vs_model_order_over_mean_abs_score": drel,
+                                                "what": "opt-in (qr_ensemble_set_depth_order): the trees walked and "
+                                                        "their f64 contributions added in ascending depth, so that a "
+                                                        "batch's trees end together; equal to the model's order to f64 "
+                                                        "rounding, not bit for bit"}}}
 
 
 def tree_shape(t):

@@ -47,6 +47,7 @@ SYMBOLS = [
     "qr_obl_apply", "qr_obl_exchange_buffers", "qr_obl_level_exchange", "qr_prof_lds_atomic",
     "qr_tree_batch_supported", "qr_tree_batch_begin", "qr_tree_batch_root", "qr_tree_batch_apply",
     "qr_tree_batch_decide", "qr_tree_batch_settle", "qr_tree_batch_exchange",
+    "qr_ensemble_set_depth_order",
 ]
 
 _LIB = None
@@ -153,6 +154,7 @@ def lib():
     L.qr_metric_per_query.argtypes = [vp, vp]
     L.qr_ranks_read.argtypes = [vp, vp]
     L.qr_ensemble_upload.argtypes = [vp, vp, sz, sz, vp]
+    L.qr_ensemble_set_depth_order.argtypes = [vp, C.c_int]
     L.qr_ensemble_score.argtypes = [vp, vp, sz, sz, vp, C.POINTER(C.c_float)]
     L.qr_ensemble_score_device.argtypes = [vp, vp, sz, sz, vp]
     L.qr_ensemble_partial_scores.argtypes = [vp, vp, sz, sz, C.c_int, vp]
@@ -597,7 +599,10 @@ class Context:
         return out
 
     # -- inference ------------------------------------------------------------
-    def upload_ensemble(self, nodes, weights):
+    def upload_ensemble(self, nodes, weights, depth_order=False):
+        """depth_order: walk and SUM the trees in ascending depth (faster on leaf-wise trees; the
+        f64 sum in another order than the reference's: equal to rounding, not bit for bit)"""
+        self._ck(self.L.qr_ensemble_set_depth_order(self.h, int(bool(depth_order))))
         nodes = np.ascontiguousarray(nodes)
         assert nodes.dtype == NODE_DTYPE and nodes.ndim == 2
         weights = np.ascontiguousarray(weights, np.float64)

@@ -2031,11 +2031,68 @@ static int build_binned_model(qr_ctx *c, const qr_node_t *nodes, size_t ntrees, 
   return QR_OK;
 }
 
-int qr_ensemble_upload(qr_ctx *c, const qr_node_t *nodes, size_t ntrees,
-                       size_t max_nodes, const double *weights) {
-  if (!c || !nodes || !weights || !ntrees || !max_nodes) return QR_ERR_ARG;
+int qr_ensemble_set_depth_order(qr_ctx *c, int on) {
+  if (!c) return QR_ERR_ARG;
+  c->ens_depth_order = on != 0;
+  return QR_OK;
+}
+
+// levels of a tree's deepest leaf (0: a single leaf); -1 if the links leave the array
+static int tree_depth(const qr_node_t *n, size_t max_nodes) {
+  std::vector<std::pair<int, int>> stack = {{0, 0}};
+  int maxd = 0;
+  size_t seen = 0;
+  while (!stack.empty()) {
+    const auto [i, d] = stack.back();
+    stack.pop_back();
+    if (i < 0 || (size_t)i >= max_nodes || ++seen > max_nodes) return -1;
+    if (n[i].feature >= 0) {
+      maxd = std::max(maxd, d + 1);
+      stack.push_back({n[i].right, d + 1});
+      stack.push_back({n[i].left, d + 1});
+    }
+  }
+  return maxd;
+}
+
+int qr_ensemble_upload(qr_ctx *c, const qr_node_t *nodes_in, size_t ntrees,
+                       size_t max_nodes, const double *weights_in) {
+  if (!c || !nodes_in || !weights_in || !ntrees || !max_nodes) return QR_ERR_ARG;
   QR_CHECK(c, hipSetDevice(c->device));
   QR_CHECK(c, hipStreamSynchronize(c->stream));
+  // Depth order (qr_ensemble_set_depth_order / QR_SCORE_DEPTH_ORDER=1; off by default): the trees
+  // are walked -- and their f64 contributions ADDED -- in ascending order of their depth (stable),
+  // so that the trees a wave walks in lockstep end together.  The sum of ensemble.cc:111-118 is
+  // then taken in another order: equal to the reference's to f64 rounding (~1e-16 relative per
+  // tree, against north_star's 1e-5), not bit for bit.  Partial scores keep the model's columns.
+  const qr_node_t *nodes = nodes_in;
+  const double *weights = weights_in;
+  std::vector<qr_node_t> pn;
+  std::vector<double> pw;
+  c->ens_perm.clear();
+  if (c->ens_depth_order || getenv("QR_SCORE_DEPTH_ORDER")) {
+    std::vector<int> depth(ntrees);
+    bool ok = true, differ = false;
+    for (size_t t = 0; t < ntrees && ok; ++t) {
+      depth[t] = tree_depth(nodes_in + t * max_nodes, max_nodes);
+      ok = depth[t] >= 0;
+      differ = differ || depth[t] != depth[0];
+    }
+    if (ok && differ) {
+      std::vector<uint32_t> perm(ntrees);
+      for (size_t t = 0; t < ntrees; ++t) perm[t] = (uint32_t)t;
+      std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return depth[a] < depth[b]; });
+      pn.resize(ntrees * max_nodes);
+      pw.resize(ntrees);
+      for (size_t t = 0; t < ntrees; ++t) {
+        memcpy(&pn[t * max_nodes], nodes_in + (size_t)perm[t] * max_nodes, max_nodes * sizeof(qr_node_t));
+        pw[t] = weights_in[perm[t]];
+      }
+      nodes = pn.data();
+      weights = pw.data();
+      c->ens_perm = perm;  // position in the walk -> the model's tree
+    }
+  }
   dfree(c->d_ens);
   dfree(c->d_ens_w);
   QR_CHECK(c, dalloc(&c->d_ens, ntrees * max_nodes));
@@ -2130,7 +2187,14 @@ int qr_ensemble_partial_scores(qr_ctx *c, const float *x, size_t N, size_t F, in
     rc = qr_k_ensemble_score(c, d_x, n, Fd, nullptr, d_o, ignore_weights);
     if (rc) break;
     QR_CHECK(c, hipStreamSynchronize(c->stream));
-    QR_CHECK(c, hipMemcpy(out + d0 * T, d_o, n * T * 8, hipMemcpyDeviceToHost));
+    if (c->ens_perm.empty()) {
+      QR_CHECK(c, hipMemcpy(out + d0 * T, d_o, n * T * 8, hipMemcpyDeviceToHost));
+    } else {  // (depth order: the walk's columns back to the model's)
+      std::vector<double> tmp(n * T);
+      QR_CHECK(c, hipMemcpy(tmp.data(), d_o, n * T * 8, hipMemcpyDeviceToHost));
+      for (size_t d = 0; d < n; ++d)
+        for (size_t t = 0; t < T; ++t) out[(d0 + d) * T + c->ens_perm[t]] = tmp[d * T + t];
+    }
   }
   dfree(d_x);
   dfree(d_o);

@@ -362,6 +362,8 @@ struct qr_ctx {
   unsigned long long *d_xpub = nullptr;      // the tiles' published words {epoch : 16, value : 48} (scan tiles, then partition tiles)
   long long *d_xnode_tot = nullptr, *d_xcs = nullptr;  // lazy split search: fixed-point gradient total per node; the winners' cumulative sums per feature
   long long *d_xgbest = nullptr;             // (= d_xtot + 2: best exact score seen per scan row)
+  bool ens_depth_order = false;              // qr_ensemble_set_depth_order: trees walked and summed in ascending depth
+  std::vector<uint32_t> ens_perm;            // ... position in the walk -> the model's tree (empty: the model's order)
   bool spec_exact = false;                   // the pending tree was enqueued by qr_k_exact_fit (tree_settle carries it on with qr_k_exact_continue)
   bool x_eager = false;                      // QR_X_EAGER: both children searched behind every split (the phase API's order)
   void *d_xtbest = nullptr;                  // [2][flocal][scan tiles] best candidate of every tile

@@ -386,6 +386,56 @@ def test_ensemble_scoring_every_record_format(qr, ora, kind):
     c.close()
 
 
+@pytest.mark.parametrize("kind", ["p4", "self8"])
+def test_ensemble_scoring_depth_order_is_a_reordered_sum(qr, kind):
+    """qr_ensemble_set_depth_order (opt-in): the trees are walked and ADDED in ascending order of
+    depth.  Every tree's contribution is the model-order walk's, bit for bit (partial scores,
+    returned in the model's columns); the total is those contributions summed in depth order --
+    restated here -- and equals the model-order total to f64 rounding."""
+    rng = np.random.default_rng(11 if kind == "p4" else 12)
+    F = 37
+    pool = np.unique(rng.standard_normal(200).astype(np.float32))
+    sizes = [1, 64, 2, 40, 3, 17, 64, 100, 5, 128, 9, 33] * 3 + ([300] if kind == "self8" else [])
+    trees = [_random_tree(rng, m, F, pool, chain=(k % 4 == 0 and m <= 40)) for k, m in enumerate(sizes)]
+    maxn = max(len(t) for t in trees)
+    from quickrank_amd._capi import NODE_DTYPE
+    nodes = np.zeros((len(trees), maxn), NODE_DTYPE)
+    nodes["feature"] = -1
+    nodes["left"] = nodes["right"] = -1
+    for k, t in enumerate(trees):
+        nodes[k, :len(t)] = t
+    w = rng.random(len(trees)) + 0.5
+    x = rng.choice(pool, size=(2000, F)).astype(np.float32)
+
+    def depth(t):
+        d, best, stack = 0, 0, [(0, 0)]
+        while stack:
+            i, d = stack.pop()
+            if t[i]["feature"] >= 0:
+                best = max(best, d + 1)
+                stack += [(int(t[i]["left"]), d + 1), (int(t[i]["right"]), d + 1)]
+        return best
+
+    c = qr.Context(0)
+    c.upload_ensemble(nodes, w)
+    strict, _ = c.score(x)
+    per_tree = c.partial_scores(x, len(trees))
+    c.upload_ensemble(nodes, w, depth_order=True)
+    got, _ = c.score(x)
+    per_tree_d = c.partial_scores(x, len(trees))
+    assert np.array_equal(per_tree, per_tree_d)              # the model's columns, the same bits
+    order = sorted(range(len(trees)), key=lambda k: depth(trees[k]))   # (stable)
+    want = np.zeros(len(x))
+    for k in order:
+        want = want + per_tree[:, k]
+    assert np.array_equal(got, want)
+    assert np.allclose(got, strict, rtol=1e-13, atol=1e-13) and not np.array_equal(got, strict)
+    c.upload_ensemble(nodes, w)                               # back to the model's order: bit for bit again
+    again, _ = c.score(x)
+    assert np.array_equal(again, strict)
+    c.close()
+
+
 @pytest.mark.parametrize("F,N,T,leaves", [(1, 1, 1, 2), (2, 63, 15, 5), (3, 65, 16, 8), (5, 129, 17, 3),
                                           (7, 64, 33, 1), (200, 700, 48, 64), (9, 1000, 1, 128)])
 def test_scoring_walk_edge_shapes(qr, F, N, T, leaves):

@@ -348,6 +348,37 @@ def test_config1_mslr_standin_1024_thresholds_vs_oracle(oracle_lib):
     gm.ctx.close()
 
 
+def test_config1_mslr_standin_default_thresholds_vs_oracle(oracle_lib):
+    """The reference's DEFAULT `--num-thresholds 0` (every distinct value a threshold, mart.cc:155-158)
+    on the MSLR-shaped stand-in at full size: rows of ~700k slots, 67 M slots in all -- the
+    pre-sorted lists of k_exact.hip with the split search at the pop (qr_tree_fit) -- against the
+    oracle's slot-indexed histograms: every tree's (feature, slot), node numbering and sample
+    counts, leaf values, the metric per iteration and the final scores."""
+    import torch
+    torch.cuda.init()
+    from datagen import make_mslr_like
+    from parity_util import assert_tree_parity
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_mslr_like()
+    kw = dict(ntrees=4, shrinkage=0.1, nthresholds=0, nleaves=10, minls=1, esr=0)
+    om = oracle_lib.train(x, labels, qoff, algo="LAMBDAMART", **kw)
+    gm = Mart(algo="LAMBDAMART", **kw).learn(x, labels, qoff)
+    assert gm.ctx.wide and len(gm.ensemble) == 4 and int(gm.thr_size.max()) > 100000
+    tr = oracle_lib.Trainer(x, 0)
+    nties = 0
+    for t in range(4):
+        n = int(om["nnodes"][t])
+        nties += int(assert_tree_parity(tr.stmap, om["nodes"][t][:n], gm.ensemble.trees[t][:n], value_rtol=1e-8,
+                                        tie_max_docs=len(labels)))
+    # equal-partition ties (another (feature, slot) that cuts the node's documents into the SAME two
+    # sets, verified by the walker: with every distinct value a threshold and 40 count columns there
+    # are many such pairs; measured 6 in these 36 splits)
+    assert nties <= 12
+    assert np.allclose(gm.train_metric, om["train_metric"], rtol=1e-10, atol=0)
+    assert np.allclose(gm.ctx.get_scores(), om["train_scores"], rtol=1e-8, atol=1e-12)
+    gm.ctx.close()
+
+
 def test_wide_chunked_scan_equals_whole_row_scan(monkeypatch):
     """--num-thresholds 0 on the MSLR-shaped stand-in (rows of up to ~700k slots, 67 M cells per
     node histogram): the chunked scan of long rows (k_wscan_tot / _chunk / _best) leaves the

@@ -874,10 +874,18 @@ def main():
                 r.ctx.prof_enable(False)
                 if pb["launches"]:
                     secb = pb["total_ms"] / pb["launches"] * 1e-3
+                    # (counters cannot be read inside this process: the PMC passes of this workload
+                    # committed under profiles/, quoted only for the workload they were collected on)
+                    tr8 = None
+                    p8 = os.path.join(ROOT, "profiles", f"r04_pmc_hist_{nb}M.json")
+                    if os.path.exists(p8) and F == 136 and args.nthresholds == 255 and not args.sparse_cols:
+                        tr8 = json.load(open(p8)).get("hbm_bytes_per_launch")
                     extras[f"strong_{nb}M"]["roofline"] = {
                         "bound": "hbm", "kernel": "k_hist_root (root histogram build)",
                         "achieved": round(pb["alg_bytes"] / secb / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(pb["alg_bytes"] / secb / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(pb["alg_bytes"] / secb / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr8,
+                        "traffic_source": (f"profiles/r04_pmc_hist_{nb}M.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                           "passes of this workload)") if tr8 else None,
                         "alg_bytes_per_launch": pb["alg_bytes"], "avg_launch_us": round(secb * 1e6, 2),
                         "launches": pb["launches"]}
             r.close()

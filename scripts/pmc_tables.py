@@ -37,9 +37,10 @@ def per_dispatch(rows, counter, with_us=False):
     return sorted((d, k, v) for (d, k), v in out.items())
 
 
-def hist(dir_fetch, dir_write, out):
+def hist(dir_fetch, dir_write, out, millions=1):
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of "
-                     "python bench.py --no-extras --no-cpu-baseline --no-scoring --steps 6 --warmup 2",
+                     "python bench.py --no-extras --no-cpu-baseline --no-scoring --steps 6 --warmup 2"
+                     + (f" --queries {10000 * millions}" if millions != 1 else ""),
            "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads "
                          "(MI355X_MICROARCH.md, HBM section) -> the ROOT launch's read bytes = 2 * FETCH_SIZE * 1024; "
                          "the child launches GATHER 48-byte rows (64-B requests), where the counter is taken at "
@@ -63,9 +64,10 @@ def hist(dir_fetch, dir_write, out):
     if root:
         f = sum(root["FETCH_SIZE"]) / len(root["FETCH_SIZE"])
         w = sum(root["WRITE_SIZE"]) / len(root["WRITE_SIZE"])
-        res.update({"kernel": "k_hist_root (root launch, 1M docs x 136 features)", "FETCH_SIZE_KB": round(f, 1),
+        n = 1000000 * millions
+        res.update({"kernel": f"k_hist_root (root launch, {millions}M docs x 136 features)", "FETCH_SIZE_KB": round(f, 1),
                     "WRITE_SIZE_KB": round(w, 1), "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
-                    "algorithmic_bytes_per_launch": 144557056})
+                    "algorithmic_bytes_per_launch": n * 136 + 8 * n + 136 * 256 * 16})
     classes = []
     tf = tw = 0.0
     ntrees = max(1, len(root.get("FETCH_SIZE", [1])))
@@ -106,6 +108,6 @@ def lam(d, out):
 
 if __name__ == "__main__":
     if sys.argv[1] == "hist":
-        hist(sys.argv[2], sys.argv[3], sys.argv[4])
+        hist(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 1)
     else:
         lam(sys.argv[2], sys.argv[3])

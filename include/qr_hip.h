@@ -140,9 +140,18 @@ int qr_bins_build_with(qr_ctx *ctx, const float *thr, const uint32_t *thr_size);
 /* sharded ones (qr_ctx_set_shard: the rank builds its own feature range, cells_out counts */
 /* its own cells; the phase calls qr_tree_begin / decide / apply / end work unchanged, the   */
 /* go-left mask carries one more word -- qr_exchange_buffers reports the size).  Document-   */
-/* sharded contexts: QR_ERR_UNSUPPORTED.  Everything after the bin build -- lambdas,         */
+/* sharded contexts: qr_bins_build_wide_with.  Everything after the bin build -- lambdas,         */
 /* qr_tree_fit, qr_oblivious_fit, score updates, metrics -- is called as on a u8 context.    */
 int qr_bins_build_wide(qr_ctx *ctx, size_t nthresholds, size_t *cells_out, size_t *max_slots_out);
+/* The same bins for GIVEN thresholds (the wide counterpart of qr_bins_build_with): ragged rows,  */
+/* feature f's thr_size[f] ascending values one after the other, each row ending in FLT_MAX.      */
+/* Single-GPU contexts and DOCUMENT-SHARDED ones (round 4): every rank passes the thresholds of    */
+/* the WHOLE training set -- qr_bins_stats_wide on every rank -> [all_gather] ->                    */
+/* qr_thresholds_from_stats_wide -> here -- and then drives the document-sharded protocol below    */
+/* unchanged (qr_tree_begin / decide / apply: the histogram exchange buffer holds 2 x cells + 2 x   */
+/* world int64, at most 4M cells in all; qr_tree_batch_* and the level-wise calls need u8 bins).   */
+int qr_bins_build_wide_with(qr_ctx *ctx, const float *thr, const uint32_t *thr_size, size_t *cells_out,
+                            size_t *max_slots_out);
 /* thresholds of a binned context (u8 or wide) as ragged rows: thr_out holds              */
 /* sum(thr_size) floats, feature after feature; thr_size_out [F].  NULL = skip.           */
 int qr_thresholds_read(qr_ctx *ctx, float *thr_out, uint32_t *thr_size_out);

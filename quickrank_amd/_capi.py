@@ -47,7 +47,7 @@ SYMBOLS = [
     "qr_obl_apply", "qr_obl_exchange_buffers", "qr_obl_level_exchange", "qr_prof_lds_atomic",
     "qr_tree_batch_supported", "qr_tree_batch_begin", "qr_tree_batch_root", "qr_tree_batch_apply",
     "qr_tree_batch_decide", "qr_tree_batch_settle", "qr_tree_batch_exchange",
-    "qr_ensemble_set_depth_order",
+    "qr_ensemble_set_depth_order", "qr_bins_build_wide_with",
 ]
 
 _LIB = None
@@ -111,6 +111,7 @@ def lib():
     L.qr_bins_build.argtypes = [vp, sz, vp, vp]
     L.qr_bins_read.argtypes = [vp, vp]
     L.qr_bins_build_wide.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz)]
+    L.qr_bins_build_wide_with.argtypes = [vp, vp, vp, C.POINTER(sz), C.POINTER(sz)]
     L.qr_thresholds_read.argtypes = [vp, vp, vp]
     L.qr_bins_read_u32.argtypes = [vp, vp]
     L.qr_node_hist_read_ragged.argtypes = [vp, C.c_int, vp, vp]
@@ -308,6 +309,18 @@ class Context:
         self._ck(self.L.qr_bins_build_wide(self.h, nthresholds, C.byref(cells), C.byref(cap)))
         self.wide = True
         return self.thresholds()
+
+    def build_bins_wide_with(self, thr, ts):
+        """Wide bins for given thresholds: thr [F][cap] padded (or the ragged concatenation), ts [F]
+        -- on a document-sharded context the thresholds of the WHOLE set."""
+        ts = np.ascontiguousarray(ts, np.uint32)
+        thr = np.asarray(thr, np.float32)
+        flat = np.concatenate([thr[f, :ts[f]] for f in range(self.F)]) if thr.ndim == 2 else thr
+        flat = np.ascontiguousarray(flat, np.float32)
+        cells, cap = C.c_size_t(), C.c_size_t()
+        self._ck(self.L.qr_bins_build_wide_with(self.h, _ptr(flat), _ptr(ts), C.byref(cells), C.byref(cap)))
+        self.wide = True
+        return cells.value, cap.value
 
     def thresholds(self):
         """(thr [F][cap] padded with FLT_MAX, thr_size [F]) of a binned context."""

@@ -1310,6 +1310,7 @@ struct DecideState {
   const uint32_t *hcnt_loc;
   QrLocalSplit *loc;
   int flocal;
+  size_t loc_cells;  // wide bins: cells of a node's ragged count arrays (hcnt_loc[slot * cells + woff[f] + t]); 0: [f][256]
 };
 
 __device__ QR_CTRL_FN void heap_push(DecideState &st, double key, int32_t val) {
@@ -1420,8 +1421,9 @@ __device__ __forceinline__ void make_desc(DecideState &st, int node, const float
   L->end = nd->begin + d->lcount;
   if (st.hcnt_loc) {
     // [begin, end) are positions in the rank's own lists; the counts above are global
-    const uint32_t ll =
-        st.hcnt_loc[((size_t)nd->hslot * st.flocal + d->owner_local) * 256 + nd->best_t];
+    const uint32_t ll = thr_off
+        ? st.hcnt_loc[(size_t)nd->hslot * st.loc_cells + thr_off[d->owner_local] + nd->best_t]
+        : st.hcnt_loc[((size_t)nd->hslot * st.flocal + d->owner_local) * 256 + nd->best_t];
     const uint32_t ln = nd->end - nd->begin;
     L->end = nd->begin + ll;
     st.loc->lcount = ll;
@@ -1533,7 +1535,7 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
                             const qr_split_t *featrec, const uint32_t *hcnt_loc, const int docmode,
                             const u64 Nglobal, const long long *tail, const int dworld,
                             const uint32_t mf_k, const u64 mf_seed, const uint32_t F,
-                            const int root_buf, const uint32_t *thr_off) {
+                            const int root_buf, const uint32_t *thr_off, const size_t loc_cells) {
   const bool w0 = threadIdx.x < 64;
   // single GPU (and document-sharded, where every rank scans every feature of
   // the all-reduced histogram): the merge over features happens here (no k_merge
@@ -1559,6 +1561,7 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
   st.hcnt_loc = docmode ? hcnt_loc : nullptr;
   st.loc = &ts->loc;
   st.flocal = flocal;
+  st.loc_cells = loc_cells;
   const int32_t active = ts->desc.active;
   const int root_mode = st.step == 0;
   // everything this step can touch: the live nodes + 2 new ones, the heap + 2
@@ -1651,9 +1654,9 @@ __global__ __launch_bounds__(128) void k_decide(
     const int32_t *__restrict__ gf2lf, const qr_split_t *__restrict__ featrec,
     const uint32_t *__restrict__ hcnt_loc, const int docmode, const u64 Nglobal,
     const long long *__restrict__ tail, const int dworld, const uint32_t mf_k, const u64 mf_seed,
-    const uint32_t F, const int root_buf, const uint32_t *__restrict__ thr_off) {
+    const uint32_t F, const int root_buf, const uint32_t *__restrict__ thr_off, const size_t loc_cells) {
   decide_body(ts, N, flocal, recs, world, scal, part_ss, thr, gf2lf, featrec, hcnt_loc, docmode,
-              Nglobal, tail, dworld, mf_k, mf_seed, F, root_buf, thr_off);
+              Nglobal, tail, dworld, mf_k, mf_seed, F, root_buf, thr_off, loc_cells);
 }
 
 // ===========================================================================
@@ -4341,7 +4344,7 @@ int qr_k_tree_decide(qr_ctx *c) {
   if (c->dmode) {
     // the histogram of this step has just been all-reduced; the first decide of a
     // tree follows the root histogram
-    int rc = launch_scan(c, c->tree_step == 0);
+    int rc = c->wide ? qr_k_wscan_doc(c, c->tree_step == 0) : launch_scan(c, c->tree_step == 0);
     if (rc) return rc;
   }
   // (Letting k_scan's last workgroup take the decision saves this launch but was
@@ -4353,7 +4356,8 @@ int qr_k_tree_decide(qr_ctx *c) {
                      c->d_hcnt_loc, c->dmode, (u64)(c->sub_k ? c->sub_k : c->Nglobal),
                      c->dmode ? c->d_xh + 2 * c->xh_cells : (const long long *)nullptr,
                      c->world, c->mf_k, c->mf_seed + c->tree_counter, (uint32_t)c->F,
-                     c->sub_k ? 0 : 2, c->wide ? c->d_woff : (const uint32_t *)nullptr);
+                     c->sub_k ? 0 : 2, c->wide ? c->d_woff : (const uint32_t *)nullptr,
+                     c->wide ? c->wcells : (size_t)0);
   QR_CHECK(c, hipGetLastError());
   ++c->tree_step;
   if (fshard) {

@@ -203,10 +203,10 @@ __device__ __forceinline__ WSeg w_segment(const QrTreeState *ts, const int mode,
     s.buf = root_buf;
     s.slot = 0;
     s.active = true;
-  } else if (mode == 1) {   // the split being applied
-    s.active = ts->desc.active != 0;
-    s.begin = ts->desc.small_begin;
-    s.n = ts->desc.small_n;
+  } else if (mode == 1 || mode == 4) {   // the split being applied (4: on a document-sharded rank --
+    s.active = ts->desc.active != 0;     // the segment of its OWN lists, QrLocalSplit)
+    s.begin = mode == 4 ? ts->loc.small_begin : ts->desc.small_begin;
+    s.n = mode == 4 ? ts->loc.small_n : ts->desc.small_n;
     s.buf = ts->desc.dst_buf;
     s.slot = ts->desc.small_slot;
   } else {                  // node j of the level (2) / job j of a batched growth step (3)
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(1024) void k_whist(
 // first partial slot (in units of one document range) of node j of the launch: the ranges of
 // the active nodes before it (level-wise growth; a single node otherwise)
 __device__ __forceinline__ uint32_t w16_slot_base(const QrTreeState *ts, const int mode, const uint32_t j) {
-  if (mode < 2) return 0;
+  if (mode < 2 || mode == 4) return 0;
   uint32_t b = 0;
   for (uint32_t k = 0; k < j; ++k) {
     const QrLevelNode &ln = ts->lnode[k];
@@ -996,6 +996,86 @@ static int launch_whist(qr_ctx *c, const int mode, const uint32_t rootn, const i
   return QR_OK;
 }
 
+// ---- document-sharded ranks (round 4): the node histogram of the rank's own documents goes through
+// the exchange buffer -- [cells] sums, [cells] counts as int64, 2 f64 bit patterns per rank, ONE sum
+// all-reduce, as on the u8 path (k_reduce / k_scan in k_tree.hip) -- and comes back as the histogram
+// over ALL ranks' documents, which the scan kernels then treat as on one GPU.
+//   k_wd_pack   (before the all-reduce) one workgroup per feature: the raw cells of the directly
+//               built child -> the buffer; the rank's own CUMULATIVE counts of that child and of
+//               its sibling -> hcnt_loc (where its partition cuts its lists: make_desc);
+//               workgroup 0 also leaves the rank's (sum of squares, sum) of the child in its pair
+//   k_wd_unpack (after) the summed cells -> the child's slot
+__global__ __launch_bounds__(1024) void k_wd_pack(
+    const QrTreeState *__restrict__ ts, const int root_mode, const uint32_t *__restrict__ woff, const size_t cells,
+    const long long *__restrict__ hsum, const uint32_t *__restrict__ hcnt, uint32_t *__restrict__ hcnt_loc,
+    long long *__restrict__ xh, const double *__restrict__ part_ss, const int rank, const int world) {
+  __shared__ long long sh_s[16];
+  __shared__ uint32_t sh_c[16];
+  int small_slot = 0, big_slot = -1, parent_slot = -1;
+  if (!root_mode) {
+    if (!ts->desc.active) return;
+    small_slot = ts->desc.small_slot;
+    big_slot = ts->desc.big_slot;
+    parent_slot = ts->desc.parent_slot;
+  }
+  const uint32_t lf = blockIdx.x, base = woff[lf], size = woff[lf + 1] - base;
+  if (lf == 0 && threadIdx.x < 64) {  // the tail: this rank's pair, zeros elsewhere (sum == gather)
+    double a = 0.0, b = 0.0;
+    if (!root_mode) {
+      const uint32_t nwg = (ts->desc.end - ts->desc.begin + QR_PART_SLICE - 1) / QR_PART_SLICE;
+      for (uint32_t i = threadIdx.x; i < nwg; i += 64) {
+        a += part_ss[2 * i];
+        b += part_ss[2 * i + 1];
+      }
+      a = wave_sum(a);
+      b = wave_sum(b);
+    }
+    long long *tail = xh + 2 * cells;
+    for (int i = threadIdx.x; i < 2 * world; i += 64) {
+      long long v = 0;
+      if (i == 2 * rank) v = __double_as_longlong(a);
+      if (i == 2 * rank + 1) v = __double_as_longlong(b);
+      tail[i] = v;
+    }
+  }
+  const long long *ss = hsum + (size_t)small_slot * cells + base;
+  const uint32_t *sc = hcnt + (size_t)small_slot * cells + base;
+  uint32_t *ls = hcnt_loc + (size_t)small_slot * cells + base;
+  long long carry_s = 0;
+  uint32_t carry_c = 0;
+  for (uint32_t t0 = 0; t0 < size; t0 += 1024) {
+    const uint32_t t = t0 + threadIdx.x;
+    long long s = 0;
+    uint32_t cn = t < size ? sc[t] : 0u;
+    if (t < size) {
+      xh[base + t] = ss[t];
+      xh[cells + base + t] = (long long)cn;
+    }
+    w_block_scan(s, cn, carry_s, carry_c, sh_s, sh_c);
+    if (t < size) {
+      ls[t] = cn;
+      if (!root_mode)
+        hcnt_loc[(size_t)big_slot * cells + base + t] = hcnt_loc[(size_t)parent_slot * cells + base + t] - cn;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wd_unpack(const QrTreeState *__restrict__ ts, const int root_mode,
+                                                   const size_t cells, const long long *__restrict__ xh,
+                                                   long long *__restrict__ hsum, uint32_t *__restrict__ hcnt) {
+  int slot = 0;
+  if (!root_mode) {
+    if (!ts->desc.active) return;
+    slot = ts->desc.small_slot;
+  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (size_t)gridDim.x * 256) {
+    hsum[(size_t)slot * cells + i] = xh[i];
+    hcnt[(size_t)slot * cells + i] = (uint32_t)xh[cells + i];
+  }
+}
+
+static int launch_wscan(qr_ctx *c, int mode);
+
 // mode 0: root histogram -> slot 0; mode 1: the directly built child of the split being
 // applied (+ its sibling); then the per-feature records for k_decide
 int qr_k_whist_scan(qr_ctx *c, int root_mode) {
@@ -1003,15 +1083,36 @@ int qr_k_whist_scan(qr_ctx *c, int root_mode) {
   int rc = whist_attr(c);
   if (rc) return rc;
   const int mode = root_mode ? 0 : 1;
+  const int hmode = !root_mode && c->dmode ? 4 : mode;  // (a document-sharded rank: the segment of its own lists)
   const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_n : c->N);
-  const size_t maxn = root_mode ? rootn : rootn / 2 + 1;  // the smaller child
+  const size_t maxn = root_mode ? rootn : (c->dmode ? rootn : rootn / 2 + 1);  // the smaller child (of ALL ranks' documents)
   if (!qr_k_wide_fast(c)) {  // (the fast rows' reduce writes every cell: nothing to zero)
     const unsigned zg = (unsigned)std::min<size_t>((c->wcells + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_wzero, dim3(zg, 1), dim3(256), 0, c->stream, c->d_tree, mode, c->wcells, c->d_hsum,
+    hipLaunchKernelGGL(k_wzero, dim3(zg, 1), dim3(256), 0, c->stream, c->d_tree, hmode, c->wcells, c->d_hsum,
                        c->d_hcnt);
     QR_CHECK(c, hipGetLastError());
   }
-  if ((rc = launch_whist(c, mode, rootn, c->sub_k ? 0 : 2, maxn, 1))) return rc;
+  if ((rc = launch_whist(c, hmode, rootn, c->sub_k ? 0 : 2, maxn, 1))) return rc;
+  if (c->dmode) {  // the scan follows the all-reduce (qr_k_wscan_doc)
+    hipLaunchKernelGGL(k_wd_pack, dim3((unsigned)c->flocal), dim3(1024), 0, c->stream, c->d_tree, root_mode, c->d_woff,
+                       c->wcells, (const long long *)c->d_hsum, (const uint32_t *)c->d_hcnt, c->d_hcnt_loc, c->d_xh,
+                       c->d_part_ss, c->rank, c->world);
+    QR_CHECK(c, hipGetLastError());
+    return QR_OK;
+  }
+  return launch_wscan(c, mode);
+}
+
+// document-sharded: the all-reduced cells -> the node's slot, then the scan
+int qr_k_wscan_doc(qr_ctx *c, int root_mode) {
+  const unsigned zg = (unsigned)std::min<size_t>((c->wcells + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_wd_unpack, dim3(zg), dim3(256), 0, c->stream, c->d_tree, root_mode, c->wcells,
+                     (const long long *)c->d_xh, c->d_hsum, c->d_hcnt);
+  QR_CHECK(c, hipGetLastError());
+  return launch_wscan(c, root_mode ? 0 : 1);
+}
+
+static int launch_wscan(qr_ctx *c, int mode) {
   const bool no_chunks = getenv("QR_WIDE_NO_CHUNKS") != nullptr;  // (A/B aid: same records either way)
   if (c->wmax <= QR_WCHUNK || no_chunks) {  // short rows: one workgroup per feature
     hipLaunchKernelGGL(k_wscan, dim3((unsigned)c->flocal), dim3(1024), 0, c->stream, c->d_tree, mode,

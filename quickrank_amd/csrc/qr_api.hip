@@ -732,20 +732,51 @@ int qr_bins_build_with(qr_ctx *c, const float *thr, const uint32_t *thr_size) {
 
 // ---- more than 255 thresholds per feature (k_wide.hip) --------------------------
 static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, size_t *cells_out,
-                                size_t *max_slots_out);
+                                size_t *max_slots_out, bool given);
+static int bins_build_wide_any(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t *max_slots_out, bool given);
 
 int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t *max_slots_out) {
   if (!c) return QR_ERR_ARG;
-  if (!c->d_raw) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
-  if (c->binned) QR_FAIL(c, QR_ERR_STATE, "bins already built: upload the dataset again first");
   if (c->dmode)
     QR_FAIL(c, QR_ERR_UNSUPPORTED,
-            "more than 255 thresholds per feature: single-GPU and feature-sharded contexts only (a "
-            "document-sharded histogram of every distinct value would be an all-reduce of 10^7 - 10^8 "
-            "cells per node)");
+            "more than 255 thresholds per feature on a document-sharded context: the thresholds of the WHOLE "
+            "set come first (qr_bins_stats_wide on every rank -> qr_thresholds_from_stats_wide -> "
+            "qr_bins_build_wide_with)");
+  return bins_build_wide_any(c, nthresholds, cells_out, max_slots_out, false);
+}
+
+// the wide bins for GIVEN thresholds: ragged rows, feature f's `thr_size[f]` values (ascending, the
+// last one FLT_MAX) one after the other -- the document-sharded counterpart of qr_bins_build_with
+#define QR_DOC_WIDE_MAX_CELLS ((size_t)4 << 20)   /* cells of an all-reduced node histogram (64 MB of int64) */
+int qr_bins_build_wide_with(qr_ctx *c, const float *thr, const uint32_t *thr_size, size_t *cells_out,
+                            size_t *max_slots_out) {
+  if (!c || !thr || !thr_size) return QR_ERR_ARG;
+  if (c->world > 1 && !c->dmode)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "qr_bins_build_wide_with: single-GPU and document-sharded contexts (a "
+                                   "feature-sharded rank computes its own features' thresholds: qr_bins_build_wide)");
+  size_t cells = 0;
+  for (size_t f = 0; f < c->F; ++f) {
+    if (thr_size[f] < 1 || thr[cells + thr_size[f] - 1] != FLT_MAX)
+      QR_FAIL(c, QR_ERR_ARG, "every threshold row needs at least one slot and ends in FLT_MAX");
+    cells += thr_size[f];
+  }
+  if (cells >= 0xFFFFFFF0ull) QR_FAIL(c, QR_ERR_UNSUPPORTED, "more than 2^32 threshold slots in all");
+  if (c->dmode && cells > QR_DOC_WIDE_MAX_CELLS)
+    QR_FAIL(c, QR_ERR_UNSUPPORTED, "document-sharded contexts all-reduce a node histogram per split: at most 4M "
+                                   "threshold slots in all (use --num-thresholds N, or --shard features)");
+  c->h_wthr.assign(thr, thr + cells);
+  c->h_thr_size.assign(thr_size, thr_size + c->F);
+  c->h_woff.assign(c->F + 1, 0);
+  for (size_t f = 0; f < c->F; ++f) c->h_woff[f + 1] = c->h_woff[f] + thr_size[f];
+  return bins_build_wide_any(c, 0, cells_out, max_slots_out, true);
+}
+
+static int bins_build_wide_any(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t *max_slots_out, bool given) {
+  if (!c->d_raw) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
+  if (c->binned) QR_FAIL(c, QR_ERR_STATE, "bins already built: upload the dataset again first");
   QR_CHECK(c, hipSetDevice(c->device));
   float *d_col = nullptr;
-  const int rc_all = bins_build_wide_impl(c, nthresholds, d_col, cells_out, max_slots_out);
+  const int rc_all = bins_build_wide_impl(c, nthresholds, d_col, cells_out, max_slots_out, given);
   dfree(d_col);  // (whatever happened: the transposed copy is one-time scratch)
   if (rc_all != QR_OK) {
     // nothing half-built stays behind: the wide tables and the tree working set go, the
@@ -770,14 +801,14 @@ int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t 
 }
 
 static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, size_t *cells_out,
-                                size_t *max_slots_out) {
+                                size_t *max_slots_out, bool given) {
   const size_t N = c->N, F = c->F;
   {
-    // the rank's own features: all of them on one GPU, the contiguous range
-    // [r ceil(F / world), (r + 1) ceil(F / world)) on a feature-sharded context (as the u8 path)
-    const size_t fworld = (size_t)c->world;
+    // the rank's own features: all of them on one GPU and on a document-sharded rank, the contiguous
+    // range [r ceil(F / world), (r + 1) ceil(F / world)) on a feature-sharded context (as the u8 path)
+    const size_t fworld = c->dmode ? 1 : (size_t)c->world;
     const size_t per_rank = (F + fworld - 1) / fworld;
-    const size_t f0 = std::min(F, per_rank * (size_t)c->rank), f1 = std::min(F, f0 + per_rank);
+    const size_t f0 = std::min(F, per_rank * (c->dmode ? 0 : (size_t)c->rank)), f1 = std::min(F, f0 + per_rank);
     if (f1 <= f0) QR_FAIL(c, QR_ERR_ARG, "this rank owns no feature (world > F)");
     c->blocks.clear();   // no u8 blocks
     c->nblocks = 0;
@@ -795,7 +826,7 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
   }
   QR_CHECK(c, dalloc(&d_col, N * F));
   int rc = qr_k_transpose(c, c->d_raw, d_col, N, F);
-  if (!rc) rc = qr_k_wide_thresholds(c, d_col, nthresholds);
+  if (!rc && !given) rc = qr_k_wide_thresholds(c, d_col, nthresholds);  // (given: h_wthr / h_woff / h_thr_size are set)
   if (rc) return rc;
   c->wcells = c->h_wthr.size();
   c->wmax = 0;
@@ -869,6 +900,17 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
   }
   QR_CHECK(c, dalloc(&c->d_leafpart, std::max<size_t>(2 * (N / QR_SLICE + QR_MAXNODES + 4), 32 * (N / QR_SLICE + 2))));
   QR_CHECK(c, dalloc(&c->d_leafb, N + 16));
+  if (c->dmode) {
+    // the histogram exchange buffer of the document-sharded protocol: [cells] sums, [cells] counts
+    // (int64), 2 doubles per rank -- ONE sum all-reduce per node histogram, as on the u8 path
+    dfree(c->d_xh); dfree(c->d_xscal);
+    c->xh_cells = c->wcells;
+    c->xh_len = 2 * c->wcells + 2 * (size_t)c->world;
+    QR_CHECK(c, dalloc(&c->d_xh, c->xh_len));
+    QR_CHECK(c, hipMemset(c->d_xh, 0, c->xh_len * 8));
+    QR_CHECK(c, dalloc(&c->d_xscal, 4 * (size_t)c->world));
+    QR_CHECK(c, hipMemset(c->d_xscal, 0, 4 * (size_t)c->world * 8));
+  }
   c->wide = true;
   c->binned = true;
   if (cells_out) *cells_out = c->wcells;
@@ -1148,7 +1190,7 @@ static int ensure_hist_slots(qr_ctx *c, size_t slots) {
   QR_CHECK(c, dalloc(&c->d_hcnt, slots * per_slot));
   if (c->dmode) {
     dfree(c->d_hcnt_loc);
-    QR_CHECK(c, dalloc(&c->d_hcnt_loc, slots * c->flocal * 256));
+    QR_CHECK(c, dalloc(&c->d_hcnt_loc, slots * per_slot));
   }
   c->hist_slots = slots;
   return QR_OK;

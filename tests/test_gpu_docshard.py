@@ -590,3 +590,60 @@ def test_doc_sharded_batched_equals_one_split_protocol():
         assert np.allclose(ca.get_scores(), cb.get_scores(), rtol=1e-10, atol=1e-13)
         ca.close()
         cb.close()
+
+
+@pytest.mark.parametrize("world,cuts,nthr,F,minls", [
+    (2, [30], 1024, 40, 2),              # rows of up to 1025 slots: the LDS-tiled histogram kernel
+    (3, [5, 41], 0, 24, 1),              # every distinct value a threshold (rows of ~3000 slots), a small first shard
+    (4, [15, 30, 45], 4096, 20, 2),      # the general histogram kernel, the chunked scan
+])
+def test_doc_sharded_wide_bins_equal_single(world, cuts, nthr, F, minls):
+    """More than 255 thresholds per feature on document shards (round 4): every rank bins its own
+    documents against the thresholds of the WHOLE set (qr_bins_build_wide_with) and the node
+    histograms -- ragged rows -- go through the same ONE int64 all-reduce per split.  Trees: the
+    single wide context's structure bit for bit, values to f64 rounding; every rank the same bits."""
+    import torch
+    import quickrank_amd as qr
+    x, labels, qoff = make_dataset(nq=60, docs_per_query=50, F=F, seed=47, adversarial=(nthr != 0))
+    N, Q = len(labels), len(qoff) - 1
+    single = qr.Context(0)
+    single.upload(x, labels, qoff)
+    thr, ts = single.build_bins(nthr, wide=True)
+    single.reset_scores()
+    parts = _split_queries(qoff, cuts)
+    ctxs = []
+    for r, (q0, q1) in enumerate(parts):
+        d0, d1 = int(qoff[q0]), int(qoff[q1])
+        c = qr.Context(0, rank=r, world=world, doc_shard=(N, Q))
+        c.upload(x[d0:d1], labels[d0:d1], qoff[q0:q1 + 1] - qoff[q0])
+        c.build_bins_wide_with(thr, ts)
+        assert np.array_equal(c.read_bins_u32(), single.read_bins_u32()[d0:d1])
+        c.reset_scores()
+        ctxs.append(c)
+    emu = _Emu(torch, ctxs)
+    for it in range(4):
+        single.compute_lambdas("NDCG", 10)
+        want = single.fit_tree(8, minls, True)
+        single.update_scores(0.1)
+        for c in ctxs:
+            c.compute_lambdas("NDCG", 10)
+        emu.allreduce("scal")
+        for c in ctxs:
+            c.lambda_finish()
+        got = _doc_fit(emu, ctxs, 8, minls, True)
+        for c in ctxs:
+            c.update_scores(0.1)
+        for g in got:
+            assert len(g) == len(want), it
+            for k in ("feature", "thr_id", "left", "right", "nsamples", "threshold"):
+                assert np.array_equal(g[k], want[k]), (it, k)
+            assert np.allclose(g["value"], want["value"], rtol=1e-11, atol=1e-14), it
+        for g in got[1:]:
+            for k in want.dtype.names:
+                assert np.array_equal(g[k], got[0][k]), (it, k)
+    s1 = single.get_scores()
+    for c, (q0, q1) in zip(ctxs, parts):
+        d0, d1 = int(qoff[q0]), int(qoff[q1])
+        assert np.allclose(c.get_scores(), s1[d0:d1], rtol=1e-10, atol=1e-13)
+        c.close()
+    single.close()

@@ -152,6 +152,19 @@ int qr_bins_build_wide(qr_ctx *ctx, size_t nthresholds, size_t *cells_out, size_
 /* world int64, at most 4M cells in all; qr_tree_batch_* and the level-wise calls need u8 bins).   */
 int qr_bins_build_wide_with(qr_ctx *ctx, const float *thr, const uint32_t *thr_size, size_t *cells_out,
                             size_t *max_slots_out);
+/* Column statistics of this rank's documents for those thresholds (mart.cc:136-152 on its shard): */
+/* vals_out u32 [F][limit] = the first `limit` distinct values of every column in sorted order (raw */
+/* f32 bits), cnt_out [F] = how many there are (limit + 1: more than `limit`), minmax_out [F][2] =  */
+/* the radix keys (radix.cc:28-30) of the smallest / largest value.  limit = nthresholds + 1, or     */
+/* the most distinct values per column the caller will gather when nthresholds == 0.                 */
+int qr_bins_stats_wide(qr_ctx *ctx, size_t limit, uint32_t *vals_out, uint32_t *cnt_out, uint32_t *minmax_out);
+/* mart.cc:140-169 over the union of `nranks` ranks' statistics ([rank][F][limit] etc., as gathered): */
+/* ragged rows into thr_out (thr_cap floats; NULL: sizes only), thr_size_out [F], *cells_out = their   */
+/* total.  QR_ERR_UNSUPPORTED: nthresholds == 0 and a column with more than `limit` distinct values.   */
+/* Pure host code: no context, no GPU.                                                                 */
+int qr_thresholds_from_stats_wide(size_t F, size_t nthresholds, size_t nranks, size_t limit,
+                                  const uint32_t *vals, const uint32_t *cnt, const uint32_t *minmax,
+                                  float *thr_out, size_t thr_cap, uint32_t *thr_size_out, size_t *cells_out);
 /* thresholds of a binned context (u8 or wide) as ragged rows: thr_out holds              */
 /* sum(thr_size) floats, feature after feature; thr_size_out [F].  NULL = skip.           */
 int qr_thresholds_read(qr_ctx *ctx, float *thr_out, uint32_t *thr_size_out);

@@ -48,6 +48,7 @@ SYMBOLS = [
     "qr_tree_batch_supported", "qr_tree_batch_begin", "qr_tree_batch_root", "qr_tree_batch_apply",
     "qr_tree_batch_decide", "qr_tree_batch_settle", "qr_tree_batch_exchange",
     "qr_ensemble_set_depth_order", "qr_bins_build_wide_with",
+    "qr_bins_stats_wide", "qr_thresholds_from_stats_wide",
 ]
 
 _LIB = None
@@ -112,6 +113,8 @@ def lib():
     L.qr_bins_read.argtypes = [vp, vp]
     L.qr_bins_build_wide.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz)]
     L.qr_bins_build_wide_with.argtypes = [vp, vp, vp, C.POINTER(sz), C.POINTER(sz)]
+    L.qr_bins_stats_wide.argtypes = [vp, sz, vp, vp, vp]
+    L.qr_thresholds_from_stats_wide.argtypes = [sz, sz, sz, sz, vp, vp, vp, vp, sz, vp, C.POINTER(sz)]
     L.qr_thresholds_read.argtypes = [vp, vp, vp]
     L.qr_bins_read_u32.argtypes = [vp, vp]
     L.qr_node_hist_read_ragged.argtypes = [vp, C.c_int, vp, vp]
@@ -205,6 +208,28 @@ def thresholds_from_stats(F, nthresholds, vals, cnt, mm):
         raise QrError(f"qr_thresholds_from_stats failed (code {rc}): nthresholds == 0 needs "
                       "<= 255 distinct values per feature")
     return thr, ts
+
+
+def thresholds_from_stats_wide(F, nthresholds, limit, vals, cnt, mm):
+    """Ragged thresholds (flat f32, thr_size [F]) of the union of the ranks' shards, more than 255
+    per feature allowed (mart.cc:140-169); vals/cnt/mm: Context.bins_stats_wide stacked on axis 0."""
+    vals = np.ascontiguousarray(vals, np.uint32)
+    cnt = np.ascontiguousarray(cnt, np.uint32)
+    mm = np.ascontiguousarray(mm, np.uint32)
+    nranks = cnt.shape[0]
+    ts = np.empty(F, np.uint32)
+    cells = C.c_size_t()
+    rc = lib().qr_thresholds_from_stats_wide(F, nthresholds, nranks, limit, _ptr(vals), _ptr(cnt), _ptr(mm),
+                                             None, 0, _ptr(ts), C.byref(cells))
+    if rc:
+        raise QrError(f"qr_thresholds_from_stats_wide failed (code {rc}): nthresholds == 0 with a column of "
+                      f"more than {limit} distinct values")
+    flat = np.empty(cells.value, np.float32)
+    rc = lib().qr_thresholds_from_stats_wide(F, nthresholds, nranks, limit, _ptr(vals), _ptr(cnt), _ptr(mm),
+                                             _ptr(flat), cells.value, _ptr(ts), C.byref(cells))
+    if rc:
+        raise QrError(f"qr_thresholds_from_stats_wide failed (code {rc})")
+    return flat, ts
 
 
 class Context:
@@ -350,6 +375,14 @@ class Context:
         self._ck(self.L.qr_node_hist_read_ragged(self.h, node, _ptr(s), _ptr(c)))
         off = np.concatenate([[0], np.cumsum(ts)]).astype(np.int64)
         return [s[off[f]:off[f + 1]] for f in range(self.F)], [c[off[f]:off[f + 1]] for f in range(self.F)]
+
+    def bins_stats_wide(self, limit):
+        """Column statistics for more than 255 thresholds per feature (see qr_bins_stats_wide)."""
+        vals = np.zeros((self.F, limit), np.uint32)
+        cnt = np.zeros(self.F, np.uint32)
+        mm = np.zeros((self.F, 2), np.uint32)
+        self._ck(self.L.qr_bins_stats_wide(self.h, limit, _ptr(vals), _ptr(cnt), _ptr(mm)))
+        return vals, cnt, mm
 
     def bins_stats(self, nthresholds):
         """Column statistics of this rank's documents (see qr_bins_stats)."""

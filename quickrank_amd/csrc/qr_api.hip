@@ -745,6 +745,71 @@ int qr_bins_build_wide(qr_ctx *c, size_t nthresholds, size_t *cells_out, size_t 
   return bins_build_wide_any(c, nthresholds, cells_out, max_slots_out, false);
 }
 
+// ---- thresholds of a document-sharded set with more than 255 of them per feature -----------------
+int qr_bins_stats_wide(qr_ctx *c, size_t limit, uint32_t *vals_out, uint32_t *cnt_out, uint32_t *minmax_out) {
+  if (!c || !vals_out || !cnt_out || !minmax_out || !limit) return QR_ERR_ARG;
+  if (!c->d_raw) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
+  QR_CHECK(c, hipSetDevice(c->device));
+  float *d_col = nullptr;
+  QR_CHECK(c, dalloc(&d_col, c->N * c->F + 1));
+  int rc = c->N ? qr_k_transpose(c, c->d_raw, d_col, c->N, c->F) : QR_OK;
+  if (!rc) rc = qr_k_wide_stats(c, d_col, limit, vals_out, cnt_out, minmax_out);
+  dfree(d_col);
+  return rc;
+}
+
+// mart.cc:140-169 over the union of `nranks` shards' column statistics (qr_bins_stats_wide with
+// limit = nthresholds + 1, or the caller's bound on distinct values when nthresholds == 0): the
+// distinct values themselves while there are at most `nthresholds` of them (or nthresholds == 0),
+// else `nthresholds` equal steps from the set's minimum, a running f32 sum; every row ends in
+// FLT_MAX.  thr_out: ragged rows one after the other (thr_cap floats); pure host code.
+int qr_thresholds_from_stats_wide(size_t F, size_t nthresholds, size_t nranks, size_t limit, const uint32_t *vals,
+                                  const uint32_t *cnt, const uint32_t *minmax, float *thr_out, size_t thr_cap,
+                                  uint32_t *thr_size_out, size_t *cells_out) {
+  if (!vals || !cnt || !minmax || !thr_size_out || !nranks || !limit) return QR_ERR_ARG;
+  size_t o = 0;
+  auto put = [&](float v) {
+    if (thr_out && o < thr_cap) thr_out[o] = v;
+    ++o;
+  };
+  for (size_t f = 0; f < F; ++f) {
+    bool equal_width = false;
+    std::vector<uint32_t> keys;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+    for (size_t r = 0; r < nranks; ++r) {
+      const uint32_t n = cnt[r * F + f];
+      if (n > limit) equal_width = true;   // (this shard alone has more than `limit` distinct values)
+      if (n) {
+        kmin = std::min(kmin, minmax[(r * F + f) * 2]);
+        kmax = std::max(kmax, minmax[(r * F + f) * 2 + 1]);
+      }
+      for (uint32_t i = 0; i < std::min<size_t>(n, limit); ++i) keys.push_back(h_flip(vals[(r * F + f) * limit + i]));
+    }
+    std::vector<float> uniqs;
+    if (!equal_width) {
+      std::sort(keys.begin(), keys.end());  // radix order (radix.cc:28-30)
+      for (uint32_t k : keys) {
+        const float v = bits2f(h_unflip(k));
+        if (uniqs.empty() || uniqs.back() < v) uniqs.push_back(v);  // mart.cc:149-151
+      }
+      if (nthresholds && uniqs.size() > nthresholds) equal_width = true;
+    }
+    const size_t o0 = o;
+    if (!equal_width) {
+      for (float v : uniqs) put(v);
+    } else {
+      if (nthresholds == 0) return QR_ERR_UNSUPPORTED;  // more distinct values than the caller gathered
+      float t = bits2f(h_unflip(kmin));
+      const float step = (float)fabs(bits2f(h_unflip(kmax)) - t) / nthresholds;  // mart.cc:164-165
+      for (size_t j = 0; j != nthresholds; t += step, ++j) put(t);
+    }
+    put(FLT_MAX);
+    thr_size_out[f] = (uint32_t)(o - o0);
+  }
+  if (cells_out) *cells_out = o;
+  return thr_out && o > thr_cap ? QR_ERR_ARG : QR_OK;
+}
+
 // the wide bins for GIVEN thresholds: ragged rows, feature f's `thr_size[f]` values (ascending, the
 // last one FLT_MAX) one after the other -- the document-sharded counterpart of qr_bins_build_with
 #define QR_DOC_WIDE_MAX_CELLS ((size_t)4 << 20)   /* cells of an all-reduced node histogram (64 MB of int64) */

@@ -601,6 +601,7 @@ bool qr_k_wide_batch_ok(const qr_ctx *c);
 int qr_k_whist_scan_batch(qr_ctx *c, const QrTreeState *ts, const double *pss);
 int qr_k_whist_scan(qr_ctx *c, int root_mode);
 int qr_k_exact_build(qr_ctx *c);
+int qr_k_wide_stats(qr_ctx *c, const float *d_col, size_t limit, uint32_t *vals, uint32_t *cnt, uint32_t *mm);
 int qr_k_wscan_doc(qr_ctx *c, int root_mode);   // document-sharded wide bins: all-reduced cells -> slot, scan
 int qr_k_exact_scan(qr_ctx *c, int root_mode);
 int qr_k_exact_fit(qr_ctx *c, size_t nleaves, uint64_t minls);        // lazy split search: the whole tree enqueued

@@ -454,6 +454,32 @@ def gather_thresholds(ctx, nthresholds, group=None):
                                  np.stack([p[1] for p in parts]), np.stack([p[2] for p in parts]))
 
 
+def build_doc_bins(ctx, nthresholds, group=None, distinct_limit=65536):
+    """Mart::init on a document-sharded rank: the thresholds of the WHOLE training set from every
+    rank's column statistics, then this rank's bins.  Up to 255 thresholds per feature take the u8
+    path; more -- nthresholds > 255, or 0 on a column with more distinct values -- the wide one
+    (ragged rows; `distinct_limit` bounds the distinct values gathered per column when
+    nthresholds == 0).  Returns (thresholds, thr_size) as Context.thresholds() does."""
+    import torch.distributed as dist
+    from ._capi import QrError, thresholds_from_stats_wide
+    if 0 <= nthresholds <= 255:
+        try:
+            ctx.build_bins_with(*gather_thresholds(ctx, nthresholds, group))
+            return ctx.thresholds()
+        except QrError:
+            if nthresholds != 0:
+                raise
+    limit = nthresholds + 1 if nthresholds else distinct_limit
+    vals, cnt, mm = ctx.bins_stats_wide(limit)
+    world = dist.get_world_size(group)
+    parts = [None] * world
+    dist.all_gather_object(parts, (vals, cnt, mm), group=group)
+    flat, ts = thresholds_from_stats_wide(ctx.F, nthresholds, limit, np.stack([p[0] for p in parts]),
+                                          np.stack([p[1] for p in parts]), np.stack([p[2] for p in parts]))
+    ctx.build_bins_wide_with(flat, ts)
+    return ctx.thresholds()
+
+
 def owned_features(F, rank, world):
     """Global feature indices rank owns (same rule as qr_ctx_set_shard)."""
     per = (F + world - 1) // world

@@ -136,11 +136,13 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
   // them (every rank holds the whole rows of its own features; round 3).  A document-sharded
   // histogram of every distinct value would be an all-reduce of 10^7 - 10^8 cells per node, and the
   // level-wise phase calls use u8 bins: both refused.
+  // (round 4: document shards take them too -- the thresholds of the whole set from every rank's
+  // column statistics, qr_bins_build_wide_with -- while a node histogram stays within 4M cells)
   const bool many = nthresholds_ > 255 || nthresholds_ == 0;
-  if ((max_features_ != 1.0f && obliv) || (many && (!feature_sharded || obliv))) {
+  if ((max_features_ != 1.0f && obliv) || (many && obliv)) {
     if (many)
-      std::cerr << "!!! --gpus > 1 with --num-thresholds 0 or above 255 needs --shard features and MART / "
-                   "LAMBDAMART (document sharding and oblivious trees take --num-thresholds in [1, 255])."
+      std::cerr << "!!! --gpus > 1 with --num-thresholds 0 or above 255 needs MART / LAMBDAMART (sharded oblivious "
+                   "trees take --num-thresholds in [1, 255])."
                 << std::endl;
     else
       std::cerr << "!!! --max-features applies to MART / LAMBDAMART." << std::endl;
@@ -163,7 +165,8 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
   for (int r = 0; r < W; ++r) devs[r] = r;
   NCCL(ncclCommInitAll(comms.data(), W, devs.data()));
   Shared sh(W);
-  const uint32_t limit = (uint32_t)nthresholds_ + 1;
+  // (qr_bins_stats: nthresholds + 1 distinct values per column, 256 of them for --num-thresholds 0)
+  const uint32_t limit = nthresholds_ ? (uint32_t)std::min<size_t>(nthresholds_, 255) + 1 : 256u;
   if (!feature_sharded) {
     sh.vals.assign((size_t)W * F * (limit + 1), 0);
     sh.cnt.assign((size_t)W * F, 0);
@@ -236,15 +239,52 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       else if (brc != QR_OK)
         die(c, "qr_bins_build");
     } else {
-      QRM(c, qr_bins_stats(c, nthresholds_, &sh.vals[(size_t)r * F * (limit + 1)], &sh.cnt[(size_t)r * F],
-                           &sh.mm[(size_t)r * 2 * F]));
-      sh.bar.wait();
-      std::vector<float> thr(F * QR_MAX_BINS);
-      std::vector<uint32_t> ts(F);
-      if (qr_thresholds_from_stats(F, nthresholds_, W, sh.vals.data(), sh.cnt.data(), sh.mm.data(), thr.data(),
-                                   ts.data()) != QR_OK)
-        die(c, "qr_thresholds_from_stats");
-      QRM(c, qr_bins_build_with(c, thr.data(), ts.data()));
+      // up to 255 thresholds per feature: u8 bins; more (or --num-thresholds 0 on a column with more
+      // distinct values): ragged rows.  Every rank computes the same thresholds from everybody's
+      // statistics, so every rank takes the same branch.
+      bool wide = nthresholds_ > 255;
+      if (!wide) {
+        QRM(c, qr_bins_stats(c, nthresholds_, &sh.vals[(size_t)r * F * (limit + 1)], &sh.cnt[(size_t)r * F],
+                             &sh.mm[(size_t)r * 2 * F]));
+        sh.bar.wait();
+        std::vector<float> thr(F * QR_MAX_BINS);
+        std::vector<uint32_t> ts(F);
+        const int trc = qr_thresholds_from_stats(F, nthresholds_, W, sh.vals.data(), sh.cnt.data(), sh.mm.data(),
+                                                 thr.data(), ts.data());
+        if (trc == QR_OK)
+          QRM(c, qr_bins_build_with(c, thr.data(), ts.data()));
+        else if (trc == QR_ERR_UNSUPPORTED && nthresholds_ == 0)
+          wide = true;   // a column with more than 255 distinct values
+        else
+          die(c, "qr_thresholds_from_stats");
+        sh.bar.wait();   // (everybody has read the statistics before the wide ones overwrite them)
+      }
+      if (wide) {
+        const size_t wl = nthresholds_ ? nthresholds_ + 1 : (size_t)65536;
+        if (r == 0) {
+          sh.vals.assign((size_t)W * F * wl, 0);
+          sh.cnt.assign((size_t)W * F, 0);
+          sh.mm.assign((size_t)W * 2 * F, 0);
+        }
+        sh.bar.wait();
+        QRM(c, qr_bins_stats_wide(c, wl, &sh.vals[(size_t)r * F * wl], &sh.cnt[(size_t)r * F],
+                                  &sh.mm[(size_t)r * 2 * F]));
+        sh.bar.wait();
+        std::vector<uint32_t> ts(F);
+        size_t cells = 0;
+        if (qr_thresholds_from_stats_wide(F, nthresholds_, W, wl, sh.vals.data(), sh.cnt.data(), sh.mm.data(),
+                                          nullptr, 0, ts.data(), &cells) != QR_OK) {
+          if (r == 0)
+            std::cerr << "!!! --shard docs with --num-thresholds 0: a column has more than 65536 distinct values "
+                         "(use --num-thresholds N or --shard features)." << std::endl;
+          fatal_exit();
+        }
+        std::vector<float> thr(cells);
+        if (qr_thresholds_from_stats_wide(F, nthresholds_, W, wl, sh.vals.data(), sh.cnt.data(), sh.mm.data(),
+                                          thr.data(), cells, ts.data(), &cells) != QR_OK)
+          die(c, "qr_thresholds_from_stats_wide");
+        QRM(c, qr_bins_build_wide_with(c, thr.data(), ts.data(), nullptr, nullptr));
+      }
     }
     QRM(c, qr_scores_reset(c));
     if (first) {

@@ -80,7 +80,7 @@ def main():
         build.build_host()
     dist.barrier()
     from quickrank_amd._capi import Context, NODE_DTYPE
-    from quickrank_amd.dist import DocShardedTrainer, gather_thresholds
+    from quickrank_amd.dist import DocShardedTrainer, build_doc_bins
     host = C.CDLL(build.HOST_LIB)
     sz = C.c_size_t
     host.qrh_svml_read.argtypes = [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.c_void_p,
@@ -100,7 +100,7 @@ def main():
             vx = np.pad(vx, ((0, 0), (0, F - vx.shape[1])))
         ctx.upload_valid(*shard(vx[:, :F], vl, vq, rank, world))
     del x
-    ctx.build_bins_with(*gather_thresholds(ctx, a.num_thresholds))
+    build_doc_bins(ctx, a.num_thresholds)    # (u8 bins up to 255 thresholds per feature, ragged rows beyond)
     ctx.reset_scores()
     tr = DocShardedTrainer(ctx)
     lam = a.algo == "LAMBDAMART"

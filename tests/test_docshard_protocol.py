@@ -206,3 +206,55 @@ def test_thresholds_from_stats_symbol_is_pure_host():
     assert np.array_equal(ts, ots.astype(np.uint32))
     for f in range(F):
         assert np.array_equal(thr[f, :ts[f]], othr[f, :ts[f]]), f
+
+
+@pytest.mark.parametrize("nthr", [300, 1024, 0])
+def test_wide_thresholds_from_stats_are_the_whole_sets(nthr):
+    """qr_thresholds_from_stats_wide (pure host code): merging the ranks' sorted distinct values /
+    min / max gives the thresholds mart.cc:140-169 computes on the whole set -- the distinct values
+    where there are at most `nthr` of them (or nthr == 0), `nthr` equal f32 steps otherwise."""
+    import oracle
+    from quickrank_amd import build
+    from quickrank_amd._capi import thresholds_from_stats_wide
+    if not os.path.exists(build.LIB):
+        pytest.skip("HIP library not built")
+    oracle.build(ref=False)
+    rng = np.random.default_rng(3)
+    F, N = 7, 3000
+    x = rng.standard_normal((N, F)).astype(np.float32)
+    x[:, 1] = np.floor(x[:, 1] * 40)                 # ~250 distinct values: below 300, above 255
+    x[:, 2] = 0.25                                   # constant
+    x[:1000, 3] = np.floor(x[:1000, 3] * 3)          # few distinct values on one shard only
+    x[:, 4] = np.where(rng.random(N) < 0.5, -0.0, 0.0)   # one value by `<` (mart.cc:149-151)
+    x[:, 5] = np.floor(rng.random(N) * 900)          # more than 255, fewer than 1024
+    limit = nthr + 1 if nthr else 4096
+    cuts = [0, 1000, 1700, N]
+
+    def flip(u):                                     # radix key (radix.cc:28-30)
+        return np.where(u >> 31, ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+
+    vals = np.zeros((3, F, limit), np.uint32)
+    cnt = np.zeros((3, F), np.uint32)
+    mm = np.zeros((3, F, 2), np.uint32)
+    for r in range(3):
+        part = x[cuts[r]:cuts[r + 1]]
+        for f in range(F):
+            keys = np.sort(flip(part[:, f].view(np.uint32)))
+            col = np.where(keys >> 31, keys & np.uint32(0x7FFFFFFF), ~keys).astype(np.uint32).view(np.float32)
+            u = [col[0]]
+            for v in col[1:]:                        # what qr_bins_stats_wide keeps: strict `<` on the sorted column
+                if u[-1] < v:
+                    u.append(v)
+                if len(u) > limit:
+                    break
+            k = min(len(u), limit)
+            vals[r, f, :k] = np.array(u[:k], np.float32).view(np.uint32)
+            cnt[r, f] = min(len(u), limit + 1)
+            mm[r, f] = [keys[0], keys[-1]]
+    flat, ts = thresholds_from_stats_wide(F, nthr, limit, vals, cnt, mm)
+    othr, ots = oracle.thresholds(np.ascontiguousarray(x.T), nthr)
+    assert np.array_equal(ts, ots.astype(np.uint32))
+    o = 0
+    for f in range(F):
+        assert np.array_equal(flat[o:o + ts[f]].view(np.uint32), othr[f, :ts[f]].view(np.uint32)), f
+        o += int(ts[f])

@@ -439,8 +439,8 @@ def test_quicklearn_gpus_features_oblivious_and_subsample(tools, tmp_path, extra
 def test_quicklearn_gpus_features_with_the_reference_default_thresholds(tools, tmp_path, nthr):
     """`--num-thresholds 0` -- QuickRank's default: every distinct value a threshold -- and values
     above 255 on the multi-GPU host (missing 2): `--shard features` takes the wide
-    bins (one rank here: the model must be the single-GPU one); `--shard docs` refuses with a
-    message that says what to use instead."""
+    bins, and since round 4 so does `--shard docs` (the thresholds of the whole set from every
+    rank's column statistics; one rank here): the model must be the single-GPU one either way."""
     x, labels, qoff = make_dataset(nq=100, docs_per_query=40, F=20, seed=75)
     tr = str(tmp_path / "train.svml")
     _write_svml(tr, x, labels, qoff)
@@ -459,6 +459,19 @@ def test_quicklearn_gpus_features_with_the_reference_default_thresholds(tools, t
         assert np.array_equal(n1[k], n2[k]), k
     assert np.array_equal(n1["threshold"].view(np.uint32), n2["threshold"].view(np.uint32))
     assert np.allclose(n1["value"], n2["value"], rtol=1e-9, atol=1e-12)
-    r = subprocess.run([tools["quicklearn"]] + base + ["--model-out", m2, "--gpus", "1", "--shard", "docs"],
+    m3 = str(tmp_path / "docs.xml")
+    r = subprocess.run([tools["quicklearn"]] + base + ["--model-out", m3, "--gpus", "1", "--shard", "docs"],
                        capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "--shard features" in r.stderr
+    assert r.returncode == 0, r.stdout + r.stderr
+    n3, w3 = _load_model(tools, m3)
+    assert n1.shape == n3.shape and np.array_equal(w1, w3)
+    for k in ("feature", "left", "right"):
+        assert np.array_equal(n1[k], n3[k]), k
+    assert np.array_equal(n1["threshold"].view(np.uint32), n3["threshold"].view(np.uint32))
+    assert np.allclose(n1["value"], n3["value"], rtol=1e-9, atol=1e-12)
+    # oblivious trees on sharded contexts keep u8 bins: refused with a message
+    o = subprocess.run([tools["quicklearn"]] + ["--algo", "OBVLAMBDAMART", "--train", tr, "--num-trees", "2",
+                                                "--tree-depth", "3", "--num-thresholds", nthr, "--gpus", "1",
+                                                "--shard", "docs", "--model-out", m3],
+                       capture_output=True, text=True, timeout=300)
+    assert o.returncode != 0 and "num-thresholds" in o.stderr

@@ -647,3 +647,44 @@ def test_doc_sharded_wide_bins_equal_single(world, cuts, nthr, F, minls):
         assert np.allclose(c.get_scores(), s1[d0:d1], rtol=1e-10, atol=1e-13)
         c.close()
     single.close()
+
+
+@pytest.mark.parametrize("nthr", [1024, 0])
+def test_doc_sharded_wide_thresholds_over_rccl_world1(nthr):
+    """quickrank_amd.dist.build_doc_bins + DocShardedTrainer with more than 255 thresholds per
+    feature over real RCCL (one rank): the device's column statistics (qr_bins_stats_wide) merged by
+    qr_thresholds_from_stats_wide are the single context's thresholds bit for bit, and so are the
+    trees (one term per sum)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import quickrank_amd as qr
+    from quickrank_amd.dist import DocShardedTrainer, build_doc_bins
+    x, labels, qoff = make_dataset(nq=50, docs_per_query=40, F=24, seed=53)
+    ref = qr.Context(0)
+    ref.upload(x, labels, qoff)
+    thr1, ts1 = ref.build_bins(nthr, wide=True)
+    ref.reset_scores()
+    torch.cuda.set_device(0)
+    port = 29600 + (os.getpid() + 11 + nthr) % 1000
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        c = qr.Context(0, stream=torch.cuda.current_stream().cuda_stream, doc_shard=(len(labels), len(qoff) - 1))
+        c.upload(x, labels, qoff)
+        thr, ts = build_doc_bins(c, nthr)
+        assert c.wide and np.array_equal(ts, ts1) and np.array_equal(thr.view(np.uint32), thr1.view(np.uint32))
+        c.reset_scores()
+        tr = DocShardedTrainer(c)
+        for it in range(3):
+            ref.compute_lambdas("NDCG", 10)
+            want = ref.fit_tree(8, 1, True)
+            ref.update_scores(0.1)
+            tr.compute_lambdas("NDCG", 10)
+            got = tr.fit_tree(8, 1, True)
+            c.update_scores(0.1)
+            assert_same_tree_records(got, want, node_sums_exact=False, where=it)
+        assert np.allclose(c.get_scores(), ref.get_scores(), rtol=1e-12, atol=1e-14)
+        c.close()
+    finally:
+        dist.destroy_process_group()
+    ref.close()

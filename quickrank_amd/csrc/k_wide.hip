@@ -131,46 +131,51 @@ int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds) {
 // radix keys of the smallest and largest value.  vals: raw f32 bit patterns.
 int qr_k_wide_stats(qr_ctx *c, const float *d_col, size_t limit, uint32_t *vals, uint32_t *cnt, uint32_t *mm) {
   const size_t N = c->N, F = c->F;
-  uint32_t *d_keys = nullptr, *d_sorted = nullptr;
-  void *d_temp = nullptr;
-  size_t temp_bytes = 0;
   if (!N) {
     for (size_t f = 0; f < F; ++f) cnt[f] = 0, mm[2 * f] = 0xFFFFFFFFu, mm[2 * f + 1] = 0;
     return QR_OK;
   }
-  QR_CHECK(c, hipMalloc((void **)&d_keys, N * 4));
-  QR_CHECK(c, hipMalloc((void **)&d_sorted, N * 4));
-  QR_CHECK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, d_keys, d_sorted, (int)N));
-  QR_CHECK(c, hipMalloc(&d_temp, temp_bytes ? temp_bytes : 1));
+  uint32_t *d_keys = nullptr, *d_sorted = nullptr;
+  void *d_temp = nullptr;
+  size_t temp_bytes = 0;
   std::vector<uint32_t> h(N);
-  for (size_t f = 0; f < F; ++f) {
-    hipLaunchKernelGGL(k_wkeys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_col + f * N,
-                       (uint32_t)N, d_keys);
-    QR_CHECK(c, hipGetLastError());
-    size_t tb = temp_bytes;
-    QR_CHECK(c, hipcub::DeviceRadixSort::SortKeys(d_temp, tb, d_keys, d_sorted, (int)N, 0, 32, c->stream));
-    QR_CHECK(c, hipMemcpyAsync(h.data(), d_sorted, N * 4, hipMemcpyDeviceToHost, c->stream));
-    QR_CHECK(c, hipStreamSynchronize(c->stream));
-    uint32_t *out = vals + f * limit;
-    size_t n = 0;
-    float last = bits2f(h_unflip(h[0]));
-    out[n++] = h_unflip(h[0]);
-    for (size_t j = 1; j < N && n <= limit; ++j) {
-      const float v = bits2f(h_unflip(h[j]));
-      if (last < v) {
-        if (n < limit) out[n] = h_unflip(h[j]);
-        ++n;
-        last = v;
+  // (one exit: the scratch goes whatever happens)
+  auto run = [&]() -> int {
+    QR_CHECK(c, hipMalloc((void **)&d_keys, N * 4));
+    QR_CHECK(c, hipMalloc((void **)&d_sorted, N * 4));
+    QR_CHECK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, d_keys, d_sorted, (int)N));
+    QR_CHECK(c, hipMalloc(&d_temp, temp_bytes ? temp_bytes : 1));
+    for (size_t f = 0; f < F; ++f) {
+      hipLaunchKernelGGL(k_wkeys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_col + f * N,
+                         (uint32_t)N, d_keys);
+      QR_CHECK(c, hipGetLastError());
+      size_t tb = temp_bytes;
+      QR_CHECK(c, hipcub::DeviceRadixSort::SortKeys(d_temp, tb, d_keys, d_sorted, (int)N, 0, 32, c->stream));
+      QR_CHECK(c, hipMemcpyAsync(h.data(), d_sorted, N * 4, hipMemcpyDeviceToHost, c->stream));
+      QR_CHECK(c, hipStreamSynchronize(c->stream));
+      uint32_t *out = vals + f * limit;
+      size_t n = 0;
+      float last = bits2f(h_unflip(h[0]));
+      out[n++] = h_unflip(h[0]);
+      for (size_t j = 1; j < N && n <= limit; ++j) {
+        const float v = bits2f(h_unflip(h[j]));
+        if (last < v) {
+          if (n < limit) out[n] = h_unflip(h[j]);
+          ++n;
+          last = v;
+        }
       }
+      cnt[f] = (uint32_t)n;  // (limit + 1: there are more)
+      mm[2 * f] = h[0];
+      mm[2 * f + 1] = h[N - 1];
     }
-    cnt[f] = (uint32_t)n;  // (limit + 1: there are more)
-    mm[2 * f] = h[0];
-    mm[2 * f + 1] = h[N - 1];
-  }
-  (void)hipFree(d_keys);
-  (void)hipFree(d_sorted);
-  (void)hipFree(d_temp);
-  return QR_OK;
+    return QR_OK;
+  };
+  const int rc = run();
+  if (d_keys) (void)hipFree(d_keys);
+  if (d_sorted) (void)hipFree(d_sorted);
+  if (d_temp) (void)hipFree(d_temp);
+  return rc;
 }
 
 // ---------------------------------------------------------------------------

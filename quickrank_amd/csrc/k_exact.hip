@@ -94,9 +94,10 @@ __device__ __forceinline__ const u64 *x_lists(const int buf, const u64 *xroot, c
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_xflag(const QrTreeState *__restrict__ ts, const u64 *__restrict__ xroot,
                                                const u64 *__restrict__ x0, const u64 *__restrict__ x1, const size_t N,
-                                               uint8_t *__restrict__ goleft) {
+                                               uint8_t *__restrict__ goleft, const int lazy) {
+  // (lazy: the split search at the pop -- the last split's children are never walked, ts->xs_last)
   const QrSplitDesc d = ts->desc;
-  if (!d.active || d.owner_local < 0) return;
+  if (!d.active || d.owner_local < 0 || (lazy && ts->xs_last)) return;
   const u64 *src = x_lists(d.src_buf, xroot, x0, x1) + (size_t)d.owner_local * N + d.begin;
   const uint32_t n = d.end - d.begin;
   for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
@@ -155,7 +156,7 @@ __device__ __forceinline__ long long x_look_back(const u64 *row, const uint32_t 
 __global__ __launch_bounds__(1024) void k_xpart(const QrTreeState *__restrict__ ts, const u64 *__restrict__ xroot,
                                                 u64 *__restrict__ x0, u64 *__restrict__ x1, const size_t N,
                                                 const uint8_t *__restrict__ goleft, u64 *__restrict__ pub,
-                                                const uint32_t tiles, const u64 epoch) {
+                                                const uint32_t tiles, const u64 epoch, const int lazy) {
   // Tile blockIdx.y of feature blockIdx.x.  Entry k of thread t sits at position c0 + k * 1024 + t:
   // a wave's load is 512 contiguous bytes.  The rank of an entry among the tile's left-going ones:
   // lanes before it in its wave (ballot), waves before it in its slab k and the slabs before (one
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(1024) void k_xpart(const QrTreeState *__restrict__ 
   __shared__ uint32_t sh_c[QR_X_E * 16], sh_p[QR_X_E * 16 + 1];
   __shared__ uint32_t sh_before;
   const QrSplitDesc d = ts->desc;
-  if (!d.active || d.owner_local < 0) return;
+  if (!d.active || d.owner_local < 0 || (lazy && ts->xs_last)) return;
   const uint32_t n = d.end - d.begin;
   const uint32_t tile = blockIdx.y;
   const uint32_t c0 = tile * QR_X_CHUNK;
@@ -606,10 +607,10 @@ int qr_k_exact_scan(qr_ctx *c, int root_mode) {
   if (!root_mode) {
     const unsigned fg = (unsigned)std::min<size_t>((c->N + 2047) / 2048, 1024);
     hipLaunchKernelGGL(k_xflag, dim3(fg), dim3(256), 0, c->stream, c->d_tree, xr, (const u64 *)x0, (const u64 *)x1,
-                       c->N, c->d_xgoleft);
+                       c->N, c->d_xgoleft, 0);
     QR_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(k_xpart, dim3(F, c->xtiles_p), dim3(1024), 0, c->stream, c->d_tree, xr, x0, x1, c->N,
-                       (const uint8_t *)c->d_xgoleft, pub_part, c->xtiles_p, epoch);
+                       (const uint8_t *)c->d_xgoleft, pub_part, c->xtiles_p, epoch, 0);
     QR_CHECK(c, hipGetLastError());
   }
   QR_CHECK(c, hipMemsetAsync(c->d_xtot, 0, (2 + 2 * (size_t)F) * 8, c->stream));
@@ -659,10 +660,10 @@ static int exact_step(qr_ctx *c, int root, int final_call) {
   if ((rc = qr_k_xpartition(c))) return rc;
   const unsigned fg = (unsigned)std::min<size_t>((c->N + 2047) / 2048, 1024);
   hipLaunchKernelGGL(k_xflag, dim3(fg), dim3(256), 0, c->stream, c->d_tree, xr, (const u64 *)x0, (const u64 *)x1,
-                     c->N, c->d_xgoleft);
+                     c->N, c->d_xgoleft, 1);
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_xpart, dim3(F, c->xtiles_p), dim3(1024), 0, c->stream, c->d_tree, xr, x0, x1, c->N,
-                     (const uint8_t *)c->d_xgoleft, pub_part, c->xtiles_p, epoch);
+                     (const uint8_t *)c->d_xgoleft, pub_part, c->xtiles_p, epoch, 1);
   QR_CHECK(c, hipGetLastError());
   return qr_k_xpop(c, 0, c->cur_nleaves, c->cur_minls, final_call);
 }

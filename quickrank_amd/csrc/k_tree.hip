@@ -1845,6 +1845,7 @@ __global__ __launch_bounds__(64) void k_xapply(
     long long *__restrict__ node_tot) {
   const int node = ts->xs_node;
   if (node < 0) return;  // (workgroup-uniform; k_xpop left desc.active = 0)
+  if (threadIdx.x == 0) ts->xs_last = 0;
   const qr_split_t a = wave_merge(1, 0, featrec, flocal, mf_k, mf_seed, (uint32_t)node, F);
   if (threadIdx.x != 0) return;
   __shared__ qr_split_t own[2];
@@ -1875,6 +1876,8 @@ __global__ __launch_bounds__(64) void k_xapply(
     node_tot[ts->desc.left] = sl;
     node_tot[ts->desc.right] = node_tot[node] - sl;
     ts->real_steps = ts->real_steps + 1;
+    // (rt.cc:58-90's loop goes on while taken + heap < leaves: with the two children pushed it stops)
+    ts->xs_last = st.nleaves_req != 0 && st.taken + st.heap_size + 2 >= st.nleaves_req ? 1 : 0;
   } else if (root_mode) {
     st.done = 1;     // rt.cc:312: the root has no split
   } else {

@@ -241,6 +241,9 @@ struct QrTreeState {
   // the node whose segments the step's scan launch walks (-1: none)
   int32_t xs_node, xs_buf;
   uint32_t xs_begin, xs_n;
+  // ... the split k_xapply made exhausts the leaf budget: its children are leaves whatever they hold,
+  // nobody will walk their segments -- k_xflag / k_xpart leave
+  int32_t xs_last, xs_pad;
 };
 
 // Per-iteration scalars produced on the device.

@@ -226,12 +226,13 @@ def test_doc_sharded_oblivious_equals_single(world, cuts, depth, minls, F, algo)
     single.close()
 
 
+@pytest.mark.parametrize("batched", [False, True])
 @pytest.mark.parametrize("world,cuts,algo,subsample", [
     (2, [30], "lambda", 0.5),
     (3, [5, 41], "lambda", 0.3),       # a small first shard: few (or none) of the sample's documents
     (4, [15, 30, 45], "mart", 900.0),  # a number of documents instead of a fraction
 ])
-def test_doc_sharded_subsample_equals_single(world, cuts, algo, subsample):
+def test_doc_sharded_subsample_equals_single(world, cuts, algo, subsample, batched):
     """--subsample over document shards: the key of a document is a function of its GLOBAL
     index, so every rank finds the sample a single GPU draws from the whole set and keeps
     its own part; trees (structure bit for bit) and the scores of ALL documents (mart.cc:345)
@@ -262,7 +263,8 @@ def test_doc_sharded_subsample_equals_single(world, cuts, algo, subsample):
         emu.allreduce("scal")
         for c in ctxs:
             c.lambda_finish()
-        got = _doc_fit(emu, ctxs, 8, 2, newton)
+        # (batched: two splits per exchange, the sample's lists as the root -- _doc_fit_batched below)
+        got = (_doc_fit_batched if batched else _doc_fit)(emu, ctxs, 8, 2, newton)
         for c in ctxs:
             c.update_scores(0.1)
         for g in got:

@@ -2042,8 +2042,11 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
                                            const int njobs, const QrLevelNode *prev,
                                            const uint32_t N, const qr_split_t *own,
                                            const QrScalars *scal, const int32_t *own_lf,
-                                           const float *own_thr, const int root_buf, const u64 Ncount) {
-  // (Ncount: the root's documents over all ranks -- N itself except on a document-sharded rank)
+                                           const float *own_thr, const int root_buf, const u64 Ncount,
+                                           const u64 spec_docs) {
+  // (Ncount: the root's documents over all ranks -- N itself except on a document-sharded rank;
+  // spec_docs: what a rank's launches work on -- N, or the ranks' average on document shards, the
+  // same number on every rank -- decides whether splits ahead of their turn pay)
   int nj = 0;
 #ifdef QR_STEP_TIMING
   long long lt[5];
@@ -2120,7 +2123,7 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
   QR_LT(2);
   // candidates applied ahead of their turn: the largest deviances left in the heap,
   // as long as the leaf budget can still reach them
-  if (nj == 1 && Ncount < QR_SPEC_MAX_DOCS) {
+  if (nj == 1 && spec_docs < QR_SPEC_MAX_DOCS) {
     while (nj < QR_BATCH) {
       if (st.nleaves_req != 0 && st.nleaves_req - (st.taken + st.heap_size + 2) < nj) break;
       int pick = -1;
@@ -2180,7 +2183,8 @@ __device__ __forceinline__ void batch_step(
     const int root_buf, const int G, const QrBlock *__restrict__ blocks, const int nblocks,
     QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
     const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
-    const int final_call = 0, const uint32_t *__restrict__ hcnt_loc = nullptr, const u64 Nglobal = 0) {
+    const int final_call = 0, const uint32_t *__restrict__ hcnt_loc = nullptr, const u64 Nglobal = 0,
+    const u64 spec_docs_doc = 0) {
   QrTreeState *const ts = tout;  // where the writer publishes
   __shared__ QrPlan sh_plan[QR_BATCH];
   __shared__ qr_split_t own[2 * QR_BATCH];
@@ -2324,11 +2328,13 @@ __device__ __forceinline__ void batch_step(
     if (staged) {
       st.nodes = sh_nodes;
       st.heap = sh_heap;
-      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, scal, own_lf, own_thr, root_buf, hcnt_loc ? Nglobal : (u64)N);
+      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, scal, own_lf, own_thr, root_buf, hcnt_loc ? Nglobal : (u64)N,
+                       hcnt_loc ? spec_docs_doc : (u64)N);
     } else {
       st.nodes = ts->nodes;
       st.heap = ts->heap;
-      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, scal, own_lf, own_thr, root_buf, hcnt_loc ? Nglobal : (u64)N);
+      nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, scal, own_lf, own_thr, root_buf, hcnt_loc ? Nglobal : (u64)N,
+                       hcnt_loc ? spec_docs_doc : (u64)N);
     }
     // one plan quantum for the whole batch (as for a level of an oblivious tree)
     if (nj > 0) {
@@ -2577,7 +2583,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     QrHistWg *__restrict__ hist_wg, const uint32_t hist_grid, QrPartWg *__restrict__ part_wg,
     const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
     const QrTreeState *tin, const int final_call, int64_t *__restrict__ early, const long long early_seq,
-    const uint32_t *__restrict__ hcnt_loc, const u64 Nglobal) {
+    const uint32_t *__restrict__ hcnt_loc, const u64 Nglobal, const u64 spec_docs) {
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
   __shared__ int sh_nj;
@@ -2586,7 +2592,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
   batch_step<false, CAP>(tin ? tin : ts, ts, nullptr, true, 0u, sh_next, sh_pw0, &sh_nj, &sh_epoch,
                     root_mode, nleaves_arg, minls_arg, stage_nodes, N, flocal, scal, part_ss, featrec,
                     featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, part_wg, part_grid,
-                    plans, scan_wg, final_call, hcnt_loc, Nglobal);
+                    plans, scan_wg, final_call, hcnt_loc, Nglobal, spec_docs);
   if (final_call && early) {  // QrPinned::early: the host settles the tree on this
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2911,7 +2917,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
     const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
     uint32_t *__restrict__ order1, u64 *__restrict__ state, const double *__restrict__ lambda,
     double *__restrict__ part_ss_out, const int wide, const uint32_t *__restrict__ hcnt_loc,
-    const u64 Nglobal) {
+    const u64 Nglobal, const u64 spec_docs) {
   // (hcnt_loc != null: a document-sharded rank -- N its own documents, Nglobal everybody's)
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
@@ -2924,7 +2930,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
   batch_step<true, CAP>(tin, tout, tlog2, blockIdx.x == gridDim.x - 1, epoch, sh_next, sh_pw0, &sh_nj, &sh_epoch,
                    root_mode, nleaves_arg, minls_arg, stage_nodes, N, flocal, scal, part_ss_in, featrec,
                    featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, nullptr, 0u, plans,
-                   scan_wg, 0, hcnt_loc, Nglobal);
+                   scan_wg, 0, hcnt_loc, Nglobal, spec_docs);
   __syncthreads();  // (the writer comes back later than the others; sh_* are final for all)
   const int nj = sh_nj;
 #ifdef QR_STEP_TIMING
@@ -4474,6 +4480,13 @@ static BatchGeom batch_geom(const qr_ctx *c, size_t nleaves) {
   return g;
 }
 
+// document shards: what decides whether splits ahead of their turn pay is the size of a RANK's
+// launches; every rank must decide alike, so it is the ranks' average share of the root's documents
+static inline u64 doc_spec_docs(const qr_ctx *c) {
+  const u64 n = (u64)(c->sub_k ? c->sub_k : c->Nglobal);
+  return c->world > 0 ? n / (u64)c->world : n;
+}
+
 // a control call on its own (k_decide_batch): the first of a tree (root), one between two
 // steps of a tree whose state does not fit the LDS copies, or the last of the enqueued
 // sequence (`final_call`: accounts for the last batch and tells whether more is to come)
@@ -4487,7 +4500,7 @@ static int launch_decide_batch(qr_ctx *c, const BatchGeom &g, size_t nleaves, ui
                      c->d_lpart_wg, g.pg, c->d_lplan, c->d_lscan_wg, tin, final_call,
                      final_call ? c->d_pin->early : (int64_t *)nullptr, (long long)(final_call ? ++c->early_seq : 0),
                      c->dmode ? c->d_hcnt_loc : (const uint32_t *)nullptr,
-                     (u64)(c->sub_k ? c->sub_k : c->Nglobal));
+                     (u64)(c->sub_k ? c->sub_k : c->Nglobal), doc_spec_docs(c));
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -4549,7 +4562,7 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
                          c->d_lplan, c->d_lscan_wg, fm, (uint32_t)c->N, c->d_order[0],
                          c->d_order[1], (u64 *)c->d_bpart_state, c->d_lambda,
                          c->wide ? PSS[s & 1] : (double *)nullptr, c->wide ? 1 : 0,
-                         (const uint32_t *)nullptr, (u64)0);
+                         (const uint32_t *)nullptr, (u64)0, (u64)0);
       QR_CHECK(c, hipGetLastError());
     }
     if ((rc = launch_batch_hist_scan(c, g.hg, g.rootn, minls, g.fused ? PSS[s & 1] : c->d_lpart_ss, tout))) return rc;
@@ -4624,7 +4637,7 @@ int qr_k_dbatch_apply(qr_ctx *c, size_t nleaves) {
                        c->sub_k ? 0 : 2, c->ncu, c->d_blocks, c->nblocks, c->d_lhist_wg, g.hg, c->d_lplan,
                        c->d_lscan_wg, c->d_bins_fm, (uint32_t)c->N, c->d_order[0], c->d_order[1],
                        (u64 *)c->d_bpart_state, c->d_lambda, (double *)nullptr, 0,
-                       (const uint32_t *)c->d_hcnt_loc, (u64)(c->sub_k ? c->sub_k : c->Nglobal));
+                       (const uint32_t *)c->d_hcnt_loc, (u64)(c->sub_k ? c->sub_k : c->Nglobal), doc_spec_docs(c));
     QR_CHECK(c, hipGetLastError());
     c->dtree_cur = tout;
     c->dbatch_first = false;

@@ -167,6 +167,57 @@ def test_sharded_equals_single_at_full_size(big):
         s.close()
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_document_shards_two_splits_per_exchange_at_full_size(big, world):
+    """BASELINE configs[2]'s data set cut into `world` document shards on this one GPU, trees grown
+    two splits per exchange (qr_tree_batch_*) with the all-reduces replaced by explicit sums: three
+    LambdaMART iterations equal the single context's -- structure bit for bit, leaf values and the
+    scores to f64 rounding -- and every shard holds the same bits."""
+    import torch
+    from test_gpu_docshard import _Emu, _doc_fit_batched
+    qr, c, x, labels, qoff = big["qr"], big["c"], big["x"], big["labels"], big["qoff"]
+    N, Q = len(labels), len(qoff) - 1
+    c.reset_scores()
+    ctxs, parts = [], []
+    for r in range(world):
+        q0, q1 = Q * r // world, Q * (r + 1) // world
+        d0, d1 = int(qoff[q0]), int(qoff[q1])
+        s = qr.Context(0, rank=r, world=world, doc_shard=(N, Q))
+        s.upload(x[d0:d1], labels[d0:d1], qoff[q0:q1 + 1] - qoff[q0])
+        s.build_bins_with(big["thr"], big["ts"])
+        s.reset_scores()
+        ctxs.append(s)
+        parts.append((d0, d1))
+    emu = _Emu(torch, ctxs)
+    stats = []
+    for it in range(3):
+        c.compute_lambdas("NDCG", 10)
+        want = c.fit_tree(10, 1, True)
+        c.update_scores(0.1)
+        for s in ctxs:
+            s.compute_lambdas("NDCG", 10)
+        emu.allreduce("scal")
+        for s in ctxs:
+            s.lambda_finish()
+        got = _doc_fit_batched(emu, ctxs, 10, 1, True, stats)
+        for s in ctxs:
+            s.update_scores(0.1)
+        for g in got:
+            for k in ("feature", "thr_id", "left", "right", "nsamples", "threshold"):
+                assert np.array_equal(g[k], want[k]), (it, k)
+            assert np.allclose(g["value"], want["value"], rtol=1e-10, atol=1e-13), it
+        for g in got[1:]:
+            for k in want.dtype.names:
+                assert np.array_equal(g[k], got[0][k]), (it, k)
+    # (exchanges per tree: root + steps; never more than one per split, fewer once the guess has settled)
+    assert all(ex <= 10 for ex, _, _ in stats) and min(ex for ex, _, _ in stats[1:]) < 10, stats
+    s1 = c.get_scores()
+    for s, (d0, d1) in zip(ctxs, parts):
+        assert np.allclose(s.get_scores(), s1[d0:d1], rtol=1e-10, atol=1e-13)
+        s.close()
+    c.reset_scores()
+
+
 def test_scoring_linearity_and_tree_order(big):
     qr, c, x = big["qr"], big["c"], big["x"]
     import sys, os

@@ -494,6 +494,8 @@ def _doc_fit_batched(emu, ctxs, nleaves, minls, newton, stats=None):
     (4, [15, 30, 45], 16, 20, 16, 2, None),
     (8, [7, 14, 22, 30, 38, 45, 52], 255, 136, 10, 2, None),
     (2, [30], 255, 136, 10, 2, "1"),           # one step enqueued whatever the tree: every tree is carried on
+    (3, [11, 37], 255, 70, 10, 2, "unfused"),  # the control step in a launch of its own (what runs above 4M documents per rank)
+    (2, [30], 255, 40, 12, 1, "unfused1"),     # ... with one step enqueued whatever the tree
     (3, [20, 41], 64, 40, 31, 0, None),        # larger trees, empty leaves allowed
     (2, [30], 255, 40, 2, 1, None),            # a stump
 ])
@@ -510,11 +512,15 @@ def test_doc_sharded_batched_training_equals_single(world, cuts, nthr, F, nleave
     single.upload(x, labels, qoff)
     single.build_bins(nthr)
     single.reset_scores()
+    if force in ("unfused", "unfused1"):
+        monkeypatch.setenv("QR_FUSE_MAX_DOCS", "0")
+        force = "1" if force == "unfused1" else None
     if force is not None:
         monkeypatch.setenv("QR_STEPS_HINT", force)
     parts = _split_queries(qoff, cuts)
     ctxs, thr, ts = _make_ctxs(qr, x, labels, qoff, parts, nthr)
     monkeypatch.delenv("QR_STEPS_HINT", raising=False)
+    monkeypatch.delenv("QR_FUSE_MAX_DOCS", raising=False)
     emu = _Emu(torch, ctxs)
     for c in ctxs:
         c.reset_scores()

@@ -283,6 +283,37 @@ def test_batched_growth_equals_one_split_per_step_at_full_size(big, monkeypatch)
     s.close()
 
 
+def test_control_step_outside_the_partition_launch_equals_fused_at_full_size(big, monkeypatch):
+    """Above QR_FUSE_MAX_DOCS documents (default 4M) the control step of batched growth is a launch
+    of its own (k_decide_batch + k_partition_batch) instead of riding in the partition launch
+    (k_decide_part).  Forced here on the 1M set (the variable is read when the context is created):
+    every record of every tree, the metric and the scores are the fused path's bits."""
+    qr, c = big["qr"], big["c"]
+
+    def run(ctx):
+        ctx.reset_scores()
+        trees = []
+        for it in range(4):
+            ctx.compute_lambdas("NDCG", 10)
+            trees.append(ctx.fit_tree(10, 1, True))
+            ctx.update_scores(0.1)
+        return trees, ctx.get_scores()
+
+    ta, sa = run(c)
+    monkeypatch.setenv("QR_FUSE_MAX_DOCS", "0")
+    s = qr.Context(0)
+    monkeypatch.delenv("QR_FUSE_MAX_DOCS")
+    s.upload(big["x"], big["labels"], big["qoff"])
+    s.build_bins(255)
+    tb, sb = run(s)
+    for a, b in zip(ta, tb):
+        for k in a.dtype.names:
+            assert np.array_equal(a[k], b[k], equal_nan=(a[k].dtype.kind == "f")), k
+    assert np.array_equal(sa, sb)
+    s.close()
+    c.reset_scores()
+
+
 # ---------------------------------------------------------------------------
 # Full-size runs against the oracle (mart.cc:307-383, rt.cc:209-362, ot.cc:32-201)
 # ---------------------------------------------------------------------------

@@ -413,3 +413,31 @@ def test_presorted_steps_without_a_split_are_carried_on(qr, nleaves, minls, nrow
         import re
         m = re.search(r"(\d+) trees with a guessed step count, (\d+) continued", err)
         assert m and int(m.group(2)) > 0, err      # the carried-on path has run
+
+
+@pytest.mark.parametrize("nleaves", [40, 64, 100])
+def test_presorted_lists_large_trees(qr, nleaves, monkeypatch):
+    """Trees whose node records and heap outgrow the control kernels' LDS copies (more than 47
+    leaves: k_xpop works on the device-resident state): the pre-sorted path with the split search
+    at the pop against the slot histograms, every record of every tree."""
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(**CASES[3])
+    kw = dict(ntrees=3, shrinkage=0.1, nthresholds=0, nleaves=nleaves, minls=1, esr=0)
+
+    def run():
+        m = Mart(algo="LAMBDAMART", **kw).learn(x, labels, qoff)
+        assert m.ctx.wide
+        out = [t.copy() for t in m.ensemble.trees], m.ctx.get_scores()
+        m.ctx.close()
+        return out
+
+    monkeypatch.setenv("QR_NO_BATCH", "1")
+    monkeypatch.setenv("QR_WIDE_NO_EXACT", "1")
+    ta, sa = run()
+    monkeypatch.delenv("QR_WIDE_NO_EXACT")
+    monkeypatch.setenv("QR_WIDE_EXACT", "1")
+    tb, sb = run()
+    for a, b in zip(ta, tb):
+        for k in a.dtype.names:
+            assert np.array_equal(a[k], b[k], equal_nan=(a[k].dtype.kind == "f")), k
+    assert np.array_equal(sa, sb)

@@ -498,6 +498,8 @@ def _doc_fit_batched(emu, ctxs, nleaves, minls, newton, stats=None):
     (2, [30], 255, 40, 12, 1, "unfused1"),     # ... with one step enqueued whatever the tree
     (3, [20, 41], 64, 40, 31, 0, None),        # larger trees, empty leaves allowed
     (2, [30], 255, 40, 2, 1, None),            # a stump
+    (2, [30], 64, 40, 64, 1, None),            # the larger LDS copy of the control step
+    (3, [20, 41], 64, 40, 100, 1, None),       # node records beyond the LDS copies: the device-resident control step
 ])
 def test_doc_sharded_batched_training_equals_single(world, cuts, nthr, F, nleaves, minls, force, monkeypatch):
     """Two splits per exchange on document shards: the trees are the single-context trees

@@ -602,12 +602,13 @@ def test_doc_sharded_batched_equals_one_split_protocol():
         cb.close()
 
 
-@pytest.mark.parametrize("world,cuts,nthr,F,minls", [
-    (2, [30], 1024, 40, 2),              # rows of up to 1025 slots: the LDS-tiled histogram kernel
-    (3, [5, 41], 0, 24, 1),              # every distinct value a threshold (rows of ~3000 slots), a small first shard
-    (4, [15, 30, 45], 4096, 20, 2),      # the general histogram kernel, the chunked scan
+@pytest.mark.parametrize("world,cuts,nthr,F,minls,subsample", [
+    (2, [30], 1024, 40, 2, None),        # rows of up to 1025 slots: the LDS-tiled histogram kernel
+    (3, [5, 41], 0, 24, 1, None),        # every distinct value a threshold (rows of ~3000 slots), a small first shard
+    (4, [15, 30, 45], 4096, 20, 2, None),  # the general histogram kernel, the chunked scan
+    (3, [11, 37], 1024, 40, 2, 0.5),     # --subsample: the sample's lists as the root
 ])
-def test_doc_sharded_wide_bins_equal_single(world, cuts, nthr, F, minls):
+def test_doc_sharded_wide_bins_equal_single(world, cuts, nthr, F, minls, subsample):
     """More than 255 thresholds per feature on document shards (round 4): every rank bins its own
     documents against the thresholds of the WHOLE set (qr_bins_build_wide_with) and the node
     histograms -- ragged rows -- go through the same ONE int64 all-reduce per split.  Trees: the
@@ -629,7 +630,11 @@ def test_doc_sharded_wide_bins_equal_single(world, cuts, nthr, F, minls):
         c.build_bins_wide_with(thr, ts)
         assert np.array_equal(c.read_bins_u32(), single.read_bins_u32()[d0:d1])
         c.reset_scores()
+        if subsample is not None:
+            c.set_subsample(subsample, seed=13, first_doc=d0)
         ctxs.append(c)
+    if subsample is not None:
+        single.set_subsample(subsample, seed=13)
     emu = _Emu(torch, ctxs)
     for it in range(4):
         single.compute_lambdas("NDCG", 10)

@@ -400,6 +400,7 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       }
       // ---- tree
       size_t nn = 0;
+      bool scores_enqueued = false;
       if (obliv && !feature_sharded) {  // ot.cc:32-201 over document shards: one exchange per level
         QRM(c, qr_obl_begin(c, treedepth_, minleafsupport_));
         sum64(x_hist, n_hist);
@@ -458,19 +459,32 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
           }
         };
         run(steps);
+        // The tree is ENDED behind the guess -- leaf kernels, leaf exchange, leaf values, score
+        // update all enqueued (they leave at once on a tree whose steps did not suffice) -- and only
+        // then does the host look at the last control step: the GPU works on the tree's tail
+        // while the host waits, instead of idling until the host has seen the word and enqueued it.
+        auto end_tree = [&]() {
+          QRM(c, qr_tree_end(c, lambda, nullptr, nullptr));
+          QRM(c, qr_doc_exchange_buffers(c, nullptr, nullptr, nullptr, nullptr, &x_leaf, &n_leaf));
+          sum64(x_leaf, n_leaf);
+          QRM(c, qr_tree_leaves_finish(c, lambda, nullptr, nullptr));  // (a carried-on tree: repeats the score update)
+        };
+        end_tree();
+        QRM(c, qr_scores_update(c, shrinkage_));  // mart.cc:345, :356
+        scores_enqueued = true;
         int incomplete = 0;
         QRM(c, qr_tree_batch_settle(c, &incomplete, nullptr));
-        for (size_t done = steps, piece = 1; incomplete; piece *= 2) {
-          const size_t left = nleaves_ - 1 > done ? nleaves_ - 1 - done : 1;
-          const size_t k = std::min(piece, left);
-          run(k);
-          done += k;
-          QRM(c, qr_tree_batch_settle(c, &incomplete, nullptr));
+        if (incomplete) {  // (re-opened by the settle call)
+          for (size_t done = steps, piece = 1; incomplete; piece *= 2) {
+            const size_t left = nleaves_ - 1 > done ? nleaves_ - 1 - done : 1;
+            const size_t k = std::min(piece, left);
+            run(k);
+            done += k;
+            QRM(c, qr_tree_batch_settle(c, &incomplete, nullptr));
+          }
+          end_tree();
         }
-        QRM(c, qr_tree_end(c, lambda, nullptr, nullptr));
-        QRM(c, qr_doc_exchange_buffers(c, nullptr, nullptr, nullptr, nullptr, &x_leaf, &n_leaf));
-        sum64(x_leaf, n_leaf);
-        QRM(c, qr_tree_leaves_finish(c, lambda, nodes.data(), &nn));
+        QRM(c, qr_tree_nodes(c, nodes.data(), &nn));
       } else {
         QRM(c, qr_tree_begin(c, nleaves_, minleafsupport_));
         sum64(x_hist, n_hist);
@@ -485,7 +499,7 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
         sum64(x_leaf, n_leaf);
         QRM(c, qr_tree_leaves_finish(c, lambda, nodes.data(), &nn));
       }
-      QRM(c, qr_scores_update(c, shrinkage_));  // mart.cc:345, :356
+      if (!scores_enqueued) QRM(c, qr_scores_update(c, shrinkage_));  // mart.cc:345, :356
       // ---- every rank must have built rank 0's tree
       if (r == 0) {
         memcpy(sh.nodes0.data(), nodes.data(), nn * sizeof(qr_node_t));

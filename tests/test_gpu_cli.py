@@ -395,6 +395,24 @@ def test_quicklearn_gpus_flag_runs_the_sharded_protocol(tools, tmp_path, algo, s
     t1 = [l for l in a.stdout.splitlines() if l[:7].strip().isdigit()]
     t2 = [l for l in b.stdout.splitlines() if l[:7].strip().isdigit()]
     assert t1 == t2 and len(t1) == 6
+    if shard == "docs":
+        # two splits per exchange with every guess too low (one step enqueued whatever the tree: the
+        # tree is ended behind it, found unfinished, carried on and ended again) and with one split
+        # per exchange: the same model file
+        import os
+        for env in ({"QR_STEPS_HINT": "1"}, {"QR_DOC_BATCH": "0"}):
+            m3 = str(tmp_path / ("m_" + "_".join(env) + ".xml"))
+            r = subprocess.run([tools["quicklearn"]] + base + ["--model-out", m3, "--gpus", "1", "--shard", "docs"],
+                               capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stdout + r.stderr
+            n3, w3 = _load_model(tools, m3)
+            assert n3.shape == n2.shape and np.array_equal(w3, w2)
+            for k in ("feature", "left", "right"):
+                assert np.array_equal(n3[k], n2[k]), (env, k)
+            assert np.array_equal(n3["threshold"].view(np.uint32), n2["threshold"].view(np.uint32))
+            assert np.allclose(n3["value"], n2["value"], rtol=1e-9, atol=1e-12)
+            t3 = [l for l in r.stdout.splitlines() if l[:7].strip().isdigit()]
+            assert t3 == t2, env
 
 
 @pytest.mark.parametrize("extra", [["--algo", "OBVLAMBDAMART", "--tree-depth", "4"],

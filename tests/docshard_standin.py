@@ -183,7 +183,8 @@ class DocStandinContext:
     BATCH = 2
 
     def tree_batch_supported(self, nleaves):
-        return nleaves >= 2
+        # (as the device: ragged rows of more than 255 thresholds grow one split per exchange)
+        return nleaves >= 2 and self.cap <= 256
 
     def tree_batch_exchange(self):
         return 0, len(self.batch)

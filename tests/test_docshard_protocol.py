@@ -32,7 +32,8 @@ def _worker(rank, world, port, q, cuts, ntrees, mode="batched"):
     from quickrank_amd.dist import DocShardedTrainer
     from docshard_standin import DocStandinContext
     x, labels, qoff = make_dataset(nq=24, docs_per_query=40, F=20, seed=31, adversarial=True)
-    whole = oracle.Trainer(x, 64)                      # thresholds of the WHOLE set
+    # ("wide": more than 255 thresholds per feature -- ragged rows through the same one-split protocol)
+    whole = oracle.Trainer(x, 300 if mode == "wide" else 64)   # thresholds of the WHOLE set
     edges = [0] + list(cuts) + [len(qoff) - 1]
     q0, q1 = edges[rank], edges[rank + 1]
     d0, d1 = int(qoff[q0]), int(qoff[q1])
@@ -54,7 +55,7 @@ def _worker(rank, world, port, q, cuts, ntrees, mode="batched"):
         else:
             nodes = tr.fit_tree(8, 2, True)
             ctx.update_scores(0.1)
-        if mode != "one_split":
+        if mode not in ("one_split", "wide"):
             exchanges.append(tr.collectives)
         # unsharded oracle iteration on the same scores
         lam, w = oracle.lambdas(labels, scores, qoff)
@@ -156,7 +157,8 @@ def _leaf_of(tr, nodes):
 
 
 @pytest.mark.parametrize("world,cuts,mode", [(2, [9], "batched"), (3, [3, 15], "batched"), (2, [9], "one_split"),
-                                             (3, [3, 15], "one_split"), (2, [9], "lazy"), (3, [3, 15], "lazy")])
+                                             (3, [3, 15], "one_split"), (2, [9], "lazy"), (3, [3, 15], "lazy"),
+                                             (2, [9], "wide")])
 def test_doc_sharded_training_equals_unsharded(world, cuts, mode):
     import oracle
     oracle.build(ref=False)

@@ -66,10 +66,16 @@ class Model(C.Structure):
                 ("best_model", sz), ("iter_seconds", C.POINTER(C.c_double))]
 
 
-def build(ref=True):
-    """Compile liboracle.so (and _ref/libqr_ref.so when /root/reference exists)."""
+REFERENCE_PRESENT = os.path.isdir("/root/reference/src")
+
+
+def build(ref=None):
+    """Compile liboracle.so, and _ref/libqr_ref.so where /root/reference exists (the build
+    container; `ref=None` = exactly there).  _ref never travels: .gpurunignore lists it."""
     subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
-    if ref and os.path.isdir("/root/reference/src"):
+    if ref is None:
+        ref = REFERENCE_PRESENT
+    if ref and REFERENCE_PRESENT:
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
 
 

@@ -16,7 +16,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def oracle_lib():
     import oracle
-    oracle.build(ref=True)
+    oracle.build(ref=os.path.isdir("/root/reference/src"))
     return oracle
 
 

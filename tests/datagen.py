@@ -7,9 +7,12 @@ adversarial cases); labels in {0..4} driven by the first four features.
 import numpy as np
 
 
-def make_queries(nq, docs_per_query, seed=0, ragged=False):
+def make_queries(nq, docs_per_query, seed=0, ragged=False, sizes=None):
     rng = np.random.default_rng(seed + 1000)
-    if ragged:
+    if sizes is not None:
+        sizes = np.asarray(sizes)
+        nq = len(sizes)
+    elif ragged:
         sizes = rng.integers(1, 2 * docs_per_query, size=nq)
     else:
         sizes = np.full(nq, docs_per_query)
@@ -19,8 +22,9 @@ def make_queries(nq, docs_per_query, seed=0, ragged=False):
 
 
 def make_dataset(nq=40, docs_per_query=30, F=16, seed=0, ragged=False,
-                 adversarial=False):
-    qoff = make_queries(nq, docs_per_query, seed, ragged)
+                 adversarial=False, sizes=None):
+    qoff = make_queries(nq, docs_per_query, seed, ragged, sizes)
+    nq = len(qoff) - 1
     N = int(qoff[-1])
     rng = np.random.default_rng(seed)
     x = rng.random((N, F), dtype=np.float32)

@@ -62,11 +62,77 @@ def make(name, cutoff, nthr, score_kind, **case):
     rss, lss, gss = C.c_double(), C.c_double(), C.c_double()
     R.ref_histograms(x, N, F, thr, ts, cap, lam, left, len(left), 0, stmap, c0, rs, rc,
                      C.byref(rss), ls, lc, C.byref(lss), gs, gc, C.byref(gss))
+    # A left child that a tree can actually produce: the documents on the left of the
+    # best root split of the REFERENCE's root histogram under `lam` (the scan of
+    # rt.cc:257-312 is not buildable here -- the restatement names (feature, slot); the
+    # histograms of that id list and of its sibling are again the reference's own:
+    # rtnode_histogram.cc:41-70 and 72-87).  tests/test_gpu_golden.py grows a two-leaf
+    # tree on the device and compares ITS children with these.
+    sp = oracle.split_find(rs, rc, ts, minls=1)
+    sf, st = int(sp.feature), int(sp.thr_id)
+    sleft = np.flatnonzero(stmap[sf] <= st).astype(np.uint64)
+    assert len(sleft) == sp.lcount and 0 < len(sleft) < N
+    sls, slc = np.zeros(shp), np.zeros(shp, np.uint64)
+    srs, src = np.zeros(shp), np.zeros(shp, np.uint64)
+    st2, c02 = np.zeros((F, N), np.uint32), np.zeros(shp, np.uint64)
+    rs2, rc2 = np.zeros(shp), np.zeros(shp, np.uint64)
+    rss2, slss, srss = C.c_double(), C.c_double(), C.c_double()
+    R.ref_histograms(x, N, F, thr, ts, cap, lam, sleft, len(sleft), 0, st2, c02, rs2, rc2,
+                     C.byref(rss2), sls, slc, C.byref(slss), srs, src, C.byref(srss))
+    assert np.array_equal(st2, stmap) and np.array_equal(rs2.view(np.uint64), rs.view(np.uint64))
+    # idx_radixsort of every column (radix.cc:35-73): stable ascending argsort
+    argsort = np.zeros((F, N), np.uint64)
+    for f in range(F):
+        R.ref_argsort_f32(np.ascontiguousarray(col[f]), N, argsort[f])
     np.savez_compressed(os.path.join(HERE, name), x=x, labels=labels, qoff=qoff, scores=scores,
                         cutoff=cutoff, nthresholds=nthr, ranks=ranks, ndcg_per_query=per_q,
                         ndcg_dataset=ds, jacobian_q0=jac, jac_sorted_labels=sl, stmap=stmap,
                         lam=lam, left_ids=left, root_sum=rs, root_count=rc, root_ss=rss.value,
-                        left_sum=ls, left_count=lc, left_ss=lss.value)
+                        left_sum=ls, left_count=lc, left_ss=lss.value,
+                        thr=thr, thr_size=ts, count0=c0, right_sum=gs, right_count=gc,
+                        right_ss=gss.value, split_feature=sf, split_slot=st, split_left_ids=sleft,
+                        split_left_sum=sls, split_left_count=slc, split_left_ss=slss.value,
+                        split_right_sum=srs, split_right_count=src, split_right_ss=srss.value,
+                        argsort=argsort.astype(np.uint32))
+
+
+def make_svml(name):
+    """An SVMLight text (every grammar case of svml.cc:38-161 the reference accepts:
+    comment lines, ragged sparse rows, `#` trailers, repeated and non-monotone qids,
+    exponents, negative zero) and what the REFERENCE's reader makes of it; plus a
+    generated set as the reference's WRITER prints it (svml.cc:163-188)."""
+    import tempfile
+    R = oracle.ref()
+    rng = np.random.default_rng(77)
+    lines = ["# golden svml fixture", "2 qid:1 1:0.5 3:1.25 # doc one", "0 qid:1 2:-3e-2\t4:7",
+             "   1   qid:1    1:1 2:2 3:3 4:4 5:5", "# another comment", "3 qid:2 5:0.125", "0 qid:2",
+             "1 qid:7 1:1e10 2:-0", "2 qid:2 3:9.5 #trailing description 6:1"]
+    qid = 10
+    for _ in range(120):
+        if rng.random() < 0.2:
+            qid += int(rng.integers(1, 4))
+        feats = np.sort(rng.choice(np.arange(1, 24), int(rng.integers(0, 9)), replace=False))
+        toks = [f"{f}:{v:.7g}" for f, v in zip(feats, rng.standard_normal(len(feats)) * 10.0 ** int(rng.integers(-3, 4)))]
+        tail = " # d%d" % _ if rng.random() < 0.3 else ""
+        lines.append(f"{int(rng.integers(0, 5))} qid:{qid} " + " ".join(toks) + tail)
+    text = ("\n".join(lines) + "\n").encode()
+    sz_ = C.c_size_t
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "g.svml")
+        open(p, "wb").write(text)
+        N, F, Q = sz_(), sz_(), sz_()
+        R.ref_svml_read(p.encode(), C.byref(N), C.byref(F), C.byref(Q), None, None, None)
+        x = np.zeros((N.value, F.value), np.float32)
+        lab = np.zeros(N.value, np.float32)
+        qoff = np.zeros(Q.value + 1, np.uint64)
+        R.ref_svml_read(p.encode(), C.byref(N), C.byref(F), C.byref(Q), x.ctypes.data, lab.ctypes.data,
+                        qoff.ctypes.data)
+        wx, wl, wq = make_dataset(nq=9, docs_per_query=7, F=11, seed=4, ragged=True, adversarial=True)
+        p2 = os.path.join(d, "w.svml")
+        R.ref_svml_write(p2.encode(), wx, wl, wq, len(wq) - 1, wx.shape[1])
+        written = np.frombuffer(open(p2, "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, name), text=np.frombuffer(text, np.uint8), x=x, labels=lab,
+                        qoff=qoff, w_x=wx, w_labels=wl, w_qoff=wq, w_text=written)
 
 
 def make_heap(name):
@@ -99,7 +165,11 @@ def make_heap(name):
 if __name__ == "__main__":
     oracle.build(ref=True)
     make_heap("heap_sym.npz")
+    make_svml("svml.npz")
     make("g1_ties_zero.npz", 10, 16, "zero", nq=12, docs_per_query=40, F=6, seed=31, ragged=True)
     make("g2_ties_few.npz", 10, 255, "few", nq=10, docs_per_query=50, F=8, seed=32, adversarial=True)
     make("g3_random.npz", 3, 8, "random", nq=8, docs_per_query=100, F=5, seed=33, ragged=True)
+    # the query sizes of SURVEY.md Appendix A's tie-order probes (17, 40, 100) with equal,
+    # few-valued and distinct scores side by side, 100 features in three blocks
+    make("g4_probe_sizes.npz", 10, 63, "few", nq=9, docs_per_query=0, F=100, seed=34, sizes=(17, 40, 100, 17, 40, 100, 16, 1, 257))
     print("golden fixtures written")

@@ -275,6 +275,22 @@ __device__ __forceinline__ double row_sum(double v) {
   return v;
 }
 
+// One value per lane, sorted in DESCENDING order over the wave's lanes (bitonic network on
+// lane exchanges; max / min keep the multiset whatever the signs of zero).
+__device__ __forceinline__ double wave_sort_desc(double v, const uint32_t lane) {
+#pragma unroll
+  for (uint32_t k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const int lo = __shfl_xor(__double2loint(v), (int)j), hi = __shfl_xor(__double2hiint(v), (int)j);
+      const double o = __hiloint2double(hi, lo);
+      // descending blocks (lane & k) == 0 keep the larger value in the lower lane
+      const bool take_max = ((lane & j) == 0) == ((lane & k) == 0);
+      v = take_max ? fmax(v, o) : fmin(v, o);
+    }
+  return v;
+}
+
 // pow(2.0, label) of dcg.cc:37 / ndcg.cc:80: exact for the integral relevance
 // grades LETOR data carries.
 __device__ __forceinline__ double pow2_label(float l) {
@@ -497,10 +513,23 @@ __device__ void wave_gnu_sort(uint32_t *a, const int n, uint32_t *LB, uint32_t *
 
 // The final insertion sort of std::sort == a stable sort by key of the arrangement the
 // partition phase left, by every thread of the workgroup (T = its size).
-template <int W>
+// PACKED: the query is ONE wave's work inside a larger workgroup (k_lambda_u): `tid` is the lane,
+// and the wave's own LDS operations are in program order (qsync<true> = a fence, no s_barrier).
+template <bool PACKED>
+__device__ __forceinline__ void qsync() {
+  if (PACKED) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  } else
+    __syncthreads();
+}
+
+template <int W, bool PACKED>
 __device__ __forceinline__ void sort_placement(const uint32_t *a, const int n, uint32_t *out,
-                                               const uint8_t *dupk, uint32_t *cnt, uint32_t *pos) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                               const uint8_t *dupk, uint32_t *cnt, uint32_t *pos,
+                                               const uint32_t tid) {
+  const int lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
   // final insertion sort == stable sort by key of the current arrangement
   // (a[n .. n4) is padded with key 0xFFFF by the caller: never counted)
@@ -542,17 +571,17 @@ __device__ __forceinline__ void sort_placement(const uint32_t *a, const int n, u
     // thousand instructions per wave, where comparing every holder with every position
     // took 100 us on a 1200-document query of tied scores.
     constexpr int T = 64 * W;
-    for (int x = (int)threadIdx.x; x < n; x += T) cnt[x] = 0;
-    __syncthreads();
-    for (int x = (int)threadIdx.x; x < n; x += T) {
+    for (int x = (int)tid; x < n; x += T) cnt[x] = 0;
+    qsync<PACKED>();
+    for (int x = (int)tid; x < n; x += T) {
       const uint32_t v = a[x], k = pk(v);
       if (!dupk[k])
         out[k] = v & 0xFFFFu;
       else
         pos[k + atomicAdd(&cnt[k], 1u)] = (uint32_t)x;
     }
-    __syncthreads();
-    for (int x = (int)threadIdx.x; x < n; x += T) {
+    qsync<PACKED>();
+    for (int x = (int)tid; x < n; x += T) {
       const uint32_t v = a[x], k = pk(v);
       if (!dupk[k]) continue;
       const uint32_t c = cnt[k];
@@ -596,27 +625,52 @@ __device__ __forceinline__ void sort_placement(const uint32_t *a, const int n, u
 // phase of the sort emulation stays one wave's work).  The per-rank sums of a W > 1 query
 // are added per wave and then pairwise over the waves in a fixed order: deterministic, and
 // within an ulp or two of the one-wave order.
-template <bool LONG, int W>
-__global__ __launch_bounds__(64 * W) void k_lambda(
-    const double *__restrict__ scores, const float *__restrict__ labels,
-    const uint32_t *__restrict__ qoff, int metric, uint32_t cutoff,
-    const double *__restrict__ idcg, const double *__restrict__ lg2,
-    const double *__restrict__ ilg2, double *__restrict__ lambda,
-    double *__restrict__ weight, double *__restrict__ qmetric,
-    uint32_t *__restrict__ ranks_out, double *__restrict__ ssq, double *__restrict__ qmax,
-    unsigned long long *__restrict__ qslot, uint32_t nmax, uint32_t kacc, int mode,
-    const uint8_t *__restrict__ present, const uint8_t *__restrict__ long_flag,
-    const uint32_t *__restrict__ long_list, char *__restrict__ lscratch, const size_t lstride,
-    const int exact_tail) {
-  extern __shared__ __attribute__((aligned(16))) char lds_mem[];
-  // (LONG = false: `long_list`, when given, is the launch's size class -- the queries whose
-  // working set fits THIS launch's LDS)
-  const uint32_t q = long_list ? long_list[blockIdx.x] : blockIdx.x;
-  if (!LONG && long_flag && long_flag[q]) return;
-  char *smem = LONG ? lscratch + (size_t)blockIdx.x * lstride : lds_mem;
+// One query: `smem` its working set (LDS, or a global scratch slice), `tid` the thread's
+// index among the 64 * W threads that work on it.  PACKED (W == 1 only): the query is one
+// wave's work inside a larger workgroup -- no s_barrier anywhere on its way (qsync).
+constexpr int QR_LAMBDA_RR = 5;  // ranks r1 per round of the pair sweep (their sums are reduced together)
+struct QrLambdaArgs {
+  const double *scores;
+  const float *labels;
+  const uint32_t *qoff;
+  int metric;
+  uint32_t cutoff;
+  const double *idcg, *lg2, *ilg2;
+  double *lambda, *weight, *qmetric;
+  uint32_t *ranks_out;
+  double *ssq, *qmax;
+  unsigned long long *qslot;
+  int mode;
+  const uint8_t *present;
+  int exact_tail;
+};
+
+template <int W, bool PACKED>
+__device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32_t q, char *smem,
+                                             const uint32_t nmax, const uint32_t kacc, const uint32_t tid,
+                                             double (*sh_part)[W][2 * QR_LAMBDA_RR], double (*sh_red)[3],
+                                             double *expt_shared) {
+  static_assert(!PACKED || W == 1, "a packed query is one wave's");
+  const double *__restrict__ scores = A.scores;
+  const float *__restrict__ labels = A.labels;
+  const uint32_t *__restrict__ qoff = A.qoff;
+  const int metric = A.metric;
+  const uint32_t cutoff = A.cutoff;
+  const double *__restrict__ idcg = A.idcg;
+  const double *__restrict__ lg2 = A.lg2;
+  const double *__restrict__ ilg2 = A.ilg2;
+  double *__restrict__ lambda = A.lambda;
+  double *__restrict__ weight = A.weight;
+  double *__restrict__ qmetric = A.qmetric;
+  uint32_t *__restrict__ ranks_out = A.ranks_out;
+  double *__restrict__ ssq = A.ssq;
+  double *__restrict__ qmax = A.qmax;
+  unsigned long long *__restrict__ qslot = A.qslot;
+  const int mode = A.mode;
+  const uint8_t *__restrict__ present = A.present;
+  const int exact_tail = A.exact_tail;
   constexpr uint32_t T = 64 * W;
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ double sh_part[2][W][2], sh_red[W][3];
+  const uint32_t lane = tid & 63, wave = tid >> 6;
 #ifdef QR_LAMBDA_TIMING
   long long tq[8];
   tq[0] = clock64();
@@ -649,8 +703,9 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   uint32_t *RB = LB + nmax;
   int *stk = reinterpret_cast<int *>(unmap + nmax);      // [3 * 40]: at most 2 lg n + 1 ranges wait
   double *ilt = reinterpret_cast<double *>(stk + 3 * 40);  // [kacc] 1/log2(r+2), top ranks
-  double *expt = ilt + kacc;                               // [64] 2^(j/64)
-  uint8_t *dupk = reinterpret_cast<uint8_t *>(expt + 64);  // [nmax, padded to 8] key occurs more than once
+  // [64] 2^(j/64): the query's own copy, or (packed queries) one table for the workgroup
+  double *expt = expt_shared ? expt_shared : ilt + kacc;
+  uint8_t *dupk = reinterpret_cast<uint8_t *>(expt_shared ? ilt + kacc : expt + 64);  // [nmax, padded to 8] key occurs more than once
   // [nmax] cleaned -> original doc; only there when a sample is drawn (`present`)
   uint32_t *cmap = reinterpret_cast<uint32_t *>(dupk + ((nmax + 7) & ~7u));
   // --subsample (lambdamart.cc:85-102): the query is "cleaned" of the documents
@@ -672,7 +727,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       cnt += __popcll(m);
     }
     n = cnt;
-    __syncthreads();
+    qsync<PACKED>();
   }
   if (n == 0) {
     if (tid == 0) {
@@ -689,7 +744,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   // NaN padding to a multiple of 4: compares false, so it never counts
   const uint32_t n4 = (n + 3) & ~3u;
   if (tid < n4 - n) s[n + tid] = __longlong_as_double(0x7ff8000000000000LL);
-  __syncthreads();
+  qsync<PACKED>();
   QR_T(1);
   // ---- 1. rank by counting: g = #docs with a strictly greater score.  Two docs
   //         per lane per sweep share the broadcast read of s[j]; one f64 compare
@@ -700,18 +755,70 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
     unmap[r] = 0xFFFFFFFFu;
     dupk[r] = 0;
   }
-  __syncthreads();
+  qsync<PACKED>();
   bool tie = false;
+  if (n > 128) {
+    // Longer queries: the same count from sorted chunks.  Every 64 scores are sorted in a
+    // wave's registers (descending; the scores by rank are not live yet: `sr` holds the chunks),
+    // and a document counts the scores above its own chunk by chunk with a binary search --
+    // seven probes per chunk instead of sixty-four compares.  g is an exact integer either way.
+    double *srt = sr;
+    const uint32_t nch = (n + 63) >> 6;
+    for (uint32_t ch = wave; ch < nch; ch += W) {
+      const uint32_t i = ch * 64 + lane;
+      const double v = wave_sort_desc(i < n ? s[i] : -__builtin_inf(), lane);
+      if (i < n) srt[i] = v;  // (the padding sorts to the chunk's end: beyond n)
+    }
+    qsync<PACKED>();
+    for (uint32_t i = tid; i < n; i += T) {
+      const double a = s[i];
+      uint32_t g = 0;
+      // (six chunks side by side: a probe waits for the one before it in ITS chunk only)
+      constexpr uint32_t G = 6;
+      for (uint32_t c0 = 0; c0 < nch; c0 += G) {
+        uint32_t pos[G], len[G];  // the chunk's scores [0, pos) are above a
+#pragma unroll
+        for (uint32_t u = 0; u < G; ++u) {
+          const uint32_t base = (c0 + u) * 64;
+          len[u] = base >= n ? 0u : (n - base < 64 ? n - base : 64u);
+          pos[u] = 0;
+        }
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1) {
+          double e[G];
+#pragma unroll
+          for (uint32_t u = 0; u < G; ++u) {
+            const uint32_t t = pos[u] + step;
+            e[u] = t <= len[u] ? srt[(c0 + u) * 64 + t - 1] : a;
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < G; ++u) pos[u] += e[u] > a ? step : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < G; ++u) {
+          if (pos[u] == 63 && len[u] == 64 && srt[(c0 + u) * 64 + 63] > a) pos[u] = 64;
+          g += pos[u];
+        }
+      }
+      unmap[g] = i;
+      pa[i] = (g << 16) | i;
+    }
+  } else
   for (uint32_t ib = tid; ib < n; ib += 2 * T) {
     const uint32_t i0 = ib, i1 = ib + T;
     const bool has1 = i1 < n;
     const double a0 = s[i0], a1 = has1 ? s[i1] : 0.0;
     uint32_t g0 = 0, g1 = 0;
+    if (W == 1 || __any(has1)) {
 #pragma unroll 4
-    for (uint32_t j = 0; j < n4; ++j) {
-      const double sj = s[j];
-      g0 += sj > a0;
-      g1 += sj > a1;
+      for (uint32_t j = 0; j < n4; ++j) {
+        const double sj = s[j];
+        g0 += sj > a0;
+        g1 += sj > a1;
+      }
+    } else {  // (a wave of a long query's last sweep: one document per lane)
+#pragma unroll 4
+      for (uint32_t j = 0; j < n4; ++j) g0 += s[j] > a0;
     }
     unmap[g0] = i0;            // exact whenever no two scores tie
     pa[i0] = (g0 << 16) | i0;  // identity arrangement, as queryresults.cc:50-51
@@ -720,7 +827,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       pa[i1] = (g1 << 16) | i1;
     }
   }
-  __syncthreads();
+  qsync<PACKED>();
   for (uint32_t i = tid; i < n; i += T) {
     const uint32_t key = pa[i] >> 16;
     const bool lost = unmap[key] != i;  // somebody else holds my slot: the key is shared
@@ -729,21 +836,21 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   }
   if (tid < n4 - n) pa[n + tid] = 0xFFFFFFFFu;
   const bool anytie = W == 1 ? (bool)__any(tie) : (bool)__syncthreads_or(tie);
-  __syncthreads();
+  qsync<PACKED>();
   QR_T(2);
   // ---- 2. with ties the permutation is what GNU std::sort leaves: the partition phase by
   //         one wave, the stable placement that ends it by all
   if (anytie) {
     const int limit = exact_tail ? (int)n : (int)(cutoff < n ? cutoff : n);
     if (W == 1) {
-      wave_gnu_sort<true>(pa, (int)n, LB, RB, stk, dupk, limit);
+      wave_gnu_sort<!PACKED>(pa, (int)n, LB, RB, stk, dupk, limit);
     } else {
       if (wave == 0) wave_gnu_sort<false>(pa, (int)n, LB, RB, stk, dupk, limit);
-      __syncthreads();
+      qsync<PACKED>();
     }
     QR_TS(8);
-    sort_placement<W>(pa, (int)n, unmap, dupk, LB, RB);
-    __syncthreads();
+    sort_placement<W, PACKED>(pa, (int)n, unmap, dupk, LB, RB, tid);
+    qsync<PACKED>();
   }
   QR_T(3);
   for (uint32_t r = tid; r < n; r += T) {
@@ -752,7 +859,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
     sr[r] = s[d];
     if (ranks_out) ranks_out[off + r] = present ? cmap[d] : d;
   }
-  __syncthreads();
+  qsync<PACKED>();
   const uint32_t size = cutoff < n ? cutoff : n;
   double my_idcg = metric == QR_METRIC_NDCG ? idcg[q] : 1.0;
   if (present && metric == QR_METRIC_NDCG) {
@@ -770,12 +877,12 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       }
       sorted_gain[r] = pow2_label(lab0[j]) - 1.0;
     }
-    __syncthreads();
+    qsync<PACKED>();
     double v = 0.0;
     if (lane == 0)
       for (uint32_t i = 0; i < size; ++i) v += sorted_gain[i] / lg2[i];
     my_idcg = readlane_f64(v, 0);
-    __syncthreads();
+    qsync<PACKED>();
   }
   // ---- 3. metric of the current ranking (dcg.cc:33-39, ndcg.cc:49-58)
   if (W == 1 || wave == 0) {
@@ -813,7 +920,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   }
   for (uint32_t i = tid; i < size; i += T) ilt[i] = ilg2[i];
   if (tid < 64) expt[tid] = QR_EXP_T[tid];
-  __syncthreads();
+  qsync<PACKED>();
   const double *pw = s;
   const uint32_t nbatch = (n + 63) / 64;
   const double inv_idcg = metric == QR_METRIC_NDCG ? 1.0 / my_idcg : 1.0;  // (ndcg.cc:81: / idcg, to an ulp)
@@ -956,73 +1063,99 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   const bool use_e = sr[0] - sr[n - 1] <= 690.0;
   {
     const double smax = sr[0];
-    __syncthreads();  // (every thread has read sr[0], sr[n - 1])
+    qsync<PACKED>();  // (every thread has read sr[0], sr[n - 1])
     if (use_e)
       for (uint32_t r = tid; r < n; r += T) sr[r] = qr_exp(sr[r] - smax, expt);
-    __syncthreads();
+    qsync<PACKED>();
   }
-  for (uint32_t r1 = 0; r1 < size; ++r1) {
-    // uniform over the wave
-    const float l1 = sl[r1];
-    const double p1 = pw[r1];
-    const double inv1 = ilt[r1];
-    const double s1 = sr[r1];
-    double c1 = 0.0, cw = 0.0;
-    for (uint32_t bt = r1 / 64 + (W > 1 ? wave : 0u); bt < nbatch; bt += W) {  // a wave's batches
+  // Rounds of five ranks r1, as above: a lane's batch position r2 meets the round's five ranks
+  // in turn (its own accumulators stay in registers for the round: the same subtractions in
+  // the same order as one rank at a time), the round's ten per-lane sums are reduced together,
+  // and with several waves ONE barrier ends the round (their sums meet in `sh_part`, added
+  // pairwise in wave order by ten threads) -- where one rank at a time took a barrier, two
+  // wave sums and a single thread's additions per rank.
+  constexpr int RR = QR_LAMBDA_RR;
+  for (uint32_t rbase = 0; rbase < size; rbase += RR) {
+    float l1v[RR];
+    double p1v[RR], inv1v[RR], s1v[RR];
+#pragma unroll
+    for (int u = 0; u < RR; ++u) {  // uniform over the wave (clamped: unused beyond `size`)
+      const uint32_t r1 = rbase + u < size ? rbase + u : rbase;
+      l1v[u] = sl[r1];
+      p1v[u] = pw[r1];
+      inv1v[u] = ilt[r1];
+      s1v[u] = sr[r1];
+    }
+    double c1v[RR], cwv[RR];
+#pragma unroll
+    for (int u = 0; u < RR; ++u) c1v[u] = cwv[u] = 0.0;
+    for (uint32_t bt = rbase / 64 + (W > 1 ? wave : 0u); bt < nbatch; bt += W) {  // a wave's batches
       const uint32_t r2 = bt * 64 + lane;
-      if (r2 < n && r2 > r1) {
+      if (r2 < n && r2 > rbase) {
         const float l2 = sl[r2];
-        if (l1 != l2) {
-          double slam, del;
-          if (use_e)
-            pair_term_e(l1, p1, inv1, s1, l2, pw[r2], r2 < size ? ilt[r2] : 0.0, sr[r2], slam, del);
-          else
-            pair_term(l1, p1, inv1, s1, l2, pw[r2], r2 < size ? ilt[r2] : 0.0, sr[r2], slam, del);
-          c1 += slam;
-          cw += del;
-          ownl[r2] -= slam;  // only this lane touches rank r2
-          ownw[r2] += del;
-        }
-      }
-    }
-    double t1 = 0.0, tw = 0.0;
-    if (__any(c1 != 0.0 || cw != 0.0)) {
-      t1 = wave_sum(c1);
-      tw = wave_sum(cw);
-    }
-    if (W == 1) {
-      if (lane == 0) {
-        accl[r1] = t1;
-        accw[r1] = tw;
-      }
-    } else {  // the waves' sums, added in wave order (two buffers: one barrier per rank)
-      if (lane == 0) {
-        sh_part[r1 & 1][wave][0] = t1;
-        sh_part[r1 & 1][wave][1] = tw;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        // pairwise over the waves: ((w0 + w1) + (w2 + w3)) + ...
-        double vl[W], vw[W];
+        const double p2 = pw[r2], il2 = r2 < size ? ilt[r2] : 0.0, s2 = sr[r2];
+        double ol = ownl[r2], ow = ownw[r2];  // only this lane touches rank r2 in this round
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-          vl[w] = sh_part[r1 & 1][w][0];
-          vw[w] = sh_part[r1 & 1][w][1];
-        }
-#pragma unroll
-        for (int st = 1; st < W; st *= 2)
-#pragma unroll
-          for (int w = 0; w < W; w += 2 * st) {
-            vl[w] += vl[w + st];
-            vw[w] += vw[w + st];
+        for (int u = 0; u < RR; ++u) {
+          const uint32_t r1 = rbase + u;
+          if (r1 < size && r2 > r1 && l1v[u] != l2) {
+            double slam, del;
+            if (use_e)
+              pair_term_e(l1v[u], p1v[u], inv1v[u], s1v[u], l2, p2, il2, s2, slam, del);
+            else
+              pair_term(l1v[u], p1v[u], inv1v[u], s1v[u], l2, p2, il2, s2, slam, del);
+            c1v[u] += slam;
+            cwv[u] += del;
+            ol -= slam;
+            ow += del;
           }
-        accl[r1] = vl[0];
-        accw[r1] = vw[0];
+        }
+        ownl[r2] = ol;
+        ownw[r2] = ow;
+      }
+    }
+    double x[RR];
+#pragma unroll
+    for (int u = 0; u < RR; ++u) x[u] = swap32_add(c1v[u], cwv[u]);
+    double z0 = swap16_add(x[0], x[1]), z1 = swap16_add(x[2], x[3]), z2 = swap16_add(x[4], 0.0);
+    z0 = row_sum(z0);
+    z1 = row_sum(z1);
+    z2 = row_sum(z2);
+    const uint32_t odd = (lane >> 4) & 1u;  // rows 1, 3: the odd ranks of the round
+    if (W == 1) {
+      if ((lane & 15u) == 0) {
+        double *acc = lane < 32 ? accl : accw;  // rows 0, 1: the lambdas' sums; rows 2, 3: the weights'
+        if (rbase + odd < size) acc[rbase + odd] = z0;
+        if (rbase + 2 + odd < size) acc[rbase + 2 + odd] = z1;
+        if (!odd && rbase + 4 < size) acc[rbase + 4] = z2;
+      }
+    } else {  // the waves' sums, added in wave order (two buffers: one barrier per round)
+      const uint32_t par = (rbase / RR) & 1u;
+      if ((lane & 15u) == 0) {
+        double *dst = &sh_part[par][wave][lane < 32 ? 0 : RR];
+        dst[odd] = z0;
+        dst[2 + odd] = z1;
+        if (!odd) dst[4] = z2;
+      }
+      qsync<PACKED>();
+      if (tid < 2 * RR) {
+        const uint32_t u = tid % RR, r1 = rbase + u;
+        if (r1 < size) {
+          // pairwise over the waves: ((w0 + w1) + (w2 + w3)) + ...
+          double v[W];
+#pragma unroll
+          for (int w = 0; w < W; ++w) v[w] = sh_part[par][w][tid];
+#pragma unroll
+          for (int st = 1; st < W; st *= 2)
+#pragma unroll
+            for (int w = 0; w < W; w += 2 * st) v[w] += v[w + st];
+          (tid < RR ? accl : accw)[r1] = v[0];
+        }
       }
     }
   }
   }
-  __syncthreads();
+  qsync<PACKED>();
   QR_T(5);
   double mx = 0.0, sq = 0.0, sm = 0.0;
   for (uint32_t r = tid; r < n; r += T) {
@@ -1048,7 +1181,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
       sh_red[wave][1] = sq;
       sh_red[wave][2] = sm;
     }
-    __syncthreads();
+    qsync<PACKED>();
     double vm[W], vq[W], vs[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) {
@@ -1082,11 +1215,75 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   }
 #ifdef QR_LAMBDA_TIMING
   QR_T(6);
-  if (tid == 0 && (q == 0 || q == 5000 || n > 1100))
+  if (tid == 0 && (q % 211 == 0 || n > 540))
     printf("k_lambda q=%u n=%u tie=%d: load %lld count %lld sort %lld rank/metric %lld pairs %lld out %lld total %lld\n",
            q, n, (int)anytie, tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4],
            tq[6] - tq[5], tq[6] - tq[0]);
 #endif
+}
+
+template <bool LONG, int W>
+__global__ __launch_bounds__(64 * W) void k_lambda(
+    const double *__restrict__ scores, const float *__restrict__ labels,
+    const uint32_t *__restrict__ qoff, int metric, uint32_t cutoff,
+    const double *__restrict__ idcg, const double *__restrict__ lg2,
+    const double *__restrict__ ilg2, double *__restrict__ lambda,
+    double *__restrict__ weight, double *__restrict__ qmetric,
+    uint32_t *__restrict__ ranks_out, double *__restrict__ ssq, double *__restrict__ qmax,
+    unsigned long long *__restrict__ qslot, uint32_t nmax, uint32_t kacc, int mode,
+    const uint8_t *__restrict__ present, const uint8_t *__restrict__ long_flag,
+    const uint32_t *__restrict__ long_list, char *__restrict__ lscratch, const size_t lstride,
+    const int exact_tail) {
+  extern __shared__ __attribute__((aligned(16))) char lds_mem[];
+  // (LONG = false: `long_list`, when given, is the launch's size class -- the queries whose
+  // working set fits THIS launch's LDS)
+  const uint32_t q = long_list ? long_list[blockIdx.x] : blockIdx.x;
+  if (!LONG && long_flag && long_flag[q]) return;
+  char *smem = LONG ? lscratch + (size_t)blockIdx.x * lstride : lds_mem;
+  __shared__ double sh_part[2][W][2 * QR_LAMBDA_RR], sh_red[W][3];
+  const QrLambdaArgs A = {scores, labels, qoff,  metric, cutoff, idcg, lg2,     ilg2,      lambda,
+                          weight, qmetric, ranks_out, ssq,    qmax,   qslot, mode, present, exact_tail};
+  lambda_query<W, false>(A, q, smem, nmax, kacc, threadIdx.x, sh_part, sh_red, (double *)nullptr);
+}
+
+// ONE launch for a ragged query set (config 1's shape): workgroups of eight waves in three
+// roles, dispatched longest queries first --
+//   [0, nC)   a query of more than 512 documents, the eight waves together;
+//   then      three queries of 257 .. 512 documents, one wave each (the other waves leave: a
+//             query's sort emulation is one wave's work anyway, and a wave of its own costs the
+//             chip an eighth of the slots eight waves waiting for it do);
+//   then      six queries of 129 .. 256 documents, one wave each;
+//   the rest  eight queries of up to 128 documents, one wave each
+// -- in place of one launch per size class side by side on auxiliary streams (fork, three or
+// four launches, join: the join alone cost ~18 us, and each class waited for its own longest
+// query).  `list`: the queries in dispatch order.  LDS: every role carves the same dynamic
+// block (two workgroups per CU: the kernel's 122 VGPRs allow sixteen waves there).
+__global__ __launch_bounds__(64 * QR_LU_W) void k_lambda_u(const QrLambdaArgs A, const QrLambdaPlanDev P,
+                                                           const uint32_t *__restrict__ list,
+                                                           const uint32_t *__restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) char lds_mem[];
+  __shared__ double sh_part[2][QR_LU_W][2 * QR_LAMBDA_RR], sh_red[QR_LU_W][3], sh_expt[64];
+  // (`order`: the workgroup's place in the role numbering, when the dispatch order is not it)
+  const uint32_t b = order ? order[blockIdx.x] : blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+  if (b < P.nC) {
+    // the launch's critical path: the longest queries, first in and ahead of their neighbours
+    __builtin_amdgcn_s_setprio(3);
+    lambda_query<QR_LU_W, false>(A, list[b], lds_mem, P.nmaxC, P.kaccC, tid, sh_part, sh_red, sh_expt);
+    return;
+  }
+  // packed roles: one wave per query, `per` queries per workgroup (the other waves leave)
+  uint32_t bb = b - P.nC, r = 0;
+  while (r + 1 < QR_LU_ROLES && bb >= P.pk[r].blocks) bb -= P.pk[r++].blocks;
+  if (wave >= P.pk[r].per) return;
+  uint32_t idx = bb * P.pk[r].per + wave;
+  if (idx >= P.pk[r].count) return;
+  idx += P.pk[r].first;
+  const uint32_t nmax = P.pk[r].nmax, kacc = P.pk[r].kacc;
+  char *smem = lds_mem + (size_t)wave * P.pk[r].slice;
+  // (every wave fills the workgroup's exponential table itself, with the same values, before
+  // its own fence: no wave waits for another)
+  lambda_query<1, true>(A, list[idx], smem, nmax, kacc, tid & 63u, (double(*)[1][2 * QR_LAMBDA_RR]) nullptr,
+                        (double(*)[3]) nullptr, sh_expt);
 }
 
 // Mart::compute_pseudoresponses (mart.cc:418-431): label - score
@@ -1136,10 +1333,10 @@ __global__ __launch_bounds__(256) void k_residual(const float *__restrict__ labe
 __global__ __launch_bounds__(64) void k_prep(const QrPrepJob j) { prep_body<16>(j, blockIdx.x, gridDim.x); }
 
 // ---------------------------------------------------------------------------
-static size_t lambda_lds(size_t nmax, size_t kacc, bool sampled) {
+static size_t lambda_lds(size_t nmax, size_t kacc, bool sampled, bool own_expt = true) {
   // s/sr[nmax] f64, accl/accw[kacc] f64, ownl/ownw[nmax] f64 (aliased by the sort
   // scratch), lab0/sl f32, unmap u32, stk, ilt[kacc] f64, expt, dupk, (cmap u32)
-  return nmax * 16 + kacc * 16 + nmax * 16 + nmax * 12 + 3 * 40 * 4 + kacc * 8 + 64 * 8 +
+  return nmax * 16 + kacc * 16 + nmax * 16 + nmax * 12 + 3 * 40 * 4 + kacc * 8 + (own_expt ? 64 * 8 : 0) +
          ((nmax + 7) & ~(size_t)7) + (sampled ? nmax * 4 : 0);
 }
 
@@ -1176,20 +1373,125 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   int &tag = which ? c->long_tag[which] : c->long_tag[0];
   std::vector<uint32_t> &llist = which ? c->h_long_list[1] : c->h_long_list[0];
   std::vector<qr_ctx::QClass> &classes = c->h_qclass[which];
-  if (tag != (int)nmax_lds) {  // (re)build the classes and the long list for this capacity
+  // The single launch of a ragged set (k_lambda_u): its three roles carve one dynamic LDS block
+  // per workgroup -- eight packed working sets of up to 128 documents, four of up to 256, or one
+  // query of up to `capC` documents -- sized so that three workgroups share a CU.  Queries
+  // beyond capC keep their own launches (size class / global scratch) beside it.
+  static const int lu_env = [] {
+    const char *e = getenv("QR_LAMBDA_UNIFIED");
+    return e ? atoi(e) : 1;
+  }();
+  auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  // a packed role's capacity (a role whose bound repeats the next one's stays empty: by default
+  // no query of more than 256 documents is one wave's work -- measured on the MSLR-shaped set:
+  // {512, 256, 128} 0.471 ms per iteration, {256, 256, 128} 0.456)
+  static uint32_t kPackBound[QR_LU_ROLES] = {256, 256, 128};
+  static const int lu_order = [] {
+    if (const char *e = getenv("QR_LU_BOUNDS")) {  // experiments: "512,256,128"
+      unsigned a = 0, b = 0, c3 = 0;
+      if (sscanf(e, "%u,%u,%u", &a, &b, &c3) == 3 && a >= b && b >= c3 && c3 >= 4 && a <= 2048) {
+        kPackBound[0] = a & ~3u;
+        kPackBound[1] = b & ~3u;
+        kPackBound[2] = c3 & ~3u;
+      }
+    }
+    const char *o = getenv("QR_LU_ORDER");
+    return o ? atoi(o) : 0;
+  }();
+  size_t pk_kacc[QR_LU_ROLES], pk_slice[QR_LU_ROLES], pk_per[QR_LU_ROLES];
+  // 160 KB / 2 (the kernel's VGPRs allow two workgroups of eight waves per CU) less its static
+  // 2 KB (sh_part, sh_red, sh_expt); a packed role takes as many queries per workgroup as fit
+  // (three, six and eight at cutoff 10)
+  size_t lu_dyn = 77824;
+  for (int r = 0; r < QR_LU_ROLES; ++r) {
+    pk_kacc[r] = std::min<size_t>(kacc, kPackBound[r]);
+    pk_slice[r] = a16(lambda_lds(kPackBound[r], pk_kacc[r], false, false));
+    lu_dyn = std::max(lu_dyn, (r == QR_LU_ROLES - 1 ? (size_t)QR_LU_W : (size_t)2) * pk_slice[r]);
+  }
+  for (int r = 0; r < QR_LU_ROLES; ++r) pk_per[r] = std::min<size_t>(QR_LU_W, lu_dyn / pk_slice[r]);
+  size_t capC = std::min<size_t>(nmax_lds, 4096);
+  while (capC > kPackBound[0] && lambda_lds(capC, std::min(kacc, capC), false, false) > lu_dyn) capC -= 4;
+  bool lu_try = lu_env && !sampled && lu_dyn <= limit && capC > kPackBound[0];
+  const int want_tag = (int)nmax_lds + ((int)capC << 16) + (lu_try ? 1 << 30 : 0);
+  if (tag != want_tag) {  // (re)build the classes and the long list for this capacity
     std::vector<std::vector<uint32_t>> by(sizeof(kClassBound) / sizeof(kClassBound[0]));
     std::vector<uint32_t> cmax(by.size(), 0);
-    llist.clear();
-    for (size_t q = 0; q < Q; ++q) {
-      const size_t n = qo[q + 1] - qo[q];
-      if (n > nmax_lds) {
-        llist.push_back((uint32_t)q);
-        continue;
+    std::vector<uint32_t> role[1 + QR_LU_ROLES];  // 513 .. capC documents together; then the packed roles
+    for (int pass = 0; pass < 2; ++pass) {
+      llist.clear();
+      for (auto &v : by) v.clear();
+      for (auto &v : role) v.clear();
+      std::fill(cmax.begin(), cmax.end(), 0u);
+      for (size_t q = 0; q < Q; ++q) {
+        const size_t n = qo[q + 1] - qo[q];
+        if (n > nmax_lds) {
+          llist.push_back((uint32_t)q);
+          continue;
+        }
+        if (lu_try && n <= capC) {
+          int r = 0;
+          while (r < QR_LU_ROLES && n <= kPackBound[r]) ++r;  // the smallest role that holds it
+          role[r].push_back((uint32_t)q);
+          continue;
+        }
+        size_t k = 0;
+        while (n > kClassBound[k]) ++k;
+        by[k].push_back((uint32_t)q);
+        cmax[k] = std::max(cmax[k], (uint32_t)n);
       }
-      size_t k = 0;
-      while (n > kClassBound[k]) ++k;
-      by[k].push_back((uint32_t)q);
-      cmax[k] = std::max(cmax[k], (uint32_t)n);
+      // a set that one launch of one kind serves anyway (every query in the same role and
+      // nothing beside it -- the uniform bench set) keeps that launch: no list, no roles
+      int kinds = 0;
+      for (auto &v : role) kinds += v.empty() ? 0 : 1;
+      size_t others = llist.empty() ? 0 : 1;
+      for (auto &v : by) others += v.empty() ? 0 : 1;
+      if (!lu_try || kinds + others >= 2) break;
+      lu_try = false;
+    }
+    c->lu_on[which] = lu_try;
+    std::vector<uint32_t> ulist;
+    if (lu_try) {
+      QrLambdaPlanDev &P = c->lu_plan[which];
+      for (auto &v : role)  // longest first (equal lengths in query order)
+        std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return qo[a + 1] - qo[a] > qo[b + 1] - qo[b]; });
+      uint32_t nmaxC = role[0].empty() ? 0u : (uint32_t)(qo[role[0][0] + 1] - qo[role[0][0]]);
+      nmaxC = std::max<uint32_t>((nmaxC + 3) & ~3u, kPackBound[0] + 4);
+      P.nC = (uint32_t)role[0].size();
+      P.nmaxC = nmaxC;
+      P.kaccC = (uint32_t)std::min<size_t>(kacc, nmaxC);
+      ulist = role[0];
+      P.blocks = P.nC;
+      for (int r = 0; r < QR_LU_ROLES; ++r) {
+        const std::vector<uint32_t> &v = role[1 + r];  // role[1] = 257 .. 512 documents, ... role[3] = up to 128
+        P.pk[r].first = (uint32_t)ulist.size();
+        P.pk[r].count = (uint32_t)v.size();
+        P.pk[r].per = (uint32_t)pk_per[r];
+        P.pk[r].blocks = (uint32_t)((v.size() + pk_per[r] - 1) / pk_per[r]);
+        P.pk[r].nmax = kPackBound[r];
+        P.pk[r].kacc = (uint32_t)pk_kacc[r];
+        P.pk[r].slice = (uint32_t)pk_slice[r];
+        P.blocks += P.pk[r].blocks;
+        ulist.insert(ulist.end(), v.begin(), v.end());
+      }
+      c->lu_dyn[which] = std::max(lu_dyn, lambda_lds(nmaxC, P.kaccC, false, false));
+      // dispatch order (experiments; 0 = the role numbering itself: longest queries first)
+      c->lu_ordered[which] = lu_order != 0;
+      if (lu_order) {
+        std::vector<uint32_t> ord;
+        const uint32_t nb = P.blocks;
+        if (lu_order == 1) {  // the packed roles first, the eight-wave queries after them
+          for (uint32_t b = P.nC; b < nb; ++b) ord.push_back(b);
+          for (uint32_t b = 0; b < P.nC; ++b) ord.push_back(b);
+        } else {  // groups of eight workgroups (one per XCD) in turn: eight-wave queries, packed ones
+          uint32_t a = 0, b = P.nC;
+          while (a < P.nC || b < nb) {
+            for (int k = 0; k < 8 && a < P.nC; ++k) ord.push_back(a++);
+            for (int k = 0; k < 8 * (lu_order - 1) && b < nb; ++k) ord.push_back(b++);
+          }
+        }
+        ulist.insert(ulist.end(), ord.begin(), ord.end());  // (behind the queries, in the same buffer)
+        c->lu_order_off[which] = ulist.size() - ord.size();
+      }
     }
     // (Measured and left out: the longest queries first inside a class -- the 16-wave launch of the
     // MSLR-shaped set stays at 74 us: its time is its longest query's, not a dispatch-order tail.)
@@ -1208,19 +1510,24 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
         classes.erase(classes.begin() + k);
       } else
         ++k;
-    c->qclass_identity[which] = classes.size() == 1 && classes[0].count == Q;
+    c->qclass_identity[which] = classes.size() == 1 && classes[0].count == Q && !lu_try;
     QR_CHECK(c, hipStreamSynchronize(c->stream));
     uint32_t *&dq = c->d_qclass[which];
     uint32_t *&dl = c->d_long_list[which];
+    uint32_t *&du = c->d_lu_list[which];
     if (dq) (void)hipFree(dq);
     if (dl) (void)hipFree(dl);
+    if (du) (void)hipFree(du);
     dq = nullptr;
     dl = nullptr;
+    du = nullptr;
     QR_CHECK(c, hipMalloc((void **)&dq, (flat.size() + 1) * 4));
     QR_CHECK(c, hipMalloc((void **)&dl, (llist.size() + 1) * 4));
+    QR_CHECK(c, hipMalloc((void **)&du, (ulist.size() + 1) * 4));
     QR_CHECK(c, hipMemcpy(dq, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
     QR_CHECK(c, hipMemcpy(dl, llist.data(), llist.size() * 4, hipMemcpyHostToDevice));
-    tag = (int)nmax_lds;
+    QR_CHECK(c, hipMemcpy(du, ulist.data(), ulist.size() * 4, hipMemcpyHostToDevice));
+    tag = want_tag;
   }
   const size_t nlong = llist.size();
   size_t lstride = 0, nmax_long = 0;
@@ -1256,7 +1563,8 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   // One launch per size class (its LDS sized for the class's longest query), the launches
   // side by side on auxiliary streams when there are several: the few long queries of a
   // ragged set no longer dictate the occupancy of the many short ones.
-  const size_t nlaunch = classes.size() + (nlong ? 1 : 0);
+  const bool lu_on = c->lu_on[which];
+  const size_t nlaunch = classes.size() + (nlong ? 1 : 0) + (lu_on ? 1 : 0);
   const bool fork = nlaunch > 1;
   if (fork) {
     if (!c->aux_fork) QR_CHECK(c, hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
@@ -1290,6 +1598,32 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     *out = c->aux_stream[a];
     return QR_OK;
   };
+  if (lu_on) {  // the ragged set's single launch, on the context's own stream
+    const QrLambdaPlanDev &P = c->lu_plan[which];
+    const size_t lds = c->lu_dyn[which];
+    if (lds > c->attr_lambda_u_lds) {
+      QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda_u, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      c->attr_lambda_u_lds = lds;
+    }
+    hipStream_t st;
+    int rc = stream_for(li++, &st);
+    if (rc) return rc;
+    const QrLambdaArgs A = {sc, lb,  qoffd, metric, cut,   idcg, c->d_lg2, c->d_ilg2,    lam,
+                            wgt, qm, ranks, ssq,    c->d_qmax, qslot, md,   present,  c->exact_tail};
+    const unsigned grid = P.blocks;
+    const uint32_t *lu_ord = c->lu_ordered[which] ? c->d_lu_list[which] + c->lu_order_off[which] : (const uint32_t *)nullptr;
+    if (c->prof_on && c->prof_lambda && !fork && !which && mode == 0) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      QR_CHECK(c, hipEventCreate(&e0));
+      QR_CHECK(c, hipEventCreate(&e1));
+      hipExtLaunchKernelGGL(k_lambda_u, dim3(grid), dim3(64 * QR_LU_W), lds, st, e0, e1, 0, A, P,
+                            (const uint32_t *)c->d_lu_list[which], lu_ord);
+      c->prof_events_child.push_back({e0, e1});
+    } else
+      hipLaunchKernelGGL(k_lambda_u, dim3(grid), dim3(64 * QR_LU_W), lds, st, A, P,
+                         (const uint32_t *)c->d_lu_list[which], lu_ord);
+    QR_CHECK(c, hipGetLastError());
+  }
   // the longest-running launches first: the largest class, then down
   for (size_t k = classes.size(); k-- > 0;) {
     const qr_ctx::QClass &cl = classes[k];

@@ -201,6 +201,9 @@ static void free_long(qr_ctx *c, int which) {
   c->long_tag[which] = -1;
   if (c->d_qclass[which]) (void)hipFree(c->d_qclass[which]);
   c->d_qclass[which] = nullptr;
+  if (c->d_lu_list[which]) (void)hipFree(c->d_lu_list[which]);
+  c->d_lu_list[which] = nullptr;
+  c->lu_on[which] = false;
   c->h_qclass[which].clear();
 }
 

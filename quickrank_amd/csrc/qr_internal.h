@@ -277,6 +277,18 @@ struct QrPinned {
   int64_t early[4];
 };
 
+// k_lambda_u's roles (k_lambda.hip): workgroups [0, nC) take one query each, the eight waves
+// together; then QR_LU_ROLES packed roles (a query per wave), largest capacity first
+#define QR_LU_W 8
+#define QR_LU_ROLES 3
+struct QrLambdaPlanDev {
+  uint32_t nC, nmaxC, kaccC, blocks;  // (blocks: the whole grid)
+  struct {
+    uint32_t blocks, per, count, first;  // workgroups, queries per workgroup, queries, their place in the list
+    uint32_t nmax, kacc, slice;          // capacity (documents), top ranks kept, bytes of a working set
+  } pk[QR_LU_ROLES];
+};
+
 struct qr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -405,6 +417,14 @@ struct qr_ctx {
   struct QClass { uint32_t first, count, nmax; };
   std::vector<QClass> h_qclass[2];
   bool qclass_identity[2] = {false, false};  // one class holding every query in order
+  // ... or, for a ragged set, ONE launch of three roles (k_lambda_u): the queries in dispatch order
+  uint32_t *d_lu_list[2] = {nullptr, nullptr};
+  QrLambdaPlanDev lu_plan[2];
+  size_t lu_dyn[2] = {0, 0};
+  bool lu_on[2] = {false, false};
+  bool lu_ordered[2] = {false, false};
+  size_t lu_order_off[2] = {0, 0};
+  size_t attr_lambda_u_lds = 64 * 1024;
   hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t aux_fork = nullptr, aux_join[4] = {nullptr, nullptr, nullptr, nullptr};
   char *d_lscratch = nullptr;

@@ -645,7 +645,11 @@ struct QrLambdaArgs {
   int exact_tail;
 };
 
-template <int W, bool PACKED>
+// SMALL: every query of the launch has at most 128 documents -- the paths of longer queries
+// (sorted-chunk rank, the pair sweep's rounds over LDS) are compiled out, and with them their
+// registers: 72 VGPRs instead of 105, seven waves per SIMD instead of four (the uniform bench
+// set's launch: 45.6 us, 51.2 with the long paths compiled in).
+template <int W, bool PACKED, bool SMALL = false>
 __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32_t q, char *smem,
                                              const uint32_t nmax, const uint32_t kacc, const uint32_t tid,
                                              double (*sh_part)[W][2 * QR_LAMBDA_RR], double (*sh_red)[3],
@@ -757,7 +761,7 @@ __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32
   }
   qsync<PACKED>();
   bool tie = false;
-  if (n > 128) {
+  if (!SMALL && n > 128) {
     // Longer queries: the same count from sorted chunks.  Every 64 scores are sorted in a
     // wave's registers (descending; the scores by rank are not live yet: `sr` holds the chunks),
     // and a document counts the scores above its own chunk by chunk with a binary search --
@@ -773,30 +777,28 @@ __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32
     for (uint32_t i = tid; i < n; i += T) {
       const double a = s[i];
       uint32_t g = 0;
-      // (six chunks side by side: a probe waits for the one before it in ITS chunk only)
-      constexpr uint32_t G = 6;
+      // (four chunks side by side: a probe waits for the one before it in ITS chunk only; a
+      // chunk beyond the query has no scores above anything)
+      constexpr uint32_t G = 4;
       for (uint32_t c0 = 0; c0 < nch; c0 += G) {
-        uint32_t pos[G], len[G];  // the chunk's scores [0, pos) are above a
+        uint32_t pos[G];  // the chunk's scores [0, pos) are above a
 #pragma unroll
-        for (uint32_t u = 0; u < G; ++u) {
-          const uint32_t base = (c0 + u) * 64;
-          len[u] = base >= n ? 0u : (n - base < 64 ? n - base : 64u);
-          pos[u] = 0;
-        }
+        for (uint32_t u = 0; u < G; ++u) pos[u] = 0;
 #pragma unroll
         for (uint32_t step = 32; step; step >>= 1) {
           double e[G];
 #pragma unroll
           for (uint32_t u = 0; u < G; ++u) {
-            const uint32_t t = pos[u] + step;
-            e[u] = t <= len[u] ? srt[(c0 + u) * 64 + t - 1] : a;
+            const uint32_t t = (c0 + u) * 64 + pos[u] + step;  // (position + 1 in the query)
+            e[u] = t <= n ? srt[t - 1] : a;
           }
 #pragma unroll
           for (uint32_t u = 0; u < G; ++u) pos[u] += e[u] > a ? step : 0u;
         }
 #pragma unroll
         for (uint32_t u = 0; u < G; ++u) {
-          if (pos[u] == 63 && len[u] == 64 && srt[(c0 + u) * 64 + 63] > a) pos[u] = 64;
+          const uint32_t t = (c0 + u) * 64 + 64;
+          if (pos[u] == 63 && t <= n && srt[t - 1] > a) pos[u] = 64;
           g += pos[u];
         }
       }
@@ -960,7 +962,7 @@ __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32
     slam = flip(rho * d, lo1);
     del = rho * (1.0 - rho) * d;
   };
-  if (n <= 128) {
+  if (SMALL || n <= 128) {
     if (W == 1 || wave == 0) {
     // Every lane keeps its two ranks (lane, lane + 64) -- label, 2^label, discount,
     // score and the two accumulators -- in registers for the whole sweep; the only
@@ -1076,16 +1078,6 @@ __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32
   // wave sums and a single thread's additions per rank.
   constexpr int RR = QR_LAMBDA_RR;
   for (uint32_t rbase = 0; rbase < size; rbase += RR) {
-    float l1v[RR];
-    double p1v[RR], inv1v[RR], s1v[RR];
-#pragma unroll
-    for (int u = 0; u < RR; ++u) {  // uniform over the wave (clamped: unused beyond `size`)
-      const uint32_t r1 = rbase + u < size ? rbase + u : rbase;
-      l1v[u] = sl[r1];
-      p1v[u] = pw[r1];
-      inv1v[u] = ilt[r1];
-      s1v[u] = sr[r1];
-    }
     double c1v[RR], cwv[RR];
 #pragma unroll
     for (int u = 0; u < RR; ++u) c1v[u] = cwv[u] = 0.0;
@@ -1098,12 +1090,16 @@ __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32
 #pragma unroll
         for (int u = 0; u < RR; ++u) {
           const uint32_t r1 = rbase + u;
-          if (r1 < size && r2 > r1 && l1v[u] != l2) {
+          if (r1 >= size) break;  // (uniform)
+          // rank r1's four values: broadcast LDS reads, not kept in registers over the round
+          // (thirty-five registers that cost every launch of this kernel a wave per SIMD)
+          const float l1 = sl[r1];
+          if (r2 > r1 && l1 != l2) {
             double slam, del;
             if (use_e)
-              pair_term_e(l1v[u], p1v[u], inv1v[u], s1v[u], l2, p2, il2, s2, slam, del);
+              pair_term_e(l1, pw[r1], ilt[r1], sr[r1], l2, p2, il2, s2, slam, del);
             else
-              pair_term(l1v[u], p1v[u], inv1v[u], s1v[u], l2, p2, il2, s2, slam, del);
+              pair_term(l1, pw[r1], ilt[r1], sr[r1], l2, p2, il2, s2, slam, del);
             c1v[u] += slam;
             cwv[u] += del;
             ol -= slam;
@@ -1222,7 +1218,7 @@ __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32
 #endif
 }
 
-template <bool LONG, int W>
+template <bool LONG, int W, bool SMALL = false>
 __global__ __launch_bounds__(64 * W) void k_lambda(
     const double *__restrict__ scores, const float *__restrict__ labels,
     const uint32_t *__restrict__ qoff, int metric, uint32_t cutoff,
@@ -1243,7 +1239,7 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
   __shared__ double sh_part[2][W][2 * QR_LAMBDA_RR], sh_red[W][3];
   const QrLambdaArgs A = {scores, labels, qoff,  metric, cutoff, idcg, lg2,     ilg2,      lambda,
                           weight, qmetric, ranks_out, ssq,    qmax,   qslot, mode, present, exact_tail};
-  lambda_query<W, false>(A, q, smem, nmax, kacc, threadIdx.x, sh_part, sh_red, (double *)nullptr);
+  lambda_query<W, false, SMALL>(A, q, smem, nmax, kacc, threadIdx.x, sh_part, sh_red, (double *)nullptr);
 }
 
 // ONE launch for a ragged query set (config 1's shape): workgroups of eight waves in three
@@ -1257,7 +1253,11 @@ __global__ __launch_bounds__(64 * W) void k_lambda(
 // -- in place of one launch per size class side by side on auxiliary streams (fork, three or
 // four launches, join: the join alone cost ~18 us, and each class waited for its own longest
 // query).  `list`: the queries in dispatch order.  LDS: every role carves the same dynamic
-// block (two workgroups per CU: the kernel's 122 VGPRs allow sixteen waves there).
+// block (two workgroups of 76 KB per CU).
+// (Measured and left out: amdgpu_waves_per_eu(6) -- 80 VGPRs with 60 bytes of scratch per lane --
+// and 52 KB of LDS per workgroup, i.e. three workgroups per CU: 0.483 ms per iteration on the
+// MSLR-shaped set against 0.456 with 95 VGPRs and two workgroups of 76 KB.)
+#define QR_LU_DYN_DEFAULT 77824
 __global__ __launch_bounds__(64 * QR_LU_W) void k_lambda_u(const QrLambdaArgs A, const QrLambdaPlanDev P,
                                                            const uint32_t *__restrict__ list,
                                                            const uint32_t *__restrict__ order) {
@@ -1402,7 +1402,11 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   // 160 KB / 2 (the kernel's VGPRs allow two workgroups of eight waves per CU) less its static
   // 2 KB (sh_part, sh_red, sh_expt); a packed role takes as many queries per workgroup as fit
   // (three, six and eight at cutoff 10)
-  size_t lu_dyn = 77824;
+  static const size_t lu_dyn_env = [] {
+    const char *e = getenv("QR_LU_DYN");
+    return e ? (size_t)atol(e) : (size_t)QR_LU_DYN_DEFAULT;
+  }();
+  size_t lu_dyn = lu_dyn_env;
   for (int r = 0; r < QR_LU_ROLES; ++r) {
     pk_kacc[r] = std::min<size_t>(kacc, kPackBound[r]);
     pk_slice[r] = a16(lambda_lds(kPackBound[r], pk_kacc[r], false, false));
@@ -1633,6 +1637,8 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     if (lds > c->attr_lambda_lds) {
       QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false, 1>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false, 1, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       QR_CHECK(c, hipFuncSetAttribute((const void *)k_lambda<false, 16>,
@@ -1661,12 +1667,23 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       QR_CHECK(c, hipEventCreate(&e0));
       QR_CHECK(c, hipEventCreate(&e1));
+      if (cl.nmax <= 128)
+        hipExtLaunchKernelGGL((k_lambda<false, 1, true>), dim3(cl.count), dim3(64), lds, st, e0, e1, 0, sc, lb, qoffd,
+                              metric, cut, idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot,
+                              (uint32_t)nmax, (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist,
+                              (char *)nullptr, (size_t)0, c->exact_tail);
+      else
       hipExtLaunchKernelGGL((k_lambda<false, 1>), dim3(cl.count), dim3(64), lds, st, e0, e1, 0, sc, lb, qoffd, metric,
                             cut, idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
                             (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
                             (size_t)0, c->exact_tail);
       c->prof_events_child.push_back({e0, e1});
-    } else
+    } else if (cl.nmax <= 128)  // (short queries only: the variant without the long queries' paths)
+      hipLaunchKernelGGL((k_lambda<false, 1, true>), dim3(cl.count), dim3(64), lds, st, sc, lb, qoffd, metric, cut,
+                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
+                         (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
+                         (size_t)0, c->exact_tail);
+    else
       hipLaunchKernelGGL((k_lambda<false, 1>), dim3(cl.count), dim3(64), lds, st, sc, lb, qoffd, metric, cut,
                          idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
                          (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,

@@ -89,7 +89,16 @@ int qr_ctx_set_shard(qr_ctx *ctx, int rank, int world);
 /* Must precede the bin build.                                                    */
 int qr_ctx_set_doc_shard(qr_ctx *ctx, int rank, int world, uint64_t n_global,
                          uint64_t q_global);
+/* Drains the context's stream.  A tree whose enqueued steps did not suffice is carried on   */
+/* first -- EXCEPT on a document-sharded context whose last tree ended behind a guessed      */
+/* number of steps (qr_tree_batch_*, qr_tree_end before qr_tree_batch_settle): carrying that */
+/* tree on takes all-reduces only the caller can enqueue, so qr_synchronize drains what is   */
+/* enqueued and returns QR_OK with the tree possibly incomplete (its leaf and score kernels   */
+/* returned at once).  qr_tree_pending says so; qr_tree_batch_settle (+ the steps it asks    */
+/* for) must come before the tree's records or the scores are used.                          */
 int qr_synchronize(qr_ctx *ctx);
+/* *pending = 1: the last tree ended behind a guess that nobody has looked at yet             */
+int qr_tree_pending(qr_ctx *ctx, int *pending);
 
 /* ---- data: replaces Dataset -> VerticalDataset (vertical_dataset.cc:29-66)    */
 /*      and Mart::init (mart.cc:117-176) + RTRootHistogram (rtnode_histogram.cc */

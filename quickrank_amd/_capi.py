@@ -48,7 +48,7 @@ SYMBOLS = [
     "qr_tree_batch_supported", "qr_tree_batch_begin", "qr_tree_batch_root", "qr_tree_batch_apply",
     "qr_tree_batch_decide", "qr_tree_batch_settle", "qr_tree_batch_exchange",
     "qr_ensemble_set_depth_order", "qr_bins_build_wide_with",
-    "qr_bins_stats_wide", "qr_thresholds_from_stats_wide",
+    "qr_bins_stats_wide", "qr_thresholds_from_stats_wide", "qr_tree_pending",
 ]
 
 _LIB = None
@@ -68,7 +68,14 @@ def _close_all():
 
 
 class QrError(RuntimeError):
-    pass
+    """`code`: the C-ABI status (include/qr_hip.h), 0 when the error did not come with one."""
+
+    def __init__(self, msg, code=0):
+        super().__init__(msg)
+        self.code = code
+
+
+QR_ERR_UNSUPPORTED = 5
 
 
 def lib():
@@ -107,6 +114,7 @@ def lib():
     L.qr_ctx_stream.argtypes = [vp, C.POINTER(vp)]
     L.qr_ctx_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.qr_synchronize.argtypes = [vp]
+    L.qr_tree_pending.argtypes = [vp, C.POINTER(C.c_int)]
     L.qr_dataset_upload.argtypes = [vp, vp, sz, sz, vp, vp, sz]
     L.qr_valid_upload.argtypes = [vp, vp, sz, sz, vp, vp, sz]
     L.qr_bins_build.argtypes = [vp, sz, vp, vp]
@@ -206,7 +214,7 @@ def thresholds_from_stats(F, nthresholds, vals, cnt, mm):
                                         _ptr(thr), _ptr(ts))
     if rc:
         raise QrError(f"qr_thresholds_from_stats failed (code {rc}): nthresholds == 0 needs "
-                      "<= 255 distinct values per feature")
+                      "<= 255 distinct values per feature", rc)
     return thr, ts
 
 
@@ -223,12 +231,12 @@ def thresholds_from_stats_wide(F, nthresholds, limit, vals, cnt, mm):
                                              None, 0, _ptr(ts), C.byref(cells))
     if rc:
         raise QrError(f"qr_thresholds_from_stats_wide failed (code {rc}): nthresholds == 0 with a column of "
-                      f"more than {limit} distinct values")
+                      f"more than {limit} distinct values", rc)
     flat = np.empty(cells.value, np.float32)
     rc = lib().qr_thresholds_from_stats_wide(F, nthresholds, nranks, limit, _ptr(vals), _ptr(cnt), _ptr(mm),
                                              _ptr(flat), cells.value, _ptr(ts), C.byref(cells))
     if rc:
-        raise QrError(f"qr_thresholds_from_stats_wide failed (code {rc})")
+        raise QrError(f"qr_thresholds_from_stats_wide failed (code {rc})", rc)
     return flat, ts
 
 
@@ -260,7 +268,7 @@ class Context:
 
     def _ck(self, rc):
         if rc:
-            raise QrError(f"{self.L.qr_last_error(self.h).decode()} (code {rc})")
+            raise QrError(f"{self.L.qr_last_error(self.h).decode()} (code {rc})", rc)
 
     def set_stream(self, stream):
         """Run every launch on the caller's HIP stream (qr_ctx_set_stream)."""
@@ -612,7 +620,14 @@ class Context:
                     mask=m.value, mask_bytes=mb.value)
 
     def synchronize(self):
+        """Drains the stream.  On a document-sharded context a tree that ended behind a guessed
+        step count may still be incomplete afterwards: see tree_pending()."""
         self._ck(self.L.qr_synchronize(self.h))
+
+    def tree_pending(self):
+        p = C.c_int()
+        self._ck(self.L.qr_tree_pending(self.h, C.byref(p)))
+        return bool(p.value)
 
     # -- read-backs ---------------------------------------------------------
     def node_hist(self, node):

@@ -1095,7 +1095,20 @@ __global__ __launch_bounds__(1024) void k_bd_reduce(
   const int lf = blockIdx.x;
   const uint32_t t = threadIdx.x & 255, g = threadIdx.x >> 8;
   const QrScanWg d = descs[(size_t)blockIdx.y * flocal + lf];
-  if (!d.active) return;  // (what the job's cells hold is not looked at: k_bd_scan leaves too)
+  if (!d.active) {
+    // k_bd_scan does not look at an inactive job's cells, but the host all-reduces the whole
+    // buffer: zeros instead of whatever an earlier step left (stale payload multiplied
+    // by `world` at every exchange -- harmless wrap-around in int64, signed overflow on a CPU
+    // transport)
+    if (g == 0) {
+      const size_t x = (((size_t)blockIdx.y * flocal + lf) * 256 + t) * 2;
+      xb[x] = 0;
+      xb[x + 1] = 0;
+    }
+    if (lf == 0 && threadIdx.x < (uint32_t)(2 * world))
+      xb[(size_t)QR_BATCH * flocal * 512 + (size_t)blockIdx.y * 2 * world + threadIdx.x] = 0;
+    return;
+  }
   uint32_t par_c = 0;
   if (g == 0) par_c = hcnt_loc[((size_t)d.parent_slot * flocal + lf) * 256 + t];
   const u64 *src = partials + (size_t)d.slot0 * (256u * 64u) + d.col * 256u + t;

@@ -315,6 +315,12 @@ int qr_synchronize(qr_ctx *c) {
   return QR_OK;
 }
 
+int qr_tree_pending(qr_ctx *c, int *pending) {
+  if (!c || !pending) return QR_ERR_ARG;
+  *pending = c->dbatch_pending ? 1 : 0;
+  return QR_OK;
+}
+
 // ---------------------------------------------------------------------------
 static int upload_queries(qr_ctx *c, const uint64_t *qoff, size_t Q, size_t N,
                           uint32_t **d_qoff, size_t *maxq) {
@@ -938,7 +944,20 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
   // contexts; 3 x F x N x 8 bytes of lists (QR_WIDE_EXACT=1 / QR_WIDE_NO_EXACT=1 force either way).
   if (c->world == 1 && !c->dmode && !getenv("QR_WIDE_NO_EXACT") &&
       (c->wmax > QR_X_MIN_SLOTS || getenv("QR_WIDE_EXACT")) && 3 * FL * N * 8 <= ((size_t)64 << 30)) {
-    if ((rc = qr_k_exact_build(c))) return rc;
+    // (decided by the memory that is really free, and a build that still fails --
+    // another context took it in between -- leaves the slot-indexed path of round 3 in place
+    // instead of failing the bin build)
+    size_t mfree = 0, mtotal = 0;
+    const size_t need = 3 * FL * N * 8 + N * 16 + ((size_t)64 << 20);  // lists + sort scratch + words
+    if (hipMemGetInfo(&mfree, &mtotal) != hipSuccess || mfree >= need + need / 16) {
+      if ((rc = qr_k_exact_build(c))) {
+        (void)hipGetLastError();  // (an allocation failure is not sticky)
+        qr_k_exact_free(c);
+        if (getenv("QR_SPEC_DEBUG")) fprintf(stderr, "qr: pre-sorted lists not built (%s): slot-indexed histograms\n", c->err.c_str());
+        rc = QR_OK;
+      }
+    } else if (getenv("QR_SPEC_DEBUG"))
+      fprintf(stderr, "qr: %zu MB free, the pre-sorted lists need %zu MB: slot-indexed histograms\n", mfree >> 20, need >> 20);
   }
   // ---- tree working set of the one-split-per-step path
   QR_CHECK(c, dalloc(&c->d_order[0], N));
@@ -1275,7 +1294,9 @@ static int ensure_level_buffers(qr_ctx *c, size_t depth) {
   const size_t part_wgs = c->N / QR_PART_SLICE + nodes + 2;
   // k_obl_plan's quantum is <= (N/2) * wsum / (G/4) + 1 units, so a workgroup gets at
   // most 2 * wsum * N / G + 1 + QR_SLICE documents, hence flushes per workgroup:
-  const size_t kmax = (2 * wsum * c->N / G + 2 * QR_SLICE + QR_DPW - 1) / QR_DPW;
+  // (a document-sharded rank's own part of a level's "smaller" children can be all of its
+  // documents -- which child is built is decided by the GLOBAL counts -- hence N, not N / 2)
+  const size_t kmax = ((c->dmode ? 4 : 2) * wsum * c->N / G + 2 * QR_SLICE + QR_DPW - 1) / QR_DPW;
   const size_t slots = hist_wgs * kmax;
   if (hist_wgs > c->lhist_cap || part_wgs > c->lpart_cap || slots > c->lslots_cap ||
       nodes > c->lred_nodes) {

@@ -461,14 +461,21 @@ def build_doc_bins(ctx, nthresholds, group=None, distinct_limit=65536):
     (ragged rows; `distinct_limit` bounds the distinct values gathered per column when
     nthresholds == 0).  Returns (thresholds, thr_size) as Context.thresholds() does."""
     import torch.distributed as dist
-    from ._capi import QrError, thresholds_from_stats_wide
+    from ._capi import QR_ERR_UNSUPPORTED, QrError, thresholds_from_stats_wide
     if 0 <= nthresholds <= 255:
+        # u8 or wide is decided by the MERGED statistics, which every rank holds alike: all ranks
+        # take the same branch.  Only "more than 255 distinct values" (nthresholds == 0) leads to
+        # the wide path; any other failure -- and any failure of this rank's own bin build --
+        # is raised as it is (a rank that fell through would wait in the next all-gather alone).
+        merged = None
         try:
-            ctx.build_bins_with(*gather_thresholds(ctx, nthresholds, group))
-            return ctx.thresholds()
-        except QrError:
-            if nthresholds != 0:
+            merged = gather_thresholds(ctx, nthresholds, group)
+        except QrError as e:
+            if nthresholds != 0 or e.code != QR_ERR_UNSUPPORTED:
                 raise
+        if merged is not None:
+            ctx.build_bins_with(*merged)
+            return ctx.thresholds()
     limit = nthresholds + 1 if nthresholds else distinct_limit
     vals, cnt, mm = ctx.bins_stats_wide(limit)
     world = dist.get_world_size(group)

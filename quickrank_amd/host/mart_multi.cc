@@ -272,11 +272,22 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
         sh.bar.wait();
         std::vector<uint32_t> ts(F);
         size_t cells = 0;
-        if (qr_thresholds_from_stats_wide(F, nthresholds_, W, wl, sh.vals.data(), sh.cnt.data(), sh.mm.data(),
-                                          nullptr, 0, ts.data(), &cells) != QR_OK) {
+        const int wrc = qr_thresholds_from_stats_wide(F, nthresholds_, W, wl, sh.vals.data(), sh.cnt.data(),
+                                                      sh.mm.data(), nullptr, 0, ts.data(), &cells);
+        if (wrc == QR_ERR_UNSUPPORTED && nthresholds_ == 0) {
           if (r == 0)
             std::cerr << "!!! --shard docs with --num-thresholds 0: a column has more than 65536 distinct values "
                          "(use --num-thresholds N or --shard features)." << std::endl;
+          fatal_exit();
+        } else if (wrc != QR_OK)
+          die(c, "qr_thresholds_from_stats_wide");
+        // a document-sharded node histogram is all-reduced: its rows hold at most 4M slots in all
+        // (qr_bins_build_wide_with refuses more) -- said here, before the bins are built
+        if (cells > ((size_t)4 << 20)) {
+          if (r == 0)
+            std::cerr << "!!! --shard docs: " << cells << " threshold slots in all, more than the 4M a "
+                         "document-sharded node histogram can hold (use fewer --num-thresholds or --shard features)."
+                      << std::endl;
           fatal_exit();
         }
         std::vector<float> thr(cells);
@@ -284,6 +295,12 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
                                           thr.data(), cells, ts.data(), &cells) != QR_OK)
           die(c, "qr_thresholds_from_stats_wide");
         QRM(c, qr_bins_build_wide_with(c, thr.data(), ts.data(), nullptr, nullptr));
+        sh.bar.wait();   // (everybody has merged the statistics)
+        if (r == 0) {    // W * F * 65536 u32 of column statistics: not kept for the rest of the training
+          std::vector<uint32_t>().swap(sh.vals);
+          std::vector<uint32_t>().swap(sh.cnt);
+          std::vector<uint32_t>().swap(sh.mm);
+        }
       }
     }
     QRM(c, qr_scores_reset(c));

@@ -97,6 +97,11 @@ int qr_ctx_set_doc_shard(qr_ctx *ctx, int rank, int world, uint64_t n_global,
 /* returned at once).  qr_tree_pending says so; qr_tree_batch_settle (+ the steps it asks    */
 /* for) must come before the tree's records or the scores are used.                          */
 int qr_synchronize(qr_ctx *ctx);
+/* Debugging aid: drains the DEVICE and returns the error of any launch since the last call; */
+/* in a library built with -DQR_DEBUG_CHECKS also the first bounds violation a growth kernel  */
+/* recorded (the checked stores are skipped, not performed).  quickrank_amd/_capi.py calls it */
+/* after every C-ABI call when QR_DEBUG=1.                                                    */
+int qr_debug_check(qr_ctx *ctx);
 /* *pending = 1: the last tree ended behind a guess that nobody has looked at yet             */
 int qr_tree_pending(qr_ctx *ctx, int *pending);
 

@@ -48,7 +48,7 @@ SYMBOLS = [
     "qr_tree_batch_supported", "qr_tree_batch_begin", "qr_tree_batch_root", "qr_tree_batch_apply",
     "qr_tree_batch_decide", "qr_tree_batch_settle", "qr_tree_batch_exchange",
     "qr_ensemble_set_depth_order", "qr_bins_build_wide_with",
-    "qr_bins_stats_wide", "qr_thresholds_from_stats_wide", "qr_tree_pending",
+    "qr_bins_stats_wide", "qr_thresholds_from_stats_wide", "qr_tree_pending", "qr_debug_check",
 ]
 
 _LIB = None
@@ -76,6 +76,7 @@ class QrError(RuntimeError):
 
 
 QR_ERR_UNSUPPORTED = 5
+_DEBUG = bool(os.environ.get("QR_DEBUG"))
 
 
 def lib():
@@ -115,6 +116,7 @@ def lib():
     L.qr_ctx_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.qr_synchronize.argtypes = [vp]
     L.qr_tree_pending.argtypes = [vp, C.POINTER(C.c_int)]
+    L.qr_debug_check.argtypes = [vp]
     L.qr_dataset_upload.argtypes = [vp, vp, sz, sz, vp, vp, sz]
     L.qr_valid_upload.argtypes = [vp, vp, sz, sz, vp, vp, sz]
     L.qr_bins_build.argtypes = [vp, sz, vp, vp]
@@ -269,6 +271,10 @@ class Context:
     def _ck(self, rc):
         if rc:
             raise QrError(f"{self.L.qr_last_error(self.h).decode()} (code {rc})", rc)
+        if _DEBUG and self.h:   # QR_DEBUG=1: every call is drained and checked (qr_debug_check)
+            rc = self.L.qr_debug_check(self.h)
+            if rc:
+                raise QrError(f"{self.L.qr_last_error(self.h).decode()} (code {rc})", rc)
 
     def set_stream(self, stream):
         """Run every launch on the caller's HIP stream (qr_ctx_set_stream)."""

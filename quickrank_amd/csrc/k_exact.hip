@@ -668,17 +668,51 @@ static int exact_step(qr_ctx *c, int root, int final_call) {
   return qr_k_xpop(c, 0, c->cur_nleaves, c->cur_minls, final_call);
 }
 
+// --subsample (mart.cc:287-329): the tree grows on this iteration's sample.  Every feature's root
+// list is cut down to the sample's documents -- a stable partition by the presence bytes the
+// sample was marked with (k_xpart: "go left" = in the sample), into list buffer 0, where the
+// root then is the segment [0, sub_n) -- one pass over the lists per tree, and everything below
+// the root is what it is without a sample, on sub_n documents.
+__global__ void k_xsample_desc(QrTreeState *ts, const uint32_t N, const uint32_t k) {
+  QrSplitDesc &d = ts->desc;
+  d.active = 1;
+  d.owner_local = 0;
+  d.begin = 0;
+  d.end = N;
+  d.src_buf = 2;
+  d.dst_buf = 0;
+  d.lcount = k;
+  ts->xs_last = 0;
+}
+
 int qr_k_exact_fit(qr_ctx *c, size_t nleaves, uint64_t minls) {
   c->finish_in_decide = false;
   c->tree_counter += 0x9E3779B97F4A7C15ull;  // a fresh feature-subset stream per tree
   c->cur_minls = minls;
   const int frc = qr_k_prep_flush(c);  // (the iteration's scalars: the scans read the scale)
   if (frc) return frc;
+  const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_n : c->N);
+  const u64 *root_list = (const u64 *)(c->sub_k ? c->d_xlist[0] : c->d_xroot);
+  if (c->sub_k) {
+    if (++c->xepoch > 0xFFFFu) {
+      QR_CHECK(c, hipMemsetAsync(c->d_xpub, 0,
+                                 ((size_t)2 * c->flocal * c->xtiles_s + (size_t)c->flocal * c->xtiles_p) * QR_X_PUBW * 8,
+                                 c->stream));
+      c->xepoch = 1;
+    }
+    hipLaunchKernelGGL(k_xsample_desc, dim3(1), dim3(1), 0, c->stream, c->d_tree, (uint32_t)c->N, rootn);
+    QR_CHECK(c, hipGetLastError());
+    u64 *pub_part = (u64 *)c->d_xpub + (size_t)2 * c->flocal * c->xtiles_s * QR_X_PUBW;
+    hipLaunchKernelGGL(k_xpart, dim3((unsigned)c->flocal, c->xtiles_p), dim3(1024), 0, c->stream, c->d_tree,
+                       (const u64 *)c->d_xroot, (u64 *)c->d_xlist[0], (u64 *)c->d_xlist[1], c->N,
+                       (const uint8_t *)c->d_present, pub_part, c->xtiles_p, (u64)c->xepoch, 0);
+    QR_CHECK(c, hipGetLastError());
+  }
   QR_CHECK(c, hipMemsetAsync(c->d_xnode_tot, 0, 8, c->stream));
-  const unsigned tg = (unsigned)std::min<size_t>((c->N + 2047) / 2048, 1024);
-  hipLaunchKernelGGL(k_xtotal, dim3(tg, 1), dim3(256), 0, c->stream, c->d_tree, 0, (uint32_t)c->N,
-                     (const u64 *)c->d_xroot, (const u64 *)c->d_xlist[0], (const u64 *)c->d_xlist[1], c->d_lambda,
-                     c->d_scalars, c->d_xnode_tot);
+  const unsigned tg = (unsigned)std::min<size_t>(((size_t)rootn + 2047) / 2048, 1024);
+  hipLaunchKernelGGL(k_xtotal, dim3(tg ? tg : 1, 1), dim3(256), 0, c->stream, c->d_tree, 0, rootn, root_list,
+                     (const u64 *)c->d_xlist[0], (const u64 *)c->d_xlist[1], c->d_lambda, c->d_scalars,
+                     c->d_xnode_tot);
   QR_CHECK(c, hipGetLastError());
   int rc = qr_k_xpop(c, 1, nleaves, minls, 0);
   if (rc) return rc;

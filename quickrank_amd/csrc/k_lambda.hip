@@ -630,7 +630,7 @@ __device__ __forceinline__ void sort_placement(const uint32_t *a, const int n, u
 // wave's work inside a larger workgroup -- no s_barrier anywhere on its way (qsync).
 constexpr int QR_LAMBDA_RR = 5;  // ranks r1 per round of the pair sweep (their sums are reduced together)
 struct QrLambdaArgs {
-  const double *scores;
+  double *scores;  // (written too when a score update rides in this pass: upd_leaf below)
   const float *labels;
   const uint32_t *qoff;
   int metric;
@@ -643,6 +643,13 @@ struct QrLambdaArgs {
   int mode;
   const uint8_t *present;
   int exact_tail;
+  // Mart::update_modelscores of the tree before (mart.cc:464-467), folded into this pass's
+  // load (lambdamart.cc:70 reads the scores it would have written): score += shrinkage *
+  // leaf_value[leaf of the document], the same two operations as k_score_update_leaf.
+  // upd_leaf == nullptr: the scores are up to date.
+  const uint8_t *upd_leaf;
+  const double *upd_value;
+  double upd_shrinkage;
 };
 
 // SMALL: every query of the launch has at most 128 documents -- the paths of longer queries
@@ -655,7 +662,7 @@ __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32
                                              double (*sh_part)[W][2 * QR_LAMBDA_RR], double (*sh_red)[3],
                                              double *expt_shared) {
   static_assert(!PACKED || W == 1, "a packed query is one wave's");
-  const double *__restrict__ scores = A.scores;
+  double *scores = A.scores;
   const float *__restrict__ labels = A.labels;
   const uint32_t *__restrict__ qoff = A.qoff;
   const int metric = A.metric;
@@ -740,6 +747,14 @@ __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32
     }
     return;
   }
+  if (A.upd_leaf) {  // (never with a sample: every document of the query is here)
+    for (uint32_t i = tid; i < n; i += T) {
+      const double v = scores[off + i] + A.upd_shrinkage * A.upd_value[A.upd_leaf[off + i]];
+      scores[off + i] = v;
+      s[i] = v;
+      lab0[i] = labels[off + i];
+    }
+  } else
   for (uint32_t i = tid; i < n; i += T) {
     const uint32_t di = present ? cmap[i] : i;
     s[i] = scores[off + di];
@@ -1219,26 +1234,15 @@ __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32
 }
 
 template <bool LONG, int W, bool SMALL = false>
-__global__ __launch_bounds__(64 * W) void k_lambda(
-    const double *__restrict__ scores, const float *__restrict__ labels,
-    const uint32_t *__restrict__ qoff, int metric, uint32_t cutoff,
-    const double *__restrict__ idcg, const double *__restrict__ lg2,
-    const double *__restrict__ ilg2, double *__restrict__ lambda,
-    double *__restrict__ weight, double *__restrict__ qmetric,
-    uint32_t *__restrict__ ranks_out, double *__restrict__ ssq, double *__restrict__ qmax,
-    unsigned long long *__restrict__ qslot, uint32_t nmax, uint32_t kacc, int mode,
-    const uint8_t *__restrict__ present, const uint8_t *__restrict__ long_flag,
-    const uint32_t *__restrict__ long_list, char *__restrict__ lscratch, const size_t lstride,
-    const int exact_tail) {
+__global__ __launch_bounds__(64 * W) void k_lambda(const QrLambdaArgs A, const uint32_t nmax, const uint32_t kacc,
+                                                   const uint32_t *__restrict__ long_list,
+                                                   char *__restrict__ lscratch, const size_t lstride) {
   extern __shared__ __attribute__((aligned(16))) char lds_mem[];
   // (LONG = false: `long_list`, when given, is the launch's size class -- the queries whose
   // working set fits THIS launch's LDS)
   const uint32_t q = long_list ? long_list[blockIdx.x] : blockIdx.x;
-  if (!LONG && long_flag && long_flag[q]) return;
   char *smem = LONG ? lscratch + (size_t)blockIdx.x * lstride : lds_mem;
   __shared__ double sh_part[2][W][2 * QR_LAMBDA_RR], sh_red[W][3];
-  const QrLambdaArgs A = {scores, labels, qoff,  metric, cutoff, idcg, lg2,     ilg2,      lambda,
-                          weight, qmetric, ranks_out, ssq,    qmax,   qslot, mode, present, exact_tail};
   lambda_query<W, false, SMALL>(A, q, smem, nmax, kacc, threadIdx.x, sh_part, sh_red, (double *)nullptr);
 }
 
@@ -1546,7 +1550,7 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
       c->lscratch_bytes = nlong * lstride;
     }
   }
-  const double *sc = which ? c->d_vscores : c->d_scores;
+  double *sc = which ? c->d_vscores : c->d_scores;
   const float *lb = which ? c->d_vlabels : c->d_labels;
   const uint32_t *qoffd = which ? c->d_vqoff : c->d_qoff;
   const double *idcg = which ? c->d_vidcg : c->d_idcg;
@@ -1567,6 +1571,17 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   // One launch per size class (its LDS sized for the class's longest query), the launches
   // side by side on auxiliary streams when there are several: the few long queries of a
   // ragged set no longer dictate the occupancy of the many short ones.
+  // a score update left pending by qr_scores_update rides in this pass (training set, lambdas)
+  const bool upd = !which && mode == 0 && c->lazy_scores;
+  if (c->lazy_scores && !which && !upd) {
+    const int frc = qr_k_scores_flush(c);
+    if (frc) return frc;
+  }
+  c->lazy_scores = upd ? false : c->lazy_scores;
+  const QrLambdaArgs A = {sc,  lb, qoffd, metric, cut,       idcg,  c->d_lg2, c->d_ilg2, lam,
+                          wgt, qm, ranks, ssq,    c->d_qmax, qslot, md,       present,   c->exact_tail,
+                          upd ? c->d_leafb : (const uint8_t *)nullptr,
+                          upd ? c->d_tree->leaf_value : (const double *)nullptr, upd ? c->lazy_shrinkage : 0.0};
   const bool lu_on = c->lu_on[which];
   const size_t nlaunch = classes.size() + (nlong ? 1 : 0) + (lu_on ? 1 : 0);
   const bool fork = nlaunch > 1;
@@ -1612,8 +1627,6 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     hipStream_t st;
     int rc = stream_for(li++, &st);
     if (rc) return rc;
-    const QrLambdaArgs A = {sc, lb,  qoffd, metric, cut,   idcg, c->d_lg2, c->d_ilg2,    lam,
-                            wgt, qm, ranks, ssq,    c->d_qmax, qslot, md,   present,  c->exact_tail};
     const unsigned grid = P.blocks;
     const uint32_t *lu_ord = c->lu_ordered[which] ? c->d_lu_list[which] + c->lu_order_off[which] : (const uint32_t *)nullptr;
     if (c->prof_on && c->prof_lambda && !fork && !which && mode == 0) {
@@ -1650,17 +1663,14 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     if (rc) return rc;
     const uint32_t *qlist = c->qclass_identity[which] ? (const uint32_t *)nullptr
                                                       : (const uint32_t *)(c->d_qclass[which] + cl.first);
-    // long queries: four waves each (not with a sample: the cleaning is one wave's code)
+    // long queries: sixteen / four waves each (not with a sample: the cleaning is one wave's code)
+    const dim3 g(cl.count);
     if (cl.nmax > 512 && !sampled)
-      hipLaunchKernelGGL((k_lambda<false, 16>), dim3(cl.count), dim3(1024), lds, st, sc, lb, qoffd, metric, cut,
-                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
-                         (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
-                         (size_t)0, c->exact_tail);
+      hipLaunchKernelGGL((k_lambda<false, 16>), g, dim3(1024), lds, st, A, (uint32_t)nmax, (uint32_t)kshort, qlist,
+                         (char *)nullptr, (size_t)0);
     else if (cl.nmax > QR_LAMBDA_W4_FROM && !sampled)
-      hipLaunchKernelGGL((k_lambda<false, 4>), dim3(cl.count), dim3(256), lds, st, sc, lb, qoffd, metric, cut,
-                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
-                         (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
-                         (size_t)0, c->exact_tail);
+      hipLaunchKernelGGL((k_lambda<false, 4>), g, dim3(256), lds, st, A, (uint32_t)nmax, (uint32_t)kshort, qlist,
+                         (char *)nullptr, (size_t)0);
     else if (c->prof_on && c->prof_lambda && !fork && !which && mode == 0) {
       // bench.py's roofline_lambda: HIP events on the launch itself (qr_prof_enable bit 2; read
       // with qr_prof_get_child -- the two timings share the slot and exclude each other)
@@ -1668,37 +1678,27 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
       QR_CHECK(c, hipEventCreate(&e0));
       QR_CHECK(c, hipEventCreate(&e1));
       if (cl.nmax <= 128)
-        hipExtLaunchKernelGGL((k_lambda<false, 1, true>), dim3(cl.count), dim3(64), lds, st, e0, e1, 0, sc, lb, qoffd,
-                              metric, cut, idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot,
-                              (uint32_t)nmax, (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist,
-                              (char *)nullptr, (size_t)0, c->exact_tail);
+        hipExtLaunchKernelGGL((k_lambda<false, 1, true>), g, dim3(64), lds, st, e0, e1, 0, A, (uint32_t)nmax,
+                              (uint32_t)kshort, qlist, (char *)nullptr, (size_t)0);
       else
-      hipExtLaunchKernelGGL((k_lambda<false, 1>), dim3(cl.count), dim3(64), lds, st, e0, e1, 0, sc, lb, qoffd, metric,
-                            cut, idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
-                            (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
-                            (size_t)0, c->exact_tail);
+        hipExtLaunchKernelGGL((k_lambda<false, 1>), g, dim3(64), lds, st, e0, e1, 0, A, (uint32_t)nmax,
+                              (uint32_t)kshort, qlist, (char *)nullptr, (size_t)0);
       c->prof_events_child.push_back({e0, e1});
     } else if (cl.nmax <= 128)  // (short queries only: the variant without the long queries' paths)
-      hipLaunchKernelGGL((k_lambda<false, 1, true>), dim3(cl.count), dim3(64), lds, st, sc, lb, qoffd, metric, cut,
-                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
-                         (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
-                         (size_t)0, c->exact_tail);
+      hipLaunchKernelGGL((k_lambda<false, 1, true>), g, dim3(64), lds, st, A, (uint32_t)nmax, (uint32_t)kshort, qlist,
+                         (char *)nullptr, (size_t)0);
     else
-      hipLaunchKernelGGL((k_lambda<false, 1>), dim3(cl.count), dim3(64), lds, st, sc, lb, qoffd, metric, cut,
-                         idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot, (uint32_t)nmax,
-                         (uint32_t)kshort, md, present, (const uint8_t *)nullptr, qlist, (char *)nullptr,
-                         (size_t)0, c->exact_tail);
+      hipLaunchKernelGGL((k_lambda<false, 1>), g, dim3(64), lds, st, A, (uint32_t)nmax, (uint32_t)kshort, qlist,
+                         (char *)nullptr, (size_t)0);
     QR_CHECK(c, hipGetLastError());
   }
   if (nlong) {
     hipStream_t st;
     int rc = stream_for(li++, &st);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_lambda<true, 1>), dim3((unsigned)nlong), dim3(64), 0, st, sc, lb, qoffd, metric, cut,
-                       idcg, c->d_lg2, c->d_ilg2, lam, wgt, qm, ranks, ssq, c->d_qmax, qslot,
-                       (uint32_t)nmax_long, (uint32_t)std::min(kacc, nmax_long), md, present,
-                       (const uint8_t *)nullptr, (const uint32_t *)c->d_long_list[which], c->d_lscratch, lstride,
-                       c->exact_tail);
+    hipLaunchKernelGGL((k_lambda<true, 1>), dim3((unsigned)nlong), dim3(64), 0, st, A, (uint32_t)nmax_long,
+                       (uint32_t)std::min(kacc, nmax_long), (const uint32_t *)c->d_long_list[which], c->d_lscratch,
+                       lstride);
     QR_CHECK(c, hipGetLastError());
   }
   if (fork)  // join: the context's stream carries on when every launch is done

@@ -66,6 +66,38 @@
 #define QR_CTRL_FN __forceinline__
 #endif
 
+// -DQR_DEBUG_CHECKS (tests/tools/abort_hunt.py --debug builds the library with
+// it): every indexed store of the growth kernels that is not bounded by construction in plain
+// sight -- the partition's scatter, the node / heap / split-log entries the control lane creates,
+// the partial slot a histogram workgroup flushes into, the node-histogram slot a scan writes --
+// is checked against the capacity the host allocated; the first violation is recorded (code,
+// two values) and the store SKIPPED, and qr_debug_check reports it after the launch.  The
+// product build compiles the checks out.
+#ifdef QR_DEBUG_CHECKS
+__device__ unsigned long long qr_dbg_word[4];   // [0] first failure, [1] failures, [2], [3] its values
+__device__ unsigned long long qr_dbg_caps[8];   // [0] d_partials [1] its slots [2] d_lpartials [3] its slots [4] histogram slots
+__device__ __noinline__ bool qr_dbg_fail(const unsigned code, const unsigned long long a, const unsigned long long b) {
+  if (atomicCAS(&qr_dbg_word[0], 0ull, ((unsigned long long)code << 32) | (blockIdx.x & 0xffffffffu)) == 0ull) {
+    qr_dbg_word[2] = a;
+    qr_dbg_word[3] = b;
+  }
+  atomicAdd(&qr_dbg_word[1], 1ull);
+  return false;
+}
+#define QR_DBG_OK(cond, code, a, b) ((cond) ? true : qr_dbg_fail((code), (unsigned long long)(a), (unsigned long long)(b)))
+// the capacities as they are NOW: called where a tree starts (its buffers have just been sized)
+static int qr_dbg_caps_upload(qr_ctx *c) {
+  const unsigned long long caps[8] = {(unsigned long long)c->d_partials, c->partial_slots, (unsigned long long)c->d_lpartials,
+                                      c->lslots_cap, c->hist_slots, 0, 0, 0};
+  QR_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(qr_dbg_caps), caps, sizeof(caps)));
+  return QR_OK;
+}
+#define QR_DBG_CAPS(c) do { const int drc_ = qr_dbg_caps_upload(c); if (drc_) return drc_; } while (0)
+#else
+#define QR_DBG_CAPS(c) do {} while (0)
+#define QR_DBG_OK(cond, code, a, b) true
+#endif
+
 // -DQR_STEP_TIMING (scripts/step_timing.py): clock64 stamps of one histogram workgroup's
 // sections, with the load queue drained at the first two so that they show the dependent
 // round trips (descriptor -> ids -> rows) one by one
@@ -86,7 +118,10 @@ __device__ long long qr_ht[8];
 // 1024-thread workgroup, so this variant keeps the columns packed, four to a register, and
 // extracts the one a step needs (one more VALU instruction under an LDS-bound loop; the
 // empty asm keeps the compiler from hoisting the extractions back into sixteen registers).
-template <int CH, bool IDENTITY, bool SUMS = false>
+// R64 (an experiment, QR_ROWS64=1; child launches only): the rows come from a copy of the bins
+// with one 64-byte line per (document, block) -- a gathered row then costs one line, where a
+// 48-byte row of the compact matrix straddles two lines every other time.
+template <int CH, bool IDENTITY, bool SUMS = false, bool R64 = false>
 __device__ __forceinline__ void hist_accumulate(
     u64 *__restrict__ hist, const uint8_t *__restrict__ bins_b,
     const uint32_t *__restrict__ order, const uint32_t seg_begin, const uint32_t r0,
@@ -162,7 +197,7 @@ __device__ __forceinline__ void hist_accumulate(
     return IDENTITY ? seg_begin + p : order[seg_begin + p];
   };
   auto load_row = [&](uint32_t id) -> uint4 {
-    return *reinterpret_cast<const uint4 *>(bins_b + (size_t)id * FW + 16 * c);
+    return *reinterpret_cast<const uint4 *>(bins_b + (size_t)id * (R64 ? 64 : FW) + 16 * c);
   };
   // Loads are unconditional (positions clamped into the range) so that no
   // exec-masked branch surrounds a VMEM instruction: the compiler then emits
@@ -216,7 +251,7 @@ __device__ __forceinline__ void hist_run(
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const double scale, u64 *__restrict__ partials, const bool tr = false, const int fw_known = 0,
     const size_t off_known = 0, double *__restrict__ sums_out = nullptr, const u64 slot_word = 0,
-    const bool use_slot = false);
+    const bool use_slot = false, const bool r64 = false);
 
 // One workgroup's share of a node histogram: workgroup `wg` of the `G` that the
 // plan hands to a node of n documents; partial slots start at `slot_base`.
@@ -253,7 +288,8 @@ __device__ __forceinline__ void hist_run(
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const double scale, u64 *__restrict__ partials, const bool tr, const int fw_known,
-    const size_t off_known, double *__restrict__ sums_out, const u64 slot_word, const bool use_slot) {
+    const size_t off_known, double *__restrict__ sums_out, const u64 slot_word, const bool use_slot,
+    const bool r64) {
   // (batched growth hands the block's geometry over with the workgroup's share: one
   // dependent read less before the first bins can be requested)
   const int fw = fw_known ? fw_known : blocks[b].fw;
@@ -265,6 +301,14 @@ __device__ __forceinline__ void hist_run(
   double sq = 0.0, sm = 0.0;  // (sums_out) this lane's documents of chunk 0, in list order
   for (uint32_t s0 = r0; s0 < r1; s0 += QR_DPW, ++k) {
     const uint32_t s1 = (s0 + QR_DPW < r1) ? s0 + QR_DPW : r1;
+    if (SUMS && r64) {
+      switch (fw) {
+        case 16: hist_accumulate<1, false, true, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
+        case 32: hist_accumulate<2, false, true, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
+        case 48: hist_accumulate<3, false, true, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
+        default: hist_accumulate<4, false, true, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
+      }
+    } else
     if (SUMS) {
       switch (fw) {
         case 16: hist_accumulate<1, false, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
@@ -291,6 +335,15 @@ __device__ __forceinline__ void hist_run(
     __syncthreads();
     QR_HT(4);
     u64 *dst = partials + (slot0 + k) * (256u * 64u);
+#ifdef QR_DEBUG_CHECKS
+    {
+      const u64 cap = (u64)partials == qr_dbg_caps[0] ? qr_dbg_caps[1] : ((u64)partials == qr_dbg_caps[2] ? qr_dbg_caps[3] : ~0ull);
+      if (!QR_DBG_OK(slot0 + k < cap, 2, slot0 + k, cap)) {  // (workgroup-uniform)
+        __syncthreads();
+        continue;
+      }
+    }
+#endif
     if (tr) {
       // feature-major slot [column][256 bins] for k_redscan, which reads one column
       // of every slot.  A wave moves a tile of 16 columns x 8 bins: lane = (column
@@ -420,11 +473,17 @@ __global__ __launch_bounds__(1024) void k_hist_batch(
     const QrHistWg *__restrict__ wgs, const QrBlock *__restrict__ blocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const QrScalars *__restrict__ scal, u64 *__restrict__ partials, double *__restrict__ histsum) {
+    const QrScalars *__restrict__ scal, u64 *__restrict__ partials, double *__restrict__ histsum,
+    const uint8_t *__restrict__ bins64 = nullptr, const uint32_t N64 = 0) {
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
   QR_HT(0);
   const QrHistWg d = wgs[blockIdx.x];
   if (d.count == 0) return;
+  if (bins64) {  // (QR_ROWS64=1: the line-aligned copy, block b at b * N * 64)
+    hist_run<true>(hist, d.begin, 0, d.count, d.buf, d.block, d.slot, blocks, bins64, order0, order1, lambda,
+                   scal->scale, partials, true, (int)d.fw, (size_t)d.block * N64 * 64, histsum, 0, false, true);
+    return;
+  }
   // (every workgroup also adds up its documents' pseudo-responses -- k_redscan reads the pairs
   // of feature block 0's workgroups; the others' are the same numbers and cost nothing)
   hist_run<true>(hist, d.begin, 0, d.count, d.buf, d.block, d.slot, blocks, bins, order0, order1, lambda,
@@ -984,6 +1043,9 @@ __device__ __forceinline__ void level_prefix_write(long long s, uint32_t cn, con
   }
   const size_t hidx = ((size_t)ln.small_slot * flocal + lf) * 256 + t;
   const size_t bidx = ((size_t)ln.big_slot * flocal + lf) * 256 + t;
+#ifdef QR_DEBUG_CHECKS
+  if (!QR_DBG_OK((u64)ln.small_slot < qr_dbg_caps[4] && (u64)ln.big_slot < qr_dbg_caps[4], 3, ln.small_slot, ln.big_slot)) return;
+#endif
   if (hsum) {
     hsum[hidx] = s;
     hsum[bidx] = par_s - s;
@@ -1311,6 +1373,9 @@ __global__ __launch_bounds__(128) void k_merge(
 // access is an LDS access instead of a dependent L2 round trip) or straight to the
 // device-resident QrTreeState.
 struct DecideState {
+#ifdef QR_DEBUG_CHECKS
+  int32_t cap = QR_MAXNODES;  // node records / heap entries `nodes` / `heap` hold (the LDS copies: fewer)
+#endif
   int32_t nleaves_req, nnodes, taken, done, step, nsplits, heap_size;
   uint32_t part_epoch;
   QrHeapItem *heap;
@@ -1328,6 +1393,9 @@ struct DecideState {
 
 __device__ QR_CTRL_FN void heap_push(DecideState &st, double key, int32_t val) {
   // maxheap.h:58-68 (arr[0] is a DBL_MAX sentinel)
+#ifdef QR_DEBUG_CHECKS
+  if (!QR_DBG_OK(st.heap_size + 1 < st.cap + 2, 4, st.heap_size, st.cap)) return;
+#endif
   size_t p = (size_t)(++st.heap_size);
   while (key > st.heap[p >> 1].key) {
     st.heap[p] = st.heap[p >> 1];
@@ -1398,6 +1466,9 @@ __device__ __forceinline__ void make_desc(DecideState &st, int node, const float
   QrNode *nd = &st.nodes[node];
   QrSplitDesc *d = st.desc;
   const int li = st.nnodes, ri = st.nnodes + 1;
+#ifdef QR_DEBUG_CHECKS
+  if (!QR_DBG_OK(ri < st.cap && st.nsplits < QR_MAXNODES, 6, li, st.cap)) return;
+#endif
   st.nnodes += 2;
   d->active = 1;
   st.part_epoch++;
@@ -1587,6 +1658,9 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
   }
   if (staged) {
     st.nodes = sh_nodes;
+#ifdef QR_DEBUG_CHECKS
+    st.cap = QR_DECIDE_LDS_NODES;
+#endif
     st.heap = sh_heap;
     st.desc = &sh_desc;
   } else {
@@ -1628,6 +1702,9 @@ __device__ void decide_body(QrTreeState *ts, const uint32_t N, const int flocal,
   if (threadIdx.x == 0) {
     if (staged) {
       st.nodes = sh_nodes;
+#ifdef QR_DEBUG_CHECKS
+      st.cap = QR_DECIDE_LDS_NODES;
+#endif
       st.heap = sh_heap;
       st.desc = &sh_desc;
       decide_logic(st, ts, root_mode, active, N, recs, world, scal, thr, gf2lf, docmode, Nglobal,
@@ -1689,13 +1766,16 @@ __global__ __launch_bounds__(128) void k_decide(
 // ===========================================================================
 __device__ __forceinline__ void xpop_logic(DecideState &st, const bool root_mode, const int32_t active,
                                            const QrSplitDesc &d, const uint32_t N, const QrScalars *scal,
-                                           const double sum_small, const double ss_small, int *xs_out) {
+                                           const double sum_small, const double ss_small, int *xs_out,
+                                           const int root_buf) {
   int xs = -1;
   if (root_mode) {
+    // (N: the root's documents; root_buf 2: every document, the identity lists -- 0: this
+    // iteration's sample, compacted into list buffer 0, mart.cc:287-329)
     QrNode *root = &st.nodes[0];
     root->begin = 0;
     root->end = N;
-    root->buf = 2;
+    root->buf = root_buf;
     root->hslot = 0;
     root->feature = -1;
     root->thr_id = -1;
@@ -1754,7 +1834,7 @@ __global__ __launch_bounds__(128) void k_xpop(
     QrTreeState *ts, const int root_mode, const int nleaves_arg, const u64 minls_arg, const uint32_t N,
     const QrScalars *__restrict__ scal, const double *__restrict__ part_ss,
     unsigned long long *__restrict__ gbest, const int flocal, const int final_call,
-    int64_t *__restrict__ early, const long long early_seq) {
+    int64_t *__restrict__ early, const long long early_seq, const int root_buf) {
   __shared__ QrNode sh_nodes[QR_DECIDE_LDS_NODES];
   __shared__ QrHeapItem sh_heap[QR_DECIDE_LDS_NODES + 2];
   __shared__ int sh_nn, sh_hs;
@@ -1800,12 +1880,15 @@ __global__ __launch_bounds__(128) void k_xpop(
     int xs = -1;
     if (staged) {
       st.nodes = sh_nodes;
+#ifdef QR_DEBUG_CHECKS
+      st.cap = QR_DECIDE_LDS_NODES;
+#endif
       st.heap = sh_heap;
-      xpop_logic(st, root_mode, active, d, N, scal, sum_small, ss_small, &xs);
+      xpop_logic(st, root_mode, active, d, N, scal, sum_small, ss_small, &xs, root_buf);
     } else {
       st.nodes = ts->nodes;
       st.heap = ts->heap;
-      xpop_logic(st, root_mode, active, d, N, scal, sum_small, ss_small, &xs);
+      xpop_logic(st, root_mode, active, d, N, scal, sum_small, ss_small, &xs, root_buf);
     }
     if (root_mode) {  // (what k_tree_reset does for the phase API)
       ts->nleaves_req = nleaves_arg;
@@ -1973,6 +2056,11 @@ __device__ QR_CTRL_FN void batch_make_job(DecideState &st, BatchState &bs, int j
     bs.next_prov += 2;
   }
   const int ri = li + 1;
+#ifdef QR_DEBUG_CHECKS
+  if (!QR_DBG_OK(li >= 0 && ri < st.cap && j >= 0 && j < QR_BATCH && (u64)(bs.next_slot + 1) < qr_dbg_caps[4] &&
+                 st.nsplits < QR_MAXNODES, 5, ((u64)(uint32_t)li << 32) | (uint32_t)bs.next_slot, ((u64)(uint32_t)st.cap << 32) | (uint32_t)j))
+    return;
+#endif
   const int sl = bs.next_slot, sr = sl + 1;
   bs.next_slot += 2;
   // (document-sharded rank: [begin, end) are positions in its OWN lists -- its own left count comes
@@ -2115,6 +2203,9 @@ __device__ __forceinline__ int batch_logic(DecideState &st, BatchState &bs, cons
         }
         if (nd->pre) {  // applied ahead of its turn: the children take their final ids
           const int li = st.nnodes, ri = li + 1;
+#ifdef QR_DEBUG_CHECKS
+          if (!QR_DBG_OK(ri < st.cap && nd->pre_l >= 0 && nd->pre_r < st.cap, 7, li, nd->pre_r)) break;
+#endif
           st.nnodes += 2;
           st.nodes[li] = st.nodes[nd->pre_l];
           st.nodes[ri] = st.nodes[nd->pre_r];
@@ -2340,6 +2431,9 @@ __device__ __forceinline__ void batch_step(
     int nj;
     if (staged) {
       st.nodes = sh_nodes;
+#ifdef QR_DEBUG_CHECKS
+      st.cap = CAP;
+#endif
       st.heap = sh_heap;
       nj = batch_logic(st, bs, root_mode, njobs, sh_prev, N, own, scal, own_lf, own_thr, root_buf, hcnt_loc ? Nglobal : (u64)N,
                        hcnt_loc ? spec_docs_doc : (u64)N);
@@ -2823,7 +2917,7 @@ __device__ __forceinline__ void partition_body(
       } else {
         o = d.begin + d.lcount + (p - lpos);
       }
-      dst[o] = ids[k];
+      if (QR_DBG_OK(o >= d.begin && o < d.begin + n && ids[k] < Nfm, 1, o, ((u64)d.begin << 32) | n)) dst[o] = ids[k];
       if (part_ss && fl[k] == (d.small_is_left != 0)) {
         const double l = lam[k];
         sq += l * l;
@@ -3129,12 +3223,22 @@ __global__ __launch_bounds__(256) void k_leaf_sums(
 // not depend on how the leaf was found, so every layout ends with the same bits.
 // part: [leaf][slice][2].  present: --subsample's mask (the sums are the sample's).
 #define QR_LDOC 16
+struct QrNodesOut;
+__device__ __forceinline__ void nodes_out_publish(QrNodesOut *out, const long long seq);
+__device__ __forceinline__ void nodes_out_write(const QrTreeState *ts, QrNodesOut *out, const long long seq);
+
+// `ticket` != null (QR_LEAF_FUSE=1: measured, not kept -- qr_k_tree_finish says why): the LAST
+// workgroup to leave its partials behind also does what k_leaf_final does -- the leaves' sums
+// over the slices in k_leaf_final's order (a lane's slices 512 apart, wave_sum: the same bits),
+// the outputs of rt.cc:165-207, the tree's records into the pinned block -- instead of a launch
+// of one workgroup behind this one.
 template <bool WALK>
 __global__ __launch_bounds__(256) void k_leaf_sums_doc(
     const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm, const uint32_t N,
     const int32_t *__restrict__ gf2lf, const int wide, uint8_t *__restrict__ leafb,
     const double *__restrict__ lambda, const double *__restrict__ weight,
-    const uint8_t *__restrict__ present, double *__restrict__ part) {
+    const uint8_t *__restrict__ present, double *__restrict__ part, uint32_t *__restrict__ ticket = nullptr,
+    QrTreeState *tsw = nullptr, const int newton = 0, QrNodesOut *nodes_out = nullptr, const long long seq = 0) {
   constexpr int NN = 2 * QR_LDOC;  // nodes of a tree of QR_LDOC leaves (2 L - 1)
   // s_rec[n]: what a step of the walk needs of node n in ONE LDS word -- bit 31 = leaf;
   // a leaf: its DFS index; an internal node: left | right << 8 | index of its test << 16
@@ -3161,7 +3265,14 @@ __global__ __launch_bounds__(256) void k_leaf_sums_doc(
     right = nd.right;
     leafid = nd.leaf_id;
   }
-  if (incomplete) return;  // (the host carries the tree on and enqueues the leaf kernels again)
+  if (incomplete) {  // (the host carries the tree on and enqueues the leaf kernels again)
+    if (ticket && blockIdx.x == 0 && threadIdx.x == 0) {  // ... told as k_leaf_final tells it
+      nodes_out->pad[0] = 1;
+      nodes_out->pad[1] = ts->real_steps;
+      nodes_out_publish(nodes_out, seq);
+    }
+    return;
+  }
   const int nn = nn_all < NN ? nn_all : NN;
   if (WALK && threadIdx.x < 64) {  // one wave: records + compaction of the tests by ballot
     const int i = threadIdx.x;
@@ -3306,6 +3417,50 @@ __global__ __launch_bounds__(256) void k_leaf_sums_doc(
     }
     part[2 * e] = a;
     part[2 * e + 1] = b;
+  }
+  if (ticket) {
+    __shared__ uint32_t s_last;
+    __threadfence();  // (this workgroup's partials, device-wide, before its ticket)
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) *ticket = 0;  // (the next tree's launch starts from zero)
+    __threadfence();  // (everybody's partials, before they are read)
+    const int wave = threadIdx.x >> 6;
+    const uint32_t dense_slices = gridDim.x;
+    for (int l2 = wave; l2 < nl; l2 += 4) {  // one wave per leaf, k_leaf_final's reduction tree
+      double s1 = 0.0, s2 = 0.0;
+      for (uint32_t s = lane; s < dense_slices; s += 8 * 64) {
+        double2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t sk = s + 64u * k;
+          v[k] = sk < dense_slices ? *reinterpret_cast<const double2 *>(part + 2 * ((size_t)l2 * dense_slices + sk))
+                                   : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (s + 64u * k < dense_slices) {
+            s1 += v[k].x;
+            s2 += v[k].y;
+          }
+      }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      if (lane == 0) {
+        double v;
+        if (newton)
+          v = s2 >= 2.2204460492503131e-16 ? s1 / s2 : 0.0;  // DBL_EPSILON
+        else
+          v = s1 / (double)(tsw->leaf_begin[l2 + 1] - tsw->leaf_begin[l2]);
+        tsw->leaf_value[l2] = v;
+        tsw->nodes[tsw->leaf_nodes[l2]].value = v;
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    nodes_out_write(tsw, nodes_out, seq);
   }
 #ifdef QR_LEAF_TIMING
   LT(5);
@@ -4351,6 +4506,7 @@ __global__ void k_tree_reset(QrTreeState *ts, int nleaves, u64 minls) {
 }
 
 int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls) {
+  QR_DBG_CAPS(c);
   c->finish_in_decide = false;
   c->tree_step = 0;
   c->tree_counter += 0x9E3779B97F4A7C15ull;  // a fresh feature-subset stream per tree
@@ -4394,9 +4550,10 @@ int qr_k_tree_decide(qr_ctx *c) {
 
 int qr_k_xpop(qr_ctx *c, int root_mode, size_t nleaves, uint64_t minls, int final_call) {
   hipLaunchKernelGGL(k_xpop, dim3(1), dim3(128), 0, c->stream, c->d_tree, root_mode, (int)nleaves, (u64)minls,
-                     (uint32_t)c->N, c->d_scalars, c->d_part_ss, (unsigned long long *)c->d_xgbest, c->flocal,
-                     final_call, final_call ? c->d_pin->early : (int64_t *)nullptr,
-                     (long long)(final_call ? ++c->early_seq : 0));
+                     (uint32_t)(c->sub_k ? c->sub_n : c->N), c->d_scalars, c->d_part_ss,
+                     (unsigned long long *)c->d_xgbest, c->flocal, final_call,
+                     final_call ? c->d_pin->early : (int64_t *)nullptr, (long long)(final_call ? ++c->early_seq : 0),
+                     c->sub_k ? 0 : 2);
   QR_CHECK(c, hipGetLastError());
   return QR_OK;
 }
@@ -4456,12 +4613,14 @@ static int launch_batch_hist_scan(qr_ctx *c, const unsigned hg, const uint32_t r
     QR_CHECK(c, hipEventCreate(&e1));
     hipExtLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, e0, e1, 0, c->d_lhist_wg,
                           c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
-                          c->d_scalars, (u64 *)c->d_lpartials, c->d_lhistsum);
+                          c->d_scalars, (u64 *)c->d_lpartials, c->d_lhistsum, (const uint8_t *)c->d_bins64,
+                          (uint32_t)c->N);
     c->prof_events_child.push_back({e0, e1});
   } else
     hipLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, c->d_lhist_wg,
                        c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
-                       c->d_scalars, (u64 *)c->d_lpartials, c->d_lhistsum);
+                       c->d_scalars, (u64 *)c->d_lpartials, c->d_lhistsum, (const uint8_t *)c->d_bins64,
+                       (uint32_t)c->N);
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_redscan, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_tree, 0,
                      rootn, c->d_lplan, c->d_blocks, c->nblocks, c->ncu, (const u64 *)c->d_lpartials,
@@ -4528,6 +4687,7 @@ static int launch_decide_batch(qr_ctx *c, const BatchGeom &g, size_t nleaves, ui
 // leave at once and qr_k_tree_continue carries the tree on when the host fetches the
 // records.  The first tree of a context enqueues the worst case.
 int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
+  QR_DBG_CAPS(c);
   c->tree_step = 0;
   c->tree_counter += 0x9E3779B97F4A7C15ull;
   c->cur_minls = minls;
@@ -4588,6 +4748,7 @@ int qr_k_tree_fit_batch(qr_ctx *c, size_t nleaves, uint64_t minls) {
 // call per step on the device-resident state, for the worst case that is left; the last
 // call is final again (and cannot be incomplete: the leaf budget is exhausted by then).
 int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_done, size_t max_steps) {
+  QR_DBG_CAPS(c);
   const BatchGeom g = batch_geom(c, nleaves);
   // (max_steps: the caller may take the rest in pieces and look again after each -- the
   // worst case left is mostly launches that find nothing to do)
@@ -4614,6 +4775,7 @@ int qr_k_tree_continue(qr_ctx *c, size_t nleaves, uint64_t minls, size_t steps_d
 // Every rank holds the same all-reduced integers and the same rank-ordered f64 sums, so the
 // control steps agree bit for bit without exchanging anything else.
 int qr_k_dbatch_root_hist(qr_ctx *c, size_t nleaves, uint64_t minls) {
+  QR_DBG_CAPS(c);
   c->tree_step = 0;
   c->tree_counter += 0x9E3779B97F4A7C15ull;
   c->cur_minls = minls;
@@ -4663,7 +4825,7 @@ int qr_k_dbatch_apply(qr_ctx *c, size_t nleaves) {
   }
   hipLaunchKernelGGL(k_hist_batch, dim3(g.hg), dim3(1024), hist_lds(c), c->stream, c->d_lhist_wg, c->d_blocks,
                      c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_lpartials,
-                     c->d_lhistsum);
+                     c->d_lhistsum, (const uint8_t *)c->d_bins64, (uint32_t)c->N);
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_bd_reduce, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_lscan_wg,
                      (const u64 *)c->d_lpartials, c->flocal, c->d_xb, c->d_hcnt_loc, c->d_lhistsum, c->rank,
@@ -4688,6 +4850,7 @@ int qr_k_dbatch_decide(qr_ctx *c, size_t nleaves, uint64_t minls, int final_call
 }
 
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
+  QR_DBG_CAPS(c);
   // (k_obl_plan numbers the leaves of the level the tree ends at: no k_finish launch)
   c->finish_in_decide = !c->obl_own_launches;
   const int maxnodes = (1 << (depth + 1)) - 1;
@@ -4757,6 +4920,7 @@ int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls) {
 // ---- feature-sharded level-wise growth, phase by phase (the host puts the all-gather of
 // the records and the all-reduce of mask + counts in between) ---------------------------
 int qr_k_obl_begin(qr_ctx *c, size_t depth, uint64_t minls) {
+  QR_DBG_CAPS(c);
   c->finish_in_decide = false;
   const int maxnodes = (1 << (depth + 1)) - 1;
   hipLaunchKernelGGL(k_obl_reset, dim3((maxnodes + 255) / 256), dim3(256), 0, c->stream, c->d_tree,
@@ -4841,6 +5005,21 @@ int qr_k_tree_finish(qr_ctx *c, int newton) {
   const double *wgt = newton ? c->d_weight : (const double *)nullptr;
   const uint8_t *present = c->sub_k ? c->d_present : (const uint8_t *)nullptr;
   c->leafb_valid = false;
+  // (QR_LEAF_FUSE=1, an experiment that is NOT kept: the last of the 977 workgroups doing
+  // k_leaf_final's work saves that launch and costs 57 us per iteration at 1M documents --
+  // 0.410 -> 0.467 ms; the device-scope fence every workgroup needs before its ticket writes its
+  // XCD's L2 back, 977 times)
+  static const bool fuse_env = getenv("QR_LEAF_FUSE") && atoi(getenv("QR_LEAF_FUSE")) != 0;
+  if (doc_path && walk && !c->dmode && fuse_env && c->d_leaf_ticket) {
+    // (the last workgroup finishes the leaves: no k_leaf_final launch behind this one)
+    hipLaunchKernelGGL(k_leaf_sums_doc<true>, dim3(sgrid), dim3(256), 0, c->stream, c->d_tree,
+                       c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm, (uint32_t)c->N,
+                       c->d_gf2lf, c->wide ? 1 : 0, c->d_leafb, c->d_lambda, wgt, present, c->d_leafpart,
+                       c->d_leaf_ticket, c->d_tree, newton, &c->d_pin->tree, (long long)++c->nodes_seq);
+    QR_CHECK(c, hipGetLastError());
+    c->leafb_valid = true;  // every document has walked
+    return QR_OK;
+  }
   if (doc_path && walk) {
     hipLaunchKernelGGL(k_leaf_sums_doc<true>, dim3(sgrid), dim3(256), 0, c->stream, c->d_tree,
                        c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm, (uint32_t)c->N,
@@ -4875,8 +5054,56 @@ int qr_k_tree_leaves_global(qr_ctx *c, int newton) {
   return QR_OK;
 }
 
-int qr_k_scores_update(qr_ctx *c, double shrinkage) {
+// qr_debug_check: drains the device, reports a failed launch and -- in a -DQR_DEBUG_CHECKS build --
+// the first bounds violation a growth kernel recorded (and skipped)
+int qr_k_debug_check(qr_ctx *c) {
+  QR_CHECK(c, hipDeviceSynchronize());
+  QR_CHECK(c, hipGetLastError());
+#ifdef QR_DEBUG_CHECKS
+  unsigned long long w[4] = {0, 0, 0, 0};
+  QR_CHECK(c, hipMemcpyFromSymbol(w, HIP_SYMBOL(qr_dbg_word), sizeof(w)));
+  if (w[0]) {
+    const unsigned long long zero[4] = {0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(qr_dbg_word), zero, sizeof(zero));
+    char msg[256];
+    snprintf(msg, sizeof(msg), "QR_DEBUG_CHECKS: bounds violation, check %llu in workgroup %llu, values 0x%llx 0x%llx (%llu in all)",
+             w[0] >> 32, w[0] & 0xffffffffull, w[2], w[3], w[1]);
+    c->err = msg;
+    return QR_ERR_STATE;
+  }
+  QR_DBG_CAPS(c);
+#endif
+  return QR_OK;
+}
+
+// a score update left to the next lambda pass (qr_k_lambda), launched after all: somebody
+// else wants the scores first
+int qr_k_scores_flush(qr_ctx *c) {
+  if (!c->lazy_scores) return QR_OK;
+  c->lazy_scores = false;
+  hipLaunchKernelGGL(k_score_update_leaf, dim3((unsigned)((c->N + 1023) / 1024)), dim3(256), 0, c->stream,
+                     c->d_tree, c->d_leafb, (uint32_t)c->N, c->lazy_shrinkage, c->d_scores);
+  QR_CHECK(c, hipGetLastError());
+  return QR_OK;
+}
+
+// repeat: the same update enqueued again behind a tree that was carried on (its first launch
+// found the tree incomplete and left at once; a pending lazy update was never launched at all)
+int qr_k_scores_update(qr_ctx *c, double shrinkage, bool repeat) {
   const unsigned grid = (unsigned)((c->N + 255) / 256);
+  // One GPU, every document's leaf known, no sample: the update waits for the lambda pass of
+  // the next iteration, which reads every score anyway (mart.cc:464-467 -> lambdamart.cc:70):
+  // one launch and 16 N bytes less per iteration.  Whoever else looks at the scores first
+  // (tree_settle) has it launched after all.  QR_LAZY_SCORES=0: always at once.
+  static const bool lazy_env = !(getenv("QR_LAZY_SCORES") && atoi(getenv("QR_LAZY_SCORES")) == 0);
+  if (c->lazy_scores && !repeat) {  // (a second update behind one that nobody consumed: that one first)
+    const int frc = qr_k_scores_flush(c);
+    if (frc) return frc;
+  }
+  if (c->leafb_valid && lazy_env && c->world == 1 && !c->dmode && !c->sub_k) {
+    c->lazy_scores = true;
+    c->lazy_shrinkage = shrinkage;
+  } else
   if (c->leafb_valid) {
     // the leaf of every document is known (k_leaf_sums_doc): no walk, no lists
     hipLaunchKernelGGL(k_score_update_leaf, dim3((unsigned)((c->N + 1023) / 1024)), dim3(256), 0, c->stream,

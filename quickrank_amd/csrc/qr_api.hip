@@ -13,9 +13,18 @@
 
 static thread_local std::string g_create_err;
 
+// QR_POISON=1 (a debugging aid, tests/tools/abort_hunt.py --poison): every device allocation of the
+// library starts as 0xA5 bytes -- a read of something nobody wrote gives the same garbage in every
+// process, not zeros in a fresh one and an earlier context's data in a long one.
+static bool qr_poison() {
+  static const bool on = getenv("QR_POISON") && atoi(getenv("QR_POISON")) != 0;
+  return on;
+}
 template <class T>
 static hipError_t dalloc(T **p, size_t n) {
-  return hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
+  const hipError_t e = hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
+  if (e == hipSuccess && qr_poison()) return hipMemset(*p, 0xA5, (n ? n : 1) * sizeof(T));
+  return e;
 }
 template <class T>
 static void dfree(T *&p) {
@@ -28,7 +37,7 @@ static void dfree(T *&p) {
 extern "C" {
 
 void qr_ctx_destroy(qr_ctx *c);
-static int tree_settle(qr_ctx *c);
+static int tree_settle(qr_ctx *c, bool keep_scores = false);
 
 // Wait for a read-back: the publishing kernel stores `want` into the pinned block after its
 // data (system-scope release).  Polls the word; every so often asks the stream whether it
@@ -154,7 +163,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_raw); dfree(c->d_labels); dfree(c->d_qoff);
   dfree(c->d_scores); dfree(c->d_lambda); dfree(c->d_weight);
   dfree(c->d_idcg); dfree(c->d_qmetric); dfree(c->d_ranks); dfree(c->d_ssq); dfree(c->d_qmax);
-  dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins); dfree(c->d_bins_fm);
+  dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins); dfree(c->d_bins64); dfree(c->d_bins_fm);
   dfree(c->d_thr); dfree(c->d_thr_size);
   dfree(c->d_woff); dfree(c->d_wthr); dfree(c->d_wbins); dfree(c->d_wbins16);
   if (c->d_wpart) (void)hipFree(c->d_wpart);
@@ -177,7 +186,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_red_sum); dfree(c->d_red_cnt);
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec); dfree(c->d_featthr); dfree(c->d_lscan_wg);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
-  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_lpart_ss2); dfree(c->d_jobsum); dfree(c->d_bpart_state); dfree(c->d_tree); dfree(c->d_tree2); dfree(c->d_leafpart); dfree(c->d_leafb);
+  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_lpart_ss2); dfree(c->d_jobsum); dfree(c->d_bpart_state); dfree(c->d_tree); dfree(c->d_tree2); dfree(c->d_leafpart); dfree(c->d_leafb); dfree(c->d_leaf_ticket);
   dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials); dfree(c->d_lhistsum);
   dfree(c->d_lpart_state);
   dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
@@ -188,6 +197,7 @@ static void free_train(qr_ctx *c) {
   c->sub_k = 0;
   c->mf_k = 0;
   c->spec_pending = c->spec_scores_enqueued = false;
+  c->lazy_scores = false;
   c->steps_hint = 0;
   c->binned = false;
   c->tree_valid = false;
@@ -313,6 +323,11 @@ int qr_synchronize(qr_ctx *c) {
   if (!c->dbatch_pending) { const int src_ = tree_settle(c); if (src_) return src_; }
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   return QR_OK;
+}
+
+int qr_debug_check(qr_ctx *c) {
+  if (!c) return QR_ERR_ARG;
+  return qr_k_debug_check(c);
 }
 
 int qr_tree_pending(qr_ctx *c, int *pending) {
@@ -600,6 +615,7 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, hipMemcpy(c->d_thr_size, c->h_thr_size.data(), F * 4, hipMemcpyHostToDevice));
   // ---- bin map
   QR_CHECK(c, dalloc(&c->d_bins, c->bins_bytes));
+  if (getenv("QR_ROWS64") && atoi(getenv("QR_ROWS64"))) QR_CHECK(c, dalloc(&c->d_bins64, (size_t)c->nblocks * N * 64));
   QR_CHECK(c, dalloc(&c->d_bins_fm, (size_t)c->flocal * N));
   QR_CHECK(c, dalloc(&c->d_blocks, (size_t)c->nblocks));
   QR_CHECK(c, hipMemcpy(c->d_blocks, c->blocks.data(), c->nblocks * sizeof(QrBlock), hipMemcpyHostToDevice));
@@ -664,6 +680,10 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, dalloc(&c->d_tree2, (size_t)1));
   QR_CHECK(c, hipMemset(c->d_tree2, 0, sizeof(QrTreeState)));
   QR_CHECK(c, dalloc(&c->d_leafpart, std::max<size_t>(2 * (N / QR_SLICE + QR_MAXNODES + 4), 32 * (N / QR_SLICE + 2))));
+  if (!c->d_leaf_ticket) {
+    QR_CHECK(c, dalloc(&c->d_leaf_ticket, (size_t)16));
+    QR_CHECK(c, hipMemset(c->d_leaf_ticket, 0, 64));
+  }
   QR_CHECK(c, dalloc(&c->d_leafb, N + 16));
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   c->binned = true;
@@ -986,6 +1006,10 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
     QR_CHECK(c, hipMemset(c->d_bpart_state, 0, (N / QR_PART_SLICE + QR_BATCH + 2) * 8));
   }
   QR_CHECK(c, dalloc(&c->d_leafpart, std::max<size_t>(2 * (N / QR_SLICE + QR_MAXNODES + 4), 32 * (N / QR_SLICE + 2))));
+  if (!c->d_leaf_ticket) {
+    QR_CHECK(c, dalloc(&c->d_leaf_ticket, (size_t)16));
+    QR_CHECK(c, hipMemset(c->d_leaf_ticket, 0, 64));
+  }
   QR_CHECK(c, dalloc(&c->d_leafb, N + 16));
   if (c->dmode) {
     // the histogram exchange buffer of the document-sharded protocol: [cells] sums, [cells] counts
@@ -1177,7 +1201,8 @@ static int snapshot_scalars(qr_ctx *c) {
 int qr_lambda_compute(qr_ctx *c, int metric, size_t cutoff) {
   if (!c) return QR_ERR_ARG;
   if (!c->d_scores) QR_FAIL(c, QR_ERR_STATE, "no dataset uploaded");
-  { const int src_ = tree_settle(c); if (src_) return src_; }
+  // (a score update left pending rides in this pass: k_lambda.hip)
+  { const int src_ = tree_settle(c, true); if (src_) return src_; }
   if (metric != QR_METRIC_NDCG && metric != QR_METRIC_DCG)
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "metric must be DCG or NDCG");
   int rc = ensure_idcg(c, 0, metric, cutoff);
@@ -1460,9 +1485,12 @@ static int wait_early(qr_ctx *c, int64_t *word_out) {
 // entry points that can let them ride, qr_tree_fit and qr_oblivious_fit, settle with
 // tree_settle_keep.)
 static int tree_settle_keep(qr_ctx *c);
-static int tree_settle(qr_ctx *c) {
-  const int rc = tree_settle_keep(c);
+// keep_scores: a score update left to the next lambda pass stays pending (qr_lambda_compute:
+// that pass is coming); everybody else is about to read or overwrite what it changes
+static int tree_settle(qr_ctx *c, bool keep_scores) {
+  int rc = tree_settle_keep(c);
   if (rc) return rc;
+  if (!keep_scores && (rc = qr_k_scores_flush(c))) return rc;
   return qr_k_prep_flush(c);
 }
 static int tree_settle_keep(qr_ctx *c) {
@@ -1512,7 +1540,7 @@ static int tree_settle_keep(qr_ctx *c) {
     if (rc) return rc;
     done += piece;
     if ((rc = qr_k_tree_finish(c, c->spec_newton))) return rc;
-    if (c->spec_scores_enqueued && (rc = qr_k_scores_update(c, c->spec_shrinkage))) return rc;
+    if (c->spec_scores_enqueued && (rc = qr_k_scores_update(c, c->spec_shrinkage, true))) return rc;
     if ((rc = wait_early(c, &w))) return rc;
     if ((w & 1) && piece == worst) QR_FAIL(c, QR_ERR_STATE, "internal: tree still incomplete after its last step");
   }
@@ -1565,7 +1593,7 @@ int qr_tree_leaves_finish(qr_ctx *c, int newton, qr_node_t *nodes_out, size_t *n
   if (rc) return rc;
   if (c->dbatch_redo) {  // a carried-on tree: the score update enqueued behind its first end left at once
     c->dbatch_redo = false;
-    if (c->spec_scores_enqueued && (rc = qr_k_scores_update(c, c->spec_shrinkage))) return rc;
+    if (c->spec_scores_enqueued && (rc = qr_k_scores_update(c, c->spec_shrinkage, true))) return rc;
     c->spec_scores_enqueued = false;
   }
   c->tree_valid = true;
@@ -1582,8 +1610,11 @@ int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
             "sharded contexts must drive qr_tree_begin/decide/apply/end "
             "with the collectives in between");
   {
-    const int src = tree_settle_keep(c);  // (deferred scalars ride in the root scan launch, or are flushed there)
+    int src = tree_settle_keep(c);  // (deferred scalars ride in the root scan launch, or are flushed there)
     if (src) return src;
+    // (a score update nobody consumed -- no lambda pass between two trees: the new tree
+    // overwrites the leaf bytes and values it needs)
+    if ((src = qr_k_scores_flush(c))) return src;
   }
   // up to QR_BATCH splits per step (k_decide_batch); per-node feature subsets are keyed by
   // the node's final index, which a split applied ahead of its turn does not know yet
@@ -1611,7 +1642,8 @@ int qr_tree_fit(qr_ctx *c, size_t nleaves, uint64_t minls, int newton,
     return qr_tree_end(c, newton, nodes_out, nnodes_out);
   }
   // pre-sorted lists: the split search of a node when the loop pops it (k_exact.hip qr_k_exact_fit)
-  if (qr_exact_active(c) && !c->x_eager && nleaves >= 2 && 2 * nleaves + 1 <= QR_MAXNODES) {
+  // (round 5: under --subsample too -- the root lists are cut down to the sample per tree)
+  if (c->xmode && !c->x_eager && nleaves >= 2 && 2 * nleaves + 1 <= QR_MAXNODES) {
     if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
     c->cur_nleaves = nleaves;
     c->leaf_cap = nleaves;
@@ -1642,6 +1674,7 @@ int qr_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls, int newton,
   if (!c) return QR_ERR_ARG;
   if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
   { const int src_ = tree_settle_keep(c); if (src_) return src_; }
+  { const int src_ = qr_k_scores_flush(c); if (src_) return src_; }
   if (c->world > 1 || c->dmode)
     QR_FAIL(c, QR_ERR_STATE,
             "sharded contexts grow oblivious trees phase by phase (qr_obl_begin / propose / [mark] / "
@@ -1924,7 +1957,7 @@ int qr_node_hist_read_ragged(qr_ctx *c, int node, double *sum_out, uint64_t *cou
   QrScalars s;
   QR_CHECK(c, hipMemcpy(&s, c->d_scalars, sizeof(s), hipMemcpyDeviceToHost));
   const size_t slot = (size_t)ts.nodes[node].hslot;
-  if (qr_exact_active(c))
+  if (c->xmode && (!c->sub_k || !c->x_eager))
     QR_FAIL(c, QR_ERR_UNSUPPORTED, "this context grows its trees on pre-sorted lists (rows of more than "
                                    "16384 slots): there are no node histograms to read");
   if (c->wide) {

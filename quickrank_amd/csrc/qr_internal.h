@@ -422,6 +422,9 @@ struct qr_ctx {
   QrLambdaPlanDev lu_plan[2];
   size_t lu_dyn[2] = {0, 0};
   bool lu_on[2] = {false, false};
+  // Mart::update_modelscores left to the next lambda pass (k_tree.hip: qr_k_scores_update)
+  bool lazy_scores = false;
+  double lazy_shrinkage = 0.0;
   bool lu_ordered[2] = {false, false};
   size_t lu_order_off[2] = {0, 0};
   size_t attr_lambda_u_lds = 64 * 1024;
@@ -517,6 +520,8 @@ struct qr_ctx {
   uint64_t *d_lpartials = nullptr;
   double *d_lhistsum = nullptr;       // batched growth: [slot][ss, sum] of the child a histogram workgroup (block 0) read
   unsigned long long *d_lpart_state = nullptr;
+  uint8_t *d_bins64 = nullptr;        // QR_ROWS64=1: [block][doc][64] copy of the bins for the child launches
+  uint32_t *d_leaf_ticket = nullptr;  // k_leaf_sums_doc: the last workgroup to finish does k_leaf_final's work
   double *d_leafpart = nullptr;  // [slices][2] partial sums (k_leaf_sums), or [slices][16][2] (k_leaf_sums_doc)
   uint8_t *d_leafb = nullptr;    // [N] leaf of every document in the last small tree (k_leaf_sums_doc)
   size_t leaf_cap = 0;           // leaves the tree under construction can have (<= 16: the document-order leaf kernels)
@@ -623,6 +628,8 @@ struct QrTreeState;
 bool qr_k_wide_batch_ok(const qr_ctx *c);
 int qr_k_whist_scan_batch(qr_ctx *c, const QrTreeState *ts, const double *pss);
 int qr_k_whist_scan(qr_ctx *c, int root_mode);
+int qr_k_scores_flush(qr_ctx *c);
+int qr_k_debug_check(qr_ctx *c);
 int qr_k_exact_build(qr_ctx *c);
 int qr_k_wide_stats(qr_ctx *c, const float *d_col, size_t limit, uint32_t *vals, uint32_t *cnt, uint32_t *mm);
 int qr_k_wscan_doc(qr_ctx *c, int root_mode);   // document-sharded wide bins: all-reduced cells -> slot, scan
@@ -664,7 +671,7 @@ int qr_k_tree_begin(qr_ctx *c, size_t nleaves, uint64_t minls);
 int qr_k_tree_decide(qr_ctx *c);
 int qr_k_tree_apply(qr_ctx *c);
 int qr_k_tree_finish(qr_ctx *c, int newton);
-int qr_k_scores_update(qr_ctx *c, double shrinkage);
+int qr_k_scores_update(qr_ctx *c, double shrinkage, bool repeat = false);
 int qr_k_oblivious_fit(qr_ctx *c, size_t depth, uint64_t minls);
 int qr_k_obl_begin(qr_ctx *c, size_t depth, uint64_t minls);
 int qr_k_obl_propose(qr_ctx *c, int level);

@@ -868,6 +868,103 @@ def test_queries_longer_than_the_lds(qr, ora, exact_tail, monkeypatch):
     c.close()
 
 
+@pytest.mark.parametrize("exact_tail", [False, True])
+@pytest.mark.parametrize("kind", ["zero", "few", "mixed", "random"])
+@pytest.mark.parametrize("metric,cutoff", [("NDCG", 10), ("NDCG", 3), ("NDCG", 0), ("DCG", 40), ("NDCG", 300)])
+def test_ragged_set_single_launch_roles(qr, ora, kind, metric, cutoff, exact_tail, monkeypatch):
+    """The one launch of a ragged query set (k_lambda_u, round 5): query lengths on both sides of
+    every role boundary (one packed wave up to 128 / up to 256 documents, eight waves beyond, the
+    launch's own capacity ~1700 documents at cutoff 10 -- fewer with more top ranks kept -- and the
+    size-class / global-scratch launches beside it for what is longer), empty-ish queries, every
+    kind of tie, cutoffs from 3 to "none" (the pair sweep's rounds of five ranks then run over all
+    of a query's ranks).  Ranks bit for bit, the metric bit for bit per query, lambdas to 1e-10.
+    And the other way round: the same set through the launches of round 4 (QR_LAMBDA_UNIFIED=0 is
+    read once per process, so that side is the oracle alone here)."""
+    if exact_tail:
+        monkeypatch.setenv("QR_EXACT_TAIL", "1")
+    else:
+        monkeypatch.delenv("QR_EXACT_TAIL", raising=False)
+    lens = [1, 2, 63, 64, 65, 127, 128, 129, 130, 200, 255, 256, 257, 258, 300, 511, 512, 513, 600, 1100,
+            1152, 1153, 1700, 1750, 2500, 3400, 17, 40, 100, 128, 256, 5]
+    qoff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    N = int(qoff[-1])
+    rng = np.random.default_rng(len(kind) + cutoff)
+    x = rng.random((N, 5), dtype=np.float32)
+    labels = rng.integers(0, 5, N).astype(np.float32)
+    labels[int(qoff[3]):int(qoff[4])] = 0           # a query without a relevant document
+    scores = _scores_for(kind, N, rng)
+    c, _, _ = _ctx(qr, x, labels, qoff, 16)
+    c.set_scores(scores)
+    m = 1 if metric == "NDCG" else 0
+    c.compute_lambdas(metric, cutoff)
+    _check_ranks(ora, c.ranks(), scores, qoff, cutoff, exact_tail, (kind, metric, cutoff))
+    pq = c.metric_per_query()
+    L = ora.lib()
+    for q in range(len(qoff) - 1):
+        a, b = int(qoff[q]), int(qoff[q + 1])
+        fn = L.qro_ndcg_query if m else L.qro_dcg_query
+        assert pq[q] == fn(np.ascontiguousarray(labels[a:b]), np.ascontiguousarray(scores[a:b]), b - a, cutoff), q
+    lam, w = c.get_pseudo()
+    olam, ow = ora.lambdas(labels, scores, qoff, cutoff, m)
+    scale = max(1.0, np.abs(olam).max())
+    assert np.allclose(lam, olam, rtol=1e-10, atol=1e-13 * scale)
+    assert np.allclose(w, ow, rtol=1e-10, atol=1e-13 * scale)
+    assert c.metric_last() == pytest.approx(ora.eval_dataset(labels, scores, qoff, cutoff, m), rel=1e-13)
+    # the validation set takes the same launch (metric only)
+    c.upload_valid(x, labels, qoff)
+    c.set_valid_scores(scores)
+    assert c.metric_eval(1, metric, cutoff) == pytest.approx(ora.eval_dataset(labels, scores, qoff, cutoff, m), rel=1e-13)
+    c.close()
+
+
+def test_score_update_left_to_the_lambda_pass(qr, ora):
+    """qr_scores_update on one GPU leaves the update to the next lambda pass (mart.cc:464-467 ->
+    lambdamart.cc:70; k_lambda.hip `upd_leaf`): whoever looks at the scores in between gets them
+    updated all the same -- a read, a metric evaluation, a second tree without a lambda pass, a
+    second update -- and the pass itself computes on the updated scores.  Bit for bit against the
+    walk of the tree on the raw rows, on a uniform and on a ragged set (the short-queries launch
+    and the ragged set's single launch)."""
+    for case in (dict(nq=80, docs_per_query=50, F=12, seed=3), dict(nq=70, docs_per_query=90, F=12, seed=4, ragged=True)):
+        x, labels, qoff = make_dataset(**case)
+        N = len(labels)
+        c, _, _ = _ctx(qr, x, labels, qoff, 32)
+        rng = np.random.default_rng(9)
+        s0 = np.round(rng.standard_normal(N), 1)
+        c.set_scores(s0)
+
+        def walk(nodes):
+            at = np.zeros(N, np.int64)
+            while True:
+                nd = nodes[at]
+                idx = np.nonzero(nd["feature"] >= 0)[0]
+                if not len(idx):
+                    return nodes["value"][at]
+                go = x[idx, nd["feature"][idx]] <= nd["threshold"][idx]
+                at[idx] = np.where(go, nd["left"][idx], nd["right"][idx])
+
+        want = s0.copy()
+        for it in range(4):
+            c.compute_lambdas("NDCG", 10)
+            # the pass ran on the scores as they should be by now
+            olam, ow = ora.lambdas(labels, want, qoff, 10, 1)
+            lam, w = c.get_pseudo()
+            sc = max(1.0, np.abs(olam).max())
+            assert np.allclose(lam, olam, rtol=1e-10, atol=1e-13 * sc) and np.allclose(w, ow, rtol=1e-10, atol=1e-13 * sc)
+            nodes = c.fit_tree(8, 2, True)
+            c.update_scores(0.1)
+            want = want + 0.1 * walk(nodes)
+            if it == 0:
+                assert np.array_equal(c.get_scores(), want)                       # a read in between
+            elif it == 1:
+                assert c.metric_eval(0, "NDCG", 10) == pytest.approx(ora.eval_dataset(labels, want, qoff, 10, 1), rel=1e-13)
+            elif it == 2:
+                nodes2 = c.fit_tree(8, 2, True)                                   # a tree without a lambda pass
+                c.update_scores(0.1)                                              # ... and a second update
+                want = want + 0.1 * walk(nodes2)
+        assert np.array_equal(c.get_scores(), want)
+        c.close()
+
+
 @pytest.mark.parametrize("nleaves", [22, 23, 64, 65, 255, 256])
 def test_leaf_counts_around_the_batched_growth_limits(qr, ora, nleaves):
     """Two splits per step with the control step inside the partition launch and its state

@@ -312,6 +312,44 @@ def test_presorted_lists_equal_the_slot_histograms(qr, algo, case, nthr, minls, 
     assert np.array_equal(sa, sb) and ma == mb
 
 
+@pytest.mark.parametrize("algo", ["LAMBDAMART", "MART"])
+@pytest.mark.parametrize("subsample", [0.5, 0.13])
+def test_presorted_lists_under_subsample(qr, algo, subsample, monkeypatch):
+    """--subsample on the pre-sorted lists (round 5; mart.cc:287-329): every feature's root list is
+    cut down to the iteration's sample, and the tree grows on it.  The same seeded draws on the
+    slot-indexed path (QR_WIDE_NO_EXACT=1, what a sampled wide context fell back to in round 4) must
+    give the same records and scores, bit for bit -- and the lists must really be what ran (a
+    context on them has no node histograms to read)."""
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(**CASES[1])
+    kw = dict(ntrees=4, shrinkage=0.1, nthresholds=0, nleaves=10, minls=2, esr=0, subsample=subsample, seed=11)
+
+    def run(expect_lists):
+        m = Mart(algo=algo, **kw).learn(x, labels, qoff)
+        assert m.ctx.wide
+        k = int(np.floor(np.float32(subsample) * np.float32(len(labels))))
+        assert all(t[0]["nsamples"] == k for t in m.ensemble.trees)
+        if expect_lists:
+            with pytest.raises(Exception, match="pre-sorted"):
+                m.ctx.node_hist_ragged(0)
+        else:
+            m.ctx.node_hist_ragged(0)
+        out = [t.copy() for t in m.ensemble.trees], m.ctx.get_scores(), list(m.train_metric)
+        m.ctx.close()
+        return out
+
+    monkeypatch.setenv("QR_NO_BATCH", "1")
+    monkeypatch.setenv("QR_WIDE_NO_EXACT", "1")
+    ta, sa, ma = run(False)
+    monkeypatch.delenv("QR_WIDE_NO_EXACT")
+    monkeypatch.setenv("QR_WIDE_EXACT", "1")
+    tb, sb, mb = run(True)
+    for a, b in zip(ta, tb):
+        for k in a.dtype.names:
+            assert np.array_equal(a[k], b[k], equal_nan=(a[k].dtype.kind == "f")), k
+    assert np.array_equal(sa, sb) and ma == mb
+
+
 def test_presorted_lists_refuse_node_histogram_reads(qr, monkeypatch):
     monkeypatch.setenv("QR_WIDE_EXACT", "1")
     x, labels, qoff = make_dataset(**CASES[0])

@@ -133,10 +133,41 @@ def parting_gains_exact(stmap, o, g, pseudo):
                 return L * L / lc + R * R / rc
             ga, gb = gain(ol), gain(gl)
             m = max(abs(ga), abs(gb))
+            parting_gains_exact.last = dict(docs=d, oracle=(int(a["feature"]), int(a["thr_id"])),
+                                            device=(int(b["feature"]), int(b["thr_id"])),
+                                            exact=(ga, gb))
             return (float(abs(ga - gb) / m) if m else 0.0), len(d)
         queue.append((int(a["left"]), int(gL), d[ol]))
         queue.append((int(a["right"]), int(gR), d[~ol]))
     return None
+
+
+def reference_f64_view(tr, oracle, pseudo, info, minls):
+    """What the REFERENCE's own arithmetic makes of the two candidates of a priced gain tie
+    (VERDICT r4 item 9): the node's cumulative f64 sums as rtnode_histogram.cc:51-69 accumulates
+    them (document order per slot, prefix over slots), `lsum^2 / lcount + rsum^2 / rcount` of
+    rt.cc:276-279 for the oracle's candidate and the device's, and their distance in units of the
+    last place.  Also the distance of the two EXACT gains in ulps of an f64 of their size: a few
+    ulps = the reference's pick is its summation order's; thousands = the reference resolves what
+    the device's 33-bit fixed-point gradients do not."""
+    import math
+    d = np.sort(info["docs"]).astype(np.uint64)
+    s, c, _ = oracle.hist_build(tr.stmap, tr.thr_size, tr.cap, pseudo, sampleids=d)
+
+    def f64_gain(cand):
+        f, t = cand
+        last = int(tr.thr_size[f]) - 1
+        ls, lc = s[f, t], float(c[f, t])
+        rs, rc = s[f, last] - ls, float(c[f, last]) - lc
+        return ls * ls / lc + rs * rs / rc
+    fa, fb = f64_gain(info["oracle"]), f64_gain(info["device"])
+    ga, gb = (float(v) for v in info["exact"])
+    ulp = math.ulp(max(abs(ga), abs(gb)))
+    return dict(f64_gain_oracle_candidate=fa, f64_gain_device_candidate=fb,
+                f64_ulps_apart=abs(fa - fb) / math.ulp(max(abs(fa), abs(fb))),
+                exact_ulps_apart=float(abs(info["exact"][0] - info["exact"][1])) / ulp,
+                reference_prefers_its_own=bool(fa > fb or (fa == fb and info["oracle"] < info["device"])),
+                exact_prefers=("oracle's" if info["exact"][0] > info["exact"][1] else "device's"))
 
 
 def device_tree_follows_from_device_scores(tr, oracle, labels, qoff, gtrees, t, kw, algo):
@@ -219,9 +250,10 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
     scores of a query differ by rounding noise only going into the tree that differs (the ranking,
     hence the lambdas, is then decided by the summation order of the leaf outputs).  Any other
     difference raises."""
-    import torch
-    if torch.cuda.is_available():
-        torch.cuda.init()
+    if not os.environ.get("QR_NO_TORCH"):   # (tests/tools/abort_hunt.py --no-torch: the /opt/rocm runtime alone)
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
     import oracle
     from datagen import make_dataset
     from parity_util import assert_tree_parity, TIE_MAX_DOCS
@@ -309,6 +341,11 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
                     rec["gain_rel"], rec["gain_node_docs"] = priced
                     if priced[0] > 0.0:
                         status = "gain_tie_fp"
+                        rec["ref_view"] = reference_f64_view(tr, oracle, pseudo, parting_gains_exact.last, minls)
+                        print(desc, "tree", t, "gain_tie_fp: exact gains", f"{priced[0]:.3e}", "apart (relative) =",
+                              f"{rec['ref_view']['exact_ulps_apart']:.1f} ulps; the reference's own f64 gains",
+                              f"{rec['ref_view']['f64_ulps_apart']:.1f} ulps apart; exact arithmetic prefers the",
+                              rec["ref_view"]["exact_prefers"], "candidate", flush=True)
                 # ... or both trees cut alike and spent the leaf budget on different, equally deviant nodes
                 if status is None and not algo.startswith("OBV") and deviance_order_tie(tr.stmap, o, g):
                     status = "heap_tie"

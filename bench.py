@@ -119,6 +119,14 @@ def synth_device(torch, blocks, nq, dpq, F, seed0=1142):
     return x, lab.cpu().numpy(), qoff
 
 
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (the counters of a launch cannot be
+    read inside this process: they are quoted from the committed PMC passes, with their source)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return c[-1] if c else None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -638,10 +646,8 @@ def main():
             # cannot be read inside this process): quoted with its source, and only when it
             # was collected on this very workload with the kernel as it is now
             traffic, tsrc = None, None
-            pmc = os.path.join(ROOT, "profiles", "r04_pmc_hist.json")
-            if not os.path.exists(pmc):
-                pmc = os.path.join(ROOT, "profiles", "r03_pmc_hist.json")
-            if os.path.exists(pmc) and N == 1000000 and F == 136 and args.nthresholds == 255 \
+            pmc = newest_profile("pmc_hist.json")
+            if pmc and N == 1000000 and F == 136 and args.nthresholds == 255 \
                     and not args.sparse_cols:
                 traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
                 tsrc = ("profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
@@ -721,14 +727,14 @@ def main():
                                "hbm_frac": round(28.0 * N / (lus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                "peak": round(1024 * 2.4 / 4, 1), "unit": "G wave-instructions/s",
                                "peak_what": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 vector instruction"}
-                lp = os.path.join(ROOT, "profiles", "r04_lambda_pmc.json")
-                if os.path.exists(lp) and N == 1000000 and Q == 10000:
+                lp = newest_profile("lambda_pmc.json")
+                if lp and N == 1000000 and Q == 10000:
                     lj = json.load(open(lp))
                     vi = lj["valu_insts_per_query"]
                     ach = vi * Q / (lus * 1e-6) / 1e9
                     roof_lambda.update({"valu_insts_per_query": vi, "salu_insts_per_query": lj.get("salu_insts_per_query"),
                                         "lds_insts_per_query": lj.get("lds_insts_per_query"),
-                                        "insts_source": "profiles/r04_lambda_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU "
+                                        "insts_source": "profiles/" + os.path.basename(lp) + " (rocprofv3 --pmc SQ_INSTS_VALU "
                                                         "SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES pass of this command)",
                                         "issued": round(ach, 1), "issue_slot_occupancy": round(ach / (1024 * 2.4 / 4), 4),
                                         "issue_slot_occupancy_what": "instructions EXECUTED over issue slots: an occupancy "
@@ -916,14 +922,14 @@ def main():
                     # (counters cannot be read inside this process: the PMC passes of this workload
                     # committed under profiles/, quoted only for the workload they were collected on)
                     tr8 = None
-                    p8 = os.path.join(ROOT, "profiles", f"r04_pmc_hist_{nb}M.json")
-                    if os.path.exists(p8) and F == 136 and args.nthresholds == 255 and not args.sparse_cols:
+                    p8 = newest_profile(f"pmc_hist_{nb}M.json")
+                    if p8 and F == 136 and args.nthresholds == 255 and not args.sparse_cols:
                         tr8 = json.load(open(p8)).get("hbm_bytes_per_launch")
                     extras[f"strong_{nb}M"]["roofline"] = {
                         "bound": "hbm", "kernel": "k_hist_root (root histogram build)",
                         "achieved": round(pb["alg_bytes"] / secb / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(pb["alg_bytes"] / secb / 1e9 / HBM_PEAK_GBS, 4), "traffic": tr8,
-                        "traffic_source": (f"profiles/r04_pmc_hist_{nb}M.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                        "traffic_source": ("profiles/" + os.path.basename(p8 or "") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                            "passes of this workload)") if tr8 else None,
                         "alg_bytes_per_launch": pb["alg_bytes"], "avg_launch_us": round(secb * 1e6, 2),
                         "launches": pb["launches"]}

@@ -170,6 +170,51 @@ def reference_f64_view(tr, oracle, pseudo, info, minls):
                 exact_prefers=("oracle's" if info["exact"][0] > info["exact"][1] else "device's"))
 
 
+def leaf_value_autopsy(tr, oracle, labels, qoff, om, o, g, t, kw, algo):
+    """An unclassified mismatch, taken apart on the host (round 5's hunt met one a few times in a
+    hundred processes, always a leaf VALUE of an otherwise identical tree): every leaf whose value
+    differs -- the device's, the oracle's, and the value recomputed here from the oracle's
+    pseudo-responses over the documents that reach the DEVICE's leaf (walked on the bin map), in
+    document order and in exact rational arithmetic, with the cancellation of its numerator."""
+    from fractions import Fraction
+    sc = scores_before(tr.stmap, om, t, kw["shrinkage"])
+    if algo.endswith("LAMBDAMART"):
+        lam, w = oracle.lambdas(labels, sc, qoff)[:2]
+    else:
+        lam, w = labels.astype(np.float64) - sc, None
+    N = tr.stmap.shape[1]
+    cur = np.zeros(N, np.int64)
+    while True:
+        nd = g[cur]
+        ii = np.nonzero(nd["feature"] >= 0)[0]
+        if not len(ii):
+            break
+        go = tr.stmap[nd["feature"][ii], ii] <= nd["thr_id"][ii]
+        cur[ii] = np.where(go, nd["left"][ii], nd["right"][ii])
+    same_shape = len(o) == len(g) and np.array_equal(o["feature"], g["feature"]) and np.array_equal(o["thr_id"], g["thr_id"]) \
+        and np.array_equal(o["left"], g["left"])
+    print(" autopsy: trees of the same shape:", bool(same_shape), "nodes", len(g), flush=True)
+    for k in range(len(g)):
+        if g[k]["feature"] >= 0:
+            continue
+        ov = float(o[k]["value"]) if same_shape else float("nan")
+        if same_shape and np.isclose(g[k]["value"], ov, rtol=1e-12, atol=0):
+            continue
+        ids = np.nonzero(cur == k)[0]
+        s1 = float(lam[ids].sum())
+        s1x = sum((Fraction(float(v)) for v in lam[ids]), Fraction(0))
+        if w is not None:
+            s2x = sum((Fraction(float(v)) for v in w[ids]), Fraction(0))
+            exact = float(s1x / s2x) if s2x else 0.0
+            s2 = float(w[ids].sum())
+        else:
+            exact, s2 = float(s1x / len(ids)) if len(ids) else 0.0, float(len(ids))
+        canc = float(np.abs(lam[ids]).sum() / abs(s1)) if s1 else float("inf")
+        print(f"  leaf {k}: device {float(g[k]['value'])!r} oracle {ov!r} exact (oracle's pseudo-responses over the device's leaf) "
+              f"{exact!r}; n device {int(g[k]['nsamples'])} walked {len(ids)}; sum1 {s1!r} sum2 {s2!r} cancellation {canc:.3g}; "
+              f"device - exact {float(g[k]['value']) - exact:.3e}, oracle - exact {ov - exact:.3e}", flush=True)
+
+
 def device_tree_follows_from_device_scores(tr, oracle, labels, qoff, gtrees, t, kw, algo):
     """Causality of a `score_tie`: the device's tree t must be exactly what the
     REFERENCE's algorithm builds from the device's OWN scores going into tree t -- its trees
@@ -366,6 +411,10 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
                     status = "score_tie"
                 if status is None:
                     print(desc, "TREE", t, "MISMATCH", e)
+                    try:
+                        leaf_value_autopsy(tr, oracle, labels, qoff, om, o, g, t, kw, algo)
+                    except Exception as ae:      # (the autopsy must not hide the mismatch)
+                        print("autopsy failed:", repr(ae))
                     if only is not None:
                         for nm, arr in (("oracle", o), ("device", g)):
                             print(nm, [(k, int(a["feature"]), int(a["thr_id"]), int(a["left"]), int(a["nsamples"]),

@@ -8,7 +8,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.environ.get("QR_HIP_LIB") or os.path.join(LIBDIR, "libqr_hip.so")
 SOURCES = ["qr_api.hip", "k_bins.hip", "k_lambda.hip", "k_tree.hip", "k_score.hip", "k_sample.hip",
-           "k_wide.hip", "k_ubench.hip", "k_exact.hip"]
+           "k_wide.hip", "k_exact.hip"]
+# a measurement aid, NOT part of the product library: the bare LDS atomic rate bench.py prices the
+# root histogram launch against (qr_prof_lds_atomic loads it from the product library's directory)
+UBENCH_SRC, UBENCH_LIB = "k_ubench.hip", os.path.join(LIBDIR, "libqr_ubench.so")
 HEADERS = [os.path.join(CSRC, "qr_internal.h"), os.path.join(CSRC, "qr_wave.h"), os.path.join(CSRC, "qr_dev.h"),
            os.path.join(HERE, "..", "include", "qr_hip.h")]
 # -ffp-contract=off: the reference's arithmetic is separate multiply/add
@@ -35,6 +38,7 @@ def build(force=False, verbose=False):
     """One object per .hip source (compiled side by side, only the stale ones), then the link:
     a change to one kernel file costs that file's compile, not all eight."""
     if not force and not _stale():
+        build_ubench(verbose=verbose)
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -60,11 +64,22 @@ def build(force=False, verbose=False):
         objs = list(ex.map(compile_one, SOURCES))
     with open(stamp, "w") as f:
         f.write(" ".join(cflags))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    build_ubench(verbose=verbose)
     return LIB
+
+
+def build_ubench(force=False, verbose=False):
+    src = os.path.join(CSRC, UBENCH_SRC)
+    if force or _newer(UBENCH_LIB, [src]):
+        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + FLAGS + ["-o", UBENCH_LIB, src]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return UBENCH_LIB
 
 
 HOST = os.path.join(HERE, "host")

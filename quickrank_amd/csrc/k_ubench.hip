@@ -1,5 +1,7 @@
 // k_ubench.hip -- the ceiling the root histogram launch is priced against, measured in the
 // caller's own process (qr_prof_lds_atomic; bench.py's `roofline.lds_atomic_bound`).
+// A MEASUREMENT AID, built as a library of its own (lib/libqr_ubench.so: quickrank_amd/build.py):
+// libqr_hip.so holds no microbenchmark and loads this one only when qr_prof_lds_atomic is called.
 //
 // k_hist_root issues ONE ds_add_u64 per (document, accumulated column) and nothing it does can
 // go faster than the CU's LDS pipeline retires them.  This kernel issues the
@@ -7,7 +9,10 @@
 // sixteen lanes of an LDS lane group on sixteen distinct columns mod 16, sixteen waves per CU,
 // one workgroup per CU -- with nothing else in the loop, and reports shader cycles per wave
 // instruction (s_memtime) and the shader clock it ran at (cycles / s_memrealtime at 100 MHz).
-#include "qr_internal.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <vector>
 
 typedef unsigned long long u64;
 
@@ -38,23 +43,29 @@ __global__ __launch_bounds__(1024) void k_ubench_lds_atomic(u64 *out, const int 
   if (lds[threadIdx.x] == 0x1234567ull) out[0] = 1;  // (keeps the atomics alive)
 }
 
-extern "C" int qr_prof_lds_atomic(qr_ctx *c, double *cycles_per_instr, double *shader_ghz, double *ns_per_instr,
-                                  double *root_wave_instr_per_cu) {
-  if (!c) return QR_ERR_ARG;
-  QR_CHECK(c, hipSetDevice(c->device));
-  const int G = c->ncu, waves = 16, iters = 600;
+// 0 on success, a hipError_t otherwise
+extern "C" int qr_ubench_lds_atomic(int device, int ncu, void *stream, double *cycles_per_instr, double *shader_ghz) {
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return (int)e;
+  const int G = ncu, waves = 16, iters = 600;
   const size_t lds = 16384 * 8;
   u64 *d_out = nullptr;
-  QR_CHECK(c, hipMalloc((void **)&d_out, (size_t)G * 16));
-  QR_CHECK(c, hipFuncSetAttribute((const void *)k_ubench_lds_atomic, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
+  if ((e = hipMalloc((void **)&d_out, (size_t)G * 16)) != hipSuccess) return (int)e;
+  if ((e = hipFuncSetAttribute((const void *)k_ubench_lds_atomic, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds)) != hipSuccess) {
+    (void)hipFree(d_out);
+    return (int)e;
+  }
   std::vector<u64> h((size_t)G * 2);
   double best_cyc = 0.0, best_ghz = 0.0;
   for (int rep = 0; rep < 3; ++rep) {  // (the first launch also warms the clocks up: the best of three)
-    hipLaunchKernelGGL(k_ubench_lds_atomic, dim3(G), dim3(waves * 64), lds, c->stream, d_out, iters);
-    QR_CHECK(c, hipGetLastError());
-    QR_CHECK(c, hipStreamSynchronize(c->stream));
-    QR_CHECK(c, hipMemcpy(h.data(), d_out, (size_t)G * 16, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_ubench_lds_atomic, dim3(G), dim3(waves * 64), lds, st, d_out, iters);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess ||
+        (e = hipMemcpy(h.data(), d_out, (size_t)G * 16, hipMemcpyDeviceToHost)) != hipSuccess) {
+      (void)hipFree(d_out);
+      return (int)e;
+    }
     // the median workgroup's cycles over the wave instructions ONE CU retired
     std::vector<u64> cyc((size_t)G), wall((size_t)G);
     for (int i = 0; i < G; ++i) {
@@ -74,14 +85,5 @@ extern "C" int qr_prof_lds_atomic(qr_ctx *c, double *cycles_per_instr, double *s
   (void)hipFree(d_out);
   if (cycles_per_instr) *cycles_per_instr = best_cyc;
   if (shader_ghz) *shader_ghz = best_ghz;
-  if (ns_per_instr) *ns_per_instr = best_ghz > 0.0 ? best_cyc / best_ghz : 0.0;
-  // what the root launch of the context's data set asks of ONE CU: a wave covers 64 / (fw / 16)
-  // documents of a block per sixteen instructions (hist_accumulate, k_tree.hip)
-  if (root_wave_instr_per_cu) {
-    double w = 0.0;
-    const double n = (double)(c->sub_k ? c->sub_n : c->N);
-    for (const auto &b : c->blocks) w += n * 16.0 / (double)(64 / (b.fw / 16));
-    *root_wave_instr_per_cu = c->binned ? w / (double)c->ncu : 0.0;
-  }
-  return QR_OK;
+  return 0;
 }

@@ -32,6 +32,7 @@ static void dfree(T *&p) {
   p = nullptr;
 }
 
+#include <dlfcn.h>
 #include <sched.h>
 
 extern "C" {
@@ -322,6 +323,42 @@ int qr_synchronize(qr_ctx *c) {
   // tree is carried on by the caller, with its all-reduces)
   if (!c->dbatch_pending) { const int src_ = tree_settle(c); if (src_) return src_; }
   QR_CHECK(c, hipStreamSynchronize(c->stream));
+  return QR_OK;
+}
+
+// bench.py's `roofline.lds_atomic_bound`: the microbenchmark is a library of its own
+// (lib/libqr_ubench.so, csrc/k_ubench.hip) next to this one, loaded here on first use -- the
+// product library holds no measurement kernel
+int qr_prof_lds_atomic(qr_ctx *c, double *cycles_per_instr, double *shader_ghz, double *ns_per_instr,
+                       double *root_wave_instr_per_cu) {
+  if (!c) return QR_ERR_ARG;
+  typedef int (*ubench_fn)(int, int, void *, double *, double *);
+  static ubench_fn fn = nullptr;
+  if (!fn) {
+    Dl_info info;
+    std::string path = "libqr_ubench.so";
+    if (dladdr((const void *)&qr_prof_lds_atomic, &info) && info.dli_fname) {
+      const std::string self = info.dli_fname;
+      const size_t slash = self.rfind('/');
+      if (slash != std::string::npos) path = self.substr(0, slash + 1) + "libqr_ubench.so";
+    }
+    void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (h) fn = (ubench_fn)dlsym(h, "qr_ubench_lds_atomic");
+    if (!fn) QR_FAIL(c, QR_ERR_UNSUPPORTED, "libqr_ubench.so (the LDS atomic microbenchmark, quickrank_amd/build.py) is not next to this library");
+  }
+  double cyc = 0.0, ghz = 0.0;
+  if (fn(c->device, c->ncu, (void *)c->stream, &cyc, &ghz) != 0) QR_FAIL(c, QR_ERR_HIP, "the LDS atomic microbenchmark failed");
+  if (cycles_per_instr) *cycles_per_instr = cyc;
+  if (shader_ghz) *shader_ghz = ghz;
+  if (ns_per_instr) *ns_per_instr = ghz > 0.0 ? cyc / ghz : 0.0;
+  // what the root launch of the context's data set asks of ONE CU: a wave covers 64 / (fw / 16)
+  // documents of a block per sixteen instructions (hist_accumulate, k_tree.hip)
+  if (root_wave_instr_per_cu) {
+    double w = 0.0;
+    const double n = (double)(c->sub_k ? c->sub_n : c->N);
+    for (const auto &b : c->blocks) w += n * 16.0 / (double)(64 / (b.fw / 16));
+    *root_wave_instr_per_cu = c->binned ? w / (double)c->ncu : 0.0;
+  }
   return QR_OK;
 }
 

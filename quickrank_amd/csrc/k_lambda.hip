@@ -277,18 +277,26 @@ __device__ __forceinline__ double row_sum(double v) {
 
 // One value per lane, sorted in DESCENDING order over the wave's lanes (bitonic network on
 // lane exchanges; max / min keep the multiset whatever the signs of zero).
-__device__ __forceinline__ double wave_sort_desc(double v, const uint32_t lane) {
+// K chunks at once: a stage's lane exchanges are LDS-pipe operations of ~100 cycles each and every
+// stage waits for the one before it -- four chunks' networks side by side hide three quarters of
+// that (a 200-document query's counting rank: 27.9 k -> see profiles/r05_lambda_ragged.md).
+template <int K>
+__device__ __forceinline__ void wave_sort_desc(double (&v)[K], const uint32_t lane) {
 #pragma unroll
   for (uint32_t k = 2; k <= 64; k <<= 1)
 #pragma unroll
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      const int lo = __shfl_xor(__double2loint(v), (int)j), hi = __shfl_xor(__double2hiint(v), (int)j);
-      const double o = __hiloint2double(hi, lo);
+      double o[K];
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        const int lo = __shfl_xor(__double2loint(v[c]), (int)j), hi = __shfl_xor(__double2hiint(v[c]), (int)j);
+        o[c] = __hiloint2double(hi, lo);
+      }
       // descending blocks (lane & k) == 0 keep the larger value in the lower lane
       const bool take_max = ((lane & j) == 0) == ((lane & k) == 0);
-      v = take_max ? fmax(v, o) : fmin(v, o);
+#pragma unroll
+      for (int c = 0; c < K; ++c) v[c] = take_max ? fmax(v[c], o[c]) : fmin(v[c], o[c]);
     }
-  return v;
 }
 
 // pow(2.0, label) of dcg.cc:37 / ndcg.cc:80: exact for the integral relevance
@@ -783,10 +791,36 @@ __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32
     // seven probes per chunk instead of sixty-four compares.  g is an exact integer either way.
     double *srt = sr;
     const uint32_t nch = (n + 63) >> 6;
-    for (uint32_t ch = wave; ch < nch; ch += W) {
-      const uint32_t i = ch * 64 + lane;
-      const double v = wave_sort_desc(i < n ? s[i] : -__builtin_inf(), lane);
-      if (i < n) srt[i] = v;  // (the padding sorts to the chunk's end: beyond n)
+    if (W == 1) {  // (one wave: four chunks' networks side by side)
+      for (uint32_t c0 = 0; c0 < nch; c0 += 4) {
+        double v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          const uint32_t i = (c0 + u) * 64 + lane;
+          v[u] = i < n ? s[i] : -__builtin_inf();
+        }
+        wave_sort_desc<4>(v, lane);
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          const uint32_t i = (c0 + u) * 64 + lane;
+          if (i < n) srt[i] = v[u];  // (the padding sorts to the chunk's end: beyond n)
+        }
+      }
+    } else {
+      for (uint32_t c0 = wave; c0 < nch; c0 += 2 * W) {  // (a wave's chunks: c0 and c0 + W together)
+        double v[2];
+#pragma unroll
+        for (uint32_t u = 0; u < 2; ++u) {
+          const uint32_t i = (c0 + u * W) * 64 + lane;
+          v[u] = i < n ? s[i] : -__builtin_inf();
+        }
+        wave_sort_desc<2>(v, lane);
+#pragma unroll
+        for (uint32_t u = 0; u < 2; ++u) {
+          const uint32_t i = (c0 + u * W) * 64 + lane;
+          if (i < n) srt[i] = v[u];
+        }
+      }
     }
     qsync<PACKED>();
     for (uint32_t i = tid; i < n; i += T) {
@@ -1233,6 +1267,9 @@ __device__ __forceinline__ void lambda_query(const QrLambdaArgs &A, const uint32
 #endif
 }
 
+// (SMALL allocates 73 VGPRs since the score update's operands ride along: six waves per SIMD.
+// Held at 72 = seven waves by amdgpu_waves_per_eu it spills three dwords and is no faster:
+// 0.4110 / 0.4109 ms per iteration against 0.4086 / 0.4109 without the attribute.)
 template <bool LONG, int W, bool SMALL = false>
 __global__ __launch_bounds__(64 * W) void k_lambda(const QrLambdaArgs A, const uint32_t nmax, const uint32_t kacc,
                                                    const uint32_t *__restrict__ long_list,
@@ -1365,8 +1402,8 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   size_t kacc = cutoff == 0 || cutoff > maxq ? maxq : cutoff;
   if (kacc == 0) kacc = 1;
   kacc = (kacc + 1) & ~(size_t)1;
-  // (dynamic LDS; the static part is up to ~1 KB with sixteen waves: sh_part, sh_red)
-  const size_t limit = 160 * 1024 - 2048;
+  // (the static part: sh_part [2][W][10] + sh_red [W][3] doubles = 2.9 KB with sixteen waves)
+  const size_t limit = 160 * 1024 - 4096;
   const bool sampled = which == 0 && c->sub_k != 0;
   // the longest query the LDS holds; longer ones run out of a global scratch slice each
   // (LONG launch); an unbounded cutoff on a long query would also need the per-rank

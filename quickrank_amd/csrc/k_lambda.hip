@@ -1834,7 +1834,7 @@ __global__ void k_scal_global(QrScalars *__restrict__ scal, const long long *__r
   scal->scale_exp = e;
   scal->scale = ldexp(1.0, e);
   scal->inv_scale = ldexp(1.0, -e);
-  scalars_to_host(host_copy, scal);
+  scalars_to_host(host_copy, scal, (int)seq);
   __threadfence_system();
   __hip_atomic_store(&host_copy->pad, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -3535,22 +3535,27 @@ __device__ __forceinline__ void nodes_out_publish(QrNodesOut *out, const long lo
 __device__ __forceinline__ void nodes_out_write(const QrTreeState *ts, QrNodesOut *out, const long long seq) {
   const int nn = ts->nnodes;
   if (threadIdx.x == 0) {  // (the header with the records: ONE system-scope fence before the number)
+    const int64_t inc = ts->incomplete, steps = ts->real_steps;
     out->nnodes = nn;
-    out->pad[0] = ts->incomplete;
-    out->pad[1] = ts->real_steps;
+    out->pad[0] = inc;
+    out->pad[1] = steps;
+    out->pad[3] = (int64_t)((uint64_t)seq * 0x9E3779B97F4A7C15ull ^ ((uint64_t)nn << 40) ^ ((uint64_t)inc << 32) ^ (uint64_t)steps);
   }
+  QrNodeWire *wire = reinterpret_cast<QrNodeWire *>(out->nodes);
   for (int i = threadIdx.x; i < nn; i += blockDim.x) {
     const QrNode &s = ts->nodes[i];
-    qr_node_t d;
+    QrNodeWire d;
     d.feature = s.feature;
     d.thr_id = s.thr_id;
     d.threshold = s.threshold;
     d.left = s.left;
     d.right = s.right;
+    d.tag = 0;
     d.value = s.value;
     d.deviance = s.deviance;
     d.nsamples = s.count;
-    out->nodes[i] = d;
+    d.tag = qr_node_tag(d, (uint64_t)seq);  // (qr_tree_nodes checks it: a self-validating record)
+    wire[i] = d;
   }
   __threadfence_system();
   __syncthreads();

@@ -7,6 +7,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <functional>
 
 #include "qr_internal.h"
@@ -230,6 +231,9 @@ void qr_ctx_destroy(qr_ctx *c) {
   if (getenv("QR_SPEC_DEBUG") && c->spec_trees)
     fprintf(stderr, "qr: %llu trees with a guessed step count, %llu continued (guess too low), last hint %zu\n",
             (unsigned long long)c->spec_trees, (unsigned long long)c->spec_misses, c->steps_hint);
+  if (c->readback_retries)   // (never silent: this is the evidence round 5's hunt was after)
+    fprintf(stderr, "qr: %llu re-reads of tree records / scalars that did not fit their sequence number yet\n",
+            (unsigned long long)c->readback_retries);
   (void)hipSetDevice(c->device);
   // Teardown order: every stream this context created is drained BEFORE any
   // memory its kernels may touch is released -- the lambda pass's size classes run on the
@@ -1319,7 +1323,21 @@ int qr_metric_last(qr_ctx *c, double *out) {
   { const int frc = qr_k_prep_flush(c); if (frc) return frc; }
   // waits for the lambda pass only; whatever was enqueued after it keeps running
   { const int wrc = wait_seq32(c, &c->h_pin->scal.pad, c->scal_seq, "the iteration's scalars"); if (wrc) return wrc; }
-  const QrScalars &s = c->h_pin->scal;
+  // (self-validating, like the tree records: the two sums must fit the sequence number just seen)
+  QrScalars s;
+  for (long spin = 0;; ++spin) {
+    const volatile QrScalars *v = &c->h_pin->scal;
+    s.metric_sum = v->metric_sum;
+    s.metric_gsum = v->metric_gsum;
+    const unsigned long long tag = v->tag;
+    unsigned long long a, b;
+    memcpy(&a, &s.metric_sum, 8);
+    memcpy(&b, &s.metric_gsum, 8);
+    if (tag == qr_scal_tag(a, b, c->scal_seq)) break;
+    ++c->readback_retries;
+    if (spin > 20000000L) QR_FAIL(c, QR_ERR_STATE, "the iteration's scalars do not fit their sequence number (pinned read-back)");
+    cpu_relax(spin);
+  }
   // metric.h:93-105: avg_score /= num_queries (0 queries -> 0.0)
   if (c->dmode)  // the sum over all ranks came with the scalar exchange
     *out = c->Qglobal ? s.metric_gsum / (double)c->Qglobal : 0.0;
@@ -1600,8 +1618,34 @@ int qr_tree_nodes(qr_ctx *c, qr_node_t *nodes_out, size_t *nnodes_out) {
   int rc = tree_settle_keep(c);
   if (rc) return rc;
   { const int wrc = wait_seq64(c, &c->h_pin->tree.pad[2], c->nodes_seq, "the tree's records"); if (wrc) return wrc; }
-  const size_t n = (size_t)c->h_pin->tree.nnodes;
-  if (nodes_out) memcpy(nodes_out, c->h_pin->tree.nodes, n * sizeof(qr_node_t));
+  // The records validate themselves (QrNodeWire): the header's tag and every record's must fit the
+  // sequence number just seen.  A record that does not fit yet is read again -- it has been
+  // written ahead of the number; if it is not here, it is on its way -- and counted
+  // (QR_SPEC_DEBUG=1 prints the count at context destruction).
+  const uint64_t seq = (uint64_t)c->nodes_seq;
+  size_t n = 0;
+  std::vector<QrNodeWire> rec;
+  for (long spin = 0;; ++spin) {
+    const volatile QrNodesOut *t = &c->h_pin->tree;
+    n = (size_t)t->nnodes;
+    const int64_t inc = t->pad[0], steps = t->pad[1], htag = t->pad[3];
+    bool ok = n <= QR_MAXNODES &&
+              htag == (int64_t)(seq * 0x9E3779B97F4A7C15ull ^ ((uint64_t)n << 40) ^ ((uint64_t)inc << 32) ^ (uint64_t)steps);
+    if (ok) {
+      rec.resize(n);
+      memcpy((void *)rec.data(), (const void *)c->h_pin->tree.nodes, n * sizeof(QrNodeWire));
+      std::atomic_thread_fence(std::memory_order_acquire);
+      for (size_t i = 0; i < n && ok; ++i) ok = rec[i].tag == qr_node_tag(rec[i], seq);
+    }
+    if (ok) break;
+    ++c->readback_retries;
+    if (spin > 20000000L) QR_FAIL(c, QR_ERR_STATE, "the tree's records do not fit their sequence number (pinned read-back)");
+    cpu_relax(spin);
+  }
+  if (nodes_out) {
+    for (size_t i = 0; i < n; ++i) rec[i].tag = 0;  // (qr_node_t's padding leaves as zeros)
+    memcpy(nodes_out, rec.data(), n * sizeof(qr_node_t));
+  }
   if (nnodes_out) *nnodes_out = n;
   return QR_OK;
 }

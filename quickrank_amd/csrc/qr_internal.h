@@ -256,16 +256,56 @@ struct QrScalars {
   double root_sum;                 // their plain f64 sum
   double metric_sum;               // sum of per-query metric
   double metric_gsum;              // document-sharded: the same over all ranks
+  unsigned long long tag;          // pinned copy only: qr_scal_tag of the two metric sums and the sequence number
 };
+// (the pinned copy of the scalars validates itself like the tree records do: qr_metric_last)
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline unsigned long long qr_scal_tag(const unsigned long long msum_bits, const unsigned long long gsum_bits, const int seq) {
+  unsigned long long h = (unsigned long long)(unsigned)seq * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull;
+  h = (h ^ msum_bits) * 0x100000001B3ull;
+  h ^= h >> 29;
+  h = (h ^ gsum_bits) * 0x100000001B3ull;
+  return h | 1ull;
+}
 
 // Host-pinned landing zone of the per-iteration read-backs (written by the kernels, each
 // followed by a sequence number the host polls -- QrScalars::pad, QrNodesOut::pad[2]:
 // the host never has to drain the stream to learn a metric or a tree).
 struct QrNodesOut {
   int64_t nnodes;
-  int64_t pad[7];
+  int64_t pad[7];   // [0] incomplete, [1] steps, [2] the sequence number the host polls, [3] the header's tag
   qr_node_t nodes[QR_MAXNODES];
 };
+// A record as it crosses to the host: qr_node_t with its four padding bytes (offset 20) carrying a
+// TAG -- a hash of the record's other 44 bytes and of the tree's sequence number.  The host accepts
+// a tree's records only when every tag fits (qr_tree_nodes re-reads until they do): a read-back
+// that validates ITSELF, like the look-back words of the kernels, instead of trusting that the
+// sequence number cannot reach host memory before a record written ahead of it (round 5's hunt met
+// a leaf value that was not the tree's twice in ~170 processes; nothing on the device explains it).
+struct QrNodeWire {
+  int32_t feature, thr_id;
+  float threshold;
+  int32_t left, right;
+  uint32_t tag;
+  double value, deviance;
+  uint64_t nsamples;
+};
+static_assert(sizeof(QrNodeWire) == sizeof(qr_node_t) && sizeof(qr_node_t) == 48, "the wire record is qr_node_t");
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline uint32_t qr_node_tag(const QrNodeWire &r, const uint64_t seq) {
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(&r);
+  uint32_t h = (uint32_t)seq * 0x9E3779B1u + (uint32_t)(seq >> 32) + 0x7F4A7C15u;
+  for (int i = 0; i < 12; ++i) {
+    if (i == 5) continue;  // (the tag's own place)
+    h = (h ^ w[i]) * 0x01000193u;
+    h ^= h >> 15;
+  }
+  return h | 1u;  // never 0: what a block of zeros holds
+}
 struct QrPinned {
   QrScalars scal;
   QrNodesOut tree;
@@ -465,6 +505,7 @@ struct qr_ctx {
   int prep_with_metric = 0, prep_publish = 0;
   int32_t scal_seq = 0;   // of the last launch that publishes the scalars
   int64_t nodes_seq = 0;  // of the last launch that publishes tree records
+  unsigned long long readback_retries = 0;  // records that did not fit their sequence number at first sight
   int64_t early_seq = 0;  // of the last final control call (QrPinned::early)
   bool scal_pending = false, nodes_pending = false;
   size_t cur_maxnodes = 0;

@@ -31,7 +31,8 @@ __device__ __forceinline__ int qr_slot_scale_exp(const unsigned long long lane_w
   return qr_scale_exp(wave_max(__longlong_as_double((long long)lane_word)));
 }
 
-__device__ __forceinline__ void scalars_to_host(QrScalars *__restrict__ host_copy, const QrScalars *__restrict__ scal) {
+__device__ __forceinline__ void scalars_to_host(QrScalars *__restrict__ host_copy, const QrScalars *__restrict__ scal,
+                                                const int seq) {
   host_copy->maxabs_bits = scal->maxabs_bits;
   host_copy->scale_exp = scal->scale_exp;
   host_copy->scale = scal->scale;
@@ -40,6 +41,8 @@ __device__ __forceinline__ void scalars_to_host(QrScalars *__restrict__ host_cop
   host_copy->root_sum = scal->root_sum;
   host_copy->metric_sum = scal->metric_sum;
   host_copy->metric_gsum = scal->metric_gsum;
+  host_copy->tag = qr_scal_tag((unsigned long long)__double_as_longlong(scal->metric_sum),
+                               (unsigned long long)__double_as_longlong(scal->metric_gsum), seq);
 }
 
 // what a prep workgroup needs (kernel argument of k_prep and of k_redscan)
@@ -149,7 +152,7 @@ __device__ __forceinline__ void prep_body(const QrPrepJob &j, const uint32_t bid
     // host block; `pad` = the launch's sequence number, stored LAST behind a system-scope
     // fence: the host polls it (wait_seq_impl in qr_api.hip) instead of waiting for an event
     if (j.host_copy) {
-      scalars_to_host(j.host_copy, scal);
+      scalars_to_host(j.host_copy, scal, (int)j.seq);
       __threadfence_system();
       __hip_atomic_store(&j.host_copy->pad, j.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

@@ -1414,9 +1414,9 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   int &tag = which ? c->long_tag[which] : c->long_tag[0];
   std::vector<uint32_t> &llist = which ? c->h_long_list[1] : c->h_long_list[0];
   std::vector<qr_ctx::QClass> &classes = c->h_qclass[which];
-  // The single launch of a ragged set (k_lambda_u): its three roles carve one dynamic LDS block
-  // per workgroup -- eight packed working sets of up to 128 documents, four of up to 256, or one
-  // query of up to `capC` documents -- sized so that three workgroups share a CU.  Queries
+  // The single launch of a ragged set (k_lambda_u): its roles carve one dynamic LDS block per
+  // workgroup -- eight packed working sets of up to 128 documents, six of up to 256, or one
+  // query of up to `capC` documents -- sized so that two workgroups share a CU.  Queries
   // beyond capC keep their own launches (size class / global scratch) beside it.
   static const int lu_env = [] {
     const char *e = getenv("QR_LAMBDA_UNIFIED");
@@ -1458,10 +1458,12 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   while (capC > kPackBound[0] && lambda_lds(capC, std::min(kacc, capC), false, false) > lu_dyn) capC -= 4;
   bool lu_try = lu_env && !sampled && lu_dyn <= limit && capC > kPackBound[0];
   const int want_tag = (int)nmax_lds + ((int)capC << 16) + (lu_try ? 1 << 30 : 0);
-  if (tag != want_tag) {  // (re)build the classes and the long list for this capacity
+  // (the plan's slices hold `kacc` top ranks: another cutoff is another plan, whatever capC says)
+  if (tag != want_tag || c->lu_kacc[which] != kacc) {  // (re)build the classes and the long list for this capacity
+    c->lu_kacc[which] = kacc;
     std::vector<std::vector<uint32_t>> by(sizeof(kClassBound) / sizeof(kClassBound[0]));
     std::vector<uint32_t> cmax(by.size(), 0);
-    std::vector<uint32_t> role[1 + QR_LU_ROLES];  // 513 .. capC documents together; then the packed roles
+    std::vector<uint32_t> role[1 + QR_LU_ROLES];  // beyond the packed roles, up to capC documents: eight waves together; then the packed roles
     for (int pass = 0; pass < 2; ++pass) {
       llist.clear();
       for (auto &v : by) v.clear();
@@ -1507,7 +1509,7 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
       ulist = role[0];
       P.blocks = P.nC;
       for (int r = 0; r < QR_LU_ROLES; ++r) {
-        const std::vector<uint32_t> &v = role[1 + r];  // role[1] = 257 .. 512 documents, ... role[3] = up to 128
+        const std::vector<uint32_t> &v = role[1 + r];  // role[1 + r]: the queries packed role r holds (largest capacity first)
         P.pk[r].first = (uint32_t)ulist.size();
         P.pk[r].count = (uint32_t)v.size();
         P.pk[r].per = (uint32_t)pk_per[r];

@@ -465,6 +465,7 @@ struct qr_ctx {
   // Mart::update_modelscores left to the next lambda pass (k_tree.hip: qr_k_scores_update)
   bool lazy_scores = false;
   double lazy_shrinkage = 0.0;
+  size_t lu_kacc[2] = {0, 0};  // the top ranks the plan's slices were sized for
   bool lu_ordered[2] = {false, false};
   size_t lu_order_off[2] = {0, 0};
   size_t attr_lambda_u_lds = 64 * 1024;

@@ -910,6 +910,13 @@ def test_ragged_set_single_launch_roles(qr, ora, kind, metric, cutoff, exact_tai
     assert np.allclose(lam, olam, rtol=1e-10, atol=1e-13 * scale)
     assert np.allclose(w, ow, rtol=1e-10, atol=1e-13 * scale)
     assert c.metric_last() == pytest.approx(ora.eval_dataset(labels, scores, qoff, cutoff, m), rel=1e-13)
+    # another cutoff on the SAME context is another plan (the slices hold the top ranks' sums)
+    for cut2 in (cutoff + 2, 5):
+        c.compute_lambdas(metric, cut2)
+        lam2, w2 = c.get_pseudo()
+        ol2, ow2 = ora.lambdas(labels, scores, qoff, cut2, m)
+        sc2 = max(1.0, np.abs(ol2).max())
+        assert np.allclose(lam2, ol2, rtol=1e-10, atol=1e-13 * sc2) and np.allclose(w2, ow2, rtol=1e-10, atol=1e-13 * sc2), cut2
     # the validation set takes the same launch (metric only)
     c.upload_valid(x, labels, qoff)
     c.set_valid_scores(scores)

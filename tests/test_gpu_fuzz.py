@@ -51,11 +51,22 @@ def _assert_fp_tie_is_the_references_rounding(r):
     assert v["exact_ulps_apart"] <= 4.0, r
 
 
+def _report_oracle_reruns(res):
+    """A configuration judged twice because two runs of the ORACLE on the same inputs gave
+    different trees (fuzz_parity.oracle_rerun_differs): reported loudly, and bounded -- the
+    second judgement (fresh oracle run, fresh device run) had to pass like any other."""
+    again = [r for r in res if r.get("oracle_reruns")]
+    for r in again:
+        print("ORACLE NOT REPRODUCIBLE (judged again, passed):", r["desc"], r["oracle_diff"])
+    assert len(again) <= 1, [r["desc"] for r in again]
+
+
 def test_fuzz_sweep_seed0():
     from fuzz_parity import sweep
     from parity_util import TIE_MAX_DOCS
     res = sweep(300, 0, verbose=False)
     assert len(res) == 300
+    _report_oracle_reruns(res)
     cut = {r["i"]: r for r in res if r["status"] != "ok"}
     assert set(cut) == set(KNOWN_ROUNDING_DECIDED), {i: r["desc"] for i, r in cut.items()}
     for i, r in cut.items():
@@ -92,6 +103,7 @@ def test_fuzz_sweep_more_seeds_divergence_rate(seed):
     n = 200
     res = sweep(n, seed, verbose=False)
     assert len(res) == n
+    _report_oracle_reruns(res)
     kinds = {}
     for r in res:
         kinds[r["status"]] = kinds.get(r["status"], 0) + 1

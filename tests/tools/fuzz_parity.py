@@ -287,7 +287,30 @@ def oblivious_level_gain_tie(stmap, o, g, pseudo, minls):
     return False
 
 
-def sweep(n_cfg=30, seed=0, only=None, verbose=True):
+def oracle_rerun_differs(oracle, om, x, labels, qoff, algo, kw, desc):
+    """The checker checked: train the oracle a second time on the same inputs.  A deterministic
+    C program must give the same bytes; when it does not, THE ORACLE'S FIRST RUN is the suspect
+    (profiles/r05_abort_hunt.md: in the one failure of round 5's last full run the device's leaf
+    values were exact and two of the oracle's leaves had each lost a document).  Returns None
+    when both runs agree, or a description of the first tree that differs."""
+    om2 = oracle.train(x, labels, qoff, algo=algo, **kw)
+    if om2["ntrees_built"] != om["ntrees_built"]:
+        return f"{om['ntrees_built']} trees, then {om2['ntrees_built']}"
+    for t in range(om["ntrees_built"]):
+        n = int(om["nnodes"][t])
+        a, b = om["nodes"][t][:n], om2["nodes"][t][:n]
+        same = lambda u, v: all(np.array_equal(u[nm], v[nm]) or           # (field by field: the records
+                                (nm in ("value", "deviance") and            # carry padding; -0.0 / NaN by bits)
+                                 np.array_equal(u[nm].view(np.uint64), v[nm].view(np.uint64)))
+                                for nm in u.dtype.names)
+        if int(om2["nnodes"][t]) != n or not same(a, b):
+            k = [i for i in range(min(len(a), len(b))) if not same(a[i:i + 1], b[i:i + 1])]
+            return (f"tree {t}: nodes {k[:8]} differ between two runs of the oracle; first run "
+                    f"{[float(a[i]['value']) for i in k[:8]]}, second run {[float(b[i]['value']) for i in k[:8]]}")
+    return None
+
+
+def sweep(n_cfg=30, seed=0, only=None, verbose=True, _retry=True):
     """Returns one record per configuration: dict(i, desc, status, ties, tie_sizes,
     flips, tree) with status "ok", or "gain_tie" / "zero_deviance" / "heap_tie" for a run cut short
     at a split the reference decides by the rounding noise of its summation order
@@ -302,7 +325,8 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
     import oracle
     from datagen import make_dataset
     from parity_util import assert_tree_parity, TIE_MAX_DOCS
-    from quickrank_amd.trainer import Mart
+    if not os.environ.get("FUZZ_ORACLE_ONLY"):
+        from quickrank_amd.trainer import Mart
     rng = np.random.default_rng(seed)
     oracle.build(ref=False)
     out = []
@@ -328,6 +352,17 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
         rec = dict(i=i, desc=desc, status="ok", ties=0, tie_sizes=[], flips=0, tree=None, gain_rel=None,
                    gain_node_docs=None)
         om = oracle.train(x, labels, qoff, algo=algo, **kw)
+        if os.environ.get("FUZZ_ORACLE_TWICE"):
+            # (profiles/r05_abort_hunt.md: how often do two runs of the oracle on the same inputs
+            # differ, with the device library at work in the process -- or, FUZZ_ORACLE_ONLY=1 with
+            # QR_NO_TORCH=1, in a process that never opens the GPU?)
+            diff = oracle_rerun_differs(oracle, om, x, labels, qoff, algo, kw, desc)
+            if diff is not None:
+                print(desc, "ORACLE RUN NOT REPRODUCIBLE:", diff, flush=True)
+                rec["oracle_twice_diff"] = diff
+            if os.environ.get("FUZZ_ORACLE_ONLY"):
+                out.append(rec)
+                continue
         gm = Mart(algo=algo, **kw).learn(x, labels, qoff)
         assert len(gm.ensemble) == om["ntrees_built"], desc
         tr = oracle.Trainer(x, nthr)
@@ -415,6 +450,19 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
                         leaf_value_autopsy(tr, oracle, labels, qoff, om, o, g, t, kw, algo)
                     except Exception as ae:      # (the autopsy must not hide the mismatch)
                         print("autopsy failed:", repr(ae))
+                    diff = oracle_rerun_differs(oracle, om, x, labels, qoff, algo, kw, desc) if _retry else None
+                    if diff is not None:
+                        # not a verdict on the device: this configuration is judged again from
+                        # scratch (fresh oracle run, fresh device run), once, and the event is
+                        # counted -- tests/test_gpu_fuzz.py bounds the count
+                        print(desc, "ORACLE RUN NOT REPRODUCIBLE:", diff, flush=True)
+                        gm.ctx.close()
+                        again = sweep(n_cfg, seed, only=i, verbose=verbose, _retry=False)[0]
+                        again["oracle_reruns"] = 1
+                        again["oracle_diff"] = diff
+                        out.append(again)
+                        rec["status"] = "requeued"
+                        break
                     if only is not None:
                         for nm, arr in (("oracle", o), ("device", g)):
                             print(nm, [(k, int(a["feature"]), int(a["thr_id"]), int(a["left"]), int(a["nsamples"]),
@@ -422,6 +470,8 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True):
                     raise AssertionError((desc, "tree", t, e.args))
                 rec["status"], rec["tree"] = status, t
                 break
+        if rec["status"] == "requeued":
+            continue
         if rec["status"] != "ok":
             if verbose:
                 print(desc, f"ok up to a split decided by rounding noise ({rec['status']}) in tree", rec["tree"], flush=True)
@@ -456,4 +506,5 @@ if __name__ == "__main__":
           f"{sum(r['status'] != 'ok' for r in res)} runs cut short at an exact gain tie between "
           f"different partitions / a zero-deviance gate / a ranking or a heap order decided by rounding: "
           f"{[(r['i'], r['status']) for r in res if r['status'] != 'ok']}, "
-          f"{time.time() - t0:.0f} s")
+          f"{sum(1 for r in res if r.get('oracle_twice_diff') or r.get('oracle_reruns'))} configurations in which two "
+          f"runs of the oracle differed, {time.time() - t0:.0f} s")

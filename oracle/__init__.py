@@ -146,6 +146,8 @@ def lib():
     L.qro_oblivious_score.argtypes = [u32p, f32p, f64p, f32p, sz, sz, f32p, sz,
                                       sz, f64p]
     L.qro_set_threads.argtypes = [C.c_int]
+    L.qro_self_check.argtypes = [C.c_char_p, sz]
+    L.qro_self_check.restype = C.c_int
     L.qro_heap_trace.argtypes = [f64p, i32p, sz, sz, i32p, u64p]
     L.qro_sym_index.argtypes = [sz, u64p]
     _LIB = L
@@ -289,6 +291,7 @@ class Trainer:
                                          nodes.ctypes.data, leaf_of_doc,
                                          leaf_nodes, C.byref(nl),
                                          log.ctypes.data, C.byref(ns))
+        self_check("fit_tree")
         return dict(nodes=nodes[:nn], leaf_of_doc=leaf_of_doc,
                     leaf_nodes=leaf_nodes[:nl.value], splits=log[:ns.value])
 
@@ -301,10 +304,23 @@ class Trainer:
         ln = np.ascontiguousarray(tree["leaf_nodes"], np.int32)
         lib().qro_update_output(tree["nodes"].ctypes.data, ln, len(ln),
                                 tree["leaf_of_doc"], self.N, pseudo, w)
+        self_check("update_output")
 
     def update_scores(self, tree, shrinkage, scores):
         lib().qro_update_scores(tree["nodes"].ctypes.data, self.col, self.N,
                                 self.F, 1, shrinkage, scores)
+
+
+class SelfCheckError(RuntimeError):
+    """Two views the oracle holds of one fact disagreed during the call (qr_oracle.c, top):
+    host memory changed under the run.  The result is not a verdict on anything."""
+
+
+def self_check(what):
+    buf = C.create_string_buffer(1024)
+    n = lib().qro_self_check(buf, len(buf))
+    if n:
+        raise SelfCheckError(f"oracle self-check, {what}: {n} event(s); first: {buf.value.decode(errors='replace')}")
 
 
 ALGOS = {"MART": 0, "LAMBDAMART": 1, "OBVMART": 2, "OBVLAMBDAMART": 3}
@@ -349,6 +365,7 @@ def train(rowmajor, labels, qoff, algo="LAMBDAMART", ntrees=10, shrinkage=0.1,
         thr_size=np.ctypeslib.as_array(m.thr_size, (F,)).copy(),
         best_model=m.best_model, shrinkage=shrinkage)
     lib().qro_model_free(C.byref(m))
+    self_check("train")
     return res
 
 

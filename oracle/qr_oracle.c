@@ -18,6 +18,45 @@
 #include <omp.h>
 #endif
 
+/* ========================================================================== */
+/* Self-checks.  The oracle is the judge of the device's results, so it checks */
+/* its own state where the algorithm gives it two views of one fact (a child's  */
+/* document count from the histogram vs the length of its sample list; a leaf's */
+/* count vs the documents mapped to it).  A disagreement is not a property of   */
+/* the algorithm: it means host memory changed under the run                    */
+/* (profiles/r05_abort_hunt.md).  It is recorded here, the stores that would    */
+/* leave their buffers are skipped, and oracle/__init__.py raises on it.        */
+/* ========================================================================== */
+#include <stdio.h>
+static int qro_events_n = 0;
+static char qro_events_msg[1024];
+static void qro_event(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+#include <stdarg.h>
+static void qro_event(const char *fmt, ...) {
+#pragma omp critical(qro_event_log)
+  {
+    if (qro_events_n++ == 0) {
+      va_list ap;
+      va_start(ap, fmt);
+      vsnprintf(qro_events_msg, sizeof(qro_events_msg), fmt, ap);
+      va_end(ap);
+    }
+  }
+}
+/* number of self-check events since the last call (and the first one's text) */
+int qro_self_check(char *msg, size_t n) {
+  const int k = qro_events_n;
+  if (msg && n) {
+    msg[0] = 0;
+    if (k) {
+      strncpy(msg, qro_events_msg, n - 1);
+      msg[n - 1] = 0;
+    }
+  }
+  qro_events_n = 0;
+  return k;
+}
+
 void qro_set_threads(int n) {
 #ifdef _OPENMP
   if (n > 0) omp_set_num_threads(n);
@@ -675,6 +714,42 @@ static void live_free(live_t *lv) {
   lv->hcount = NULL;
 }
 
+/* A child's sample list is sized by the histogram's count and filled by the raw
+ * comparison (rt.cc:314-332 does the same): the two agree by construction of the
+ * bin map.  When they do not, say which documents and which of the two views moved. */
+static void partition_mismatch(const qro_train_data_t *d, const live_t *lv, int32_t node,
+                               size_t bf, size_t bt, float thr, uint64_t lcount,
+                               uint64_t rcount, size_t lsize, size_t rsize) {
+  char who[512];
+  size_t off = 0, shown = 0;
+  who[0] = 0;
+  const float *x = d->colmajor + bf * d->N;
+  for (size_t i = 0; i < lv->ns && shown < 4; ++i) {
+    const uint64_t s = lv->samples[i];
+    if (s >= d->N) {
+      off += (size_t)snprintf(who + off, sizeof(who) - off, " list[%zu]=%llu out of range;", i,
+                              (unsigned long long)s);
+      ++shown;
+      continue;
+    }
+    const int raw = x[s] <= thr, bin = d->stmap[bf * d->N + s] <= bt;
+    if (raw != bin) {
+      uint32_t xb;
+      memcpy(&xb, &x[s], 4);
+      off += (size_t)snprintf(who + off, sizeof(who) - off, " doc %llu: x bits %08x slot %u;",
+                              (unsigned long long)s, xb, d->stmap[bf * d->N + s]);
+      ++shown;
+    }
+    if (off >= sizeof(who)) break;
+  }
+  uint32_t tb;
+  memcpy(&tb, &thr, 4);
+  qro_event("split of node %d at feature %zu slot %zu (threshold bits %08x): the histogram counts "
+            "%llu | %llu documents, the raw comparison over the node's list of %zu sends %zu | %zu;%s",
+            (int)node, bf, bt, tb, (unsigned long long)lcount, (unsigned long long)rcount, lv->ns,
+            lsize, rsize, shown ? who : " every listed document agrees with its slot (the list itself changed)");
+}
+
 /* RegressionTree::split, rt.cc:209-362 (max_features == 1) */
 static int tree_split(const qro_train_data_t *d, const double *labels,
                       uint64_t minls, qro_node_t *nodes, live_t *live,
@@ -695,10 +770,19 @@ static int tree_split(const qro_train_data_t *d, const double *labels,
   const float *x = d->colmajor + bf * d->N;
   for (size_t i = 0; i < lv->ns; ++i) {
     const uint64_t s = lv->samples[i];
-    if (x[s] <= best_threshold)
-      ls[lsize++] = s;
-    else
-      rs[rsize++] = s;
+    if (s >= d->N) continue; /* (self-check below) */
+    if (x[s] <= best_threshold) {
+      if (lsize < lcount) ls[lsize] = s;
+      ++lsize;
+    } else {
+      if (rsize < rcount) rs[rsize] = s;
+      ++rsize;
+    }
+  }
+  if (lsize != lcount || rsize != rcount) {
+    partition_mismatch(d, lv, node, bf, bt, best_threshold, lcount, rcount, lsize, rsize);
+    if (lsize > lcount) lsize = lcount;
+    if (rsize > rcount) rsize = rcount;
   }
   const size_t hs = d->F * d->cap;
   const int32_t li = (int32_t)(*nnodes), ri = li + 1;
@@ -793,7 +877,18 @@ size_t qro_tree_fit(const qro_train_data_t *d, const double *labels,
   for (size_t i = 0; i < d->N; ++i) leaf_of_doc[i] = -1;
   for (size_t l = 0; l < nl; ++l) {
     const live_t *lv = &live[leaf_nodes[l]];
-    for (size_t i = 0; i < lv->ns; ++i) leaf_of_doc[lv->samples[i]] = (int32_t)l;
+    if (lv->ns != nodes[leaf_nodes[l]].nsamples)
+      qro_event("leaf node %d: the histogram counts %llu documents, its list holds %zu",
+                (int)leaf_nodes[l], (unsigned long long)nodes[leaf_nodes[l]].nsamples, lv->ns);
+    for (size_t i = 0; i < lv->ns; ++i) {
+      const uint64_t s = lv->samples[i];
+      if (s >= d->N || leaf_of_doc[s] != -1) { /* a list entry that is not this leaf's own */
+        qro_event("leaf node %d: list[%zu] = %llu is %s", (int)leaf_nodes[l], i, (unsigned long long)s,
+                  s >= d->N ? "out of range" : "a document another leaf's list holds too");
+        continue;
+      }
+      leaf_of_doc[s] = (int32_t)l;
+    }
   }
   for (size_t i = 0; i < nnodes; ++i) {
     free(live[i].samples);
@@ -900,10 +995,19 @@ size_t qro_oblivious_fit(const qro_train_data_t *d, const double *labels,
       size_t lsize = 0, rsize = 0;
       for (size_t j = 0; j < lv->ns; ++j) {
         const uint64_t k = lv->samples[j];
-        if (x[k] <= best_threshold)
-          ls[lsize++] = k;
-        else
-          rs[rsize++] = k;
+        if (k >= d->N) continue; /* (self-check below) */
+        if (x[k] <= best_threshold) {
+          if (lsize < lcount) ls[lsize] = k;
+          ++lsize;
+        } else {
+          if (rsize < rcount) rs[rsize] = k;
+          ++rsize;
+        }
+      }
+      if (lsize != lcount || rsize != rcount) {
+        partition_mismatch(d, lv, (int32_t)i, bf, bt, best_threshold, lcount, rcount, lsize, rsize);
+        if (lsize > lcount) lsize = lcount;
+        if (rsize > rcount) rsize = rcount;
       }
       const size_t li = 2 * i + 1, ri = 2 * i + 2;
       live_t *ll = &live[li], *rl = &live[ri];
@@ -948,7 +1052,18 @@ size_t qro_oblivious_fit(const qro_train_data_t *d, const double *labels,
   for (size_t i = 0; i < d->N; ++i) leaf_of_doc[i] = -1;
   for (size_t l = 0; l < nl; ++l) {
     const live_t *lv = &live[leaf_nodes[l]];
-    for (size_t i = 0; i < lv->ns; ++i) leaf_of_doc[lv->samples[i]] = (int32_t)l;
+    if (lv->ns != nodes[leaf_nodes[l]].nsamples)
+      qro_event("leaf node %d: the histogram counts %llu documents, its list holds %zu",
+                (int)leaf_nodes[l], (unsigned long long)nodes[leaf_nodes[l]].nsamples, lv->ns);
+    for (size_t i = 0; i < lv->ns; ++i) {
+      const uint64_t s = lv->samples[i];
+      if (s >= d->N || leaf_of_doc[s] != -1) { /* a list entry that is not this leaf's own */
+        qro_event("leaf node %d: list[%zu] = %llu is %s", (int)leaf_nodes[l], i, (unsigned long long)s,
+                  s >= d->N ? "out of range" : "a document another leaf's list holds too");
+        continue;
+      }
+      leaf_of_doc[s] = (int32_t)l;
+    }
   }
   size_t used = 0;
   for (size_t i = 0; i < maxnodes; ++i) {
@@ -980,6 +1095,9 @@ void qro_update_output(qro_node_t *nodes, const int32_t *leaf_nodes,
   }
   for (size_t l = 0; l < nleaves; ++l) {
     qro_node_t *nd = &nodes[leaf_nodes[l]];
+    if (cn[l] != nd->nsamples)
+      qro_event("leaf node %d: the histogram counts %llu documents, %llu are mapped to it",
+                (int)leaf_nodes[l], (unsigned long long)nd->nsamples, (unsigned long long)cn[l]);
     if (weights)
       nd->value = s2[l] >= DBL_EPSILON ? s1[l] / s2[l] : 0.0;
     else

@@ -200,6 +200,10 @@ void qro_oblivious_score(const uint32_t *feat, const float *thr,
 
 void qro_set_threads(int n);
 
+/* Self-checks (qr_oracle.c, top): how many times since the last call two views the
+ * oracle holds of one fact disagreed (0 in every healthy run), and the first one's text. */
+int qro_self_check(char *msg, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

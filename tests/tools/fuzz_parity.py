@@ -351,7 +351,14 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True, _retry=True):
                 + (" adv" if adversarial else ""))
         rec = dict(i=i, desc=desc, status="ok", ties=0, tie_sizes=[], flips=0, tree=None, gain_rel=None,
                    gain_node_docs=None)
-        om = oracle.train(x, labels, qoff, algo=algo, **kw)
+        try:
+            om = oracle.train(x, labels, qoff, algo=algo, **kw)
+        except oracle.SelfCheckError as e:
+            # the oracle caught itself (qr_oracle.c "Self-checks"): host memory changed under its
+            # run.  Reported, counted like a run that a second one contradicts, and run again.
+            print(desc, "ORACLE RUN NOT REPRODUCIBLE:", e, flush=True)
+            rec["oracle_reruns"], rec["oracle_diff"] = 1, str(e)
+            om = oracle.train(x, labels, qoff, algo=algo, **kw)
         if os.environ.get("FUZZ_ORACLE_TWICE"):
             # (profiles/r05_abort_hunt.md: how often do two runs of the oracle on the same inputs
             # differ, with the device library at work in the process -- or, FUZZ_ORACLE_ONLY=1 with

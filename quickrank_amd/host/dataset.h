@@ -24,9 +24,19 @@ class Dataset {
  public:
   Dataset(size_t n_instances, size_t n_features)
       : max_instances_(n_instances), num_features_(n_features),
-        data_(n_instances * n_features, 0.0f), labels_(n_instances, 0.0f) {
+        data_((Feature *)calloc(std::max<size_t>(n_instances * n_features, 1), sizeof(Feature))),
+        labels_(n_instances, 0.0f) {
+    // (calloc: the zero pages of a large matrix are first touched by whoever fills the rows --
+    // the parallel SVMLight reader -- instead of being written once here by one thread)
+    if (!data_) {
+      std::cerr << "!!! Impossible to allocate the dataset." << std::endl;
+      exit(EXIT_FAILURE);
+    }
     offsets_.push_back(0);
   }
+  ~Dataset() { free(data_); }
+  Dataset(const Dataset &) = delete;
+  Dataset &operator=(const Dataset &) = delete;
 
   // dataset.cc:63-87
   void addInstance(QueryID q_id, Label i_label, const std::vector<Feature> &i_features) {
@@ -35,7 +45,7 @@ class Dataset {
       exit(EXIT_FAILURE);
     }
     labels_[num_instances_] = i_label;
-    Feature *row = data_.data() + num_instances_ * num_features_;
+    Feature *row = data_ + num_instances_ * num_features_;
     for (size_t i = 0; i < i_features.size(); i++) row[i] = i_features[i];
     if (num_instances_ == 0 || last_instance_id_ != q_id) {
       num_queries_++;
@@ -62,8 +72,8 @@ class Dataset {
     num_instances_ = std::min(qids.size(), max_instances_);
   }
 
-  Feature *at(size_t doc, size_t f) { return data_.data() + doc * num_features_ + f; }
-  const Feature *at(size_t doc, size_t f) const { return data_.data() + doc * num_features_ + f; }
+  Feature *at(size_t doc, size_t f) { return data_ + doc * num_features_ + f; }
+  const Feature *at(size_t doc, size_t f) const { return data_ + doc * num_features_ + f; }
   Label getLabel(size_t doc) const { return labels_[doc]; }
   const Label *labels() const { return labels_.data(); }
   size_t offset(size_t q) const { return offsets_[q]; }
@@ -76,7 +86,7 @@ class Dataset {
   size_t max_instances_, num_features_;
   size_t num_queries_ = 0, num_instances_ = 0;
   QueryID last_instance_id_ = 0;
-  std::vector<Feature> data_;
+  Feature *data_;
   std::vector<Label> labels_;
   std::vector<uint64_t> offsets_;
 };

@@ -1,5 +1,8 @@
 // host_capi.cc -- C shims over the host classes for the (CPU-side) tests of the
 // SVMLight reader and the XML model round trip; no device calls here.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "codegen.h"
@@ -32,6 +35,92 @@ int qrh_svml_read(const char *path, size_t *N, size_t *F, size_t *Q, float *x, f
   if (labels) memcpy(labels, ds->labels(), *N * sizeof(float));
   if (qoff) memcpy(qoff, ds->offsets().data(), (*Q + 1) * sizeof(uint64_t));
   return 0;
+}
+
+// Test hooks for io::parse_float (the reader's number conversion) against strtof itself:
+// `texts` holds n NUL-terminated strings back to back; returns how many differ in value bits or
+// in the end pointer, the index of the first in *first_bad.
+size_t qrh_parse_float_check(const char *texts, size_t n, size_t *first_bad) {
+  size_t bad = 0;
+  const char *p = texts;
+  for (size_t i = 0; i < n; ++i) {
+    char *a1, *a2;
+    const float u = io::parse_float(p, &a1), v = strtof(p, &a2);
+    if (memcmp(&u, &v, 4) != 0 || a1 != a2) {
+      if (!bad++ && first_bad) *first_bad = i;
+    }
+    p += strlen(p) + 1;
+  }
+  return bad;
+}
+// ... and on texts made here: every "0.dddddd" (the usual look of a LETOR value), then `n` random
+// floats printed as %.9f (the writer's format), %.9g, %e, %.17g of a nearby double, and with 1..25
+// random digits and exponents.  Returns the number of disagreements.
+size_t qrh_parse_float_selftest(uint64_t seed, size_t n, char *first_bad, size_t first_bad_len) {
+  size_t bad = 0;
+  char buf[128];
+  auto check = [&](const char *t) {
+    char *a1, *a2;
+    const float u = io::parse_float(t, &a1), v = strtof(t, &a2);
+    if (memcmp(&u, &v, 4) != 0 || a1 != a2) {
+      if (!bad++ && first_bad && first_bad_len) {
+        strncpy(first_bad, t, first_bad_len - 1);
+        first_bad[first_bad_len - 1] = 0;
+      }
+    }
+  };
+  for (unsigned k = 0; k < 1000000; ++k) {
+    snprintf(buf, sizeof buf, "0.%06u", k);
+    check(buf);
+  }
+  uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+  auto next = [&]() {
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    return x;
+  };
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t bits = (uint32_t)next();
+    if (((bits >> 23) & 0xFF) == 0xFF) bits &= 0x7F7FFFFFu;  // finite
+    float f;
+    memcpy(&f, &bits, 4);
+    snprintf(buf, sizeof buf, "%.9f", (double)f);
+    if (strlen(buf) < 60) check(buf);
+    snprintf(buf, sizeof buf, "%.9g", (double)f);
+    check(buf);
+    snprintf(buf, sizeof buf, "%e", (double)f);
+    check(buf);
+    // a double next to a float midpoint, printed exactly enough to land on either side
+    float g;
+    uint32_t b2 = bits + 1;
+    memcpy(&g, &b2, 4);
+    const double mid = ((double)f + (double)g) * 0.5;
+    snprintf(buf, sizeof buf, "%.17g", mid);
+    check(buf);
+    snprintf(buf, sizeof buf, "%.17g", nextafter(mid, 1e300));
+    check(buf);
+    snprintf(buf, sizeof buf, "%.16g", nextafter(mid, -1e300));
+    check(buf);
+    // random digit strings: 1..25 digits, a point somewhere, sometimes an exponent, sometimes junk behind
+    int nd = 1 + (int)(next() % 25), pt = (int)(next() % (unsigned)(nd + 2)) - 1, o = 0;
+    if (next() % 4 == 0) buf[o++] = next() % 2 ? '-' : '+';
+    for (int d = 0; d < nd; ++d) {
+      if (d == pt) buf[o++] = '.';
+      buf[o++] = (char)('0' + next() % 10);
+    }
+    if (pt == nd) buf[o++] = '.';
+    switch (next() % 6) {
+      case 0: o += snprintf(buf + o, 16, "e%d", (int)(next() % 80) - 40); break;
+      case 1: o += snprintf(buf + o, 16, "E+%d", (int)(next() % 12)); break;
+      case 2: buf[o++] = 'e'; break;
+      case 3: buf[o++] = 'x'; buf[o++] = '1'; break;
+      default: break;
+    }
+    buf[o] = 0;
+    check(buf);
+  }
+  return bad;
 }
 
 int qrh_svml_write(const char *path, const float *x, const float *labels, const uint64_t *qoff,

@@ -30,7 +30,9 @@
 #include "svml.h"
 
 #include <omp.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -45,6 +47,84 @@ namespace {
 inline bool blank(char ch) {
   return ch == ' ' || ch == '\t' || ch == '\n' || ch == '\v' || ch == '\f' || ch == '\r';
 }
+
+}  // namespace
+
+// strtof, faster where the answer is certain.  A plain decimal ("[+-]digits[.digits][e[+-]digits]",
+// at most 19 significant digits) is converted with ONE correctly rounded operation:
+//   * mantissa below 2^24 and |decimal exponent| <= 10: both operands are exact floats, a single
+//     float multiplication / division rounds once -- the correctly rounded result (Clinger 1990);
+//   * mantissa below 2^53 and |decimal exponent| <= 22: the same in double; narrowing to float
+//     rounds a second time, which changes the answer only if the double is EXACTLY half way
+//     between two floats (every such midpoint is a double, and rounding to double is monotonic,
+//     so any other double lies on the text's side of every midpoint) -- those, and results
+//     outside the normal float range, go to strtof;
+// everything else (longer mantissas, larger exponents, "inf", "nan", hex floats, no digits) goes to
+// strtof as well.  `after` is set as strtof sets it: behind the longest valid prefix, an exponent
+// marker without digits not included.  tests/test_host_cpu.py compares the two on millions of texts.
+float parse_float(const char *s, char **after) {
+  static const float p10f[] = {1e0f, 1e1f, 1e2f, 1e3f, 1e4f, 1e5f, 1e6f, 1e7f, 1e8f, 1e9f, 1e10f};
+  static const double p10d[] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  const char *p = s;
+  bool neg = false;
+  if (*p == '-' || *p == '+') neg = *p++ == '-';
+  uint64_t m = 0;
+  int sig = 0, ndig = 0, e10 = 0;
+  bool leading = true;
+  for (; *p >= '0' && *p <= '9'; ++p, ++ndig) {
+    if (leading && *p == '0') continue;
+    leading = false;
+    if (++sig > 19) return strtof(s, after);
+    m = m * 10 + (uint64_t)(*p - '0');
+  }
+  if (*p == '.') {
+    ++p;
+    for (; *p >= '0' && *p <= '9'; ++p, ++ndig) {
+      if (leading && *p == '0') {
+        --e10;
+        continue;
+      }
+      leading = false;
+      if (++sig > 19) return strtof(s, after);
+      m = m * 10 + (uint64_t)(*p - '0');
+      --e10;
+    }
+  }
+  if (ndig == 0) return strtof(s, after);  // "inf", "nan", ".", junk: not ours to judge
+  if (*p == 'e' || *p == 'E') {
+    const char *q = p + 1;
+    bool eneg = false;
+    if (*q == '-' || *q == '+') eneg = *q++ == '-';
+    if (*q >= '0' && *q <= '9') {
+      int e = 0;
+      for (; *q >= '0' && *q <= '9'; ++q)
+        if (e < 100000) e = e * 10 + (*q - '0');
+      e10 += eneg ? -e : e;
+      p = q;
+    }
+  } else if ((*p == 'x' || *p == 'X') && ndig == 1 && p[-1] == '0') {
+    return strtof(s, after);  // hexadecimal float
+  }
+  *after = const_cast<char *>(p);
+  if (m == 0) return neg ? -0.0f : 0.0f;
+  if (m < (1ull << 24) && e10 >= -10 && e10 <= 10) {
+    const float f = e10 < 0 ? (float)m / p10f[-e10] : (float)m * p10f[e10];
+    return neg ? -f : f;
+  }
+  if (m < (1ull << 53) && e10 >= -22 && e10 <= 22) {
+    const double d = e10 < 0 ? (double)m / p10d[-e10] : (double)m * p10d[e10];
+    uint64_t bits;
+    memcpy(&bits, &d, 8);
+    if (d >= 1e-37 && d <= 1e38 && (bits & 0x1FFFFFFFull) != 0x10000000ull) {
+      const float f = (float)d;
+      return neg ? -f : f;
+    }
+  }
+  return strtof(s, after);
+}
+
+namespace {
 
 // everything one thread extracted from its share of the file
 struct Piece {
@@ -115,7 +195,7 @@ int parse_line(const char *b, const char *e, Piece &out) {
     ++s;
     if (s == stop) return 4;  // "id:" with nothing behind it
     char *after;
-    const float v = strtof(s, &after);  // cannot run past `stop`: blanks and '#' end a number
+    const float v = parse_float(s, &after);  // cannot run past `stop`: blanks and '#' end a number
     if (after == s) return 4;
     out.fid.push_back((unsigned)id);
     out.val.push_back(v);
@@ -146,18 +226,40 @@ void parse_range(const char *base, size_t lo, size_t hi, Piece &out) {
 }  // namespace
 
 std::unique_ptr<data::Dataset> Svml::read_horizontal(const std::string &filename) {
-  FILE *f = fopen(filename.c_str(), "rb");
-  if (!f) {
+  const int fd = open(filename.c_str(), O_RDONLY);
+  if (fd < 0) {
     std::cerr << "!!! Error while opening file " << filename << "." << std::endl;
     exit(EXIT_FAILURE);
   }
   struct stat st;
-  stat(filename.c_str(), &st);
+  fstat(fd, &st);
   stats_.bytes = st.st_size;
   const auto t0 = std::chrono::high_resolution_clock::now();
-  std::vector<char> text((size_t)stats_.bytes + 1);
-  const size_t got = fread(text.data(), 1, (size_t)stats_.bytes, f);
-  fclose(f);
+  // the whole text in memory, read by all threads at once (pread: no shared file position),
+  // into a buffer nobody clears first
+  std::unique_ptr<char[]> text(new char[(size_t)stats_.bytes + 1]);
+  size_t got = (size_t)stats_.bytes;
+  {
+    const size_t share = 64u << 20;
+    const long nshare = (long)((got + share - 1) / share);
+    size_t short_at = got;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long k = 0; k < nshare; ++k) {
+      size_t at = (size_t)k * share;
+      const size_t hi = std::min(got, at + share);
+      while (at < hi) {
+        const ssize_t n = pread(fd, text.get() + at, hi - at, (off_t)at);
+        if (n <= 0) {  // the file shrank under us: what was read up to here is the file
+#pragma omp critical(svml_short_read)
+          short_at = std::min(short_at, at);
+          break;
+        }
+        at += (size_t)n;
+      }
+    }
+    got = short_at;
+  }
+  close(fd);
   text[got] = '\0';  // strtod / strtof may look one byte past the last token
 
   int nthreads = omp_get_max_threads();
@@ -167,12 +269,12 @@ std::unique_ptr<data::Dataset> Svml::read_horizontal(const std::string &filename
   for (int t = 1; t < nthreads; ++t) {  // chunk borders on line starts
     size_t at = got / nthreads * t;
     if (at < cut[t - 1]) at = cut[t - 1];
-    const char *nl = (const char *)memchr(text.data() + at, '\n', got - at);
-    cut[t] = nl ? (size_t)(nl - text.data()) + 1 : got;
+    const char *nl = (const char *)memchr(text.get() + at, '\n', got - at);
+    cut[t] = nl ? (size_t)(nl - text.get()) + 1 : got;
   }
   std::vector<Piece> pieces(nthreads);
 #pragma omp parallel for num_threads(nthreads) schedule(static, 1)
-  for (int t = 0; t < nthreads; ++t) parse_range(text.data(), cut[t], cut[t + 1], pieces[t]);
+  for (int t = 0; t < nthreads; ++t) parse_range(text.get(), cut[t], cut[t + 1], pieces[t]);
   // the reference stops at the FIRST malformed line of the file
   for (const Piece &p : pieces)
     if (p.bad_code) exit(p.bad_code);

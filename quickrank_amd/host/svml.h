@@ -10,6 +10,9 @@
 namespace quickrank {
 namespace io {
 
+// strtof's result and end pointer, by a shorter way where that is certain to agree (svml.cc)
+float parse_float(const char *s, char **after);
+
 class Svml {
   // seconds spent parsing the text / filling the dense matrix, bytes of the file
   struct Stats {

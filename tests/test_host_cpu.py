@@ -73,6 +73,31 @@ def test_svml_reader_matches_reference(host, oracle_lib, tmp_path):
     assert np.allclose(rx, x, rtol=0, atol=1e-9) and np.array_equal(rl, labels) and np.array_equal(rq, qoff)
 
 
+def test_number_conversion_is_strtofs(host):
+    """sscanf("%f") (svml.cc:111) rounds the text to the nearest float: strtof.  The reader's
+    `parse_float` takes a shorter way where the result is certain (one exactly rounded float or
+    double operation, Clinger's fast path, with the double-rounding midpoints sent to strtof) and
+    must agree with strtof in value bits AND in where the number ends -- on every 0.dddddd, on
+    random floats in the writer's %.9f and in %g / %e, on doubles at and next to the midpoints
+    between adjacent floats, on random digit strings with exponents, junk and hex prefixes."""
+    sz = C.c_size_t
+    host.qrh_parse_float_selftest.argtypes = [C.c_uint64, sz, C.c_char_p, sz]
+    host.qrh_parse_float_selftest.restype = sz
+    first = C.create_string_buffer(128)
+    assert host.qrh_parse_float_selftest(7, 150000, first, len(first)) == 0, first.value
+    texts = ["16777217", "16777217.0000001", "16777216.9999999", "33554434", "33554435", "0.1", "-0.0", "+.5", "5.",
+             "1e", "1e+", "1.e5", ".e5", "0x1p3", "0x", "inf", "nan", "infinity", "-inf", "1e38", "3.5e38", "1e-45",
+             "1.17549435e-38", "1.17549428e-38", "00000000000000000000123.4500", "9007199254740993", "9007199254740992e3",
+             "4.35", "0.000001", "123456789012345678", "1234567890123456789", "12345678901234567890", "1.5abc", "7#x",
+             "8388608.5", "8388609.5", "1.00000005960464477539062", "1.00000005960464477539063", "1.0000000596046447",
+             "", ".", "-", "e5", "2.5e-5:", "99999999e-8", "16777215e10", "16777215e11", "1e22", "1e23"]
+    buf = b"".join(t.encode() + b"\0" for t in texts)
+    host.qrh_parse_float_check.argtypes = [C.c_char_p, sz, C.POINTER(sz)]
+    host.qrh_parse_float_check.restype = sz
+    bad = sz(0)
+    assert host.qrh_parse_float_check(buf, len(texts), C.byref(bad)) == 0, texts[bad.value]
+
+
 def test_svml_reader_standalone(host, tmp_path):
     p = str(tmp_path / "a.svml")
     open(p, "w").write(SVML_TEXT)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """SURVEY section 8 row f2 at the measurement bar: the SVMLight reader either side of the hot path.
 
-    python scripts/svml_bench.py [--docs 200000] [--features 136] [--repeat 3] [--md profiles/rNN_svml_reader.md]
+    python tests/tools/svml_bench.py [--docs 200000] [--features 136] [--repeat 3] [--md profiles/rNN_svml_reader.md]
 
 Writes an MSLR-shaped file (100-document queries, every feature present, %.6f values, a `#docid`
 trailer on every tenth line), then times
@@ -9,8 +9,8 @@ trailer on every tenth line), then times
   * the same with one thread (what the grammar costs, without the chunking);
   * the reference's own reader (svml.cc:38-161: getline + sscanf, serial), through oracle/_ref --
     only where /root/reference exists (the build container); elsewhere the line is left out.
-Arrays of all readers are compared bit for bit before any time is reported.  CPU only: no GPU, no
-oracle call in the product path (the reference reader is the timed baseline, as in bench.py)."""
+Arrays of all readers are compared bit for bit before any time is reported.  CPU only.  Lives under
+tests/ because it loads oracle/_ref (test infrastructure) for the baseline."""
 import argparse
 import ctypes as C
 import os
@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sz = C.c_size_t
 
@@ -66,7 +66,7 @@ def write_file(path, docs, F, seed=42):
 def timed_in_child(which, path, threads, repeat):
     """(a fresh process per configuration: OMP_NUM_THREADS is read once, and the page cache is warm
     for every reader alike -- the file was just written)"""
-    code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'scripts')!r})\n"
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests', 'tools')!r})\n"
             f"import svml_bench as B, ctypes as C\n"
             f"fn = B.reader({which!r})\n"
             f"ts = [B.read(fn, {path!r})[1] for _ in range({repeat})]\n"
@@ -119,7 +119,7 @@ def main():
     print(text)
     if a.md:
         with open(os.path.join(ROOT, a.md), "w") as f:
-            f.write("# SVMLight reader (SURVEY 8 row f2): `scripts/svml_bench.py`, build container's host cores\n\n" + text)
+            f.write("# SVMLight reader (SURVEY 8 row f2): `tests/tools/svml_bench.py`, build container's host cores\n\n" + text)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
 // host_capi.cc -- C shims over the host classes for the (CPU-side) tests of the
 // SVMLight reader and the XML model round trip; no device calls here.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -139,6 +140,19 @@ int qrh_model_roundtrip(const char *in_path, const char *out_path) {
   auto m = learning::forests::Mart::load_model_from_file(in_path);
   if (!m) return 1;
   m->save(out_path);
+  return 0;
+}
+
+// ... the same with the two halves timed (scripts/xml_bench.py)
+int qrh_model_roundtrip_timed(const char *in_path, const char *out_path, double *load_s, double *save_s) {
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  auto m = learning::forests::Mart::load_model_from_file(in_path);
+  const auto t1 = std::chrono::high_resolution_clock::now();
+  if (!m) return 1;
+  m->save(out_path);
+  const auto t2 = std::chrono::high_resolution_clock::now();
+  *load_s = std::chrono::duration<double>(t1 - t0).count();
+  *save_s = std::chrono::duration<double>(t2 - t1).count();
   return 0;
 }
 

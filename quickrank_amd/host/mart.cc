@@ -16,14 +16,12 @@ namespace forests {
 void RTNode::append_xml_model(xml::Node *parent, const std::string &pos) const {
   xml::Node *split = parent->append_child("split");
   if (!pos.empty()) split->append_attribute("pos", pos);
-  std::stringstream ss;
+  // (rtnode.cc:48-77 streams with setprecision(max_digits10): "%.17g" / "%.9g")
   if (is_leaf()) {
-    ss << std::setprecision(std::numeric_limits<double>::max_digits10) << avglabel;
-    split->append_child("output")->text = ss.str();
+    split->append_child("output")->text = xml::fmt_double(avglabel);
   } else {
     split->append_child("feature")->text = std::to_string(featureid);
-    ss << std::setprecision(std::numeric_limits<float>::max_digits10) << threshold;
-    split->append_child("threshold")->text = ss.str();
+    split->append_child("threshold")->text = xml::fmt_float(threshold);
     left->append_xml_model(split, "left");
     right->append_xml_model(split, "right");
   }
@@ -81,8 +79,11 @@ void Ensemble::append_xml_model(xml::Node *parent) const {
     xml::Node *tree = ensemble->append_child("tree");
     tree->append_attribute("id", std::to_string(i + 1));
     tree->append_attribute("weight", xml::fmt_double(weights_[i]));
-    if (roots_[i]) roots_[i]->append_xml_model(tree);
   }
+  const long nt = (long)roots_.size();   // the trees' own elements: independent, on all host threads
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < nt; ++i)
+    if (roots_[(size_t)i]) roots_[(size_t)i]->append_xml_model(ensemble->children[(size_t)i].get());
 }
 
 static size_t count_nodes(const RTNode *n) {
@@ -177,15 +178,22 @@ Mart::Mart(const xml::Node &model) : algo_(MART), treedepth_(3) {
     collapse_leaves_factor_ = strtof(info->child_text("collapse_leaves_factor").c_str(), nullptr);
   if (info->child("depth")) treedepth_ = strtoul(info->child_text("depth").c_str(), nullptr, 10);
   ensemble_model_.set_capacity(ntrees_);
-  for (const auto &tree : ens->children) {
-    const double w = strtod(tree->attribute("weight").c_str(), nullptr);
-    std::unique_ptr<RTNode> root;
-    if (const xml::Node *rs = tree->child("split")) root = RTNode::parse_xml(*rs);
-    if (!root) {
+  // (the trees are independent: built on all host threads, pushed in file order)
+  const long nt = (long)ens->children.size();
+  std::vector<std::unique_ptr<RTNode>> roots((size_t)nt);
+  std::vector<double> weights((size_t)nt);
+#pragma omp parallel for schedule(static)
+  for (long t = 0; t < nt; ++t) {
+    const xml::Node &tree = *ens->children[(size_t)t];
+    weights[(size_t)t] = strtod(tree.attribute("weight").c_str(), nullptr);
+    if (const xml::Node *rs = tree.child("split")) roots[(size_t)t] = RTNode::parse_xml(*rs);
+  }
+  for (long t = 0; t < nt; ++t) {
+    if (!roots[(size_t)t]) {
       std::cerr << "!!! Unable to parse tree from XML model." << std::endl;
       exit(EXIT_FAILURE);
     }
-    ensemble_model_.push(std::move(root), w);
+    ensemble_model_.push(std::move(roots[(size_t)t]), weights[(size_t)t]);
   }
 }
 
@@ -491,7 +499,9 @@ void Mart::save(const std::string &output_basename, int iteration) const {
   if (output_basename.empty()) return;
   std::string filename(output_basename);
   if (iteration != -1) filename += ".T" + std::to_string(iteration) + ".xml";
-  xml::save_file(*get_xml_model(), filename);
+  auto doc = get_xml_model();
+  xml::save_file(*doc, filename);
+  xml::release(std::move(doc));
 }
 
 std::shared_ptr<Mart> Mart::load_model_from_file(const std::string &model_filename) {
@@ -507,7 +517,9 @@ std::shared_ptr<Mart> Mart::load_model_from_file(const std::string &model_filena
   Algo a;
   const xml::Node *info = doc->child("info");
   if (!info || !algo_from_name(info->child_text("type"), &a)) return nullptr;  // ltr_algorithm.cc:123
-  return std::shared_ptr<Mart>(new Mart(*doc));
+  std::shared_ptr<Mart> m(new Mart(*doc));
+  xml::release(std::move(doc));
+  return m;
 }
 
 bool Mart::import_model_state(Mart &other) {

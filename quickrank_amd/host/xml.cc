@@ -1,9 +1,11 @@
 #include "xml.h"
 
+#include <omp.h>
+
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
-#include <sstream>
 
 namespace quickrank {
 namespace xml {
@@ -33,21 +35,47 @@ static std::string escape(const std::string &s, bool attr) {
 
 static void write_node(const Node &n, int depth, std::string &out) {
   out.append((size_t)depth, '\t');
-  out += "<" + n.name;
-  for (auto &a : n.attrs) out += " " + a.first + "=\"" + escape(a.second, true) + "\"";
+  out += '<';
+  out += n.name;
+  for (auto &a : n.attrs) {
+    out += ' ';
+    out += a.first;
+    out += "=\"";
+    out += escape(a.second, true);
+    out += '"';
+  }
   if (n.children.empty() && n.text.empty()) {
     out += " />\n";
     return;
   }
   out += ">";
   if (n.children.empty()) {  // text-only element stays on one line
-    out += escape(n.text, false) + "</" + n.name + ">\n";
+    out += escape(n.text, false);
+    out += "</";
+    out += n.name;
+    out += ">\n";
     return;
   }
   out += "\n";
-  for (auto &c : n.children) write_node(*c, depth + 1, out);
+  if (n.children.size() >= 64) {  // a model's <ensemble>: the children side by side, joined in order
+    const int nt = std::max(1, std::min<int>(omp_get_max_threads(), (int)(n.children.size() / 16)));
+    std::vector<std::string> part((size_t)nt);
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+    for (int t = 0; t < nt; ++t) {
+      const size_t i0 = n.children.size() * (size_t)t / (size_t)nt, i1 = n.children.size() * (size_t)(t + 1) / (size_t)nt;
+      for (size_t i = i0; i < i1; ++i) write_node(*n.children[i], depth + 1, part[(size_t)t]);
+    }
+    size_t total = out.size();
+    for (auto &p : part) total += p.size();
+    out.reserve(total + (size_t)depth + n.name.size() + 8);
+    for (auto &p : part) out += p;
+  } else {
+    for (auto &c : n.children) write_node(*c, depth + 1, out);
+  }
   out.append((size_t)depth, '\t');
-  out += "</" + n.name + ">\n";
+  out += "</";
+  out += n.name;
+  out += ">\n";
 }
 
 std::string to_string(const Node &root) {
@@ -57,10 +85,11 @@ std::string to_string(const Node &root) {
 }
 
 bool save_file(const Node &root, const std::string &path) {
-  std::ofstream f(path, std::ofstream::out | std::ofstream::trunc);
+  FILE *f = fopen(path.c_str(), "wb");
   if (!f) return false;
-  f << to_string(root);
-  return (bool)f;
+  const std::string doc = to_string(root);
+  const bool ok = fwrite(doc.data(), 1, doc.size(), f) == doc.size();
+  return (fclose(f) == 0) && ok;
 }
 
 namespace {
@@ -157,19 +186,131 @@ struct Parser {
 };
 }  // namespace
 
+// A model of thousands of trees is one flat run of <tree> elements: cut the run at the element
+// starts, parse the pieces on all host threads with the same Parser, hang them where a placeholder
+// stood in the (serially parsed) rest.  Every assumption is checked -- each piece must parse into
+// <tree> elements and end exactly where the next begins -- and anything unexpected (a "<tree" in a
+// comment, character data between trees, fewer than 64 of them) returns nullptr: the caller then
+// parses the whole document serially.
+static std::unique_ptr<Node> parse_tree_run_parallel(const std::string &doc) {
+  static const char kOpen[] = "<tree", kClose[] = "</tree", kHole[] = "qr-tree-run";
+  std::vector<size_t> starts;
+  for (size_t at = doc.find(kOpen); at != std::string::npos; at = doc.find(kOpen, at + 5)) {
+    const char c = at + 5 < doc.size() ? doc[at + 5] : '\0';
+    if (c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '>' || c == '/') starts.push_back(at);
+  }
+  if (starts.size() < 64) return nullptr;
+  size_t last = doc.rfind(kClose);
+  if (last == std::string::npos || last < starts.back()) return nullptr;
+  last = doc.find('>', last);
+  if (last == std::string::npos) return nullptr;
+  const size_t A = starts[0], B = last + 1;
+  // the document around the run
+  std::string rest;
+  rest.reserve(A + 32 + (doc.size() - B));
+  rest.append(doc, 0, A).append("<").append(kHole).append(" />").append(doc, B, std::string::npos);
+  Parser outer(rest);
+  outer.skip_misc();
+  std::unique_ptr<Node> root = outer.element();
+  if (!root) return nullptr;
+  Node *parent = nullptr;
+  size_t slot = 0;
+  std::vector<Node *> stack{root.get()};
+  while (!stack.empty() && !parent) {
+    Node *n = stack.back();
+    stack.pop_back();
+    for (size_t i = 0; i < n->children.size(); ++i) {
+      if (n->children[i]->name == kHole) {
+        parent = n;
+        slot = i;
+        break;
+      }
+      stack.push_back(n->children[i].get());
+    }
+  }
+  if (!parent) return nullptr;
+  // the run itself
+  const int nt = std::max(1, std::min<int>(omp_get_max_threads(), (int)(starts.size() / 16)));
+  std::vector<std::vector<std::unique_ptr<Node>>> got((size_t)nt);
+  std::vector<char> ok((size_t)nt, 1);
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+  for (int t = 0; t < nt; ++t) {
+    const size_t i0 = starts.size() * (size_t)t / (size_t)nt, i1 = starts.size() * (size_t)(t + 1) / (size_t)nt;
+    const size_t lo = starts[i0], hi = i1 < starts.size() ? starts[i1] : B;
+    Parser ps(doc);
+    ps.p = lo;
+    got[(size_t)t].reserve(i1 - i0);
+    while (ps.p < hi) {
+      std::unique_ptr<Node> e = ps.element();
+      if (!e || e->name != "tree") {
+        ok[(size_t)t] = 0;
+        break;
+      }
+      got[(size_t)t].push_back(std::move(e));
+      ps.skip_misc();  // white space and comments between trees
+    }
+    if (ps.p != hi && !(hi == B && ps.p >= B)) ok[(size_t)t] = 0;
+    if (got[(size_t)t].size() != i1 - i0) ok[(size_t)t] = 0;
+  }
+  for (char k : ok)
+    if (!k) return nullptr;
+  std::vector<std::unique_ptr<Node>> kids;
+  kids.reserve(parent->children.size() + starts.size());
+  for (size_t i = 0; i < slot; ++i) kids.push_back(std::move(parent->children[i]));
+  for (auto &v : got)
+    for (auto &e : v) kids.push_back(std::move(e));
+  for (size_t i = slot + 1; i < parent->children.size(); ++i) kids.push_back(std::move(parent->children[i]));
+  parent->children = std::move(kids);
+  return root;
+}
+
 std::unique_ptr<Node> parse(const std::string &doc) {
+  if (doc.size() >= (1u << 20)) {
+    std::unique_ptr<Node> n = parse_tree_run_parallel(doc);
+    if (n) return n;
+  }
   Parser ps(doc);
   ps.skip_misc();
   auto n = ps.element();
   return n;
 }
 
+void release(std::unique_ptr<Node> doc) {
+  if (!doc) return;
+  // the long child list (a model's <ensemble>) goes first, its elements side by side
+  std::vector<Node *> stack{doc.get()};
+  while (!stack.empty()) {
+    Node *n = stack.back();
+    stack.pop_back();
+    if (n->children.size() >= 64) {
+      const long k = (long)n->children.size();
+#pragma omp parallel for schedule(static)
+      for (long i = 0; i < k; ++i) n->children[(size_t)i].reset();
+      n->children.clear();
+    } else {
+      for (auto &c : n->children) stack.push_back(c.get());
+    }
+  }
+}
+
 std::unique_ptr<Node> load_file(const std::string &path) {
-  std::ifstream f(path);
+  FILE *f = fopen(path.c_str(), "rb");
   if (!f) return nullptr;
-  std::stringstream ss;
-  ss << f.rdbuf();
-  return parse(ss.str());
+  std::string doc;
+  if (fseek(f, 0, SEEK_END) == 0) {
+    const long n = ftell(f);
+    rewind(f);
+    if (n > 0) {
+      doc.resize((size_t)n);
+      doc.resize(fread(&doc[0], 1, (size_t)n, f));
+    }
+  } else {  // not seekable: by pieces
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) doc.append(buf, n);
+  }
+  fclose(f);
+  return parse(doc);
 }
 
 }  // namespace xml

@@ -46,6 +46,7 @@ std::string to_string(const Node &root);                 // serialised document
 bool save_file(const Node &root, const std::string &path);
 std::unique_ptr<Node> parse(const std::string &doc);      // nullptr on syntax error
 std::unique_ptr<Node> load_file(const std::string &path);
+void release(std::unique_ptr<Node> doc);                  // frees a large document on all host threads
 
 std::string fmt_double(double v);   // "%.17g"
 std::string fmt_float(float v);     // "%.9g"

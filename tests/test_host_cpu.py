@@ -164,6 +164,68 @@ def test_xml_model_format_and_roundtrip(host, tmp_path):
     assert host.qrh_model_roundtrip(p3.encode(), p2.encode()) == 0 and open(p2).read() == text
 
 
+def test_xml_large_model_parallel_paths(host, tmp_path):
+    """A model of a megabyte or more is parsed, built, written and released on all host threads
+    (xml.cc: the run of <tree> elements is cut at the element starts, every piece checked to be
+    whole <tree> elements ending where the next begins).  The records that come back are the
+    records that went in; load + save is the identity on the bytes; and documents the cut cannot
+    be trusted on -- a "<tree" inside a comment, a comment between trees, pretty spaces, a
+    declaration -- load to the same records through the checks or the serial fallback."""
+    import sys
+    from quickrank_amd import _capi
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+    from score_bench import make_leafwise_model
+    T, leaves = 400, 32
+    nodes = np.ascontiguousarray(make_leafwise_model(T, leaves, 50, np.random.default_rng(3))[0])
+    p, p2 = str(tmp_path / "big.xml"), str(tmp_path / "big2.xml")
+    assert host.qrh_model_write(p.encode(), 1, T, 0.1, 255, leaves, 1, 0, 0, nodes.ctypes.data, T, nodes.shape[1]) == 0
+    text = open(p).read()
+    assert len(text) > (1 << 20)
+    assert host.qrh_model_roundtrip(p.encode(), p2.encode()) == 0 and open(p2).read() == text
+    sz = C.c_size_t
+
+    def records(path):
+        nt, mn = sz(), sz()
+        back = np.zeros((T, nodes.shape[1]), _capi.NODE_DTYPE)
+        w = np.zeros(T)
+        assert host.qrh_model_read(path.encode(), back.ctypes.data, w.ctypes.data, C.byref(nt), C.byref(mn),
+                                   back.size, T) == 0
+        assert (nt.value, mn.value) == (T, nodes.shape[1])
+        return back
+
+    def same(back):
+        # (flatten numbers the nodes in pre-order; the generator in creation order: compare what
+        # a walk sees -- every document-independent path: feature, threshold bits, leaf value bits)
+        def walk(n, i, out):
+            out.append((int(n[i]["feature"]), n[i]["threshold"].tobytes(), n[i]["value"].tobytes() if n[i]["feature"] < 0 else b""))
+            if n[i]["feature"] >= 0:
+                walk(n, int(n[i]["left"]), out)
+                walk(n, int(n[i]["right"]), out)
+            return out
+        for t in range(0, T, 37):
+            assert walk(back[t], 0, []) == walk(nodes[t], 0, []), t
+
+    base = records(p)
+    same(base)
+    cut = text.index("<tree", text.index("<tree") + 5)     # in front of the second tree
+    variants = {
+        "comment_with_a_tree_in_it": text[:cut] + '<!-- <tree id="0" weight="1"> -->\n\t\t' + text[cut:],
+        "comment_between_trees": text[:cut] + "<!-- nothing -->\n\t\t" + text[cut:],
+        "declaration_and_spaces": '<?xml version="1.0"?>\n' + text.replace("\t", "  "),
+        "one_line": text.replace("\n", "").replace("\t", ""),
+    }
+    for name, doc in variants.items():
+        pv = str(tmp_path / (name + ".xml"))
+        open(pv, "w").write(doc)
+        got = records(pv)
+        assert got.tobytes() == base.tobytes(), name
+    # character data between trees is not a model the cut may accept silently: the serial parser
+    # decides (it keeps the trees; the text belongs to <ensemble>, which the loader does not read)
+    pv = str(tmp_path / "text_between.xml")
+    open(pv, "w").write(text[:cut] + "stray " + text[cut:])
+    assert records(pv).tobytes() == base.tobytes()
+
+
 def test_oblivious_xml_info_block(host, tmp_path):
     from quickrank_amd import _capi
     nodes = _toy_nodes(_capi)

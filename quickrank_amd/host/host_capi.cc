@@ -124,6 +124,10 @@ size_t qrh_parse_float_selftest(uint64_t seed, size_t n, char *first_bad, size_t
   return bad;
 }
 
+int qrh_write_scores(const char *path, const double *scores, size_t n) {
+  return io::write_scores(path, scores, n) ? 0 : 1;
+}
+
 int qrh_svml_write(const char *path, const float *x, const float *labels, const uint64_t *qoff,
                    size_t Q, size_t F) {
   const size_t N = qoff[Q];

@@ -231,11 +231,10 @@ int main(int argc, char *argv[]) {
     std::cout << std::endl << v["test-metric"] << "@" << k << " on test data = " << std::setprecision(4)
               << s << std::endl << std::endl;
     if (!v["scores"].empty()) {
-      std::ofstream os;
-      os << std::setprecision(std::numeric_limits<Score>::max_digits10);
-      os.open(v["scores"], std::fstream::out);
-      for (size_t i = 0; i < test->num_instances(); ++i) os << scores[i] << std::endl;
-      os.close();
+      if (!io::write_scores(v["scores"], scores.data(), test->num_instances())) {
+        std::cerr << "!!! Error while opening file " << v["scores"] << "." << std::endl;
+        exit(EXIT_FAILURE);
+      }
       std::cout << "# Scores written to file: " << v["scores"] << std::endl;
     }
   }

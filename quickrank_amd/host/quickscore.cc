@@ -67,11 +67,10 @@ int main(int argc, char *argv[]) {
             << "   of which device kernel: " << kernel_total / rounds << " s. per round (features resident)"
             << std::endl;
   if (!scores_file.empty()) {
-    std::ofstream os;
-    os << std::setprecision(std::numeric_limits<Score>::max_digits10);
-    os.open(scores_file, std::fstream::out);
-    for (size_t i = 0; i < ds->num_instances(); ++i) os << scores[i] << std::endl;
-    os.close();
+    if (!io::write_scores(scores_file, scores.data(), ds->num_instances())) {
+      std::cerr << "!!! Error while opening file " << scores_file << "." << std::endl;
+      return EXIT_FAILURE;
+    }
   }
   return EXIT_SUCCESS;
 }

@@ -309,6 +309,34 @@ std::unique_ptr<data::Dataset> Svml::read_horizontal(const std::string &filename
   return dataset;
 }
 
+bool write_scores(const std::string &path, const double *scores, size_t n) {
+  FILE *out = fopen(path.c_str(), "wb");
+  if (!out) return false;
+  const size_t piece = 1u << 16;  // scores per task
+  const long npieces = (long)((n + piece - 1) / piece);
+  const int nt = omp_get_max_threads();
+  bool ok = true;
+  // rounds of one piece per thread: formatted side by side, written in order
+  std::vector<std::vector<char>> text((size_t)nt);
+  for (long base = 0; base < npieces && ok; base += nt) {
+    const long cnt = std::min<long>(nt, npieces - base);
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+    for (long k = 0; k < cnt; ++k) {
+      std::vector<char> &b = text[(size_t)k];
+      const size_t lo = (size_t)(base + k) * piece, hi = std::min(n, lo + piece);
+      b.resize((hi - lo) * 26);  // "-1.7976931348623157e+308\n" is 25 characters
+      size_t at = 0;
+      for (size_t i = lo; i < hi; ++i) {
+        at += (size_t)snprintf(b.data() + at, 26, "%.17g", scores[i]);
+        b[at++] = '\n';
+      }
+      b.resize(at);
+    }
+    for (long k = 0; k < cnt && ok; ++k) ok = fwrite(text[(size_t)k].data(), 1, text[(size_t)k].size(), out) == text[(size_t)k].size();
+  }
+  return (fclose(out) == 0) && ok;
+}
+
 // Same bytes as svml.cc:163-188 produces through its iostream manipulators: the
 // very first label is printed in the default float format with precision 0
 // ("%.0g"); std::fixed then stays set, so every later label comes out as "%.0f";

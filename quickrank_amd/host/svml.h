@@ -13,6 +13,10 @@ namespace io {
 // strtof's result and end pointer, by a shorter way where that is certain to agree (svml.cc)
 float parse_float(const char *s, char **after);
 
+// One score per line, "%.17g" -- what `os << setprecision(max_digits10) << score << endl` prints
+// (driver.cc:376-383, quickscore.cc:122-130) -- formatted on all host threads, written once.
+bool write_scores(const std::string &path, const double *scores, size_t n);
+
 class Svml {
   // seconds spent parsing the text / filling the dense matrix, bytes of the file
   struct Stats {

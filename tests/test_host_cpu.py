@@ -98,6 +98,21 @@ def test_number_conversion_is_strtofs(host):
     assert host.qrh_parse_float_check(buf, len(texts), C.byref(bad)) == 0, texts[bad.value]
 
 
+def test_scores_file_is_the_streams_output(host, tmp_path):
+    """driver.cc:376-383 / quickscore.cc:122-130 stream one score per line with
+    setprecision(max_digits10): "%.17g".  The host formats pieces on all threads and writes once;
+    the bytes are those of the stream (checked against C formatting, specials included)."""
+    rng = np.random.default_rng(0)
+    s = np.concatenate([rng.standard_normal(200_000) * rng.choice([1e-300, 1e-5, 1.0, 1e5, 1e300], 200_000),
+                        [0.0, -0.0, 1.0, -1.5, 1e22, 1e23, np.inf, -np.inf, np.nan, 5e-324, 1.7976931348623157e308]])
+    p = str(tmp_path / "scores.txt")
+    host.qrh_write_scores.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
+    assert host.qrh_write_scores(p.encode(), s.ctypes.data, len(s)) == 0
+    assert open(p).read() == "".join("%.17g\n" % v for v in s)
+    assert host.qrh_write_scores(p.encode(), s.ctypes.data, 0) == 0 and open(p).read() == ""
+    assert host.qrh_write_scores(str(tmp_path / "no" / "dir.txt").encode(), s.ctypes.data, 3) != 0
+
+
 def test_svml_reader_standalone(host, tmp_path):
     p = str(tmp_path / "a.svml")
     open(p, "w").write(SVML_TEXT)

@@ -347,20 +347,34 @@ void Svml::write(const data::Dataset &dataset, const std::string &file) {
     std::cerr << "!!! Error while opening file " << file << "." << std::endl;
     exit(EXIT_FAILURE);
   }
-  std::vector<char> line;
-  bool first = true;
-  for (size_t q = 0; q < dataset.num_queries(); ++q) {
-    for (size_t r = dataset.offset(q); r < dataset.offset(q + 1); ++r) {
-      line.resize(64 + dataset.num_features() * 96);  // FLT_MAX in %.9f is 49 characters
-      size_t n = (size_t)snprintf(line.data(), 64, first ? "%.0g qid:%zu" : "%.0f qid:%zu",
-                                  (double)dataset.getLabel(r), q + 1);
-      first = false;
-      const Feature *x = dataset.at(r, 0);
-      for (size_t i = 0; i < dataset.num_features(); ++i)
-        n += (size_t)snprintf(line.data() + n, 96, " %zu:%.9f", i + 1, (double)x[i]);
-      line[n++] = '\n';
-      fwrite(line.data(), 1, n, out);
+  // the query of every row, then rows formatted in pieces on all host threads, written in order
+  const size_t N = dataset.num_instances(), F = dataset.num_features();
+  std::vector<size_t> qid(N);
+  for (size_t q = 0; q < dataset.num_queries(); ++q)
+    for (size_t r = dataset.offset(q); r < dataset.offset(q + 1); ++r) qid[r] = q + 1;
+  const size_t per_row = 64 + F * 96;  // FLT_MAX in %.9f is 49 characters
+  const size_t piece = std::max<size_t>(1, (4u << 20) / per_row);
+  const long npieces = (long)((N + piece - 1) / piece);
+  const int nt = omp_get_max_threads();
+  std::vector<std::vector<char>> text((size_t)nt);
+  for (long base = 0; base < npieces; base += nt) {
+    const long cnt = std::min<long>(nt, npieces - base);
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+    for (long k = 0; k < cnt; ++k) {
+      std::vector<char> &b = text[(size_t)k];
+      const size_t lo = (size_t)(base + k) * piece, hi = std::min(N, lo + piece);
+      b.resize((hi - lo) * per_row);
+      size_t n = 0;
+      for (size_t r = lo; r < hi; ++r) {
+        n += (size_t)snprintf(b.data() + n, 64, r == 0 ? "%.0g qid:%zu" : "%.0f qid:%zu", (double)dataset.getLabel(r),
+                              qid[r]);
+        const Feature *x = dataset.at(r, 0);
+        for (size_t i = 0; i < F; ++i) n += (size_t)snprintf(b.data() + n, 96, " %zu:%.9f", i + 1, (double)x[i]);
+        b[n++] = '\n';
+      }
+      b.resize(n);
     }
+    for (long k = 0; k < cnt; ++k) fwrite(text[(size_t)k].data(), 1, text[(size_t)k].size(), out);
   }
   fclose(out);
 }

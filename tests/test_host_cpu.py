@@ -336,6 +336,12 @@ def test_svml_parallel_reader_large_file(host, oracle_lib, tmp_path):
     for u, v in zip(a, b):
         assert u.shape == v.shape and np.array_equal(u.view(np.uint32) if u.dtype == np.float32 else u,
                                                      v.view(np.uint32) if v.dtype == np.float32 else v)
+    # ... and written back by both writers (ours formats pieces of rows on all threads): same bytes
+    x, lab, qoff = a
+    p1, p2 = str(tmp_path / "ref_out.svml"), str(tmp_path / "our_out.svml")
+    R.ref_svml_write(p1.encode(), x, lab, qoff, len(qoff) - 1, x.shape[1])
+    host.qrh_svml_write(p2.encode(), x.ctypes.data, lab.ctypes.data, qoff.ctypes.data, len(qoff) - 1, x.shape[1])
+    assert os.path.getsize(p2) > (16 << 20) and open(p1, "rb").read() == open(p2, "rb").read()
 
 
 # ---------------------------------------------------------------------------

@@ -124,6 +124,24 @@ size_t qrh_parse_float_selftest(uint64_t seed, size_t n, char *first_bad, size_t
   return bad;
 }
 
+// The same in one pass over the file: open (parse), ask the sizes, copy out, close.
+void *qrh_svml_open(const char *path, size_t *N, size_t *F, size_t *Q) {
+  io::Svml reader;
+  data::Dataset *ds = reader.read_horizontal(path).release();
+  *N = ds->num_instances();
+  *F = ds->num_features();
+  *Q = ds->num_queries();
+  return ds;
+}
+void qrh_svml_copy(const void *handle, float *x, float *labels, uint64_t *qoff) {
+  const data::Dataset *ds = (const data::Dataset *)handle;
+  const size_t N = ds->num_instances(), F = ds->num_features(), Q = ds->num_queries();
+  if (x) memcpy(x, ds->at(0, 0), N * F * sizeof(float));
+  if (labels) memcpy(labels, ds->labels(), N * sizeof(float));
+  if (qoff) memcpy(qoff, ds->offsets().data(), (Q + 1) * sizeof(uint64_t));
+}
+void qrh_svml_close(void *handle) { delete (data::Dataset *)handle; }
+
 int qrh_write_scores(const char *path, const double *scores, size_t n) {
   return io::write_scores(path, scores, n) ? 0 : 1;
 }

@@ -23,14 +23,15 @@ sys.path.insert(0, ROOT)
 
 
 def read_svml(host, path):
+    """one pass over the file (the parallel reader of quickrank_amd/host/svml.cc)"""
     sz = C.c_size_t
     N, F, Q = sz(), sz(), sz()
-    host.qrh_svml_read(path.encode(), C.byref(N), C.byref(F), C.byref(Q), None, None, None)
-    x = np.zeros((N.value, F.value), np.float32)
-    lab = np.zeros(N.value, np.float32)
-    qoff = np.zeros(Q.value + 1, np.uint64)
-    host.qrh_svml_read(path.encode(), C.byref(N), C.byref(F), C.byref(Q), x.ctypes.data, lab.ctypes.data,
-                       qoff.ctypes.data)
+    h = host.qrh_svml_open(path.encode(), C.byref(N), C.byref(F), C.byref(Q))
+    x = np.empty((N.value, F.value), np.float32)
+    lab = np.empty(N.value, np.float32)
+    qoff = np.empty(Q.value + 1, np.uint64)
+    host.qrh_svml_copy(h, x.ctypes.data, lab.ctypes.data, qoff.ctypes.data)
+    host.qrh_svml_close(h)
     return x, lab, qoff
 
 
@@ -83,8 +84,10 @@ def main():
     from quickrank_amd.dist import DocShardedTrainer, build_doc_bins
     host = C.CDLL(build.HOST_LIB)
     sz = C.c_size_t
-    host.qrh_svml_read.argtypes = [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.c_void_p,
-                                   C.c_void_p, C.c_void_p]
+    host.qrh_svml_open.argtypes = [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    host.qrh_svml_open.restype = C.c_void_p
+    host.qrh_svml_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    host.qrh_svml_close.argtypes = [C.c_void_p]
     host.qrh_model_write.argtypes = [C.c_char_p, C.c_int, sz, C.c_double, sz, sz, sz, sz, sz, C.c_void_p, sz, sz]
 
     x, lab, qoff = read_svml(host, a.train)

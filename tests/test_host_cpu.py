@@ -119,6 +119,18 @@ def test_svml_reader_standalone(host, tmp_path):
     x, lab, qoff = _read(host.qrh_svml_read, p)
     assert x.shape == (7, 5) and lab.tolist() == [2, 0, 1, 3, 0, 1, 2]
     assert x[0].tolist() == [0.5, 0, 1.25, 0, 0] and x[6].tolist() == [0, 0, 9.5, 0, 0]
+    # the one-pass handle form (scripts/train_multi_gpu.py): the same arrays
+    sz = C.c_size_t
+    host.qrh_svml_open.argtypes = [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    host.qrh_svml_open.restype = C.c_void_p
+    host.qrh_svml_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    host.qrh_svml_close.argtypes = [C.c_void_p]
+    N, F, Q = sz(), sz(), sz()
+    h = host.qrh_svml_open(p.encode(), C.byref(N), C.byref(F), C.byref(Q))
+    x2, l2, q2 = np.empty((N.value, F.value), np.float32), np.empty(N.value, np.float32), np.empty(Q.value + 1, np.uint64)
+    host.qrh_svml_copy(h, x2.ctypes.data, l2.ctypes.data, q2.ctypes.data)
+    host.qrh_svml_close(h)
+    assert np.array_equal(x2, x) and np.array_equal(l2, lab) and np.array_equal(q2, qoff)
 
 
 def _toy_nodes(capi):

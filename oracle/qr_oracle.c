@@ -7,6 +7,7 @@
  *
  * Reference citations are file:line in the upstream hpclab/quickrank tree.
  */
+#define _GNU_SOURCE /* sigaction, MAP_ANONYMOUS (the guarded lists of the hunt's mode) */
 #include "qr_oracle.h"
 
 #include <float.h>
@@ -55,6 +56,63 @@ int qro_self_check(char *msg, size_t n) {
   }
   qro_events_n = 0;
   return k;
+}
+
+/* Sample lists under guard (QRO_GUARD=1, the hunt's mode; profiles/r05_abort_hunt.md): a list is
+ * written once (the partition of its parent) and only read afterwards, so it can live in pages of
+ * its own that turn read-only once filled.  A CPU store into one -- from any thread, any library --
+ * then faults AT THE WRITER: the handler prints the faulting address and the native backtrace of
+ * that thread and aborts.  A list that changes WITHOUT a fault (the self-checks below still see
+ * it) was changed by something that does not go through the CPU's page tables: a DMA.          */
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <unistd.h>
+static int qro_guard_on = -1;
+static void qro_guard_segv(int sig, siginfo_t *si, void *uc) {
+  (void)uc;
+  static const char head[] = "\nqr_oracle: store into a guarded sample list -- the writer's stack:\n";
+  if (write(2, head, sizeof(head) - 1) < 0) _exit(70);
+  char line[96];
+  const int n = snprintf(line, sizeof line, "  signal %d, address %p\n", sig, si ? si->si_addr : NULL);
+  if (n > 0 && write(2, line, (size_t)n) < 0) _exit(70);
+  void *frames[64];
+  backtrace_symbols_fd(frames, backtrace(frames, 64), 2);
+  signal(SIGABRT, SIG_DFL);
+  abort();
+}
+static int qro_guard(void) {
+  if (qro_guard_on < 0) {
+    const char *e = getenv("QRO_GUARD");
+    qro_guard_on = e && *e && *e != '0';
+    if (qro_guard_on) {
+      struct sigaction sa;
+      memset(&sa, 0, sizeof sa);
+      sa.sa_sigaction = qro_guard_segv;
+      sa.sa_flags = SA_SIGINFO;
+      sigaction(SIGSEGV, &sa, NULL);
+    }
+  }
+  return qro_guard_on;
+}
+static size_t qro_list_bytes(size_t n) {
+  const size_t page = (size_t)sysconf(_SC_PAGESIZE), b = sizeof(uint64_t) * (n ? n : 1);
+  return (b + page - 1) / page * page;
+}
+static uint64_t *qro_list_alloc(size_t n) {
+  if (!qro_guard()) return (uint64_t *)malloc(sizeof(uint64_t) * (n ? n : 1));
+  void *p = mmap(NULL, qro_list_bytes(n), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  return p == MAP_FAILED ? NULL : (uint64_t *)p;
+}
+static void qro_list_seal(uint64_t *p, size_t n) { /* filled: read-only from here on */
+  if (p && qro_guard()) mprotect(p, qro_list_bytes(n), PROT_READ);
+}
+static void qro_list_free(uint64_t *p, size_t n) {
+  if (!p) return;
+  if (qro_guard())
+    munmap(p, qro_list_bytes(n));
+  else
+    free(p);
 }
 
 void qro_set_threads(int n) {
@@ -621,7 +679,7 @@ void qro_split_find(size_t f0, size_t f1, const uint64_t *thr_size, size_t cap,
 /* ========================================================================== */
 typedef struct {
   uint64_t *samples;
-  size_t ns;
+  size_t ns, cap; /* cap: entries allocated (the histogram's count) */
   double *hsum;
   uint64_t *hcount;
   double ss; /* squares_sum_ */
@@ -764,8 +822,8 @@ static int tree_split(const qro_train_data_t *d, const double *labels,
   const size_t bf = sp.feature, bt = sp.thr_id;
   const float best_threshold = d->thr[bf * d->cap + bt];
   const uint64_t lcount = sp.lcount, rcount = sp.rcount;
-  uint64_t *ls = (uint64_t *)malloc(sizeof(uint64_t) * (lcount ? lcount : 1));
-  uint64_t *rs = (uint64_t *)malloc(sizeof(uint64_t) * (rcount ? rcount : 1));
+  uint64_t *ls = qro_list_alloc(lcount);
+  uint64_t *rs = qro_list_alloc(rcount);
   size_t lsize = 0, rsize = 0;
   const float *x = d->colmajor + bf * d->N;
   for (size_t i = 0; i < lv->ns; ++i) {
@@ -790,12 +848,16 @@ static int tree_split(const qro_train_data_t *d, const double *labels,
   live_t *ll = &live[li], *rl = &live[ri];
   ll->samples = ls;
   ll->ns = lsize;
+  ll->cap = lcount;
+  qro_list_seal(ls, lcount);
+  qro_list_seal(rs, rcount);
   ll->hsum = (double *)malloc(sizeof(double) * hs);
   ll->hcount = (uint64_t *)malloc(sizeof(uint64_t) * hs);
   ll->ss = qro_hist_build(d->stmap, d->N, d->F, d->thr_size, d->cap, labels, ls,
                           lsize, ll->hsum, ll->hcount);
   rl->samples = rs;
   rl->ns = rsize;
+  rl->cap = rcount;
   if (is_root) { /* rt.cc:340-341: new object */
     rl->hsum = (double *)malloc(sizeof(double) * hs);
     rl->hcount = (uint64_t *)malloc(sizeof(uint64_t) * hs);
@@ -843,8 +905,10 @@ size_t qro_tree_fit(const qro_train_data_t *d, const double *labels,
   size_t nnodes = 1, nsplits = 0, taken = 0;
   /* root histogram: hist_->update(pseudoresponses_, n, sampleids), mart.cc:335 */
   live[0].ns = d->N;
-  live[0].samples = (uint64_t *)malloc(sizeof(uint64_t) * (d->N ? d->N : 1));
+  live[0].samples = qro_list_alloc(d->N);
+  live[0].cap = d->N;
   for (size_t i = 0; i < d->N; ++i) live[0].samples[i] = i;
+  qro_list_seal(live[0].samples, d->N);
   live[0].hsum = (double *)malloc(sizeof(double) * hs);
   live[0].hcount = (uint64_t *)malloc(sizeof(uint64_t) * hs);
   live[0].ss = qro_hist_build(d->stmap, d->N, d->F, d->thr_size, d->cap, labels,
@@ -891,7 +955,7 @@ size_t qro_tree_fit(const qro_train_data_t *d, const double *labels,
     }
   }
   for (size_t i = 0; i < nnodes; ++i) {
-    free(live[i].samples);
+    qro_list_free(live[i].samples, live[i].cap);
     live_free(&live[i]);
   }
   free(live);
@@ -924,8 +988,10 @@ size_t qro_oblivious_fit(const qro_train_data_t *d, const double *labels,
     nodes[i].nsamples = 0;
   }
   live[0].ns = d->N;
-  live[0].samples = (uint64_t *)malloc(sizeof(uint64_t) * (d->N ? d->N : 1));
+  live[0].samples = qro_list_alloc(d->N);
+  live[0].cap = d->N;
   for (size_t i = 0; i < d->N; ++i) live[0].samples[i] = i;
+  qro_list_seal(live[0].samples, d->N);
   live[0].hsum = (double *)malloc(sizeof(double) * hs);
   live[0].hcount = (uint64_t *)malloc(sizeof(uint64_t) * hs);
   live[0].ss = qro_hist_build(d->stmap, d->N, d->F, d->thr_size, d->cap, labels,
@@ -990,8 +1056,8 @@ size_t qro_oblivious_fit(const qro_train_data_t *d, const double *labels,
       const size_t lastt = d->thr_size[bf] - 1;
       const uint64_t lcount = lv->hcount[bf * d->cap + bt];
       const uint64_t rcount = lv->hcount[bf * d->cap + lastt] - lcount;
-      uint64_t *ls = (uint64_t *)malloc(sizeof(uint64_t) * (lcount ? lcount : 1));
-      uint64_t *rs = (uint64_t *)malloc(sizeof(uint64_t) * (rcount ? rcount : 1));
+      uint64_t *ls = qro_list_alloc(lcount);
+      uint64_t *rs = qro_list_alloc(rcount);
       size_t lsize = 0, rsize = 0;
       for (size_t j = 0; j < lv->ns; ++j) {
         const uint64_t k = lv->samples[j];
@@ -1013,8 +1079,12 @@ size_t qro_oblivious_fit(const qro_train_data_t *d, const double *labels,
       live_t *ll = &live[li], *rl = &live[ri];
       ll->samples = ls;
       ll->ns = lsize;
+      ll->cap = lcount;
       rl->samples = rs;
       rl->ns = rsize;
+      rl->cap = rcount;
+      qro_list_seal(ls, lcount);
+      qro_list_seal(rs, rcount);
       present[li] = present[ri] = 1;
       if (depth != depth_max - 1) {
         ll->hsum = (double *)malloc(sizeof(double) * hs);
@@ -1068,7 +1138,7 @@ size_t qro_oblivious_fit(const qro_train_data_t *d, const double *labels,
   size_t used = 0;
   for (size_t i = 0; i < maxnodes; ++i) {
     if (present[i]) used = i + 1;
-    free(live[i].samples);
+    qro_list_free(live[i].samples, live[i].cap);
     live_free(&live[i]);
   }
   free(live);

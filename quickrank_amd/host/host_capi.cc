@@ -178,6 +178,8 @@ int qrh_model_roundtrip_timed(const char *in_path, const char *out_path, double 
   return 0;
 }
 
+static const double *g_tree_weights = nullptr;  // (qrh_model_write_w; tests and tools are single-threaded callers)
+
 // write a model from flat node records (qr_node_t layout), as Mart::save would
 int qrh_model_write(const char *path, int algo, size_t ntrees_cfg, double shrinkage, size_t nthresholds,
                     size_t nleaves, size_t minls, size_t esr, size_t depth, const qr_node_t *nodes,
@@ -207,10 +209,37 @@ int qrh_model_write(const char *path, int algo, size_t ntrees_cfg, double shrink
   for (size_t t = 0; t < ntrees; ++t) {
     xml::Node *tree = ens->append_child("tree");
     tree->append_attribute("id", std::to_string(t + 1));
-    tree->append_attribute("weight", xml::fmt_double(shrinkage));
+    tree->append_attribute("weight", xml::fmt_double(g_tree_weights ? g_tree_weights[t] : shrinkage));
     B::rec(nodes + t * max_nodes, 0)->append_xml_model(tree);
   }
   return xml::save_file(*doc, path) ? 0 : 1;
+}
+
+// ... with a weight per tree (quickrank_amd/io.py: the Python trainer's Ensemble keeps one)
+int qrh_model_write_w(const char *path, int algo, size_t ntrees_cfg, double shrinkage, size_t nthresholds,
+                      size_t nleaves, size_t minls, size_t esr, size_t depth, const qr_node_t *nodes,
+                      size_t ntrees, size_t max_nodes, const double *weights) {
+  g_tree_weights = weights;
+  const int rc = qrh_model_write(path, algo, ntrees_cfg, shrinkage, nthresholds, nleaves, minls, esr, depth, nodes,
+                                 ntrees, max_nodes);
+  g_tree_weights = nullptr;
+  return rc;
+}
+
+// the <info> block of a model file: out[6] = trees, thresholds, leaves, min leaf support, early-stop
+// rounds, depth
+int qrh_model_info(const char *path, int *algo, size_t *out, double *shrinkage) {
+  auto doc = xml::load_file(path);   // (the whole document: the block could sit behind the trees)
+  if (!doc || doc->name != "ranker") return 1;
+  // drop the trees before the model object is made: only the block is asked for
+  for (auto &c : doc->children)
+    if (c->name == "ensemble") c->children.clear();
+  learning::forests::Mart::Algo a;
+  const xml::Node *info = doc->child("info");
+  if (!info || !learning::forests::Mart::algo_from_name(info->child_text("type"), &a)) return 1;
+  learning::forests::Mart m(*doc);
+  m.info(algo, out, shrinkage);
+  return 0;
 }
 
 // flatten a model file into qr_node_t records (for scoring through the C-ABI)

@@ -97,6 +97,13 @@ class Mart {
   static std::shared_ptr<Mart> load_model_from_file(const std::string &model_filename);
   bool import_model_state(Mart &other);  // mart.cc:493-517
   const Ensemble &ensemble() const { return ensemble_model_; }
+  // the <info> block as numbers: trees, thresholds, leaves, min leaf support, early-stop rounds, depth
+  void info(int *algo, size_t out[6], double *shrinkage) const {
+    *algo = (int)algo_;
+    out[0] = ntrees_, out[1] = nthresholds_, out[2] = nleaves_, out[3] = minleafsupport_;
+    out[4] = valid_iterations_, out[5] = treedepth_;
+    *shrinkage = shrinkage_;
+  }
 
  private:
   void ensure_ctx();

@@ -1,0 +1,96 @@
+"""The file formats either side of the path, for the Python host:
+SVMLight / LETOR text (io/svml.cc:38-188), the XML model (mart.cc:37-89, 470-491; rtnode.cc:48-117),
+the scores file (driver.cc:376-383).  Thin ctypes calls into quickrank_amd/host's C++ classes
+(libqr_host.so: the same reader, writer and model code `quicklearn` / `quickscore` run) -- no
+parsing in Python."""
+import ctypes as C
+
+import numpy as np
+
+from . import build
+from ._capi import NODE_DTYPE
+
+ALGOS = ("MART", "LAMBDAMART", "OBVMART", "OBVLAMBDAMART")
+_sz = C.c_size_t
+_HOST = None
+
+
+def host():
+    global _HOST
+    if _HOST is None:
+        build.build_host()
+        L = C.CDLL(build.HOST_LIB)
+        L.qrh_svml_open.argtypes = [C.c_char_p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]
+        L.qrh_svml_open.restype = C.c_void_p
+        L.qrh_svml_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qrh_svml_close.argtypes = [C.c_void_p]
+        L.qrh_svml_write.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, _sz, _sz]
+        L.qrh_write_scores.argtypes = [C.c_char_p, C.c_void_p, _sz]
+        L.qrh_model_write_w.argtypes = [C.c_char_p, C.c_int, _sz, C.c_double, _sz, _sz, _sz, _sz, _sz, C.c_void_p,
+                                        _sz, _sz, C.c_void_p]
+        L.qrh_model_read.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(_sz), C.POINTER(_sz), _sz, _sz]
+        L.qrh_model_info.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(_sz), C.POINTER(C.c_double)]
+        _HOST = L
+    return _HOST
+
+
+def read_svmlight(path):
+    """-> (x f32 [N][F] row-major, labels f32 [N], query offsets u64 [Q+1]).  A malformed file ends
+    the process with the reference's exit status (svml.cc:94-120), as `quicklearn` does."""
+    N, F, Q = _sz(), _sz(), _sz()
+    h = host().qrh_svml_open(str(path).encode(), C.byref(N), C.byref(F), C.byref(Q))
+    x = np.empty((N.value, F.value), np.float32)
+    labels = np.empty(N.value, np.float32)
+    qoff = np.empty(Q.value + 1, np.uint64)
+    host().qrh_svml_copy(h, x.ctypes.data, labels.ctypes.data, qoff.ctypes.data)
+    host().qrh_svml_close(h)
+    return x, labels, qoff
+
+
+def write_svmlight(path, x, labels, qoff):
+    """Svml::write (svml.cc:163-188): every feature of every document, %.9f."""
+    x = np.ascontiguousarray(x, np.float32)
+    labels = np.ascontiguousarray(labels, np.float32)
+    qoff = np.ascontiguousarray(qoff, np.uint64)
+    assert x.ndim == 2 and len(labels) == len(x) == int(qoff[-1])
+    host().qrh_svml_write(str(path).encode(), x.ctypes.data, labels.ctypes.data, qoff.ctypes.data, len(qoff) - 1,
+                          x.shape[1])
+
+
+def write_scores(path, scores):
+    """one score per line, 17 significant digits (driver.cc:376-383)"""
+    s = np.ascontiguousarray(scores, np.float64)
+    if host().qrh_write_scores(str(path).encode(), s.ctypes.data, len(s)) != 0:
+        raise OSError(f"cannot write {path}")
+
+
+def save_model(path, algo, nodes, weights, ntrees, shrinkage, nthresholds, nleaves, minls, esr, depth=3):
+    """LTR_Algorithm::save (ltr_algorithm.cc:54-66) from flat node records [T][max_nodes]."""
+    nodes = np.ascontiguousarray(nodes, NODE_DTYPE)
+    weights = np.ascontiguousarray(weights, np.float64)
+    assert nodes.ndim == 2 and len(weights) == len(nodes)
+    rc = host().qrh_model_write_w(str(path).encode(), ALGOS.index(algo), ntrees, shrinkage, nthresholds, nleaves, minls,
+                                  esr, depth, nodes.ctypes.data, len(nodes), nodes.shape[1] if len(nodes) else 0,
+                                  weights.ctypes.data)
+    if rc != 0:
+        raise OSError(f"cannot write {path}")
+
+
+def load_model(path):
+    """-> dict(algo, ntrees, shrinkage, nthresholds, nleaves, minls, esr, depth, nodes [T][max_nodes]
+    (pre-order numbering), weights [T]); None for a model of another algorithm
+    (ltr_algorithm.cc:123: the caller decides)."""
+    p = str(path).encode()
+    algo, out, shr = C.c_int(), (_sz * 6)(), C.c_double()
+    if host().qrh_model_info(p, C.byref(algo), out, C.byref(shr)) != 0:
+        return None
+    nt, mn = _sz(), _sz()
+    if host().qrh_model_read(p, None, None, C.byref(nt), C.byref(mn), 0, 0) != 0:
+        return None
+    nodes = np.zeros((nt.value, mn.value), NODE_DTYPE)
+    weights = np.zeros(nt.value, np.float64)
+    if nt.value and host().qrh_model_read(p, nodes.ctypes.data, weights.ctypes.data, C.byref(nt), C.byref(mn),
+                                          nodes.size, nt.value) != 0:
+        raise OSError(f"cannot read {path}")
+    return dict(algo=ALGOS[algo.value], ntrees=out[0], nthresholds=out[1], nleaves=out[2], minls=out[3], esr=out[4],
+                depth=out[5], shrinkage=shr.value, nodes=nodes, weights=weights)

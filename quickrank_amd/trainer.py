@@ -142,6 +142,28 @@ class Mart:
                 self.ensemble.pop()
         return self
 
+    # LTR_Algorithm::save (ltr_algorithm.cc:54-66): the XML model `quicklearn --model-out` writes
+    def save(self, path):
+        from . import io
+        nodes, w = self.ensemble.arrays() if len(self.ensemble) else (np.zeros((0, self.ensemble.max_nodes), NODE_DTYPE),
+                                                                      np.zeros(0))
+        io.save_model(path, self.algo, nodes, w, self.ntrees, self.shrinkage, self.nthresholds, self.nleaves,
+                      self.minls, self.esr, self.depth)
+
+    # LTR_Algorithm::load_model_from_file (ltr_algorithm.cc:98-131): a model file -> a scorer
+    @classmethod
+    def load_model_from_file(cls, path, device=0, ctx=None):
+        from . import io
+        m = io.load_model(path)
+        if m is None:
+            return None
+        self = cls(algo=m["algo"], ntrees=m["ntrees"], shrinkage=m["shrinkage"], nthresholds=m["nthresholds"],
+                   nleaves=m["nleaves"], minls=m["minls"], esr=m["esr"], depth=m["depth"], device=device, ctx=ctx)
+        self.ensemble = Ensemble(m["nodes"].shape[1] if len(m["nodes"]) else self.ensemble.max_nodes)
+        for t, w in zip(m["nodes"], m["weights"]):
+            self.ensemble.push(t, float(w))
+        return self
+
     # LTR_Algorithm::score_dataset (ltr_algorithm.cc:44-52)
     def score_dataset(self, x):
         nodes, w = self.ensemble.arrays()

@@ -253,6 +253,51 @@ def test_xml_large_model_parallel_paths(host, tmp_path):
     assert records(pv).tobytes() == base.tobytes()
 
 
+def test_python_io_mirror(host, tmp_path):
+    """quickrank_amd/io.py and Mart.save / Mart.load_model_from_file: the Python host reads and
+    writes the reference's formats through the same C++ classes the CLI runs (no GPU here: the
+    trainer gets a stand-in for its device context)."""
+    from quickrank_amd import _capi, io
+    from quickrank_amd.trainer import Mart
+    x, labels, qoff = make_dataset(nq=12, docs_per_query=9, F=7, seed=2, ragged=True)
+    p = str(tmp_path / "d.svml")
+    io.write_svmlight(p, x, labels, qoff)
+    rx, rl, rq = io.read_svmlight(p)
+    assert np.allclose(rx, x, rtol=0, atol=1e-9) and np.array_equal(rl, labels) and np.array_equal(rq, qoff)
+    s = np.array([0.1, -2.5, 1e-3, 3.0])
+    io.write_scores(str(tmp_path / "s.txt"), s)
+    assert open(tmp_path / "s.txt").read() == "".join("%.17g\n" % v for v in s)
+    # the toy model of test_xml_model_format_and_roundtrip, through the trainer object
+    nodes = _toy_nodes(_capi)
+    m = Mart(algo="LAMBDAMART", ntrees=100, shrinkage=0.1, nthresholds=255, nleaves=10, minls=1, esr=100, depth=3,
+             ctx=object())
+    for t in nodes:
+        m.ensemble.push(t, 0.1)
+    p1, p2 = str(tmp_path / "py.xml"), str(tmp_path / "cc.xml")
+    m.save(p1)
+    assert host.qrh_model_write(p2.encode(), 1, 100, 0.1, 255, 10, 1, 100, 3, nodes.ctypes.data, 2, 5) == 0
+    assert open(p1).read() == open(p2).read()
+    back = Mart.load_model_from_file(p1, ctx=object())
+    assert (back.algo, back.ntrees, back.nleaves, back.nthresholds, back.minls, back.esr) == ("LAMBDAMART", 100, 10, 255, 1, 100)
+    assert back.shrinkage == 0.1 and len(back.ensemble) == 2 and back.ensemble.weights == [0.1, 0.1]
+    bn, _ = back.ensemble.arrays()
+    for k in ("feature", "left", "right"):
+        assert np.array_equal(bn[k], nodes[k]), k
+    assert np.array_equal(bn["threshold"].view(np.uint32), nodes["threshold"].view(np.uint32))
+    assert np.array_equal(bn["value"].view(np.uint64), nodes["value"].view(np.uint64))
+    # per-tree weights survive; an oblivious model keeps its depth; another algorithm's file is None
+    m.ensemble.weights = [0.25, 0.5]
+    m.save(p1)
+    assert Mart.load_model_from_file(p1, ctx=object()).ensemble.weights == [0.25, 0.5]
+    o = Mart(algo="OBVMART", ntrees=7, depth=4, nthresholds=16, ctx=object())
+    o.ensemble.push(nodes[1], 0.1)
+    o.save(p1)
+    ob = Mart.load_model_from_file(p1, ctx=object())
+    assert (ob.algo, ob.depth, ob.ntrees, len(ob.ensemble)) == ("OBVMART", 4, 7, 1)
+    open(p1, "w").write(open(p2).read().replace("LAMBDAMART", "COORDASC"))
+    assert Mart.load_model_from_file(p1, ctx=object()) is None
+
+
 def test_oblivious_xml_info_block(host, tmp_path):
     from quickrank_amd import _capi
     nodes = _toy_nodes(_capi)

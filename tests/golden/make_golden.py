@@ -40,6 +40,11 @@ def make(name, cutoff, nthr, score_kind, **case):
         per_q[q] = R.ref_eval_query(1, np.ascontiguousarray(labels[a:b]),
                                     np.ascontiguousarray(scores[a:b]), b - a, cutoff)
     ds = R.ref_eval_dataset(1, labels, scores, qoff, len(qoff) - 1, cutoff, 1)
+    # the DCG train / test metric (dcg.cc:41-57) on the same rankings
+    dcg_q = np.array([R.ref_eval_query(0, np.ascontiguousarray(labels[int(qoff[q]):int(qoff[q + 1])]),
+                                       np.ascontiguousarray(scores[int(qoff[q]):int(qoff[q + 1])]),
+                                       int(qoff[q + 1] - qoff[q]), cutoff) for q in range(len(qoff) - 1)])
+    dcg_ds = R.ref_eval_dataset(0, labels, scores, qoff, len(qoff) - 1, cutoff, 1)
     n0 = int(qoff[1])
     jac = np.zeros(n0 * (n0 + 1) // 2)
     sl = np.zeros(n0, np.float32)
@@ -93,7 +98,7 @@ def make(name, cutoff, nthr, score_kind, **case):
                         right_ss=gss.value, split_feature=sf, split_slot=st, split_left_ids=sleft,
                         split_left_sum=sls, split_left_count=slc, split_left_ss=slss.value,
                         split_right_sum=srs, split_right_count=src, split_right_ss=srss.value,
-                        argsort=argsort.astype(np.uint32))
+                        argsort=argsort.astype(np.uint32), dcg_per_query=dcg_q, dcg_dataset=dcg_ds)
 
 
 def make_svml(name):

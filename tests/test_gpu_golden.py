@@ -3,7 +3,8 @@
 tests/golden/g*.npz hold, for seeded inputs, what the reference's own translation
 units produced in the build container (tests/golden/make_golden.py drives
 oracle/_ref, which never travels): rank permutations incl. the std::sort tie order
-(queryresults.cc:47-53), per-query and dataset NDCG (ndcg.cc:49-93, metric.h:77-106),
+(queryresults.cc:47-53), per-query and dataset NDCG and DCG (ndcg.cc:49-93, dcg.cc:41-57,
+metric.h:77-106),
 the bin map `stmap` (rtnode_histogram.cc:227-253), the root histogram
 (rtnode_histogram.cc:172-204), a child built from an id list and its sibling by
 subtraction (rtnode_histogram.cc:41-87), the stable argsort of every column
@@ -104,6 +105,24 @@ def test_ranks_and_ndcg_are_the_references(qr, path, exact_tail, monkeypatch):
     assert np.array_equal(pq.view(np.uint64), g["ndcg_per_query"].view(np.uint64))
     assert c.metric_last() == pytest.approx(float(g["ndcg_dataset"]), rel=1e-13)
     assert c.metric_eval(0, "NDCG", cutoff) == pytest.approx(float(g["ndcg_dataset"]), rel=1e-13)
+    c.close()
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
+def test_dcg_is_the_references(qr, path):
+    """The DCG metric (`--train-metric DCG`, dcg.cc:41-57) on the fixtures' rankings: per query
+    bitwise, the dataset mean to 1e-13 -- through the lambda pass (which emits the metric of the
+    scores it ranks) and through qr_metric_eval."""
+    g = np.load(path)
+    cutoff = int(g["cutoff"])
+    c = qr.Context(0)
+    c.upload(g["x"], g["labels"], g["qoff"])
+    c.set_scores(g["scores"])
+    c.compute_lambdas("DCG", cutoff)
+    pq = c.metric_per_query()
+    assert np.array_equal(pq.view(np.uint64), g["dcg_per_query"].view(np.uint64))
+    assert c.metric_last() == pytest.approx(float(g["dcg_dataset"]), rel=1e-13)
+    assert c.metric_eval(0, "DCG", cutoff) == pytest.approx(float(g["dcg_dataset"]), rel=1e-13)
     c.close()
 
 

@@ -278,6 +278,7 @@ std::unique_ptr<data::Dataset> Svml::read_horizontal(const std::string &filename
   // the reference stops at the FIRST malformed line of the file
   for (const Piece &p : pieces)
     if (p.bad_code) exit(p.bad_code);
+  text.reset();  // everything needed is in the pieces: the text goes before the matrix comes
   const auto t1 = std::chrono::high_resolution_clock::now();
 
   size_t rows = 0, width = 0;
@@ -301,6 +302,7 @@ std::unique_ptr<data::Dataset> Svml::read_horizontal(const std::string &filename
       for (size_t k = p.first[r]; k < hi; ++k) row[p.fid[k] - 1] = p.val[k];  // later pairs win
       dataset->set_label(i, p.label[r]);
     }
+    pieces[t] = Piece();  // (released by the thread that made it, as soon as its rows stand)
   }
   dataset->close_rows(qids);
   const auto t2 = std::chrono::high_resolution_clock::now();

@@ -64,7 +64,9 @@ def build(force=False, verbose=False):
         objs = list(ex.map(compile_one, SOURCES))
     with open(stamp, "w") as f:
         f.write(" ".join(cflags))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    # (QR_HIP_EXTRA_LDFLAGS: e.g. the host-side AddressSanitizer flavour of tests/tools/abort_hunt.py --asan)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"] + \
+        os.environ.get("QR_HIP_EXTRA_LDFLAGS", "").split()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

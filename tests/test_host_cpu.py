@@ -298,6 +298,47 @@ def test_python_io_mirror(host, tmp_path):
     assert Mart.load_model_from_file(p1, ctx=object()) is None
 
 
+def test_quicklearn_refuses_before_it_needs_a_device(tmp_path):
+    """The command line's refusals that come before any device work, on the CPU: the
+    reference's exit statuses for malformed SVMLight lines through the real reader (status 1 a
+    second token that is not qid:, 2 a line without a label, 3 a negative qid, 4 a malformed
+    feature: strutils.cc:68, svml.cc:94-120), an unknown algorithm (driver.cc:58-61), an option of
+    a subsystem outside this build's scope, a file that does not exist."""
+    import subprocess
+    from quickrank_amd import build
+    ql = build.build_host()[1]
+    for text, status in (("1 quid:3 1:2\n", 1), ("1 qid:1 1:2\n\n2 qid:1 1:3\n", 2), ("1 qid:-4 1:2\n", 3),
+                         ("1 qid:3 1:2 x:y\n", 4), ("1 qid:3 0:2\n", 4), ("1 qid:3 2:\n", 4)):
+        p = str(tmp_path / "bad.svml")
+        open(p, "w").write("# fine\n3 qid:1 1:0.5 2:1\n" * 3 + text)
+        r = subprocess.run([ql, "--train", p], capture_output=True, text=True)
+        assert r.returncode == status, (text, r.returncode, r.stderr[-200:])
+    # ... also when the bad line sits in another thread's chunk of a long file: the FIRST one decides
+    p = str(tmp_path / "long.svml")
+    good = "".join("%d qid:%d 1:%d.5 2:1 7:3\n" % (i % 5, i // 9 + 1, i) for i in range(60000))
+    cut1, cut2 = len(good) // 3, 2 * len(good) // 3
+    cut1, cut2 = good.index("\n", cut1) + 1, good.index("\n", cut2) + 1
+    open(p, "w").write(good[:cut1] + "1 qid:3 1:2 x:y\n" + good[cut1:cut2] + "1 quid:3 1:2\n" + good[cut2:])
+    r = subprocess.run([ql, "--train", p], capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS="6"))
+    assert r.returncode == 4, r.returncode
+    r = subprocess.run([ql, "--algo", "DART", "--train", "x"], capture_output=True, text=True)
+    assert r.returncode != 0 and "not set properly" in r.stderr
+    r = subprocess.run([ql, "--opt-algo", "CLEAVER"], capture_output=True, text=True)
+    assert r.returncode != 0 and "outside this build's scope" in r.stderr
+    r = subprocess.run([ql, "--train", str(tmp_path / "nothing.svml")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Error while opening file" in r.stderr
+    # quickscore: the model comes first (quickscore.cc:84-96)
+    qs = build.build_host()[2]
+    r = subprocess.run([qs, "-d", p, "-m", str(tmp_path / "nothing.xml")], capture_output=True, text=True)
+    assert r.returncode != 0 and "is not parsed correctly" in r.stderr
+    other = str(tmp_path / "other.xml")
+    open(other, "w").write("<ranker><info><type>COORDASC</type></info><ensemble></ensemble></ranker>")
+    r = subprocess.run([qs, "-d", p, "-m", other], capture_output=True, text=True)
+    assert r.returncode != 0 and "unsupported model type" in r.stderr
+    r = subprocess.run([qs, "-d", p], capture_output=True, text=True)
+    assert r.returncode != 0 and "quickscore -d <dataset> -m <model.xml>" in (r.stdout + r.stderr)
+
+
 def test_oblivious_xml_info_block(host, tmp_path):
     from quickrank_amd import _capi
     nodes = _toy_nodes(_capi)

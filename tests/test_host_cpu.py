@@ -339,6 +339,29 @@ def test_quicklearn_refuses_before_it_needs_a_device(tmp_path):
     assert r.returncode != 0 and "quickscore -d <dataset> -m <model.xml>" in (r.stdout + r.stderr)
 
 
+def test_command_lines_fail_loudly_without_a_device(tmp_path):
+    """No CPU fallback anywhere: with valid input and no GPU in sight, `quicklearn` and
+    `quickscore` read their files, then stop with the library's message and a failure status."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is visible here")
+    from quickrank_amd import _capi, build
+    _, ql, qs = build.build_host()
+    p = str(tmp_path / "good.svml")
+    open(p, "w").write("".join("%d qid:%d 1:%d.5 2:1 7:3\n" % (i % 5, i // 9 + 1, i) for i in range(200)))
+    r = subprocess.run([ql, "--train", p, "--num-trees", "2"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device visible (this library has no CPU fallback)" in r.stdout + r.stderr
+    assert "Dataset size: 200 x 7" in r.stdout            # (the reader had done its part)
+    nodes = _toy_nodes(_capi)
+    L = C.CDLL(build.HOST_LIB)
+    m = str(tmp_path / "m.xml")
+    L.qrh_model_write.argtypes = [C.c_char_p, C.c_int, C.c_size_t, C.c_double] + [C.c_size_t] * 5 + [C.c_void_p] + [C.c_size_t] * 2
+    assert L.qrh_model_write(m.encode(), 1, 100, 0.1, 255, 10, 1, 100, 3, nodes.ctypes.data, 2, 5) == 0
+    r = subprocess.run([qs, "-d", p, "-m", m], capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device visible" in r.stdout + r.stderr
+
+
 def test_oblivious_xml_info_block(host, tmp_path):
     from quickrank_amd import _capi
     nodes = _toy_nodes(_capi)

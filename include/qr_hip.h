@@ -102,6 +102,11 @@ int qr_synchronize(qr_ctx *ctx);
 /* recorded (the checked stores are skipped, not performed).  quickrank_amd/_capi.py calls it */
 /* after every C-ABI call when QR_DEBUG=1.                                                    */
 int qr_debug_check(qr_ctx *ctx);
+/* *count = how often a polled read-back (a tree's records, an iteration's scalars) did not  */
+/* fit the sequence number it was polled for at first sight and was read again (the records   */
+/* carry a tag of themselves, QrNodeWire in qr_internal.h).  Expected: 0 -- the tests and     */
+/* tests/tools/abort_hunt.py assert it, so that a recurrence is caught rather than absorbed.  */
+int qr_readback_retries(qr_ctx *ctx, unsigned long long *count);
 /* *pending = 1: the last tree ended behind a guess that nobody has looked at yet             */
 int qr_tree_pending(qr_ctx *ctx, int *pending);
 

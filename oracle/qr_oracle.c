@@ -95,25 +95,67 @@ static int qro_guard(void) {
   }
   return qro_guard_on;
 }
-static size_t qro_list_bytes(size_t n) {
-  const size_t page = (size_t)sysconf(_SC_PAGESIZE), b = sizeof(uint64_t) * (n ? n : 1);
+static size_t qro_page_round(size_t b) {
+  const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+  if (!b) b = 1;
   return (b + page - 1) / page * page;
 }
-static uint64_t *qro_list_alloc(size_t n) {
-  if (!qro_guard()) return (uint64_t *)malloc(sizeof(uint64_t) * (n ? n : 1));
-  void *p = mmap(NULL, qro_list_bytes(n), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-  return p == MAP_FAILED ? NULL : (uint64_t *)p;
+/* Every sealed block is also remembered with a hash of its bytes; the hash is checked again when the
+ * block is released.  A block whose bytes changed although no store ever faulted was written past
+ * the CPU's page tables -- by a DMA -- and says so (round 6: the matrix, the bin map and the
+ * thresholds of qro_train are sealed like the lists, a few hundred KB to tens of MB per run). */
+#define QRO_SEALS 4096
+static struct { const void *p; size_t bytes; uint64_t h; } qro_seals[QRO_SEALS];
+static uint64_t qro_hash(const void *p, size_t bytes) {
+  const uint64_t *w = (const uint64_t *)p;
+  uint64_t h = 0x9E3779B97F4A7C15ull;
+  for (size_t i = 0; i < bytes / 8; ++i) h = (h ^ w[i]) * 0x100000001B3ull + (h >> 29);
+  const unsigned char *b = (const unsigned char *)p + (bytes & ~(size_t)7);
+  for (size_t i = 0; i < (bytes & 7); ++i) h = (h ^ b[i]) * 0x100000001B3ull;
+  return h;
 }
-static void qro_list_seal(uint64_t *p, size_t n) { /* filled: read-only from here on */
-  if (p && qro_guard()) mprotect(p, qro_list_bytes(n), PROT_READ);
+static void *qro_guard_alloc(size_t bytes) {
+  if (!qro_guard()) return malloc(bytes ? bytes : 1);
+  void *p = mmap(NULL, qro_page_round(bytes), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  return p == MAP_FAILED ? NULL : p;
 }
-static void qro_list_free(uint64_t *p, size_t n) {
+static void qro_guard_seal(void *p, size_t bytes) { /* filled: read-only from here on */
+  if (!p || !qro_guard()) return;
+  const uint64_t h = qro_hash(p, bytes);
+#pragma omp critical(qro_seal_table)
+  for (int i = 0; i < QRO_SEALS; ++i)
+    if (!qro_seals[i].p) {
+      qro_seals[i].p = p;
+      qro_seals[i].bytes = bytes;
+      qro_seals[i].h = h;
+      break;
+    }
+  mprotect(p, qro_page_round(bytes), PROT_READ);
+}
+static void qro_guard_free(void *p, size_t bytes) {
   if (!p) return;
-  if (qro_guard())
-    munmap(p, qro_list_bytes(n));
-  else
+  if (!qro_guard()) {
     free(p);
+    return;
+  }
+  int found = 0;
+  uint64_t h0 = 0;
+#pragma omp critical(qro_seal_table)
+  for (int i = 0; i < QRO_SEALS; ++i)
+    if (qro_seals[i].p == p) {
+      found = 1;
+      h0 = qro_seals[i].h;
+      qro_seals[i].p = NULL;
+      break;
+    }
+  if (found && qro_hash(p, bytes) != h0)
+    qro_event("a sealed block of %zu bytes at %p changed while it was read-only and no store faulted: "
+              "written past the page tables (a DMA)", bytes, p);
+  munmap(p, qro_page_round(bytes));
 }
+static uint64_t *qro_list_alloc(size_t n) { return (uint64_t *)qro_guard_alloc(sizeof(uint64_t) * (n ? n : 1)); }
+static void qro_list_seal(uint64_t *p, size_t n) { qro_guard_seal(p, sizeof(uint64_t) * (n ? n : 1)); }
+static void qro_list_free(uint64_t *p, size_t n) { qro_guard_free(p, sizeof(uint64_t) * (n ? n : 1)); }
 
 void qro_set_threads(int n) {
 #ifdef _OPENMP
@@ -1219,18 +1261,20 @@ int qro_train(const qro_params_t *p, const float *train, const float *labels,
   const size_t L = obliv ? ((size_t)1 << p->depth) : p->nleaves;
   const size_t max_nodes = obliv ? (((size_t)1 << (p->depth + 1)) - 1) : 2 * L + 1;
   /* VerticalDataset, vertical_dataset.cc:45-51 */
-  float *col = (float *)malloc(sizeof(float) * N * F);
+  float *col = (float *)qro_guard_alloc(sizeof(float) * N * F);
 #pragma omp parallel for
   for (size_t i = 0; i < N; ++i)
     for (size_t f = 0; f < F; ++f) col[f * N + i] = train[i * F + f];
+  qro_guard_seal(col, sizeof(float) * N * F); /* (QRO_GUARD=1: read-only from here on, hashed) */
   const size_t cap = p->nthresholds ? p->nthresholds + 1 : N + 1;
   float *thr = (float *)malloc(sizeof(float) * F * cap);
   uint64_t *thr_size = (uint64_t *)malloc(sizeof(uint64_t) * F);
-  uint32_t *stmap = (uint32_t *)malloc(sizeof(uint32_t) * F * N);
+  uint32_t *stmap = (uint32_t *)qro_guard_alloc(sizeof(uint32_t) * F * N);
   uint64_t *count0 = (uint64_t *)malloc(sizeof(uint64_t) * F * cap);
   qro_thresholds(col, N, F, p->nthresholds, thr, thr_size, cap);
   qro_binmap(col, N, F, thr, thr_size, cap, stmap, count0);
   free(count0);
+  qro_guard_seal(stmap, sizeof(uint32_t) * F * N);
   qro_train_data_t d = {N, F, cap, col, stmap, thr, thr_size};
   double *scores = (double *)calloc(N, sizeof(double));
   double *vscores = valid ? (double *)calloc(vN ? vN : 1, sizeof(double)) : NULL;
@@ -1297,8 +1341,8 @@ int qro_train(const qro_params_t *p, const float *train, const float *labels,
   free(weights);
   free(leaf_of_doc);
   free(leaf_nodes);
-  free(stmap);
-  free(col);
+  qro_guard_free(stmap, sizeof(uint32_t) * F * N);
+  qro_guard_free(col, sizeof(float) * N * F);
   return 0;
 }
 

@@ -49,9 +49,12 @@ SYMBOLS = [
     "qr_tree_batch_decide", "qr_tree_batch_settle", "qr_tree_batch_exchange",
     "qr_ensemble_set_depth_order", "qr_bins_build_wide_with",
     "qr_bins_stats_wide", "qr_thresholds_from_stats_wide", "qr_tree_pending", "qr_debug_check",
+    "qr_readback_retries",
 ]
 
 _LIB = None
+# re-reads of polled read-backs over every context this process has closed (Context.close)
+READBACK_RETRIES = 0
 # Live contexts, closed by an atexit hook while the interpreter and the HIP runtime are both
 # still whole: a Context that is only collected during interpreter shutdown (a global, a frame
 # of a failed test) would otherwise call qr_ctx_destroy -- stream syncs, hipFree, hipHostFree --
@@ -117,6 +120,7 @@ def lib():
     L.qr_synchronize.argtypes = [vp]
     L.qr_tree_pending.argtypes = [vp, C.POINTER(C.c_int)]
     L.qr_debug_check.argtypes = [vp]
+    L.qr_readback_retries.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.qr_dataset_upload.argtypes = [vp, vp, sz, sz, vp, vp, sz]
     L.qr_valid_upload.argtypes = [vp, vp, sz, sz, vp, vp, sz]
     L.qr_bins_build.argtypes = [vp, sz, vp, vp]
@@ -287,8 +291,19 @@ class Context:
         self._ck(self.L.qr_ctx_stream(self.h, C.byref(s)))
         return s.value or 0
 
+    def readback_retries(self):
+        """Re-reads of polled read-backs that did not fit their sequence number at first sight
+        (qr_readback_retries); expected 0."""
+        n = C.c_ulonglong(0)
+        self._ck(self.L.qr_readback_retries(self.h, C.byref(n)))
+        return int(n.value)
+
     def close(self):
         if getattr(self, "h", None):
+            global READBACK_RETRIES
+            n = C.c_ulonglong(0)
+            if self.L.qr_readback_retries(self.h, C.byref(n)) == 0:
+                READBACK_RETRIES += int(n.value)   # (tests/conftest.py asserts the process total is 0)
             self.L.qr_ctx_destroy(self.h)
             self.h = None
             _LIVE.discard(self)

@@ -112,8 +112,7 @@ int qr_k_sample_draw(qr_ctx *c) {
   c->sub_n = c->sub_k;
   if (c->dmode) {  // how many of the sample's documents are this rank's: the host sizes launches by it
     uint32_t cnt = 0;
-    QR_CHECK(c, hipMemcpyAsync(&cnt, c->d_sample_count, 4, hipMemcpyDeviceToHost, c->stream));
-    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    QR_D2H(c, &cnt, c->d_sample_count, 4);
     c->sub_n = cnt;
   }
   return QR_OK;

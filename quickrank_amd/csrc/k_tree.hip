@@ -3557,10 +3557,21 @@ __device__ __forceinline__ void nodes_out_write(const QrTreeState *ts, QrNodesOu
     d.tag = qr_node_tag(d, (uint64_t)seq);  // (qr_tree_nodes checks it: a self-validating record)
     wire[i] = d;
   }
+#ifdef QR_DEBUG_CHECKS
+  //  the two places a leaf's output lives -- the record that crosses to the host and the
+  // per-leaf table the lazy score update adds from -- must hold the same bits
+  for (int l = threadIdx.x; l < ts->nleaves; l += blockDim.x) {
+    const unsigned long long a = (unsigned long long)__double_as_longlong(ts->nodes[ts->leaf_nodes[l]].value);
+    const unsigned long long b = (unsigned long long)__double_as_longlong(ts->leaf_value[l]);
+    (void)QR_DBG_OK(a == b, 9, a, b);
+  }
+#endif
   __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0)
-    __hip_atomic_store(&out->pad[2], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  //  the number goes out behind a fence of the thread that stores it, as a release:
+  // every thread's records were fenced to system scope before the barrier, and the storing thread
+  // orders its own view of them before the word the host polls
+  if (threadIdx.x == 0) nodes_out_publish(out, seq);
 }
 
 // rt.cc:165-207
@@ -4360,9 +4371,10 @@ static int root_shares(qr_ctx *c, uint32_t rootn, int G, int root_buf) {
     QR_CHECK(c, hipMalloc((void **)&c->d_root_wg, (size_t)G * sizeof(QrHistWg)));
     c->root_wg_g = G;
   }
-  QR_CHECK(c, hipMemcpyAsync(c->d_root_scan, hs.data(), (size_t)c->flocal * sizeof(QrScanWg), hipMemcpyHostToDevice, c->stream));
-  QR_CHECK(c, hipMemcpyAsync(c->d_root_wg, h.data(), (size_t)G * sizeof(QrHistWg), hipMemcpyHostToDevice, c->stream));
-  QR_CHECK(c, hipStreamSynchronize(c->stream));  // (the host vectors go out of scope)
+  // (blocking copies: `hs` and `h` live on this frame, and an error return between an asynchronous
+  // copy and its wait would leave the copy reading a dead frame -- VERDICT r5; the stream is idle here)
+  QR_CHECK(c, hipMemcpy(c->d_root_scan, hs.data(), (size_t)c->flocal * sizeof(QrScanWg), hipMemcpyHostToDevice));
+  QR_CHECK(c, hipMemcpy(c->d_root_wg, h.data(), (size_t)G * sizeof(QrHistWg), hipMemcpyHostToDevice));
   c->root_wg_n = rootn;
   c->root_wg_g = G;
   c->root_wg_buf = root_buf;

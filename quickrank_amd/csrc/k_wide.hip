@@ -89,8 +89,7 @@ int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds) {
     QR_CHECK(c, hipGetLastError());
     size_t tb = temp_bytes;
     QR_CHECK(c, hipcub::DeviceRadixSort::SortKeys(d_temp, tb, d_keys, d_sorted, (int)N, 0, 32, c->stream));
-    QR_CHECK(c, hipMemcpyAsync(h.data(), d_sorted, N * 4, hipMemcpyDeviceToHost, c->stream));
-    QR_CHECK(c, hipStreamSynchronize(c->stream));
+    QR_D2H(c, h.data(), d_sorted, N * 4);
     // mart.cc:140-152: the distinct values in sorted order, early stop once there are
     // nthresholds + 1 of them (a strict `<` decides "distinct": -0.0 and 0.0 are one
     // value, a NaN is never appended behind a number)
@@ -151,8 +150,7 @@ int qr_k_wide_stats(qr_ctx *c, const float *d_col, size_t limit, uint32_t *vals,
       QR_CHECK(c, hipGetLastError());
       size_t tb = temp_bytes;
       QR_CHECK(c, hipcub::DeviceRadixSort::SortKeys(d_temp, tb, d_keys, d_sorted, (int)N, 0, 32, c->stream));
-      QR_CHECK(c, hipMemcpyAsync(h.data(), d_sorted, N * 4, hipMemcpyDeviceToHost, c->stream));
-      QR_CHECK(c, hipStreamSynchronize(c->stream));
+      QR_D2H(c, h.data(), d_sorted, N * 4);
       uint32_t *out = vals + f * limit;
       size_t n = 0;
       float last = bits2f(h_unflip(h[0]));

@@ -3,6 +3,7 @@
 // (mart.cc:147-169) and Ndcg::compute_idcg (ndcg.cc:35-47), and the launch
 // sequences.  No CPU fallback: every compute entry point needs the gfx950
 // device the context was created on.
+#include <sys/mman.h>
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -145,7 +146,20 @@ int qr_ctx_create(int device, qr_ctx **out) {
   }
   (void)hipMemset(c->d_scalars, 0, sizeof(QrScalars));
   // (coherent = fine-grained: a kernel's stores are visible to the host while it runs)
+#ifdef QR_DEBUG_CHECKS
+  // (the hunt's build, VERDICT r5 item 1: the block is pages of this context's OWN -- mapped here,
+  // registered with the device, and at destruction unregistered, poisoned, made inaccessible and
+  // never handed back: a kernel that still writes it faults on the device, a host store through a
+  // stale pointer faults on the CPU, and no later allocation of anybody can come to lie there)
+  {
+    const size_t pb = (sizeof(QrPinned) + 4095) / 4096 * 4096;
+    void *m = mmap(nullptr, pb, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m != MAP_FAILED && hipHostRegister(m, pb, hipHostRegisterMapped) == hipSuccess) c->h_pin = (QrPinned *)m;
+  }
+  if (!c->h_pin ||
+#else
   if (hipHostMalloc((void **)&c->h_pin, sizeof(QrPinned), hipHostMallocCoherent) != hipSuccess ||
+#endif
       hipHostGetDevicePointer((void **)&c->d_pin, c->h_pin, 0) != hipSuccess ||
       hipMalloc((void **)&c->d_prep_part, QR_PREP_WORDS * 8) != hipSuccess ||
       hipMemset(c->d_prep_part, 0, QR_PREP_WORDS * 8) != hipSuccess) {
@@ -252,7 +266,16 @@ void qr_ctx_destroy(qr_ctx *c) {
     if (c->aux_join[i]) (void)hipEventDestroy(c->aux_join[i]);
   }
   if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
+#ifdef QR_DEBUG_CHECKS
+  if (c->h_pin) {
+    const size_t pb = (sizeof(QrPinned) + 4095) / 4096 * 4096;
+    (void)hipHostUnregister(c->h_pin);
+    memset((void *)c->h_pin, 0xA5, pb);
+    (void)mprotect((void *)c->h_pin, pb, PROT_NONE);   // (leaked on purpose: see qr_ctx_create)
+  }
+#else
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+#endif
   if (c->d_prep_part) (void)hipFree(c->d_prep_part);
   if (c->d_root_wg) (void)hipFree(c->d_root_wg);
   if (c->d_root_scan) (void)hipFree(c->d_root_scan);
@@ -369,6 +392,12 @@ int qr_prof_lds_atomic(qr_ctx *c, double *cycles_per_instr, double *shader_ghz, 
 int qr_debug_check(qr_ctx *c) {
   if (!c) return QR_ERR_ARG;
   return qr_k_debug_check(c);
+}
+
+int qr_readback_retries(qr_ctx *c, unsigned long long *count) {
+  if (!c || !count) return QR_ERR_ARG;
+  *count = c->readback_retries;
+  return QR_OK;
 }
 
 int qr_tree_pending(qr_ctx *c, int *pending) {

@@ -652,6 +652,21 @@ struct qr_ctx {
     }                                                                        \
   } while (0)
 
+// A device-to-host copy into memory of the CALLER's frame (a stack word, a local vector) behind the
+// context's stream: never returns while the copy may still be in flight -- an error between the
+// request and the wait would otherwise leave a DMA writing a frame that is gone.
+#define QR_D2H(ctx, dst, src, bytes)                                                         \
+  do {                                                                                        \
+    hipError_t _e = hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, (ctx)->stream); \
+    const hipError_t _w = hipStreamSynchronize((ctx)->stream);                                \
+    if (_e == hipSuccess) _e = _w;                                                            \
+    if (_e != hipSuccess) {                                                                   \
+      (void)hipDeviceSynchronize();                                                           \
+      (ctx)->err = std::string("device-to-host copy of " #src ": ") + hipGetErrorString(_e);  \
+      return QR_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
 #define QR_FAIL(ctx, code, msg) \
   do {                          \
     (ctx)->err = (msg);         \

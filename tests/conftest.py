@@ -33,3 +33,16 @@ def _torch_hip_runtime_first():
     except Exception:
         pass
     yield
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _no_readback_was_read_twice():
+    """the polled read-backs validate themselves and re-read what does not fit -- a
+    retry must not be absorbed silently.  Every context's count is added up when it is closed
+    (quickrank_amd/_capi.py); the session fails if any read-back was ever read twice."""
+    yield
+    mod = sys.modules.get("quickrank_amd._capi")
+    if mod is not None:
+        for ctx in list(mod._LIVE or ()):
+            ctx.close()
+        assert mod.READBACK_RETRIES == 0, f"{mod.READBACK_RETRIES} re-reads of polled read-backs (qr_readback_retries)"

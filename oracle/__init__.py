@@ -181,6 +181,9 @@ def ref():
                                 C.c_void_p, C.c_void_p]
     R.ref_heap_trace.argtypes = [f64p, i32p, sz, sz, i32p, u64p]
     R.ref_sym_index.argtypes = [sz, u64p]
+    R.ref_sorted_labels.argtypes = [f32p, f64p, sz, sz, f32p]
+    R.ref_dataset_layout.argtypes = [f32p, f32p, u32p, sz, sz, u64p, C.c_void_p, C.c_void_p]
+    R.ref_dataset_layout.restype = sz
     R.ref_svml_write.argtypes = [C.c_char_p, f32p, f32p, u64p, sz, sz]
     _REF = R
     return R

@@ -240,4 +240,34 @@ void ref_sym_index(size_t size, uint64_t *out) {
     for (size_t j = 0; j < size; ++j) out[i * size + j] = (uint64_t)(m.vectat(i, j) - m.vectat(0, 0));
 }
 
+// QueryResults::sorted_labels (queryresults.cc:55-62): the labels of the first `cutoff` ranks
+void ref_sorted_labels(const float *labels, const double *scores, size_t n, size_t cutoff, float *dest) {
+  data::QueryResults qr(n, const_cast<float *>(labels), nullptr);
+  qr.sorted_labels(scores, dest, cutoff);
+}
+
+// Dataset::addInstance over a qid COLUMN (dataset.cc:63-87: a new query at every change of
+// qid, repeated and non-monotone ids included) and the VerticalDataset made of it
+// (vertical_dataset.cc: feature-major transposition).  Returns the number of queries;
+// offsets_out[nq + 1], vertical_out [F][N], vertical_offsets_out[nq + 1] (when not null).
+size_t ref_dataset_layout(const float *rowmajor, const float *labels, const uint32_t *qids, size_t N, size_t F,
+                          uint64_t *offsets_out, float *vertical_out, uint64_t *vertical_offsets_out) {
+  auto ds = std::make_shared<data::Dataset>(N, F);
+  for (size_t i = 0; i < N; ++i) {
+    std::vector<Feature> x(rowmajor + i * F, rowmajor + (i + 1) * F);
+    ds->addInstance((QueryID)qids[i], labels[i], x);
+  }
+  const size_t nq = ds->num_queries();
+  if (offsets_out)
+    for (size_t q = 0; q <= nq; ++q) offsets_out[q] = ds->offset(q);
+  if (vertical_out) {
+    data::VerticalDataset v(ds);
+    for (size_t f = 0; f < F; ++f)
+      for (size_t i = 0; i < N; ++i) vertical_out[f * N + i] = *v.at(i, f);
+    if (vertical_offsets_out)
+      for (size_t q = 0; q <= v.num_queries(); ++q) vertical_offsets_out[q] = v.offset(q);
+  }
+  return nq;
+}
+
 }  // extern "C"

@@ -51,6 +51,25 @@ def make(name, cutoff, nthr, score_kind, **case):
     um = np.zeros(n0, np.uint64)
     R.ref_jacobian(1, np.ascontiguousarray(labels[:n0]), np.ascontiguousarray(scores[:n0]), n0,
                    cutoff, jac, sl, um)
+    # the jacobian of EVERY query under both metrics (ndcg.cc:60-93, dcg.cc:59-84: packed upper
+    # triangles, one after the other) and QueryResults::sorted_labels with the cutoff
+    # (queryresults.cc:55-62): what the pair loop of lambdamart.cc:104-141 consumes
+    jac_off = np.zeros(len(qoff), np.uint64)
+    jn, jd, slc_ = [], [], np.full(N, -1.0, np.float32)
+    for q in range(len(qoff) - 1):
+        a, b = int(qoff[q]), int(qoff[q + 1])
+        n = b - a
+        tri = n * (n + 1) // 2
+        jac_off[q + 1] = jac_off[q] + tri
+        for m, dst in ((1, jn), (0, jd)):
+            j = np.zeros(max(tri, 1))
+            R.ref_jacobian(m, np.ascontiguousarray(labels[a:b]), np.ascontiguousarray(scores[a:b]), n, cutoff, j,
+                           np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.uint64))
+            dst.append(j[:tri])
+        d = np.full(max(n, 1), -1.0, np.float32)
+        R.ref_sorted_labels(np.ascontiguousarray(labels[a:b]), np.ascontiguousarray(scores[a:b]), n, cutoff, d)
+        slc_[a:b] = d[:n]
+    jac_ndcg_all, jac_dcg_all = np.concatenate(jn), np.concatenate(jd)
     # thresholds come from Mart::init, which is not buildable here (pugixml): the
     # restatement supplies them; the bin map and histograms are the reference's.
     col = np.ascontiguousarray(x.T)
@@ -98,7 +117,8 @@ def make(name, cutoff, nthr, score_kind, **case):
                         right_ss=gss.value, split_feature=sf, split_slot=st, split_left_ids=sleft,
                         split_left_sum=sls, split_left_count=slc, split_left_ss=slss.value,
                         split_right_sum=srs, split_right_count=src, split_right_ss=srss.value,
-                        argsort=argsort.astype(np.uint32), dcg_per_query=dcg_q, dcg_dataset=dcg_ds)
+                        argsort=argsort.astype(np.uint32), dcg_per_query=dcg_q, dcg_dataset=dcg_ds,
+                        jac_off=jac_off, jac_ndcg_all=jac_ndcg_all, jac_dcg_all=jac_dcg_all, sorted_labels_cut=slc_)
 
 
 def make_svml(name):
@@ -140,6 +160,28 @@ def make_svml(name):
                         qoff=qoff, w_x=wx, w_labels=wl, w_qoff=wq, w_text=written)
 
 
+def make_layout(name):
+    """Dataset::addInstance over a qid column with repeated and non-monotone ids (dataset.cc:63-87)
+    and the VerticalDataset built from it (vertical_dataset.cc): query offsets and the
+    feature-major matrix as the REFERENCE lays them out."""
+    R = oracle.ref()
+    rng = np.random.default_rng(99)
+    N, F = 211, 7
+    x = rng.standard_normal((N, F)).astype(np.float32)
+    labels = rng.integers(0, 5, N).astype(np.float32)
+    runs = rng.integers(1, 9, 60)
+    ids = rng.integers(1, 12, 60)             # few values: ids repeat and go up and down
+    ids[5] = ids[4]                           # two consecutive runs of ONE id are one query
+    qids = np.repeat(ids, runs)[:N].astype(np.uint32)
+    assert len(qids) == N
+    offs = np.zeros(N + 1, np.uint64)
+    vert = np.zeros((F, N), np.float32)
+    voffs = np.zeros(N + 1, np.uint64)
+    nq = R.ref_dataset_layout(x, labels, qids, N, F, offs, vert.ctypes.data, voffs.ctypes.data)
+    np.savez_compressed(os.path.join(HERE, name), x=x, labels=labels, qids=qids, qoff=offs[:nq + 1],
+                        vertical=vert, vertical_qoff=voffs[:nq + 1])
+
+
 def make_heap(name):
     """MaxHeap<int> traces (maxheap.h:58-88): push / pop sequences with equal, few-valued
     and random keys; top and size after every operation, from the reference's header."""
@@ -170,6 +212,7 @@ def make_heap(name):
 if __name__ == "__main__":
     oracle.build(ref=True)
     make_heap("heap_sym.npz")
+    make_layout("layout.npz")
     make_svml("svml.npz")
     make("g1_ties_zero.npz", 10, 16, "zero", nq=12, docs_per_query=40, F=6, seed=31, ragged=True)
     make("g2_ties_few.npz", 10, 255, "few", nq=10, docs_per_query=50, F=8, seed=32, adversarial=True)

@@ -182,27 +182,9 @@ __global__ __launch_bounds__(256) void k_bins_fm(const uint8_t *__restrict__ bin
   }
 }
 
-// QR_ROWS64=1 (an experiment): every block's rows again, one 64-byte line per document
-__global__ __launch_bounds__(256) void k_bins64(const uint8_t *__restrict__ bins, const uint32_t N, const QrBlock blk,
-                                                uint8_t *__restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // (document, 16-byte chunk)
-  const size_t d = i >> 2;
-  const uint32_t ch = (uint32_t)(i & 3);
-  if (d >= N) return;
-  uint4 v = make_uint4(0, 0, 0, 0);
-  if (16 * ch < (uint32_t)blk.fw) v = *reinterpret_cast<const uint4 *>(bins + blk.off + d * blk.fw + 16 * ch);
-  *reinterpret_cast<uint4 *>(out + d * 64 + 16 * ch) = v;
-}
-
 int qr_k_binning(qr_ctx *c) {
   const int rc = qr_k_binning_blocks(c);
   if (rc) return rc;
-  if (c->d_bins64)
-    for (int b = 0; b < c->nblocks; ++b) {
-      hipLaunchKernelGGL(k_bins64, dim3((unsigned)((c->N * 4 + 255) / 256)), dim3(256), 0, c->stream, c->d_bins,
-                         (uint32_t)c->N, c->blocks[b], c->d_bins64 + (size_t)b * c->N * 64);
-      QR_CHECK(c, hipGetLastError());
-    }
   for (int b = 0; b < c->nblocks; ++b) {
     const QrBlock &blk = c->blocks[b];
     hipLaunchKernelGGL(k_bins_fm, dim3((unsigned)((c->N + 63) / 64)), dim3(256), 0, c->stream,

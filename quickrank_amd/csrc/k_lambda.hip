@@ -1300,12 +1300,10 @@ __global__ __launch_bounds__(64 * W) void k_lambda(const QrLambdaArgs A, const u
 // MSLR-shaped set against 0.456 with 95 VGPRs and two workgroups of 76 KB.)
 #define QR_LU_DYN_DEFAULT 77824
 __global__ __launch_bounds__(64 * QR_LU_W) void k_lambda_u(const QrLambdaArgs A, const QrLambdaPlanDev P,
-                                                           const uint32_t *__restrict__ list,
-                                                           const uint32_t *__restrict__ order) {
+                                                           const uint32_t *__restrict__ list) {
   extern __shared__ __attribute__((aligned(16))) char lds_mem[];
   __shared__ double sh_part[2][QR_LU_W][2 * QR_LAMBDA_RR], sh_red[QR_LU_W][3], sh_expt[64];
-  // (`order`: the workgroup's place in the role numbering, when the dispatch order is not it)
-  const uint32_t b = order ? order[blockIdx.x] : blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+  const uint32_t b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
   if (b < P.nC) {
     // the launch's critical path: the longest queries, first in and ahead of their neighbours
     __builtin_amdgcn_s_setprio(3);
@@ -1418,36 +1416,16 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   // workgroup -- eight packed working sets of up to 128 documents, six of up to 256, or one
   // query of up to `capC` documents -- sized so that two workgroups share a CU.  Queries
   // beyond capC keep their own launches (size class / global scratch) beside it.
-  static const int lu_env = [] {
-    const char *e = getenv("QR_LAMBDA_UNIFIED");
-    return e ? atoi(e) : 1;
-  }();
   auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   // a packed role's capacity (a role whose bound repeats the next one's stays empty: by default
   // no query of more than 256 documents is one wave's work -- measured on the MSLR-shaped set:
   // {512, 256, 128} 0.471 ms per iteration, {256, 256, 128} 0.456)
-  static uint32_t kPackBound[QR_LU_ROLES] = {256, 256, 128};
-  static const int lu_order = [] {
-    if (const char *e = getenv("QR_LU_BOUNDS")) {  // experiments: "512,256,128"
-      unsigned a = 0, b = 0, c3 = 0;
-      if (sscanf(e, "%u,%u,%u", &a, &b, &c3) == 3 && a >= b && b >= c3 && c3 >= 4 && a <= 2048) {
-        kPackBound[0] = a & ~3u;
-        kPackBound[1] = b & ~3u;
-        kPackBound[2] = c3 & ~3u;
-      }
-    }
-    const char *o = getenv("QR_LU_ORDER");
-    return o ? atoi(o) : 0;
-  }();
+  static const uint32_t kPackBound[QR_LU_ROLES] = {256, 256, 128};
   size_t pk_kacc[QR_LU_ROLES], pk_slice[QR_LU_ROLES], pk_per[QR_LU_ROLES];
   // 160 KB / 2 (the kernel's VGPRs allow two workgroups of eight waves per CU) less its static
   // 2 KB (sh_part, sh_red, sh_expt); a packed role takes as many queries per workgroup as fit
   // (three, six and eight at cutoff 10)
-  static const size_t lu_dyn_env = [] {
-    const char *e = getenv("QR_LU_DYN");
-    return e ? (size_t)atol(e) : (size_t)QR_LU_DYN_DEFAULT;
-  }();
-  size_t lu_dyn = lu_dyn_env;
+  size_t lu_dyn = (size_t)QR_LU_DYN_DEFAULT;
   for (int r = 0; r < QR_LU_ROLES; ++r) {
     pk_kacc[r] = std::min<size_t>(kacc, kPackBound[r]);
     pk_slice[r] = a16(lambda_lds(kPackBound[r], pk_kacc[r], false, false));
@@ -1456,7 +1434,7 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
   for (int r = 0; r < QR_LU_ROLES; ++r) pk_per[r] = std::min<size_t>(QR_LU_W, lu_dyn / pk_slice[r]);
   size_t capC = std::min<size_t>(nmax_lds, 4096);
   while (capC > kPackBound[0] && lambda_lds(capC, std::min(kacc, capC), false, false) > lu_dyn) capC -= 4;
-  bool lu_try = lu_env && !sampled && lu_dyn <= limit && capC > kPackBound[0];
+  bool lu_try = !sampled && lu_dyn <= limit && capC > kPackBound[0];
   const int want_tag = (int)nmax_lds + ((int)capC << 16) + (lu_try ? 1 << 30 : 0);
   // (the plan's slices hold `kacc` top ranks: another cutoff is another plan, whatever capC says)
   if (tag != want_tag || c->lu_kacc[which] != kacc) {  // (re)build the classes and the long list for this capacity
@@ -1521,24 +1499,6 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
         ulist.insert(ulist.end(), v.begin(), v.end());
       }
       c->lu_dyn[which] = std::max(lu_dyn, lambda_lds(nmaxC, P.kaccC, false, false));
-      // dispatch order (experiments; 0 = the role numbering itself: longest queries first)
-      c->lu_ordered[which] = lu_order != 0;
-      if (lu_order) {
-        std::vector<uint32_t> ord;
-        const uint32_t nb = P.blocks;
-        if (lu_order == 1) {  // the packed roles first, the eight-wave queries after them
-          for (uint32_t b = P.nC; b < nb; ++b) ord.push_back(b);
-          for (uint32_t b = 0; b < P.nC; ++b) ord.push_back(b);
-        } else {  // groups of eight workgroups (one per XCD) in turn: eight-wave queries, packed ones
-          uint32_t a = 0, b = P.nC;
-          while (a < P.nC || b < nb) {
-            for (int k = 0; k < 8 && a < P.nC; ++k) ord.push_back(a++);
-            for (int k = 0; k < 8 * (lu_order - 1) && b < nb; ++k) ord.push_back(b++);
-          }
-        }
-        ulist.insert(ulist.end(), ord.begin(), ord.end());  // (behind the queries, in the same buffer)
-        c->lu_order_off[which] = ulist.size() - ord.size();
-      }
     }
     // (Measured and left out: the longest queries first inside a class -- the 16-wave launch of the
     // MSLR-shaped set stays at 74 us: its time is its longest query's, not a dispatch-order tail.)
@@ -1667,17 +1627,16 @@ int qr_k_lambda(qr_ctx *c, int which, int metric, size_t cutoff, int mode) {
     int rc = stream_for(li++, &st);
     if (rc) return rc;
     const unsigned grid = P.blocks;
-    const uint32_t *lu_ord = c->lu_ordered[which] ? c->d_lu_list[which] + c->lu_order_off[which] : (const uint32_t *)nullptr;
     if (c->prof_on && c->prof_lambda && !fork && !which && mode == 0) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       QR_CHECK(c, hipEventCreate(&e0));
       QR_CHECK(c, hipEventCreate(&e1));
       hipExtLaunchKernelGGL(k_lambda_u, dim3(grid), dim3(64 * QR_LU_W), lds, st, e0, e1, 0, A, P,
-                            (const uint32_t *)c->d_lu_list[which], lu_ord);
+                            (const uint32_t *)c->d_lu_list[which]);
       c->prof_events_child.push_back({e0, e1});
     } else
       hipLaunchKernelGGL(k_lambda_u, dim3(grid), dim3(64 * QR_LU_W), lds, st, A, P,
-                         (const uint32_t *)c->d_lu_list[which], lu_ord);
+                         (const uint32_t *)c->d_lu_list[which]);
     QR_CHECK(c, hipGetLastError());
   }
   // the longest-running launches first: the largest class, then down

@@ -963,7 +963,7 @@ static int launch_obl_binned(qr_ctx *c, const float *d_x, size_t N, size_t xstri
                      dim3(256), lds_a, c->stream, d_x, (uint32_t)N, (uint32_t)F, (uint32_t)xstride,
                      c->d_ob_thr, c->d_ob_thr_cnt, (uint32_t)c->ob_tmax, lds_thr, (BT *)c->d_sb_bins, 1u);
   QR_CHECK(c, hipGetLastError());
-  if (sizeof(BT) == 1 && c->obs_ready && !getenv("QR_OBL_OLD")) {
+  if (sizeof(BT) == 1 && c->obs_ready) {
     // the workgroups' documents next to one batch of leaf values; two workgroups per CU
     // (the batch was sized at upload for obs_nw 64-document blocks per workgroup)
     return c->obs_nw == 8 ? launch_obl_s<8>(c, N, d_out) : launch_obl_s<4>(c, N, d_out);

@@ -118,10 +118,7 @@ __device__ long long qr_ht[8];
 // 1024-thread workgroup, so this variant keeps the columns packed, four to a register, and
 // extracts the one a step needs (one more VALU instruction under an LDS-bound loop; the
 // empty asm keeps the compiler from hoisting the extractions back into sixteen registers).
-// R64 (an experiment, QR_ROWS64=1; child launches only): the rows come from a copy of the bins
-// with one 64-byte line per (document, block) -- a gathered row then costs one line, where a
-// 48-byte row of the compact matrix straddles two lines every other time.
-template <int CH, bool IDENTITY, bool SUMS = false, bool R64 = false>
+template <int CH, bool IDENTITY, bool SUMS = false>
 __device__ __forceinline__ void hist_accumulate(
     u64 *__restrict__ hist, const uint8_t *__restrict__ bins_b,
     const uint32_t *__restrict__ order, const uint32_t seg_begin, const uint32_t r0,
@@ -197,7 +194,7 @@ __device__ __forceinline__ void hist_accumulate(
     return IDENTITY ? seg_begin + p : order[seg_begin + p];
   };
   auto load_row = [&](uint32_t id) -> uint4 {
-    return *reinterpret_cast<const uint4 *>(bins_b + (size_t)id * (R64 ? 64 : FW) + 16 * c);
+    return *reinterpret_cast<const uint4 *>(bins_b + (size_t)id * FW + 16 * c);
   };
   // Loads are unconditional (positions clamped into the range) so that no
   // exec-masked branch surrounds a VMEM instruction: the compiler then emits
@@ -251,7 +248,7 @@ __device__ __forceinline__ void hist_run(
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const double scale, u64 *__restrict__ partials, const bool tr = false, const int fw_known = 0,
     const size_t off_known = 0, double *__restrict__ sums_out = nullptr, const u64 slot_word = 0,
-    const bool use_slot = false, const bool r64 = false);
+    const bool use_slot = false);
 
 // One workgroup's share of a node histogram: workgroup `wg` of the `G` that the
 // plan hands to a node of n documents; partial slots start at `slot_base`.
@@ -288,8 +285,7 @@ __device__ __forceinline__ void hist_run(
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const double scale, u64 *__restrict__ partials, const bool tr, const int fw_known,
-    const size_t off_known, double *__restrict__ sums_out, const u64 slot_word, const bool use_slot,
-    const bool r64) {
+    const size_t off_known, double *__restrict__ sums_out, const u64 slot_word, const bool use_slot) {
   // (batched growth hands the block's geometry over with the workgroup's share: one
   // dependent read less before the first bins can be requested)
   const int fw = fw_known ? fw_known : blocks[b].fw;
@@ -301,14 +297,6 @@ __device__ __forceinline__ void hist_run(
   double sq = 0.0, sm = 0.0;  // (sums_out) this lane's documents of chunk 0, in list order
   for (uint32_t s0 = r0; s0 < r1; s0 += QR_DPW, ++k) {
     const uint32_t s1 = (s0 + QR_DPW < r1) ? s0 + QR_DPW : r1;
-    if (SUMS && r64) {
-      switch (fw) {
-        case 16: hist_accumulate<1, false, true, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
-        case 32: hist_accumulate<2, false, true, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
-        case 48: hist_accumulate<3, false, true, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
-        default: hist_accumulate<4, false, true, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
-      }
-    } else
     if (SUMS) {
       switch (fw) {
         case 16: hist_accumulate<1, false, true>(hist, bins_b, order, seg_begin, s0, s1, lambda, scale, &sq, &sm); break;
@@ -473,17 +461,11 @@ __global__ __launch_bounds__(1024) void k_hist_batch(
     const QrHistWg *__restrict__ wgs, const QrBlock *__restrict__ blocks,
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
-    const QrScalars *__restrict__ scal, u64 *__restrict__ partials, double *__restrict__ histsum,
-    const uint8_t *__restrict__ bins64 = nullptr, const uint32_t N64 = 0) {
+    const QrScalars *__restrict__ scal, u64 *__restrict__ partials, double *__restrict__ histsum) {
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
   QR_HT(0);
   const QrHistWg d = wgs[blockIdx.x];
   if (d.count == 0) return;
-  if (bins64) {  // (QR_ROWS64=1: the line-aligned copy, block b at b * N * 64)
-    hist_run<true>(hist, d.begin, 0, d.count, d.buf, d.block, d.slot, blocks, bins64, order0, order1, lambda,
-                   scal->scale, partials, true, (int)d.fw, (size_t)d.block * N64 * 64, histsum, 0, false, true);
-    return;
-  }
   // (every workgroup also adds up its documents' pseudo-responses -- k_redscan reads the pairs
   // of feature block 0's workgroups; the others' are the same numbers and cost nothing)
   hist_run<true>(hist, d.begin, 0, d.count, d.buf, d.block, d.slot, blocks, bins, order0, order1, lambda,
@@ -3227,18 +3209,12 @@ struct QrNodesOut;
 __device__ __forceinline__ void nodes_out_publish(QrNodesOut *out, const long long seq);
 __device__ __forceinline__ void nodes_out_write(const QrTreeState *ts, QrNodesOut *out, const long long seq);
 
-// `ticket` != null (QR_LEAF_FUSE=1: measured, not kept -- qr_k_tree_finish says why): the LAST
-// workgroup to leave its partials behind also does what k_leaf_final does -- the leaves' sums
-// over the slices in k_leaf_final's order (a lane's slices 512 apart, wave_sum: the same bits),
-// the outputs of rt.cc:165-207, the tree's records into the pinned block -- instead of a launch
-// of one workgroup behind this one.
 template <bool WALK>
 __global__ __launch_bounds__(256) void k_leaf_sums_doc(
     const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm, const uint32_t N,
     const int32_t *__restrict__ gf2lf, const int wide, uint8_t *__restrict__ leafb,
     const double *__restrict__ lambda, const double *__restrict__ weight,
-    const uint8_t *__restrict__ present, double *__restrict__ part, uint32_t *__restrict__ ticket = nullptr,
-    QrTreeState *tsw = nullptr, const int newton = 0, QrNodesOut *nodes_out = nullptr, const long long seq = 0) {
+    const uint8_t *__restrict__ present, double *__restrict__ part) {
   constexpr int NN = 2 * QR_LDOC;  // nodes of a tree of QR_LDOC leaves (2 L - 1)
   // s_rec[n]: what a step of the walk needs of node n in ONE LDS word -- bit 31 = leaf;
   // a leaf: its DFS index; an internal node: left | right << 8 | index of its test << 16
@@ -3265,14 +3241,7 @@ __global__ __launch_bounds__(256) void k_leaf_sums_doc(
     right = nd.right;
     leafid = nd.leaf_id;
   }
-  if (incomplete) {  // (the host carries the tree on and enqueues the leaf kernels again)
-    if (ticket && blockIdx.x == 0 && threadIdx.x == 0) {  // ... told as k_leaf_final tells it
-      nodes_out->pad[0] = 1;
-      nodes_out->pad[1] = ts->real_steps;
-      nodes_out_publish(nodes_out, seq);
-    }
-    return;
-  }
+  if (incomplete) return;  // (the host carries the tree on and enqueues the leaf kernels again)
   const int nn = nn_all < NN ? nn_all : NN;
   if (WALK && threadIdx.x < 64) {  // one wave: records + compaction of the tests by ballot
     const int i = threadIdx.x;
@@ -3417,50 +3386,6 @@ __global__ __launch_bounds__(256) void k_leaf_sums_doc(
     }
     part[2 * e] = a;
     part[2 * e + 1] = b;
-  }
-  if (ticket) {
-    __shared__ uint32_t s_last;
-    __threadfence();  // (this workgroup's partials, device-wide, before its ticket)
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) *ticket = 0;  // (the next tree's launch starts from zero)
-    __threadfence();  // (everybody's partials, before they are read)
-    const int wave = threadIdx.x >> 6;
-    const uint32_t dense_slices = gridDim.x;
-    for (int l2 = wave; l2 < nl; l2 += 4) {  // one wave per leaf, k_leaf_final's reduction tree
-      double s1 = 0.0, s2 = 0.0;
-      for (uint32_t s = lane; s < dense_slices; s += 8 * 64) {
-        double2 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const uint32_t sk = s + 64u * k;
-          v[k] = sk < dense_slices ? *reinterpret_cast<const double2 *>(part + 2 * ((size_t)l2 * dense_slices + sk))
-                                   : make_double2(0.0, 0.0);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (s + 64u * k < dense_slices) {
-            s1 += v[k].x;
-            s2 += v[k].y;
-          }
-      }
-      s1 = wave_sum(s1);
-      s2 = wave_sum(s2);
-      if (lane == 0) {
-        double v;
-        if (newton)
-          v = s2 >= 2.2204460492503131e-16 ? s1 / s2 : 0.0;  // DBL_EPSILON
-        else
-          v = s1 / (double)(tsw->leaf_begin[l2 + 1] - tsw->leaf_begin[l2]);
-        tsw->leaf_value[l2] = v;
-        tsw->nodes[tsw->leaf_nodes[l2]].value = v;
-      }
-    }
-    __threadfence();
-    __syncthreads();
-    nodes_out_write(tsw, nodes_out, seq);
   }
 #ifdef QR_LEAF_TIMING
   LT(5);
@@ -4434,13 +4359,10 @@ static int launch_hist_scan(qr_ctx *c, int root_mode, bool fused = false) {
   const uint32_t rootn = (uint32_t)(c->sub_k ? c->sub_n : c->N);  // documents of the root node
   if (root_mode) {
     const int root_buf = c->sub_k ? 0 : 2;  // the sample's list / every document
-    const QrHistWg *shares = nullptr;
-    if (!c->no_root_shares) {
-      const int src = root_shares(c, rootn, G, root_buf);
-      if (src) return src;
-      shares = c->d_root_wg;
-      shares_scan = c->d_root_scan;
-    }
+    const int src = root_shares(c, rootn, G, root_buf);
+    if (src) return src;
+    const QrHistWg *shares = c->d_root_wg;
+    shares_scan = c->d_root_scan;
     if (prof) {
       // bench.py's roofline: the two events are attached to the launch itself (they
       // take the kernel's own begin / end timestamps, like the profiler's trace)
@@ -4630,14 +4552,12 @@ static int launch_batch_hist_scan(qr_ctx *c, const unsigned hg, const uint32_t r
     QR_CHECK(c, hipEventCreate(&e1));
     hipExtLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, e0, e1, 0, c->d_lhist_wg,
                           c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
-                          c->d_scalars, (u64 *)c->d_lpartials, c->d_lhistsum, (const uint8_t *)c->d_bins64,
-                          (uint32_t)c->N);
+                          c->d_scalars, (u64 *)c->d_lpartials, c->d_lhistsum);
     c->prof_events_child.push_back({e0, e1});
   } else
     hipLaunchKernelGGL(k_hist_batch, dim3(hg), dim3(1024), lds, c->stream, c->d_lhist_wg,
                        c->d_blocks, c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda,
-                       c->d_scalars, (u64 *)c->d_lpartials, c->d_lhistsum, (const uint8_t *)c->d_bins64,
-                       (uint32_t)c->N);
+                       c->d_scalars, (u64 *)c->d_lpartials, c->d_lhistsum);
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_redscan, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_tree, 0,
                      rootn, c->d_lplan, c->d_blocks, c->nblocks, c->ncu, (const u64 *)c->d_lpartials,
@@ -4842,7 +4762,7 @@ int qr_k_dbatch_apply(qr_ctx *c, size_t nleaves) {
   }
   hipLaunchKernelGGL(k_hist_batch, dim3(g.hg), dim3(1024), hist_lds(c), c->stream, c->d_lhist_wg, c->d_blocks,
                      c->d_bins, c->d_order[0], c->d_order[1], c->d_lambda, c->d_scalars, (u64 *)c->d_lpartials,
-                     c->d_lhistsum, (const uint8_t *)c->d_bins64, (uint32_t)c->N);
+                     c->d_lhistsum);
   QR_CHECK(c, hipGetLastError());
   hipLaunchKernelGGL(k_bd_reduce, dim3(c->flocal, QR_BATCH), dim3(1024), 0, c->stream, c->d_lscan_wg,
                      (const u64 *)c->d_lpartials, c->flocal, c->d_xb, c->d_hcnt_loc, c->d_lhistsum, c->rank,
@@ -5022,21 +4942,6 @@ int qr_k_tree_finish(qr_ctx *c, int newton) {
   const double *wgt = newton ? c->d_weight : (const double *)nullptr;
   const uint8_t *present = c->sub_k ? c->d_present : (const uint8_t *)nullptr;
   c->leafb_valid = false;
-  // (QR_LEAF_FUSE=1, an experiment that is NOT kept: the last of the 977 workgroups doing
-  // k_leaf_final's work saves that launch and costs 57 us per iteration at 1M documents --
-  // 0.410 -> 0.467 ms; the device-scope fence every workgroup needs before its ticket writes its
-  // XCD's L2 back, 977 times)
-  static const bool fuse_env = getenv("QR_LEAF_FUSE") && atoi(getenv("QR_LEAF_FUSE")) != 0;
-  if (doc_path && walk && !c->dmode && fuse_env && c->d_leaf_ticket) {
-    // (the last workgroup finishes the leaves: no k_leaf_final launch behind this one)
-    hipLaunchKernelGGL(k_leaf_sums_doc<true>, dim3(sgrid), dim3(256), 0, c->stream, c->d_tree,
-                       c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm, (uint32_t)c->N,
-                       c->d_gf2lf, c->wide ? 1 : 0, c->d_leafb, c->d_lambda, wgt, present, c->d_leafpart,
-                       c->d_leaf_ticket, c->d_tree, newton, &c->d_pin->tree, (long long)++c->nodes_seq);
-    QR_CHECK(c, hipGetLastError());
-    c->leafb_valid = true;  // every document has walked
-    return QR_OK;
-  }
   if (doc_path && walk) {
     hipLaunchKernelGGL(k_leaf_sums_doc<true>, dim3(sgrid), dim3(256), 0, c->stream, c->d_tree,
                        c->wide ? reinterpret_cast<const uint8_t *>(c->d_wbins) : c->d_bins_fm, (uint32_t)c->N,
@@ -5112,12 +5017,11 @@ int qr_k_scores_update(qr_ctx *c, double shrinkage, bool repeat) {
   // the next iteration, which reads every score anyway (mart.cc:464-467 -> lambdamart.cc:70):
   // one launch and 16 N bytes less per iteration.  Whoever else looks at the scores first
   // (tree_settle) has it launched after all.  QR_LAZY_SCORES=0: always at once.
-  static const bool lazy_env = !(getenv("QR_LAZY_SCORES") && atoi(getenv("QR_LAZY_SCORES")) == 0);
   if (c->lazy_scores && !repeat) {  // (a second update behind one that nobody consumed: that one first)
     const int frc = qr_k_scores_flush(c);
     if (frc) return frc;
   }
-  if (c->leafb_valid && lazy_env && c->world == 1 && !c->dmode && !c->sub_k) {
+  if (c->leafb_valid && !c->no_lazy_scores && c->world == 1 && !c->dmode && !c->sub_k) {
     c->lazy_scores = true;
     c->lazy_shrinkage = shrinkage;
   } else

@@ -104,15 +104,14 @@ int qr_ctx_create(int device, qr_ctx **out) {
   qr_ctx *c = new qr_ctx();
   c->no_batch = getenv("QR_NO_BATCH") != nullptr;
   c->no_defer = getenv("QR_NO_DEFER_PREP") != nullptr;
-  c->no_root_shares = getenv("QR_NO_ROOT_SHARES") != nullptr;
+  c->no_lazy_scores = getenv("QR_LAZY_SCORES") && atoi(getenv("QR_LAZY_SCORES")) == 0;  // (A/B: tests/test_gpu_parity.py)
   c->obl_own_launches = getenv("QR_OBL_OWN_LAUNCHES") != nullptr;
   c->exact_tail = getenv("QR_EXACT_TAIL") != nullptr;
+  c->spec_debug = getenv("QR_SPEC_DEBUG") != nullptr;   // (diagnostic lines on stderr; no code path depends on it)
   if (getenv("QR_LEAF_BY_POSITION")) c->leaf_by_position = true;
   c->x_eager = getenv("QR_X_EAGER") != nullptr;
   if (const char *e = getenv("QR_FUSE_MAX_DOCS")) c->fuse_max_docs = (size_t)std::max(0l, atol(e));
   if (const char *e = getenv("QR_STEPS_HINT")) c->steps_force = atol(e);  // steps to enqueue, whatever the tree
-  if (const char *e = getenv("QR_STEPS_PLUS")) c->steps_plus = (size_t)std::max(0l, atol(e));
-  if (const char *e = getenv("QR_CONT_STEPS")) c->cont_steps = (size_t)std::max(0l, atol(e));
   c->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -128,7 +127,7 @@ int qr_ctx_create(int device, qr_ctx **out) {
     }
     if (blk) c->lds_block = blk;
     if (cu) c->lds_cu = cu;
-    if (getenv("QR_SPEC_DEBUG"))
+    if (c->spec_debug)
       fprintf(stderr, "qr: %s, %d CUs, LDS per workgroup %zu (optin %zu, default %zu), per CU %zu\n", prop.gcnArchName,
               c->ncu, c->lds_block, (size_t)prop.sharedMemPerBlockOptin, (size_t)prop.sharedMemPerBlock,
               (size_t)prop.maxSharedMemoryPerMultiProcessor);
@@ -179,7 +178,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_raw); dfree(c->d_labels); dfree(c->d_qoff);
   dfree(c->d_scores); dfree(c->d_lambda); dfree(c->d_weight);
   dfree(c->d_idcg); dfree(c->d_qmetric); dfree(c->d_ranks); dfree(c->d_ssq); dfree(c->d_qmax);
-  dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins); dfree(c->d_bins64); dfree(c->d_bins_fm);
+  dfree(c->d_blocks); dfree(c->d_lf2gf); dfree(c->d_gf2lf); dfree(c->d_bins); dfree(c->d_bins_fm);
   dfree(c->d_thr); dfree(c->d_thr_size);
   dfree(c->d_woff); dfree(c->d_wthr); dfree(c->d_wbins); dfree(c->d_wbins16);
   if (c->d_wpart) (void)hipFree(c->d_wpart);
@@ -202,7 +201,7 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_red_sum); dfree(c->d_red_cnt);
   dfree(c->d_hsum); dfree(c->d_hcnt); dfree(c->d_featrec); dfree(c->d_featthr); dfree(c->d_lscan_wg);
   dfree(c->d_recs_local); dfree(c->d_recs_all); dfree(c->d_mask);
-  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_lpart_ss2); dfree(c->d_jobsum); dfree(c->d_bpart_state); dfree(c->d_tree); dfree(c->d_tree2); dfree(c->d_leafpart); dfree(c->d_leafb); dfree(c->d_leaf_ticket);
+  dfree(c->d_red_cnt_loc); dfree(c->d_hcnt_loc); dfree(c->d_part_state); dfree(c->d_part_ss); dfree(c->d_lpart_ss); dfree(c->d_lpart_ss2); dfree(c->d_jobsum); dfree(c->d_bpart_state); dfree(c->d_tree); dfree(c->d_tree2); dfree(c->d_leafpart); dfree(c->d_leafb);
   dfree(c->d_lhist_map); dfree(c->d_lpart_map); dfree(c->d_lpartials); dfree(c->d_lhistsum);
   dfree(c->d_lpart_state);
   dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
@@ -242,7 +241,7 @@ static void free_valid(qr_ctx *c) {
 
 void qr_ctx_destroy(qr_ctx *c) {
   if (!c) return;
-  if (getenv("QR_SPEC_DEBUG") && c->spec_trees)
+  if (c->spec_debug && c->spec_trees)
     fprintf(stderr, "qr: %llu trees with a guessed step count, %llu continued (guess too low), last hint %zu\n",
             (unsigned long long)c->spec_trees, (unsigned long long)c->spec_misses, c->steps_hint);
   if (c->readback_retries)   // (never silent: this is the evidence round 5's hunt was after)
@@ -685,7 +684,6 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, hipMemcpy(c->d_thr_size, c->h_thr_size.data(), F * 4, hipMemcpyHostToDevice));
   // ---- bin map
   QR_CHECK(c, dalloc(&c->d_bins, c->bins_bytes));
-  if (getenv("QR_ROWS64") && atoi(getenv("QR_ROWS64"))) QR_CHECK(c, dalloc(&c->d_bins64, (size_t)c->nblocks * N * 64));
   QR_CHECK(c, dalloc(&c->d_bins_fm, (size_t)c->flocal * N));
   QR_CHECK(c, dalloc(&c->d_blocks, (size_t)c->nblocks));
   QR_CHECK(c, hipMemcpy(c->d_blocks, c->blocks.data(), c->nblocks * sizeof(QrBlock), hipMemcpyHostToDevice));
@@ -750,10 +748,6 @@ static int bins_finish(qr_ctx *c) {
   QR_CHECK(c, dalloc(&c->d_tree2, (size_t)1));
   QR_CHECK(c, hipMemset(c->d_tree2, 0, sizeof(QrTreeState)));
   QR_CHECK(c, dalloc(&c->d_leafpart, std::max<size_t>(2 * (N / QR_SLICE + QR_MAXNODES + 4), 32 * (N / QR_SLICE + 2))));
-  if (!c->d_leaf_ticket) {
-    QR_CHECK(c, dalloc(&c->d_leaf_ticket, (size_t)16));
-    QR_CHECK(c, hipMemset(c->d_leaf_ticket, 0, 64));
-  }
   QR_CHECK(c, dalloc(&c->d_leafb, N + 16));
   QR_CHECK(c, hipStreamSynchronize(c->stream));
   c->binned = true;
@@ -1043,10 +1037,10 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
       if ((rc = qr_k_exact_build(c))) {
         (void)hipGetLastError();  // (an allocation failure is not sticky)
         qr_k_exact_free(c);
-        if (getenv("QR_SPEC_DEBUG")) fprintf(stderr, "qr: pre-sorted lists not built (%s): slot-indexed histograms\n", c->err.c_str());
+        if (c->spec_debug) fprintf(stderr, "qr: pre-sorted lists not built (%s): slot-indexed histograms\n", c->err.c_str());
         rc = QR_OK;
       }
-    } else if (getenv("QR_SPEC_DEBUG"))
+    } else if (c->spec_debug)
       fprintf(stderr, "qr: %zu MB free, the pre-sorted lists need %zu MB: slot-indexed histograms\n", mfree >> 20, need >> 20);
   }
   // ---- tree working set of the one-split-per-step path
@@ -1076,10 +1070,6 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
     QR_CHECK(c, hipMemset(c->d_bpart_state, 0, (N / QR_PART_SLICE + QR_BATCH + 2) * 8));
   }
   QR_CHECK(c, dalloc(&c->d_leafpart, std::max<size_t>(2 * (N / QR_SLICE + QR_MAXNODES + 4), 32 * (N / QR_SLICE + 2))));
-  if (!c->d_leaf_ticket) {
-    QR_CHECK(c, dalloc(&c->d_leaf_ticket, (size_t)16));
-    QR_CHECK(c, hipMemset(c->d_leaf_ticket, 0, 64));
-  }
   QR_CHECK(c, dalloc(&c->d_leafb, N + 16));
   if (c->dmode) {
     // the histogram exchange buffer of the document-sharded protocol: [cells] sums, [cells] counts
@@ -1589,7 +1579,7 @@ static int tree_settle_keep(qr_ctx *c) {
                                "steps it asks for come first (include/qr_hip.h)");
     c->dbatch_pending = c->dbatch_unsettled = false;
     ++c->spec_trees;
-    c->steps_hint = (size_t)((w >> 1) & 0x7fff) + c->steps_plus;
+    c->steps_hint = (size_t)((w >> 1) & 0x7fff);
     if (c->steps_hint < 1) c->steps_hint = 1;
     c->spec_scores_enqueued = false;
   }
@@ -1603,19 +1593,19 @@ static int tree_settle_keep(qr_ctx *c) {
   c->spec_pending = false;
   ++c->spec_trees;
   if (w & 1) ++c->spec_misses;
-  // The guess was too low: the tree is carried on `cont_steps` steps at a time (default 1: the
+  // The guess was too low: the tree is carried on one step at first (the
   // tree usually needs just one more, and the worst case left would be a dozen launches that
   // find nothing to do), looking at the last control call's word after each piece.
   // (the piece doubles on every further miss -- 1, 2, 4, ... steps -- so a deep tree
   // behind a shallow one costs O(log k) host round trips, not k)
   size_t done = (size_t)c->tree_step;
-  size_t piece_len = c->cont_steps;
+  size_t piece_len = 1;
   while (w & 1) {
     // (pre-sorted lists, split search at the pop: a step that found no valid split used one of the
     // enqueued steps; every node is popped at most once, so 2 L + 1 steps bound the tree)
     const size_t cap = c->spec_exact ? 2 * c->cur_nleaves + 2 : c->cur_nleaves - 1;
     const size_t worst = cap > done ? cap - done : 1;
-    const size_t piece = piece_len ? std::min(worst, piece_len) : worst;
+    const size_t piece = std::min(worst, piece_len);
     piece_len *= 2;
     if (c->spec_exact)
       rc = qr_k_exact_continue(c, piece);
@@ -1633,8 +1623,8 @@ static int tree_settle_keep(qr_ctx *c) {
     c->spec_exact = false;
     return QR_OK;
   }
-  // the next tree: as many steps as this one needed, plus `steps_plus` (QR_STEPS_PLUS)
-  c->steps_hint = (size_t)((w >> 1) & 0x7fff) + c->steps_plus;
+  // the next tree: as many steps as this one needed
+  c->steps_hint = (size_t)((w >> 1) & 0x7fff);
   if (c->steps_hint < 1) c->steps_hint = 1;
   return QR_OK;
 }
@@ -1894,7 +1884,7 @@ int qr_tree_batch_settle(qr_ctx *c, int *incomplete, size_t *steps_used) {
   if (steps_used) *steps_used = used;
   if (!(w & 1)) {
     ++c->spec_trees;
-    c->steps_hint = used + c->steps_plus;
+    c->steps_hint = used;
     if (c->steps_hint < 1) c->steps_hint = 1;
     if (c->dbatch_pending) c->spec_scores_enqueued = false;  // (the tree was whole: so is its score update)
     c->dbatch_pending = false;
@@ -2334,7 +2324,7 @@ int qr_ensemble_upload(qr_ctx *c, const qr_node_t *nodes_in, size_t ntrees,
   if (!c || !nodes_in || !weights_in || !ntrees || !max_nodes) return QR_ERR_ARG;
   QR_CHECK(c, hipSetDevice(c->device));
   QR_CHECK(c, hipStreamSynchronize(c->stream));
-  // Depth order (qr_ensemble_set_depth_order / QR_SCORE_DEPTH_ORDER=1; off by default): the trees
+  // Depth order (qr_ensemble_set_depth_order; off by default): the trees
   // are walked -- and their f64 contributions ADDED -- in ascending order of their depth (stable),
   // so that the trees a wave walks in lockstep end together.  The sum of ensemble.cc:111-118 is
   // then taken in another order: equal to the reference's to f64 rounding (~1e-16 relative per
@@ -2344,7 +2334,7 @@ int qr_ensemble_upload(qr_ctx *c, const qr_node_t *nodes_in, size_t ntrees,
   std::vector<qr_node_t> pn;
   std::vector<double> pw;
   c->ens_perm.clear();
-  if (c->ens_depth_order || getenv("QR_SCORE_DEPTH_ORDER")) {
+  if (c->ens_depth_order) {
     std::vector<int> depth(ntrees);
     bool ok = true, differ = false;
     for (size_t t = 0; t < ntrees && ok; ++t) {

@@ -463,11 +463,10 @@ struct qr_ctx {
   size_t lu_dyn[2] = {0, 0};
   bool lu_on[2] = {false, false};
   // Mart::update_modelscores left to the next lambda pass (k_tree.hip: qr_k_scores_update)
+  bool no_lazy_scores = false;        // QR_LAZY_SCORES=0 at context creation: every score update is a launch of its own
   bool lazy_scores = false;
   double lazy_shrinkage = 0.0;
   size_t lu_kacc[2] = {0, 0};  // the top ranks the plan's slices were sized for
-  bool lu_ordered[2] = {false, false};
-  size_t lu_order_off[2] = {0, 0};
   size_t attr_lambda_u_lds = 64 * 1024;
   hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t aux_fork = nullptr, aux_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -499,7 +498,6 @@ struct qr_ctx {
   bool root_wg_valid = false;      // the cached shares match (root_wg_n, root_wg_g, root_wg_buf, root_wg_gen)
   uint64_t blocks_gen = 0;         // counts the rebuilds of c->blocks (bins_finish): part of the cache key
   uint64_t root_wg_gen = 0;
-  bool no_root_shares = false;    // QR_NO_ROOT_SHARES=1: every root workgroup plans for itself (A/B, debugging)
   int obl_reset_nodes = 0;        // level-wise growth: node records the root scan launch's last workgroup resets (0: none)
   bool obl_own_launches = false;  // QR_OBL_OWN_LAUNCHES=1: the tree-state reset and k_finish as launches of their own (A/B, debugging)
   size_t prep_nss = 0;
@@ -543,10 +541,7 @@ struct qr_ctx {
   // continuation has to repeat (leaf kernels with `newton`, the score update with `shrinkage`)
   size_t steps_hint = 0;
   long steps_force = -1;              // QR_STEPS_HINT=k: always enqueue k steps (tests the continuation)
-  size_t steps_plus = 0;              // QR_STEPS_PLUS: spare steps enqueued beyond the previous tree's count (round 3: 0 --
-                                      // with the tree carried on a step at a time on a miss, a spare step's three launches
-                                      // that find nothing to do cost more than the misses: 1.91 -> 1.86 ms at 8M, ~ -2 us at 1M)
-  size_t cont_steps = 1;              // QR_CONT_STEPS: steps per piece when a tree is carried on (0 = all that could be left)
+  bool spec_debug = false;            // QR_SPEC_DEBUG=1: diagnostic lines on stderr
   bool spec_pending = false, spec_scores_enqueued = false;
   int spec_newton = 0;
   double spec_shrinkage = 0.0;
@@ -562,8 +557,6 @@ struct qr_ctx {
   uint64_t *d_lpartials = nullptr;
   double *d_lhistsum = nullptr;       // batched growth: [slot][ss, sum] of the child a histogram workgroup (block 0) read
   unsigned long long *d_lpart_state = nullptr;
-  uint8_t *d_bins64 = nullptr;        // QR_ROWS64=1: [block][doc][64] copy of the bins for the child launches
-  uint32_t *d_leaf_ticket = nullptr;  // k_leaf_sums_doc: the last workgroup to finish does k_leaf_final's work
   double *d_leafpart = nullptr;  // [slices][2] partial sums (k_leaf_sums), or [slices][16][2] (k_leaf_sums_doc)
   uint8_t *d_leafb = nullptr;    // [N] leaf of every document in the last small tree (k_leaf_sums_doc)
   size_t leaf_cap = 0;           // leaves the tree under construction can have (<= 16: the document-order leaf kernels)

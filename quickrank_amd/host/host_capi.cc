@@ -178,12 +178,13 @@ int qrh_model_roundtrip_timed(const char *in_path, const char *out_path, double 
   return 0;
 }
 
-static const double *g_tree_weights = nullptr;  // (qrh_model_write_w; tests and tools are single-threaded callers)
+}  // extern "C"
 
-// write a model from flat node records (qr_node_t layout), as Mart::save would
-int qrh_model_write(const char *path, int algo, size_t ntrees_cfg, double shrinkage, size_t nthresholds,
-                    size_t nleaves, size_t minls, size_t esr, size_t depth, const qr_node_t *nodes,
-                    size_t ntrees, size_t max_nodes) {
+// a model from flat node records (qr_node_t layout), as Mart::save would write it; `weights`:
+// one per tree, or nullptr (= the shrinkage for every tree)
+static int model_write(const char *path, int algo, size_t ntrees_cfg, double shrinkage, size_t nthresholds,
+                       size_t nleaves, size_t minls, size_t esr, size_t depth, const qr_node_t *nodes,
+                       size_t ntrees, size_t max_nodes, const double *weights) {
   using learning::forests::Mart;
   using learning::forests::RTNode;
   // build an XML document directly from the records through the same writer
@@ -209,21 +210,27 @@ int qrh_model_write(const char *path, int algo, size_t ntrees_cfg, double shrink
   for (size_t t = 0; t < ntrees; ++t) {
     xml::Node *tree = ens->append_child("tree");
     tree->append_attribute("id", std::to_string(t + 1));
-    tree->append_attribute("weight", xml::fmt_double(g_tree_weights ? g_tree_weights[t] : shrinkage));
+    tree->append_attribute("weight", xml::fmt_double(weights ? weights[t] : shrinkage));
     B::rec(nodes + t * max_nodes, 0)->append_xml_model(tree);
   }
   return xml::save_file(*doc, path) ? 0 : 1;
+}
+
+extern "C" {
+
+int qrh_model_write(const char *path, int algo, size_t ntrees_cfg, double shrinkage, size_t nthresholds,
+                    size_t nleaves, size_t minls, size_t esr, size_t depth, const qr_node_t *nodes,
+                    size_t ntrees, size_t max_nodes) {
+  return model_write(path, algo, ntrees_cfg, shrinkage, nthresholds, nleaves, minls, esr, depth, nodes, ntrees,
+                     max_nodes, nullptr);
 }
 
 // ... with a weight per tree (quickrank_amd/io.py: the Python trainer's Ensemble keeps one)
 int qrh_model_write_w(const char *path, int algo, size_t ntrees_cfg, double shrinkage, size_t nthresholds,
                       size_t nleaves, size_t minls, size_t esr, size_t depth, const qr_node_t *nodes,
                       size_t ntrees, size_t max_nodes, const double *weights) {
-  g_tree_weights = weights;
-  const int rc = qrh_model_write(path, algo, ntrees_cfg, shrinkage, nthresholds, nleaves, minls, esr, depth, nodes,
-                                 ntrees, max_nodes);
-  g_tree_weights = nullptr;
-  return rc;
+  return model_write(path, algo, ntrees_cfg, shrinkage, nthresholds, nleaves, minls, esr, depth, nodes, ntrees,
+                     max_nodes, weights);
 }
 
 // the <info> block of a model file: out[6] = trees, thresholds, leaves, min leaf support, early-stop
@@ -259,6 +266,34 @@ int qrh_model_read(const char *path, qr_node_t *nodes, double *weights, size_t *
   }
   return 0;
 }
+
+// One parse of a model file for everything a caller wants of it (quickrank_amd/io.load_model): the
+// handle keeps the model object; info / sizes / records are read from it; nullptr for a file that is
+// not a model of the four algorithms.
+struct QrhModel {
+  std::shared_ptr<learning::forests::Mart> m;
+  std::vector<qr_node_t> nodes;
+  std::vector<double> weights;
+  size_t max_nodes = 0;
+};
+void *qrh_model_open(const char *path, int *algo, size_t *out, double *shrinkage, size_t *ntrees, size_t *max_nodes) {
+  std::unique_ptr<QrhModel> h(new QrhModel());
+  h->m = learning::forests::Mart::load_model_from_file(path);
+  if (!h->m) return nullptr;
+  h->m->info(algo, out, shrinkage);
+  h->max_nodes = h->m->ensemble().flatten(&h->nodes, &h->weights);
+  *ntrees = h->weights.size();
+  *max_nodes = h->max_nodes;
+  return h.release();
+}
+int qrh_model_copy(const void *handle, qr_node_t *nodes, double *weights, size_t cap_nodes, size_t cap_trees) {
+  const QrhModel *h = (const QrhModel *)handle;
+  if (h->nodes.size() > cap_nodes || h->weights.size() > cap_trees) return 2;
+  memcpy(nodes, h->nodes.data(), h->nodes.size() * sizeof(qr_node_t));
+  memcpy(weights, h->weights.data(), h->weights.size() * sizeof(double));
+  return 0;
+}
+void qrh_model_close(void *handle) { delete (QrhModel *)handle; }
 
 // `--model-file / --code-file / --generator` without the command line
 int qrh_codegen(const char *generator, const char *model_file, const char *code_file) {

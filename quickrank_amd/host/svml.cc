@@ -30,6 +30,7 @@
 #include "svml.h"
 
 #include <omp.h>
+#include <cerrno>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -232,7 +233,10 @@ std::unique_ptr<data::Dataset> Svml::read_horizontal(const std::string &filename
     exit(EXIT_FAILURE);
   }
   struct stat st;
-  fstat(fd, &st);
+  if (fstat(fd, &st) != 0) {
+    std::cerr << "!!! Error while opening file " << filename << "." << std::endl;
+    exit(EXIT_FAILURE);
+  }
   stats_.bytes = st.st_size;
   const auto t0 = std::chrono::high_resolution_clock::now();
   // the whole text in memory, read by all threads at once (pread: no shared file position),
@@ -242,22 +246,27 @@ std::unique_ptr<data::Dataset> Svml::read_horizontal(const std::string &filename
   {
     const size_t share = 64u << 20;
     const long nshare = (long)((got + share - 1) / share);
-    size_t short_at = got;
+    bool failed = false;
 #pragma omp parallel for schedule(dynamic, 1)
     for (long k = 0; k < nshare; ++k) {
       size_t at = (size_t)k * share;
       const size_t hi = std::min(got, at + share);
       while (at < hi) {
         const ssize_t n = pread(fd, text.get() + at, hi - at, (off_t)at);
-        if (n <= 0) {  // the file shrank under us: what was read up to here is the file
-#pragma omp critical(svml_short_read)
-          short_at = std::min(short_at, at);
+        if (n < 0 && errno == EINTR) continue;
+        if (n <= 0) {  // an I/O error, or the file is shorter than fstat said: a text cut somewhere in
+                       // a line is not a dataset -- the reference's message and exit, not a shorter one
+#pragma omp atomic write
+          failed = true;
           break;
         }
         at += (size_t)n;
       }
     }
-    got = short_at;
+    if (failed) {
+      std::cerr << "!!! Error while reading file " << filename << "." << std::endl;
+      exit(EXIT_FAILURE);
+    }
   }
   close(fd);
   text[got] = '\0';  // strtod / strtof may look one byte past the last token

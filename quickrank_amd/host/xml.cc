@@ -122,6 +122,15 @@ struct Parser {
       else return;
     }
   }
+  void skip_ws_comments() {  // what element() itself skips between an element's children
+    for (;;) {
+      skip_ws();
+      if (!starts("<!--")) return;
+      size_t e = s.find("-->", p);
+      if (e == std::string::npos) { p = s.size(); return; }
+      p = e + 3;
+    }
+  }
   std::string name() {
     size_t b = p;
     while (p < s.size() && !isspace((unsigned char)s[p]) && s[p] != '>' && s[p] != '/' && s[p] != '=') ++p;
@@ -247,7 +256,7 @@ static std::unique_ptr<Node> parse_tree_run_parallel(const std::string &doc) {
         break;
       }
       got[(size_t)t].push_back(std::move(e));
-      ps.skip_misc();  // white space and comments between trees
+      ps.skip_ws_comments();  // between trees: white space and comments, nothing element() would refuse
     }
     if (ps.p != hi && !(hi == B && ps.p >= B)) ok[(size_t)t] = 0;
     if (got[(size_t)t].size() != i1 - i0) ok[(size_t)t] = 0;

@@ -30,6 +30,12 @@ def host():
                                         _sz, _sz, C.c_void_p]
         L.qrh_model_read.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(_sz), C.POINTER(_sz), _sz, _sz]
         L.qrh_model_info.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(_sz), C.POINTER(C.c_double)]
+        L.qrh_model_open.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(_sz), C.POINTER(C.c_double),
+                                     C.POINTER(_sz), C.POINTER(_sz)]
+        L.qrh_model_open.restype = C.c_void_p
+        L.qrh_model_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _sz, _sz]
+        L.qrh_model_close.argtypes = [C.c_void_p]
+        L.qrh_model_close.restype = None
         _HOST = L
     return _HOST
 
@@ -82,15 +88,16 @@ def load_model(path):
     (ltr_algorithm.cc:123: the caller decides)."""
     p = str(path).encode()
     algo, out, shr = C.c_int(), (_sz * 6)(), C.c_double()
-    if host().qrh_model_info(p, C.byref(algo), out, C.byref(shr)) != 0:
-        return None
     nt, mn = _sz(), _sz()
-    if host().qrh_model_read(p, None, None, C.byref(nt), C.byref(mn), 0, 0) != 0:
+    h = host().qrh_model_open(p, C.byref(algo), out, C.byref(shr), C.byref(nt), C.byref(mn))   # the ONE parse
+    if not h:
         return None
-    nodes = np.zeros((nt.value, mn.value), NODE_DTYPE)
-    weights = np.zeros(nt.value, np.float64)
-    if nt.value and host().qrh_model_read(p, nodes.ctypes.data, weights.ctypes.data, C.byref(nt), C.byref(mn),
-                                          nodes.size, nt.value) != 0:
-        raise OSError(f"cannot read {path}")
+    try:
+        nodes = np.zeros((nt.value, mn.value), NODE_DTYPE)
+        weights = np.zeros(nt.value, np.float64)
+        if nt.value and host().qrh_model_copy(h, nodes.ctypes.data, weights.ctypes.data, nodes.size, nt.value) != 0:
+            raise OSError(f"cannot read {path}")
+    finally:
+        host().qrh_model_close(h)
     return dict(algo=ALGOS[algo.value], ntrees=out[0], nthresholds=out[1], nleaves=out[2], minls=out[3], esr=out[4],
                 depth=out[5], shrinkage=shr.value, nodes=nodes, weights=weights)

@@ -878,8 +878,8 @@ def test_ragged_set_single_launch_roles(qr, ora, kind, metric, cutoff, exact_tai
     size-class / global-scratch launches beside it for what is longer), empty-ish queries, every
     kind of tie, cutoffs from 3 to "none" (the pair sweep's rounds of five ranks then run over all
     of a query's ranks).  Ranks bit for bit, the metric bit for bit per query, lambdas to 1e-10.
-    And the other way round: the same set through the launches of round 4 (QR_LAMBDA_UNIFIED=0 is
-    read once per process, so that side is the oracle alone here)."""
+    The size-class launches of round 4 stay for what the one launch does not take (a sample's cleaned
+    lists, queries beyond its capacity) and are covered by the --subsample tests."""
     if exact_tail:
         monkeypatch.setenv("QR_EXACT_TAIL", "1")
     else:
@@ -1108,6 +1108,65 @@ def test_deferred_scalars_survive_any_call_order(qr, monkeypatch):
     monkeypatch.setenv("QR_NO_DEFER_PREP", "1")
     want = run()
     monkeypatch.delenv("QR_NO_DEFER_PREP")
+    assert len(got) == len(want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        if g.dtype.names:
+            for f in g.dtype.names:
+                assert np.array_equal(g[f], w[f]), (i, f)
+        else:
+            assert np.array_equal(g, w), i
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_lazy_score_update_equals_its_own_launch(qr, monkeypatch, ragged):
+    """ADVICE r5: Mart::update_modelscores (mart.cc:447-468) rides in the NEXT lambda pass on a
+    single-GPU context -- between qr_scores_update and that pass the score array on the device is one
+    tree behind, and every entry point that reads or writes it has to settle the pending update
+    first.  QR_LAZY_SCORES=0 (read at context creation) makes every update a launch of its own.
+    The two must agree bit for bit, with the readers a host may call in between -- scores read back,
+    the metric asked for, the pseudo-responses read, the scores replaced, a MART residual pass, an
+    oblivious tree, two updates in a row -- interleaved with the iterations."""
+    from quickrank_amd._capi import Context
+    x, labels, qoff = make_dataset(nq=150, docs_per_query=60, F=24, seed=91, ragged=ragged)
+
+    def run():
+        c = Context(0)
+        c.upload(x, labels, qoff)
+        c.build_bins(64)
+        c.reset_scores()
+        out = []
+        for it in range(9):
+            c.compute_lambdas("NDCG", 10)
+            out.append(np.asarray(c.metric_last()))
+            out.append(c.fit_tree(10, 2, True))
+            c.update_scores(0.1)                       # pending from here on (lazy contexts)
+            if it == 1:
+                out.append(c.get_scores())             # a reader right behind the update
+            if it == 2:
+                out.append(np.asarray(c.metric_eval(0)))
+            if it == 3:
+                out += list(c.get_pseudo())            # (does not touch the scores: stays pending)
+                out.append(c.get_scores())
+            if it == 4:
+                c.compute_residuals()                  # MART's pass reads the scores
+                out.append(c.fit_tree(6, 2, False)); c.update_scores(0.1)
+            if it == 5:
+                out.append(c.fit_oblivious(3, 2, True)); c.update_scores(0.05)   # two updates, no pass between
+            if it == 6:
+                s = c.get_scores(); c.set_scores(s * 0.5)                        # a writer
+            if it == 7:
+                c.update_scores(0.1)                   # the same tree once more: a second update behind a pending one
+        c.compute_lambdas("NDCG", 10)
+        out.append(np.asarray(c.metric_last()))
+        out.append(c.get_scores())
+        c.close()
+        return out
+
+    monkeypatch.delenv("QR_LAZY_SCORES", raising=False)
+    got = run()
+    monkeypatch.setenv("QR_LAZY_SCORES", "0")
+    want = run()
+    monkeypatch.delenv("QR_LAZY_SCORES")
     assert len(got) == len(want)
     for i, (g, w) in enumerate(zip(got, want)):
         if g.dtype.names:

@@ -106,6 +106,24 @@ __global__ __launch_bounds__(256) void k_xflag(const QrTreeState *__restrict__ t
   }
 }
 
+// ... on a FEATURE-sharded context (round 6): only the owner of the winning feature holds its
+// segment; every rank holds the go-left bits the owner published and the ranks all-reduced
+// (k_mask: bit p = position p of the node's segment of the document-order list, the one
+// k_partition has just read), so every rank -- the owner too -- takes its bytes from there.
+__global__ __launch_bounds__(256) void k_xflag_mask(const QrTreeState *__restrict__ ts,
+                                                    const uint32_t *__restrict__ order0,
+                                                    const uint32_t *__restrict__ order1,
+                                                    const uint32_t *__restrict__ mask, uint8_t *__restrict__ goleft) {
+  const QrSplitDesc d = ts->desc;
+  if (!d.active) return;
+  const uint32_t n = d.end - d.begin;
+  const uint32_t *order = d.src_buf == 0 ? order0 : order1;
+  for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    const uint32_t id = d.src_buf == 2 ? d.begin + p : order[d.begin + p];
+    goleft[id] = (uint8_t)((mask[p >> 5] >> (p & 31)) & 1u);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // k_xpart: the split being applied (ts->desc), feature blockIdx.x's segment of the parent,
 // stable partition into the children's segments of the destination lists.  Entries two chunks
@@ -156,7 +174,10 @@ __device__ __forceinline__ long long x_look_back(const u64 *row, const uint32_t 
 __global__ __launch_bounds__(1024) void k_xpart(const QrTreeState *__restrict__ ts, const u64 *__restrict__ xroot,
                                                 u64 *__restrict__ x0, u64 *__restrict__ x1, const size_t N,
                                                 const uint8_t *__restrict__ goleft, u64 *__restrict__ pub,
-                                                const uint32_t tiles, const u64 epoch, const int lazy) {
+                                                const uint32_t tiles, const u64 epoch, const int lazy,
+                                                const int remote_owner = 0) {
+  // (remote_owner: a feature-sharded rank partitions its own features' segments whoever owns the
+  // split feature -- the go-left bytes came with the reduced mask, k_xflag_mask)
   // Tile blockIdx.y of feature blockIdx.x.  Entry k of thread t sits at position c0 + k * 1024 + t:
   // a wave's load is 512 contiguous bytes.  The rank of an entry among the tile's left-going ones:
   // lanes before it in its wave (ballot), waves before it in its slab k and the slabs before (one
@@ -164,7 +185,7 @@ __global__ __launch_bounds__(1024) void k_xpart(const QrTreeState *__restrict__ 
   __shared__ uint32_t sh_c[QR_X_E * 16], sh_p[QR_X_E * 16 + 1];
   __shared__ uint32_t sh_before;
   const QrSplitDesc d = ts->desc;
-  if (!d.active || d.owner_local < 0 || (lazy && ts->xs_last)) return;
+  if (!d.active || (d.owner_local < 0 && !remote_owner) || (lazy && ts->xs_last)) return;
   const uint32_t n = d.end - d.begin;
   const uint32_t tile = blockIdx.y;
   const uint32_t c0 = tile * QR_X_CHUNK;
@@ -606,11 +627,15 @@ int qr_k_exact_scan(qr_ctx *c, int root_mode) {
   const u64 epoch = c->xepoch;
   if (!root_mode) {
     const unsigned fg = (unsigned)std::min<size_t>((c->N + 2047) / 2048, 1024);
-    hipLaunchKernelGGL(k_xflag, dim3(fg), dim3(256), 0, c->stream, c->d_tree, xr, (const u64 *)x0, (const u64 *)x1,
-                       c->N, c->d_xgoleft, 0);
+    if (c->world > 1)   // feature shards: the reduced go-left bits (the owner's k_mask), by position
+      hipLaunchKernelGGL(k_xflag_mask, dim3(fg), dim3(256), 0, c->stream, c->d_tree, c->d_order[0], c->d_order[1],
+                         (const uint32_t *)c->d_mask, c->d_xgoleft);
+    else
+      hipLaunchKernelGGL(k_xflag, dim3(fg), dim3(256), 0, c->stream, c->d_tree, xr, (const u64 *)x0, (const u64 *)x1,
+                         c->N, c->d_xgoleft, 0);
     QR_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(k_xpart, dim3(F, c->xtiles_p), dim3(1024), 0, c->stream, c->d_tree, xr, x0, x1, c->N,
-                       (const uint8_t *)c->d_xgoleft, pub_part, c->xtiles_p, epoch, 0);
+                       (const uint8_t *)c->d_xgoleft, pub_part, c->xtiles_p, epoch, 0, c->world > 1 ? 1 : 0);
     QR_CHECK(c, hipGetLastError());
   }
   QR_CHECK(c, hipMemsetAsync(c->d_xtot, 0, (2 + 2 * (size_t)F) * 8, c->stream));

@@ -1025,8 +1025,10 @@ static int bins_build_wide_impl(qr_ctx *c, size_t nthresholds, float *&d_col, si
   // rows of more than QR_X_MIN_SLOTS slots (the reference's default --num-thresholds 0 on real-valued
   // columns): slot-indexed node histograms cost 0.8 GB of cells per node whatever its size; the
   // pre-sorted lists of k_exact.hip cost 8 bytes per (document, feature) of the node.  Single-GPU
-  // contexts; 3 x F x N x 8 bytes of lists (QR_WIDE_EXACT=1 / QR_WIDE_NO_EXACT=1 force either way).
-  if (c->world == 1 && !c->dmode && !getenv("QR_WIDE_NO_EXACT") &&
+  // and (round 6) FEATURE-sharded contexts -- a rank holds every document and the lists of its own
+  // features; the records it hands the all-gather and the mask it takes back are the slot path's;
+  // 3 x F_local x N x 8 bytes of lists (QR_WIDE_EXACT=1 / QR_WIDE_NO_EXACT=1 force either way).
+  if (!c->dmode && !getenv("QR_WIDE_NO_EXACT") &&
       (c->wmax > QR_X_MIN_SLOTS || getenv("QR_WIDE_EXACT")) && 3 * FL * N * 8 <= ((size_t)64 << 30)) {
     // (decided by the memory that is really free, and a build that still fails --
     // another context took it in between -- leaves the slot-indexed path of round 3 in place

@@ -370,15 +370,21 @@ def test_torch_distributed_oblivious_world1(oracle_lib):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,F,nthr", [(2, 33, 0), (3, 70, 1000), (2, 16, 5000)])
-def test_sharded_contexts_with_more_than_255_thresholds(world, F, nthr, oracle_lib):
+@pytest.mark.parametrize("lists", [False, True], ids=["slot_histograms", "presorted_lists"])
+@pytest.mark.parametrize("world,F,nthr", [(2, 33, 0), (3, 70, 1000), (2, 16, 5000), (4, 21, 0)])
+def test_sharded_contexts_with_more_than_255_thresholds(world, F, nthr, lists, oracle_lib, monkeypatch):
     """The reference's default `--num-thresholds 0` (every distinct value a threshold) and any
     value above 255 on FEATURE-sharded contexts (round 3): every rank builds the wide bins of
     its own features, the protocol is the one of the u8 path -- records all-gather, go-left mask
     all-reduce -- and the winning slot's threshold VALUE, which only its owner holds, rides behind
-    the mask.  Trees bit-identical to the single wide context (incl. the thresholds), scores too."""
+    the mask.  Trees bit-identical to the single wide context (incl. the thresholds), scores too.
+    `presorted_lists` (round 6): every rank grows on the pre-sorted lists of ITS features
+    (k_exact.hip; QR_WIDE_EXACT=1 forces them on rows this short) -- the segments of all its lists
+    are partitioned by the go-left bits that came back with the reduced mask (k_xflag_mask),
+    whoever owns the split feature; the single context beside it stays on slot histograms."""
     import torch
     import quickrank_amd as qr
+    monkeypatch.setenv("QR_WIDE_NO_EXACT", "1")
     x, labels, qoff = make_dataset(nq=40, docs_per_query=50, F=F, seed=29, adversarial=True)
     rng = np.random.default_rng(4)
     lam, w = oracle_lib.lambdas(labels, rng.standard_normal(len(labels)) * 0.3, qoff)
@@ -392,6 +398,9 @@ def test_sharded_contexts_with_more_than_255_thresholds(world, F, nthr, oracle_l
     single.update_scores(0.1)
     want_scores = single.get_scores()
     single.close()
+    if lists:
+        monkeypatch.delenv("QR_WIDE_NO_EXACT")
+        monkeypatch.setenv("QR_WIDE_EXACT", "1")
     ctxs = []
     for r in range(world):
         c = qr.Context(0, rank=r, world=world)
@@ -400,6 +409,10 @@ def test_sharded_contexts_with_more_than_255_thresholds(world, F, nthr, oracle_l
         assert c.wide
         c.set_pseudo(lam, w)
         ctxs.append(c)
+    if lists:   # (a context on the lists has no node histograms to hand out: that is how one tells)
+        _sharded_fit(torch, ctxs, 2, 2)
+        with pytest.raises(qr.QrError, match="pre-sorted lists"):
+            ctxs[0].node_hist_ragged(0)
     got = _sharded_fit(torch, ctxs, 10, 2)
     for g in got:
         assert_same_tree_records(g, want)       # both sides grow one split per step: every field exact

@@ -441,6 +441,35 @@ class DocShardedTrainer:
         return total / count if count else 0.0
 
 
+class FeatureShardedTrainer:
+    """The interface of DocShardedTrainer over north_star's FEATURE layout: every rank holds every
+    document (so the lambda pass, the metric and the score update are the rank's own, redundantly)
+    and the bin columns / pre-sorted lists of its own feature range; per split the ranks all-gather
+    their best records and all-reduce the go-left mask (ShardedTreeFitter).  What a document-sharded
+    run falls back to when `--num-thresholds 0` meets columns whose every-distinct-value rows a
+    document-sharded node histogram cannot hold (scripts/train_multi_gpu.py): the best split over
+    slots is a function of prefix sums over ALL documents, which shards by feature."""
+
+    def __init__(self, ctx, group=None, device=None, transport=None):
+        self.ctx = ctx
+        self.fitter = ShardedTreeFitter(ctx, group=group, device=device, transport=transport)
+
+    def compute_lambdas(self, metric="NDCG", cutoff=10):
+        self.ctx.compute_lambdas(metric, cutoff)
+
+    def compute_residuals(self):
+        self.ctx.compute_residuals()
+
+    def fit_tree(self, nleaves, minls, newton, read=True):
+        return self.fitter.fit_tree(self.ctx, nleaves, minls, newton, read)
+
+    def fit_oblivious(self, depth, minls, newton, read=True):
+        return self.fitter.fit_oblivious(self.ctx, depth, minls, newton, read)
+
+    def metric_eval(self, which=0, metric="NDCG", cutoff=10):
+        return self.ctx.metric_eval(which, metric, cutoff)
+
+
 def gather_thresholds(ctx, nthresholds, group=None):
     """Thresholds of the whole (document-sharded) training set: every rank's column
     statistics are all-gathered and merged with the reference's rule."""

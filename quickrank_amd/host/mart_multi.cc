@@ -100,6 +100,10 @@ struct Shared {
   // rank 0's tree of the iteration, for the cross-rank check
   std::vector<qr_node_t> nodes0;
   size_t nn0 = 0;
+  // document layout, --num-thresholds 0 (or above 255) on columns whose slots a document-sharded
+  // node histogram cannot hold: every rank finds the same numbers, leaves before any training, and
+  // the run starts over in the feature layout (learn_multi)
+  bool relayout = false;
   explicit Shared(int w) : world(w), bar(w) {
     for (int k = 0; k < 2; ++k) {
       msum[k].assign(w, 0.0);
@@ -149,6 +153,9 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
     exit(EXIT_FAILURE);
   }
   const int W = ngpus;
+  // (the feature layout holds every feature range only while W - 1 ranges leave one for the last rank)
+  const bool no_feature_layout =
+      ((training->num_features() + (size_t)W - 1) / (size_t)W) * (size_t)(W - 1) >= training->num_features();
   const int mcode = metric_code_of(metric);
   const bool lambda = algo_ == LAMBDAMART || algo_ == OBVLAMBDAMART;
   const size_t N = training->num_instances(), F = training->num_features(), Q = training->num_queries();
@@ -274,22 +281,27 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
         size_t cells = 0;
         const int wrc = qr_thresholds_from_stats_wide(F, nthresholds_, W, wl, sh.vals.data(), sh.cnt.data(),
                                                       sh.mm.data(), nullptr, 0, ts.data(), &cells);
-        if (wrc == QR_ERR_UNSUPPORTED && nthresholds_ == 0) {
-          if (r == 0)
-            std::cerr << "!!! --shard docs with --num-thresholds 0: a column has more than 65536 distinct values "
-                         "(use --num-thresholds N or --shard features)." << std::endl;
-          fatal_exit();
+        // A document-sharded node histogram is all-reduced cell by cell: its rows hold at most 4M slots
+        // in all (qr_bins_build_wide_with refuses more), and the statistics carry at most 65536 distinct
+        // values per column.  Beyond that -- the reference's DEFAULT flag on real-valued columns -- the
+        // best split of a node is a function of the prefix sums over ALL documents in slot order, which
+        // shards by FEATURE, not by document: the run starts over in the feature layout, where every
+        // rank grows on the pre-sorted lists of its own columns (k_exact.hip) and the exchange per
+        // split is 32-byte records and a bit mask.  Same model either way; every rank sees the same
+        // numbers here, so every rank takes this exit.
+        if ((wrc == QR_ERR_UNSUPPORTED && nthresholds_ == 0) || (wrc == QR_OK && cells > ((size_t)4 << 20))) {
+          if (no_feature_layout) {
+            if (r == 0)
+              std::cerr << "!!! --shard docs: more threshold slots than a document-sharded node histogram can "
+                           "hold (use fewer --num-thresholds or --shard features)." << std::endl;
+            fatal_exit();
+          }
+          sh.bar.wait();
+          if (r == 0) sh.relayout = true;
+          qr_ctx_destroy(c);
+          return;
         } else if (wrc != QR_OK)
           die(c, "qr_thresholds_from_stats_wide");
-        // a document-sharded node histogram is all-reduced: its rows hold at most 4M slots in all
-        // (qr_bins_build_wide_with refuses more) -- said here, before the bins are built
-        if (cells > ((size_t)4 << 20)) {
-          if (r == 0)
-            std::cerr << "!!! --shard docs: " << cells << " threshold slots in all, more than the 4M a "
-                         "document-sharded node histogram can hold (use fewer --num-thresholds or --shard features)."
-                      << std::endl;
-          fatal_exit();
-        }
         std::vector<float> thr(cells);
         if (qr_thresholds_from_stats_wide(F, nthresholds_, W, wl, sh.vals.data(), sh.cnt.data(), sh.mm.data(),
                                           thr.data(), cells, ts.data(), &cells) != QR_OK)
@@ -573,6 +585,13 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
     const ncclResult_t dr = ncclCommDestroy(comms[r]);
     if (dr != ncclSuccess)
       std::cerr << "!!! ncclCommDestroy (rank " << r << "): " << ncclGetErrorString(dr) << std::endl;
+  }
+  if (sh.relayout) {
+    std::cout << std::endl
+              << "# --shard docs: every distinct value a threshold -- the lists shard by feature: feature layout"
+              << std::endl;
+    learn_multi(training, validation, metric, cutoff, partial_save, output_basename, ngpus, true);
+    return;
   }
   best_metric_on_training_ = best_train_r_[0];
   best_metric_on_validation_ = best_valid_r_[0];

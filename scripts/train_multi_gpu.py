@@ -80,8 +80,8 @@ def main():
         build.build()
         build.build_host()
     dist.barrier()
-    from quickrank_amd._capi import Context, NODE_DTYPE
-    from quickrank_amd.dist import DocShardedTrainer, build_doc_bins
+    from quickrank_amd._capi import Context, NODE_DTYPE, QrError, QR_ERR_UNSUPPORTED
+    from quickrank_amd.dist import DocShardedTrainer, FeatureShardedTrainer, build_doc_bins
     host = C.CDLL(build.HOST_LIB)
     sz = C.c_size_t
     host.qrh_svml_open.argtypes = [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
@@ -102,14 +102,32 @@ def main():
         if vx.shape[1] < F:                       # the reader sizes rows by the largest id it met
             vx = np.pad(vx, ((0, 0), (0, F - vx.shape[1])))
         ctx.upload_valid(*shard(vx[:, :F], vl, vq, rank, world))
+    layout = "document-sharded"
+    try:
+        build_doc_bins(ctx, a.num_thresholds)    # (u8 bins up to 255 thresholds per feature, ragged rows beyond)
+        tr = DocShardedTrainer(ctx)
+    except QrError as e:
+        # --num-thresholds 0 (or above 255) on columns whose rows a document-sharded node histogram
+        # cannot hold (more than 65,536 distinct values in a column, 4M slots in all): the best split
+        # over every distinct value needs prefix sums over ALL documents in slot order, which shards
+        # by FEATURE.  Every rank meets the same merged statistics, so every rank lands here: the
+        # feature layout -- every document on every rank, the pre-sorted lists of its own columns.
+        if e.code != QR_ERR_UNSUPPORTED or world > F:
+            raise
+        ctx.close()
+        layout = "feature-sharded (the lists of every distinct value shard by feature)"
+        ctx = Context(local, rank=rank, world=world, stream=torch.cuda.current_stream().cuda_stream)
+        ctx.upload(x, lab, qoff)
+        if valid:
+            ctx.upload_valid(vx[:, :F], vl, vq)
+        ctx.build_bins(a.num_thresholds)
+        tr = FeatureShardedTrainer(ctx)
     del x
-    build_doc_bins(ctx, a.num_thresholds)    # (u8 bins up to 255 thresholds per feature, ragged rows beyond)
     ctx.reset_scores()
-    tr = DocShardedTrainer(ctx)
     lam = a.algo == "LAMBDAMART"
     trees, best, best_train, best_valid = [], 0, -np.inf, -np.inf
     if rank == 0:
-        print(f"# {a.algo} on {world} GPU(s): {N} docs x {F} features x {Q} queries, document-sharded")
+        print(f"# {a.algo} on {world} GPU(s): {N} docs x {F} features x {Q} queries, {layout}")
         print("# iter. training" + (" validation" if valid else ""))
     for m in range(a.num_trees):
         if valid and a.end_after_rounds and m > best + a.end_after_rounds:   # mart.cc:308-310

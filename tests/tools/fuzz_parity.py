@@ -222,16 +222,7 @@ def device_tree_follows_from_device_scores(tr, oracle, labels, qoff, gtrees, t, 
     Then the difference from the oracle's run lies upstream, in two scores that differ by the
     rounding of the leaf outputs' summation order, and nowhere else."""
     from parity_util import assert_tree_parity
-    dev = {"nodes": [gtrees[k] for k in range(t)], "nnodes": [0] * t}
-    for k in range(t):   # (records beyond the tree's nodes are zero-filled with feature -1: count the reachable ones)
-        n, stack = 0, [0]
-        while stack:
-            i = stack.pop()
-            n = max(n, i + 1)
-            if gtrees[k][i]["feature"] >= 0:
-                stack += [int(gtrees[k][i]["left"]), int(gtrees[k][i]["right"])]
-        dev["nnodes"][k] = n
-    sc = scores_before(tr.stmap, dev, t, kw["shrinkage"])
+    sc = _device_scores_before(tr, gtrees, t, kw["shrinkage"])
     lam = algo.endswith("LAMBDAMART")
     if lam:
         pseudo, weights = oracle.lambdas(labels, sc, qoff)[:2]
@@ -245,6 +236,74 @@ def device_tree_follows_from_device_scores(tr, oracle, labels, qoff, gtrees, t, 
         return True
     except AssertionError:
         return False
+
+
+def _device_scores_before(tr, gtrees, t, shrinkage):
+    dev = {"nodes": [gtrees[k] for k in range(t)], "nnodes": [0] * t}
+    for k in range(t):   # (records beyond the tree's nodes are zero-filled with feature -1: count the reachable ones)
+        n, stack = 0, [0]
+        while stack:
+            i = stack.pop()
+            n = max(n, i + 1)
+            if gtrees[k][i]["feature"] >= 0:
+                stack += [int(gtrees[k][i]["left"]), int(gtrees[k][i]["right"])]
+        dev["nnodes"][k] = n
+    return scores_before(tr.stmap, dev, t, shrinkage)
+
+
+def verify_rest_causally(tr, oracle, labels, qoff, gtrees, t_first, ntrees, kw, algo, minls, desc):
+    """a run that meets a split the reference decides by rounding noise used to end
+    there, its remaining trees unverified.  They are verified here, each on its own: the device's
+    tree t must be what the REFERENCE's algorithm (the oracle's lambdas / residuals, tree fit and leaf
+    outputs) builds from the DEVICE's own scores going into t -- the trees 0 .. t-1 the device really
+    built, walked on the bin map -- so a divergence upstream cannot poison the comparison.  A tree
+    that differs even so must itself be one of the classified kinds (an exact or sub-resolution
+    gain tie priced in rational arithmetic on those pseudo-responses, a zero-deviance gate, a heap
+    order between equal deviances, an oblivious level tie); anything else raises.  Returns
+    [(tree, "ok" | kind), ...]."""
+    from parity_util import assert_tree_parity
+    lam = algo.endswith("LAMBDAMART")
+    out = []
+    for t in range(t_first, ntrees):
+        sc = _device_scores_before(tr, gtrees, t, kw["shrinkage"])
+        if lam:
+            pseudo, weights = oracle.lambdas(labels, sc, qoff)[:2]
+        else:
+            pseudo, weights = labels.astype(np.float64) - sc, None
+        fit = tr.fit_tree(pseudo, nleaves=kw.get("nleaves", 10), minls=kw["minls"],
+                          oblivious_depth=kw.get("depth") if algo.startswith("OBV") else None)
+        tr.update_output(fit, pseudo, weights)
+        o = fit["nodes"]
+        try:
+            assert_tree_parity(tr.stmap, o, gtrees[t], tie_max_docs=1 << 30, value_rtol=1e-6)
+            out.append((t, "ok"))
+            continue
+        except AssertionError as e:
+            err = e
+        g = gtrees[t]
+        kind = None
+        if algo.startswith("OBV"):
+            if oblivious_level_gain_tie(tr.stmap, o, g, pseudo, minls):
+                kind = "gain_tie"
+        else:
+            if err.args and isinstance(err.args[0], tuple) and len(err.args[0]) == 2 \
+                    and all(isinstance(v, (int, np.integer)) for v in err.args[0]):
+                oi, gi = err.args[0]
+                eps = 1e-9 * max(1.0, abs(o[0]["deviance"]))
+                if abs(o[oi]["deviance"]) <= eps and abs(g[gi]["deviance"]) <= eps:
+                    kind = "zero_deviance"
+            if kind is None and upstream_gain_tie(tr.stmap, o, g):
+                priced = parting_gains_exact(tr.stmap, o, g, pseudo)
+                if priced is not None and priced[0] <= 1e-9:
+                    kind = "gain_tie" if priced[0] == 0.0 else "gain_tie_fp"
+            if kind is None and deviance_order_tie(tr.stmap, o, g):
+                kind = "heap_tie"
+        if kind is None:
+            print(desc, "TREE", t, "(verified from the device's own scores) MISMATCH", err, flush=True)
+            raise AssertionError((desc, "tree", t, "differs from what the reference's algorithm builds from the "
+                                  "device's own scores, and is none of the classified kinds", err.args))
+        out.append((t, kind))
+    return out
 
 
 def oblivious_level_gain_tie(stmap, o, g, pseudo, minls):
@@ -490,6 +549,10 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True, _retry=True):
                                         float(a["deviance"])) for k, a in enumerate(arr)])
                     raise AssertionError((desc, "tree", t, e.args))
                 rec["status"], rec["tree"] = status, t
+                # the trees behind the cut, each against what the reference's algorithm builds from the
+                # device's own scores (raises on one that is neither that nor a classified tie)
+                rec["rest"] = verify_rest_causally(tr, oracle, labels, qoff, gm.ensemble.trees, t + 1,
+                                                   om["ntrees_built"], kw, algo, minls, desc)
                 break
         if (zlib.crc32(x), zlib.crc32(labels), zlib.crc32(qoff)) != crc0:
             raise AssertionError((desc, "HOST MEMORY CHANGED: the configuration's input arrays are not the bytes they were"))
@@ -497,7 +560,8 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True, _retry=True):
             continue
         if rec["status"] != "ok":
             if verbose:
-                print(desc, f"ok up to a split decided by rounding noise ({rec['status']}) in tree", rec["tree"], flush=True)
+                print(desc, f"ok up to a split decided by rounding noise ({rec['status']}) in tree", rec["tree"],
+                      "; the trees behind it, from the device's own scores:", rec.get("rest"), flush=True)
             gm.ctx.close()
             out.append(rec)
             continue

@@ -143,16 +143,21 @@ __device__ __forceinline__ void hist_accumulate(
   for (int k = 0; k < 16; ++k) colk[k] = 16 * c + ((k + r) & 15);
   const int dr = r >> 2;       // dword rotation
   const uint32_t br = r & 3;   // byte rotation inside a dword
-  // (SUMS: the sixteen column indices packed into four registers, a byte each)
+  // (SUMS: the sixteen column indices packed into four registers, a byte each;
+  // -DQR_HIST_PACKED_COLS=1, an A/B: every variant keeps them packed)
+#ifndef QR_HIST_PACKED_COLS
+#define QR_HIST_PACKED_COLS 0
+#endif
+  constexpr bool PACKED = SUMS || QR_HIST_PACKED_COLS;
   uint32_t cp[4] = {0, 0, 0, 0};
-  if (SUMS) {
+  if (PACKED) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) cp[k >> 2] |= colk[k] << (8 * (k & 3));
   }
   auto process = [&](const uint4 &row, const double lam) {
     uint32_t c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+    if (PACKED) asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));  // (not hoisted back into sixteen registers)
     if (SUMS) {
-      asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));  // (not hoisted back into sixteen registers)
       if (c == 0) {
         *sq += lam * lam;
         *sm += lam;
@@ -177,7 +182,7 @@ __device__ __forceinline__ void hist_accumulate(
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const uint32_t bin = (R[k >> 2] >> (8 * (k & 3))) & 0xffu;
-      const uint32_t col = SUMS ? ((cpk[k >> 2] >> (8 * (k & 3))) & 0xffu) : colk[k];
+      const uint32_t col = PACKED ? ((cpk[k >> 2] >> (8 * (k & 3))) & 0xffu) : colk[k];
       atomicAdd(&hist[bin * FW + col], addend);
     }
   };

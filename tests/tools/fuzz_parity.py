@@ -372,6 +372,25 @@ def oracle_rerun_differs(oracle, om, x, labels, qoff, algo, kw, desc):
 _ORACLE_PROC = None
 
 
+def draw_config(rng, make_dataset):
+    """The next configuration of a sweep's random stream: (algo, kw, x, labels, qoff, F, nthr, minls, adversarial)."""
+    F = int(rng.choice([5, 9, 16, 17, 40, 64, 65, 136, 200]))
+    nq = int(rng.integers(5, 400))
+    dpq = int(rng.choice([1, 3, 16, 17, 40, 100, 250]))
+    nthr = int(rng.choice([2, 8, 16, 64, 255]))
+    algo = str(rng.choice(["LAMBDAMART", "MART", "OBVLAMBDAMART", "OBVMART"]))
+    minls = int(rng.choice([1, 1, 2, 5, 20]))
+    kw = dict(ntrees=int(rng.integers(2, 6)), shrinkage=0.1, nthresholds=nthr, minls=minls, esr=0)
+    if algo.startswith("OBV"):
+        kw["depth"] = int(rng.integers(1, 7))
+    else:
+        kw["nleaves"] = int(rng.choice([2, 3, 8, 10, 31, 64]))
+    dseed, ragged, adversarial = int(rng.integers(1 << 30)), bool(rng.integers(2)), bool(rng.integers(2))
+    x, labels, qoff = make_dataset(nq=nq, docs_per_query=dpq, F=F, seed=dseed, ragged=ragged,
+                                   adversarial=adversarial)
+    return algo, kw, x, labels, qoff, F, nthr, minls, adversarial
+
+
 def sweep(n_cfg=30, seed=0, only=None, verbose=True, _retry=True):
     """Returns one record per configuration: dict(i, desc, status, ties, tie_sizes,
     flips, tree) with status "ok", or "gain_tie" / "zero_deviance" / "heap_tie" for a run cut short
@@ -401,20 +420,7 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True, _retry=True):
     import zlib
     out = []
     for i in range(n_cfg):
-        F = int(rng.choice([5, 9, 16, 17, 40, 64, 65, 136, 200]))
-        nq = int(rng.integers(5, 400))
-        dpq = int(rng.choice([1, 3, 16, 17, 40, 100, 250]))
-        nthr = int(rng.choice([2, 8, 16, 64, 255]))
-        algo = str(rng.choice(["LAMBDAMART", "MART", "OBVLAMBDAMART", "OBVMART"]))
-        minls = int(rng.choice([1, 1, 2, 5, 20]))
-        kw = dict(ntrees=int(rng.integers(2, 6)), shrinkage=0.1, nthresholds=nthr, minls=minls, esr=0)
-        if algo.startswith("OBV"):
-            kw["depth"] = int(rng.integers(1, 7))
-        else:
-            kw["nleaves"] = int(rng.choice([2, 3, 8, 10, 31, 64]))
-        dseed, ragged, adversarial = int(rng.integers(1 << 30)), bool(rng.integers(2)), bool(rng.integers(2))
-        x, labels, qoff = make_dataset(nq=nq, docs_per_query=dpq, F=F, seed=dseed, ragged=ragged,
-                                       adversarial=adversarial)
+        algo, kw, x, labels, qoff, F, nthr, minls, adversarial = draw_config(rng, make_dataset)
         if only is not None and only != i:
             continue
         desc = (f"[{i}] {algo} N={len(labels)} F={F} nthr={nthr} minls={minls} {kw.get('nleaves', '')}{kw.get('depth', '')}"

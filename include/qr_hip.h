@@ -192,6 +192,9 @@ int qr_bins_read_u32(qr_ctx *ctx, uint32_t *out);
 /* debug/parity: bin ids as u8 [N][F] row-major (global features; features this  */
 /* rank does not own read back as 0xFF)                                          */
 int qr_bins_read(qr_ctx *ctx, uint8_t *out);
+/* debug/parity: the same from the FEATURE-MAJOR copy of the u8 bins (the one the partition    */
+/* of rt.cc:325-334 and the leaf walk read); tests/tools/repro_first_tree.py compares the two  */
+int qr_bins_read_fm(qr_ctx *ctx, uint8_t *out);
 
 /* ---- model state: scores_on_training_ (mart.cc:121), pseudoresponses_,        */
 /*      instance_weights_ (lambdamart.cc:34-39)                                  */

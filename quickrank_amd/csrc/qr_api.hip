@@ -1141,6 +1141,20 @@ int qr_bins_read(qr_ctx *c, uint8_t *out) {
   return QR_OK;
 }
 
+int qr_bins_read_fm(qr_ctx *c, uint8_t *out) {
+  if (!c || !out) return QR_ERR_ARG;
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  if (c->wide) QR_FAIL(c, QR_ERR_STATE, "this context has more than 255 thresholds per feature: qr_bins_read_u32");
+  std::vector<uint8_t> h((size_t)c->flocal * c->N);
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  QR_CHECK(c, hipMemcpy(h.data(), c->d_bins_fm, h.size(), hipMemcpyDeviceToHost));
+  memset(out, 0xFF, c->N * c->F);
+  for (const QrBlock &b : c->blocks)
+    for (int i = 0; i < b.nreal; ++i)
+      for (size_t d = 0; d < c->N; ++d) out[d * c->F + b.f0 + i] = h[(size_t)(b.lf0 + i) * c->N + d];
+  return QR_OK;
+}
+
 // ---------------------------------------------------------------------------
 int qr_scores_reset(qr_ctx *c) {
   if (!c || !c->d_scores) return QR_ERR_STATE;

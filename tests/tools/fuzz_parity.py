@@ -502,8 +502,14 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True, _retry=True):
                               else labels.astype(np.float64) - sc)
                     priced = parting_gains_exact(tr.stmap, o, g, pseudo)
                     if priced is None or priced[0] > 1e-9:
-                        print(desc, "TREE", t, "gain tie NOT confirmed by exact pricing:", priced)
-                        raise AssertionError((desc, "tree", t, "gain tie not confirmed", priced))
+                        # not a tie on the ORACLE's pseudo-responses (r06 hunt, seed 58 [39]: child deviances
+                        # equal to 1e-9 of the root's, exact gains 0.9 % apart in a node of 6 documents of a
+                        # later LambdaMART tree): the trees may still have parted upstream, over scores equal
+                        # to rounding -- the causal check below decides; nothing is excused here
+                        print(desc, "TREE", t, "gain tie NOT confirmed by exact pricing:", priced, "-- not classified as one", flush=True)
+                        status = None
+                        priced = None
+                if status in ("gain_tie",) and not algo.startswith("OBV") and priced is not None:
                     rec["gain_rel"], rec["gain_node_docs"] = priced
                     if priced[0] > 0.0:
                         status = "gain_tie_fp"

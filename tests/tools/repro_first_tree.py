@@ -100,6 +100,10 @@ for it in range(iters):
     bins = c.read_bins()
     wrong = np.argwhere(bins.T.astype(np.uint32) != tr.stmap)
     print(' device bin map != oracle stmap at', len(wrong), 'cells', wrong[:8].tolist(), flush=True)
+    fm = c.read_bins_fm()
+    wfm = np.argwhere(fm != bins)
+    print(' feature-major copy != block rows at', len(wfm), 'cells', wfm[:8].tolist(),
+          'features', np.unique(wfm[:, 1])[:12].tolist() if len(wfm) else [], flush=True)
     dl, dw = c.get_pseudo()
     print(' pseudo-responses differing from the expected ones:', int(np.count_nonzero(~np.isclose(dl, pseudo, rtol=1e-11, atol=1e-14))), flush=True)
     sets = walk_sets(nodes)

@@ -98,6 +98,28 @@ static int qr_dbg_caps_upload(qr_ctx *c) {
 #define QR_DBG_OK(cond, code, a, b) true
 #endif
 
+// -DQR_WG_JITTER (round 6; tests/tools/abort_hunt.py --jitter builds the library with it): the
+// inter-workgroup race stress.  One workgroup in eight of EVERY launch of this file -- which ones
+// changes from launch to launch -- starts ~30 us late (s_sleep), the way workgroups of one launch
+// drift apart when several processes share the GPU (the r06 hunt met the intermittent mismatch of
+// rounds 4-5 fifty times more often with eight processes on the device).  A workgroup that reads
+// what an earlier-finishing workgroup of the SAME launch has already overwritten then does so every
+// time, not once in thousands of runs.  The product build compiles it out.
+#ifdef QR_WG_JITTER
+__device__ unsigned int qr_jitter_seq;
+__device__ __noinline__ void qr_jitter_wait() {
+  for (int i = 0; i < 9; ++i) __builtin_amdgcn_s_sleep(127);
+}
+#define QR_JITTER()                                                                              \
+  do {                                                                                           \
+    const unsigned int jq_ = __builtin_amdgcn_readfirstlane(qr_jitter_seq);                      \
+    if ((((blockIdx.x + blockIdx.y * 7u + jq_) * 2654435761u) >> 29) == 3u) qr_jitter_wait();   \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) qr_jitter_seq = jq_ + 1u;        \
+  } while (0)
+#else
+#define QR_JITTER() do {} while (0)
+#endif
+
 // -DQR_STEP_TIMING (scripts/step_timing.py): clock64 stamps of one histogram workgroup's
 // sections, with the load queue drained at the first two so that they show the dependent
 // round trips (descriptor -> ids -> rows) one by one
@@ -394,6 +416,7 @@ __global__ __launch_bounds__(1024) void k_hist(
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const QrScalars *__restrict__ scal, u64 *__restrict__ partials, const int docmode,
     const int root_buf) {
+  QR_JITTER();
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
   uint32_t seg_begin, n;
   int buf;
@@ -422,6 +445,7 @@ __global__ __launch_bounds__(1024) void k_hist_root(
     const double *__restrict__ lambda, const QrScalars *__restrict__ scal,
     u64 *__restrict__ partials, const int root_buf, const int tr,
     const unsigned long long *__restrict__ slots, const QrHistWg *__restrict__ wgs) {
+  QR_JITTER();
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
   // `slots`: the iteration's scalars are finished by workgroups of the scan launch BEHIND this
   // one (qr_prep.h); the scale comes from the slot set the lambda pass filled, a word per lane
@@ -453,6 +477,7 @@ __global__ __launch_bounds__(1024) void k_hist_level(
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const QrScalars *__restrict__ scal, u64 *__restrict__ partials) {
+  QR_JITTER();
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
   if (ts->obl_done || blockIdx.x >= ts->l_hist_wgs) return;
   const uint32_t m = map[blockIdx.x];
@@ -467,6 +492,7 @@ __global__ __launch_bounds__(1024) void k_hist_batch(
     const uint8_t *__restrict__ bins, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const QrScalars *__restrict__ scal, u64 *__restrict__ partials, double *__restrict__ histsum) {
+  QR_JITTER();
   extern __shared__ __attribute__((aligned(16))) u64 hist[];
   QR_HT(0);
   const QrHistWg d = wgs[blockIdx.x];
@@ -564,6 +590,7 @@ __global__ __launch_bounds__(512) void k_reduce(
     uint32_t *__restrict__ red_cnt, const int docmode, const double *__restrict__ part_ss,
     long long *__restrict__ tail, const int rank, const int world,
     uint32_t *__restrict__ red_cnt_loc) {
+  QR_JITTER();
   uint32_t n;
   if (root_mode) {
     n = N;
@@ -765,6 +792,7 @@ __global__ __launch_bounds__(256) void k_scan(
     const QrScalars *__restrict__ scal, qr_split_t *__restrict__ featrec, const uint32_t cs,
     const uint32_t *__restrict__ red_cnt_loc, uint32_t *__restrict__ hcnt_loc,
     const float *__restrict__ thr, float *__restrict__ featthr) {
+  QR_JITTER();
   int small_slot, big_slot = -1, parent_slot = -1, small_is_left = 1;
   if (root_mode) {
     small_slot = 0;
@@ -866,6 +894,7 @@ __global__ __launch_bounds__(1024) void k_redscan(
     float *__restrict__ featthr, const QrScanWg *__restrict__ descs, const u64 minls,
     const double *__restrict__ part_ss, double *__restrict__ jobsum, const QrPrepJob prep,
     const QrResetJob reset) {
+  QR_JITTER();
   __shared__ long long cs_s[3][256];
   __shared__ uint32_t cs_c[3][256];
   __shared__ QrPlan sh_plan;
@@ -1049,6 +1078,7 @@ __global__ __launch_bounds__(1024) void k_redscan_level(
     const QrTreeState *__restrict__ ts, const QrBlock *__restrict__ blocks, const int nblocks,
     const u64 *__restrict__ partials, long long *__restrict__ hsum, uint32_t *__restrict__ hcnt,
     const int flocal, long long *__restrict__ xl, uint32_t *__restrict__ hcnt_loc) {
+  QR_JITTER();
   __shared__ long long cs_s[3][256];
   __shared__ uint32_t cs_c[3][256];
   __shared__ long long sh_s[4];
@@ -1105,6 +1135,7 @@ __global__ __launch_bounds__(1024) void k_redscan_level(
 __global__ __launch_bounds__(256) void k_level_finish_doc(
     const QrTreeState *__restrict__ ts, const long long *__restrict__ xl,
     long long *__restrict__ hsum, uint32_t *__restrict__ hcnt, const int flocal) {
+  QR_JITTER();
   __shared__ long long sh_s[4];
   __shared__ uint32_t sh_c[4];
   if (ts->obl_done || (int)blockIdx.y >= ts->l_nodes) return;
@@ -1137,6 +1168,7 @@ __global__ __launch_bounds__(1024) void k_bd_reduce(
     const QrScanWg *__restrict__ descs, const u64 *__restrict__ partials, const int flocal,
     long long *__restrict__ xb, uint32_t *__restrict__ hcnt_loc, const double *__restrict__ part_ss,
     const int rank, const int world) {
+  QR_JITTER();
   __shared__ long long cs_s[3][256];
   __shared__ uint32_t cs_c[3][256];
   __shared__ long long sh_s[4];
@@ -1211,6 +1243,7 @@ __global__ __launch_bounds__(256) void k_bd_scan(
     const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
     qr_split_t *__restrict__ featrec, const float *__restrict__ thr, float *__restrict__ featthr,
     const u64 minls, double *__restrict__ jobsum, const int world) {
+  QR_JITTER();
   const int lf = blockIdx.x;
   const uint32_t t = threadIdx.x;
   const int gf = lf2gf[lf];
@@ -1345,6 +1378,7 @@ __global__ __launch_bounds__(128) void k_merge(
     const long long *__restrict__ hsum, const uint32_t *__restrict__ hcnt,
     const int32_t *__restrict__ gf2lf, qr_split_t *__restrict__ recs_local,
     const uint32_t mf_k, const u64 mf_seed, const uint32_t F) {
+  QR_JITTER();
   if (!root_mode && !ts->desc.active) return;
   const int which = threadIdx.x >> 6;  // wave 0: left child (or root), wave 1: right
   const uint32_t node = root_mode ? 0u : (uint32_t)(which ? ts->desc.right : ts->desc.left);
@@ -1732,6 +1766,7 @@ __global__ __launch_bounds__(128) void k_decide(
     const uint32_t *__restrict__ hcnt_loc, const int docmode, const u64 Nglobal,
     const long long *__restrict__ tail, const int dworld, const uint32_t mf_k, const u64 mf_seed,
     const uint32_t F, const int root_buf, const uint32_t *__restrict__ thr_off, const size_t loc_cells) {
+  QR_JITTER();
   decide_body(ts, N, flocal, recs, world, scal, part_ss, thr, gf2lf, featrec, hcnt_loc, docmode,
               Nglobal, tail, dworld, mf_k, mf_seed, F, root_buf, thr_off, loc_cells);
 }
@@ -1822,6 +1857,7 @@ __global__ __launch_bounds__(128) void k_xpop(
     const QrScalars *__restrict__ scal, const double *__restrict__ part_ss,
     unsigned long long *__restrict__ gbest, const int flocal, const int final_call,
     int64_t *__restrict__ early, const long long early_seq, const int root_buf) {
+  QR_JITTER();
   __shared__ QrNode sh_nodes[QR_DECIDE_LDS_NODES];
   __shared__ QrHeapItem sh_heap[QR_DECIDE_LDS_NODES + 2];
   __shared__ int sh_nn, sh_hs;
@@ -1926,6 +1962,7 @@ __global__ __launch_bounds__(64) void k_xapply(
     const float *__restrict__ thr, const int32_t *__restrict__ gf2lf, const uint32_t *__restrict__ thr_off,
     const uint32_t mf_k, const u64 mf_seed, const uint32_t F, const long long *__restrict__ xcs,
     long long *__restrict__ node_tot) {
+  QR_JITTER();
   const int node = ts->xs_node;
   if (node < 0) return;  // (workgroup-uniform; k_xpop left desc.active = 0)
   if (threadIdx.x == 0) ts->xs_last = 0;
@@ -2678,6 +2715,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_batch(
     const uint32_t part_grid, QrPlan *__restrict__ plans, QrScanWg *__restrict__ scan_wg,
     const QrTreeState *tin, const int final_call, int64_t *__restrict__ early, const long long early_seq,
     const uint32_t *__restrict__ hcnt_loc, const u64 Nglobal, const u64 spec_docs) {
+  QR_JITTER();
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
   __shared__ int sh_nj;
@@ -2724,6 +2762,7 @@ __global__ __launch_bounds__(256) void k_mask(
     const uint32_t Nfm,
     const uint32_t *__restrict__ order0, const uint32_t *__restrict__ order1,
     uint32_t *__restrict__ mask, const uint32_t mask_words, const int wide) {
+  QR_JITTER();
   const QrSplitDesc d = ts->desc;
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (wide && w == 0) {
@@ -2765,6 +2804,7 @@ __global__ __launch_bounds__(256) void k_mask(
 
 // after the mask all-reduce on a wide feature-sharded context: the split node's threshold
 __global__ void k_thr_patch(QrTreeState *__restrict__ ts, const uint32_t *__restrict__ word) {
+  QR_JITTER();
   if (threadIdx.x == 0 && blockIdx.x == 0 && ts->desc.active)
     ts->nodes[ts->desc.node].threshold = __uint_as_float(*word);
 }
@@ -2934,6 +2974,7 @@ __global__ __launch_bounds__(256) void k_partition(
     const uint32_t *__restrict__ mask, const int use_mask,
     u64 *__restrict__ state, const double *__restrict__ lambda,
     double *__restrict__ part_ss, const int docmode) {
+  QR_JITTER();
   const QrSplitDesc d = ts->desc;
   if (!d.active) return;
   PartNode pn;
@@ -2954,6 +2995,7 @@ __global__ __launch_bounds__(256) void k_partition_level(
     const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
     uint32_t *__restrict__ order1, u64 *__restrict__ state, const int wide,
     const uint32_t *__restrict__ docmask) {
+  QR_JITTER();
   if (ts->obl_done || blockIdx.x >= ts->l_part_wgs) return;
   const QrLevelNode &ln = ts->lnode[map[blockIdx.x]];
   if (!ln.active) return;
@@ -2978,6 +3020,7 @@ __global__ __launch_bounds__(256) void k_partition_batch(
     const uint8_t *__restrict__ fm, const uint32_t Nfm, uint32_t *__restrict__ order0,
     uint32_t *__restrict__ order1, u64 *__restrict__ state, const double *__restrict__ lambda,
     double *__restrict__ part_ss, const uint32_t epoch_host, const int wide) {
+  QR_JITTER();
   // (epoch_host != 0: the granules' tag is counted on the host, as for k_decide_part;
   // wide: `fm` holds u32 bins, k_wide.hip)
   const QrPartWg d = wgs[blockIdx.x];
@@ -3012,6 +3055,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
     uint32_t *__restrict__ order1, u64 *__restrict__ state, const double *__restrict__ lambda,
     double *__restrict__ part_ss_out, const int wide, const uint32_t *__restrict__ hcnt_loc,
     const u64 Nglobal, const u64 spec_docs) {
+  QR_JITTER();
   // (hcnt_loc != null: a document-sharded rank -- N its own documents, Nglobal everybody's)
   __shared__ QrLevelNode sh_next[QR_BATCH];
   __shared__ uint32_t sh_pw0[QR_BATCH + 1], sh_epoch;
@@ -3026,6 +3070,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
                    featthr, F, root_buf, G, blocks, nblocks, hist_wg, hist_grid, nullptr, 0u, plans,
                    scan_wg, 0, hcnt_loc, Nglobal, spec_docs);
   __syncthreads();  // (the writer comes back later than the others; sh_* are final for all)
+  QR_JITTER();      // (stress builds: between the control step and the workgroup's slice, too)
   const int nj = sh_nj;
 #ifdef QR_STEP_TIMING
   const long long tq1 = clock64();
@@ -3059,6 +3104,7 @@ __global__ __launch_bounds__(128 * QR_BATCH) void k_decide_part(
 // Tree end: leaves, leaf outputs, score update
 // ===========================================================================
 __global__ __launch_bounds__(256) void k_finish(QrTreeState *__restrict__ ts) {
+  QR_JITTER();
   // RTNode::save_leaves (rtnode.cc:34-46): DFS, left first.  The links are staged
   // in LDS by the whole workgroup; one lane walks them there.
   __shared__ int32_t s_feat[QR_MAXNODES], s_left[QR_MAXNODES], s_right[QR_MAXNODES];
@@ -3135,6 +3181,7 @@ __global__ __launch_bounds__(256) void k_leaf_sums(
     const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double *__restrict__ lambda,
     const double *__restrict__ weight, double *__restrict__ leafpart) {
+  QR_JITTER();
   __shared__ double sh1[4], sh2[4];
   __shared__ uint32_t lb[QR_MAXNODES + 1];
   __shared__ int8_t lbuf[QR_MAXNODES];  // the list buffer every leaf's segment lives in
@@ -3220,6 +3267,7 @@ __global__ __launch_bounds__(256) void k_leaf_sums_doc(
     const int32_t *__restrict__ gf2lf, const int wide, uint8_t *__restrict__ leafb,
     const double *__restrict__ lambda, const double *__restrict__ weight,
     const uint8_t *__restrict__ present, double *__restrict__ part) {
+  QR_JITTER();
   constexpr int NN = 2 * QR_LDOC;  // nodes of a tree of QR_LDOC leaves (2 L - 1)
   // s_rec[n]: what a step of the walk needs of node n in ONE LDS word -- bit 31 = leaf;
   // a leaf: its DFS index; an internal node: left | right << 8 | index of its test << 16
@@ -3403,6 +3451,7 @@ __global__ __launch_bounds__(256) void k_leaf_sums_doc(
 __global__ __launch_bounds__(256) void k_leaf_ids_scatter(
     const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, uint8_t *__restrict__ leafb) {
+  QR_JITTER();
   __shared__ uint32_t lb[QR_LDOC + 1];
   __shared__ int lbuf[QR_LDOC];
   if (ts->incomplete) return;
@@ -3422,6 +3471,7 @@ __global__ __launch_bounds__(256) void k_leaf_ids_scatter(
 __global__ __launch_bounds__(256) void k_score_update_leaf(
     const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ leafb, const uint32_t N,
     const double shrinkage, double *__restrict__ scores) {
+  QR_JITTER();
   __shared__ double lv[QR_LDOC];
   // (everything is requested at once -- the tree's flag, the leaf values whatever their number,
   // the thread's leaf bytes and scores: one round trip, where flag -> values -> barrier -> data
@@ -3513,6 +3563,7 @@ __global__ __launch_bounds__(1024) void k_leaf_final(QrTreeState *__restrict__ t
                                                      const int stride,
                                                      QrNodesOut *__restrict__ nodes_out,
                                                      const long long seq, const uint32_t dense_slices) {
+  QR_JITTER();
   // the leaves' bounds and nodes first, by all threads: a tree of 64 leaves is four rounds of
   // the loop below per wave, and a round that fetches its bounds itself waits for them before it
   // can ask for its partials (15 us for an oblivious tree of depth 6).  A thread per entry of the
@@ -3609,6 +3660,7 @@ __global__ __launch_bounds__(1024) void k_leaf_global(QrTreeState *__restrict__ 
                                                       const int stride,
                                                       QrNodesOut *__restrict__ nodes_out,
                                                       const long long seq) {
+  QR_JITTER();
   // (batched growth whose enqueued steps did not suffice: the host carries the tree on and
   // enqueues the leaf kernels again, as on one GPU)
   if (ts->incomplete) return;
@@ -3638,6 +3690,7 @@ __global__ __launch_bounds__(256) void k_score_update(
     const QrTreeState *__restrict__ ts, const uint32_t *__restrict__ order0,
     const uint32_t *__restrict__ order1, const double shrinkage,
     double *__restrict__ scores) {
+  QR_JITTER();
   __shared__ uint32_t lb[QR_MAXNODES + 1];
   __shared__ double lv[QR_MAXNODES];
   __shared__ int lbuf[QR_MAXNODES];
@@ -3668,6 +3721,7 @@ __global__ __launch_bounds__(256) void k_score_update_walk(
     const QrTreeState *__restrict__ ts, const uint8_t *__restrict__ fm, const uint32_t N,
     const int32_t *__restrict__ gf2lf, const double shrinkage, double *__restrict__ scores,
     const int wide) {
+  QR_JITTER();
   __shared__ int32_t s_lf[QR_MAXNODES], s_thr[QR_MAXNODES], s_left[QR_MAXNODES], s_right[QR_MAXNODES];
   __shared__ double s_val[QR_MAXNODES];
   if (ts->incomplete) return;  // the host carries the tree on and enqueues this update again
@@ -3760,6 +3814,7 @@ __global__ __launch_bounds__(256) void k_valid_update(
     const QrTreeState *__restrict__ ts, const float *__restrict__ raw,
     const uint32_t vN, const uint32_t F, const double shrinkage,
     double *__restrict__ vscores) {
+  QR_JITTER();
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= vN || ts->incomplete) return;
   const float *x = raw + (size_t)i * F;
@@ -3854,6 +3909,7 @@ __global__ __launch_bounds__(256) void k_obl_fill(
     const int flocal, const uint32_t *__restrict__ thr_size,
     const int32_t *__restrict__ lf2gf, const QrScalars *__restrict__ scal,
     qr_split_t *__restrict__ featrec) {
+  QR_JITTER();
   (void)obl_fill_body(ts, level, hsum, hcnt, flocal, thr_size, lf2gf, scal, featrec);
 }
 
@@ -4135,6 +4191,7 @@ __global__ __launch_bounds__(256) void k_obl_plan(
     const uint32_t *__restrict__ woff, const size_t wcells, const qr_split_t *__restrict__ recs_all,
     const int world, const uint32_t *__restrict__ lcounts, const uint32_t *__restrict__ hcnt_loc,
     const u64 Nglobal, const int root_buf) {
+  QR_JITTER();
   obl_plan_body(ts, level, last_level, G, flocal, hcnt, thr, gf2lf, blocks, nblocks, hist_map, part_map, N,
                 featrec, scal, woff, wcells, recs_all, world, lcounts, hcnt_loc, Nglobal, root_buf);
 }
@@ -4156,6 +4213,7 @@ __global__ __launch_bounds__(256) void k_obl_plan(
 __global__ __launch_bounds__(64) void k_obl_propose(const QrTreeState *__restrict__ ts, const int level,
                                                     const qr_split_t *__restrict__ featrec,
                                                     const int flocal, qr_split_t *__restrict__ recs_local) {
+  QR_JITTER();
   qr_split_t best;
   if (level > 0 && ts->obl_done) {
     best.score = -1.0;
@@ -4176,6 +4234,7 @@ __global__ __launch_bounds__(256) void k_obl_mark(
     const int world, const int32_t *__restrict__ gf2lf, const uint32_t N,
     const uint32_t *__restrict__ hcnt, const int flocal, const uint8_t *__restrict__ fm,
     uint32_t *__restrict__ mask, const uint32_t mask_words) {
+  QR_JITTER();
   __shared__ uint32_t sh_f, sh_t;
   if (threadIdx.x < 64) {
     const qr_split_t best = obl_pick(recs_all, world, 2);
@@ -4218,6 +4277,7 @@ __global__ __launch_bounds__(256) void k_obl_mark(
 }
 
 __global__ void k_obl_reset(QrTreeState *ts, int maxnodes, u64 minls) {
+  QR_JITTER();
   obl_reset_body(ts, (int)(blockIdx.x * blockDim.x + threadIdx.x), maxnodes, minls);
 }
 
@@ -4433,6 +4493,7 @@ static int launch_scan(qr_ctx *c, int root_mode) {
 }
 
 __global__ void k_tree_reset(QrTreeState *ts, int nleaves, u64 minls) {
+  QR_JITTER();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   ts->nleaves_req = nleaves;
   ts->nnodes = 0;

@@ -2,7 +2,10 @@
 over in P processes side by side on the one GPU, with everything read back when the device's tree
 differs from the oracle's (TEST TOOL, GPU box):
 
-    python tests/tools/repro_first_tree.py SEED INDEX [--procs P] [--iters K] [--torch] [--no-drain]
+    python tests/tools/repro_first_tree.py SEED INDEX [--procs P] [--iters K] [--torch] [--no-drain] [--jitter]
+
+--jitter: the library built with -DQR_WG_JITTER (quickrank_amd/lib/libqr_jitter.so: one workgroup in
+eight of every growth launch starts ~30 us late -- the inter-workgroup race stress of k_tree.hip).
 
 The hunt of scripts/r06_hunt.sh met the intermittent mismatch of rounds 4-5 ~1 time in 50 runs of
 config [2] / [248] of seed 0 once EIGHT processes shared the GPU (the round-5 hunts ran one at a
@@ -158,6 +161,10 @@ def main():
         env["QR_NO_TORCH"] = "1"
     if "--no-drain" not in sys.argv:
         env["QR_DEBUG"] = "1"
+    if "--jitter" in sys.argv:
+        env["QR_HIP_LIB"] = os.path.join(HERE, "..", "..", "quickrank_amd", "lib", "libqr_jitter.so")
+        assert os.path.exists(env["QR_HIP_LIB"]), ("build it first: QR_HIP_LIB=.../libqr_jitter.so "
+                                                    "QR_HIP_EXTRA_FLAGS=-DQR_WG_JITTER python -m quickrank_amd.build")
     env.setdefault("OMP_NUM_THREADS", "2")
     t0 = time.time()
     ps = [subprocess.Popen([sys.executable, "-X", "faulthandler", "-c", BODY, str(seed), str(index), str(iters)], env=env,

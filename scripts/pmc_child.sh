@@ -18,11 +18,13 @@ P6=$(pick TCC_REQ_sum TCC_READ_sum TCC_EA0_RD_UNCACHED_32B_sum TCC_TAG_STALL_sum
 P7=FETCH_SIZE
 P8=WRITE_SIZE
 i=0
-for P in "$P1" "$P2" "$P3" "$P4" "$P5" "$P6" "$P7" "$P8"; do
+# (round 6: the TCP_* pass aborts inside rocprofv3 on this image and the wrapped command then hangs -- left out,
+# the TCC request counters with it; every pass under its own timeout)
+for P in "$P1" "$P2" "$P3" "$P7" "$P8"; do
   i=$((i+1))
   [ -z "$P" ] && continue
   echo "pass $i: $P" >> $O/passes.txt
-  rocprofv3 --kernel-trace --pmc $P -d $O/p$i -o pmc --output-format csv -- $B > /dev/null 2> $O/p$i.err || echo "pass $i failed" >> $O/passes.txt
+  timeout -k 10 ${PMC_TIMEOUT:-420} rocprofv3 --kernel-trace --pmc $P -d $O/p$i -o pmc --output-format csv -- $B > /dev/null 2> $O/p$i.err || echo "pass $i failed" >> $O/passes.txt
 done
 python scripts/pmc_child_table.py $O/table.md $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 $O/p6 $O/p7 $O/p8 > /dev/null 2> $O/table.err
 for d in $O/p?; do f=$(find $d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && gzip -c $f > $O/$(basename $d)_cc.csv.gz; rm -rf $d; done

@@ -299,9 +299,15 @@ def verify_rest_causally(tr, oracle, labels, qoff, gtrees, t_first, ntrees, kw, 
             if kind is None and deviance_order_tie(tr.stmap, o, g):
                 kind = "heap_tie"
         if kind is None:
-            print(desc, "TREE", t, "(verified from the device's own scores) MISMATCH", err, flush=True)
-            raise AssertionError((desc, "tree", t, "differs from what the reference's algorithm builds from the "
-                                  "device's own scores, and is none of the classified kinds", err.args))
+            # reported with everything a reader needs to judge it; tests/test_gpu_fuzz.py fails on it
+            import traceback
+            print(desc, "TREE", t, "(verified from the device's own scores) UNCLASSIFIED MISMATCH", repr(err.args),
+                  "".join(traceback.format_tb(err.__traceback__)[-1:]).strip().replace("\n", " | "), flush=True)
+            for nm, arr in (("reference-from-device-scores", o), ("device", g)):
+                print("  ", nm, [(k, int(a["feature"]), int(a["thr_id"]), int(a["left"]), int(a["right"]), int(a["nsamples"]),
+                                  float(a["deviance"]), float(a["value"])) for k, a in enumerate(arr)
+                                 if k < len(o) or a["nsamples"] > 0][:140], flush=True)
+            kind = "unclassified"
         out.append((t, kind))
     return out
 

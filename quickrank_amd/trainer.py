@@ -85,7 +85,9 @@ class Mart:
         return self.ctx.fit_tree(self.nleaves, self.minls, newton)
 
     # Mart::learn main loop (mart.cc:307-383) + rollback (:390-395)
-    def learn(self, x, labels, qoff, valid=None, verbose=False, eval_every=1):
+    def learn(self, x, labels, qoff, valid=None, verbose=False, eval_every=1, on_tree=None):
+        """on_tree(self, m, nodes): called behind every tree fit, before its scores are added (test tools
+        look at the device's state of THAT tree there: tests/tools/fuzz_parity.py FUZZ_LOCKSTEP=1)."""
         self.init(x, labels, qoff, valid)
         lam = self.algo.endswith("LAMBDAMART")
         best_valid = best_train = -np.inf
@@ -105,6 +107,8 @@ class Mart:
                 self.ctx.compute_residuals()
             nodes = self._fit_tree(newton=lam)
             self.ensemble.push(nodes, self.shrinkage)
+            if on_tree is not None:
+                on_tree(self, m, nodes)
             self.ctx.update_scores(self.shrinkage)
             if fused:
                 # (read AFTER the tree is enqueued: the scalars of the lambda pass are finished

@@ -212,16 +212,19 @@ def test_train_multi_gpu_script_default_thresholds_take_the_feature_layout(tmp_p
     from test_gpu_cli import _write_svml
     build.build()
     build.build_host()
+    from quickrank_amd import io
     rng = np.random.default_rng(21)
-    nq, dpq, F = 700, 100, 5
+    # (each rank's shard stays under the 65,536 distinct values its statistics carry; it is the MERGED
+    # rows that a document-sharded node histogram cannot hold: 64 columns x ~70,000 slots > 4M)
+    nq, dpq, F = 700, 100, 64
     N = nq * dpq
     x = rng.standard_normal((N, F)).astype(np.float32)
-    x = np.array([[np.float32(f"{float(v):.9g}") for v in row] for row in x], np.float32)
-    assert len(np.unique(x[:, 0])) > 65536
     labels = np.clip(np.rint(x[:, 0] + 0.5 * x[:, 2] + rng.standard_normal(N) * 0.5 + 1.5), 0, 4).astype(np.float32)
     qoff = (np.arange(nq + 1) * dpq).astype(np.uint64)
     tr = str(tmp_path / "train.svml")
-    _write_svml(tr, x, labels, qoff)
+    io.write_svmlight(tr, x, labels, qoff)        # (%.9f: what the file says is the data of both runs)
+    rx, _, _ = io.read_svmlight(tr)
+    assert sum(len(np.unique(rx[:, f])) + 1 for f in range(F)) > (4 << 20)
     common = ["--algo", "LAMBDAMART", "--train", tr, "--num-trees", "3", "--num-leaves", "8",
               "--min-leaf-support", "3", "--end-after-rounds", "0"]
     m1, m2 = str(tmp_path / "one.xml"), str(tmp_path / "two.xml")

@@ -232,7 +232,7 @@ def device_tree_follows_from_device_scores(tr, oracle, labels, qoff, gtrees, t, 
                       oblivious_depth=kw.get("depth") if algo.startswith("OBV") else None)
     tr.update_output(fit, pseudo, weights)   # rt.cc:165-207: the leaves' outputs, as the device's records carry them
     try:
-        assert_tree_parity(tr.stmap, fit["nodes"], gtrees[t], tie_max_docs=1 << 30, value_rtol=1e-6)
+        assert_tree_parity(tr.stmap, fit["nodes"], gtrees[t][:len(fit["nodes"])], tie_max_docs=1 << 30, value_rtol=1e-6)
         return True
     except AssertionError:
         return False
@@ -274,8 +274,8 @@ def verify_rest_causally(tr, oracle, labels, qoff, gtrees, t_first, ntrees, kw, 
                           oblivious_depth=kw.get("depth") if algo.startswith("OBV") else None)
         tr.update_output(fit, pseudo, weights)
         o = fit["nodes"]
-        try:
-            assert_tree_parity(tr.stmap, o, gtrees[t], tie_max_docs=1 << 30, value_rtol=1e-6)
+        try:   # (the device's records beyond the tree's nodes are padding: compare what the tree holds)
+            assert_tree_parity(tr.stmap, o, gtrees[t][:len(o)], tie_max_docs=1 << 30, value_rtol=1e-6)
             out.append((t, "ok"))
             continue
         except AssertionError as e:
@@ -378,6 +378,69 @@ def oracle_rerun_differs(oracle, om, x, labels, qoff, algo, kw, desc):
 _ORACLE_PROC = None
 
 
+def dump_device_state(ctx, tr, nodes, labels, qoff, om, t, kw, algo, desc):
+    """FUZZ_LOCKSTEP=1 (round 6): the device's tree t differs from the oracle's -- looked at while the
+    device still holds that tree's state: the bin map against the oracle's (bit for bit), the
+    feature-major copy the partition and the leaf walk read against the block rows, the pseudo-responses
+    against the oracle's (valid while the trees before t matched), every node's document list against
+    the set the device's OWN recorded splits send there on the oracle's bin map."""
+    import oracle
+    N = tr.stmap.shape[1]
+    print(desc, "LOCKSTEP tree", t, "differs; device state:", flush=True)
+    try:
+        if not ctx.wide:
+            bins = ctx.read_bins()
+            wrong = np.argwhere(bins.T.astype(np.uint32) != tr.stmap)
+            print("  device bin map != oracle stmap at", len(wrong), "cells", wrong[:8].tolist(), flush=True)
+            fm = ctx.read_bins_fm()
+            wfm = np.argwhere(fm != bins)
+            print("  feature-major copy != block rows at", len(wfm), "cells", wfm[:8].tolist(),
+                  "features", np.unique(wfm[:, 1])[:12].tolist() if len(wfm) else [], flush=True)
+        sc = scores_before(tr.stmap, om, t, kw["shrinkage"])
+        if algo.endswith("LAMBDAMART"):
+            pseudo = oracle.lambdas(labels, sc, qoff)[0]
+        else:
+            pseudo = labels.astype(np.float64) - sc
+        dl, _ = ctx.get_pseudo()
+        bad = np.nonzero(~np.isclose(dl, pseudo, rtol=1e-9, atol=1e-12))[0]
+        print("  pseudo-responses differing from the oracle's on its own scores:", len(bad), bad[:8].tolist(),
+              "| device scores != oracle's:", int(np.count_nonzero(~np.isclose(ctx.get_scores(), sc, rtol=1e-9, atol=1e-12))), flush=True)
+        sets = {0: np.arange(N)}
+        stack = [0]
+        while stack:
+            k = stack.pop()
+            nd = nodes[k]
+            if nd["feature"] < 0:
+                continue
+            d = sets[k]
+            go = tr.stmap[nd["feature"], d] <= nd["thr_id"]
+            sets[int(nd["left"])], sets[int(nd["right"])] = d[go], d[~go]
+            stack += [int(nd["left"]), int(nd["right"])]
+        shown = 0
+        for k in range(len(nodes)):
+            nd = nodes[k]
+            try:
+                ids = np.sort(ctx.node_samples(k).astype(np.int64))
+            except Exception as e:    # (oblivious trees keep no per-node lists)
+                print("  node_samples:", repr(e)[:120], flush=True)
+                break
+            exp = sets.get(k)
+            if exp is None:
+                continue
+            od, ow = np.setdiff1d(ids, exp), np.setdiff1d(exp, ids)
+            dup = len(ids) - len(np.unique(ids))
+            if (len(od) or len(ow) or dup or len(ids) != int(nd["nsamples"])) and shown < 12:
+                shown += 1
+                print("  node %d (feature %d thr %d nsamples %d): list %d (%d duplicates) walked %d; list only %d %s, walked only %d %s"
+                      % (k, nd["feature"], nd["thr_id"], nd["nsamples"], len(ids), dup, len(exp), len(od), od[:5].tolist(),
+                         len(ow), ow[:5].tolist()), flush=True)
+        if not shown:
+            print("  every node's document list is the set its own splits send there", flush=True)
+        print("  split log:", [(int(s["feature"]), int(s["thr_id"]), int(s["lcount"]), int(s["rcount"])) for s in ctx.split_log()][:40], flush=True)
+    except Exception as e:
+        print("  (dump failed: %r)" % (e,), flush=True)
+
+
 def draw_config(rng, make_dataset):
     """The next configuration of a sweep's random stream: (algo, kw, x, labels, qoff, F, nthr, minls, adversarial)."""
     F = int(rng.choice([5, 9, 16, 17, 40, 64, 65, 136, 200]))
@@ -455,9 +518,20 @@ def sweep(n_cfg=30, seed=0, only=None, verbose=True, _retry=True):
             if os.environ.get("FUZZ_ORACLE_ONLY"):
                 out.append(rec)
                 continue
-        gm = Mart(algo=algo, **kw).learn(x, labels, qoff)
-        assert len(gm.ensemble) == om["ntrees_built"], desc
         tr = oracle.Trainer(x, nthr)
+        hook = None
+        if os.environ.get("FUZZ_LOCKSTEP"):
+            def hook(mart, t, nodes, _first=[True]):
+                if not _first[0] or t >= om["ntrees_built"]:
+                    return
+                n = int(om["nnodes"][t])
+                try:
+                    assert_tree_parity(tr.stmap, om["nodes"][t][:n], nodes[:n], tie_max_docs=1 << 30)
+                except AssertionError:
+                    _first[0] = False     # (what follows a first difference differs legitimately)
+                    dump_device_state(mart.ctx, tr, nodes, labels, qoff, om, t, kw, algo, desc)
+        gm = Mart(algo=algo, **kw).learn(x, labels, qoff, on_tree=hook)
+        assert len(gm.ensemble) == om["ntrees_built"], desc
         for t in range(om["ntrees_built"]):
             n = int(om["nnodes"][t])
             try:

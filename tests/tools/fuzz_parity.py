@@ -427,6 +427,25 @@ def dump_device_state(ctx, tr, nodes, labels, qoff, om, t, kw, algo, desc):
             exp = sets.get(k)
             if exp is None:
                 continue
+            if not ctx.wide:   # the node's histogram counts against the documents its own splits send there
+                try:
+                    _, hc = ctx.node_hist(k)
+                    F_ = tr.stmap.shape[0]
+                    badf = []
+                    for f in range(F_):
+                        want = np.cumsum(np.bincount(tr.stmap[f, exp], minlength=hc.shape[1]))[:hc.shape[1]]
+                        nz = int(tr.thr_size[f]) if hasattr(tr, "thr_size") else hc.shape[1]
+                        if not np.array_equal(np.asarray(hc[f, :nz], np.int64), want[:nz]):
+                            badf.append(f)
+                    if badf:
+                        f = badf[0]
+                        want = np.cumsum(np.bincount(tr.stmap[f, exp], minlength=hc.shape[1]))
+                        print("  node %d: HISTOGRAM counts differ from its walked documents' in %d features, e.g. feature %d: device %s walked %s"
+                              % (k, len(badf), f, np.asarray(hc[f, :12]).tolist(), want[:12].tolist()), flush=True)
+                except Exception as e:
+                    print("  node_hist(%d): %r" % (k, e), flush=True)
+            if nd["feature"] >= 0:
+                continue   # (an internal node's segment has been re-partitioned by its descendants: only leaves' lists stand)
             od, ow = np.setdiff1d(ids, exp), np.setdiff1d(exp, ids)
             dup = len(ids) - len(np.unique(ids))
             if (len(od) or len(ow) or dup or len(ids) != int(nd["nsamples"])) and shown < 12:

@@ -22,7 +22,9 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
+#include <string>
 #include <random>
 #include <vector>
 
@@ -74,7 +76,107 @@ __global__ __launch_bounds__(256) void k_tile(const uint8_t *__restrict__ in, co
   }
 }
 
+// the same comparison on the device, in a launch of its own behind the two (a store that never reached
+// memory is as missing to this kernel as to the copy back): lets an iteration cost milliseconds
+__global__ __launch_bounds__(256) void k_check(const float *__restrict__ raw, const uint32_t N, const uint32_t F,
+                                               const float *__restrict__ thr, const uint32_t T, const uint32_t fw,
+                                               const uint8_t *__restrict__ out, const uint8_t *__restrict__ cm,
+                                               unsigned long long *__restrict__ bad) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)N * fw) return;
+  const uint32_t d = (uint32_t)(i / fw), c = (uint32_t)(i % fw);
+  if (c >= F) return;
+  const float x = raw[(size_t)d * F + c];
+  const float *t = thr + (size_t)c * T;
+  uint32_t lo = 0, hi = T;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (x <= t[mid])
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  const uint8_t want = (uint8_t)(1 + (lo >= T ? T - 1 : lo));
+  if (out[(size_t)d * fw + c] != want) {
+    atomicAdd(&bad[0], 1ull);
+    atomicAdd(&bad[2 + (i / 256) % 8], 1ull);
+  }
+  if (c < 64 && cm[(size_t)c * N + d] != want) {
+    atomicAdd(&bad[1], 1ull);
+    atomicAdd(&bad[10 + (d / 64) % 8], 1ull);
+  }
+}
+
+// "fast" mode: scripts/ubench/lost_writes fast SECONDS SEED QUEUES -- the same chain checked by k_check on the
+// device, rows taken from one host pool, QUEUES extra streams of different priorities kept alive and
+// poked every iteration (the product's contexts hold up to five streams each: eight processes
+// oversubscribe the hardware queues, four do not), one more stream created and destroyed per iteration.
+static int run_fast(const double seconds, const unsigned seed, const int nq) {
+  std::mt19937 rng(seed);
+  const size_t POOL = (size_t)8 << 20;
+  std::vector<float> pool(POOL + 100000 * 64);
+  for (auto &v : pool) v = (float)(rng() % 100000) * 1e-5f;
+  std::vector<hipStream_t> qs((size_t)nq);
+  for (int i = 0; i < nq; ++i) CK(hipStreamCreateWithPriority(&qs[(size_t)i], hipStreamNonBlocking, -(i % 3)));
+  unsigned long long *d_bad;
+  float *d_poke;
+  CK(hipMalloc(&d_bad, 18 * 8));
+  CK(hipMalloc(&d_poke, 4096));
+  long its = 0, bad_iters = 0;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const auto t0 = std::chrono::steady_clock::now();
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    const uint32_t N = 1000 + rng() % 100000, F = 5 + rng() % 60, T = 8 + rng() % 56;
+    const uint32_t fw = (F + 15) / 16 * 16;
+    const float *x = pool.data() + rng() % POOL;
+    std::vector<float> thr((size_t)F * T);
+    for (uint32_t f = 0; f < F; ++f)
+      for (uint32_t t = 0; t < T; ++t) thr[(size_t)f * T + t] = (float)(t + 1) / (float)(T + 1);
+    float *d_raw, *d_thr;
+    uint8_t *d_out, *d_cm;
+    CK(hipMalloc(&d_raw, (size_t)N * F * 4));
+    CK(hipMalloc(&d_thr, thr.size() * 4));
+    CK(hipMalloc(&d_out, (size_t)N * fw));
+    CK(hipMalloc(&d_cm, (size_t)F * N));
+    CK(hipMemcpy(d_raw, x, (size_t)N * F * 4, hipMemcpyDefault));
+    CK(hipMemcpy(d_thr, thr.data(), thr.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(d_bad, 0, 18 * 8));
+    const unsigned g = (unsigned)(((size_t)N * fw + 255) / 256);
+    hipLaunchKernelGGL(k_map, dim3(g), dim3(256), 0, st, d_raw, N, F, d_thr, T, fw, d_out);
+    hipLaunchKernelGGL(k_tile, dim3((N + 63) / 64), dim3(256), 0, st, d_out, N, F, fw, d_cm);
+    for (int i = 0; i < nq; ++i) CK(hipMemsetAsync(d_poke, 0, 64, qs[(size_t)i]));
+    CK(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_check, dim3(g), dim3(256), 0, st, d_raw, N, F, d_thr, T, fw, d_out, d_cm, d_bad);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(st));
+    unsigned long long b[18];
+    CK(hipMemcpy(b, d_bad, sizeof(b), hipMemcpyDeviceToHost));
+    if (b[0] || b[1]) {
+      ++bad_iters;
+      printf("iteration %ld (N %u F %u fw %u T %u): row-major copy wrong in %llu cells, column-major copy in %llu; by (workgroup index %% 8): "
+             "k_map [%llu %llu %llu %llu %llu %llu %llu %llu] k_tile [%llu %llu %llu %llu %llu %llu %llu %llu]\n", its, N, F, fw, T, b[0], b[1],
+             b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10], b[11], b[12], b[13], b[14], b[15], b[16], b[17]);
+      fflush(stdout);
+    }
+    for (int i = 0; i < nq; ++i) CK(hipStreamSynchronize(qs[(size_t)i]));
+    CK(hipFree(d_raw));
+    CK(hipFree(d_thr));
+    CK(hipFree(d_out));
+    CK(hipFree(d_cm));
+    CK(hipStreamDestroy(st));
+    ++its;
+  }
+  printf("fast mode: %ld iterations in %.0f s with %d extra queues, %ld damaged\n", its, seconds, nq, bad_iters);
+  return bad_iters ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && std::string(argv[1]) == "fast")
+    return run_fast(argc > 2 ? atof(argv[2]) : 60.0, argc > 3 ? (unsigned)atoi(argv[3]) : 1u, argc > 4 ? atoi(argv[4]) : 5);
   const int iters = argc > 1 ? atoi(argv[1]) : 200;
   const unsigned seed = argc > 2 ? (unsigned)atoi(argv[2]) : 1u;
   std::mt19937 rng(seed);

@@ -52,13 +52,18 @@ def _assert_fp_tie_is_the_references_rounding(r):
 
 
 def _report_oracle_reruns(res):
-    """A configuration judged twice because two runs of the ORACLE on the same inputs gave
-    different trees (fuzz_parity.oracle_rerun_differs): reported loudly, and bounded -- the
-    second judgement (fresh oracle run, fresh device run) had to pass like any other."""
+    """A configuration judged twice because two runs of the ORACLE on the same inputs gave different
+    trees (fuzz_parity.oracle_rerun_differs) is printed with both values -- and FAILS the sweep
+    (round 6; rounds 4-5 tolerated one per sweep).  What round 6's hunt found
+    (profiles/r06_hunt.md): 144,000 sweep configurations in 400 processes, four at a time on the GPU,
+    every device tree compared behind its fit: not one event of either kind; the events of rounds
+    4-6 need eight processes and a host oversubscribed eight times over, and are then the DEVICE's
+    memory -- the stores of one workgroup in eight of an element-wise kernel missing, GPU page
+    faults beside them -- not the checker's."""
     again = [r for r in res if r.get("oracle_reruns")]
     for r in again:
-        print("ORACLE NOT REPRODUCIBLE (judged again, passed):", r["desc"], r["oracle_diff"])
-    assert len(again) <= 1, [r["desc"] for r in again]
+        print("ORACLE NOT REPRODUCIBLE (judged again):", r["desc"], r["oracle_diff"])
+    assert len(again) == 0, [r["desc"] for r in again]
 
 
 def test_fuzz_sweep_seed0():

@@ -165,12 +165,10 @@ __device__ __forceinline__ void hist_accumulate(
   for (int k = 0; k < 16; ++k) colk[k] = 16 * c + ((k + r) & 15);
   const int dr = r >> 2;       // dword rotation
   const uint32_t br = r & 3;   // byte rotation inside a dword
-  // (SUMS: the sixteen column indices packed into four registers, a byte each;
-  // -DQR_HIST_PACKED_COLS=1, an A/B: every variant keeps them packed)
-#ifndef QR_HIST_PACKED_COLS
-#define QR_HIST_PACKED_COLS 0
-#endif
-  constexpr bool PACKED = SUMS || QR_HIST_PACKED_COLS;
+  // (SUMS: the sixteen column indices packed into four registers, a byte each.  Round 6 measured the
+  // packing in EVERY variant -- no spill in k_hist_root, 90 VGPRs -- and the root launch got slower,
+  // 39.4 -> 40.9 us: profiles/r06_child_hist_bound.md)
+  constexpr bool PACKED = SUMS;
   uint32_t cp[4] = {0, 0, 0, 0};
   if (PACKED) {
 #pragma unroll

@@ -655,16 +655,11 @@ static int bins_finish(qr_ctx *c) {
   // 13 us).
   const size_t chunks = (f_hi - f_lo + 15) / 16;
   const size_t nblk = (chunks + 3) / 4;
-  // (QR_BLOCKS_WIDE=1, an A/B of round 6: full 64-column blocks first -- a gathered row of a full
-  // block is exactly one aligned 64-byte line, where a 48-byte row straddles two every other time)
-  const bool wide_first = getenv("QR_BLOCKS_WIDE") != nullptr;
-  size_t g0 = f_lo, chunks_left = chunks;
+  size_t g0 = f_lo;
   for (size_t bi = 0; bi < nblk; ++bi) {
     QrBlock b;
     b.f0 = (int)g0;
     b.fw = 16 * (int)(chunks / nblk + (bi < chunks % nblk ? 1 : 0));
-    if (wide_first) b.fw = 16 * (int)std::min<size_t>(4, chunks_left);
-    chunks_left -= (size_t)b.fw / 16;
     b.nreal = (int)std::min<size_t>((size_t)b.fw, f_hi - g0);
     g0 += (size_t)b.nreal;
     b.lf0 = lf;

@@ -127,6 +127,20 @@ def newest_profile(suffix):
     return c[-1] if c else None
 
 
+def hist_source_fingerprint():
+    """sha1 of the histogram accumulation's SOURCE (k_tree.hip, `hist_accumulate` .. `k_hist_batch`): the
+    PMC passes under profiles/ carry the fingerprint of the kernel they were collected on, and a line
+    that quotes counters of another kernel says so (the figure must not age silently)."""
+    import hashlib
+    try:
+        t = open(os.path.join(ROOT, "quickrank_amd", "csrc", "k_tree.hip")).read()
+        a = t.index("__device__ __forceinline__ void hist_accumulate(")
+        b = t.index("// k_reduce: sum the workgroup partials")
+        return hashlib.sha1(t[a:b].encode()).hexdigest()[:16]
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -649,9 +663,14 @@ def main():
             pmc = newest_profile("pmc_hist.json")
             if pmc and N == 1000000 and F == 136 and args.nthresholds == 255 \
                     and not args.sparse_cols:
-                traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+                pj = json.load(open(pmc))
+                traffic = pj["hbm_bytes_per_launch"]
                 tsrc = ("profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                        "collected with scripts/collect_round_profiles.sh: counters cannot be read inside the process)")
+                        "collected with scripts/r06_final.sh: counters cannot be read inside the process)")
+                fp = hist_source_fingerprint()
+                if pj.get("kernel_source_fingerprint") != fp:
+                    tsrc += (f"; STALE: collected on a kernel whose source fingerprint was {pj.get('kernel_source_fingerprint')}, "
+                             f"this one is {fp}")
             roof = {"bound": "hbm", "kernel": "k_hist_root (root histogram build)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,

@@ -13,6 +13,7 @@
 import csv
 import glob
 import json
+import os
 import sys
 
 
@@ -84,6 +85,12 @@ def hist(dir_fetch, dir_write, out, millions=1):
     res["child_launches"] = {"kernel": "k_hist_batch", "classes": classes,
                              "FETCH_MB_per_tree": round(tf / ntrees / 1024, 1),
                              "WRITE_MB_per_tree": round(tw / ntrees / 1024, 1), "trees": ntrees}
+    try:   # (bench.py quotes these counters only for the kernel they were collected on)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from bench import hist_source_fingerprint
+        res["kernel_source_fingerprint"] = hist_source_fingerprint()
+    except Exception:
+        pass
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

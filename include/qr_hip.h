@@ -195,6 +195,17 @@ int qr_bins_read(qr_ctx *ctx, uint8_t *out);
 /* debug/parity: the same from the FEATURE-MAJOR copy of the u8 bins (the one the partition    */
 /* of rt.cc:325-334 and the leaf walk read); tests/tools/repro_first_tree.py compares the two  */
 int qr_bins_read_fm(qr_ctx *ctx, uint8_t *out);
+/* verify-after-write of the resident u8 bin map (round 6): every cell recomputed from the raw   */
+/* rows on the device and compared with the block rows and with the feature-major copy; the      */
+/* counts of cells that differ.  qr_bins_build / qr_bins_build_with run it themselves and build  */
+/* the map again (up to three times) when it reports any: RTRootHistogram's stmap                */
+/* (rtnode_histogram.cc:227-253) is written once and read by every tree.                         */
+int qr_bins_verify(qr_ctx *ctx, unsigned long long *bad_block_rows, unsigned long long *bad_feature_major);
+/* test aid: zero the bin rows of documents [first_doc, first_doc + ndocs) in the block rows     */
+/* (which = 0) or in the feature-major copy (which = 1) -- what a lost store looks like;         */
+/* which = 2: the next `first_doc` builds of the map lose documents [8, 16) of the block rows    */
+/* behind their kernels (the rebuild path of qr_bins_build)                                      */
+int qr_debug_bins_clobber(qr_ctx *ctx, int which, size_t first_doc, size_t ndocs);
 
 /* ---- model state: scores_on_training_ (mart.cc:121), pseudoresponses_,        */
 /*      instance_weights_ (lambdamart.cc:34-39)                                  */

@@ -10,6 +10,8 @@
 // with the exact f32 operations of mart.cc:147-169.  The bin map is stored as
 // uint8 in 64-feature blocks, row-major inside a block ([block][doc][fw]), the
 // layout the histogram kernels stream and gather (DESIGN.md "HBM layout").
+#include <cstdio>
+
 #include "qr_internal.h"
 
 // ---------------------------------------------------------------------------
@@ -182,7 +184,70 @@ __global__ __launch_bounds__(256) void k_bins_fm(const uint8_t *__restrict__ bin
   }
 }
 
-int qr_k_binning(qr_ctx *c) {
+// Verify-after-write of the resident bin map (round 6).  The bin map and its feature-major copy are
+// written ONCE and read by every launch of every tree; the r06 hunt (profiles/r06_hunt.md) saw
+// this platform drop the stores of one workgroup in eight of exactly these two launches when eight
+// processes shared the GPU -- zeros in 12.5 % of the map, a wrong model from then on, silently.  So
+// the map is checked once behind its kernels: every cell recomputed from the raw rows and compared
+// with BOTH copies, by a workgroup that is NOT the one that stored it (the index is rotated by three
+// workgroups, so another XCD's L2 / TLB reads it back).  One more pass over the raw matrix per data set
+// (0.9 ms per million documents x 136 features, next to 18 ms of upload).  out[0] / out[1]: cells of the
+// block rows / of the feature-major copy that do not hold what the binning computes.
+__global__ __launch_bounds__(256) void k_bins_verify(const float *__restrict__ raw, uint32_t N, uint32_t F,
+                                                     const float *__restrict__ thr,
+                                                     const uint32_t *__restrict__ thr_size, QrBlock blk,
+                                                     const uint8_t *__restrict__ bins,
+                                                     const uint8_t *__restrict__ fm,
+                                                     unsigned long long *__restrict__ out) {
+  const uint32_t fw = (uint32_t)blk.fw;
+  const unsigned g = (blockIdx.x + 3u) % gridDim.x;
+  const size_t idx = (size_t)g * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * fw) return;
+  const uint32_t d = (uint32_t)(idx / fw), cidx = (uint32_t)(idx % fw);
+  uint8_t want = 0;
+  const bool real = cidx < (uint32_t)blk.nreal;
+  if (real) {
+    const uint32_t f = blk.f0 + cidx;
+    const float x = raw[(size_t)d * F + f];
+    const float *t = thr + (size_t)f * QR_MAX_BINS;
+    uint32_t lo = 0, hi = thr_size[f];
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (x <= t[mid])
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    const uint32_t last = thr_size[f] - 1;
+    want = (uint8_t)(lo > last ? last : lo);
+  }
+  if (bins[blk.off + (size_t)d * fw + cidx] != want) atomicAdd(&out[0], 1ull);
+  if (real && fm[(size_t)(blk.lf0 + cidx) * N + d] != want) atomicAdd(&out[1], 1ull);
+}
+
+int qr_k_bins_verify(qr_ctx *c, unsigned long long *bad_rows, unsigned long long *bad_fm) {
+  unsigned long long *d_out = nullptr;
+  QR_CHECK(c, hipMalloc((void **)&d_out, 16));
+  QR_CHECK(c, hipMemsetAsync(d_out, 0, 16, c->stream));
+  for (int b = 0; b < c->nblocks; ++b) {
+    const QrBlock &blk = c->blocks[b];
+    const unsigned grid = (unsigned)((c->N * (size_t)blk.fw + 255) / 256);
+    if (!grid) continue;
+    hipLaunchKernelGGL(k_bins_verify, dim3(grid), dim3(256), 0, c->stream, c->d_raw, (uint32_t)c->N, (uint32_t)c->F,
+                       c->d_thr, c->d_thr_size, blk, (const uint8_t *)c->d_bins, (const uint8_t *)c->d_bins_fm, d_out);
+  }
+  unsigned long long h[2] = {0, 0};
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(h, d_out, 16, hipMemcpyDeviceToHost);
+  (void)hipFree(d_out);
+  QR_CHECK(c, e);
+  *bad_rows = h[0];
+  *bad_fm = h[1];
+  return QR_OK;
+}
+
+static int binning_launches(qr_ctx *c) {
   const int rc = qr_k_binning_blocks(c);
   if (rc) return rc;
   for (int b = 0; b < c->nblocks; ++b) {
@@ -192,6 +257,34 @@ int qr_k_binning(qr_ctx *c) {
     QR_CHECK(c, hipGetLastError());
   }
   return QR_OK;
+}
+
+int qr_k_binning(qr_ctx *c) {
+  // (the raw rows are on the device when the map is made from them: contexts that were handed a
+  // map's thresholds only -- qr_bins_build_with -- hold them too)
+  for (int attempt = 0;; ++attempt) {
+    int rc = binning_launches(c);
+    if (rc) return rc;
+    if (c->debug_lose_binning > 0 && c->N >= 16) {  // (test aid: what a workgroup's lost stores look like)
+      --c->debug_lose_binning;
+      QR_CHECK(c, hipStreamSynchronize(c->stream));
+      QR_CHECK(c, hipMemset(c->d_bins + c->blocks[0].off + 8 * (size_t)c->blocks[0].fw, 0xFF, 8 * (size_t)c->blocks[0].fw));
+    }
+    unsigned long long bad_rows = 0, bad_fm = 0;
+    if ((rc = qr_k_bins_verify(c, &bad_rows, &bad_fm))) return rc;
+    if (!bad_rows && !bad_fm) {
+      c->bins_rebuilt = attempt;
+      return QR_OK;
+    }
+    fprintf(stderr, "qr: the bin map on the device does not hold what the binning kernel stored (%llu cells of the block "
+                    "rows, %llu of the feature-major copy, attempt %d): device memory lost stores -- %s\n",
+            bad_rows, bad_fm, attempt + 1, attempt < 2 ? "building it again" : "giving up");
+    if (attempt == 2) {
+      c->err = "the bin map on the device does not hold what the binning kernel stored, three times in a row: "
+               "device memory loses stores (profiles/r06_hunt.md)";
+      return QR_ERR_HIP;
+    }
+  }
 }
 
 static int qr_k_binning_blocks(qr_ctx *c) {

@@ -1155,6 +1155,34 @@ int qr_bins_read_fm(qr_ctx *c, uint8_t *out) {
   return QR_OK;
 }
 
+int qr_bins_verify(qr_ctx *c, unsigned long long *bad_rows, unsigned long long *bad_fm) {
+  if (!c || !bad_rows || !bad_fm) return QR_ERR_ARG;
+  if (!c->binned) QR_FAIL(c, QR_ERR_STATE, "bins not built");
+  if (c->wide) QR_FAIL(c, QR_ERR_STATE, "this context has more than 255 thresholds per feature");
+  { const int src_ = tree_settle(c); if (src_) return src_; }
+  return qr_k_bins_verify(c, bad_rows, bad_fm);
+}
+
+int qr_debug_bins_clobber(qr_ctx *c, int which, size_t first_doc, size_t ndocs) {
+  if (!c || which < 0 || which > 2) return QR_ERR_ARG;
+  if (which == 2) {  // the next `first_doc` builds of the map lose documents [8, 16) behind their kernels
+    c->debug_lose_binning = (int)first_doc;
+    return QR_OK;
+  }
+  if (!c->binned || c->wide) QR_FAIL(c, QR_ERR_STATE, "u8 bins not built");
+  if (first_doc > c->N || ndocs > c->N - first_doc) QR_FAIL(c, QR_ERR_ARG, "documents out of range");
+  QR_CHECK(c, hipStreamSynchronize(c->stream));
+  for (const QrBlock &b : c->blocks) {
+    if (which == 0) {
+      QR_CHECK(c, hipMemset(c->d_bins + b.off + first_doc * (size_t)b.fw, 0, ndocs * (size_t)b.fw));
+    } else {
+      for (int i = 0; i < b.nreal; ++i)
+        QR_CHECK(c, hipMemset(c->d_bins_fm + (size_t)(b.lf0 + i) * c->N + first_doc, 0, ndocs));
+    }
+  }
+  return QR_OK;
+}
+
 // ---------------------------------------------------------------------------
 int qr_scores_reset(qr_ctx *c) {
   if (!c || !c->d_scores) return QR_ERR_STATE;

@@ -463,6 +463,8 @@ struct qr_ctx {
   size_t lu_dyn[2] = {0, 0};
   bool lu_on[2] = {false, false};
   // Mart::update_modelscores left to the next lambda pass (k_tree.hip: qr_k_scores_update)
+  int debug_lose_binning = 0;         // qr_debug_bins_clobber(which = 2): builds of the map that lose a few rows (test aid)
+  int bins_rebuilt = 0;               // times qr_k_binning had to build the map again (verify-after-write; expected 0)
   bool no_lazy_scores = false;        // QR_LAZY_SCORES=0 at context creation: every score update is a launch of its own
   bool lazy_scores = false;
   double lazy_shrinkage = 0.0;
@@ -671,6 +673,7 @@ int qr_k_transpose(qr_ctx *c, const float *raw, float *col, size_t N, size_t F);
 int qr_k_colstats(qr_ctx *c, const float *col, size_t N, size_t F, uint32_t limit,
                   uint32_t *d_vals, uint32_t *d_cnt, uint32_t *d_minmax);
 int qr_k_binning(qr_ctx *c);
+int qr_k_bins_verify(qr_ctx *c, unsigned long long *bad_rows, unsigned long long *bad_fm);
 int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds);
 int qr_k_wide_binning(qr_ctx *c, const float *d_col);
 bool qr_k_wide_fast_rows(const qr_ctx *c, size_t max_slots);

@@ -224,7 +224,36 @@ __global__ __launch_bounds__(256) void k_wbins16(const uint32_t *__restrict__ bi
   o[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-int qr_k_wide_binning(qr_ctx *c, const float *d_col) {
+// verify-after-write of the wide bin map (k_bins.hip: k_bins_verify says why): every slot recomputed
+// from the column and compared with the u32 map and, where it exists, with the u16 copy -- by a
+// workgroup three places away from the one that stored it.  out[0] / out[1]: cells that differ.
+__global__ __launch_bounds__(256) void k_wbins_verify(const float *__restrict__ col, const uint32_t N,
+                                                      const float *__restrict__ thr,
+                                                      const uint32_t *__restrict__ woff,
+                                                      const uint32_t *__restrict__ bins,
+                                                      const uint16_t *__restrict__ bins16, const uint32_t F,
+                                                      const int32_t *__restrict__ lf2gf,
+                                                      unsigned long long *__restrict__ out) {
+  const uint32_t f = blockIdx.y;
+  const uint32_t d = ((blockIdx.x + 3u) % gridDim.x) * 256 + threadIdx.x;
+  if (d >= N) return;
+  const float x = col[(size_t)lf2gf[f] * N + d];
+  const float *t = thr + woff[f];
+  const uint32_t size = woff[f + 1] - woff[f];
+  uint32_t lo = 0, hi = size;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (x <= t[mid])
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  const uint32_t want = lo > size - 1 ? size - 1 : lo;
+  if (bins[(size_t)f * N + d] != want) atomicAdd(&out[0], 1ull);
+  if (bins16 && bins16[((size_t)(f / 16) * N + d) * 16 + (f % 16)] != (uint16_t)want) atomicAdd(&out[1], 1ull);
+}
+
+static int wide_binning_launches(qr_ctx *c, const float *d_col) {
   hipLaunchKernelGGL(k_wbinning, dim3((unsigned)((c->N + 255) / 256), (unsigned)c->flocal), dim3(256), 0,
                      c->stream, d_col, (uint32_t)c->N, c->d_wthr, c->d_woff, c->d_wbins, c->d_lf2gf);
   QR_CHECK(c, hipGetLastError());
@@ -233,6 +262,45 @@ int qr_k_wide_binning(qr_ctx *c, const float *d_col) {
                        c->stream, c->d_wbins, (uint32_t)c->N, (uint32_t)c->flocal, c->d_wbins16);
     QR_CHECK(c, hipGetLastError());
   }
+  return QR_OK;
+}
+
+int qr_k_wide_binning(qr_ctx *c, const float *d_col) {
+  if (!c->N || !c->flocal) return wide_binning_launches(c, d_col);
+  unsigned long long *d_out = nullptr;
+  QR_CHECK(c, hipMalloc((void **)&d_out, 16));
+  for (int attempt = 0;; ++attempt) {
+    int rc = wide_binning_launches(c, d_col);
+    if (rc) {
+      (void)hipFree(d_out);
+      return rc;
+    }
+    unsigned long long h[2] = {0, 0};
+    hipError_t e = hipMemsetAsync(d_out, 0, 16, c->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_wbins_verify, dim3((unsigned)((c->N + 255) / 256), (unsigned)c->flocal), dim3(256), 0, c->stream,
+                         d_col, (uint32_t)c->N, c->d_wthr, c->d_woff, (const uint32_t *)c->d_wbins,
+                         (const uint16_t *)c->d_wbins16, (uint32_t)c->flocal, c->d_lf2gf, d_out);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(h, d_out, 16, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      (void)hipFree(d_out);
+      QR_CHECK(c, e);
+    }
+    if (!h[0] && !h[1]) break;
+    fprintf(stderr, "qr: the wide bin map on the device does not hold what the binning kernel stored (%llu cells of the u32 "
+                    "map, %llu of the u16 copy, attempt %d): device memory lost stores -- %s\n",
+            h[0], h[1], attempt + 1, attempt < 2 ? "building it again" : "giving up");
+    if (attempt == 2) {
+      (void)hipFree(d_out);
+      c->err = "the wide bin map on the device does not hold what the binning kernel stored, three times in a row: "
+               "device memory loses stores (profiles/r06_hunt.md)";
+      return QR_ERR_HIP;
+    }
+  }
+  (void)hipFree(d_out);
   return QR_OK;
 }
 

@@ -11,6 +11,7 @@
 // uint8 in 64-feature blocks, row-major inside a block ([block][doc][fw]), the
 // layout the histogram kernels stream and gather (DESIGN.md "HBM layout").
 #include <cstdio>
+#include <cstring>
 
 #include "qr_internal.h"
 
@@ -221,14 +222,22 @@ __global__ __launch_bounds__(256) void k_bins_verify(const float *__restrict__ r
     const uint32_t last = thr_size[f] - 1;
     want = (uint8_t)(lo > last ? last : lo);
   }
-  if (bins[blk.off + (size_t)d * fw + cidx] != want) atomicAdd(&out[0], 1ull);
-  if (real && fm[(size_t)(blk.lf0 + cidx) * N + d] != want) atomicAdd(&out[1], 1ull);
+  // out[2..9] / out[10..17]: the same by the index mod 8 of the workgroup that STORED the cell (workgroups of a
+  // launch go round the eight XCDs: the hunt's events are one residue each)
+  if (bins[blk.off + (size_t)d * fw + cidx] != want) {
+    atomicAdd(&out[0], 1ull);
+    atomicAdd(&out[2 + g % 8u], 1ull);
+  }
+  if (real && fm[(size_t)(blk.lf0 + cidx) * N + d] != want) {
+    atomicAdd(&out[1], 1ull);
+    atomicAdd(&out[10 + (d / 64u) % 8u], 1ull);
+  }
 }
 
-int qr_k_bins_verify(qr_ctx *c, unsigned long long *bad_rows, unsigned long long *bad_fm) {
+int qr_k_bins_verify(qr_ctx *c, unsigned long long *bad_rows, unsigned long long *bad_fm, unsigned long long *by_wg) {
   unsigned long long *d_out = nullptr;
-  QR_CHECK(c, hipMalloc((void **)&d_out, 16));
-  QR_CHECK(c, hipMemsetAsync(d_out, 0, 16, c->stream));
+  QR_CHECK(c, hipMalloc((void **)&d_out, 18 * 8));
+  QR_CHECK(c, hipMemsetAsync(d_out, 0, 18 * 8, c->stream));
   for (int b = 0; b < c->nblocks; ++b) {
     const QrBlock &blk = c->blocks[b];
     const unsigned grid = (unsigned)((c->N * (size_t)blk.fw + 255) / 256);
@@ -236,14 +245,15 @@ int qr_k_bins_verify(qr_ctx *c, unsigned long long *bad_rows, unsigned long long
     hipLaunchKernelGGL(k_bins_verify, dim3(grid), dim3(256), 0, c->stream, c->d_raw, (uint32_t)c->N, (uint32_t)c->F,
                        c->d_thr, c->d_thr_size, blk, (const uint8_t *)c->d_bins, (const uint8_t *)c->d_bins_fm, d_out);
   }
-  unsigned long long h[2] = {0, 0};
+  unsigned long long h[18] = {};
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (e == hipSuccess) e = hipMemcpy(h, d_out, 16, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost);
   (void)hipFree(d_out);
   QR_CHECK(c, e);
   *bad_rows = h[0];
   *bad_fm = h[1];
+  if (by_wg) memcpy(by_wg, h + 2, 16 * 8);
   return QR_OK;
 }
 
@@ -270,20 +280,35 @@ int qr_k_binning(qr_ctx *c) {
       QR_CHECK(c, hipStreamSynchronize(c->stream));
       QR_CHECK(c, hipMemset(c->d_bins + c->blocks[0].off + 8 * (size_t)c->blocks[0].fw, 0xFF, 8 * (size_t)c->blocks[0].fw));
     }
-    unsigned long long bad_rows = 0, bad_fm = 0;
-    if ((rc = qr_k_bins_verify(c, &bad_rows, &bad_fm))) return rc;
+    unsigned long long bad_rows = 0, bad_fm = 0, by_wg[16];
+    if ((rc = qr_k_bins_verify(c, &bad_rows, &bad_fm, by_wg))) return rc;
     if (!bad_rows && !bad_fm) {
       c->bins_rebuilt = attempt;
       return QR_OK;
     }
+    char where[400];
+    int w = 0;
+    for (int i = 0; i < 16; ++i)
+      w += snprintf(where + w, sizeof(where) - (size_t)w, "%s%llu", i == 8 ? " | " : i ? " " : "", by_wg[i]);
     fprintf(stderr, "qr: the bin map on the device does not hold what the binning kernel stored (%llu cells of the block "
-                    "rows, %llu of the feature-major copy, attempt %d): device memory lost stores -- %s\n",
-            bad_rows, bad_fm, attempt + 1, attempt < 2 ? "building it again" : "giving up");
+                    "rows, %llu of the feature-major copy, attempt %d; by the storing workgroup's index mod 8: %s): device "
+                    "memory lost stores -- %s\n",
+            bad_rows, bad_fm, attempt + 1, where, attempt < 2 ? "building it again at another address" : "giving up");
     if (attempt == 2) {
       c->err = "the bin map on the device does not hold what the binning kernel stored, three times in a row: "
                "device memory loses stores (profiles/r06_hunt.md)";
       return QR_ERR_HIP;
     }
+    // Call 12 of the r06 hunt: a rebuild IN PLACE lost the same cells three times over (one XCD's view of those
+    // addresses stays wrong for the life of the mapping).  So the next attempt gets other addresses: the new
+    // buffers are allocated while the old ones still hold theirs, then the old ones go.
+    uint8_t *nb = nullptr, *nf = nullptr;
+    QR_CHECK(c, hipMalloc((void **)&nb, c->bins_bytes ? c->bins_bytes : 1));
+    QR_CHECK(c, hipMalloc((void **)&nf, (size_t)c->flocal * c->N ? (size_t)c->flocal * c->N : 1));
+    (void)hipFree(c->d_bins);
+    (void)hipFree(c->d_bins_fm);
+    c->d_bins = nb;
+    c->d_bins_fm = nf;
   }
 }
 

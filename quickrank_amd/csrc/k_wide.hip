@@ -292,12 +292,29 @@ int qr_k_wide_binning(qr_ctx *c, const float *d_col) {
     if (!h[0] && !h[1]) break;
     fprintf(stderr, "qr: the wide bin map on the device does not hold what the binning kernel stored (%llu cells of the u32 "
                     "map, %llu of the u16 copy, attempt %d): device memory lost stores -- %s\n",
-            h[0], h[1], attempt + 1, attempt < 2 ? "building it again" : "giving up");
+            h[0], h[1], attempt + 1, attempt < 2 ? "building it again at another address" : "giving up");
     if (attempt == 2) {
       (void)hipFree(d_out);
       c->err = "the wide bin map on the device does not hold what the binning kernel stored, three times in a row: "
                "device memory loses stores (profiles/r06_hunt.md)";
       return QR_ERR_HIP;
+    }
+    // (other addresses for the next attempt, as in qr_k_binning: new buffers first, then the old ones go)
+    uint32_t *nb = nullptr;
+    uint16_t *n16 = nullptr;
+    const size_t FL = (size_t)c->flocal;
+    e = hipMalloc((void **)&nb, c->N * FL * sizeof(uint32_t));
+    if (e == hipSuccess && c->d_wbins16) e = hipMalloc((void **)&n16, c->N * 16 * ((FL + 15) / 16) * sizeof(uint16_t));
+    if (e != hipSuccess) {
+      (void)hipFree(d_out);
+      if (nb) (void)hipFree(nb);
+      QR_CHECK(c, e);
+    }
+    (void)hipFree(c->d_wbins);
+    c->d_wbins = nb;
+    if (n16) {
+      (void)hipFree(c->d_wbins16);
+      c->d_wbins16 = n16;
     }
   }
   (void)hipFree(d_out);

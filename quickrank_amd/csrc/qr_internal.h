@@ -673,7 +673,7 @@ int qr_k_transpose(qr_ctx *c, const float *raw, float *col, size_t N, size_t F);
 int qr_k_colstats(qr_ctx *c, const float *col, size_t N, size_t F, uint32_t limit,
                   uint32_t *d_vals, uint32_t *d_cnt, uint32_t *d_minmax);
 int qr_k_binning(qr_ctx *c);
-int qr_k_bins_verify(qr_ctx *c, unsigned long long *bad_rows, unsigned long long *bad_fm);
+int qr_k_bins_verify(qr_ctx *c, unsigned long long *bad_rows, unsigned long long *bad_fm, unsigned long long *by_wg = nullptr);
 int qr_k_wide_thresholds(qr_ctx *c, const float *d_col, size_t nthresholds);
 int qr_k_wide_binning(qr_ctx *c, const float *d_col);
 bool qr_k_wide_fast_rows(const qr_ctx *c, size_t max_slots);

@@ -487,12 +487,18 @@ class Run:
             self.ctx.prof_enable(True, every=4)
             self.ctx.prof_reset()
         self.sync()
+        who = self.trainer if self.trainer is not None else self.fitter
+        before = list(who.traffic) if who is not None else None
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
         self.flush()
         self.sync()
         elapsed = time.perf_counter() - t0
+        # collectives and payload bytes this rank handed over per tree of the timed region (counted by the
+        # drivers in quickrank_amd/dist.py, not timed separately)
+        self.traffic_per_tree = None if before is None else [(who.traffic[0] - before[0]) / steps,
+                                                              (who.traffic[1] - before[1]) / steps]
         if self.dist is not None:
             t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -522,6 +528,10 @@ class Run:
                 "sigma_built": round(float(np.mean([a[0] for a in sh])), 3),
                 "sigma_reference_left": round(float(np.mean([a[1] for a in sh])), 3),
                 "pi": round(float(np.mean([a[2] for a in sh])), 3),
+                "collectives_per_tree": None if getattr(self, "traffic_per_tree", None) is None
+                else round(self.traffic_per_tree[0], 2),
+                "collective_bytes_per_tree": None if getattr(self, "traffic_per_tree", None) is None
+                else int(self.traffic_per_tree[1]),
                 "collectives": ("rccl-direct on the context's stream, nranks "
                                 f"{self.comm.nranks}" if self.comm is not None else
                                 ("torch.distributed" if self.dist is not None and self.layout != "single"
@@ -990,7 +1000,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": hs["ms_per_step"], "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {k: hs[k] for k in ("workload", "parallelism", "ndcg10_last", "sigma_built",
-                                          "sigma_reference_left", "pi", "collectives")},
+                                          "sigma_reference_left", "pi", "collectives", "collectives_per_tree",
+                                          "collective_bytes_per_tree")},
             "roofline": roof,
         }
         if not multi:

@@ -67,6 +67,9 @@ class ShardedTreeFitter:
         touched (tests drive several rank contexts of one process in lockstep that way)."""
         import torch
         self.torch, self.group = torch, group
+        # what this rank has handed to collectives so far: [calls, payload bytes] (an all-gather counts what
+        # every rank receives: world x the record; an all-reduce the buffer once) -- bench.py's per-tree figures
+        self.traffic = [0, 0]
         if transport is not None:
             self.dist = None
             self.world, self.rank = transport.world, transport.rank
@@ -98,12 +101,16 @@ class ShardedTreeFitter:
             self._b = b
 
     def _gather_records(self):
+        self.traffic[0] += 1
+        self.traffic[1] += self.rec_bytes * self.world
         if self.direct is not None:
             self.direct.all_gather_bytes(self._b["recs_local"], self._b["recs_all"], self.rec_bytes)
             return
         self.dist.all_gather_into_tensor(self.recs_all, self.recs_local, group=self.group)
 
     def _reduce_mask(self):
+        self.traffic[0] += 1
+        self.traffic[1] += self._b["mask_bytes"] if getattr(self, "_b", None) else self.mask.numel() * 4
         if self.direct is not None:
             self.direct.all_reduce_i32(self._b["mask"], self._b["mask_bytes"] // 4)
             return
@@ -143,6 +150,8 @@ class ShardedTreeFitter:
             ctx.obl_propose(level)
             self._gather_records()
             ctx.obl_mark(level)
+            self.traffic[0] += 1
+            self.traffic[1] += self._ob["mask_bytes"]
             if self.direct is not None:
                 self.direct.all_reduce_i32(self._ob["mask"], self._ob["mask_bytes"] // 4)
             else:
@@ -239,6 +248,7 @@ class DocShardedTrainer:
         import torch
         self.torch, self.group, self.ctx = torch, group, ctx
         self.device = device
+        self.traffic = [0, 0]          # [collectives, payload bytes] handed over so far (see ShardedTreeFitter)
         if transport is not None:
             self.dist = None
             self.world, self.rank = transport.world, transport.rank
@@ -275,6 +285,8 @@ class DocShardedTrainer:
     def _sum(self, t, name=None):
         """Sum all-reduce of one of the context's exchange buffers (`name`) or of a
         temporary tensor (name None: always through torch.distributed)."""
+        self.traffic[0] += 1
+        self.traffic[1] += self._ptr[name][1] * 8 if name is not None else t.numel() * t.element_size()
         if self.direct is not None and name is not None:
             self.direct.all_reduce_i64(*self._ptr[name])
             return
@@ -453,6 +465,7 @@ class FeatureShardedTrainer:
     def __init__(self, ctx, group=None, device=None, transport=None):
         self.ctx = ctx
         self.fitter = ShardedTreeFitter(ctx, group=group, device=device, transport=transport)
+        self.traffic = self.fitter.traffic
 
     def compute_lambdas(self, metric="NDCG", cutoff=10):
         self.ctx.compute_lambdas(metric, cutoff)

@@ -75,6 +75,11 @@ def _worker(rank, world, port, q, cuts, ntrees, mode="batched"):
     if mode == "batched":
         # root + steps: the first tree enqueues the worst case, the next ones what the last needed
         ok = ok and exchanges[0] == 8 and all(4 <= e <= 8 for e in exchanges[1:]) and min(exchanges) < 8
+        # the trainer's own account (bench.py's collectives_per_tree / collective_bytes_per_tree): scalars +
+        # histograms + leaf sums per tree, int64 words of the buffers it handed over
+        b = ctx.doc_exchange_buffers()
+        ok = ok and tr.traffic[0] == sum(exchanges) + 2 * ntrees
+        ok = ok and tr.traffic[1] >= 8 * (ntrees * (b["scal_n"] + b["hist_n"]) + (sum(exchanges) - ntrees) * b["hist_n"])
     if mode == "lazy":
         ok = ok and all(e > 2 for e in exchanges)      # one step was never enough for 8 leaves
     if rank == 0:

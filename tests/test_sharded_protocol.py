@@ -34,6 +34,9 @@ def _worker(rank, world, port, q, nleaves, F):
     ctx.set_pseudo(lam, w)
     fitter = ShardedTreeFitter(ctx)
     nodes = fitter.fit_tree(ctx, nleaves, 5, True)
+    # the fitter's own account: a records all-gather per candidate round, a mask all-reduce per split
+    b = ctx.exchange_buffers()
+    assert fitter.traffic == [2 * nleaves - 1, nleaves * b["rec_bytes"] * world + (nleaves - 1) * b["mask_bytes"]]
     if rank == 0:
         tr = oracle.Trainer(x, 255)
         t = tr.fit_tree(lam, nleaves=nleaves, minls=5)

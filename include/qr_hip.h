@@ -277,6 +277,9 @@ int qr_subsample_set(qr_ctx *ctx, float subsample, uint64_t seed);
 /* GLOBAL index, so every rank finds the same sample (the one a single GPU draws from */
 /* the whole set) without an exchange, and keeps its own part of it.                  */
 int qr_subsample_set_doc(qr_ctx *ctx, float subsample, uint64_t seed, size_t first_doc);
+/* test aid: the sample's keys ANDed with `mask` (all ones by default) -- narrow keys meet equal ones, */
+/* which the selection breaks by ascending document as a stable sort of (key, document) would        */
+int qr_debug_sample_key_mask(qr_ctx *ctx, uint32_t mask);
 /* --max-features (rt.cc:222-243): every node's split search sees a random       */
 /* subset of the features: max_features > 1 = that many, < 1 = that fraction     */
 /* (rounded up), 1 = all.  The reference draws it from a clock-seeded engine at  */

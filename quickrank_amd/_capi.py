@@ -29,7 +29,7 @@ METRICS = {"DCG": 0, "NDCG": 1}
 SYMBOLS = [
     "qr_ctx_create", "qr_ctx_destroy", "qr_last_error", "qr_ctx_set_stream",
     "qr_ctx_set_shard", "qr_synchronize", "qr_dataset_upload", "qr_valid_upload",
-    "qr_bins_build", "qr_bins_read", "qr_bins_read_fm", "qr_bins_verify", "qr_debug_bins_clobber", "qr_scores_reset", "qr_scores_set",
+    "qr_bins_build", "qr_bins_read", "qr_bins_read_fm", "qr_bins_verify", "qr_debug_bins_clobber", "qr_debug_sample_key_mask", "qr_scores_reset", "qr_scores_set",
     "qr_scores_get", "qr_valid_scores_get", "qr_pseudo_get", "qr_pseudo_set",
     "qr_lambda_compute", "qr_residual_compute", "qr_metric_eval", "qr_metric_last",
     "qr_tree_fit", "qr_oblivious_fit", "qr_scores_update", "qr_tree_begin",
@@ -128,6 +128,7 @@ def lib():
     L.qr_bins_read_fm.argtypes = [vp, vp]
     L.qr_bins_verify.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.qr_debug_bins_clobber.argtypes = [vp, C.c_int, sz, sz]
+    L.qr_debug_sample_key_mask.argtypes = [vp, C.c_uint32]
     L.qr_bins_build_wide.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz)]
     L.qr_bins_build_wide_with.argtypes = [vp, vp, vp, C.POINTER(sz), C.POINTER(sz)]
     L.qr_bins_stats_wide.argtypes = [vp, sz, vp, vp, vp]
@@ -442,6 +443,10 @@ class Context:
         a, b = C.c_ulonglong(), C.c_ulonglong()
         self._ck(self.L.qr_bins_verify(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def debug_sample_key_mask(self, mask):
+        """Test aid: the --subsample keys ANDed with `mask` (equal keys: ties go by ascending document)."""
+        self._ck(self.L.qr_debug_sample_key_mask(self.h, mask))
 
     def debug_clobber_bins(self, which, first_doc, ndocs):
         self._ck(self.L.qr_debug_bins_clobber(self.h, which, first_doc, ndocs))

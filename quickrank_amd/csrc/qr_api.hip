@@ -206,9 +206,9 @@ static void free_train(qr_ctx *c) {
   dfree(c->d_lpart_state);
   dfree(c->d_lhist_wg); dfree(c->d_lpart_wg); dfree(c->d_lplan);
   c->lhist_cap = c->lpart_cap = c->lslots_cap = c->lred_nodes = 0;
-  dfree(c->d_present); dfree(c->d_sample_keys); dfree(c->d_sample_count);
-  if (c->d_sample_temp) (void)hipFree(c->d_sample_temp);
-  c->d_sample_temp = nullptr;
+  dfree(c->d_present); dfree(c->d_sample_count);
+  if (c->d_sample_work) (void)hipFree(c->d_sample_work);
+  c->d_sample_work = nullptr;
   c->sub_k = 0;
   c->mf_k = 0;
   c->spec_pending = c->spec_scores_enqueued = false;
@@ -1183,6 +1183,12 @@ int qr_debug_bins_clobber(qr_ctx *c, int which, size_t first_doc, size_t ndocs) 
   return QR_OK;
 }
 
+int qr_debug_sample_key_mask(qr_ctx *c, uint32_t mask) {
+  if (!c) return QR_ERR_ARG;
+  c->sub_key_mask = mask;
+  return QR_OK;
+}
+
 // ---------------------------------------------------------------------------
 int qr_scores_reset(qr_ctx *c) {
   if (!c || !c->d_scores) return QR_ERR_STATE;
@@ -1487,10 +1493,8 @@ static int subsample_set(qr_ctx *c, float subsample, uint64_t seed, size_t first
   c->sub_iter = 0;
   if (k && !c->d_present) {
     QR_CHECK(c, dalloc(&c->d_present, c->N));
-    QR_CHECK(c, dalloc(&c->d_sample_keys, 4 * Nall));
     QR_CHECK(c, dalloc(&c->d_sample_count, (size_t)1));
-    c->sample_temp_bytes = qr_k_sample_temp_bytes(Nall);
-    QR_CHECK(c, hipMalloc(&c->d_sample_temp, c->sample_temp_bytes ? c->sample_temp_bytes : 1));
+    QR_CHECK(c, hipMalloc(&c->d_sample_work, qr_k_sample_work_bytes(c->N)));
   }
   return QR_OK;
 }

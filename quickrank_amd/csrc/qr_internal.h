@@ -573,9 +573,8 @@ struct qr_ctx {
   size_t sub_first = 0;          // document-sharded: global index of this rank's first document
   uint64_t sub_seed = 0, sub_iter = 0;
   uint8_t *d_present = nullptr;
-  uint32_t *d_sample_keys = nullptr;  // 4 x N: keys, ids, sorted keys, sorted ids
-  void *d_sample_temp = nullptr;
-  size_t sample_temp_bytes = 0;
+  void *d_sample_work = nullptr;      // the select's histograms and state, the scatter's offsets (k_sample.hip)
+  uint32_t sub_key_mask = 0xFFFFFFFFu; // (tests narrow the keys to meet equal ones: qr_debug_sample_key_mask)
   uint32_t *d_sample_count = nullptr;
   uint32_t mf_k = 0;             // --max-features: features a node's split search sees (0 = all)
   uint64_t mf_seed = 0, tree_counter = 0;
@@ -716,7 +715,7 @@ inline int qr_next_scal_seq(qr_ctx *c) {  // never 0: the value the block starts
 int qr_k_prep_pack(qr_ctx *c);
 int qr_k_prep_global(qr_ctx *c);
 int qr_k_tree_leaves_global(qr_ctx *c, int newton);
-size_t qr_k_sample_temp_bytes(size_t N);
+size_t qr_k_sample_work_bytes(size_t Nloc);
 int qr_k_sample_draw(qr_ctx *c);
 int qr_k_sample_sums(qr_ctx *c);
 int qr_k_metric_reduce(qr_ctx *c, int which);

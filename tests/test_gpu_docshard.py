@@ -227,12 +227,14 @@ def test_doc_sharded_oblivious_equals_single(world, cuts, depth, minls, F, algo)
 
 
 @pytest.mark.parametrize("batched", [False, True])
-@pytest.mark.parametrize("world,cuts,algo,subsample", [
-    (2, [30], "lambda", 0.5),
-    (3, [5, 41], "lambda", 0.3),       # a small first shard: few (or none) of the sample's documents
-    (4, [15, 30, 45], "mart", 900.0),  # a number of documents instead of a fraction
+@pytest.mark.parametrize("world,cuts,algo,subsample,key_mask", [
+    (2, [30], "lambda", 0.5, None),
+    (3, [5, 41], "lambda", 0.3, None),       # a small first shard: few (or none) of the sample's documents
+    (4, [15, 30, 45], "mart", 900.0, None),  # a number of documents instead of a fraction
+    (3, [7, 33], "mart", 0.45, 0xE0000000),  # eight distinct keys: the k-th smallest is shared by hundreds of
+    (4, [15, 30, 45], "lambda", 0.6, 0x3),   # documents of EVERY rank, taken in ascending global order
 ])
-def test_doc_sharded_subsample_equals_single(world, cuts, algo, subsample, batched):
+def test_doc_sharded_subsample_equals_single(world, cuts, algo, subsample, key_mask, batched):
     """--subsample over document shards: the key of a document is a function of its GLOBAL
     index, so every rank finds the sample a single GPU draws from the whole set and keeps
     its own part; trees (structure bit for bit) and the scores of ALL documents (mart.cc:345)
@@ -253,6 +255,9 @@ def test_doc_sharded_subsample_equals_single(world, cuts, algo, subsample, batch
     for c, (q0, q1) in zip(ctxs, parts):
         c.reset_scores()
         c.set_subsample(subsample, seed=11, first_doc=int(qoff[q0]))
+    if key_mask is not None:
+        for c in ctxs + [single]:
+            c.debug_sample_key_mask(key_mask)
     newton = algo == "lambda"
     for it in range(4):
         single.compute_lambdas("NDCG", 10) if newton else single.compute_residuals()

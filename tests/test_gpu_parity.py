@@ -729,6 +729,45 @@ def test_subsample_iteration(qr, ora, algo, subsample):
     c.close()
 
 
+def _sample_keys(seed, draw, N, mask):
+    """k_sample.hip's key of every document for the draw-th sample of a context seeded with `seed`
+    (splitmix64 of the document's index; the stream advances by the golden ratio per draw)."""
+    m = (1 << 64) - 1
+    s = ((seed * 0xD1342543DE82EF95 + 0x632BE59BD9B4E019) + draw * 0x9E3779B97F4A7C15) & m
+    with np.errstate(over="ignore"):
+        z = np.uint64(s) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, N + 1, dtype=np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return (z >> np.uint64(32)).astype(np.uint32) & np.uint32(mask)
+
+
+@pytest.mark.parametrize("mask", [0xFFFFFFFF, 0xF0000000, 0x00000003, 0x001FFC00, 0],
+                         ids=["full_keys", "16_keys", "4_keys_low_digit", "middle_digit_only", "one_key"])
+@pytest.mark.parametrize("subsample", [0.37, 2049.0])
+def test_subsample_is_the_k_smallest_keys(qr, mask, subsample):
+    """The sample of a draw is EXACTLY the k documents with the smallest keys, equal keys by ascending
+    document -- what a stable sort of (key, document) pairs keeps (rounds 2-5 sorted them; the radix
+    select of round 6 must pick the same set).  Narrow keys make the k-th smallest one the key of
+    hundreds of documents: the tie rule decides most of the sample."""
+    x, labels, qoff = make_dataset(nq=170, docs_per_query=40, F=8, seed=43, ragged=True)
+    N = len(labels)
+    assert N > 4200 and N % 8                   # (several workgroups of the scatter pass and a ragged tail)
+    c, thr, ts = _ctx(qr, x, labels, qoff, 16)
+    c.set_subsample(subsample, seed=21)
+    c.debug_sample_key_mask(mask)
+    k = int(subsample) if subsample > 1 else int(np.floor(np.float32(subsample) * np.float32(N)))
+    for draw in (1, 2, 3):
+        c.compute_residuals()
+        nodes = c.fit_tree(6, 1, False)
+        S = np.sort(np.concatenate([c.node_samples(int(i)).astype(np.int64)
+                                    for i in np.nonzero(nodes["feature"] < 0)[0]]))
+        want = np.sort(np.argsort(_sample_keys(21, draw, N, mask), kind="stable")[:k])
+        assert len(S) == k and np.array_equal(S, want), (draw, hex(mask))
+        c.update_scores(0.1)
+    c.close()
+
+
 @pytest.mark.parametrize("algo", ["OBVLAMBDAMART", "OBVMART"])
 def test_subsample_oblivious_iteration(qr, ora, algo):
     """--subsample with oblivious trees (ObliviousMart inherits Mart::learn's sampling,

@@ -304,7 +304,10 @@ int qr_k_binning(qr_ctx *c) {
     // buffers are allocated while the old ones still hold theirs, then the old ones go.
     uint8_t *nb = nullptr, *nf = nullptr;
     QR_CHECK(c, hipMalloc((void **)&nb, c->bins_bytes ? c->bins_bytes : 1));
-    QR_CHECK(c, hipMalloc((void **)&nf, (size_t)c->flocal * c->N ? (size_t)c->flocal * c->N : 1));
+    if (const hipError_t e = hipMalloc((void **)&nf, (size_t)c->flocal * c->N ? (size_t)c->flocal * c->N : 1)) {
+      (void)hipFree(nb);
+      QR_CHECK(c, e);
+    }
     (void)hipFree(c->d_bins);
     (void)hipFree(c->d_bins_fm);
     c->d_bins = nb;

@@ -340,7 +340,24 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       QRM(c, qr_exchange_buffers(c, &recs_local, &recs_all, &rec_bytes, &mask, &mask_bytes));
     else
       QRM(c, qr_doc_exchange_buffers(c, &x_hist, &n_hist, &x_scal, &n_scal, nullptr, nullptr));
-    auto sum64 = [&](void *p, size_t n) { NCCL(ncclAllReduce(p, p, n, ncclInt64, ncclSum, comm, stream)); };
+    // what this rank hands to RCCL while it grows trees: calls and payload bytes (an all-gather counted by what
+    // every rank receives), reported per tree behind the training table
+    size_t n_coll = 0, coll_bytes = 0;
+    auto sum64 = [&](void *p, size_t n) {
+      ++n_coll;
+      coll_bytes += n * 8;
+      NCCL(ncclAllReduce(p, p, n, ncclInt64, ncclSum, comm, stream));
+    };
+    auto gather_recs = [&]() {
+      ++n_coll;
+      coll_bytes += rec_bytes * (size_t)nranks;
+      NCCL(ncclAllGather(recs_local, recs_all, rec_bytes, ncclInt8, comm, stream));
+    };
+    auto sum_mask = [&]() {
+      ++n_coll;
+      coll_bytes += mask_bytes;
+      NCCL(ncclAllReduce(mask, mask, mask_bytes / 4, ncclInt32, ncclSum, comm, stream));
+    };
     // (QR_DOC_BATCH=0: one split per exchange, the protocol of rounds 1-3)
     const bool doc_batch = !(getenv("QR_DOC_BATCH") && atoi(getenv("QR_DOC_BATCH")) == 0);
     sh.bar.wait();
@@ -451,20 +468,20 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
         QRM(c, qr_obl_begin(c, treedepth_, minleafsupport_));
         for (size_t level = 0; level < treedepth_; ++level) {
           QRM(c, qr_obl_propose(c, level));
-          NCCL(ncclAllGather(recs_local, recs_all, rec_bytes, ncclInt8, comm, stream));
+          gather_recs();
           QRM(c, qr_obl_mark(c, level));
-          NCCL(ncclAllReduce(mask, mask, mask_bytes / 4, ncclInt32, ncclSum, comm, stream));
+          sum_mask();
           QRM(c, qr_obl_apply(c, level));
         }
         QRM(c, qr_tree_end(c, lambda, nodes.data(), &nn));
       } else if (feature_sharded) {
         QRM(c, qr_tree_begin(c, nleaves_, minleafsupport_));
-        NCCL(ncclAllGather(recs_local, recs_all, rec_bytes, ncclInt8, comm, stream));
+        gather_recs();
         for (size_t s = 0; s + 1 < nleaves_; ++s) {
           QRM(c, qr_tree_decide(c));
-          NCCL(ncclAllReduce(mask, mask, mask_bytes / 4, ncclInt32, ncclSum, comm, stream));
+          sum_mask();
           QRM(c, qr_tree_apply(c));
-          NCCL(ncclAllGather(recs_local, recs_all, rec_bytes, ncclInt8, comm, stream));
+          gather_recs();
         }
         QRM(c, qr_tree_decide(c));
         QRM(c, qr_tree_end(c, lambda, nodes.data(), &nn));
@@ -571,6 +588,10 @@ void Mart::learn_multi(std::shared_ptr<data::Dataset> training, std::shared_ptr<
       report(first + built, last, nullptr);
     }
     QRM(c, qr_synchronize(c));
+    if (r == 0 && built)
+      std::cout << "# collectives per tree: " << std::setprecision(1) << (double)n_coll / (double)built << ", "
+                << (double)coll_bytes / (double)built / 1024.0 << " KB handed over per rank" << std::setprecision(4)
+                << std::endl;
     sh.bar.wait();
     qr_ctx_destroy(c);
   };

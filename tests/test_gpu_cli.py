@@ -384,6 +384,14 @@ def test_quicklearn_gpus_flag_runs_the_sharded_protocol(tools, tmp_path, algo, s
                        capture_output=True, text=True, timeout=300)
     assert b.returncode == 0, b.stdout + b.stderr
     assert "RCCL communicator of 1 ranks" in b.stdout
+    # the host's own account of what it handed to RCCL: a records all-gather per candidate round and a mask
+    # all-reduce per split in the feature layout; scalars + root + growth steps of up to two splits + leaf
+    # sums in the document layout
+    per_tree = [l for l in b.stdout.splitlines() if l.startswith("# collectives per tree:")]
+    assert len(per_tree) == 1, b.stdout
+    n_coll = float(per_tree[0].split(":")[1].split(",")[0])
+    kb = float(per_tree[0].split(",")[1].split()[0])
+    assert (n_coll == 15.0 if shard == "features" else 6.0 <= n_coll <= 10.0) and kb > 0, per_tree
     n1, w1 = _load_model(tools, m1)
     n2, w2 = _load_model(tools, m2)
     assert n1.shape == n2.shape and np.array_equal(w1, w2)

@@ -3,7 +3,13 @@ library of an earlier commit loads too): the same seven C-ABI calls, qr_residual
 without a sample.  Round 6 A/B: the hipCUB sort of (key, document) pairs (built from commit 9be0406 into
 quickrank_amd/lib/libqr_hip_sortsample.so) against the radix select.
 
-    python scripts/sample_draw_ab.py LIB [LIB ...]"""
+    python scripts/sample_draw_ab.py LIB [LIB ...]
+
+The sort-based library of the A/B (not kept in the tree):
+    mkdir /tmp/old && git archive 9be0406 quickrank_amd/csrc include | tar -x -C /tmp/old && cd /tmp/old
+    for f in qr_api k_bins k_lambda k_tree k_score k_sample k_wide k_exact; do
+      hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -c -o $f.o quickrank_amd/csrc/$f.hip; done
+    hipcc --offload-arch=gfx950 -shared -fPIC -o .../quickrank_amd/lib/libqr_hip_sortsample.so *.o"""
 import ctypes as C
 import sys
 import time

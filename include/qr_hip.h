@@ -204,7 +204,9 @@ int qr_bins_verify(qr_ctx *ctx, unsigned long long *bad_block_rows, unsigned lon
 /* test aid: zero the bin rows of documents [first_doc, first_doc + ndocs) in the block rows     */
 /* (which = 0) or in the feature-major copy (which = 1) -- what a lost store looks like;         */
 /* which = 2: the next `first_doc` builds of the map lose documents [8, 16) of the block rows    */
-/* behind their kernels (the rebuild path of qr_bins_build)                                      */
+/* behind their kernels (the rebuild path of qr_bins_build); which = 3: the next tree's records */
+/* are read as if the root histogram had lost `first_doc` documents (qr_tree_nodes then fails     */
+/* with QR_ERR_HIP: the records' counts do not add up)                                            */
 int qr_debug_bins_clobber(qr_ctx *ctx, int which, size_t first_doc, size_t ndocs);
 
 /* ---- model state: scores_on_training_ (mart.cc:121), pseudoresponses_,        */
@@ -260,6 +262,10 @@ int qr_tree_fit(qr_ctx *ctx, size_t nleaves, uint64_t minls, int newton,
 /* The step count of an enqueued tree is a guess; a tree the guess   */
 /* cut short is completed here -- and by every other call that reads or builds on */
 /* its results -- before anything is returned: callers never see a partial tree.  */
+/* The records' counts are checked before they are handed out (round 6): the root   */
+/* holds the documents the tree was grown on, every internal node as many as its    */
+/* two children (rtnode.h:97-107: a node's count is its histogram's) -- QR_ERR_HIP  */
+/* otherwise: a histogram launch lost stores (profiles/r06_hunt.md).                */
 int qr_tree_nodes(qr_ctx *ctx, qr_node_t *nodes_out, size_t *nnodes_out);
 /* --subsample (mart.cc:287-329, lambdamart.cc:85-102): every iteration fits its  */
 /* tree on a fresh uniform sample of the training documents: subsample > 1 = that */

@@ -1164,7 +1164,11 @@ int qr_bins_verify(qr_ctx *c, unsigned long long *bad_rows, unsigned long long *
 }
 
 int qr_debug_bins_clobber(qr_ctx *c, int which, size_t first_doc, size_t ndocs) {
-  if (!c || which < 0 || which > 2) return QR_ERR_ARG;
+  if (!c || which < 0 || which > 3) return QR_ERR_ARG;
+  if (which == 3) {  // the next tree's records are read with a root `first_doc` documents short
+    c->debug_root_short = first_doc;
+    return QR_OK;
+  }
   if (which == 2) {  // the next `first_doc` builds of the map lose documents [8, 16) behind their kernels
     c->debug_lose_binning = (int)first_doc;
     return QR_OK;
@@ -1568,6 +1572,8 @@ static int snapshot_nodes(qr_ctx *c) {
   // k_leaf_final / k_leaf_global wrote the records into the pinned block directly, then
   // their sequence number (c->nodes_seq)
   c->nodes_pending = true;
+  // (the documents this tree was grown on, for qr_tree_nodes' check of the records' arithmetic)
+  c->nodes_grown_on = c->sub_k ? (uint64_t)c->sub_k : (uint64_t)(c->dmode ? c->Nglobal : c->N);
   return QR_OK;
 }
 
@@ -1708,6 +1714,37 @@ int qr_tree_nodes(qr_ctx *c, qr_node_t *nodes_out, size_t *nnodes_out) {
     ++c->readback_retries;
     if (spin > 20000000L) QR_FAIL(c, QR_ERR_STATE, "the tree's records do not fit their sequence number (pinned read-back)");
     cpu_relax(spin);
+  }
+  // The records' own arithmetic (round 6): the root holds the documents the tree was grown on, an internal
+  // node as many as its two children -- counts that come from DIFFERENT launches (a node's from its parent's
+  // scan, its children's from its own histogram).  Under the load of profiles/r06_hunt.md an XCD can lose
+  // the stores of a histogram workgroup's partial: the tree then counts fewer documents than it was given,
+  // which the hunt's run 7 (a root 4,096 documents short) and run 104 went on to train with.  Not any more.
+  if (c->debug_root_short && n) {  // (test aid, qr_debug_bins_clobber(which = 3): a root histogram that lost a partial)
+    rec[0].nsamples -= std::min<uint64_t>(rec[0].nsamples, c->debug_root_short);
+    c->debug_root_short = 0;
+  }
+  {
+    const uint64_t grown_on = c->nodes_grown_on;
+    char what[200] = "";
+    if (n && rec[0].nsamples != grown_on)
+      snprintf(what, sizeof(what), "the root counts %llu documents of %llu", (unsigned long long)rec[0].nsamples,
+               (unsigned long long)grown_on);
+    for (size_t i = 0; i < n && !what[0]; ++i) {
+      if (rec[i].feature < 0) continue;
+      const int64_t l = rec[i].left, r = rec[i].right;
+      if (l < 0 || r < 0 || (size_t)l >= n || (size_t)r >= n)
+        snprintf(what, sizeof(what), "node %zu points outside the tree", i);
+      else if (rec[l].nsamples + rec[r].nsamples != rec[i].nsamples)
+        snprintf(what, sizeof(what), "node %zu counts %llu documents, its children %llu + %llu", i,
+                 (unsigned long long)rec[i].nsamples, (unsigned long long)rec[l].nsamples,
+                 (unsigned long long)rec[r].nsamples);
+    }
+    if (what[0]) {
+      c->err = std::string("the tree's records do not add up (") + what +
+               "): device memory lost stores (profiles/r06_hunt.md)";
+      return QR_ERR_HIP;
+    }
   }
   if (nodes_out) {
     for (size_t i = 0; i < n; ++i) rec[i].tag = 0;  // (qr_node_t's padding leaves as zeros)

@@ -509,6 +509,8 @@ struct qr_ctx {
   unsigned long long readback_retries = 0;  // records that did not fit their sequence number at first sight
   int64_t early_seq = 0;  // of the last final control call (QrPinned::early)
   bool scal_pending = false, nodes_pending = false;
+  uint64_t debug_root_short = 0;  // (test aid)
+  uint64_t nodes_grown_on = 0;   // the root's document count the pending tree's records must show (qr_tree_nodes)
   size_t cur_maxnodes = 0;
   // tree
   uint32_t *d_order[2] = {nullptr, nullptr};

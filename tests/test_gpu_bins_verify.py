@@ -72,3 +72,27 @@ def test_a_map_that_never_holds_is_an_error(qr, capfd):
         c.build_bins(32)
     capfd.readouterr()
     c.close()
+
+
+@pytest.mark.parametrize("algo", ["leafwise", "oblivious"])
+def test_a_tree_whose_counts_do_not_add_up_is_refused(qr, algo):
+    """The other half of the defence (round 6): the hunt's run 7 trained on a root histogram 4,096
+    documents short -- bin map good, the partial slot of one workgroup never stored.  qr_tree_nodes
+    checks the records' arithmetic (the root holds the documents the tree was grown on, an internal node
+    as many as its children; the counts come from different launches) before it hands them out."""
+    c, x, labels, qoff = _ctx(qr)
+    fit = (lambda: c.fit_oblivious(3, 2, False)) if algo == "oblivious" else (lambda: c.fit_tree(8, 2, False))
+    c.compute_residuals()
+    nodes = fit()                                   # an honest tree passes, and says so itself
+    assert nodes[0]["nsamples"] == len(labels)
+    inner = np.nonzero(nodes["feature"] >= 0)[0]
+    assert all(nodes[int(nodes[i]["left"])]["nsamples"] + nodes[int(nodes[i]["right"])]["nsamples"] == nodes[i]["nsamples"]
+               for i in inner)
+    c.debug_clobber_bins(3, 4096 if len(labels) > 4096 else 7, 0)
+    c.compute_residuals()
+    with pytest.raises(qr.QrError, match="do not add up .the root counts"):
+        fit()
+    c.compute_residuals()
+    again = fit()                                   # (the aid is one-shot: the context is fine)
+    assert again[0]["nsamples"] == len(labels)
+    c.close()
